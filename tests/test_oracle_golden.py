@@ -1,0 +1,78 @@
+"""Pin the CPU oracle (oracle/ani_oracle.c) against fixtures produced by the reference itself.
+
+The fixtures in tests/golden were written by tests/golden/gen_golden.py, which imports the reference
+(fp64, pyaev) -- so agreement here to ~1e-12 means the C restatement IS the reference's arithmetic.
+"""
+import numpy as np
+import pytest
+
+from _util import GOLDEN_NAMES, load_golden, oracle_networks, oracle_params
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+@pytest.mark.parametrize("cell_list", [False, True])
+def test_oracle_matches_reference(oracle64, name, cell_list):
+    g = load_golden(name)
+    if cell_list and g["species"].shape[0] != 1:
+        pytest.skip("cell list handles one system at a time (neighbors.py:373-381)")
+    dims, flat, sae = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"])
+    out = oracle64.energy_forces(p, g["species"], g["coords"].astype(np.float64), dims, flat,
+                                 g["n_members"], sae=sae, cell=g["cell"], pbc=g["pbc"],
+                                 cell_list=cell_list, want_aev=True)
+    C, A = g["species"].shape
+    aev = out["aev"].reshape(C * A, -1)[g["aev_rows"]]
+    assert np.abs(aev - g["aev"]).max() < 2e-13
+    assert np.abs(out["atomic_energies"] - g["atomic_energies"]).max() < 1e-12
+    assert np.abs(out["energies"] - g["energies"]).max() < 1e-9 * max(1.0, np.abs(g["energies"]).max())
+    # Forces go through torch's fp64 CELU backward, which evaluates exp(x * (1 / float32(alpha))) instead
+    # of exp(x / alpha) (a torch artefact, relative error up to 1.5e-8 * |x| / alpha); the oracle uses the
+    # exact derivative, so whole-path forces agree to ~1e-9 while the AEV backward alone (below) agrees
+    # to 1e-13.
+    assert np.abs(out["forces"] - g["forces"]).max() < 2e-9
+    w = np.random.RandomState(g["seed"] + 1000).uniform(-1.0, 1.0, out["aev"].shape)
+    _, vjp = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), g["cell"], g["pbc"],
+                          cell_list=cell_list, grad_aev=w)
+    assert np.abs(vjp - g["aev_vjp"]).max() < 1e-12 * max(1.0, np.abs(g["aev_vjp"]).max())
+    # padding atoms: exactly zero everywhere (neighbors.py:72-82, nn/_containers.py:412-416)
+    pad = g["species"] < 0
+    assert np.all(out["forces"][pad] == 0) and np.all(out["atomic_energies"][pad] == 0)
+
+
+def test_member_energies(oracle64):
+    g = load_golden("simple2_ani2x")
+    dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"])
+    aev = oracle64.aev(p, g["species"], g["coords"].astype(np.float64))
+    ae, _, me = oracle64.mlp(g["species"], aev, dims, flat, n_members=8, want_members=True)
+    assert np.abs(me.reshape(8, *g["species"].shape) - g["member_atomic_energies"]).max() < 1e-12
+    # Ensemble == mean of members (tests/test_ensemble.py:20-36)
+    assert np.abs(me.mean(0) - ae).max() < 1e-14
+
+
+@pytest.mark.parametrize("name", ["water_pbc_ani2x", "triclinic_pbc_ani2x", "1hz5_ani2x", "dense90_ani2x"])
+def test_cell_list_equals_brute_force(oracle64, name):
+    g = load_golden(name)
+    x = g["coords"].astype(np.float64)
+    a = oracle64.neighbors(g["species"], x, 5.1, g["cell"], g["pbc"], cell_list=False)
+    b = oracle64.neighbors(g["species"], x, 5.1, g["cell"], g["pbc"], cell_list=True)
+    assert np.array_equal(a[0], b[0])  # same count per central atom
+    for i in range(len(a[0]) - 1):
+        sa, sb = slice(a[0][i], a[0][i + 1]), slice(b[0][i], b[0][i + 1])
+        ka = np.lexsort((a[2][sa, 2], a[2][sa, 1], a[2][sa, 0], a[1][sa]))
+        kb = np.lexsort((b[2][sb, 2], b[2][sb, 1], b[2][sb, 0], b[1][sb]))
+        assert np.array_equal(a[1][sa][ka], b[1][sb][kb])
+        assert np.allclose(a[2][sa][ka], b[2][sb][kb], atol=1e-12)
+
+
+def test_f32_port_close_to_f64(oracle64):
+    """The float build (bench.py's cpu_baseline 'port') is the same code; sanity-check it."""
+    from oracle.oracle import Oracle
+
+    o32 = Oracle("f32")
+    g = load_golden("small_ani2x")
+    dims, flat, sae = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"])
+    out = o32.energy_forces(p, g["species"], g["coords"], dims, flat, 8, sae=sae)
+    assert np.abs(out["atomic_energies"] - g["atomic_energies"]).max() < 2e-5
+    assert np.abs(out["forces"] - g["forces"]).max() < 2e-5

@@ -1,0 +1,95 @@
+"""Model constants of the ANI hot path (values restated from the reference, cited per item).
+
+Reference paths are relative to /root/reference/torchani/.
+"""
+from __future__ import annotations
+
+import math
+import typing as tp
+
+# utils.py:63-66
+SYMBOLS_1X: tp.Tuple[str, ...] = ("H", "C", "N", "O")
+SYMBOLS_2X: tp.Tuple[str, ...] = ("H", "C", "N", "O", "S", "F", "Cl")
+ATOMIC_NUMBER: tp.Dict[str, int] = {"H": 1, "C": 6, "N": 7, "O": 8, "F": 9, "S": 16, "Cl": 17}
+PADDING_SPECIES = -1  # utils.py:67-74
+
+# constants.py:88-96, ground-state atomic self energies wB97X/6-31G(d), Hartree
+GSAES_WB97X_631GD: tp.Dict[str, float] = {
+    "C": -37.8338334,
+    "Cl": -460.116700600,
+    "F": -99.6949007,
+    "H": -0.4993212,
+    "N": -54.5732825,
+    "O": -75.0424519,
+    "S": -398.0814169,
+}
+
+
+def linspace(start: float, stop: float, steps: int) -> tp.Tuple[float, ...]:
+    """End-point-excluding linspace used for all ANI shifts (utils.py:101-107)."""
+    return tuple(start + ((stop - start) / steps) * j for j in range(steps))
+
+
+class AEVConstants(tp.NamedTuple):
+    """Hyper-parameters of the radial/angular symmetry functions."""
+
+    num_species: int
+    Rcr: float
+    Rca: float
+    EtaR: float
+    ShfR: tp.Tuple[float, ...]
+    EtaA: float
+    Zeta: float
+    ShfA: tp.Tuple[float, ...]
+    ShfZ: tp.Tuple[float, ...]
+
+    @property
+    def radial_len(self) -> int:
+        return self.num_species * len(self.ShfR)
+
+    @property
+    def num_species_pairs(self) -> int:
+        return self.num_species * (self.num_species + 1) // 2
+
+    @property
+    def angular_len(self) -> int:
+        return self.num_species_pairs * len(self.ShfA) * len(self.ShfZ)
+
+    @property
+    def out_dim(self) -> int:
+        return self.radial_len + self.angular_len
+
+
+def aev_constants_2x(num_species: int = 7) -> AEVConstants:
+    # aev/_computer.py:550-600; aev/_terms.py:188-207 (radial), :345-366 (angular)
+    return AEVConstants(
+        num_species, 5.1, 3.5, 19.7, linspace(0.8, 5.1, 16), 12.5, 14.1, linspace(0.8, 3.5, 8),
+        linspace(math.pi / 8, math.pi + math.pi / 8, 4),
+    )
+
+
+def aev_constants_1x(num_species: int = 4) -> AEVConstants:
+    # aev/_computer.py:498-548
+    return AEVConstants(
+        num_species, 5.2, 3.5, 16.0, linspace(0.9, 5.2, 16), 8.0, 32.0, linspace(0.9, 3.5, 4),
+        linspace(math.pi / 16, math.pi + math.pi / 16, 8),
+    )
+
+
+# nn/_containers.py:506-533 (ANI-2x) and :546-570 (ANI-1x): hidden widths per element
+HIDDEN_DIMS_2X: tp.Dict[str, tp.Tuple[int, ...]] = {
+    "H": (256, 192, 160),
+    "C": (224, 192, 160),
+    "N": (192, 160, 128),
+    "O": (192, 160, 128),
+    "S": (160, 128, 96),
+    "F": (160, 128, 96),
+    "Cl": (160, 128, 96),
+}
+HIDDEN_DIMS_1X: tp.Dict[str, tp.Tuple[int, ...]] = {
+    "H": (160, 128, 96),
+    "C": (144, 112, 96),
+    "N": (128, 112, 96),
+    "O": (128, 112, 96),
+}
+CELU_ALPHA = 0.1  # nn/_core.py:163-167

@@ -1,0 +1,49 @@
+"""Deterministic random ANI network parameters under the reference's state-dict key names.
+
+The published ANI-2x parameters cannot be fetched offline (the reference downloads them,
+arch.py:1185-1220), so tests and bench.py use the ANI architecture with seeded random weights.  The
+generator is numpy's frozen legacy ``RandomState`` so the very same numbers are reproduced on any box
+(the golden fixtures in tests/golden were computed by the reference with exactly these weights).
+Keys follow SURVEY section 5: ``potentials.nnp.neural_networks.members.{m}.atomics.{Sym}.layers.{l}.weight``
+etc.; a real ``ani2x_state_dict.pt`` uses the same names and loads through the same code path.
+"""
+from __future__ import annotations
+
+import typing as tp
+
+import numpy as np
+
+from .constants import (GSAES_WB97X_631GD, HIDDEN_DIMS_1X, HIDDEN_DIMS_2X, SYMBOLS_1X, SYMBOLS_2X,
+                        aev_constants_1x, aev_constants_2x)
+
+NN_PREFIX = "potentials.nnp.neural_networks."
+
+
+def arch_spec(kind: str):
+    """(symbols, AEVConstants, hidden dims) of a builtin architecture (models.py:112-119,185-193)."""
+    if kind == "ani2x":
+        return SYMBOLS_2X, aev_constants_2x(), HIDDEN_DIMS_2X
+    if kind == "ani1x":
+        return SYMBOLS_1X, aev_constants_1x(), HIDDEN_DIMS_1X
+    raise ValueError(f"Unknown architecture {kind!r}")
+
+
+def random_state_dict(kind: str = "ani2x", n_members: int = 8, seed: int = 0,
+                      scale: float = 1.0) -> tp.Dict[str, np.ndarray]:
+    """fp32 parameters, uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) like torch.nn.Linear's default."""
+    symbols, consts, hidden = arch_spec(kind)
+    rs = np.random.RandomState(seed)
+    out: tp.Dict[str, np.ndarray] = {}
+    for m in range(n_members):
+        for sym in symbols:
+            dims = (consts.out_dim,) + tuple(hidden[sym]) + (1,)
+            nl = len(dims) - 1
+            for l in range(nl):
+                name = f"layers.{l}" if l < nl - 1 else "final_layer"
+                bound = scale / np.sqrt(dims[l])
+                base = f"{NN_PREFIX}members.{m}.atomics.{sym}.{name}."
+                out[base + "weight"] = rs.uniform(-bound, bound, (dims[l + 1], dims[l])).astype(np.float32)
+                out[base + "bias"] = rs.uniform(-bound, bound, (dims[l + 1],)).astype(np.float32)
+    out["energy_shifter.self_energies"] = np.asarray(
+        [GSAES_WB97X_631GD[s] for s in symbols], dtype=np.float32)
+    return out
