@@ -1,0 +1,167 @@
+/*
+ * anihip.h -- C ABI of libanihip.so, the MI355X (gfx950) ANI hot-path engine.
+ *
+ * One shared object replaces, for the ANI energy+forces path, the three native plug-ins of the
+ * reference (paths relative to /root/reference/torchani/):
+ *   cuaev.so      csrc/cuaev.cpp:246-294   (cuaev::run, run_with_half_nbrlist, run_with_full_nbrlist,
+ *                                           CuaevComputer::{forward,backward}, csrc/aev.cu:1687-2067)
+ *   cell_list.so  csrc/cell_list.cpp:342-363 (cell_list::cell_list)
+ *   mnp.so        csrc/mnp.cpp:238-280     (mnp::run, MultiNetFunction fwd / input-grad bwd)
+ *
+ * Conventions:
+ *   - plain C: raw device pointers, explicit sizes, no torch types, no exceptions across the ABI;
+ *   - every function returns 0 on success, non-zero on error; anihip_last_error() gives the text
+ *     (thread-local), replacing the reference's TORCH_CHECK -> RuntimeError (csrc/aev.cu:1693-1710);
+ *   - the CALLER owns all device memory (inputs, outputs, workspaces); the library never allocates,
+ *     frees or retains device pointers across calls;
+ *   - every call is asynchronous on the given hipStream_t (passed as void*), never synchronises the
+ *     host (the reference syncs >= 3 times per forward, csrc/aev.cu:1292,1763-1767);
+ *   - capacity overflows are reported through the device-side `status` words (never assert/trap like
+ *     csrc/aev.cu:229); the host wrapper reads them when convenient;
+ *   - fp32 compute, int32 indices, fp64 energy accumulation.
+ *
+ * Atoms are the flattened [C*A] array of the reference's (species[C,A], coords[C,A,3]) pair
+ * (aev/_computer.py:193-199); species are element indices 0..S-1, padding = -1 (utils.py:67-74).
+ */
+#ifndef ANIHIP_H
+#define ANIHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANIHIP_ABI_VERSION 1
+
+/* status word bits written by the kernels into status[0] */
+#define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
+#define ANIHIP_ST_ROW_OVERFLOW 2u     /* one atom has > ANIHIP_MAX_ANG / ANIHIP_MAX_RAD neighbors or > 255 of one species */
+#define ANIHIP_ST_GRID_OVERFLOW 4u    /* internal: grid coarsened to fit max_cells (not an error) */
+#define ANIHIP_STATUS_WORDS 8         /* status[1] = total neighbor entries, status[2] = #cells */
+
+#define ANIHIP_MAX_SPECIES 8
+#define ANIHIP_MAX_ANG 128 /* angular neighbors per atom (cuAEV's analogous bound: csrc/aev.cu:11) */
+#define ANIHIP_MAX_RAD 256 /* radial neighbors per atom */
+#define ANIHIP_META_WORDS 6 /* uint32 words of per-atom neighbor metadata */
+
+/* Scalar AEV hyper-parameters; replaces the CuaevComputer constructor arguments
+ * (csrc/cuaev.cpp:248: Rcr, Rca, EtaR, ShfR, EtaA, Zeta, ShfA, ShfZ, num_species, use_cos_cutoff). */
+typedef struct {
+    int32_t num_species; /* S <= 8 */
+    int32_t n_shf_r;     /* must be 16 */
+    int32_t n_shf_a;     /* n_shf_a * n_shf_z must be 32, both multiples of 4 */
+    int32_t n_shf_z;
+    float Rcr, Rca;
+    float EtaR, EtaA, Zeta;
+} anihip_aev_params;
+
+/* Length in floats of the device constant table consumed by the AEV kernels, and a host-side packer:
+ * table = ShfR[32] | ShfA[16] | cos(ShfZ)[16] | sin(ShfZ)[16]  (trig evaluated in double on the
+ * fp32-rounded ShfZ).  The caller uploads it to the device. */
+#define ANIHIP_AEV_TABLE_FLOATS 80
+int anihip_aev_table_pack(const anihip_aev_params *p, const float *ShfR, const float *ShfA,
+                          const float *ShfZ, float *table_out /* host, 80 floats */);
+
+const char *anihip_last_error(void);
+int anihip_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Neighbor lists.  Output format (shared by all builders and consumed by the AEV kernels):
+ *   meta[i*6 + 0]   = first entry of atom i's row
+ *   meta[i*6 + 1]   = nA | (nF << 16): #neighbors with r <= Rca, # with Rca < r <= Rcr
+ *   meta[i*6 + 2,3] = 8 x uint8: per-species counts of the nA angular-range neighbors
+ *   meta[i*6 + 4,5] = 8 x uint8: per-species counts of the nF far neighbors
+ *   ent[row..]      = float4 {dx, dy, dz, bits(j | species_j << 28)}, d = r_j (+ image shift) - r_i,
+ *                     angular-range neighbors first, each group ordered by species then by discovery.
+ * It is a FULL list (both directions), like cuAEV's internal lists (csrc/aev.cu:975-1039).
+ * Only central atoms lo <= i < hi get rows (the data-parallel shard of this rank); all atoms are
+ * neighbor candidates.
+ */
+
+/* Workspace bytes for anihip_nbr_build_batch / anihip_nbr_build_cell (two-call pattern like
+ * csrc/cuaev_cub.cuh:10-17). */
+size_t anihip_nbr_workspace_bytes(int64_t n_atoms, int64_t max_cells);
+
+/* Batched molecules, all pairs inside each molecule: replaces pairwiseDistance + postProcessNbrList1
+ * (csrc/aev.cu:180-249,975-1039) and neighbors.py:187-275 (all_pairs incl. PBC images).
+ * cell: device float[9] (rows = lattice vectors) or NULL; pbc_mask bit k = periodic along vector k. */
+int anihip_nbr_build_batch(void *stream, const anihip_aev_params *p, int32_t n_mol, int32_t n_atoms_per_mol,
+                           const int32_t *species, const float *coords, const float *cell,
+                           int32_t pbc_mask, int64_t lo, int64_t hi, void *workspace,
+                           size_t workspace_bytes, uint32_t *meta, float *ent, int64_t ent_capacity,
+                           uint32_t *status);
+
+/* One large system through a cell grid (O(N)): replaces cell_list::cell_list
+ * (csrc/cell_list.cpp:342-354, neighbors.py:366-507) + postProcessExternalHalfNbrList
+ * (csrc/aev.cu:1128-1208).  Without pbc the grid spans the bounding box (neighbors.py:389-394). */
+int anihip_nbr_build_cell(void *stream, const anihip_aev_params *p, int64_t n_atoms,
+                          const int32_t *species, const float *coords, const float *cell,
+                          int32_t pbc_mask, int64_t lo, int64_t hi, int64_t max_cells, void *workspace,
+                          size_t workspace_bytes, uint32_t *meta, float *ent, int64_t ent_capacity,
+                          uint32_t *status);
+
+/* ---------------------------------------------------------------------------------------------
+ * AEV forward / backward: replace cuRadialAEVs + cuAngularAEVs (csrc/aev.cu:768-834,323-472) and their
+ * backward kernels (csrc/aev.cu:837-967,474-766).  aev / grad_aev are [n_atoms, L] row-major with
+ * L = S*16 + S(S+1)/2*32, layout [radial | angular] (aev/_computer.py:298).  Rows of atoms outside
+ * [lo,hi) are not touched; padding atoms inside the range get zero rows.
+ * grad_coords [n_atoms,3] is ACCUMULATED into with float atomics (caller zeroes it), i.e.
+ * grad_coords += d(sum grad_aev * aev)/d coords  (csrc/aev.cu:1958-1984). */
+int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
+                       int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
+                       const float *ent, float *aev, uint32_t *status);
+int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
+                        int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
+                        const float *ent, const float *grad_aev, float *grad_coords, uint32_t *status);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-species MLP ensemble: replaces mnp::run (csrc/mnp.cpp:238-265; forward :32-136, input-gradient
+ * backward :138-232) and BmmEnsemble (nn/_infer.py:61-216).
+ *
+ * Packed parameter layout (host code packs once per model, cf. BmmAtomicNetwork nn/_infer.py:141-161).
+ * M = ensemble members, widths padded up to multiples of 32 with zeros (Hp):
+ *   layer 0 : w [K0][M*H1p]  (column m*H1p+o = member m, unit o)   wt [M*H1p][K0p]  bias [M*H1p]
+ *   layer l : w [M][Hlp][H(l+1)p]   wt [M][H(l+1)p][Hlp]   bias [M][H(l+1)p]      (hidden layers)
+ *   final   : w [M][Hlastp]  bias [M]
+ * K0 = AEV length (multiple of 16), K0p = K0 rounded up to a multiple of 32.
+ */
+#define ANIHIP_MAX_LAYERS 4 /* Linear layers per network incl. the final one */
+typedef struct {
+    int32_t n_layers;                      /* Linear layers incl. final (ANI: 4) */
+    int32_t dims[ANIHIP_MAX_LAYERS + 1];   /* padded widths: K0, H1p, H2p, H3p, 1 */
+    const float *w[ANIHIP_MAX_LAYERS];     /* device pointers, layouts above */
+    const float *wt[ANIHIP_MAX_LAYERS];    /* transposed copies (unused for the final layer) */
+    const float *bias[ANIHIP_MAX_LAYERS];
+} anihip_species_net;
+
+typedef struct {
+    int32_t num_species;
+    int32_t n_members;
+    int32_t aev_len;
+    float celu_alpha;
+    anihip_species_net net[ANIHIP_MAX_SPECIES];
+} anihip_mlp_desc;
+
+/* Workspace for n central atoms (activations of every hidden layer for all members, species-sorted
+ * index lists). */
+size_t anihip_mlp_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central);
+
+/* atomic_e[i] = mean over members of net_{m,species(i)}(aev[i]) for lo <= i < hi (0 for padding);
+ * if grad_aev != NULL also grad_aev[i] = d atomic_e[i] / d aev[i] (rows of padding atoms zeroed).
+ * member_e (optional) = [M, n_atoms] per-member energies (ensemble_values, nn/_containers.py:638-651). */
+int anihip_mlp_forward_backward(void *stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo,
+                                int64_t hi, const int32_t *species, const float *aev, void *workspace,
+                                size_t workspace_bytes, float *atomic_e, float *grad_aev,
+                                float *member_e);
+
+/* mol_e[c] (fp64) = sum_a atomic_e[c,a] + sae[species[c,a]] over the atoms lo <= c*A+a < hi; padding
+ * contributes nothing (sae.py:54-64).  sae may be NULL.  mol_e is overwritten. */
+int anihip_energy_reduce(void *stream, int32_t n_mol, int32_t n_atoms_per_mol, int64_t lo, int64_t hi,
+                         const int32_t *species, const float *atomic_e, const double *sae, double *mol_e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANIHIP_H */

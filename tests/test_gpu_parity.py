@@ -1,0 +1,325 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the golden fixtures written by the
+reference and against the pinned CPU oracle, on identical inputs.
+
+Tolerances (north_star): per-atom / NN-only energies <= 1e-5 Ha, forces <= 1e-4 Ha/A; AEV elements are
+held to 2e-5 absolute (the reference's own cuAEV-vs-pyaev gate is 5e-5, tests/test_cuaev.py:169).
+Modelled on tests/test_cuaev.py:152-798 of the reference (differential tests of the native path).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import GOLDEN_NAMES, load_golden, oracle_networks, oracle_params, seeded_state
+
+pytestmark = pytest.mark.gpu
+
+AEV_TOL = 2e-5
+E_ATOM_TOL = 1e-5
+F_TOL = 1e-4
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                      "parity_report.txt")
+
+
+def report(line):
+    print(line)
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        with open(REPORT, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from torchani_amd import _lib
+
+    _lib.lib()  # fail loudly if the native library is missing
+    return torch.device("cuda:0")
+
+
+_models = {}
+
+
+def get_model(kind, seed, dev, **kw):
+    from torchani_amd.models import ANI1x, ANI2x
+
+    key = (kind, seed, tuple(sorted(kw.items())))
+    if key not in _models:
+        ctor = ANI2x if kind == "ani2x" else ANI1x
+        _models[key] = ctor(state_dict=seeded_state(kind, 8, seed), device=dev, periodic_table_index=False, **kw)
+    return _models[key]
+
+
+def modes_for(g):
+    return ["batch", "cell"] if g["species"].shape[0] == 1 else ["batch"]
+
+
+def to_dev(g, dev):
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev)
+    cell = None if g["cell"] is None else torch.from_numpy(g["cell"]).to(dev)
+    pbc = None if g["pbc"] is None else tuple(bool(b) for b in g["pbc"])
+    return sp, x, cell, pbc
+
+
+def unpack_rows(nbrs, n):
+    meta = nbrs.meta.cpu().numpy().view(np.uint32).reshape(n, 6)
+    ent = nbrs.ent.cpu().numpy().reshape(-1, 4)
+    return meta, ent
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_neighbor_rows_match_oracle(dev, oracle64, name):
+    """Same neighbor set per atom as the reference's pair list (seen from both ends), correct
+    angular/far split, species ordering and per-species counts."""
+    from torchani_amd.engine import AevEngine
+    from torchani_amd.weights import arch_spec
+
+    g = load_golden(name)
+    _, consts, _ = arch_spec(g["kind"])
+    eng = AevEngine(consts)
+    sp, x, cell, pbc = to_dev(g, dev)
+    C, A = g["species"].shape
+    start, j, d, r = oracle64.neighbors(g["species"], g["coords"].astype(np.float64), consts.Rcr, g["cell"],
+                                        g["pbc"])
+    for mode in modes_for(g):
+        nbrs = eng.neighbors(sp.to(torch.int32).contiguous(), x.contiguous(), cell, pbc, mode=mode, row_cap=256)
+        torch.cuda.synchronize()
+        nbrs.raise_on_overflow()
+        meta, ent = unpack_rows(nbrs, C * A)
+        worst = 0.0
+        for i in range(C * A):
+            nA, nF = int(meta[i, 1] & 0xFFFF), int(meta[i, 1] >> 16)
+            lo, hi = start[i], start[i + 1]
+            assert nA + nF == hi - lo, f"{name}/{mode}: atom {i} has {nA + nF} neighbors, oracle {hi - lo}"
+            if hi == lo:
+                continue
+            row = ent[meta[i, 0]: meta[i, 0] + nA + nF]
+            w = row[:, 3].copy().view(np.uint32)
+            jj, spj = (w & 0x0FFFFFFF).astype(np.int64), (w >> 28).astype(np.int64)
+            assert np.array_equal(spj, g["species"].reshape(-1)[jj])
+            rr = np.linalg.norm(row[:, :3].astype(np.float64), axis=1)
+            # angular-range group first, each group sorted by species
+            assert np.all(rr[:nA] <= consts.Rca + 1e-5) and np.all(rr[nA:] >= consts.Rca - 1e-5)
+            assert np.all(np.diff(spj[:nA]) >= 0) and np.all(np.diff(spj[nA:]) >= 0)
+            cntA = np.concatenate([(meta[i, 2] >> (8 * np.arange(4))) & 255, (meta[i, 3] >> (8 * np.arange(4))) & 255])
+            cntF = np.concatenate([(meta[i, 4] >> (8 * np.arange(4))) & 255, (meta[i, 5] >> (8 * np.arange(4))) & 255])
+            assert np.array_equal(cntA, np.bincount(spj[:nA], minlength=8))
+            assert np.array_equal(cntF, np.bincount(spj[nA:], minlength=8))
+            # same (j, displacement) multiset as the oracle
+            ko = np.lexsort((d[lo:hi, 2], d[lo:hi, 1], d[lo:hi, 0], j[lo:hi]))
+            km = np.lexsort((row[:, 2], row[:, 1], row[:, 0], jj))
+            assert np.array_equal(j[lo:hi][ko], jj[km]), f"{name}/{mode}: atom {i} neighbor indices differ"
+            worst = max(worst, np.abs(d[lo:hi][ko] - row[km, :3]).max())
+        report(f"nbr   {name:22s} {mode:5s} max|d - d_ref| = {worst:.2e} A")
+        assert worst < 5e-6
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_aev_forward_and_backward(dev, name):
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.weights import arch_spec
+
+    g = load_golden(name)
+    _, consts, _ = arch_spec(g["kind"])
+    sp, x, cell, pbc = to_dev(g, dev)
+    C, A = g["species"].shape
+    pbc_t = None if pbc is None else torch.tensor(pbc)
+    w = torch.from_numpy(np.random.RandomState(g["seed"] + 1000).uniform(-1.0, 1.0, (C, A, consts.out_dim))
+                         .astype(np.float32)).to(dev)
+    for mode in modes_for(g):
+        aevc = AEVComputer(consts, neighborlist=mode, row_capacity=256).to(dev)
+        xx = x.clone().requires_grad_(True)
+        aev = aevc(sp, xx, cell, pbc_t)
+        (vjp,) = torch.autograd.grad((aev * w).sum(), xx)
+        torch.cuda.synchronize()
+        aevc.last_neighbors().raise_on_overflow()
+        got = aev.detach().cpu().numpy().reshape(C * A, -1)
+        err = np.abs(got[g["aev_rows"]] - g["aev"]).max()
+        pad = g["species"].reshape(-1) < 0
+        assert np.all(got[pad] == 0), "padding atoms must have zero AEV rows"
+        verr = np.abs(vjp.cpu().numpy() - g["aev_vjp"]).max()
+        vmag = np.abs(g["aev_vjp"]).max()
+        report(f"aev   {name:22s} {mode:5s} max|aev err| = {err:.2e}   vjp err = {verr:.2e} (|vjp|max {vmag:.1f})")
+        assert err < AEV_TOL
+        assert verr < 2e-5 * max(1.0, vmag)
+        assert np.all(vjp.cpu().numpy()[g["species"] < 0] == 0)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_mlp_ensemble(dev, oracle64, name):
+    """Networks alone: reference-exact AEVs in, per-atom energies and d/d aev out."""
+    g = load_golden(name)
+    dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"])
+    aev = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), g["cell"], g["pbc"])
+    ae, ga, me = oracle64.mlp(g["species"], aev, dims, flat, n_members=8, want_members=True)
+    model = get_model(g["kind"], g["seed"], dev)
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    a32 = torch.from_numpy(aev.astype(np.float32)).to(dev).requires_grad_(True)
+    e = model.neural_networks(sp, a32, atomic=True)
+    (gr,) = torch.autograd.grad(e.sum(), a32)
+    em = model.neural_networks(sp, a32.detach(), atomic=True, ensemble_values=True)
+    torch.cuda.synchronize()
+    C, A = g["species"].shape
+    e_err = np.abs(e.detach().cpu().numpy() - ae.reshape(C, A)).max()
+    g_err = np.abs(gr.cpu().numpy().reshape(C * A, -1) - ga).max()
+    m_err = np.abs(em.cpu().numpy() - me.reshape(8, C, A)).max()
+    report(f"mlp   {name:22s}       max|e_atom err| = {e_err:.2e}  |d e/d aev err| = {g_err:.2e} "
+           f"(max {np.abs(ga).max():.2e})  members {m_err:.2e}")
+    assert e_err < E_ATOM_TOL and m_err < E_ATOM_TOL
+    assert g_err < 1e-6 + 1e-5 * np.abs(ga).max()
+    pad = g["species"] < 0
+    assert np.all(e.detach().cpu().numpy()[pad] == 0) and np.all(gr.cpu().numpy()[pad] == 0)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_energies_and_forces_fused(dev, name):
+    g = load_golden(name)
+    sp, x, cell, pbc = to_dev(g, dev)
+    for mode in modes_for(g):
+        model = get_model(g["kind"], g["seed"], dev, neighborlist=mode, row_capacity=256)
+        out = model.energies_and_forces(sp, x, cell, pbc, check_overflow=True)
+        torch.cuda.synchronize()
+        ea = np.abs(out.atomic_energies.cpu().numpy() - g["atomic_energies"]).max()
+        et = np.abs(out.energies.cpu().numpy() - g["energies"]).max()
+        fe = np.abs(out.forces.cpu().numpy() - g["forces"]).max()
+        n_real = int((g["species"] >= 0).sum())
+        report(f"e+f   {name:22s} {mode:5s} atoms={n_real:4d} max|e_atom err| = {ea:.2e}  |E_total err| = {et:.2e}"
+               f"  |F err| = {fe:.2e}")
+        assert ea < E_ATOM_TOL
+        assert fe < F_TOL
+        # totals are accumulated in fp64 from fp32 per-atom energies: error grows at most like n * eps
+        assert et < E_ATOM_TOL * max(1.0, np.sqrt(n_real))
+        assert np.all(out.forces.cpu().numpy()[g["species"] < 0] == 0)
+
+
+@pytest.mark.parametrize("name", ["ch4_ani1x", "rand_batch_ani2x", "water_pbc_ani2x"])
+def test_autograd_path_equals_fused(dev, name):
+    """model((species, coords)) + torch.autograd == fused engine path (same kernels underneath)."""
+    from torchani_amd.grad import energies_and_forces
+
+    g = load_golden(name)
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = get_model(g["kind"], g["seed"], dev)
+    pbc_t = None if pbc is None else torch.tensor(pbc)
+    e, f = energies_and_forces(model, sp, x, cell, pbc_t)
+    out = model.energies_and_forces(sp, x, cell, pbc)
+    assert not x.requires_grad
+    assert np.abs(f.cpu().numpy() - g["forces"]).max() < F_TOL
+    assert torch.allclose(f, out.forces, atol=2e-6)
+    assert np.abs(e.double().cpu().numpy() - g["energies"]).max() < 2e-6 * np.abs(g["energies"]).max()
+    # NN-only energies with the shifter disabled (arch.py:136-142)
+    model.set_enabled("energy_shifter", False)
+    e_nn = model((sp, x), cell, pbc_t).energies
+    model.set_enabled("energy_shifter", True)
+    assert np.abs(e_nn.double().cpu().numpy() - g["energies_nn"]).max() < 1e-5 * max(1.0, np.sqrt(sp.shape[1]))
+
+
+def test_api_details(dev):
+    """Legacy tuple call, atomic / ensemble_values outputs, active members (nn/_containers.py:590-660)."""
+    g = load_golden("simple2_ani2x")
+    sp, x, _, _ = to_dev(g, dev)
+    model = get_model("ani2x", g["seed"], dev)
+    with pytest.warns(UserWarning):
+        s2, aev = model.aev_computer((sp, x))
+    assert aev.shape == (2, 7, 1008) and s2 is sp
+    em = model.neural_networks(sp, aev, atomic=True, ensemble_values=True)
+    ea = model.neural_networks(sp, aev, atomic=True)
+    assert em.shape == (8, 2, 7) and torch.allclose(em.mean(0), ea, atol=1e-6)  # tests/test_ensemble.py:20-36
+    assert np.abs(em.cpu().numpy() - g["member_atomic_energies"]).max() < E_ATOM_TOL
+    ens = model.neural_networks
+    ens.set_active_members([1, 5])
+    assert ens.get_active_members_num() == 2
+    e2 = ens(sp, aev, atomic=True)
+    ens.set_active_members(list(range(8)))
+    assert torch.allclose(e2, (em[1] + em[5]) / 2, atol=1e-6)
+    with pytest.raises(ValueError):
+        model.aev_computer(sp.cpu(), x.cpu())
+    # atomic numbers in, element indices out; unsupported element -> ValueError
+    from torchani_amd.models import ANI2x
+
+    m2 = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev)
+    znum = torch.tensor([1, 6, 7, 8, 16, 9, 17], device=dev)
+    z = torch.where(sp >= 0, znum[sp.clamp(min=0)], torch.full_like(sp, -1))
+    out_z = m2.energies_and_forces(z, x)
+    out_i = model.energies_and_forces(sp, x)
+    assert torch.equal(out_z.energies, out_i.energies)
+    with pytest.raises(ValueError):
+        m2.energies_and_forces(torch.full_like(sp, 5), x)
+
+
+def _water_box(n_side, seed, dev, box_per=3.1):
+    """n_side^3 waters on a jittered lattice, periodic cubic box (0.1 atoms / A^3)."""
+    rs = np.random.RandomState(seed)
+    L = n_side * box_per
+    gx = (np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3) + 0.5) * box_per
+    o = gx + rs.uniform(-0.3, 0.3, gx.shape)
+    def rnd_unit(n):
+        v = rs.normal(size=(n, 3))
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+    a = rnd_unit(len(o))
+    b = np.cross(a, rnd_unit(len(o)))
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    th = np.deg2rad(104.52) / 2
+    h1 = o + 0.9572 * (np.cos(th) * a + np.sin(th) * b)
+    h2 = o + 0.9572 * (np.cos(th) * a - np.sin(th) * b)
+    x = np.stack([o, h1, h2], 1).reshape(1, -1, 3).astype(np.float32)
+    sp = np.tile(np.array([3, 0, 0]), len(o)).reshape(1, -1)
+    cell = np.eye(3, dtype=np.float32) * L
+    return sp, x, cell
+
+
+def test_water_box_properties_and_oracle(dev, oracle64):
+    """Mid-size periodic box (3000 atoms): cell-list rows == all-pairs rows, oracle parity, Newton's 3rd
+    law, translation / image invariance (size-independent properties used again at bench sizes)."""
+    sp, x, cell = _water_box(10, 1, dev)
+    model_c = get_model("ani2x", 21, dev, neighborlist="cell")
+    model_b = get_model("ani2x", 21, dev, neighborlist="batch")
+    spt, xt, ct = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(cell).to(dev)
+    pbc = (True, True, True)
+    oc = model_c.energies_and_forces(spt, xt, ct, pbc, check_overflow=True)
+    ob = model_b.energies_and_forces(spt, xt, ct, pbc, check_overflow=True)
+    assert torch.allclose(oc.atomic_energies, ob.atomic_energies, atol=2e-6)
+    assert torch.allclose(oc.forces, ob.forces, atol=5e-6)
+    dims, flat, sae = oracle_networks("ani2x", 8, 21)
+    ref = oracle64.energy_forces(oracle_params("ani2x"), sp, x.astype(np.float64), dims, flat, 8, sae=sae,
+                                 cell=cell, pbc=pbc, cell_list=True)
+    ea = np.abs(oc.atomic_energies.cpu().numpy() - ref["atomic_energies"]).max()
+    fe = np.abs(oc.forces.cpu().numpy() - ref["forces"]).max()
+    et = abs(float(oc.energies[0]) - ref["energies"][0])
+    report(f"box   water 3000 atoms pbc        max|e_atom err| = {ea:.2e}  |E_total err| = {et:.2e}  |F err| = {fe:.2e}")
+    assert ea < E_ATOM_TOL and fe < F_TOL and et < 1e-4
+    assert oc.forces.sum(dim=1).abs().max() < 2e-4  # momentum conservation
+    # translate by a non-lattice vector and by a lattice vector: energies unchanged
+    sh = torch.tensor([1.234, -7.77, 30.05], device=dev)
+    o2 = model_c.energies_and_forces(spt, xt + sh, ct, pbc)
+    o3 = model_c.energies_and_forces(spt, xt + ct[1], ct, pbc)
+    assert abs(float(o2.energies[0] - oc.energies[0])) < 2e-4
+    assert abs(float(o3.energies[0] - oc.energies[0])) < 2e-4
+    assert torch.allclose(o3.forces, oc.forces, atol=2e-5)
+
+
+def test_solvated_box_46k(dev, oracle64):
+    """BASELINE config 3 scale: ~46k-atom periodic water box.  Full-size checks are the size-independent
+    properties; a random sample of atoms is checked against the oracle on the same box."""
+    sp, x, cell = _water_box(25, 3, dev)  # 15625 waters = 46875 atoms, 77.5 A box
+    model = get_model("ani2x", 23, dev, neighborlist="cell")
+    spt, xt, ct = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(cell).to(dev)
+    pbc = (True, True, True)
+    out = model.energies_and_forces(spt, xt, ct, pbc, check_overflow=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.forces).all()
+    assert out.forces.sum(dim=1).abs().max() < 2e-3
+    # oracle on the same box: AEVs of every atom, networks on a random sample of 1500 atoms
+    dims, flat, _ = oracle_networks("ani2x", 8, 23)
+    aev = oracle64.aev(oracle_params("ani2x"), sp, x.astype(np.float64), cell, pbc, cell_list=True)
+    pick = np.random.RandomState(0).choice(sp.shape[1], 1500, replace=False)
+    ae, _, _ = oracle64.mlp(sp[0, pick], aev[0, pick], dims, flat, n_members=8, want_grad=False)
+    ea = np.abs(out.atomic_energies.cpu().numpy()[0, pick] - ae).max()
+    report(f"box   water 46875 atoms pbc       max|e_atom err| (1500 sampled atoms) = {ea:.2e}")
+    assert ea < E_ATOM_TOL

@@ -1,0 +1,141 @@
+"""Loader and ctypes prototypes of libanihip.so (the C ABI declared in include/anihip.h).
+
+The product path has NO CPU fallback: if the library is missing or there is no GPU the calls raise.
+``build()`` compiles the HIP sources in-tree with plain ``hipcc --offload-arch=gfx950`` (no hipify, no
+torch cpp_extension), so the resulting .so travels with the repository snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+import typing as tp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libanihip.so")
+SOURCES = ["api.hip", "nbr.hip", "aev.hip", "mlp.hip"]
+HEADERS = ["anihip_common.h", os.path.join("..", "..", "include", "anihip.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared"]
+
+MAX_SPECIES = 8
+MAX_LAYERS = 4
+META_WORDS = 6
+STATUS_WORDS = 8
+MAX_ANG = 128
+MAX_RAD = 256
+TABLE_FLOATS = 80
+ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
+
+
+class AevParams(C.Structure):
+    _fields_ = [
+        ("num_species", C.c_int32),
+        ("n_shf_r", C.c_int32),
+        ("n_shf_a", C.c_int32),
+        ("n_shf_z", C.c_int32),
+        ("Rcr", C.c_float),
+        ("Rca", C.c_float),
+        ("EtaR", C.c_float),
+        ("EtaA", C.c_float),
+        ("Zeta", C.c_float),
+    ]
+
+
+class SpeciesNet(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32),
+        ("dims", C.c_int32 * (MAX_LAYERS + 1)),
+        ("w", C.c_void_p * MAX_LAYERS),
+        ("wt", C.c_void_p * MAX_LAYERS),
+        ("bias", C.c_void_p * MAX_LAYERS),
+    ]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ("num_species", C.c_int32),
+        ("n_members", C.c_int32),
+        ("aev_len", C.c_int32),
+        ("celu_alpha", C.c_float),
+        ("net", SpeciesNet * MAX_SPECIES),
+    ]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(_HERE, "csrc", s) for s in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libanihip.so for gfx950 if it is missing or older than its sources."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libanihip.so")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(_HERE, "csrc", s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib: tp.Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library.  torch must be imported first so that both share one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first; ours resolves to the same soname)
+
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP engine is not built. Run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` (there is no CPU fallback)."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    L.anihip_last_error.restype = C.c_char_p
+    L.anihip_abi_version.restype = C.c_int
+    L.anihip_aev_table_pack.argtypes = [C.POINTER(AevParams), vp, vp, vp, vp]
+    L.anihip_nbr_workspace_bytes.restype = sz
+    L.anihip_nbr_workspace_bytes.argtypes = [i64, i64]
+    L.anihip_nbr_build_batch.argtypes = [vp, C.POINTER(AevParams), i32, i32, vp, vp, vp, i32, i64, i64, vp,
+                                         sz, vp, vp, i64, vp]
+    L.anihip_nbr_build_cell.argtypes = [vp, C.POINTER(AevParams), i64, vp, vp, vp, i32, i64, i64, i64, vp,
+                                        sz, vp, vp, i64, vp]
+    L.anihip_aev_forward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.anihip_aev_backward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.anihip_mlp_workspace_bytes.restype = sz
+    L.anihip_mlp_workspace_bytes.argtypes = [C.POINTER(MlpDesc), i64]
+    L.anihip_mlp_forward_backward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, sz, vp, vp,
+                                              vp]
+    L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
+    for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell",
+                 "anihip_aev_forward", "anihip_aev_backward", "anihip_mlp_forward_backward",
+                 "anihip_energy_reduce"):
+        getattr(L, name).restype = C.c_int
+    if L.anihip_abi_version() != 1:
+        raise RuntimeError("libanihip.so ABI version mismatch: rebuild it")
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "anihip_last_error", "anihip_abi_version", "anihip_aev_table_pack", "anihip_nbr_workspace_bytes",
+    "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_aev_forward", "anihip_aev_backward",
+    "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_energy_reduce",
+]
+
+
+def check(rc: int) -> None:
+    """Map a non-zero status of the C ABI to RuntimeError (the reference raises c10::Error ->
+    RuntimeError from TORCH_CHECK, csrc/aev.cu:1693-1710)."""
+    if rc != 0:
+        raise RuntimeError("libanihip: " + lib().anihip_last_error().decode())

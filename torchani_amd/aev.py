@@ -1,0 +1,184 @@
+"""AEVComputer with the reference's call signature, backed by the HIP engine.
+
+Mirrors torchani/aev/_computer.py:73-129 (constructor), :193-249 (forward), :498-666 (like_1x / like_2x /
+from_constants) and the buffers of torchani/aev/_terms.py:153-156,288-292 so that a reference state dict
+loads unchanged.  ``strategy`` is always the native HIP path: there is no pyaev fallback here.
+"""
+from __future__ import annotations
+
+import typing as tp
+import warnings
+
+import torch
+from torch import Tensor
+
+from .constants import AEVConstants, aev_constants_1x, aev_constants_2x
+from .engine import AevEngine, NeighborRows
+from .tuples import SpeciesAEV
+
+
+class _RadialTerms(torch.nn.Module):
+    """Holder of the radial hyper-parameters under the reference's buffer names (eta, shifts)."""
+
+    def __init__(self, eta: float, shifts: tp.Sequence[float], cutoff: float) -> None:
+        super().__init__()
+        self.register_buffer("eta", torch.tensor([eta], dtype=torch.float))
+        self.register_buffer("shifts", torch.tensor(list(shifts), dtype=torch.float))
+        self.cutoff = float(cutoff)
+
+
+class _AngularTerms(torch.nn.Module):
+    """Holder of the angular hyper-parameters (eta, zeta, shifts, sections)."""
+
+    def __init__(self, eta: float, zeta: float, shifts: tp.Sequence[float], sections: tp.Sequence[float],
+                 cutoff: float) -> None:
+        super().__init__()
+        self.register_buffer("eta", torch.tensor([eta], dtype=torch.float))
+        self.register_buffer("zeta", torch.tensor([zeta], dtype=torch.float))
+        self.register_buffer("shifts", torch.tensor(list(shifts), dtype=torch.float))
+        self.register_buffer("sections", torch.tensor(list(sections), dtype=torch.float))
+        self.cutoff = float(cutoff)
+
+
+class _AEVFunction(torch.autograd.Function):
+    """coords -> aevs with the analytic HIP backward (the role of CuaevAutograd, csrc/cuaev.cpp:120-139)."""
+
+    @staticmethod
+    def forward(ctx, coords: Tensor, species32: Tensor, cell, pbc, computer: "AEVComputer") -> Tensor:
+        eng = computer.engine()
+        c32 = coords.detach().to(torch.float32).contiguous()
+        nbrs = eng.neighbors(species32, c32, cell, pbc, mode=computer.neighbor_mode,
+                             row_cap=computer.row_capacity)
+        aev = eng.forward(species32, nbrs)
+        ctx.eng, ctx.nbrs, ctx.species32 = eng, nbrs, species32
+        ctx.in_dtype = coords.dtype
+        computer._last_neighbors = nbrs
+        return aev.view(species32.shape[0], species32.shape[1], eng.L).to(coords.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_aev: Tensor):
+        g = grad_aev.to(torch.float32).contiguous()
+        gc = ctx.eng.backward(ctx.species32, ctx.nbrs, g)
+        C, A = ctx.species32.shape
+        return gc.view(C, A, 3).to(ctx.in_dtype), None, None, None, None
+
+
+class AEVComputer(torch.nn.Module):
+    """Atomic environment vectors [C, A, S*16 + S(S+1)/2*32] on the MI355X engine."""
+
+    def __init__(self, consts: AEVConstants, neighborlist: str = "auto", row_capacity: int = 128,
+                 strategy: str = "hip", cutoff_fn: str = "cosine") -> None:
+        super().__init__()
+        if strategy not in ("hip", "auto"):
+            # the reference raises ValueError for unknown strategies (aev/_computer.py:127-128)
+            raise ValueError(f"Unsupported strategy {strategy!r}: torchani_amd only has the native 'hip' path")
+        if cutoff_fn != "cosine":
+            raise ValueError("only the cosine cutoff is implemented in the HIP kernels")
+        modes = {"auto": "auto", "all_pairs": "batch", "cell_list": "cell", "batch": "batch", "cell": "cell",
+                 "adaptive": "auto"}
+        if neighborlist not in modes:
+            raise ValueError(f"Unsupported neighborlist {neighborlist!r}")
+        self.neighbor_mode = modes[neighborlist]
+        self.row_capacity = int(row_capacity)
+        self.num_species = consts.num_species
+        self.radial = _RadialTerms(consts.EtaR, consts.ShfR, consts.Rcr)
+        self.angular = _AngularTerms(consts.EtaA, consts.Zeta, consts.ShfA, consts.ShfZ, consts.Rca)
+        self.register_buffer("triu_index", self._calculate_triu_index(consts.num_species))
+        self._engine: tp.Optional[AevEngine] = None
+        self._engine_key: tp.Optional[tuple] = None
+        self._last_neighbors: tp.Optional[NeighborRows] = None
+        self.strategy = "hip"
+
+    # aev/_computer.py:183-191
+    @staticmethod
+    def _calculate_triu_index(num_species: int) -> Tensor:
+        s1, s2 = torch.triu_indices(num_species, num_species).unbind(0)
+        pair_index = torch.arange(s1.shape[0], dtype=torch.long)
+        ret = torch.zeros(num_species, num_species, dtype=torch.long)
+        ret[s1, s2] = pair_index
+        ret[s2, s1] = pair_index
+        return ret
+
+    @classmethod
+    def like_2x(cls, num_species: int = 7, **kw) -> "AEVComputer":
+        return cls(aev_constants_2x(num_species), **kw)
+
+    @classmethod
+    def like_1x(cls, num_species: int = 4, **kw) -> "AEVComputer":
+        return cls(aev_constants_1x(num_species), **kw)
+
+    @classmethod
+    def from_constants(cls, radial_cutoff: float, angular_cutoff: float, radial_eta: float,
+                       radial_shifts: tp.Sequence[float], angular_eta: float, angular_zeta: float,
+                       angular_shifts: tp.Sequence[float], sections: tp.Sequence[float], num_species: int,
+                       **kw) -> "AEVComputer":
+        # aev/_computer.py:602-666
+        return cls(AEVConstants(num_species, radial_cutoff, angular_cutoff, radial_eta, tuple(radial_shifts),
+                                angular_eta, angular_zeta, tuple(angular_shifts), tuple(sections)), **kw)
+
+    # ---- derived sizes (aev/_computer.py:61-71,131-149) ----
+    @property
+    def num_species_pairs(self) -> int:
+        return self.num_species * (self.num_species + 1) // 2
+
+    @property
+    def radial_len(self) -> int:
+        return self.num_species * self.radial.shifts.numel()
+
+    @property
+    def angular_len(self) -> int:
+        return self.num_species_pairs * self.angular.shifts.numel() * self.angular.sections.numel()
+
+    @property
+    def out_dim(self) -> int:
+        return self.radial_len + self.angular_len
+
+    def constants(self) -> AEVConstants:
+        """Current hyper-parameters, read back from the (possibly state-dict-loaded) fp32 buffers."""
+        r, a = self.radial, self.angular
+        return AEVConstants(
+            self.num_species, r.cutoff, a.cutoff, float(r.eta.item()),
+            tuple(float(x) for x in r.shifts.tolist()), float(a.eta.item()), float(a.zeta.item()),
+            tuple(float(x) for x in a.shifts.tolist()), tuple(float(x) for x in a.sections.tolist()))
+
+    def engine(self) -> AevEngine:
+        key = (self.radial.eta._version, self.radial.shifts._version, self.angular.eta._version,
+               self.angular.zeta._version, self.angular.shifts._version, self.angular.sections._version,
+               self.radial.cutoff, self.angular.cutoff)
+        if self._engine is None or self._engine_key != key:
+            self._engine = AevEngine(self.constants())
+            self._engine_key = key
+        return self._engine
+
+    def set_strategy(self, strategy: str) -> None:
+        if strategy not in ("hip", "auto"):
+            raise ValueError(f"Unsupported strategy {strategy!r}")
+
+    def forward(self, elem_idxs, coords: tp.Optional[Tensor] = None, cell: tp.Optional[Tensor] = None,
+                pbc: tp.Optional[Tensor] = None):
+        """aevs = aevc(elem_idxs, coords, cell=None, pbc=None); the legacy tuple form
+        ``_, aevs = aevc((idxs, coords), cell, pbc)`` is accepted with a warning
+        (aev/_computer.py:211-222)."""
+        if isinstance(elem_idxs, tuple):
+            warnings.warn("The tuple call signature is deprecated; use aevc(elem_idxs, coords, cell, pbc)")
+            idxs, crd = elem_idxs
+            # legacy call: (species, coords), cell, pbc were positional
+            cell, pbc = (coords if coords is not None else cell), (cell if coords is not None else pbc)
+            return SpeciesAEV(idxs, self.forward(idxs, crd, cell, pbc))
+        assert coords is not None
+        if not coords.is_cuda:
+            raise ValueError("torchani_amd's AEVComputer needs tensors on a ROCm device (no CPU fallback)")
+        if elem_idxs.dim() != 2 or coords.shape != (elem_idxs.shape[0], elem_idxs.shape[1], 3):
+            raise ValueError("expected elem_idxs [C, A] and coords [C, A, 3]")
+        if (cell is None) != (pbc is None):
+            raise ValueError("cell and pbc must be given together")
+        pbc_t = None if pbc is None else tuple(bool(b) for b in pbc.tolist())
+        species32 = elem_idxs.to(torch.int32).contiguous()
+        return _AEVFunction.apply(coords, species32, cell, pbc_t, self)
+
+    def last_neighbors(self) -> tp.Optional[NeighborRows]:
+        return self._last_neighbors
+
+    def extra_repr(self) -> str:
+        return (f"num_species={self.num_species}, out_dim={self.out_dim}, strategy=hip, "
+                f"neighborlist={self.neighbor_mode}, row_capacity={self.row_capacity}")

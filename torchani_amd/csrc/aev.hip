@@ -1,0 +1,551 @@
+// Radial + angular AEV forward and analytic backward for gfx950 (wave64).
+//
+// One wave owns one central atom at a time (persistent waves stride over the shard).  The atom's
+// species-sorted neighbor row (written by nbr.hip) is loaded with one coalesced 16-B load per lane,
+// turned into unit vectors / cutoff factors once per neighbor and staged in the wave's private LDS.
+//
+//   radial : lane = (neighbor slot p in 0..7, shift pair sq in 0..7); neighbors are visited species by
+//            species, sums stay in registers, one 3-step cross-slot reduction per species.
+//   angular: lane = (pair slot p in 0..15, quarter q in 0..3).  For every species pair block (sj<=sk)
+//            the (j,k) pairs form a dense rectangle / circular-tournament triangle of the sorted row,
+//            so 16 pairs are evaluated per step with a wave-uniform output block: each lane
+//            computes one quarter of the angular factors (2 exp2 for F2, one log2/exp2 for F1), the 4
+//            F1 values are shared inside the quad with DPP, and the 8x4 outer product accumulates in 8
+//            registers.  One cross-slot reduction per block, no LDS/global atomics in the forward,
+//            deterministic.  The finished 1008-float row is staged in LDS and stored with full-width
+//            16-B-per-lane coalesced writes.
+//   backward: same tiling; the per-pair derivative coefficients (sum_w f1 f2, sum_w f1' f2,
+//            sum_w f1 f2') are reduced inside the quad, per-neighbor gradient vectors accumulate in
+//            LDS and leave as one float atomic per component per neighbor.
+//
+// Maths restated from the reference (paths relative to /root/reference/torchani/):
+//   aev/_terms.py:99-104,171-186 (radial), :34-55,324-325,339-343 (angular), cutoffs.py:80-81,
+//   aev/_computer.py:183-191,302-350 (species / species-pair binning and layout).  cos(theta - ShfZ)
+//   is expanded as cos(theta)cos(ShfZ)+sin(theta)sin(ShfZ) with cos(theta)=0.95 cos(angle), which
+//   is algebraically identical to acos + cos (aev/_terms.py:339-343) and needs no acos.
+#include "anihip_common.h"
+
+namespace anihip {
+
+constexpr int FWD_WPB = 4;
+constexpr int BWD_WPB = 2;
+constexpr int STAGE_FLOATS = 1024;  // >= L (S<=7: 1008)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float PI_F = 3.14159265358979323846f;
+
+struct AevArgs {
+    int S, NR, L, radlen;
+    float Rcr, Rca, kR, kA, EtaR, EtaA, Zeta;
+};
+
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v)
+{
+    // DPP quad_perm: every lane of a quad reads quad-lane Q
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), Q * 0x55, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float quad_bcast_rt(float v, int q)
+{
+    switch (q) {
+        case 0: return quad_bcast<0>(v);
+        case 1: return quad_bcast<1>(v);
+        case 2: return quad_bcast<2>(v);
+        default: return quad_bcast<3>(v);
+    }
+}
+
+__device__ __forceinline__ int cnt_of(uint64_t pk, int t) { return (int)((pk >> (8 * t)) & 255u); }
+
+// (j,k) of the t-th pair of a block: rectangle for two different species, circular tournament for
+// pairs inside one species (every unordered pair exactly once, no sqrt / triangular-index decode)
+__device__ __forceinline__ void decode_pair(bool same, int t, int nj, int nk, float inv_div, int div,
+                                            int &jr, int &kr)
+{
+    if (!same) {
+        jr = (int)(((float)t + 0.5f) * inv_div);  // t / nk
+        kr = t - jr * nk;
+    } else {
+        const int rect = nj * div;  // div = (n-1)/2 partners per row
+        if (t < rect) {
+            jr = (int)(((float)t + 0.5f) * inv_div);
+            kr = jr + 1 + (t - jr * div);
+            kr = kr >= nj ? kr - nj : kr;
+        } else {  // n even: the n/2 diameters
+            jr = t - rect;
+            kr = jr + (nj >> 1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int NA, int NZ>
+__global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
+    AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
+    const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
+    const float4 *__restrict__ ent, float *__restrict__ aev)
+{
+    static_assert(NA % 4 == 0 && NZ % 4 == 0 && NA * NZ == 32, "angular tiling");
+    constexpr int AQ = NA / 4, ZQ = NZ / 4;
+    __shared__ float4 s_ang[FWD_WPB][MAXA];   // ux uy uz r
+    __shared__ float s_afc[FWD_WPB][MAXA];    // fc(r, Rca)
+    __shared__ float2 s_rad[FWD_WPB][MAXR];   // r, 0.25 fc(r, Rcr)
+    __shared__ __attribute__((aligned(16))) float s_stage[FWD_WPB][STAGE_FLOATS];
+
+    const int wib = threadIdx.x >> 6, lane = lane_id();
+    float4 *ang = s_ang[wib];
+    float *afc = s_afc[wib];
+    float2 *rad = s_rad[wib];
+    float *stage = s_stage[wib];
+
+    // per-lane constants
+    const int rp = lane >> 3, rsq = lane & 7;  // radial: neighbor slot, shift pair
+    const float shfR0 = tab[TAB_SHFR + rsq], shfR1 = tab[TAB_SHFR + rsq + 8];
+    const int p = lane >> 2, q = lane & 3;  // angular: pair slot, quarter
+    float shfA[AQ], cosZ[ZQ], sinZ[ZQ];
+#pragma unroll
+    for (int u = 0; u < AQ; ++u) shfA[u] = tab[TAB_SHFA + q + 4 * u];
+#pragma unroll
+    for (int v = 0; v < ZQ; ++v) {
+        cosZ[v] = tab[TAB_COSZ + q + 4 * v];
+        sinZ[v] = tab[TAB_SINZ + q + 4 * v];
+    }
+    const float pi_rcr = PI_F / a.Rcr, pi_rca = PI_F / a.Rca;
+    const int L4 = a.L >> 2;
+
+    const int64_t nw = (int64_t)gridDim.x * FWD_WPB;
+    for (int64_t i = lo + blockIdx.x * (int64_t)FWD_WPB + wib; i < hi; i += nw) {
+        float4 *out4 = reinterpret_cast<float4 *>(aev + (size_t)i * a.L);
+        if (species[i] < 0) {
+            for (int f = lane; f < L4; f += WAVE) out4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const uint32_t *m = meta + (size_t)i * META_W;
+        const uint32_t start = m[0], cntw = m[1];
+        const int nA = uniform((int)(cntw & 0xFFFFu)), nF = uniform((int)(cntw >> 16));
+        const int nR = nA + nF;
+        const uint64_t pkA = ((uint64_t)(uint32_t)uniform((int)m[3]) << 32) | (uint32_t)uniform((int)m[2]);
+        const uint64_t pkF = ((uint64_t)(uint32_t)uniform((int)m[5]) << 32) | (uint32_t)uniform((int)m[4]);
+
+        // ---- load + per-neighbor precompute ----
+        for (int e = lane; e < nR; e += WAVE) {
+            const float4 d = ent[start + e];
+            const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+            rad[e] = make_float2(r, 0.25f * (0.5f * cosf(r * pi_rcr) + 0.5f));
+            if (e < nA) {
+                const float inv = 1.0f / r;
+                ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, r);
+                afc[e] = 0.5f * cosf(r * pi_rca) + 0.5f;
+            }
+        }
+        wave_sync();
+
+        // ---- radial ----
+        {
+            int oA = 0, oF = 0;
+            for (int t = 0; t < a.S; ++t) {
+                const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t), n = cA + cF;
+                float acc0 = 0.f, acc1 = 0.f;
+                for (int b = 0; b < n; b += 8) {
+                    const int idx = b + rp;
+                    const bool v = idx < n;
+                    int e = idx < cA ? oA + idx : nA + oF + (idx - cA);
+                    e = v ? e : 0;
+                    const float2 rf = rad[e];
+                    const float f = v ? rf.y : 0.f;
+                    const float d0 = rf.x - shfR0, d1 = rf.x - shfR1;
+                    acc0 += __builtin_amdgcn_exp2f(a.kR * d0 * d0) * f;
+                    acc1 += __builtin_amdgcn_exp2f(a.kR * d1 * d1) * f;
+                }
+                acc0 += __shfl_xor(acc0, 8);  acc1 += __shfl_xor(acc1, 8);
+                acc0 += __shfl_xor(acc0, 16); acc1 += __shfl_xor(acc1, 16);
+                acc0 += __shfl_xor(acc0, 32); acc1 += __shfl_xor(acc1, 32);
+                if (lane < 8) {
+                    stage[t * 16 + rsq] = acc0;
+                    stage[t * 16 + 8 + rsq] = acc1;
+                }
+                oA += cA;
+                oF += cF;
+            }
+        }
+
+        // ---- angular ----
+        {
+            int P = 0, oj = 0;
+            for (int tj = 0; tj < a.S; ++tj) {
+                const int nj = cnt_of(pkA, tj);
+                int ok = oj;
+                for (int tk = tj; tk < a.S; ++tk, ++P) {
+                    const int nk = cnt_of(pkA, tk);
+                    const bool same = (tk == tj);
+                    const int np = same ? (nj * (nj - 1)) >> 1 : nj * nk;
+                    float *blk = stage + a.radlen + P * 32;
+                    if (np == 0) {
+                        if (lane < 32) blk[lane] = 0.f;
+                        ok += nk;
+                        continue;
+                    }
+                    const int div = same ? ((nj - 1) >> 1) : nk;
+                    const float inv_div = div > 0 ? 1.0f / (float)div : 0.f;
+                    float acc[AQ][NZ];
+#pragma unroll
+                    for (int u = 0; u < AQ; ++u)
+#pragma unroll
+                        for (int z = 0; z < NZ; ++z) acc[u][z] = 0.f;
+                    for (int t0 = 0; t0 < np; t0 += 16) {
+                        const int t = t0 + p;
+                        const bool v = t < np;
+                        int jr, kr;
+                        decode_pair(same, v ? t : 0, nj, nk, inv_div, div, jr, kr);
+                        const float4 J = ang[oj + jr], K = ang[ok + kr];
+                        const float fcc = v ? 2.0f * afc[oj + jr] * afc[ok + kr] : 0.f;
+                        const float c = J.x * K.x + J.y * K.y + J.z * K.z;
+                        const float ct = 0.95f * c;
+                        const float st = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ct * ct, 0.f));
+                        const float rm = 0.5f * (J.w + K.w);
+                        float f1t[ZQ], f2[AQ];
+#pragma unroll
+                        for (int vz = 0; vz < ZQ; ++vz) {
+                            const float cz = ct * cosZ[vz] + st * sinZ[vz];
+                            const float h = fmaxf(0.5f + 0.5f * cz, 0.f);
+                            f1t[vz] = __builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(h)) * fcc;
+                        }
+#pragma unroll
+                        for (int u = 0; u < AQ; ++u) {
+                            const float d = rm - shfA[u];
+                            f2[u] = __builtin_amdgcn_exp2f(a.kA * d * d);
+                        }
+#pragma unroll
+                        for (int z = 0; z < NZ; ++z) {
+                            const float f1 = quad_bcast_rt(f1t[z >> 2], z & 3);
+#pragma unroll
+                            for (int u = 0; u < AQ; ++u) acc[u][z] += f2[u] * f1;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < AQ; ++u)
+#pragma unroll
+                        for (int z = 0; z < NZ; ++z) {
+                            float s = acc[u][z];
+                            s += __shfl_xor(s, 4);
+                            s += __shfl_xor(s, 8);
+                            s += __shfl_xor(s, 16);
+                            s += __shfl_xor(s, 32);
+                            acc[u][z] = s;
+                        }
+                    if (lane < 4) {
+#pragma unroll
+                        for (int u = 0; u < AQ; ++u)
+#pragma unroll
+                            for (int z = 0; z < NZ; ++z) blk[(q + 4 * u) * NZ + z] = acc[u][z];
+                    }
+                    ok += nk;
+                }
+                oj += nj;
+            }
+        }
+        wave_sync();
+        const float4 *st4 = reinterpret_cast<const float4 *>(stage);
+        for (int f = lane; f < L4; f += WAVE) out4[f] = st4[f];
+        wave_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int NA, int NZ>
+__global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
+    AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
+    const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
+    const float4 *__restrict__ ent, const float *__restrict__ grad_aev, float *__restrict__ grad_coords)
+{
+    constexpr int AQ = NA / 4, ZQ = NZ / 4;
+    __shared__ float4 s_nb[BWD_WPB][MAXR];    // ux uy uz r (all neighbors)
+    __shared__ float2 s_rad[BWD_WPB][MAXR];   // 0.25 fc, 0.25 fc'   (Rcr)
+    __shared__ float4 s_afc[BWD_WPB][MAXA];   // fc, fc', 1/r, -    (Rca)
+    __shared__ float s_g[BWD_WPB][3][MAXR];   // per-neighbor gradient accumulators
+    __shared__ uint32_t s_j[BWD_WPB][MAXR];
+    __shared__ __attribute__((aligned(16))) float s_stage[BWD_WPB][STAGE_FLOATS];
+
+    const int wib = threadIdx.x >> 6, lane = lane_id();
+    float4 *nb = s_nb[wib];
+    float2 *rad = s_rad[wib];
+    float4 *afc = s_afc[wib];
+    float *gx = s_g[wib][0], *gy = s_g[wib][1], *gz = s_g[wib][2];
+    uint32_t *jx = s_j[wib];
+    float *stage = s_stage[wib];
+
+    const int rp = lane >> 3, rsq = lane & 7;
+    const float shfR0 = tab[TAB_SHFR + rsq], shfR1 = tab[TAB_SHFR + rsq + 8];
+    const int p = lane >> 2, q = lane & 3;
+    float shfA[AQ], cosZ[ZQ], sinZ[ZQ];
+#pragma unroll
+    for (int u = 0; u < AQ; ++u) shfA[u] = tab[TAB_SHFA + q + 4 * u];
+#pragma unroll
+    for (int v = 0; v < ZQ; ++v) {
+        cosZ[v] = tab[TAB_COSZ + q + 4 * v];
+        sinZ[v] = tab[TAB_SINZ + q + 4 * v];
+    }
+    const float pi_rcr = PI_F / a.Rcr, pi_rca = PI_F / a.Rca;
+    const int L4 = a.L >> 2;
+
+    const int64_t nw = (int64_t)gridDim.x * BWD_WPB;
+    for (int64_t i = lo + blockIdx.x * (int64_t)BWD_WPB + wib; i < hi; i += nw) {
+        if (species[i] < 0) continue;
+        const uint32_t *m = meta + (size_t)i * META_W;
+        const uint32_t start = m[0], cntw = m[1];
+        const int nA = uniform((int)(cntw & 0xFFFFu)), nF = uniform((int)(cntw >> 16));
+        const int nR = nA + nF;
+        if (nR == 0) continue;
+        const uint64_t pkA = ((uint64_t)(uint32_t)uniform((int)m[3]) << 32) | (uint32_t)uniform((int)m[2]);
+        const uint64_t pkF = ((uint64_t)(uint32_t)uniform((int)m[5]) << 32) | (uint32_t)uniform((int)m[4]);
+
+        const float4 *g4 = reinterpret_cast<const float4 *>(grad_aev + (size_t)i * a.L);
+        float4 *st4 = reinterpret_cast<float4 *>(stage);
+        for (int f = lane; f < L4; f += WAVE) st4[f] = g4[f];
+        for (int e = lane; e < nR; e += WAVE) {
+            const float4 d = ent[start + e];
+            const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+            const float inv = 1.0f / r;
+            nb[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, r);
+            jx[e] = __float_as_uint(d.w) & IDX_MASK;
+            float sn, cs;
+            sincosf(r * pi_rcr, &sn, &cs);
+            rad[e] = make_float2(0.25f * (0.5f * cs + 0.5f), 0.25f * (-0.5f * pi_rcr * sn));
+            if (e < nA) {
+                sincosf(r * pi_rca, &sn, &cs);
+                afc[e] = make_float4(0.5f * cs + 0.5f, -0.5f * pi_rca * sn, inv, 0.f);
+            }
+        }
+        wave_sync();
+
+        // ---- radial: visits every neighbor exactly once => initialises the accumulators ----
+        {
+            int oA = 0, oF = 0;
+            for (int t = 0; t < a.S; ++t) {
+                const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t), n = cA + cF;
+                const float w0 = stage[t * 16 + rsq], w1 = stage[t * 16 + 8 + rsq];
+                for (int b = 0; b < n; b += 8) {
+                    const int idx = b + rp;
+                    const bool v = idx < n;
+                    int e = idx < cA ? oA + idx : nA + oF + (idx - cA);
+                    e = v ? e : 0;
+                    const float4 U = nb[e];
+                    const float2 ff = rad[e];
+                    const float d0 = U.w - shfR0, d1 = U.w - shfR1;
+                    const float e0 = __builtin_amdgcn_exp2f(a.kR * d0 * d0);
+                    const float e1 = __builtin_amdgcn_exp2f(a.kR * d1 * d1);
+                    // d/dr [exp(-eta d^2) fc] = exp(..) (fc' - 2 eta d fc)
+                    float dR = w0 * e0 * (ff.y - 2.0f * a.EtaR * d0 * ff.x) +
+                               w1 * e1 * (ff.y - 2.0f * a.EtaR * d1 * ff.x);
+                    dR += __shfl_xor(dR, 1);
+                    dR += __shfl_xor(dR, 2);
+                    dR += __shfl_xor(dR, 4);
+                    if (v && rsq == 0) {
+                        gx[e] = dR * U.x;
+                        gy[e] = dR * U.y;
+                        gz[e] = dR * U.z;
+                    }
+                }
+                oA += cA;
+                oF += cF;
+            }
+        }
+        wave_sync();
+
+        // ---- angular ----
+        {
+            int P = 0, oj = 0;
+            for (int tj = 0; tj < a.S; ++tj) {
+                const int nj = cnt_of(pkA, tj);
+                int ok = oj;
+                for (int tk = tj; tk < a.S; ++tk, ++P) {
+                    const int nk = cnt_of(pkA, tk);
+                    const bool same = (tk == tj);
+                    const int np = same ? (nj * (nj - 1)) >> 1 : nj * nk;
+                    if (np == 0) {
+                        ok += nk;
+                        continue;
+                    }
+                    const int div = same ? ((nj - 1) >> 1) : nk;
+                    const float inv_div = div > 0 ? 1.0f / (float)div : 0.f;
+                    const float *blk = stage + a.radlen + P * 32;
+                    float w[AQ][NZ];
+#pragma unroll
+                    for (int u = 0; u < AQ; ++u)
+#pragma unroll
+                        for (int z = 0; z < NZ; ++z) w[u][z] = blk[(q + 4 * u) * NZ + z];
+                    for (int t0 = 0; t0 < np; t0 += 16) {
+                        const int t = t0 + p;
+                        const bool v = t < np;
+                        int jr, kr;
+                        decode_pair(same, v ? t : 0, nj, nk, inv_div, div, jr, kr);
+                        const int ej = oj + jr, ek = ok + kr;
+                        const float4 J = nb[ej], K = nb[ek];
+                        const float4 FJ = afc[ej], FK = afc[ek];
+                        const float c = J.x * K.x + J.y * K.y + J.z * K.z;
+                        const float ct = 0.95f * c;
+                        const float st = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ct * ct, 0.f));
+                        const float rm = 0.5f * (J.w + K.w);
+                        // this lane's quarter of the factors
+                        float f1q[ZQ], df1q[ZQ], f2[AQ], df2[AQ];
+#pragma unroll
+                        for (int vz = 0; vz < ZQ; ++vz) {
+                            const float cz = ct * cosZ[vz] + st * sinZ[vz];   // cos(theta - ShfZ)
+                            const float sz = st * cosZ[vz] - ct * sinZ[vz];   // sin(theta - ShfZ)
+                            const float h = fmaxf(0.5f + 0.5f * cz, 0.f);
+                            const float p1 = __builtin_amdgcn_exp2f((a.Zeta - 1.0f) * __builtin_amdgcn_logf(h));
+                            f1q[vz] = 2.0f * h * p1;          // 2 h^zeta
+                            df1q[vz] = -a.Zeta * p1 * sz;     // d/dtheta
+                        }
+#pragma unroll
+                        for (int u = 0; u < AQ; ++u) {
+                            const float d = rm - shfA[u];
+                            f2[u] = __builtin_amdgcn_exp2f(a.kA * d * d);
+                            df2[u] = -2.0f * a.EtaA * d * f2[u];  // d/d rm
+                        }
+                        float C0 = 0.f, Cth = 0.f, CR = 0.f;
+#pragma unroll
+                        for (int z = 0; z < NZ; ++z) {
+                            const float f1 = quad_bcast_rt(f1q[z >> 2], z & 3);
+                            const float df1 = quad_bcast_rt(df1q[z >> 2], z & 3);
+#pragma unroll
+                            for (int u = 0; u < AQ; ++u) {
+                                const float wf2 = w[u][z] * f2[u];
+                                C0 += wf2 * f1;
+                                Cth += wf2 * df1;
+                                CR += w[u][z] * df2[u] * f1;
+                            }
+                        }
+                        C0 += __shfl_xor(C0, 1);  Cth += __shfl_xor(Cth, 1);  CR += __shfl_xor(CR, 1);
+                        C0 += __shfl_xor(C0, 2);  Cth += __shfl_xor(Cth, 2);  CR += __shfl_xor(CR, 2);
+                        const float fcc = v ? FJ.x * FK.x : 0.f;
+                        const float kth = Cth * fcc * (-0.95f / st);
+                        const float k1 = 0.5f * CR * fcc + (v ? C0 * FJ.y * FK.x : 0.f);
+                        const float k2 = 0.5f * CR * fcc + (v ? C0 * FJ.x * FK.y : 0.f);
+                        // component q of the two gradient vectors (q == 3 idles)
+                        const float uj = q == 0 ? J.x : (q == 1 ? J.y : J.z);
+                        const float uk = q == 0 ? K.x : (q == 1 ? K.y : K.z);
+                        const float gj = kth * (uk - c * uj) * FJ.z + k1 * uj;
+                        const float gk = kth * (uj - c * uk) * FK.z + k2 * uk;
+                        if (v && q < 3) {
+                            float *gq = q == 0 ? gx : (q == 1 ? gy : gz);
+                            atomicAdd(&gq[ej], gj);  // LDS ds_add_f32
+                            atomicAdd(&gq[ek], gk);
+                        }
+                    }
+                    ok += nk;
+                }
+                oj += nj;
+            }
+        }
+        wave_sync();
+        // ---- scatter: +G to each neighbor, -sum(G) to the central atom ----
+        float sx = 0.f, sy = 0.f, sz_ = 0.f;
+        for (int e = lane; e < nR; e += WAVE) {
+            const float x = gx[e], y = gy[e], z = gz[e];
+            float *gc = grad_coords + 3 * (size_t)jx[e];
+            atomicAdd(gc + 0, x);
+            atomicAdd(gc + 1, y);
+            atomicAdd(gc + 2, z);
+            sx += x; sy += y; sz_ += z;
+        }
+        sx = wave_sum(sx); sy = wave_sum(sy); sz_ = wave_sum(sz_);
+        if (lane == 0) {
+            float *gc = grad_coords + 3 * (size_t)i;
+            atomicAdd(gc + 0, -sx);
+            atomicAdd(gc + 1, -sy);
+            atomicAdd(gc + 2, -sz_);
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace anihip
+
+using namespace anihip;
+
+extern "C" int anihip_aev_table_pack(const anihip_aev_params *p, const float *ShfR, const float *ShfA,
+                                     const float *ShfZ, float *t)
+{
+    ANIHIP_REQUIRE(p && ShfR && ShfA && ShfZ && t, "null pointer argument");
+    ANIHIP_REQUIRE(p->n_shf_r == 16, "n_shf_r must be 16 (got %d)", p->n_shf_r);
+    ANIHIP_REQUIRE(p->n_shf_a * p->n_shf_z == 32 && p->n_shf_a % 4 == 0 && p->n_shf_z % 4 == 0,
+                   "n_shf_a x n_shf_z must be 8x4 or 4x8 (got %dx%d)", p->n_shf_a, p->n_shf_z);
+    for (int k = 0; k < ANIHIP_AEV_TABLE_FLOATS; ++k) t[k] = 0.f;
+    for (int k = 0; k < p->n_shf_r; ++k) t[TAB_SHFR + k] = ShfR[k];
+    for (int k = 0; k < p->n_shf_a; ++k) t[TAB_SHFA + k] = ShfA[k];
+    for (int k = 0; k < p->n_shf_z; ++k) {
+        t[TAB_COSZ + k] = (float)cos((double)ShfZ[k]);
+        t[TAB_SINZ + k] = (float)sin((double)ShfZ[k]);
+    }
+    return 0;
+}
+
+static int make_args(const anihip_aev_params *p, AevArgs *a)
+{
+    ANIHIP_REQUIRE(p->num_species >= 1 && p->num_species <= MAX_S - 1, "num_species must be 1..7");
+    ANIHIP_REQUIRE(p->n_shf_r == 16, "n_shf_r must be 16");
+    ANIHIP_REQUIRE((p->n_shf_a == 8 && p->n_shf_z == 4) || (p->n_shf_a == 4 && p->n_shf_z == 8),
+                   "angular grid must be 8x4 (ANI-2x) or 4x8 (ANI-1x)");
+    a->S = p->num_species;
+    a->NR = p->n_shf_r;
+    a->radlen = a->S * a->NR;
+    a->L = a->radlen + (a->S * (a->S + 1) / 2) * 32;
+    a->Rcr = p->Rcr; a->Rca = p->Rca;
+    a->EtaR = p->EtaR; a->EtaA = p->EtaA; a->Zeta = p->Zeta;
+    a->kR = -p->EtaR * LOG2E;
+    a->kA = -p->EtaA * LOG2E;
+    return 0;
+}
+
+static int persistent_blocks(int64_t n_central, int wpb, int blocks_per_cu)
+{
+    int64_t b = (n_central + wpb - 1) / wpb;
+    if (b < 1) b = 1;
+    if (b > 256 * blocks_per_cu) b = 256 * blocks_per_cu;
+    return (int)b;
+}
+
+extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table,
+                                  int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                                  const uint32_t *meta, const float *ent, float *aev, uint32_t *status)
+{
+    ANIHIP_REQUIRE(p && table && species && meta && ent && aev, "null pointer argument");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    AevArgs a;
+    if (int rc = make_args(p, &a)) return rc;
+    if (hi == lo) return 0;
+    dim3 grid(persistent_blocks(hi - lo, FWD_WPB, 4)), block(FWD_WPB * WAVE);
+    if (p->n_shf_a == 8)
+        hipLaunchKernelGGL((k_aev_fwd<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, aev);
+    else
+        hipLaunchKernelGGL((k_aev_fwd<4, 8>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, aev);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    (void)status;
+    return 0;
+}
+
+extern "C" int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table,
+                                   int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                                   const uint32_t *meta, const float *ent, const float *grad_aev,
+                                   float *grad_coords, uint32_t *status)
+{
+    ANIHIP_REQUIRE(p && table && species && meta && ent && grad_aev && grad_coords, "null pointer argument");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    AevArgs a;
+    if (int rc = make_args(p, &a)) return rc;
+    if (hi == lo) return 0;
+    dim3 grid(persistent_blocks(hi - lo, BWD_WPB, 5)), block(BWD_WPB * WAVE);
+    if (p->n_shf_a == 8)
+        hipLaunchKernelGGL((k_aev_bwd<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, grad_aev, grad_coords);
+    else
+        hipLaunchKernelGGL((k_aev_bwd<4, 8>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, grad_aev, grad_coords);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    (void)status;
+    return 0;
+}

@@ -1,0 +1,572 @@
+// Per-species MLP ensemble forward + input-gradient backward on fp32 MFMA (gfx950).
+//
+// Structure (replaces mnp::run, csrc/mnp.cpp:32-232, and BmmEnsemble, nn/_infer.py:61-216):
+//   1. atoms of the shard are bucketed by species on the device (ballot ranks, no host sync, no
+//      nonzero()/index_select like nn/_containers.py:406-416);
+//   2. every layer is ONE grouped-GEMM launch covering all species and all ensemble members:
+//        layer 0 fwd : [n_s, K0] (AEV rows gathered through the bucket list) x [K0, M*H1]   (all M
+//                      members share the A operand -> one wide GEMM, cf. SURVEY section 7 hard parts)
+//        layer l fwd : M independent [n_s, Hl] x [Hl, Hl+1]
+//        backward    : same GEMMs against the pre-transposed weights, activation derivative fused;
+//                      the last one scatters d(energy)/d(aev) rows back to atom order.
+//      bias + CELU (forward) and CELU' (backward, evaluated from the stored activation) are fused in
+//      the epilogues, so each activation makes one HBM round trip.
+//   3. GEMM core: v_mfma_f32_32x32x2_f32 (exact fp32 products/accumulation, needed for the 1e-5 Ha
+//      budget), 128 x 128 x 16 tiles, 4 waves each owning a 32-row stripe x 4 column blocks, operands
+//      staged through LDS (A transposed on the way in so both fragment reads are conflict-free
+//      ds_read_b32), register-prefetched double buffering, XCD-aware tile order so the tiles sharing
+//      an A stripe run on one XCD's L2.
+#include "anihip_common.h"
+
+namespace anihip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const v4f gf4;  // global-memory float4 (forces global_load_dwordx4)
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDS_LD = BM + 4;
+constexpr int GEMM_THREADS = 256;
+
+enum Epilogue { EPI_BIAS_CELU = 0, EPI_DCELU = 1, EPI_SCATTER = 2 };
+
+struct GemmProblem {
+    const float *B;     // [batch][K][ldb]
+    const float *bias;  // [batch][N] (EPI_BIAS_CELU)
+    int K, N, ldb;
+    int a_boff, c_boff;        // column offset of batch b in A / C rows = b * off
+    int64_t b_stride;          // elements between consecutive batches of B
+    int bias_stride;
+};
+
+struct GemmArgs {
+    GemmProblem prob[MAX_S];
+    const int *ctl;        // device control block (see MlpCtl)
+    const float *A;
+    int64_t lda;
+    const int *a_gather;   // sorted position -> source row (layer 0) or NULL
+    float *C;
+    int64_t ldc;
+    const int *c_scatter;  // sorted position -> destination row (last backward GEMM) or NULL
+    int n_store;           // EPI_SCATTER: only columns < n_store are stored
+    int S, batch, ncol_max, nrow_tiles_ub;
+    float alpha, inv_alpha;
+};
+
+// control block layout (ints) in the workspace
+constexpr int CTL_CNT = 0;      // [8]  atoms per species
+constexpr int CTL_CURSOR = 8;   // [8]  scatter cursors
+constexpr int CTL_OFF = 16;     // [9]  first sorted position of each species
+constexpr int CTL_TILE = 32;    // [9]  first row tile of each species
+constexpr int CTL_WORDS = 48;
+
+// ---- species bucketing --------------------------------------------------------------------------
+
+constexpr int SP_CHUNK = 1024;  // atoms per wave in the bucketing kernels
+
+// each wave owns a contiguous chunk: one atomic per species per chunk instead of per 64 atoms
+__global__ void k_sp_count(int64_t lo, int64_t hi, const int32_t *species, int S, int *ctl)
+{
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t c0 = lo + wave * SP_CHUNK;
+    if (c0 >= hi) return;
+    int cnt[MAX_S];
+#pragma unroll
+    for (int t = 0; t < MAX_S; ++t) cnt[t] = 0;
+    for (int it = 0; it < SP_CHUNK / WAVE; ++it) {
+        const int64_t i = c0 + it * WAVE + lane_id();
+        const int sp = (i < hi) ? species[i] : -1;
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t)
+            if (t < S) cnt[t] += __popcll(__ballot(sp == t));
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t)
+            if (t < S && cnt[t]) atomicAdd(&ctl[CTL_CNT + t], cnt[t]);
+    }
+}
+
+__global__ void k_sp_offsets(int S, int *ctl)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int run = 0, trun = 0;
+    for (int t = 0; t < S; ++t) {
+        ctl[CTL_OFF + t] = run;
+        ctl[CTL_TILE + t] = trun;
+        ctl[CTL_CURSOR + t] = run;
+        run += ctl[CTL_CNT + t];
+        trun += (ctl[CTL_CNT + t] + BM - 1) / BM;
+    }
+    ctl[CTL_OFF + S] = run;
+    ctl[CTL_TILE + S] = trun;
+}
+
+__global__ void k_sp_scatter(int64_t lo, int64_t hi, const int32_t *species, int S, int *ctl, int *perm)
+{
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t c0 = lo + wave * SP_CHUNK;
+    if (c0 >= hi) return;
+    int base[MAX_S];
+#pragma unroll
+    for (int t = 0; t < MAX_S; ++t) base[t] = 0;
+    for (int it = 0; it < SP_CHUNK / WAVE; ++it) {
+        const int64_t i = c0 + it * WAVE + lane_id();
+        const int sp = (i < hi) ? species[i] : -1;
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t)
+            if (t < S) base[t] += __popcll(__ballot(sp == t));
+    }
+#pragma unroll
+    for (int t = 0; t < MAX_S; ++t) {
+        int b = 0;
+        if (t < S && base[t] && lane_id() == 0) b = atomicAdd(&ctl[CTL_CURSOR + t], base[t]);
+        base[t] = __shfl(b, 0);
+    }
+    for (int it = 0; it < SP_CHUNK / WAVE; ++it) {
+        const int64_t i = c0 + it * WAVE + lane_id();
+        const int sp = (i < hi) ? species[i] : -1;
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t)
+            if (t < S) {
+                const uint64_t m = __ballot(sp == t);
+                if (sp == t) perm[base[t] + mbcnt(m)] = (int)i;
+                base[t] += __popcll(m);
+            }
+    }
+}
+
+// ---- grouped GEMM -----------------------------------------------------------------------------------
+
+__device__ __forceinline__ float celu(float x, float alpha, float inv_alpha)
+{
+    // nn/_core.py:163-167 : celu(x, 0.1) = max(0,x) + min(0, alpha (exp(x/alpha) - 1))
+    return x > 0.f ? x : alpha * (__expf(x * inv_alpha) - 1.0f);
+}
+
+// K loop of one 128 x (32 NB) tile: register-prefetched global loads, double-buffered LDS, one
+// barrier per K step; NB is compile-time so the MFMA stream has no branches.
+constexpr int LDS_BUF = BK * LDS_LD;  // floats per buffer
+template <int NB>
+__device__ __forceinline__ void gemm_kloop(f32x16 (&acc)[4], const gf4 *a_src, const float *b_src,
+                                           int64_t b_step, int nk, float *a_dst, float *b_dst,
+                                           const float *a_frag, const float *b_frag)
+{
+    v4f ra0, ra1, rb0, rb1;
+    auto gload = [&](int kt) {
+        ra0 = a_src[kt * (BK / 4)];
+        ra1 = a_src[kt * (BK / 4) + 1];
+        const gf4 *bp = (const gf4 *)(b_src + kt * b_step);
+        rb0 = bp[0];
+        rb1 = bp[1];
+    };
+    auto lstore = [&](int buf) {
+        float *ap = a_dst + buf * LDS_BUF;
+        ap[0 * LDS_LD] = ra0.x; ap[1 * LDS_LD] = ra0.y; ap[2 * LDS_LD] = ra0.z; ap[3 * LDS_LD] = ra0.w;
+        ap[4 * LDS_LD] = ra1.x; ap[5 * LDS_LD] = ra1.y; ap[6 * LDS_LD] = ra1.z; ap[7 * LDS_LD] = ra1.w;
+        *reinterpret_cast<v4f *>(b_dst + buf * LDS_BUF) = rb0;
+        *reinterpret_cast<v4f *>(b_dst + buf * LDS_BUF + 4) = rb1;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const float *af = a_frag + buf * LDS_BUF, *bf = b_frag + buf * LDS_BUF;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const float av = af[2 * kk * LDS_LD];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float bv = bf[2 * kk * LDS_LD + nb * 32];
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nb], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs g)
+{
+    __shared__ float As[2][BK][LDS_LD];
+    __shared__ float Bs[2][BK][LDS_LD];
+
+    // XCD-aware bijective remap: consecutive logical tiles (same A stripe) share one XCD / L2
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = id & 7;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
+    }
+    const int col_t = id % g.ncol_max;
+    const int bb = (id / g.ncol_max) % g.batch;
+    const int row_t = id / (g.ncol_max * g.batch);
+
+    const int *ctl = g.ctl;
+    if (row_t >= ctl[CTL_TILE + g.S]) return;
+    int s = 0;
+    while (s + 1 < g.S && row_t >= ctl[CTL_TILE + s + 1]) ++s;
+    const GemmProblem &pr = g.prob[s];
+    const int n0 = col_t * BN;
+    if (n0 >= pr.N) return;
+    const int m0 = (row_t - ctl[CTL_TILE + s]) * BM;          // first row inside the species
+    const int n_rows = ctl[CTL_CNT + s] - m0;                 // valid rows in this tile (may be > BM)
+    const int p0 = ctl[CTL_OFF + s] + m0;                     // sorted position of tile row 0
+    const int nb_act = min(4, (pr.N - n0) >> 5);              // active 32-column blocks
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // A loader: row = tid>>1, 8 consecutive k.  Rows past the species end re-read row 0 of the tile
+    // (always valid memory); their accumulators are simply never stored.
+    const int a_row = tid >> 1, a_k = (tid & 1) * 8;
+    const gf4 *a_src;
+    {
+        const int rr = a_row < n_rows ? a_row : 0;
+        const int64_t src_row = g.a_gather ? (int64_t)g.a_gather[p0 + rr] : (int64_t)(p0 + rr);
+        a_src = (const gf4 *)(g.A + src_row * g.lda + (int64_t)bb * pr.a_boff + a_k);
+    }
+    // B loader: k = tid>>4, 8 consecutive n.  Column chunks past N (inactive blocks) re-read chunk 0.
+    const int b_k = tid >> 4, b_n = (tid & 15) * 8;
+    const int b_col = (n0 + b_n < pr.N) ? n0 + b_n : n0;
+    const float *b_src = pr.B + (int64_t)bb * pr.b_stride + (int64_t)b_k * pr.ldb + b_col;
+    const int64_t b_step = (int64_t)BK * pr.ldb;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    const int nk = pr.K / BK;
+    const int fr = lane & 31, fk = lane >> 5;
+    float *a_dst = &As[0][a_k][a_row];
+    float *b_dst = &Bs[0][b_k][b_n];
+    const float *a_frag = &As[0][fk][wave * 32 + fr];
+    const float *b_frag = &Bs[0][fk][fr];
+    switch (nb_act) {
+        case 4: gemm_kloop<4>(acc, a_src, b_src, b_step, nk, a_dst, b_dst, a_frag, b_frag); break;
+        case 3: gemm_kloop<3>(acc, a_src, b_src, b_step, nk, a_dst, b_dst, a_frag, b_frag); break;
+        case 2: gemm_kloop<2>(acc, a_src, b_src, b_step, nk, a_dst, b_dst, a_frag, b_frag); break;
+        default: gemm_kloop<1>(acc, a_src, b_src, b_step, nk, a_dst, b_dst, a_frag, b_frag); break;
+    }
+
+    // epilogue.  C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb >= nb_act) continue;
+        const int col = n0 + nb * 32 + fr;
+        float bias = 0.f;
+        if (EPI == EPI_BIAS_CELU) bias = pr.bias[(int64_t)bb * pr.bias_stride + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+            if (row >= n_rows) continue;
+            float v = acc[nb][r];
+            if (EPI == EPI_BIAS_CELU) {
+                g.C[(int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col] =
+                    celu(v + bias, g.alpha, g.inv_alpha);
+            } else if (EPI == EPI_DCELU) {
+                // stored activation y = celu(x):  celu'(x) = 1 (y > 0)  or  exp(x/alpha) = y/alpha + 1
+                float *cp = g.C + (int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col;
+                const float y = *cp;
+                *cp = v * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+            } else {
+                if (col < g.n_store)
+                    g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ---- output layer: energies + seed of the backward pass --------------------------------------------
+
+struct HeadArgs {
+    const float *w[MAX_S];     // [M][Hp]
+    const float *bias[MAX_S];  // [M]
+    int Hp[MAX_S];
+    const int *ctl;
+    const int *perm;
+    float *act;   // last hidden activations [n][ld]; overwritten with d(mean energy)/d(activation)
+    int64_t ld;
+    float *atomic_e;   // [n_atoms]
+    float *member_e;   // [M][n_atoms] or NULL
+    int64_t n_atoms;
+    int S, M;
+    float inv_alpha;
+    int want_grad;
+};
+
+__global__ __launch_bounds__(256) void k_head(HeadArgs h)
+{
+    const int lane = lane_id();
+    const int64_t n = h.ctl[CTL_OFF + h.S];
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nw) {
+        int s = 0;
+        while (s + 1 < h.S && p >= h.ctl[CTL_OFF + s + 1]) ++s;
+        const int Hp = h.Hp[s];
+        float *row = h.act + p * h.ld;
+        const int atom = h.perm[p];
+        float esum = 0.f;
+        const float invM = 1.0f / (float)h.M;
+        for (int m = 0; m < h.M; ++m) {
+            const float *w = h.w[s] + (int64_t)m * Hp;
+            float part = 0.f;
+            for (int o = lane; o < Hp; o += WAVE) {
+                const float y = row[m * Hp + o];
+                part += y * w[o];
+                if (h.want_grad) row[m * Hp + o] = invM * w[o] * (y > 0.f ? 1.0f : y * h.inv_alpha + 1.0f);
+            }
+            part = wave_sum(part) + h.bias[s][m];
+            if (h.member_e && lane == 0) h.member_e[(int64_t)m * h.n_atoms + atom] = part;
+            esum += part;
+        }
+        if (lane == 0) h.atomic_e[atom] = esum * invM;
+    }
+}
+
+// padding atoms inside the shard: zero energy / zero gradient rows
+__global__ void k_zero_padding(int64_t lo, int64_t hi, const int32_t *species, float *atomic_e,
+                               float *grad_aev, int L, float *member_e, int M, int64_t n_atoms)
+{
+    const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t i = lo + blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6); i < hi; i += nw) {
+        if (species[i] >= 0) continue;
+        if (lane_id() == 0) {
+            atomic_e[i] = 0.f;
+            if (member_e)
+                for (int m = 0; m < M; ++m) member_e[(int64_t)m * n_atoms + i] = 0.f;
+        }
+        if (grad_aev)
+            for (int f = lane_id(); f < L; f += WAVE) grad_aev[(size_t)i * L + f] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_energy_reduce(int n_mol, int A, int64_t lo, int64_t hi,
+                                                       const int32_t *species, const float *atomic_e,
+                                                       const double *sae, double *mol_e)
+{
+    const int mol = blockIdx.x;
+    double acc = 0.0;
+    for (int a = blockIdx.y * blockDim.x + threadIdx.x; a < A; a += gridDim.y * blockDim.x) {
+        const int64_t i = (int64_t)mol * A + a;
+        if (i < lo || i >= hi) continue;
+        const int sp = species[i];
+        if (sp < 0) continue;
+        acc += (double)atomic_e[i] + (sae ? sae[sp] : 0.0);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double part[4];
+    if (lane_id() == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&mol_e[mol], part[0] + part[1] + part[2] + part[3]);
+}
+
+struct MlpWorkspace {
+    int *ctl;
+    int *perm;
+    float *act[ANIHIP_MAX_LAYERS];
+    int64_t ld[ANIHIP_MAX_LAYERS];
+};
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWorkspace *w)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    int *ctl = (int *)take(sizeof(int) * CTL_WORDS);
+    int *perm = (int *)take(sizeof(int) * (size_t)(n + 1));
+    if (w) { w->ctl = ctl; w->perm = perm; }
+    const int nh = d->net[0].n_layers - 1;  // hidden layers
+    for (int l = 0; l < nh; ++l) {
+        int mx = 0;
+        for (int s = 0; s < d->num_species; ++s) mx = mx > d->net[s].dims[l + 1] ? mx : d->net[s].dims[l + 1];
+        int64_t ld = (int64_t)mx * d->n_members;
+        float *a = (float *)take(sizeof(float) * (size_t)ld * (size_t)(n + 1));
+        if (w) { w->act[l] = a; w->ld[l] = ld; }
+    }
+    return off;
+}
+
+}  // namespace anihip
+
+using namespace anihip;
+
+extern "C" size_t anihip_mlp_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central)
+{
+    if (!d || n_central < 0) return 0;
+    return mlp_carve(d, n_central, nullptr, nullptr);
+}
+
+static int check_desc(const anihip_mlp_desc *d)
+{
+    ANIHIP_REQUIRE(d, "null descriptor");
+    ANIHIP_REQUIRE(d->num_species >= 1 && d->num_species <= MAX_S - 1, "num_species must be 1..7");
+    ANIHIP_REQUIRE(d->n_members >= 1 && d->n_members <= 64, "n_members must be 1..64");
+    ANIHIP_REQUIRE(d->aev_len % BK == 0, "aev_len must be a multiple of %d", BK);
+    const int nl = d->net[0].n_layers;
+    ANIHIP_REQUIRE(nl >= 2 && nl <= ANIHIP_MAX_LAYERS, "n_layers must be 2..%d", ANIHIP_MAX_LAYERS);
+    for (int s = 0; s < d->num_species; ++s) {
+        const anihip_species_net &n = d->net[s];
+        ANIHIP_REQUIRE(n.n_layers == nl, "all species must have the same depth");
+        ANIHIP_REQUIRE(n.dims[0] == d->aev_len && n.dims[nl] == 1, "species %d: bad first/last width", s);
+        for (int l = 1; l < nl; ++l)
+            ANIHIP_REQUIRE(n.dims[l] > 0 && n.dims[l] % 32 == 0, "species %d: hidden width %d not padded to 32",
+                           s, n.dims[l]);
+        for (int l = 0; l < nl; ++l) {
+            ANIHIP_REQUIRE(n.w[l] && n.bias[l], "species %d layer %d: null parameter pointer", s, l);
+            if (l < nl - 1) ANIHIP_REQUIRE(n.wt[l], "species %d layer %d: null transposed weights", s, l);
+        }
+    }
+    return 0;
+}
+
+template <int EPI>
+static void launch_gemm(hipStream_t stream, GemmArgs &g)
+{
+    const int64_t total = (int64_t)g.nrow_tiles_ub * g.ncol_max * g.batch;
+    hipLaunchKernelGGL((k_gemm<EPI>), dim3((unsigned)total), dim3(GEMM_THREADS), 0, stream, g);
+}
+
+extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc *d, int64_t n_atoms,
+                                           int64_t lo, int64_t hi, const int32_t *species, const float *aev,
+                                           void *workspace, size_t workspace_bytes, float *atomic_e,
+                                           float *grad_aev, float *member_e)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_desc(d)) return rc;
+    ANIHIP_REQUIRE(species && aev && workspace && atomic_e, "null pointer argument");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    const int64_t n = hi - lo;
+    if (n == 0) return 0;
+    ANIHIP_REQUIRE(workspace_bytes >= mlp_carve(d, n, nullptr, nullptr), "workspace too small");
+    MlpWorkspace w;
+    mlp_carve(d, n, (char *)workspace, &w);
+    const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1;
+    const int L = d->aev_len;
+    const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
+
+    // 1. bucket by species
+    ANIHIP_CHECK_HIP(hipMemsetAsync(w.ctl, 0, sizeof(int) * CTL_WORDS, stream));
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
+    hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl);
+    hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(64), 0, stream, S, w.ctl);
+    hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, w.perm);
+    hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
+                       atomic_e, grad_aev, L, member_e, M, n_atoms);
+
+    const int nrow_ub = (int)((n + BM - 1) / BM) + S;
+    auto ncol_of = [&](int l_out, bool cat) {
+        int mx = 0;
+        for (int s = 0; s < S; ++s) {
+            int N = d->net[s].dims[l_out] * (cat ? M : 1);
+            mx = mx > N ? mx : N;
+        }
+        return (mx + BN - 1) / BN;
+    };
+
+    // 2. forward through the hidden layers
+    for (int l = 0; l < nh; ++l) {
+        GemmArgs g{};
+        g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha;
+        g.nrow_tiles_ub = nrow_ub;
+        g.C = w.act[l]; g.ldc = w.ld[l]; g.c_scatter = nullptr; g.n_store = 0;
+        if (l == 0) {
+            g.A = aev; g.lda = L; g.a_gather = w.perm; g.batch = 1;
+            g.ncol_max = ncol_of(1, true);
+        } else {
+            g.A = w.act[l - 1]; g.lda = w.ld[l - 1]; g.a_gather = nullptr; g.batch = M;
+            g.ncol_max = ncol_of(l + 1, false);
+        }
+        for (int s = 0; s < S; ++s) {
+            const anihip_species_net &nn = d->net[s];
+            GemmProblem &p = g.prob[s];
+            p.B = nn.w[l]; p.bias = nn.bias[l];
+            if (l == 0) {
+                p.K = nn.dims[0]; p.N = nn.dims[1] * M; p.ldb = p.N;
+                p.a_boff = 0; p.c_boff = 0; p.b_stride = 0; p.bias_stride = 0;
+            } else {
+                p.K = nn.dims[l]; p.N = nn.dims[l + 1]; p.ldb = p.N;
+                p.a_boff = nn.dims[l]; p.c_boff = nn.dims[l + 1];
+                p.b_stride = (int64_t)p.K * p.N; p.bias_stride = p.N;
+            }
+        }
+        launch_gemm<EPI_BIAS_CELU>(stream, g);
+    }
+
+    // 3. output layer (+ seed of the backward pass, written in place over the last activations)
+    {
+        HeadArgs h{};
+        for (int s = 0; s < S; ++s) {
+            h.w[s] = d->net[s].w[nl - 1];
+            h.bias[s] = d->net[s].bias[nl - 1];
+            h.Hp[s] = d->net[s].dims[nl - 1];
+        }
+        h.ctl = w.ctl; h.perm = w.perm; h.act = w.act[nh - 1]; h.ld = w.ld[nh - 1];
+        h.atomic_e = atomic_e; h.member_e = member_e; h.n_atoms = n_atoms; h.S = S; h.M = M;
+        h.inv_alpha = inv_alpha; h.want_grad = grad_aev ? 1 : 0;
+        int64_t blocks = (n + 3) / 4;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(k_head, dim3((unsigned)blocks), dim3(256), 0, stream, h);
+    }
+
+    // 4. backward to the AEV rows
+    if (grad_aev) {
+        for (int l = nh - 1; l >= 0; --l) {
+            GemmArgs g{};
+            g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha;
+            g.nrow_tiles_ub = nrow_ub;
+            g.A = w.act[l]; g.lda = w.ld[l]; g.a_gather = nullptr;
+            if (l == 0) {
+                g.batch = 1; g.C = grad_aev; g.ldc = L; g.c_scatter = w.perm; g.n_store = L;
+                g.ncol_max = (((L + 31) / 32) * 32 + BN - 1) / BN;
+            } else {
+                g.batch = M; g.C = w.act[l - 1]; g.ldc = w.ld[l - 1]; g.c_scatter = nullptr;
+                g.ncol_max = ncol_of(l, false);
+            }
+            for (int s = 0; s < S; ++s) {
+                const anihip_species_net &nn = d->net[s];
+                GemmProblem &p = g.prob[s];
+                p.B = nn.wt[l]; p.bias = nullptr; p.bias_stride = 0;
+                if (l == 0) {
+                    p.K = nn.dims[1] * M; p.N = ((L + 31) / 32) * 32; p.ldb = p.N;
+                    p.a_boff = 0; p.c_boff = 0; p.b_stride = 0;
+                } else {
+                    p.K = nn.dims[l + 1]; p.N = nn.dims[l]; p.ldb = p.N;
+                    p.a_boff = nn.dims[l + 1]; p.c_boff = nn.dims[l];
+                    p.b_stride = (int64_t)p.K * p.N;
+                }
+            }
+            if (l == 0) launch_gemm<EPI_SCATTER>(stream, g);
+            else launch_gemm<EPI_DCELU>(stream, g);
+        }
+    }
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int anihip_energy_reduce(void *stream_, int32_t n_mol, int32_t A, int64_t lo, int64_t hi,
+                                    const int32_t *species, const float *atomic_e, const double *sae,
+                                    double *mol_e)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    ANIHIP_REQUIRE(species && atomic_e && mol_e, "null pointer argument");
+    ANIHIP_REQUIRE(n_mol >= 1 && A >= 1, "bad shape");
+    ANIHIP_CHECK_HIP(hipMemsetAsync(mol_e, 0, sizeof(double) * (size_t)n_mol, stream));
+    int ny = (A + 256 * 16 - 1) / (256 * 16);
+    if (ny < 1) ny = 1;
+    if (ny > 1024) ny = 1024;
+    hipLaunchKernelGGL(k_energy_reduce, dim3((unsigned)n_mol, (unsigned)ny), dim3(256), 0, stream, (int)n_mol,
+                       (int)A, lo, hi, species, atomic_e, sae, mol_e);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}

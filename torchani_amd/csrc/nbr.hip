@@ -1,0 +1,618 @@
+// Neighbor-list builders of libanihip (gfx950, wave64).
+//
+// One wave owns one central atom: lanes sweep the candidate atoms (the atom's own molecule, or the
+// 27+ grid bins around it), hits are compacted with ballot + mbcnt prefix ranks into a per-wave LDS
+// list (no LDS/global atomics), classified into {r <= Rca, r > Rca} x species with ballots and written
+// as one species-sorted fixed-capacity row.  Single pass, no host sync, deterministic.
+//
+// What this replaces in the reference (paths relative to /root/reference/torchani/):
+//   neighbors.py:187-275 all_pairs (+PBC images), :366-507 cell_list, :64-113 narrow_down,
+//   csrc/aev.cu:180-321 pairwiseDistance*, :975-1039 postProcessNbrList1, csrc/cell_list.cpp.
+#include "anihip_common.h"
+
+namespace anihip {
+
+// Device-resident description of the periodic cell / bin grid (written by k_setup, read by the rest).
+struct GridDesc {
+    double cell[9];   // rows = lattice vectors (identity without a cell)
+    double inv[9];    // inverse: frac = r @ inv
+    double f0[3];     // non-periodic axes: lower fractional bound of the atoms
+    double sc[3];     // (frac - f0) * sc = continuous bin coordinate
+    float step[9];    // step[k] = cell_k / sc_k : displacement of one bin along axis k
+    int nb[3];        // bins per axis
+    int range[3];     // stencil half-width per axis
+    int rep[3];       // batch mode: periodic image repeats per axis (neighbors.py:250-275)
+    int pbc[3];
+    int ncell;
+    unsigned lo_enc[3], hi_enc[3];  // order-preserving encodings of the fractional bounding box
+};
+
+struct NbrWorkspace {
+    GridDesc *desc;
+    float4 *pos4;      // [N] batch: wrapped xyz + packed (i | species << 28); cell: bin-local offsets
+    int *cellid;       // [N]
+    int *sorted_idx;   // [N]
+    float4 *pos4s;     // [N] pos4 in bin-sorted order
+    int *cell_start;   // [max_cells + 1]
+    int *cell_fill;    // [max_cells]
+    int *scan_tmp;     // [max_cells / 1024 + 2]
+};
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t carve(NbrWorkspace *w, char *base, int64_t n, int64_t max_cells)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    GridDesc *desc = (GridDesc *)take(sizeof(GridDesc));
+    float4 *pos4 = (float4 *)take(sizeof(float4) * (size_t)n);
+    int *cellid = (int *)take(sizeof(int) * (size_t)n);
+    int *sorted_idx = (int *)take(sizeof(int) * (size_t)n);
+    float4 *pos4s = (float4 *)take(sizeof(float4) * (size_t)n);
+    int *cell_start = (int *)take(sizeof(int) * (size_t)(max_cells + 1));
+    int *cell_fill = (int *)take(sizeof(int) * (size_t)(max_cells + 1));
+    int *scan_tmp = (int *)take(sizeof(int) * (size_t)(max_cells / 1024 + 4));
+    if (w) *w = NbrWorkspace{desc, pos4, cellid, sorted_idx, pos4s, cell_start, cell_fill, scan_tmp};
+    return off;
+}
+
+__device__ __forceinline__ unsigned enc_f(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f(unsigned e)
+{
+    unsigned u = (e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e;
+    return __uint_as_float(u);
+}
+
+__device__ void inv3(const double *m, double *o)
+{
+    double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    double id = 1.0 / det;
+    o[0] = (e * i - f * h) * id; o[1] = (c * h - b * i) * id; o[2] = (b * f - c * e) * id;
+    o[3] = (f * g - d * i) * id; o[4] = (a * i - c * g) * id; o[5] = (c * d - a * f) * id;
+    o[6] = (d * h - e * g) * id; o[7] = (b * g - a * h) * id; o[8] = (a * e - b * d) * id;
+}
+
+// ---- setup -------------------------------------------------------------------------------------
+
+__global__ void k_desc_init(GridDesc *g, const float *cell, int pbc_mask, float cutoff)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int q = 0; q < 9; ++q) g->cell[q] = cell ? (double)cell[q] : ((q % 4 == 0) ? 1.0 : 0.0);
+    inv3(g->cell, g->inv);
+    for (int k = 0; k < 3; ++k) {
+        g->pbc[k] = (cell && ((pbc_mask >> k) & 1)) ? 1 : 0;
+        double nrm = sqrt(g->inv[0 + k] * g->inv[0 + k] + g->inv[3 + k] * g->inv[3 + k] +
+                          g->inv[6 + k] * g->inv[6 + k]);
+        g->rep[k] = g->pbc[k] ? (int)ceil((double)cutoff * nrm) : 0;  // neighbors.py:253-256
+        g->lo_enc[k] = 0xFFFFFFFFu;
+        g->hi_enc[k] = 0u;
+        g->f0[k] = 0.0;
+        g->sc[k] = 1.0;
+        g->nb[k] = 1;
+        g->range[k] = 0;
+    }
+    g->ncell = 1;
+}
+
+// fractional bounding box of the real atoms (needed along non-periodic axes only)
+__global__ void k_bbox(GridDesc *g, int64_t n, const int32_t *species, const float *coords)
+{
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (species[i] < 0) continue;
+        double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+        for (int k = 0; k < 3; ++k) {
+            float f = (float)(x * g->inv[0 + k] + y * g->inv[3 + k] + z * g->inv[6 + k]);
+            lo[k] = fminf(lo[k], f);
+            hi[k] = fmaxf(hi[k], f);
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], o));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o));
+        }
+        if (lane_id() == 0) {
+            atomicMin(&g->lo_enc[k], enc_f(lo[k]));
+            atomicMax(&g->hi_enc[k], enc_f(hi[k]));
+        }
+    }
+}
+
+__global__ void k_grid_setup(GridDesc *g, float cutoff, int64_t max_cells, uint32_t *status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double h[3], span[3];
+    for (int k = 0; k < 3; ++k) {
+        double nrm = sqrt(g->inv[0 + k] * g->inv[0 + k] + g->inv[3 + k] * g->inv[3 + k] +
+                          g->inv[6 + k] * g->inv[6 + k]);
+        h[k] = 1.0 / nrm;  // distance between the faces perpendicular to axis k
+        if (g->pbc[k]) {
+            span[k] = 1.0;
+            g->f0[k] = 0.0;
+        } else {
+            // widen by one float ulp-ish margin so every atom falls strictly inside
+            double lo = (double)dec_f(g->lo_enc[k]), hi = (double)dec_f(g->hi_enc[k]);
+            if (!(hi >= lo)) { lo = 0.0; hi = 0.0; }  // no real atoms
+            double pad = 1e-4 * nrm + 1e-6 * (fabs(lo) + fabs(hi));
+            lo -= pad; hi += pad;
+            span[k] = hi - lo;
+            g->f0[k] = lo;
+        }
+        int nb = (int)floor(span[k] * h[k] / (double)cutoff);
+        g->nb[k] = nb < 1 ? 1 : nb;
+    }
+    // coarsen until the grid fits the workspace (bins only get wider => still correct)
+    bool coarsened = false;
+    while ((int64_t)g->nb[0] * g->nb[1] * g->nb[2] > max_cells) {
+        int k = 0;
+        if (g->nb[1] > g->nb[k]) k = 1;
+        if (g->nb[2] > g->nb[k]) k = 2;
+        g->nb[k] = (g->nb[k] + 1) / 2;
+        coarsened = true;
+    }
+    if (coarsened) atomicOr(&status[0], ANIHIP_ST_GRID_OVERFLOW);
+    for (int k = 0; k < 3; ++k) {
+        g->sc[k] = (double)g->nb[k] / span[k];
+        double width = span[k] * h[k] / g->nb[k];
+        g->range[k] = g->pbc[k] ? (int)ceil((double)cutoff / width) : 1;
+        for (int q = 0; q < 3; ++q) g->step[3 * k + q] = (float)(g->cell[3 * k + q] / g->sc[k]);
+    }
+    g->ncell = g->nb[0] * g->nb[1] * g->nb[2];
+    status[2] = (uint32_t)g->ncell;
+}
+
+// ---- batch mode: packed (wrapped) positions -------------------------------------------------------
+
+__global__ void k_prep_batch(const GridDesc *g, int64_t n, const int32_t *species, const float *coords,
+                             float4 *pos4)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+    if (g->pbc[0] | g->pbc[1] | g->pbc[2]) {
+        // utils.py:237-255 map_to_central, in double
+        double f[3];
+        for (int k = 0; k < 3; ++k) {
+            f[k] = (double)x * g->inv[0 + k] + (double)y * g->inv[3 + k] + (double)z * g->inv[6 + k];
+            if (g->pbc[k]) f[k] -= floor(f[k]);
+        }
+        x = (float)(f[0] * g->cell[0] + f[1] * g->cell[3] + f[2] * g->cell[6]);
+        y = (float)(f[0] * g->cell[1] + f[1] * g->cell[4] + f[2] * g->cell[7]);
+        z = (float)(f[0] * g->cell[2] + f[1] * g->cell[5] + f[2] * g->cell[8]);
+    }
+    int sp = species[i];
+    uint32_t w = ((uint32_t)i & IDX_MASK) | ((sp < 0 ? SP_PAD : (uint32_t)sp) << 28);
+    pos4[i] = make_float4(x, y, z, __uint_as_float(w));
+}
+
+// ---- cell mode: binning ----------------------------------------------------------------------------
+
+__global__ void k_bin_count(const GridDesc *g, int64_t n, const int32_t *species, const float *coords,
+                            float4 *pos4, int *cellid, int *cell_cnt)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int sp = species[i];
+    if (sp < 0) {
+        cellid[i] = -1;
+        return;
+    }
+    double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+    int b[3];
+    double loc[3];
+    for (int k = 0; k < 3; ++k) {
+        double f = x * g->inv[0 + k] + y * g->inv[3 + k] + z * g->inv[6 + k];
+        if (g->pbc[k]) f -= floor(f);
+        double q = (f - g->f0[k]) * g->sc[k];
+        int bk = (int)floor(q);
+        bk = bk < 0 ? 0 : (bk >= g->nb[k] ? g->nb[k] - 1 : bk);
+        b[k] = bk;
+        loc[k] = (q - bk) / g->sc[k];  // fractional offset from the bin corner
+    }
+    // bin-local cartesian offset: small magnitude => fp32 keeps ~1e-7 A resolution in any box size
+    float ox = (float)(loc[0] * g->cell[0] + loc[1] * g->cell[3] + loc[2] * g->cell[6]);
+    float oy = (float)(loc[0] * g->cell[1] + loc[1] * g->cell[4] + loc[2] * g->cell[7]);
+    float oz = (float)(loc[0] * g->cell[2] + loc[1] * g->cell[5] + loc[2] * g->cell[8]);
+    uint32_t w = ((uint32_t)i & IDX_MASK) | ((uint32_t)sp << 28);
+    pos4[i] = make_float4(ox, oy, oz, __uint_as_float(w));
+    int c = (b[0] * g->nb[1] + b[1]) * g->nb[2] + b[2];
+    cellid[i] = c;
+    atomicAdd(&cell_cnt[c], 1);
+}
+
+// exclusive scan of `in[0..n)` (n read from device) into out[0..n], three small kernels
+__global__ void k_scan_local(const GridDesc *g, const int *in, int *out, int *block_sums)
+{
+    __shared__ int s[1024];
+    const int n = g->ncell;
+    int i = blockIdx.x * 1024 + threadIdx.x;
+    if (blockIdx.x * 1024 >= n + 1) return;
+    int v = (i < n) ? in[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int t = (threadIdx.x >= o) ? s[threadIdx.x - o] : 0;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (i <= n) out[i] = s[threadIdx.x] - v;  // exclusive
+    if (threadIdx.x == 1023) block_sums[blockIdx.x] = s[1023];
+}
+
+__global__ void k_scan_top(const GridDesc *g, int *block_sums)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int nblk = (g->ncell + 1 + 1023) / 1024;
+    int run = 0;
+    for (int b = 0; b < nblk; ++b) {
+        int t = block_sums[b];
+        block_sums[b] = run;
+        run += t;
+    }
+}
+
+__global__ void k_scan_add(const GridDesc *g, int *out, const int *block_sums)
+{
+    int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i <= g->ncell) out[i] += block_sums[blockIdx.x];
+}
+
+__global__ void k_bin_fill(int64_t n, const int *cellid, const int *cell_start, int *cell_fill,
+                           int *sorted_idx)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = cellid[i];
+    if (c < 0) return;
+    int slot = atomicAdd(&cell_fill[c], 1);
+    sorted_idx[cell_start[c] + slot] = (int)i;
+}
+
+// make the order inside every bin deterministic (ascending atom index) and gather the positions
+__global__ void k_bin_sort_gather(const GridDesc *g, const int *cell_start, int *sorted_idx,
+                                  const float4 *pos4, float4 *pos4s)
+{
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= g->ncell) return;
+    int b = cell_start[c], e = cell_start[c + 1];
+    for (int p = b + 1; p < e; ++p) {
+        int v = sorted_idx[p], q = p - 1;
+        while (q >= b && sorted_idx[q] > v) {
+            sorted_idx[q + 1] = sorted_idx[q];
+            --q;
+        }
+        sorted_idx[q + 1] = v;
+    }
+    for (int p = b; p < e; ++p) pos4s[p] = pos4[sorted_idx[p]];
+}
+
+// ---- the per-atom search -----------------------------------------------------------------------------
+
+constexpr int NBR_WPB = 4;  // waves per block
+
+struct HitList {
+    float4 *buf;  // per-wave LDS, MAXR entries
+    int n;        // wave-uniform
+    bool overflow;
+};
+
+// Append the lanes with `hit` set (ballot-compacted, keeps candidate order => deterministic rows).
+__device__ __forceinline__ void push_hits(HitList &h, bool hit, float dx, float dy, float dz, float w)
+{
+    uint64_t m = __ballot(hit);
+    if (m == 0) return;
+    int pos = h.n + mbcnt(m);
+    if (hit && pos < MAXR) h.buf[pos] = make_float4(dx, dy, dz, w);
+    h.n += __popcll(m);
+    if (h.n > MAXR) {
+        h.overflow = true;
+        h.n = MAXR;
+    }
+}
+
+// Classify the compacted hits into {r<=Rca, r>Rca} x species, write the row + metadata.
+__device__ void emit_row(HitList &h, int S, float rca2, int row_cap, uint32_t *meta_i, float4 *row,
+                         uint32_t *status)
+{
+    wave_sync();
+    const int lane = lane_id();
+    int cnt[2][MAX_S];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) cnt[g][t] = 0;
+    const int n = h.n;
+    for (int b0 = 0; b0 < n; b0 += WAVE) {
+        int e = b0 + lane;
+        bool v = e < n;
+        float4 q = h.buf[v ? e : 0];
+        int grp = (q.x * q.x + q.y * q.y + q.z * q.z <= rca2) ? 0 : 1;
+        int sp = (int)(__float_as_uint(q.w) >> 28);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < MAX_S; ++t)
+                if (t < S) cnt[g][t] += __popcll(__ballot(v && grp == g && sp == t));
+    }
+    int nA = 0, nF = 0, mx = 0;
+#pragma unroll
+    for (int t = 0; t < MAX_S; ++t) {
+        nA += cnt[0][t];
+        nF += cnt[1][t];
+        mx = max(mx, max(cnt[0][t], cnt[1][t]));
+    }
+    bool bad = h.overflow || (nA + nF > row_cap) || nA > MAXA || mx > 255;
+    if (bad) {
+        if (lane == 0) {
+            atomicOr(&status[0], ANIHIP_ST_ROW_OVERFLOW);
+            meta_i[1] = 0; meta_i[2] = 0; meta_i[3] = 0; meta_i[4] = 0; meta_i[5] = 0;
+        }
+        return;
+    }
+    int base[2][MAX_S];
+    int run = 0;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) {
+            base[g][t] = run;
+            run += cnt[g][t];
+        }
+    for (int b0 = 0; b0 < n; b0 += WAVE) {
+        int e = b0 + lane;
+        bool v = e < n;
+        float4 q = h.buf[v ? e : 0];
+        int grp = (q.x * q.x + q.y * q.y + q.z * q.z <= rca2) ? 0 : 1;
+        int sp = (int)(__float_as_uint(q.w) >> 28);
+        int pos = -1;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < MAX_S; ++t)
+                if (t < S) {
+                    bool mine = v && grp == g && sp == t;
+                    uint64_t m = __ballot(mine);
+                    if (mine) pos = base[g][t] + mbcnt(m);
+                    base[g][t] += __popcll(m);
+                }
+        if (pos >= 0) row[pos] = q;
+    }
+    if (lane == 0) {
+        uint32_t pk[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) {
+            pk[t >> 2] |= (uint32_t)cnt[0][t] << (8 * (t & 3));
+            pk[2 + (t >> 2)] |= (uint32_t)cnt[1][t] << (8 * (t & 3));
+        }
+        meta_i[1] = (uint32_t)nA | ((uint32_t)nF << 16);
+        meta_i[2] = pk[0]; meta_i[3] = pk[1]; meta_i[4] = pk[2]; meta_i[5] = pk[3];
+    }
+}
+
+__global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_batch(
+    const GridDesc *g, int S, float rcr2, float rca2, int A, int64_t lo, int64_t hi,
+    const float4 *pos4, int row_cap, uint32_t *meta, float4 *ent, uint32_t *status)
+{
+    __shared__ float4 s_hits[NBR_WPB][MAXR];
+    const int wib = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nw = (int64_t)gridDim.x * NBR_WPB;
+    const int r0 = g->rep[0], r1 = g->rep[1], r2 = g->rep[2];
+    for (int64_t i = lo + blockIdx.x * (int64_t)NBR_WPB + wib; i < hi; i += nw) {
+        uint32_t *meta_i = meta + (size_t)i * META_W;
+        const size_t row0 = (size_t)(i - lo) * row_cap;
+        if (lane == 0) meta_i[0] = (uint32_t)row0;
+        const float4 pi = pos4[i];
+        if ((__float_as_uint(pi.w) >> 28) == SP_PAD) {
+            if (lane == 0) { meta_i[1] = 0; meta_i[2] = 0; meta_i[3] = 0; meta_i[4] = 0; meta_i[5] = 0; }
+            continue;
+        }
+        HitList h{s_hits[wib], 0, false};
+        const int64_t mol0 = (i / A) * A;
+        for (int n0 = -r0; n0 <= r0; ++n0)
+            for (int n1 = -r1; n1 <= r1; ++n1)
+                for (int n2 = -r2; n2 <= r2; ++n2) {
+                    const float sx = (float)(n0 * g->cell[0] + n1 * g->cell[3] + n2 * g->cell[6]);
+                    const float sy = (float)(n0 * g->cell[1] + n1 * g->cell[4] + n2 * g->cell[7]);
+                    const float sz = (float)(n0 * g->cell[2] + n1 * g->cell[5] + n2 * g->cell[8]);
+                    const bool central_img = (n0 == 0 && n1 == 0 && n2 == 0);
+                    for (int a0 = 0; a0 < A; a0 += WAVE) {
+                        int a = a0 + lane;
+                        bool v = a < A;
+                        float4 c = pos4[mol0 + (v ? a : 0)];
+                        float dx = (c.x + sx) - pi.x, dy = (c.y + sy) - pi.y, dz = (c.z + sz) - pi.z;
+                        float d2 = dx * dx + dy * dy + dz * dz;
+                        bool hit = v && ((__float_as_uint(c.w) >> 28) != SP_PAD) && d2 <= rcr2 &&
+                                   !(central_img && (mol0 + a) == i);
+                        push_hits(h, hit, dx, dy, dz, c.w);
+                    }
+                }
+        emit_row(h, S, rca2, row_cap, meta_i, ent + row0, status);
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_cell(
+    const GridDesc *g, int S, float rcr2, float rca2, int64_t lo, int64_t hi, const float4 *pos4,
+    const int *cellid, const int *cell_start, const float4 *pos4s, int row_cap, uint32_t *meta,
+    float4 *ent, uint32_t *status)
+{
+    __shared__ float4 s_hits[NBR_WPB][MAXR];
+    const int wib = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nw = (int64_t)gridDim.x * NBR_WPB;
+    const int nb0 = g->nb[0], nb1 = g->nb[1], nb2 = g->nb[2];
+    const int R0 = g->range[0], R1 = g->range[1], R2 = g->range[2];
+    const int p0 = g->pbc[0], p1 = g->pbc[1], p2 = g->pbc[2];
+    float st[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) st[q] = g->step[q];
+    for (int64_t i = lo + blockIdx.x * (int64_t)NBR_WPB + wib; i < hi; i += nw) {
+        uint32_t *meta_i = meta + (size_t)i * META_W;
+        const size_t row0 = (size_t)(i - lo) * row_cap;
+        if (lane == 0) meta_i[0] = (uint32_t)row0;
+        const int c = cellid[i];
+        if (c < 0) {
+            if (lane == 0) { meta_i[1] = 0; meta_i[2] = 0; meta_i[3] = 0; meta_i[4] = 0; meta_i[5] = 0; }
+            continue;
+        }
+        const float4 pi = pos4[i];
+        const int b2 = c % nb2, b1 = (c / nb2) % nb1, b0 = c / (nb2 * nb1);
+        HitList h{s_hits[wib], 0, false};
+        for (int o0 = -R0; o0 <= R0; ++o0) {
+            int c0 = b0 + o0;
+            if (p0) c0 = ((c0 % nb0) + nb0) % nb0;
+            else if (c0 < 0 || c0 >= nb0) continue;
+            for (int o1 = -R1; o1 <= R1; ++o1) {
+                int c1 = b1 + o1;
+                if (p1) c1 = ((c1 % nb1) + nb1) % nb1;
+                else if (c1 < 0 || c1 >= nb1) continue;
+                const int rowc = (c0 * nb1 + c1) * nb2;
+                const float bx = o0 * st[0] + o1 * st[3] - pi.x;
+                const float by = o0 * st[1] + o1 * st[4] - pi.y;
+                const float bz = o0 * st[2] + o1 * st[5] - pi.z;
+                // bins along the fastest axis are contiguous in the sorted array: sweep the whole
+                // [b2-R2, b2+R2] run at once when it does not wrap, bin by bin otherwise
+                const bool merged = (b2 - R2 >= 0) && (b2 + R2 < nb2);
+                const int nseg = merged ? 1 : (2 * R2 + 1);
+                for (int sgm = 0; sgm < nseg; ++sgm) {
+                    int o2lo, kbeg, kend;
+                    if (merged) {
+                        o2lo = -R2;
+                        kbeg = cell_start[rowc + b2 - R2];
+                        kend = cell_start[rowc + b2 + R2 + 1];
+                    } else {
+                        o2lo = sgm - R2;
+                        int c2 = b2 + o2lo;
+                        if (p2) c2 = ((c2 % nb2) + nb2) % nb2;
+                        else if (c2 < 0 || c2 >= nb2) continue;
+                        kbeg = cell_start[rowc + c2];
+                        kend = cell_start[rowc + c2 + 1];
+                    }
+                    for (int k0 = kbeg; k0 < kend; k0 += WAVE) {
+                        int k = k0 + lane;
+                        bool v = k < kend;
+                        float4 cnd = pos4s[v ? k : kbeg];
+                        int o2 = o2lo;
+                        if (merged) {
+                            // which bin of the run does sorted position k belong to
+                            for (int q = 1; q <= 2 * R2; ++q) o2 += (k >= cell_start[rowc + b2 - R2 + q]);
+                        }
+                        float dx = cnd.x + bx + o2 * st[6];
+                        float dy = cnd.y + by + o2 * st[7];
+                        float dz = cnd.z + bz + o2 * st[8];
+                        float d2 = dx * dx + dy * dy + dz * dz;
+                        bool self = (o0 == 0 && o1 == 0 && o2 == 0) &&
+                                    ((__float_as_uint(cnd.w) & IDX_MASK) == ((uint32_t)i & IDX_MASK));
+                        bool hit = v && d2 <= rcr2 && !self;
+                        push_hits(h, hit, dx, dy, dz, cnd.w);
+                    }
+                }
+            }
+        }
+        emit_row(h, S, rca2, row_cap, meta_i, ent + row0, status);
+        wave_sync();
+    }
+}
+
+}  // namespace anihip
+
+using namespace anihip;
+
+extern "C" size_t anihip_nbr_workspace_bytes(int64_t n_atoms, int64_t max_cells)
+{
+    return carve(nullptr, nullptr, n_atoms, max_cells < 1 ? 1 : max_cells);
+}
+
+static int nbr_grid_blocks(int64_t n_central)
+{
+    int64_t b = (n_central + NBR_WPB - 1) / NBR_WPB;
+    if (b < 1) b = 1;
+    if (b > 256 * 16) b = 256 * 16;  // persistent: each wave strides over central atoms
+    return (int)b;
+}
+
+extern "C" int anihip_nbr_build_batch(void *stream_, const anihip_aev_params *p, int32_t n_mol,
+                                      int32_t A, const int32_t *species, const float *coords,
+                                      const float *cell, int32_t pbc_mask, int64_t lo, int64_t hi,
+                                      void *workspace, size_t workspace_bytes, uint32_t *meta, float *ent,
+                                      int64_t ent_capacity, uint32_t *status)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t n = (int64_t)n_mol * A;
+    ANIHIP_REQUIRE(p && species && coords && workspace && meta && ent && status, "null pointer argument");
+    ANIHIP_REQUIRE(p->num_species >= 1 && p->num_species <= MAX_S - 1, "num_species must be 1..7");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n, "central range [%lld,%lld) outside 0..%lld",
+                   (long long)lo, (long long)hi, (long long)n);
+    ANIHIP_REQUIRE(n < (int64_t)IDX_MASK, "too many atoms for 28-bit neighbor indices");
+    ANIHIP_REQUIRE(workspace_bytes >= anihip_nbr_workspace_bytes(n, 1), "workspace too small");
+    if (hi == lo) return 0;
+    const int64_t row_cap = ent_capacity / (hi - lo);
+    ANIHIP_REQUIRE(row_cap >= 1 && (hi - lo) * row_cap < ((int64_t)1 << 32), "bad ent_capacity");
+    NbrWorkspace w;
+    carve(&w, (char *)workspace, n, 1);
+    hipLaunchKernelGGL(k_desc_init, dim3(1), dim3(64), 0, stream, w.desc, cell, pbc_mask, p->Rcr);
+    hipLaunchKernelGGL(k_prep_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w.desc, n,
+                       species, coords, w.pos4);
+    hipLaunchKernelGGL(k_nbr_batch, dim3(nbr_grid_blocks(hi - lo)), dim3(NBR_WPB * WAVE), 0, stream,
+                       w.desc, p->num_species, p->Rcr * p->Rcr, p->Rca * p->Rca, (int)A, lo, hi, w.pos4,
+                       (int)(row_cap > MAXR ? MAXR : row_cap), meta, (float4 *)ent, status);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int anihip_nbr_build_cell(void *stream_, const anihip_aev_params *p, int64_t n,
+                                     const int32_t *species, const float *coords, const float *cell,
+                                     int32_t pbc_mask, int64_t lo, int64_t hi, int64_t max_cells,
+                                     void *workspace, size_t workspace_bytes, uint32_t *meta, float *ent,
+                                     int64_t ent_capacity, uint32_t *status)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    ANIHIP_REQUIRE(p && species && coords && workspace && meta && ent && status, "null pointer argument");
+    ANIHIP_REQUIRE(p->num_species >= 1 && p->num_species <= MAX_S - 1, "num_species must be 1..7");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n, "central range outside 0..n");
+    ANIHIP_REQUIRE(n < (int64_t)IDX_MASK, "too many atoms for 28-bit neighbor indices");
+    ANIHIP_REQUIRE(max_cells >= 1 && max_cells < ((int64_t)1 << 30), "bad max_cells");
+    ANIHIP_REQUIRE(workspace_bytes >= anihip_nbr_workspace_bytes(n, max_cells), "workspace too small");
+    if (hi == lo) return 0;
+    const int64_t row_cap = ent_capacity / (hi - lo);
+    ANIHIP_REQUIRE(row_cap >= 1 && (hi - lo) * row_cap < ((int64_t)1 << 32), "bad ent_capacity");
+    NbrWorkspace w;
+    carve(&w, (char *)workspace, n, max_cells);
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    const unsigned cblk = (unsigned)((max_cells + 1 + 1023) / 1024);
+    hipLaunchKernelGGL(k_desc_init, dim3(1), dim3(64), 0, stream, w.desc, cell, pbc_mask, p->Rcr);
+    const bool all_pbc = cell && ((pbc_mask & 7) == 7);
+    if (!all_pbc)
+        hipLaunchKernelGGL(k_bbox, dim3(nblk > 1024 ? 1024 : nblk), dim3(256), 0, stream, w.desc, n,
+                           species, coords);
+    hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(64), 0, stream, w.desc, p->Rcr, max_cells, status);
+    ANIHIP_CHECK_HIP(hipMemsetAsync(w.cell_fill, 0, sizeof(int) * (size_t)(max_cells + 1), stream));
+    hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(256), 0, stream, w.desc, n, species, coords, w.pos4,
+                       w.cellid, w.cell_fill);
+    hipLaunchKernelGGL(k_scan_local, dim3(cblk), dim3(1024), 0, stream, w.desc, w.cell_fill, w.cell_start,
+                       w.scan_tmp);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, stream, w.desc, w.scan_tmp);
+    hipLaunchKernelGGL(k_scan_add, dim3(cblk), dim3(1024), 0, stream, w.desc, w.cell_start, w.scan_tmp);
+    ANIHIP_CHECK_HIP(hipMemsetAsync(w.cell_fill, 0, sizeof(int) * (size_t)(max_cells + 1), stream));
+    hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, stream, n, w.cellid, w.cell_start, w.cell_fill,
+                       w.sorted_idx);
+    hipLaunchKernelGGL(k_bin_sort_gather, dim3((unsigned)((max_cells + 255) / 256)), dim3(256), 0, stream,
+                       w.desc, w.cell_start, w.sorted_idx, w.pos4, w.pos4s);
+    hipLaunchKernelGGL(k_nbr_cell, dim3(nbr_grid_blocks(hi - lo)), dim3(NBR_WPB * WAVE), 0, stream, w.desc,
+                       p->num_species, p->Rcr * p->Rcr, p->Rca * p->Rca, lo, hi, w.pos4, w.cellid,
+                       w.cell_start, w.pos4s, (int)(row_cap > MAXR ? MAXR : row_cap), meta, (float4 *)ent,
+                       status);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}

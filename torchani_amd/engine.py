@@ -1,0 +1,282 @@
+"""Tensor-level front-end of the C ABI: torch tensors in, torch tensors out, current HIP stream.
+
+PyTorch is used here only as plumbing (device memory, streams); all arithmetic of the hot path happens
+inside libanihip.so.  Every function requires CUDA(ROCm) tensors and raises otherwise -- there is no
+eager/CPU fallback on purpose.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import typing as tp
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _lib
+from .constants import AEVConstants
+
+
+def _ptr(t: tp.Optional[Tensor]) -> tp.Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(*ts: tp.Optional[Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            # same error class as the reference for non-CUDA input to the native path
+            # (aev/_computer.py:444-447)
+            raise ValueError("torchani_amd's HIP engine needs tensors on a ROCm device (no CPU fallback)")
+
+
+class NeighborRows(tp.NamedTuple):
+    """Fixed-capacity, species-sorted full neighbor rows (format: include/anihip.h)."""
+
+    meta: Tensor      # [N, 6] int32 (uint32 words)
+    ent: Tensor       # [(hi-lo) * row_cap, 4] float32
+    status: Tensor    # [8] int32
+    row_cap: int
+    lo: int
+    hi: int
+
+    def raise_on_overflow(self) -> None:
+        """Synchronising check of the device-side status words."""
+        st = int(self.status[0].item())
+        if st & (_lib.ST_ROW_OVERFLOW | _lib.ST_ENTRY_OVERFLOW):
+            raise RuntimeError(
+                f"neighbor row overflow (status={st}): an atom has more than row_capacity={self.row_cap} "
+                f"neighbors within the radial cutoff, > {_lib.MAX_ANG} within the angular cutoff or > 255 of "
+                "one species; raise row_capacity (max 256)")
+
+
+class AevEngine:
+    """Neighbor rows + AEV forward/backward for one set of AEV constants."""
+
+    def __init__(self, consts: AEVConstants) -> None:
+        self.consts = consts
+        p = _lib.AevParams()
+        p.num_species = consts.num_species
+        p.n_shf_r, p.n_shf_a, p.n_shf_z = len(consts.ShfR), len(consts.ShfA), len(consts.ShfZ)
+        p.Rcr, p.Rca = consts.Rcr, consts.Rca
+        p.EtaR, p.EtaA, p.Zeta = consts.EtaR, consts.EtaA, consts.Zeta
+        if p.n_shf_r != 16 or (p.n_shf_a, p.n_shf_z) not in ((8, 4), (4, 8)) or not 1 <= p.num_species <= 7:
+            raise ValueError(
+                "HIP AEV kernels support 16 radial shifts, 8x4 (ANI-2x) or 4x8 (ANI-1x) angular grids and "
+                f"up to 7 species; got nR={p.n_shf_r}, nA x nZ={p.n_shf_a}x{p.n_shf_z}, S={p.num_species}")
+        self.params = p
+        self.L = consts.out_dim
+        self._host_table: tp.Optional[np.ndarray] = None
+        self._tables: tp.Dict[torch.device, Tensor] = {}
+
+    def host_table(self) -> np.ndarray:
+        if self._host_table is None:
+            c = self.consts
+            shfr = np.asarray(c.ShfR, dtype=np.float32)
+            shfa = np.asarray(c.ShfA, dtype=np.float32)
+            shfz = np.asarray(c.ShfZ, dtype=np.float32)
+            out = np.zeros(_lib.TABLE_FLOATS, dtype=np.float32)
+            _lib.check(_lib.lib().anihip_aev_table_pack(
+                C.byref(self.params), shfr.ctypes.data, shfa.ctypes.data, shfz.ctypes.data, out.ctypes.data))
+            self._host_table = out
+        return self._host_table
+
+    def table(self, device: torch.device) -> Tensor:
+        t = self._tables.get(device)
+        if t is None:
+            t = torch.from_numpy(self.host_table()).to(device)
+            self._tables[device] = t
+        return t
+
+    # ---- neighbor rows ----------------------------------------------------------------------------
+    def neighbors(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
+                  pbc: tp.Optional[tp.Sequence[bool]] = None, lo: int = 0, hi: tp.Optional[int] = None,
+                  mode: str = "auto", row_cap: int = 128, max_cells: tp.Optional[int] = None) -> NeighborRows:
+        """species [C,A] int32, coords [C,A,3] float32 (contiguous).  mode: batch | cell | auto."""
+        _require_cuda(species, coords, cell)
+        assert species.dtype == torch.int32 and coords.dtype == torch.float32
+        assert species.is_contiguous() and coords.is_contiguous()
+        Cn, A = species.shape
+        n = Cn * A
+        hi = n if hi is None else hi
+        dev = coords.device
+        pbc_mask = 0
+        cell_t = None
+        if cell is not None and pbc is not None and any(bool(b) for b in pbc):
+            cell_t = cell.detach().to(device=dev, dtype=torch.float32).contiguous()
+            pbc_mask = sum((1 << k) for k in range(3) if bool(pbc[k]))
+        if mode == "auto":
+            # the reference switches from all-pairs to the cell list at 190 (pbc) / 1770 atoms
+            # (neighbors.py:324); a wave sweeps 64 candidates at a time so the crossover is later here
+            mode = "cell" if (Cn == 1 and A > 512) else "batch"
+        if mode == "cell" and Cn != 1:
+            raise ValueError("the cell-list builder handles one system at a time (neighbors.py:373-381)")
+        row_cap = int(min(max(row_cap, 1), _lib.MAX_RAD))
+        n_central = max(hi - lo, 0)
+        meta = torch.empty((n, _lib.META_WORDS), dtype=torch.int32, device=dev)
+        ent = torch.empty((max(n_central, 1) * row_cap, 4), dtype=torch.float32, device=dev)
+        status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+        L = _lib.lib()
+        if mode == "batch":
+            ws = torch.empty(L.anihip_nbr_workspace_bytes(n, 1), dtype=torch.uint8, device=dev)
+            _lib.check(L.anihip_nbr_build_batch(
+                _stream(), C.byref(self.params), Cn, A, _ptr(species), _ptr(coords), _ptr(cell_t), pbc_mask,
+                lo, hi, _ptr(ws), ws.numel(), _ptr(meta), _ptr(ent), n_central * row_cap, _ptr(status)))
+        elif mode == "cell":
+            if max_cells is None:
+                max_cells = max(4096, 2 * n)
+            ws = torch.empty(L.anihip_nbr_workspace_bytes(n, max_cells), dtype=torch.uint8, device=dev)
+            _lib.check(L.anihip_nbr_build_cell(
+                _stream(), C.byref(self.params), n, _ptr(species), _ptr(coords), _ptr(cell_t), pbc_mask, lo,
+                hi, max_cells, _ptr(ws), ws.numel(), _ptr(meta), _ptr(ent), n_central * row_cap,
+                _ptr(status)))
+        else:
+            raise ValueError(f"unknown neighbor mode {mode!r}")
+        return NeighborRows(meta, ent, status, row_cap, lo, hi)
+
+    # ---- AEV ----------------------------------------------------------------------------------------
+    def forward(self, species: Tensor, nbrs: NeighborRows, out: tp.Optional[Tensor] = None) -> Tensor:
+        """AEV rows [N, L] for the central atoms nbrs.lo..nbrs.hi (other rows are left untouched)."""
+        _require_cuda(species)
+        n = species.numel()
+        if out is None:
+            alloc = torch.empty if (nbrs.lo == 0 and nbrs.hi == n) else torch.zeros
+            out = alloc((n, self.L), dtype=torch.float32, device=species.device)
+        _lib.check(_lib.lib().anihip_aev_forward(
+            _stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
+            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent), _ptr(out), _ptr(nbrs.status)))
+        return out
+
+    def backward(self, species: Tensor, nbrs: NeighborRows, grad_aev: Tensor,
+                 grad_coords: tp.Optional[Tensor] = None) -> Tensor:
+        """grad_coords [N,3] += d(sum grad_aev*aev)/d coords for the central atoms of nbrs."""
+        _require_cuda(species, grad_aev)
+        n = species.numel()
+        assert grad_aev.dtype == torch.float32 and grad_aev.is_contiguous()
+        assert grad_aev.numel() == n * self.L
+        if grad_coords is None:
+            grad_coords = torch.zeros((n, 3), dtype=torch.float32, device=species.device)
+        _lib.check(_lib.lib().anihip_aev_backward(
+            _stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
+            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent), _ptr(grad_aev), _ptr(grad_coords),
+            _ptr(nbrs.status)))
+        return grad_coords
+
+
+def _pad32(x: int) -> int:
+    return (x + 31) // 32 * 32
+
+
+class PackedNetworks:
+    """Ensemble parameters in the MFMA-friendly layout of include/anihip.h (members concatenated, widths
+    padded to 32, transposed copies for the backward GEMMs); cf. BmmAtomicNetwork, nn/_infer.py:141-161."""
+
+    def __init__(self, weights: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]],
+                 biases: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]], aev_len: int, celu_alpha: float,
+                 device: torch.device) -> None:
+        """weights[m][s][l]: [out, in] (torch.nn.Linear layout) of member m, species s, layer l."""
+        M, S = len(weights), len(weights[0])
+        nl = len(weights[0][0])
+        if not (2 <= nl <= _lib.MAX_LAYERS):
+            raise ValueError(f"networks must have 2..{_lib.MAX_LAYERS} Linear layers")
+        if aev_len % 16 != 0:
+            raise ValueError("AEV length must be a multiple of 16")
+        self.M, self.S, self.nl, self.aev_len = M, S, nl, aev_len
+        self.device = device
+        self._keep: tp.List[Tensor] = []
+        d = _lib.MlpDesc()
+        d.num_species, d.n_members, d.aev_len, d.celu_alpha = S, M, aev_len, celu_alpha
+        k0p = _pad32(aev_len)
+        f32 = dict(dtype=torch.float32, device=device)
+        for s in range(S):
+            net = d.net[s]
+            net.n_layers = nl
+            dims = [aev_len] + [_pad32(weights[0][s][l].shape[0]) for l in range(nl - 1)] + [1]
+            if weights[0][s][nl - 1].shape[0] != 1:
+                raise ValueError("final layer must have one output")
+            for l, v in enumerate(dims):
+                net.dims[l] = v
+            for l in range(nl):
+                kin, kout = dims[l], dims[l + 1]
+                Ws = []
+                Bs = []
+                for m in range(M):
+                    W = weights[m][s][l].detach().to(**f32)
+                    b = biases[m][s][l].detach().to(**f32)
+                    Wp = torch.zeros((kout, kin), **f32)
+                    Wp[: W.shape[0], : W.shape[1]] = W
+                    bp = torch.zeros((kout,), **f32)
+                    bp[: b.shape[0]] = b
+                    Ws.append(Wp)
+                    Bs.append(bp)
+                Wst = torch.stack(Ws)   # [M, out_p, in_p]
+                bst = torch.stack(Bs)   # [M, out_p]
+                if l == nl - 1:
+                    w = Wst.reshape(M, kin).contiguous()
+                    wt = None
+                    bias = bst.reshape(M).contiguous()
+                elif l == 0:
+                    cat = Wst.reshape(M * kout, kin)              # row m*H1p+o
+                    w = cat.t().contiguous()                      # [K0, M*H1p]
+                    wt = torch.zeros((M * kout, k0p), **f32)      # [M*H1p, K0p]
+                    wt[:, :kin] = cat
+                    bias = bst.reshape(M * kout).contiguous()
+                else:
+                    w = Wst.transpose(1, 2).contiguous()          # [M, in_p, out_p]
+                    wt = Wst.contiguous()                         # [M, out_p, in_p]
+                    bias = bst.contiguous()
+                self._keep += [w, bias] + ([wt] if wt is not None else [])
+                net.w[l] = w.data_ptr()
+                net.bias[l] = bias.data_ptr()
+                net.wt[l] = wt.data_ptr() if wt is not None else None
+        self.desc = d
+        self._ws: tp.Optional[Tensor] = None
+
+    def workspace(self, n_central: int) -> Tensor:
+        need = _lib.lib().anihip_mlp_workspace_bytes(C.byref(self.desc), n_central)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward_backward(self, species: Tensor, aev: Tensor, lo: int = 0, hi: tp.Optional[int] = None,
+                         want_grad: bool = True, want_members: bool = False, chunk: int = 1 << 18,
+                         atomic_e: tp.Optional[Tensor] = None, grad_aev: tp.Optional[Tensor] = None
+                         ) -> tp.Tuple[Tensor, tp.Optional[Tensor], tp.Optional[Tensor]]:
+        """Per-atom ensemble-mean energies [N], d e/d aev [N,L] (optional), member energies [M,N]."""
+        _require_cuda(species, aev)
+        n = species.numel()
+        hi = n if hi is None else hi
+        assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == n * self.aev_len
+        dev = aev.device
+        full = lo == 0 and hi == n
+        if atomic_e is None:
+            atomic_e = (torch.empty if full else torch.zeros)(n, dtype=torch.float32, device=dev)
+        if want_grad and grad_aev is None:
+            grad_aev = (torch.empty if full else torch.zeros)((n, self.aev_len), dtype=torch.float32, device=dev)
+        member_e = torch.zeros((self.M, n), dtype=torch.float32, device=dev) if want_members else None
+        L = _lib.lib()
+        for c0 in range(lo, hi, chunk):
+            c1 = min(hi, c0 + chunk)
+            ws = self.workspace(c1 - c0)
+            _lib.check(L.anihip_mlp_forward_backward(
+                _stream(), C.byref(self.desc), n, c0, c1, _ptr(species), _ptr(aev), _ptr(ws), ws.numel(),
+                _ptr(atomic_e), _ptr(grad_aev) if want_grad else None, _ptr(member_e)))
+        return atomic_e, (grad_aev if want_grad else None), member_e
+
+
+def energy_reduce(species: Tensor, atomic_e: Tensor, sae: tp.Optional[Tensor], lo: int = 0,
+                  hi: tp.Optional[int] = None) -> Tensor:
+    """Molecular energies [C] in float64 = sum over atoms lo..hi of (atomic_e + sae[species])."""
+    _require_cuda(species, atomic_e, sae)
+    Cn, A = species.shape
+    n = Cn * A
+    hi = n if hi is None else hi
+    out = torch.empty(Cn, dtype=torch.float64, device=species.device)
+    if sae is not None:
+        assert sae.dtype == torch.float64
+    _lib.check(_lib.lib().anihip_energy_reduce(
+        _stream(), Cn, A, lo, hi, _ptr(species), _ptr(atomic_e), _ptr(sae), _ptr(out)))
+    return out

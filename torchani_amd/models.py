@@ -1,0 +1,177 @@
+"""ANI model assembly with the reference's API surface, plus the fused engine path.
+
+Mirrors torchani/arch.py:302-349 (ANI.forward), :116-126,263-275 (sub-module names), torchani/models.py:
+112-119,185-193 (ANI1x / ANI2x recipes) and torchani/grad.py:263-290 (energies_and_forces).
+
+Two ways to evaluate:
+  * ``model((species, coords), cell, pbc)`` -> SpeciesEnergies, differentiable through
+    torch.autograd (custom Functions wrapping the HIP forward/backward kernels), like the reference;
+  * ``model.energies_and_forces(species, coords, cell, pbc)`` -> the fused path used for MD and by
+    bench.py: neighbor rows -> AEV -> ensemble fwd+bwd -> AEV backward -> fp64 energy reduction, no
+    autograd graph, no host synchronisation, optional sharding of the central atoms over the ranks of a
+    torch.distributed (RCCL) process group.
+"""
+from __future__ import annotations
+
+import typing as tp
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .aev import AEVComputer
+from .constants import GSAES_WB97X_631GD
+from .engine import energy_reduce
+from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
+from .parallel import shard_range
+from .tuples import EnergiesForces, SpeciesEnergies
+from .weights import arch_spec, random_state_dict
+
+
+class NNPotential(torch.nn.Module):
+    """aev_computer + neural_networks pair (potentials/nnp.py:20-32)."""
+
+    def __init__(self, aev_computer: AEVComputer, neural_networks: torch.nn.Module) -> None:
+        super().__init__()
+        self.aev_computer = aev_computer
+        self.neural_networks = neural_networks
+        self._enabled = True
+
+
+class ANI(torch.nn.Module):
+    """ANI-style neural network interatomic potential (arch.py:298-349)."""
+
+    def __init__(self, symbols: tp.Sequence[str], aev_computer: AEVComputer, neural_networks: torch.nn.Module,
+                 self_energies: tp.Sequence[float], periodic_table_index: bool = True) -> None:
+        super().__init__()
+        self.symbols = tuple(symbols)
+        self.periodic_table_index = periodic_table_index
+        self.species_converter = SpeciesConverter(symbols)
+        self.potentials = torch.nn.ModuleDict({"nnp": NNPotential(aev_computer, neural_networks)})
+        self.energy_shifter = SelfEnergy(symbols, self_energies)
+        self.register_buffer("atomic_numbers", self.species_converter.atomic_numbers.clone())
+        self.cutoff = aev_computer.radial.cutoff
+        self.mlp_chunk = 1 << 18
+
+    # arch.py:263-275 convenience accessors
+    @property
+    def aev_computer(self) -> AEVComputer:
+        return self.potentials["nnp"].aev_computer
+
+    @property
+    def neural_networks(self):
+        return self.potentials["nnp"].neural_networks
+
+    def set_enabled(self, key: str, val: bool = True) -> None:
+        # arch.py:136-142
+        if key == "energy_shifter":
+            self.energy_shifter._enabled = val
+        else:
+            self.potentials[key]._enabled = val
+
+    def _elem_idxs(self, species: Tensor) -> Tensor:
+        return self.species_converter(species, nop=not self.periodic_table_index)
+
+    def forward(self, species_coordinates: tp.Tuple[Tensor, Tensor], cell: tp.Optional[Tensor] = None,
+                pbc: tp.Optional[Tensor] = None, charge: int = 0, atomic: bool = False,
+                ensemble_values: bool = False) -> SpeciesEnergies:
+        species, coords = species_coordinates
+        if species.dim() != 2 or coords.shape != (species.shape[0], species.shape[1], 3):
+            raise ValueError("expected species [C, A] and coords [C, A, 3]")
+        assert charge == 0, "Model only supports neutral molecules"
+        elem_idxs = self._elem_idxs(species)
+        energies = coords.new_zeros(elem_idxs.shape if atomic else elem_idxs.shape[:1])
+        if ensemble_values:
+            energies = energies.unsqueeze(0)
+        if self.potentials["nnp"]._enabled:
+            aevs = self.aev_computer(elem_idxs, coords, cell, pbc)
+            energies = energies + self.neural_networks(elem_idxs, aevs, atomic, ensemble_values)
+        if self.energy_shifter._enabled:
+            energies = energies + self.energy_shifter(elem_idxs, atomic=atomic)
+        return SpeciesEnergies(elem_idxs, energies)
+
+    # ---- fused path ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def energies_and_forces(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
+                            pbc: tp.Optional[tp.Sequence[bool]] = None, group=None,
+                            reduce_forces: bool = True, check_overflow: bool = False) -> EnergiesForces:
+        """Energies [C] (float64, NN + self energies) and forces [C, A, 3] without autograd.
+
+        With a torch.distributed ``group`` (one process per GPU, RCCL) the central atoms are sharded
+        contiguously over the ranks; every rank sees all coordinates, evaluates its shard, and the
+        partial energies (and, for a shared system, partial forces) are all-reduced.
+        """
+        if not coords.is_cuda:
+            raise ValueError("torchani_amd's engine needs tensors on a ROCm device (no CPU fallback)")
+        elem_idxs = self._elem_idxs(species)
+        C, A = elem_idxs.shape
+        n = C * A
+        species32 = elem_idxs.to(torch.int32).contiguous()
+        c32 = coords.detach().to(torch.float32).contiguous()
+        lo, hi = shard_range(n, group)
+        aevc = self.aev_computer
+        eng = aevc.engine()
+        pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
+        nbrs = eng.neighbors(species32, c32, cell, pbc_t, lo=lo, hi=hi, mode=aevc.neighbor_mode,
+                             row_cap=aevc.row_capacity)
+        aev = eng.forward(species32, nbrs)
+        packed = self.neural_networks._pack(c32.device)
+        atomic_e, grad_aev, _ = packed.forward_backward(species32, aev, lo=lo, hi=hi, want_grad=True,
+                                                        chunk=self.mlp_chunk)
+        grad_coords = eng.backward(species32, nbrs, grad_aev)
+        sae = None
+        if self.energy_shifter._enabled:
+            sae = self.energy_shifter.self_energies.to(device=c32.device, dtype=torch.float64)
+        energies = energy_reduce(species32, atomic_e, sae, lo, hi)
+        forces = grad_coords.neg_().view(C, A, 3)
+        if group is not None and torch.distributed.get_world_size(group) > 1:
+            torch.distributed.all_reduce(energies, group=group)
+            if reduce_forces:
+                torch.distributed.all_reduce(forces, group=group)
+        if check_overflow:
+            nbrs.raise_on_overflow()
+        aevc._last_neighbors = nbrs
+        return EnergiesForces(energies, forces, atomic_e.view(C, A))
+
+    def load_reference_state_dict(self, state: tp.Mapping[str, tp.Any], strict: bool = False):
+        """Load a (reference or seeded) state dict given as tensors or numpy arrays."""
+        conv = {k: (torch.from_numpy(np.asarray(v)) if not isinstance(v, Tensor) else v) for k, v in state.items()}
+        return self.load_state_dict(conv, strict=strict)
+
+
+def _assemble(kind: str, n_members: int, neighborlist: str, row_capacity: int,
+              periodic_table_index: bool) -> ANI:
+    symbols, consts, hidden = arch_spec(kind)
+    aevc = AEVComputer(consts, neighborlist=neighborlist, row_capacity=row_capacity)
+    members = [ANINetworks.build(symbols, consts.out_dim, hidden) for _ in range(n_members)]
+    nets: torch.nn.Module = Ensemble(members) if n_members > 1 else members[0]
+    sae = [GSAES_WB97X_631GD[s] for s in symbols]
+    return ANI(symbols, aevc, nets, sae, periodic_table_index)
+
+
+def _builtin(kind: str, state_dict, seed, n_members, device, neighborlist, row_capacity,
+             periodic_table_index) -> ANI:
+    model = _assemble(kind, n_members, neighborlist, row_capacity, periodic_table_index)
+    if state_dict is None:
+        # the published parameters are a download in the reference (arch.py:1185-1220); offline we use
+        # the same architecture with seeded random parameters
+        state_dict = random_state_dict(kind, n_members, 0 if seed is None else seed)
+    model.load_reference_state_dict(state_dict, strict=False)
+    model.requires_grad_(False)
+    if device is not None:
+        model = model.to(device)
+    return model
+
+
+def ANI2x(state_dict=None, seed: tp.Optional[int] = None, n_members: int = 8, device=None,
+          neighborlist: str = "auto", row_capacity: int = 128, periodic_table_index: bool = True) -> ANI:
+    """ANI-2x architecture: H C N O S F Cl, 1008-dim AEV, 8-member ensemble (models.py:185-196)."""
+    return _builtin("ani2x", state_dict, seed, n_members, device, neighborlist, row_capacity,
+                    periodic_table_index)
+
+
+def ANI1x(state_dict=None, seed: tp.Optional[int] = None, n_members: int = 8, device=None,
+          neighborlist: str = "auto", row_capacity: int = 128, periodic_table_index: bool = True) -> ANI:
+    """ANI-1x architecture: H C N O, 384-dim AEV, 8-member ensemble (models.py:112-119)."""
+    return _builtin("ani1x", state_dict, seed, n_members, device, neighborlist, row_capacity,
+                    periodic_table_index)

@@ -1,0 +1,227 @@
+"""Network containers with the reference's API, evaluated by the HIP/MFMA ensemble engine.
+
+Mirrors torchani/nn/_core.py:117-167 (AtomicNetwork, TightCELU), torchani/nn/_containers.py:377-421
+(ANINetworks), :590-660 (Ensemble), :663-734 (SpeciesConverter) and torchani/sae.py:54-64 (SelfEnergy).
+Module/parameter names equal the reference's so its state dicts load unchanged
+(``members.{m}.atomics.{Sym}.layers.{l}.weight``, ``...final_layer.weight``).
+
+Inference only for now: gradients flow to the AEVs (hence to coordinates), not to the weights -- the same
+contract as the reference's native MNP path (csrc/mnp.cpp:138-232, csrc/README.md:6-7).
+"""
+from __future__ import annotations
+
+import typing as tp
+import warnings
+
+import torch
+from torch import Tensor
+
+from .constants import ATOMIC_NUMBER, CELU_ALPHA
+from .engine import PackedNetworks
+from .tuples import SpeciesEnergies
+
+
+class TightCELU(torch.nn.Module):
+    """CELU with alpha = 0.1 (nn/_core.py:163-167)."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        return torch.nn.functional.celu(x, alpha=CELU_ALPHA)
+
+
+class AtomicNetwork(torch.nn.Module):
+    """MLP parameter holder ``in -> h1 -> ... -> 1`` (nn/_core.py:117-149).  The arithmetic is done by the
+    engine for whole containers; calling one network directly is not part of the hot path."""
+
+    def __init__(self, layer_dims: tp.Sequence[int], activation: str = "celu", bias: bool = True) -> None:
+        super().__init__()
+        if any(d <= 0 for d in layer_dims):
+            raise ValueError("Layer dims must be strict positive integers")
+        if activation != "celu" or not bias:
+            raise ValueError("the HIP ensemble kernels implement CELU(0.1) networks with biases (ANI-1x/2x)")
+        dims = tuple(layer_dims)
+        self.layers = torch.nn.ModuleList(
+            [torch.nn.Linear(i, o, bias=True) for i, o in zip(dims[:-2], dims[1:-1])])
+        self.final_layer = torch.nn.Linear(dims[-2], dims[-1], bias=True)
+        self.activation = TightCELU()
+        self.has_biases = True
+        self.requires_grad_(False)  # models.py:196 does the same for the builtin models
+
+    def linears(self) -> tp.List[torch.nn.Linear]:
+        return list(self.layers) + [self.final_layer]
+
+
+class _MLPFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aevs: Tensor, species32: Tensor, packed: PackedNetworks, want_members: bool) -> Tensor:
+        C, A = species32.shape
+        need_grad = aevs.requires_grad
+        a32 = aevs.detach().to(torch.float32).contiguous().view(C * A, -1)
+        ae, g, me = packed.forward_backward(species32, a32, want_grad=need_grad, want_members=want_members)
+        ctx.g = g
+        ctx.in_dtype = aevs.dtype
+        ctx.shape = aevs.shape
+        ctx.want_members = want_members
+        if want_members:
+            return me.view(packed.M, C, A).to(aevs.dtype)
+        return ae.view(C, A).to(aevs.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        if ctx.want_members:
+            raise RuntimeError("ensemble_values=True is not differentiable in the HIP engine")
+        if ctx.g is None:
+            raise RuntimeError("AEVs did not require grad in forward")
+        g = ctx.g.view(ctx.shape) * grad_out.to(torch.float32).unsqueeze(-1)
+        return g.to(ctx.in_dtype), None, None, None
+
+
+class _EngineContainer(torch.nn.Module):
+    """Shared machinery of ANINetworks / Ensemble: parameter packing cache + engine call."""
+
+    symbols: tp.Tuple[str, ...]
+
+    def _member_networks(self) -> tp.List["ANINetworks"]:
+        raise NotImplementedError
+
+    def _pack(self, device: torch.device) -> PackedNetworks:
+        members = self._member_networks()
+        params = [p for m in members for p in m.parameters()]
+        if any(p.requires_grad for p in params) and torch.is_grad_enabled():
+            warnings.warn("torchani_amd evaluates networks in inference mode: weight gradients are not "
+                          "computed by the HIP engine (only d/d aev)")
+        key = (device, tuple(id(m) for m in members), tuple(p._version for p in params),
+               tuple(p.data_ptr() for p in params))
+        if getattr(self, "_packed_key", None) != key:
+            weights = [[[lin.weight for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
+            biases = [[[lin.bias for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
+            aev_len = weights[0][0][0].shape[1]
+            self._packed = PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device)
+            self._packed_key = key
+        return self._packed
+
+    def _run(self, elem_idxs: Tensor, aevs: Tensor, atomic: bool, ensemble_values: bool) -> Tensor:
+        if not aevs.is_cuda:
+            raise ValueError("torchani_amd's network containers need tensors on a ROCm device")
+        species32 = elem_idxs.to(torch.int32).contiguous()
+        packed = self._pack(aevs.device)
+        out = _MLPFunction.apply(aevs, species32, packed, ensemble_values)
+        # [C, A] (or [M, C, A]); molecular energies are the sum over atoms (nn/_containers.py:417-421)
+        return out if atomic else out.sum(dim=-1)
+
+    def forward(self, elem_idxs, aevs: tp.Optional[Tensor] = None, atomic: bool = False,
+                ensemble_values: bool = False):
+        if isinstance(elem_idxs, tuple):  # legacy ``_, E = nets((idxs, aevs), cell, pbc)``
+            warnings.warn("The tuple call signature is deprecated; use nets(elem_idxs, aevs)")
+            idxs, a = elem_idxs
+            return SpeciesEnergies(idxs, self._run(idxs, a, False, False))
+        assert aevs is not None
+        return self._run(elem_idxs, aevs, atomic, ensemble_values)
+
+
+class ANINetworks(_EngineContainer):
+    """Per-element networks: ``E = nets(elem_idxs, aevs, atomic=False)`` (nn/_containers.py:325-425)."""
+
+    def __init__(self, modules: tp.Dict[str, AtomicNetwork]) -> None:
+        super().__init__()
+        self.symbols = tuple(modules.keys())
+        self.atomics = torch.nn.ModuleDict(modules)
+        self.num_species = len(self.symbols)
+        self.atomic_numbers = torch.tensor([ATOMIC_NUMBER[s] for s in self.symbols], dtype=torch.long)
+        self.total_members_num = 1
+        self.active_members_idxs = [0]
+
+    def __getitem__(self, sym: str) -> AtomicNetwork:
+        return self.atomics[sym]
+
+    def _member_networks(self) -> tp.List["ANINetworks"]:
+        return [self]
+
+    def forward(self, elem_idxs, aevs=None, atomic: bool = False, ensemble_values: bool = False):
+        out = super().forward(elem_idxs, aevs, atomic, ensemble_values)
+        return out
+
+    @classmethod
+    def build(cls, symbols: tp.Sequence[str], in_dim: int, hidden: tp.Dict[str, tp.Sequence[int]]):
+        return cls({s: AtomicNetwork((in_dim,) + tuple(hidden[s]) + (1,)) for s in symbols})
+
+    def to_infer_model(self, use_mnp: bool = False) -> "ANINetworks":
+        return self  # already the fused native path (reference: nn/_containers.py:423-425)
+
+
+class Ensemble(_EngineContainer):
+    """Mean over member containers, all members evaluated in one grouped GEMM per layer
+    (nn/_containers.py:590-660)."""
+
+    def __init__(self, modules: tp.Sequence[ANINetworks]) -> None:
+        super().__init__()
+        self.members = torch.nn.ModuleList(modules)
+        self.symbols = modules[0].symbols
+        self.num_species = modules[0].num_species
+        self.atomic_numbers = modules[0].atomic_numbers
+        self.total_members_num = len(self.members)
+        self.active_members_idxs = list(range(len(self.members)))
+
+    def __len__(self) -> int:
+        return len(self.members)
+
+    def __getitem__(self, idx: int) -> ANINetworks:
+        return self.members[idx]
+
+    def set_active_members(self, idxs: tp.Sequence[int]) -> None:
+        # nn/_core.py:99-110
+        if not idxs or any(i < 0 or i >= self.total_members_num for i in idxs) or len(set(idxs)) != len(idxs):
+            raise IndexError("Invalid member indices")
+        self.active_members_idxs = list(idxs)
+
+    def get_active_members_num(self) -> int:
+        return len(self.active_members_idxs)
+
+    def _member_networks(self) -> tp.List[ANINetworks]:
+        return [self.members[i] for i in self.active_members_idxs]
+
+    def to_infer_model(self, use_mnp: bool = False) -> "Ensemble":
+        return self
+
+
+class SpeciesConverter(torch.nn.Module):
+    """Atomic numbers -> element indices (nn/_containers.py:663-734); unsupported elements raise
+    ValueError."""
+
+    def __init__(self, symbols: tp.Sequence[str]) -> None:
+        super().__init__()
+        if isinstance(symbols, str):
+            raise ValueError("Please use SpeciesConverter(['H', 'C', 'N', 'O']) instead of a string")
+        conv = torch.full((120,), -1, dtype=torch.long)
+        for i, s in enumerate(symbols):
+            conv[ATOMIC_NUMBER[s]] = i
+        self.register_buffer("conv_tensor", conv)
+        self.atomic_numbers = torch.tensor([ATOMIC_NUMBER[s] for s in symbols], dtype=torch.long)
+
+    def forward(self, atomic_nums, nop: bool = False):
+        if isinstance(atomic_nums, tuple):
+            warnings.warn("The tuple call signature is deprecated; use idxs = converter(atomic_nums)")
+            return (self.forward(atomic_nums[0]), atomic_nums[1])
+        if nop:
+            if atomic_nums.max() >= len(self.atomic_numbers):
+                raise ValueError(f"Unsupported element idx in {atomic_nums}")
+            return atomic_nums
+        elem_idxs = self.conv_tensor[atomic_nums.clamp(min=-1)]  # -1 indexes the last (unused, -1) slot
+        if (elem_idxs[atomic_nums != -1] == -1).any():
+            raise ValueError(f"Model doesn't support some elements in input. Input elements include: "
+                             f"{torch.unique(atomic_nums)} Supported elements are: {self.atomic_numbers}")
+        return elem_idxs
+
+
+class SelfEnergy(torch.nn.Module):
+    """Per-element constant energies (sae.py:25-64); the buffer is float32 like the reference's."""
+
+    def __init__(self, symbols: tp.Sequence[str], self_energies: tp.Sequence[float]) -> None:
+        super().__init__()
+        self.symbols = tuple(symbols)
+        self.register_buffer("self_energies", torch.tensor(list(self_energies), dtype=torch.float))
+        self._enabled = True
+
+    def forward(self, elem_idxs: Tensor, atomic: bool = False) -> Tensor:
+        e = self.self_energies[elem_idxs.clamp(min=0)]
+        e = e.masked_fill(elem_idxs == -1, 0.0)
+        return e if atomic else e.sum(dim=-1)

@@ -1,0 +1,62 @@
+"""Data-parallel sharding of the hot path: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference has no multi-device code at all; the decomposition is ours:
+  * central atoms (flattened molecule-major) are split into contiguous, equal ranges, one per rank --
+    for batches of molecules this is a split over molecules, for one big periodic box a split over the
+    atoms of the box; every rank keeps the full coordinate array (37 MB for 2.3 M atoms), so building the
+    shard's neighbor rows needs no halo exchange;
+  * energies: each rank reduces its shard in fp64, one scalar-per-molecule all-reduce;
+  * forces: a central atom pushes gradient onto its neighbors, which may belong to other ranks, so a
+    shared system ends with one all-reduce of the [N,3] fp32 force array (27.6 MB at 2.3 M atoms; a few
+    hundred microseconds over xGMI against tens of milliseconds of compute).  Batches whose molecules do
+    not straddle ranks can skip it (reduce_forces=False) and keep only the energy all-reduce.
+"""
+from __future__ import annotations
+
+import os
+import typing as tp
+
+import torch
+
+
+def shard_bounds(n: int, world: int) -> tp.List[int]:
+    """world+1 monotone boundaries splitting range(n) into near-equal contiguous shards."""
+    base, rem = divmod(n, world)
+    out = [0]
+    for r in range(world):
+        out.append(out[-1] + base + (1 if r < rem else 0))
+    return out
+
+
+def shard_range(n: int, group=None, rank: tp.Optional[int] = None, world: tp.Optional[int] = None
+                ) -> tp.Tuple[int, int]:
+    """[lo, hi) of this rank's central atoms."""
+    if world is None:
+        if group is None and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return 0, n
+        if group is None:
+            return 0, n  # sharding is opt-in: pass the process group explicitly
+        world = torch.distributed.get_world_size(group)
+        rank = torch.distributed.get_rank(group)
+    b = shard_bounds(n, world)
+    return b[rank], b[rank + 1]
+
+
+def init_from_env(backend: tp.Optional[str] = None):
+    """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local_rank, group-or-None)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return rank, world, local, None
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not torch.distributed.is_initialized():
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            torch.distributed.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(backend)
+    return rank, world, local, torch.distributed.group.WORLD

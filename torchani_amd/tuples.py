@@ -1,0 +1,25 @@
+"""Named tuples returned by the public API (mirrors torchani/tuples.py:32-36,92-96)."""
+from __future__ import annotations
+
+import typing as tp
+
+from torch import Tensor
+
+
+class SpeciesAEV(tp.NamedTuple):
+    species: Tensor
+    aevs: Tensor
+
+
+class SpeciesEnergies(tp.NamedTuple):
+    species: Tensor
+    energies: Tensor
+
+
+class EnergiesForces(tp.NamedTuple):
+    """Result of the fused engine path: energies [C] float64 Hartree, forces [C,A,3] float32 Ha/A,
+    atomic_energies [C,A] float32 (network part only, no self energies)."""
+
+    energies: Tensor
+    forces: Tensor
+    atomic_energies: Tensor
