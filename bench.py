@@ -1,0 +1,227 @@
+"""Headline benchmark: ANI-2x energy+forces throughput (atom*steps/s) on a periodic water box.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json north_star / configs[3]): 8-member ANI-2x ensemble on a 2.3 M-atom periodic water
+box (0.1 atoms/A^3), energies + forces.  It fits one MI355X, so N=1 runs the whole box and N>1 shards
+the SAME box over the ranks (strong scaling): central atoms split contiguously, coordinates replicated,
+one fp64 energy all-reduce + one fp32 force all-reduce over RCCL.  Weights are seeded random parameters
+of the ANI-2x architecture (the published ones are a download), data is synthetic.
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  roofline      : the fused radial+angular AEV forward kernel against the HBM roofline
+  roofline_mfma : the ensemble GEMM stack (fwd + input-gradient bwd) against the fp32-MFMA peak
+  cpu_baseline  : the CPU oracle (float build, all host cores) timed on a bounded sub-box, N=1 only
+  stages_ms     : per-stage device time of one step on this rank (HIP events on the engine's stream)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak
+
+
+def water_box(n_side: int, seed: int = 4, spacing: float = 3.107):
+    """n_side^3 TIP3P-geometry waters on a jittered lattice, cubic periodic box at 0.1 atoms/A^3.
+    Element indices: O=3, H=0 (ANI-2x order H C N O S F Cl)."""
+    rs = np.random.RandomState(seed)
+    L = n_side * spacing
+    ax = (np.arange(n_side, dtype=np.float32) + 0.5) * spacing
+    o = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    n = o.shape[0]
+    o = o + rs.uniform(-0.35, 0.35, (n, 3)).astype(np.float32)
+
+    def unit(v):
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+    a = unit(rs.normal(size=(n, 3)).astype(np.float32))
+    b = unit(np.cross(a, rs.normal(size=(n, 3)).astype(np.float32)))
+    th = np.deg2rad(104.52) / 2
+    h1 = o + 0.9572 * (np.cos(th) * a + np.sin(th) * b)
+    h2 = o + 0.9572 * (np.cos(th) * a - np.sin(th) * b)
+    x = np.stack([o, h1, h2], 1).reshape(1, 3 * n, 3).astype(np.float32)
+    sp = np.tile(np.array([3, 0, 0], dtype=np.int64), n).reshape(1, 3 * n)
+    cell = (np.eye(3) * L).astype(np.float32)
+    return sp, x, cell
+
+
+def mlp_flops_per_atom(species_idx: np.ndarray) -> float:
+    """fwd + input-gradient bwd flops of the 8-member ensemble, averaged over the atoms."""
+    from torchani_amd.constants import HIDDEN_DIMS_2X, SYMBOLS_2X, aev_constants_2x
+
+    L = aev_constants_2x().out_dim
+    per = []
+    for s in SYMBOLS_2X:
+        d = (L,) + tuple(HIDDEN_DIMS_2X[s]) + (1,)
+        per.append(8 * sum(2 * d[i] * d[i + 1] for i in range(len(d) - 1)))
+    per = np.asarray(per, dtype=np.float64)
+    cnt = np.bincount(species_idx[species_idx >= 0], minlength=len(per))
+    return float(2.0 * (per * cnt).sum() / cnt.sum())
+
+
+def time_stage(fn, reps):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps
+
+
+def cpu_baseline(n_side: int, seed: int):
+    """CPU oracle ('port' of the reference path, float build, OpenMP over all host cores) on a bounded
+    periodic sub-box of the same density; returns the cpu_baseline object."""
+    from oracle import oracle as orc
+    from torchani_amd.weights import arch_spec, random_state_dict
+
+    sp, x, cell = water_box(n_side, seed=seed)
+    sd = random_state_dict("ani2x", 8, 0)
+    symbols, _, _ = arch_spec("ani2x")
+    dims, flat = orc.pack_networks(sd, symbols, 8)
+    o32 = orc.Oracle("f32")
+    cores = o32.num_threads()
+    t0 = time.perf_counter()
+    o32.energy_forces(orc.params_2x(), sp, x, dims, flat, 8, sae=sd["energy_shifter.self_energies"].astype(np.float64),
+                      cell=cell, pbc=(True, True, True), cell_list=True)
+    dt = time.perf_counter() - t0
+    n = sp.shape[1]
+    return {
+        "value": n / dt, "unit": "atom*steps/s", "cores": cores, "kind": "port",
+        "sample": f"{n}-atom periodic water sub-box (same density and model), 1 energy+forces step, "
+                  f"{dt:.1f} s, oracle/ani_oracle.c float build with OpenMP",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--waters-side", type=int, default=92, help="waters per box edge (92 -> 2,336,064 atoms)")
+    ap.add_argument("--cpu-side", type=int, default=16, help="waters per edge of the CPU-baseline sub-box")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from torchani_amd import _lib
+    from torchani_amd.models import ANI2x
+    from torchani_amd.parallel import init_from_env, shard_range
+
+    rank, world, local, group = init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    _lib.lib()
+
+    sp_np, x_np, cell_np = water_box(args.waters_side)
+    n_atoms = sp_np.shape[1]
+    species = torch.from_numpy(sp_np).to(dev)
+    coords = torch.from_numpy(x_np).to(dev)
+    cell = torch.from_numpy(cell_np).to(dev)
+    pbc = (True, True, True)
+    model = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="cell", row_capacity=128)
+
+    def step():
+        return model.energies_and_forces(species, coords, cell, pbc, group=group)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if group is not None:
+        torch.distributed.barrier(group)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if group is not None:
+        torch.distributed.barrier(group)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if group is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
+        elapsed = float(t.item())
+    model.aev_computer.last_neighbors().raise_on_overflow()
+    assert torch.isfinite(out.energies).all() and torch.isfinite(out.forces).all()
+
+    # ---- per-stage device timing on this rank's shard (outside the timed region) -----------------------
+    lo, hi = shard_range(n_atoms, group)
+    eng = model.aev_computer.engine()
+    sp32 = species.to(torch.int32).contiguous()
+    packed = model.neural_networks._pack(dev)
+    st = {}
+    reps = 3
+    nbrs = eng.neighbors(sp32, coords, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
+    st["neighbors"] = time_stage(lambda: eng.neighbors(sp32, coords, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128), reps)
+    aev = eng.forward(sp32, nbrs)
+    st["aev_forward"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev), reps)
+    ae = torch.zeros(n_atoms, dtype=torch.float32, device=dev)
+    gaev = torch.zeros_like(aev)
+    st["mlp_fwd_bwd"] = time_stage(
+        lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk), reps)
+    gc = torch.zeros((n_atoms, 3), dtype=torch.float32, device=dev)
+    st["aev_backward"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc), reps)
+    meta = nbrs.meta[lo:hi, 1].to(torch.int64) & 0xFFFFFFFF
+    n_a = float((meta & 0xFFFF).double().mean())
+    n_r = n_a + float((meta >> 16).double().mean())
+    n_shard = hi - lo
+    # algorithmic bytes per atom of the fused AEV forward: angular 3584 + 20 n_a + 8, radial 448 + 8 n_r
+    bytes_per_atom = 3584 + 20 * n_a + 8 + 448 + 8 * n_r
+    aev_gbs = bytes_per_atom * n_shard / (st["aev_forward"] * 1e-3) / 1e9
+    flops_atom = mlp_flops_per_atom(sp_np.reshape(-1))
+    mlp_tflops = flops_atom * n_shard / (st["mlp_fwd_bwd"] * 1e-3) / 1e12
+
+    res = {
+        "metric": "atom*steps/sec (energy+forces) ANI-2x",
+        "value": n_atoms * args.steps / elapsed,
+        "unit": "atom*steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"ANI-2x 8-member ensemble, {n_atoms}-atom periodic water box (0.1 atoms/A^3), "
+                        "energy+forces, seeded random weights",
+            "n_atoms": n_atoms, "box_A": float(cell_np[0, 0]),
+            "sharding": "central atoms split contiguously over ranks; coords replicated; "
+                        "all-reduce of energy (fp64) and forces (fp32)",
+        },
+        "roofline": {
+            "kernel": "k_aev_fwd<8,4> (fused radial+angular AEV forward)", "bound": "hbm",
+            "achieved": aev_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": aev_gbs / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_atom": bytes_per_atom,
+            "mean_radial_neighbors": n_r, "mean_angular_neighbors": n_a, "avg_launch_ms": st["aev_forward"],
+        },
+        "roofline_mfma": {
+            "kernel": "k_gemm<*> stack: ensemble forward + input-gradient backward", "bound": "mfma",
+            "achieved": mlp_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": mlp_tflops / MFMA_F32_PEAK_TFLOPS, "flops_per_atom": flops_atom,
+        },
+        "stages_ms": st,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_side, seed=5)
+        print(json.dumps(res))
+    if group is not None:
+        torch.distributed.barrier(group)
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
