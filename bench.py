@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--waters-side", type=int, default=92, help="waters per box edge (92 -> 2,336,064 atoms)")
-    ap.add_argument("--cpu-side", type=int, default=16, help="waters per edge of the CPU-baseline sub-box")
+    ap.add_argument("--cpu-side", type=int, default=36, help="waters per edge of the CPU-baseline sub-box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -1,0 +1,173 @@
+"""CPU-only checks: the C-ABI library builds/loads and exports everything include/anihip.h declares, the
+host-side packing/partition logic, and the API error behaviour without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from torchani_amd import _lib
+
+    _lib.build()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from torchani_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "anihip.h")).read()
+    declared = set(re.findall(r"\b(anihip_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no prototypes found in include/anihip.h"
+    assert declared == set(_lib.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.anihip_abi_version() == 1
+
+
+def test_struct_layouts_match_header(lib):
+    """ctypes mirrors of the POD structs must have the C sizes (checked through the workspace query, which
+    dereferences an anihip_mlp_desc)."""
+    from torchani_amd import _lib
+
+    assert ctypes.sizeof(_lib.AevParams) == 9 * 4
+    assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 3 * 4 * 8
+    d = _lib.MlpDesc()
+    d.num_species, d.n_members, d.aev_len, d.celu_alpha = 2, 8, 1008, 0.1
+    for s in range(2):
+        d.net[s].n_layers = 4
+        for l, v in enumerate((1008, 256, 192, 160, 1)):
+            d.net[s].dims[l] = v
+    n = 1000
+    need = lib.anihip_mlp_workspace_bytes(ctypes.byref(d), n)
+    acts = 4 * 8 * (256 + 192 + 160) * (n + 1)
+    assert acts <= need <= acts + 4 * (n + 1) + 16 * 256
+
+
+def test_error_reporting_without_gpu(lib):
+    from torchani_amd import _lib
+
+    p = _lib.AevParams(num_species=7, n_shf_r=16, n_shf_a=5, n_shf_z=4, Rcr=5.1, Rca=3.5, EtaR=19.7, EtaA=12.5,
+                       Zeta=14.1)
+    z = np.zeros(80, dtype=np.float32)
+    rc = lib.anihip_aev_table_pack(ctypes.byref(p), z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data)
+    assert rc != 0 and b"8x4 or 4x8" in lib.anihip_last_error()
+    with pytest.raises(RuntimeError, match="libanihip"):
+        _lib.check(rc)
+
+
+def test_aev_table_pack_matches_constants(lib):
+    from torchani_amd.constants import aev_constants_2x
+    from torchani_amd.engine import AevEngine
+
+    c = aev_constants_2x()
+    t = AevEngine(c).host_table()
+    assert np.array_equal(t[:16], np.asarray(c.ShfR, dtype=np.float32))
+    assert np.array_equal(t[32:40], np.asarray(c.ShfA, dtype=np.float32))
+    z = np.asarray(c.ShfZ, dtype=np.float32).astype(np.float64)
+    assert np.allclose(t[48:52], np.cos(z), atol=1e-7) and np.allclose(t[64:68], np.sin(z), atol=1e-7)
+    assert c.out_dim == 1008 and c.radial_len == 112 and c.angular_len == 896
+
+
+def test_constants_match_reference_values():
+    """SURVEY section 0 table (values cross-checked there against the reference's .params files)."""
+    from torchani_amd.constants import aev_constants_1x, aev_constants_2x
+
+    c2, c1 = aev_constants_2x(), aev_constants_1x()
+    assert (c2.Rcr, c2.Rca, c2.EtaR, c2.EtaA, c2.Zeta) == (5.1, 3.5, 19.7, 12.5, 14.1)
+    assert abs(c2.ShfR[1] - 1.06875) < 1e-12 and abs(c2.ShfA[7] - 3.1625) < 1e-12
+    assert abs(c2.ShfZ[0] - np.pi / 8) < 1e-15 and len(c2.ShfZ) == 4
+    assert c1.out_dim == 384 and (c1.Rcr, c1.EtaR, c1.EtaA, c1.Zeta) == (5.2, 16.0, 8.0, 32.0)
+
+
+def test_model_state_dict_keys_and_loading():
+    """Reference key names and parameter count of the ANI-2x architecture."""
+    from torchani_amd.models import ANI2x
+    from torchani_amd.weights import random_state_dict
+
+    sd = random_state_dict("ani2x", 8, 3)
+    m = ANI2x(state_dict=sd)
+    keys = set(m.state_dict().keys())
+    for k in ("potentials.nnp.neural_networks.members.7.atomics.Cl.final_layer.weight",
+              "potentials.nnp.aev_computer.angular.sections", "potentials.nnp.aev_computer.triu_index",
+              "energy_shifter.self_energies", "species_converter.conv_tensor"):
+        assert k in keys
+    assert sum(p.numel() for p in m.parameters()) == 13705784
+    w = m.state_dict()["potentials.nnp.neural_networks.members.2.atomics.N.layers.1.weight"]
+    assert torch.equal(w, torch.from_numpy(sd["potentials.nnp.neural_networks.members.2.atomics.N.layers.1.weight"]))
+    assert m.aev_computer.out_dim == 1008 and m.aev_computer.triu_index[2, 1] == m.aev_computer.triu_index[1, 2]
+    assert not any(p.requires_grad for p in m.parameters())  # models.py:196
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    """No CPU fallback: the product path refuses non-device tensors (aev/_computer.py:444-447 analogue)."""
+    from torchani_amd.models import ANI2x
+
+    m = ANI2x(seed=1)
+    sp = torch.tensor([[1, 6, 1, 1, 1]])
+    x = torch.zeros(1, 5, 3)
+    with pytest.raises(ValueError, match="ROCm device"):
+        m.energies_and_forces(sp, x)
+    with pytest.raises(ValueError, match="ROCm device"):
+        m((sp, x))
+    with pytest.raises(ValueError):
+        m.species_converter(torch.tensor([[1, 5]]))  # boron is not an ANI-2x element
+
+
+def test_species_converter_and_self_energy():
+    from torchani_amd.nn import SelfEnergy, SpeciesConverter
+
+    conv = SpeciesConverter(("H", "C", "N", "O", "S", "F", "Cl"))
+    z = torch.tensor([[1, 6, 7, 8, 16, 9, 17, -1]])
+    assert conv(z).tolist() == [[0, 1, 2, 3, 4, 5, 6, -1]]
+    sae = SelfEnergy(("H", "C"), (-0.5, -37.8))
+    e = sae(torch.tensor([[0, 1, -1], [0, 0, 0]]))
+    assert torch.allclose(e, torch.tensor([-38.3, -1.5]))  # padding contributes nothing (sae.py:61)
+
+
+def test_packed_network_layout_cpu():
+    """PackedNetworks (host packing into the layout of include/anihip.h) checked on CPU tensors."""
+    from torchani_amd.engine import PackedNetworks
+
+    rs = np.random.RandomState(0)
+    M, S, K0 = 2, 2, 32
+    hid = [(40, 24), (33, 16)]  # widths that need padding to 64/32 and 64/32
+    W = [[[torch.from_numpy(rs.randn(o, i).astype(np.float32)) for i, o in
+           zip((K0,) + hid[s], hid[s] + (1,))] for s in range(S)] for m in range(M)]
+    B = [[[torch.from_numpy(rs.randn(w.shape[0]).astype(np.float32)) for w in W[m][s]] for s in range(S)]
+         for m in range(M)]
+    pk = PackedNetworks(W, B, K0, 0.1, torch.device("cpu"))
+    d = pk.desc
+    assert [d.net[0].dims[l] for l in range(4)] == [32, 64, 32, 1]
+    assert [d.net[1].dims[l] for l in range(4)] == [32, 64, 32, 1]
+    # layer 0 of species 1: w [K0, M*H1p], column m*H1p+o = W[m][1][0][o, :]
+    w0 = next(t for t in pk._keep if t.data_ptr() == d.net[1].w[0])
+    assert w0.shape == (32, 2 * 64)
+    assert torch.equal(w0[:, 64 + 5], W[1][1][0][5]) and torch.all(w0[:, 64 + 33:] == 0)
+    wt0 = next(t for t in pk._keep if t.data_ptr() == d.net[1].wt[0])
+    assert wt0.shape == (128, 32) and torch.equal(wt0[64 + 5, :32], W[1][1][0][5])
+    # hidden layer 1 of species 0: w [M][H1p][H2p] = W^T padded, wt = W padded
+    w1 = next(t for t in pk._keep if t.data_ptr() == d.net[0].w[1])
+    wt1 = next(t for t in pk._keep if t.data_ptr() == d.net[0].wt[1])
+    assert w1.shape == (2, 64, 32) and wt1.shape == (2, 32, 64)
+    assert torch.equal(w1[1, :40, :24], W[1][0][1].t()) and torch.equal(wt1[1, :24, :40], W[1][0][1])
+    assert torch.all(w1[:, 40:, :] == 0) and torch.all(w1[:, :, 24:] == 0)
+    wf = next(t for t in pk._keep if t.data_ptr() == d.net[0].w[2])
+    assert wf.shape == (2, 32) and torch.equal(wf[0, :24], W[0][0][2][0]) and torch.all(wf[:, 24:] == 0)
+
+
+def test_shard_bounds():
+    from torchani_amd.parallel import shard_bounds, shard_range
+
+    for n in (0, 1, 7, 2336064):
+        for w in (1, 2, 3, 8):
+            b = shard_bounds(n, w)
+            assert b[0] == 0 and b[-1] == n and all(0 <= b[i + 1] - b[i] <= n // w + 1 for i in range(w))
+    assert shard_range(100, None) == (0, 100)
+    assert shard_range(10, rank=1, world=4) == (3, 6)
