@@ -134,13 +134,31 @@ typedef struct {
     const float *w[ANIHIP_MAX_LAYERS];     /* device pointers, layouts above */
     const float *wt[ANIHIP_MAX_LAYERS];    /* transposed copies (unused for the final layer) */
     const float *bias[ANIHIP_MAX_LAYERS];
+    /* precision == ANIHIP_MLP_F16X3 only: the same hidden-layer matrices as two fp16 planes {hi, lo}
+     * with hi + lo = w * wh_scale (power of two), stored [2][rows = output index][cols = reduction index]:
+     * wh[l] has the shape of wt[l] (forward GEMMs), wth[l] the shape of w[l] (backward GEMMs; layer 0
+     * padded to K0p rows). */
+    const void *wh[ANIHIP_MAX_LAYERS];
+    const void *wth[ANIHIP_MAX_LAYERS];
+    float wh_scale[ANIHIP_MAX_LAYERS];
 } anihip_species_net;
 
+/* GEMM arithmetic of the hidden layers.
+ *   FP32  : v_mfma_f32_32x32x2_f32, exact fp32 products.
+ *   F16X3 : every fp32 operand x is split on the fly into two fp16 numbers hi + lo = x * 2^e (e chosen per
+ *           tensor from a device-side running max so nothing overflows); a product is evaluated as
+ *           hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: relative error
+ *           ~4e-7 per product (fp32: 6e-8) at 16/3 of the fp32-MFMA rate.  Layer-0 inputs use the static
+ *           scale 4, valid for |x| < 16376 -- above the largest value an AEV element can take with the
+ *           row limits of this library (2 * C(128,2) = 16256). */
+#define ANIHIP_MLP_FP32 0
+#define ANIHIP_MLP_F16X3 1
 typedef struct {
     int32_t num_species;
     int32_t n_members;
     int32_t aev_len;
     float celu_alpha;
+    int32_t precision; /* ANIHIP_MLP_FP32 or ANIHIP_MLP_F16X3 */
     anihip_species_net net[ANIHIP_MAX_SPECIES];
 } anihip_mlp_desc;
 

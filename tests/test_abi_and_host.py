@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(lib):
     from torchani_amd import _lib
 
     assert ctypes.sizeof(_lib.AevParams) == 9 * 4
-    assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 3 * 4 * 8
+    assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 5 * 4 * 8 + 4 * 4
     d = _lib.MlpDesc()
     d.num_species, d.n_members, d.aev_len, d.celu_alpha = 2, 8, 1008, 0.1
     for s in range(2):
@@ -47,7 +47,7 @@ def test_struct_layouts_match_header(lib):
     n = 1000
     need = lib.anihip_mlp_workspace_bytes(ctypes.byref(d), n)
     acts = 4 * 8 * (256 + 192 + 160) * (n + 1)
-    assert acts <= need <= acts + 4 * (n + 1) + 16 * 256
+    assert acts <= need <= acts + 4 * (n + 1) + 64 * 256
 
 
 def test_error_reporting_without_gpu(lib):
@@ -142,7 +142,7 @@ def test_packed_network_layout_cpu():
            zip((K0,) + hid[s], hid[s] + (1,))] for s in range(S)] for m in range(M)]
     B = [[[torch.from_numpy(rs.randn(w.shape[0]).astype(np.float32)) for w in W[m][s]] for s in range(S)]
          for m in range(M)]
-    pk = PackedNetworks(W, B, K0, 0.1, torch.device("cpu"))
+    pk = PackedNetworks(W, B, K0, 0.1, torch.device("cpu"), precision="f16x3")
     d = pk.desc
     assert [d.net[0].dims[l] for l in range(4)] == [32, 64, 32, 1]
     assert [d.net[1].dims[l] for l in range(4)] == [32, 64, 32, 1]
@@ -158,6 +158,14 @@ def test_packed_network_layout_cpu():
     assert w1.shape == (2, 64, 32) and wt1.shape == (2, 32, 64)
     assert torch.equal(w1[1, :40, :24], W[1][0][1].t()) and torch.equal(wt1[1, :24, :40], W[1][0][1])
     assert torch.all(w1[:, 40:, :] == 0) and torch.all(w1[:, :, 24:] == 0)
+    # f16x3 planes: hi + lo reproduces scale * weight to ~2^-22, forward planes shaped like wt
+    wh1 = next(t for t in pk._keep if t.data_ptr() == d.net[0].wh[1])
+    sc = d.net[0].wh_scale[1]
+    assert wh1.dtype == torch.float16 and wh1.shape == (2, 2, 32, 64) and 2 ** 13 <= sc * wt1.abs().max() < 2 ** 14
+    rec = (wh1[0].float() + wh1[1].float()) / sc
+    assert (rec - wt1).abs().max() <= 2.0 ** -21 * wt1.abs().max()
+    wth0 = next(t for t in pk._keep if t.data_ptr() == d.net[1].wth[0])
+    assert wth0.shape == (2, 32, 128)
     wf = next(t for t in pk._keep if t.data_ptr() == d.net[0].w[2])
     assert wf.shape == (2, 32) and torch.equal(wf[0, :24], W[0][0][2][0]) and torch.all(wf[:, 24:] == 0)
 

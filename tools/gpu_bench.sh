@@ -17,6 +17,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && timeout 900 rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/pmc_$c -o pmc -- python $REPO/bench.py --waters-side ${PMC_SIDE:-40} --steps 1 --warmup 0 --no-cpu-baseline > $REPO/gpurun_out/pmc_$c.log 2>&1
   echo "pmc $c exit $?"
 done
-cd $REPO; find gpurun_out/pmc_* -type f | head; python tools_pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE | tee gpurun_out/pmc_summary.txt
+cd $REPO; find gpurun_out/pmc_* -type f | head; python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE | tee gpurun_out/pmc_summary.txt
 fi
 exit 0

@@ -26,6 +26,7 @@ MAX_ANG = 128
 MAX_RAD = 256
 TABLE_FLOATS = 80
 ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
+MLP_FP32, MLP_F16X3 = 0, 1
 
 
 class AevParams(C.Structure):
@@ -49,6 +50,9 @@ class SpeciesNet(C.Structure):
         ("w", C.c_void_p * MAX_LAYERS),
         ("wt", C.c_void_p * MAX_LAYERS),
         ("bias", C.c_void_p * MAX_LAYERS),
+        ("wh", C.c_void_p * MAX_LAYERS),
+        ("wth", C.c_void_p * MAX_LAYERS),
+        ("wh_scale", C.c_float * MAX_LAYERS),
     ]
 
 
@@ -58,6 +62,7 @@ class MlpDesc(C.Structure):
         ("n_members", C.c_int32),
         ("aev_len", C.c_int32),
         ("celu_alpha", C.c_float),
+        ("precision", C.c_int32),
         ("net", SpeciesNet * MAX_SPECIES),
     ]
 

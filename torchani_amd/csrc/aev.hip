@@ -79,6 +79,68 @@ __device__ __forceinline__ void decode_pair(bool same, int t, int nj, int nk, fl
     }
 }
 
+// ---- cross-lane helpers (gfx950) -------------------------------------------------------------------
+// v + (v shifted right by N lanes inside each 16-lane DPP row, zero fill)
+template <int N>
+__device__ __forceinline__ float row_shr_add(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + N, 0xF, 0xF, true));
+}
+// rows (16 lanes) of the result: [x.r0+x.r1, y.r0+y.r1, x.r2+x.r3, y.r2+y.r3]
+__device__ __forceinline__ float sum16(float x, float y)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// rows of the result: [x.r0+x.r2, x.r1+x.r3, y.r0+y.r2, y.r1+y.r3]
+__device__ __forceinline__ float sum32(float x, float y)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// branch-free (j,k) decode of pair t of a block (see decode_pair); `rect` = INT_MAX for rectangles
+__device__ __forceinline__ void decode_pair2(bool same, int t, int nj, int div, float inv_div, int rect,
+                                             int half, int &jr, int &kr)
+{
+    const int q = (int)(((float)t + 0.5f) * inv_div);
+    const int rem = t - q * div;
+    int k2 = same ? q + 1 + rem : rem;
+    k2 = (same && k2 >= nj) ? k2 - nj : k2;
+    const bool diam = t >= rect;
+    jr = diam ? t - rect : q;
+    kr = diam ? t - rect + half : k2;
+}
+
+// per-atom header prefetched one iteration ahead: lanes 0..5 hold the meta words, lane 6 the species
+struct AtomHdr {
+    uint32_t start;
+    int nA, nF, sp;
+    uint64_t pkA, pkF;
+};
+__device__ __forceinline__ uint32_t hdr_load(const uint32_t *meta, const int32_t *species, int64_t i, bool ok)
+{
+    const int lane = lane_id();
+    uint32_t w = 0;
+    if (ok && lane < META_W) w = meta[(size_t)i * META_W + lane];
+    if (ok && lane == META_W) w = (uint32_t)species[i];
+    return w;
+}
+__device__ __forceinline__ AtomHdr hdr_decode(uint32_t w)
+{
+    AtomHdr h;
+    h.start = (uint32_t)__builtin_amdgcn_readlane((int)w, 0);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)w, 1);
+    h.nA = (int)(c & 0xFFFFu);
+    h.nF = (int)(c >> 16);
+    h.pkA = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)w, 3) << 32) |
+            (uint32_t)__builtin_amdgcn_readlane((int)w, 2);
+    h.pkF = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)w, 5) << 32) |
+            (uint32_t)__builtin_amdgcn_readlane((int)w, 4);
+    h.sp = __builtin_amdgcn_readlane((int)w, 6);
+    return h;
+}
+
 // ---------------------------------------------------------------------------------------------------
 template <int NA, int NZ>
 __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
@@ -91,13 +153,11 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
     __shared__ float4 s_ang[FWD_WPB][MAXA];   // ux uy uz r
     __shared__ float s_afc[FWD_WPB][MAXA];    // fc(r, Rca)
     __shared__ float2 s_rad[FWD_WPB][MAXR];   // r, 0.25 fc(r, Rcr)
-    __shared__ __attribute__((aligned(16))) float s_stage[FWD_WPB][STAGE_FLOATS];
 
     const int wib = threadIdx.x >> 6, lane = lane_id();
     float4 *ang = s_ang[wib];
     float *afc = s_afc[wib];
     float2 *rad = s_rad[wib];
-    float *stage = s_stage[wib];
 
     // per-lane constants
     const int rp = lane >> 3, rsq = lane & 7;  // radial: neighbor slot, shift pair
@@ -111,33 +171,69 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
         cosZ[v] = tab[TAB_COSZ + q + 4 * v];
         sinZ[v] = tab[TAB_SINZ + q + 4 * v];
     }
-    const float pi_rcr = PI_F / a.Rcr, pi_rca = PI_F / a.Rca;
-    const int L4 = a.L >> 2;
+    // cutoffs through v_cos_f32 (argument in revolutions): cos(pi r / Rc) = cos(2 pi * r / (2 Rc))
+    const float rev_rcr = 0.5f / a.Rcr, rev_rca = 0.5f / a.Rca;
+    // output positions of the reduced angular block / radial species rows (see the reductions below)
+    const int row = lane >> 4;
+    const bool ang_writer = (lane & 15) >= 12;   // lanes 12..15 of every DPP row hold the totals
+    const int ang_o0 = (NZ == 4) ? (q * 4 + row) : (q * 8 + row);            // value index `row`
+    const int ang_o1 = (NZ == 4) ? ((q + 4) * 4 + row) : (q * 8 + 4 + row);  // value index 4 + `row`
+    const bool rad_writer = (lane & 8) && row < 2;
+    const int rad_o = row * 8 + rsq;
 
     const int64_t nw = (int64_t)gridDim.x * FWD_WPB;
-    for (int64_t i = lo + blockIdx.x * (int64_t)FWD_WPB + wib; i < hi; i += nw) {
-        float4 *out4 = reinterpret_cast<float4 *>(aev + (size_t)i * a.L);
-        if (species[i] < 0) {
-            for (int f = lane; f < L4; f += WAVE) out4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
-        }
-        const uint32_t *m = meta + (size_t)i * META_W;
-        const uint32_t start = m[0], cntw = m[1];
-        const int nA = uniform((int)(cntw & 0xFFFFu)), nF = uniform((int)(cntw >> 16));
-        const int nR = nA + nF;
-        const uint64_t pkA = ((uint64_t)(uint32_t)uniform((int)m[3]) << 32) | (uint32_t)uniform((int)m[2]);
-        const uint64_t pkF = ((uint64_t)(uint32_t)uniform((int)m[5]) << 32) | (uint32_t)uniform((int)m[4]);
+    int64_t i = lo + blockIdx.x * (int64_t)FWD_WPB + wib;
+    // software pipeline over atoms: header of atom i+nw and the first 128 entries of atom i+nw are in
+    // flight while atom i is being computed
+    uint32_t hw = hdr_load(meta, species, i, i < hi);
+    AtomHdr h = hdr_decode(hw);
+    float4 e0 = make_float4(1.f, 0.f, 0.f, 0.f), e1 = e0;
+    if (i < hi && h.sp >= 0) {
+        if (lane < h.nA + h.nF) e0 = ent[h.start + lane];
+        if (lane + WAVE < h.nA + h.nF) e1 = ent[h.start + lane + WAVE];
+    }
+    uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
 
-        // ---- load + per-neighbor precompute ----
-        for (int e = lane; e < nR; e += WAVE) {
-            const float4 d = ent[start + e];
-            const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
-            rad[e] = make_float2(r, 0.25f * (0.5f * cosf(r * pi_rcr) + 0.5f));
-            if (e < nA) {
-                const float inv = 1.0f / r;
-                ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, r);
-                afc[e] = 0.5f * cosf(r * pi_rca) + 0.5f;
+    for (; i < hi; i += nw) {
+        float *out = aev + (size_t)i * a.L;
+        const int nA = h.nA, nR = h.nA + h.nF;
+        const uint64_t pkA = h.pkA, pkF = h.pkF;
+        const bool padding = h.sp < 0;
+        const uint32_t start = h.start;
+
+        // ---- per-neighbor precompute -> LDS ----
+        if (!padding) {
+            for (int c0 = 0; c0 < nR; c0 += WAVE) {
+                const int e = c0 + lane;
+                float4 d = c0 == 0 ? e0 : (c0 == WAVE ? e1 : make_float4(1.f, 0.f, 0.f, 0.f));
+                if (c0 >= 2 * WAVE && e < nR) d = ent[start + e];
+                if (e < nR) {
+                    const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+                    rad[e] = make_float2(r, 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f);
+                    if (e < nA) {
+                        const float inv = 1.0f / r;
+                        ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, r);
+                        afc[e] = 0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f;
+                    }
+                }
             }
+        }
+        // ---- prefetch the next atom ----
+        h = hdr_decode(hw_next);
+        {
+            const int64_t in = i + nw;
+            e0 = make_float4(1.f, 0.f, 0.f, 0.f);
+            e1 = e0;
+            if (in < hi && h.sp >= 0) {
+                if (lane < h.nA + h.nF) e0 = ent[h.start + lane];
+                if (lane + WAVE < h.nA + h.nF) e1 = ent[h.start + lane + WAVE];
+            }
+            hw_next = hdr_load(meta, species, in + nw, in + nw < hi);
+        }
+        if (padding) {
+            float4 *out4 = reinterpret_cast<float4 *>(out);
+            for (int f = lane; f < (a.L >> 2); f += WAVE) out4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
         }
         wave_sync();
 
@@ -158,13 +254,13 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
                     acc0 += __builtin_amdgcn_exp2f(a.kR * d0 * d0) * f;
                     acc1 += __builtin_amdgcn_exp2f(a.kR * d1 * d1) * f;
                 }
-                acc0 += __shfl_xor(acc0, 8);  acc1 += __shfl_xor(acc1, 8);
-                acc0 += __shfl_xor(acc0, 16); acc1 += __shfl_xor(acc1, 16);
-                acc0 += __shfl_xor(acc0, 32); acc1 += __shfl_xor(acc1, 32);
-                if (lane < 8) {
-                    stage[t * 16 + rsq] = acc0;
-                    stage[t * 16 + 8 + rsq] = acc1;
-                }
+                // 8 slots -> 1: inside the DPP row, then across rows.  Row 0 ends with the totals of
+                // acc0, row 1 with those of acc1 (lanes 8..15 = shift pair rsq).
+                acc0 = row_shr_add<8>(acc0);
+                acc1 = row_shr_add<8>(acc1);
+                float x = sum16(acc0, acc1);
+                x = sum32(x, x);
+                if (rad_writer) out[t * 16 + rad_o] = x;
                 oA += cA;
                 oF += cF;
             }
@@ -180,7 +276,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
                     const int nk = cnt_of(pkA, tk);
                     const bool same = (tk == tj);
                     const int np = same ? (nj * (nj - 1)) >> 1 : nj * nk;
-                    float *blk = stage + a.radlen + P * 32;
+                    float *blk = out + a.radlen + P * 32;
                     if (np == 0) {
                         if (lane < 32) blk[lane] = 0.f;
                         ok += nk;
@@ -188,28 +284,40 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
                     }
                     const int div = same ? ((nj - 1) >> 1) : nk;
                     const float inv_div = div > 0 ? 1.0f / (float)div : 0.f;
+                    const int rect = same ? nj * div : 0x7FFFFFFF;
+                    const int half = nj >> 1;
                     float acc[AQ][NZ];
 #pragma unroll
                     for (int u = 0; u < AQ; ++u)
 #pragma unroll
                         for (int z = 0; z < NZ; ++z) acc[u][z] = 0.f;
+                    // software-pipelined over the steps: LDS reads of step s+1 are issued before the
+                    // arithmetic of step s
+                    int jr, kr;
+                    decode_pair2(same, min(p, np - 1), nj, div, inv_div, rect, half, jr, kr);
+                    float4 J = ang[oj + jr], K = ang[ok + kr];
+                    float fj = afc[oj + jr], fk = afc[ok + kr];
                     for (int t0 = 0; t0 < np; t0 += 16) {
-                        const int t = t0 + p;
-                        const bool v = t < np;
-                        int jr, kr;
-                        decode_pair(same, v ? t : 0, nj, nk, inv_div, div, jr, kr);
-                        const float4 J = ang[oj + jr], K = ang[ok + kr];
-                        const float fcc = v ? 2.0f * afc[oj + jr] * afc[ok + kr] : 0.f;
-                        const float c = J.x * K.x + J.y * K.y + J.z * K.z;
+                        const bool v = t0 + p < np;
+                        const float4 Jc = J, Kc = K;
+                        const float fcc = v ? 2.0f * fj * fk : 0.f;
+                        if (t0 + 16 < np) {
+                            decode_pair2(same, min(t0 + 16 + p, np - 1), nj, div, inv_div, rect, half, jr, kr);
+                            J = ang[oj + jr];
+                            K = ang[ok + kr];
+                            fj = afc[oj + jr];
+                            fk = afc[ok + kr];
+                        }
+                        const float c = Jc.x * Kc.x + Jc.y * Kc.y + Jc.z * Kc.z;
                         const float ct = 0.95f * c;
                         const float st = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ct * ct, 0.f));
-                        const float rm = 0.5f * (J.w + K.w);
+                        const float rm = 0.5f * (Jc.w + Kc.w);
                         float f1t[ZQ], f2[AQ];
 #pragma unroll
                         for (int vz = 0; vz < ZQ; ++vz) {
                             const float cz = ct * cosZ[vz] + st * sinZ[vz];
-                            const float h = fmaxf(0.5f + 0.5f * cz, 0.f);
-                            f1t[vz] = __builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(h)) * fcc;
+                            const float hh = fmaxf(0.5f + 0.5f * cz, 0.f);
+                            f1t[vz] = __builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(hh)) * fcc;
                         }
 #pragma unroll
                         for (int u = 0; u < AQ; ++u) {
@@ -223,31 +331,25 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
                             for (int u = 0; u < AQ; ++u) acc[u][z] += f2[u] * f1;
                         }
                     }
+                    // 16 slots -> 1.  Inside each DPP row (4 slots): two shifted adds leave the row
+                    // totals in lanes 12..15 (= quarter q).  Across the 4 rows: permlane swaps reduce two
+                    // values per instruction; row r ends with the total of value r (x0) / 4+r (x1).
+                    float v8[8];
 #pragma unroll
                     for (int u = 0; u < AQ; ++u)
 #pragma unroll
-                        for (int z = 0; z < NZ; ++z) {
-                            float s = acc[u][z];
-                            s += __shfl_xor(s, 4);
-                            s += __shfl_xor(s, 8);
-                            s += __shfl_xor(s, 16);
-                            s += __shfl_xor(s, 32);
-                            acc[u][z] = s;
-                        }
-                    if (lane < 4) {
-#pragma unroll
-                        for (int u = 0; u < AQ; ++u)
-#pragma unroll
-                            for (int z = 0; z < NZ; ++z) blk[(q + 4 * u) * NZ + z] = acc[u][z];
+                        for (int z = 0; z < NZ; ++z) v8[u * NZ + z] = row_shr_add<8>(row_shr_add<4>(acc[u][z]));
+                    const float x0 = sum32(sum16(v8[0], v8[1]), sum16(v8[2], v8[3]));
+                    const float x1 = sum32(sum16(v8[4], v8[5]), sum16(v8[6], v8[7]));
+                    if (ang_writer) {
+                        blk[ang_o0] = x0;
+                        blk[ang_o1] = x1;
                     }
                     ok += nk;
                 }
                 oj += nj;
             }
         }
-        wave_sync();
-        const float4 *st4 = reinterpret_cast<const float4 *>(stage);
-        for (int f = lane; f < L4; f += WAVE) out4[f] = st4[f];
         wave_sync();
     }
 }

@@ -31,12 +31,19 @@ constexpr int GEMM_THREADS = 256;
 enum Epilogue { EPI_BIAS_CELU = 0, EPI_DCELU = 1, EPI_SCATTER = 2 };
 
 struct GemmProblem {
-    const float *B;     // [batch][K][ldb]
+    const float *B;     // fp32 path: [batch][K][ldb]
     const float *bias;  // [batch][N] (EPI_BIAS_CELU)
     int K, N, ldb;
     int a_boff, c_boff;        // column offset of batch b in A / C rows = b * off
     int64_t b_stride;          // elements between consecutive batches of B
     int bias_stride;
+    // f16x3 path: B as two fp16 planes {hi, lo}, each [batch][N][ldbh] (reduction index contiguous)
+    const _Float16 *Bh;
+    int64_t bh_plane;          // elements between the hi and the lo plane
+    int64_t bh_stride;         // elements between consecutive batches inside a plane
+    int ldbh;
+    int k_valid;               // A columns >= k_valid are read as zero (K padded up to a multiple of 32)
+    float w_inv_scale;         // 1 / (power-of-two scale baked into Bh)
 };
 
 struct GemmArgs {
@@ -51,6 +58,10 @@ struct GemmArgs {
     int n_store;           // EPI_SCATTER: only columns < n_store are stored
     int S, batch, ncol_max, nrow_tiles_ub;
     float alpha, inv_alpha;
+    // f16x3 path: operand scaling.  amax_in/out = stage index into the running-max table (or -1)
+    int amax_in, amax_out;
+    float a_static_scale;
+    unsigned *amax;            // device [AMAX_STAGES][MAX_S][AMAX_SLOTS] float bits
 };
 
 // control block layout (ints) in the workspace
@@ -59,6 +70,10 @@ constexpr int CTL_CURSOR = 8;   // [8]  scatter cursors
 constexpr int CTL_OFF = 16;     // [9]  first sorted position of each species
 constexpr int CTL_TILE = 32;    // [9]  first row tile of each species
 constexpr int CTL_WORDS = 48;
+// running |max| of every intermediate tensor (per stage, per species), spread over slots to keep the
+// atomics off a single address; lives right behind the control block
+constexpr int AMAX_STAGES = 8, AMAX_SLOTS = 32;
+constexpr int AMAX_WORDS = AMAX_STAGES * MAX_S * AMAX_SLOTS;
 
 // ---- species bucketing --------------------------------------------------------------------------
 
@@ -281,6 +296,211 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs g)
     }
 }
 
+// ---- f16x3 grouped GEMM ---------------------------------------------------------------------------
+// Same tiling / epilogues as k_gemm, but every fp32 operand is split into two fp16 numbers
+// (hi + lo = x * 2^e) and a product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 (fp32
+// accumulate): ~2^-21.5 relative error per product at 16/3 of the fp32-MFMA rate.  A (AEV rows /
+// activations / gradients, fp32 in HBM) is split in the loader; its power-of-two scale comes from the
+// running max the producing kernel left in the amax table, so the scaled values sit in [2^13, 2^14)
+// at most and can neither overflow nor lose their low part.  B (weights) is pre-split at pack time.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const h8 gh8;
+
+constexpr int HBK = 32;            // reduction depth per LDS stage
+constexpr int H_LD = HBK + 8;      // halves per LDS row: 80 B stride -> conflict-free ds_read_b128
+constexpr int H_PLANE = BM * H_LD; // halves per operand plane per stage
+
+__device__ __forceinline__ float amax_scale(const unsigned *amax, int stage, int s)
+{
+    // every lane reads one slot; wave max; scale = 2^(13 - floor(log2(amax)))
+    const unsigned *p = amax + (stage * MAX_S + s) * AMAX_SLOTS;
+    unsigned v = p[lane_id() & (AMAX_SLOTS - 1)];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    if (v == 0u) return 1.0f;
+    const int e = (int)(v >> 23) - 127;  // floor(log2(amax)) for normal floats
+    return __uint_as_float((unsigned)(127 + 13 - e) << 23);
+}
+
+__device__ __forceinline__ void amax_update(unsigned *amax, int stage, int s, float m)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane_id() == 0)
+        atomicMax(amax + (stage * MAX_S + s) * AMAX_SLOTS + (blockIdx.x & (AMAX_SLOTS - 1)), __float_as_uint(m));
+}
+
+template <int NB>
+__device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src, int a_k, int k_valid,
+                                             float sa, const _Float16 *bh_src, int64_t bh_plane, int nk,
+                                             _Float16 *a_dst, _Float16 *b_dst, const _Float16 *a_frag,
+                                             const _Float16 *b_frag)
+{
+    constexpr int STAGE = 4 * H_PLANE;  // halves per LDS stage: A_hi, A_lo, B_hi, B_lo
+    v4f ra[4];
+    h8 rbh[2], rbl[2];
+    auto gload = [&](int kt) {
+        const bool ok = kt * HBK + a_k < k_valid;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ra[j] = a_src[ok ? kt * (HBK / 4) + j : 0];
+            if (!ok) ra[j] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        const gh8 *bp = (const gh8 *)(bh_src + kt * HBK);
+        rbh[0] = bp[0];
+        rbh[1] = bp[1];
+        const gh8 *bl = (const gh8 *)(bh_src + bh_plane + kt * HBK);
+        rbl[0] = bl[0];
+        rbl[1] = bl[1];
+    };
+    auto lstore = [&](int buf) {
+        h8 hi[2], lo[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float x = ra[j][c] * sa;
+                const _Float16 h = (_Float16)x;
+                hi[j >> 1][(j & 1) * 4 + c] = h;
+                lo[j >> 1][(j & 1) * 4 + c] = (_Float16)(x - (float)h);
+            }
+        _Float16 *ad = a_dst + buf * STAGE;
+        *reinterpret_cast<h8 *>(ad) = hi[0];
+        *reinterpret_cast<h8 *>(ad + 8) = hi[1];
+        *reinterpret_cast<h8 *>(ad + H_PLANE) = lo[0];
+        *reinterpret_cast<h8 *>(ad + H_PLANE + 8) = lo[1];
+        _Float16 *bd = b_dst + buf * STAGE;
+        *reinterpret_cast<h8 *>(bd) = rbh[0];
+        *reinterpret_cast<h8 *>(bd + 8) = rbh[1];
+        *reinterpret_cast<h8 *>(bd + H_PLANE) = rbl[0];
+        *reinterpret_cast<h8 *>(bd + H_PLANE + 8) = rbl[1];
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const _Float16 *af = a_frag + buf * STAGE, *bf = b_frag + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {
+            const h8 ahi = *reinterpret_cast<const h8 *>(af + ks * 16);
+            const h8 alo = *reinterpret_cast<const h8 *>(af + H_PLANE + ks * 16);
+            h8 bhi[NB], blo[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bhi[nb] = *reinterpret_cast<const h8 *>(bf + nb * 32 * H_LD + ks * 16);
+                blo[nb] = *reinterpret_cast<const h8 *>(bf + H_PLANE + nb * 32 * H_LD + ks * 16);
+            }
+            // small terms first, independent accumulators between dependent MFMAs
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[nb], acc[nb], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 sm[2 * 4 * H_PLANE];
+
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = id & 7;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
+    }
+    const int col_t = id % g.ncol_max;
+    const int bb = (id / g.ncol_max) % g.batch;
+    const int row_t = id / (g.ncol_max * g.batch);
+
+    const int *ctl = g.ctl;
+    if (row_t >= ctl[CTL_TILE + g.S]) return;
+    int s = 0;
+    while (s + 1 < g.S && row_t >= ctl[CTL_TILE + s + 1]) ++s;
+    const GemmProblem &pr = g.prob[s];
+    const int n0 = col_t * BN;
+    if (n0 >= pr.N) return;
+    const int m0 = (row_t - ctl[CTL_TILE + s]) * BM;
+    const int n_rows = ctl[CTL_CNT + s] - m0;
+    const int p0 = ctl[CTL_OFF + s] + m0;
+    const int nb_act = min(4, (pr.N - n0) >> 5);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float sa = g.amax_in >= 0 ? amax_scale(g.amax, g.amax_in, s) : g.a_static_scale;
+    const float out_scale = pr.w_inv_scale / sa;
+
+    // A loader: row = tid>>1, 16 consecutive k (4 x float4 per stage)
+    const int a_row = tid >> 1, a_k = (tid & 1) * 16;
+    const gf4 *a_src;
+    {
+        const int rr = a_row < n_rows ? a_row : 0;
+        const int64_t src_row = g.a_gather ? (int64_t)g.a_gather[p0 + rr] : (int64_t)(p0 + rr);
+        a_src = (const gf4 *)(g.A + src_row * g.lda + (int64_t)bb * pr.a_boff + a_k);
+    }
+    // B loader: output column n = tid>>1, 16 consecutive k of both planes
+    const int b_nl = tid >> 1;
+    const int b_n = (n0 + b_nl < pr.N) ? n0 + b_nl : n0;
+    const _Float16 *bh_src = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)b_n * pr.ldbh + a_k;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+    const int nk = pr.K / HBK;
+    const int fr = lane & 31, fk = lane >> 5;
+    _Float16 *a_dst = sm + a_row * H_LD + a_k;
+    _Float16 *b_dst = sm + 2 * H_PLANE + b_nl * H_LD + a_k;
+    const _Float16 *a_frag = sm + (wave * 32 + fr) * H_LD + fk * 8;
+    const _Float16 *b_frag = sm + 2 * H_PLANE + fr * H_LD + fk * 8;
+    switch (nb_act) {
+        case 4: gemm_h_kloop<4>(acc, a_src, a_k, pr.k_valid, sa, bh_src, pr.bh_plane, nk, a_dst, b_dst, a_frag, b_frag); break;
+        case 3: gemm_h_kloop<3>(acc, a_src, a_k, pr.k_valid, sa, bh_src, pr.bh_plane, nk, a_dst, b_dst, a_frag, b_frag); break;
+        case 2: gemm_h_kloop<2>(acc, a_src, a_k, pr.k_valid, sa, bh_src, pr.bh_plane, nk, a_dst, b_dst, a_frag, b_frag); break;
+        default: gemm_h_kloop<1>(acc, a_src, a_k, pr.k_valid, sa, bh_src, pr.bh_plane, nk, a_dst, b_dst, a_frag, b_frag); break;
+    }
+
+    float vmax = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb >= nb_act) continue;
+        const int col = n0 + nb * 32 + fr;
+        float bias = 0.f;
+        if (EPI == EPI_BIAS_CELU) bias = pr.bias[(int64_t)bb * pr.bias_stride + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+            if (row >= n_rows) continue;
+            float v = acc[nb][r] * out_scale;
+            if (EPI == EPI_BIAS_CELU) {
+                v = celu(v + bias, g.alpha, g.inv_alpha);
+                g.C[(int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col] = v;
+            } else if (EPI == EPI_DCELU) {
+                float *cp = g.C + (int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col;
+                const float y = *cp;
+                v = v * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+                *cp = v;
+            } else {
+                if (col < g.n_store) g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + col] = v;
+            }
+            vmax = fmaxf(vmax, fabsf(v));
+        }
+    }
+    if (g.amax_out >= 0) amax_update(g.amax, g.amax_out, s, vmax);
+}
+
 // ---- output layer: energies + seed of the backward pass --------------------------------------------
 
 struct HeadArgs {
@@ -297,6 +517,8 @@ struct HeadArgs {
     int S, M;
     float inv_alpha;
     int want_grad;
+    unsigned *amax;   // f16x3: running max table (or NULL)
+    int amax_out;
 };
 
 __global__ __launch_bounds__(256) void k_head(HeadArgs h)
@@ -310,7 +532,7 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs h)
         const int Hp = h.Hp[s];
         float *row = h.act + p * h.ld;
         const int atom = h.perm[p];
-        float esum = 0.f;
+        float esum = 0.f, gmax = 0.f;
         const float invM = 1.0f / (float)h.M;
         for (int m = 0; m < h.M; ++m) {
             const float *w = h.w[s] + (int64_t)m * Hp;
@@ -318,13 +540,18 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs h)
             for (int o = lane; o < Hp; o += WAVE) {
                 const float y = row[m * Hp + o];
                 part += y * w[o];
-                if (h.want_grad) row[m * Hp + o] = invM * w[o] * (y > 0.f ? 1.0f : y * h.inv_alpha + 1.0f);
+                if (h.want_grad) {
+                    const float gq = invM * w[o] * (y > 0.f ? 1.0f : y * h.inv_alpha + 1.0f);
+                    row[m * Hp + o] = gq;
+                    gmax = fmaxf(gmax, fabsf(gq));
+                }
             }
             part = wave_sum(part) + h.bias[s][m];
             if (h.member_e && lane == 0) h.member_e[(int64_t)m * h.n_atoms + atom] = part;
             esum += part;
         }
         if (lane == 0) h.atomic_e[atom] = esum * invM;
+        if (h.amax && h.want_grad) amax_update(h.amax, h.amax_out, s, gmax);
     }
 }
 
@@ -367,6 +594,7 @@ __global__ __launch_bounds__(256) void k_energy_reduce(int n_mol, int A, int64_t
 
 struct MlpWorkspace {
     int *ctl;
+    unsigned *amax;
     int *perm;
     float *act[ANIHIP_MAX_LAYERS];
     int64_t ld[ANIHIP_MAX_LAYERS];
@@ -382,9 +610,9 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
         off += align256(bytes);
         return p;
     };
-    int *ctl = (int *)take(sizeof(int) * CTL_WORDS);
+    int *ctl = (int *)take(sizeof(int) * (CTL_WORDS + AMAX_WORDS));
     int *perm = (int *)take(sizeof(int) * (size_t)(n + 1));
-    if (w) { w->ctl = ctl; w->perm = perm; }
+    if (w) { w->ctl = ctl; w->amax = (unsigned *)(ctl + CTL_WORDS); w->perm = perm; }
     const int nh = d->net[0].n_layers - 1;  // hidden layers
     for (int l = 0; l < nh; ++l) {
         int mx = 0;
@@ -412,6 +640,7 @@ static int check_desc(const anihip_mlp_desc *d)
     ANIHIP_REQUIRE(d->num_species >= 1 && d->num_species <= MAX_S - 1, "num_species must be 1..7");
     ANIHIP_REQUIRE(d->n_members >= 1 && d->n_members <= 64, "n_members must be 1..64");
     ANIHIP_REQUIRE(d->aev_len % BK == 0, "aev_len must be a multiple of %d", BK);
+    ANIHIP_REQUIRE(d->precision == ANIHIP_MLP_FP32 || d->precision == ANIHIP_MLP_F16X3, "unknown precision");
     const int nl = d->net[0].n_layers;
     ANIHIP_REQUIRE(nl >= 2 && nl <= ANIHIP_MAX_LAYERS, "n_layers must be 2..%d", ANIHIP_MAX_LAYERS);
     for (int s = 0; s < d->num_species; ++s) {
@@ -424,16 +653,22 @@ static int check_desc(const anihip_mlp_desc *d)
         for (int l = 0; l < nl; ++l) {
             ANIHIP_REQUIRE(n.w[l] && n.bias[l], "species %d layer %d: null parameter pointer", s, l);
             if (l < nl - 1) ANIHIP_REQUIRE(n.wt[l], "species %d layer %d: null transposed weights", s, l);
+            if (l < nl - 1 && d->precision == ANIHIP_MLP_F16X3)
+                ANIHIP_REQUIRE(n.wh[l] && n.wth[l] && n.wh_scale[l] > 0.f,
+                               "species %d layer %d: missing fp16 weight planes", s, l);
         }
     }
     return 0;
 }
 
 template <int EPI>
-static void launch_gemm(hipStream_t stream, GemmArgs &g)
+static void launch_gemm(hipStream_t stream, GemmArgs &g, bool f16x3)
 {
     const int64_t total = (int64_t)g.nrow_tiles_ub * g.ncol_max * g.batch;
-    hipLaunchKernelGGL((k_gemm<EPI>), dim3((unsigned)total), dim3(GEMM_THREADS), 0, stream, g);
+    if (f16x3)
+        hipLaunchKernelGGL((k_gemm_h<EPI>), dim3((unsigned)total), dim3(GEMM_THREADS), 0, stream, g);
+    else
+        hipLaunchKernelGGL((k_gemm<EPI>), dim3((unsigned)total), dim3(GEMM_THREADS), 0, stream, g);
 }
 
 extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc *d, int64_t n_atoms,
@@ -452,10 +687,12 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     mlp_carve(d, n, (char *)workspace, &w);
     const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1;
     const int L = d->aev_len;
+    const int K0p = ((L + 31) / 32) * 32;
     const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
+    const bool h3 = d->precision == ANIHIP_MLP_F16X3;
 
     // 1. bucket by species
-    ANIHIP_CHECK_HIP(hipMemsetAsync(w.ctl, 0, sizeof(int) * CTL_WORDS, stream));
+    ANIHIP_CHECK_HIP(hipMemsetAsync(w.ctl, 0, sizeof(int) * (CTL_WORDS + AMAX_WORDS), stream));
     const unsigned nblk = (unsigned)((n + 255) / 256);
     const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
     hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl);
@@ -499,8 +736,20 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                 p.a_boff = nn.dims[l]; p.c_boff = nn.dims[l + 1];
                 p.b_stride = (int64_t)p.K * p.N; p.bias_stride = p.N;
             }
+            if (h3) {  // B planes shaped like wt[l]: [N][K], K contiguous
+                p.Bh = (const _Float16 *)nn.wh[l];
+                p.k_valid = p.K;
+                p.w_inv_scale = 1.0f / nn.wh_scale[l];
+                if (l == 0) {
+                    p.K = K0p; p.ldbh = K0p; p.bh_stride = 0; p.bh_plane = (int64_t)p.N * K0p;
+                } else {
+                    p.ldbh = p.K; p.bh_stride = (int64_t)p.N * p.K; p.bh_plane = (int64_t)M * p.N * p.K;
+                }
+            }
         }
-        launch_gemm<EPI_BIAS_CELU>(stream, g);
+        g.amax = w.amax; g.amax_out = h3 ? l : -1; g.amax_in = (h3 && l > 0) ? l - 1 : -1;
+        g.a_static_scale = 4.0f;  // layer-0 input: |aev| < 16376 by construction (see include/anihip.h)
+        launch_gemm<EPI_BIAS_CELU>(stream, g, h3);
     }
 
     // 3. output layer (+ seed of the backward pass, written in place over the last activations)
@@ -514,6 +763,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         h.ctl = w.ctl; h.perm = w.perm; h.act = w.act[nh - 1]; h.ld = w.ld[nh - 1];
         h.atomic_e = atomic_e; h.member_e = member_e; h.n_atoms = n_atoms; h.S = S; h.M = M;
         h.inv_alpha = inv_alpha; h.want_grad = grad_aev ? 1 : 0;
+        h.amax = h3 ? w.amax : nullptr; h.amax_out = 3;
         int64_t blocks = (n + 3) / 4;
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(k_head, dim3((unsigned)blocks), dim3(256), 0, stream, h);
@@ -538,16 +788,28 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                 GemmProblem &p = g.prob[s];
                 p.B = nn.wt[l]; p.bias = nullptr; p.bias_stride = 0;
                 if (l == 0) {
-                    p.K = nn.dims[1] * M; p.N = ((L + 31) / 32) * 32; p.ldb = p.N;
+                    p.K = nn.dims[1] * M; p.N = K0p; p.ldb = p.N;
                     p.a_boff = 0; p.c_boff = 0; p.b_stride = 0;
                 } else {
                     p.K = nn.dims[l + 1]; p.N = nn.dims[l]; p.ldb = p.N;
                     p.a_boff = nn.dims[l + 1]; p.c_boff = nn.dims[l];
                     p.b_stride = (int64_t)p.K * p.N;
                 }
+                if (h3) {  // B planes shaped like w[l]: [N = layer input index][K = layer output index]
+                    p.Bh = (const _Float16 *)nn.wth[l];
+                    p.k_valid = p.K;
+                    p.w_inv_scale = 1.0f / nn.wh_scale[l];
+                    p.ldbh = p.K;
+                    p.bh_stride = l == 0 ? 0 : (int64_t)p.N * p.K;
+                    p.bh_plane = (l == 0 ? 1 : (int64_t)M) * p.N * p.K;
+                }
             }
-            if (l == 0) launch_gemm<EPI_SCATTER>(stream, g);
-            else launch_gemm<EPI_DCELU>(stream, g);
+            g.amax = w.amax;
+            g.amax_in = h3 ? 3 + (nh - 1 - l) : -1;
+            g.amax_out = (h3 && l > 0) ? 3 + (nh - l) : -1;
+            g.a_static_scale = 1.0f;
+            if (l == 0) launch_gemm<EPI_SCATTER>(stream, g, h3);
+            else launch_gemm<EPI_DCELU>(stream, g, h3);
         }
     }
     ANIHIP_CHECK_HIP(hipGetLastError());

@@ -176,8 +176,14 @@ class PackedNetworks:
 
     def __init__(self, weights: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]],
                  biases: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]], aev_len: int, celu_alpha: float,
-                 device: torch.device) -> None:
-        """weights[m][s][l]: [out, in] (torch.nn.Linear layout) of member m, species s, layer l."""
+                 device: torch.device, precision: str = "f16x3") -> None:
+        """weights[m][s][l]: [out, in] (torch.nn.Linear layout) of member m, species s, layer l.
+
+        precision: "fp32" (exact fp32 MFMA) or "f16x3" (split-fp16 three-product MFMA, ~4e-7 relative
+        error per product, see include/anihip.h)."""
+        if precision not in ("fp32", "f16x3"):
+            raise ValueError(f"unknown MLP precision {precision!r}")
+        self.precision = precision
         M, S = len(weights), len(weights[0])
         nl = len(weights[0][0])
         if not (2 <= nl <= _lib.MAX_LAYERS):
@@ -189,6 +195,7 @@ class PackedNetworks:
         self._keep: tp.List[Tensor] = []
         d = _lib.MlpDesc()
         d.num_species, d.n_members, d.aev_len, d.celu_alpha = S, M, aev_len, celu_alpha
+        d.precision = _lib.MLP_F16X3 if precision == "f16x3" else _lib.MLP_FP32
         k0p = _pad32(aev_len)
         f32 = dict(dtype=torch.float32, device=device)
         for s in range(S):
@@ -232,6 +239,25 @@ class PackedNetworks:
                 net.w[l] = w.data_ptr()
                 net.bias[l] = bias.data_ptr()
                 net.wt[l] = wt.data_ptr() if wt is not None else None
+                if precision == "f16x3" and wt is not None:
+                    # power-of-two scale putting the largest weight into [2^13, 2^14); planes {hi, lo}
+                    amax = float(Wst.abs().max())
+                    scale = 2.0 ** (13 - int(np.floor(np.log2(amax)))) if amax > 0 else 1.0
+                    if l == 0:
+                        bwd_src = torch.zeros((k0p, M * kout), **f32)   # w padded to K0p rows
+                        bwd_src[:kin] = w
+                    else:
+                        bwd_src = w
+                    planes = []
+                    for src in (wt, bwd_src):
+                        x = src * scale
+                        hi = x.to(torch.float16)
+                        lo = (x - hi.to(torch.float32)).to(torch.float16)
+                        planes.append(torch.stack([hi, lo]).contiguous())
+                    self._keep += planes
+                    net.wh[l] = planes[0].data_ptr()
+                    net.wth[l] = planes[1].data_ptr()
+                    net.wh_scale[l] = scale
         self.desc = d
         self._ws: tp.Optional[Tensor] = None
 

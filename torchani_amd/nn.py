@@ -10,6 +10,7 @@ contract as the reference's native MNP path (csrc/mnp.cpp:138-232, csrc/README.m
 """
 from __future__ import annotations
 
+import os
 import typing as tp
 import warnings
 
@@ -76,9 +77,13 @@ class _MLPFunction(torch.autograd.Function):
 
 
 class _EngineContainer(torch.nn.Module):
-    """Shared machinery of ANINetworks / Ensemble: parameter packing cache + engine call."""
+    """Shared machinery of ANINetworks / Ensemble: parameter packing cache + engine call.
+
+    ``mlp_precision`` ("f16x3" default, or "fp32"; env TORCHANI_AMD_MLP_PRECISION) selects the GEMM
+    arithmetic of the hidden layers (include/anihip.h)."""
 
     symbols: tp.Tuple[str, ...]
+    mlp_precision: tp.Optional[str] = None
 
     def _member_networks(self) -> tp.List["ANINetworks"]:
         raise NotImplementedError
@@ -89,13 +94,14 @@ class _EngineContainer(torch.nn.Module):
         if any(p.requires_grad for p in params) and torch.is_grad_enabled():
             warnings.warn("torchani_amd evaluates networks in inference mode: weight gradients are not "
                           "computed by the HIP engine (only d/d aev)")
-        key = (device, tuple(id(m) for m in members), tuple(p._version for p in params),
+        precision = getattr(self, "mlp_precision", None) or os.environ.get("TORCHANI_AMD_MLP_PRECISION", "f16x3")
+        key = (device, precision, tuple(id(m) for m in members), tuple(p._version for p in params),
                tuple(p.data_ptr() for p in params))
         if getattr(self, "_packed_key", None) != key:
             weights = [[[lin.weight for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
             biases = [[[lin.bias for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
             aev_len = weights[0][0][0].shape[1]
-            self._packed = PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device)
+            self._packed = PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, precision)
             self._packed_key = key
         return self._packed
 
