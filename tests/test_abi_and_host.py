@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(lib):
     from torchani_amd import _lib
 
     assert ctypes.sizeof(_lib.AevParams) == 9 * 4
-    assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 5 * 4 * 8 + 4 * 4
+    assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 5 * 4 * 8 + 4 * 4 + 2 * 4 * 8 + 0
     d = _lib.MlpDesc()
     d.num_species, d.n_members, d.aev_len, d.celu_alpha = 2, 8, 1008, 0.1
     for s in range(2):

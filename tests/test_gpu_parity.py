@@ -150,9 +150,9 @@ def test_aev_forward_and_backward(dev, name):
         assert np.all(vjp.cpu().numpy()[g["species"] < 0] == 0)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3-unfused", "fp32"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
-def test_mlp_ensemble(dev, oracle64, name, precision):
+def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     """Networks alone: reference-exact AEVs in, per-atom energies and d/d aev out, for both GEMM
     arithmetics (exact fp32 MFMA and the split-fp16 three-product MFMA)."""
     g = load_golden(name)
@@ -161,7 +161,9 @@ def test_mlp_ensemble(dev, oracle64, name, precision):
     aev = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), g["cell"], g["pbc"])
     ae, ga, me = oracle64.mlp(g["species"], aev, dims, flat, n_members=8, want_members=True)
     model = get_model(g["kind"], g["seed"], dev)
-    model.neural_networks.mlp_precision = precision
+    if precision == "f16x3-unfused":  # layer-by-layer f16x3 GEMMs instead of the fused hidden-stack kernel
+        monkeypatch.setenv("ANIHIP_NO_FUSED_HIDDEN", "1")
+    model.neural_networks.mlp_precision = precision.split("-")[0]
     sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
     a32 = torch.from_numpy(aev.astype(np.float32)).to(dev).requires_grad_(True)
     e = model.neural_networks(sp, a32, atomic=True)
@@ -173,7 +175,7 @@ def test_mlp_ensemble(dev, oracle64, name, precision):
     e_err = np.abs(e.detach().cpu().numpy() - ae.reshape(C, A)).max()
     g_err = np.abs(gr.cpu().numpy().reshape(C * A, -1) - ga).max()
     m_err = np.abs(em.cpu().numpy() - me.reshape(8, C, A)).max()
-    report(f"mlp   {name:22s} {precision:5s} max|e_atom err| = {e_err:.2e}  |d e/d aev err| = {g_err:.2e} "
+    report(f"mlp   {name:22s} {precision:13s} max|e_atom err| = {e_err:.2e}  |d e/d aev err| = {g_err:.2e} "
            f"(max {np.abs(ga).max():.2e})  members {m_err:.2e}")
     assert e_err < E_ATOM_TOL and m_err < E_ATOM_TOL
     assert g_err < 1e-6 + 1e-5 * np.abs(ga).max()

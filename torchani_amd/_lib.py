@@ -13,7 +13,7 @@ import subprocess
 import typing as tp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libanihip.so")
+LIB_PATH = os.environ.get("TORCHANI_AMD_LIB") or os.path.join(_HERE, "libanihip.so")
 SOURCES = ["api.hip", "nbr.hip", "aev.hip", "mlp.hip"]
 HEADERS = ["anihip_common.h", os.path.join("..", "..", "include", "anihip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared"]
@@ -53,6 +53,8 @@ class SpeciesNet(C.Structure):
         ("wh", C.c_void_p * MAX_LAYERS),
         ("wth", C.c_void_p * MAX_LAYERS),
         ("wh_scale", C.c_float * MAX_LAYERS),
+        ("whf", C.c_void_p * MAX_LAYERS),
+        ("wthf", C.c_void_p * MAX_LAYERS),
     ]
 
 

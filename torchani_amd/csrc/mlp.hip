@@ -16,6 +16,8 @@
 //      staged through LDS (A transposed on the way in so both fragment reads are conflict-free
 //      ds_read_b32), register-prefetched double buffering, XCD-aware tile order so the tiles sharing
 //      an A stripe run on one XCD's L2.
+#include <stdlib.h>
+
 #include "anihip_common.h"
 
 namespace anihip {
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs g)
             } else if (EPI == EPI_DCELU) {
                 // stored activation y = celu(x):  celu'(x) = 1 (y > 0)  or  exp(x/alpha) = y/alpha + 1
                 float *cp = g.C + (int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col;
-                const float y = *cp;
+                const float y = __builtin_nontemporal_load(cp);
                 *cp = v * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
             } else {
                 if (col < g.n_store)
@@ -381,7 +383,9 @@ __device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src,
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
+#ifndef ANIHIP_ABLATE_NOLOAD
         if (kt + 1 < nk) gload(kt + 1);
+#endif
         const _Float16 *af = a_frag + buf * STAGE, *bf = b_frag + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < HBK / 16; ++ks) {
@@ -394,17 +398,21 @@ __device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src,
                 blo[nb] = *reinterpret_cast<const h8 *>(bf + H_PLANE + nb * 32 * H_LD + ks * 16);
             }
             // small terms first, independent accumulators between dependent MFMAs
+#ifndef ANIHIP_ABLATE_ONEPROD
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[nb], acc[nb], 0, 0, 0);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[nb], acc[nb], 0, 0, 0);
+#endif
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[nb], acc[nb], 0, 0, 0);
         }
+#ifndef ANIHIP_ABLATE_NOSTORE
         if (kt + 1 < nk) lstore(buf ^ 1);
+#endif
         __syncthreads();
     }
 }
@@ -501,6 +509,459 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
     if (g.amax_out >= 0) amax_update(g.amax, g.amax_out, s, vmax);
 }
 
+// ---- fused hidden stack (f16x3) ----------------------------------------------------------------------
+// The hidden layers behind layer 0 are small (Hl <= 256) and, run as separate GEMMs, are bound by the
+// HBM round trips of their activations (~73 KB per atom).  This kernel keeps them on chip: one
+// workgroup takes 64 atoms of one species and ONE ensemble member through
+//   act0 -> L1 -> act1 -> L2 -> act2 -> output layer (energy) -> d act2 -> d act1 -> d act0
+// reading act0 (layer-0 output) once and overwriting it with d(E)/d(act0) for the final layer-0
+// backward GEMM.  Activations / gradients live in LDS as split-fp16 {hi, lo} planes with a per-tile
+// power-of-two scale (tile max via an LDS atomic).  The weights are pre-packed on the host in MFMA
+// FRAGMENT ORDER ([col block][k step][plane][lane][8 halves]) so every wave streams its B operands
+// straight from L2 into registers with fully coalesced 1-KB loads through a deep register ring: no LDS
+// staging, no barriers inside a GEMM phase (the GEMV-style weight path of the CDNA guide, applied to
+// a 64-row tile).  MFMAs are the three-product v_mfma_f32_32x32x16_f16 of k_gemm_h.
+constexpr int FB_ROWS = 64;     // atoms per workgroup
+constexpr int FB_MAXH = 256;    // largest padded hidden width
+constexpr int FB_DEPTH = 6;     // k steps of B fragments in flight per wave
+constexpr int FRAG = 512;       // halves per fragment plane: 64 lanes x 8
+
+struct FusedSpecies {
+    int H1, H2, H3;                          // padded widths
+    // fragment-ordered planes, per member: [N/32][K/16][2][64][8]
+    const _Float16 *w1, *w2, *w2t, *w1t;     // (N,K) = (H2,H1), (H3,H2), (H2,H3), (H1,H2)
+    float is1, is2;                          // 1 / weight scales of hidden layers 1 and 2
+    const float *b1, *b2;                    // [M][H2], [M][H3]
+    const float *w3, *b3;                    // output layer [M][H3], [M]
+};
+
+struct FusedArgs {
+    FusedSpecies sp[MAX_S];
+    const int *ctl;
+    unsigned *amax;
+    float *act0;       // [n][ld0]: in: layer-0 activations, out: d E / d act0
+    int64_t ld0;
+    const int *perm;
+    float *member_part;  // [n][M] per-member atomic energies (summed by k_fused_finish)
+    int S, M;
+    float alpha, inv_alpha;
+    int want_grad;
+};
+
+__device__ __forceinline__ float pow2_scale_for(float mx)
+{
+    if (!(mx > 0.f)) return 1.0f;
+    const int e = (int)(__float_as_uint(mx) >> 23) - 127;
+    return __uint_as_float((unsigned)(127 + 13 - e) << 23);
+}
+
+// Register ring of B fragments for NB column blocks of one wave.
+template <int NB>
+struct BRing {
+    h8 hi[FB_DEPTH][NB], lo[FB_DEPTH][NB];
+    const _Float16 *base;  // fragment (cb0, ks = 0, plane 0) + lane * 8
+    int ks_stride;         // halves between consecutive k steps      = 2 * FRAG
+    int cb_stride;         // halves between consecutive column blocks = KS * 2 * FRAG
+    int KS;
+    // unconditional (clamped) loads: a branch around a load makes hipcc drain the whole ring with
+    // s_waitcnt vmcnt(0) at every join (CDNA guide, "load everything or hoist the condition")
+    template <int SLOT>
+    __device__ __forceinline__ void load(int ks)
+    {
+        ks = ks < KS ? ks : KS - 1;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const _Float16 *p = base + (int64_t)nb * cb_stride + (int64_t)ks * ks_stride;
+            hi[SLOT][nb] = *(const gh8 *)p;
+            lo[SLOT][nb] = *(const gh8 *)(p + FRAG);
+        }
+    }
+    __device__ __forceinline__ void prime()
+    {
+        load<0>(0); load<1>(1); load<2>(2); load<3>(3); load<4>(4); load<5>(5);
+    }
+};
+
+// acc[nb] += X[wave rows, :] x B[cols]^T over all k steps; A fragments from LDS planes (xa = hi plane of the
+// wave's row, + x_plane = lo), B fragments from the ring.  KS is even; the main loop runs whole groups
+// of FB_DEPTH steps without any branch, the tail (0, 2 or 4 steps) issues no loads.
+template <int NB>
+__device__ __forceinline__ void fb_gemm(f32x16 (&acc)[4], const _Float16 *xa, int x_plane, BRing<NB> &rg)
+{
+    const int fk = (threadIdx.x & 63) >> 5;
+    const _Float16 *af = xa + fk * 8;
+    auto step = [&](const h8 (&bh)[NB], const h8 (&bl)[NB], int ks) {
+        const h8 ahi = *reinterpret_cast<const h8 *>(af + ks * 16);
+        const h8 alo = *reinterpret_cast<const h8 *>(af + x_plane + ks * 16);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bh[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bl[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bh[nb], acc[nb], 0, 0, 0);
+    };
+    int k0 = 0;
+    for (; k0 + FB_DEPTH <= rg.KS; k0 += FB_DEPTH) {
+        step(rg.hi[0], rg.lo[0], k0);     rg.template load<0>(k0 + FB_DEPTH);
+        step(rg.hi[1], rg.lo[1], k0 + 1); rg.template load<1>(k0 + 1 + FB_DEPTH);
+        step(rg.hi[2], rg.lo[2], k0 + 2); rg.template load<2>(k0 + 2 + FB_DEPTH);
+        step(rg.hi[3], rg.lo[3], k0 + 3); rg.template load<3>(k0 + 3 + FB_DEPTH);
+        step(rg.hi[4], rg.lo[4], k0 + 4); rg.template load<4>(k0 + 4 + FB_DEPTH);
+        step(rg.hi[5], rg.lo[5], k0 + 5); rg.template load<5>(k0 + 5 + FB_DEPTH);
+    }
+    const int rem = rg.KS - k0;
+    if (rem >= 2) {
+        step(rg.hi[0], rg.lo[0], k0);
+        step(rg.hi[1], rg.lo[1], k0 + 1);
+    }
+    if (rem >= 4) {
+        step(rg.hi[2], rg.lo[2], k0 + 2);
+        step(rg.hi[3], rg.lo[3], k0 + 3);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ BRing<NB> fb_ring(const _Float16 *w, int64_t member_halves, int m, int N, int K,
+                                             int cb0)
+{
+    BRing<NB> r;
+    r.KS = K >> 4;
+    r.ks_stride = 2 * FRAG;
+    r.cb_stride = r.KS * 2 * FRAG;
+    r.base = w + (int64_t)m * member_halves + (int64_t)cb0 * r.cb_stride + (threadIdx.x & 63) * 8;
+    (void)N;
+    return r;
+}
+
+// One workgroup = 4 waves as 2 (rows) x 2 (column halves).  NB1..NB4 = column blocks of THIS wave in the
+// four GEMM phases (compile-time so the fragment rings live in registers); the kernel body is
+// instantiated for the (few) combinations that occur and dispatched per wave.
+struct FusedCtx {
+    const FusedArgs *g;
+    const FusedSpecies *fs;
+    _Float16 *X1, *XU;
+    unsigned *s_max;
+    int m, n_rows, p0, s;
+};
+
+template <int NB1, int NB2, int NB4>
+__device__ __forceinline__ void fused_body(const FusedCtx &c, int cb1, int cb2, int cb4)
+{
+    // column blocks: phase 1 -> H2 (NB1 @ cb1), phase 2 -> H3 (NB2 @ cb2), phase 3 -> H2 (NB1 @ cb1),
+    // phase 4 -> H1 (NB4 @ cb4)
+    const FusedArgs &g = *c.g;
+    const FusedSpecies &fs = *c.fs;
+    const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3, m = c.m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5, wm = wave >> 1;
+    const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
+    const int x0_plane = FB_ROWS * ld0, x1_plane = FB_ROWS * ld1, x2_plane = FB_ROWS * ld2;
+    _Float16 *X0 = c.XU, *X1 = c.X1, *X2 = c.XU;
+    unsigned &s_max = *c.s_max;
+
+    f32x16 acc[4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    };
+    auto tile_max = [&](float vmax) {  // workgroup max of a non-negative value (two barriers)
+        if (tid == 0) s_max = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0) atomicMax(&s_max, __float_as_uint(vmax));
+        __syncthreads();
+        return __uint_as_float(s_max);
+    };
+
+    // weights of phase 1 start streaming before the activations are converted
+    BRing<NB1> r1 = fb_ring<NB1>(fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H2, H1, cb1);
+    r1.prime();
+
+    // =============== phase 0: act0 tile -> split planes X0 ===============
+    const float sa = amax_scale(g.amax, 0, c.s);
+    {
+        const int row = tid >> 2, q = tid & 3;           // 4 threads per row, interleaved 8-column chunks
+        const int rr = row < c.n_rows ? row : 0;
+        const gf4 *src = (const gf4 *)(g.act0 + (int64_t)(c.p0 + rr) * g.ld0 + (int64_t)m * H1);
+        // all global loads first (clamped, branch-free), then convert + store
+        const int nch = H1 >> 3;                 // 8-column chunks per row (<= 32)
+        v4f va[FB_MAXH / 32][2];
+#pragma unroll
+        for (int it = 0; it < FB_MAXH / 32; ++it) {
+            const int cchunk = min(q + 4 * it, nch - 1);
+            va[it][0] = src[2 * cchunk];
+            va[it][1] = src[2 * cchunk + 1];
+        }
+#pragma unroll
+        for (int it = 0; it < FB_MAXH / 32; ++it) {
+            const int cchunk = q + 4 * it;
+            if (cchunk < nch) {
+                h8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = (e < 4 ? va[it][0][e & 3] : va[it][1][e & 3]) * sa;
+                    const _Float16 h = (_Float16)x;
+                    hi[e] = h;
+                    lo[e] = (_Float16)(x - (float)h);
+                }
+                *reinterpret_cast<h8 *>(X0 + row * ld0 + cchunk * 8) = hi;
+                *reinterpret_cast<h8 *>(X0 + x0_plane + row * ld0 + cchunk * 8) = lo;
+            }
+        }
+    }
+    __syncthreads();
+
+    // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
+    zero_acc();
+    fb_gemm<NB1>(acc, X0 + (wm * 32 + fr) * ld0, x0_plane, r1);
+    BRing<NB2> r2 = fb_ring<NB2>(fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H3, H2, cb2);
+    r2.prime();
+    float s1;
+    {
+        const float oscale = fs.is1 / sa;
+        float vmax = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB1; ++nb) {
+            const float bias = fs.b1[(int64_t)m * H2 + (cb1 + nb) * 32 + fr];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = celu(acc[nb][r] * oscale + bias, g.alpha, g.inv_alpha);
+                acc[nb][r] = v;
+                vmax = fmaxf(vmax, fabsf(v));
+            }
+        }
+        s1 = pow2_scale_for(tile_max(vmax));
+#pragma unroll
+        for (int nb = 0; nb < NB1; ++nb) {
+            const int col = (cb1 + nb) * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const float x = acc[nb][r] * s1;
+                const _Float16 h = (_Float16)x;
+                X1[row * ld1 + col] = h;
+                X1[x1_plane + row * ld1 + col] = (_Float16)(x - (float)h);
+            }
+        }
+    }
+    __syncthreads();  // X1 complete; every wave is done reading X0 (tile_max barriers) -> XU reusable
+
+    // =============== phase 2: act2 = celu(act1 x W2^T + b2)  (fp32 into XU) ===============
+    zero_acc();
+    fb_gemm<NB2>(acc, X1 + (wm * 32 + fr) * ld1, x1_plane, r2);
+    float *A2 = reinterpret_cast<float *>(c.XU);  // [64][H3 + 4] fp32 (padded: conflict-free quad reads)
+    const int lda2 = H3 + 4;
+    {
+        const float osc2 = fs.is2 / s1;
+#pragma unroll
+        for (int nb = 0; nb < NB2; ++nb) {
+            const int col = (cb2 + nb) * 32 + fr;
+            const float bias = fs.b2[(int64_t)m * H3 + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                A2[row * lda2 + col] = celu(acc[nb][r] * osc2 + bias, g.alpha, g.inv_alpha);
+            }
+        }
+    }
+    __syncthreads();
+
+    // =============== output layer + backward seed ===============
+    // thread = (row = tid >> 2, quarter = tid & 3): dot over a quarter of the columns, quad reduce
+    const int hrow = tid >> 2, part = tid & 3;
+    const int per = H3 >> 2;
+    float gv[FB_MAXH / 4];
+    float gmax = 0.f;
+    {
+        const float *w3 = fs.w3 + (int64_t)m * H3;
+        const float invM = 1.0f / (float)g.M;
+        float e = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < FB_MAXH / 4; ++cc) {
+            // column = cc * 4 + part: the 4 threads of a row read 4 consecutive floats.  Loads are
+            // unconditional (clamped) so the compiler keeps them all in flight; the tail is masked.
+            const bool ok = cc < per;
+            const int col = (ok ? cc : per - 1) * 4 + part;
+            const float y = A2[hrow * lda2 + col];
+            float w = w3[col];
+            w = ok ? w : 0.f;
+            e += y * w;
+            gv[cc] = invM * w * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+            gmax = fmaxf(gmax, fabsf(gv[cc]));
+        }
+        e += __shfl_xor(e, 1);
+        e += __shfl_xor(e, 2);
+        if (part == 0 && hrow < c.n_rows) g.member_part[(int64_t)(c.p0 + hrow) * g.M + m] = e + fs.b3[m];
+    }
+    if (!g.want_grad) return;
+    BRing<NB1> r3 = fb_ring<NB1>(fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H2, H3, cb1);
+    r3.prime();
+    const float s2 = pow2_scale_for(tile_max(gmax));  // barriers inside: all fp32 reads of A2 are done
+#pragma unroll
+    for (int cc = 0; cc < FB_MAXH / 4; ++cc) {
+        if (cc < per) {
+            const int col = cc * 4 + part;
+            const float x = gv[cc] * s2;
+            const _Float16 h = (_Float16)x;
+            X2[hrow * ld2 + col] = h;
+            X2[x2_plane + hrow * ld2 + col] = (_Float16)(x - (float)h);
+        }
+    }
+    __syncthreads();
+
+    // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
+    zero_acc();
+    fb_gemm<NB1>(acc, X2 + (wm * 32 + fr) * ld2, x2_plane, r3);
+    BRing<NB4> r4 = fb_ring<NB4>(fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H1, H2, cb4);
+    r4.prime();
+    float s3;
+    {
+        const float osc3 = fs.is2 / s2, inv_s1 = 1.0f / s1;
+        float vmax3 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB1; ++nb) {
+            const int col = (cb1 + nb) * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const float y = ((float)X1[row * ld1 + col] + (float)X1[x1_plane + row * ld1 + col]) * inv_s1;
+                const float v = acc[nb][r] * osc3 * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+                acc[nb][r] = v;
+                vmax3 = fmaxf(vmax3, fabsf(v));
+            }
+        }
+        s3 = pow2_scale_for(tile_max(vmax3));  // barrier: every act1 read above is done
+#pragma unroll
+        for (int nb = 0; nb < NB1; ++nb) {
+            const int col = (cb1 + nb) * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const float x = acc[nb][r] * s3;
+                const _Float16 h = (_Float16)x;
+                X1[row * ld1 + col] = h;
+                X1[x1_plane + row * ld1 + col] = (_Float16)(x - (float)h);
+            }
+        }
+    }
+    __syncthreads();
+
+    // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global, in place ===============
+    zero_acc();
+    fb_gemm<NB4>(acc, X1 + (wm * 32 + fr) * ld1, x1_plane, r4);
+    {
+        const float osc4 = fs.is1 / s3;
+        float vmax4 = 0.f;
+        // all act0 reads first (independent loads in flight together), then the stores: interleaving
+        // load/store per element serialises 64 global round trips (possible aliasing)
+        float yv[NB4][16];
+#pragma unroll
+        for (int nb = 0; nb < NB4; ++nb) {
+            const int col = (cb4 + nb) * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int rr = row < c.n_rows ? row : 0;
+                yv[nb][r] = g.act0[(int64_t)(c.p0 + rr) * g.ld0 + (int64_t)m * H1 + col];
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB4; ++nb) {
+            const int col = (cb4 + nb) * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const float y = yv[nb][r];
+                const float v = acc[nb][r] * osc4 * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+                if (row < c.n_rows) {
+                    g.act0[(int64_t)(c.p0 + row) * g.ld0 + (int64_t)m * H1 + col] = v;
+                    vmax4 = fmaxf(vmax4, fabsf(v));
+                }
+            }
+        }
+        amax_update(g.amax, 5, c.s, vmax4);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hidden_fused(FusedArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 fsm[];
+
+    // ---- tile -> (species, rows, member).  Member-major order: at any time the chip works on one or two
+    // members, whose weights (1.3 MB of planes per member) stay resident in every XCD's L2 ----
+    const int tiles_total = gridDim.x / g.M;
+    const int m = blockIdx.x / tiles_total;
+    int tile = blockIdx.x % tiles_total;
+    const int *ctl = g.ctl;
+    int s = 0, cnt = 0;
+    for (; s < g.S; ++s) {
+        cnt = ctl[CTL_CNT + s];
+        const int nt = (cnt + FB_ROWS - 1) / FB_ROWS;
+        if (tile < nt) break;
+        tile -= nt;
+    }
+    if (s >= g.S) return;
+    const FusedSpecies &fs = g.sp[s];
+    const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
+    const int m0 = tile * FB_ROWS;
+
+    // LDS carve (halves): X1 planes [2][64][H2+8] | XU = max(X0 planes [2][64][H1+8], X2 planes) | s_max
+    FusedCtx c;
+    c.g = &g; c.fs = &fs; c.m = m; c.s = s;
+    c.n_rows = min(FB_ROWS, cnt - m0);
+    c.p0 = ctl[CTL_OFF + s] + m0;
+    c.X1 = fsm;
+    c.XU = fsm + 2 * FB_ROWS * (H2 + 8);
+    const int xu = max(2 * FB_ROWS * (H1 + 8), 2 * FB_ROWS * (H3 + 8));
+    c.s_max = reinterpret_cast<unsigned *>(c.XU + xu);
+
+    // column blocks of this wave (wn = column half): first half gets the extra block of an odd count
+    const int wn = (threadIdx.x >> 6) & 1;
+    auto split = [&](int N, int &cb0, int &nbw) {
+        const int nblk = N >> 5, half = (nblk + 1) >> 1;
+        cb0 = wn * half;
+        nbw = wn == 0 ? half : nblk - half;
+    };
+    int cb1, nb1, cb2, nb2, cb4, nb4;
+    split(H2, cb1, nb1);
+    split(H3, cb2, nb2);
+    split(H1, cb4, nb4);
+    // wave-uniform dispatch on the block counts.  Every barrier is executed by all four waves regardless
+    // of the instantiation they run.  The host only selects this kernel for widths covered here
+    // (fused_key_supported).
+    switch (nb1 * 100 + nb2 * 10 + nb4) {
+#define FB_CASE(a, b, d) case a * 100 + b * 10 + d: fused_body<a, b, d>(c, cb1, cb2, cb4); break;
+        FB_CASE(3, 3, 4) FB_CASE(3, 2, 4)   // 256/192/160 (ANI-2x H), first half of 224/192/160 (C)
+        FB_CASE(3, 2, 3) FB_CASE(2, 2, 3)   // 224/192/160 second half; 192/160/128 (N, O)
+        FB_CASE(2, 1, 2) FB_CASE(2, 2, 2)   // 160/128/96 (S, F, Cl; ANI-1x H, C); 128/128/96 (ANI-1x N, O)
+#undef FB_CASE
+        default: break;
+    }
+}
+
+// sum the per-member energies of the fused kernel: atomic_e = mean_m, optional [M][n_atoms] copy
+__global__ void k_fused_finish(const int *ctl, int S, int M, const int *perm, const float *member_part,
+                               float *atomic_e, float *member_e, int64_t n_atoms)
+{
+    const int64_t n = ctl[CTL_OFF + S];
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int atom = perm[p];
+        float e = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float v = member_part[p * M + m];
+            e += v;
+            if (member_e) member_e[(int64_t)m * n_atoms + atom] = v;
+        }
+        atomic_e[atom] = e / (float)M;
+    }
+}
+
 // ---- output layer: energies + seed of the backward pass --------------------------------------------
 
 struct HeadArgs {
@@ -526,13 +987,20 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs h)
     const int lane = lane_id();
     const int64_t n = h.ctl[CTL_OFF + h.S];
     const int64_t nw = (int64_t)gridDim.x * 4;
+    float gmax = 0.f;   // running max of the backward seed, flushed when the species changes
+    int gs = -1;
     for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nw) {
         int s = 0;
         while (s + 1 < h.S && p >= h.ctl[CTL_OFF + s + 1]) ++s;
+        if (s != gs) {
+            if (gs >= 0 && h.amax && h.want_grad) amax_update(h.amax, h.amax_out, gs, gmax);
+            gs = s;
+            gmax = 0.f;
+        }
         const int Hp = h.Hp[s];
         float *row = h.act + p * h.ld;
         const int atom = h.perm[p];
-        float esum = 0.f, gmax = 0.f;
+        float esum = 0.f;
         const float invM = 1.0f / (float)h.M;
         for (int m = 0; m < h.M; ++m) {
             const float *w = h.w[s] + (int64_t)m * Hp;
@@ -551,8 +1019,8 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs h)
             esum += part;
         }
         if (lane == 0) h.atomic_e[atom] = esum * invM;
-        if (h.amax && h.want_grad) amax_update(h.amax, h.amax_out, s, gmax);
     }
+    if (gs >= 0 && h.amax && h.want_grad) amax_update(h.amax, h.amax_out, gs, gmax);
 }
 
 // padding atoms inside the shard: zero energy / zero gradient rows
@@ -595,6 +1063,7 @@ __global__ __launch_bounds__(256) void k_energy_reduce(int n_mol, int A, int64_t
 struct MlpWorkspace {
     int *ctl;
     unsigned *amax;
+    float *member_part;
     int *perm;
     float *act[ANIHIP_MAX_LAYERS];
     int64_t ld[ANIHIP_MAX_LAYERS];
@@ -612,7 +1081,8 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
     };
     int *ctl = (int *)take(sizeof(int) * (CTL_WORDS + AMAX_WORDS));
     int *perm = (int *)take(sizeof(int) * (size_t)(n + 1));
-    if (w) { w->ctl = ctl; w->amax = (unsigned *)(ctl + CTL_WORDS); w->perm = perm; }
+    float *mpart = (float *)take(sizeof(float) * (size_t)(n + 1) * (size_t)d->n_members);
+    if (w) { w->ctl = ctl; w->amax = (unsigned *)(ctl + CTL_WORDS); w->perm = perm; w->member_part = mpart; }
     const int nh = d->net[0].n_layers - 1;  // hidden layers
     for (int l = 0; l < nh; ++l) {
         int mx = 0;
@@ -659,6 +1129,21 @@ static int check_desc(const anihip_mlp_desc *d)
         }
     }
     return 0;
+}
+
+// widths the fused hidden-stack kernel has instantiations for (see the dispatch in k_hidden_fused)
+static bool fused_dims_supported(int H1, int H2, int H3)
+{
+    if (H1 > FB_MAXH || H2 > FB_MAXH || H3 > FB_MAXH) return false;
+    for (int wn = 0; wn < 2; ++wn) {
+        auto nb = [&](int H) { const int n = H >> 5, half = (n + 1) >> 1; return wn == 0 ? half : n - half; };
+        const int key = nb(H2) * 100 + nb(H3) * 10 + nb(H1);
+        const int ok[] = {334, 324, 323, 223, 212, 222};
+        bool f = false;
+        for (int k : ok) f = f || k == key;
+        if (!f) return false;
+    }
+    return true;
 }
 
 template <int EPI>
@@ -711,8 +1196,18 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         return (mx + BN - 1) / BN;
     };
 
+    // fused hidden stack (f16x3, three hidden layers of width <= 256): layer-0 GEMM, one fused kernel for
+    // everything behind it, layer-0 backward GEMM
+    bool fused = h3 && nh == 3;
+    for (int s = 0; s < S && fused; ++s) {
+        const anihip_species_net &nn = d->net[s];
+        fused = fused && nn.whf[1] && nn.whf[2] && nn.wthf[1] && nn.wthf[2] &&
+                fused_dims_supported(nn.dims[1], nn.dims[2], nn.dims[3]);
+    }
+    if (const char *e = getenv("ANIHIP_NO_FUSED_HIDDEN")) fused = fused && e[0] == '0';
+
     // 2. forward through the hidden layers
-    for (int l = 0; l < nh; ++l) {
+    for (int l = 0; l < (fused ? 1 : nh); ++l) {
         GemmArgs g{};
         g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha;
         g.nrow_tiles_ub = nrow_ub;
@@ -752,8 +1247,36 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         launch_gemm<EPI_BIAS_CELU>(stream, g, h3);
     }
 
+    if (fused) {
+        FusedArgs f{};
+        size_t lds = 0;
+        for (int s = 0; s < S; ++s) {
+            const anihip_species_net &nn = d->net[s];
+            FusedSpecies &fs = f.sp[s];
+            fs.H1 = nn.dims[1]; fs.H2 = nn.dims[2]; fs.H3 = nn.dims[3];
+            fs.w1 = (const _Float16 *)nn.whf[1]; fs.w2 = (const _Float16 *)nn.whf[2];
+            fs.w2t = (const _Float16 *)nn.wthf[2]; fs.w1t = (const _Float16 *)nn.wthf[1];
+            fs.is1 = 1.0f / nn.wh_scale[1]; fs.is2 = 1.0f / nn.wh_scale[2];
+            fs.b1 = nn.bias[1]; fs.b2 = nn.bias[2]; fs.w3 = nn.w[3]; fs.b3 = nn.bias[3];
+            const size_t xu = fs.H1 > fs.H3 ? fs.H1 : fs.H3;
+            const size_t halves = 2 * (size_t)FB_ROWS * (fs.H2 + 8) + 2 * (size_t)FB_ROWS * (xu + 8);
+            lds = lds > halves * 2 + 16 ? lds : halves * 2 + 16;
+        }
+        f.ctl = w.ctl; f.amax = w.amax; f.act0 = w.act[0]; f.ld0 = w.ld[0]; f.perm = w.perm;
+        f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
+        f.want_grad = grad_aev ? 1 : 0;
+        ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_hidden_fused,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int64_t tiles = (n + FB_ROWS - 1) / FB_ROWS + S;
+        hipLaunchKernelGGL(k_hidden_fused, dim3((unsigned)(tiles * M)), dim3(256), lds, stream, f);
+        int64_t fb = (n + 255) / 256;
+        if (fb > 2048) fb = 2048;
+        hipLaunchKernelGGL(k_fused_finish, dim3((unsigned)fb), dim3(256), 0, stream, w.ctl, S, M, w.perm,
+                           w.member_part, atomic_e, member_e, n_atoms);
+    }
+
     // 3. output layer (+ seed of the backward pass, written in place over the last activations)
-    {
+    if (!fused) {
         HeadArgs h{};
         for (int s = 0; s < S; ++s) {
             h.w[s] = d->net[s].w[nl - 1];
@@ -771,7 +1294,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
 
     // 4. backward to the AEV rows
     if (grad_aev) {
-        for (int l = nh - 1; l >= 0; --l) {
+        for (int l = fused ? 0 : nh - 1; l >= 0; --l) {
             GemmArgs g{};
             g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha;
             g.nrow_tiles_ub = nrow_ub;
