@@ -28,7 +28,7 @@
 namespace anihip {
 
 constexpr int FWD_WPB = 4;
-constexpr int BWD_WPB = 2;
+constexpr int BWD_WPB = 4;
 constexpr int STAGE_FLOATS = 1024;  // >= L (S<=7: 1008)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float PI_F = 3.14159265358979323846f;
@@ -97,6 +97,25 @@ __device__ __forceinline__ float sum32(float x, float y)
 {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// sums inside a quad / an aligned group of 8 lanes on the VALU (DPP), no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_sum(float v)
+{
+    v += dpp_perm<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_perm<0x4E>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ float oct_sum(float v)
+{
+    v = quad_sum(v);
+    v += dpp_perm<0x141>(v);  // row_half_mirror: lane l <-> 7 - l of each 8-lane half row
+    return v;
 }
 
 // branch-free (j,k) decode of pair t of a block (see decode_pair); `rect` = INT_MAX for rectangles
@@ -362,23 +381,18 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
     const float4 *__restrict__ ent, const float *__restrict__ grad_aev, float *__restrict__ grad_coords)
 {
     constexpr int AQ = NA / 4, ZQ = NZ / 4;
-    __shared__ float4 s_nb[BWD_WPB][MAXR];    // ux uy uz r (all neighbors)
-    __shared__ float2 s_rad[BWD_WPB][MAXR];   // 0.25 fc, 0.25 fc'   (Rcr)
-    __shared__ float4 s_afc[BWD_WPB][MAXA];   // fc, fc', 1/r, -    (Rca)
-    __shared__ float s_g[BWD_WPB][3][MAXR];   // per-neighbor gradient accumulators
-    __shared__ uint32_t s_j[BWD_WPB][MAXR];
+    // per-wave LDS: only the angular-range neighbors need to be shared between lanes
+    __shared__ float4 s_nb[BWD_WPB][MAXA];    // ux uy uz r
+    __shared__ float4 s_afc[BWD_WPB][MAXA];   // fc, fc', 1/r, bits(j)    (Rca)
+    __shared__ float s_g[BWD_WPB][3][MAXA];   // per-neighbor gradient accumulators
     __shared__ __attribute__((aligned(16))) float s_stage[BWD_WPB][STAGE_FLOATS];
 
     const int wib = threadIdx.x >> 6, lane = lane_id();
     float4 *nb = s_nb[wib];
-    float2 *rad = s_rad[wib];
     float4 *afc = s_afc[wib];
     float *gx = s_g[wib][0], *gy = s_g[wib][1], *gz = s_g[wib][2];
-    uint32_t *jx = s_j[wib];
     float *stage = s_stage[wib];
 
-    const int rp = lane >> 3, rsq = lane & 7;
-    const float shfR0 = tab[TAB_SHFR + rsq], shfR1 = tab[TAB_SHFR + rsq + 8];
     const int p = lane >> 2, q = lane & 3;
     float shfA[AQ], cosZ[ZQ], sinZ[ZQ];
 #pragma unroll
@@ -388,71 +402,101 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
         cosZ[v] = tab[TAB_COSZ + q + 4 * v];
         sinZ[v] = tab[TAB_SINZ + q + 4 * v];
     }
+    float shfR[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) shfR[k] = tab[TAB_SHFR + k];   // wave-uniform
     const float pi_rcr = PI_F / a.Rcr, pi_rca = PI_F / a.Rca;
+    const float rev_rcr = 0.5f / a.Rcr, rev_rca = 0.5f / a.Rca;  // v_sin/v_cos take revolutions
     const int L4 = a.L >> 2;
 
     const int64_t nw = (int64_t)gridDim.x * BWD_WPB;
-    for (int64_t i = lo + blockIdx.x * (int64_t)BWD_WPB + wib; i < hi; i += nw) {
-        if (species[i] < 0) continue;
-        const uint32_t *m = meta + (size_t)i * META_W;
-        const uint32_t start = m[0], cntw = m[1];
-        const int nA = uniform((int)(cntw & 0xFFFFu)), nF = uniform((int)(cntw >> 16));
-        const int nR = nA + nF;
-        if (nR == 0) continue;
-        const uint64_t pkA = ((uint64_t)(uint32_t)uniform((int)m[3]) << 32) | (uint32_t)uniform((int)m[2]);
-        const uint64_t pkF = ((uint64_t)(uint32_t)uniform((int)m[5]) << 32) | (uint32_t)uniform((int)m[4]);
+    int64_t i = lo + blockIdx.x * (int64_t)BWD_WPB + wib;
+    // software pipeline over atoms (as in the forward kernel): the header, the first 128 neighbor entries
+    // and the dE/dAEV row of atom i+nw are in flight while atom i is processed
+    uint32_t hw = hdr_load(meta, species, i, i < hi);
+    AtomHdr h = hdr_decode(hw);
+    const float4 zero4 = make_float4(1.f, 0.f, 0.f, 0.f);
+    float4 e0 = zero4, e1 = zero4, gr0, gr1, gr2, gr3;
+    // (a macro, not a lambda: captured register arrays would be spilled to scratch)
+#define ANIHIP_BWD_ISSUE(ia, hh)                                                                         \
+    {                                                                                                    \
+        e0 = zero4;                                                                                      \
+        e1 = zero4;                                                                                      \
+        const bool ok_ = (ia) < hi && (hh).sp >= 0 && (hh).nA + (hh).nF > 0;                             \
+        const int n_ = ok_ ? (hh).nA + (hh).nF : 0;                                                      \
+        if (lane < n_) e0 = ent[(hh).start + lane];                                                      \
+        if (lane + WAVE < n_) e1 = ent[(hh).start + lane + WAVE];                                        \
+        const float4 *g4_ = reinterpret_cast<const float4 *>(grad_aev + (size_t)((ia) < hi ? (ia) : lo) * a.L); \
+        gr0 = g4_[lane];                                                                                 \
+        gr1 = g4_[lane + WAVE];                                                                          \
+        gr2 = g4_[lane + 2 * WAVE];                                                                      \
+        gr3 = g4_[min(lane + 3 * WAVE, L4 - 1)];                                                         \
+    }
+    ANIHIP_BWD_ISSUE(i, h)
+    uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
 
-        const float4 *g4 = reinterpret_cast<const float4 *>(grad_aev + (size_t)i * a.L);
-        float4 *st4 = reinterpret_cast<float4 *>(stage);
-        for (int f = lane; f < L4; f += WAVE) st4[f] = g4[f];
-        for (int e = lane; e < nR; e += WAVE) {
-            const float4 d = ent[start + e];
-            const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
-            const float inv = 1.0f / r;
-            nb[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, r);
-            jx[e] = __float_as_uint(d.w) & IDX_MASK;
-            float sn, cs;
-            sincosf(r * pi_rcr, &sn, &cs);
-            rad[e] = make_float2(0.25f * (0.5f * cs + 0.5f), 0.25f * (-0.5f * pi_rcr * sn));
-            if (e < nA) {
-                sincosf(r * pi_rca, &sn, &cs);
-                afc[e] = make_float4(0.5f * cs + 0.5f, -0.5f * pi_rca * sn, inv, 0.f);
-            }
-        }
-        wave_sync();
-
-        // ---- radial: visits every neighbor exactly once => initialises the accumulators ----
-        {
-            int oA = 0, oF = 0;
-            for (int t = 0; t < a.S; ++t) {
-                const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t), n = cA + cF;
-                const float w0 = stage[t * 16 + rsq], w1 = stage[t * 16 + 8 + rsq];
-                for (int b = 0; b < n; b += 8) {
-                    const int idx = b + rp;
-                    const bool v = idx < n;
-                    int e = idx < cA ? oA + idx : nA + oF + (idx - cA);
-                    e = v ? e : 0;
-                    const float4 U = nb[e];
-                    const float2 ff = rad[e];
-                    const float d0 = U.w - shfR0, d1 = U.w - shfR1;
-                    const float e0 = __builtin_amdgcn_exp2f(a.kR * d0 * d0);
-                    const float e1 = __builtin_amdgcn_exp2f(a.kR * d1 * d1);
+    for (; i < hi; i += nw) {
+        const int nA = h.nA, nR = h.nA + h.nF;
+        const uint64_t pkA = h.pkA;
+        const bool skip = h.sp < 0 || nR == 0;
+        const uint32_t start = h.start;
+        float sx = 0.f, sy = 0.f, sz_ = 0.f;   // sum of everything pushed onto neighbors (-> central atom)
+        if (!skip) {
+            float4 *st4 = reinterpret_cast<float4 *>(stage);
+            st4[lane] = gr0;
+            st4[lane + WAVE] = gr1;
+            st4[lane + 2 * WAVE] = gr2;
+            if (lane + 3 * WAVE < L4) st4[lane + 3 * WAVE] = gr3;
+            wave_sync();
+            // ---- per-neighbor pass (lane = neighbor): geometry, cutoffs and the WHOLE radial backward.
+            // dE/dr of a neighbor needs only that neighbor: 16 exp2 per lane, no cross-lane reduction.
+            // Far neighbors (r > Rca) are finished here and go straight to the global accumulator.
+            for (int c0 = 0; c0 < nR; c0 += WAVE) {
+                const int e = c0 + lane;
+                float4 d = c0 == 0 ? e0 : (c0 == WAVE ? e1 : zero4);
+                if (c0 >= 2 * WAVE && e < nR) d = ent[start + e];
+                const bool ve = e < nR;
+                const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+                const float inv = 1.0f / r;
+                const float ux = d.x * inv, uy = d.y * inv, uz = d.z * inv;
+                const uint32_t wbits = __float_as_uint(d.w);
+                const int t = ve ? (int)(wbits >> 28) : 0;
+                const float fcr = 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f;       // 0.25 fc
+                const float dfcr = -0.125f * pi_rcr * __builtin_amdgcn_sinf(r * rev_rcr);    // 0.25 fc'
+                float dR = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float dd = r - shfR[k];
+                    const float ex = __builtin_amdgcn_exp2f(a.kR * dd * dd);
                     // d/dr [exp(-eta d^2) fc] = exp(..) (fc' - 2 eta d fc)
-                    float dR = w0 * e0 * (ff.y - 2.0f * a.EtaR * d0 * ff.x) +
-                               w1 * e1 * (ff.y - 2.0f * a.EtaR * d1 * ff.x);
-                    dR += __shfl_xor(dR, 1);
-                    dR += __shfl_xor(dR, 2);
-                    dR += __shfl_xor(dR, 4);
-                    if (v && rsq == 0) {
-                        gx[e] = dR * U.x;
-                        gy[e] = dR * U.y;
-                        gz[e] = dR * U.z;
+                    dR += stage[t * 16 + k] * ex * (dfcr - 2.0f * a.EtaR * dd * fcr);
+                }
+                dR = ve ? dR : 0.f;
+                const float Gx = dR * ux, Gy = dR * uy, Gz = dR * uz;
+                if (ve) {
+                    if (e < nA) {
+                        nb[e] = make_float4(ux, uy, uz, r);
+                        afc[e] = make_float4(0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f,
+                                             -0.5f * pi_rca * __builtin_amdgcn_sinf(r * rev_rca), inv,
+                                             __uint_as_float(wbits & IDX_MASK));
+                        gx[e] = Gx;
+                        gy[e] = Gy;
+                        gz[e] = Gz;
+                    } else {
+                        float *gc = grad_coords + 3 * (size_t)(wbits & IDX_MASK);
+                        atomicAdd(gc + 0, Gx);
+                        atomicAdd(gc + 1, Gy);
+                        atomicAdd(gc + 2, Gz);
+                        sx += Gx; sy += Gy; sz_ += Gz;
                     }
                 }
-                oA += cA;
-                oF += cF;
             }
         }
+        // prefetch the next atom
+        h = hdr_decode(hw_next);
+        ANIHIP_BWD_ISSUE(i + nw, h)
+        hw_next = hdr_load(meta, species, i + 2 * nw, i + 2 * nw < hi);
+        if (skip) continue;
         wave_sync();
 
         // ---- angular ----
@@ -471,24 +515,38 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
                     }
                     const int div = same ? ((nj - 1) >> 1) : nk;
                     const float inv_div = div > 0 ? 1.0f / (float)div : 0.f;
+                    const int rect = same ? nj * div : 0x7FFFFFFF;
+                    const int half = nj >> 1;
                     const float *blk = stage + a.radlen + P * 32;
                     float w[AQ][NZ];
 #pragma unroll
                     for (int u = 0; u < AQ; ++u)
 #pragma unroll
                         for (int z = 0; z < NZ; ++z) w[u][z] = blk[(q + 4 * u) * NZ + z];
+                    // software pipelined: the LDS reads of step s+1 are issued before the arithmetic of s
+                    int jr, kr;
+                    decode_pair2(same, min(p, np - 1), nj, div, inv_div, rect, half, jr, kr);
+                    int ej = oj + jr, ek = ok + kr;
+                    float4 J = nb[ej], K = nb[ek], FJ = afc[ej], FK = afc[ek];
                     for (int t0 = 0; t0 < np; t0 += 16) {
-                        const int t = t0 + p;
-                        const bool v = t < np;
-                        int jr, kr;
-                        decode_pair(same, v ? t : 0, nj, nk, inv_div, div, jr, kr);
-                        const int ej = oj + jr, ek = ok + kr;
-                        const float4 J = nb[ej], K = nb[ek];
-                        const float4 FJ = afc[ej], FK = afc[ek];
-                        const float c = J.x * K.x + J.y * K.y + J.z * K.z;
+                        const bool v = t0 + p < np;
+                        const float4 Jc = J, Kc = K, FJc = FJ, FKc = FK;
+                        const int ejc = ej, ekc = ek;
+                        if (t0 + 16 < np) {
+                            decode_pair2(same, min(t0 + 16 + p, np - 1), nj, div, inv_div, rect, half, jr, kr);
+                            ej = oj + jr;
+                            ek = ok + kr;
+                            J = nb[ej];
+                            K = nb[ek];
+                            FJ = afc[ej];
+                            FK = afc[ek];
+                        }
+                        const float c = Jc.x * Kc.x + Jc.y * Kc.y + Jc.z * Kc.z;
                         const float ct = 0.95f * c;
-                        const float st = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ct * ct, 0.f));
-                        const float rm = 0.5f * (J.w + K.w);
+                        const float st2 = fmaxf(1.0f - ct * ct, 1e-12f);
+                        const float rst = __builtin_amdgcn_rsqf(st2);   // 1 / sin(theta)
+                        const float st = st2 * rst;
+                        const float rm = 0.5f * (Jc.w + Kc.w);
                         // this lane's quarter of the factors
                         float f1q[ZQ], df1q[ZQ], f2[AQ], df2[AQ];
 #pragma unroll
@@ -506,34 +564,38 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
                             f2[u] = __builtin_amdgcn_exp2f(a.kA * d * d);
                             df2[u] = -2.0f * a.EtaA * d * f2[u];  // d/d rm
                         }
+                        // C0 = sum w f1 f2, Cth = sum w f1' f2, CR = sum w f1 f2': contract the shift index first
                         float C0 = 0.f, Cth = 0.f, CR = 0.f;
 #pragma unroll
                         for (int z = 0; z < NZ; ++z) {
                             const float f1 = quad_bcast_rt(f1q[z >> 2], z & 3);
                             const float df1 = quad_bcast_rt(df1q[z >> 2], z & 3);
+                            float A = 0.f, B = 0.f;
 #pragma unroll
                             for (int u = 0; u < AQ; ++u) {
-                                const float wf2 = w[u][z] * f2[u];
-                                C0 += wf2 * f1;
-                                Cth += wf2 * df1;
-                                CR += w[u][z] * df2[u] * f1;
+                                A += w[u][z] * f2[u];
+                                B += w[u][z] * df2[u];
                             }
+                            C0 += A * f1;
+                            Cth += A * df1;
+                            CR += B * f1;
                         }
-                        C0 += __shfl_xor(C0, 1);  Cth += __shfl_xor(Cth, 1);  CR += __shfl_xor(CR, 1);
-                        C0 += __shfl_xor(C0, 2);  Cth += __shfl_xor(Cth, 2);  CR += __shfl_xor(CR, 2);
-                        const float fcc = v ? FJ.x * FK.x : 0.f;
-                        const float kth = Cth * fcc * (-0.95f / st);
-                        const float k1 = 0.5f * CR * fcc + (v ? C0 * FJ.y * FK.x : 0.f);
-                        const float k2 = 0.5f * CR * fcc + (v ? C0 * FJ.x * FK.y : 0.f);
+                        C0 = quad_sum(C0);
+                        Cth = quad_sum(Cth);
+                        CR = quad_sum(CR);
+                        const float fcc = v ? FJc.x * FKc.x : 0.f;
+                        const float kth = Cth * fcc * (-0.95f * rst);
+                        const float k1 = 0.5f * CR * fcc + (v ? C0 * FJc.y * FKc.x : 0.f);
+                        const float k2 = 0.5f * CR * fcc + (v ? C0 * FJc.x * FKc.y : 0.f);
                         // component q of the two gradient vectors (q == 3 idles)
-                        const float uj = q == 0 ? J.x : (q == 1 ? J.y : J.z);
-                        const float uk = q == 0 ? K.x : (q == 1 ? K.y : K.z);
-                        const float gj = kth * (uk - c * uj) * FJ.z + k1 * uj;
-                        const float gk = kth * (uj - c * uk) * FK.z + k2 * uk;
+                        const float uj = q == 0 ? Jc.x : (q == 1 ? Jc.y : Jc.z);
+                        const float uk = q == 0 ? Kc.x : (q == 1 ? Kc.y : Kc.z);
+                        const float gj = kth * (uk - c * uj) * FJc.z + k1 * uj;
+                        const float gk = kth * (uj - c * uk) * FKc.z + k2 * uk;
                         if (v && q < 3) {
                             float *gq = q == 0 ? gx : (q == 1 ? gy : gz);
-                            atomicAdd(&gq[ej], gj);  // LDS ds_add_f32
-                            atomicAdd(&gq[ek], gk);
+                            atomicAdd(&gq[ejc], gj);  // LDS ds_add_f32
+                            atomicAdd(&gq[ekc], gk);
                         }
                     }
                     ok += nk;
@@ -542,11 +604,10 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
             }
         }
         wave_sync();
-        // ---- scatter: +G to each neighbor, -sum(G) to the central atom ----
-        float sx = 0.f, sy = 0.f, sz_ = 0.f;
-        for (int e = lane; e < nR; e += WAVE) {
+        // ---- scatter: +G to each angular-range neighbor, -sum(all G) to the central atom ----
+        for (int e = lane; e < nA; e += WAVE) {
             const float x = gx[e], y = gy[e], z = gz[e];
-            float *gc = grad_coords + 3 * (size_t)jx[e];
+            float *gc = grad_coords + 3 * (size_t)__float_as_uint(afc[e].w);
             atomicAdd(gc + 0, x);
             atomicAdd(gc + 1, y);
             atomicAdd(gc + 2, z);
@@ -640,7 +701,7 @@ extern "C" int anihip_aev_backward(void *stream, const anihip_aev_params *p, con
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
     if (hi == lo) return 0;
-    dim3 grid(persistent_blocks(hi - lo, BWD_WPB, 5)), block(BWD_WPB * WAVE);
+    dim3 grid(persistent_blocks(hi - lo, BWD_WPB, 4)), block(BWD_WPB * WAVE);
     if (p->n_shf_a == 8)
         hipLaunchKernelGGL((k_aev_bwd<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
                            meta, (const float4 *)ent, grad_aev, grad_coords);
