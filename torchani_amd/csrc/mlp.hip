@@ -310,8 +310,11 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const h8 gh8;
 
 constexpr int HBK = 32;            // reduction depth per LDS stage
-constexpr int H_LD = HBK + 8;      // halves per LDS row: 80 B stride -> conflict-free ds_read_b128
-constexpr int H_PLANE = BM * H_LD; // halves per operand plane per stage
+// LDS stage: 4 planes (A_hi, A_lo, B_hi, B_lo) of [128 rows][32 halves] = 64-B rows, no padding; the four
+// 16-B pieces of a row are XOR-swizzled with (row >> 2) & 3, which makes both the staging stores
+// (8-lane groups: two whole rows) and the MFMA fragment loads (ds_read_b128, 16-lane groups) conflict-free.
+constexpr int H_PLANE = BM * HBK;  // halves per operand plane per stage
+__device__ __forceinline__ int h_off(int row, int piece) { return row * HBK + ((piece ^ ((row >> 2) & 3)) << 3); }
 
 __device__ __forceinline__ float amax_scale(const unsigned *amax, int stage, int s)
 {
@@ -333,87 +336,102 @@ __device__ __forceinline__ void amax_update(unsigned *amax, int stage, int s, fl
         atomicMax(amax + (stage * MAX_S + s) * AMAX_SLOTS + (blockIdx.x & (AMAX_SLOTS - 1)), __float_as_uint(m));
 }
 
+// K loop of one 128 x (32 NB) tile.  Thread t stages rows t>>2 and 64 + (t>>2), 16-B piece t&3 of all four
+// planes; global loads run two stages ahead of the MFMAs (register ring), LDS is double buffered, one
+// barrier per stage.
+struct HStage {
+    v4f a[2][2];   // [row pass][2 x float4 = 8 k values]
+    h8 bh[2], bl[2];
+};
+
 template <int NB>
-__device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src, int a_k, int k_valid,
-                                             float sa, const _Float16 *bh_src, int64_t bh_plane, int nk,
-                                             _Float16 *a_dst, _Float16 *b_dst, const _Float16 *a_frag,
-                                             const _Float16 *b_frag)
+__device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src0, const gf4 *a_src1,
+                                             int k_valid, float sa, const _Float16 *b_src0,
+                                             const _Float16 *b_src1, int64_t bh_plane, int nk, _Float16 *sm,
+                                             int wave)
 {
     constexpr int STAGE = 4 * H_PLANE;  // halves per LDS stage: A_hi, A_lo, B_hi, B_lo
-    v4f ra[4];
-    h8 rbh[2], rbl[2];
-    auto gload = [&](int kt) {
-        const bool ok = kt * HBK + a_k < k_valid;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ra[j] = a_src[ok ? kt * (HBK / 4) + j : 0];
-            if (!ok) ra[j] = v4f{0.f, 0.f, 0.f, 0.f};
-        }
-        const gh8 *bp = (const gh8 *)(bh_src + kt * HBK);
-        rbh[0] = bp[0];
-        rbh[1] = bp[1];
-        const gh8 *bl = (const gh8 *)(bh_src + bh_plane + kt * HBK);
-        rbl[0] = bl[0];
-        rbl[1] = bl[1];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int srow = tid >> 2, piece = tid & 3;
+    const int fr = lane & 31, fk = lane >> 5;
+    const v4f z4 = v4f{0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](HStage &st, int kt) {
+        // clamped, branch-free: columns >= k_valid re-read chunk 0 and are zeroed by a select
+        const bool ok = kt * HBK + piece * 8 < k_valid;
+        const int o = ok ? kt * (HBK / 4) : 0;
+        st.a[0][0] = a_src0[o]; st.a[0][1] = a_src0[o + 1];
+        st.a[1][0] = a_src1[o]; st.a[1][1] = a_src1[o + 1];
+        if (!ok) { st.a[0][0] = z4; st.a[0][1] = z4; st.a[1][0] = z4; st.a[1][1] = z4; }
+        st.bh[0] = *(const gh8 *)(b_src0 + kt * HBK);
+        st.bl[0] = *(const gh8 *)(b_src0 + bh_plane + kt * HBK);
+        st.bh[1] = *(const gh8 *)(b_src1 + kt * HBK);
+        st.bl[1] = *(const gh8 *)(b_src1 + bh_plane + kt * HBK);
     };
-    auto lstore = [&](int buf) {
-        h8 hi[2], lo[2];
+    auto lstore = [&](const HStage &st, int buf) {
+        _Float16 *base = sm + buf * STAGE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int ps = 0; ps < 2; ++ps) {
+            h8 hi, lo;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float x = ra[j][c] * sa;
+            for (int c = 0; c < 8; ++c) {
+                const float x = (c < 4 ? st.a[ps][0][c & 3] : st.a[ps][1][c & 3]) * sa;
                 const _Float16 h = (_Float16)x;
-                hi[j >> 1][(j & 1) * 4 + c] = h;
-                lo[j >> 1][(j & 1) * 4 + c] = (_Float16)(x - (float)h);
+                hi[c] = h;
+                lo[c] = (_Float16)(x - (float)h);
             }
-        _Float16 *ad = a_dst + buf * STAGE;
-        *reinterpret_cast<h8 *>(ad) = hi[0];
-        *reinterpret_cast<h8 *>(ad + 8) = hi[1];
-        *reinterpret_cast<h8 *>(ad + H_PLANE) = lo[0];
-        *reinterpret_cast<h8 *>(ad + H_PLANE + 8) = lo[1];
-        _Float16 *bd = b_dst + buf * STAGE;
-        *reinterpret_cast<h8 *>(bd) = rbh[0];
-        *reinterpret_cast<h8 *>(bd + 8) = rbh[1];
-        *reinterpret_cast<h8 *>(bd + H_PLANE) = rbl[0];
-        *reinterpret_cast<h8 *>(bd + H_PLANE + 8) = rbl[1];
+            const int off = h_off(srow + 64 * ps, piece);
+            *reinterpret_cast<h8 *>(base + off) = hi;
+            *reinterpret_cast<h8 *>(base + H_PLANE + off) = lo;
+            *reinterpret_cast<h8 *>(base + 2 * H_PLANE + off) = st.bh[ps];
+            *reinterpret_cast<h8 *>(base + 3 * H_PLANE + off) = st.bl[ps];
+        }
     };
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-#ifndef ANIHIP_ABLATE_NOLOAD
-        if (kt + 1 < nk) gload(kt + 1);
-#endif
-        const _Float16 *af = a_frag + buf * STAGE, *bf = b_frag + buf * STAGE;
+    auto compute = [&](int buf) {
+        const _Float16 *base = sm + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < HBK / 16; ++ks) {
-            const h8 ahi = *reinterpret_cast<const h8 *>(af + ks * 16);
-            const h8 alo = *reinterpret_cast<const h8 *>(af + H_PLANE + ks * 16);
+            const int pc = ks * 2 + fk;
+            const int ao = h_off(wave * 32 + fr, pc);
+            const h8 ahi = *reinterpret_cast<const h8 *>(base + ao);
+            const h8 alo = *reinterpret_cast<const h8 *>(base + H_PLANE + ao);
             h8 bhi[NB], blo[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                bhi[nb] = *reinterpret_cast<const h8 *>(bf + nb * 32 * H_LD + ks * 16);
-                blo[nb] = *reinterpret_cast<const h8 *>(bf + H_PLANE + nb * 32 * H_LD + ks * 16);
+                const int bo = h_off(nb * 32 + fr, pc);
+                bhi[nb] = *reinterpret_cast<const h8 *>(base + 2 * H_PLANE + bo);
+                blo[nb] = *reinterpret_cast<const h8 *>(base + 3 * H_PLANE + bo);
             }
             // small terms first, independent accumulators between dependent MFMAs
-#ifndef ANIHIP_ABLATE_ONEPROD
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[nb], acc[nb], 0, 0, 0);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[nb], acc[nb], 0, 0, 0);
-#endif
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
                 acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[nb], acc[nb], 0, 0, 0);
         }
-#ifndef ANIHIP_ABLATE_NOSTORE
-        if (kt + 1 < nk) lstore(buf ^ 1);
-#endif
+    };
+    // ring of two register stages: s0 holds stage kt+1 (even kt) / kt+2 ..., see the unrolled-by-2 loop
+    HStage s0, s1;
+    gload(s0, 0);
+    gload(s1, min(1, nk - 1));
+    lstore(s0, 0);
+    gload(s0, min(2, nk - 1));
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // stage kt is in LDS buffer 0; registers: s1 = stage kt+1, s0 = stage kt+2
+        compute(0);
+        if (kt + 1 < nk) lstore(s1, 1);
+        gload(s1, min(kt + 3, nk - 1));
         __syncthreads();
+        if (kt + 1 < nk) {
+            compute(1);
+            if (kt + 2 < nk) lstore(s0, 0);
+            gload(s0, min(kt + 4, nk - 1));
+            __syncthreads();
+        }
     }
 }
 
@@ -448,18 +466,19 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
     const float sa = g.amax_in >= 0 ? amax_scale(g.amax, g.amax_in, s) : g.a_static_scale;
     const float out_scale = pr.w_inv_scale / sa;
 
-    // A loader: row = tid>>1, 16 consecutive k (4 x float4 per stage)
-    const int a_row = tid >> 1, a_k = (tid & 1) * 16;
-    const gf4 *a_src;
+    // loaders: thread t -> rows t>>2 and 64 + (t>>2), 8 consecutive k (piece t&3) of every plane
+    const int srow = tid >> 2, piece = tid & 3;
+    const gf4 *a_src0, *a_src1;
     {
-        const int rr = a_row < n_rows ? a_row : 0;
-        const int64_t src_row = g.a_gather ? (int64_t)g.a_gather[p0 + rr] : (int64_t)(p0 + rr);
-        a_src = (const gf4 *)(g.A + src_row * g.lda + (int64_t)bb * pr.a_boff + a_k);
+        const int r0 = srow < n_rows ? srow : 0, r1 = srow + 64 < n_rows ? srow + 64 : 0;
+        const int64_t s0r = g.a_gather ? (int64_t)g.a_gather[p0 + r0] : (int64_t)(p0 + r0);
+        const int64_t s1r = g.a_gather ? (int64_t)g.a_gather[p0 + r1] : (int64_t)(p0 + r1);
+        a_src0 = (const gf4 *)(g.A + s0r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
+        a_src1 = (const gf4 *)(g.A + s1r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
     }
-    // B loader: output column n = tid>>1, 16 consecutive k of both planes
-    const int b_nl = tid >> 1;
-    const int b_n = (n0 + b_nl < pr.N) ? n0 + b_nl : n0;
-    const _Float16 *bh_src = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)b_n * pr.ldbh + a_k;
+    const int bn0 = (n0 + srow < pr.N) ? n0 + srow : n0, bn1 = (n0 + srow + 64 < pr.N) ? n0 + srow + 64 : n0;
+    const _Float16 *b_src0 = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)bn0 * pr.ldbh + piece * 8;
+    const _Float16 *b_src1 = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)bn1 * pr.ldbh + piece * 8;
 
     f32x16 acc[4];
 #pragma unroll
@@ -469,15 +488,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
 
     const int nk = pr.K / HBK;
     const int fr = lane & 31, fk = lane >> 5;
-    _Float16 *a_dst = sm + a_row * H_LD + a_k;
-    _Float16 *b_dst = sm + 2 * H_PLANE + b_nl * H_LD + a_k;
-    const _Float16 *a_frag = sm + (wave * 32 + fr) * H_LD + fk * 8;
-    const _Float16 *b_frag = sm + 2 * H_PLANE + fr * H_LD + fk * 8;
     switch (nb_act) {
-        case 4: gemm_h_kloop<4>(acc, a_src, a_k, pr.k_valid, sa, bh_src, pr.bh_plane, nk, a_dst, b_dst, a_frag, b_frag); break;
-        case 3: gemm_h_kloop<3>(acc, a_src, a_k, pr.k_valid, sa, bh_src, pr.bh_plane, nk, a_dst, b_dst, a_frag, b_frag); break;
-        case 2: gemm_h_kloop<2>(acc, a_src, a_k, pr.k_valid, sa, bh_src, pr.bh_plane, nk, a_dst, b_dst, a_frag, b_frag); break;
-        default: gemm_h_kloop<1>(acc, a_src, a_k, pr.k_valid, sa, bh_src, pr.bh_plane, nk, a_dst, b_dst, a_frag, b_frag); break;
+        case 4: gemm_h_kloop<4>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
+        case 3: gemm_h_kloop<3>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
+        case 2: gemm_h_kloop<2>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
+        default: gemm_h_kloop<1>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
     }
 
     float vmax = 0.f;
@@ -521,7 +536,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
 // straight from L2 into registers with fully coalesced 1-KB loads through a deep register ring: no LDS
 // staging, no barriers inside a GEMM phase (the GEMV-style weight path of the CDNA guide, applied to
 // a 64-row tile).  MFMAs are the three-product v_mfma_f32_32x32x16_f16 of k_gemm_h.
-constexpr int FB_ROWS = 64;     // atoms per workgroup
+constexpr int FB_ROWS = 32;     // atoms per workgroup (32: two workgroups per CU overlap MFMA and epilogue phases)
+constexpr int FB_RB = FB_ROWS / 32;   // 32-row MFMA blocks per wave
+constexpr int FB_TPR = 256 / FB_ROWS; // threads per row in the thread-mapped sections
 constexpr int FB_MAXH = 256;    // largest padded hidden width
 constexpr int FB_DEPTH = 6;     // k steps of B fragments in flight per wave
 constexpr int FRAG = 512;       // halves per fragment plane: 64 lanes x 8
@@ -586,22 +603,33 @@ struct BRing {
 // wave's row, + x_plane = lo), B fragments from the ring.  KS is even; the main loop runs whole groups
 // of FB_DEPTH steps without any branch, the tail (0, 2 or 4 steps) issues no loads.
 template <int NB>
-__device__ __forceinline__ void fb_gemm(f32x16 (&acc)[4], const _Float16 *xa, int x_plane, BRing<NB> &rg)
+__device__ __forceinline__ void fb_gemm(f32x16 (&acc)[4], const _Float16 *xa, int ldx, int x_plane, BRing<NB> &rg)
 {
-    const int fk = (threadIdx.x & 63) >> 5;
-    const _Float16 *af = xa + fk * 8;
+    // this wave: all FB_ROWS rows (FB_RB 32-row blocks) x its NB column blocks; acc[rb * 2 + nb]
+    const int lane = threadIdx.x & 63, fr = lane & 31, fk = lane >> 5;
+    const _Float16 *af = xa + fr * ldx + fk * 8;
     auto step = [&](const h8 (&bh)[NB], const h8 (&bl)[NB], int ks) {
-        const h8 ahi = *reinterpret_cast<const h8 *>(af + ks * 16);
-        const h8 alo = *reinterpret_cast<const h8 *>(af + x_plane + ks * 16);
+        h8 ah[FB_RB], al[FB_RB];
+#pragma unroll
+        for (int rb = 0; rb < FB_RB; ++rb) {
+            ah[rb] = *reinterpret_cast<const h8 *>(af + rb * 32 * ldx + ks * 16);
+            al[rb] = *reinterpret_cast<const h8 *>(af + rb * 32 * ldx + x_plane + ks * 16);
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bh[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < FB_RB; ++rb)
+                acc[rb * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rb], bh[nb], acc[rb * 2 + nb], 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bl[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < FB_RB; ++rb)
+                acc[rb * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], bl[nb], acc[rb * 2 + nb], 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bh[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < FB_RB; ++rb)
+                acc[rb * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], bh[nb], acc[rb * 2 + nb], 0, 0, 0);
     };
     int k0 = 0;
     for (; k0 + FB_DEPTH <= rg.KS; k0 += FB_DEPTH) {
@@ -624,21 +652,22 @@ __device__ __forceinline__ void fb_gemm(f32x16 (&acc)[4], const _Float16 *xa, in
 }
 
 template <int NB>
-__device__ __forceinline__ BRing<NB> fb_ring(const _Float16 *w, int64_t member_halves, int m, int N, int K,
-                                             int cb0)
+__device__ __forceinline__ BRing<NB> fb_ring(const _Float16 *w, int64_t member_halves, int m, int K)
 {
+    // this wave's column blocks are {wave, wave + 4}
     BRing<NB> r;
     r.KS = K >> 4;
     r.ks_stride = 2 * FRAG;
-    r.cb_stride = r.KS * 2 * FRAG;
-    r.base = w + (int64_t)m * member_halves + (int64_t)cb0 * r.cb_stride + (threadIdx.x & 63) * 8;
-    (void)N;
+    const int one_cb = r.KS * 2 * FRAG;
+    r.cb_stride = 4 * one_cb;
+    r.base = w + (int64_t)m * member_halves + (int64_t)(threadIdx.x >> 6) * one_cb + (threadIdx.x & 63) * 8;
     return r;
 }
 
-// One workgroup = 4 waves as 2 (rows) x 2 (column halves).  NB1..NB4 = column blocks of THIS wave in the
-// four GEMM phases (compile-time so the fragment rings live in registers); the kernel body is
-// instantiated for the (few) combinations that occur and dispatched per wave.
+// One workgroup = 4 waves; every wave owns all 64 rows and the column blocks {wave, wave + 4} of each GEMM
+// phase, so each weight fragment is fetched exactly once per workgroup.  NB1 / NB2 / NB4 = number of column
+// blocks (0..2) of THIS wave in the phases producing H2 / H3 / H1 columns (compile-time so the fragment
+// rings live in registers); the body is instantiated for the combinations that occur and dispatched per wave.
 struct FusedCtx {
     const FusedArgs *g;
     const FusedSpecies *fs;
@@ -648,15 +677,13 @@ struct FusedCtx {
 };
 
 template <int NB1, int NB2, int NB4>
-__device__ __forceinline__ void fused_body(const FusedCtx &c, int cb1, int cb2, int cb4)
+__device__ __forceinline__ void fused_body(const FusedCtx &c)
 {
-    // column blocks: phase 1 -> H2 (NB1 @ cb1), phase 2 -> H3 (NB2 @ cb2), phase 3 -> H2 (NB1 @ cb1),
-    // phase 4 -> H1 (NB4 @ cb4)
     const FusedArgs &g = *c.g;
     const FusedSpecies &fs = *c.fs;
     const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3, m = c.m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 31, fk = lane >> 5, wm = wave >> 1;
+    const int fr = lane & 31, fk = lane >> 5;
     const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
     const int x0_plane = FB_ROWS * ld0, x1_plane = FB_ROWS * ld1, x2_plane = FB_ROWS * ld2;
     _Float16 *X0 = c.XU, *X1 = c.X1, *X2 = c.XU;
@@ -678,29 +705,33 @@ __device__ __forceinline__ void fused_body(const FusedCtx &c, int cb1, int cb2, 
         __syncthreads();
         return __uint_as_float(s_max);
     };
+    // element (rb, nb, r) of this wave's accumulators <-> (row, col) of the tile
+    auto row_of = [&](int rb, int r) { return rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk; };
+    auto col_of = [&](int nb) { return (wave + 4 * nb) * 32 + fr; };
 
     // weights of phase 1 start streaming before the activations are converted
-    BRing<NB1> r1 = fb_ring<NB1>(fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H2, H1, cb1);
-    r1.prime();
+    BRing<NB1> r1 = fb_ring<NB1>(fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1);
+    if (NB1) r1.prime();
 
     // =============== phase 0: act0 tile -> split planes X0 ===============
     const float sa = amax_scale(g.amax, 0, c.s);
     {
-        const int row = tid >> 2, q = tid & 3;           // 4 threads per row, interleaved 8-column chunks
+        const int row = tid / FB_TPR, q = tid % FB_TPR;  // FB_TPR threads per row, interleaved 8-column chunks
         const int rr = row < c.n_rows ? row : 0;
         const gf4 *src = (const gf4 *)(g.act0 + (int64_t)(c.p0 + rr) * g.ld0 + (int64_t)m * H1);
         // all global loads first (clamped, branch-free), then convert + store
         const int nch = H1 >> 3;                 // 8-column chunks per row (<= 32)
-        v4f va[FB_MAXH / 32][2];
+        constexpr int NIT = FB_MAXH / 8 / FB_TPR;
+        v4f va[NIT][2];
 #pragma unroll
-        for (int it = 0; it < FB_MAXH / 32; ++it) {
-            const int cchunk = min(q + 4 * it, nch - 1);
+        for (int it = 0; it < NIT; ++it) {
+            const int cchunk = min(q + FB_TPR * it, nch - 1);
             va[it][0] = src[2 * cchunk];
             va[it][1] = src[2 * cchunk + 1];
         }
 #pragma unroll
-        for (int it = 0; it < FB_MAXH / 32; ++it) {
-            const int cchunk = q + 4 * it;
+        for (int it = 0; it < NIT; ++it) {
+            const int cchunk = q + FB_TPR * it;
             if (cchunk < nch) {
                 h8 hi, lo;
 #pragma unroll
@@ -719,75 +750,79 @@ __device__ __forceinline__ void fused_body(const FusedCtx &c, int cb1, int cb2, 
 
     // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
     zero_acc();
-    fb_gemm<NB1>(acc, X0 + (wm * 32 + fr) * ld0, x0_plane, r1);
-    BRing<NB2> r2 = fb_ring<NB2>(fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H3, H2, cb2);
-    r2.prime();
+    if (NB1) fb_gemm<NB1>(acc, X0, ld0, x0_plane, r1);
+    BRing<NB2> r2 = fb_ring<NB2>(fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2);
     float s1;
     {
         const float oscale = fs.is1 / sa;
+        float bias[2] = {0.f, 0.f};
+#pragma unroll
+        for (int nb = 0; nb < NB1; ++nb) bias[nb] = fs.b1[(int64_t)m * H2 + col_of(nb)];
+        if (NB2) r2.prime();
         float vmax = 0.f;
 #pragma unroll
-        for (int nb = 0; nb < NB1; ++nb) {
-            const float bias = fs.b1[(int64_t)m * H2 + (cb1 + nb) * 32 + fr];
+        for (int rb = 0; rb < FB_RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = celu(acc[nb][r] * oscale + bias, g.alpha, g.inv_alpha);
-                acc[nb][r] = v;
-                vmax = fmaxf(vmax, fabsf(v));
-            }
-        }
+            for (int nb = 0; nb < NB1; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = celu(acc[rb * 2 + nb][r] * oscale + bias[nb], g.alpha, g.inv_alpha);
+                    acc[rb * 2 + nb][r] = v;
+                    vmax = fmaxf(vmax, fabsf(v));
+                }
         s1 = pow2_scale_for(tile_max(vmax));
 #pragma unroll
-        for (int nb = 0; nb < NB1; ++nb) {
-            const int col = (cb1 + nb) * 32 + fr;
+        for (int rb = 0; rb < FB_RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                const float x = acc[nb][r] * s1;
-                const _Float16 h = (_Float16)x;
-                X1[row * ld1 + col] = h;
-                X1[x1_plane + row * ld1 + col] = (_Float16)(x - (float)h);
-            }
-        }
+            for (int nb = 0; nb < NB1; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = acc[rb * 2 + nb][r] * s1;
+                    const _Float16 h = (_Float16)x;
+                    const int o = row_of(rb, r) * ld1 + col_of(nb);
+                    X1[o] = h;
+                    X1[x1_plane + o] = (_Float16)(x - (float)h);
+                }
     }
     __syncthreads();  // X1 complete; every wave is done reading X0 (tile_max barriers) -> XU reusable
 
     // =============== phase 2: act2 = celu(act1 x W2^T + b2)  (fp32 into XU) ===============
     zero_acc();
-    fb_gemm<NB2>(acc, X1 + (wm * 32 + fr) * ld1, x1_plane, r2);
-    float *A2 = reinterpret_cast<float *>(c.XU);  // [64][H3 + 4] fp32 (padded: conflict-free quad reads)
-    const int lda2 = H3 + 4;
+    if (NB2) fb_gemm<NB2>(acc, X1, ld1, x1_plane, r2);
+    float *A2 = reinterpret_cast<float *>(c.XU);  // [rows][H3 + 8] fp32 (padded: conflict-free reads)
+    const int lda2 = H3 + 8;
     {
         const float osc2 = fs.is2 / s1;
+        float bias[2] = {0.f, 0.f};
 #pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) {
-            const int col = (cb2 + nb) * 32 + fr;
-            const float bias = fs.b2[(int64_t)m * H3 + col];
+        for (int nb = 0; nb < NB2; ++nb) bias[nb] = fs.b2[(int64_t)m * H3 + col_of(nb)];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                A2[row * lda2 + col] = celu(acc[nb][r] * osc2 + bias, g.alpha, g.inv_alpha);
-            }
-        }
+        for (int rb = 0; rb < FB_RB; ++rb)
+#pragma unroll
+            for (int nb = 0; nb < NB2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    A2[row_of(rb, r) * lda2 + col_of(nb)] =
+                        celu(acc[rb * 2 + nb][r] * osc2 + bias[nb], g.alpha, g.inv_alpha);
     }
     __syncthreads();
 
     // =============== output layer + backward seed ===============
-    // thread = (row = tid >> 2, quarter = tid & 3): dot over a quarter of the columns, quad reduce
-    const int hrow = tid >> 2, part = tid & 3;
-    const int per = H3 >> 2;
-    float gv[FB_MAXH / 4];
+    // thread = (row = tid / FB_TPR, part = tid % FB_TPR): dot over a slice of the columns, reduce over the parts
+    const int hrow = tid / FB_TPR, part = tid % FB_TPR;
+    const int per = H3 / FB_TPR;
+    float gv[FB_MAXH / FB_TPR];
     float gmax = 0.f;
     {
         const float *w3 = fs.w3 + (int64_t)m * H3;
         const float invM = 1.0f / (float)g.M;
         float e = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < FB_MAXH / 4; ++cc) {
-            // column = cc * 4 + part: the 4 threads of a row read 4 consecutive floats.  Loads are
+        for (int cc = 0; cc < FB_MAXH / FB_TPR; ++cc) {
+            // column = cc * FB_TPR + part: the threads of a row read consecutive floats.  Loads are
             // unconditional (clamped) so the compiler keeps them all in flight; the tail is masked.
             const bool ok = cc < per;
-            const int col = (ok ? cc : per - 1) * 4 + part;
+            const int col = (ok ? cc : per - 1) * FB_TPR + part;
             const float y = A2[hrow * lda2 + col];
             float w = w3[col];
             w = ok ? w : 0.f;
@@ -795,18 +830,18 @@ __device__ __forceinline__ void fused_body(const FusedCtx &c, int cb1, int cb2, 
             gv[cc] = invM * w * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
             gmax = fmaxf(gmax, fabsf(gv[cc]));
         }
-        e += __shfl_xor(e, 1);
-        e += __shfl_xor(e, 2);
+#pragma unroll
+        for (int o = 1; o < FB_TPR; o <<= 1) e += __shfl_xor(e, o);
         if (part == 0 && hrow < c.n_rows) g.member_part[(int64_t)(c.p0 + hrow) * g.M + m] = e + fs.b3[m];
     }
     if (!g.want_grad) return;
-    BRing<NB1> r3 = fb_ring<NB1>(fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H2, H3, cb1);
-    r3.prime();
+    BRing<NB1> r3 = fb_ring<NB1>(fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3);
+    if (NB1) r3.prime();
     const float s2 = pow2_scale_for(tile_max(gmax));  // barriers inside: all fp32 reads of A2 are done
 #pragma unroll
-    for (int cc = 0; cc < FB_MAXH / 4; ++cc) {
+    for (int cc = 0; cc < FB_MAXH / FB_TPR; ++cc) {
         if (cc < per) {
-            const int col = cc * 4 + part;
+            const int col = cc * FB_TPR + part;
             const float x = gv[cc] * s2;
             const _Float16 h = (_Float16)x;
             X2[hrow * ld2 + col] = h;
@@ -817,79 +852,79 @@ __device__ __forceinline__ void fused_body(const FusedCtx &c, int cb1, int cb2, 
 
     // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
     zero_acc();
-    fb_gemm<NB1>(acc, X2 + (wm * 32 + fr) * ld2, x2_plane, r3);
-    BRing<NB4> r4 = fb_ring<NB4>(fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H1, H2, cb4);
-    r4.prime();
+    if (NB1) fb_gemm<NB1>(acc, X2, ld2, x2_plane, r3);
+    BRing<NB4> r4 = fb_ring<NB4>(fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2);
+    if (NB4) r4.prime();
     float s3;
     {
         const float osc3 = fs.is2 / s2, inv_s1 = 1.0f / s1;
         float vmax3 = 0.f;
 #pragma unroll
-        for (int nb = 0; nb < NB1; ++nb) {
-            const int col = (cb1 + nb) * 32 + fr;
+        for (int rb = 0; rb < FB_RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                const float y = ((float)X1[row * ld1 + col] + (float)X1[x1_plane + row * ld1 + col]) * inv_s1;
-                const float v = acc[nb][r] * osc3 * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
-                acc[nb][r] = v;
-                vmax3 = fmaxf(vmax3, fabsf(v));
-            }
-        }
+            for (int nb = 0; nb < NB1; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = row_of(rb, r) * ld1 + col_of(nb);
+                    const float y = ((float)X1[o] + (float)X1[x1_plane + o]) * inv_s1;
+                    const float v = acc[rb * 2 + nb][r] * osc3 * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+                    acc[rb * 2 + nb][r] = v;
+                    vmax3 = fmaxf(vmax3, fabsf(v));
+                }
         s3 = pow2_scale_for(tile_max(vmax3));  // barrier: every act1 read above is done
 #pragma unroll
-        for (int nb = 0; nb < NB1; ++nb) {
-            const int col = (cb1 + nb) * 32 + fr;
+        for (int rb = 0; rb < FB_RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                const float x = acc[nb][r] * s3;
-                const _Float16 h = (_Float16)x;
-                X1[row * ld1 + col] = h;
-                X1[x1_plane + row * ld1 + col] = (_Float16)(x - (float)h);
-            }
-        }
+            for (int nb = 0; nb < NB1; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float x = acc[rb * 2 + nb][r] * s3;
+                    const _Float16 h = (_Float16)x;
+                    const int o = row_of(rb, r) * ld1 + col_of(nb);
+                    X1[o] = h;
+                    X1[x1_plane + o] = (_Float16)(x - (float)h);
+                }
     }
     __syncthreads();
 
     // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global, in place ===============
     zero_acc();
-    fb_gemm<NB4>(acc, X1 + (wm * 32 + fr) * ld1, x1_plane, r4);
+    if (NB4) fb_gemm<NB4>(acc, X1, ld1, x1_plane, r4);
     {
         const float osc4 = fs.is1 / s3;
         float vmax4 = 0.f;
         // all act0 reads first (independent loads in flight together), then the stores: interleaving
-        // load/store per element serialises 64 global round trips (possible aliasing)
-        float yv[NB4][16];
+        // load/store per element serialises the global round trips (possible aliasing)
+        float yv[FB_RB][NB4 ? NB4 : 1][16];
 #pragma unroll
-        for (int nb = 0; nb < NB4; ++nb) {
-            const int col = (cb4 + nb) * 32 + fr;
+        for (int rb = 0; rb < FB_RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                const int rr = row < c.n_rows ? row : 0;
-                yv[nb][r] = g.act0[(int64_t)(c.p0 + rr) * g.ld0 + (int64_t)m * H1 + col];
-            }
-        }
+            for (int nb = 0; nb < NB4; ++nb)
 #pragma unroll
-        for (int nb = 0; nb < NB4; ++nb) {
-            const int col = (cb4 + nb) * 32 + fr;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                const float y = yv[nb][r];
-                const float v = acc[nb][r] * osc4 * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
-                if (row < c.n_rows) {
-                    g.act0[(int64_t)(c.p0 + row) * g.ld0 + (int64_t)m * H1 + col] = v;
-                    vmax4 = fmaxf(vmax4, fabsf(v));
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_of(rb, r);
+                    const int rr = row < c.n_rows ? row : 0;
+                    yv[rb][nb][r] = g.act0[(int64_t)(c.p0 + rr) * g.ld0 + (int64_t)m * H1 + col_of(nb)];
                 }
-            }
-        }
+#pragma unroll
+        for (int rb = 0; rb < FB_RB; ++rb)
+#pragma unroll
+            for (int nb = 0; nb < NB4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_of(rb, r);
+                    const float y = yv[rb][nb][r];
+                    const float v = acc[rb * 2 + nb][r] * osc4 * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+                    if (row < c.n_rows) {
+                        g.act0[(int64_t)(c.p0 + row) * g.ld0 + (int64_t)m * H1 + col_of(nb)] = v;
+                        vmax4 = fmaxf(vmax4, fabsf(v));
+                    }
+                }
         amax_update(g.amax, 5, c.s, vmax4);
     }
 }
 
-__global__ __launch_bounds__(256) void k_hidden_fused(FusedArgs g)
+__global__ __launch_bounds__(256, 2) void k_hidden_fused(FusedArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) _Float16 fsm[];
 
@@ -921,25 +956,16 @@ __global__ __launch_bounds__(256) void k_hidden_fused(FusedArgs g)
     const int xu = max(2 * FB_ROWS * (H1 + 8), 2 * FB_ROWS * (H3 + 8));
     c.s_max = reinterpret_cast<unsigned *>(c.XU + xu);
 
-    // column blocks of this wave (wn = column half): first half gets the extra block of an odd count
-    const int wn = (threadIdx.x >> 6) & 1;
-    auto split = [&](int N, int &cb0, int &nbw) {
-        const int nblk = N >> 5, half = (nblk + 1) >> 1;
-        cb0 = wn * half;
-        nbw = wn == 0 ? half : nblk - half;
-    };
-    int cb1, nb1, cb2, nb2, cb4, nb4;
-    split(H2, cb1, nb1);
-    split(H3, cb2, nb2);
-    split(H1, cb4, nb4);
+    // column blocks of this wave: {wave, wave + 4} clipped to the block count of each phase
+    const int wave = threadIdx.x >> 6;
+    auto nbw = [&](int N) { const int nblk = N >> 5; return (nblk > wave ? 1 : 0) + (nblk > wave + 4 ? 1 : 0); };
     // wave-uniform dispatch on the block counts.  Every barrier is executed by all four waves regardless
     // of the instantiation they run.  The host only selects this kernel for widths covered here
-    // (fused_key_supported).
-    switch (nb1 * 100 + nb2 * 10 + nb4) {
-#define FB_CASE(a, b, d) case a * 100 + b * 10 + d: fused_body<a, b, d>(c, cb1, cb2, cb4); break;
-        FB_CASE(3, 3, 4) FB_CASE(3, 2, 4)   // 256/192/160 (ANI-2x H), first half of 224/192/160 (C)
-        FB_CASE(3, 2, 3) FB_CASE(2, 2, 3)   // 224/192/160 second half; 192/160/128 (N, O)
-        FB_CASE(2, 1, 2) FB_CASE(2, 2, 2)   // 160/128/96 (S, F, Cl; ANI-1x H, C); 128/128/96 (ANI-1x N, O)
+    // (fused_dims_supported).
+    switch (nbw(H2) * 100 + nbw(H3) * 10 + nbw(H1)) {
+#define FB_CASE(a, b, d) case a * 100 + b * 10 + d: fused_body<a, b, d>(c); break;
+        FB_CASE(2, 2, 2) FB_CASE(2, 1, 2) FB_CASE(1, 1, 2)   // 256/192/160, 224/192/160, 192/160/128
+        FB_CASE(1, 1, 1) FB_CASE(1, 0, 1)                    // 160/128/96, 128/128/96 and tails
 #undef FB_CASE
         default: break;
     }
@@ -1135,10 +1161,10 @@ static int check_desc(const anihip_mlp_desc *d)
 static bool fused_dims_supported(int H1, int H2, int H3)
 {
     if (H1 > FB_MAXH || H2 > FB_MAXH || H3 > FB_MAXH) return false;
-    for (int wn = 0; wn < 2; ++wn) {
-        auto nb = [&](int H) { const int n = H >> 5, half = (n + 1) >> 1; return wn == 0 ? half : n - half; };
+    for (int wave = 0; wave < 4; ++wave) {
+        auto nb = [&](int H) { const int n = H >> 5; return (n > wave ? 1 : 0) + (n > wave + 4 ? 1 : 0); };
         const int key = nb(H2) * 100 + nb(H3) * 10 + nb(H1);
-        const int ok[] = {334, 324, 323, 223, 212, 222};
+        const int ok[] = {222, 212, 112, 111, 101};
         bool f = false;
         for (int k : ok) f = f || k == key;
         if (!f) return false;
