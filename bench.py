@@ -10,7 +10,8 @@ of the ANI-2x architecture (the published ones are a download), data is syntheti
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline      : the fused radial+angular AEV forward kernel against the HBM roofline
-  roofline_mfma : the ensemble GEMM stack (fwd + input-gradient bwd) against the fp32-MFMA peak
+  roofline_mfma : the ensemble stack (fwd + input-gradient bwd): algorithmic fp32 flops against the fp32-MFMA
+                  peak, plus the fp16 MFMA flops actually issued by the split-fp16 path against the fp16 peak
   cpu_baseline  : the CPU oracle (float build, all host cores) timed on a bounded sub-box, N=1 only
   stages_ms     : per-stage device time of one step on this rank (HIP events on the engine's stream)
 """
@@ -30,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (the f16x3 path issues 3 fp16 MFMA flops per fp32 flop)
 
 
 def water_box(n_side: int, seed: int = 4, spacing: float = 3.107):
@@ -193,7 +195,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 (ensemble GEMMs: split-fp16 x3 MFMA, fp32 accumulate, fp32-class accuracy)", "data": "synthetic",
         "config": {
             "workload": f"ANI-2x 8-member ensemble, {n_atoms}-atom periodic water box (0.1 atoms/A^3), "
                         "energy+forces, seeded random weights",
@@ -208,9 +210,17 @@ def main():
             "mean_radial_neighbors": n_r, "mean_angular_neighbors": n_a, "avg_launch_ms": st["aev_forward"],
         },
         "roofline_mfma": {
-            "kernel": "k_gemm<*> stack: ensemble forward + input-gradient backward", "bound": "mfma",
+            "kernel": "ensemble fwd + input-gradient bwd: k_gemm_h<*> (layer 0) + k_hidden_fused, "
+                      f"precision {packed.precision}",
+            "bound": "mfma",
+            # algorithmic fp32 flops / time, against the fp32-MFMA peak BASELINE.md names ...
             "achieved": mlp_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": mlp_tflops / MFMA_F32_PEAK_TFLOPS, "flops_per_atom": flops_atom,
+            # ... and, for the split-fp16 path, the fp16 MFMA flops actually issued (3 per fp32 flop)
+            # against the dense fp16 MFMA peak
+            "issued_f16_tflops": (3.0 if packed.precision == "f16x3" else 0.0) * mlp_tflops,
+            "f16_peak": MFMA_F16_PEAK_TFLOPS,
+            "f16_frac": (3.0 * mlp_tflops / MFMA_F16_PEAK_TFLOPS) if packed.precision == "f16x3" else None,
         },
         "stages_ms": st,
     }

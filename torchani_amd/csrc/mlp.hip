@@ -377,7 +377,11 @@ __device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src0
                 const float x = (c < 4 ? st.a[ps][0][c & 3] : st.a[ps][1][c & 3]) * sa;
                 const _Float16 h = (_Float16)x;
                 hi[c] = h;
+#ifndef ANIHIP_ABLATE_NOCONV
                 lo[c] = (_Float16)(x - (float)h);
+#else
+                lo[c] = h;
+#endif
             }
             const int off = h_off(srow + 64 * ps, piece);
             *reinterpret_cast<h8 *>(base + off) = hi;
@@ -423,13 +427,21 @@ __device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src0
     for (int kt = 0; kt < nk; kt += 2) {
         // stage kt is in LDS buffer 0; registers: s1 = stage kt+1, s0 = stage kt+2
         compute(0);
+#ifndef ANIHIP_ABLATE_NOSTORE
         if (kt + 1 < nk) lstore(s1, 1);
+#endif
+#ifndef ANIHIP_ABLATE_NOLOAD
         gload(s1, min(kt + 3, nk - 1));
+#endif
         __syncthreads();
         if (kt + 1 < nk) {
             compute(1);
+#ifndef ANIHIP_ABLATE_NOSTORE
             if (kt + 2 < nk) lstore(s0, 0);
+#endif
+#ifndef ANIHIP_ABLATE_NOLOAD
             gload(s0, min(kt + 4, nk - 1));
+#endif
             __syncthreads();
         }
     }
@@ -520,6 +532,196 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
             }
             vmax = fmaxf(vmax, fabsf(v));
         }
+    }
+    if (g.amax_out >= 0) amax_update(g.amax, g.amax_out, s, vmax);
+}
+
+// ---- f16x3 grouped GEMM, 256 x 256 x 32 tiles (layer-0 GEMMs) -----------------------------------------
+// The 128 x 128 kernel above is bound by LDS traffic (staging stores + fragment reads ~ the MFMA time).  For the
+// two big layer-0 GEMMs (N >= 1024) this variant runs 8 waves as 4 (M) x 2 (N), each wave owning a
+// 64 x 128 sub-tile: every A fragment feeds 4 column blocks and every B fragment 2 row blocks, so LDS reads,
+// staging stores and L2 traffic per MFMA are halved.  One workgroup per CU (128 KB of LDS, double
+// buffered), two waves per SIMD.
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int H2_PLANE = BM2 * HBK;        // halves per plane per stage
+constexpr int H2_STAGE = 4 * H2_PLANE;     // A_hi, A_lo, B_hi, B_lo
+constexpr int GEMM2_THREADS = 512;
+
+template <int NB>
+__device__ __forceinline__ void gemm_h2_kloop(f32x16 (&acc)[8], const gf4 *a_src0, const gf4 *a_src1,
+                                              int k_valid, float sa, const _Float16 *b_src0,
+                                              const _Float16 *b_src1, int64_t bh_plane, int nk, _Float16 *sm,
+                                              int wm, int wn)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int srow = tid >> 2, piece = tid & 3;   // staging: rows srow and 128 + srow, 16-B piece
+    const int fr = lane & 31, fk = lane >> 5;
+    const v4f z4 = v4f{0.f, 0.f, 0.f, 0.f};
+    HStage st;
+    auto gload = [&](int kt) {
+        const bool ok = kt * HBK + piece * 8 < k_valid;
+        const int o = ok ? kt * (HBK / 4) : 0;
+        st.a[0][0] = a_src0[o]; st.a[0][1] = a_src0[o + 1];
+        st.a[1][0] = a_src1[o]; st.a[1][1] = a_src1[o + 1];
+        if (!ok) { st.a[0][0] = z4; st.a[0][1] = z4; st.a[1][0] = z4; st.a[1][1] = z4; }
+        st.bh[0] = *(const gh8 *)(b_src0 + kt * HBK);
+        st.bl[0] = *(const gh8 *)(b_src0 + bh_plane + kt * HBK);
+        st.bh[1] = *(const gh8 *)(b_src1 + kt * HBK);
+        st.bl[1] = *(const gh8 *)(b_src1 + bh_plane + kt * HBK);
+    };
+    auto lstore = [&](int buf) {
+        _Float16 *base = sm + buf * H2_STAGE;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            h8 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float x = (c < 4 ? st.a[ps][0][c & 3] : st.a[ps][1][c & 3]) * sa;
+                const _Float16 h = (_Float16)x;
+                hi[c] = h;
+                lo[c] = (_Float16)(x - (float)h);
+            }
+            const int off = h_off(srow + 128 * ps, piece);
+            *reinterpret_cast<h8 *>(base + off) = hi;
+            *reinterpret_cast<h8 *>(base + H2_PLANE + off) = lo;
+            *reinterpret_cast<h8 *>(base + 2 * H2_PLANE + off) = st.bh[ps];
+            *reinterpret_cast<h8 *>(base + 3 * H2_PLANE + off) = st.bl[ps];
+        }
+    };
+    auto compute = [&](int buf) {
+        const _Float16 *base = sm + buf * H2_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {
+            const int pc = ks * 2 + fk;
+            h8 ah[2], al[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int ao = h_off(wm * 64 + rb * 32 + fr, pc);
+                ah[rb] = *reinterpret_cast<const h8 *>(base + ao);
+                al[rb] = *reinterpret_cast<const h8 *>(base + H2_PLANE + ao);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int bo = h_off(wn * 128 + nb * 32 + fr, pc);
+                const h8 bhi = *reinterpret_cast<const h8 *>(base + 2 * H2_PLANE + bo);
+                const h8 blo = *reinterpret_cast<const h8 *>(base + 3 * H2_PLANE + bo);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[rb * 4 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rb], bhi, acc[rb * 4 + nb], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[rb * 4 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], blo, acc[rb * 4 + nb], 0, 0, 0);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                    acc[rb * 4 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], bhi, acc[rb * 4 + nb], 0, 0, 0);
+            }
+        }
+    };
+    gload(0);
+    lstore(0);
+    gload(min(1, nk - 1));
+    __syncthreads();
+    // main loop without branches in the body: the compiler interleaves the conversion VALU / ds_write of
+    // stage kt+1 and the global loads of stage kt+2 into the MFMA stream of stage kt
+    for (int kt = 0; kt < nk - 1; ++kt) {
+        const int buf = kt & 1;
+        if (NB > 0) compute(buf);
+        lstore(buf ^ 1);                      // stage kt+1 (its loads were issued one iteration ago)
+        gload(min(kt + 2, nk - 1));
+        __syncthreads();
+    }
+    if (NB > 0) compute((nk - 1) & 1);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 sm2[];
+
+    const int nwg = gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = id & 7;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
+    }
+    const int col_t = id % g.ncol_max;
+    const int bb = (id / g.ncol_max) % g.batch;
+    int row_t = id / (g.ncol_max * g.batch);
+
+    // row tile -> species (256-row tiles are counted here, the control block holds 128-row tiles)
+    const int *ctl = g.ctl;
+    int s = 0, cnt = 0;
+    for (; s < g.S; ++s) {
+        cnt = ctl[CTL_CNT + s];
+        const int nt = (cnt + BM2 - 1) / BM2;
+        if (row_t < nt) break;
+        row_t -= nt;
+    }
+    if (s >= g.S) return;
+    const GemmProblem &pr = g.prob[s];
+    const int n0 = col_t * BN2;
+    if (n0 >= pr.N) return;
+    const int m0 = row_t * BM2;
+    const int n_rows = cnt - m0;
+    const int p0 = ctl[CTL_OFF + s] + m0;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nb_act = max(0, min(4, (pr.N - n0 - wn * 128) >> 5));   // active 32-column blocks of this wave
+    const float sa = g.amax_in >= 0 ? amax_scale(g.amax, g.amax_in, s) : g.a_static_scale;
+    const float out_scale = pr.w_inv_scale / sa;
+
+    const int srow = tid >> 2, piece = tid & 3;
+    const gf4 *a_src0, *a_src1;
+    {
+        const int r0 = srow < n_rows ? srow : 0, r1 = srow + 128 < n_rows ? srow + 128 : 0;
+        const int64_t s0r = g.a_gather ? (int64_t)g.a_gather[p0 + r0] : (int64_t)(p0 + r0);
+        const int64_t s1r = g.a_gather ? (int64_t)g.a_gather[p0 + r1] : (int64_t)(p0 + r1);
+        a_src0 = (const gf4 *)(g.A + s0r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
+        a_src1 = (const gf4 *)(g.A + s1r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
+    }
+    const int bn0 = (n0 + srow < pr.N) ? n0 + srow : n0, bn1 = (n0 + srow + 128 < pr.N) ? n0 + srow + 128 : n0;
+    const _Float16 *b_src0 = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)bn0 * pr.ldbh + piece * 8;
+    const _Float16 *b_src1 = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)bn1 * pr.ldbh + piece * 8;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int nk = pr.K / HBK;
+    const int fr = lane & 31, fk = lane >> 5;
+    switch (nb_act) {
+        case 4: gemm_h2_kloop<4>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
+        case 3: gemm_h2_kloop<3>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
+        case 2: gemm_h2_kloop<2>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
+        case 1: gemm_h2_kloop<1>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
+        default: gemm_h2_kloop<0>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
+    }
+
+    float vmax = 0.f;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        if (nb >= nb_act) continue;
+        const int col = n0 + wn * 128 + nb * 32 + fr;
+        float bias = 0.f;
+        if (EPI == EPI_BIAS_CELU) bias = pr.bias[(int64_t)bb * pr.bias_stride + col];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row >= n_rows) continue;
+                float v = acc[rb * 4 + nb][r] * out_scale;
+                if (EPI == EPI_BIAS_CELU) {
+                    v = celu(v + bias, g.alpha, g.inv_alpha);
+                    g.C[(int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col] = v;
+                } else if (EPI == EPI_SCATTER) {
+                    if (col < g.n_store) g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + col] = v;
+                }
+                vmax = fmaxf(vmax, fabsf(v));
+            }
     }
     if (g.amax_out >= 0) amax_update(g.amax, g.amax_out, s, vmax);
 }
@@ -1173,6 +1375,23 @@ static bool fused_dims_supported(int H1, int H2, int H3)
 }
 
 template <int EPI>
+static int launch_gemm_big(hipStream_t stream, GemmArgs &g, int64_t n_rows_total)
+{
+    // 256 x 256 tiles: recompute the tile upper bounds for this tiling
+    const size_t lds = sizeof(_Float16) * 2 * H2_STAGE;
+    int nmax = 0;
+    for (int s = 0; s < g.S; ++s) nmax = nmax > g.prob[s].N ? nmax : g.prob[s].N;
+    GemmArgs h = g;
+    h.ncol_max = (nmax + BN2 - 1) / BN2;
+    h.nrow_tiles_ub = (int)((n_rows_total + BM2 - 1) / BM2) + g.S;
+    ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_h2<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+    const int64_t total = (int64_t)h.nrow_tiles_ub * h.ncol_max * h.batch;
+    hipLaunchKernelGGL((k_gemm_h2<EPI>), dim3((unsigned)total), dim3(GEMM2_THREADS), lds, stream, h);
+    return 0;
+}
+
+template <int EPI>
 static void launch_gemm(hipStream_t stream, GemmArgs &g, bool f16x3)
 {
     const int64_t total = (int64_t)g.nrow_tiles_ub * g.ncol_max * g.batch;
@@ -1231,6 +1450,9 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                 fused_dims_supported(nn.dims[1], nn.dims[2], nn.dims[3]);
     }
     if (const char *e = getenv("ANIHIP_NO_FUSED_HIDDEN")) fused = fused && e[0] == '0';
+    // 256 x 256 tiles for the layer-0 GEMMs once there are enough rows to fill the chip with them
+    bool big_tiles = h3 && n >= 16384;
+    if (const char *e = getenv("ANIHIP_GEMM_TILE")) big_tiles = h3 && e[0] == '2';
 
     // 2. forward through the hidden layers
     for (int l = 0; l < (fused ? 1 : nh); ++l) {
@@ -1270,7 +1492,11 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         }
         g.amax = w.amax; g.amax_out = h3 ? l : -1; g.amax_in = (h3 && l > 0) ? l - 1 : -1;
         g.a_static_scale = 4.0f;  // layer-0 input: |aev| < 16376 by construction (see include/anihip.h)
-        launch_gemm<EPI_BIAS_CELU>(stream, g, h3);
+        if (h3 && l == 0 && big_tiles) {
+            if (int rc = launch_gemm_big<EPI_BIAS_CELU>(stream, g, n)) return rc;
+        } else {
+            launch_gemm<EPI_BIAS_CELU>(stream, g, h3);
+        }
     }
 
     if (fused) {
@@ -1357,8 +1583,13 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             g.amax_in = h3 ? 3 + (nh - 1 - l) : -1;
             g.amax_out = (h3 && l > 0) ? 3 + (nh - l) : -1;
             g.a_static_scale = 1.0f;
-            if (l == 0) launch_gemm<EPI_SCATTER>(stream, g, h3);
-            else launch_gemm<EPI_DCELU>(stream, g, h3);
+            if (l == 0 && h3 && big_tiles) {
+                if (int rc = launch_gemm_big<EPI_SCATTER>(stream, g, n)) return rc;
+            } else if (l == 0) {
+                launch_gemm<EPI_SCATTER>(stream, g, h3);
+            } else {
+                launch_gemm<EPI_DCELU>(stream, g, h3);
+            }
         }
     }
     ANIHIP_CHECK_HIP(hipGetLastError());

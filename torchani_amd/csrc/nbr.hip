@@ -302,6 +302,16 @@ __global__ void k_bin_sort_gather(const GridDesc *g, const int *cell_start, int 
 
 constexpr int NBR_WPB = 4;  // waves per block
 
+// periodic wrap of a bin index that is at most a few bins outside [0, nb): no integer division on the
+// common path (the stencil half-width exceeds the grid only for cells thinner than the cutoff)
+__device__ __forceinline__ int wrap_bin(int c, int nb)
+{
+    c = c < 0 ? c + nb : c;
+    c = c >= nb ? c - nb : c;
+    if (c < 0 || c >= nb) c = ((c % nb) + nb) % nb;
+    return c;
+}
+
 struct HitList {
     float4 *buf;  // per-wave LDS, MAXR entries
     int n;        // wave-uniform
@@ -467,15 +477,17 @@ __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_cell(
             continue;
         }
         const float4 pi = pos4[i];
-        const int b2 = c % nb2, b1 = (c / nb2) % nb1, b0 = c / (nb2 * nb1);
+        // bin coordinates, wave-uniform (scalar registers): one division chain per atom
+        const int cu = uniform(c);
+        const int b2 = cu % nb2, b1 = (cu / nb2) % nb1, b0 = cu / (nb2 * nb1);
         HitList h{s_hits[wib], 0, false};
         for (int o0 = -R0; o0 <= R0; ++o0) {
             int c0 = b0 + o0;
-            if (p0) c0 = ((c0 % nb0) + nb0) % nb0;
+            if (p0) c0 = wrap_bin(c0, nb0);
             else if (c0 < 0 || c0 >= nb0) continue;
             for (int o1 = -R1; o1 <= R1; ++o1) {
                 int c1 = b1 + o1;
-                if (p1) c1 = ((c1 % nb1) + nb1) % nb1;
+                if (p1) c1 = wrap_bin(c1, nb1);
                 else if (c1 < 0 || c1 >= nb1) continue;
                 const int rowc = (c0 * nb1 + c1) * nb2;
                 const float bx = o0 * st[0] + o1 * st[3] - pi.x;
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_cell(
                     } else {
                         o2lo = sgm - R2;
                         int c2 = b2 + o2lo;
-                        if (p2) c2 = ((c2 % nb2) + nb2) % nb2;
+                        if (p2) c2 = wrap_bin(c2, nb2);
                         else if (c2 < 0 || c2 >= nb2) continue;
                         kbeg = cell_start[rowc + c2];
                         kend = cell_start[rowc + c2 + 1];
