@@ -170,12 +170,16 @@ def main():
     reps = 3
     nbrs = eng.neighbors(sp32, coords, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
     st["neighbors"] = time_stage(lambda: eng.neighbors(sp32, coords, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128), reps)
-    aev = eng.forward(sp32, nbrs)
-    st["aev_forward"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev), reps)
+    mask = torch.zeros(n_atoms, dtype=torch.int32, device=dev)   # per-atom slab flags, as in the product path
+    aev = eng.forward(sp32, nbrs, slab_mask=mask)
+    st["aev_forward"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev, slab_mask=mask), reps)
     ae = torch.zeros(n_atoms, dtype=torch.float32, device=dev)
     gaev = torch.zeros_like(aev)
     st["mlp_fwd_bwd"] = time_stage(
-        lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk), reps)
+        lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk,
+                                        slab_mask=mask), reps)
+    st["mlp_fwd_bwd_dense"] = time_stage(
+        lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk), 2)
     gc = torch.zeros((n_atoms, 3), dtype=torch.float32, device=dev)
     st["aev_backward"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc), reps)
     meta = nbrs.meta[lo:hi, 1].to(torch.int64) & 0xFFFFFFFF

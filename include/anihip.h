@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 1
+#define ANIHIP_ABI_VERSION 2
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -108,10 +108,16 @@ int anihip_nbr_build_cell(void *stream, const anihip_aev_params *p, int64_t n_at
  * L = S*16 + S(S+1)/2*32, layout [radial | angular] (aev/_computer.py:298).  Rows of atoms outside
  * [lo,hi) are not touched; padding atoms inside the range get zero rows.
  * grad_coords [n_atoms,3] is ACCUMULATED into with float atomics (caller zeroes it), i.e.
- * grad_coords += d(sum grad_aev * aev)/d coords  (csrc/aev.cu:1958-1984). */
+ * grad_coords += d(sum grad_aev * aev)/d coords  (csrc/aev.cu:1958-1984).
+ *
+ * slab_mask (optional, may be NULL; needs ceil(S/2) + S(S+1)/2 <= 32): slab_mask[i] flags the 32-wide
+ * "slabs" of row i that can be non-zero -- bit j < ceil(S/2): radial blocks of species 2j, 2j+1; bit
+ * ceil(S/2) + P: angular block of species pair P.  An AEV block is identically zero when atom i has no
+ * neighbor (pair) of that species inside the cutoff; anihip_mlp_forward_backward skips those slabs.
+ * anihip_aev_backward reads grad_aev only inside the flagged slabs. */
 int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                        int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
-                       const float *ent, float *aev, uint32_t *status);
+                       const float *ent, float *aev, uint32_t *slab_mask, uint32_t *status);
 int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                         int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
                         const float *ent, const float *grad_aev, float *grad_coords, uint32_t *status);
@@ -126,6 +132,11 @@ int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *t
  *   layer l : w [M][Hlp][H(l+1)p]   wt [M][H(l+1)p][Hlp]   bias [M][H(l+1)p]      (hidden layers)
  *   final   : w [M][Hlastp]  bias [M]
  * K0 = AEV length (multiple of 16), K0p = K0 rounded up to a multiple of 32.
+ *
+ * Slab order of the layer-0 fp16 planes (desc.aev_radial_len = R > 0, needs (K0 - R) % 32 == 0): the AEV
+ * index of wh[0] / wth[0] runs over [radial part zero-padded to a multiple of 32 | angular part], so that
+ * every 32-deep slab holds whole species blocks of the AEV (two radial blocks or one angular block) and
+ * K0p = 32 * (ceil(R/32) + (K0 - R)/32).  With R = 0 the planes are in plain AEV order.
  */
 #define ANIHIP_MAX_LAYERS 4 /* Linear layers per network incl. the final one */
 typedef struct {
@@ -137,7 +148,7 @@ typedef struct {
     /* precision == ANIHIP_MLP_F16X3 only: the same hidden-layer matrices as two fp16 planes {hi, lo}
      * with hi + lo = w * wh_scale (power of two), stored [2][rows = output index][cols = reduction index]:
      * wh[l] has the shape of wt[l] (forward GEMMs), wth[l] the shape of w[l] (backward GEMMs; layer 0
-     * padded to K0p rows). */
+     * padded to K0p rows).  Layer 0 uses the slab order described above when aev_radial_len > 0. */
     const void *wh[ANIHIP_MAX_LAYERS];
     const void *wth[ANIHIP_MAX_LAYERS];
     float wh_scale[ANIHIP_MAX_LAYERS];
@@ -165,6 +176,7 @@ typedef struct {
     int32_t aev_len;
     float celu_alpha;
     int32_t precision; /* ANIHIP_MLP_FP32 or ANIHIP_MLP_F16X3 */
+    int32_t aev_radial_len; /* R of the slab order of wh[0] / wth[0] (0 = plain order) */
     anihip_species_net net[ANIHIP_MAX_SPECIES];
 } anihip_mlp_desc;
 
@@ -174,11 +186,16 @@ size_t anihip_mlp_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central);
 
 /* atomic_e[i] = mean over members of net_{m,species(i)}(aev[i]) for lo <= i < hi (0 for padding);
  * if grad_aev != NULL also grad_aev[i] = d atomic_e[i] / d aev[i] (rows of padding atoms zeroed).
- * member_e (optional) = [M, n_atoms] per-member energies (ensemble_values, nn/_containers.py:638-651). */
+ * member_e (optional) = [M, n_atoms] per-member energies (ensemble_values, nn/_containers.py:638-651).
+ * slab_mask (optional; F16X3 with aev_radial_len > 0 only, otherwise ignored): the per-atom slab flags
+ * written by anihip_aev_forward.  Slabs that no atom of a row tile flags are skipped in the layer-0
+ * GEMMs (their AEV entries are exactly zero, so energies are unchanged); the matching entries of
+ * grad_aev are then NOT written -- the caller must only consume grad_aev inside the flagged slabs
+ * (anihip_aev_backward does) or pre-zero it. */
 int anihip_mlp_forward_backward(void *stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo,
-                                int64_t hi, const int32_t *species, const float *aev, void *workspace,
-                                size_t workspace_bytes, float *atomic_e, float *grad_aev,
-                                float *member_e);
+                                int64_t hi, const int32_t *species, const float *aev,
+                                const uint32_t *slab_mask, void *workspace, size_t workspace_bytes,
+                                float *atomic_e, float *grad_aev, float *member_e);
 
 /* mol_e[c] (fp64) = sum_a atomic_e[c,a] + sae[species[c,a]] over the atoms lo <= c*A+a < hi; padding
  * contributes nothing (sae.py:54-64).  sae may be NULL.  mol_e is overwritten. */

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.anihip_abi_version() == 1
+    assert lib.anihip_abi_version() == 2
 
 
 def test_struct_layouts_match_header(lib):
@@ -38,6 +38,8 @@ def test_struct_layouts_match_header(lib):
 
     assert ctypes.sizeof(_lib.AevParams) == 9 * 4
     assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 5 * 4 * 8 + 4 * 4 + 2 * 4 * 8 + 0
+    assert ctypes.sizeof(_lib.MlpDesc) == 6 * 4 + 8 * ctypes.sizeof(_lib.SpeciesNet)
+    assert _lib.MlpDesc.net.offset == 24
     d = _lib.MlpDesc()
     d.num_species, d.n_members, d.aev_len, d.celu_alpha = 2, 8, 1008, 0.1
     for s in range(2):
@@ -168,6 +170,38 @@ def test_packed_network_layout_cpu():
     assert wth0.shape == (2, 32, 128)
     wf = next(t for t in pk._keep if t.data_ptr() == d.net[0].w[2])
     assert wf.shape == (2, 32) and torch.equal(wf[0, :24], W[0][0][2][0]) and torch.all(wf[:, 24:] == 0)
+
+
+def test_packed_network_slab_order_cpu():
+    """Layer-0 fp16 planes in slab order (include/anihip.h): radial part padded to a multiple of 32, then
+    the angular part, for the ANI-2x shape (S = 7: 112 -> 128, K0p = 1024)."""
+    from torchani_amd.engine import PackedNetworks
+
+    rs = np.random.RandomState(1)
+    M, S, K0 = 1, 7, 1008
+    W = [[[torch.from_numpy(rs.randn(o, i).astype(np.float32)) for i, o in ((K0, 32), (32, 32), (32, 1))]
+          for s in range(S)] for m in range(M)]
+    B = [[[torch.zeros(w.shape[0]) for w in W[m][s]] for s in range(S)] for m in range(M)]
+    pk = PackedNetworks(W, B, K0, 0.1, torch.device("cpu"), precision="f16x3")
+    d = pk.desc
+    assert pk.radial_len == 112 and d.aev_radial_len == 112
+    wh0 = next(t for t in pk._keep if t.data_ptr() == d.net[3].wh[0])
+    wth0 = next(t for t in pk._keep if t.data_ptr() == d.net[3].wth[0])
+    assert wh0.shape == (2, 32, 1024) and wth0.shape == (2, 1024, 32)
+    sc = d.net[3].wh_scale[0]
+    rec = (wh0[0].float() + wh0[1].float()) / sc
+    ref = W[0][3][0]
+    tol = 2.0 ** -21 * ref.abs().max()
+    assert (rec[:, :112] - ref[:, :112]).abs().max() <= tol
+    assert torch.all(rec[:, 112:128] == 0)
+    assert (rec[:, 128:] - ref[:, 112:]).abs().max() <= tol
+    assert torch.equal(wth0[0], wh0[0].t())
+    # fp32 packing and AEV lengths without the ANI structure keep the plain order
+    assert PackedNetworks(W, B, K0, 0.1, torch.device("cpu"), precision="fp32").radial_len == 0
+    W2 = [[[torch.from_numpy(rs.randn(o, i).astype(np.float32)) for i, o in ((64, 32), (32, 1))]
+           for s in range(2)]]
+    B2 = [[[torch.zeros(w.shape[0]) for w in W2[0][s]] for s in range(2)]]
+    assert PackedNetworks(W2, B2, 64, 0.1, torch.device("cpu")).radial_len == 0
 
 
 def test_shard_bounds():

@@ -206,6 +206,74 @@ def test_energies_and_forces_fused(dev, name):
         assert np.all(out.forces.cpu().numpy()[g["species"] < 0] == 0)
 
 
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_energies_and_forces_slab_masks(dev, name, monkeypatch):
+    """The large-system configuration of the fused path on the golden cases: 256x256-tile layer-0 GEMMs
+    that skip the AEV slabs of absent neighbor species (per-atom slab masks from the AEV kernel)."""
+    monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
+    g = load_golden(name)
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = get_model(g["kind"], g["seed"], dev, neighborlist=modes_for(g)[-1], row_capacity=256)
+    out = model.energies_and_forces(sp, x, cell, pbc, check_overflow=True)
+    torch.cuda.synchronize()
+    ea = np.abs(out.atomic_energies.cpu().numpy() - g["atomic_energies"]).max()
+    fe = np.abs(out.forces.cpu().numpy() - g["forces"]).max()
+    report(f"slab  {name:22s} max|e_atom err| = {ea:.2e}  |F err| = {fe:.2e}")
+    assert ea < E_ATOM_TOL and fe < F_TOL
+    assert np.all(out.forces.cpu().numpy()[g["species"] < 0] == 0)
+
+
+@pytest.mark.parametrize("name", ["small_ani2x", "water_pbc_ani2x", "ch4_ani1x", "1hz5_ani2x"])
+def test_slab_masks_flag_exactly_the_nonzero_blocks(dev, name, monkeypatch):
+    """slab_mask[i] bit j set <=> atom i has a neighbor (pair) contributing to slab j; masked and dense
+    layer-0 GEMMs give the same energies, and the same gradients inside the flagged slabs."""
+    from torchani_amd.weights import arch_spec
+
+    monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
+    g = load_golden(name)
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = get_model(g["kind"], g["seed"], dev)
+    _, consts, _ = arch_spec(g["kind"])
+    eng = model.aev_computer.engine()
+    sp32 = sp.to(torch.int32).contiguous().view(-1)
+    n = sp32.numel()
+    nbrs = eng.neighbors(sp32.view(sp.shape), x, cell, pbc, mode=modes_for(g)[-1], row_cap=256)
+    mask = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    aev = eng.forward(sp32, nbrs, slab_mask=mask)
+    S = eng.params.num_species
+    rs, R = (S + 1) // 2, 16 * S
+    a = aev.cpu().numpy()
+    mk = mask.cpu().numpy().astype(np.uint32)
+    # expected flags from the AEV rows themselves (a block with a contributing neighbor is > 0 somewhere
+    # unless every term underflows; the converse -- unflagged => all zero -- must hold exactly)
+    for j in range(eng.n_slabs):
+        if j < rs:
+            blk = a[:, 32 * j:min(32 * j + 32, R)]
+        else:
+            blk = a[:, R + 32 * (j - rs):R + 32 * (j - rs) + 32]
+        flagged = (mk >> j) & 1 == 1
+        assert np.all(blk[~flagged] == 0), f"slab {j}: non-zero AEV entries outside the mask"
+    assert np.all(mk[g["species"].reshape(-1) < 0] == 0)
+    packed = model.neural_networks._pack(dev)
+    assert packed.radial_len == R
+    e0, g0, _ = packed.forward_backward(sp32, aev)
+    g1 = torch.full_like(g0, float("nan"))
+    e1, g1, _ = packed.forward_backward(sp32, aev, slab_mask=mask, grad_aev=g1)
+    torch.cuda.synchronize()
+    assert torch.allclose(e0, e1, atol=2e-7, rtol=0)
+    g0n, g1n = g0.cpu().numpy(), g1.cpu().numpy()
+    real = g["species"].reshape(-1) >= 0
+    for j in range(eng.n_slabs):
+        cols = slice(32 * j, min(32 * j + 32, R)) if j < rs else slice(R + 32 * (j - rs), R + 32 * (j - rs) + 32)
+        flagged = ((mk >> j) & 1 == 1) & real
+        d = np.abs(g0n[flagged, cols] - g1n[flagged, cols])
+        assert d.size == 0 or d.max() <= 1e-6 * max(1.0, np.abs(g0n).max())
+    # forces through the masked gradient
+    f0 = eng.backward(sp32, nbrs, g0)
+    f1 = eng.backward(sp32, nbrs, g1)
+    assert torch.isfinite(f1).all() and torch.allclose(f0, f1, atol=2e-6)
+
+
 @pytest.mark.parametrize("name", ["ch4_ani1x", "rand_batch_ani2x", "water_pbc_ani2x"])
 def test_autograd_path_equals_fused(dev, name):
     """model((species, coords)) + torch.autograd == fused engine path (same kernels underneath)."""

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--side", type=int, default=56)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--stages", default="nbr,fwd,bwd,mlp")
+    ap.add_argument("--mask", default="both", choices=["on", "off", "both"], help="slab masks in the mlp stage")
     args = ap.parse_args()
     from torchani_amd.models import ANI2x
 
@@ -31,7 +32,8 @@ def main():
     eng = model.aev_computer.engine()
     packed = model.neural_networks._pack(dev)
     nbrs = eng.neighbors(sp32, coords, cell, pbc, mode="cell")
-    aev = eng.forward(sp32, nbrs)
+    mask = torch.zeros(n, dtype=torch.int32, device=dev)
+    aev = eng.forward(sp32, nbrs, slab_mask=mask)
     ae = torch.zeros(n, dtype=torch.float32, device=dev)
     gaev = torch.randn_like(aev) * 1e-3
     gc = torch.zeros((n, 3), dtype=torch.float32, device=dev)
@@ -43,11 +45,16 @@ def main():
     if "nbr" in st:
         out["nbr"] = time_stage(lambda: eng.neighbors(sp32, coords, cell, pbc, mode="cell"), args.reps)
     if "fwd" in st:
-        out["fwd"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev), args.reps)
+        out["fwd"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev, slab_mask=mask), args.reps)
     if "bwd" in st:
         out["bwd"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc), args.reps)
     if "mlp" in st:
-        out["mlp"] = time_stage(lambda: packed.forward_backward(sp32, aev, atomic_e=ae, grad_aev=gaev), args.reps)
+        if args.mask != "on":
+            out["mlp_dense"] = time_stage(lambda: packed.forward_backward(sp32, aev, atomic_e=ae, grad_aev=gaev),
+                                          args.reps)
+    if "mlp" in st and args.mask != "off":
+        out["mlp"] = time_stage(lambda: packed.forward_backward(sp32, aev, atomic_e=ae, grad_aev=gaev,
+                                                                slab_mask=mask), args.reps)
     bpa = 3584 + 20 * n_a + 8 + 448 + 8 * n_r
     line = f"atoms={n} n_r={n_r:.1f} n_a={n_a:.1f} | " + " ".join(f"{k}={v:.3f}ms" for k, v in out.items())
     if "fwd" in out:

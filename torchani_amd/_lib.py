@@ -27,6 +27,7 @@ MAX_RAD = 256
 TABLE_FLOATS = 80
 ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
 MLP_FP32, MLP_F16X3 = 0, 1
+ABI_VERSION = 2
 
 
 class AevParams(C.Structure):
@@ -65,6 +66,7 @@ class MlpDesc(C.Structure):
         ("aev_len", C.c_int32),
         ("celu_alpha", C.c_float),
         ("precision", C.c_int32),
+        ("aev_radial_len", C.c_int32),
         ("net", SpeciesNet * MAX_SPECIES),
     ]
 
@@ -117,18 +119,18 @@ def lib() -> C.CDLL:
                                          sz, vp, vp, i64, vp]
     L.anihip_nbr_build_cell.argtypes = [vp, C.POINTER(AevParams), i64, vp, vp, vp, i32, i64, i64, i64, vp,
                                         sz, vp, vp, i64, vp]
-    L.anihip_aev_forward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp]
+    L.anihip_aev_forward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_aev_backward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_mlp_workspace_bytes.restype = sz
     L.anihip_mlp_workspace_bytes.argtypes = [C.POINTER(MlpDesc), i64]
-    L.anihip_mlp_forward_backward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, sz, vp, vp,
-                                              vp]
+    L.anihip_mlp_forward_backward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, vp, sz, vp,
+                                              vp, vp]
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell",
                  "anihip_aev_forward", "anihip_aev_backward", "anihip_mlp_forward_backward",
                  "anihip_energy_reduce"):
         getattr(L, name).restype = C.c_int
-    if L.anihip_abi_version() != 1:
+    if L.anihip_abi_version() != ABI_VERSION:
         raise RuntimeError("libanihip.so ABI version mismatch: rebuild it")
     _lib = L
     return L

@@ -165,7 +165,7 @@ template <int NA, int NZ>
 __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
-    const float4 *__restrict__ ent, float *__restrict__ aev)
+    const float4 *__restrict__ ent, float *__restrict__ aev, uint32_t *__restrict__ slab_mask)
 {
     static_assert(NA % 4 == 0 && NZ % 4 == 0 && NA * NZ == 32, "angular tiling");
     constexpr int AQ = NA / 4, ZQ = NZ / 4;
@@ -252,9 +252,12 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
         if (padding) {
             float4 *out4 = reinterpret_cast<float4 *>(out);
             for (int f = lane; f < (a.L >> 2); f += WAVE) out4[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slab_mask && lane == 0) slab_mask[i] = 0u;
             continue;
         }
         wave_sync();
+        uint32_t smask = 0u;   // 32-wide slabs of this row that are not identically zero (include/anihip.h)
+        const int rslabs = (a.S + 1) >> 1;
 
         // ---- radial ----
         {
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
             for (int t = 0; t < a.S; ++t) {
                 const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t), n = cA + cF;
                 float acc0 = 0.f, acc1 = 0.f;
+                if (n > 0) smask |= 1u << (t >> 1);
                 for (int b = 0; b < n; b += 8) {
                     const int idx = b + rp;
                     const bool v = idx < n;
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
                         ok += nk;
                         continue;
                     }
+                    smask |= 1u << ((rslabs + P) & 31);
                     const int div = same ? ((nj - 1) >> 1) : nk;
                     const float inv_div = div > 0 ? 1.0f / (float)div : 0.f;
                     const int rect = same ? nj * div : 0x7FFFFFFF;
@@ -369,6 +374,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
                 oj += nj;
             }
         }
+        if (slab_mask && lane == 0) slab_mask[i] = smask;
         wave_sync();
     }
 }
@@ -672,9 +678,12 @@ static int persistent_blocks(int64_t n_central, int wpb, int blocks_per_cu)
 
 extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table,
                                   int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
-                                  const uint32_t *meta, const float *ent, float *aev, uint32_t *status)
+                                  const uint32_t *meta, const float *ent, float *aev, uint32_t *slab_mask,
+                                  uint32_t *status)
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && aev, "null pointer argument");
+    ANIHIP_REQUIRE(!slab_mask || (p->num_species + 1) / 2 + p->num_species * (p->num_species + 1) / 2 <= 32,
+                   "slab_mask needs at most 32 slabs (num_species <= 7)");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
@@ -682,10 +691,10 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     dim3 grid(persistent_blocks(hi - lo, FWD_WPB, 4)), block(FWD_WPB * WAVE);
     if (p->n_shf_a == 8)
         hipLaunchKernelGGL((k_aev_fwd<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, aev);
+                           meta, (const float4 *)ent, aev, slab_mask);
     else
         hipLaunchKernelGGL((k_aev_fwd<4, 8>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, aev);
+                           meta, (const float4 *)ent, aev, slab_mask);
     ANIHIP_CHECK_HIP(hipGetLastError());
     (void)status;
     return 0;

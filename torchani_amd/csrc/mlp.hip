@@ -60,6 +60,13 @@ struct GemmArgs {
     int n_store;           // EPI_SCATTER: only columns < n_store are stored
     int S, batch, ncol_max, nrow_tiles_ub;
     float alpha, inv_alpha;
+    // f16x3 layer-0 GEMMs: the reduction (fwd) / output (bwd) index runs over the AEV in "K' order": the
+    // radial part padded up to a multiple of 32, then one 32-wide slab per species pair, so every 32-deep
+    // stage / 32-column block is one (pair of) species block(s) of the AEV.  kp_rad = radial length
+    // (0 = plain order).  stage_mask[atom] (optional) flags the slabs that can be non-zero for that atom
+    // (written by the AEV forward kernel); tiles skip the slabs no row needs.
+    int kp_rad;
+    const uint32_t *stage_mask;
     // f16x3 path: operand scaling.  amax_in/out = stage index into the running-max table (or -1)
     int amax_in, amax_out;
     float a_static_scale;
@@ -309,6 +316,18 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const h8 gh8;
 
+// K' order helpers: slab j -> first AEV column and number of valid columns
+__device__ __forceinline__ int kp_col(int kp_rad, int j)
+{
+    const int rs = (kp_rad + 31) >> 5;
+    return j < rs ? 32 * j : kp_rad + 32 * (j - rs);
+}
+__device__ __forceinline__ int kp_valid(int kp_rad, int j)
+{
+    const int rs = (kp_rad + 31) >> 5;
+    return (j == rs - 1) ? kp_rad - 32 * (rs - 1) : 32;
+}
+
 constexpr int HBK = 32;            // reduction depth per LDS stage
 // LDS stage: 4 planes (A_hi, A_lo, B_hi, B_lo) of [128 rows][32 halves] = 64-B rows, no padding; the four
 // 16-B pieces of a row are XOR-swizzled with (row >> 2) & 3, which makes both the staging stores
@@ -346,7 +365,7 @@ struct HStage {
 
 template <int NB>
 __device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src0, const gf4 *a_src1,
-                                             int k_valid, float sa, const _Float16 *b_src0,
+                                             int k_valid, int kp_rad, float sa, const _Float16 *b_src0,
                                              const _Float16 *b_src1, int64_t bh_plane, int nk, _Float16 *sm,
                                              int wave)
 {
@@ -356,9 +375,10 @@ __device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src0
     const int fr = lane & 31, fk = lane >> 5;
     const v4f z4 = v4f{0.f, 0.f, 0.f, 0.f};
     auto gload = [&](HStage &st, int kt) {
-        // clamped, branch-free: columns >= k_valid re-read chunk 0 and are zeroed by a select
-        const bool ok = kt * HBK + piece * 8 < k_valid;
-        const int o = ok ? kt * (HBK / 4) : 0;
+        // clamped, branch-free: invalid columns re-read chunk 0 and are zeroed by a select
+        const int acol = kp_rad ? kp_col(kp_rad, kt) : kt * HBK;
+        const bool ok = kp_rad ? piece * 8 < kp_valid(kp_rad, kt) : kt * HBK + piece * 8 < k_valid;
+        const int o = ok ? acol / 4 : 0;
         st.a[0][0] = a_src0[o]; st.a[0][1] = a_src0[o + 1];
         st.a[1][0] = a_src1[o]; st.a[1][1] = a_src1[o + 1];
         if (!ok) { st.a[0][0] = z4; st.a[0][1] = z4; st.a[1][0] = z4; st.a[1][1] = z4; }
@@ -501,10 +521,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
     const int nk = pr.K / HBK;
     const int fr = lane & 31, fk = lane >> 5;
     switch (nb_act) {
-        case 4: gemm_h_kloop<4>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
-        case 3: gemm_h_kloop<3>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
-        case 2: gemm_h_kloop<2>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
-        default: gemm_h_kloop<1>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
+        case 4: gemm_h_kloop<4>(acc, a_src0, a_src1, pr.k_valid, EPI == EPI_BIAS_CELU ? g.kp_rad : 0, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
+        case 3: gemm_h_kloop<3>(acc, a_src0, a_src1, pr.k_valid, EPI == EPI_BIAS_CELU ? g.kp_rad : 0, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
+        case 2: gemm_h_kloop<2>(acc, a_src0, a_src1, pr.k_valid, EPI == EPI_BIAS_CELU ? g.kp_rad : 0, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
+        default: gemm_h_kloop<1>(acc, a_src0, a_src1, pr.k_valid, EPI == EPI_BIAS_CELU ? g.kp_rad : 0, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
     }
 
     float vmax = 0.f;
@@ -528,7 +548,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
                 v = v * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
                 *cp = v;
             } else {
-                if (col < g.n_store) g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + col] = v;
+                // column of the K'-ordered output -> AEV feature
+                const int cb = col >> 5;
+                const int feat = g.kp_rad ? kp_col(g.kp_rad, cb) + fr : col;
+                const bool okc = g.kp_rad ? fr < kp_valid(g.kp_rad, cb) : true;
+                if (okc && feat < g.n_store) g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + feat] = v;
             }
             vmax = fmaxf(vmax, fabsf(v));
         }
@@ -549,18 +573,21 @@ constexpr int GEMM2_THREADS = 512;
 
 template <int NB>
 __device__ __forceinline__ void gemm_h2_kloop(f32x16 (&acc)[8], const gf4 *a_src0, const gf4 *a_src1,
-                                              int k_valid, float sa, const _Float16 *b_src0,
-                                              const _Float16 *b_src1, int64_t bh_plane, int nk, _Float16 *sm,
-                                              int wm, int wn)
+                                              int k_valid, int kp_rad, uint32_t smask, int nk, float sa,
+                                              const _Float16 *b_src0, const _Float16 *b_src1, int64_t bh_plane,
+                                              _Float16 *sm, int wm, int wn)
 {
+    // smask != 0: iterate only the flagged 32-deep reduction slabs (layer-0 forward, K' order);
+    // smask == 0: all nk slabs
     const int tid = threadIdx.x, lane = tid & 63;
     const int srow = tid >> 2, piece = tid & 3;   // staging: rows srow and 128 + srow, 16-B piece
     const int fr = lane & 31, fk = lane >> 5;
     const v4f z4 = v4f{0.f, 0.f, 0.f, 0.f};
     HStage st;
     auto gload = [&](int kt) {
-        const bool ok = kt * HBK + piece * 8 < k_valid;
-        const int o = ok ? kt * (HBK / 4) : 0;
+        const int acol = kp_rad ? kp_col(kp_rad, kt) : kt * HBK;
+        const bool ok = kp_rad ? piece * 8 < kp_valid(kp_rad, kt) : kt * HBK + piece * 8 < k_valid;
+        const int o = ok ? acol / 4 : 0;
         st.a[0][0] = a_src0[o]; st.a[0][1] = a_src0[o + 1];
         st.a[1][0] = a_src1[o]; st.a[1][1] = a_src1[o + 1];
         if (!ok) { st.a[0][0] = z4; st.a[0][1] = z4; st.a[1][0] = z4; st.a[1][1] = z4; }
@@ -617,20 +644,37 @@ __device__ __forceinline__ void gemm_h2_kloop(f32x16 (&acc)[8], const gf4 *a_src
             }
         }
     };
-    gload(0);
+    // stage sequence: set bits of smask (ascending) or 0..nk-1
+    const bool masked = smask != 0u;
+    const int nact = masked ? __popc(smask) : nk;
+    if (nact == 0) return;
+    uint32_t rem = smask;
+    int seq = 0;
+    auto next_stage = [&]() {
+        int j;
+        if (masked) {
+            j = rem ? (int)__builtin_ctz(rem) : 0;
+            rem &= rem - 1;
+        } else {
+            j = seq < nk ? seq : nk - 1;
+            ++seq;
+        }
+        return j;
+    };
+    gload(next_stage());
     lstore(0);
-    gload(min(1, nk - 1));
+    gload(nact > 1 ? next_stage() : 0);
     __syncthreads();
     // main loop without branches in the body: the compiler interleaves the conversion VALU / ds_write of
-    // stage kt+1 and the global loads of stage kt+2 into the MFMA stream of stage kt
-    for (int kt = 0; kt < nk - 1; ++kt) {
-        const int buf = kt & 1;
+    // the next stage and the global loads of the one after into the MFMA stream of the current stage
+    for (int it = 0; it < nact - 1; ++it) {
+        const int buf = it & 1;
         if (NB > 0) compute(buf);
-        lstore(buf ^ 1);                      // stage kt+1 (its loads were issued one iteration ago)
-        gload(min(kt + 2, nk - 1));
+        lstore(buf ^ 1);                      // next stage (its loads were issued one iteration ago)
+        gload(next_stage());                  // (past the end: harmless re-load of a valid slab)
         __syncthreads();
     }
-    if (NB > 0) compute((nk - 1) & 1);
+    if (NB > 0) compute((nact - 1) & 1);
 }
 
 template <int EPI>
@@ -659,28 +703,78 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
     }
     if (s >= g.S) return;
     const GemmProblem &pr = g.prob[s];
-    const int n0 = col_t * BN2;
-    if (n0 >= pr.N) return;
     const int m0 = row_t * BM2;
     const int n_rows = cnt - m0;
     const int p0 = ctl[CTL_OFF + s] + m0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int nb_act = max(0, min(4, (pr.N - n0 - wn * 128) >> 5));   // active 32-column blocks of this wave
+    const int srow = tid >> 2, piece = tid & 3;
+    const int r0 = srow < n_rows ? srow : 0, r1 = srow + 128 < n_rows ? srow + 128 : 0;
+    const int64_t s0r = g.a_gather ? (int64_t)g.a_gather[p0 + r0] : (int64_t)(p0 + r0);
+    const int64_t s1r = g.a_gather ? (int64_t)g.a_gather[p0 + r1] : (int64_t)(p0 + r1);
+
+    // ---- slab mask of this row tile: OR over its atoms (layer 0 only) ----
+    uint32_t tmask = 0u;
+    int *s_tab = reinterpret_cast<int *>(sm2 + 2 * H2_STAGE);   // [0] = tile mask, [1..8] = column blocks
+    if (g.stage_mask) {
+        const int *rows = g.a_gather ? g.a_gather : g.c_scatter;   // sorted position -> atom
+        uint32_t mk = g.stage_mask[rows[p0 + r0]] | g.stage_mask[rows[p0 + r1]];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mk |= (uint32_t)__shfl_xor((int)mk, o);
+        if (tid == 0) s_tab[0] = 0;
+        __syncthreads();
+        if (lane == 0) atomicOr(reinterpret_cast<unsigned *>(&s_tab[0]), mk);
+        __syncthreads();
+        tmask = (uint32_t)s_tab[0];
+        if (tmask == 0u && EPI == EPI_SCATTER) return;   // atoms without neighbors: nothing to differentiate
+    }
+
+    // ---- columns of this tile ----
+    // EPI_SCATTER with a mask: the tile's 8 column blocks are the (8 col_t .. 8 col_t + 7)-th ACTIVE blocks;
+    // otherwise block j of the tile is 8 col_t + j
+    int n0 = col_t * BN2;
+    int cbw[4];                 // this wave's column blocks (K' block index), -1 = inactive
+    int nb_act;
+    const bool compact = (EPI == EPI_SCATTER) && g.stage_mask;
+    if (compact) {
+        if (col_t * 8 >= __popc(tmask)) return;
+        if (tid < 8) {
+            // slot nb of wave half wn takes the (8 col_t + 2 nb + wn)-th set bit of tmask (alternating, so
+            // a partially filled tile is balanced over the two halves)
+            const int want = col_t * 8 + 2 * (tid & 3) + (tid >> 2);
+            uint32_t m = tmask;
+            for (int k = 0; k < want; ++k) m &= m - 1;
+            s_tab[1 + tid] = m ? (int)__builtin_ctz(m) : -1;
+        }
+        __syncthreads();
+        nb_act = 0;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            cbw[nb] = s_tab[1 + wn * 4 + nb];
+            if (cbw[nb] >= 0) nb_act = nb + 1;
+        }
+    } else {
+        if (n0 >= pr.N) return;
+        nb_act = max(0, min(4, (pr.N - n0 - wn * 128) >> 5));
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) cbw[nb] = (n0 >> 5) + wn * 4 + nb;
+    }
     const float sa = g.amax_in >= 0 ? amax_scale(g.amax, g.amax_in, s) : g.a_static_scale;
     const float out_scale = pr.w_inv_scale / sa;
 
-    const int srow = tid >> 2, piece = tid & 3;
-    const gf4 *a_src0, *a_src1;
-    {
-        const int r0 = srow < n_rows ? srow : 0, r1 = srow + 128 < n_rows ? srow + 128 : 0;
-        const int64_t s0r = g.a_gather ? (int64_t)g.a_gather[p0 + r0] : (int64_t)(p0 + r0);
-        const int64_t s1r = g.a_gather ? (int64_t)g.a_gather[p0 + r1] : (int64_t)(p0 + r1);
-        a_src0 = (const gf4 *)(g.A + s0r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
-        a_src1 = (const gf4 *)(g.A + s1r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
+    const gf4 *a_src0 = (const gf4 *)(g.A + s0r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
+    const gf4 *a_src1 = (const gf4 *)(g.A + s1r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
+    // B rows staged by this thread: tile columns srow and srow + 128
+    int bn0, bn1;
+    if (compact) {
+        const int c0 = s_tab[1 + (srow >> 5)], c1 = s_tab[1 + 4 + (srow >> 5)];
+        bn0 = (c0 >= 0 ? c0 : 0) * 32 + (srow & 31);
+        bn1 = (c1 >= 0 ? c1 : 0) * 32 + (srow & 31);
+    } else {
+        bn0 = (n0 + srow < pr.N) ? n0 + srow : n0;
+        bn1 = (n0 + srow + 128 < pr.N) ? n0 + srow + 128 : n0;
     }
-    const int bn0 = (n0 + srow < pr.N) ? n0 + srow : n0, bn1 = (n0 + srow + 128 < pr.N) ? n0 + srow + 128 : n0;
     const _Float16 *b_src0 = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)bn0 * pr.ldbh + piece * 8;
     const _Float16 *b_src1 = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)bn1 * pr.ldbh + piece * 8;
 
@@ -692,21 +786,28 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
 
     const int nk = pr.K / HBK;
     const int fr = lane & 31, fk = lane >> 5;
-    switch (nb_act) {
-        case 4: gemm_h2_kloop<4>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
-        case 3: gemm_h2_kloop<3>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
-        case 2: gemm_h2_kloop<2>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
-        case 1: gemm_h2_kloop<1>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
-        default: gemm_h2_kloop<0>(acc, a_src0, a_src1, pr.k_valid, sa, b_src0, b_src1, pr.bh_plane, nk, sm2, wm, wn); break;
+    const int kp_a = EPI == EPI_BIAS_CELU ? g.kp_rad : 0;               // K' order on the reduction side
+    const uint32_t smask = (EPI == EPI_BIAS_CELU && g.stage_mask) ? tmask : 0u;
+    if (!(EPI == EPI_BIAS_CELU && g.stage_mask && tmask == 0u)) {
+        switch (nb_act) {
+            case 4: gemm_h2_kloop<4>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+            case 3: gemm_h2_kloop<3>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+            case 2: gemm_h2_kloop<2>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+            case 1: gemm_h2_kloop<1>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+            default: gemm_h2_kloop<0>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+        }
     }
 
     float vmax = 0.f;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-        if (nb >= nb_act) continue;
-        const int col = n0 + wn * 128 + nb * 32 + fr;
+        if (nb >= nb_act || cbw[nb] < 0) continue;
+        const int col = cbw[nb] * 32 + fr;   // column in the (K'-ordered, for layer-0 bwd) output space
         float bias = 0.f;
         if (EPI == EPI_BIAS_CELU) bias = pr.bias[(int64_t)bb * pr.bias_stride + col];
+        // layer-0 backward: K' column -> AEV feature
+        const int feat = (EPI == EPI_SCATTER && g.kp_rad) ? kp_col(g.kp_rad, cbw[nb]) + fr : col;
+        const bool okc = (EPI == EPI_SCATTER && g.kp_rad) ? fr < kp_valid(g.kp_rad, cbw[nb]) : true;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -718,7 +819,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
                     v = celu(v + bias, g.alpha, g.inv_alpha);
                     g.C[(int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col] = v;
                 } else if (EPI == EPI_SCATTER) {
-                    if (col < g.n_store) g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + col] = v;
+                    if (okc && feat < g.n_store) g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + feat] = v;
                 }
                 vmax = fmaxf(vmax, fabsf(v));
             }
@@ -1339,6 +1440,9 @@ static int check_desc(const anihip_mlp_desc *d)
     ANIHIP_REQUIRE(d->n_members >= 1 && d->n_members <= 64, "n_members must be 1..64");
     ANIHIP_REQUIRE(d->aev_len % BK == 0, "aev_len must be a multiple of %d", BK);
     ANIHIP_REQUIRE(d->precision == ANIHIP_MLP_FP32 || d->precision == ANIHIP_MLP_F16X3, "unknown precision");
+    ANIHIP_REQUIRE(d->aev_radial_len >= 0 && d->aev_radial_len <= d->aev_len &&
+                       (d->aev_radial_len == 0 || (d->aev_len - d->aev_radial_len) % 32 == 0),
+                   "aev_radial_len: the angular part must be a multiple of 32 long");
     const int nl = d->net[0].n_layers;
     ANIHIP_REQUIRE(nl >= 2 && nl <= ANIHIP_MAX_LAYERS, "n_layers must be 2..%d", ANIHIP_MAX_LAYERS);
     for (int s = 0; s < d->num_species; ++s) {
@@ -1378,7 +1482,7 @@ template <int EPI>
 static int launch_gemm_big(hipStream_t stream, GemmArgs &g, int64_t n_rows_total)
 {
     // 256 x 256 tiles: recompute the tile upper bounds for this tiling
-    const size_t lds = sizeof(_Float16) * 2 * H2_STAGE;
+    const size_t lds = sizeof(_Float16) * 2 * H2_STAGE + 64;
     int nmax = 0;
     for (int s = 0; s < g.S; ++s) nmax = nmax > g.prob[s].N ? nmax : g.prob[s].N;
     GemmArgs h = g;
@@ -1403,8 +1507,8 @@ static void launch_gemm(hipStream_t stream, GemmArgs &g, bool f16x3)
 
 extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc *d, int64_t n_atoms,
                                            int64_t lo, int64_t hi, const int32_t *species, const float *aev,
-                                           void *workspace, size_t workspace_bytes, float *atomic_e,
-                                           float *grad_aev, float *member_e)
+                                           const uint32_t *slab_mask, void *workspace, size_t workspace_bytes,
+                                           float *atomic_e, float *grad_aev, float *member_e)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
@@ -1417,9 +1521,11 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     mlp_carve(d, n, (char *)workspace, &w);
     const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1;
     const int L = d->aev_len;
-    const int K0p = ((L + 31) / 32) * 32;
-    const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
     const bool h3 = d->precision == ANIHIP_MLP_F16X3;
+    // layer-0 reduction length: plain AEV order padded to 32, or the slab order of the fp16 planes
+    const int kp_rad = h3 ? d->aev_radial_len : 0;
+    const int K0p = kp_rad > 0 ? 32 * ((kp_rad + 31) / 32 + (L - kp_rad) / 32) : ((L + 31) / 32) * 32;
+    const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
 
     // 1. bucket by species
     ANIHIP_CHECK_HIP(hipMemsetAsync(w.ctl, 0, sizeof(int) * (CTL_WORDS + AMAX_WORDS), stream));
@@ -1453,6 +1559,9 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     // 256 x 256 tiles for the layer-0 GEMMs once there are enough rows to fill the chip with them
     bool big_tiles = h3 && n >= 16384;
     if (const char *e = getenv("ANIHIP_GEMM_TILE")) big_tiles = h3 && e[0] == '2';
+    // per-atom slab flags: honoured by the 256 x 256 kernels on slab-ordered planes
+    const uint32_t *smask = (big_tiles && kp_rad > 0 && K0p <= 32 * 32) ? slab_mask : nullptr;
+    if (const char *e = getenv("ANIHIP_NO_SLAB_MASK")) smask = e[0] == '0' ? smask : nullptr;
 
     // 2. forward through the hidden layers
     for (int l = 0; l < (fused ? 1 : nh); ++l) {
@@ -1492,6 +1601,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         }
         g.amax = w.amax; g.amax_out = h3 ? l : -1; g.amax_in = (h3 && l > 0) ? l - 1 : -1;
         g.a_static_scale = 4.0f;  // layer-0 input: |aev| < 16376 by construction (see include/anihip.h)
+        if (l == 0) { g.kp_rad = kp_rad; g.stage_mask = smask; }
         if (h3 && l == 0 && big_tiles) {
             if (int rc = launch_gemm_big<EPI_BIAS_CELU>(stream, g, n)) return rc;
         } else {
@@ -1553,7 +1663,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             g.A = w.act[l]; g.lda = w.ld[l]; g.a_gather = nullptr;
             if (l == 0) {
                 g.batch = 1; g.C = grad_aev; g.ldc = L; g.c_scatter = w.perm; g.n_store = L;
-                g.ncol_max = (((L + 31) / 32) * 32 + BN - 1) / BN;
+                g.ncol_max = (K0p + BN - 1) / BN;
             } else {
                 g.batch = M; g.C = w.act[l - 1]; g.ldc = w.ld[l - 1]; g.c_scatter = nullptr;
                 g.ncol_max = ncol_of(l, false);
@@ -1583,6 +1693,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             g.amax_in = h3 ? 3 + (nh - 1 - l) : -1;
             g.amax_out = (h3 && l > 0) ? 3 + (nh - l) : -1;
             g.a_static_scale = 1.0f;
+            if (l == 0) { g.kp_rad = kp_rad; g.stage_mask = smask; }
             if (l == 0 && h3 && big_tiles) {
                 if (int rc = launch_gemm_big<EPI_SCATTER>(stream, g, n)) return rc;
             } else if (l == 0) {

@@ -138,16 +138,27 @@ class AevEngine:
         return NeighborRows(meta, ent, status, row_cap, lo, hi)
 
     # ---- AEV ----------------------------------------------------------------------------------------
-    def forward(self, species: Tensor, nbrs: NeighborRows, out: tp.Optional[Tensor] = None) -> Tensor:
-        """AEV rows [N, L] for the central atoms nbrs.lo..nbrs.hi (other rows are left untouched)."""
-        _require_cuda(species)
+    @property
+    def n_slabs(self) -> int:
+        """Number of 32-wide slabs of an AEV row in slab order (include/anihip.h)."""
+        S = self.params.num_species
+        return (S + 1) // 2 + S * (S + 1) // 2
+
+    def forward(self, species: Tensor, nbrs: NeighborRows, out: tp.Optional[Tensor] = None,
+                slab_mask: tp.Optional[Tensor] = None) -> Tensor:
+        """AEV rows [N, L] for the central atoms nbrs.lo..nbrs.hi (other rows are left untouched).
+        slab_mask (optional int32 [N], written for the same atoms): flags of the slabs of each row that are
+        not identically zero, consumed by PackedNetworks.forward_backward."""
+        _require_cuda(species, slab_mask)
         n = species.numel()
         if out is None:
             alloc = torch.empty if (nbrs.lo == 0 and nbrs.hi == n) else torch.zeros
             out = alloc((n, self.L), dtype=torch.float32, device=species.device)
+        if slab_mask is not None:
+            assert slab_mask.dtype == torch.int32 and slab_mask.numel() == n and slab_mask.is_contiguous()
         _lib.check(_lib.lib().anihip_aev_forward(
             _stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
-            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent), _ptr(out), _ptr(nbrs.status)))
+            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent), _ptr(out), _ptr(slab_mask), _ptr(nbrs.status)))
         return out
 
     def backward(self, species: Tensor, nbrs: NeighborRows, grad_aev: Tensor,
@@ -176,8 +187,12 @@ class PackedNetworks:
 
     def __init__(self, weights: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]],
                  biases: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]], aev_len: int, celu_alpha: float,
-                 device: torch.device, precision: str = "f16x3") -> None:
+                 device: torch.device, precision: str = "f16x3", radial_len: tp.Optional[int] = None) -> None:
         """weights[m][s][l]: [out, in] (torch.nn.Linear layout) of member m, species s, layer l.
+
+        radial_len: length R of the radial part of the AEV; the layer-0 fp16 planes are then stored in slab
+        order (include/anihip.h) so that forward_backward can skip all-zero AEV blocks given slab masks.
+        Default: 16 S when aev_len has the ANI form 16 S + 32 S(S+1)/2, else plain order.
 
         precision: "fp32" (exact fp32 MFMA) or "f16x3" (split-fp16 three-product MFMA, ~4e-7 relative
         error per product, see include/anihip.h)."""
@@ -197,6 +212,16 @@ class PackedNetworks:
         d.num_species, d.n_members, d.aev_len, d.celu_alpha = S, M, aev_len, celu_alpha
         d.precision = _lib.MLP_F16X3 if precision == "f16x3" else _lib.MLP_FP32
         k0p = _pad32(aev_len)
+        if radial_len is None:
+            radial_len = 16 * S if aev_len == 16 * S + 16 * S * (S + 1) else 0
+        if precision != "f16x3" or radial_len <= 0 or (aev_len - radial_len) % 32 != 0:
+            radial_len = 0
+        self.radial_len = d.aev_radial_len = radial_len
+        # slab order: column of the padded layer-0 reduction index <- AEV feature
+        rpad = _pad32(radial_len)
+        k0h = rpad + (aev_len - radial_len) if radial_len else k0p
+        slab_cols = torch.cat([torch.arange(radial_len), rpad + torch.arange(aev_len - radial_len)]).to(device) \
+            if radial_len else torch.arange(aev_len, device=device)
         f32 = dict(dtype=torch.float32, device=device)
         for s in range(S):
             net = d.net[s]
@@ -244,12 +269,13 @@ class PackedNetworks:
                     amax = float(Wst.abs().max())
                     scale = 2.0 ** (13 - int(np.floor(np.log2(amax)))) if amax > 0 else 1.0
                     if l == 0:
-                        bwd_src = torch.zeros((k0p, M * kout), **f32)   # w padded to K0p rows
-                        bwd_src[:kin] = w
+                        fwd_src = torch.zeros((M * kout, k0h), **f32)   # wt, columns in slab order
+                        fwd_src[:, slab_cols] = cat
+                        bwd_src = fwd_src.t().contiguous()              # [K0h, M*H1p]
                     else:
-                        bwd_src = w
+                        fwd_src, bwd_src = wt, w
                     planes = []
-                    for src in (wt, bwd_src):
+                    for src in (fwd_src, bwd_src):
                         x = src * scale
                         hi = x.to(torch.float16)
                         lo = (x - hi.to(torch.float32)).to(torch.float16)
@@ -280,10 +306,18 @@ class PackedNetworks:
 
     def forward_backward(self, species: Tensor, aev: Tensor, lo: int = 0, hi: tp.Optional[int] = None,
                          want_grad: bool = True, want_members: bool = False, chunk: int = 1 << 18,
-                         atomic_e: tp.Optional[Tensor] = None, grad_aev: tp.Optional[Tensor] = None
+                         atomic_e: tp.Optional[Tensor] = None, grad_aev: tp.Optional[Tensor] = None,
+                         slab_mask: tp.Optional[Tensor] = None
                          ) -> tp.Tuple[Tensor, tp.Optional[Tensor], tp.Optional[Tensor]]:
-        """Per-atom ensemble-mean energies [N], d e/d aev [N,L] (optional), member energies [M,N]."""
-        _require_cuda(species, aev)
+        """Per-atom ensemble-mean energies [N], d e/d aev [N,L] (optional), member energies [M,N].
+
+        slab_mask (int32 [N] from AevEngine.forward): the layer-0 GEMMs skip AEV slabs no atom of a row tile
+        flags; grad_aev is then only defined inside the flagged slabs (all AevEngine.backward reads)."""
+        _require_cuda(species, aev, slab_mask)
+        if slab_mask is not None:
+            assert slab_mask.dtype == torch.int32 and slab_mask.numel() == species.numel()
+            if self.radial_len == 0:
+                slab_mask = None
         n = species.numel()
         hi = n if hi is None else hi
         assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == n * self.aev_len
@@ -299,7 +333,8 @@ class PackedNetworks:
             c1 = min(hi, c0 + chunk)
             ws = self.workspace(c1 - c0)
             _lib.check(L.anihip_mlp_forward_backward(
-                _stream(), C.byref(self.desc), n, c0, c1, _ptr(species), _ptr(aev), _ptr(ws), ws.numel(),
+                _stream(), C.byref(self.desc), n, c0, c1, _ptr(species), _ptr(aev), _ptr(slab_mask), _ptr(ws),
+                ws.numel(),
                 _ptr(atomic_e), _ptr(grad_aev) if want_grad else None, _ptr(member_e)))
         return atomic_e, (grad_aev if want_grad else None), member_e
 

@@ -114,10 +114,15 @@ class ANI(torch.nn.Module):
         pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
         nbrs = eng.neighbors(species32, c32, cell, pbc_t, lo=lo, hi=hi, mode=aevc.neighbor_mode,
                              row_cap=aevc.row_capacity)
-        aev = eng.forward(species32, nbrs)
         packed = self.neural_networks._pack(c32.device)
+        # per-atom flags of the AEV slabs that are not identically zero (absent neighbor species): the
+        # layer-0 GEMMs skip the others
+        slab_mask = None
+        if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
+            slab_mask = torch.zeros(n, dtype=torch.int32, device=c32.device)
+        aev = eng.forward(species32, nbrs, slab_mask=slab_mask)
         atomic_e, grad_aev, _ = packed.forward_backward(species32, aev, lo=lo, hi=hi, want_grad=True,
-                                                        chunk=self.mlp_chunk)
+                                                        chunk=self.mlp_chunk, slab_mask=slab_mask)
         grad_coords = eng.backward(species32, nbrs, grad_aev)
         sae = None
         if self.energy_shifter._enabled:
