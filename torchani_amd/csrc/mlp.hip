@@ -688,7 +688,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
         const int qd = nwg >> 3, rm = nwg & 7, xcd = id & 7;
         id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
     }
-    const int col_t = id % g.ncol_max;
+    const int col_t0 = id % g.ncol_max;
     const int bb = (id / g.ncol_max) % g.batch;
     int row_t = id / (g.ncol_max * g.batch);
 
@@ -733,12 +733,16 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
     // ---- columns of this tile ----
     // EPI_SCATTER with a mask: the tile's 8 column blocks are the (8 col_t .. 8 col_t + 7)-th ACTIVE blocks;
     // otherwise block j of the tile is 8 col_t + j
+    const bool compact = (EPI == EPI_SCATTER) && g.stage_mask;
+    const int ncg = compact ? (__popc(tmask) + 7) >> 3 : 1;
+    float vmax = 0.f;
+    for (int cg = 0; cg < ncg; ++cg) {
+    const int col_t = compact ? cg : col_t0;
     int n0 = col_t * BN2;
     int cbw[4];                 // this wave's column blocks (K' block index), -1 = inactive
     int nb_act;
-    const bool compact = (EPI == EPI_SCATTER) && g.stage_mask;
     if (compact) {
-        if (col_t * 8 >= __popc(tmask)) return;
+        if (cg > 0) __syncthreads();   // the previous group is done with s_tab and the staging buffers
         if (tid < 8) {
             // slot nb of wave half wn takes the (8 col_t + 2 nb + wn)-th set bit of tmask (alternating, so
             // a partially filled tile is balanced over the two halves)
@@ -798,7 +802,6 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
         }
     }
 
-    float vmax = 0.f;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         if (nb >= nb_act || cbw[nb] < 0) continue;
@@ -824,6 +827,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
                 vmax = fmaxf(vmax, fabsf(v));
             }
     }
+    }   // column groups
     if (g.amax_out >= 0) amax_update(g.amax, g.amax_out, s, vmax);
 }
 
@@ -1487,6 +1491,10 @@ static int launch_gemm_big(hipStream_t stream, GemmArgs &g, int64_t n_rows_total
     for (int s = 0; s < g.S; ++s) nmax = nmax > g.prob[s].N ? nmax : g.prob[s].N;
     GemmArgs h = g;
     h.ncol_max = (nmax + BN2 - 1) / BN2;
+    // compacted output columns (layer-0 backward with slab masks): one workgroup per row tile walks the
+    // groups of 8 active column blocks itself.  (Launching a workgroup per potential column tile and
+    // letting the empty ones exit cost 3x the kernel time: every 128-KB-LDS workgroup occupies a CU slot.)
+    if (EPI == EPI_SCATTER && g.stage_mask) h.ncol_max = 1;
     h.nrow_tiles_ub = (int)((n_rows_total + BM2 - 1) / BM2) + g.S;
     ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_h2<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
