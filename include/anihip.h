@@ -152,10 +152,11 @@ typedef struct {
     const void *wh[ANIHIP_MAX_LAYERS];
     const void *wth[ANIHIP_MAX_LAYERS];
     float wh_scale[ANIHIP_MAX_LAYERS];
-    /* optional (layers 1..n_layers-2): the same planes re-ordered into MFMA fragment order
+    /* optional: the same planes re-ordered into MFMA fragment order
      * [member][N/32][K/16][2 planes][64 lanes][8 halves] (lane l <-> output n = 32 cb + (l & 31),
-     * k = 16 ks + 8 (l >> 5) + j) for the fused hidden-stack kernel, which streams them straight into
-     * registers.  NULL disables the fused kernel. */
+     * k = 16 ks + 8 (l >> 5) + j) for the fused network kernel, which streams them straight into
+     * registers: whf[l] for layers 0..n_layers-2 (layer 0 per member: N = H1p, K = K0p in the order of
+     * wh[0]), wthf[l] for layers 1..n_layers-2.  NULL disables the fused kernel. */
     const void *whf[ANIHIP_MAX_LAYERS];
     const void *wthf[ANIHIP_MAX_LAYERS];
 } anihip_species_net;

@@ -831,31 +831,39 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
     if (g.amax_out >= 0) amax_update(g.amax, g.amax_out, s, vmax);
 }
 
-// ---- fused hidden stack (f16x3) ----------------------------------------------------------------------
-// The hidden layers behind layer 0 are small (Hl <= 256) and, run as separate GEMMs, are bound by the
-// HBM round trips of their activations (~73 KB per atom).  This kernel keeps them on chip: one
-// workgroup takes 64 atoms of one species and ONE ensemble member through
-//   act0 -> L1 -> act1 -> L2 -> act2 -> output layer (energy) -> d act2 -> d act1 -> d act0
-// reading act0 (layer-0 output) once and overwriting it with d(E)/d(act0) for the final layer-0
-// backward GEMM.  Activations / gradients live in LDS as split-fp16 {hi, lo} planes with a per-tile
-// power-of-two scale (tile max via an LDS atomic).  The weights are pre-packed on the host in MFMA
-// FRAGMENT ORDER ([col block][k step][plane][lane][8 halves]) so every wave streams its B operands
-// straight from L2 into registers with fully coalesced 1-KB loads through a deep register ring: no LDS
-// staging, no barriers inside a GEMM phase (the GEMV-style weight path of the CDNA guide, applied to
-// a 64-row tile).  MFMAs are the three-product v_mfma_f32_32x32x16_f16 of k_gemm_h.
-constexpr int FB_ROWS = 32;     // atoms per workgroup (32: two workgroups per CU overlap MFMA and epilogue phases)
-constexpr int FB_RB = FB_ROWS / 32;   // 32-row MFMA blocks per wave
-constexpr int FB_TPR = 256 / FB_ROWS; // threads per row in the thread-mapped sections
-constexpr int FB_MAXH = 256;    // largest padded hidden width
-constexpr int FB_DEPTH = 6;     // k steps of B fragments in flight per wave
-constexpr int FRAG = 512;       // halves per fragment plane: 64 lanes x 8
+// ---- fused network kernel (f16x3) ---------------------------------------------------------------------
+// Run as separate GEMMs the network is bound by the HBM round trips of its activations (~73 KB per atom for
+// the hidden layers, 16 KB more for the layer-0 output).  This kernel keeps them on chip: one workgroup
+// takes 64 atoms of one species and ONE ensemble member through
+//   AEV rows -> L0 -> act0 -> L1 -> act1 -> L2 -> act2 -> output layer (energy)
+//            -> d act2 -> d act1 -> d act0                                   (-> layer-0 backward GEMM)
+// Layer 0 reads only the AEV slabs the tile's slab mask flags (include/anihip.h): the fp32 slab tiles
+// (64 rows x 32 columns) are split into fp16 {hi, lo} planes in LDS, three slabs per barrier, double
+// buffered.  Activations / gradients live in LDS as split-fp16 planes with a per-tile power-of-two scale
+// (tile max via an LDS atomic); the CELU derivatives of act0 / act1 stay in registers (the wave that
+// produces a column block of a layer is the one that needs its derivative on the way back).  The weights
+// are pre-packed on the host in MFMA FRAGMENT ORDER ([col block][k step][plane][lane][8 halves]) so every
+// wave streams its B operands straight from L2 into registers with fully coalesced 1-KB loads through a
+// register ring: no LDS staging of weights, no barriers inside a GEMM phase.  8 waves; wave w owns all 64
+// rows (two 32-row MFMA blocks: every weight fragment feeds six MFMAs) and column block w of each phase.
+// MFMAs are the three-product v_mfma_f32_32x32x16_f16 of k_gemm_h.
+constexpr int FR_ROWS = 64;       // atoms per workgroup
+constexpr int FR_THREADS = 512;
+constexpr int FR_TPR = FR_THREADS / FR_ROWS;   // threads per row in the thread-mapped sections
+constexpr int FR_MAXH = 256;      // largest padded hidden width (8 waves x 32 columns)
+constexpr int FR_DEPTH = 6;       // k steps of B fragments in flight per wave
+constexpr int FRAG = 512;         // halves per fragment plane: 64 lanes x 8
+constexpr int FR_SLAB_LD = 40;    // halves per staged slab row (32 + 8: conflict-free ds_read_b128)
+constexpr int FR_SLAB = 2 * FR_ROWS * FR_SLAB_LD;   // halves per staged slab {hi plane, lo plane}
+constexpr int FR_GROUP = 3;       // slabs per barrier (= FR_DEPTH / 2 k steps)
+constexpr int FR_STAGE_HALVES = 2 * FR_GROUP * FR_SLAB;   // double-buffered staging area
 
 struct FusedSpecies {
     int H1, H2, H3;                          // padded widths
     // fragment-ordered planes, per member: [N/32][K/16][2][64][8]
-    const _Float16 *w1, *w2, *w2t, *w1t;     // (N,K) = (H2,H1), (H3,H2), (H2,H3), (H1,H2)
-    float is1, is2;                          // 1 / weight scales of hidden layers 1 and 2
-    const float *b1, *b2;                    // [M][H2], [M][H3]
+    const _Float16 *w0, *w1, *w2, *w2t, *w1t;  // (N,K) = (H1,K0p), (H2,H1), (H3,H2), (H2,H3), (H1,H2)
+    float is0, is1, is2;                     // 1 / weight scales of layers 0, 1 and 2
+    const float *b0, *b1, *b2;               // [M*H1], [M][H2], [M][H3]
     const float *w3, *b3;                    // output layer [M][H3], [M]
 };
 
@@ -863,10 +871,14 @@ struct FusedArgs {
     FusedSpecies sp[MAX_S];
     const int *ctl;
     unsigned *amax;
-    float *act0;       // [n][ld0]: in: layer-0 activations, out: d E / d act0
+    const float *aev;          // [n_atoms][L]
+    int64_t L;
+    int kp_rad, n_slabs;       // slab order of the layer-0 planes (kp_rad = 0: plain order, 32-column slabs)
+    const uint32_t *slab_mask; // per atom, or NULL (all slabs)
+    float *d0;                 // [n][ld0]: out: d E / d act0 (member m at columns m*H1..)
     int64_t ld0;
-    const int *perm;
-    float *member_part;  // [n][M] per-member atomic energies (summed by k_fused_finish)
+    const int *perm;           // sorted position -> atom
+    float *member_part;        // [n][M] per-member atomic energies (summed by k_fused_finish)
     int S, M;
     float alpha, inv_alpha;
     int want_grad;
@@ -879,129 +891,127 @@ __device__ __forceinline__ float pow2_scale_for(float mx)
     return __uint_as_float((unsigned)(127 + 13 - e) << 23);
 }
 
-// Register ring of B fragments for NB column blocks of one wave.
-template <int NB>
-struct BRing {
-    h8 hi[FB_DEPTH][NB], lo[FB_DEPTH][NB];
-    const _Float16 *base;  // fragment (cb0, ks = 0, plane 0) + lane * 8
-    int ks_stride;         // halves between consecutive k steps      = 2 * FRAG
-    int cb_stride;         // halves between consecutive column blocks = KS * 2 * FRAG
-    int KS;
-    // unconditional (clamped) loads: a branch around a load makes hipcc drain the whole ring with
-    // s_waitcnt vmcnt(0) at every join (CDNA guide, "load everything or hoist the condition")
+// Register ring of the B fragments {hi, lo} of one column block, FR_DEPTH k steps deep.  Loads are
+// unconditional (callers clamp the k step): a branch around a load makes hipcc drain the whole ring with
+// s_waitcnt vmcnt(0) at every join (CDNA guide, "load everything or hoist the condition").
+struct WRing {
+    h8 hi[FR_DEPTH], lo[FR_DEPTH];
+    const _Float16 *base;   // fragment (cb, ks = 0, plane 0) + lane * 8
     template <int SLOT>
     __device__ __forceinline__ void load(int ks)
     {
-        ks = ks < KS ? ks : KS - 1;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const _Float16 *p = base + (int64_t)nb * cb_stride + (int64_t)ks * ks_stride;
-            hi[SLOT][nb] = *(const gh8 *)p;
-            lo[SLOT][nb] = *(const gh8 *)(p + FRAG);
-        }
-    }
-    __device__ __forceinline__ void prime()
-    {
-        load<0>(0); load<1>(1); load<2>(2); load<3>(3); load<4>(4); load<5>(5);
+        const _Float16 *p = base + (int64_t)ks * (2 * FRAG);
+        hi[SLOT] = *(const gh8 *)p;
+        lo[SLOT] = *(const gh8 *)(p + FRAG);
     }
 };
 
-// acc[nb] += X[wave rows, :] x B[cols]^T over all k steps; A fragments from LDS planes (xa = hi plane of the
-// wave's row, + x_plane = lo), B fragments from the ring.  KS is even; the main loop runs whole groups
-// of FB_DEPTH steps without any branch, the tail (0, 2 or 4 steps) issues no loads.
-template <int NB>
-__device__ __forceinline__ void fb_gemm(f32x16 (&acc)[4], const _Float16 *xa, int ldx, int x_plane, BRing<NB> &rg)
+// one k step: acc[rb] += A[rb rows, 16 k] x B[16 k, 32 cols] for both 32-row blocks, three products.
+// a = hi-plane fragment address of this lane for row block 0; + a_plane = lo plane; + rb_stride = row block 1
+template <int SLOT>
+__device__ __forceinline__ void fr_step(f32x16 (&acc)[2], const WRing &rg, const _Float16 *a, int a_plane,
+                                        int rb_stride)
 {
-    // this wave: all FB_ROWS rows (FB_RB 32-row blocks) x its NB column blocks; acc[rb * 2 + nb]
+    const h8 ah0 = *reinterpret_cast<const h8 *>(a), al0 = *reinterpret_cast<const h8 *>(a + a_plane);
+    const h8 ah1 = *reinterpret_cast<const h8 *>(a + rb_stride);
+    const h8 al1 = *reinterpret_cast<const h8 *>(a + rb_stride + a_plane);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, rg.hi[SLOT], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, rg.hi[SLOT], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, rg.lo[SLOT], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, rg.lo[SLOT], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, rg.hi[SLOT], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, rg.hi[SLOT], acc[1], 0, 0, 0);
+}
+
+// ring of column block `cb` of a [N/32][KS] fragment matrix of member m, first FR_DEPTH steps in flight
+__device__ __forceinline__ void fr_ring(WRing &r, const _Float16 *w, int64_t member_halves, int m, int KS, int cb)
+{
+    r.base = w + (int64_t)m * member_halves + (int64_t)cb * KS * (2 * FRAG) + (threadIdx.x & 63) * 8;
+    r.load<0>(0);
+    r.load<1>(min(1, KS - 1));
+    r.load<2>(min(2, KS - 1));
+    r.load<3>(min(3, KS - 1));
+    r.load<4>(min(4, KS - 1));
+    r.load<5>(min(5, KS - 1));
+}
+
+// acc += X[64 rows, K] x B over all KS = K/16 k steps (KS even): whole groups of FR_DEPTH steps without a
+// branch, the tail (0, 2 or 4 steps) issues no loads.  xa = hi plane of X, ldx = row stride (halves)
+__device__ __forceinline__ void fr_gemm(f32x16 (&acc)[2], const _Float16 *xa, int ldx, int x_plane, WRing &rg,
+                                        int KS)
+{
     const int lane = threadIdx.x & 63, fr = lane & 31, fk = lane >> 5;
     const _Float16 *af = xa + fr * ldx + fk * 8;
-    auto step = [&](const h8 (&bh)[NB], const h8 (&bl)[NB], int ks) {
-        h8 ah[FB_RB], al[FB_RB];
-#pragma unroll
-        for (int rb = 0; rb < FB_RB; ++rb) {
-            ah[rb] = *reinterpret_cast<const h8 *>(af + rb * 32 * ldx + ks * 16);
-            al[rb] = *reinterpret_cast<const h8 *>(af + rb * 32 * ldx + x_plane + ks * 16);
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int rb = 0; rb < FB_RB; ++rb)
-                acc[rb * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rb], bh[nb], acc[rb * 2 + nb], 0, 0, 0);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int rb = 0; rb < FB_RB; ++rb)
-                acc[rb * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], bl[nb], acc[rb * 2 + nb], 0, 0, 0);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int rb = 0; rb < FB_RB; ++rb)
-                acc[rb * 2 + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], bh[nb], acc[rb * 2 + nb], 0, 0, 0);
-    };
+    const int rbs = 32 * ldx;
     int k0 = 0;
-    for (; k0 + FB_DEPTH <= rg.KS; k0 += FB_DEPTH) {
-        step(rg.hi[0], rg.lo[0], k0);     rg.template load<0>(k0 + FB_DEPTH);
-        step(rg.hi[1], rg.lo[1], k0 + 1); rg.template load<1>(k0 + 1 + FB_DEPTH);
-        step(rg.hi[2], rg.lo[2], k0 + 2); rg.template load<2>(k0 + 2 + FB_DEPTH);
-        step(rg.hi[3], rg.lo[3], k0 + 3); rg.template load<3>(k0 + 3 + FB_DEPTH);
-        step(rg.hi[4], rg.lo[4], k0 + 4); rg.template load<4>(k0 + 4 + FB_DEPTH);
-        step(rg.hi[5], rg.lo[5], k0 + 5); rg.template load<5>(k0 + 5 + FB_DEPTH);
+    for (; k0 + FR_DEPTH <= KS; k0 += FR_DEPTH) {
+        const _Float16 *a = af + k0 * 16;
+        fr_step<0>(acc, rg, a, x_plane, rbs);      rg.load<0>(min(k0 + 6, KS - 1));
+        fr_step<1>(acc, rg, a + 16, x_plane, rbs); rg.load<1>(min(k0 + 7, KS - 1));
+        fr_step<2>(acc, rg, a + 32, x_plane, rbs); rg.load<2>(min(k0 + 8, KS - 1));
+        fr_step<3>(acc, rg, a + 48, x_plane, rbs); rg.load<3>(min(k0 + 9, KS - 1));
+        fr_step<4>(acc, rg, a + 64, x_plane, rbs); rg.load<4>(min(k0 + 10, KS - 1));
+        fr_step<5>(acc, rg, a + 80, x_plane, rbs); rg.load<5>(min(k0 + 11, KS - 1));
     }
-    const int rem = rg.KS - k0;
+    const int rem = KS - k0;
+    const _Float16 *a = af + k0 * 16;
     if (rem >= 2) {
-        step(rg.hi[0], rg.lo[0], k0);
-        step(rg.hi[1], rg.lo[1], k0 + 1);
+        fr_step<0>(acc, rg, a, x_plane, rbs);
+        fr_step<1>(acc, rg, a + 16, x_plane, rbs);
     }
     if (rem >= 4) {
-        step(rg.hi[2], rg.lo[2], k0 + 2);
-        step(rg.hi[3], rg.lo[3], k0 + 3);
+        fr_step<2>(acc, rg, a + 32, x_plane, rbs);
+        fr_step<3>(acc, rg, a + 48, x_plane, rbs);
     }
 }
 
-template <int NB>
-__device__ __forceinline__ BRing<NB> fb_ring(const _Float16 *w, int64_t member_halves, int m, int K)
+__global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
 {
-    // this wave's column blocks are {wave, wave + 4}
-    BRing<NB> r;
-    r.KS = K >> 4;
-    r.ks_stride = 2 * FRAG;
-    const int one_cb = r.KS * 2 * FRAG;
-    r.cb_stride = 4 * one_cb;
-    r.base = w + (int64_t)m * member_halves + (int64_t)(threadIdx.x >> 6) * one_cb + (threadIdx.x & 63) * 8;
-    return r;
-}
+    extern __shared__ __attribute__((aligned(16))) _Float16 fsm[];
 
-// One workgroup = 4 waves; every wave owns all 64 rows and the column blocks {wave, wave + 4} of each GEMM
-// phase, so each weight fragment is fetched exactly once per workgroup.  NB1 / NB2 / NB4 = number of column
-// blocks (0..2) of THIS wave in the phases producing H2 / H3 / H1 columns (compile-time so the fragment
-// rings live in registers); the body is instantiated for the combinations that occur and dispatched per wave.
-struct FusedCtx {
-    const FusedArgs *g;
-    const FusedSpecies *fs;
-    _Float16 *X1, *XU;
-    unsigned *s_max;
-    int m, n_rows, p0, s;
-};
+    // ---- tile -> (species, rows, member).  Member-major order: at any time the chip works on one or two
+    // members, whose weights stay resident in every XCD's L2 ----
+    const int tiles_total = gridDim.x / g.M;
+    const int m = blockIdx.x / tiles_total;
+    int tile = blockIdx.x % tiles_total;
+    const int *ctl = g.ctl;
+    int s = 0, cnt = 0;
+    for (; s < g.S; ++s) {
+        cnt = ctl[CTL_CNT + s];
+        const int nt = (cnt + FR_ROWS - 1) / FR_ROWS;
+        if (tile < nt) break;
+        tile -= nt;
+    }
+    if (s >= g.S) return;
+    const FusedSpecies &fs = g.sp[s];
+    const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
+    const int m0 = tile * FR_ROWS;
+    const int n_rows = min(FR_ROWS, cnt - m0);
+    const int p0 = ctl[CTL_OFF + s] + m0;
 
-template <int NB1, int NB2, int NB4>
-__device__ __forceinline__ void fused_body(const FusedCtx &c)
-{
-    const FusedArgs &g = *c.g;
-    const FusedSpecies &fs = *c.fs;
-    const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3, m = c.m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fk = lane >> 5;
+    // LDS carve (halves): X1 planes [2][64][H2+8] | XU = max(X0 planes [2][64][H1+8], X2 planes, A2 fp32)
+    // | table.  The layer-0 staging area overlays X1 | XU (both are dead until the layer-0 epilogue).
     const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
-    const int x0_plane = FB_ROWS * ld0, x1_plane = FB_ROWS * ld1, x2_plane = FB_ROWS * ld2;
-    _Float16 *X0 = c.XU, *X1 = c.X1, *X2 = c.XU;
-    unsigned &s_max = *c.s_max;
+    const int x0_plane = FR_ROWS * ld0, x1_plane = FR_ROWS * ld1, x2_plane = FR_ROWS * ld2;
+    _Float16 *X1 = fsm;
+    _Float16 *XU = fsm + 2 * FR_ROWS * ld1;
+    _Float16 *X0 = XU, *X2 = XU;
+    const int body = max(2 * FR_ROWS * ld1 + max(2 * FR_ROWS * ld0, 2 * FR_ROWS * ld2), FR_STAGE_HALVES);
+    unsigned *s_tab = reinterpret_cast<unsigned *>(fsm + body);   // [0] tile max, [1] tile slab mask
+    unsigned &s_max = s_tab[0];
 
-    f32x16 acc[4];
+    // this wave's column block in the phases producing H1 / H2 / H3 columns
+    const bool has1 = wave < (H1 >> 5), has2 = wave < (H2 >> 5), has3 = wave < (H3 >> 5);
+    const int colw = wave * 32 + fr;   // this lane's column in every phase
+
+    f32x16 acc[2];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
     };
     auto tile_max = [&](float vmax) {  // workgroup max of a non-negative value (two barriers)
         if (tid == 0) s_max = 0u;
@@ -1012,124 +1022,196 @@ __device__ __forceinline__ void fused_body(const FusedCtx &c)
         __syncthreads();
         return __uint_as_float(s_max);
     };
-    // element (rb, nb, r) of this wave's accumulators <-> (row, col) of the tile
+    // element (rb, r) of this wave's accumulators <-> row of the tile
     auto row_of = [&](int rb, int r) { return rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk; };
-    auto col_of = [&](int nb) { return (wave + 4 * nb) * 32 + fr; };
+    // split x (already scaled) into planes at offset o
+    auto put = [&](_Float16 *X, int plane, int o, float x) {
+        const _Float16 h = (_Float16)x;
+        X[o] = h;
+        X[plane + o] = (_Float16)(x - (float)h);
+    };
 
-    // weights of phase 1 start streaming before the activations are converted
-    BRing<NB1> r1 = fb_ring<NB1>(fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1);
-    if (NB1) r1.prime();
-
-    // =============== phase 0: act0 tile -> split planes X0 ===============
-    const float sa = amax_scale(g.amax, 0, c.s);
+    // =============== layer 0: act0 = celu(aev x W0^T + b0) over the flagged slabs ===============
+    const int KS0 = g.n_slabs * 2;
+    uint32_t tmask;
     {
-        const int row = tid / FB_TPR, q = tid % FB_TPR;  // FB_TPR threads per row, interleaved 8-column chunks
-        const int rr = row < c.n_rows ? row : 0;
-        const gf4 *src = (const gf4 *)(g.act0 + (int64_t)(c.p0 + rr) * g.ld0 + (int64_t)m * H1);
-        // all global loads first (clamped, branch-free), then convert + store
-        const int nch = H1 >> 3;                 // 8-column chunks per row (<= 32)
-        constexpr int NIT = FB_MAXH / 8 / FB_TPR;
-        v4f va[NIT][2];
+        // slab mask of the tile = OR over its atoms (wave 0 holds one row per lane)
+        if (wave == 0) {
+            uint32_t mk = g.n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << g.n_slabs) - 1u);
+            if (g.slab_mask) {
+                mk = g.slab_mask[g.perm[p0 + min(lane, n_rows - 1)]];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int cchunk = min(q + FB_TPR * it, nch - 1);
-            va[it][0] = src[2 * cchunk];
-            va[it][1] = src[2 * cchunk + 1];
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int cchunk = q + FB_TPR * it;
-            if (cchunk < nch) {
-                h8 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float x = (e < 4 ? va[it][0][e & 3] : va[it][1][e & 3]) * sa;
-                    const _Float16 h = (_Float16)x;
-                    hi[e] = h;
-                    lo[e] = (_Float16)(x - (float)h);
-                }
-                *reinterpret_cast<h8 *>(X0 + row * ld0 + cchunk * 8) = hi;
-                *reinterpret_cast<h8 *>(X0 + x0_plane + row * ld0 + cchunk * 8) = lo;
+                for (int o = 32; o > 0; o >>= 1) mk |= (uint32_t)__shfl_xor((int)mk, o);
             }
+            if (lane == 0) s_tab[1] = mk;
+        }
+        __syncthreads();
+        tmask = s_tab[1];
+    }
+    const int nact = __popc(tmask);
+    const int ngrp = (nact + FR_GROUP - 1) / FR_GROUP;
+    // staging role of this thread: row srow, 16-B piece sp (4 of the slab's 32 columns)
+    const int srow = tid >> 3, spc = tid & 7;
+    const float *arow = g.aev + (int64_t)g.perm[p0 + min(srow, n_rows - 1)] * g.L + spc * 4;
+    uint32_t rem_a = tmask;   // slabs not yet fetched
+    v4f va[FR_GROUP];
+    auto fetch_group = [&]() {   // next FR_GROUP flagged slabs -> registers (zeros past the end)
+#pragma unroll
+        for (int j = 0; j < FR_GROUP; ++j) {
+            const bool live = rem_a != 0u;
+            const int slab = live ? (int)__builtin_ctz(rem_a) : 0;
+            rem_a &= rem_a - 1u;
+            const int c0 = g.kp_rad ? kp_col(g.kp_rad, slab) : 32 * slab;
+            const int nv = g.kp_rad ? kp_valid(g.kp_rad, slab) : min(32, (int)g.L - 32 * slab);
+            const bool ok = live && spc * 4 < nv;
+            va[j] = *(const gf4 *)(arow + (ok ? c0 : 0));
+            if (!ok) va[j] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_group = [&](_Float16 *buf) {   // registers -> split planes of FR_GROUP staged slabs
+#pragma unroll
+        for (int j = 0; j < FR_GROUP; ++j) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = va[j][e] * 4.0f;   // static scale of the layer-0 input (include/anihip.h)
+                const _Float16 h = (_Float16)x;
+                hi[e] = h;
+                lo[e] = (_Float16)(x - (float)h);
+            }
+            _Float16 *d = buf + j * FR_SLAB + srow * FR_SLAB_LD + spc * 4;
+            *reinterpret_cast<h4 *>(d) = hi;
+            *reinterpret_cast<h4 *>(d + FR_ROWS * FR_SLAB_LD) = lo;
+        }
+    };
+    WRing rg;
+    uint32_t rem_w = tmask;   // k steps of the weight ring not yet requested
+    int w_odd = 0;
+    auto next_ks = [&]() {    // k step (in the slab order of W0) of the next ring request, clamped
+        const int slab = rem_w ? (int)__builtin_ctz(rem_w) : (31 - (int)__builtin_clz(tmask | 1u));
+        const int ks = 2 * slab + (rem_w ? w_odd : 1);
+        if (w_odd) rem_w &= rem_w - 1u;
+        w_odd ^= 1;
+        return ks;
+    };
+    zero_acc();
+    if (nact > 0) {
+        fetch_group();
+        if (has1) {
+            rg.base = fs.w0 + (int64_t)m * (H1 >> 5) * KS0 * (2 * FRAG) + (int64_t)wave * KS0 * (2 * FRAG) + lane * 8;
+            rg.load<0>(next_ks()); rg.load<1>(next_ks()); rg.load<2>(next_ks());
+            rg.load<3>(next_ks()); rg.load<4>(next_ks()); rg.load<5>(next_ks());
+        }
+        store_group(fsm);
+        __syncthreads();
+        for (int grp = 0; grp < ngrp; ++grp) {
+            const _Float16 *buf = fsm + (grp & 1) * (FR_GROUP * FR_SLAB);
+            fetch_group();   // (past the last group: zeros, no traffic beyond one clamped line)
+            if (has1) {
+                const _Float16 *a = buf + fr * FR_SLAB_LD + fk * 8;
+                constexpr int PL = FR_ROWS * FR_SLAB_LD, RB = 32 * FR_SLAB_LD;
+                fr_step<0>(acc, rg, a, PL, RB);                    rg.load<0>(next_ks());
+                fr_step<1>(acc, rg, a + 16, PL, RB);               rg.load<1>(next_ks());
+                fr_step<2>(acc, rg, a + FR_SLAB, PL, RB);          rg.load<2>(next_ks());
+                fr_step<3>(acc, rg, a + FR_SLAB + 16, PL, RB);     rg.load<3>(next_ks());
+                fr_step<4>(acc, rg, a + 2 * FR_SLAB, PL, RB);      rg.load<4>(next_ks());
+                fr_step<5>(acc, rg, a + 2 * FR_SLAB + 16, PL, RB); rg.load<5>(next_ks());
+            }
+            store_group(fsm + ((grp + 1) & 1) * (FR_GROUP * FR_SLAB));
+            __syncthreads();
+        }
+    }
+    // weights of phase 1 start streaming during the layer-0 epilogue
+    WRing r1;
+    if (has2) fr_ring(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave);
+    float d0f[2][16];   // celu'(act0) of this wave's block
+    float s0;
+    {
+        const float oscale = fs.is0 * 0.25f;
+        const float bias = has1 ? fs.b0[(int64_t)m * H1 + colw] : 0.f;
+        float vmax = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = celu(acc[rb][r] * oscale + bias, g.alpha, g.inv_alpha);
+                acc[rb][r] = v;
+                d0f[rb][r] = v > 0.f ? 1.0f : v * g.inv_alpha + 1.0f;
+                vmax = fmaxf(vmax, fabsf(v));
+            }
+        s0 = pow2_scale_for(tile_max(has1 ? vmax : 0.f));
+        if (has1) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) put(X0, x0_plane, row_of(rb, r) * ld0 + colw, acc[rb][r] * s0);
         }
     }
     __syncthreads();
 
     // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
     zero_acc();
-    if (NB1) fb_gemm<NB1>(acc, X0, ld0, x0_plane, r1);
-    BRing<NB2> r2 = fb_ring<NB2>(fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2);
+    if (has2) fr_gemm(acc, X0, ld0, x0_plane, r1, H1 >> 4);
+    WRing r2;
+    if (has3) fr_ring(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
+    float d1f[2][16];   // celu'(act1) of this wave's block
     float s1;
     {
-        const float oscale = fs.is1 / sa;
-        float bias[2] = {0.f, 0.f};
-#pragma unroll
-        for (int nb = 0; nb < NB1; ++nb) bias[nb] = fs.b1[(int64_t)m * H2 + col_of(nb)];
-        if (NB2) r2.prime();
+        const float oscale = fs.is1 / s0;
+        const float bias = has2 ? fs.b1[(int64_t)m * H2 + colw] : 0.f;
         float vmax = 0.f;
 #pragma unroll
-        for (int rb = 0; rb < FB_RB; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int nb = 0; nb < NB1; ++nb)
+            for (int r = 0; r < 16; ++r) {
+                const float v = celu(acc[rb][r] * oscale + bias, g.alpha, g.inv_alpha);
+                acc[rb][r] = v;
+                d1f[rb][r] = v > 0.f ? 1.0f : v * g.inv_alpha + 1.0f;
+                vmax = fmaxf(vmax, fabsf(v));
+            }
+        s1 = pow2_scale_for(tile_max(has2 ? vmax : 0.f));
+        if (has2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = celu(acc[rb * 2 + nb][r] * oscale + bias[nb], g.alpha, g.inv_alpha);
-                    acc[rb * 2 + nb][r] = v;
-                    vmax = fmaxf(vmax, fabsf(v));
-                }
-        s1 = pow2_scale_for(tile_max(vmax));
+            for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int rb = 0; rb < FB_RB; ++rb)
-#pragma unroll
-            for (int nb = 0; nb < NB1; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float x = acc[rb * 2 + nb][r] * s1;
-                    const _Float16 h = (_Float16)x;
-                    const int o = row_of(rb, r) * ld1 + col_of(nb);
-                    X1[o] = h;
-                    X1[x1_plane + o] = (_Float16)(x - (float)h);
-                }
+                for (int r = 0; r < 16; ++r) put(X1, x1_plane, row_of(rb, r) * ld1 + colw, acc[rb][r] * s1);
+        }
     }
     __syncthreads();  // X1 complete; every wave is done reading X0 (tile_max barriers) -> XU reusable
 
     // =============== phase 2: act2 = celu(act1 x W2^T + b2)  (fp32 into XU) ===============
     zero_acc();
-    if (NB2) fb_gemm<NB2>(acc, X1, ld1, x1_plane, r2);
-    float *A2 = reinterpret_cast<float *>(c.XU);  // [rows][H3 + 8] fp32 (padded: conflict-free reads)
+    if (has3) fr_gemm(acc, X1, ld1, x1_plane, r2, H2 >> 4);
+    float *A2 = reinterpret_cast<float *>(XU);  // [rows][H3 + 8] fp32 (padded: conflict-free reads)
     const int lda2 = H3 + 8;
-    {
+    if (has3) {
         const float osc2 = fs.is2 / s1;
-        float bias[2] = {0.f, 0.f};
+        const float bias = fs.b2[(int64_t)m * H3 + colw];
 #pragma unroll
-        for (int nb = 0; nb < NB2; ++nb) bias[nb] = fs.b2[(int64_t)m * H3 + col_of(nb)];
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int rb = 0; rb < FB_RB; ++rb)
-#pragma unroll
-            for (int nb = 0; nb < NB2; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    A2[row_of(rb, r) * lda2 + col_of(nb)] =
-                        celu(acc[rb * 2 + nb][r] * osc2 + bias[nb], g.alpha, g.inv_alpha);
+            for (int r = 0; r < 16; ++r)
+                A2[row_of(rb, r) * lda2 + colw] = celu(acc[rb][r] * osc2 + bias, g.alpha, g.inv_alpha);
     }
     __syncthreads();
 
     // =============== output layer + backward seed ===============
-    // thread = (row = tid / FB_TPR, part = tid % FB_TPR): dot over a slice of the columns, reduce over the parts
-    const int hrow = tid / FB_TPR, part = tid % FB_TPR;
-    const int per = H3 / FB_TPR;
-    float gv[FB_MAXH / FB_TPR];
+    // thread = (row = tid / FR_TPR, part = tid % FR_TPR): dot over a slice of the columns, reduce over the parts
+    const int hrow = tid / FR_TPR, part = tid % FR_TPR;
+    const int per = H3 / FR_TPR;
+    float gv[FR_MAXH / FR_TPR];
     float gmax = 0.f;
     {
         const float *w3 = fs.w3 + (int64_t)m * H3;
         const float invM = 1.0f / (float)g.M;
         float e = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < FB_MAXH / FB_TPR; ++cc) {
-            // column = cc * FB_TPR + part: the threads of a row read consecutive floats.  Loads are
+        for (int cc = 0; cc < FR_MAXH / FR_TPR; ++cc) {
+            // column = cc * FR_TPR + part: the threads of a row read consecutive floats.  Loads are
             // unconditional (clamped) so the compiler keeps them all in flight; the tail is masked.
             const bool ok = cc < per;
-            const int col = (ok ? cc : per - 1) * FB_TPR + part;
+            const int col = (ok ? cc : per - 1) * FR_TPR + part;
             const float y = A2[hrow * lda2 + col];
             float w = w3[col];
             w = ok ? w : 0.f;
@@ -1138,143 +1220,64 @@ __device__ __forceinline__ void fused_body(const FusedCtx &c)
             gmax = fmaxf(gmax, fabsf(gv[cc]));
         }
 #pragma unroll
-        for (int o = 1; o < FB_TPR; o <<= 1) e += __shfl_xor(e, o);
-        if (part == 0 && hrow < c.n_rows) g.member_part[(int64_t)(c.p0 + hrow) * g.M + m] = e + fs.b3[m];
+        for (int o = 1; o < FR_TPR; o <<= 1) e += __shfl_xor(e, o);
+        if (part == 0 && hrow < n_rows) g.member_part[(int64_t)(p0 + hrow) * g.M + m] = e + fs.b3[m];
     }
     if (!g.want_grad) return;
-    BRing<NB1> r3 = fb_ring<NB1>(fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3);
-    if (NB1) r3.prime();
+    WRing r3;
+    if (has2) fr_ring(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave);
     const float s2 = pow2_scale_for(tile_max(gmax));  // barriers inside: all fp32 reads of A2 are done
 #pragma unroll
-    for (int cc = 0; cc < FB_MAXH / FB_TPR; ++cc) {
-        if (cc < per) {
-            const int col = cc * FB_TPR + part;
-            const float x = gv[cc] * s2;
-            const _Float16 h = (_Float16)x;
-            X2[hrow * ld2 + col] = h;
-            X2[x2_plane + hrow * ld2 + col] = (_Float16)(x - (float)h);
-        }
+    for (int cc = 0; cc < FR_MAXH / FR_TPR; ++cc) {
+        if (cc < per) put(X2, x2_plane, hrow * ld2 + cc * FR_TPR + part, gv[cc] * s2);
     }
     __syncthreads();
 
     // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
     zero_acc();
-    if (NB1) fb_gemm<NB1>(acc, X2, ld2, x2_plane, r3);
-    BRing<NB4> r4 = fb_ring<NB4>(fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2);
-    if (NB4) r4.prime();
+    if (has2) fr_gemm(acc, X2, ld2, x2_plane, r3, H3 >> 4);
+    WRing r4;
+    if (has1) fr_ring(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
     float s3;
     {
-        const float osc3 = fs.is2 / s2, inv_s1 = 1.0f / s1;
+        const float osc3 = fs.is2 / s2;
         float vmax3 = 0.f;
 #pragma unroll
-        for (int rb = 0; rb < FB_RB; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int nb = 0; nb < NB1; ++nb)
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[rb][r] * osc3 * d1f[rb][r];
+                acc[rb][r] = v;
+                vmax3 = fmaxf(vmax3, fabsf(v));
+            }
+        s3 = pow2_scale_for(tile_max(has2 ? vmax3 : 0.f));  // barrier: every read of X1 (phase 2) is long done
+        if (has2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = row_of(rb, r) * ld1 + col_of(nb);
-                    const float y = ((float)X1[o] + (float)X1[x1_plane + o]) * inv_s1;
-                    const float v = acc[rb * 2 + nb][r] * osc3 * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
-                    acc[rb * 2 + nb][r] = v;
-                    vmax3 = fmaxf(vmax3, fabsf(v));
-                }
-        s3 = pow2_scale_for(tile_max(vmax3));  // barrier: every act1 read above is done
+            for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int rb = 0; rb < FB_RB; ++rb)
-#pragma unroll
-            for (int nb = 0; nb < NB1; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float x = acc[rb * 2 + nb][r] * s3;
-                    const _Float16 h = (_Float16)x;
-                    const int o = row_of(rb, r) * ld1 + col_of(nb);
-                    X1[o] = h;
-                    X1[x1_plane + o] = (_Float16)(x - (float)h);
-                }
+                for (int r = 0; r < 16; ++r) put(X1, x1_plane, row_of(rb, r) * ld1 + colw, acc[rb][r] * s3);
+        }
     }
     __syncthreads();
 
-    // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global, in place ===============
+    // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
     zero_acc();
-    if (NB4) fb_gemm<NB4>(acc, X1, ld1, x1_plane, r4);
-    {
+    if (has1) {
+        fr_gemm(acc, X1, ld1, x1_plane, r4, H2 >> 4);
         const float osc4 = fs.is1 / s3;
         float vmax4 = 0.f;
-        // all act0 reads first (independent loads in flight together), then the stores: interleaving
-        // load/store per element serialises the global round trips (possible aliasing)
-        float yv[FB_RB][NB4 ? NB4 : 1][16];
 #pragma unroll
-        for (int rb = 0; rb < FB_RB; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int nb = 0; nb < NB4; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_of(rb, r);
-                    const int rr = row < c.n_rows ? row : 0;
-                    yv[rb][nb][r] = g.act0[(int64_t)(c.p0 + rr) * g.ld0 + (int64_t)m * H1 + col_of(nb)];
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_of(rb, r);
+                const float v = acc[rb][r] * osc4 * d0f[rb][r];
+                if (row < n_rows) {
+                    g.d0[(int64_t)(p0 + row) * g.ld0 + (int64_t)m * H1 + colw] = v;
+                    vmax4 = fmaxf(vmax4, fabsf(v));
                 }
-#pragma unroll
-        for (int rb = 0; rb < FB_RB; ++rb)
-#pragma unroll
-            for (int nb = 0; nb < NB4; ++nb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_of(rb, r);
-                    const float y = yv[rb][nb][r];
-                    const float v = acc[rb * 2 + nb][r] * osc4 * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
-                    if (row < c.n_rows) {
-                        g.act0[(int64_t)(c.p0 + row) * g.ld0 + (int64_t)m * H1 + col_of(nb)] = v;
-                        vmax4 = fmaxf(vmax4, fabsf(v));
-                    }
-                }
-        amax_update(g.amax, 5, c.s, vmax4);
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void k_hidden_fused(FusedArgs g)
-{
-    extern __shared__ __attribute__((aligned(16))) _Float16 fsm[];
-
-    // ---- tile -> (species, rows, member).  Member-major order: at any time the chip works on one or two
-    // members, whose weights (1.3 MB of planes per member) stay resident in every XCD's L2 ----
-    const int tiles_total = gridDim.x / g.M;
-    const int m = blockIdx.x / tiles_total;
-    int tile = blockIdx.x % tiles_total;
-    const int *ctl = g.ctl;
-    int s = 0, cnt = 0;
-    for (; s < g.S; ++s) {
-        cnt = ctl[CTL_CNT + s];
-        const int nt = (cnt + FB_ROWS - 1) / FB_ROWS;
-        if (tile < nt) break;
-        tile -= nt;
-    }
-    if (s >= g.S) return;
-    const FusedSpecies &fs = g.sp[s];
-    const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
-    const int m0 = tile * FB_ROWS;
-
-    // LDS carve (halves): X1 planes [2][64][H2+8] | XU = max(X0 planes [2][64][H1+8], X2 planes) | s_max
-    FusedCtx c;
-    c.g = &g; c.fs = &fs; c.m = m; c.s = s;
-    c.n_rows = min(FB_ROWS, cnt - m0);
-    c.p0 = ctl[CTL_OFF + s] + m0;
-    c.X1 = fsm;
-    c.XU = fsm + 2 * FB_ROWS * (H2 + 8);
-    const int xu = max(2 * FB_ROWS * (H1 + 8), 2 * FB_ROWS * (H3 + 8));
-    c.s_max = reinterpret_cast<unsigned *>(c.XU + xu);
-
-    // column blocks of this wave: {wave, wave + 4} clipped to the block count of each phase
-    const int wave = threadIdx.x >> 6;
-    auto nbw = [&](int N) { const int nblk = N >> 5; return (nblk > wave ? 1 : 0) + (nblk > wave + 4 ? 1 : 0); };
-    // wave-uniform dispatch on the block counts.  Every barrier is executed by all four waves regardless
-    // of the instantiation they run.  The host only selects this kernel for widths covered here
-    // (fused_dims_supported).
-    switch (nbw(H2) * 100 + nbw(H3) * 10 + nbw(H1)) {
-#define FB_CASE(a, b, d) case a * 100 + b * 10 + d: fused_body<a, b, d>(c); break;
-        FB_CASE(2, 2, 2) FB_CASE(2, 1, 2) FB_CASE(1, 1, 2)   // 256/192/160, 224/192/160, 192/160/128
-        FB_CASE(1, 1, 1) FB_CASE(1, 0, 1)                    // 160/128/96, 128/128/96 and tails
-#undef FB_CASE
-        default: break;
+            }
+        amax_update(g.amax, 5, s, vmax4);
     }
 }
 
@@ -1467,19 +1470,10 @@ static int check_desc(const anihip_mlp_desc *d)
     return 0;
 }
 
-// widths the fused hidden-stack kernel has instantiations for (see the dispatch in k_hidden_fused)
+// widths the fused network kernel covers: 8 waves x one 32-column block
 static bool fused_dims_supported(int H1, int H2, int H3)
 {
-    if (H1 > FB_MAXH || H2 > FB_MAXH || H3 > FB_MAXH) return false;
-    for (int wave = 0; wave < 4; ++wave) {
-        auto nb = [&](int H) { const int n = H >> 5; return (n > wave ? 1 : 0) + (n > wave + 4 ? 1 : 0); };
-        const int key = nb(H2) * 100 + nb(H3) * 10 + nb(H1);
-        const int ok[] = {222, 212, 112, 111, 101};
-        bool f = false;
-        for (int k : ok) f = f || k == key;
-        if (!f) return false;
-    }
-    return true;
+    return H1 <= FR_MAXH && H2 <= FR_MAXH && H3 <= FR_MAXH;
 }
 
 template <int EPI>
@@ -1555,12 +1549,12 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         return (mx + BN - 1) / BN;
     };
 
-    // fused hidden stack (f16x3, three hidden layers of width <= 256): layer-0 GEMM, one fused kernel for
-    // everything behind it, layer-0 backward GEMM
-    bool fused = h3 && nh == 3;
+    // fused network kernel (f16x3, three hidden layers of width <= 256, at most 32 AEV slabs): one kernel
+    // from the AEV rows to d E / d act0, then the layer-0 backward GEMM
+    bool fused = h3 && nh == 3 && K0p <= 32 * 32 && L % 4 == 0;
     for (int s = 0; s < S && fused; ++s) {
         const anihip_species_net &nn = d->net[s];
-        fused = fused && nn.whf[1] && nn.whf[2] && nn.wthf[1] && nn.wthf[2] &&
+        fused = fused && nn.whf[0] && nn.whf[1] && nn.whf[2] && nn.wthf[1] && nn.wthf[2] &&
                 fused_dims_supported(nn.dims[1], nn.dims[2], nn.dims[3]);
     }
     if (const char *e = getenv("ANIHIP_NO_FUSED_HIDDEN")) fused = fused && e[0] == '0';
@@ -1572,7 +1566,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     if (const char *e = getenv("ANIHIP_NO_SLAB_MASK")) smask = e[0] == '0' ? smask : nullptr;
 
     // 2. forward through the hidden layers
-    for (int l = 0; l < (fused ? 1 : nh); ++l) {
+    for (int l = 0; l < (fused ? 0 : nh); ++l) {
         GemmArgs g{};
         g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha;
         g.nrow_tiles_ub = nrow_ub;
@@ -1624,21 +1618,26 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             const anihip_species_net &nn = d->net[s];
             FusedSpecies &fs = f.sp[s];
             fs.H1 = nn.dims[1]; fs.H2 = nn.dims[2]; fs.H3 = nn.dims[3];
+            fs.w0 = (const _Float16 *)nn.whf[0];
             fs.w1 = (const _Float16 *)nn.whf[1]; fs.w2 = (const _Float16 *)nn.whf[2];
             fs.w2t = (const _Float16 *)nn.wthf[2]; fs.w1t = (const _Float16 *)nn.wthf[1];
-            fs.is1 = 1.0f / nn.wh_scale[1]; fs.is2 = 1.0f / nn.wh_scale[2];
-            fs.b1 = nn.bias[1]; fs.b2 = nn.bias[2]; fs.w3 = nn.w[3]; fs.b3 = nn.bias[3];
+            fs.is0 = 1.0f / nn.wh_scale[0]; fs.is1 = 1.0f / nn.wh_scale[1]; fs.is2 = 1.0f / nn.wh_scale[2];
+            fs.b0 = nn.bias[0]; fs.b1 = nn.bias[1]; fs.b2 = nn.bias[2]; fs.w3 = nn.w[3]; fs.b3 = nn.bias[3];
             const size_t xu = fs.H1 > fs.H3 ? fs.H1 : fs.H3;
-            const size_t halves = 2 * (size_t)FB_ROWS * (fs.H2 + 8) + 2 * (size_t)FB_ROWS * (xu + 8);
+            size_t halves = 2 * (size_t)FR_ROWS * (fs.H2 + 8) + 2 * (size_t)FR_ROWS * (xu + 8);
+            if (halves < (size_t)FR_STAGE_HALVES) halves = FR_STAGE_HALVES;
             lds = lds > halves * 2 + 16 ? lds : halves * 2 + 16;
         }
-        f.ctl = w.ctl; f.amax = w.amax; f.act0 = w.act[0]; f.ld0 = w.ld[0]; f.perm = w.perm;
+        f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = K0p / 32;
+        f.slab_mask = kp_rad > 0 ? slab_mask : nullptr;
+        if (const char *e = getenv("ANIHIP_NO_SLAB_MASK")) f.slab_mask = e[0] == '0' ? f.slab_mask : nullptr;
+        f.d0 = w.act[0]; f.ld0 = w.ld[0]; f.perm = w.perm;
         f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
         f.want_grad = grad_aev ? 1 : 0;
-        ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_hidden_fused,
+        ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_mlp_fused,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int64_t tiles = (n + FB_ROWS - 1) / FB_ROWS + S;
-        hipLaunchKernelGGL(k_hidden_fused, dim3((unsigned)(tiles * M)), dim3(256), lds, stream, f);
+        const int64_t tiles = (n + FR_ROWS - 1) / FR_ROWS + S;
+        hipLaunchKernelGGL(k_mlp_fused, dim3((unsigned)(tiles * M)), dim3(FR_THREADS), lds, stream, f);
         int64_t fb = (n + 255) / 256;
         if (fb > 2048) fb = 2048;
         hipLaunchKernelGGL(k_fused_finish, dim3((unsigned)fb), dim3(256), 0, stream, w.ctl, S, M, w.perm,

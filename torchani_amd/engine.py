@@ -284,16 +284,17 @@ class PackedNetworks:
                     net.wh[l] = planes[0].data_ptr()
                     net.wth[l] = planes[1].data_ptr()
                     net.wh_scale[l] = scale
+                    # MFMA fragment order for the fused network kernel (include/anihip.h):
+                    # planes [2][M][N][K] -> [M][N/32][K/16][2][h*32 + r][8]
+                    # (layer 0: forward planes only, viewed per member: [2][M*H1p][K0h] -> [2][M][H1p][K0h])
+                    frags = []
+                    for pl in (planes if l >= 1 else [planes[0].view(2, M, kout, k0h)]):
+                        N_, K_ = pl.shape[2], pl.shape[3]
+                        f = pl.view(2, M, N_ // 32, 32, K_ // 16, 2, 8).permute(1, 2, 4, 0, 5, 3, 6)
+                        frags.append(f.contiguous())
+                    self._keep += frags
+                    net.whf[l] = frags[0].data_ptr()
                     if l >= 1:
-                        # MFMA fragment order for the fused hidden-stack kernel (include/anihip.h):
-                        # planes [2][M][N][K] -> [M][N/32][K/16][2][h*32 + r][8]
-                        frags = []
-                        for pl in planes:
-                            N_, K_ = pl.shape[2], pl.shape[3]
-                            f = pl.view(2, M, N_ // 32, 32, K_ // 16, 2, 8).permute(1, 2, 4, 0, 5, 3, 6)
-                            frags.append(f.contiguous())
-                        self._keep += frags
-                        net.whf[l] = frags[0].data_ptr()
                         net.wthf[l] = frags[1].data_ptr()
         self.desc = d
         self._ws: tp.Optional[Tensor] = None
