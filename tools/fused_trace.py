@@ -1,0 +1,20 @@
+"""Phase timeline of k_mlp_fused from the ANIHIP_FUSED_TRACE stamps (development aid).
+
+    ANIHIP_FUSED_TRACE=/tmp/ft.bin python tools/kbench.py --side 40 --stages mlp --mask on --reps 1
+    python tools/fused_trace.py /tmp/ft.bin
+"""
+import sys
+
+import numpy as np
+
+STAMPS = [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13]
+NAMES = ["start->mask", "mask->L0 first group staged", "L0 k-loop", "L0 epilogue", "P1 gemm", "P1 epilogue",
+         "P2 gemm", "P2 epilogue+head+seed", "P3 gemm", "P3 epilogue", "P4 gemm", "P4 store"]
+
+t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16).astype(np.int64)
+t = t[(t[:, 0] > 0) & (t[:, 13] > 0)]
+d = np.diff(t[:, STAMPS], axis=1)
+tot = t[:, 13] - t[:, 0]
+print(f"{len(t)} workgroups, total {tot.mean():.0f} ticks (median {np.median(tot):.0f})  [shader clock ticks, wave 0]")
+for i, n in enumerate(NAMES):
+    print(f"  {n:30s} mean {d[:, i].mean():9.1f}  median {np.median(d[:, i]):9.1f}  ({d[:, i].mean() / tot.mean():6.1%})")

@@ -433,9 +433,9 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
         if (lane < n_) e0 = ent[(hh).start + lane];                                                      \
         if (lane + WAVE < n_) e1 = ent[(hh).start + lane + WAVE];                                        \
         const float4 *g4_ = reinterpret_cast<const float4 *>(grad_aev + (size_t)((ia) < hi ? (ia) : lo) * a.L); \
-        gr0 = g4_[lane];                                                                                 \
-        gr1 = g4_[lane + WAVE];                                                                          \
-        gr2 = g4_[lane + 2 * WAVE];                                                                      \
+        gr0 = g4_[min(lane, L4 - 1)];              /* clamped: rows shorter than 256 float4 (ANI-1x) */  \
+        gr1 = g4_[min(lane + WAVE, L4 - 1)];                                                             \
+        gr2 = g4_[min(lane + 2 * WAVE, L4 - 1)];                                                         \
         gr3 = g4_[min(lane + 3 * WAVE, L4 - 1)];                                                         \
     }
     ANIHIP_BWD_ISSUE(i, h)

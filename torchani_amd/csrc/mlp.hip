@@ -19,6 +19,8 @@
 #include <stdlib.h>
 
 #include "anihip_common.h"
+#include <vector>
+#include <cstdio>
 
 namespace anihip {
 
@@ -882,6 +884,7 @@ struct FusedArgs {
     int S, M;
     float alpha, inv_alpha;
     int want_grad;
+    unsigned long long *trace;   // development aid (env ANIHIP_FUSED_TRACE): [workgroup][16] s_memtime stamps
 };
 
 __device__ __forceinline__ float pow2_scale_for(float mx)
@@ -906,7 +909,10 @@ struct WRing {
     }
 };
 
-// one k step: acc[rb] += A[rb rows, 16 k] x B[16 k, 32 cols] for both 32-row blocks, three products.
+// one k step for both 32-row blocks, three products.  The WEIGHT fragment is the MFMA's first operand and
+// the activation fragment its second, i.e. the wave accumulates the TRANSPOSED tile: lane (fr, fk) ends up
+// with tile row rb*32 + fr and the 16 output columns 8 q + 4 fk + e (q = r >> 2, e = r & 3) of the wave's
+// block -- four runs of four consecutive columns, so the epilogues write 8-byte / 16-byte vectors.
 // a = hi-plane fragment address of this lane for row block 0; + a_plane = lo plane; + rb_stride = row block 1
 template <int SLOT>
 __device__ __forceinline__ void fr_step(f32x16 (&acc)[2], const WRing &rg, const _Float16 *a, int a_plane,
@@ -915,12 +921,12 @@ __device__ __forceinline__ void fr_step(f32x16 (&acc)[2], const WRing &rg, const
     const h8 ah0 = *reinterpret_cast<const h8 *>(a), al0 = *reinterpret_cast<const h8 *>(a + a_plane);
     const h8 ah1 = *reinterpret_cast<const h8 *>(a + rb_stride);
     const h8 al1 = *reinterpret_cast<const h8 *>(a + rb_stride + a_plane);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, rg.hi[SLOT], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, rg.hi[SLOT], acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, rg.lo[SLOT], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, rg.lo[SLOT], acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, rg.hi[SLOT], acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, rg.hi[SLOT], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[SLOT], al0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[SLOT], al1, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.lo[SLOT], ah0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.lo[SLOT], ah1, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[SLOT], ah0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[SLOT], ah1, acc[1], 0, 0, 0);
 }
 
 // ring of column block `cb` of a [N/32][KS] fragment matrix of member m, first FR_DEPTH steps in flight
@@ -1004,8 +1010,12 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
 
     // this wave's column block in the phases producing H1 / H2 / H3 columns
     const bool has1 = wave < (H1 >> 5), has2 = wave < (H2 >> 5), has3 = wave < (H3 >> 5);
-    const int colw = wave * 32 + fr;   // this lane's column in every phase
+    // accumulator element (rb, r) of this lane <-> tile row rb*32 + fr, column colq(r >> 2) + (r & 3)
+    const int col0 = wave * 32 + 4 * fk;   // first column of run q = 0; run q starts at col0 + 8 q
+    float *s_e = reinterpret_cast<float *>(s_tab + 4);   // [8 waves][64 rows] energy partials
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter();
 
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     f32x16 acc[2];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -1022,13 +1032,33 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
         __syncthreads();
         return __uint_as_float(s_max);
     };
-    // element (rb, r) of this wave's accumulators <-> row of the tile
-    auto row_of = [&](int rb, int r) { return rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk; };
-    // split x (already scaled) into planes at offset o
-    auto put = [&](_Float16 *X, int plane, int o, float x) {
-        const _Float16 h = (_Float16)x;
-        X[o] = h;
-        X[plane + o] = (_Float16)(x - (float)h);
+    // acc * scale -> split planes of X (row stride ldx), this lane's 2 x 4 runs of 4 columns
+    auto put_acc = [&](_Float16 *X, int plane, int ldx, float scale) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = acc[rb][4 * q + e] * scale;
+                    const _Float16 h = (_Float16)x;
+                    hi[e] = h;
+                    lo[e] = (_Float16)(x - (float)h);
+                }
+                _Float16 *d = X + (rb * 32 + fr) * ldx + col0 + 8 * q;
+                *reinterpret_cast<h4 *>(d) = hi;
+                *reinterpret_cast<h4 *>(d + plane) = lo;
+            }
+    };
+    // 16 per-column parameters of this lane (bias / output weights), as 4 float4 loads
+    auto load_cols = [&](const float *base, float (&v)[16], bool has) {   // (no block: block 0, unused)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4f t = *(const gf4 *)(base + (has ? col0 : 4 * fk) + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+        }
     };
 
     // =============== layer 0: act0 = celu(aev x W0^T + b0) over the flagged slabs ===============
@@ -1048,14 +1078,14 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
         __syncthreads();
         tmask = s_tab[1];
     }
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 1] = __builtin_readcyclecounter();
     const int nact = __popc(tmask);
     const int ngrp = (nact + FR_GROUP - 1) / FR_GROUP;
-    // staging role of this thread: row srow, 16-B piece sp (4 of the slab's 32 columns)
+    // staging role of this thread: row srow, 16-B piece spc (4 of the slab's 32 columns)
     const int srow = tid >> 3, spc = tid & 7;
     const float *arow = g.aev + (int64_t)g.perm[p0 + min(srow, n_rows - 1)] * g.L + spc * 4;
     uint32_t rem_a = tmask;   // slabs not yet fetched
-    v4f va[FR_GROUP];
-    auto fetch_group = [&]() {   // next FR_GROUP flagged slabs -> registers (zeros past the end)
+    auto fetch_group = [&](v4f (&v)[FR_GROUP]) {   // next FR_GROUP flagged slabs -> registers (zeros past the end)
 #pragma unroll
         for (int j = 0; j < FR_GROUP; ++j) {
             const bool live = rem_a != 0u;
@@ -1064,18 +1094,17 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
             const int c0 = g.kp_rad ? kp_col(g.kp_rad, slab) : 32 * slab;
             const int nv = g.kp_rad ? kp_valid(g.kp_rad, slab) : min(32, (int)g.L - 32 * slab);
             const bool ok = live && spc * 4 < nv;
-            va[j] = *(const gf4 *)(arow + (ok ? c0 : 0));
-            if (!ok) va[j] = v4f{0.f, 0.f, 0.f, 0.f};
+            v[j] = *(const gf4 *)(arow + (ok ? c0 : 0));
+            if (!ok) v[j] = v4f{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto store_group = [&](_Float16 *buf) {   // registers -> split planes of FR_GROUP staged slabs
+    auto store_group = [&](const v4f (&v)[FR_GROUP], _Float16 *buf) {   // registers -> split planes of the staged slabs
 #pragma unroll
         for (int j = 0; j < FR_GROUP; ++j) {
-            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             h4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float x = va[j][e] * 4.0f;   // static scale of the layer-0 input (include/anihip.h)
+                const float x = v[j][e] * 4.0f;   // static scale of the layer-0 input (include/anihip.h)
                 const _Float16 h = (_Float16)x;
                 hi[e] = h;
                 lo[e] = (_Float16)(x - (float)h);
@@ -1097,17 +1126,20 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
     };
     zero_acc();
     if (nact > 0) {
-        fetch_group();
+        // AEV slabs run two groups ahead of the MFMAs in registers, one group ahead in LDS
+        v4f va[FR_GROUP], vb[FR_GROUP];
+        fetch_group(va);
+        fetch_group(vb);
         if (has1) {
             rg.base = fs.w0 + (int64_t)m * (H1 >> 5) * KS0 * (2 * FRAG) + (int64_t)wave * KS0 * (2 * FRAG) + lane * 8;
             rg.load<0>(next_ks()); rg.load<1>(next_ks()); rg.load<2>(next_ks());
             rg.load<3>(next_ks()); rg.load<4>(next_ks()); rg.load<5>(next_ks());
         }
-        store_group(fsm);
+        store_group(va, fsm);
         __syncthreads();
+        if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 2] = __builtin_readcyclecounter();
         for (int grp = 0; grp < ngrp; ++grp) {
             const _Float16 *buf = fsm + (grp & 1) * (FR_GROUP * FR_SLAB);
-            fetch_group();   // (past the last group: zeros, no traffic beyond one clamped line)
             if (has1) {
                 const _Float16 *a = buf + fr * FR_SLAB_LD + fk * 8;
                 constexpr int PL = FR_ROWS * FR_SLAB_LD, RB = 32 * FR_SLAB_LD;
@@ -1118,124 +1150,113 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
                 fr_step<4>(acc, rg, a + 2 * FR_SLAB, PL, RB);      rg.load<4>(next_ks());
                 fr_step<5>(acc, rg, a + 2 * FR_SLAB + 16, PL, RB); rg.load<5>(next_ks());
             }
-            store_group(fsm + ((grp + 1) & 1) * (FR_GROUP * FR_SLAB));
+            store_group(vb, fsm + ((grp + 1) & 1) * (FR_GROUP * FR_SLAB));   // group grp + 1
+            fetch_group(vb);                                                 // group grp + 2
             __syncthreads();
         }
     }
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 3] = __builtin_readcyclecounter();
     // weights of phase 1 start streaming during the layer-0 epilogue
     WRing r1;
     if (has2) fr_ring(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave);
-    float d0f[2][16];   // celu'(act0) of this wave's block
+    float d0f[2][16];   // celu'(act0) of this lane's elements
     float s0;
     {
         const float oscale = fs.is0 * 0.25f;
-        const float bias = has1 ? fs.b0[(int64_t)m * H1 + colw] : 0.f;
+        float bias[16];
+        load_cols(fs.b0 + (int64_t)m * H1, bias, has1);
         float vmax = 0.f;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = celu(acc[rb][r] * oscale + bias, g.alpha, g.inv_alpha);
+                const float v = celu(acc[rb][r] * oscale + bias[r], g.alpha, g.inv_alpha);
                 acc[rb][r] = v;
                 d0f[rb][r] = v > 0.f ? 1.0f : v * g.inv_alpha + 1.0f;
                 vmax = fmaxf(vmax, fabsf(v));
             }
         s0 = pow2_scale_for(tile_max(has1 ? vmax : 0.f));
-        if (has1) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) put(X0, x0_plane, row_of(rb, r) * ld0 + colw, acc[rb][r] * s0);
-        }
+        if (has1) put_acc(X0, x0_plane, ld0, s0);
     }
     __syncthreads();
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 4] = __builtin_readcyclecounter();
 
     // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
     zero_acc();
     if (has2) fr_gemm(acc, X0, ld0, x0_plane, r1, H1 >> 4);
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 5] = __builtin_readcyclecounter();
     WRing r2;
     if (has3) fr_ring(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
-    float d1f[2][16];   // celu'(act1) of this wave's block
+    float d1f[2][16];   // celu'(act1) of this lane's elements
     float s1;
     {
         const float oscale = fs.is1 / s0;
-        const float bias = has2 ? fs.b1[(int64_t)m * H2 + colw] : 0.f;
+        float bias[16];
+        load_cols(fs.b1 + (int64_t)m * H2, bias, has2);
         float vmax = 0.f;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = celu(acc[rb][r] * oscale + bias, g.alpha, g.inv_alpha);
+                const float v = celu(acc[rb][r] * oscale + bias[r], g.alpha, g.inv_alpha);
                 acc[rb][r] = v;
                 d1f[rb][r] = v > 0.f ? 1.0f : v * g.inv_alpha + 1.0f;
                 vmax = fmaxf(vmax, fabsf(v));
             }
         s1 = pow2_scale_for(tile_max(has2 ? vmax : 0.f));
-        if (has2) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) put(X1, x1_plane, row_of(rb, r) * ld1 + colw, acc[rb][r] * s1);
-        }
+        if (has2) put_acc(X1, x1_plane, ld1, s1);
     }
     __syncthreads();  // X1 complete; every wave is done reading X0 (tile_max barriers) -> XU reusable
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 6] = __builtin_readcyclecounter();
 
-    // =============== phase 2: act2 = celu(act1 x W2^T + b2)  (fp32 into XU) ===============
+    // =============== phase 2: act2 = celu(act1 x W2^T + b2); output layer; backward seed ===============
     zero_acc();
     if (has3) fr_gemm(acc, X1, ld1, x1_plane, r2, H2 >> 4);
-    float *A2 = reinterpret_cast<float *>(XU);  // [rows][H3 + 8] fp32 (padded: conflict-free reads)
-    const int lda2 = H3 + 8;
-    if (has3) {
-        const float osc2 = fs.is2 / s1;
-        const float bias = fs.b2[(int64_t)m * H3 + colw];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                A2[row_of(rb, r) * lda2 + colw] = celu(acc[rb][r] * osc2 + bias, g.alpha, g.inv_alpha);
-    }
-    __syncthreads();
-
-    // =============== output layer + backward seed ===============
-    // thread = (row = tid / FR_TPR, part = tid % FR_TPR): dot over a slice of the columns, reduce over the parts
-    const int hrow = tid / FR_TPR, part = tid % FR_TPR;
-    const int per = H3 / FR_TPR;
-    float gv[FR_MAXH / FR_TPR];
-    float gmax = 0.f;
-    {
-        const float *w3 = fs.w3 + (int64_t)m * H3;
-        const float invM = 1.0f / (float)g.M;
-        float e = 0.f;
-#pragma unroll
-        for (int cc = 0; cc < FR_MAXH / FR_TPR; ++cc) {
-            // column = cc * FR_TPR + part: the threads of a row read consecutive floats.  Loads are
-            // unconditional (clamped) so the compiler keeps them all in flight; the tail is masked.
-            const bool ok = cc < per;
-            const int col = (ok ? cc : per - 1) * FR_TPR + part;
-            const float y = A2[hrow * lda2 + col];
-            float w = w3[col];
-            w = ok ? w : 0.f;
-            e += y * w;
-            gv[cc] = invM * w * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
-            gmax = fmaxf(gmax, fabsf(gv[cc]));
-        }
-#pragma unroll
-        for (int o = 1; o < FR_TPR; o <<= 1) e += __shfl_xor(e, o);
-        if (part == 0 && hrow < n_rows) g.member_part[(int64_t)(p0 + hrow) * g.M + m] = e + fs.b3[m];
-    }
-    if (!g.want_grad) return;
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 7] = __builtin_readcyclecounter();
     WRing r3;
-    if (has2) fr_ring(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave);
-    const float s2 = pow2_scale_for(tile_max(gmax));  // barriers inside: all fp32 reads of A2 are done
+    if (has2 && g.want_grad) fr_ring(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave);
+    float s2;
+    {
+        // e = sum_col act2 * w3 (+ b3): per-lane partial over its 16 columns, the two k halves of a row
+        // combined with a lane swap, the waves through LDS in a fixed order (deterministic sum).
+        // seed: d act2 = w3 * celu'(act2) / M, kept in the accumulators
+        const float osc2 = fs.is2 / s1;
+        const float invM = 1.0f / (float)g.M;
+        float bias[16], w3[16];
+        load_cols(fs.b2 + (int64_t)m * H3, bias, has3);
+        load_cols(fs.w3 + (int64_t)m * H3, w3, has3);
+        float gmax = 0.f;
 #pragma unroll
-    for (int cc = 0; cc < FR_MAXH / FR_TPR; ++cc) {
-        if (cc < per) put(X2, x2_plane, hrow * ld2 + cc * FR_TPR + part, gv[cc] * s2);
+        for (int rb = 0; rb < 2; ++rb) {
+            float e = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float y = celu(acc[rb][r] * osc2 + bias[r], g.alpha, g.inv_alpha);
+                e += y * w3[r];
+                const float gq = invM * w3[r] * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+                acc[rb][r] = gq;
+                gmax = fmaxf(gmax, fabsf(gq));
+            }
+            e += __shfl_xor(e, 32);
+            if (fk == 0) s_e[wave * FR_ROWS + rb * 32 + fr] = has3 ? e : 0.f;
+        }
+        s2 = pow2_scale_for(tile_max(has3 ? gmax : 0.f));   // barriers: s_e complete
+        if (tid < n_rows) {
+            float e = fs.b3[m];
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) e += s_e[w8 * FR_ROWS + tid];
+            g.member_part[(int64_t)(p0 + tid) * g.M + m] = e;
+        }
+        if (!g.want_grad) return;
+        if (has3) put_acc(X2, x2_plane, ld2, s2);
     }
     __syncthreads();
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_readcyclecounter();
 
     // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
     zero_acc();
     if (has2) fr_gemm(acc, X2, ld2, x2_plane, r3, H3 >> 4);
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 10] = __builtin_readcyclecounter();
     WRing r4;
     if (has1) fr_ring(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
     float s3;
@@ -1251,34 +1272,36 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
                 vmax3 = fmaxf(vmax3, fabsf(v));
             }
         s3 = pow2_scale_for(tile_max(has2 ? vmax3 : 0.f));  // barrier: every read of X1 (phase 2) is long done
-        if (has2) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) put(X1, x1_plane, row_of(rb, r) * ld1 + colw, acc[rb][r] * s3);
-        }
+        if (has2) put_acc(X1, x1_plane, ld1, s3);
     }
     __syncthreads();
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 11] = __builtin_readcyclecounter();
 
     // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
     zero_acc();
     if (has1) {
         fr_gemm(acc, X1, ld1, x1_plane, r4, H2 >> 4);
+        if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 12] = __builtin_readcyclecounter();
         const float osc4 = fs.is1 / s3;
         float vmax4 = 0.f;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2; ++rb) {
+            const int row = rb * 32 + fr;
+            float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_of(rb, r);
-                const float v = acc[rb][r] * osc4 * d0f[rb][r];
-                if (row < n_rows) {
-                    g.d0[(int64_t)(p0 + row) * g.ld0 + (int64_t)m * H1 + colw] = v;
-                    vmax4 = fmaxf(vmax4, fabsf(v));
+            for (int q = 0; q < 4; ++q) {
+                v4f v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = acc[rb][4 * q + e] * osc4 * d0f[rb][4 * q + e];
+                    vmax4 = fmaxf(vmax4, row < n_rows ? fabsf(v[e]) : 0.f);
                 }
+                if (row < n_rows) *reinterpret_cast<v4f *>(dst + 8 * q) = v;
             }
+        }
         amax_update(g.amax, 5, s, vmax4);
     }
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 13] = __builtin_readcyclecounter();
 }
 
 // sum the per-member energies of the fused kernel: atomic_e = mean_m, optional [M][n_atoms] copy
@@ -1626,7 +1649,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             const size_t xu = fs.H1 > fs.H3 ? fs.H1 : fs.H3;
             size_t halves = 2 * (size_t)FR_ROWS * (fs.H2 + 8) + 2 * (size_t)FR_ROWS * (xu + 8);
             if (halves < (size_t)FR_STAGE_HALVES) halves = FR_STAGE_HALVES;
-            lds = lds > halves * 2 + 16 ? lds : halves * 2 + 16;
+            lds = lds > halves * 2 + 16 + 8 * FR_ROWS * 4 ? lds : halves * 2 + 16 + 8 * FR_ROWS * 4;
         }
         f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = K0p / 32;
         f.slab_mask = kp_rad > 0 ? slab_mask : nullptr;
@@ -1637,7 +1660,22 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_mlp_fused,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t tiles = (n + FR_ROWS - 1) / FR_ROWS + S;
+        const char *trace_path = getenv("ANIHIP_FUSED_TRACE");   // development aid: per-workgroup phase stamps
+        if (trace_path) {
+            ANIHIP_CHECK_HIP(hipMalloc((void **)&f.trace, sizeof(unsigned long long) * 16 * tiles * M));
+            ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * 16 * tiles * M));
+        }
         hipLaunchKernelGGL(k_mlp_fused, dim3((unsigned)(tiles * M)), dim3(FR_THREADS), lds, stream, f);
+        if (trace_path) {
+            ANIHIP_CHECK_HIP(hipStreamSynchronize(stream));
+            std::vector<unsigned long long> host((size_t)16 * tiles * M);
+            ANIHIP_CHECK_HIP(hipMemcpy(host.data(), f.trace, host.size() * 8, hipMemcpyDeviceToHost));
+            ANIHIP_CHECK_HIP(hipFree(f.trace));
+            if (FILE *fp = fopen(trace_path, "wb")) {
+                fwrite(host.data(), 8, host.size(), fp);
+                fclose(fp);
+            }
+        }
         int64_t fb = (n + 255) / 256;
         if (fb > 2048) fb = 2048;
         hipLaunchKernelGGL(k_fused_finish, dim3((unsigned)fb), dim3(256), 0, stream, w.ctl, S, M, w.perm,
