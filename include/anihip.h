@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 2
+#define ANIHIP_ABI_VERSION 3
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -159,6 +159,13 @@ typedef struct {
      * wh[0]), wthf[l] for layers 1..n_layers-2.  NULL disables the fused kernel. */
     const void *whf[ANIHIP_MAX_LAYERS];
     const void *wthf[ANIHIP_MAX_LAYERS];
+    /* optional, fused kernel of 4-layer networks: per member 8 floats ([5..7] = 0) that bound the operands
+     * of the inner GEMMs so their fp16 split scales need no reduction over the tile:
+     *   [0] max_j sum_k |W1[j][k]|   [1] max_j |b1[j]|   [2] max_j |w3[j]| / M
+     *   [3] [2] * max_k sum_j |W2[j][k]|   [4] [3] * max_k sum_j |W1[j][k]|
+     * (|act1| <= max|act0| * [0] + [1], |d act2| <= [2], |d act1| <= [3], |d act0| <= [4]).
+     * NULL disables the fused kernel. */
+    const float *fused_bounds;
 } anihip_species_net;
 
 /* GEMM arithmetic of the hidden layers.

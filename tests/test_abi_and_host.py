@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.anihip_abi_version() == 2
+    assert lib.anihip_abi_version() == 3
 
 
 def test_struct_layouts_match_header(lib):
@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(lib):
     from torchani_amd import _lib
 
     assert ctypes.sizeof(_lib.AevParams) == 9 * 4
-    assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 5 * 4 * 8 + 4 * 4 + 2 * 4 * 8 + 0
+    assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 5 * 4 * 8 + 4 * 4 + 2 * 4 * 8 + 8
     assert ctypes.sizeof(_lib.MlpDesc) == 6 * 4 + 8 * ctypes.sizeof(_lib.SpeciesNet)
     assert _lib.MlpDesc.net.offset == 24
     d = _lib.MlpDesc()
@@ -49,7 +49,8 @@ def test_struct_layouts_match_header(lib):
     n = 1000
     need = lib.anihip_mlp_workspace_bytes(ctypes.byref(d), n)
     acts = 4 * 8 * (256 + 192 + 160) * (n + 1)
-    assert acts <= need <= acts + 4 * (n + 1) * (1 + 8) + 64 * 256
+    tiles = (n + 63) // 64 + 8   # tile table of the fused kernel: 16-B entry + 64 atom rows per tile
+    assert acts <= need <= acts + 4 * (n + 1) * (1 + 8) + (16 + 256) * tiles + 64 * 256
 
 
 def test_error_reporting_without_gpu(lib):

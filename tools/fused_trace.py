@@ -16,5 +16,10 @@ t = t[(t[:, 0] > 0) & (t[:, 13] > 0)]
 d = np.diff(t[:, STAMPS], axis=1)
 tot = t[:, 13] - t[:, 0]
 print(f"{len(t)} workgroups, total {tot.mean():.0f} ticks (median {np.median(tot):.0f})  [shader clock ticks, wave 0]")
+if t[:, 8].min() > 0 and t[:, 14].min() > 0:
+    for a, b, n in ((1, 8, "  mask -> group 0 converted"), (8, 2, "  first barrier"), (2, 14, "  group-0 steps"),
+                    (14, 15, "  stage group 1 + barrier"), (15, 3, "  rest of the k-loop")):
+        x = t[:, b] - t[:, a]
+        print(f"{n:32s} mean {x.mean():9.1f}  median {np.median(x):9.1f}")
 for i, n in enumerate(NAMES):
     print(f"  {n:30s} mean {d[:, i].mean():9.1f}  median {np.median(d[:, i]):9.1f}  ({d[:, i].mean() / tot.mean():6.1%})")

@@ -27,7 +27,7 @@ MAX_RAD = 256
 TABLE_FLOATS = 80
 ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
 MLP_FP32, MLP_F16X3 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class AevParams(C.Structure):
@@ -56,6 +56,7 @@ class SpeciesNet(C.Structure):
         ("wh_scale", C.c_float * MAX_LAYERS),
         ("whf", C.c_void_p * MAX_LAYERS),
         ("wthf", C.c_void_p * MAX_LAYERS),
+        ("fused_bounds", C.c_void_p),
     ]
 
 

@@ -867,6 +867,7 @@ struct FusedSpecies {
     float is0, is1, is2;                     // 1 / weight scales of layers 0, 1 and 2
     const float *b0, *b1, *b2;               // [M*H1], [M][H2], [M][H3]
     const float *w3, *b3;                    // output layer [M][H3], [M]
+    const float *bounds;                     // [M][4] operand bounds (include/anihip.h, fused_bounds)
 };
 
 struct FusedArgs {
@@ -880,8 +881,11 @@ struct FusedArgs {
     float *d0;                 // [n][ld0]: out: d E / d act0 (member m at columns m*H1..)
     int64_t ld0;
     const int *perm;           // sorted position -> atom
+    const int4 *tile_tab;      // [tiles_total] {species (-1: empty), first sorted position, rows, slab mask}
+    const int *tile_rows;      // [tiles_total][64] atom of each row (short tiles: last atom repeated)
     float *member_part;        // [n][M] per-member atomic energies (summed by k_fused_finish)
     int S, M;
+    int tiles_total;           // upper bound of the number of 64-atom tiles (work items = tiles_total * M)
     float alpha, inv_alpha;
     int want_grad;
     unsigned long long *trace;   // development aid (env ANIHIP_FUSED_TRACE): [workgroup][16] s_memtime stamps
@@ -971,120 +975,73 @@ __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[2], const _Float16 *xa, in
     }
 }
 
-__global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
-{
-    extern __shared__ __attribute__((aligned(16))) _Float16 fsm[];
+// fixed part of the dynamic LDS: [0] tile max, [1] slab mask, [2] slab mask of the next item | energy
+// partials [8 waves][64 rows] | staging slot 0 (never overlaid: the next item's first slabs land here while
+// the current item is still in its last phases)
+constexpr int FR_FIXED_HALVES = (16 + 8 * FR_ROWS * 4) / 2 + FR_GROUP * FR_SLAB;
 
-    // ---- tile -> (species, rows, member).  Member-major order: at any time the chip works on one or two
-    // members, whose weights stay resident in every XCD's L2 ----
-    const int tiles_total = gridDim.x / g.M;
-    const int m = blockIdx.x / tiles_total;
-    int tile = blockIdx.x % tiles_total;
-    const int *ctl = g.ctl;
-    int s = 0, cnt = 0;
-    for (; s < g.S; ++s) {
+// Tile table of the fused kernel: one wave per 64-atom tile resolves (species, rows, atoms, OR of the atoms'
+// slab masks) once, so that the 8 member workgroups of a tile start from two independent loads instead of
+// a chain of five dependent ones.
+__global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const int *perm,
+                                                    const uint32_t *slab_mask, uint32_t all_slabs,
+                                                    int tiles_total, int4 *tile_tab, int *tile_rows)
+{
+    const int tile0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile0 >= tiles_total) return;
+    int tile = tile0, s = 0, cnt = 0;
+    for (; s < S; ++s) {
         cnt = ctl[CTL_CNT + s];
         const int nt = (cnt + FR_ROWS - 1) / FR_ROWS;
         if (tile < nt) break;
         tile -= nt;
     }
-    if (s >= g.S) return;
-    const FusedSpecies &fs = g.sp[s];
-    const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
-    const int m0 = tile * FR_ROWS;
-    const int n_rows = min(FR_ROWS, cnt - m0);
-    const int p0 = ctl[CTL_OFF + s] + m0;
+    if (s >= S) {
+        if (lane == 0) tile_tab[tile0] = make_int4(-1, 0, 0, 0);
+        return;
+    }
+    const int n_rows = min(FR_ROWS, cnt - tile * FR_ROWS);
+    const int p0 = ctl[CTL_OFF + s] + tile * FR_ROWS;
+    const int atom = perm[p0 + min(lane, n_rows - 1)];
+    tile_rows[(size_t)tile0 * FR_ROWS + lane] = atom;
+    uint32_t mk = all_slabs;
+    if (slab_mask) {
+        mk = slab_mask[atom];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mk |= (uint32_t)__shfl_xor((int)mk, o);
+    }
+    if (lane == 0) tile_tab[tile0] = make_int4(s, p0, n_rows, (int)mk);
+}
+
+__global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 fsm_all[];
+    unsigned *s_tab = reinterpret_cast<unsigned *>(fsm_all);
+    unsigned &s_max = s_tab[0];
+    float *s_e = reinterpret_cast<float *>(s_tab + 4);                    // [8 waves][64 rows]
+    _Float16 *slot0 = fsm_all + (16 + 8 * FR_ROWS * 4) / 2;               // staging slot 0
+    _Float16 *fsm = fsm_all + FR_FIXED_HALVES;                            // X1 | XU; staging slots 1..3 overlay
+    auto slot = [&](int k) { return k == 0 ? slot0 : fsm + (k - 1) * (FR_GROUP * FR_SLAB); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fk = lane >> 5;
-    // LDS carve (halves): X1 planes [2][64][H2+8] | XU = max(X0 planes [2][64][H1+8], X2 planes, A2 fp32)
-    // | table.  The layer-0 staging area overlays X1 | XU (both are dead until the layer-0 epilogue).
-    const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
-    const int x0_plane = FR_ROWS * ld0, x1_plane = FR_ROWS * ld1, x2_plane = FR_ROWS * ld2;
-    _Float16 *X1 = fsm;
-    _Float16 *XU = fsm + 2 * FR_ROWS * ld1;
-    _Float16 *X0 = XU, *X2 = XU;
-    const int body = max(2 * FR_ROWS * ld1 + max(2 * FR_ROWS * ld0, 2 * FR_ROWS * ld2), FR_STAGE_HALVES);
-    unsigned *s_tab = reinterpret_cast<unsigned *>(fsm + body);   // [0] tile max, [1] tile slab mask
-    unsigned &s_max = s_tab[0];
-
-    // this wave's column block in the phases producing H1 / H2 / H3 columns
-    const bool has1 = wave < (H1 >> 5), has2 = wave < (H2 >> 5), has3 = wave < (H3 >> 5);
-    // accumulator element (rb, r) of this lane <-> tile row rb*32 + fr, column colq(r >> 2) + (r & 3)
     const int col0 = wave * 32 + 4 * fk;   // first column of run q = 0; run q starts at col0 + 8 q
-    float *s_e = reinterpret_cast<float *>(s_tab + 4);   // [8 waves][64 rows] energy partials
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter();
-
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    f32x16 acc[2];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
-    };
-    auto tile_max = [&](float vmax) {  // workgroup max of a non-negative value (two barriers)
-        if (tid == 0) s_max = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        if (lane == 0) atomicMax(&s_max, __float_as_uint(vmax));
-        __syncthreads();
-        return __uint_as_float(s_max);
-    };
-    // acc * scale -> split planes of X (row stride ldx), this lane's 2 x 4 runs of 4 columns
-    auto put_acc = [&](_Float16 *X, int plane, int ldx, float scale) {
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                h4 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = acc[rb][4 * q + e] * scale;
-                    const _Float16 h = (_Float16)x;
-                    hi[e] = h;
-                    lo[e] = (_Float16)(x - (float)h);
-                }
-                _Float16 *d = X + (rb * 32 + fr) * ldx + col0 + 8 * q;
-                *reinterpret_cast<h4 *>(d) = hi;
-                *reinterpret_cast<h4 *>(d + plane) = lo;
-            }
-    };
-    // 16 per-column parameters of this lane (bias / output weights), as 4 float4 loads
-    auto load_cols = [&](const float *base, float (&v)[16], bool has) {   // (no block: block 0, unused)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const v4f t = *(const gf4 *)(base + (has ? col0 : 4 * fk) + 8 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
-        }
-    };
-
-    // =============== layer 0: act0 = celu(aev x W0^T + b0) over the flagged slabs ===============
-    const int KS0 = g.n_slabs * 2;
-    uint32_t tmask;
-    {
-        // slab mask of the tile = OR over its atoms (wave 0 holds one row per lane)
-        if (wave == 0) {
-            uint32_t mk = g.n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << g.n_slabs) - 1u);
-            if (g.slab_mask) {
-                mk = g.slab_mask[g.perm[p0 + min(lane, n_rows - 1)]];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mk |= (uint32_t)__shfl_xor((int)mk, o);
-            }
-            if (lane == 0) s_tab[1] = mk;
-        }
-        __syncthreads();
-        tmask = s_tab[1];
-    }
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 1] = __builtin_readcyclecounter();
-    const int nact = __popc(tmask);
-    const int ngrp = (nact + FR_GROUP - 1) / FR_GROUP;
-    // staging role of this thread: row srow, 16-B piece spc (4 of the slab's 32 columns)
+    // staging role of this thread: row srow, 16-B piece spc (4 of a slab's 32 columns)
     const int srow = tid >> 3, spc = tid & 7;
-    const float *arow = g.aev + (int64_t)g.perm[p0 + min(srow, n_rows - 1)] * g.L + spc * 4;
-    uint32_t rem_a = tmask;   // slabs not yet fetched
+    const int KS0 = g.n_slabs * 2;
+    const uint32_t all_slabs = g.n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << g.n_slabs) - 1u);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+    // the d0 scale of the layer-0 backward GEMM comes from the weight-norm bounds too (amax stage 5)
+    if (blockIdx.x == 0 && tid < g.S) {
+        float b = 0.f;
+        for (int mm = 0; mm < g.M; ++mm) b = fmaxf(b, g.sp[tid].bounds[8 * mm + 4]);
+        g.amax[(5 * MAX_S + tid) * AMAX_SLOTS] = __float_as_uint(b);
+    }
+
+    // ---- AEV slab fetch / staging (layer-0 A operand) ----
+    const float *arow = nullptr;   // this thread's AEV row (+ its 16-B piece)
+    uint32_t rem_a = 0u;           // slabs not yet fetched
     auto fetch_group = [&](v4f (&v)[FR_GROUP]) {   // next FR_GROUP flagged slabs -> registers (zeros past the end)
 #pragma unroll
         for (int j = 0; j < FR_GROUP; ++j) {
@@ -1104,45 +1061,132 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
             h4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float x = v[j][e] * 4.0f;   // static scale of the layer-0 input (include/anihip.h)
-                const _Float16 h = (_Float16)x;
+                // static scale 4 of the layer-0 input (include/anihip.h)
+                const _Float16 h = (_Float16)(v[j][e] * 4.0f);
                 hi[e] = h;
-                lo[e] = (_Float16)(x - (float)h);
+                lo[e] = (_Float16)__builtin_fmaf(v[j][e], 4.0f, -(float)h);
             }
             _Float16 *d = buf + j * FR_SLAB + srow * FR_SLAB_LD + spc * 4;
             *reinterpret_cast<h4 *>(d) = hi;
             *reinterpret_cast<h4 *>(d + FR_ROWS * FR_SLAB_LD) = lo;
         }
     };
-    WRing rg;
-    uint32_t rem_w = tmask;   // k steps of the weight ring not yet requested
-    int w_odd = 0;
-    auto next_ks = [&]() {    // k step (in the slab order of W0) of the next ring request, clamped
-        const int slab = rem_w ? (int)__builtin_ctz(rem_w) : (31 - (int)__builtin_clz(tmask | 1u));
-        const int ks = 2 * slab + (rem_w ? w_odd : 1);
-        if (w_odd) rem_w &= rem_w - 1u;
-        w_odd ^= 1;
-        return ks;
-    };
-    zero_acc();
-    if (nact > 0) {
-        // AEV slabs run two groups ahead of the MFMAs in registers, one group ahead in LDS
-        v4f va[FR_GROUP], vb[FR_GROUP];
-        fetch_group(va);
-        fetch_group(vb);
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter();
+    // ---- this workgroup's item (member-major order: at any time the chip works on one or two members,
+    // whose weights stay resident in every XCD's L2): tile entry and atom rows are independent loads ----
+    const int item = blockIdx.x;
+    const int tile_id = item % g.tiles_total;
+    const int4 te = g.tile_tab[tile_id];
+    const int my_atom = g.tile_rows[(size_t)tile_id * FR_ROWS + srow];
+    if (te.x < 0) return;   // (at most num_species empty tiles per member)
+    const uint32_t tmask = (uint32_t)te.w;
+    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 1] = __builtin_readcyclecounter();
+    v4f va[FR_GROUP], vb[FR_GROUP];
+    arow = g.aev + (int64_t)my_atom * g.L + spc * 4;
+    rem_a = tmask;
+    fetch_group(va);
+    fetch_group(vb);
+    {
+        const int m = item / g.tiles_total, s = te.x, n_rows = te.z, p0 = te.y;
+        // (slabs 0..5 of this item are on their way to the registers; rem_a = the rest)
+        const FusedSpecies &fs = g.sp[s];
+        const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
+        // LDS carve (halves): X1 planes [2][64][H2+8] | XU = max(X0 planes [2][64][H1+8], X2 planes)
+        const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
+        const int x0_plane = FR_ROWS * ld0, x1_plane = FR_ROWS * ld1, x2_plane = FR_ROWS * ld2;
+        _Float16 *X1 = fsm;
+        _Float16 *XU = fsm + 2 * FR_ROWS * ld1;
+        _Float16 *X0 = XU, *X2 = XU;
+        // this wave's column block in the phases producing H1 / H2 / H3 columns
+        const bool has1 = wave < (H1 >> 5), has2 = wave < (H2 >> 5), has3 = wave < (H3 >> 5);
+        unsigned long long *trace = g.trace ? g.trace + (size_t)item * 16 : nullptr;
+
+        f32x16 acc[2];
+        auto zero_acc = [&]() {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+        };
+        auto tile_max = [&](float vmax) {  // workgroup max of a non-negative value (two barriers)
+            if (tid == 0) s_max = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            if (lane == 0) atomicMax(&s_max, __float_as_uint(vmax));
+            __syncthreads();
+            return __uint_as_float(s_max);
+        };
+        // acc * scale -> split planes of X (row stride ldx), this lane's 2 x 4 runs of 4 columns
+        auto put_acc = [&](_Float16 *X, int plane, int ldx, float scale) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // hi = fp16(x * scale), lo = fp16(x * scale - hi): two mixed-precision FMAs
+                        const _Float16 h = (_Float16)(acc[rb][4 * q + e] * scale);
+                        hi[e] = h;
+                        lo[e] = (_Float16)__builtin_fmaf(acc[rb][4 * q + e], scale, -(float)h);
+                    }
+                    _Float16 *d = X + (rb * 32 + fr) * ldx + col0 + 8 * q;
+                    *reinterpret_cast<h4 *>(d) = hi;
+                    *reinterpret_cast<h4 *>(d + plane) = lo;
+                }
+        };
+        // 16 per-column parameters of this lane (bias / output weights), as 4 float4 loads
+        auto load_cols = [&](const float *base, float (&v)[16], bool has) {   // (no block: block 0, unused)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f t = *(const gf4 *)(base + (has ? col0 : 4 * fk) + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+            }
+        };
+
+        // =============== layer 0: act0 = celu(aev x W0^T + b0) over the flagged slabs ===============
+        const v4f bnd = *(const gf4 *)(fs.bounds + 8 * m);   // operand bounds of this member
+        float bias0[16];
+        load_cols(fs.b0 + (int64_t)m * H1, bias0, has1);
+        const int nact = __popc(tmask);
+        const int npair = (nact + 2 * FR_GROUP - 1) / (2 * FR_GROUP);
+        WRing rg;
+        uint32_t rem_w = tmask;   // k steps of the weight ring not yet requested
+        int w_odd = 0;
+        auto next_ks = [&]() {    // k step (in the slab order of W0) of the next ring request, clamped
+            const int slab = rem_w ? (int)__builtin_ctz(rem_w) : (31 - (int)__builtin_clz(tmask | 1u));
+            const int ks = 2 * slab + (rem_w ? w_odd : 1);
+            if (w_odd) rem_w &= rem_w - 1u;
+            w_odd ^= 1;
+            return ks;
+        };
         if (has1) {
             rg.base = fs.w0 + (int64_t)m * (H1 >> 5) * KS0 * (2 * FRAG) + (int64_t)wave * KS0 * (2 * FRAG) + lane * 8;
             rg.load<0>(next_ks()); rg.load<1>(next_ks()); rg.load<2>(next_ks());
             rg.load<3>(next_ks()); rg.load<4>(next_ks()); rg.load<5>(next_ks());
         }
-        store_group(va, fsm);
-        __syncthreads();
-        if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 2] = __builtin_readcyclecounter();
-        for (int grp = 0; grp < ngrp; ++grp) {
-            const _Float16 *buf = fsm + (grp & 1) * (FR_GROUP * FR_SLAB);
+        zero_acc();
+        store_group(va, slot(0));
+        store_group(vb, slot(1));
+        __syncthreads();   // slots 0 / 1 published
+        if (trace && tid == 0) trace[2] = __builtin_readcyclecounter();
+        // six slabs (two staging slots, 12 k steps) per barrier; the next six are fetched into registers
+        // before the MFMAs of the current ones and staged after them
+        for (int pr = 0; pr < npair; ++pr) {
+            fetch_group(va);
+            fetch_group(vb);
             if (has1) {
-                const _Float16 *a = buf + fr * FR_SLAB_LD + fk * 8;
                 constexpr int PL = FR_ROWS * FR_SLAB_LD, RB = 32 * FR_SLAB_LD;
+                const _Float16 *a = slot(2 * (pr & 1)) + fr * FR_SLAB_LD + fk * 8;
+                fr_step<0>(acc, rg, a, PL, RB);                    rg.load<0>(next_ks());
+                fr_step<1>(acc, rg, a + 16, PL, RB);               rg.load<1>(next_ks());
+                fr_step<2>(acc, rg, a + FR_SLAB, PL, RB);          rg.load<2>(next_ks());
+                fr_step<3>(acc, rg, a + FR_SLAB + 16, PL, RB);     rg.load<3>(next_ks());
+                fr_step<4>(acc, rg, a + 2 * FR_SLAB, PL, RB);      rg.load<4>(next_ks());
+                fr_step<5>(acc, rg, a + 2 * FR_SLAB + 16, PL, RB); rg.load<5>(next_ks());
+                a = slot(2 * (pr & 1) + 1) + fr * FR_SLAB_LD + fk * 8;
                 fr_step<0>(acc, rg, a, PL, RB);                    rg.load<0>(next_ks());
                 fr_step<1>(acc, rg, a + 16, PL, RB);               rg.load<1>(next_ks());
                 fr_step<2>(acc, rg, a + FR_SLAB, PL, RB);          rg.load<2>(next_ks());
@@ -1150,158 +1194,146 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
                 fr_step<4>(acc, rg, a + 2 * FR_SLAB, PL, RB);      rg.load<4>(next_ks());
                 fr_step<5>(acc, rg, a + 2 * FR_SLAB + 16, PL, RB); rg.load<5>(next_ks());
             }
-            store_group(vb, fsm + ((grp + 1) & 1) * (FR_GROUP * FR_SLAB));   // group grp + 1
-            fetch_group(vb);                                                 // group grp + 2
-            __syncthreads();
-        }
-    }
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 3] = __builtin_readcyclecounter();
-    // weights of phase 1 start streaming during the layer-0 epilogue
-    WRing r1;
-    if (has2) fr_ring(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave);
-    float d0f[2][16];   // celu'(act0) of this lane's elements
-    float s0;
-    {
-        const float oscale = fs.is0 * 0.25f;
-        float bias[16];
-        load_cols(fs.b0 + (int64_t)m * H1, bias, has1);
-        float vmax = 0.f;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = celu(acc[rb][r] * oscale + bias[r], g.alpha, g.inv_alpha);
-                acc[rb][r] = v;
-                d0f[rb][r] = v > 0.f ? 1.0f : v * g.inv_alpha + 1.0f;
-                vmax = fmaxf(vmax, fabsf(v));
+            if (pr + 1 < npair) {   // (the last pair's successors are zeros nobody reads)
+                store_group(va, slot(2 * ((pr + 1) & 1)));
+                store_group(vb, slot(2 * ((pr + 1) & 1) + 1));
+                __syncthreads();
             }
-        s0 = pow2_scale_for(tile_max(has1 ? vmax : 0.f));
+        }
+        if (trace && tid == 0) trace[3] = __builtin_readcyclecounter();
+        // weights of phase 1 start streaming during the layer-0 epilogue
+        WRing r1;
+        if (has2) fr_ring(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave);
+        // celu and its derivative from one exponential: x > 0: (x, 1), else (alpha (e - 1), e), e = exp(x / alpha)
+        const float ia_log2e = g.inv_alpha * 1.44269504f;
+        auto celu_d = [&](float x, float &d) {
+            const float e = __builtin_amdgcn_exp2f(x * ia_log2e);
+            d = x > 0.f ? 1.0f : e;
+            return x > 0.f ? x : __builtin_fmaf(g.alpha, e, -g.alpha);
+        };
+        float d0f[2][16];   // celu'(act0) of this lane's elements
+        float a0max;        // tile max of |act0|
+        {
+            const float oscale = fs.is0 * 0.25f;
+            float vmax = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = celu_d(__builtin_fmaf(acc[rb][r], oscale, bias0[r]), d0f[rb][r]);
+                    acc[rb][r] = v;
+                    vmax = fmaxf(vmax, fabsf(v));
+                }
+            a0max = tile_max(has1 ? vmax : 0.f);   // (barriers: every wave is past the staging slots)
+        }
+        const float s0 = pow2_scale_for(a0max);
         if (has1) put_acc(X0, x0_plane, ld0, s0);
-    }
-    __syncthreads();
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 4] = __builtin_readcyclecounter();
+        // the scales of the inner GEMM operands follow from a0max and the weight-norm bounds: no more reductions
+        const float s1 = pow2_scale_for(__builtin_fmaf(a0max, bnd[0], bnd[1]));   // |act1| <= a0max ||W1||_inf + |b1|
+        const float s2 = pow2_scale_for(bnd[2]);                                  // |d act2| <= max |w3| / M
+        const float s3 = pow2_scale_for(bnd[3]);                                  // |d act1| <= [2] ||W2||_1
+        __syncthreads();
+        if (trace && tid == 0) trace[4] = __builtin_readcyclecounter();
 
-    // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
-    zero_acc();
-    if (has2) fr_gemm(acc, X0, ld0, x0_plane, r1, H1 >> 4);
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 5] = __builtin_readcyclecounter();
-    WRing r2;
-    if (has3) fr_ring(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
-    float d1f[2][16];   // celu'(act1) of this lane's elements
-    float s1;
-    {
-        const float oscale = fs.is1 / s0;
-        float bias[16];
-        load_cols(fs.b1 + (int64_t)m * H2, bias, has2);
-        float vmax = 0.f;
+        // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
+        float bias1[16];   // (per-column parameters travel during the GEMM)
+        load_cols(fs.b1 + (int64_t)m * H2, bias1, has2);
+        zero_acc();
+        if (has2) fr_gemm(acc, X0, ld0, x0_plane, r1, H1 >> 4);
+        if (trace && tid == 0) trace[5] = __builtin_readcyclecounter();
+        WRing r2;
+        if (has3) fr_ring(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
+        float d1f[2][16];   // celu'(act1) of this lane's elements
+        if (has2) {
+            const float oscale = fs.is1 / s0;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = celu(acc[rb][r] * oscale + bias[r], g.alpha, g.inv_alpha);
-                acc[rb][r] = v;
-                d1f[rb][r] = v > 0.f ? 1.0f : v * g.inv_alpha + 1.0f;
-                vmax = fmaxf(vmax, fabsf(v));
-            }
-        s1 = pow2_scale_for(tile_max(has2 ? vmax : 0.f));
-        if (has2) put_acc(X1, x1_plane, ld1, s1);
-    }
-    __syncthreads();  // X1 complete; every wave is done reading X0 (tile_max barriers) -> XU reusable
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 6] = __builtin_readcyclecounter();
-
-    // =============== phase 2: act2 = celu(act1 x W2^T + b2); output layer; backward seed ===============
-    zero_acc();
-    if (has3) fr_gemm(acc, X1, ld1, x1_plane, r2, H2 >> 4);
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 7] = __builtin_readcyclecounter();
-    WRing r3;
-    if (has2 && g.want_grad) fr_ring(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave);
-    float s2;
-    {
-        // e = sum_col act2 * w3 (+ b3): per-lane partial over its 16 columns, the two k halves of a row
-        // combined with a lane swap, the waves through LDS in a fixed order (deterministic sum).
-        // seed: d act2 = w3 * celu'(act2) / M, kept in the accumulators
-        const float osc2 = fs.is2 / s1;
-        const float invM = 1.0f / (float)g.M;
-        float bias[16], w3[16];
-        load_cols(fs.b2 + (int64_t)m * H3, bias, has3);
-        load_cols(fs.w3 + (int64_t)m * H3, w3, has3);
-        float gmax = 0.f;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            float e = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float y = celu(acc[rb][r] * osc2 + bias[r], g.alpha, g.inv_alpha);
-                e += y * w3[r];
-                const float gq = invM * w3[r] * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
-                acc[rb][r] = gq;
-                gmax = fmaxf(gmax, fabsf(gq));
-            }
-            e += __shfl_xor(e, 32);
-            if (fk == 0) s_e[wave * FR_ROWS + rb * 32 + fr] = has3 ? e : 0.f;
+                for (int r = 0; r < 16; ++r)
+                    acc[rb][r] = celu_d(__builtin_fmaf(acc[rb][r], oscale, bias1[r]), d1f[rb][r]);
+            put_acc(X1, x1_plane, ld1, s1);
         }
-        s2 = pow2_scale_for(tile_max(has3 ? gmax : 0.f));   // barriers: s_e complete
+        __syncthreads();  // X1 complete; every wave is done reading X0 -> XU reusable
+        if (trace && tid == 0) trace[6] = __builtin_readcyclecounter();
+
+        // =============== phase 2: act2 = celu(act1 x W2^T + b2); output layer; backward seed ===============
+        float bias2[16], w3[16];
+        load_cols(fs.b2 + (int64_t)m * H3, bias2, has3);
+        load_cols(fs.w3 + (int64_t)m * H3, w3, has3);
+        zero_acc();
+        if (has3) fr_gemm(acc, X1, ld1, x1_plane, r2, H2 >> 4);
+        if (trace && tid == 0) trace[7] = __builtin_readcyclecounter();
+        WRing r3;
+        if (has2 && g.want_grad) fr_ring(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave);
+        {
+            // e = sum_col act2 * w3 (+ b3): per-lane partial over its 16 columns, the two k halves of a row
+            // combined with a lane swap, the waves through LDS in a fixed order (deterministic sum).
+            // seed: d act2 = w3 * celu'(act2) / M, kept in the accumulators
+            const float osc2 = fs.is2 / s1;
+            const float invM = 1.0f / (float)g.M;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                float e = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float dy;
+                    const float y = celu_d(__builtin_fmaf(acc[rb][r], osc2, bias2[r]), dy);
+                    e = __builtin_fmaf(y, w3[r], e);
+                    acc[rb][r] = invM * w3[r] * dy;
+                }
+                e += __shfl_xor(e, 32);
+                if (fk == 0) s_e[wave * FR_ROWS + rb * 32 + fr] = has3 ? e : 0.f;
+            }
+            if (has3 && g.want_grad) put_acc(X2, x2_plane, ld2, s2);   // (XU: X0 is dead since the last barrier)
+        }
+        __syncthreads();
         if (tid < n_rows) {
             float e = fs.b3[m];
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) e += s_e[w8 * FR_ROWS + tid];
             g.member_part[(int64_t)(p0 + tid) * g.M + m] = e;
         }
-        if (!g.want_grad) return;
-        if (has3) put_acc(X2, x2_plane, ld2, s2);
-    }
-    __syncthreads();
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 9] = __builtin_readcyclecounter();
+        if (trace && tid == 0) trace[9] = __builtin_readcyclecounter();
 
-    // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
-    zero_acc();
-    if (has2) fr_gemm(acc, X2, ld2, x2_plane, r3, H3 >> 4);
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 10] = __builtin_readcyclecounter();
-    WRing r4;
-    if (has1) fr_ring(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
-    float s3;
-    {
-        const float osc3 = fs.is2 / s2;
-        float vmax3 = 0.f;
+        WRing r4;
+        if (g.want_grad) {
+            // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
+            zero_acc();
+            if (has2) fr_gemm(acc, X2, ld2, x2_plane, r3, H3 >> 4);
+            if (trace && tid == 0) trace[10] = __builtin_readcyclecounter();
+            if (has1) fr_ring(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
+            if (has2) {
+                const float osc3 = fs.is2 / s2;
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[rb][r] * osc3 * d1f[rb][r];
-                acc[rb][r] = v;
-                vmax3 = fmaxf(vmax3, fabsf(v));
-            }
-        s3 = pow2_scale_for(tile_max(has2 ? vmax3 : 0.f));  // barrier: every read of X1 (phase 2) is long done
-        if (has2) put_acc(X1, x1_plane, ld1, s3);
-    }
-    __syncthreads();
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 11] = __builtin_readcyclecounter();
-
-    // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
-    zero_acc();
-    if (has1) {
-        fr_gemm(acc, X1, ld1, x1_plane, r4, H2 >> 4);
-        if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 12] = __builtin_readcyclecounter();
-        const float osc4 = fs.is1 / s3;
-        float vmax4 = 0.f;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            const int row = rb * 32 + fr;
-            float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v4f v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[rb][4 * q + e] * osc4 * d0f[rb][4 * q + e];
-                    vmax4 = fmaxf(vmax4, row < n_rows ? fabsf(v[e]) : 0.f);
-                }
-                if (row < n_rows) *reinterpret_cast<v4f *>(dst + 8 * q) = v;
+                    for (int r = 0; r < 16; ++r) acc[rb][r] *= osc3 * d1f[rb][r];
+                put_acc(X1, x1_plane, ld1, s3);   // (X1: its last readers finished before the previous barrier)
             }
         }
-        amax_update(g.amax, 5, s, vmax4);
+        __syncthreads();
+        if (trace && tid == 0) trace[11] = __builtin_readcyclecounter();
+        // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
+        if (g.want_grad && has1) {
+            zero_acc();
+            fr_gemm(acc, X1, ld1, x1_plane, r4, H2 >> 4);
+            if (trace && tid == 0) trace[12] = __builtin_readcyclecounter();
+            const float osc4 = fs.is1 / s3;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int row = rb * 32 + fr;
+                float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[rb][4 * q + e] * osc4 * d0f[rb][4 * q + e];
+                    if (row < n_rows) *reinterpret_cast<v4f *>(dst + 8 * q) = v;
+                }
+            }
+        }
+        if (trace && tid == 0) trace[13] = __builtin_readcyclecounter();
     }
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 13] = __builtin_readcyclecounter();
 }
 
 // sum the per-member energies of the fused kernel: atomic_e = mean_m, optional [M][n_atoms] copy
@@ -1424,6 +1456,8 @@ struct MlpWorkspace {
     unsigned *amax;
     float *member_part;
     int *perm;
+    int4 *tile_tab;
+    int *tile_rows;
     float *act[ANIHIP_MAX_LAYERS];
     int64_t ld[ANIHIP_MAX_LAYERS];
 };
@@ -1441,7 +1475,13 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
     int *ctl = (int *)take(sizeof(int) * (CTL_WORDS + AMAX_WORDS));
     int *perm = (int *)take(sizeof(int) * (size_t)(n + 1));
     float *mpart = (float *)take(sizeof(float) * (size_t)(n + 1) * (size_t)d->n_members);
-    if (w) { w->ctl = ctl; w->amax = (unsigned *)(ctl + CTL_WORDS); w->perm = perm; w->member_part = mpart; }
+    const size_t tiles = (size_t)((n + FR_ROWS - 1) / FR_ROWS) + ANIHIP_MAX_SPECIES;
+    int4 *ttab = (int4 *)take(sizeof(int4) * tiles);
+    int *trows = (int *)take(sizeof(int) * FR_ROWS * tiles);
+    if (w) {
+        w->ctl = ctl; w->amax = (unsigned *)(ctl + CTL_WORDS); w->perm = perm; w->member_part = mpart;
+        w->tile_tab = ttab; w->tile_rows = trows;
+    }
     const int nh = d->net[0].n_layers - 1;  // hidden layers
     for (int l = 0; l < nh; ++l) {
         int mx = 0;
@@ -1577,7 +1617,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     bool fused = h3 && nh == 3 && K0p <= 32 * 32 && L % 4 == 0;
     for (int s = 0; s < S && fused; ++s) {
         const anihip_species_net &nn = d->net[s];
-        fused = fused && nn.whf[0] && nn.whf[1] && nn.whf[2] && nn.wthf[1] && nn.wthf[2] &&
+        fused = fused && nn.whf[0] && nn.whf[1] && nn.whf[2] && nn.wthf[1] && nn.wthf[2] && nn.fused_bounds &&
                 fused_dims_supported(nn.dims[1], nn.dims[2], nn.dims[3]);
     }
     if (const char *e = getenv("ANIHIP_NO_FUSED_HIDDEN")) fused = fused && e[0] == '0';
@@ -1646,29 +1686,38 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             fs.w2t = (const _Float16 *)nn.wthf[2]; fs.w1t = (const _Float16 *)nn.wthf[1];
             fs.is0 = 1.0f / nn.wh_scale[0]; fs.is1 = 1.0f / nn.wh_scale[1]; fs.is2 = 1.0f / nn.wh_scale[2];
             fs.b0 = nn.bias[0]; fs.b1 = nn.bias[1]; fs.b2 = nn.bias[2]; fs.w3 = nn.w[3]; fs.b3 = nn.bias[3];
+            fs.bounds = nn.fused_bounds;
             const size_t xu = fs.H1 > fs.H3 ? fs.H1 : fs.H3;
             size_t halves = 2 * (size_t)FR_ROWS * (fs.H2 + 8) + 2 * (size_t)FR_ROWS * (xu + 8);
-            if (halves < (size_t)FR_STAGE_HALVES) halves = FR_STAGE_HALVES;
-            lds = lds > halves * 2 + 16 + 8 * FR_ROWS * 4 ? lds : halves * 2 + 16 + 8 * FR_ROWS * 4;
+            if (halves < (size_t)3 * FR_GROUP * FR_SLAB) halves = 3 * FR_GROUP * FR_SLAB;   // staging slots 1..3
+            halves += FR_FIXED_HALVES;
+            lds = lds > halves * 2 ? lds : halves * 2;
         }
         f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = K0p / 32;
         f.slab_mask = kp_rad > 0 ? slab_mask : nullptr;
         if (const char *e = getenv("ANIHIP_NO_SLAB_MASK")) f.slab_mask = e[0] == '0' ? f.slab_mask : nullptr;
         f.d0 = w.act[0]; f.ld0 = w.ld[0]; f.perm = w.perm;
+        f.tile_tab = w.tile_tab; f.tile_rows = w.tile_rows;
         f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
         f.want_grad = grad_aev ? 1 : 0;
         ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_mlp_fused,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t tiles = (n + FR_ROWS - 1) / FR_ROWS + S;
-        const char *trace_path = getenv("ANIHIP_FUSED_TRACE");   // development aid: per-workgroup phase stamps
+        f.tiles_total = (int)tiles;
+        const int64_t grid = tiles * M;   // one workgroup per (member, tile) item; empty ones exit at once
+        hipLaunchKernelGGL(k_tile_table, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, w.ctl, S, w.perm,
+                           f.slab_mask, f.n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << f.n_slabs) - 1u), (int)tiles,
+                           w.tile_tab, w.tile_rows);
+        const char *trace_path = getenv("ANIHIP_FUSED_TRACE");   // development aid: per-item phase stamps
+        const size_t trace_words = (size_t)16 * grid;
         if (trace_path) {
-            ANIHIP_CHECK_HIP(hipMalloc((void **)&f.trace, sizeof(unsigned long long) * 16 * tiles * M));
-            ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * 16 * tiles * M));
+            ANIHIP_CHECK_HIP(hipMalloc((void **)&f.trace, sizeof(unsigned long long) * trace_words));
+            ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * trace_words));
         }
-        hipLaunchKernelGGL(k_mlp_fused, dim3((unsigned)(tiles * M)), dim3(FR_THREADS), lds, stream, f);
+        hipLaunchKernelGGL(k_mlp_fused, dim3((unsigned)grid), dim3(FR_THREADS), lds, stream, f);
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipStreamSynchronize(stream));
-            std::vector<unsigned long long> host((size_t)16 * tiles * M);
+            std::vector<unsigned long long> host(trace_words);
             ANIHIP_CHECK_HIP(hipMemcpy(host.data(), f.trace, host.size() * 8, hipMemcpyDeviceToHost));
             ANIHIP_CHECK_HIP(hipFree(f.trace));
             if (FILE *fp = fopen(trace_path, "wb")) {

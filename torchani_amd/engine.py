@@ -296,6 +296,20 @@ class PackedNetworks:
                     net.whf[l] = frags[0].data_ptr()
                     if l >= 1:
                         net.wthf[l] = frags[1].data_ptr()
+            if precision == "f16x3" and nl == 4:
+                # operand bounds of the fused kernel's inner GEMMs (include/anihip.h), per member
+                W1 = torch.stack([weights[m][s][1].detach().to(**f32) for m in range(M)])   # [M, H2, H1]
+                W2 = torch.stack([weights[m][s][2].detach().to(**f32) for m in range(M)])   # [M, H3, H2]
+                b1 = torch.stack([biases[m][s][1].detach().to(**f32) for m in range(M)])
+                w3 = torch.stack([weights[m][s][3].detach().to(**f32).reshape(-1) for m in range(M)])
+                g2 = w3.abs().amax(dim=1) / M
+                g3 = g2 * W2.abs().sum(dim=1).amax(dim=1)
+                g4 = g3 * W1.abs().sum(dim=1).amax(dim=1)
+                zero = torch.zeros_like(g2)
+                bounds = torch.stack([W1.abs().sum(dim=2).amax(dim=1), b1.abs().amax(dim=1), g2, g3, g4,
+                                      zero, zero, zero], dim=1).contiguous()
+                self._keep.append(bounds)
+                net.fused_bounds = bounds.data_ptr()
         self.desc = d
         self._ws: tp.Optional[Tensor] = None
 
