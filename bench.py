@@ -58,14 +58,15 @@ def water_box(n_side: int, seed: int = 4, spacing: float = 3.107):
     return sp, x, cell
 
 
-def mlp_flops_per_atom(species_idx: np.ndarray) -> float:
-    """fwd + input-gradient bwd flops of the 8-member ensemble, averaged over the atoms."""
+def mlp_flops_per_atom(species_idx: np.ndarray, l0_cols: float = None) -> float:
+    """fwd + input-gradient bwd flops of the 8-member ensemble, averaged over the atoms.
+    l0_cols: AEV columns layer 0 actually multiplies (slab skipping); default = all of them."""
     from torchani_amd.constants import HIDDEN_DIMS_2X, SYMBOLS_2X, aev_constants_2x
 
     L = aev_constants_2x().out_dim
     per = []
     for s in SYMBOLS_2X:
-        d = (L,) + tuple(HIDDEN_DIMS_2X[s]) + (1,)
+        d = (L if l0_cols is None else l0_cols,) + tuple(HIDDEN_DIMS_2X[s]) + (1,)
         per.append(8 * sum(2 * d[i] * d[i + 1] for i in range(len(d) - 1)))
     per = np.asarray(per, dtype=np.float64)
     cnt = np.bincount(species_idx[species_idx >= 0], minlength=len(per))
@@ -116,6 +117,9 @@ def main():
     ap.add_argument("--waters-side", type=int, default=92, help="waters per box edge (92 -> 2,336,064 atoms)")
     ap.add_argument("--cpu-side", type=int, default=36, help="waters per edge of the CPU-baseline sub-box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-shard", default=None, metavar="RANK/WORLD",
+                    help="development aid (N=1 only): time what rank RANK of WORLD does in a step, without "
+                         "the all-reduces -- prints ms/step and exits")
     args = ap.parse_args()
 
     from torchani_amd import _lib
@@ -139,6 +143,18 @@ def main():
 
     def step():
         return model.energies_and_forces(species, coords, cell, pbc, group=group)
+
+    if args.emulate_shard:
+        r, wd = (int(v) for v in args.emulate_shard.split("/"))
+        for _ in range(2):
+            model.energies_and_forces(species, coords, cell, pbc, shard=(r, wd))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model.energies_and_forces(species, coords, cell, pbc, shard=(r, wd))
+        torch.cuda.synchronize()
+        print(f"shard {r}/{wd}: {(time.perf_counter() - t0) / args.steps * 1e3:.3f} ms/step (no collectives)")
+        return
 
     for _ in range(args.warmup):
         out = step()
@@ -171,17 +187,18 @@ def main():
     nbrs = eng.neighbors(sp32, coords, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
     st["neighbors"] = time_stage(lambda: eng.neighbors(sp32, coords, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128), reps)
     mask = torch.zeros(n_atoms, dtype=torch.int32, device=dev)   # per-atom slab flags, as in the product path
-    aev = eng.forward(sp32, nbrs, slab_mask=mask)
-    st["aev_forward"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev, slab_mask=mask), reps)
+    aev = eng.forward(sp32, nbrs, slab_mask=mask, shard_rows=True)   # [hi - lo, L], as in the product path
+    st["aev_forward"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev, slab_mask=mask, shard_rows=True), reps)
     ae = torch.zeros(n_atoms, dtype=torch.float32, device=dev)
     gaev = torch.zeros_like(aev)
     st["mlp_fwd_bwd"] = time_stage(
         lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk,
-                                        slab_mask=mask), reps)
+                                        slab_mask=mask, shard_rows=True), reps)
     st["mlp_fwd_bwd_dense"] = time_stage(
-        lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk), 2)
+        lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk,
+                                        shard_rows=True), 2)
     gc = torch.zeros((n_atoms, 3), dtype=torch.float32, device=dev)
-    st["aev_backward"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc), reps)
+    st["aev_backward"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc, shard_rows=True), reps)
     meta = nbrs.meta[lo:hi, 1].to(torch.int64) & 0xFFFFFFFF
     n_a = float((meta & 0xFFFF).double().mean())
     n_r = n_a + float((meta >> 16).double().mean())
@@ -189,8 +206,14 @@ def main():
     # algorithmic bytes per atom of the fused AEV forward: angular 3584 + 20 n_a + 8, radial 448 + 8 n_r
     bytes_per_atom = 3584 + 20 * n_a + 8 + 448 + 8 * n_r
     aev_gbs = bytes_per_atom * n_shard / (st["aev_forward"] * 1e-3) / 1e9
-    flops_atom = mlp_flops_per_atom(sp_np.reshape(-1))
+    # layer 0 multiplies only the 32-column AEV slabs flagged for an atom (absent neighbor species give
+    # identically-zero blocks): executed flops = dense flops with the AEV length replaced by the staged columns
+    pop = mask[lo:hi].to(torch.int64) & 0xFFFFFFFF
+    mean_slabs = float(sum(((pop >> b) & 1).double().mean() for b in range(32)))
+    flops_dense = mlp_flops_per_atom(sp_np.reshape(-1))
+    flops_atom = mlp_flops_per_atom(sp_np.reshape(-1), l0_cols=32.0 * mean_slabs)
     mlp_tflops = flops_atom * n_shard / (st["mlp_fwd_bwd"] * 1e-3) / 1e12
+    mlp_tflops_dense = flops_dense * n_shard / (st["mlp_fwd_bwd_dense"] * 1e-3) / 1e12
 
     res = {
         "metric": "atom*steps/sec (energy+forces) ANI-2x",
@@ -214,17 +237,17 @@ def main():
             "mean_radial_neighbors": n_r, "mean_angular_neighbors": n_a, "avg_launch_ms": st["aev_forward"],
         },
         "roofline_mfma": {
-            "kernel": "ensemble fwd + input-gradient bwd: k_gemm_h<*> (layer 0) + k_hidden_fused, "
-                      f"precision {packed.precision}",
+            "kernel": "ensemble fwd + input-gradient bwd: k_mlp_fused (layer 0 over flagged AEV slabs + hidden "
+                      f"stack + backward) + k_gemm_h2<2> (layer-0 backward), precision {packed.precision}",
             "bound": "mfma",
-            # algorithmic fp32 flops / time, against the fp32-MFMA peak BASELINE.md names ...
-            "achieved": mlp_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": mlp_tflops / MFMA_F32_PEAK_TFLOPS, "flops_per_atom": flops_atom,
-            # ... and, for the split-fp16 path, the fp16 MFMA flops actually issued (3 per fp32 flop)
-            # against the dense fp16 MFMA peak
-            "issued_f16_tflops": (3.0 if packed.precision == "f16x3" else 0.0) * mlp_tflops,
-            "f16_peak": MFMA_F16_PEAK_TFLOPS,
-            "f16_frac": (3.0 * mlp_tflops / MFMA_F16_PEAK_TFLOPS) if packed.precision == "f16x3" else None,
+            # the split-fp16 path issues 3 fp16 MFMA flops per fp32 flop it replaces: price the ISSUED fp16
+            # flops of the EXECUTED (slab-skipped) work against the dense fp16 MFMA peak
+            "achieved": 3.0 * mlp_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": 3.0 * mlp_tflops / MFMA_F16_PEAK_TFLOPS,
+            "fp32_equivalent_tflops": mlp_tflops, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
+            "flops_per_atom_executed": flops_atom, "flops_per_atom_dense": flops_dense,
+            "mean_active_slabs": mean_slabs,
+            "dense_fp32_equivalent_tflops": mlp_tflops_dense,   # all 32 slabs multiplied (no masks)
         },
         "stages_ms": st,
     }

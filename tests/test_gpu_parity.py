@@ -274,6 +274,31 @@ def test_slab_masks_flag_exactly_the_nonzero_blocks(dev, name, monkeypatch):
     assert torch.isfinite(f1).all() and torch.allclose(f0, f1, atol=2e-6)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["rand_batch_ani2x", "small_ani2x", "water_pbc_ani2x", "1hz5_ani2x"])
+def test_shards_add_up_to_the_whole(dev, name, world, monkeypatch):
+    """The multi-GPU decomposition on one device: every rank's shard of the central atoms evaluated alone
+    (what a rank does before the all-reduces of models.ANI.energies_and_forces); the partial energies and
+    forces must add up to the golden result.  Run in the large-system configuration (slab masks)."""
+    monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
+    g = load_golden(name)
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = get_model(g["kind"], g["seed"], dev, neighborlist=modes_for(g)[-1], row_capacity=256)
+    e = torch.zeros(sp.shape[0], dtype=torch.float64, device=dev)
+    f = torch.zeros_like(x)
+    ae = torch.zeros(sp.shape, dtype=torch.float32, device=dev)
+    for rank in range(world):
+        out = model.energies_and_forces(sp, x, cell, pbc, shard=(rank, world), check_overflow=True)
+        e += out.energies
+        f += out.forces
+        ae += out.atomic_energies
+    torch.cuda.synchronize()
+    assert np.abs(ae.cpu().numpy() - g["atomic_energies"]).max() < E_ATOM_TOL
+    assert np.abs(f.cpu().numpy() - g["forces"]).max() < F_TOL
+    n_real = int((g["species"] >= 0).sum())
+    assert np.abs(e.cpu().numpy() - g["energies"]).max() < E_ATOM_TOL * max(1.0, np.sqrt(n_real))
+
+
 @pytest.mark.parametrize("name", ["ch4_ani1x", "rand_batch_ani2x", "water_pbc_ani2x"])
 def test_autograd_path_equals_fused(dev, name):
     """model((species, coords)) + torch.autograd == fused engine path (same kernels underneath)."""

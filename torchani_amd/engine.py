@@ -21,6 +21,13 @@ def _ptr(t: tp.Optional[Tensor]) -> tp.Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+def _row_ptr(t: Tensor, row_offset: int, row_len: int) -> int:
+    """Base pointer of a [*, row_len] fp32 buffer whose first row is atom ``row_offset``: the C ABI indexes
+    rows by absolute atom index but only touches the central range, so a rank can keep buffers of its shard
+    alone (the shifted base is never dereferenced outside the shard's rows)."""
+    return t.data_ptr() - 4 * row_offset * row_len
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -145,35 +152,44 @@ class AevEngine:
         return (S + 1) // 2 + S * (S + 1) // 2
 
     def forward(self, species: Tensor, nbrs: NeighborRows, out: tp.Optional[Tensor] = None,
-                slab_mask: tp.Optional[Tensor] = None) -> Tensor:
+                slab_mask: tp.Optional[Tensor] = None, shard_rows: bool = False) -> Tensor:
         """AEV rows [N, L] for the central atoms nbrs.lo..nbrs.hi (other rows are left untouched).
         slab_mask (optional int32 [N], written for the same atoms): flags of the slabs of each row that are
-        not identically zero, consumed by PackedNetworks.forward_backward."""
+        not identically zero, consumed by PackedNetworks.forward_backward.
+        shard_rows=True: the result holds only the rows lo..hi ([hi - lo, L], row 0 = atom lo)."""
         _require_cuda(species, slab_mask)
         n = species.numel()
+        rows0 = nbrs.lo if shard_rows else 0
         if out is None:
-            alloc = torch.empty if (nbrs.lo == 0 and nbrs.hi == n) else torch.zeros
-            out = alloc((n, self.L), dtype=torch.float32, device=species.device)
+            if shard_rows:
+                out = torch.empty((nbrs.hi - nbrs.lo, self.L), dtype=torch.float32, device=species.device)
+            else:
+                alloc = torch.empty if (nbrs.lo == 0 and nbrs.hi == n) else torch.zeros
+                out = alloc((n, self.L), dtype=torch.float32, device=species.device)
+        assert out.dtype == torch.float32 and out.is_contiguous()
+        assert out.numel() == ((nbrs.hi - nbrs.lo) if shard_rows else n) * self.L
         if slab_mask is not None:
             assert slab_mask.dtype == torch.int32 and slab_mask.numel() == n and slab_mask.is_contiguous()
         _lib.check(_lib.lib().anihip_aev_forward(
             _stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
-            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent), _ptr(out), _ptr(slab_mask), _ptr(nbrs.status)))
+            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent), _row_ptr(out, rows0, self.L), _ptr(slab_mask),
+            _ptr(nbrs.status)))
         return out
 
     def backward(self, species: Tensor, nbrs: NeighborRows, grad_aev: Tensor,
-                 grad_coords: tp.Optional[Tensor] = None) -> Tensor:
-        """grad_coords [N,3] += d(sum grad_aev*aev)/d coords for the central atoms of nbrs."""
+                 grad_coords: tp.Optional[Tensor] = None, shard_rows: bool = False) -> Tensor:
+        """grad_coords [N,3] += d(sum grad_aev*aev)/d coords for the central atoms of nbrs.
+        shard_rows=True: grad_aev holds only the rows lo..hi."""
         _require_cuda(species, grad_aev)
         n = species.numel()
         assert grad_aev.dtype == torch.float32 and grad_aev.is_contiguous()
-        assert grad_aev.numel() == n * self.L
+        assert grad_aev.numel() == ((nbrs.hi - nbrs.lo) if shard_rows else n) * self.L
         if grad_coords is None:
             grad_coords = torch.zeros((n, 3), dtype=torch.float32, device=species.device)
         _lib.check(_lib.lib().anihip_aev_backward(
             _stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
-            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent), _ptr(grad_aev), _ptr(grad_coords),
-            _ptr(nbrs.status)))
+            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent),
+            _row_ptr(grad_aev, nbrs.lo if shard_rows else 0, self.L), _ptr(grad_coords), _ptr(nbrs.status)))
         return grad_coords
 
 
@@ -322,12 +338,13 @@ class PackedNetworks:
     def forward_backward(self, species: Tensor, aev: Tensor, lo: int = 0, hi: tp.Optional[int] = None,
                          want_grad: bool = True, want_members: bool = False, chunk: int = 1 << 18,
                          atomic_e: tp.Optional[Tensor] = None, grad_aev: tp.Optional[Tensor] = None,
-                         slab_mask: tp.Optional[Tensor] = None
+                         slab_mask: tp.Optional[Tensor] = None, shard_rows: bool = False
                          ) -> tp.Tuple[Tensor, tp.Optional[Tensor], tp.Optional[Tensor]]:
         """Per-atom ensemble-mean energies [N], d e/d aev [N,L] (optional), member energies [M,N].
 
         slab_mask (int32 [N] from AevEngine.forward): the layer-0 GEMMs skip AEV slabs no atom of a row tile
-        flags; grad_aev is then only defined inside the flagged slabs (all AevEngine.backward reads)."""
+        flags; grad_aev is then only defined inside the flagged slabs (all AevEngine.backward reads).
+        shard_rows=True: aev (and the returned / given grad_aev) hold only the rows lo..hi."""
         _require_cuda(species, aev, slab_mask)
         if slab_mask is not None:
             assert slab_mask.dtype == torch.int32 and slab_mask.numel() == species.numel()
@@ -335,22 +352,27 @@ class PackedNetworks:
                 slab_mask = None
         n = species.numel()
         hi = n if hi is None else hi
-        assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == n * self.aev_len
+        rows = (hi - lo) if shard_rows else n
+        rows0 = lo if shard_rows else 0
+        assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == rows * self.aev_len
         dev = aev.device
-        full = lo == 0 and hi == n
+        full = (lo == 0 and hi == n) or shard_rows
         if atomic_e is None:
-            atomic_e = (torch.empty if full else torch.zeros)(n, dtype=torch.float32, device=dev)
+            atomic_e = (torch.empty if (lo == 0 and hi == n) else torch.zeros)(n, dtype=torch.float32, device=dev)
         if want_grad and grad_aev is None:
-            grad_aev = (torch.empty if full else torch.zeros)((n, self.aev_len), dtype=torch.float32, device=dev)
+            grad_aev = (torch.empty if full else torch.zeros)((rows, self.aev_len), dtype=torch.float32, device=dev)
+        if want_grad:
+            assert grad_aev.dtype == torch.float32 and grad_aev.is_contiguous()
+            assert grad_aev.numel() == rows * self.aev_len
         member_e = torch.zeros((self.M, n), dtype=torch.float32, device=dev) if want_members else None
         L = _lib.lib()
         for c0 in range(lo, hi, chunk):
             c1 = min(hi, c0 + chunk)
             ws = self.workspace(c1 - c0)
             _lib.check(L.anihip_mlp_forward_backward(
-                _stream(), C.byref(self.desc), n, c0, c1, _ptr(species), _ptr(aev), _ptr(slab_mask), _ptr(ws),
-                ws.numel(),
-                _ptr(atomic_e), _ptr(grad_aev) if want_grad else None, _ptr(member_e)))
+                _stream(), C.byref(self.desc), n, c0, c1, _ptr(species), _row_ptr(aev, rows0, self.aev_len),
+                _ptr(slab_mask), _ptr(ws), ws.numel(), _ptr(atomic_e),
+                _row_ptr(grad_aev, rows0, self.aev_len) if want_grad else None, _ptr(member_e)))
         return atomic_e, (grad_aev if want_grad else None), member_e
 
 

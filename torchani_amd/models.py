@@ -94,12 +94,15 @@ class ANI(torch.nn.Module):
     @torch.no_grad()
     def energies_and_forces(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
                             pbc: tp.Optional[tp.Sequence[bool]] = None, group=None,
-                            reduce_forces: bool = True, check_overflow: bool = False) -> EnergiesForces:
+                            reduce_forces: bool = True, check_overflow: bool = False,
+                            shard: tp.Optional[tp.Tuple[int, int]] = None) -> EnergiesForces:
         """Energies [C] (float64, NN + self energies) and forces [C, A, 3] without autograd.
 
         With a torch.distributed ``group`` (one process per GPU, RCCL) the central atoms are sharded
         contiguously over the ranks; every rank sees all coordinates, evaluates its shard, and the
         partial energies (and, for a shared system, partial forces) are all-reduced.
+        ``shard=(rank, world)`` evaluates that shard alone, without any collective (partial energies and
+        forces that add up to the full result over the shards).
         """
         if not coords.is_cuda:
             raise ValueError("torchani_amd's engine needs tensors on a ROCm device (no CPU fallback)")
@@ -108,7 +111,7 @@ class ANI(torch.nn.Module):
         n = C * A
         species32 = elem_idxs.to(torch.int32).contiguous()
         c32 = coords.detach().to(torch.float32).contiguous()
-        lo, hi = shard_range(n, group)
+        lo, hi = shard_range(n, group) if shard is None else shard_range(n, rank=shard[0], world=shard[1])
         aevc = self.aev_computer
         eng = aevc.engine()
         pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
@@ -120,10 +123,12 @@ class ANI(torch.nn.Module):
         slab_mask = None
         if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
             slab_mask = torch.zeros(n, dtype=torch.int32, device=c32.device)
-        aev = eng.forward(species32, nbrs, slab_mask=slab_mask)
+        # AEV rows and their gradients exist for this rank's central atoms only ([hi - lo, L] buffers)
+        aev = eng.forward(species32, nbrs, slab_mask=slab_mask, shard_rows=True)
         atomic_e, grad_aev, _ = packed.forward_backward(species32, aev, lo=lo, hi=hi, want_grad=True,
-                                                        chunk=self.mlp_chunk, slab_mask=slab_mask)
-        grad_coords = eng.backward(species32, nbrs, grad_aev)
+                                                        chunk=self.mlp_chunk, slab_mask=slab_mask,
+                                                        shard_rows=True)
+        grad_coords = eng.backward(species32, nbrs, grad_aev, shard_rows=True)
         sae = None
         if self.energy_shifter._enabled:
             sae = self.energy_shifter.self_energies.to(device=c32.device, dtype=torch.float64)
