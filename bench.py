@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--waters-side", type=int, default=92, help="waters per box edge (92 -> 2,336,064 atoms)")
     ap.add_argument("--cpu-side", type=int, default=36, help="waters per edge of the CPU-baseline sub-box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-stage", action="store_true",
+                    help="skip the extra (untimed-region) dense-MLP stage timing, e.g. under rocprofv3 so the "
+                         "kernel statistics hold the product configuration only")
     ap.add_argument("--emulate-shard", default=None, metavar="RANK/WORLD",
                     help="development aid (N=1 only): time what rank RANK of WORLD does in a step, without "
                          "the all-reduces -- prints ms/step and exits")
@@ -194,9 +197,10 @@ def main():
     st["mlp_fwd_bwd"] = time_stage(
         lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk,
                                         slab_mask=mask, shard_rows=True), reps)
-    st["mlp_fwd_bwd_dense"] = time_stage(
-        lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk,
-                                        shard_rows=True), 2)
+    if not args.no_dense_stage:
+        st["mlp_fwd_bwd_dense"] = time_stage(
+            lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev,
+                                            chunk=model.mlp_chunk, shard_rows=True), 2)
     gc = torch.zeros((n_atoms, 3), dtype=torch.float32, device=dev)
     st["aev_backward"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc, shard_rows=True), reps)
     meta = nbrs.meta[lo:hi, 1].to(torch.int64) & 0xFFFFFFFF
@@ -206,6 +210,15 @@ def main():
     # algorithmic bytes per atom of the fused AEV forward: angular 3584 + 20 n_a + 8, radial 448 + 8 n_r
     bytes_per_atom = 3584 + 20 * n_a + 8 + 448 + 8 * n_r
     aev_gbs = bytes_per_atom * n_shard / (st["aev_forward"] * 1e-3) / 1e9
+    # HBM traffic of the AEV forward kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB per
+    # dispatch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) measured on a smaller box of
+    # the same density and committed under profiles/; scaled by the atom count of this launch
+    aev_traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_aev_fwd.json")
+    if os.path.exists(pmc_file):
+        with open(pmc_file) as fh:
+            pm = json.load(fh)
+        aev_traffic = (pm["fetch_size_kb"] * pm["fetch_correction"] + pm["write_size_kb"]) * 1024.0 / pm["n_atoms"] * n_shard
     # layer 0 multiplies only the 32-column AEV slabs flagged for an atom (absent neighbor species give
     # identically-zero blocks): executed flops = dense flops with the AEV length replaced by the staged columns
     pop = mask[lo:hi].to(torch.int64) & 0xFFFFFFFF
@@ -213,7 +226,8 @@ def main():
     flops_dense = mlp_flops_per_atom(sp_np.reshape(-1))
     flops_atom = mlp_flops_per_atom(sp_np.reshape(-1), l0_cols=32.0 * mean_slabs)
     mlp_tflops = flops_atom * n_shard / (st["mlp_fwd_bwd"] * 1e-3) / 1e12
-    mlp_tflops_dense = flops_dense * n_shard / (st["mlp_fwd_bwd_dense"] * 1e-3) / 1e12
+    mlp_tflops_dense = (flops_dense * n_shard / (st["mlp_fwd_bwd_dense"] * 1e-3) / 1e12
+                        if "mlp_fwd_bwd_dense" in st else None)
 
     res = {
         "metric": "atom*steps/sec (energy+forces) ANI-2x",
@@ -233,7 +247,7 @@ def main():
         "roofline": {
             "kernel": "k_aev_fwd<8,4> (fused radial+angular AEV forward)", "bound": "hbm",
             "achieved": aev_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": aev_gbs / HBM_PEAK_GBS,
-            "traffic": None, "algorithmic_bytes_per_atom": bytes_per_atom,
+            "traffic": aev_traffic, "algorithmic_bytes_per_atom": bytes_per_atom,
             "mean_radial_neighbors": n_r, "mean_angular_neighbors": n_a, "avg_launch_ms": st["aev_forward"],
         },
         "roofline_mfma": {

@@ -8,7 +8,7 @@ timeout 900 python bench.py --waters-side ${SIDE:-92} --steps ${STEPS:-5} --warm
 echo "bench exit $?" >> gpurun_out/bench.err
 tail -3 gpurun_out/bench.err; cat gpurun_out/bench.log
 fi
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o bench -- python $REPO/bench.py --waters-side ${SIDE:-92} --steps 2 --warmup 1 --no-cpu-baseline > $REPO/gpurun_out/prof_bench.log 2>&1
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o bench -- python $REPO/bench.py --waters-side ${SIDE:-92} --steps 2 --warmup 1 --no-cpu-baseline --no-dense-stage > $REPO/gpurun_out/prof_bench.log 2>&1
 echo "rocprof exit $?"
 cd $REPO; find gpurun_out/prof -type f | head -20
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -40 "$f"
