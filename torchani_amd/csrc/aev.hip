@@ -162,7 +162,7 @@ __device__ __forceinline__ AtomHdr hdr_decode(uint32_t w)
 
 // ---------------------------------------------------------------------------------------------------
 template <int NA, int NZ>
-__global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
+__global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
     const float4 *__restrict__ ent, float *__restrict__ aev, uint32_t *__restrict__ slab_mask)
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE) void k_aev_fwd(
 
 // ---------------------------------------------------------------------------------------------------
 template <int NA, int NZ>
-__global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
+__global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
     const float4 *__restrict__ ent, const float *__restrict__ grad_aev, float *__restrict__ grad_coords)
@@ -390,13 +390,14 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
     // per-wave LDS: only the angular-range neighbors need to be shared between lanes
     __shared__ float4 s_nb[BWD_WPB][MAXA];    // ux uy uz r
     __shared__ float4 s_afc[BWD_WPB][MAXA];   // fc, fc', 1/r, bits(j)    (Rca)
-    __shared__ float s_g[BWD_WPB][3][MAXA];   // per-neighbor gradient accumulators
+    __shared__ float4 s_g[BWD_WPB][MAXA];     // per-neighbor gradient accumulators (x, y, z, -)
     __shared__ __attribute__((aligned(16))) float s_stage[BWD_WPB][STAGE_FLOATS];
 
     const int wib = threadIdx.x >> 6, lane = lane_id();
     float4 *nb = s_nb[wib];
     float4 *afc = s_afc[wib];
-    float *gx = s_g[wib][0], *gy = s_g[wib][1], *gz = s_g[wib][2];
+    float4 *g4 = s_g[wib];
+    float *gflat = reinterpret_cast<float *>(g4);   // component q of neighbor e at 4 e + q
     float *stage = s_stage[wib];
 
     const int p = lane >> 2, q = lane & 3;
@@ -485,9 +486,7 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
                         afc[e] = make_float4(0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f,
                                              -0.5f * pi_rca * __builtin_amdgcn_sinf(r * rev_rca), inv,
                                              __uint_as_float(wbits & IDX_MASK));
-                        gx[e] = Gx;
-                        gy[e] = Gy;
-                        gz[e] = Gz;
+                        g4[e] = make_float4(Gx, Gy, Gz, 0.f);
                     } else {
                         float *gc = grad_coords + 3 * (size_t)(wbits & IDX_MASK);
                         atomicAdd(gc + 0, Gx);
@@ -519,7 +518,13 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
                         ok += nk;
                         continue;
                     }
-                    const int div = same ? ((nj - 1) >> 1) : nk;
+                    // Pair order of a rectangle (two species): the RUN index (constant over `div` consecutive
+                    // pairs) is the smaller group, the other one cycles with period div = size of the larger
+                    // group -- same-address LDS atomics of a wave serialise, so the run side is pre-reduced
+                    // across lanes below and the cycling side repeats as rarely as possible.
+                    const bool sw = !same && nk < nj;
+                    const int na = sw ? nk : nj, oa = sw ? ok : oj, ob = sw ? oj : ok;
+                    const int div = same ? ((nj - 1) >> 1) : (sw ? nj : nk);
                     const float inv_div = div > 0 ? 1.0f / (float)div : 0.f;
                     const int rect = same ? nj * div : 0x7FFFFFFF;
                     const int half = nj >> 1;
@@ -531,17 +536,17 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
                         for (int z = 0; z < NZ; ++z) w[u][z] = blk[(q + 4 * u) * NZ + z];
                     // software pipelined: the LDS reads of step s+1 are issued before the arithmetic of s
                     int jr, kr;
-                    decode_pair2(same, min(p, np - 1), nj, div, inv_div, rect, half, jr, kr);
-                    int ej = oj + jr, ek = ok + kr;
+                    decode_pair2(same, min(p, np - 1), na, div, inv_div, rect, half, jr, kr);
+                    int ej = oa + jr, ek = ob + kr;
                     float4 J = nb[ej], K = nb[ek], FJ = afc[ej], FK = afc[ek];
                     for (int t0 = 0; t0 < np; t0 += 16) {
                         const bool v = t0 + p < np;
                         const float4 Jc = J, Kc = K, FJc = FJ, FKc = FK;
                         const int ejc = ej, ekc = ek;
                         if (t0 + 16 < np) {
-                            decode_pair2(same, min(t0 + 16 + p, np - 1), nj, div, inv_div, rect, half, jr, kr);
-                            ej = oj + jr;
-                            ek = ok + kr;
+                            decode_pair2(same, min(t0 + 16 + p, np - 1), na, div, inv_div, rect, half, jr, kr);
+                            ej = oa + jr;
+                            ek = ob + kr;
                             J = nb[ej];
                             K = nb[ek];
                             FJ = afc[ej];
@@ -596,12 +601,22 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
                         // component q of the two gradient vectors (q == 3 idles)
                         const float uj = q == 0 ? Jc.x : (q == 1 ? Jc.y : Jc.z);
                         const float uk = q == 0 ? Kc.x : (q == 1 ? Kc.y : Kc.z);
-                        const float gj = kth * (uk - c * uj) * FJc.z + k1 * uj;
+                        float gj = kth * (uk - c * uj) * FJc.z + k1 * uj;   // (0 for idle pair slots)
                         const float gk = kth * (uj - c * uk) * FKc.z + k2 * uk;
-                        if (v && q < 3) {
-                            float *gq = q == 0 ? gx : (q == 1 ? gy : gz);
-                            atomicAdd(&gq[ejc], gj);  // LDS ds_add_f32
-                            atomicAdd(&gq[ekc], gk);
+                        // run side: segmented sum over the (up to 4) pair slots of this 16-lane DPP row that
+                        // share the neighbor, then one atomic from the last slot of each run
+                        {
+                            const int e1 = __builtin_amdgcn_update_dpp(-1, ejc, 0x114, 0xF, 0xF, false);  // row_shr:4
+                            const float g1 = dpp_perm<0x114>(gj);
+                            gj += e1 == ejc ? g1 : 0.f;
+                            const int e2 = __builtin_amdgcn_update_dpp(-1, ejc, 0x118, 0xF, 0xF, false);  // row_shr:8
+                            const float g2 = dpp_perm<0x118>(gj);
+                            gj += e2 == ejc ? g2 : 0.f;
+                        }
+                        const int en = __builtin_amdgcn_update_dpp(-1, ejc, 0x104, 0xF, 0xF, false);      // row_shl:4
+                        if (q < 3) {
+                            if (en != ejc) atomicAdd(&gflat[4 * ejc + q], gj);  // LDS ds_add_f32
+                            if (v) atomicAdd(&gflat[4 * ekc + q], gk);
                         }
                     }
                     ok += nk;
@@ -612,7 +627,8 @@ __global__ __launch_bounds__(BWD_WPB * WAVE) void k_aev_bwd(
         wave_sync();
         // ---- scatter: +G to each angular-range neighbor, -sum(all G) to the central atom ----
         for (int e = lane; e < nA; e += WAVE) {
-            const float x = gx[e], y = gy[e], z = gz[e];
+            const float4 gv = g4[e];
+            const float x = gv.x, y = gv.y, z = gv.z;
             float *gc = grad_coords + 3 * (size_t)__float_as_uint(afc[e].w);
             atomicAdd(gc + 0, x);
             atomicAdd(gc + 1, y);
@@ -688,7 +704,7 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
     if (hi == lo) return 0;
-    dim3 grid(persistent_blocks(hi - lo, FWD_WPB, 4)), block(FWD_WPB * WAVE);
+    dim3 grid(persistent_blocks(hi - lo, FWD_WPB, 7)), block(FWD_WPB * WAVE);
     if (p->n_shf_a == 8)
         hipLaunchKernelGGL((k_aev_fwd<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
                            meta, (const float4 *)ent, aev, slab_mask);
