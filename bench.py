@@ -10,8 +10,8 @@ of the ANI-2x architecture (the published ones are a download), data is syntheti
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline      : the fused radial+angular AEV forward kernel against the HBM roofline
-  roofline_mfma : the ensemble stack (fwd + input-gradient bwd): algorithmic fp32 flops against the fp32-MFMA
-                  peak, plus the fp16 MFMA flops actually issued by the split-fp16 path against the fp16 peak
+  roofline_mfma : the ensemble stack (fwd + input-gradient bwd): the fp16 MFMA flops issued by the split-fp16
+                  path for the EXECUTED work (layer 0 skips all-zero AEV slabs) against the dense fp16 MFMA peak
   cpu_baseline  : the CPU oracle (float build, all host cores) timed on a bounded sub-box, N=1 only
   stages_ms     : per-stage device time of one step on this rank (HIP events on the engine's stream)
 """
