@@ -150,7 +150,7 @@ def test_aev_forward_and_backward(dev, name):
         assert np.all(vjp.cpu().numpy()[g["species"] < 0] == 0)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16x3-unfused", "f16x3-bigtile", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3-rows32", "f16x3-unfused", "f16x3-bigtile", "fp32"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     """Networks alone: reference-exact AEVs in, per-atom energies and d/d aev out, for both GEMM
@@ -163,6 +163,8 @@ def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     model = get_model(g["kind"], g["seed"], dev)
     if precision == "f16x3-unfused":  # layer-by-layer f16x3 GEMMs instead of the fused hidden-stack kernel
         monkeypatch.setenv("ANIHIP_NO_FUSED_HIDDEN", "1")
+    if precision == "f16x3-rows32":  # the 32-atom / two-workgroups-per-CU tiling of the fused kernel
+        monkeypatch.setenv("ANIHIP_FUSED_ROWS", "32")
     if precision == "f16x3-bigtile":  # force the 256x256-tile layer-0 GEMM that large systems use
         monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
     model.neural_networks.mlp_precision = precision.split("-")[0]

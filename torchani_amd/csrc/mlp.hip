@@ -849,16 +849,33 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
 // register ring: no LDS staging of weights, no barriers inside a GEMM phase.  8 waves; wave w owns all 64
 // rows (two 32-row MFMA blocks: every weight fragment feeds six MFMAs) and column block w of each phase.
 // MFMAs are the three-product v_mfma_f32_32x32x16_f16 of k_gemm_h.
-constexpr int FR_ROWS = 64;       // atoms per workgroup
-constexpr int FR_THREADS = 512;
-constexpr int FR_TPR = FR_THREADS / FR_ROWS;   // threads per row in the thread-mapped sections
-constexpr int FR_MAXH = 256;      // largest padded hidden width (8 waves x 32 columns)
-constexpr int FR_DEPTH = 6;       // k steps of B fragments in flight per wave
+// Two tilings of the same kernel, template <RB, NB>: a wave owns RB 32-row blocks x NB 32-column blocks
+// (32 accumulator elements per lane either way):
+//   <2, 1>: 64 atoms, 8 waves, 119 KB LDS, one workgroup per CU -- every weight fragment feeds six MFMAs,
+//           but MFMA loops and VALU epilogues of the whole CU alternate;
+//   <1, 2>: 32 atoms, 4 waves, 60 KB LDS, TWO workgroups per CU that drift out of phase, so the epilogues
+//           (VALU) of one overlap the GEMM phases (matrix pipe) of the other, at twice the L2 weight traffic.
+constexpr int FR_MAXH = 256;      // largest padded hidden width (8 column blocks)
 constexpr int FRAG = 512;         // halves per fragment plane: 64 lanes x 8
 constexpr int FR_SLAB_LD = 40;    // halves per staged slab row (32 + 8: conflict-free ds_read_b128)
-constexpr int FR_SLAB = 2 * FR_ROWS * FR_SLAB_LD;   // halves per staged slab {hi plane, lo plane}
-constexpr int FR_GROUP = 3;       // slabs per barrier (= FR_DEPTH / 2 k steps)
-constexpr int FR_STAGE_HALVES = 2 * FR_GROUP * FR_SLAB;   // double-buffered staging area
+constexpr int FR_GROUP = 3;       // slabs per staging slot
+
+template <int RB, int NB>
+struct FusedCfg {
+    static constexpr int NW = 8 / NB;               // waves; wave w owns column blocks w, w + NW, ...
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int ROWS = 32 * RB;            // atoms per workgroup (= THREADS / 8: one staging piece each)
+    static constexpr int TPR = THREADS / ROWS;      // = 8
+    static constexpr int DEPTH = 6;                 // k steps of B fragments in flight per wave (even)
+    // two workgroups per CU hide each other's latencies: per-column parameters are then fetched right where
+    // they are used instead of ahead of the GEMM (32 registers less per array during the MFMA loops)
+    static constexpr bool LAZY = NB == 2;
+    static constexpr int SLAB = 2 * ROWS * FR_SLAB_LD;            // halves per staged slab {hi plane, lo plane}
+    // fixed part of the dynamic LDS: [0] tile max | energy partials [NW][ROWS] | staging slot 0
+    static constexpr int FIXED_BYTES = 16 + NW * ROWS * 4;
+    static constexpr int FIXED_HALVES = FIXED_BYTES / 2 + FR_GROUP * SLAB;
+    static_assert(THREADS == ROWS * 8, "one 16-B staging piece per thread");
+};
 
 struct FusedSpecies {
     int H1, H2, H3;                          // padded widths
@@ -867,7 +884,7 @@ struct FusedSpecies {
     float is0, is1, is2;                     // 1 / weight scales of layers 0, 1 and 2
     const float *b0, *b1, *b2;               // [M*H1], [M][H2], [M][H3]
     const float *w3, *b3;                    // output layer [M][H3], [M]
-    const float *bounds;                     // [M][4] operand bounds (include/anihip.h, fused_bounds)
+    const float *bounds;                     // [M][8] operand bounds (include/anihip.h, fused_bounds)
 };
 
 struct FusedArgs {
@@ -882,10 +899,10 @@ struct FusedArgs {
     int64_t ld0;
     const int *perm;           // sorted position -> atom
     const int4 *tile_tab;      // [tiles_total] {species (-1: empty), first sorted position, rows, slab mask}
-    const int *tile_rows;      // [tiles_total][64] atom of each row (short tiles: last atom repeated)
+    const int *tile_rows;      // [tiles_total][rows per tile] atom of each row (short tiles: last atom repeated)
     float *member_part;        // [n][M] per-member atomic energies (summed by k_fused_finish)
     int S, M;
-    int tiles_total;           // upper bound of the number of 64-atom tiles (work items = tiles_total * M)
+    int tiles_total;           // upper bound of the number of tiles (work items = tiles_total * M)
     float alpha, inv_alpha;
     int want_grad;
     unsigned long long *trace;   // development aid (env ANIHIP_FUSED_TRACE): [workgroup][16] s_memtime stamps
@@ -898,101 +915,136 @@ __device__ __forceinline__ float pow2_scale_for(float mx)
     return __uint_as_float((unsigned)(127 + 13 - e) << 23);
 }
 
-// Register ring of the B fragments {hi, lo} of one column block, FR_DEPTH k steps deep.  Loads are
-// unconditional (callers clamp the k step): a branch around a load makes hipcc drain the whole ring with
+// Register ring of the B fragments {hi, lo} of NB column blocks, D k steps deep.  Loads are unconditional
+// (callers clamp the k step): a branch around a load makes hipcc drain the whole ring with
 // s_waitcnt vmcnt(0) at every join (CDNA guide, "load everything or hoist the condition").
+template <int NB, int D>
 struct WRing {
-    h8 hi[FR_DEPTH], lo[FR_DEPTH];
-    const _Float16 *base;   // fragment (cb, ks = 0, plane 0) + lane * 8
-    template <int SLOT>
-    __device__ __forceinline__ void load(int ks)
+    h8 hi[D][NB], lo[D][NB];
+    const _Float16 *base;   // fragment (cb of block 0, ks = 0, plane 0) + lane * 8
+    int64_t nb_stride;      // halves between this wave's consecutive column blocks
+    template <int NBA>
+    __device__ __forceinline__ void load(int slot, int ks)   // (slot: compile-time after unrolling)
     {
-        const _Float16 *p = base + (int64_t)ks * (2 * FRAG);
-        hi[SLOT] = *(const gh8 *)p;
-        lo[SLOT] = *(const gh8 *)(p + FRAG);
+#pragma unroll
+        for (int nb = 0; nb < NBA; ++nb) {
+            const _Float16 *p = base + nb * nb_stride + (int64_t)ks * (2 * FRAG);
+            hi[slot][nb] = *(const gh8 *)p;
+            lo[slot][nb] = *(const gh8 *)(p + FRAG);
+        }
     }
 };
 
-// one k step for both 32-row blocks, three products.  The WEIGHT fragment is the MFMA's first operand and
-// the activation fragment its second, i.e. the wave accumulates the TRANSPOSED tile: lane (fr, fk) ends up
-// with tile row rb*32 + fr and the 16 output columns 8 q + 4 fk + e (q = r >> 2, e = r & 3) of the wave's
+// one k step, three products, RB row blocks x NBA column blocks.  TR: the WEIGHT fragment is the MFMA's first
+// operand and the activation fragment its second, i.e. the wave accumulates the TRANSPOSED tile: lane (fr, fk)
+// ends up with tile row rb*32 + fr and the 16 output columns 8 q + 4 fk + e (q = r >> 2, e = r & 3) of each
 // block -- four runs of four consecutive columns, so the epilogues write 8-byte / 16-byte vectors.
-// a = hi-plane fragment address of this lane for row block 0; + a_plane = lo plane; + rb_stride = row block 1
-template <int SLOT>
-__device__ __forceinline__ void fr_step(f32x16 (&acc)[2], const WRing &rg, const _Float16 *a, int a_plane,
-                                        int rb_stride)
+// a = hi-plane fragment address of this lane for row block 0; + a_plane = lo plane; + rb_stride = next row block
+template <int RB>
+struct AFrag {   // activation fragments {hi, lo} of RB row blocks for one k step
+    h8 hi[RB], lo[RB];
+    __device__ __forceinline__ void load(const _Float16 *a, int a_plane, int rb_stride)
+    {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            hi[rb] = *reinterpret_cast<const h8 *>(a + rb * rb_stride);
+            lo[rb] = *reinterpret_cast<const h8 *>(a + rb * rb_stride + a_plane);
+        }
+    }
+};
+
+template <int RB, int NB, int NBA, int D>
+__device__ __forceinline__ void fr_mfma(f32x16 (&acc)[RB * NB], const WRing<NB, D> &rg, int slot, const AFrag<RB> &x)
 {
-    const h8 ah0 = *reinterpret_cast<const h8 *>(a), al0 = *reinterpret_cast<const h8 *>(a + a_plane);
-    const h8 ah1 = *reinterpret_cast<const h8 *>(a + rb_stride);
-    const h8 al1 = *reinterpret_cast<const h8 *>(a + rb_stride + a_plane);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[SLOT], al0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[SLOT], al1, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.lo[SLOT], ah0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.lo[SLOT], ah1, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[SLOT], ah0, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[SLOT], ah1, acc[1], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            acc[rb * NB + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[slot][nb], x.lo[rb], acc[rb * NB + nb], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            acc[rb * NB + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.lo[slot][nb], x.hi[rb], acc[rb * NB + nb], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            acc[rb * NB + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[slot][nb], x.hi[rb], acc[rb * NB + nb], 0, 0, 0);
 }
 
-// ring of column block `cb` of a [N/32][KS] fragment matrix of member m, first FR_DEPTH steps in flight
-__device__ __forceinline__ void fr_ring(WRing &r, const _Float16 *w, int64_t member_halves, int m, int KS, int cb)
+// a = hi-plane fragment address of this lane for row block 0; + a_plane = lo plane; + rb_stride = next row block
+template <int RB, int NB, int NBA, int D>
+__device__ __forceinline__ void fr_step(f32x16 (&acc)[RB * NB], const WRing<NB, D> &rg, int slot,
+                                        const _Float16 *a, int a_plane, int rb_stride)
 {
+    AFrag<RB> x;
+    x.load(a, a_plane, rb_stride);
+    fr_mfma<RB, NB, NBA, D>(acc, rg, slot, x);
+}
+
+// ring of this wave's column blocks cb, cb + NW, ... of a [N/32][KS] fragment matrix of member m, first D
+// steps in flight
+template <int NB, int NBA, int D>
+__device__ __forceinline__ void fr_ring(WRing<NB, D> &r, const _Float16 *w, int64_t member_halves, int m, int KS,
+                                        int cb, int nw)
+{
+    r.nb_stride = (int64_t)nw * KS * (2 * FRAG);
     r.base = w + (int64_t)m * member_halves + (int64_t)cb * KS * (2 * FRAG) + (threadIdx.x & 63) * 8;
-    r.load<0>(0);
-    r.load<1>(min(1, KS - 1));
-    r.load<2>(min(2, KS - 1));
-    r.load<3>(min(3, KS - 1));
-    r.load<4>(min(4, KS - 1));
-    r.load<5>(min(5, KS - 1));
+#pragma unroll
+    for (int sl = 0; sl < D; ++sl) r.template load<NBA>(sl, min(sl, KS - 1));
 }
 
-// acc += X[64 rows, K] x B over all KS = K/16 k steps (KS even): whole groups of FR_DEPTH steps without a
-// branch, the tail (0, 2 or 4 steps) issues no loads.  xa = hi plane of X, ldx = row stride (halves)
-__device__ __forceinline__ void fr_gemm(f32x16 (&acc)[2], const _Float16 *xa, int ldx, int x_plane, WRing &rg,
-                                        int KS)
+// acc += X[rows, K] x B over all KS = K/16 k steps (KS even): whole groups of D steps without a branch, the
+// tail (an even number of steps < D) issues no loads.  xa = hi plane of X, ldx = row stride (halves)
+template <int RB, int NB, int NBA, int D>
+__device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *xa, int ldx, int x_plane,
+                                        WRing<NB, D> &rg, int KS)
 {
+    // the activation fragments of step k + 1 are read from LDS before the MFMAs of step k (two register sets)
     const int lane = threadIdx.x & 63, fr = lane & 31, fk = lane >> 5;
     const _Float16 *af = xa + fr * ldx + fk * 8;
     const int rbs = 32 * ldx;
+    AFrag<RB> xe, xo;
+    xe.load(af, x_plane, rbs);
     int k0 = 0;
-    for (; k0 + FR_DEPTH <= KS; k0 += FR_DEPTH) {
-        const _Float16 *a = af + k0 * 16;
-        fr_step<0>(acc, rg, a, x_plane, rbs);      rg.load<0>(min(k0 + 6, KS - 1));
-        fr_step<1>(acc, rg, a + 16, x_plane, rbs); rg.load<1>(min(k0 + 7, KS - 1));
-        fr_step<2>(acc, rg, a + 32, x_plane, rbs); rg.load<2>(min(k0 + 8, KS - 1));
-        fr_step<3>(acc, rg, a + 48, x_plane, rbs); rg.load<3>(min(k0 + 9, KS - 1));
-        fr_step<4>(acc, rg, a + 64, x_plane, rbs); rg.load<4>(min(k0 + 10, KS - 1));
-        fr_step<5>(acc, rg, a + 80, x_plane, rbs); rg.load<5>(min(k0 + 11, KS - 1));
+    for (; k0 + D <= KS; k0 += D) {
+#pragma unroll
+        for (int sl = 0; sl < D; sl += 2) {
+            xo.load(af + (k0 + sl + 1) * 16, x_plane, rbs);
+            fr_mfma<RB, NB, NBA, D>(acc, rg, sl, xe);
+            rg.template load<NBA>(sl, min(k0 + sl + D, KS - 1));
+            xe.load(af + min(k0 + sl + 2, KS - 1) * 16, x_plane, rbs);
+            fr_mfma<RB, NB, NBA, D>(acc, rg, sl + 1, xo);
+            rg.template load<NBA>(sl + 1, min(k0 + sl + 1 + D, KS - 1));
+        }
     }
     const int rem = KS - k0;
-    const _Float16 *a = af + k0 * 16;
-    if (rem >= 2) {
-        fr_step<0>(acc, rg, a, x_plane, rbs);
-        fr_step<1>(acc, rg, a + 16, x_plane, rbs);
-    }
-    if (rem >= 4) {
-        fr_step<2>(acc, rg, a + 32, x_plane, rbs);
-        fr_step<3>(acc, rg, a + 48, x_plane, rbs);
+#pragma unroll
+    for (int sl = 0; sl < D - 2; sl += 2) {
+        if (rem > sl) {
+            xo.load(af + (k0 + sl + 1) * 16, x_plane, rbs);
+            fr_mfma<RB, NB, NBA, D>(acc, rg, sl, xe);
+            xe.load(af + min(k0 + sl + 2, KS - 1) * 16, x_plane, rbs);
+            fr_mfma<RB, NB, NBA, D>(acc, rg, sl + 1, xo);
+        }
     }
 }
 
-// fixed part of the dynamic LDS: [0] tile max, [1] slab mask, [2] slab mask of the next item | energy
-// partials [8 waves][64 rows] | staging slot 0 (never overlaid: the next item's first slabs land here while
-// the current item is still in its last phases)
-constexpr int FR_FIXED_HALVES = (16 + 8 * FR_ROWS * 4) / 2 + FR_GROUP * FR_SLAB;
-
-// Tile table of the fused kernel: one wave per 64-atom tile resolves (species, rows, atoms, OR of the atoms'
-// slab masks) once, so that the 8 member workgroups of a tile start from two independent loads instead of
-// a chain of five dependent ones.
+// Tile table of the fused kernel: one wave per tile resolves (species, rows, atoms, OR of the atoms' slab
+// masks) once, so that the member workgroups of a tile start from two independent loads instead of a chain of
+// five dependent ones.
 __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const int *perm,
                                                     const uint32_t *slab_mask, uint32_t all_slabs,
-                                                    int tiles_total, int4 *tile_tab, int *tile_rows)
+                                                    int tiles_total, int rows_per_tile, int4 *tile_tab,
+                                                    int *tile_rows)
 {
     const int tile0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile0 >= tiles_total) return;
     int tile = tile0, s = 0, cnt = 0;
     for (; s < S; ++s) {
         cnt = ctl[CTL_CNT + s];
-        const int nt = (cnt + FR_ROWS - 1) / FR_ROWS;
+        const int nt = (cnt + rows_per_tile - 1) / rows_per_tile;
         if (tile < nt) break;
         tile -= nt;
     }
@@ -1000,10 +1052,10 @@ __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const
         if (lane == 0) tile_tab[tile0] = make_int4(-1, 0, 0, 0);
         return;
     }
-    const int n_rows = min(FR_ROWS, cnt - tile * FR_ROWS);
-    const int p0 = ctl[CTL_OFF + s] + tile * FR_ROWS;
+    const int n_rows = min(rows_per_tile, cnt - tile * rows_per_tile);
+    const int p0 = ctl[CTL_OFF + s] + tile * rows_per_tile;
     const int atom = perm[p0 + min(lane, n_rows - 1)];
-    tile_rows[(size_t)tile0 * FR_ROWS + lane] = atom;
+    if (lane < rows_per_tile) tile_rows[(size_t)tile0 * rows_per_tile + lane] = atom;
     uint32_t mk = all_slabs;
     if (slab_mask) {
         mk = slab_mask[atom];
@@ -1013,25 +1065,39 @@ __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const
     if (lane == 0) tile_tab[tile0] = make_int4(s, p0, n_rows, (int)mk);
 }
 
-__global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
+// wave-uniform dispatch on the number of column blocks this wave really has in a phase (compile-time inside)
+#define FR_BLOCKS(n, CALL)                       \
+    if ((n) >= NB) { constexpr int NBA = NB; CALL; } \
+    else if ((n) == 1) { constexpr int NBA = 1; CALL; }
+
+template <int RB, int NB>
+__global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 {
+    using C = FusedCfg<RB, NB>;
+    constexpr int NW = C::NW, ROWS = C::ROWS, D = C::DEPTH, SLAB = C::SLAB, NE = RB * NB;
+    typedef WRing<NB, D> Ring;
     extern __shared__ __attribute__((aligned(16))) _Float16 fsm_all[];
     unsigned *s_tab = reinterpret_cast<unsigned *>(fsm_all);
     unsigned &s_max = s_tab[0];
-    float *s_e = reinterpret_cast<float *>(s_tab + 4);                    // [8 waves][64 rows]
-    _Float16 *slot0 = fsm_all + (16 + 8 * FR_ROWS * 4) / 2;               // staging slot 0
-    _Float16 *fsm = fsm_all + FR_FIXED_HALVES;                            // X1 | XU; staging slots 1..3 overlay
-    auto slot = [&](int k) { return k == 0 ? slot0 : fsm + (k - 1) * (FR_GROUP * FR_SLAB); };
+    float *s_e = reinterpret_cast<float *>(s_tab + 4);                    // [NW][ROWS]
+    _Float16 *slot0 = fsm_all + C::FIXED_BYTES / 2;                       // staging slot 0
+    _Float16 *fsm = fsm_all + C::FIXED_HALVES;                            // X1 | XU; staging slots 1..3 overlay
+    auto slot = [&](int k) { return k == 0 ? slot0 : fsm + (k - 1) * (FR_GROUP * SLAB); };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fk = lane >> 5;
-    const int col0 = wave * 32 + 4 * fk;   // first column of run q = 0; run q starts at col0 + 8 q
     // staging role of this thread: row srow, 16-B piece spc (4 of a slab's 32 columns)
     const int srow = tid >> 3, spc = tid & 7;
     const int KS0 = g.n_slabs * 2;
-    const uint32_t all_slabs = g.n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << g.n_slabs) - 1u);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
+    // Two co-resident workgroups that start together would stay in lockstep (same phase at the same time:
+    // both on the matrix pipe, then both on the VALU).  The one placed second in the CU's LDS gets a higher
+    // issue priority: it wins the shared pipes, runs ahead, and the two settle into complementary phases.
+    if (NB == 2) {
+        const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6);   // HW_REG_LDS_ALLOC.LDS_BASE
+        if (lds_base != 0u) __builtin_amdgcn_s_setprio(2);
+    }
     // the d0 scale of the layer-0 backward GEMM comes from the weight-norm bounds too (amax stage 5)
     if (blockIdx.x == 0 && tid < g.S) {
         float b = 0.f;
@@ -1066,18 +1132,19 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
                 hi[e] = h;
                 lo[e] = (_Float16)__builtin_fmaf(v[j][e], 4.0f, -(float)h);
             }
-            _Float16 *d = buf + j * FR_SLAB + srow * FR_SLAB_LD + spc * 4;
+            _Float16 *d = buf + j * SLAB + srow * FR_SLAB_LD + spc * 4;
             *reinterpret_cast<h4 *>(d) = hi;
-            *reinterpret_cast<h4 *>(d + FR_ROWS * FR_SLAB_LD) = lo;
+            *reinterpret_cast<h4 *>(d + ROWS * FR_SLAB_LD) = lo;
         }
     };
+
     if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter();
     // ---- this workgroup's item (member-major order: at any time the chip works on one or two members,
     // whose weights stay resident in every XCD's L2): tile entry and atom rows are independent loads ----
     const int item = blockIdx.x;
     const int tile_id = item % g.tiles_total;
     const int4 te = g.tile_tab[tile_id];
-    const int my_atom = g.tile_rows[(size_t)tile_id * FR_ROWS + srow];
+    const int my_atom = g.tile_rows[(size_t)tile_id * ROWS + srow];
     if (te.x < 0) return;   // (at most num_species empty tiles per member)
     const uint32_t tmask = (uint32_t)te.w;
     if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 1] = __builtin_readcyclecounter();
@@ -1091,22 +1158,25 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
         // (slabs 0..5 of this item are on their way to the registers; rem_a = the rest)
         const FusedSpecies &fs = g.sp[s];
         const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
-        // LDS carve (halves): X1 planes [2][64][H2+8] | XU = max(X0 planes [2][64][H1+8], X2 planes)
+        // LDS carve (halves): X1 planes [2][ROWS][H2+8] | XU = max(X0 planes [2][ROWS][H1+8], X2 planes)
         const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
-        const int x0_plane = FR_ROWS * ld0, x1_plane = FR_ROWS * ld1, x2_plane = FR_ROWS * ld2;
+        const int x0_plane = ROWS * ld0, x1_plane = ROWS * ld1, x2_plane = ROWS * ld2;
         _Float16 *X1 = fsm;
-        _Float16 *XU = fsm + 2 * FR_ROWS * ld1;
+        _Float16 *XU = fsm + 2 * ROWS * ld1;
         _Float16 *X0 = XU, *X2 = XU;
-        // this wave's column block in the phases producing H1 / H2 / H3 columns
-        const bool has1 = wave < (H1 >> 5), has2 = wave < (H2 >> 5), has3 = wave < (H3 >> 5);
+        // number of column blocks (w, w + NW, ...) this wave has in the phases producing H1 / H2 / H3 columns
+        auto nblk = [&](int H) { const int t = (H >> 5) - wave; return t <= 0 ? 0 : (t + NW - 1) / NW; };
+        const int n1 = nblk(H1), n2 = nblk(H2), n3 = nblk(H3);
+        // accumulator element (rb, nb, r) of this lane <-> tile row rb*32 + fr, column col0(nb) + 8 (r >> 2) + (r & 3)
+        auto col0 = [&](int nb) { return (wave + NW * nb) * 32 + 4 * fk; };
         unsigned long long *trace = g.trace ? g.trace + (size_t)item * 16 : nullptr;
 
-        f32x16 acc[2];
+        f32x16 acc[NE];
         auto zero_acc = [&]() {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int i = 0; i < NE; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         };
         auto tile_max = [&](float vmax) {  // workgroup max of a non-negative value (two barriers)
             if (tid == 0) s_max = 0u;
@@ -1117,42 +1187,49 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
             __syncthreads();
             return __uint_as_float(s_max);
         };
-        // acc * scale -> split planes of X (row stride ldx), this lane's 2 x 4 runs of 4 columns
-        auto put_acc = [&](_Float16 *X, int plane, int ldx, float scale) {
+        // acc * scale -> split planes of X (row stride ldx): this lane's runs of 4 columns of its first nba blocks
+        auto put_acc = [&](_Float16 *X, int plane, int ldx, float scale, int nba) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    h4 hi, lo;
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (nb >= nba) continue;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        // hi = fp16(x * scale), lo = fp16(x * scale - hi): two mixed-precision FMAs
-                        const _Float16 h = (_Float16)(acc[rb][4 * q + e] * scale);
-                        hi[e] = h;
-                        lo[e] = (_Float16)__builtin_fmaf(acc[rb][4 * q + e], scale, -(float)h);
+                    for (int q = 0; q < 4; ++q) {
+                        h4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // hi = fp16(x * scale), lo = fp16(x * scale - hi): two mixed-precision FMAs
+                            const float x = acc[rb * NB + nb][4 * q + e];
+                            const _Float16 h = (_Float16)(x * scale);
+                            hi[e] = h;
+                            lo[e] = (_Float16)__builtin_fmaf(x, scale, -(float)h);
+                        }
+                        _Float16 *d = X + (rb * 32 + fr) * ldx + col0(nb) + 8 * q;
+                        *reinterpret_cast<h4 *>(d) = hi;
+                        *reinterpret_cast<h4 *>(d + plane) = lo;
                     }
-                    _Float16 *d = X + (rb * 32 + fr) * ldx + col0 + 8 * q;
-                    *reinterpret_cast<h4 *>(d) = hi;
-                    *reinterpret_cast<h4 *>(d + plane) = lo;
                 }
         };
-        // 16 per-column parameters of this lane (bias / output weights), as 4 float4 loads
-        auto load_cols = [&](const float *base, float (&v)[16], bool has) {   // (no block: block 0, unused)
+        // 16 per-column parameters per block of this lane (bias / output weights), as float4 loads
+        auto load_cols = [&](const float *base, float (&v)[NB][16], int nba) {   // (missing blocks: block 0, unused)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4f t = *(const gf4 *)(base + (has ? col0 : 4 * fk) + 8 * q);
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const v4f t = *(const gf4 *)(base + (nb < nba ? col0(nb) : 4 * fk) + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[nb][4 * q + e] = t[e];
+                }
         };
 
         // =============== layer 0: act0 = celu(aev x W0^T + b0) over the flagged slabs ===============
         const v4f bnd = *(const gf4 *)(fs.bounds + 8 * m);   // operand bounds of this member
-        float bias0[16];
-        load_cols(fs.b0 + (int64_t)m * H1, bias0, has1);
+        float bias0[NB][16];
+        if (!C::LAZY) load_cols(fs.b0 + (int64_t)m * H1, bias0, n1);
         const int nact = __popc(tmask);
         const int npair = (nact + 2 * FR_GROUP - 1) / (2 * FR_GROUP);
-        WRing rg;
+        Ring rg;
         uint32_t rem_w = tmask;   // k steps of the weight ring not yet requested
         int w_odd = 0;
         auto next_ks = [&]() {    // k step (in the slab order of W0) of the next ring request, clamped
@@ -1162,10 +1239,11 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
             w_odd ^= 1;
             return ks;
         };
-        if (has1) {
-            rg.base = fs.w0 + (int64_t)m * (H1 >> 5) * KS0 * (2 * FRAG) + (int64_t)wave * KS0 * (2 * FRAG) + lane * 8;
-            rg.load<0>(next_ks()); rg.load<1>(next_ks()); rg.load<2>(next_ks());
-            rg.load<3>(next_ks()); rg.load<4>(next_ks()); rg.load<5>(next_ks());
+        rg.nb_stride = (int64_t)NW * KS0 * (2 * FRAG);
+        rg.base = fs.w0 + (int64_t)m * (H1 >> 5) * KS0 * (2 * FRAG) + (int64_t)wave * KS0 * (2 * FRAG) + lane * 8;
+        if (n1 > 0) {
+#pragma unroll
+            for (int sl = 0; sl < D; ++sl) { FR_BLOCKS(n1, rg.template load<NBA>(sl, next_ks())) }
         }
         zero_acc();
         store_group(va, slot(0));
@@ -1177,22 +1255,16 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
         for (int pr = 0; pr < npair; ++pr) {
             fetch_group(va);
             fetch_group(vb);
-            if (has1) {
-                constexpr int PL = FR_ROWS * FR_SLAB_LD, RB = 32 * FR_SLAB_LD;
-                const _Float16 *a = slot(2 * (pr & 1)) + fr * FR_SLAB_LD + fk * 8;
-                fr_step<0>(acc, rg, a, PL, RB);                    rg.load<0>(next_ks());
-                fr_step<1>(acc, rg, a + 16, PL, RB);               rg.load<1>(next_ks());
-                fr_step<2>(acc, rg, a + FR_SLAB, PL, RB);          rg.load<2>(next_ks());
-                fr_step<3>(acc, rg, a + FR_SLAB + 16, PL, RB);     rg.load<3>(next_ks());
-                fr_step<4>(acc, rg, a + 2 * FR_SLAB, PL, RB);      rg.load<4>(next_ks());
-                fr_step<5>(acc, rg, a + 2 * FR_SLAB + 16, PL, RB); rg.load<5>(next_ks());
-                a = slot(2 * (pr & 1) + 1) + fr * FR_SLAB_LD + fk * 8;
-                fr_step<0>(acc, rg, a, PL, RB);                    rg.load<0>(next_ks());
-                fr_step<1>(acc, rg, a + 16, PL, RB);               rg.load<1>(next_ks());
-                fr_step<2>(acc, rg, a + FR_SLAB, PL, RB);          rg.load<2>(next_ks());
-                fr_step<3>(acc, rg, a + FR_SLAB + 16, PL, RB);     rg.load<3>(next_ks());
-                fr_step<4>(acc, rg, a + 2 * FR_SLAB, PL, RB);      rg.load<4>(next_ks());
-                fr_step<5>(acc, rg, a + 2 * FR_SLAB + 16, PL, RB); rg.load<5>(next_ks());
+            if (n1 > 0) {
+                constexpr int PL = ROWS * FR_SLAB_LD, RBS = 32 * FR_SLAB_LD;
+                // 12 k steps = 2 slots x 3 slabs x 2; ring slot = step % D (12 % D == 0)
+#pragma unroll
+                for (int st = 0; st < 4 * FR_GROUP; ++st) {
+                    const _Float16 *a = slot(2 * (pr & 1) + st / (2 * FR_GROUP)) + ((st / 2) % FR_GROUP) * SLAB +
+                                        (st & 1) * 16 + fr * FR_SLAB_LD + fk * 8;
+                    FR_BLOCKS(n1, (fr_step<RB, NB, NBA, D>(acc, rg, st % D, a, PL, RBS),
+                                   rg.template load<NBA>(st % D, next_ks())))
+                }
             }
             if (pr + 1 < npair) {   // (the last pair's successors are zeros nobody reads)
                 store_group(va, slot(2 * ((pr + 1) & 1)));
@@ -1202,8 +1274,8 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
         }
         if (trace && tid == 0) trace[3] = __builtin_readcyclecounter();
         // weights of phase 1 start streaming during the layer-0 epilogue
-        WRing r1;
-        if (has2) fr_ring(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave);
+        Ring r1;
+        FR_BLOCKS(n2, (fr_ring<NB, NBA, D>(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave, NW)))
         // celu and its derivative from one exponential: x > 0: (x, 1), else (alpha (e - 1), e), e = exp(x / alpha)
         const float ia_log2e = g.inv_alpha * 1.44269504f;
         auto celu_d = [&](float x, float &d) {
@@ -1211,23 +1283,27 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
             d = x > 0.f ? 1.0f : e;
             return x > 0.f ? x : __builtin_fmaf(g.alpha, e, -g.alpha);
         };
-        float d0f[2][16];   // celu'(act0) of this lane's elements
-        float a0max;        // tile max of |act0|
+        float d0f[NE][16];   // celu'(act0) of this lane's elements
+        float a0max;         // tile max of |act0|
         {
+            if (C::LAZY) load_cols(fs.b0 + (int64_t)m * H1, bias0, n1);
             const float oscale = fs.is0 * 0.25f;
             float vmax = 0.f;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = celu_d(__builtin_fmaf(acc[rb][r], oscale, bias0[r]), d0f[rb][r]);
-                    acc[rb][r] = v;
-                    vmax = fmaxf(vmax, fabsf(v));
-                }
-            a0max = tile_max(has1 ? vmax : 0.f);   // (barriers: every wave is past the staging slots)
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = rb * NB + nb;
+                        const float v = celu_d(__builtin_fmaf(acc[i][r], oscale, bias0[nb][r]), d0f[i][r]);
+                        acc[i][r] = v;
+                        vmax = fmaxf(vmax, nb < n1 ? fabsf(v) : 0.f);
+                    }
+            a0max = tile_max(vmax);   // (barriers: every wave is past the staging slots)
         }
         const float s0 = pow2_scale_for(a0max);
-        if (has1) put_acc(X0, x0_plane, ld0, s0);
+        put_acc(X0, x0_plane, ld0, s0, n1);
         // the scales of the inner GEMM operands follow from a0max and the weight-norm bounds: no more reductions
         const float s1 = pow2_scale_for(__builtin_fmaf(a0max, bnd[0], bnd[1]));   // |act1| <= a0max ||W1||_inf + |b1|
         const float s2 = pow2_scale_for(bnd[2]);                                  // |d act2| <= max |w3| / M
@@ -1236,105 +1312,151 @@ __global__ __launch_bounds__(FR_THREADS, 2) void k_mlp_fused(FusedArgs g)
         if (trace && tid == 0) trace[4] = __builtin_readcyclecounter();
 
         // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
-        float bias1[16];   // (per-column parameters travel during the GEMM)
-        load_cols(fs.b1 + (int64_t)m * H2, bias1, has2);
+        float bias1[NB][16];   // (per-column parameters travel during the GEMM)
+        if (!C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, n2);
         zero_acc();
-        if (has2) fr_gemm(acc, X0, ld0, x0_plane, r1, H1 >> 4);
+        FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X0, ld0, x0_plane, r1, H1 >> 4)))
         if (trace && tid == 0) trace[5] = __builtin_readcyclecounter();
-        WRing r2;
-        if (has3) fr_ring(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
-        float d1f[2][16];   // celu'(act1) of this lane's elements
-        if (has2) {
+        Ring r2;
+        FR_BLOCKS(n3, (fr_ring<NB, NBA, D>(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW)))
+        float d1f[NE][16];   // celu'(act1) of this lane's elements
+        if (n2 > 0) {
+            if (C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, n2);
             const float oscale = fs.is1 / s0;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[rb][r] = celu_d(__builtin_fmaf(acc[rb][r], oscale, bias1[r]), d1f[rb][r]);
-            put_acc(X1, x1_plane, ld1, s1);
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = rb * NB + nb;
+                        float dloc;
+                        acc[i][r] = celu_d(__builtin_fmaf(acc[i][r], oscale, bias1[nb][r]), C::LAZY ? dloc : d1f[i][r]);
+                    }
+            put_acc(X1, x1_plane, ld1, s1, n2);
         }
         __syncthreads();  // X1 complete; every wave is done reading X0 -> XU reusable
         if (trace && tid == 0) trace[6] = __builtin_readcyclecounter();
 
         // =============== phase 2: act2 = celu(act1 x W2^T + b2); output layer; backward seed ===============
-        float bias2[16], w3[16];
-        load_cols(fs.b2 + (int64_t)m * H3, bias2, has3);
-        load_cols(fs.w3 + (int64_t)m * H3, w3, has3);
+        float bias2[NB][16], w3[NB][16];
+        if (!C::LAZY) {
+            load_cols(fs.b2 + (int64_t)m * H3, bias2, n3);
+            load_cols(fs.w3 + (int64_t)m * H3, w3, n3);
+        }
         zero_acc();
-        if (has3) fr_gemm(acc, X1, ld1, x1_plane, r2, H2 >> 4);
+        FR_BLOCKS(n3, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r2, H2 >> 4)))
         if (trace && tid == 0) trace[7] = __builtin_readcyclecounter();
-        WRing r3;
-        if (has2 && g.want_grad) fr_ring(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave);
+        Ring r3;
+        if (g.want_grad) {
+            FR_BLOCKS(n2, (fr_ring<NB, NBA, D>(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave, NW)))
+        }
         {
-            // e = sum_col act2 * w3 (+ b3): per-lane partial over its 16 columns, the two k halves of a row
+            // e = sum_col act2 * w3 (+ b3): per-lane partial over its columns, the two k halves of a row
             // combined with a lane swap, the waves through LDS in a fixed order (deterministic sum).
             // seed: d act2 = w3 * celu'(act2) / M, kept in the accumulators
+            if (C::LAZY) {
+                load_cols(fs.b2 + (int64_t)m * H3, bias2, n3);
+                load_cols(fs.w3 + (int64_t)m * H3, w3, n3);
+            }
             const float osc2 = fs.is2 / s1;
             const float invM = 1.0f / (float)g.M;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
+            for (int rb = 0; rb < RB; ++rb) {
                 float e = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float dy;
-                    const float y = celu_d(__builtin_fmaf(acc[rb][r], osc2, bias2[r]), dy);
-                    e = __builtin_fmaf(y, w3[r], e);
-                    acc[rb][r] = invM * w3[r] * dy;
-                }
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int i = rb * NB + nb;
+                        float dy;
+                        const float y = celu_d(__builtin_fmaf(acc[i][r], osc2, bias2[nb][r]), dy);
+                        e = __builtin_fmaf(nb < n3 ? y : 0.f, w3[nb][r], e);
+                        acc[i][r] = invM * w3[nb][r] * dy;
+                    }
                 e += __shfl_xor(e, 32);
-                if (fk == 0) s_e[wave * FR_ROWS + rb * 32 + fr] = has3 ? e : 0.f;
+                if (fk == 0) s_e[wave * ROWS + rb * 32 + fr] = e;
             }
-            if (has3 && g.want_grad) put_acc(X2, x2_plane, ld2, s2);   // (XU: X0 is dead since the last barrier)
+            if (g.want_grad) put_acc(X2, x2_plane, ld2, s2, n3);   // (XU: X0 is dead since the last barrier)
         }
         __syncthreads();
         if (tid < n_rows) {
             float e = fs.b3[m];
 #pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) e += s_e[w8 * FR_ROWS + tid];
+            for (int w8 = 0; w8 < NW; ++w8) e += s_e[w8 * ROWS + tid];
             g.member_part[(int64_t)(p0 + tid) * g.M + m] = e;
         }
         if (trace && tid == 0) trace[9] = __builtin_readcyclecounter();
 
-        WRing r4;
+        Ring r4;
         if (g.want_grad) {
             // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
             zero_acc();
-            if (has2) fr_gemm(acc, X2, ld2, x2_plane, r3, H3 >> 4);
+            FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X2, ld2, x2_plane, r3, H3 >> 4)))
             if (trace && tid == 0) trace[10] = __builtin_readcyclecounter();
-            if (has1) fr_ring(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave);
-            if (has2) {
+            FR_BLOCKS(n1, (fr_ring<NB, NBA, D>(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW)))
+            if (n2 > 0) {
                 const float osc3 = fs.is2 / s2;
+                if constexpr (!C::LAZY) {
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                    for (int i = 0; i < NE; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[rb][r] *= osc3 * d1f[rb][r];
-                put_acc(X1, x1_plane, ld1, s3);   // (X1: its last readers finished before the previous barrier)
+                        for (int r = 0; r < 16; ++r) acc[i][r] *= osc3 * d1f[i][r];
+                } else {
+                    // celu'(act1) from act1 itself, which this lane still finds at its own positions of X1
+                    // (celu' = 1 for y > 0, else y / alpha + 1), before d act1 overwrites it
+                    const float inv_s1 = 1.0f / s1;
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            if (nb >= n2) continue;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const _Float16 *d = X1 + (rb * 32 + fr) * ld1 + col0(nb) + 8 * q;
+                                const h4 yh = *reinterpret_cast<const h4 *>(d);
+                                const h4 yl = *reinterpret_cast<const h4 *>(d + x1_plane);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float y = ((float)yh[e] + (float)yl[e]) * inv_s1;
+                                    acc[rb * NB + nb][4 * q + e] *= osc3 * (y > 0.f ? 1.0f : __builtin_fmaf(y, g.inv_alpha, 1.0f));
+                                }
+                            }
+                        }
+                }
+                put_acc(X1, x1_plane, ld1, s3, n2);   // (X1: its last readers finished before the previous barrier)
             }
         }
         __syncthreads();
         if (trace && tid == 0) trace[11] = __builtin_readcyclecounter();
         // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
-        if (g.want_grad && has1) {
+        if (g.want_grad && n1 > 0) {
             zero_acc();
-            fr_gemm(acc, X1, ld1, x1_plane, r4, H2 >> 4);
+            FR_BLOCKS(n1, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r4, H2 >> 4)))
             if (trace && tid == 0) trace[12] = __builtin_readcyclecounter();
             const float osc4 = fs.is1 / s3;
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
+            for (int rb = 0; rb < RB; ++rb) {
                 const int row = rb * 32 + fr;
-                float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v4f v;
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (nb >= n1) continue;
+                    float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0(nb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[rb][4 * q + e] * osc4 * d0f[rb][4 * q + e];
-                    if (row < n_rows) *reinterpret_cast<v4f *>(dst + 8 * q) = v;
+                    for (int q = 0; q < 4; ++q) {
+                        v4f v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = acc[rb * NB + nb][4 * q + e] * osc4 * d0f[rb * NB + nb][4 * q + e];
+                        if (row < n_rows) *reinterpret_cast<v4f *>(dst + 8 * q) = v;
+                    }
                 }
             }
         }
         if (trace && tid == 0) trace[13] = __builtin_readcyclecounter();
     }
 }
+#undef FR_BLOCKS
 
 // sum the per-member energies of the fused kernel: atomic_e = mean_m, optional [M][n_atoms] copy
 __global__ void k_fused_finish(const int *ctl, int S, int M, const int *perm, const float *member_part,
@@ -1475,9 +1597,9 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
     int *ctl = (int *)take(sizeof(int) * (CTL_WORDS + AMAX_WORDS));
     int *perm = (int *)take(sizeof(int) * (size_t)(n + 1));
     float *mpart = (float *)take(sizeof(float) * (size_t)(n + 1) * (size_t)d->n_members);
-    const size_t tiles = (size_t)((n + FR_ROWS - 1) / FR_ROWS) + ANIHIP_MAX_SPECIES;
+    const size_t tiles = (size_t)((n + 31) / 32) + ANIHIP_MAX_SPECIES;   // (finest tiling of the fused kernel)
     int4 *ttab = (int4 *)take(sizeof(int4) * tiles);
-    int *trows = (int *)take(sizeof(int) * FR_ROWS * tiles);
+    int *trows = (int *)take(sizeof(int) * 32 * tiles);
     if (w) {
         w->ctl = ctl; w->amax = (unsigned *)(ctl + CTL_WORDS); w->perm = perm; w->member_part = mpart;
         w->tile_tab = ttab; w->tile_rows = trows;
@@ -1677,6 +1799,10 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     if (fused) {
         FusedArgs f{};
         size_t lds = 0;
+        // tiling: 64 atoms x 8 waves, one workgroup per CU (default: 3 % faster on the water box), or
+        // 32 atoms x 4 waves, two per CU (ANIHIP_FUSED_ROWS=32)
+        int rows = 64;
+        if (const char *e = getenv("ANIHIP_FUSED_ROWS")) rows = atoi(e) == 32 ? 32 : 64;
         for (int s = 0; s < S; ++s) {
             const anihip_species_net &nn = d->net[s];
             FusedSpecies &fs = f.sp[s];
@@ -1688,9 +1814,10 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             fs.b0 = nn.bias[0]; fs.b1 = nn.bias[1]; fs.b2 = nn.bias[2]; fs.w3 = nn.w[3]; fs.b3 = nn.bias[3];
             fs.bounds = nn.fused_bounds;
             const size_t xu = fs.H1 > fs.H3 ? fs.H1 : fs.H3;
-            size_t halves = 2 * (size_t)FR_ROWS * (fs.H2 + 8) + 2 * (size_t)FR_ROWS * (xu + 8);
-            if (halves < (size_t)3 * FR_GROUP * FR_SLAB) halves = 3 * FR_GROUP * FR_SLAB;   // staging slots 1..3
-            halves += FR_FIXED_HALVES;
+            size_t halves = 2 * (size_t)rows * (fs.H2 + 8) + 2 * (size_t)rows * (xu + 8);
+            const size_t slab = 2 * (size_t)rows * FR_SLAB_LD;
+            if (halves < 3 * FR_GROUP * slab) halves = 3 * FR_GROUP * slab;   // staging slots 1..3
+            halves += (16 + (size_t)(256 / rows) * rows * 4) / 2 + FR_GROUP * slab;   // FusedCfg::FIXED_HALVES
             lds = lds > halves * 2 ? lds : halves * 2;
         }
         f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = K0p / 32;
@@ -1700,21 +1827,24 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         f.tile_tab = w.tile_tab; f.tile_rows = w.tile_rows;
         f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
         f.want_grad = grad_aev ? 1 : 0;
-        ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_mlp_fused,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int64_t tiles = (n + FR_ROWS - 1) / FR_ROWS + S;
+        const void *kfn = rows == 64 ? (const void *)k_mlp_fused<2, 1> : (const void *)k_mlp_fused<1, 2>;
+        ANIHIP_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int64_t tiles = (n + rows - 1) / rows + S;
         f.tiles_total = (int)tiles;
         const int64_t grid = tiles * M;   // one workgroup per (member, tile) item; empty ones exit at once
         hipLaunchKernelGGL(k_tile_table, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, w.ctl, S, w.perm,
                            f.slab_mask, f.n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << f.n_slabs) - 1u), (int)tiles,
-                           w.tile_tab, w.tile_rows);
+                           rows, w.tile_tab, w.tile_rows);
         const char *trace_path = getenv("ANIHIP_FUSED_TRACE");   // development aid: per-item phase stamps
         const size_t trace_words = (size_t)16 * grid;
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipMalloc((void **)&f.trace, sizeof(unsigned long long) * trace_words));
             ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * trace_words));
         }
-        hipLaunchKernelGGL(k_mlp_fused, dim3((unsigned)grid), dim3(FR_THREADS), lds, stream, f);
+        if (rows == 64)
+            hipLaunchKernelGGL((k_mlp_fused<2, 1>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+        else
+            hipLaunchKernelGGL((k_mlp_fused<1, 2>), dim3((unsigned)grid), dim3(256), lds, stream, f);
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipStreamSynchronize(stream));
             std::vector<unsigned long long> host(trace_words);
