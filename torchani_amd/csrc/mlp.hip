@@ -1091,13 +1091,6 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     const int KS0 = g.n_slabs * 2;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-    // Two co-resident workgroups that start together would stay in lockstep (same phase at the same time:
-    // both on the matrix pipe, then both on the VALU).  The one placed second in the CU's LDS gets a higher
-    // issue priority: it wins the shared pipes, runs ahead, and the two settle into complementary phases.
-    if (NB == 2) {
-        const unsigned lds_base = __builtin_amdgcn_s_getreg((7 << 11) | 6);   // HW_REG_LDS_ALLOC.LDS_BASE
-        if (lds_base != 0u) __builtin_amdgcn_s_setprio(2);
-    }
     // the d0 scale of the layer-0 backward GEMM comes from the weight-norm bounds too (amax stage 5)
     if (blockIdx.x == 0 && tid < g.S) {
         float b = 0.f;
