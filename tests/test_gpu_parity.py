@@ -182,6 +182,9 @@ def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     report(f"mlp   {name:22s} {precision:13s} max|e_atom err| = {e_err:.2e}  |d e/d aev err| = {g_err:.2e} "
            f"(max {np.abs(ga).max():.2e})  members {m_err:.2e}")
     assert e_err < E_ATOM_TOL and m_err < E_ATOM_TOL
+    # regression guard well inside the parity gate: every arithmetic variant sits at the fp32 round-off level
+    # (<= 8e-8 Ha per atom, 3.3e-7 per member on these cases); a lost fp16 "lo" plane shows up as ~1e-6
+    assert e_err < 3e-7 and m_err < 1.5e-6
     assert g_err < 1e-6 + 1e-5 * np.abs(ga).max()
     pad = g["species"] < 0
     assert np.all(e.detach().cpu().numpy()[pad] == 0) and np.all(gr.cpu().numpy()[pad] == 0)

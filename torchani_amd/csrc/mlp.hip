@@ -1810,7 +1810,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             size_t halves = 2 * (size_t)rows * (fs.H2 + 8) + 2 * (size_t)rows * (xu + 8);
             const size_t slab = 2 * (size_t)rows * FR_SLAB_LD;
             if (halves < 3 * FR_GROUP * slab) halves = 3 * FR_GROUP * slab;   // staging slots 1..3
-            halves += (16 + (size_t)(256 / rows) * rows * 4) / 2 + FR_GROUP * slab;   // FusedCfg::FIXED_HALVES
+            halves += (rows == 64 ? FusedCfg<2, 1>::FIXED_BYTES : FusedCfg<1, 2>::FIXED_BYTES) / 2 + FR_GROUP * slab;   // = FIXED_HALVES
             lds = lds > halves * 2 ? lds : halves * 2;
         }
         f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = K0p / 32;
