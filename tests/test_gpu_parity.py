@@ -161,7 +161,7 @@ def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     aev = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), g["cell"], g["pbc"])
     ae, ga, me = oracle64.mlp(g["species"], aev, dims, flat, n_members=8, want_members=True)
     model = get_model(g["kind"], g["seed"], dev)
-    if precision == "f16x3-unfused":  # layer-by-layer f16x3 GEMMs instead of the fused hidden-stack kernel
+    if precision == "f16x3-unfused":  # layer-by-layer f16x3 GEMMs instead of the fused network kernel
         monkeypatch.setenv("ANIHIP_NO_FUSED_HIDDEN", "1")
     if precision == "f16x3-rows32":  # the 32-atom / two-workgroups-per-CU tiling of the fused kernel
         monkeypatch.setenv("ANIHIP_FUSED_ROWS", "32")

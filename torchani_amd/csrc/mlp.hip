@@ -1,21 +1,23 @@
-// Per-species MLP ensemble forward + input-gradient backward on fp32 MFMA (gfx950).
+// Per-species MLP ensemble forward + input-gradient backward on the gfx950 matrix cores.
 //
-// Structure (replaces mnp::run, csrc/mnp.cpp:32-232, and BmmEnsemble, nn/_infer.py:61-216):
-//   1. atoms of the shard are bucketed by species on the device (ballot ranks, no host sync, no
-//      nonzero()/index_select like nn/_containers.py:406-416);
-//   2. every layer is ONE grouped-GEMM launch covering all species and all ensemble members:
-//        layer 0 fwd : [n_s, K0] (AEV rows gathered through the bucket list) x [K0, M*H1]   (all M
-//                      members share the A operand -> one wide GEMM, cf. SURVEY section 7 hard parts)
-//        layer l fwd : M independent [n_s, Hl] x [Hl, Hl+1]
-//        backward    : same GEMMs against the pre-transposed weights, activation derivative fused;
-//                      the last one scatters d(energy)/d(aev) rows back to atom order.
-//      bias + CELU (forward) and CELU' (backward, evaluated from the stored activation) are fused in
-//      the epilogues, so each activation makes one HBM round trip.
-//   3. GEMM core: v_mfma_f32_32x32x2_f32 (exact fp32 products/accumulation, needed for the 1e-5 Ha
-//      budget), 128 x 128 x 16 tiles, 4 waves each owning a 32-row stripe x 4 column blocks, operands
-//      staged through LDS (A transposed on the way in so both fragment reads are conflict-free
-//      ds_read_b32), register-prefetched double buffering, XCD-aware tile order so the tiles sharing
-//      an A stripe run on one XCD's L2.
+// Replaces mnp::run (csrc/mnp.cpp:32-232) and BmmEnsemble (nn/_infer.py:61-216).  Common to all paths:
+// the atoms of the shard are bucketed by species on the device (ballot ranks, no host sync, no
+// nonzero()/index_select like nn/_containers.py:406-416).  Then, by network shape and precision:
+//
+//   A. split-fp16 ("f16x3", default), three hidden layers of width <= 256 (ANI-1x / ANI-2x):
+//        k_tile_table -> k_mlp_fused<RB,NB> -> k_fused_finish -> k_gemm_h2<EPI_SCATTER> / k_gemm_h<EPI_SCATTER>
+//      one fused kernel from the AEV rows to d E / d act0 (layer 0 only over the AEV slabs flagged non-zero,
+//      activations in LDS, weights streamed from L2 in MFMA fragment order), then the layer-0 backward
+//      GEMM over the flagged slabs.  See the comment block above k_mlp_fused.
+//   B. split-fp16, other shapes: every layer ONE grouped-GEMM launch over all species and members
+//      (k_gemm_h, 128 x 128 x 32 tiles; layer 0 = [n_s, K0] x [K0, M*H1] with rows gathered through the bucket
+//      list, hidden layers = M independent GEMMs, backward against pre-transposed weights, the last one
+//      scatters d E / d AEV rows back to atom order), bias + CELU / CELU' fused in the epilogues, k_head for
+//      the output layer and the backward seed.
+//   C. exact fp32 (precision = ANIHIP_MLP_FP32): the same grouped GEMMs on v_mfma_f32_32x32x2_f32 (k_gemm,
+//      128 x 128 x 16 tiles, A transposed on the way into LDS so both fragment reads are conflict-free
+//      ds_read_b32, register-prefetched double buffering).
+// All GEMM kernels use an XCD-aware bijective tile order (tiles sharing an A stripe land on one XCD's L2).
 #include <stdlib.h>
 
 #include "anihip_common.h"
