@@ -575,21 +575,27 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                             f2[u] = __builtin_amdgcn_exp2f(a.kA * d * d);
                             df2[u] = -2.0f * a.EtaA * d * f2[u];  // d/d rm
                         }
-                        // C0 = sum w f1 f2, Cth = sum w f1' f2, CR = sum w f1 f2': contract the shift index first
-                        float C0 = 0.f, Cth = 0.f, CR = 0.f;
+                        // C0 = sum w f1 f2, Cth = sum w f1' f2, CR = sum w f1 f2': contract the angle index z first
+                        // (P_u = sum_z w f1, Q_u = sum_z w f1'), then the few radial shifts of this lane
+                        float Pu[AQ], Qu[AQ];
+#pragma unroll
+                        for (int u = 0; u < AQ; ++u) { Pu[u] = 0.f; Qu[u] = 0.f; }
 #pragma unroll
                         for (int z = 0; z < NZ; ++z) {
                             const float f1 = quad_bcast_rt(f1q[z >> 2], z & 3);
                             const float df1 = quad_bcast_rt(df1q[z >> 2], z & 3);
-                            float A = 0.f, B = 0.f;
 #pragma unroll
                             for (int u = 0; u < AQ; ++u) {
-                                A += w[u][z] * f2[u];
-                                B += w[u][z] * df2[u];
+                                Pu[u] += w[u][z] * f1;
+                                Qu[u] += w[u][z] * df1;
                             }
-                            C0 += A * f1;
-                            Cth += A * df1;
-                            CR += B * f1;
+                        }
+                        float C0 = 0.f, Cth = 0.f, CR = 0.f;
+#pragma unroll
+                        for (int u = 0; u < AQ; ++u) {
+                            C0 += Pu[u] * f2[u];
+                            Cth += Qu[u] * f2[u];
+                            CR += Pu[u] * df2[u];
                         }
                         C0 = quad_sum(C0);
                         Cth = quad_sum(Cth);

@@ -366,8 +366,11 @@ class PackedNetworks:
             assert grad_aev.numel() == rows * self.aev_len
         member_e = torch.zeros((self.M, n), dtype=torch.float32, device=dev) if want_members else None
         L = _lib.lib()
-        for c0 in range(lo, hi, chunk):
-            c1 = min(hi, c0 + chunk)
+        # equal chunks (a short last chunk would leave most CUs idle in its tail)
+        nchunk = max(1, -(-(hi - lo) // chunk))
+        step = max(1, -(-(-(-(hi - lo) // nchunk)) // 256) * 256)
+        for c0 in range(lo, hi, step):
+            c1 = min(hi, c0 + step)
             ws = self.workspace(c1 - c0)
             _lib.check(L.anihip_mlp_forward_backward(
                 _stream(), C.byref(self.desc), n, c0, c1, _ptr(species), _row_ptr(aev, rows0, self.aev_len),
