@@ -1133,7 +1133,12 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         }
     };
 
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter();
+    if (g.trace && tid == 0) {
+        g.trace[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter();
+        // placement: HW_REG_HW_ID (cu / sh / se) and HW_REG_XCC_ID, for co-residency analysis
+        g.trace[(size_t)blockIdx.x * 16 + 14] = 1 + (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
+                                                     ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
+    }
     // ---- this workgroup's item (member-major order: at any time the chip works on one or two members,
     // whose weights stay resident in every XCD's L2): tile entry and atom rows are independent loads ----
     const int item = blockIdx.x;
