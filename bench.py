@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--no-dense-stage", action="store_true",
                     help="skip the extra (untimed-region) dense-MLP stage timing, e.g. under rocprofv3 so the "
                          "kernel statistics hold the product configuration only")
+    ap.add_argument("--dist-backend", default=None,
+                    help="development aid: torch.distributed backend override (gloo lets several ranks share one "
+                         "GPU to exercise the N>1 code path without RCCL); implies --share-gpu")
     ap.add_argument("--emulate-shard", default=None, metavar="RANK/WORLD",
                     help="development aid (N=1 only): time what rank RANK of WORLD does in a step, without "
                          "the all-reduces -- prints ms/step and exits")
@@ -129,7 +132,9 @@ def main():
     from torchani_amd.models import ANI2x
     from torchani_amd.parallel import init_from_env, shard_range
 
-    rank, world, local, group = init_from_env()
+    rank, world, local, group = init_from_env(args.dist_backend)
+    if args.dist_backend == "gloo":
+        local = 0   # every rank on GPU 0
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
