@@ -265,7 +265,11 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
             for (int t = 0; t < a.S; ++t) {
                 const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t), n = cA + cF;
                 float acc0 = 0.f, acc1 = 0.f;
-                if (n > 0) smask |= 1u << (t >> 1);
+                if (n == 0) {   // no neighbor of this species: zero block, no reduction
+                    if (rad_writer) out[t * 16 + rad_o] = 0.f;
+                    continue;
+                }
+                smask |= 1u << (t >> 1);
                 for (int b = 0; b < n; b += 8) {
                     const int idx = b + rp;
                     const bool v = idx < n;
