@@ -326,6 +326,32 @@ def test_autograd_path_equals_fused(dev, name):
     assert np.abs(e_nn.double().cpu().numpy() - g["energies_nn"]).max() < 1e-5 * max(1.0, np.sqrt(sp.shape[1]))
 
 
+@pytest.mark.parametrize("name", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x"])
+def test_hip_graph_replay(dev, name):
+    """energies_and_forces captured into a HIP graph: replays reproduce the eager result, also after the
+    coordinates change."""
+    g = load_golden(name)
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = get_model(g["kind"], g["seed"], dev, neighborlist=modes_for(g)[-1], row_capacity=256)
+    f = model.graphed(sp, x, cell, pbc)
+    out = f(x, cell)
+    torch.cuda.synchronize()
+    f.check()
+    assert np.abs(out.atomic_energies.cpu().numpy() - g["atomic_energies"]).max() < E_ATOM_TOL
+    assert np.abs(out.forces.cpu().numpy() - g["forces"]).max() < F_TOL
+    # other coordinates through the same graph == eager evaluation of those coordinates
+    x2 = x + 0.02 * torch.randn_like(x) * (sp >= 0).unsqueeze(-1)
+    ref = model.energies_and_forces(sp, x2, cell, pbc)
+    e_ref, f_ref = ref.energies.clone(), ref.forces.clone()
+    out2 = f(x2, cell)
+    torch.cuda.synchronize()
+    assert torch.allclose(out2.energies, e_ref, atol=1e-9, rtol=1e-12)
+    assert torch.allclose(out2.forces, f_ref, atol=2e-6)
+    # and back
+    out3 = f(x, cell)
+    assert np.abs(out3.forces.cpu().numpy() - g["forces"]).max() < F_TOL
+
+
 def test_api_details(dev):
     """Legacy tuple call, atomic / ensemble_values outputs, active members (nn/_containers.py:590-660)."""
     g = load_golden("simple2_ani2x")

@@ -62,4 +62,20 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+
+// Stream-ordered zero fill by a kernel instead of hipMemsetAsync: memset nodes of a captured HIP graph
+// faulted on replay (ROCm 7.0), a plain kernel node replays fine.
+static __global__ void k_zero_words(uint32_t *p, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline void zero_words_async(hipStream_t stream, void *p, size_t bytes)
+{
+    const size_t n = bytes / 4;   // (all callers pass multiples of 4)
+    if (n == 0) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t *)p, n);
+}
+
 }  // namespace anihip

@@ -1715,7 +1715,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
 
     // 1. bucket by species
-    ANIHIP_CHECK_HIP(hipMemsetAsync(w.ctl, 0, sizeof(int) * (CTL_WORDS + AMAX_WORDS), stream));
+    zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
     const unsigned nblk = (unsigned)((n + 255) / 256);
     const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
     hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl);
@@ -1938,7 +1938,7 @@ extern "C" int anihip_energy_reduce(void *stream_, int32_t n_mol, int32_t A, int
     hipStream_t stream = (hipStream_t)stream_;
     ANIHIP_REQUIRE(species && atomic_e && mol_e, "null pointer argument");
     ANIHIP_REQUIRE(n_mol >= 1 && A >= 1, "bad shape");
-    ANIHIP_CHECK_HIP(hipMemsetAsync(mol_e, 0, sizeof(double) * (size_t)n_mol, stream));
+    zero_words_async(stream, mol_e, sizeof(double) * (size_t)n_mol);
     int ny = (A + 256 * 16 - 1) / (256 * 16);
     if (ny < 1) ny = 1;
     if (ny > 1024) ny = 1024;

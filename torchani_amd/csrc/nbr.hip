@@ -621,14 +621,14 @@ extern "C" int anihip_nbr_build_cell(void *stream_, const anihip_aev_params *p, 
         hipLaunchKernelGGL(k_bbox, dim3(nblk > 1024 ? 1024 : nblk), dim3(256), 0, stream, w.desc, n,
                            species, coords);
     hipLaunchKernelGGL(k_grid_setup, dim3(1), dim3(64), 0, stream, w.desc, p->Rcr, max_cells, status);
-    ANIHIP_CHECK_HIP(hipMemsetAsync(w.cell_fill, 0, sizeof(int) * (size_t)(max_cells + 1), stream));
+    zero_words_async(stream, w.cell_fill, sizeof(int) * (size_t)(max_cells + 1));
     hipLaunchKernelGGL(k_bin_count, dim3(nblk), dim3(256), 0, stream, w.desc, n, species, coords, w.pos4,
                        w.cellid, w.cell_fill);
     hipLaunchKernelGGL(k_scan_local, dim3(cblk), dim3(1024), 0, stream, w.desc, w.cell_fill, w.cell_start,
                        w.scan_tmp);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, stream, w.desc, w.scan_tmp);
     hipLaunchKernelGGL(k_scan_add, dim3(cblk), dim3(1024), 0, stream, w.desc, w.cell_start, w.scan_tmp);
-    ANIHIP_CHECK_HIP(hipMemsetAsync(w.cell_fill, 0, sizeof(int) * (size_t)(max_cells + 1), stream));
+    zero_words_async(stream, w.cell_fill, sizeof(int) * (size_t)(max_cells + 1));
     hipLaunchKernelGGL(k_bin_fill, dim3(nblk), dim3(256), 0, stream, n, w.cellid, w.cell_start, w.cell_fill,
                        w.sorted_idx);
     hipLaunchKernelGGL(k_bin_sort_gather, dim3((unsigned)((max_cells + 255) / 256)), dim3(256), 0, stream,

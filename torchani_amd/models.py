@@ -107,10 +107,16 @@ class ANI(torch.nn.Module):
         if not coords.is_cuda:
             raise ValueError("torchani_amd's engine needs tensors on a ROCm device (no CPU fallback)")
         elem_idxs = self._elem_idxs(species)
-        C, A = elem_idxs.shape
-        n = C * A
         species32 = elem_idxs.to(torch.int32).contiguous()
         c32 = coords.detach().to(torch.float32).contiguous()
+        return self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, check_overflow, shard)
+
+    def _energies_and_forces_core(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces,
+                                  check_overflow, shard) -> EnergiesForces:
+        """The stream-ordered part of energies_and_forces (element indices int32, coords fp32 contiguous):
+        no host synchronisation unless check_overflow, so it can be captured into a HIP graph."""
+        C, A = species32.shape
+        n = C * A
         lo, hi = shard_range(n, group) if shard is None else shard_range(n, rank=shard[0], world=shard[1])
         aevc = self.aev_computer
         eng = aevc.engine()
@@ -143,10 +149,61 @@ class ANI(torch.nn.Module):
         aevc._last_neighbors = nbrs
         return EnergiesForces(energies, forces, atomic_e.view(C, A))
 
+    def graphed(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
+                pbc: tp.Optional[tp.Sequence[bool]] = None) -> "GraphedEnergiesForces":
+        """Capture energies_and_forces for this (species, shapes, pbc) into a HIP graph and return a callable
+        ``f(coords, cell=None) -> EnergiesForces`` that replays it: one graph launch instead of ~25 kernel
+        launches, for launch-bound sizes (batches of small molecules, MD of small systems)."""
+        return GraphedEnergiesForces(self, species, coords, cell, pbc)
+
     def load_reference_state_dict(self, state: tp.Mapping[str, tp.Any], strict: bool = False):
         """Load a (reference or seeded) state dict given as tensors or numpy arrays."""
         conv = {k: (torch.from_numpy(np.asarray(v)) if not isinstance(v, Tensor) else v) for k, v in state.items()}
         return self.load_state_dict(conv, strict=strict)
+
+
+class GraphedEnergiesForces:
+    """HIP-graph replay of ANI.energies_and_forces for fixed species / shapes (single process, no sharding).
+
+    The kernels are launched through the C ABI on torch's current stream, so ``torch.cuda.graph`` records
+    them like any other stream work; all buffers come from the graph's private memory pool.  Outputs are static
+    tensors overwritten by every call (clone them to keep a result).  Neighbor-row overflow cannot raise inside
+    a graph: call ``check()`` when convenient."""
+
+    def __init__(self, model: ANI, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
+                 pbc: tp.Optional[tp.Sequence[bool]] = None, warmup: int = 3) -> None:
+        if not coords.is_cuda:
+            raise ValueError("torchani_amd's engine needs tensors on a ROCm device (no CPU fallback)")
+        self.model = model
+        self.species32 = model._elem_idxs(species).to(torch.int32).contiguous()   # (validity check syncs once)
+        self.coords = coords.detach().to(torch.float32).contiguous().clone()
+        self.cell = None if cell is None else cell.detach().clone()
+        self.pbc = pbc
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):   # packs the weights, sizes the workspaces
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = self._run()
+
+    def _run(self) -> EnergiesForces:
+        return self.model._energies_and_forces_core(self.species32, self.coords, self.cell, self.pbc, None, True,
+                                                    False, None)
+
+    def __call__(self, coords: Tensor, cell: tp.Optional[Tensor] = None) -> EnergiesForces:
+        self.coords.copy_(coords)
+        if cell is not None:
+            assert self.cell is not None, "the graph was captured without a cell"
+            self.cell.copy_(cell)
+        self.graph.replay()
+        return self.out
+
+    def check(self) -> None:
+        """Raise if a neighbor row overflowed in the last replay (host sync)."""
+        self.model.aev_computer.last_neighbors().raise_on_overflow()
 
 
 def _assemble(kind: str, n_members: int, neighborlist: str, row_capacity: int,
