@@ -385,6 +385,50 @@ def test_api_details(dev):
         m2.energies_and_forces(torch.full_like(sp, 5), x)
 
 
+def test_ensemble_conveniences(dev):
+    """atomic_energies / energies_qbcs / atomic_stdev / members_forces / force_magnitudes / force_qbc /
+    model[i] / len(model) of the reference model (arch.py:133-135,245-264,385-585), against the
+    reference-generated member energies of the golden case and the golden ensemble forces."""
+    g = load_golden("simple2_ani2x")
+    sp, x, _, _ = to_dev(g, dev)
+    model = get_model("ani2x", g["seed"], dev)
+    me = g["member_atomic_energies"]                               # [8, C, A] network part
+    sae = np.asarray(model.energy_shifter.self_energies.cpu(), dtype=np.float64)
+    real = g["species"] >= 0
+    sae_mol = np.where(real, sae[np.clip(g["species"], 0, None)], 0.0).sum(1)
+    e_members = me.sum(-1) + sae_mol                               # [8, C]
+    assert len(model) == 8
+    # atomic energies (with self energies, like the reference's forward(atomic=True))
+    _, ea = model.atomic_energies((sp, x))
+    ref_atomic = np.where(real, me.mean(0) + sae[np.clip(g["species"], 0, None)], 0.0)
+    assert np.abs(ea.double().cpu().numpy() - ref_atomic).max() < 2e-5 * np.abs(ref_atomic).max()  # fp32 output
+    # qbc factors
+    _, e, qbc = model.energies_qbcs((sp, x))
+    n_at = real.sum(1)
+    assert np.abs(qbc.double().cpu().numpy() - e_members.std(0, ddof=1) / np.sqrt(n_at)).max() < 2e-4
+    assert np.abs(e.double().cpu().numpy() - e_members.mean(0)).max() < 2e-5 * np.abs(e_members).max()
+    # atomic stdev
+    _, _, sd = model.atomic_stdev((sp, x))
+    assert np.abs(sd.double().cpu().numpy() - np.where(real, me.std(0, ddof=1), 0.0)).max() < 1e-5
+    # members' forces: their mean is the ensemble force; members' energies match the reference
+    _, em, fm = model.members_forces((sp, x))
+    assert fm.shape == (8,) + tuple(x.shape) and em.shape == (8, sp.shape[0])
+    assert np.abs(fm.mean(0).cpu().numpy() - g["forces"]).max() < F_TOL
+    assert np.abs(em.cpu().numpy() - e_members).max() < 1e-5
+    assert list(model.neural_networks.active_members_idxs) == list(range(8))   # restored
+    # single-member view
+    m3 = model[3]
+    o3 = m3.energies_and_forces(sp, x)
+    assert torch.allclose(o3.forces, fm[3], atol=2e-6) and torch.allclose(o3.energies, em[3], atol=1e-9)
+    # force statistics
+    _, mags = model.force_magnitudes((sp, x))
+    assert torch.allclose(mags, fm.norm(dim=-1).mean(0), atol=1e-6)
+    _, mg, rstd, rrange = model.force_qbc((sp, x))
+    allm = fm.norm(dim=-1)
+    assert torch.allclose(rstd, (allm.std(0) + 1e-8) / (allm.mean(0) + 1e-8), atol=1e-5)
+    assert torch.all(rrange >= rstd)
+
+
 def _water_box(n_side, seed, dev, box_per=3.1):
     """n_side^3 waters on a jittered lattice, periodic cubic box (0.1 atoms / A^3)."""
     rs = np.random.RandomState(seed)

@@ -24,7 +24,7 @@ from .constants import GSAES_WB97X_631GD
 from .engine import energy_reduce
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import shard_range
-from .tuples import EnergiesForces, SpeciesEnergies
+from .tuples import AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
 from .weights import arch_spec, random_state_dict
 
 
@@ -148,6 +148,94 @@ class ANI(torch.nn.Module):
             nbrs.raise_on_overflow()
         aevc._last_neighbors = nbrs
         return EnergiesForces(energies, forces, atomic_e.view(C, A))
+
+    # ---- ensemble conveniences of the reference model (arch.py:133-135,245-264,385-585) ---------------
+    def set_active_members(self, idxs: tp.Sequence[int]) -> None:
+        self.neural_networks.set_active_members(list(idxs))
+
+    def __len__(self) -> int:
+        return self.neural_networks.get_active_members_num() if hasattr(self.neural_networks, "members") else 1
+
+    def __getitem__(self, idx: int) -> "ANI":
+        """Model with the idx-th ensemble member only (shares the parameters and the AEV computer)."""
+        nets = self.neural_networks
+        member = nets.members[idx] if hasattr(nets, "members") else nets
+        m = ANI(self.symbols, self.aev_computer, member, self.energy_shifter.self_energies.tolist(),
+                self.periodic_table_index)
+        m.energy_shifter._enabled = self.energy_shifter._enabled
+        return m.to(self.atomic_numbers.device)
+
+    def atomic_energies(self, species_coordinates, cell=None, pbc=None, charge: int = 0,
+                        ensemble_values: bool = False) -> SpeciesEnergies:
+        """Per-atom energies [C, A] (or [M, C, A]), arch.py:385-400."""
+        return self(species_coordinates, cell, pbc, charge, True, ensemble_values)
+
+    def energies_qbcs(self, species_coordinates, cell=None, pbc=None, unbiased: bool = True,
+                      charge: int = 0) -> SpeciesEnergiesQBC:
+        """Ensemble-mean energies and query-by-committee factors std_m(E) / sqrt(n_atoms), arch.py:438-486."""
+        elem_idxs, energies = self(species_coordinates, cell, pbc, charge, False, True)
+        if energies.shape[0] == 1:
+            qbc = torch.zeros_like(energies).squeeze(0)
+        else:
+            qbc = energies.std(0, unbiased=unbiased)
+        num_atoms = (elem_idxs >= 0).sum(dim=1, dtype=energies.dtype)
+        return SpeciesEnergiesQBC(elem_idxs, energies.mean(dim=0), qbc / num_atoms.sqrt())
+
+    def atomic_stdev(self, species_coordinates, cell=None, pbc=None, charge: int = 0,
+                     ensemble_values: bool = False, unbiased: bool = True) -> AtomicStdev:
+        """Standard deviation of the atomic energies across the ensemble, arch.py:488-516."""
+        elem_idxs, energies = self(species_coordinates, cell, pbc, charge, True, True)
+        if energies.shape[0] == 1:
+            stdev = torch.zeros_like(energies).squeeze(0)
+        else:
+            stdev = energies.std(0, unbiased=unbiased)
+        if not ensemble_values:
+            energies = energies.mean(0)
+        return AtomicStdev(elem_idxs, energies, stdev)
+
+    @torch.no_grad()
+    def members_forces(self, species_coordinates, cell=None, pbc=None, charge: int = 0) -> SpeciesForces:
+        """Energies [M, C] and forces [M, C, A, 3] of every active member (arch.py:403-436).  The engine
+        differentiates the ensemble mean in one pass; per-member forces take one fused pass per member."""
+        assert charge == 0, "Model only supports neutral molecules"
+        species, coords = species_coordinates
+        elem_idxs = self._elem_idxs(species)
+        nets = self.neural_networks
+        if not hasattr(nets, "members"):
+            out = self.energies_and_forces(species, coords, cell, pbc)
+            return SpeciesForces(elem_idxs, out.energies.unsqueeze(0), out.forces.unsqueeze(0))
+        active = list(nets.active_members_idxs)
+        es, fs = [], []
+        try:
+            for m in active:
+                nets.set_active_members([m])
+                out = self.energies_and_forces(species, coords, cell, pbc)
+                es.append(out.energies.clone())
+                fs.append(out.forces.clone())
+        finally:
+            nets.set_active_members(active)
+        return SpeciesForces(elem_idxs, torch.stack(es), torch.stack(fs))
+
+    def force_magnitudes(self, species_coordinates, cell=None, pbc=None,
+                         ensemble_values: bool = False) -> ForceMagnitudes:
+        """L2 norm of the members' atomic force vectors, averaged by default (arch.py:518-541)."""
+        species, _, mf = self.members_forces(species_coordinates, cell, pbc)
+        mags = mf.norm(dim=-1)
+        return ForceMagnitudes(species, mags if ensemble_values else mags.mean(0))
+
+    def force_qbc(self, species_coordinates, cell=None, pbc=None, ensemble_values: bool = False,
+                  unbiased: bool = True) -> ForceStdev:
+        """Mean force magnitudes with their relative std and range across the ensemble (arch.py:543-577)."""
+        species, mags = self.force_magnitudes(species_coordinates, cell, pbc, True)
+        eps = 1e-8
+        mean_mags = mags.mean(0)
+        if mags.shape[0] == 1:
+            rel_std = torch.zeros_like(mags).squeeze(0)
+            rel_range = torch.ones_like(mags).squeeze(0)
+        else:
+            rel_std = (mags.std(0, unbiased=unbiased) + eps) / (mean_mags + eps)
+            rel_range = ((mags.max(dim=0).values - mags.min(dim=0).values) + eps) / (mean_mags + eps)
+        return ForceStdev(species, mags if ensemble_values else mean_mags, rel_std, rel_range)
 
     def graphed(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
                 pbc: tp.Optional[tp.Sequence[bool]] = None) -> "GraphedEnergiesForces":

@@ -97,13 +97,15 @@ class _EngineContainer(torch.nn.Module):
         precision = getattr(self, "mlp_precision", None) or os.environ.get("TORCHANI_AMD_MLP_PRECISION", "f16x3")
         key = (device, precision, tuple(id(m) for m in members), tuple(p._version for p in params),
                tuple(p.data_ptr() for p in params))
-        if getattr(self, "_packed_key", None) != key:
+        cache = self.__dict__.setdefault("_packed_cache", {})   # several member subsets stay packed
+        if key not in cache:
             weights = [[[lin.weight for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
             biases = [[[lin.bias for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
             aev_len = weights[0][0][0].shape[1]
-            self._packed = PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, precision)
-            self._packed_key = key
-        return self._packed
+            if len(cache) >= 12:   # (parameters updated in place leave stale entries behind)
+                cache.clear()
+            cache[key] = PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, precision)
+        return cache[key]
 
     def _run(self, elem_idxs: Tensor, aevs: Tensor, atomic: bool, ensemble_values: bool) -> Tensor:
         if not aevs.is_cuda:

@@ -23,3 +23,35 @@ class EnergiesForces(tp.NamedTuple):
     energies: Tensor
     forces: Tensor
     atomic_energies: Tensor
+
+
+class SpeciesForces(tp.NamedTuple):
+    """members_forces: energies [M, C], forces [M, C, A, 3] (torchani/tuples.py)."""
+
+    species: Tensor
+    energies: Tensor
+    forces: Tensor
+
+
+class SpeciesEnergiesQBC(tp.NamedTuple):
+    species: Tensor
+    energies: Tensor
+    qbcs: Tensor
+
+
+class AtomicStdev(tp.NamedTuple):
+    species: Tensor
+    energies: Tensor
+    stdev_atomic_energies: Tensor
+
+
+class ForceMagnitudes(tp.NamedTuple):
+    species: Tensor
+    magnitudes: Tensor
+
+
+class ForceStdev(tp.NamedTuple):
+    species: Tensor
+    magnitudes: Tensor
+    relative_stdev: Tensor
+    relative_range: Tensor
