@@ -102,6 +102,19 @@ int anihip_nbr_build_cell(void *stream, const anihip_aev_params *p, int64_t n_at
                           size_t workspace_bytes, uint32_t *meta, float *ent, int64_t ent_capacity,
                           uint32_t *status);
 
+/* Rows from an externally supplied HALF neighbor list (LAMMPS / Amber style drivers, the reference's
+ * AEVComputer.compute_from_neighbors, aev/_computer.py:251-272, and cuaev::run_with_half_nbrlist ->
+ * postProcessExternalHalfNbrList, csrc/cuaev.cpp:205-224, csrc/aev.cu:1128-1208).  Pair p joins the
+ * flattened atom indices idx[p] and idx[n_pairs + p] (int64 like Neighbors.indices, neighbors.py:22-29) with
+ * diff[p] = r_idx0 - r_idx1 (+ image shift) as produced by narrow_down (neighbors.py:105-112).  Pairs longer
+ * than Rcr or touching a padding atom are dropped; every other pair is entered in both rows.  Rows come out
+ * in the same format (and a canonical order) as those of the builders above. */
+size_t anihip_nbr_half_workspace_bytes(int64_t n_central);
+int anihip_nbr_from_half(void *stream, const anihip_aev_params *p, int64_t n_atoms, const int32_t *species,
+                         int64_t n_pairs, const int64_t *idx, const float *diff, int64_t lo, int64_t hi,
+                         void *workspace, size_t workspace_bytes, uint32_t *meta, float *ent,
+                         int64_t ent_capacity, uint32_t *status);
+
 /* ---------------------------------------------------------------------------------------------
  * AEV forward / backward: replace cuRadialAEVs + cuAngularAEVs (csrc/aev.cu:768-834,323-472) and their
  * backward kernels (csrc/aev.cu:837-967,474-766).  aev / grad_aev are [n_atoms, L] row-major with

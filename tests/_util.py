@@ -11,7 +11,8 @@ from oracle import oracle as orc
 from torchani_amd.weights import random_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-GOLDEN_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+GOLDEN_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                      if not os.path.basename(p).startswith("nbrs_"))   # nbrs_*: reference neighbor lists
 
 
 def load_golden(name):

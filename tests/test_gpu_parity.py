@@ -150,6 +150,87 @@ def test_aev_forward_and_backward(dev, name):
         assert np.all(vjp.cpu().numpy()[g["species"] < 0] == 0)
 
 
+NBR_CASES = ["simple2_ani2x", "rand_batch_ani2x", "water_pbc_ani2x", "triclinic_pbc_ani2x", "small_ani2x",
+             "ch4_ani1x"]
+
+
+@pytest.mark.parametrize("name", NBR_CASES)
+def test_compute_from_external_half_list(dev, name):
+    """AEVComputer.compute_from_neighbors on the REFERENCE's own half neighbor list (tests/golden/nbrs_*.npz,
+    written by gen_golden_nbrs.py): same AEVs and coordinate gradients as the golden fixture, and the same
+    neighbor rows as the engine's own builder (up to the order inside a species group)."""
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.tuples import Neighbors
+    from torchani_amd.weights import arch_spec
+
+    g = load_golden(name)
+    nb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"nbrs_{name}.npz"))
+    _, consts, _ = arch_spec(g["kind"])
+    sp, x, cell, pbc = to_dev(g, dev)
+    C, A = g["species"].shape
+    idx = torch.from_numpy(nb["indices"]).to(dev)
+    diff = torch.from_numpy(nb["diff_vectors"]).to(dev)
+    aevc = AEVComputer(consts, row_capacity=256).to(dev)
+    w = torch.from_numpy(np.random.RandomState(g["seed"] + 1000).uniform(-1.0, 1.0, (C, A, consts.out_dim))
+                         .astype(np.float32)).to(dev)
+    xx = x.clone().requires_grad_(True)
+    aev = aevc.compute_from_neighbors(sp, xx, Neighbors(idx, diff.norm(dim=-1), diff))
+    (vjp,) = torch.autograd.grad((aev * w).sum(), xx)
+    torch.cuda.synchronize()
+    aevc.last_neighbors().raise_on_overflow()
+    got = aev.detach().cpu().numpy().reshape(C * A, -1)
+    err = np.abs(got[g["aev_rows"]] - g["aev"]).max()
+    verr = np.abs(vjp.cpu().numpy() - g["aev_vjp"]).max()
+    report(f"half  {name:22s} pairs={idx.shape[1]:5d} max|aev err| = {err:.2e}   vjp err = {verr:.2e}")
+    assert err < AEV_TOL
+    assert verr < 2e-5 * max(1.0, np.abs(g["aev_vjp"]).max())
+    assert np.all(got[g["species"].reshape(-1) < 0] == 0)
+    # rows: same neighbor multiset per atom as the engine's own list
+    meta_h, ent_h = unpack_rows(aevc.last_neighbors(), C * A)
+    pbc_t = None if pbc is None else torch.tensor(pbc)
+    aevc2 = AEVComputer(consts, neighborlist="all_pairs", row_capacity=256).to(dev)
+    aevc2(sp, x, cell, pbc_t)
+    meta_o, ent_o = unpack_rows(aevc2.last_neighbors(), C * A)
+    assert np.array_equal(meta_h[:, 1:], meta_o[:, 1:])   # counts per group and species
+    for i in range(C * A):
+        n = int(meta_h[i, 1] & 0xFFFF) + int(meta_h[i, 1] >> 16)
+        a = ent_h[meta_h[i, 0]:meta_h[i, 0] + n]
+        b = ent_o[meta_o[i, 0]:meta_o[i, 0] + n]
+        def canon(rows):   # order by (packed neighbor, displacement), compare displacements with a tolerance
+            k = np.lexsort((rows[:, 2], rows[:, 1], rows[:, 0], rows[:, 3].view(np.uint32)))
+            return rows[k]
+        a, b = canon(a), canon(b)
+        assert np.array_equal(a[:, 3].view(np.uint32), b[:, 3].view(np.uint32)), f"atom {i}"
+        assert np.abs(a[:, :3] - b[:, :3]).max(initial=0.0) < 5e-6, f"atom {i}"
+
+
+@pytest.mark.parametrize("name", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x"])
+def test_model_from_external_neighbors(dev, name):
+    """ANI.compute_from_neighbors / compute_from_external_neighbors (arch.py:171-206,354-381): energies and
+    autograd forces from the reference's half list equal the golden values; a Verlet-skin style list with
+    extra, longer pairs gives the same result."""
+    g = load_golden(name)
+    nb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"nbrs_{name}.npz"))
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = get_model(g["kind"], g["seed"], dev, row_capacity=256)
+    idx = torch.from_numpy(nb["indices"]).to(dev)
+    diff = torch.from_numpy(nb["diff_vectors"]).to(dev)
+    xx = x.clone().requires_grad_(True)
+    e = model.compute_from_neighbors(sp, xx, (idx, diff.norm(dim=-1), diff))
+    (gx,) = torch.autograd.grad(e.sum(), xx)
+    assert np.abs(e.detach().double().cpu().numpy() - g["energies"]).max() < 2e-6 * np.abs(g["energies"]).max()
+    assert np.abs(-gx.cpu().numpy() - g["forces"]).max() < F_TOL
+    # external list: cartesian shifts = diff - (r0 - r1); add far pairs that the screening must drop
+    flat = x.reshape(-1, 3)
+    shifts = diff - (flat[idx[0]] - flat[idx[1]])
+    n = flat.shape[0]
+    extra = torch.tensor([[0], [n - 1]], device=dev)
+    far = torch.tensor([[40.0, 0.0, 0.0]], device=dev) - (flat[0] - flat[n - 1]).unsqueeze(0)
+    idx2, shifts2 = torch.cat([idx, extra], 1), torch.cat([shifts, far], 0)
+    e2 = model.compute_from_external_neighbors(sp, x, idx2, shifts2)
+    assert torch.allclose(e2, e.detach(), rtol=0, atol=1e-5)
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "f16x3-rows32", "f16x3-unfused", "f16x3-bigtile", "fp32"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):

@@ -120,6 +120,10 @@ def lib() -> C.CDLL:
                                          sz, vp, vp, i64, vp]
     L.anihip_nbr_build_cell.argtypes = [vp, C.POINTER(AevParams), i64, vp, vp, vp, i32, i64, i64, i64, vp,
                                         sz, vp, vp, i64, vp]
+    L.anihip_nbr_half_workspace_bytes.restype = sz
+    L.anihip_nbr_half_workspace_bytes.argtypes = [i64]
+    L.anihip_nbr_from_half.argtypes = [vp, C.POINTER(AevParams), i64, vp, i64, vp, vp, i64, i64, vp, sz, vp, vp,
+                                       i64, vp]
     L.anihip_aev_forward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_aev_backward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_mlp_workspace_bytes.restype = sz
@@ -127,7 +131,7 @@ def lib() -> C.CDLL:
     L.anihip_mlp_forward_backward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, vp, sz, vp,
                                               vp, vp]
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
-    for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell",
+    for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half",
                  "anihip_aev_forward", "anihip_aev_backward", "anihip_mlp_forward_backward",
                  "anihip_energy_reduce"):
         getattr(L, name).restype = C.c_int
@@ -139,7 +143,8 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "anihip_last_error", "anihip_abi_version", "anihip_aev_table_pack", "anihip_nbr_workspace_bytes",
-    "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_aev_forward", "anihip_aev_backward",
+    "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_half_workspace_bytes", "anihip_nbr_from_half",
+    "anihip_aev_forward", "anihip_aev_backward",
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_energy_reduce",
 ]
 

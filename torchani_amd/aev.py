@@ -14,7 +14,7 @@ from torch import Tensor
 
 from .constants import AEVConstants, aev_constants_1x, aev_constants_2x
 from .engine import AevEngine, NeighborRows
-from .tuples import SpeciesAEV
+from .tuples import Neighbors, SpeciesAEV
 
 
 class _RadialTerms(torch.nn.Module):
@@ -61,6 +61,28 @@ class _AEVFunction(torch.autograd.Function):
         gc = ctx.eng.backward(ctx.species32, ctx.nbrs, g)
         C, A = ctx.species32.shape
         return gc.view(C, A, 3).to(ctx.in_dtype), None, None, None, None
+
+
+class _AEVFromRowsFunction(torch.autograd.Function):
+    """coords -> aevs for externally supplied neighbor rows (the role of cuaev::run_with_half_nbrlist,
+    csrc/cuaev.cpp:205-224): the gradient flows to coords through the analytic HIP backward, exactly like the
+    native operator, whose displacement inputs are not differentiated either."""
+
+    @staticmethod
+    def forward(ctx, coords: Tensor, species32: Tensor, nbrs: NeighborRows, computer: "AEVComputer") -> Tensor:
+        eng = computer.engine()
+        aev = eng.forward(species32, nbrs)
+        ctx.eng, ctx.nbrs, ctx.species32 = eng, nbrs, species32
+        ctx.in_dtype = coords.dtype
+        computer._last_neighbors = nbrs
+        return aev.view(species32.shape[0], species32.shape[1], eng.L).to(coords.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_aev: Tensor):
+        g = grad_aev.to(torch.float32).contiguous()
+        gc = ctx.eng.backward(ctx.species32, ctx.nbrs, g)
+        C, A = ctx.species32.shape
+        return gc.view(C, A, 3).to(ctx.in_dtype), None, None, None
 
 
 class AEVComputer(torch.nn.Module):
@@ -149,6 +171,19 @@ class AEVComputer(torch.nn.Module):
             self._engine = AevEngine(self.constants())
             self._engine_key = key
         return self._engine
+
+    def compute_from_neighbors(self, elem_idxs: Tensor, coords: Tensor, neighbors: Neighbors) -> Tensor:
+        """AEVs from the result of an external neighbor-list calculation (aev/_computer.py:251-272): any
+        3-tuple (indices [2, P], distances [P], diff_vectors [P, 3]) in the reference's convention."""
+        if not coords.is_cuda:
+            raise ValueError("torchani_amd's AEVComputer needs tensors on a ROCm device (no CPU fallback)")
+        if elem_idxs.dim() != 2 or coords.shape != (elem_idxs.shape[0], elem_idxs.shape[1], 3):
+            raise ValueError("expected elem_idxs [C, A] and coords [C, A, 3]")
+        indices, _, diff_vectors = neighbors
+        species32 = elem_idxs.to(torch.int32).contiguous()
+        nbrs = self.engine().rows_from_half(species32, indices.to(coords.device), diff_vectors.to(coords.device),
+                                            row_cap=self.row_capacity)
+        return _AEVFromRowsFunction.apply(coords, species32, nbrs, self)
 
     def set_strategy(self, strategy: str) -> None:
         if strategy not in ("hip", "auto"):

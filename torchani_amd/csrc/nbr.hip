@@ -549,6 +549,84 @@ __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_cell(
     }
 }
 
+// ---- rows from an external half neighbor list ---------------------------------------------------------
+// pass 1: every pair (a, b) with diff = r_a - r_b (+ image shift) appends {r_b - r_a, b} to row a and
+// {r_a - r_b, a} to row b (slot = atomic counter of the row; rows outside [lo, hi) are skipped)
+__global__ __launch_bounds__(256) void k_half_scatter(int64_t n_pairs, const int64_t *idx, const float *diff,
+                                                     const int32_t *species, int64_t n_atoms, float rcr2,
+                                                     int64_t lo, int64_t hi, int row_cap, int *count,
+                                                     float4 *ent, uint32_t *status)
+{
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n_pairs;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = idx[p], b = idx[n_pairs + p];
+        if (a < 0 || b < 0 || a >= n_atoms || b >= n_atoms) {
+            atomicOr(&status[0], ANIHIP_ST_ENTRY_OVERFLOW);
+            continue;
+        }
+        const int sa = species[a], sb = species[b];
+        if (sa < 0 || sb < 0) continue;   // dummy atoms (neighbors.py:72-83)
+        const float dx = diff[3 * p], dy = diff[3 * p + 1], dz = diff[3 * p + 2];
+        if (dx * dx + dy * dy + dz * dz > rcr2) continue;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int64_t c = side ? b : a, o = side ? a : b;
+            const int so = side ? sa : sb;
+            const float sg = side ? 1.0f : -1.0f;
+            if (c < lo || c >= hi) continue;
+            const int slot = atomicAdd(&count[c - lo], 1);
+            if (slot < row_cap)
+                ent[(size_t)(c - lo) * row_cap + slot] =
+                    make_float4(sg * dx, sg * dy, sg * dz, __uint_as_float(((uint32_t)o & IDX_MASK) | ((uint32_t)so << 28)));
+        }
+    }
+}
+
+// pass 2: one wave per central atom loads its unsorted row, puts it into a canonical order (by neighbor
+// index, then displacement: the atomic slots of pass 1 are not reproducible) and emits the sorted row
+__global__ __launch_bounds__(NBR_WPB * WAVE) void k_half_finish(int S, float rca2, int64_t lo, int64_t hi,
+                                                               const int32_t *species, int row_cap,
+                                                               const int *count, uint32_t *meta, float4 *ent,
+                                                               uint32_t *status)
+{
+    __shared__ float4 s_raw[NBR_WPB][MAXR];
+    __shared__ float4 s_hits[NBR_WPB][MAXR];
+    const int wib = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nw = (int64_t)gridDim.x * NBR_WPB;
+    for (int64_t i = lo + blockIdx.x * (int64_t)NBR_WPB + wib; i < hi; i += nw) {
+        uint32_t *meta_i = meta + (size_t)i * META_W;
+        const size_t row0 = (size_t)(i - lo) * row_cap;
+        if (lane == 0) meta_i[0] = (uint32_t)row0;
+        const int cnt = count[i - lo];
+        if (species[i] < 0 || cnt == 0) {
+            if (lane == 0) { meta_i[1] = 0; meta_i[2] = 0; meta_i[3] = 0; meta_i[4] = 0; meta_i[5] = 0; }
+            continue;
+        }
+        HitList h{s_hits[wib], min(cnt, min(row_cap, MAXR)), cnt > row_cap || cnt > MAXR};
+        float4 *raw = s_raw[wib];
+        for (int e = lane; e < h.n; e += WAVE) raw[e] = ent[row0 + e];
+        wave_sync();
+        auto less = [](const float4 &x, const float4 &y) {
+            const uint32_t jx = __float_as_uint(x.w) & IDX_MASK, jy = __float_as_uint(y.w) & IDX_MASK;
+            if (jx != jy) return jx < jy;
+            if (x.x != y.x) return x.x < y.x;
+            if (x.y != y.y) return x.y < y.y;
+            return x.z < y.z;
+        };
+        for (int e = lane; e < h.n; e += WAVE) {   // rank sort (rows are short; this path is not hot)
+            const float4 me = raw[e];
+            int rank = 0;
+            for (int o = 0; o < h.n; ++o) {
+                const float4 ot = raw[o];
+                rank += (less(ot, me) || (!less(me, ot) && o < e)) ? 1 : 0;
+            }
+            h.buf[rank] = me;
+        }
+        emit_row(h, S, rca2, row_cap, meta_i, ent + row0, status);
+        wave_sync();
+    }
+}
+
 }  // namespace anihip
 
 using namespace anihip;
@@ -637,6 +715,42 @@ extern "C" int anihip_nbr_build_cell(void *stream_, const anihip_aev_params *p, 
                        p->num_species, p->Rcr * p->Rcr, p->Rca * p->Rca, lo, hi, w.pos4, w.cellid,
                        w.cell_start, w.pos4s, (int)(row_cap > MAXR ? MAXR : row_cap), meta, (float4 *)ent,
                        status);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" size_t anihip_nbr_half_workspace_bytes(int64_t n_central)
+{
+    return align256(sizeof(int) * (size_t)(n_central > 0 ? n_central : 1));
+}
+
+extern "C" int anihip_nbr_from_half(void *stream_, const anihip_aev_params *p, int64_t n, const int32_t *species,
+                                    int64_t n_pairs, const int64_t *idx, const float *diff, int64_t lo,
+                                    int64_t hi, void *workspace, size_t workspace_bytes, uint32_t *meta,
+                                    float *ent, int64_t ent_capacity, uint32_t *status)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    ANIHIP_REQUIRE(p && species && workspace && meta && ent && status, "null pointer argument");
+    ANIHIP_REQUIRE(n_pairs == 0 || (idx && diff), "null neighbor list");
+    ANIHIP_REQUIRE(p->num_species >= 1 && p->num_species <= MAX_S - 1, "num_species must be 1..7");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n, "central range outside 0..n");
+    ANIHIP_REQUIRE(n < (int64_t)IDX_MASK, "too many atoms for 28-bit neighbor indices");
+    ANIHIP_REQUIRE(n_pairs >= 0, "negative pair count");
+    ANIHIP_REQUIRE(workspace_bytes >= anihip_nbr_half_workspace_bytes(hi - lo), "workspace too small");
+    if (hi == lo) return 0;
+    const int64_t row_cap = ent_capacity / (hi - lo);
+    ANIHIP_REQUIRE(row_cap >= 1 && (hi - lo) * row_cap < ((int64_t)1 << 32), "bad ent_capacity");
+    const int cap = (int)(row_cap > MAXR ? MAXR : row_cap);
+    int *count = (int *)workspace;
+    zero_words_async(stream, count, sizeof(int) * (size_t)(hi - lo));
+    if (n_pairs > 0) {
+        int64_t blocks = (n_pairs + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL(k_half_scatter, dim3((unsigned)blocks), dim3(256), 0, stream, n_pairs, idx, diff, species,
+                           n, p->Rcr * p->Rcr, lo, hi, cap, count, (float4 *)ent, status);
+    }
+    hipLaunchKernelGGL(k_half_finish, dim3(nbr_grid_blocks(hi - lo)), dim3(NBR_WPB * WAVE), 0, stream,
+                       p->num_species, p->Rca * p->Rca, lo, hi, species, cap, count, meta, (float4 *)ent, status);
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }

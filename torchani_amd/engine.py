@@ -144,6 +144,30 @@ class AevEngine:
             raise ValueError(f"unknown neighbor mode {mode!r}")
         return NeighborRows(meta, ent, status, row_cap, lo, hi)
 
+    def rows_from_half(self, species: Tensor, indices: Tensor, diff_vectors: Tensor, lo: int = 0,
+                       hi: tp.Optional[int] = None, row_cap: int = 128) -> NeighborRows:
+        """Neighbor rows from an external half list: indices [2, P] int64 (flattened atom indices),
+        diff_vectors [P, 3] = r[indices[0]] - r[indices[1]] (+ image shift), neighbors.py:22-29,105-112."""
+        _require_cuda(species, indices, diff_vectors)
+        assert species.dtype == torch.int32 and species.is_contiguous()
+        n = species.numel()
+        hi = n if hi is None else hi
+        dev = species.device
+        idx = indices.to(torch.int64).contiguous()
+        diff = diff_vectors.detach().to(torch.float32).contiguous()
+        assert idx.dim() == 2 and idx.shape[0] == 2 and diff.shape == (idx.shape[1], 3)
+        row_cap = int(min(max(row_cap, 1), _lib.MAX_RAD))
+        n_central = max(hi - lo, 0)
+        meta = torch.empty((n, _lib.META_WORDS), dtype=torch.int32, device=dev)
+        ent = torch.empty((max(n_central, 1) * row_cap, 4), dtype=torch.float32, device=dev)
+        status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+        L = _lib.lib()
+        ws = torch.empty(L.anihip_nbr_half_workspace_bytes(n_central), dtype=torch.uint8, device=dev)
+        _lib.check(L.anihip_nbr_from_half(
+            _stream(), C.byref(self.params), n, _ptr(species), idx.shape[1], _ptr(idx), _ptr(diff), lo, hi,
+            _ptr(ws), ws.numel(), _ptr(meta), _ptr(ent), n_central * row_cap, _ptr(status)))
+        return NeighborRows(meta, ent, status, row_cap, lo, hi)
+
     # ---- AEV ----------------------------------------------------------------------------------------
     @property
     def n_slabs(self) -> int:

@@ -149,6 +149,37 @@ class ANI(torch.nn.Module):
         aevc._last_neighbors = nbrs
         return EnergiesForces(energies, forces, atomic_e.view(C, A))
 
+    # ---- external neighbor lists (arch.py:151-206,354-381) ------------------------------------------
+    def compute_from_neighbors(self, elem_idxs: Tensor, coords: Tensor, neighbors, charge: int = 0,
+                               atomic: bool = False, ensemble_values: bool = False) -> Tensor:
+        """Energies from element indices and an already screened half neighbor list (any
+        (indices [2, P], distances [P], diff_vectors [P, 3]) tuple in the reference's convention).
+        Differentiable with respect to ``coords`` like the reference's native cuAEV entry point."""
+        assert charge == 0, "Model only supports neutral molecules"
+        energies = coords.new_zeros(elem_idxs.shape if atomic else elem_idxs.shape[:1])
+        if ensemble_values:
+            energies = energies.unsqueeze(0)
+        if self.potentials["nnp"]._enabled:
+            aevs = self.aev_computer.compute_from_neighbors(elem_idxs, coords, neighbors)
+            energies = energies + self.neural_networks(elem_idxs, aevs, atomic, ensemble_values)
+        if self.energy_shifter._enabled:
+            energies = energies + self.energy_shifter(elem_idxs, atomic=atomic)
+        return energies
+
+    def compute_from_external_neighbors(self, species: Tensor, coords: Tensor, neighbor_idxs: Tensor,
+                                        shifts: tp.Optional[Tensor], charge: int = 0, atomic: bool = False,
+                                        ensemble_values: bool = False) -> Tensor:
+        """Entry point for a neighbor list owned by an MD engine: ``neighbor_idxs`` [2, P] and cartesian image
+        ``shifts`` [P, 3] (or None); coords must be mapped to the central cell.  Pairs beyond the cutoff (Verlet
+        skin) and pairs with padding atoms are dropped by the ingestion kernel (arch.py:171-206)."""
+        elem_idxs = self._elem_idxs(species)
+        flat = coords.detach().reshape(-1, 3)
+        diff = flat.index_select(0, neighbor_idxs[0]) - flat.index_select(0, neighbor_idxs[1])
+        if shifts is not None:
+            diff = diff + shifts.to(diff.dtype)
+        neighbors = (neighbor_idxs, diff.norm(dim=-1), diff)
+        return self.compute_from_neighbors(elem_idxs, coords, neighbors, charge, atomic, ensemble_values)
+
     # ---- ensemble conveniences of the reference model (arch.py:133-135,245-264,385-585) ---------------
     def set_active_members(self, idxs: tp.Sequence[int]) -> None:
         self.neural_networks.set_active_members(list(idxs))

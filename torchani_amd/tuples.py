@@ -6,6 +6,15 @@ import typing as tp
 from torch import Tensor
 
 
+class Neighbors(tp.NamedTuple):
+    """Half neighbor list of the reference (neighbors.py:22-29): indices [2, P] into the flattened atoms,
+    distances [P], diff_vectors [P, 3] = r[indices[0]] - r[indices[1]] (+ image shift)."""
+
+    indices: Tensor
+    distances: Tensor
+    diff_vectors: Tensor
+
+
 class SpeciesAEV(tp.NamedTuple):
     species: Tensor
     aevs: Tensor
