@@ -65,6 +65,33 @@ def test_error_reporting_without_gpu(lib):
         _lib.check(rc)
 
 
+def test_argument_validation_without_gpu(lib):
+    """Entry points validate their arguments before touching the device: bad calls return non-zero and leave a
+    message (the reference raises from TORCH_CHECK, csrc/aev.cu:1693-1710)."""
+    from torchani_amd import _lib
+
+    p = _lib.AevParams(num_species=7, n_shf_r=16, n_shf_a=8, n_shf_z=4, Rcr=5.1, Rca=3.5, EtaR=19.7, EtaA=12.5,
+                       Zeta=14.1)
+    rc = lib.anihip_nbr_from_half(None, ctypes.byref(p), 10, None, 0, None, None, 0, 10, None, 0, None, None, 0, None)
+    assert rc != 0 and b"null pointer" in lib.anihip_last_error()
+    buf = (ctypes.c_char * 4096)()
+    addr = ctypes.addressof(buf)
+    rc = lib.anihip_nbr_from_half(None, ctypes.byref(p), 10, addr, 5, None, None, 0, 10, addr, 4096, addr, addr, 1280,
+                                  addr)
+    assert rc != 0 and b"null neighbor list" in lib.anihip_last_error()
+    rc = lib.anihip_nbr_from_half(None, ctypes.byref(p), 10, addr, 0, None, None, 4, 12, addr, 4096, addr, addr, 1280,
+                                  addr)
+    assert rc != 0 and b"central range" in lib.anihip_last_error()
+    assert lib.anihip_nbr_half_workspace_bytes(1000) >= 4000
+    rc = lib.anihip_aev_forward(None, ctypes.byref(p), None, 10, 0, 10, None, None, None, None, None, None)
+    assert rc != 0 and b"null pointer" in lib.anihip_last_error()
+    d = _lib.MlpDesc()
+    d.num_species, d.n_members, d.aev_len, d.celu_alpha, d.precision = 9, 8, 1008, 0.1, _lib.MLP_F16X3
+    rc = lib.anihip_mlp_forward_backward(None, ctypes.byref(d), 10, 0, 10, addr, addr, None, addr, 4096, addr, None,
+                                         None)
+    assert rc != 0 and b"num_species" in lib.anihip_last_error()
+
+
 def test_aev_table_pack_matches_constants(lib):
     from torchani_amd.constants import aev_constants_2x
     from torchani_amd.engine import AevEngine
