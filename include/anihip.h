@@ -115,6 +115,17 @@ int anihip_nbr_from_half(void *stream, const anihip_aev_params *p, int64_t n_ato
                          void *workspace, size_t workspace_bytes, uint32_t *meta, float *ent,
                          int64_t ent_capacity, uint32_t *status);
 
+/* Rows from an externally supplied FULL neighbor list in the LAMMPS convention (local + ghost atoms, every ghost
+ * with its own coordinates; cuaev::run_with_full_nbrlist -> postProcessNbrList2, csrc/cuaev.cpp:226-244,
+ * csrc/aev.cu:1048-1126, call site aev/_computer.py:420-438): listed atom ilist[g] has the numneigh[g] neighbors
+ * jlist[start[g] .. start[g] + numneigh[g]) (start = exclusive prefix sum of numneigh, int64).  Displacements are
+ * r_j - r_i from coords [n_atoms, 3]; neighbors beyond Rcr, padding atoms and j == i are dropped.  Atoms that are
+ * not listed get empty rows (zero AEVs).  ent_capacity = n_atoms * row capacity. */
+int anihip_nbr_from_full(void *stream, const anihip_aev_params *p, int64_t n_atoms, const int32_t *species,
+                         const float *coords, int64_t n_listed, const int32_t *ilist, const int32_t *numneigh,
+                         const int64_t *start, const int32_t *jlist, uint32_t *meta, float *ent,
+                         int64_t ent_capacity, uint32_t *status);
+
 /* ---------------------------------------------------------------------------------------------
  * AEV forward / backward: replace cuRadialAEVs + cuAngularAEVs (csrc/aev.cu:768-834,323-472) and their
  * backward kernels (csrc/aev.cu:837-967,474-766).  aev / grad_aev are [n_atoms, L] row-major with

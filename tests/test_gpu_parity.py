@@ -204,6 +204,49 @@ def test_compute_from_external_half_list(dev, name):
         assert np.abs(a[:, :3] - b[:, :3]).max(initial=0.0) < 5e-6, f"atom {i}"
 
 
+@pytest.mark.parametrize("name", ["small_ani2x", "ch4_ani1x"])
+def test_compute_from_full_neighbor_list(dev, name):
+    """LAMMPS-style full list (aev/_computer.py:420-438, tests/test_cuaev.py:740-790): built here from the
+    reference's half list of a non-periodic case (both directions, plus some pairs beyond the cutoff and a
+    self pair that must be screened out); atoms left out of ilist get zero rows."""
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.weights import arch_spec
+
+    g = load_golden(name)
+    nb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"nbrs_{name}.npz"))
+    _, consts, _ = arch_spec(g["kind"])
+    sp, x, _, _ = to_dev(g, dev)
+    n = sp.numel()
+    i0, i1 = nb["indices"]
+    adj = [[] for _ in range(n)]
+    for a, b in zip(i0, i1):
+        adj[a].append(int(b))
+        adj[b].append(int(a))
+    rs = np.random.RandomState(0)
+    for a in range(n):   # skin: extra candidates incl. the atom itself; the kernel screens by distance
+        adj[a] += [int(v) for v in rs.randint(0, n, 3)] + [a]
+        adj[a] = list(dict.fromkeys(adj[a]))
+    listed = [a for a in range(n) if a % 7 != 3]   # leave some atoms out
+    ilist = torch.tensor(listed, dtype=torch.int32, device=dev)
+    numneigh = torch.tensor([len(adj[a]) for a in listed], dtype=torch.int32, device=dev)
+    jlist = torch.tensor([j for a in listed for j in adj[a]], dtype=torch.int32, device=dev)
+    aevc = AEVComputer(consts, row_capacity=256).to(dev)
+    xx = x.clone().requires_grad_(True)
+    aev = aevc.compute_from_full_nbrlist(sp, xx, ilist, jlist, numneigh)
+    torch.cuda.synchronize()
+    aevc.last_neighbors().raise_on_overflow()
+    got = aev.detach().cpu().numpy().reshape(n, -1)
+    ref = np.zeros_like(got)
+    ref[g["aev_rows"]] = g["aev"]
+    mask = np.zeros(n, dtype=bool)
+    mask[listed] = True
+    rows = np.intersect1d(g["aev_rows"], np.asarray(listed))
+    assert np.abs(got[rows] - ref[rows]).max() < AEV_TOL
+    assert np.all(got[~mask] == 0)
+    (gx,) = torch.autograd.grad(aev.sum(), xx)
+    assert torch.isfinite(gx).all() and gx.abs().max() > 0
+
+
 @pytest.mark.parametrize("name", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x"])
 def test_model_from_external_neighbors(dev, name):
     """ANI.compute_from_neighbors / compute_from_external_neighbors (arch.py:171-206,354-381): energies and

@@ -124,6 +124,7 @@ def lib() -> C.CDLL:
     L.anihip_nbr_half_workspace_bytes.argtypes = [i64]
     L.anihip_nbr_from_half.argtypes = [vp, C.POINTER(AevParams), i64, vp, i64, vp, vp, i64, i64, vp, sz, vp, vp,
                                        i64, vp]
+    L.anihip_nbr_from_full.argtypes = [vp, C.POINTER(AevParams), i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]
     L.anihip_aev_forward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_aev_backward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_mlp_workspace_bytes.restype = sz
@@ -131,7 +132,7 @@ def lib() -> C.CDLL:
     L.anihip_mlp_forward_backward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, vp, sz, vp,
                                               vp, vp]
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
-    for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half",
+    for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half", "anihip_nbr_from_full",
                  "anihip_aev_forward", "anihip_aev_backward", "anihip_mlp_forward_backward",
                  "anihip_energy_reduce"):
         getattr(L, name).restype = C.c_int
@@ -143,7 +144,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "anihip_last_error", "anihip_abi_version", "anihip_aev_table_pack", "anihip_nbr_workspace_bytes",
-    "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_half_workspace_bytes", "anihip_nbr_from_half",
+    "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_half_workspace_bytes", "anihip_nbr_from_half", "anihip_nbr_from_full",
     "anihip_aev_forward", "anihip_aev_backward",
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_energy_reduce",
 ]

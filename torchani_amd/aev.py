@@ -185,6 +185,22 @@ class AEVComputer(torch.nn.Module):
                                             row_cap=self.row_capacity)
         return _AEVFromRowsFunction.apply(coords, species32, nbrs, self)
 
+    def compute_from_full_nbrlist(self, elem_idxs: Tensor, coords: Tensor, ilist_unique: Tensor, jlist: Tensor,
+                                  numneigh: Tensor) -> Tensor:
+        """AEVs from a LAMMPS-style full neighbor list over local + ghost atoms (the reference's
+        _compute_cuaev_with_full_nbrlist, aev/_computer.py:420-438): one molecule, atoms that are not in
+        ilist_unique get zero rows."""
+        if not coords.is_cuda:
+            raise ValueError("torchani_amd's AEVComputer needs tensors on a ROCm device (no CPU fallback)")
+        if coords.shape[0] != 1:
+            raise ValueError("the full-neighborlist entry point doesn't support batches")
+        species32 = elem_idxs.to(torch.int32).contiguous()
+        c32 = coords.detach().to(torch.float32).contiguous()
+        nbrs = self.engine().rows_from_full(species32, c32, ilist_unique, jlist, numneigh, row_cap=self.row_capacity)
+        return _AEVFromRowsFunction.apply(coords, species32, nbrs, self)
+
+    _compute_cuaev_with_full_nbrlist = compute_from_full_nbrlist   # the reference's (private) name
+
     def set_strategy(self, strategy: str) -> None:
         if strategy not in ("hip", "auto"):
             raise ValueError(f"Unsupported strategy {strategy!r}")

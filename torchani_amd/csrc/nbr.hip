@@ -549,6 +549,50 @@ __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_cell(
     }
 }
 
+// ---- rows from an external FULL neighbor list (LAMMPS style: local + ghost atoms with explicit coordinates) ----
+// one wave per listed atom gi: i = ilist[gi], neighbors jlist[start[gi] .. start[gi] + numneigh[gi]),
+// displacement r_j - r_i straight from the coordinates, cutoff screen, sorted row (postProcessNbrList2,
+// csrc/aev.cu:1048-1126)
+__global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_full(int S, float rcr2, float rca2, int64_t n_atoms,
+                                                            const int32_t *species, const float *coords,
+                                                            int64_t n_i, const int32_t *ilist,
+                                                            const int32_t *numneigh, const int64_t *start,
+                                                            const int32_t *jlist, int row_cap, uint32_t *meta,
+                                                            float4 *ent, uint32_t *status)
+{
+    __shared__ float4 s_hits[NBR_WPB][MAXR];
+    const int wib = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nw = (int64_t)gridDim.x * NBR_WPB;
+    for (int64_t gi = blockIdx.x * (int64_t)NBR_WPB + wib; gi < n_i; gi += nw) {
+        const int64_t i = ilist[gi];
+        if (i < 0 || i >= n_atoms) {
+            if (lane == 0) atomicOr(&status[0], ANIHIP_ST_ENTRY_OVERFLOW);
+            continue;
+        }
+        if (species[i] < 0) continue;   // (meta rows were zeroed)
+        uint32_t *meta_i = meta + (size_t)i * META_W;
+        const size_t row0 = (size_t)i * row_cap;
+        if (lane == 0) meta_i[0] = (uint32_t)row0;
+        const float xi = coords[3 * i], yi = coords[3 * i + 1], zi = coords[3 * i + 2];
+        const int jnum = numneigh[gi];
+        const int64_t st = start[gi];
+        HitList h{s_hits[wib], 0, false};
+        for (int j0 = 0; j0 < jnum; j0 += WAVE) {
+            const int jj = j0 + lane;
+            const bool v = jj < jnum;
+            const int64_t j = v ? (int64_t)jlist[st + jj] : i;
+            const bool okj = v && j >= 0 && j < n_atoms && j != i;
+            const int sj = okj ? species[j] : -1;
+            const int64_t jc = okj ? j : i;
+            const float dx = coords[3 * jc] - xi, dy = coords[3 * jc + 1] - yi, dz = coords[3 * jc + 2] - zi;
+            const bool hit = okj && sj >= 0 && dx * dx + dy * dy + dz * dz <= rcr2;
+            push_hits(h, hit, dx, dy, dz, __uint_as_float(((uint32_t)jc & IDX_MASK) | ((uint32_t)(sj < 0 ? 0 : sj) << 28)));
+        }
+        emit_row(h, S, rca2, row_cap, meta_i, ent + row0, status);
+        wave_sync();
+    }
+}
+
 // ---- rows from an external half neighbor list ---------------------------------------------------------
 // pass 1: every pair (a, b) with diff = r_a - r_b (+ image shift) appends {r_b - r_a, b} to row a and
 // {r_a - r_b, a} to row b (slot = atomic counter of the row; rows outside [lo, hi) are skipped)
@@ -751,6 +795,29 @@ extern "C" int anihip_nbr_from_half(void *stream_, const anihip_aev_params *p, i
     }
     hipLaunchKernelGGL(k_half_finish, dim3(nbr_grid_blocks(hi - lo)), dim3(NBR_WPB * WAVE), 0, stream,
                        p->num_species, p->Rca * p->Rca, lo, hi, species, cap, count, meta, (float4 *)ent, status);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int anihip_nbr_from_full(void *stream_, const anihip_aev_params *p, int64_t n, const int32_t *species,
+                                    const float *coords, int64_t n_i, const int32_t *ilist,
+                                    const int32_t *numneigh, const int64_t *start, const int32_t *jlist,
+                                    uint32_t *meta, float *ent, int64_t ent_capacity, uint32_t *status)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    ANIHIP_REQUIRE(p && species && coords && meta && ent && status, "null pointer argument");
+    ANIHIP_REQUIRE(n_i == 0 || (ilist && numneigh && start && jlist), "null neighbor list");
+    ANIHIP_REQUIRE(p->num_species >= 1 && p->num_species <= MAX_S - 1, "num_species must be 1..7");
+    ANIHIP_REQUIRE(n >= 1 && n < (int64_t)IDX_MASK, "bad atom count");
+    ANIHIP_REQUIRE(n_i >= 0 && n_i <= n, "more listed atoms than atoms");
+    const int64_t row_cap = ent_capacity / n;
+    ANIHIP_REQUIRE(row_cap >= 1 && n * row_cap < ((int64_t)1 << 32), "bad ent_capacity");
+    const int cap = (int)(row_cap > MAXR ? MAXR : row_cap);
+    zero_words_async(stream, meta, sizeof(uint32_t) * META_W * (size_t)n);   // atoms that are not listed: empty rows
+    if (n_i > 0)
+        hipLaunchKernelGGL(k_nbr_full, dim3(nbr_grid_blocks(n_i)), dim3(NBR_WPB * WAVE), 0, stream, p->num_species,
+                           p->Rcr * p->Rcr, p->Rca * p->Rca, n, species, coords, n_i, ilist, numneigh, start, jlist,
+                           cap, meta, (float4 *)ent, status);
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -168,6 +168,29 @@ class AevEngine:
             _ptr(ws), ws.numel(), _ptr(meta), _ptr(ent), n_central * row_cap, _ptr(status)))
         return NeighborRows(meta, ent, status, row_cap, lo, hi)
 
+    def rows_from_full(self, species: Tensor, coords: Tensor, ilist_unique: Tensor, jlist: Tensor,
+                       numneigh: Tensor, row_cap: int = 128) -> NeighborRows:
+        """Neighbor rows from a LAMMPS-style full list (aev/_computer.py:420-438): species [1, A] int32, coords
+        [1, A, 3] float32 incl. ghost atoms; listed atom ilist_unique[g] has numneigh[g] consecutive jlist
+        entries."""
+        _require_cuda(species, coords, ilist_unique, jlist, numneigh)
+        assert species.dtype == torch.int32 and coords.dtype == torch.float32
+        assert species.is_contiguous() and coords.is_contiguous()
+        n = species.numel()
+        dev = coords.device
+        il = ilist_unique.to(torch.int32).contiguous()
+        jl = jlist.to(torch.int32).contiguous()
+        nn = numneigh.to(torch.int32).contiguous()
+        start = (torch.cumsum(nn.to(torch.int64), 0) - nn.to(torch.int64)).contiguous()
+        row_cap = int(min(max(row_cap, 1), _lib.MAX_RAD))
+        meta = torch.empty((n, _lib.META_WORDS), dtype=torch.int32, device=dev)
+        ent = torch.empty((n * row_cap, 4), dtype=torch.float32, device=dev)
+        status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().anihip_nbr_from_full(
+            _stream(), C.byref(self.params), n, _ptr(species), _ptr(coords), il.numel(), _ptr(il), _ptr(nn),
+            _ptr(start), _ptr(jl), _ptr(meta), _ptr(ent), n * row_cap, _ptr(status)))
+        return NeighborRows(meta, ent, status, row_cap, 0, n)
+
     # ---- AEV ----------------------------------------------------------------------------------------
     @property
     def n_slabs(self) -> int:
