@@ -623,3 +623,40 @@ def test_solvated_box_46k(dev, oracle64):
     ea = np.abs(out.atomic_energies.cpu().numpy()[0, pick] - ae).max()
     report(f"box   water 46875 atoms pbc       max|e_atom err| (1500 sampled atoms) = {ea:.2e}")
     assert ea < E_ATOM_TOL
+
+
+def test_periodic_replica_and_symmetries_at_scale(dev):
+    """Size-independent properties at ~0.33 M atoms (no oracle at this size): a periodic box replicated 2 x 2 x 2
+    has the same per-atom energies and forces as the original box (every atom sees the same environment), the
+    net force vanishes, and a rigid translation / a permutation of the atoms change nothing."""
+    sp, x, cell = _water_box(24, 11, dev)            # 41 472 atoms
+    n = sp.shape[1]
+    model = get_model("ani2x", 5, dev, neighborlist="cell")
+    pbc = (True, True, True)
+    spt, xt, ct = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev), torch.from_numpy(cell).to(dev)
+    base = model.energies_and_forces(spt, xt, ct, pbc, check_overflow=True)
+    e0, f0, a0 = base.energies.clone(), base.forces.clone(), base.atomic_energies.clone()
+    # 2 x 2 x 2 replica: 331 776 atoms
+    L = np.diag(cell).astype(np.float32)
+    shifts = np.array([[i, j, k] for i in range(2) for j in range(2) for k in range(2)], dtype=np.float32) * L
+    x8 = (x[0][None, :, :] + shifts[:, None, :]).reshape(1, 8 * n, 3)
+    sp8 = np.tile(sp[0], 8).reshape(1, 8 * n)
+    big = model.energies_and_forces(torch.from_numpy(sp8).to(dev), torch.from_numpy(x8).to(dev),
+                                    torch.from_numpy(2 * cell).to(dev), pbc, check_overflow=True)
+    torch.cuda.synchronize()
+    a8 = big.atomic_energies.view(8, n)
+    f8 = big.forces.view(8, n, 3)
+    ea = (a8 - a0.view(1, n)).abs().max().item()
+    fe = (f8 - f0.view(1, n, 3)).abs().max().item()
+    report(f"box   water replica 8 x {n} atoms   max|e_atom - e_atom(box)| = {ea:.2e}  |F - F(box)| = {fe:.2e}")
+    assert ea < 2e-6 and fe < 2e-5      # (coordinates differ by fp32 rounding of the shifted positions)
+    assert abs(big.energies.item() - 8 * e0.item()) < 1e-6 * abs(8 * e0.item())
+    assert big.forces.sum(dim=1).abs().max() < 2e-2 and f0.sum(dim=1).abs().max() < 2e-3
+    # rigid translation (wraps atoms across the cell boundary) and a permutation of the atom order
+    t = torch.tensor([1.2345, -7.25, 40.0], device=dev)
+    tr = model.energies_and_forces(spt, xt + t, ct, pbc)
+    assert (tr.forces - f0).abs().max() < 2e-5 and abs(tr.energies.item() - e0.item()) < 1e-6 * abs(e0.item())
+    perm = torch.from_numpy(np.random.RandomState(1).permutation(n)).to(dev)
+    pm = model.energies_and_forces(spt[:, perm], xt[:, perm], ct, pbc)
+    assert (pm.forces - f0[:, perm]).abs().max() < 2e-5
+    assert (pm.atomic_energies - a0[:, perm]).abs().max() < 2e-6
