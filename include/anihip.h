@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 3
+#define ANIHIP_ABI_VERSION 4
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -46,6 +46,12 @@ extern "C" {
 #define ANIHIP_MAX_RAD 256 /* radial neighbors per atom */
 #define ANIHIP_META_WORDS 6 /* uint32 words of per-atom neighbor metadata */
 
+/* Cutoff envelopes: cutoffs.py:74-81 (CutoffCosine, 0.5 cos(pi r / Rc) + 0.5) and cutoffs.py:84-101 (CutoffSmooth,
+ * order 2, eps 1e-10: exp(1 - 1 / max(eps, 1 - (r/Rc)^2))); the reference's kernels select them with the
+ * use_cos_cutoff template flag (csrc/aev.cu:150-178). */
+#define ANIHIP_CUTOFF_COSINE 0
+#define ANIHIP_CUTOFF_SMOOTH 1
+
 /* Scalar AEV hyper-parameters; replaces the CuaevComputer constructor arguments
  * (csrc/cuaev.cpp:248: Rcr, Rca, EtaR, ShfR, EtaA, Zeta, ShfA, ShfZ, num_species, use_cos_cutoff). */
 typedef struct {
@@ -55,6 +61,7 @@ typedef struct {
     int32_t n_shf_z;
     float Rcr, Rca;
     float EtaR, EtaA, Zeta;
+    int32_t cutoff_kind; /* ANIHIP_CUTOFF_COSINE | ANIHIP_CUTOFF_SMOOTH (use_cos_cutoff = false) */
 } anihip_aev_params;
 
 /* Length in floats of the device constant table consumed by the AEV kernels, and a host-side packer:

@@ -41,6 +41,7 @@ typedef struct {
     double ShfR[ANI_MAX_SHIFTS];
     double ShfA[ANI_MAX_SHIFTS];
     double ShfZ[ANI_MAX_SHIFTS];
+    int cutoff_kind; /* 0 = CutoffCosine (cutoffs.py:71-81), 1 = CutoffSmooth order 2, eps 1e-10 (cutoffs.py:84-101) */
 } ani_params;
 
 /* Full (both directions) neighbor list, CSR by central atom over the flattened C*A atoms. */
@@ -381,12 +382,29 @@ void ani_oracle_nbrs_export(const ani_nbrs *nb, int64_t *start, int32_t *j, real
 /* ------------------------------------------------------------------------------------ */
 /* AEV terms */
 
-/* cutoffs.py:80-81 CutoffCosine: 0.5*cos(r*pi/Rc)+0.5 ; derivative for the backward */
-static inline real fcut(real r, double Rc) { return (real)(0.5 * cos((double)r * (M_PI / Rc)) + 0.5); }
-static inline real dfcut(real r, double Rc)
+/* cutoffs.py:80-81 CutoffCosine: 0.5*cos(r*pi/Rc)+0.5 ; cutoffs.py:98-100 CutoffSmooth (order 2, eps 1e-10):
+ * exp(1 - 1/max(eps, 1 - (r/Rc)^2)); derivatives for the backward (the smooth one as in csrc/aev.cu:165-178:
+ * zero where the clamp is active) */
+#define ANI_SMOOTH_EPS 1.0e-10
+static inline real fcut_k(int kind, real r, double Rc)
 {
+    if (kind == 1) {
+        const double q = (double)r / Rc, m = fmax(ANI_SMOOTH_EPS, 1.0 - q * q);
+        return (real)exp(1.0 - 1.0 / m);
+    }
+    return (real)(0.5 * cos((double)r * (M_PI / Rc)) + 0.5);
+}
+static inline real dfcut_k(int kind, real r, double Rc)
+{
+    if (kind == 1) {
+        const double q = (double)r / Rc, pw = q * q, m = fmax(ANI_SMOOTH_EPS, 1.0 - pw);
+        if (1.0 - pw - ANI_SMOOTH_EPS < 0.0) return (real)0;
+        return (real)(-2.0 * pw * exp(1.0 - 1.0 / m) / ((double)r * m * m));
+    }
     return (real)(-0.5 * (M_PI / Rc) * sin((double)r * (M_PI / Rc)));
 }
+#define fcut(r, Rc) fcut_k(p->cutoff_kind, (r), (Rc))
+#define dfcut(r, Rc) dfcut_k(p->cutoff_kind, (r), (Rc))
 
 /* aev/_computer.py:183-191 triu_index: row-major index into the upper triangle incl. diagonal */
 static inline int triu_index(int S, int a, int b)

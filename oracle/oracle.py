@@ -30,6 +30,7 @@ class Params(C.Structure):
         ("ShfR", C.c_double * MAX_SHIFTS),
         ("ShfA", C.c_double * MAX_SHIFTS),
         ("ShfZ", C.c_double * MAX_SHIFTS),
+        ("cutoff_kind", C.c_int),
     ]
 
 
@@ -54,28 +55,29 @@ def linspace(start: float, stop: float, steps: int) -> tp.List[float]:
     return [start + ((stop - start) / steps) * j for j in range(steps)]
 
 
-def params_2x() -> Params:
+def params_2x(cutoff_fn: str = "cosine") -> Params:
     # aev/_computer.py:550-600, aev/_terms.py:188-207,345-366
     import math
 
     return make_params(
         7, 5.1, 3.5, 19.7, 12.5, 14.1, linspace(0.8, 5.1, 16), linspace(0.8, 3.5, 8),
-        linspace(math.pi / 8, math.pi + math.pi / 8, 4),
+        linspace(math.pi / 8, math.pi + math.pi / 8, 4), cutoff_fn,
     )
 
 
-def params_1x() -> Params:
+def params_1x(cutoff_fn: str = "cosine") -> Params:
     # aev/_computer.py:498-548
     import math
 
     return make_params(
         4, 5.2, 3.5, 16.0, 8.0, 32.0, linspace(0.9, 5.2, 16), linspace(0.9, 3.5, 4),
-        linspace(math.pi / 16, math.pi + math.pi / 16, 8),
+        linspace(math.pi / 16, math.pi + math.pi / 16, 8), cutoff_fn,
     )
 
 
-def make_params(S, Rcr, Rca, EtaR, EtaA, Zeta, ShfR, ShfA, ShfZ) -> Params:
+def make_params(S, Rcr, Rca, EtaR, EtaA, Zeta, ShfR, ShfA, ShfZ, cutoff_fn: str = "cosine") -> Params:
     p = Params()
+    p.cutoff_kind = {"cosine": 0, "smooth": 1}[cutoff_fn]
     p.S, p.nR, p.nA, p.nZ = S, len(ShfR), len(ShfA), len(ShfZ)
     p.Rcr, p.Rca = float(Rcr), float(Rca)
     p.EtaR, p.EtaA, p.Zeta = f32_consts([EtaR, EtaA, Zeta])

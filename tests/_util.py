@@ -24,6 +24,7 @@ def load_golden(name):
     g["symbols"] = [str(s) for s in g["symbols"]]
     g.setdefault("cell", None)
     g.setdefault("pbc", None)
+    g["cutoff_fn"] = str(g["cutoff_fn"]) if "cutoff_fn" in g else "cosine"
     return g
 
 
@@ -43,5 +44,5 @@ def oracle_networks(kind, n_members, seed):
     return dims, flat, sae
 
 
-def oracle_params(kind):
-    return orc.params_2x() if kind == "ani2x" else orc.params_1x()
+def oracle_params(kind, cutoff_fn="cosine"):
+    return orc.params_2x(cutoff_fn) if kind == "ani2x" else orc.params_1x(cutoff_fn)

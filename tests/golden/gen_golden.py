@@ -47,13 +47,14 @@ from torchani.utils import SYMBOLS_1X, SYMBOLS_2X  # noqa: E402
 from torchani_amd.weights import random_state_dict  # noqa: E402
 
 RES = "/root/reference/tests/resources"
+CUTOFF_FN = "cosine"   # gen_golden_smooth.py switches this to "smooth" (cutoffs.py:84-101)
 ZNUM = {"H": 1, "C": 6, "N": 7, "O": 8, "S": 16, "F": 9, "Cl": 17}
 
 
 def build_reference(kind: str, seed: int, neighborlist: str = "all_pairs"):
     asm = Assembler()
     asm.set_symbols(SYMBOLS_2X if kind == "ani2x" else SYMBOLS_1X)
-    asm.set_global_cutoff_fn("cosine")
+    asm.set_global_cutoff_fn(CUTOFF_FN)
     asm.set_aev_computer(radial=kind, angular=kind, strategy="pyaev")
     asm.set_atomic_networks(ctor=kind)
     asm.set_neighborlist(neighborlist)
@@ -113,6 +114,8 @@ def run_case(name, kind, seed, znums, coords, cell=None, pbc=None, aev_rows=None
         out["pbc"] = np.asarray(pbc, dtype=bool)
     if members is not None:
         out["member_atomic_energies"] = members.detach().numpy()
+    if CUTOFF_FN != "cosine":
+        out["cutoff_fn"] = np.asarray(CUTOFF_FN)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: C={elem.shape[0]} A={elem.shape[1]} E_nn[0]={e_nn[0].item():+.9f} "

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.anihip_abi_version() == 3
+    assert lib.anihip_abi_version() == 4
 
 
 def test_struct_layouts_match_header(lib):
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header(lib):
     dereferences an anihip_mlp_desc)."""
     from torchani_amd import _lib
 
-    assert ctypes.sizeof(_lib.AevParams) == 9 * 4
+    assert ctypes.sizeof(_lib.AevParams) == 10 * 4
     assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 5 * 4 * 8 + 4 * 4 + 2 * 4 * 8 + 8
     assert ctypes.sizeof(_lib.MlpDesc) == 6 * 4 + 8 * ctypes.sizeof(_lib.SpeciesNet)
     assert _lib.MlpDesc.net.offset == 24
@@ -85,6 +85,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.anihip_nbr_half_workspace_bytes(1000) >= 4000
     rc = lib.anihip_aev_forward(None, ctypes.byref(p), None, 10, 0, 10, None, None, None, None, None, None)
     assert rc != 0 and b"null pointer" in lib.anihip_last_error()
+    p.cutoff_kind = 7   # neither ANIHIP_CUTOFF_COSINE nor ANIHIP_CUTOFF_SMOOTH
+    rc = lib.anihip_aev_forward(None, ctypes.byref(p), addr, 10, 0, 10, addr, addr, addr, addr, None, addr)
+    assert rc != 0 and b"cutoff_kind" in lib.anihip_last_error()
     d = _lib.MlpDesc()
     d.num_species, d.n_members, d.aev_len, d.celu_alpha, d.precision = 9, 8, 1008, 0.1, _lib.MLP_F16X3
     rc = lib.anihip_mlp_forward_backward(None, ctypes.byref(d), 10, 0, 10, addr, addr, None, addr, 4096, addr, None,
@@ -241,3 +244,19 @@ def test_shard_bounds():
             assert b[0] == 0 and b[-1] == n and all(0 <= b[i + 1] - b[i] <= n // w + 1 for i in range(w))
     assert shard_range(100, None) == (0, 100)
     assert shard_range(10, rank=1, world=4) == (3, 6)
+
+
+def test_cutoff_fn_selection():
+    """cutoff_fn travels AEVComputer -> AEVConstants -> anihip_aev_params.cutoff_kind; unknown names raise like the
+    reference's _parse_cutoff_fn (cutoffs.py:104-121)."""
+    from torchani_amd import _lib
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.engine import AevEngine
+
+    assert AEVComputer.like_2x().constants().cutoff_fn == "cosine"
+    aevc = AEVComputer.like_2x(cutoff_fn="smooth")
+    assert aevc.constants().cutoff_fn == "smooth"
+    assert AevEngine(aevc.constants()).params.cutoff_kind == _lib.CUTOFF_KINDS["smooth"] == 1
+    assert AevEngine(AEVComputer.like_1x().constants()).params.cutoff_kind == 0
+    with pytest.raises(ValueError, match="cutoff"):
+        AEVComputer.like_2x(cutoff_fn="biweight")

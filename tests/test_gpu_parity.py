@@ -80,7 +80,7 @@ def test_neighbor_rows_match_oracle(dev, oracle64, name):
     from torchani_amd.weights import arch_spec
 
     g = load_golden(name)
-    _, consts, _ = arch_spec(g["kind"])
+    consts = arch_spec(g["kind"])[1]._replace(cutoff_fn=g["cutoff_fn"])
     eng = AevEngine(consts)
     sp, x, cell, pbc = to_dev(g, dev)
     C, A = g["species"].shape
@@ -125,7 +125,7 @@ def test_aev_forward_and_backward(dev, name):
     from torchani_amd.weights import arch_spec
 
     g = load_golden(name)
-    _, consts, _ = arch_spec(g["kind"])
+    consts = arch_spec(g["kind"])[1]._replace(cutoff_fn=g["cutoff_fn"])
     sp, x, cell, pbc = to_dev(g, dev)
     C, A = g["species"].shape
     pbc_t = None if pbc is None else torch.tensor(pbc)
@@ -165,7 +165,7 @@ def test_compute_from_external_half_list(dev, name):
 
     g = load_golden(name)
     nb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"nbrs_{name}.npz"))
-    _, consts, _ = arch_spec(g["kind"])
+    consts = arch_spec(g["kind"])[1]._replace(cutoff_fn=g["cutoff_fn"])
     sp, x, cell, pbc = to_dev(g, dev)
     C, A = g["species"].shape
     idx = torch.from_numpy(nb["indices"]).to(dev)
@@ -214,7 +214,7 @@ def test_compute_from_full_neighbor_list(dev, name):
 
     g = load_golden(name)
     nb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"nbrs_{name}.npz"))
-    _, consts, _ = arch_spec(g["kind"])
+    consts = arch_spec(g["kind"])[1]._replace(cutoff_fn=g["cutoff_fn"])
     sp, x, _, _ = to_dev(g, dev)
     n = sp.numel()
     i0, i1 = nb["indices"]
@@ -255,7 +255,7 @@ def test_model_from_external_neighbors(dev, name):
     g = load_golden(name)
     nb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"nbrs_{name}.npz"))
     sp, x, cell, pbc = to_dev(g, dev)
-    model = get_model(g["kind"], g["seed"], dev, row_capacity=256)
+    model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"], row_capacity=256)
     idx = torch.from_numpy(nb["indices"]).to(dev)
     diff = torch.from_numpy(nb["diff_vectors"]).to(dev)
     xx = x.clone().requires_grad_(True)
@@ -281,10 +281,10 @@ def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     arithmetics (exact fp32 MFMA and the split-fp16 three-product MFMA)."""
     g = load_golden(name)
     dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
-    p = oracle_params(g["kind"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
     aev = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), g["cell"], g["pbc"])
     ae, ga, me = oracle64.mlp(g["species"], aev, dims, flat, n_members=8, want_members=True)
-    model = get_model(g["kind"], g["seed"], dev)
+    model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"])
     if precision == "f16x3-unfused":  # layer-by-layer f16x3 GEMMs instead of the fused network kernel
         monkeypatch.setenv("ANIHIP_NO_FUSED_HIDDEN", "1")
     if precision == "f16x3-rows32":  # the 32-atom / two-workgroups-per-CU tiling of the fused kernel
@@ -319,7 +319,7 @@ def test_energies_and_forces_fused(dev, name):
     g = load_golden(name)
     sp, x, cell, pbc = to_dev(g, dev)
     for mode in modes_for(g):
-        model = get_model(g["kind"], g["seed"], dev, neighborlist=mode, row_capacity=256)
+        model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"], neighborlist=mode, row_capacity=256)
         out = model.energies_and_forces(sp, x, cell, pbc, check_overflow=True)
         torch.cuda.synchronize()
         ea = np.abs(out.atomic_energies.cpu().numpy() - g["atomic_energies"]).max()
@@ -342,7 +342,7 @@ def test_energies_and_forces_slab_masks(dev, name, monkeypatch):
     monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
     g = load_golden(name)
     sp, x, cell, pbc = to_dev(g, dev)
-    model = get_model(g["kind"], g["seed"], dev, neighborlist=modes_for(g)[-1], row_capacity=256)
+    model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"], neighborlist=modes_for(g)[-1], row_capacity=256)
     out = model.energies_and_forces(sp, x, cell, pbc, check_overflow=True)
     torch.cuda.synchronize()
     ea = np.abs(out.atomic_energies.cpu().numpy() - g["atomic_energies"]).max()
@@ -361,8 +361,8 @@ def test_slab_masks_flag_exactly_the_nonzero_blocks(dev, name, monkeypatch):
     monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
     g = load_golden(name)
     sp, x, cell, pbc = to_dev(g, dev)
-    model = get_model(g["kind"], g["seed"], dev)
-    _, consts, _ = arch_spec(g["kind"])
+    model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"])
+    consts = arch_spec(g["kind"])[1]._replace(cutoff_fn=g["cutoff_fn"])
     eng = model.aev_computer.engine()
     sp32 = sp.to(torch.int32).contiguous().view(-1)
     n = sp32.numel()
@@ -412,7 +412,7 @@ def test_shards_add_up_to_the_whole(dev, name, world, monkeypatch):
     monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
     g = load_golden(name)
     sp, x, cell, pbc = to_dev(g, dev)
-    model = get_model(g["kind"], g["seed"], dev, neighborlist=modes_for(g)[-1], row_capacity=256)
+    model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"], neighborlist=modes_for(g)[-1], row_capacity=256)
     e = torch.zeros(sp.shape[0], dtype=torch.float64, device=dev)
     f = torch.zeros_like(x)
     ae = torch.zeros(sp.shape, dtype=torch.float32, device=dev)
@@ -435,7 +435,7 @@ def test_autograd_path_equals_fused(dev, name):
 
     g = load_golden(name)
     sp, x, cell, pbc = to_dev(g, dev)
-    model = get_model(g["kind"], g["seed"], dev)
+    model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"])
     pbc_t = None if pbc is None else torch.tensor(pbc)
     e, f = energies_and_forces(model, sp, x, cell, pbc_t)
     out = model.energies_and_forces(sp, x, cell, pbc)
@@ -456,7 +456,7 @@ def test_hip_graph_replay(dev, name):
     coordinates change."""
     g = load_golden(name)
     sp, x, cell, pbc = to_dev(g, dev)
-    model = get_model(g["kind"], g["seed"], dev, neighborlist=modes_for(g)[-1], row_capacity=256)
+    model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"], neighborlist=modes_for(g)[-1], row_capacity=256)
     f = model.graphed(sp, x, cell, pbc)
     out = f(x, cell)
     torch.cuda.synchronize()

@@ -16,7 +16,7 @@ def test_oracle_matches_reference(oracle64, name, cell_list):
     if cell_list and g["species"].shape[0] != 1:
         pytest.skip("cell list handles one system at a time (neighbors.py:373-381)")
     dims, flat, sae = oracle_networks(g["kind"], g["n_members"], g["seed"])
-    p = oracle_params(g["kind"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
     out = oracle64.energy_forces(p, g["species"], g["coords"].astype(np.float64), dims, flat,
                                  g["n_members"], sae=sae, cell=g["cell"], pbc=g["pbc"],
                                  cell_list=cell_list, want_aev=True)
@@ -42,7 +42,7 @@ def test_oracle_matches_reference(oracle64, name, cell_list):
 def test_member_energies(oracle64):
     g = load_golden("simple2_ani2x")
     dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
-    p = oracle_params(g["kind"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
     aev = oracle64.aev(p, g["species"], g["coords"].astype(np.float64))
     ae, _, me = oracle64.mlp(g["species"], aev, dims, flat, n_members=8, want_members=True)
     assert np.abs(me.reshape(8, *g["species"].shape) - g["member_atomic_energies"]).max() < 1e-12
@@ -72,7 +72,7 @@ def test_f32_port_close_to_f64(oracle64):
     o32 = Oracle("f32")
     g = load_golden("small_ani2x")
     dims, flat, sae = oracle_networks(g["kind"], g["n_members"], g["seed"])
-    p = oracle_params(g["kind"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
     out = o32.energy_forces(p, g["species"], g["coords"], dims, flat, 8, sae=sae)
     assert np.abs(out["atomic_energies"] - g["atomic_energies"]).max() < 2e-5
     assert np.abs(out["forces"] - g["forces"]).max() < 2e-5

@@ -27,7 +27,7 @@ MAX_RAD = 256
 TABLE_FLOATS = 80
 ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
 MLP_FP32, MLP_F16X3 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class AevParams(C.Structure):
@@ -41,7 +41,11 @@ class AevParams(C.Structure):
         ("EtaR", C.c_float),
         ("EtaA", C.c_float),
         ("Zeta", C.c_float),
+        ("cutoff_kind", C.c_int32),
     ]
+
+
+CUTOFF_KINDS = {"cosine": 0, "smooth": 1}  # ANIHIP_CUTOFF_*
 
 
 class SpeciesNet(C.Structure):

@@ -89,13 +89,17 @@ class AEVComputer(torch.nn.Module):
     """Atomic environment vectors [C, A, S*16 + S(S+1)/2*32] on the MI355X engine."""
 
     def __init__(self, consts: AEVConstants, neighborlist: str = "auto", row_capacity: int = 128,
-                 strategy: str = "hip", cutoff_fn: str = "cosine") -> None:
+                 strategy: str = "hip", cutoff_fn: tp.Optional[str] = None) -> None:
         super().__init__()
         if strategy not in ("hip", "auto"):
             # the reference raises ValueError for unknown strategies (aev/_computer.py:127-128)
             raise ValueError(f"Unsupported strategy {strategy!r}: torchani_amd only has the native 'hip' path")
-        if cutoff_fn != "cosine":
-            raise ValueError("only the cosine cutoff is implemented in the HIP kernels")
+        # one cutoff function for both terms like the native strategies of the reference (aev/_computer.py:91-98);
+        # an explicit argument overrides the one carried by the constants
+        self.cutoff_fn = consts.cutoff_fn if cutoff_fn is None else str(cutoff_fn)
+        if self.cutoff_fn not in ("cosine", "smooth"):
+            raise ValueError(f"Unsupported cutoff function {self.cutoff_fn!r}: the HIP kernels implement 'cosine' "
+                             "(CutoffCosine) and 'smooth' (CutoffSmooth, order 2)")
         modes = {"auto": "auto", "all_pairs": "batch", "cell_list": "cell", "batch": "batch", "cell": "cell",
                  "adaptive": "auto"}
         if neighborlist not in modes:
@@ -122,21 +126,21 @@ class AEVComputer(torch.nn.Module):
         return ret
 
     @classmethod
-    def like_2x(cls, num_species: int = 7, **kw) -> "AEVComputer":
-        return cls(aev_constants_2x(num_species), **kw)
+    def like_2x(cls, num_species: int = 7, cutoff_fn: str = "cosine", **kw) -> "AEVComputer":
+        return cls(aev_constants_2x(num_species, cutoff_fn), **kw)
 
     @classmethod
-    def like_1x(cls, num_species: int = 4, **kw) -> "AEVComputer":
-        return cls(aev_constants_1x(num_species), **kw)
+    def like_1x(cls, num_species: int = 4, cutoff_fn: str = "cosine", **kw) -> "AEVComputer":
+        return cls(aev_constants_1x(num_species, cutoff_fn), **kw)
 
     @classmethod
     def from_constants(cls, radial_cutoff: float, angular_cutoff: float, radial_eta: float,
                        radial_shifts: tp.Sequence[float], angular_eta: float, angular_zeta: float,
                        angular_shifts: tp.Sequence[float], sections: tp.Sequence[float], num_species: int,
-                       **kw) -> "AEVComputer":
+                       cutoff_fn: str = "cosine", **kw) -> "AEVComputer":
         # aev/_computer.py:602-666
         return cls(AEVConstants(num_species, radial_cutoff, angular_cutoff, radial_eta, tuple(radial_shifts),
-                                angular_eta, angular_zeta, tuple(angular_shifts), tuple(sections)), **kw)
+                                angular_eta, angular_zeta, tuple(angular_shifts), tuple(sections), cutoff_fn), **kw)
 
     # ---- derived sizes (aev/_computer.py:61-71,131-149) ----
     @property
@@ -161,12 +165,13 @@ class AEVComputer(torch.nn.Module):
         return AEVConstants(
             self.num_species, r.cutoff, a.cutoff, float(r.eta.item()),
             tuple(float(x) for x in r.shifts.tolist()), float(a.eta.item()), float(a.zeta.item()),
-            tuple(float(x) for x in a.shifts.tolist()), tuple(float(x) for x in a.sections.tolist()))
+            tuple(float(x) for x in a.shifts.tolist()), tuple(float(x) for x in a.sections.tolist()),
+            self.cutoff_fn)
 
     def engine(self) -> AevEngine:
         key = (self.radial.eta._version, self.radial.shifts._version, self.angular.eta._version,
                self.angular.zeta._version, self.angular.shifts._version, self.angular.sections._version,
-               self.radial.cutoff, self.angular.cutoff)
+               self.radial.cutoff, self.angular.cutoff, self.cutoff_fn)
         if self._engine is None or self._engine_key != key:
             self._engine = AevEngine(self.constants())
             self._engine_key = key

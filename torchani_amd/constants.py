@@ -42,6 +42,7 @@ class AEVConstants(tp.NamedTuple):
     Zeta: float
     ShfA: tp.Tuple[float, ...]
     ShfZ: tp.Tuple[float, ...]
+    cutoff_fn: str = "cosine"  # "cosine" (cutoffs.py:74-81) | "smooth" (CutoffSmooth order 2, cutoffs.py:84-101)
 
     @property
     def radial_len(self) -> int:
@@ -60,19 +61,19 @@ class AEVConstants(tp.NamedTuple):
         return self.radial_len + self.angular_len
 
 
-def aev_constants_2x(num_species: int = 7) -> AEVConstants:
+def aev_constants_2x(num_species: int = 7, cutoff_fn: str = "cosine") -> AEVConstants:
     # aev/_computer.py:550-600; aev/_terms.py:188-207 (radial), :345-366 (angular)
     return AEVConstants(
         num_species, 5.1, 3.5, 19.7, linspace(0.8, 5.1, 16), 12.5, 14.1, linspace(0.8, 3.5, 8),
-        linspace(math.pi / 8, math.pi + math.pi / 8, 4),
+        linspace(math.pi / 8, math.pi + math.pi / 8, 4), cutoff_fn,
     )
 
 
-def aev_constants_1x(num_species: int = 4) -> AEVConstants:
+def aev_constants_1x(num_species: int = 4, cutoff_fn: str = "cosine") -> AEVConstants:
     # aev/_computer.py:498-548
     return AEVConstants(
         num_species, 5.2, 3.5, 16.0, linspace(0.9, 5.2, 16), 8.0, 32.0, linspace(0.9, 3.5, 4),
-        linspace(math.pi / 16, math.pi + math.pi / 16, 8),
+        linspace(math.pi / 16, math.pi + math.pi / 16, 8), cutoff_fn,
     )
 
 

@@ -36,7 +36,21 @@ constexpr float PI_F = 3.14159265358979323846f;
 struct AevArgs {
     int S, NR, L, radlen;
     float Rcr, Rca, kR, kA, EtaR, EtaA, Zeta;
+    int smooth;  // cutoff_kind: 0 = CutoffCosine, 1 = CutoffSmooth (order 2, eps 1e-10)
 };
+
+// CutoffSmooth (cutoffs.py:84-101, csrc/aev.cu:150-178): fc = exp(1 - 1/max(eps, 1 - (r/Rc)^2)); 1 - q^2 is formed
+// as (1-q)(1+q) to keep its relative error at one ulp close to the cutoff.  Returns {fc, dfc/dr}.
+#define SMOOTH_EPS 1e-10f
+__device__ __forceinline__ float2 smooth_cutoff(float r, float inv_rc)
+{
+    const float q = r * inv_rc;
+    const float m1 = (1.0f - q) * (1.0f + q);
+    const float im = 1.0f / fmaxf(SMOOTH_EPS, m1);
+    const float f = __builtin_amdgcn_exp2f((1.0f - im) * LOG2E);
+    const float df = m1 - SMOOTH_EPS >= 0.0f ? -2.0f * r * inv_rc * inv_rc * f * im * im : 0.0f;
+    return make_float2(f, df);
+}
 
 template <int Q>
 __device__ __forceinline__ float quad_bcast(float v)
@@ -228,11 +242,13 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
                 if (c0 >= 2 * WAVE && e < nR) d = ent[start + e];
                 if (e < nR) {
                     const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
-                    rad[e] = make_float2(r, 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f);
+                    rad[e] = make_float2(r, a.smooth ? 0.25f * smooth_cutoff(r, 1.0f / a.Rcr).x
+                                                     : 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f);
                     if (e < nA) {
                         const float inv = 1.0f / r;
                         ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, r);
-                        afc[e] = 0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f;
+                        afc[e] = a.smooth ? smooth_cutoff(r, 1.0f / a.Rca).x
+                                          : 0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f;
                     }
                 }
             }
@@ -472,8 +488,14 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                 const float ux = d.x * inv, uy = d.y * inv, uz = d.z * inv;
                 const uint32_t wbits = __float_as_uint(d.w);
                 const int t = ve ? (int)(wbits >> 28) : 0;
-                const float fcr = 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f;       // 0.25 fc
-                const float dfcr = -0.125f * pi_rcr * __builtin_amdgcn_sinf(r * rev_rcr);    // 0.25 fc'
+                float fcr, dfcr;  // 0.25 fc, 0.25 fc' of the radial cutoff
+                if (a.smooth) {
+                    const float2 cr = smooth_cutoff(r, 1.0f / a.Rcr);
+                    fcr = 0.25f * cr.x; dfcr = 0.25f * cr.y;
+                } else {
+                    fcr = 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f;
+                    dfcr = -0.125f * pi_rcr * __builtin_amdgcn_sinf(r * rev_rcr);
+                }
                 float dR = 0.f;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
@@ -487,9 +509,10 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                 if (ve) {
                     if (e < nA) {
                         nb[e] = make_float4(ux, uy, uz, r);
-                        afc[e] = make_float4(0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f,
-                                             -0.5f * pi_rca * __builtin_amdgcn_sinf(r * rev_rca), inv,
-                                             __uint_as_float(wbits & IDX_MASK));
+                        const float2 ca = a.smooth ? smooth_cutoff(r, 1.0f / a.Rca)
+                                                   : make_float2(0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f,
+                                                                 -0.5f * pi_rca * __builtin_amdgcn_sinf(r * rev_rca));
+                        afc[e] = make_float4(ca.x, ca.y, inv, __uint_as_float(wbits & IDX_MASK));
                         g4[e] = make_float4(Gx, Gy, Gz, 0.f);
                     } else {
                         float *gc = grad_coords + 3 * (size_t)(wbits & IDX_MASK);
@@ -691,6 +714,9 @@ static int make_args(const anihip_aev_params *p, AevArgs *a)
     a->EtaR = p->EtaR; a->EtaA = p->EtaA; a->Zeta = p->Zeta;
     a->kR = -p->EtaR * LOG2E;
     a->kA = -p->EtaA * LOG2E;
+    ANIHIP_REQUIRE(p->cutoff_kind == ANIHIP_CUTOFF_COSINE || p->cutoff_kind == ANIHIP_CUTOFF_SMOOTH,
+                   "cutoff_kind must be ANIHIP_CUTOFF_COSINE or ANIHIP_CUTOFF_SMOOTH");
+    a->smooth = p->cutoff_kind == ANIHIP_CUTOFF_SMOOTH;
     return 0;
 }
 

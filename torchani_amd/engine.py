@@ -70,6 +70,10 @@ class AevEngine:
         p.n_shf_r, p.n_shf_a, p.n_shf_z = len(consts.ShfR), len(consts.ShfA), len(consts.ShfZ)
         p.Rcr, p.Rca = consts.Rcr, consts.Rca
         p.EtaR, p.EtaA, p.Zeta = consts.EtaR, consts.EtaA, consts.Zeta
+        if consts.cutoff_fn not in _lib.CUTOFF_KINDS:
+            raise ValueError(f"Unsupported cutoff function {consts.cutoff_fn!r}: the HIP kernels have "
+                             f"{sorted(_lib.CUTOFF_KINDS)}")
+        p.cutoff_kind = _lib.CUTOFF_KINDS[consts.cutoff_fn]
         if p.n_shf_r != 16 or (p.n_shf_a, p.n_shf_z) not in ((8, 4), (4, 8)) or not 1 <= p.num_species <= 7:
             raise ValueError(
                 "HIP AEV kernels support 16 radial shifts, 8x4 (ANI-2x) or 4x8 (ANI-1x) angular grids and "

@@ -326,9 +326,9 @@ class GraphedEnergiesForces:
 
 
 def _assemble(kind: str, n_members: int, neighborlist: str, row_capacity: int,
-              periodic_table_index: bool) -> ANI:
+              periodic_table_index: bool, cutoff_fn: str = "cosine") -> ANI:
     symbols, consts, hidden = arch_spec(kind)
-    aevc = AEVComputer(consts, neighborlist=neighborlist, row_capacity=row_capacity)
+    aevc = AEVComputer(consts, neighborlist=neighborlist, row_capacity=row_capacity, cutoff_fn=cutoff_fn)
     members = [ANINetworks.build(symbols, consts.out_dim, hidden) for _ in range(n_members)]
     nets: torch.nn.Module = Ensemble(members) if n_members > 1 else members[0]
     sae = [GSAES_WB97X_631GD[s] for s in symbols]
@@ -336,8 +336,8 @@ def _assemble(kind: str, n_members: int, neighborlist: str, row_capacity: int,
 
 
 def _builtin(kind: str, state_dict, seed, n_members, device, neighborlist, row_capacity,
-             periodic_table_index) -> ANI:
-    model = _assemble(kind, n_members, neighborlist, row_capacity, periodic_table_index)
+             periodic_table_index, cutoff_fn: str = "cosine") -> ANI:
+    model = _assemble(kind, n_members, neighborlist, row_capacity, periodic_table_index, cutoff_fn)
     if state_dict is None:
         # the published parameters are a download in the reference (arch.py:1185-1220); offline we use
         # the same architecture with seeded random parameters
@@ -350,14 +350,17 @@ def _builtin(kind: str, state_dict, seed, n_members, device, neighborlist, row_c
 
 
 def ANI2x(state_dict=None, seed: tp.Optional[int] = None, n_members: int = 8, device=None,
-          neighborlist: str = "auto", row_capacity: int = 128, periodic_table_index: bool = True) -> ANI:
-    """ANI-2x architecture: H C N O S F Cl, 1008-dim AEV, 8-member ensemble (models.py:185-196)."""
+          neighborlist: str = "auto", row_capacity: int = 128, periodic_table_index: bool = True,
+          cutoff_fn: str = "cosine") -> ANI:
+    """ANI-2x architecture: H C N O S F Cl, 1008-dim AEV, 8-member ensemble (models.py:185-196).
+    cutoff_fn="smooth" gives the envelope of the reference's newer models (arch.py:1006, CutoffSmooth)."""
     return _builtin("ani2x", state_dict, seed, n_members, device, neighborlist, row_capacity,
-                    periodic_table_index)
+                    periodic_table_index, cutoff_fn)
 
 
 def ANI1x(state_dict=None, seed: tp.Optional[int] = None, n_members: int = 8, device=None,
-          neighborlist: str = "auto", row_capacity: int = 128, periodic_table_index: bool = True) -> ANI:
+          neighborlist: str = "auto", row_capacity: int = 128, periodic_table_index: bool = True,
+          cutoff_fn: str = "cosine") -> ANI:
     """ANI-1x architecture: H C N O, 384-dim AEV, 8-member ensemble (models.py:112-119)."""
     return _builtin("ani1x", state_dict, seed, n_members, device, neighborlist, row_capacity,
-                    periodic_table_index)
+                    periodic_table_index, cutoff_fn)
