@@ -702,6 +702,94 @@ void ani_oracle_mlp(int64_t n, int S, int M, int nl, const int *dims, const real
 }
 
 /*
+ * Gradients of  Loss = sum_i g_atom[i] * atomic_e[i]  (atomic_e = ensemble mean, as in ani_oracle_mlp) with respect
+ * to every weight and bias: what autograd produces for the reference's containers when a loss on the energies is
+ * back-propagated (training loop of tools/training-aev-benchmark.py:120-135; nn/_core.py:146-149,
+ * nn/_containers.py:377-421,608-636).  grad_params has the layout of params and is overwritten.
+ * One (member, species) network per task, so no two threads touch the same gradient block.
+ */
+void ani_oracle_mlp_weight_grads(int64_t n, int S, int M, int nl, const int *dims, const real *params,
+                                 real celu_alpha, const int32_t *species, const real *aev,
+                                 const real *g_atom, real *grad_params)
+{
+    const int L = dims[0];
+    size_t *off = (size_t *)malloc(sizeof(size_t) * (size_t)(M * S + 1));
+    off[0] = 0;
+    int maxw = 0;
+    for (int m = 0; m < M; ++m)
+        for (int s = 0; s < S; ++s) {
+            off[m * S + s + 1] = off[m * S + s] + net_param_count(dims + s * (nl + 1), nl);
+            for (int l = 0; l <= nl; ++l)
+                if (dims[s * (nl + 1) + l] > maxw) maxw = dims[s * (nl + 1) + l];
+        }
+    for (size_t q = 0; q < off[M * S]; ++q) grad_params[q] = 0;
+#pragma omp parallel
+    {
+        real *act = (real *)malloc(sizeof(real) * (size_t)(nl + 1) * maxw);
+        real *dact = (real *)malloc(sizeof(real) * (size_t)(nl + 1) * maxw);
+        real *ga = (real *)malloc(sizeof(real) * (size_t)maxw);
+        real *gb = (real *)malloc(sizeof(real) * (size_t)maxw);
+#pragma omp for schedule(dynamic, 1)
+        for (int task = 0; task < M * S; ++task) {
+            const int s = task % S;
+            const int *d = dims + s * (nl + 1);
+            const real *P = params + off[task];
+            real *G = grad_params + off[task];
+            for (int64_t i = 0; i < n; ++i) {
+                if (species[i] != s) continue;
+                /* forward, keeping the input of every layer (act[l]) and celu' of its output (dact[l+1]) */
+                const real *x = aev + (size_t)i * L;
+                for (int k = 0; k < L; ++k) act[k] = x[k];
+                const real *Pl = P;
+                for (int l = 0; l < nl; ++l) {
+                    const int in = d[l], out = d[l + 1];
+                    const real *W = Pl, *b = Pl + (size_t)out * in;
+                    const real *xin = act + (size_t)l * maxw;
+                    real *y = act + (size_t)(l + 1) * maxw, *dy = dact + (size_t)(l + 1) * maxw;
+                    for (int o = 0; o < out; ++o) {
+                        real acc = b[o];
+                        const real *wr = W + (size_t)o * in;
+                        for (int k = 0; k < in; ++k) acc += wr[k] * xin[k];
+                        if (l < nl - 1) {
+                            y[o] = celu01(acc, celu_alpha);
+                            dy[o] = acc > 0 ? (real)1 : (real)exp((double)(acc / celu_alpha));
+                        } else {
+                            y[o] = acc;
+                            dy[o] = 1;
+                        }
+                    }
+                    Pl += (size_t)out * in + out;
+                }
+                /* backward: d Loss / d e_member = g_atom / M (mean over members) */
+                for (int o = 0; o < d[nl]; ++o) ga[o] = g_atom[i] / M;
+                for (int l = nl - 1; l >= 0; --l) {
+                    const int in = d[l], out = d[l + 1];
+                    size_t lo = 0;
+                    for (int q = 0; q < l; ++q) lo += (size_t)d[q + 1] * d[q] + d[q + 1];
+                    const real *Wl = P + lo;
+                    real *GW = G + lo, *Gb = G + lo + (size_t)out * in;
+                    const real *xin = act + (size_t)l * maxw, *dy = dact + (size_t)(l + 1) * maxw;
+                    for (int k = 0; k < in; ++k) gb[k] = 0;
+                    for (int o = 0; o < out; ++o) {
+                        const real go = ga[o] * dy[o];
+                        const real *wr = Wl + (size_t)o * in;
+                        real *gr = GW + (size_t)o * in;
+                        Gb[o] += go;
+                        for (int k = 0; k < in; ++k) {
+                            gr[k] += go * xin[k];
+                            gb[k] += go * wr[k];
+                        }
+                    }
+                    real *t = ga; ga = gb; gb = t;
+                }
+            }
+        }
+        free(act); free(dact); free(ga); free(gb);
+    }
+    free(off);
+}
+
+/*
  * Whole path: species/coords -> per-atom NN energies, molecular energies (NN + self energies), forces.
  *   arch.py:302-349 ANI.forward; sae.py:54-64 SelfEnergy (padding -> 0); grad.py:57-64 forces = -dE/dr.
  * mol_energy is accumulated in double regardless of `real`.

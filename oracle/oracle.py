@@ -118,6 +118,10 @@ class Oracle:
             C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp,
             C.c_double if kind == "f64" else C.c_float, vp, vp, vp, vp, vp,
         ]
+        L.ani_oracle_mlp_weight_grads.argtypes = [
+            C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp,
+            C.c_double if kind == "f64" else C.c_float, vp, vp, vp, vp,
+        ]
         L.ani_oracle_energy_forces.restype = C.c_int
         L.ani_oracle_energy_forces.argtypes = [
             C.POINTER(Params), C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp,
@@ -196,6 +200,21 @@ class Oracle:
                                 self._ptr(species), self._ptr(aev), self._ptr(ae), self._ptr(g),
                                 self._ptr(me))
         return ae, g, me
+
+    def mlp_weight_grads(self, species, aev, g_atom, dims, params, celu_alpha=0.1, n_members=None):
+        """d (sum_i g_atom[i] * atomic_e[i]) / d params, in the layout of ``params`` (pack_networks)."""
+        species = self._i32(species).reshape(-1)
+        n = species.shape[0]
+        dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int32))
+        S, nlp1 = dims.shape
+        aev = self._r(aev).reshape(n, dims[0, 0])
+        params = self._r(params)
+        g_atom = self._r(g_atom).reshape(n)
+        out = np.empty_like(params)
+        self.lib.ani_oracle_mlp_weight_grads(n, S, int(n_members), nlp1 - 1, self._ptr(dims), self._ptr(params),
+                                             celu_alpha, self._ptr(species), self._ptr(aev), self._ptr(g_atom),
+                                             self._ptr(out))
+        return out
 
     # -- AEV only --------------------------------------------------------------------------
     def aev(self, p: Params, species, coords, cell=None, pbc=None, cell_list=False,

@@ -12,7 +12,32 @@ from torchani_amd.weights import random_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if not os.path.basename(p).startswith("nbrs_"))   # nbrs_*: reference neighbor lists
+                      if not os.path.basename(p).startswith(("nbrs_", "wgrads_")))   # reference neighbor lists /
+#                                                                                      weight-gradient digests
+WGRAD_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "wgrads_*.npz")))
+WGRAD_BLOCK = 4096
+
+
+def wgrad_upstream(C, A):
+    """Per-atom loss weights of tests/golden/gen_golden_wgrads.py."""
+    k = np.arange(C * A, dtype=np.float64)
+    return (0.5 + np.modf(0.37 * k)[0]).reshape(C, A)
+
+
+def wgrad_digest(flat):
+    """Block sums / pattern dot products / sampled heads of a packed gradient vector (gen_golden_wgrads.py)."""
+    n = flat.shape[0]
+    nb = (n + WGRAD_BLOCK - 1) // WGRAD_BLOCK
+    pad = np.zeros(nb * WGRAD_BLOCK, dtype=np.float64)
+    pad[:n] = flat
+    pat = np.cos(0.37 * np.arange(nb * WGRAD_BLOCK, dtype=np.float64))
+    blocks = pad.reshape(nb, WGRAD_BLOCK)
+    return blocks.sum(axis=1), (pad * pat).reshape(nb, WGRAD_BLOCK).sum(axis=1), blocks[::97, :64].copy()
+
+
+def load_wgrads(base):
+    with np.load(os.path.join(GOLDEN_DIR, "wgrads_" + base + ".npz")) as z:
+        return {k: z[k] for k in z.files}
 
 
 def load_golden(name):

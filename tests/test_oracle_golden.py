@@ -6,7 +6,8 @@ The fixtures in tests/golden were written by tests/golden/gen_golden.py, which i
 import numpy as np
 import pytest
 
-from _util import GOLDEN_NAMES, load_golden, oracle_networks, oracle_params
+from _util import (GOLDEN_NAMES, WGRAD_NAMES, load_golden, load_wgrads, oracle_networks, oracle_params, wgrad_digest,
+                   wgrad_upstream)
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
@@ -37,6 +38,28 @@ def test_oracle_matches_reference(oracle64, name, cell_list):
     # padding atoms: exactly zero everywhere (neighbors.py:72-82, nn/_containers.py:412-416)
     pad = g["species"] < 0
     assert np.all(out["forces"][pad] == 0) and np.all(out["atomic_energies"][pad] == 0)
+
+
+@pytest.mark.parametrize("base", WGRAD_NAMES)
+def test_oracle_weight_gradients_match_reference_autograd(oracle64, base):
+    """d Loss / d (weights, biases) of the oracle against the digest of the reference's autograd gradients
+    (tests/golden/gen_golden_wgrads.py).  Tolerance: torch's fp64 CELU backward artefact (see above), ~1e-8 relative."""
+    g, w = load_golden(base), load_wgrads(base)
+    dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
+    aev = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), g["cell"], g["pbc"])
+    up = wgrad_upstream(*g["species"].shape)
+    grads = oracle64.mlp_weight_grads(g["species"], aev, up, dims, flat, n_members=g["n_members"])
+    assert grads.shape[0] == int(w["n_params"])
+    ae, _, _ = oracle64.mlp(g["species"], aev, dims, flat, n_members=g["n_members"], want_grad=False)
+    assert abs(float((ae.reshape(up.shape) * up).sum()) - float(w["loss"])) < 1e-11
+    sums, dots, heads = wgrad_digest(grads)
+    scale = float(w["grad_abs_max"])
+    assert abs(np.abs(grads).max() - scale) < 1e-7 * scale
+    assert abs(np.linalg.norm(grads) - float(w["grad_l2"])) < 1e-7 * float(w["grad_l2"])
+    assert np.abs(sums - w["block_sums"]).max() < 1e-7 * scale
+    assert np.abs(dots - w["block_dots"]).max() < 1e-7 * scale
+    assert np.abs(heads - w["block_heads"]).max() < 1e-7 * scale
 
 
 def test_member_energies(oracle64):
