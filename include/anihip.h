@@ -236,6 +236,31 @@ int anihip_mlp_forward_backward(void *stream, const anihip_mlp_desc *d, int64_t 
                                 const uint32_t *slab_mask, void *workspace, size_t workspace_bytes,
                                 float *atomic_e, float *grad_aev, float *member_e);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training pass: gradients with respect to every weight and bias.  The reference gets them from torch autograd
+ * through nn/_core.py:146-149 + nn/_containers.py:377-421,608-636 (its native MNP path has no weight gradients,
+ * csrc/mnp.cpp:138-232); the loop this serves is tools/training-aev-benchmark.py:120-135 (BASELINE config 5).
+ *
+ * For  Loss = sum_i grad_atomic_e[i] * atomic_e[i]  (the caller folds d Loss / d E_molecule into per-atom factors;
+ * atomic_e = ensemble mean as above):
+ *   grads[s].gw[l]    = d Loss / d w[l]    of species s, same shape and layout as anihip_species_net.w[l]
+ *   grads[s].gbias[l] = d Loss / d bias[l] of species s, same shape as bias[l]
+ * (padded rows/columns come out zero).  All gradient arrays are OVERWRITTEN.  atomic_e is written as in
+ * anihip_mlp_forward_backward; grad_aev (optional) = d Loss / d aev rows, i.e. already scaled by grad_atomic_e.
+ * Arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32 whatever desc.precision says (only w / wt / bias are read);
+ * sums over atoms use float atomics, so the last bits depend on the execution order.
+ */
+typedef struct {
+    float *gw[ANIHIP_MAX_LAYERS];
+    float *gbias[ANIHIP_MAX_LAYERS];
+} anihip_species_grads;
+
+size_t anihip_mlp_train_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central);
+int anihip_mlp_weight_grads(void *stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo, int64_t hi,
+                            const int32_t *species, const float *aev, const float *grad_atomic_e,
+                            void *workspace, size_t workspace_bytes, const anihip_species_grads *grads /* [num_species] */,
+                            float *atomic_e, float *grad_aev);
+
 /* mol_e[c] (fp64) = sum_a atomic_e[c,a] + sae[species[c,a]] over the atoms lo <= c*A+a < hi; padding
  * contributes nothing (sae.py:54-64).  sae may be NULL.  mol_e is overwritten. */
 int anihip_energy_reduce(void *stream, int32_t n_mol, int32_t n_atoms_per_mol, int64_t lo, int64_t hi,

@@ -51,6 +51,10 @@ def test_struct_layouts_match_header(lib):
     acts = 4 * 8 * (256 + 192 + 160) * (n + 1)
     tiles = (n + 63) // 64 + 8   # tile table of the fused kernel: 16-B entry + 64 atom rows per tile
     assert acts <= need <= acts + 4 * (n + 1) * (1 + 8) + (16 + 256) * tiles + 64 * 256
+    # training pass: the activations are kept and every hidden layer gets a gradient buffer of the same size
+    assert ctypes.sizeof(_lib.SpeciesGrads) == 2 * 4 * 8
+    need_t = lib.anihip_mlp_train_workspace_bytes(ctypes.byref(d), n)
+    assert need + acts <= need_t <= need + acts + 4 * 256
 
 
 def test_error_reporting_without_gpu(lib):
@@ -88,6 +92,8 @@ def test_argument_validation_without_gpu(lib):
     p.cutoff_kind = 7   # neither ANIHIP_CUTOFF_COSINE nor ANIHIP_CUTOFF_SMOOTH
     rc = lib.anihip_aev_forward(None, ctypes.byref(p), addr, 10, 0, 10, addr, addr, addr, addr, None, addr)
     assert rc != 0 and b"cutoff_kind" in lib.anihip_last_error()
+    rc = lib.anihip_mlp_weight_grads(None, None, 10, 0, 10, addr, addr, addr, addr, 4096, None, addr, None)
+    assert rc != 0 and b"null descriptor" in lib.anihip_last_error()
     d = _lib.MlpDesc()
     d.num_species, d.n_members, d.aev_len, d.celu_alpha, d.precision = 9, 8, 1008, 0.1, _lib.MLP_F16X3
     rc = lib.anihip_mlp_forward_backward(None, ctypes.byref(d), 10, 0, 10, addr, addr, None, addr, 4096, addr, None,

@@ -1,0 +1,168 @@
+"""GPU parity of the training pass (weight / bias gradients, BASELINE config 5) against the CPU oracle, whose
+gradients are pinned to the reference's autograd by tests/golden/wgrads_*.npz (tests/test_oracle_golden.py).
+
+Tolerance: gradients are sums over atoms of fp32 products accumulated in fp32 (MFMA + float atomics); they are held
+to 2e-5 of the largest gradient entry of the case (measured: ~1e-6).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import WGRAD_NAMES, load_golden, oracle_networks, oracle_params, seeded_state, wgrad_upstream
+from test_gpu_parity import report
+
+pytestmark = pytest.mark.gpu
+
+WG_REL_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from torchani_amd import _lib
+
+    _lib.lib()  # fail loudly if the native library is missing
+    return torch.device("cuda:0")
+
+
+def fresh_model(kind, seed, dev, cutoff_fn="cosine"):
+    from torchani_amd.models import ANI1x, ANI2x
+
+    ctor = ANI2x if kind == "ani2x" else ANI1x
+    return ctor(state_dict=seeded_state(kind, 8, seed), device=dev, periodic_table_index=False, cutoff_fn=cutoff_fn)
+
+
+def flat_from_lists(gw, gb, M, S, nl):
+    """Engine gradients (Linear layout lists) -> the oracle's packed layout (oracle.pack_networks)."""
+    out = []
+    for m in range(M):
+        for s in range(S):
+            for l in range(nl):
+                out.append(gw[m][s][l].detach().cpu().numpy().astype(np.float64).reshape(-1))
+                out.append(gb[m][s][l].detach().cpu().numpy().astype(np.float64).reshape(-1))
+    return np.concatenate(out)
+
+
+def flat_from_params(nets, symbols):
+    out = []
+    for member in nets.members:
+        for sym in symbols:
+            for lin in member.atomics[sym].linears():
+                for p in (lin.weight, lin.bias):
+                    g = p.grad if p.grad is not None else torch.zeros_like(p)
+                    out.append(g.detach().cpu().numpy().astype(np.float64).reshape(-1))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("base", WGRAD_NAMES)
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_weight_grads_match_oracle(dev, oracle64, base, precision):
+    g = load_golden(base)
+    dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
+    aev = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), g["cell"], g["pbc"])
+    a32 = aev.astype(np.float32)
+    C, A = g["species"].shape
+    up = wgrad_upstream(C, A).astype(np.float32)
+    ref = oracle64.mlp_weight_grads(g["species"], a32.astype(np.float64), up.astype(np.float64), dims, flat,
+                                    n_members=8)
+    ae, ga, _ = oracle64.mlp(g["species"], a32.astype(np.float64), dims, flat, n_members=8)
+    model = fresh_model(g["kind"], g["seed"], dev, g["cutoff_fn"])
+    nets = model.neural_networks
+    nets.mlp_precision = precision
+    packed = nets._pack(dev)
+    sp32 = torch.from_numpy(g["species"].astype(np.int32)).to(dev)
+    at = torch.from_numpy(a32).to(dev).view(C * A, -1)
+    gw, gb, e, gaev = packed.weight_grads(sp32, at, torch.from_numpy(up).to(dev), want_grad_aev=True)
+    torch.cuda.synchronize()
+    got = flat_from_lists(gw, gb, packed.M, packed.S, packed.nl)
+    assert got.shape == ref.shape
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    e_err = np.abs(e.cpu().numpy() - ae).max()
+    ga_ref = ga * up.reshape(-1, 1)
+    ga_err = np.abs(gaev.cpu().numpy() - ga_ref).max()
+    report(f"wgrad {base:22s} {precision:6s} max|dL/dw err| = {err:.2e} (max |dL/dw| {scale:.2e})  "
+           f"|e_atom err| = {e_err:.2e}  |dL/daev err| = {ga_err:.2e}")
+    assert err < WG_REL_TOL * scale
+    assert e_err < 3e-7
+    assert ga_err < 1e-6 + 1e-5 * np.abs(ga_ref).max()
+    # chunked evaluation (gradients of the chunks are summed) gives the same result
+    gw2, gb2, e2, _ = packed.weight_grads(sp32, at, torch.from_numpy(up).to(dev), chunk=max(7, (C * A) // 3))
+    got2 = flat_from_lists(gw2, gb2, packed.M, packed.S, packed.nl)
+    assert np.abs(got2 - ref).max() < WG_REL_TOL * scale
+    assert np.abs(e2.cpu().numpy() - ae).max() < 3e-7
+
+
+def test_autograd_training_step(dev, oracle64):
+    """loss.backward() through the containers fills .grad of every Linear parameter (what the reference's training
+    loop relies on, tools/training-aev-benchmark.py:120-135), and a few Adam steps reduce the loss."""
+    g = load_golden("rand_batch_ani2x")
+    model = fresh_model("ani2x", g["seed"], dev)
+    nets = model.neural_networks
+    nets.requires_grad_(True)
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev)
+    C, A = g["species"].shape
+    target = torch.from_numpy(np.linspace(-0.3, 0.4, C)).to(dev)
+    aev = model.aev_computer(sp, x).detach()
+    e = nets(sp, aev).double()
+    loss = ((e - target) ** 2).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle: upstream per atom = 2 (E_c - target_c) on the fp32 AEVs the engine produced
+    dims, flat, _ = oracle_networks("ani2x", 8, g["seed"])
+    a64 = aev.cpu().numpy().astype(np.float64).reshape(C * A, -1)
+    ae, _, _ = oracle64.mlp(g["species"], a64, dims, flat, n_members=8, want_grad=False)
+    e_ref = ae.reshape(C, A).sum(axis=1)
+    up = np.repeat(2.0 * (e_ref - target.cpu().numpy())[:, None], A, axis=1)
+    ref = oracle64.mlp_weight_grads(g["species"], a64, up, dims, flat, n_members=8)
+    got = flat_from_params(nets, model.symbols if hasattr(model, "symbols") else nets.symbols)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    report(f"train autograd rand_batch_ani2x  max|grad err| = {err:.2e} (max |grad| {scale:.2e})")
+    assert err < 5e-5 * scale
+    # double backward is not implemented: it must raise, not return silently wrong numbers
+    aev_g = aev.clone().requires_grad_(True)
+    e2 = nets(sp, aev_g).sum()
+    (ga,) = torch.autograd.grad(e2, aev_g, create_graph=True)
+    with pytest.raises(RuntimeError):
+        ga.pow(2).sum().backward()
+    # a short optimisation run
+    opt = torch.optim.Adam(nets.parameters(), lr=1e-4)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        e = nets(sp, aev).double()
+        loss = ((e - target) ** 2).sum()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    report("train adam losses " + " ".join(f"{v:.5f}" for v in losses))
+    assert losses[-1] < 0.7 * losses[0]
+
+
+def test_frozen_species_and_inference_unchanged(dev):
+    """Parameters without requires_grad get no gradient; with everything frozen the containers take the inference
+    path (no training pass, d/d aev from the fused kernel)."""
+    g = load_golden("rand_batch_ani2x")
+    model = fresh_model("ani2x", g["seed"], dev)
+    nets = model.neural_networks
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev)
+    aev = model.aev_computer(sp, x).detach().requires_grad_(True)
+    e0 = nets(sp, aev).sum()
+    (g0,) = torch.autograd.grad(e0, aev)
+    nets.members[0].atomics["H"].requires_grad_(True)
+    e1 = nets(sp, aev).sum()
+    e1.backward()
+    torch.cuda.synchronize()
+    assert abs(float(e1) - float(e0)) < 1e-6
+    # the training pass computes d/d aev in exact fp32, the inference path in split fp16: same to round-off
+    assert (aev.grad - g0).abs().max().item() < 1e-6 + 1e-5 * g0.abs().max().item()
+    got = [p.grad is not None for p in nets.members[0].atomics["H"].parameters()]
+    assert all(got)
+    assert all(p.grad is None for p in nets.members[1].parameters())
+    assert all(p.grad is None for p in nets.members[0].atomics["C"].parameters())

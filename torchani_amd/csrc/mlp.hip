@@ -60,6 +60,8 @@ struct GemmArgs {
     const int *a_gather;   // sorted position -> source row (layer 0) or NULL
     float *C;
     int64_t ldc;
+    const float *Y;        // EPI_DCELU of the training pass (k_gemm): activations read from here, C only written
+    int64_t ldy;           //   (NULL: C holds the activations and is overwritten in place)
     const int *c_scatter;  // sorted position -> destination row (last backward GEMM) or NULL
     int n_store;           // EPI_SCATTER: only columns < n_store are stored
     int S, batch, ncol_max, nrow_tiles_ub;
@@ -299,7 +301,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs g)
             } else if (EPI == EPI_DCELU) {
                 // stored activation y = celu(x):  celu'(x) = 1 (y > 0)  or  exp(x/alpha) = y/alpha + 1
                 float *cp = g.C + (int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col;
-                const float y = __builtin_nontemporal_load(cp);
+                const float y = g.Y ? g.Y[(int64_t)(p0 + row) * g.ldy + (int64_t)bb * pr.c_boff + col]
+                                    : __builtin_nontemporal_load(cp);
                 *cp = v * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
             } else {
                 if (col < g.n_store)
@@ -1485,6 +1488,8 @@ struct HeadArgs {
     const int *perm;
     float *act;   // last hidden activations [n][ld]; overwritten with d(mean energy)/d(activation)
     int64_t ld;
+    float *seed;             // training pass: the backward seed goes here ([n][ld]) and act is kept (NULL: in place)
+    const float *g_atom;     // training pass: upstream d Loss / d atomic_e per atom (NULL: 1)
     float *atomic_e;   // [n_atoms]
     float *member_e;   // [M][n_atoms] or NULL
     int64_t n_atoms;
@@ -1512,9 +1517,11 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs h)
         }
         const int Hp = h.Hp[s];
         float *row = h.act + p * h.ld;
+        float *srow = h.seed ? h.seed + p * h.ld : row;
         const int atom = h.perm[p];
         float esum = 0.f;
         const float invM = 1.0f / (float)h.M;
+        const float up = h.g_atom ? h.g_atom[atom] * invM : invM;
         for (int m = 0; m < h.M; ++m) {
             const float *w = h.w[s] + (int64_t)m * Hp;
             float part = 0.f;
@@ -1522,8 +1529,8 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs h)
                 const float y = row[m * Hp + o];
                 part += y * w[o];
                 if (h.want_grad) {
-                    const float gq = invM * w[o] * (y > 0.f ? 1.0f : y * h.inv_alpha + 1.0f);
-                    row[m * Hp + o] = gq;
+                    const float gq = up * w[o] * (y > 0.f ? 1.0f : y * h.inv_alpha + 1.0f);
+                    srow[m * Hp + o] = gq;
                     gmax = fmaxf(gmax, fabsf(gq));
                 }
             }
@@ -1534,6 +1541,164 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs h)
         if (lane == 0) h.atomic_e[atom] = esum * invM;
     }
     if (gs >= 0 && h.amax && h.want_grad) amax_update(h.amax, h.amax_out, gs, gmax);
+}
+
+// ---- weight gradients (training pass) ----------------------------------------------------------------
+// dW = X^T D over the rows (atoms) of one species: X = input of the layer (AEV rows gathered through the bucket
+// list, or the activations of the previous layer), D = d Loss / d (pre-activation) of the layer.  The reduction
+// index is the ROW index, so both operands are consumed exactly as they lie in memory: for two consecutive rows
+// (k = lane >> 5) a lane reads the float2 at columns 2 (lane & 31) of X and of D, and
+// v_mfma_f32_32x32x2_f32 accumulates the four (even/odd) x (even/odd) column combinations -- a 64 x 64 block of dW
+// per wave with no LDS staging and no transposes.  A workgroup = 4 waves on the same 64 input columns and four
+// neighbouring 64-column blocks of D (X is then shared through L1); rows are cut into chunks of WG_ROWS and the
+// partial blocks are added to dW with float atomics (dW is zeroed by the host function).
+constexpr int WG_ROWS = 2048;   // rows per workgroup
+constexpr int WG_U = 8;         // row pairs in flight
+
+struct WgradProblem {
+    const float *X;   // input of the layer
+    int64_t ldx;
+    int x_boff;       // column offset of batch b in X rows = b * x_boff
+    int K, k_valid;   // input width (padded), columns >= k_valid are neither read nor written
+    const float *D;
+    int64_t ldd;
+    int d_boff;
+    int N;            // output width per batch
+    float *dW;        // [batch][K][ldw]
+    int64_t ldw, w_bstride;
+};
+struct WgradArgs {
+    WgradProblem prob[MAX_S];
+    const int *ctl;
+    const int *x_gather;   // sorted position -> source row of X (layer 0) or NULL
+    int S, batch, ki_max, nj_max;
+};
+
+__device__ __forceinline__ bool chunk_lookup(const int *ctl, int S, int chunk, int rows_per_chunk, int &s, int &m0)
+{
+    int first = 0;
+    for (s = 0; s < S; ++s) {
+        const int nc = (ctl[CTL_CNT + s] + rows_per_chunk - 1) / rows_per_chunk;
+        if (chunk < first + nc) {
+            m0 = (chunk - first) * rows_per_chunk;
+            return true;
+        }
+        first += nc;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs g)
+{
+    int id = blockIdx.x;
+    const int nj = id % g.nj_max; id /= g.nj_max;
+    const int ki = id % g.ki_max; id /= g.ki_max;
+    const int bb = id % g.batch;
+    const int chunk = id / g.batch;
+    int s, m0;
+    if (!chunk_lookup(g.ctl, g.S, chunk, WG_ROWS, s, m0)) return;
+    const WgradProblem &pr = g.prob[s];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int i0 = ki * 64, j0 = (nj * 4 + wave) * 64;
+    if (i0 >= pr.k_valid || j0 >= pr.N) return;
+    const int n_rows = min(WG_ROWS, g.ctl[CTL_CNT + s] - m0);
+    const int p0 = g.ctl[CTL_OFF + s] + m0;
+    const int c2 = 2 * (lane & 31), kk = lane >> 5;
+    const bool x_ok = i0 + c2 < pr.k_valid;      // k_valid is even: the float2 is inside or outside as a whole
+    const bool d_ok = j0 + c2 < pr.N;
+    const int xc = x_ok ? i0 + c2 : 0, dc = d_ok ? j0 + c2 : 0;
+    const float *Xb = pr.X + (int64_t)bb * pr.x_boff + xc;
+    const float *Db = pr.D + (int64_t)bb * pr.d_boff + dc;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float2 xs[WG_U], ds[WG_U];
+    auto load = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            const int r = r0 + 2 * u + kk;
+            const bool v = r < n_rows;
+            const int rr = v ? r : 0;                                  // clamped: always valid memory
+            const int64_t xrow = g.x_gather ? (int64_t)g.x_gather[p0 + rr] : (int64_t)(p0 + rr);
+            float2 x = *reinterpret_cast<const float2 *>(Xb + xrow * pr.ldx);
+            float2 d = *reinterpret_cast<const float2 *>(Db + (int64_t)(p0 + rr) * pr.ldd);
+            if (!(v && x_ok)) x = make_float2(0.f, 0.f);
+            if (!d_ok) d = make_float2(0.f, 0.f);
+            xs[u] = x;
+            ds[u] = d;
+        }
+    };
+    load(0);
+    for (int r0 = 0; r0 < n_rows; r0 += 2 * WG_U) {
+        float2 xc_[WG_U], dc_[WG_U];
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) { xc_[u] = xs[u]; dc_[u] = ds[u]; }
+        if (r0 + 2 * WG_U < n_rows) load(r0 + 2 * WG_U);
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc_[u].x, dc_[u].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc_[u].x, dc_[u].y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc_[u].y, dc_[u].x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc_[u].y, dc_[u].y, acc[1][1], 0, 0, 0);
+        }
+    }
+    // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float *W = pr.dW + (int64_t)bb * pr.w_bstride;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int j = j0 + c2 + b;
+            if (j >= pr.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + a;
+                if (i < pr.k_valid) atomicAdd(W + (int64_t)i * pr.ldw + j, acc[a][b][r]);
+            }
+        }
+}
+
+// out[col] += sum over the rows of species s of  scale(row) * X[row][col]   (bias gradients: X = D, scale = 1;
+// output layer: X = last activations, scale = upstream / M, and extra[m] += sum of the scales = d Loss / d b3)
+constexpr int CR_ROWS = 512;
+struct ColReduceArgs {
+    const float *X[MAX_S];
+    float *out[MAX_S];
+    float *extra[MAX_S];
+    int ncols[MAX_S];
+    int64_t ldx;
+    const int *ctl;
+    const int *perm;
+    const float *g_atom;   // scale source (NULL: 1)
+    float inv_m;
+    int S, M, ct_max;
+};
+
+__global__ __launch_bounds__(256) void k_col_reduce(ColReduceArgs g)
+{
+    const int ct = blockIdx.x % g.ct_max, chunk = blockIdx.x / g.ct_max;
+    int s, m0;
+    if (!chunk_lookup(g.ctl, g.S, chunk, CR_ROWS, s, m0)) return;
+    const int col = ct * 256 + threadIdx.x;
+    if (ct * 256 >= g.ncols[s]) return;
+    const int n_rows = min(CR_ROWS, g.ctl[CTL_CNT + s] - m0);
+    const int p0 = g.ctl[CTL_OFF + s] + m0;
+    const bool cv = col < g.ncols[s];
+    const float *x = g.X[s] + (cv ? col : 0);
+    float acc = 0.f, sacc = 0.f;
+    for (int r = 0; r < n_rows; ++r) {
+        const float sc = g.g_atom ? g.g_atom[g.perm[p0 + r]] * g.inv_m : 1.0f;
+        acc += sc * x[(int64_t)(p0 + r) * g.ldx];
+        sacc += sc;
+    }
+    if (cv) atomicAdd(g.out[s] + col, acc);
+    if (g.extra[s] && ct == 0 && threadIdx.x < g.M) atomicAdd(g.extra[s] + threadIdx.x, sacc);
 }
 
 // padding atoms inside the shard: zero energy / zero gradient rows
@@ -1611,6 +1776,22 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
         int64_t ld = (int64_t)mx * d->n_members;
         float *a = (float *)take(sizeof(float) * (size_t)ld * (size_t)(n + 1));
         if (w) { w->act[l] = a; w->ld[l] = ld; }
+    }
+    return off;
+}
+
+// training pass: the inference workspace + one gradient buffer per hidden layer (the activations are kept)
+static size_t mlp_train_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWorkspace *w,
+                              float **dlt /* [ANIHIP_MAX_LAYERS] */)
+{
+    size_t off = align256(mlp_carve(d, n, base, w));
+    const int nh = d->net[0].n_layers - 1;
+    for (int l = 0; l < nh; ++l) {
+        int mx = 0;
+        for (int s = 0; s < d->num_species; ++s) mx = mx > d->net[s].dims[l + 1] ? mx : d->net[s].dims[l + 1];
+        const size_t bytes = sizeof(float) * (size_t)mx * d->n_members * (size_t)(n + 1);
+        if (dlt) dlt[l] = base ? (float *)(base + off) : nullptr;
+        off += align256(bytes);
     }
     return off;
 }
@@ -1926,6 +2107,184 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                 launch_gemm<EPI_DCELU>(stream, g, h3);
             }
         }
+    }
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" size_t anihip_mlp_train_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central)
+{
+    if (!d || n_central < 0) return 0;
+    return mlp_train_carve(d, n_central, nullptr, nullptr, nullptr);
+}
+
+extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo,
+                                       int64_t hi, const int32_t *species, const float *aev,
+                                       const float *grad_atomic_e, void *workspace, size_t workspace_bytes,
+                                       const anihip_species_grads *grads, float *atomic_e, float *grad_aev)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_desc(d)) return rc;
+    ANIHIP_REQUIRE(species && aev && grad_atomic_e && workspace && grads && atomic_e, "null pointer argument");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1, L = d->aev_len;
+    for (int s = 0; s < S; ++s)
+        for (int l = 0; l < nl; ++l)
+            ANIHIP_REQUIRE(grads[s].gw[l] && grads[s].gbias[l], "species %d layer %d: null gradient pointer", s, l);
+    // gradients are overwritten: zero, then accumulate with atomics
+    for (int s = 0; s < S; ++s) {
+        const anihip_species_net &nn = d->net[s];
+        for (int l = 0; l < nl; ++l) {
+            const size_t nw = (size_t)M * nn.dims[l] * nn.dims[l + 1], nb = (size_t)M * nn.dims[l + 1];
+            zero_words_async(stream, grads[s].gw[l], sizeof(float) * nw);
+            zero_words_async(stream, grads[s].gbias[l], sizeof(float) * nb);
+        }
+    }
+    const int64_t n = hi - lo;
+    if (n == 0) return 0;
+    ANIHIP_REQUIRE(workspace_bytes >= mlp_train_carve(d, n, nullptr, nullptr, nullptr), "workspace too small");
+    MlpWorkspace w;
+    float *dlt[ANIHIP_MAX_LAYERS];
+    mlp_train_carve(d, n, (char *)workspace, &w, dlt);
+    const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
+
+    // 1. bucket by species
+    zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
+    hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl);
+    hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(64), 0, stream, S, w.ctl);
+    hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, w.perm);
+    hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
+                       atomic_e, grad_aev, L, (float *)nullptr, M, n_atoms);
+    const int nrow_ub = (int)((n + BM - 1) / BM) + S;
+    auto width_max = [&](int l) {
+        int mx = 0;
+        for (int s = 0; s < S; ++s) mx = mx > d->net[s].dims[l] ? mx : d->net[s].dims[l];
+        return mx;
+    };
+    auto gemm_base = [&]() {
+        GemmArgs g{};
+        g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha; g.nrow_tiles_ub = nrow_ub;
+        g.amax_in = g.amax_out = -1;
+        return g;
+    };
+
+    // 2. forward in exact fp32, activations kept
+    for (int l = 0; l < nh; ++l) {
+        GemmArgs g = gemm_base();
+        g.C = w.act[l]; g.ldc = w.ld[l];
+        if (l == 0) {
+            g.A = aev; g.lda = L; g.a_gather = w.perm; g.batch = 1;
+            g.ncol_max = (width_max(1) * M + BN - 1) / BN;
+        } else {
+            g.A = w.act[l - 1]; g.lda = w.ld[l - 1]; g.batch = M;
+            g.ncol_max = (width_max(l + 1) + BN - 1) / BN;
+        }
+        for (int s = 0; s < S; ++s) {
+            const anihip_species_net &nn = d->net[s];
+            GemmProblem &p = g.prob[s];
+            p.B = nn.w[l]; p.bias = nn.bias[l];
+            if (l == 0) {
+                p.K = nn.dims[0]; p.N = nn.dims[1] * M; p.ldb = p.N;
+            } else {
+                p.K = nn.dims[l]; p.N = nn.dims[l + 1]; p.ldb = p.N;
+                p.a_boff = nn.dims[l]; p.c_boff = nn.dims[l + 1];
+                p.b_stride = (int64_t)p.K * p.N; p.bias_stride = p.N;
+            }
+        }
+        launch_gemm<EPI_BIAS_CELU>(stream, g, false);
+    }
+
+    // 3. output layer: energies, seed of the backward pass (scaled by the upstream gradient), d w_out, d b_out
+    {
+        HeadArgs h{};
+        for (int s = 0; s < S; ++s) {
+            h.w[s] = d->net[s].w[nl - 1];
+            h.bias[s] = d->net[s].bias[nl - 1];
+            h.Hp[s] = d->net[s].dims[nl - 1];
+        }
+        h.ctl = w.ctl; h.perm = w.perm; h.act = w.act[nh - 1]; h.ld = w.ld[nh - 1];
+        h.seed = dlt[nh - 1]; h.g_atom = grad_atomic_e;
+        h.atomic_e = atomic_e; h.member_e = nullptr; h.n_atoms = n_atoms; h.S = S; h.M = M;
+        h.inv_alpha = inv_alpha; h.want_grad = 1; h.amax = nullptr; h.amax_out = 0;
+        int64_t blocks = (n + 3) / 4;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(k_head, dim3((unsigned)blocks), dim3(256), 0, stream, h);
+    }
+    const int cr_chunks = (int)((n + CR_ROWS - 1) / CR_ROWS) + S;
+    auto col_reduce = [&](int l, const float *X, int64_t ldx, bool output_layer) {
+        ColReduceArgs c{};
+        int mx = 0;
+        for (int s = 0; s < S; ++s) {
+            c.X[s] = X;
+            c.ncols[s] = M * d->net[s].dims[output_layer ? nl - 1 : l + 1];
+            c.out[s] = output_layer ? grads[s].gw[nl - 1] : grads[s].gbias[l];
+            c.extra[s] = output_layer ? grads[s].gbias[nl - 1] : nullptr;
+            mx = mx > c.ncols[s] ? mx : c.ncols[s];
+        }
+        c.ldx = ldx; c.ctl = w.ctl; c.perm = w.perm; c.S = S; c.M = M;
+        c.g_atom = output_layer ? grad_atomic_e : nullptr;
+        c.inv_m = output_layer ? 1.0f / (float)M : 1.0f;
+        c.ct_max = (mx + 255) / 256;
+        hipLaunchKernelGGL(k_col_reduce, dim3((unsigned)(cr_chunks * c.ct_max)), dim3(256), 0, stream, c);
+    };
+    col_reduce(nl - 1, w.act[nh - 1], w.ld[nh - 1], true);
+
+    // 4. backward through the hidden layers (gradients in their own buffers), weight and bias gradients
+    const int wg_chunks = (int)((n + WG_ROWS - 1) / WG_ROWS) + S;
+    for (int l = nh - 1; l >= 0; --l) {
+        col_reduce(l, dlt[l], w.ld[l], false);
+        WgradArgs a{};
+        a.ctl = w.ctl; a.S = S;
+        a.x_gather = l == 0 ? w.perm : nullptr;
+        a.batch = l == 0 ? 1 : M;
+        int kmax = 0, nmax = 0;
+        for (int s = 0; s < S; ++s) {
+            const anihip_species_net &nn = d->net[s];
+            WgradProblem &p = a.prob[s];
+            p.D = dlt[l]; p.ldd = w.ld[l]; p.dW = grads[s].gw[l];
+            if (l == 0) {
+                p.X = aev; p.ldx = L; p.x_boff = 0; p.K = L; p.k_valid = L;
+                p.d_boff = 0; p.N = nn.dims[1] * M; p.ldw = p.N; p.w_bstride = 0;
+            } else {
+                p.X = w.act[l - 1]; p.ldx = w.ld[l - 1]; p.x_boff = nn.dims[l]; p.K = nn.dims[l]; p.k_valid = p.K;
+                p.d_boff = nn.dims[l + 1]; p.N = nn.dims[l + 1]; p.ldw = p.N; p.w_bstride = (int64_t)p.K * p.N;
+            }
+            kmax = kmax > p.K ? kmax : p.K;
+            nmax = nmax > p.N ? nmax : p.N;
+        }
+        a.ki_max = (kmax + 63) / 64;
+        a.nj_max = (nmax + 255) / 256;
+        const int64_t total = (int64_t)wg_chunks * a.batch * a.ki_max * a.nj_max;
+        hipLaunchKernelGGL(k_wgrad, dim3((unsigned)total), dim3(256), 0, stream, a);
+
+        if (l == 0 && !grad_aev) break;
+        GemmArgs g = gemm_base();
+        g.A = dlt[l]; g.lda = w.ld[l];
+        if (l == 0) {
+            g.batch = 1; g.C = grad_aev; g.ldc = L; g.c_scatter = w.perm; g.n_store = L;
+            g.ncol_max = (((L + 31) / 32) * 32 + BN - 1) / BN;
+        } else {
+            g.batch = M; g.C = dlt[l - 1]; g.ldc = w.ld[l - 1]; g.Y = w.act[l - 1]; g.ldy = w.ld[l - 1];
+            g.ncol_max = (width_max(l) + BN - 1) / BN;
+        }
+        for (int s = 0; s < S; ++s) {
+            const anihip_species_net &nn = d->net[s];
+            GemmProblem &p = g.prob[s];
+            p.B = nn.wt[l];
+            if (l == 0) {
+                p.K = nn.dims[1] * M; p.N = ((L + 31) / 32) * 32; p.ldb = p.N;
+            } else {
+                p.K = nn.dims[l + 1]; p.N = nn.dims[l]; p.ldb = p.N;
+                p.a_boff = nn.dims[l + 1]; p.c_boff = nn.dims[l];
+                p.b_stride = (int64_t)p.K * p.N;
+            }
+        }
+        if (l == 0)
+            launch_gemm<EPI_SCATTER>(stream, g, false);
+        else
+            launch_gemm<EPI_DCELU>(stream, g, false);
     }
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;

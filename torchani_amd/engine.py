@@ -274,6 +274,7 @@ class PackedNetworks:
             raise ValueError("AEV length must be a multiple of 16")
         self.M, self.S, self.nl, self.aev_len = M, S, nl, aev_len
         self.device = device
+        self.shapes = [[tuple(weights[0][s][l].shape) for l in range(nl)] for s in range(S)]   # unpadded [out, in]
         self._keep: tp.List[Tensor] = []
         d = _lib.MlpDesc()
         d.num_species, d.n_members, d.aev_len, d.celu_alpha = S, M, aev_len, celu_alpha
@@ -379,6 +380,7 @@ class PackedNetworks:
                 net.fused_bounds = bounds.data_ptr()
         self.desc = d
         self._ws: tp.Optional[Tensor] = None
+        self._train_ws: tp.Optional[Tensor] = None
 
     def workspace(self, n_central: int) -> Tensor:
         need = _lib.lib().anihip_mlp_workspace_bytes(C.byref(self.desc), n_central)
@@ -428,6 +430,72 @@ class PackedNetworks:
                 _ptr(slab_mask), _ptr(ws), ws.numel(), _ptr(atomic_e),
                 _row_ptr(grad_aev, rows0, self.aev_len) if want_grad else None, _ptr(member_e)))
         return atomic_e, (grad_aev if want_grad else None), member_e
+
+    def weight_grads(self, species: Tensor, aev: Tensor, grad_atomic_e: Tensor,
+                     want_grad_aev: bool = False, chunk: int = 1 << 16):
+        """Training pass (anihip_mlp_weight_grads): gradients of  sum_i grad_atomic_e[i] * atomic_e[i]  with respect
+        to every weight and bias, returned in torch.nn.Linear layout: gw[m][s][l] [out, in], gb[m][s][l] [out];
+        plus atomic_e [N] and, optionally, d Loss / d aev [N, L].  Replaces torch autograd through
+        nn/_core.py:146-149 / nn/_containers.py:377-421,608-636."""
+        _require_cuda(species, aev, grad_atomic_e)
+        n = species.numel()
+        dev = aev.device
+        assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == n * self.aev_len
+        g_at = grad_atomic_e.to(torch.float32).contiguous().view(-1)
+        assert g_at.numel() == n
+        M, S, nl, d = self.M, self.S, self.nl, self.desc
+        # packed gradient buffers, shapes of anihip_species_net.w / bias
+        sizes = []
+        for s in range(S):
+            dims = [d.net[s].dims[l] for l in range(nl + 1)]
+            for l in range(nl):
+                sizes += [M * dims[l] * dims[l + 1], M * dims[l + 1]]
+        offs = np.concatenate([[0], np.cumsum([(x + 63) // 64 * 64 for x in sizes])])
+        atomic_e = torch.zeros(n, dtype=torch.float32, device=dev)
+        grad_aev = torch.zeros((n, self.aev_len), dtype=torch.float32, device=dev) if want_grad_aev else None
+        L = _lib.lib()
+        total = None
+        for c0 in range(0, max(n, 1), chunk):
+            c1 = min(n, c0 + chunk)
+            buf = torch.empty(int(offs[-1]), dtype=torch.float32, device=dev)
+            sg = (_lib.SpeciesGrads * S)()
+            q = 0
+            for s in range(S):
+                for l in range(nl):
+                    sg[s].gw[l] = buf.data_ptr() + 4 * int(offs[q])
+                    sg[s].gbias[l] = buf.data_ptr() + 4 * int(offs[q + 1])
+                    q += 2
+            need = L.anihip_mlp_train_workspace_bytes(C.byref(d), c1 - c0)
+            if self._train_ws is None or self._train_ws.numel() < need:
+                self._train_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            _lib.check(L.anihip_mlp_weight_grads(
+                _stream(), C.byref(d), n, c0, c1, _ptr(species), _ptr(aev), _ptr(g_at), _ptr(self._train_ws),
+                self._train_ws.numel(), sg, _ptr(atomic_e), _ptr(grad_aev)))
+            total = buf if total is None else total.add_(buf)
+        # unpack into Linear layout
+        gw = [[[None] * nl for _ in range(S)] for _ in range(M)]
+        gb = [[[None] * nl for _ in range(S)] for _ in range(M)]
+        q = 0
+        for s in range(S):
+            dims = [d.net[s].dims[l] for l in range(nl + 1)]
+            for l in range(nl):
+                out, inn = self.shapes[s][l]
+                w = total[int(offs[q]): int(offs[q]) + sizes[q]]
+                b = total[int(offs[q + 1]): int(offs[q + 1]) + sizes[q + 1]]
+                q += 2
+                if l == nl - 1:
+                    wv = w.view(M, 1, dims[l])                       # [M][Hlast_p]
+                    bv = b.view(M, 1)
+                elif l == 0:
+                    wv = w.view(dims[0], M, dims[1]).permute(1, 2, 0)    # [K0][M*H1p] -> [M, H1p, K0]
+                    bv = b.view(M, dims[1])
+                else:
+                    wv = w.view(M, dims[l], dims[l + 1]).transpose(1, 2)  # [M][in_p][out_p] -> [M, out_p, in_p]
+                    bv = b.view(M, dims[l + 1])
+                for m in range(M):
+                    gw[m][s][l] = wv[m, :out, :inn]
+                    gb[m][s][l] = bv[m, :out]
+        return gw, gb, atomic_e, grad_aev
 
 
 def energy_reduce(species: Tensor, atomic_e: Tensor, sae: tp.Optional[Tensor], lo: int = 0,

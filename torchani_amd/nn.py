@@ -5,8 +5,9 @@ Mirrors torchani/nn/_core.py:117-167 (AtomicNetwork, TightCELU), torchani/nn/_co
 Module/parameter names equal the reference's so its state dicts load unchanged
 (``members.{m}.atomics.{Sym}.layers.{l}.weight``, ``...final_layer.weight``).
 
-Inference only for now: gradients flow to the AEVs (hence to coordinates), not to the weights -- the same
-contract as the reference's native MNP path (csrc/mnp.cpp:138-232, csrc/README.md:6-7).
+Gradients flow to the AEVs (hence to coordinates) and -- when parameters have requires_grad -- to every weight
+and bias through the engine's training pass (anihip_mlp_weight_grads; the reference's native MNP path has no
+weight gradients, csrc/mnp.cpp:138-232, it trains through eager autograd).  First order only.
 """
 from __future__ import annotations
 
@@ -45,20 +46,27 @@ class AtomicNetwork(torch.nn.Module):
         self.final_layer = torch.nn.Linear(dims[-2], dims[-1], bias=True)
         self.activation = TightCELU()
         self.has_biases = True
-        self.requires_grad_(False)  # models.py:196 does the same for the builtin models
 
     def linears(self) -> tp.List[torch.nn.Linear]:
         return list(self.layers) + [self.final_layer]
 
 
 class _MLPFunction(torch.autograd.Function):
+    """params = the Linear parameters in the order member -> species -> layer -> (weight, bias)."""
+
     @staticmethod
-    def forward(ctx, aevs: Tensor, species32: Tensor, packed: PackedNetworks, want_members: bool) -> Tensor:
+    def forward(ctx, aevs: Tensor, species32: Tensor, packed: PackedNetworks, want_members: bool,
+                *params: Tensor) -> Tensor:
         C, A = species32.shape
-        need_grad = aevs.requires_grad
+        train = any(p.requires_grad for p in params)
+        need_grad = aevs.requires_grad and not train
         a32 = aevs.detach().to(torch.float32).contiguous().view(C * A, -1)
         ae, g, me = packed.forward_backward(species32, a32, want_grad=need_grad, want_members=want_members)
         ctx.g = g
+        ctx.train = train
+        ctx.aev_grad = aevs.requires_grad
+        ctx.saved = (a32, species32, packed) if train else None
+        ctx.param_dtypes = [p.dtype for p in params]
         ctx.in_dtype = aevs.dtype
         ctx.shape = aevs.shape
         ctx.want_members = want_members
@@ -67,13 +75,27 @@ class _MLPFunction(torch.autograd.Function):
         return ae.view(C, A).to(aevs.dtype)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out: Tensor):
         if ctx.want_members:
             raise RuntimeError("ensemble_values=True is not differentiable in the HIP engine")
+        if ctx.train:
+            # training pass: forward recomputed in exact fp32 with the activations kept, then d/d weights, d/d biases
+            # (and d/d aev scaled by the upstream gradient) in one engine call
+            a32, species32, packed = ctx.saved
+            gw, gb, _, gaev = packed.weight_grads(species32, a32, grad_out.contiguous(), want_grad_aev=ctx.aev_grad)
+            flat = []
+            for m in range(packed.M):
+                for s in range(packed.S):
+                    for l in range(packed.nl):
+                        flat += [gw[m][s][l], gb[m][s][l]]
+            flat = [t.to(dt) for t, dt in zip(flat, ctx.param_dtypes)]
+            ga = gaev.view(ctx.shape).to(ctx.in_dtype) if gaev is not None else None
+            return (ga, None, None, None, *flat)
         if ctx.g is None:
             raise RuntimeError("AEVs did not require grad in forward")
         g = ctx.g.view(ctx.shape) * grad_out.to(torch.float32).unsqueeze(-1)
-        return g.to(ctx.in_dtype), None, None, None
+        return (g.to(ctx.in_dtype), None, None, None, *([None] * len(ctx.param_dtypes)))
 
 
 class _EngineContainer(torch.nn.Module):
@@ -91,9 +113,6 @@ class _EngineContainer(torch.nn.Module):
     def _pack(self, device: torch.device) -> PackedNetworks:
         members = self._member_networks()
         params = [p for m in members for p in m.parameters()]
-        if any(p.requires_grad for p in params) and torch.is_grad_enabled():
-            warnings.warn("torchani_amd evaluates networks in inference mode: weight gradients are not "
-                          "computed by the HIP engine (only d/d aev)")
         precision = getattr(self, "mlp_precision", None) or os.environ.get("TORCHANI_AMD_MLP_PRECISION", "f16x3")
         key = (device, precision, tuple(id(m) for m in members), tuple(p._version for p in params),
                tuple(p.data_ptr() for p in params))
@@ -112,7 +131,12 @@ class _EngineContainer(torch.nn.Module):
             raise ValueError("torchani_amd's network containers need tensors on a ROCm device")
         species32 = elem_idxs.to(torch.int32).contiguous()
         packed = self._pack(aevs.device)
-        out = _MLPFunction.apply(aevs, species32, packed, ensemble_values)
+        params: tp.List[Tensor] = []
+        if torch.is_grad_enabled():
+            lins = [lin for m in self._member_networks() for s in self.symbols for lin in m.atomics[s].linears()]
+            if any(lin.weight.requires_grad or lin.bias.requires_grad for lin in lins):
+                params = [p for lin in lins for p in (lin.weight, lin.bias)]
+        out = _MLPFunction.apply(aevs, species32, packed, ensemble_values, *params)
         # [C, A] (or [M, C, A]); molecular energies are the sum over atoms (nn/_containers.py:417-421)
         return out if atomic else out.sum(dim=-1)
 
