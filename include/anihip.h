@@ -259,7 +259,22 @@ size_t anihip_mlp_train_workspace_bytes(const anihip_mlp_desc *d, int64_t n_cent
 int anihip_mlp_weight_grads(void *stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo, int64_t hi,
                             const int32_t *species, const float *aev, const float *grad_atomic_e,
                             void *workspace, size_t workspace_bytes, const anihip_species_grads *grads /* [num_species] */,
-                            float *atomic_e, float *grad_aev);
+                            float *atomic_e, float *grad_aev, int32_t forward_done);
+
+/* The two halves of a training step as autograd needs them (forward now, backward later): the exact-fp32 forward
+ * that leaves the species buckets and every hidden activation in the workspace (anihip_mlp_train_workspace_bytes),
+ * writing atomic_e.  A later anihip_mlp_weight_grads call with forward_done != 0 and the SAME descriptor, range,
+ * species, aev and (untouched) workspace skips its own forward. */
+int anihip_mlp_train_forward(void *stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo, int64_t hi,
+                             const int32_t *species, const float *aev, void *workspace, size_t workspace_bytes,
+                             float *atomic_e);
+
+/* Refresh the packed fp32 parameter arrays of an ANIHIP_MLP_FP32 descriptor (the arrays w / wt / bias point to are
+ * REWRITTEN in place; padding stays zero) from the torch.nn.Linear tensors after an optimizer step -- one launch
+ * instead of re-packing on the host (cf. BmmAtomicNetwork packing once per model, nn/_infer.py:141-161).
+ * src: DEVICE array of 2 * M * S * n_layers pointers ordered member, species, layer, {weight [out][in] row-major,
+ * bias [out]}; out_in: HOST array [S][n_layers][2] with the (out, in) widths of the source tensors. */
+int anihip_mlp_repack(void *stream, const anihip_mlp_desc *d, const void *const *src, const int32_t *out_in);
 
 /* mol_e[c] (fp64) = sum_a atomic_e[c,a] + sae[species[c,a]] over the atoms lo <= c*A+a < hi; padding
  * contributes nothing (sae.py:54-64).  sae may be NULL.  mol_e is overwritten. */

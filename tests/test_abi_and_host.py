@@ -92,7 +92,11 @@ def test_argument_validation_without_gpu(lib):
     p.cutoff_kind = 7   # neither ANIHIP_CUTOFF_COSINE nor ANIHIP_CUTOFF_SMOOTH
     rc = lib.anihip_aev_forward(None, ctypes.byref(p), addr, 10, 0, 10, addr, addr, addr, addr, None, addr)
     assert rc != 0 and b"cutoff_kind" in lib.anihip_last_error()
-    rc = lib.anihip_mlp_weight_grads(None, None, 10, 0, 10, addr, addr, addr, addr, 4096, None, addr, None)
+    rc = lib.anihip_mlp_weight_grads(None, None, 10, 0, 10, addr, addr, addr, addr, 4096, None, addr, None, 0)
+    assert rc != 0 and b"null descriptor" in lib.anihip_last_error()
+    rc = lib.anihip_mlp_train_forward(None, None, 10, 0, 10, addr, addr, addr, 4096, addr)
+    assert rc != 0 and b"null descriptor" in lib.anihip_last_error()
+    rc = lib.anihip_mlp_repack(None, None, addr, addr)
     assert rc != 0 and b"null descriptor" in lib.anihip_last_error()
     d = _lib.MlpDesc()
     d.num_species, d.n_members, d.aev_len, d.celu_alpha, d.precision = 9, 8, 1008, 0.1, _lib.MLP_F16X3

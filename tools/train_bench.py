@@ -1,0 +1,90 @@
+"""Training-step timing for BASELINE.json config 5 (the recipe of the reference's tools/training-aev-benchmark.py:
+minibatch of 2560 conformers, MSE(E) / sqrt(n_atoms) loss, Adam lr 1e-4; stages timed separately like
+csrc/README.md:108-112):
+
+    python tools/train_bench.py [--kind ani1x|ani2x] [--members M] [--batch 2560] [--atoms 24]
+
+Synthetic ANI-1x-like conformers (H C N O, 2..atoms real atoms, padded with -1), seeded random weights.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def conformers(n_mol, n_at, seed=5):
+    rs = np.random.RandomState(seed)
+    sp = np.full((n_mol, n_at), -1, dtype=np.int64)
+    x = np.zeros((n_mol, n_at, 3), dtype=np.float32)
+    # a jittered lattice of spacing 1.1 A gives organic-molecule-like neighbor counts without rejection sampling
+    side = int(np.ceil(n_at ** (1 / 3)))
+    grid = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    for m in range(n_mol):
+        k = rs.randint(2, n_at + 1)
+        pick = rs.permutation(len(grid))[:k]
+        x[m, :k] = 1.1 * grid[pick] + rs.uniform(-0.15, 0.15, (k, 3)).astype(np.float32)
+        sp[m, :k] = rs.choice([0, 1, 2, 3], size=k, p=[0.5, 0.3, 0.1, 0.1])
+    return sp, x
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kind", default="ani1x")
+    ap.add_argument("--members", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=2560)
+    ap.add_argument("--atoms", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    from torchani_amd.models import ANI1x, ANI2x
+
+    dev = torch.device("cuda:0")
+    ctor = ANI2x if args.kind == "ani2x" else ANI1x
+    model = ctor(seed=0, n_members=args.members, device=dev, periodic_table_index=False, neighborlist="batch")
+    nets = model.neural_networks
+    nets.requires_grad_(True)
+    opt = torch.optim.Adam(nets.parameters(), lr=1e-4)
+    sp, x = conformers(args.batch, args.atoms)
+    spd, xd = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev)
+    n_at = (spd >= 0).sum(dim=1).float()
+    target = torch.from_numpy(np.random.RandomState(1).normal(0, 0.1, args.batch).astype(np.float32)).to(dev)
+    acc = dict(aev=0.0, nn=0.0, backward=0.0, optimizer=0.0)
+
+    def step(timed):
+        def mark():
+            torch.cuda.synchronize()
+            return time.perf_counter()
+        t0 = mark()
+        aev = model.aev_computer(spd, xd)
+        t1 = mark()
+        e = nets(spd, aev)
+        t2 = mark()
+        loss = (torch.nn.functional.mse_loss(e, target, reduction="none") / n_at.sqrt()).mean()
+        opt.zero_grad()
+        loss.backward()
+        t3 = mark()
+        opt.step()
+        t4 = mark()
+        if timed:
+            for k, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                acc[k] += v
+        return float(loss.detach())
+
+    for _ in range(args.warmup):
+        step(False)
+    losses = [step(True) for _ in range(args.steps)]
+    total = sum(acc.values()) / args.steps
+    n_real = int((sp >= 0).sum())
+    print(f"config 5: {args.kind} x{args.members}, batch {args.batch} conformers ({n_real} atoms): "
+          f"{total * 1e3:.2f} ms/step = {args.batch / total:.0f} conformers/s")
+    print("  " + "  ".join(f"{k} {v / args.steps * 1e3:.2f} ms" for k, v in acc.items()))
+    print(f"  loss {losses[0]:.5f} -> {losses[-1]:.5f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,7 @@ class _AEVFunction(torch.autograd.Function):
         return aev.view(species32.shape[0], species32.shape[1], eng.L).to(coords.dtype)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable   # no AEV double backward yet: raise rather than mislead
     def backward(ctx, grad_aev: Tensor):
         g = grad_aev.to(torch.float32).contiguous()
         gc = ctx.eng.backward(ctx.species32, ctx.nbrs, g)
@@ -78,6 +79,7 @@ class _AEVFromRowsFunction(torch.autograd.Function):
         return aev.view(species32.shape[0], species32.shape[1], eng.L).to(coords.dtype)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable   # no AEV double backward yet: raise rather than mislead
     def backward(ctx, grad_aev: Tensor):
         g = grad_aev.to(torch.float32).contiguous()
         gc = ctx.eng.backward(ctx.species32, ctx.nbrs, g)

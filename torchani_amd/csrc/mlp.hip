@@ -1666,7 +1666,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs g)
 
 // out[col] += sum over the rows of species s of  scale(row) * X[row][col]   (bias gradients: X = D, scale = 1;
 // output layer: X = last activations, scale = upstream / M, and extra[m] += sum of the scales = d Loss / d b3)
-constexpr int CR_ROWS = 512;
+constexpr int CR_ROWS = 64;
 struct ColReduceArgs {
     const float *X[MAX_S];
     float *out[MAX_S];
@@ -1699,6 +1699,45 @@ __global__ __launch_bounds__(256) void k_col_reduce(ColReduceArgs g)
     }
     if (cv) atomicAdd(g.out[s] + col, acc);
     if (g.extra[s] && ct == 0 && threadIdx.x < g.M) atomicAdd(g.extra[s] + threadIdx.x, sacc);
+}
+
+// ---- parameter refresh (training) ----------------------------------------------------------------------
+// Rewrites the packed fp32 arrays (w, wt, bias; layouts in include/anihip.h) from the torch.nn.Linear tensors they
+// were packed from, after an optimizer step: one thread per source weight, two scattered stores.
+struct RepackArgs {
+    const float *const *src;   // device: [M][S][nl][2] pointers {weight [out][in], bias [out]}
+    float *w[MAX_S][ANIHIP_MAX_LAYERS], *wt[MAX_S][ANIHIP_MAX_LAYERS], *bias[MAX_S][ANIHIP_MAX_LAYERS];
+    int dims[MAX_S][ANIHIP_MAX_LAYERS + 1];   // padded widths
+    int out[MAX_S][ANIHIP_MAX_LAYERS], in[MAX_S][ANIHIP_MAX_LAYERS];   // widths of the source tensors
+    int S, M, nl, k0p;
+};
+
+__global__ __launch_bounds__(256) void k_repack(RepackArgs g)
+{
+    int id = blockIdx.y;
+    const int l = id % g.nl; id /= g.nl;
+    const int s = id % g.S;
+    const int m = id / g.S;
+    const int out = g.out[s][l], in = g.in[s][l];
+    const float *W = g.src[((m * g.S + s) * g.nl + l) * 2 + 0];
+    const float *b = g.src[((m * g.S + s) * g.nl + l) * 2 + 1];
+    const int inp = g.dims[s][l], outp = g.dims[s][l + 1];
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < (int64_t)out * in; e += (int64_t)gridDim.x * 256) {
+        const int o = (int)(e / in), k = (int)(e - (int64_t)o * in);
+        const float v = W[e];
+        if (l == g.nl - 1) {
+            g.w[s][l][(int64_t)m * inp + k] = v;
+        } else if (l == 0) {
+            g.w[s][l][(int64_t)k * ((int64_t)g.M * outp) + (int64_t)m * outp + o] = v;
+            g.wt[s][l][((int64_t)m * outp + o) * g.k0p + k] = v;
+        } else {
+            g.w[s][l][((int64_t)m * inp + k) * outp + o] = v;
+            g.wt[s][l][((int64_t)m * outp + o) * inp + k] = v;
+        }
+    }
+    if (blockIdx.x == 0)
+        for (int o = threadIdx.x; o < out; o += 256)
+            g.bias[s][l][(l == g.nl - 1) ? m : (int64_t)m * outp + o] = b[o];
 }
 
 // padding atoms inside the shard: zero energy / zero gradient rows
@@ -2118,10 +2157,133 @@ extern "C" size_t anihip_mlp_train_workspace_bytes(const anihip_mlp_desc *d, int
     return mlp_train_carve(d, n_central, nullptr, nullptr, nullptr);
 }
 
+// bucketing + exact-fp32 forward with the activations kept in the workspace (first half of the training pass)
+static int train_forward(hipStream_t stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo, int64_t hi,
+                         const int32_t *species, const float *aev, MlpWorkspace &w, float *atomic_e,
+                         float *grad_aev)
+{
+    const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1, L = d->aev_len;
+    const int64_t n = hi - lo;
+    zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
+    const unsigned nblk = (unsigned)((n + 255) / 256);
+    const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
+    hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl);
+    hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(64), 0, stream, S, w.ctl);
+    hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, w.perm);
+    hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
+                       atomic_e, grad_aev, L, (float *)nullptr, M, n_atoms);
+    for (int l = 0; l < nh; ++l) {
+        GemmArgs g{};
+        g.ctl = w.ctl; g.S = S; g.alpha = d->celu_alpha; g.inv_alpha = 1.0f / d->celu_alpha;
+        g.nrow_tiles_ub = (int)((n + BM - 1) / BM) + S;
+        g.amax_in = g.amax_out = -1;
+        g.C = w.act[l]; g.ldc = w.ld[l];
+        int wmax = 0;
+        for (int s = 0; s < S; ++s) wmax = wmax > d->net[s].dims[l + 1] ? wmax : d->net[s].dims[l + 1];
+        if (l == 0) {
+            g.A = aev; g.lda = L; g.a_gather = w.perm; g.batch = 1;
+            g.ncol_max = (wmax * M + BN - 1) / BN;
+        } else {
+            g.A = w.act[l - 1]; g.lda = w.ld[l - 1]; g.batch = M;
+            g.ncol_max = (wmax + BN - 1) / BN;
+        }
+        for (int s = 0; s < S; ++s) {
+            const anihip_species_net &nn = d->net[s];
+            GemmProblem &p = g.prob[s];
+            p.B = nn.w[l]; p.bias = nn.bias[l];
+            if (l == 0) {
+                p.K = nn.dims[0]; p.N = nn.dims[1] * M; p.ldb = p.N;
+            } else {
+                p.K = nn.dims[l]; p.N = nn.dims[l + 1]; p.ldb = p.N;
+                p.a_boff = nn.dims[l]; p.c_boff = nn.dims[l + 1];
+                p.b_stride = (int64_t)p.K * p.N; p.bias_stride = p.N;
+            }
+        }
+        launch_gemm<EPI_BIAS_CELU>(stream, g, false);
+    }
+    return 0;
+}
+
+static void train_head(hipStream_t stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t n, MlpWorkspace &w,
+                       float *seed, const float *g_atom, float *atomic_e)
+{
+    const int S = d->num_species, nl = d->net[0].n_layers, nh = nl - 1;
+    HeadArgs h{};
+    for (int s = 0; s < S; ++s) {
+        h.w[s] = d->net[s].w[nl - 1];
+        h.bias[s] = d->net[s].bias[nl - 1];
+        h.Hp[s] = d->net[s].dims[nl - 1];
+    }
+    h.ctl = w.ctl; h.perm = w.perm; h.act = w.act[nh - 1]; h.ld = w.ld[nh - 1];
+    h.seed = seed; h.g_atom = g_atom;
+    h.atomic_e = atomic_e; h.member_e = nullptr; h.n_atoms = n_atoms; h.S = S; h.M = d->n_members;
+    h.inv_alpha = 1.0f / d->celu_alpha; h.want_grad = seed ? 1 : 0; h.amax = nullptr; h.amax_out = 0;
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(k_head, dim3((unsigned)blocks), dim3(256), 0, stream, h);
+}
+
+extern "C" int anihip_mlp_train_forward(void *stream_, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo,
+                                        int64_t hi, const int32_t *species, const float *aev, void *workspace,
+                                        size_t workspace_bytes, float *atomic_e)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_desc(d)) return rc;
+    ANIHIP_REQUIRE(species && aev && workspace && atomic_e, "null pointer argument");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    const int64_t n = hi - lo;
+    if (n == 0) return 0;
+    ANIHIP_REQUIRE(workspace_bytes >= mlp_train_carve(d, n, nullptr, nullptr, nullptr), "workspace too small");
+    MlpWorkspace w;
+    float *dlt[ANIHIP_MAX_LAYERS];
+    mlp_train_carve(d, n, (char *)workspace, &w, dlt);
+    if (int rc = train_forward(stream, d, n_atoms, lo, hi, species, aev, w, atomic_e, nullptr)) return rc;
+    train_head(stream, d, n_atoms, n, w, nullptr, nullptr, atomic_e);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int anihip_mlp_repack(void *stream_, const anihip_mlp_desc *d, const void *const *src,
+                                 const int32_t *out_in)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_desc(d)) return rc;
+    ANIHIP_REQUIRE(src && out_in, "null pointer argument");
+    ANIHIP_REQUIRE(d->precision == ANIHIP_MLP_FP32, "only fp32 descriptors can be refreshed in place (the fp16 "
+                                                    "planes of an F16X3 descriptor would go stale)");
+    RepackArgs a{};
+    a.src = (const float *const *)src;
+    a.S = d->num_species; a.M = d->n_members; a.nl = d->net[0].n_layers;
+    a.k0p = ((d->aev_len + 31) / 32) * 32;
+    int64_t biggest = 0;
+    for (int s = 0; s < a.S; ++s) {
+        const anihip_species_net &nn = d->net[s];
+        for (int l = 0; l <= a.nl; ++l) a.dims[s][l] = nn.dims[l];
+        for (int l = 0; l < a.nl; ++l) {
+            a.out[s][l] = out_in[(s * a.nl + l) * 2 + 0];
+            a.in[s][l] = out_in[(s * a.nl + l) * 2 + 1];
+            ANIHIP_REQUIRE(a.out[s][l] >= 1 && a.out[s][l] <= nn.dims[l + 1] && a.in[s][l] >= 1 &&
+                               a.in[s][l] <= nn.dims[l],
+                           "species %d layer %d: source shape outside the packed shape", s, l);
+            a.w[s][l] = const_cast<float *>(nn.w[l]);
+            a.wt[s][l] = const_cast<float *>(nn.wt[l]);
+            a.bias[s][l] = const_cast<float *>(nn.bias[l]);
+            const int64_t e = (int64_t)a.out[s][l] * a.in[s][l];
+            biggest = biggest > e ? biggest : e;
+        }
+    }
+    unsigned bx = (unsigned)((biggest + 256 * 8 - 1) / (256 * 8));
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_repack, dim3(bx, (unsigned)(a.M * a.S * a.nl)), dim3(256), 0, stream, a);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo,
                                        int64_t hi, const int32_t *species, const float *aev,
                                        const float *grad_atomic_e, void *workspace, size_t workspace_bytes,
-                                       const anihip_species_grads *grads, float *atomic_e, float *grad_aev)
+                                       const anihip_species_grads *grads, float *atomic_e, float *grad_aev,
+                                       int32_t forward_done)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
@@ -2148,15 +2310,14 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
     mlp_train_carve(d, n, (char *)workspace, &w, dlt);
     const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
 
-    // 1. bucket by species
-    zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
-    const unsigned nblk = (unsigned)((n + 255) / 256);
-    const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
-    hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl);
-    hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(64), 0, stream, S, w.ctl);
-    hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, w.perm);
-    hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
-                       atomic_e, grad_aev, L, (float *)nullptr, M, n_atoms);
+    // 1.-2. bucket by species, forward in exact fp32 with the activations kept (or reuse anihip_mlp_train_forward's)
+    if (!forward_done) {
+        if (int rc = train_forward(stream, d, n_atoms, lo, hi, species, aev, w, atomic_e, grad_aev)) return rc;
+    } else if (grad_aev) {
+        const unsigned nblk = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
+                           atomic_e, grad_aev, L, (float *)nullptr, M, n_atoms);
+    }
     const int nrow_ub = (int)((n + BM - 1) / BM) + S;
     auto width_max = [&](int l) {
         int mx = 0;
@@ -2170,48 +2331,8 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
         return g;
     };
 
-    // 2. forward in exact fp32, activations kept
-    for (int l = 0; l < nh; ++l) {
-        GemmArgs g = gemm_base();
-        g.C = w.act[l]; g.ldc = w.ld[l];
-        if (l == 0) {
-            g.A = aev; g.lda = L; g.a_gather = w.perm; g.batch = 1;
-            g.ncol_max = (width_max(1) * M + BN - 1) / BN;
-        } else {
-            g.A = w.act[l - 1]; g.lda = w.ld[l - 1]; g.batch = M;
-            g.ncol_max = (width_max(l + 1) + BN - 1) / BN;
-        }
-        for (int s = 0; s < S; ++s) {
-            const anihip_species_net &nn = d->net[s];
-            GemmProblem &p = g.prob[s];
-            p.B = nn.w[l]; p.bias = nn.bias[l];
-            if (l == 0) {
-                p.K = nn.dims[0]; p.N = nn.dims[1] * M; p.ldb = p.N;
-            } else {
-                p.K = nn.dims[l]; p.N = nn.dims[l + 1]; p.ldb = p.N;
-                p.a_boff = nn.dims[l]; p.c_boff = nn.dims[l + 1];
-                p.b_stride = (int64_t)p.K * p.N; p.bias_stride = p.N;
-            }
-        }
-        launch_gemm<EPI_BIAS_CELU>(stream, g, false);
-    }
-
     // 3. output layer: energies, seed of the backward pass (scaled by the upstream gradient), d w_out, d b_out
-    {
-        HeadArgs h{};
-        for (int s = 0; s < S; ++s) {
-            h.w[s] = d->net[s].w[nl - 1];
-            h.bias[s] = d->net[s].bias[nl - 1];
-            h.Hp[s] = d->net[s].dims[nl - 1];
-        }
-        h.ctl = w.ctl; h.perm = w.perm; h.act = w.act[nh - 1]; h.ld = w.ld[nh - 1];
-        h.seed = dlt[nh - 1]; h.g_atom = grad_atomic_e;
-        h.atomic_e = atomic_e; h.member_e = nullptr; h.n_atoms = n_atoms; h.S = S; h.M = M;
-        h.inv_alpha = inv_alpha; h.want_grad = 1; h.amax = nullptr; h.amax_out = 0;
-        int64_t blocks = (n + 3) / 4;
-        if (blocks > 256 * 8) blocks = 256 * 8;
-        hipLaunchKernelGGL(k_head, dim3((unsigned)blocks), dim3(256), 0, stream, h);
-    }
+    train_head(stream, d, n_atoms, n, w, dlt[nh - 1], grad_atomic_e, atomic_e);
     const int cr_chunks = (int)((n + CR_ROWS - 1) / CR_ROWS) + S;
     auto col_reduce = [&](int l, const float *X, int64_t ldx, bool output_layer) {
         ColReduceArgs c{};

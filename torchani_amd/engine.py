@@ -431,8 +431,43 @@ class PackedNetworks:
                 _row_ptr(grad_aev, rows0, self.aev_len) if want_grad else None, _ptr(member_e)))
         return atomic_e, (grad_aev if want_grad else None), member_e
 
+    def refresh(self, weights, biases) -> None:
+        """Re-read the parameter values (same shapes as at construction) into the packed fp32 arrays with one kernel
+        (anihip_mlp_repack); only for precision="fp32" packs, which is what the training pass reads."""
+        M, S, nl = self.M, self.S, self.nl
+        ptrs = [t.data_ptr() for m in range(M) for s in range(S) for l in range(nl)
+                for t in (weights[m][s][l], biases[m][s][l])]
+        key = tuple(ptrs)
+        if getattr(self, "_src_key", None) != key:
+            for m in range(M):
+                for s in range(S):
+                    for l in range(nl):
+                        W, b = weights[m][s][l], biases[m][s][l]
+                        if (tuple(W.shape) != self.shapes[s][l] or W.dtype != torch.float32 or not W.is_contiguous()
+                                or b.dtype != torch.float32 or not b.is_contiguous() or W.device != self.device):
+                            raise ValueError("refresh() needs contiguous fp32 parameters of the packed shapes")
+            self._src_tab = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+            self._src_key = key
+            self._out_in = np.asarray(self.shapes, dtype=np.int32).reshape(-1).copy()
+        _lib.check(_lib.lib().anihip_mlp_repack(_stream(), C.byref(self.desc), _ptr(self._src_tab),
+                                                self._out_in.ctypes.data))
+
+    def train_forward(self, species: Tensor, aev: Tensor) -> tp.Tuple[Tensor, Tensor]:
+        """First half of a training step: exact-fp32 forward that keeps the activations.  Returns (atomic_e [N],
+        workspace) -- hand the workspace to weight_grads(..., workspace=ws) for the backward half."""
+        _require_cuda(species, aev)
+        n = species.numel()
+        assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == n * self.aev_len
+        L = _lib.lib()
+        ws = torch.empty(L.anihip_mlp_train_workspace_bytes(C.byref(self.desc), n), dtype=torch.uint8,
+                         device=aev.device)
+        atomic_e = torch.zeros(n, dtype=torch.float32, device=aev.device)
+        _lib.check(L.anihip_mlp_train_forward(_stream(), C.byref(self.desc), n, 0, n, _ptr(species), _ptr(aev),
+                                              _ptr(ws), ws.numel(), _ptr(atomic_e)))
+        return atomic_e, ws
+
     def weight_grads(self, species: Tensor, aev: Tensor, grad_atomic_e: Tensor,
-                     want_grad_aev: bool = False, chunk: int = 1 << 16):
+                     want_grad_aev: bool = False, chunk: int = 1 << 16, workspace: tp.Optional[Tensor] = None):
         """Training pass (anihip_mlp_weight_grads): gradients of  sum_i grad_atomic_e[i] * atomic_e[i]  with respect
         to every weight and bias, returned in torch.nn.Linear layout: gw[m][s][l] [out, in], gb[m][s][l] [out];
         plus atomic_e [N] and, optionally, d Loss / d aev [N, L].  Replaces torch autograd through
@@ -455,6 +490,8 @@ class PackedNetworks:
         grad_aev = torch.zeros((n, self.aev_len), dtype=torch.float32, device=dev) if want_grad_aev else None
         L = _lib.lib()
         total = None
+        if workspace is not None:
+            chunk = max(n, 1)   # the forward half ran over all atoms at once (train_forward)
         for c0 in range(0, max(n, 1), chunk):
             c1 = min(n, c0 + chunk)
             buf = torch.empty(int(offs[-1]), dtype=torch.float32, device=dev)
@@ -466,11 +503,16 @@ class PackedNetworks:
                     sg[s].gbias[l] = buf.data_ptr() + 4 * int(offs[q + 1])
                     q += 2
             need = L.anihip_mlp_train_workspace_bytes(C.byref(d), c1 - c0)
-            if self._train_ws is None or self._train_ws.numel() < need:
-                self._train_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            if workspace is not None:
+                ws = workspace
+                assert ws.numel() >= need
+            else:
+                if self._train_ws is None or self._train_ws.numel() < need:
+                    self._train_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                ws = self._train_ws
             _lib.check(L.anihip_mlp_weight_grads(
-                _stream(), C.byref(d), n, c0, c1, _ptr(species), _ptr(aev), _ptr(g_at), _ptr(self._train_ws),
-                self._train_ws.numel(), sg, _ptr(atomic_e), _ptr(grad_aev)))
+                _stream(), C.byref(d), n, c0, c1, _ptr(species), _ptr(aev), _ptr(g_at), _ptr(ws),
+                ws.numel(), sg, _ptr(atomic_e), _ptr(grad_aev), 1 if workspace is not None else 0))
             total = buf if total is None else total.add_(buf)
         # unpack into Linear layout
         gw = [[[None] * nl for _ in range(S)] for _ in range(M)]

@@ -51,6 +51,11 @@ class AtomicNetwork(torch.nn.Module):
         return list(self.layers) + [self.final_layer]
 
 
+# training batches up to this many atoms keep their activations between forward and backward (39 KB / atom for
+# ANI-2x x 8); larger ones recompute the forward chunk by chunk inside the backward call
+_TRAIN_SPLIT_MAX_ATOMS = 1 << 17
+
+
 class _MLPFunction(torch.autograd.Function):
     """params = the Linear parameters in the order member -> species -> layer -> (weight, bias)."""
 
@@ -61,11 +66,17 @@ class _MLPFunction(torch.autograd.Function):
         train = any(p.requires_grad for p in params)
         need_grad = aevs.requires_grad and not train
         a32 = aevs.detach().to(torch.float32).contiguous().view(C * A, -1)
-        ae, g, me = packed.forward_backward(species32, a32, want_grad=need_grad, want_members=want_members)
+        ws = None
+        if train and not want_members and C * A <= _TRAIN_SPLIT_MAX_ATOMS:
+            # first half of the training pass: exact-fp32 forward, activations stay in ws for backward
+            ae, ws = packed.train_forward(species32, a32)
+            g = me = None
+        else:
+            ae, g, me = packed.forward_backward(species32, a32, want_grad=need_grad, want_members=want_members)
         ctx.g = g
         ctx.train = train
         ctx.aev_grad = aevs.requires_grad
-        ctx.saved = (a32, species32, packed) if train else None
+        ctx.saved = (a32, species32, packed, ws) if train else None
         ctx.param_dtypes = [p.dtype for p in params]
         ctx.in_dtype = aevs.dtype
         ctx.shape = aevs.shape
@@ -82,8 +93,9 @@ class _MLPFunction(torch.autograd.Function):
         if ctx.train:
             # training pass: forward recomputed in exact fp32 with the activations kept, then d/d weights, d/d biases
             # (and d/d aev scaled by the upstream gradient) in one engine call
-            a32, species32, packed = ctx.saved
-            gw, gb, _, gaev = packed.weight_grads(species32, a32, grad_out.contiguous(), want_grad_aev=ctx.aev_grad)
+            a32, species32, packed, ws = ctx.saved
+            gw, gb, _, gaev = packed.weight_grads(species32, a32, grad_out.contiguous(), want_grad_aev=ctx.aev_grad,
+                                                  workspace=ws)
             flat = []
             for m in range(packed.M):
                 for s in range(packed.S):
@@ -126,16 +138,39 @@ class _EngineContainer(torch.nn.Module):
             cache[key] = PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, precision)
         return cache[key]
 
+    def _train_pack(self, device: torch.device) -> PackedNetworks:
+        """fp32 pack read by the training pass; built once per parameter set and refreshed in place (one kernel,
+        anihip_mlp_repack) whenever an optimizer step changed the parameters."""
+        members = self._member_networks()
+        lins = [[m.atomics[s].linears() for s in self.symbols] for m in members]
+        weights = [[[lin.weight for lin in sl] for sl in ml] for ml in lins]
+        biases = [[[lin.bias for lin in sl] for sl in ml] for ml in lins]
+        params = [p for ml in lins for sl in ml for lin in sl for p in (lin.weight, lin.bias)]
+        key = (device, tuple(p.data_ptr() for p in params), tuple(tuple(p.shape) for p in params))
+        versions = tuple(p._version for p in params)
+        cache = self.__dict__.setdefault("_train_cache", {})
+        if key not in cache:
+            cache.clear()
+            aev_len = weights[0][0][0].shape[1]
+            cache[key] = [PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, "fp32"), versions]
+        elif cache[key][1] != versions:
+            cache[key][0].refresh(weights, biases)
+            cache[key][1] = versions
+        return cache[key][0]
+
     def _run(self, elem_idxs: Tensor, aevs: Tensor, atomic: bool, ensemble_values: bool) -> Tensor:
         if not aevs.is_cuda:
             raise ValueError("torchani_amd's network containers need tensors on a ROCm device")
         species32 = elem_idxs.to(torch.int32).contiguous()
-        packed = self._pack(aevs.device)
         params: tp.List[Tensor] = []
         if torch.is_grad_enabled():
             lins = [lin for m in self._member_networks() for s in self.symbols for lin in m.atomics[s].linears()]
             if any(lin.weight.requires_grad or lin.bias.requires_grad for lin in lins):
                 params = [p for lin in lins for p in (lin.weight, lin.bias)]
+        trainable_fast = (params and not ensemble_values
+                          and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == aevs.device
+                                  for p in params))
+        packed = self._train_pack(aevs.device) if trainable_fast else self._pack(aevs.device)
         out = _MLPFunction.apply(aevs, species32, packed, ensemble_values, *params)
         # [C, A] (or [M, C, A]); molecular energies are the sum over atoms (nn/_containers.py:417-421)
         return out if atomic else out.sum(dim=-1)
