@@ -133,6 +133,19 @@ int anihip_nbr_from_full(void *stream, const anihip_aev_params *p, int64_t n_ato
                          const int64_t *start, const int32_t *jlist, uint32_t *meta, float *ent,
                          int64_t ent_capacity, uint32_t *status);
 
+/* Verlet-skin reuse (VerletCellList, neighbors.py:759-884): verlet_meta / verlet_ent are rows produced by one of the
+ * builders above from coords_build with an ENLARGED radial cutoff (Rcr + skin; the caller passes a copy of the
+ * parameters with Rcr raised -- and Rca lowered to ~0 so that all of a row counts against the 256-entry radial
+ * limit).  While no atom has moved more than skin / 2 since then, the rows for the current coordinates follow
+ * without a pair search: every stored displacement is updated with the motion of its two atoms, screened against
+ * the real Rcr of p and re-sorted (the narrow_down step, neighbors.py:64-113).  coords and coords_build must be the
+ * same unwrapped trajectory (an atom re-wrapped by a lattice vector in between looks like a large move: rebuild).
+ * Rows come out for lo <= i < hi in the standard format; ent_capacity = (hi - lo) * row capacity. */
+int anihip_nbr_refresh(void *stream, const anihip_aev_params *p, int64_t n_atoms, int64_t lo, int64_t hi,
+                       const int32_t *species, const float *coords, const float *coords_build,
+                       const uint32_t *verlet_meta, const float *verlet_ent, uint32_t *meta, float *ent,
+                       int64_t ent_capacity, uint32_t *status);
+
 /* ---------------------------------------------------------------------------------------------
  * AEV forward / backward: replace cuRadialAEVs + cuAngularAEVs (csrc/aev.cu:768-834,323-472) and their
  * backward kernels (csrc/aev.cu:837-967,474-766).  aev / grad_aev are [n_atoms, L] row-major with

@@ -270,3 +270,17 @@ def test_cutoff_fn_selection():
     assert AevEngine(AEVComputer.like_1x().constants()).params.cutoff_kind == 0
     with pytest.raises(ValueError, match="cutoff"):
         AEVComputer.like_2x(cutoff_fn="biweight")
+
+
+def test_verlet_neighborlist_selection():
+    """neighborlist names of the reference (neighbors.py:899-914); the Verlet skin must be positive (:767-768)."""
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.engine import VerletRows
+
+    assert AEVComputer.like_2x(neighborlist="cell_list").verlet is None
+    v = AEVComputer.like_2x(neighborlist="verlet_cell_list", skin=0.8)
+    assert isinstance(v.verlet, VerletRows) and v.verlet.skin == 0.8 and v.neighbor_mode == "cell"
+    with pytest.raises(ValueError, match="skin"):
+        VerletRows(0.0)
+    with pytest.raises(ValueError, match="neighborlist"):
+        AEVComputer.like_2x(neighborlist="octree")

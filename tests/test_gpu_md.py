@@ -1,0 +1,128 @@
+"""GPU tests of the Verlet-skin neighbor reuse (anihip_nbr_refresh; the reference's VerletCellList,
+neighbors.py:759-884) and of the MD driver built on it (the reference drives the same path through
+ASE, torchani/ase.py + tools/md-benchmark.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from _util import load_golden, seeded_state
+from test_gpu_parity import report
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from torchani_amd import _lib
+
+    _lib.lib()  # fail loudly if the native library is missing
+    return torch.device("cuda:0")
+
+
+def water(side):
+    from bench import water_box
+
+    sp, x, cell = water_box(side)
+    return sp.astype(np.int32), x.astype(np.float32), cell.astype(np.float32), (True, True, True)
+
+
+def cases():
+    out = {}
+    sp, x, cell, pbc = water(10)
+    out["water3000_cell"] = (sp, x, cell, pbc, "cell")
+    g = load_golden("triclinic_pbc_ani2x")
+    out["triclinic_batch"] = (g["species"].astype(np.int32), g["coords"], g["cell"], tuple(bool(b) for b in g["pbc"]),
+                              "batch")
+    g = load_golden("rand_batch_ani2x")
+    out["rand_batch"] = (g["species"].astype(np.int32), g["coords"], None, None, "batch")
+    return out
+
+
+@pytest.mark.parametrize("name", ["water3000_cell", "triclinic_batch", "rand_batch"])
+def test_verlet_refresh_equals_rebuild(dev, name):
+    from torchani_amd.constants import aev_constants_2x
+    from torchani_amd.engine import AevEngine, VerletRows
+
+    sp, x, cell, pbc, mode = cases()[name]
+    eng = AevEngine(aev_constants_2x())
+    spd = torch.from_numpy(sp).to(dev)
+    x0 = torch.from_numpy(x).to(dev).contiguous()
+    cd = None if cell is None else torch.from_numpy(cell).to(dev)
+    n = spd.numel()
+    ver = VerletRows(skin=1.0)
+    r0 = ver.rows(eng, spd, x0, cd, pbc, 0, n, mode, 256)
+    f0 = eng.neighbors(spd, x0, cd, pbc, mode=mode, row_cap=256)
+    assert torch.equal(r0.meta[:, 1:], f0.meta[:, 1:])      # same counts per class and species at the build point
+    rs = np.random.RandomState(3)
+    # every atom moves by less than skin / 2 = 0.5 A (|delta| <= 0.28 sqrt(3) = 0.485)
+    x1 = (x0 + torch.from_numpy(rs.uniform(-0.28, 0.28, x.shape).astype(np.float32)).to(dev)).contiguous()
+    r1 = ver.rows(eng, spd, x1, cd, pbc, 0, n, mode, 256)
+    assert (ver.n_builds, ver.n_reuses) == (1, 1)
+    f1 = eng.neighbors(spd, x1, cd, pbc, mode=mode, row_cap=256)
+    assert int(r1.status[0]) & 3 == 0 and int(f1.status[0]) & 3 == 0
+    # identical neighbor sets: counts per (class, species) match exactly; the AEVs (sums over the rows) to round-off
+    same = torch.equal(r1.meta[:, 1:], f1.meta[:, 1:])
+    a1, b1 = eng.forward(spd, r1), eng.forward(spd, f1)
+    err = (a1 - b1).abs().max().item()
+    report(f"verlet {name:16s} refresh vs rebuild: counts equal = {same}  max|aev diff| = {err:.2e}")
+    assert same and err < 2e-5
+    # the backward pass through refreshed rows
+    w = torch.from_numpy(rs.uniform(-1, 1, tuple(a1.shape)).astype(np.float32)).to(dev)
+    ga, gb = eng.backward(spd, r1, w), eng.backward(spd, f1, w)
+    assert (ga - gb).abs().max().item() < 1e-4 * max(1.0, gb.abs().max().item())
+    # one atom jumps beyond skin / 2: the pair search must run again
+    x2 = x1.clone()
+    x2.view(-1, 3)[0, 0] += 0.9
+    ver.rows(eng, spd, x2, cd, pbc, 0, n, mode, 256)
+    assert ver.n_builds == 2
+    # sharded refresh: rows of a sub-range equal the rows of the full call
+    lo, hi = n // 3, n // 3 + max(1, n // 4)
+    rpart = eng.refresh_rows(spd, x2, ver._coords0, ver._rows, lo, hi, 256)
+    rfull = eng.refresh_rows(spd, x2, ver._coords0, ver._rows, 0, n, 256)
+    assert torch.equal(rpart.meta[lo:hi, 1:], rfull.meta[lo:hi, 1:])
+
+
+def make_model(dev, neighborlist):
+    from torchani_amd.models import ANI2x
+
+    return ANI2x(state_dict=seeded_state("ani2x", 8, 7), device=dev, periodic_table_index=False,
+                 neighborlist=neighborlist)
+
+
+def test_md_verlet_matches_plain_and_conserves_energy(dev):
+    from torchani_amd.md import MolecularDynamics
+
+    sp, x, cell, pbc = water(10)
+    spd = torch.from_numpy(sp.astype(np.int64)).to(dev)
+    xd = torch.from_numpy(x).to(dev)
+    cd = torch.from_numpy(cell).to(dev)
+    masses = torch.tensor([1.008, 12.011, 14.007, 15.999, 32.06, 18.998, 35.45], device=dev)[spd]
+    runs = {}
+    for nl in ("cell_list", "verlet_cell_list"):
+        model = make_model(dev, nl)
+        md = MolecularDynamics(model, spd, xd, cd, pbc, dt=0.25, masses=masses, seed=1)
+        md.set_temperature(150.0)
+        e0 = md.total_energies().clone()
+        ke0 = md.kinetic_energies().clone()
+        md.run(60)
+        torch.cuda.synchronize()
+        runs[nl] = (md, e0, ke0)
+    md_p, e0, ke0 = runs["cell_list"]
+    md_v = runs["verlet_cell_list"][0]
+    ver = md_v.model.aev_computer.verlet
+    drift = (md_v.total_energies() - e0).abs().item()
+    dx = (md_v.coords - md_p.coords).abs().max().item()
+    moved = (md_v.coords - xd).norm(dim=-1).max().item()
+    dke = (md_v.kinetic_energies() - ke0).abs().item()
+    report(f"md     water 3000 atoms, 60 x 0.25 fs NVE: |dE_total| = {drift:.2e} Ha (|dKE| = {dke:.2e}, KE0 = "
+           f"{ke0.item():.3f}), max move {moved:.3f} A, verlet builds/reuses = {ver.n_builds}/{ver.n_reuses}, "
+           f"max|x_verlet - x_plain| = {dx:.2e} A")
+    assert ver.n_reuses > 0 and ver.n_builds >= 1
+    assert dx < 1e-3
+    assert drift < 0.02 * max(dke, 1e-3) + 1e-4

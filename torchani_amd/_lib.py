@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
     L.anihip_nbr_from_half.argtypes = [vp, C.POINTER(AevParams), i64, vp, i64, vp, vp, i64, i64, vp, sz, vp, vp,
                                        i64, vp]
     L.anihip_nbr_from_full.argtypes = [vp, C.POINTER(AevParams), i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.anihip_nbr_refresh.argtypes = [vp, C.POINTER(AevParams), i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.anihip_aev_forward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_aev_backward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_mlp_workspace_bytes.restype = sz
@@ -149,7 +150,8 @@ def lib() -> C.CDLL:
     L.anihip_mlp_train_forward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, sz, vp]
     L.anihip_mlp_repack.argtypes = [vp, C.POINTER(MlpDesc), vp, vp]
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
-    for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half", "anihip_nbr_from_full",
+    for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half",
+                 "anihip_nbr_from_full", "anihip_nbr_refresh",
                  "anihip_aev_forward", "anihip_aev_backward", "anihip_mlp_forward_backward",
                  "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce"):
         getattr(L, name).restype = C.c_int
@@ -162,7 +164,7 @@ def lib() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "anihip_last_error", "anihip_abi_version", "anihip_aev_table_pack", "anihip_nbr_workspace_bytes",
     "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_half_workspace_bytes", "anihip_nbr_from_half", "anihip_nbr_from_full",
-    "anihip_aev_forward", "anihip_aev_backward",
+    "anihip_nbr_refresh", "anihip_aev_forward", "anihip_aev_backward",
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
     "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
 ]

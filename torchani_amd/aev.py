@@ -13,7 +13,7 @@ import torch
 from torch import Tensor
 
 from .constants import AEVConstants, aev_constants_1x, aev_constants_2x
-from .engine import AevEngine, NeighborRows
+from .engine import AevEngine, NeighborRows, VerletRows
 from .tuples import Neighbors, SpeciesAEV
 
 
@@ -47,8 +47,7 @@ class _AEVFunction(torch.autograd.Function):
     def forward(ctx, coords: Tensor, species32: Tensor, cell, pbc, computer: "AEVComputer") -> Tensor:
         eng = computer.engine()
         c32 = coords.detach().to(torch.float32).contiguous()
-        nbrs = eng.neighbors(species32, c32, cell, pbc, mode=computer.neighbor_mode,
-                             row_cap=computer.row_capacity)
+        nbrs = computer.neighbor_rows(species32, c32, cell, pbc)
         aev = eng.forward(species32, nbrs)
         ctx.eng, ctx.nbrs, ctx.species32 = eng, nbrs, species32
         ctx.in_dtype = coords.dtype
@@ -91,7 +90,7 @@ class AEVComputer(torch.nn.Module):
     """Atomic environment vectors [C, A, S*16 + S(S+1)/2*32] on the MI355X engine."""
 
     def __init__(self, consts: AEVConstants, neighborlist: str = "auto", row_capacity: int = 128,
-                 strategy: str = "hip", cutoff_fn: tp.Optional[str] = None) -> None:
+                 strategy: str = "hip", cutoff_fn: tp.Optional[str] = None, skin: float = 1.0) -> None:
         super().__init__()
         if strategy not in ("hip", "auto"):
             # the reference raises ValueError for unknown strategies (aev/_computer.py:127-128)
@@ -103,10 +102,13 @@ class AEVComputer(torch.nn.Module):
             raise ValueError(f"Unsupported cutoff function {self.cutoff_fn!r}: the HIP kernels implement 'cosine' "
                              "(CutoffCosine) and 'smooth' (CutoffSmooth, order 2)")
         modes = {"auto": "auto", "all_pairs": "batch", "cell_list": "cell", "batch": "batch", "cell": "cell",
-                 "adaptive": "auto"}
+                 "adaptive": "auto", "fast_cell_list": "cell", "verlet_cell_list": "cell", "verlet": "auto"}
         if neighborlist not in modes:
-            raise ValueError(f"Unsupported neighborlist {neighborlist!r}")
+            raise ValueError(f"Unsupported neighborlist {neighborlist!r}")   # neighbors.py:899-914
         self.neighbor_mode = modes[neighborlist]
+        # Verlet-skin reuse of the pair search (VerletCellList, neighbors.py:759-884); "verlet" = the same on top of
+        # the batched builder for several molecules
+        self.verlet: tp.Optional[VerletRows] = VerletRows(skin) if neighborlist.startswith("verlet") else None
         self.row_capacity = int(row_capacity)
         self.num_species = consts.num_species
         self.radial = _RadialTerms(consts.EtaR, consts.ShfR, consts.Rcr)
@@ -178,6 +180,20 @@ class AEVComputer(torch.nn.Module):
             self._engine = AevEngine(self.constants())
             self._engine_key = key
         return self._engine
+
+    def neighbor_rows(self, species32: Tensor, c32: Tensor, cell: tp.Optional[Tensor] = None, pbc=None,
+                      lo: int = 0, hi: tp.Optional[int] = None) -> NeighborRows:
+        """Neighbor rows of the central atoms lo..hi for this computer's neighborlist setting (pair search, or
+        the Verlet-skin refresh of an earlier one)."""
+        eng = self.engine()
+        hi = species32.numel() if hi is None else hi
+        if self.verlet is not None:
+            mode = self.neighbor_mode
+            if mode == "auto":
+                mode = "cell" if (species32.shape[0] == 1 and species32.shape[1] > 512) else "batch"
+            return self.verlet.rows(eng, species32, c32, cell, pbc, lo, hi, mode, self.row_capacity)
+        return eng.neighbors(species32, c32, cell, pbc, lo=lo, hi=hi, mode=self.neighbor_mode,
+                             row_cap=self.row_capacity)
 
     def compute_from_neighbors(self, elem_idxs: Tensor, coords: Tensor, neighbors: Neighbors) -> Tensor:
         """AEVs from the result of an external neighbor-list calculation (aev/_computer.py:251-272): any

@@ -593,6 +593,52 @@ __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_full(int S, float rcr2, 
     }
 }
 
+// ---- Verlet-skin reuse -----------------------------------------------------------------------------------
+// Rows built once with an enlarged radial cutoff (Rcr + skin) stay a superset of every atom's neighborhood while
+// no atom has moved more than skin / 2 (VerletCellList, neighbors.py:759-884).  One wave per central atom walks its
+// stored row, updates each displacement with the motion since the build,
+//     d(t) = d(t0) + (x_j(t) - x_j(t0)) - (x_i(t) - x_i(t0))
+// (image shifts are constants of the stored row, so unwrapped coordinates need no cell here), screens it against the
+// real cutoff and emits a row in the standard order -- the narrow_down step of the reference (neighbors.py:64-113)
+// without the pair search.
+__global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_refresh(int S, float rcr2, float rca2, int64_t lo, int64_t hi,
+                                                               const int32_t *species, const float *coords,
+                                                               const float *coords0, const uint32_t *vmeta,
+                                                               const float4 *vent, int row_cap, uint32_t *meta,
+                                                               float4 *ent, uint32_t *status)
+{
+    __shared__ float4 s_hits[NBR_WPB][MAXR];
+    const int wib = threadIdx.x >> 6, lane = lane_id();
+    const int64_t nw = (int64_t)gridDim.x * NBR_WPB;
+    for (int64_t i = lo + blockIdx.x * (int64_t)NBR_WPB + wib; i < hi; i += nw) {
+        uint32_t *meta_i = meta + (size_t)i * META_W;
+        const size_t row0 = (size_t)(i - lo) * row_cap;
+        if (lane == 0) meta_i[0] = (uint32_t)row0;
+        const uint32_t *vm = vmeta + (size_t)i * META_W;
+        const int cnt = (int)(vm[1] & 0xFFFFu) + (int)(vm[1] >> 16);
+        if (species[i] < 0 || cnt == 0) {
+            if (lane == 0) { meta_i[1] = 0; meta_i[2] = 0; meta_i[3] = 0; meta_i[4] = 0; meta_i[5] = 0; }
+            continue;
+        }
+        const float mx = coords[3 * i] - coords0[3 * i], my = coords[3 * i + 1] - coords0[3 * i + 1],
+                    mz = coords[3 * i + 2] - coords0[3 * i + 2];
+        const float4 *row = vent + vm[0];
+        HitList h{s_hits[wib], 0, false};
+        for (int e0 = 0; e0 < cnt; e0 += WAVE) {
+            const int e = e0 + lane;
+            const bool v = e < cnt;
+            const float4 d0 = v ? row[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int64_t j = v ? (int64_t)(__float_as_uint(d0.w) & IDX_MASK) : i;
+            const float dx = d0.x + (coords[3 * j] - coords0[3 * j]) - mx;
+            const float dy = d0.y + (coords[3 * j + 1] - coords0[3 * j + 1]) - my;
+            const float dz = d0.z + (coords[3 * j + 2] - coords0[3 * j + 2]) - mz;
+            push_hits(h, v && dx * dx + dy * dy + dz * dz <= rcr2, dx, dy, dz, d0.w);
+        }
+        emit_row(h, S, rca2, row_cap, meta_i, ent + row0, status);
+        wave_sync();
+    }
+}
+
 // ---- rows from an external half neighbor list ---------------------------------------------------------
 // pass 1: every pair (a, b) with diff = r_a - r_b (+ image shift) appends {r_b - r_a, b} to row a and
 // {r_a - r_b, a} to row b (slot = atomic counter of the row; rows outside [lo, hi) are skipped)
@@ -795,6 +841,27 @@ extern "C" int anihip_nbr_from_half(void *stream_, const anihip_aev_params *p, i
     }
     hipLaunchKernelGGL(k_half_finish, dim3(nbr_grid_blocks(hi - lo)), dim3(NBR_WPB * WAVE), 0, stream,
                        p->num_species, p->Rca * p->Rca, lo, hi, species, cap, count, meta, (float4 *)ent, status);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int anihip_nbr_refresh(void *stream_, const anihip_aev_params *p, int64_t n, int64_t lo, int64_t hi,
+                                  const int32_t *species, const float *coords, const float *coords_build,
+                                  const uint32_t *verlet_meta, const float *verlet_ent, uint32_t *meta, float *ent,
+                                  int64_t ent_capacity, uint32_t *status)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    ANIHIP_REQUIRE(p && species && coords && coords_build && verlet_meta && verlet_ent && meta && ent && status,
+                   "null pointer argument");
+    ANIHIP_REQUIRE(p->num_species >= 1 && p->num_species <= MAX_S - 1, "num_species must be 1..7");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n, "central range outside 0..n_atoms");
+    if (hi == lo) return 0;
+    const int64_t row_cap = ent_capacity / (hi - lo);
+    ANIHIP_REQUIRE(row_cap >= 1 && (hi - lo) * row_cap < ((int64_t)1 << 32), "bad ent_capacity");
+    hipLaunchKernelGGL(k_nbr_refresh, dim3(nbr_grid_blocks(hi - lo)), dim3(NBR_WPB * WAVE), 0, stream,
+                       p->num_species, p->Rcr * p->Rcr, p->Rca * p->Rca, lo, hi, species, coords, coords_build,
+                       verlet_meta, (const float4 *)verlet_ent, (int)(row_cap > MAXR ? MAXR : row_cap), meta,
+                       (float4 *)ent, status);
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }

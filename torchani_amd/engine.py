@@ -195,6 +195,26 @@ class AevEngine:
             _ptr(start), _ptr(jl), _ptr(meta), _ptr(ent), n * row_cap, _ptr(status)))
         return NeighborRows(meta, ent, status, row_cap, 0, n)
 
+    def refresh_rows(self, species: Tensor, coords: Tensor, coords_build: Tensor, verlet: NeighborRows,
+                     lo: int = 0, hi: tp.Optional[int] = None, row_cap: int = 128) -> NeighborRows:
+        """Rows for the current coordinates from rows built at coords_build with cutoff Rcr + skin
+        (anihip_nbr_refresh): no pair search, valid while no atom moved more than skin / 2."""
+        _require_cuda(species, coords, coords_build)
+        assert coords.dtype == torch.float32 and coords.is_contiguous() and coords_build.is_contiguous()
+        n = species.numel()
+        hi = n if hi is None else hi
+        assert verlet.lo <= lo and hi <= verlet.hi and verlet.lo == 0, "Verlet rows must cover the central range"
+        row_cap = int(min(max(row_cap, 1), _lib.MAX_RAD))
+        n_central = max(hi - lo, 0)
+        dev = coords.device
+        meta = torch.empty((n, _lib.META_WORDS), dtype=torch.int32, device=dev)
+        ent = torch.empty((max(n_central, 1) * row_cap, 4), dtype=torch.float32, device=dev)
+        status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().anihip_nbr_refresh(
+            _stream(), C.byref(self.params), n, lo, hi, _ptr(species), _ptr(coords), _ptr(coords_build),
+            _ptr(verlet.meta), _ptr(verlet.ent), _ptr(meta), _ptr(ent), n_central * row_cap, _ptr(status)))
+        return NeighborRows(meta, ent, status, row_cap, lo, hi)
+
     # ---- AEV ----------------------------------------------------------------------------------------
     @property
     def n_slabs(self) -> int:
@@ -246,6 +266,57 @@ class AevEngine:
 
 def _pad32(x: int) -> int:
     return (x + 31) // 32 * 32
+
+
+class VerletRows:
+    """Neighbor rows with a Verlet skin (the reference's VerletCellList, neighbors.py:759-884): the pair search runs
+    with cutoff Rcr + skin and is repeated only when some atom has moved more than skin / 2 since (or the cell
+    changed); in between, rows come from anihip_nbr_refresh.  Like the reference, the displacement check is a
+    host-synchronising reduction."""
+
+    def __init__(self, skin: float = 1.0) -> None:
+        if skin <= 0.0:
+            raise ValueError("skin must be a positive float")
+        self.skin = float(skin)
+        self.reset_cached_values()
+        self.n_builds = 0
+        self.n_reuses = 0
+
+    def reset_cached_values(self) -> None:
+        self._wide: tp.Optional[AevEngine] = None
+        self._rows: tp.Optional[NeighborRows] = None
+        self._coords0: tp.Optional[Tensor] = None
+        self._cell0: tp.Optional[Tensor] = None
+        self._key: tp.Optional[tuple] = None
+
+    def _can_use_prev_list(self, coords: Tensor, cell: tp.Optional[Tensor], key: tuple) -> bool:
+        if self._rows is None or self._key != key or self._coords0.shape != coords.shape:
+            return False
+        if (cell is None) != (self._cell0 is None) or (cell is not None and not torch.equal(cell, self._cell0)):
+            return False
+        moved2 = (coords - self._coords0).pow(2).sum(-1).max()
+        return bool(moved2 < (0.5 * self.skin) ** 2)
+
+    def rows(self, eng: AevEngine, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor], pbc, lo: int, hi: int,
+             mode: str, row_cap: int) -> NeighborRows:
+        cell_d = None if cell is None else cell.detach().to(device=coords.device, dtype=torch.float32)
+        key = (eng.consts, tuple(species.shape), None if pbc is None else tuple(bool(b) for b in pbc), mode)
+        if not self._can_use_prev_list(coords, cell_d, key):
+            if self._wide is None or self._key is None or self._key[0] != eng.consts:
+                # every stored neighbor in the "far" class: rows may then hold up to 256 entries (include/anihip.h)
+                self._wide = AevEngine(eng.consts._replace(Rcr=eng.consts.Rcr + self.skin, Rca=1e-3))
+            self._rows = self._wide.neighbors(species, coords, cell, pbc, lo=0, hi=species.numel(), mode=mode,
+                                              row_cap=_lib.MAX_RAD)
+            self._coords0 = coords.clone()
+            self._cell0 = None if cell_d is None else cell_d.clone()
+            self._key = key
+            self.n_builds += 1
+        else:
+            self.n_reuses += 1
+        out = eng.refresh_rows(species, coords, self._coords0, self._rows, lo, hi, row_cap)
+        # a Verlet row that overflowed would silently lose neighbors: surface it in the refreshed rows' status
+        out.status.bitwise_or_(self._rows.status & (_lib.ST_ROW_OVERFLOW | _lib.ST_ENTRY_OVERFLOW))
+        return out
 
 
 class PackedNetworks:

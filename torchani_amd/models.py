@@ -121,8 +121,7 @@ class ANI(torch.nn.Module):
         aevc = self.aev_computer
         eng = aevc.engine()
         pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
-        nbrs = eng.neighbors(species32, c32, cell, pbc_t, lo=lo, hi=hi, mode=aevc.neighbor_mode,
-                             row_cap=aevc.row_capacity)
+        nbrs = aevc.neighbor_rows(species32, c32, cell, pbc_t, lo=lo, hi=hi)
         packed = self.neural_networks._pack(c32.device)
         # per-atom flags of the AEV slabs that are not identically zero (absent neighbor species): the
         # layer-0 GEMMs skip the others
