@@ -145,6 +145,50 @@ __device__ __forceinline__ void decode_pair2(bool same, int t, int nj, int div, 
     kr = diam ? t - rect + half : k2;
 }
 
+// The same decode advanced incrementally: pair t = qd * div + rem of slot p moves on by 16 per step, so the quotient /
+// remainder follow from two adds and a carry instead of a float division and an integer multiply per step.
+// 16 / div for the wave-uniform group size div (0 for div == 0), on the scalar unit
+__device__ __forceinline__ int quot16(int div)
+{
+    return div > 16 ? 0 : div > 8 ? 1 : div > 5 ? 2 : div == 5 ? 3 : div == 4 ? 4 : div == 3 ? 5 : div == 2 ? 8
+         : div == 1 ? 16 : 0;
+}
+struct PairIter {
+    int t, qd, rem;
+};
+__device__ __forceinline__ PairIter pair_begin(int t, int div, float inv_div)
+{
+    PairIter it;
+    it.t = t;
+    it.qd = (int)(((float)t + 0.5f) * inv_div);
+    it.rem = t - it.qd * div;
+    return it;
+}
+__device__ __forceinline__ void pair_next(PairIter &it, int div, int q16, int r16)
+{
+    it.t += 16;
+    it.rem += r16;
+    it.qd += q16;
+    const bool carry = it.rem >= div;   // (div == 0: only diameter pairs, qd / rem are not used)
+    it.rem -= carry ? div : 0;
+    it.qd += carry ? 1 : 0;
+}
+// (j, k) of the current pair, clamped into the groups (slots past the last pair read valid entries and are masked)
+__device__ __forceinline__ void pair_get(const PairIter &it, bool same, int nj, int rect, int half, int jmax,
+                                         int kmax, int &jr, int &kr)
+{
+    int j = it.qd, k = it.rem;
+    if (same) {   // wave-uniform
+        int k2 = it.qd + 1 + it.rem;
+        k2 -= k2 >= nj ? nj : 0;
+        const bool diam = it.t >= rect;
+        j = diam ? it.t - rect : it.qd;
+        k = diam ? it.t - rect + half : k2;
+    }
+    jr = min(j, jmax);
+    kr = min(k, kmax);
+}
+
 // per-atom header prefetched one iteration ahead: lanes 0..5 hold the meta words, lane 6 the species
 struct AtomHdr {
     uint32_t start;
@@ -187,7 +231,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
     __shared__ float s_afc[FWD_WPB][MAXA];    // fc(r, Rca)
     __shared__ float2 s_rad[FWD_WPB][MAXR];   // r, 0.25 fc(r, Rcr)
 
-    const int wib = threadIdx.x >> 6, lane = lane_id();
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();   // scalar LDS bases
     float4 *ang = s_ang[wib];
     float *afc = s_afc[wib];
     float2 *rad = s_rad[wib];
@@ -338,15 +382,19 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
                     // software-pipelined over the steps: LDS reads of step s+1 are issued before the
                     // arithmetic of step s
                     int jr, kr;
-                    decode_pair2(same, min(p, np - 1), nj, div, inv_div, rect, half, jr, kr);
+                    const int q16 = quot16(div), r16 = 16 - q16 * div;
+                    const int jmax = nj - 1, kmax = (same ? nj : nk) - 1;
+                    PairIter it = pair_begin(p, div, inv_div);
+                    pair_get(it, same, nj, rect, half, jmax, kmax, jr, kr);
                     float4 J = ang[oj + jr], K = ang[ok + kr];
                     float fj = afc[oj + jr], fk = afc[ok + kr];
                     for (int t0 = 0; t0 < np; t0 += 16) {
-                        const bool v = t0 + p < np;
+                        const bool v = it.t < np;
                         const float4 Jc = J, Kc = K;
                         const float fcc = v ? 2.0f * fj * fk : 0.f;
                         if (t0 + 16 < np) {
-                            decode_pair2(same, min(t0 + 16 + p, np - 1), nj, div, inv_div, rect, half, jr, kr);
+                            pair_next(it, div, q16, r16);
+                            pair_get(it, same, nj, rect, half, jmax, kmax, jr, kr);
                             J = ang[oj + jr];
                             K = ang[ok + kr];
                             fj = afc[oj + jr];
