@@ -1283,7 +1283,8 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const float ia_log2e = g.inv_alpha * 1.44269504f;
         auto celu_d = [&](float x, float &d) {
             const float e = __builtin_amdgcn_exp2f(x * ia_log2e);
-            d = x > 0.f ? 1.0f : e;
+            d = fminf(e, 1.0f);   // (e > 1 exactly when x > 0; as a select the compare masks of all 32 elements stay
+                                  //  live until the backward phases and spill from SGPRs into VGPR lanes)
             return x > 0.f ? x : __builtin_fmaf(g.alpha, e, -g.alpha);
         };
         float d0f[NE][16];   // celu'(act0) of this lane's elements
