@@ -483,8 +483,8 @@ void ani_oracle_aev_forward(const ani_params *p, const ani_nbrs *nb, const int32
  * closed forms are the chain rule on those same expressions.
  * d = r_j - r_i, so d/dr_j = +, d/dr_i = -.
  */
-void ani_oracle_aev_backward(const ani_params *p, const ani_nbrs *nb, const int32_t *species,
-                             const real *grad_aev, real *grad_coords)
+static void aev_backward_impl(const ani_params *p, const ani_nbrs *nb, const int32_t *species,
+                              const real *grad_aev, real *grad_coords, double *virial)
 {
     const int L = ani_oracle_aev_dim(p);
     const int rad_len = p->S * p->nR;
@@ -493,6 +493,7 @@ void ani_oracle_aev_backward(const ani_params *p, const ani_nbrs *nb, const int3
     for (int64_t q = 0; q < 3 * n; ++q) grad_coords[q] = 0;
     int nthreads = ani_oracle_num_threads();
     double *priv = (double *)calloc((size_t)nthreads * 3 * (size_t)n, sizeof(double));
+    double *vpriv = (double *)calloc((size_t)nthreads * 9, sizeof(double));
 #pragma omp parallel
     {
 #ifdef _OPENMP
@@ -501,6 +502,7 @@ void ani_oracle_aev_backward(const ani_params *p, const ani_nbrs *nb, const int3
         int tid = 0;
 #endif
         double *g = priv + (size_t)tid * 3 * (size_t)n;
+        double *vir = vpriv + (size_t)tid * 9;
 #pragma omp for schedule(dynamic, 8)
         for (int64_t i = 0; i < n; ++i) {
             if (species[i] < 0) continue;
@@ -523,6 +525,7 @@ void ani_oracle_aev_backward(const ani_params *p, const ani_nbrs *nb, const int3
                     double v = (double)(dR * d[k] / r);
                     g[3 * nb->j[e] + k] += v;
                     g[3 * i + k] -= v;
+                    for (int b = 0; b < 3; ++b) vir[3 * k + b] += v * (double)d[b];
                 }
             }
             /* angular */
@@ -571,6 +574,7 @@ void ani_oracle_aev_backward(const ani_params *p, const ani_nbrs *nb, const int3
                         g[3 * nb->j[e1] + k] += g1;
                         g[3 * nb->j[e2] + k] += g2;
                         g[3 * i + k] -= g1 + g2;
+                        for (int b = 0; b < 3; ++b) vir[3 * k + b] += g1 * (double)d1[b] + g2 * (double)d2[b];
                     }
                 }
             }
@@ -580,7 +584,31 @@ void ani_oracle_aev_backward(const ani_params *p, const ani_nbrs *nb, const int3
         const double *g = priv + (size_t)t * 3 * (size_t)n;
         for (int64_t q = 0; q < 3 * n; ++q) grad_coords[q] += (real)g[q];
     }
+    if (virial) {
+        for (int q = 0; q < 9; ++q) virial[q] = 0;
+        for (int t = 0; t < nthreads; ++t)
+            for (int q = 0; q < 9; ++q) virial[q] += vpriv[(size_t)t * 9 + q];
+    }
     free(priv);
+    free(vpriv);
+}
+
+void ani_oracle_aev_backward(const ani_params *p, const ani_nbrs *nb, const int32_t *species,
+                             const real *grad_aev, real *grad_coords)
+{
+    aev_backward_impl(p, nb, species, grad_aev, grad_coords, NULL);
+}
+
+/*
+ * The same backward pass, also returning the virial  W[a][b] = sum over (central atom i, neighbor j) of
+ * (d E_i / d d_ij)[a] * d_ij[b]  with d_ij the displacement stored in the neighbor list -- the "fdotr" stress of the
+ * reference (ase.py:164-168: virial = dE/d(diff_vectors)^T @ diff_vectors; stress = virial / volume), which under
+ * periodic boundary conditions equals d E / d strain (ase.py:170-173, the "scaling" stress).
+ */
+void ani_oracle_aev_backward_virial(const ani_params *p, const ani_nbrs *nb, const int32_t *species,
+                                    const real *grad_aev, real *grad_coords, double *virial)
+{
+    aev_backward_impl(p, nb, species, grad_aev, grad_coords, virial);
 }
 
 /* ------------------------------------------------------------------------------------ */

@@ -114,6 +114,7 @@ class Oracle:
         L.ani_oracle_map_to_central.argtypes = [C.c_int64, vp, vp, vp, vp]
         L.ani_oracle_aev_forward.argtypes = [C.POINTER(Params), vp, vp, vp]
         L.ani_oracle_aev_backward.argtypes = [C.POINTER(Params), vp, vp, vp, vp]
+        L.ani_oracle_aev_backward_virial.argtypes = [C.POINTER(Params), vp, vp, vp, vp, vp]
         L.ani_oracle_mlp.argtypes = [
             C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp,
             C.c_double if kind == "f64" else C.c_float, vp, vp, vp, vp, vp,
@@ -218,8 +219,9 @@ class Oracle:
 
     # -- AEV only --------------------------------------------------------------------------
     def aev(self, p: Params, species, coords, cell=None, pbc=None, cell_list=False,
-            grad_aev=None):
-        """AEVs [C,A,L]; with grad_aev also returns d(sum grad_aev*aev)/d coords [C,A,3]."""
+            grad_aev=None, want_virial=False):
+        """AEVs [C,A,L]; with grad_aev also returns d(sum grad_aev*aev)/d coords [C,A,3] (and, with want_virial,
+        the fp64 virial [3,3] of that scalar, see ani_oracle_aev_backward_virial)."""
         species = self._i32(species)
         Cn, A = species.shape
         n = Cn * A
@@ -243,10 +245,23 @@ class Oracle:
         if grad_aev is not None:
             ga = self._r(grad_aev).reshape(n, L)
             gc = np.empty((Cn, A, 3), dtype=self.dtype)
+            if want_virial:
+                vir = np.zeros((3, 3), dtype=np.float64)
+                self.lib.ani_oracle_aev_backward_virial(C.byref(p), h, self._ptr(species), self._ptr(ga),
+                                                        self._ptr(gc), self._ptr(vir))
+                self.lib.ani_oracle_free_nbrs(h)
+                return out, gc, vir
             self.lib.ani_oracle_aev_backward(C.byref(p), h, self._ptr(species), self._ptr(ga),
                                              self._ptr(gc))
         self.lib.ani_oracle_free_nbrs(h)
         return (out, gc) if grad_aev is not None else out
+
+    def virial(self, p: Params, species, coords, dims, params, n_members, cell=None, pbc=None, cell_list=False):
+        """Virial [3,3] (Hartree) of the NN energy of all atoms: sum_ij dE/d d_ij (x) d_ij; stress = virial / volume."""
+        aev = self.aev(p, species, coords, cell, pbc, cell_list)
+        _, g, _ = self.mlp(species, aev, dims, params, n_members=n_members)
+        _, _, vir = self.aev(p, species, coords, cell, pbc, cell_list, grad_aev=g, want_virial=True)
+        return vir
 
     # -- whole path ------------------------------------------------------------------------
     def energy_forces(self, p: Params, species, coords, dims, params, n_members, sae=None,

@@ -12,9 +12,10 @@ from torchani_amd.weights import random_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if not os.path.basename(p).startswith(("nbrs_", "wgrads_")))   # reference neighbor lists /
+                      if not os.path.basename(p).startswith(("nbrs_", "wgrads_", "stress_")))   # reference neighbor lists /
 #                                                                                      weight-gradient digests
 WGRAD_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "wgrads_*.npz")))
+STRESS_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "stress_*.npz")))
 WGRAD_BLOCK = 4096
 
 
@@ -71,3 +72,8 @@ def oracle_networks(kind, n_members, seed):
 
 def oracle_params(kind, cutoff_fn="cosine"):
     return orc.params_2x(cutoff_fn) if kind == "ani2x" else orc.params_1x(cutoff_fn)
+
+
+def load_stress(base):
+    with np.load(os.path.join(GOLDEN_DIR, "stress_" + base + ".npz")) as z:
+        return {k: z[k] for k in z.files}

@@ -6,8 +6,8 @@ The fixtures in tests/golden were written by tests/golden/gen_golden.py, which i
 import numpy as np
 import pytest
 
-from _util import (GOLDEN_NAMES, WGRAD_NAMES, load_golden, load_wgrads, oracle_networks, oracle_params, wgrad_digest,
-                   wgrad_upstream)
+from _util import (GOLDEN_NAMES, STRESS_NAMES, WGRAD_NAMES, load_golden, load_stress, load_wgrads, oracle_networks,
+                   oracle_params, wgrad_digest, wgrad_upstream)
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
@@ -60,6 +60,21 @@ def test_oracle_weight_gradients_match_reference_autograd(oracle64, base):
     assert np.abs(sums - w["block_sums"]).max() < 1e-7 * scale
     assert np.abs(dots - w["block_dots"]).max() < 1e-7 * scale
     assert np.abs(heads - w["block_heads"]).max() < 1e-7 * scale
+
+
+@pytest.mark.parametrize("base", STRESS_NAMES)
+@pytest.mark.parametrize("cell_list", [False, True])
+def test_oracle_virial_matches_reference_scaling_stress(oracle64, base, cell_list):
+    """sum_ij dE/d d_ij (x) d_ij of the oracle (the reference's fdotr virial, ase.py:164-168) against the reference's
+    autograd derivative with respect to a strain of coordinates and cell (ase.py:170-173), tests/golden/gen_golden_stress.py."""
+    g, st = load_golden(base), load_stress(base)
+    dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
+    vir = oracle64.virial(p, g["species"], g["coords"].astype(np.float64), dims, flat, g["n_members"], g["cell"],
+                          g["pbc"], cell_list=cell_list)
+    # (torch's fp64 CELU backward artefact, see above: ~1e-8 relative)
+    assert np.abs(vir - st["virial"]).max() < 2e-8 * max(1.0, np.abs(st["virial"]).max())
+    assert np.abs(vir - vir.T).max() < 1e-12   # rotational invariance of the energy
 
 
 def test_member_energies(oracle64):
