@@ -166,6 +166,17 @@ int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *t
                         int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
                         const float *ent, const float *grad_aev, float *grad_coords, uint32_t *status);
 
+/* anihip_aev_backward plus the virial of the back-propagated scalar,
+ *   virial[3a + b] = sum over central atoms lo <= i < hi and their neighbors j of (d E_i / d d_ij)[a] * d_ij[b]
+ * (fp64 [9], OVERWRITTEN; d_ij = the displacement stored in the row): the reference's "fdotr" virial
+ * (ase.py:164-168, dE/d(diff_vectors)^T @ diff_vectors), which under periodic boundary conditions equals the
+ * derivative of the energy with respect to a strain of coordinates and cell (ase.py:170-173); stress = virial /
+ * volume.  It needs neither the cell nor whole molecules, so shards / domains simply add their partial virials. */
+int anihip_aev_backward_virial(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
+                               int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
+                               const float *ent, const float *grad_aev, float *grad_coords, double *virial,
+                               uint32_t *status);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-species MLP ensemble: replaces mnp::run (csrc/mnp.cpp:238-265; forward :32-136, input-gradient
  * backward :138-232) and BmmEnsemble (nn/_infer.py:61-216).

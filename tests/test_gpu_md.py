@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from _util import load_golden, seeded_state
+from _util import STRESS_NAMES, load_golden, load_stress, oracle_networks, oracle_params, seeded_state
 from test_gpu_parity import report
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -126,3 +126,55 @@ def test_md_verlet_matches_plain_and_conserves_energy(dev):
     assert ver.n_reuses > 0 and ver.n_builds >= 1
     assert dx < 1e-3
     assert drift < 0.02 * max(dke, 1e-3) + 1e-4
+
+
+@pytest.mark.parametrize("base", STRESS_NAMES)
+def test_virial_matches_reference_stress(dev, base):
+    """energies_and_forces(stress=True): the fdotr virial of the HIP backward against the reference's scaling stress
+    (tests/golden/gen_golden_stress.py).  Tolerance like the forces: 1e-4 Ha per unit strain (measured ~1e-7)."""
+    from torchani_amd.models import ANI2x
+
+    g, st = load_golden(base), load_stress(base)
+    for mode in ("batch", "cell"):
+        model = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False,
+                      neighborlist=mode, row_capacity=256, cutoff_fn=g["cutoff_fn"])
+        sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+        x = torch.from_numpy(g["coords"]).to(dev)
+        cell = torch.from_numpy(g["cell"]).to(dev)
+        pbc = tuple(bool(b) for b in g["pbc"])
+        out = model.energies_and_forces(sp, x, cell, pbc, stress=True)
+        torch.cuda.synchronize()
+        vir = out.virial.cpu().numpy()
+        err = np.abs(vir - st["virial"]).max()
+        report(f"stress {base:24s} {mode:5s} max|virial err| = {err:.2e} Ha (max |virial| {np.abs(st['virial']).max():.3f})")
+        assert err < 1e-4
+        assert np.abs(vir - vir.T).max() == 0.0
+        # forces are those of the plain call, and two half shards add up to the whole virial
+        plain = model.energies_and_forces(sp, x, cell, pbc)
+        assert plain.virial is None and torch.equal(plain.energies, out.energies)
+        parts = [model.energies_and_forces(sp, x, cell, pbc, shard=(r, 2), stress=True).virial for r in range(2)]
+        assert (parts[0] + parts[1] - out.virial).abs().max().item() < 1e-6
+
+
+def test_virial_finite_difference_large_box(dev):
+    """Strain derivative by central differences of the energy on the 3000-atom water box (size-independent property:
+    no oracle needed): dE/d eps_ab = virial_ab."""
+    sp, x, cell, pbc = water(10)
+    model = make_model(dev, "cell_list")
+    spd = torch.from_numpy(sp.astype(np.int64)).to(dev)
+    xd = torch.from_numpy(x).to(dev).double()
+    cd = torch.from_numpy(cell).to(dev).double()
+    out = model.energies_and_forces(spd, xd.float(), cd.float(), pbc, stress=True)
+    h = 2e-3
+    for (a, b) in ((0, 0), (1, 2)):
+        es = []
+        for sgn in (+1.0, -1.0):
+            eps = torch.eye(3, dtype=torch.float64, device=dev)
+            eps[a, b] += sgn * h / 2
+            eps[b, a] += sgn * h / 2
+            o = model.energies_and_forces(spd, (xd @ eps).float(), (cd @ eps).float(), pbc)
+            es.append(o.energies.item())
+        fd = (es[0] - es[1]) / (2 * h)
+        v = 0.5 * (out.virial[a, b] + out.virial[b, a]).item()
+        report(f"stress water3000 d E/d eps[{a}{b}]: finite difference {fd:+.5f}  virial {v:+.5f}")
+        assert abs(fd - v) < 2e-3 * max(1.0, abs(v))

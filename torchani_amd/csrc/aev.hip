@@ -448,12 +448,16 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NA, int NZ>
+// VIRIAL: also accumulate  W[a][b] = sum_ij (d E_i / d d_ij)[a] d_ij[b]  (the "fdotr" virial, ase.py:164-168) over the
+// central atoms of this launch: six per-lane running sums (W is symmetric), one double atomic per wave at the end.
+template <int NA, int NZ, bool VIRIAL>
 __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
-    const float4 *__restrict__ ent, const float *__restrict__ grad_aev, float *__restrict__ grad_coords)
+    const float4 *__restrict__ ent, const float *__restrict__ grad_aev, float *__restrict__ grad_coords,
+    double *__restrict__ virial)
 {
+    float vxx = 0.f, vyy = 0.f, vzz = 0.f, vxy = 0.f, vxz = 0.f, vyz = 0.f;
     constexpr int AQ = NA / 4, ZQ = NZ / 4;
     // per-wave LDS: only the angular-range neighbors need to be shared between lanes
     __shared__ float4 s_nb[BWD_WPB][MAXA];    // ux uy uz r
@@ -568,6 +572,10 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                         atomicAdd(gc + 1, Gy);
                         atomicAdd(gc + 2, Gz);
                         sx += Gx; sy += Gy; sz_ += Gz;
+                        if (VIRIAL) {
+                            vxx += Gx * d.x; vyy += Gy * d.y; vzz += Gz * d.z;
+                            vxy += Gx * d.y; vxz += Gx * d.z; vyz += Gy * d.z;
+                        }
                     }
                 }
             }
@@ -715,6 +723,12 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
             atomicAdd(gc + 1, y);
             atomicAdd(gc + 2, z);
             sx += x; sy += y; sz_ += z;
+            if (VIRIAL) {
+                const float4 u = nb[e];   // unit vector, r
+                const float dx = u.x * u.w, dy = u.y * u.w, dz = u.z * u.w;
+                vxx += x * dx; vyy += y * dy; vzz += z * dz;
+                vxy += x * dy; vxz += x * dz; vyz += y * dz;
+            }
         }
         sx = wave_sum(sx); sy = wave_sum(sy); sz_ = wave_sum(sz_);
         if (lane == 0) {
@@ -724,6 +738,16 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
             atomicAdd(gc + 2, -sz_);
         }
         wave_sync();
+    }
+    if (VIRIAL) {
+        vxx = wave_sum(vxx); vyy = wave_sum(vyy); vzz = wave_sum(vzz);
+        vxy = wave_sum(vxy); vxz = wave_sum(vxz); vyz = wave_sum(vyz);
+        if (lane == 0) {
+            atomicAdd(virial + 0, (double)vxx); atomicAdd(virial + 4, (double)vyy); atomicAdd(virial + 8, (double)vzz);
+            atomicAdd(virial + 1, (double)vxy); atomicAdd(virial + 3, (double)vxy);
+            atomicAdd(virial + 2, (double)vxz); atomicAdd(virial + 6, (double)vxz);
+            atomicAdd(virial + 5, (double)vyz); atomicAdd(virial + 7, (double)vyz);
+        }
     }
 }
 
@@ -800,24 +824,50 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     return 0;
 }
 
-extern "C" int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table,
-                                   int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
-                                   const uint32_t *meta, const float *ent, const float *grad_aev,
-                                   float *grad_coords, uint32_t *status)
+static int aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms, int64_t lo,
+                        int64_t hi, const int32_t *species, const uint32_t *meta, const float *ent,
+                        const float *grad_aev, float *grad_coords, double *virial)
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && grad_aev && grad_coords, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
+    if (virial) zero_words_async((hipStream_t)stream, virial, 9 * sizeof(double));
     if (hi == lo) return 0;
     dim3 grid(persistent_blocks(hi - lo, BWD_WPB, 4)), block(BWD_WPB * WAVE);
-    if (p->n_shf_a == 8)
-        hipLaunchKernelGGL((k_aev_bwd<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, grad_aev, grad_coords);
+    const float4 *e4 = (const float4 *)ent;
+    hipStream_t st = (hipStream_t)stream;
+    if (p->n_shf_a == 8 && !virial)
+        hipLaunchKernelGGL((k_aev_bwd<8, 4, false>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
+                           grad_coords, virial);
+    else if (p->n_shf_a == 8)
+        hipLaunchKernelGGL((k_aev_bwd<8, 4, true>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
+                           grad_coords, virial);
+    else if (!virial)
+        hipLaunchKernelGGL((k_aev_bwd<4, 8, false>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
+                           grad_coords, virial);
     else
-        hipLaunchKernelGGL((k_aev_bwd<4, 8>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, grad_aev, grad_coords);
+        hipLaunchKernelGGL((k_aev_bwd<4, 8, true>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
+                           grad_coords, virial);
     ANIHIP_CHECK_HIP(hipGetLastError());
-    (void)status;
     return 0;
+}
+
+extern "C" int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table,
+                                   int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                                   const uint32_t *meta, const float *ent, const float *grad_aev,
+                                   float *grad_coords, uint32_t *status)
+{
+    (void)status;
+    return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, nullptr);
+}
+
+extern "C" int anihip_aev_backward_virial(void *stream, const anihip_aev_params *p, const float *table,
+                                          int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                                          const uint32_t *meta, const float *ent, const float *grad_aev,
+                                          float *grad_coords, double *virial, uint32_t *status)
+{
+    (void)status;
+    ANIHIP_REQUIRE(virial, "null pointer argument");
+    return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, virial);
 }

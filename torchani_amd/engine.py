@@ -248,19 +248,26 @@ class AevEngine:
         return out
 
     def backward(self, species: Tensor, nbrs: NeighborRows, grad_aev: Tensor,
-                 grad_coords: tp.Optional[Tensor] = None, shard_rows: bool = False) -> Tensor:
+                 grad_coords: tp.Optional[Tensor] = None, shard_rows: bool = False,
+                 virial: tp.Optional[Tensor] = None) -> Tensor:
         """grad_coords [N,3] += d(sum grad_aev*aev)/d coords for the central atoms of nbrs.
-        shard_rows=True: grad_aev holds only the rows lo..hi."""
+        shard_rows=True: grad_aev holds only the rows lo..hi.
+        virial (optional float64 [3,3], overwritten): sum_ij dE/d d_ij (x) d_ij over those central atoms."""
         _require_cuda(species, grad_aev)
         n = species.numel()
         assert grad_aev.dtype == torch.float32 and grad_aev.is_contiguous()
         assert grad_aev.numel() == ((nbrs.hi - nbrs.lo) if shard_rows else n) * self.L
         if grad_coords is None:
             grad_coords = torch.zeros((n, 3), dtype=torch.float32, device=species.device)
-        _lib.check(_lib.lib().anihip_aev_backward(
-            _stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
-            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent),
-            _row_ptr(grad_aev, nbrs.lo if shard_rows else 0, self.L), _ptr(grad_coords), _ptr(nbrs.status)))
+        args = (_stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
+                _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent),
+                _row_ptr(grad_aev, nbrs.lo if shard_rows else 0, self.L), _ptr(grad_coords))
+        if virial is None:
+            _lib.check(_lib.lib().anihip_aev_backward(*args, _ptr(nbrs.status)))
+        else:
+            _require_cuda(virial)
+            assert virial.dtype == torch.float64 and virial.is_contiguous() and virial.numel() == 9
+            _lib.check(_lib.lib().anihip_aev_backward_virial(*args, _ptr(virial), _ptr(nbrs.status)))
         return grad_coords
 
 

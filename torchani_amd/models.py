@@ -95,7 +95,7 @@ class ANI(torch.nn.Module):
     def energies_and_forces(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
                             pbc: tp.Optional[tp.Sequence[bool]] = None, group=None,
                             reduce_forces: bool = True, check_overflow: bool = False,
-                            shard: tp.Optional[tp.Tuple[int, int]] = None) -> EnergiesForces:
+                            shard: tp.Optional[tp.Tuple[int, int]] = None, stress: bool = False) -> EnergiesForces:
         """Energies [C] (float64, NN + self energies) and forces [C, A, 3] without autograd.
 
         With a torch.distributed ``group`` (one process per GPU, RCCL) the central atoms are sharded
@@ -103,16 +103,19 @@ class ANI(torch.nn.Module):
         partial energies (and, for a shared system, partial forces) are all-reduced.
         ``shard=(rank, world)`` evaluates that shard alone, without any collective (partial energies and
         forces that add up to the full result over the shards).
+        ``stress=True`` also returns the virial [3,3] (float64, Hartree) = dE/d strain of all atoms together, summed
+        over shards like the energy -- the reference's "fdotr" stress times the volume (ase.py:164-168).
         """
         if not coords.is_cuda:
             raise ValueError("torchani_amd's engine needs tensors on a ROCm device (no CPU fallback)")
         elem_idxs = self._elem_idxs(species)
         species32 = elem_idxs.to(torch.int32).contiguous()
         c32 = coords.detach().to(torch.float32).contiguous()
-        return self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, check_overflow, shard)
+        return self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, check_overflow, shard,
+                                              stress)
 
     def _energies_and_forces_core(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces,
-                                  check_overflow, shard) -> EnergiesForces:
+                                  check_overflow, shard, stress: bool = False) -> EnergiesForces:
         """The stream-ordered part of energies_and_forces (element indices int32, coords fp32 contiguous):
         no host synchronisation unless check_overflow, so it can be captured into a HIP graph."""
         C, A = species32.shape
@@ -133,7 +136,8 @@ class ANI(torch.nn.Module):
         atomic_e, grad_aev, _ = packed.forward_backward(species32, aev, lo=lo, hi=hi, want_grad=True,
                                                         chunk=self.mlp_chunk, slab_mask=slab_mask,
                                                         shard_rows=True)
-        grad_coords = eng.backward(species32, nbrs, grad_aev, shard_rows=True)
+        virial = torch.empty((3, 3), dtype=torch.float64, device=c32.device) if stress else None
+        grad_coords = eng.backward(species32, nbrs, grad_aev, shard_rows=True, virial=virial)
         sae = None
         if self.energy_shifter._enabled:
             sae = self.energy_shifter.self_energies.to(device=c32.device, dtype=torch.float64)
@@ -141,12 +145,14 @@ class ANI(torch.nn.Module):
         forces = grad_coords.neg_().view(C, A, 3)
         if group is not None and torch.distributed.get_world_size(group) > 1:
             torch.distributed.all_reduce(energies, group=group)
+            if virial is not None:
+                torch.distributed.all_reduce(virial, group=group)
             if reduce_forces:
                 torch.distributed.all_reduce(forces, group=group)
         if check_overflow:
             nbrs.raise_on_overflow()
         aevc._last_neighbors = nbrs
-        return EnergiesForces(energies, forces, atomic_e.view(C, A))
+        return EnergiesForces(energies, forces, atomic_e.view(C, A), virial)
 
     # ---- external neighbor lists (arch.py:151-206,354-381) ------------------------------------------
     def compute_from_neighbors(self, elem_idxs: Tensor, coords: Tensor, neighbors, charge: int = 0,

@@ -32,6 +32,7 @@ class EnergiesForces(tp.NamedTuple):
     energies: Tensor
     forces: Tensor
     atomic_energies: Tensor
+    virial: tp.Optional[Tensor] = None   # [3,3] float64 Hartree (stress=True): dE/d strain; stress = virial / volume
 
 
 class SpeciesForces(tp.NamedTuple):
