@@ -178,3 +178,52 @@ def test_virial_finite_difference_large_box(dev):
         v = 0.5 * (out.virial[a, b] + out.virial[b, a]).item()
         report(f"stress water3000 d E/d eps[{a}{b}]: finite difference {fd:+.5f}  virial {v:+.5f}")
         assert abs(fd - v) < 2e-3 * max(1.0, abs(v))
+
+
+class FakeAtoms:
+    """The slice of ase.Atoms the calculator touches."""
+
+    def __init__(self, numbers, positions, cell, pbc):
+        self.numbers, self.positions, self.cell, self.pbc = numbers, positions.copy(), cell, pbc
+
+    def get_atomic_numbers(self):
+        return self.numbers
+
+    def get_positions(self):
+        return self.positions
+
+    def set_positions(self, p):
+        self.positions = np.asarray(p, dtype=np.float64)
+
+    def get_cell(self, complete=True):
+        return self.cell
+
+    def get_pbc(self):
+        return self.pbc
+
+    def get_volume(self):
+        return abs(np.linalg.det(self.cell))
+
+
+def test_ase_calculator_protocol(dev):
+    """model.ase().calculate(atoms, ["energy", "forces", "stress"]) in ASE units (ase.py:75-173)."""
+    from torchani_amd.ase import HARTREE_TO_EV
+    from torchani_amd.models import ANI2x
+
+    g, st = load_golden("water_pbc_ani2x"), load_stress("water_pbc_ani2x")
+    model = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev)   # periodic_table_index=True
+    znum = np.asarray([1, 6, 7, 8, 16, 9, 17])[g["species"][0]]
+    shifted = g["coords"][0].astype(np.float64) + 3.0 * g["cell"][0]           # outside the central cell
+    atoms = FakeAtoms(znum, shifted, g["cell"].astype(np.float64), np.asarray(g["pbc"]))
+    calc = model.ase(overwrite=True)
+    calc.calculate(atoms, ["energy", "forces", "stress"])
+    assert abs(calc.results["energy"] - g["energies"][0] * HARTREE_TO_EV) < 1e-4
+    assert calc.results["free_energy"] == calc.results["energy"]
+    assert np.abs(calc.results["forces"] - g["forces"][0] * HARTREE_TO_EV).max() < 1e-4 * HARTREE_TO_EV
+    vol = abs(np.linalg.det(g["cell"].astype(np.float64)))
+    assert np.abs(calc.results["stress"] - st["virial"] * HARTREE_TO_EV / vol).max() < 1e-6
+    # overwrite=True wrote the wrapped positions back (ase.py:101-104)
+    frac = atoms.get_positions() @ np.linalg.inv(g["cell"].astype(np.float64))
+    assert frac.min() > -1e-5 and frac.max() < 1 + 1e-5
+    with pytest.raises(ValueError, match="periodic_table_index"):
+        ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False).ase()

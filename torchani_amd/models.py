@@ -154,6 +154,12 @@ class ANI(torch.nn.Module):
         aevc._last_neighbors = nbrs
         return EnergiesForces(energies, forces, atomic_e.view(C, A), virial)
 
+    def ase(self, overwrite: bool = False, stress_kind: str = "fdotr"):
+        """ASE calculator for this model (arch.py ``ANI.ase``, torchani/ase.py:32-173)."""
+        from .ase import Calculator
+
+        return Calculator(self, overwrite=overwrite, stress_kind=stress_kind)
+
     # ---- external neighbor lists (arch.py:151-206,354-381) ------------------------------------------
     def compute_from_neighbors(self, elem_idxs: Tensor, coords: Tensor, neighbors, charge: int = 0,
                                atomic: bool = False, ensemble_values: bool = False) -> Tensor:
