@@ -267,7 +267,9 @@ int anihip_mlp_forward_backward(void *stream, const anihip_mlp_desc *d, int64_t 
  *
  * For  Loss = sum_i grad_atomic_e[i] * atomic_e[i]  (the caller folds d Loss / d E_molecule into per-atom factors;
  * atomic_e = ensemble mean as above):
- *   grads[s].gw[l]    = d Loss / d w[l]    of species s, same shape and layout as anihip_species_net.w[l]
+ *   grads[s].gw[l]    = d Loss / d weight of layer l of species s as [M][out_p][in_p] (in_p = K0 for layer 0, [M][Hp]
+ *                       for the output layer): per member torch.nn.Linear's [out][in] layout at the padded widths, so
+ *                       unpadded networks (ANI-2x) read their gradients in place
  *   grads[s].gbias[l] = d Loss / d bias[l] of species s, same shape as bias[l]
  * (padded rows/columns come out zero).  All gradient arrays are OVERWRITTEN.  atomic_e is written as in
  * anihip_mlp_forward_backward; grad_aev (optional) = d Loss / d aev rows, i.e. already scaled by grad_atomic_e.

@@ -1565,7 +1565,7 @@ struct WgradProblem {
     int64_t ldd;
     int d_boff;
     int N;            // output width per batch
-    float *dW;        // [batch][K][ldw]
+    float *dW;        // [batch][N][ldw]: rows = output units (torch.nn.Linear layout), ldw >= k_valid
     int64_t ldw, w_bstride;
 };
 struct WgradArgs {
@@ -1643,26 +1643,28 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs g)
         if (r0 + 2 * WG_U < n_rows) load(r0 + 2 * WG_U);
 #pragma unroll
         for (int u = 0; u < WG_U; ++u) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc_[u].x, dc_[u].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc_[u].x, dc_[u].y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc_[u].y, dc_[u].x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xc_[u].y, dc_[u].y, acc[1][1], 0, 0, 0);
+            // D as the first operand: the accumulator holds the TRANSPOSED block (rows = output unit, columns =
+            // input unit), i.e. torch.nn.Linear's [out][in] layout with the lanes along the contiguous index
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc_[u].x, xc_[u].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc_[u].y, xc_[u].x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc_[u].x, xc_[u].y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(dc_[u].y, xc_[u].y, acc[1][1], 0, 0, 0);
         }
     }
     // C/D layout of 32x32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float *W = pr.dW + (int64_t)bb * pr.w_bstride;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a) {
+        const int i = i0 + c2 + a;          // input unit: along the lanes
+        if (i >= pr.k_valid) continue;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int j = j0 + c2 + b;
-            if (j >= pr.N) continue;
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = i0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + a;
-                if (i < pr.k_valid) atomicAdd(W + (int64_t)i * pr.ldw + j, acc[a][b][r]);
+                const int j = j0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * kk) + b;   // output unit
+                if (j < pr.N) atomicAdd(W + (int64_t)j * pr.ldw + i, acc[a][b][r]);
             }
-        }
+    }
 }
 
 // out[col] += sum over the rows of species s of  scale(row) * X[row][col]   (bias gradients: X = D, scale = 1;
@@ -2368,10 +2370,10 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
             p.D = dlt[l]; p.ldd = w.ld[l]; p.dW = grads[s].gw[l];
             if (l == 0) {
                 p.X = aev; p.ldx = L; p.x_boff = 0; p.K = L; p.k_valid = L;
-                p.d_boff = 0; p.N = nn.dims[1] * M; p.ldw = p.N; p.w_bstride = 0;
+                p.d_boff = 0; p.N = nn.dims[1] * M; p.ldw = L; p.w_bstride = 0;
             } else {
                 p.X = w.act[l - 1]; p.ldx = w.ld[l - 1]; p.x_boff = nn.dims[l]; p.K = nn.dims[l]; p.k_valid = p.K;
-                p.d_boff = nn.dims[l + 1]; p.N = nn.dims[l + 1]; p.ldw = p.N; p.w_bstride = (int64_t)p.K * p.N;
+                p.d_boff = nn.dims[l + 1]; p.N = nn.dims[l + 1]; p.ldw = p.K; p.w_bstride = (int64_t)p.K * p.N;
             }
             kmax = kmax > p.K ? kmax : p.K;
             nmax = nmax > p.N ? nmax : p.N;

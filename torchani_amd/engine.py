@@ -606,11 +606,8 @@ class PackedNetworks:
                 if l == nl - 1:
                     wv = w.view(M, 1, dims[l])                       # [M][Hlast_p]
                     bv = b.view(M, 1)
-                elif l == 0:
-                    wv = w.view(dims[0], M, dims[1]).permute(1, 2, 0)    # [K0][M*H1p] -> [M, H1p, K0]
-                    bv = b.view(M, dims[1])
                 else:
-                    wv = w.view(M, dims[l], dims[l + 1]).transpose(1, 2)  # [M][in_p][out_p] -> [M, out_p, in_p]
+                    wv = w.view(M, dims[l + 1], dims[l])   # [M][out_p][in_p]: Linear layout, plain views when unpadded
                     bv = b.view(M, dims[l + 1])
                 for m in range(M):
                     gw[m][s][l] = wv[m, :out, :inn]
