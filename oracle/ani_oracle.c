@@ -611,6 +611,86 @@ void ani_oracle_aev_backward_virial(const ani_params *p, const ani_nbrs *nb, con
     aev_backward_impl(p, nb, species, grad_aev, grad_coords, virial);
 }
 
+/*
+ * Forward-mode derivative of the AEVs: daev[i][q] = sum_k (d aev[i][q] / d r_k) . tang[k]  (J t, a Jacobian-vector
+ * product).  This is what the reference's cuaev_double_backward returns for tang = the gradient arriving at the forces
+ * (csrc/aev.cu:1986-2015 with the is_double_backward kernel variants, :474-766,837-967): the derivative of
+ * grad_coords = J^T grad_aev with respect to grad_aev, contracted with that incoming gradient.
+ * With d = r_j - r_i:  d' = t_j - t_i,  r' = u . d',  u' = (d' - u r') / r.
+ */
+void ani_oracle_aev_jvp(const ani_params *p, const ani_nbrs *nb, const int32_t *species, const real *tang,
+                        real *daev)
+{
+    const int L = ani_oracle_aev_dim(p);
+    const int rad_len = p->S * p->nR;
+    const int nAZ = p->nA * p->nZ;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int64_t i = 0; i < nb->n_atoms; ++i) {
+        real *out = daev + (size_t)i * L;
+        for (int q = 0; q < L; ++q) out[q] = 0;
+        if (species[i] < 0) continue;
+        const int64_t s0 = nb->start[i], s1 = nb->start[i + 1];
+        for (int64_t e = s0; e < s1; ++e) {
+            const real r = nb->r[e];
+            const int64_t j = nb->j[e];
+            const int sj = species[j];
+            const real *d = &nb->d[3 * e];
+            real rdot = 0;
+            for (int k = 0; k < 3; ++k) rdot += d[k] / r * (tang[3 * j + k] - tang[3 * i + k]);
+            const real fc = fcut(r, p->Rcr), dfc = dfcut(r, p->Rcr);
+            for (int s = 0; s < p->nR; ++s) {
+                real dr = r - (real)p->ShfR[s];
+                real ex = (real)0.25 * (real)exp((double)(-(real)p->EtaR * dr * dr));
+                out[sj * p->nR + s] += (-2 * (real)p->EtaR * dr * ex * fc + ex * dfc) * rdot;
+            }
+        }
+        for (int64_t e1 = s0; e1 < s1; ++e1) {
+            const real r1 = nb->r[e1];
+            if (r1 > (real)p->Rca) continue;
+            const real fc1 = fcut(r1, p->Rca), dfc1 = dfcut(r1, p->Rca);
+            const int64_t j1 = nb->j[e1];
+            for (int64_t e2 = e1 + 1; e2 < s1; ++e2) {
+                const real r2 = nb->r[e2];
+                if (r2 > (real)p->Rca) continue;
+                const real fc2 = fcut(r2, p->Rca), dfc2 = dfcut(r2, p->Rca);
+                const int64_t j2 = nb->j[e2];
+                const real *d1 = &nb->d[3 * e1], *d2 = &nb->d[3 * e2];
+                real u1[3], u2[3], t1[3], t2[3], r1d = 0, r2d = 0;
+                for (int k = 0; k < 3; ++k) {
+                    u1[k] = d1[k] / r1; u2[k] = d2[k] / r2;
+                    t1[k] = tang[3 * j1 + k] - tang[3 * i + k];
+                    t2[k] = tang[3 * j2 + k] - tang[3 * i + k];
+                    r1d += u1[k] * t1[k]; r2d += u2[k] * t2[k];
+                }
+                real c = 0, cdot = 0;
+                for (int k = 0; k < 3; ++k) {
+                    c += u1[k] * u2[k];
+                    cdot += (t1[k] - u1[k] * r1d) / r1 * u2[k] + u1[k] * (t2[k] - u2[k] * r2d) / r2;
+                }
+                const real ct = (real)0.95 * c;
+                const real theta = (real)acos((double)ct);
+                const real thdot = -(real)0.95 * cdot / (real)sqrt((double)(1 - ct * ct));
+                const real rm = (r1 + r2) / 2, rmdot = (r1d + r2d) / 2;
+                const real fcc = fc1 * fc2, fccdot = dfc1 * r1d * fc2 + fc1 * dfc2 * r2d;
+                int pidx = triu_index(p->S, species[j1], species[j2]);
+                real *o = out + rad_len + pidx * nAZ;
+                for (int a = 0; a < p->nA; ++a) {
+                    real dr = rm - (real)p->ShfA[a];
+                    real f2 = (real)exp((double)(-(real)p->EtaA * dr * dr));
+                    real df2 = -2 * (real)p->EtaA * dr * f2;
+                    for (int z = 0; z < p->nZ; ++z) {
+                        real dev = theta - (real)p->ShfZ[z];
+                        real h = (1 + (real)cos((double)dev)) / 2;
+                        real f1 = 2 * (real)pow((double)h, p->Zeta);
+                        real df1 = -(real)p->Zeta * (real)pow((double)h, p->Zeta - 1) * (real)sin((double)dev);
+                        o[a * p->nZ + z] += df1 * thdot * f2 * fcc + f1 * df2 * rmdot * fcc + f1 * f2 * fccdot;
+                    }
+                }
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* Networks */
 
@@ -815,6 +895,112 @@ void ani_oracle_mlp_weight_grads(int64_t n, int S, int M, int nl, const int *dim
         free(act); free(dact); free(ga); free(gb);
     }
     free(off);
+}
+
+/*
+ * Second-order pass for training on forces.  For tangents v_i (one AEV-shaped row per atom) let
+ *     S = sum_i v_i . d atomic_e[i] / d aev_i          (atomic_e = ensemble mean)
+ * -- with v = -J t this is  S = sum_k t_k . F_k  for the forces F = -dE/dr, i.e. the part of a force loss that autograd
+ * back-propagates through torch.autograd.grad(E, coords, create_graph=True) (tools/training-aev-benchmark.py:136-150).
+ * Returns dS/d(weights, biases) in the layout of params (grad_params, overwritten) and S itself.
+ * Forward-over-reverse: activations a_l, their tangents adot_l (adot_0 = v), then the adjoints of both:
+ *     mu_l = dS/d adot_l, nu_l = dS/d a_l;   p = mu c'(z),  q = mu c''(z) zdot + nu c'(z);
+ *     dS/dW_l = p adot_{l-1}^T + q a_{l-1}^T,  dS/db_l = q,  mu_{l-1} = W_l^T p,  nu_{l-1} = W_l^T q.
+ */
+double ani_oracle_mlp_tangent_weight_grads(int64_t n, int S, int M, int nl, const int *dims, const real *params,
+                                           real celu_alpha, const int32_t *species, const real *aev,
+                                           const real *tangent, real *grad_params)
+{
+    const int L = dims[0];
+    size_t *off = (size_t *)malloc(sizeof(size_t) * (size_t)(M * S + 1));
+    off[0] = 0;
+    int maxw = 0;
+    for (int m = 0; m < M; ++m)
+        for (int s = 0; s < S; ++s) {
+            off[m * S + s + 1] = off[m * S + s] + net_param_count(dims + s * (nl + 1), nl);
+            for (int l = 0; l <= nl; ++l)
+                if (dims[s * (nl + 1) + l] > maxw) maxw = dims[s * (nl + 1) + l];
+        }
+    for (size_t q = 0; q < off[M * S]; ++q) grad_params[q] = 0;
+    double total = 0;
+#pragma omp parallel
+    {
+        const size_t W = (size_t)maxw, NL = (size_t)(nl + 1);
+        real *act = (real *)malloc(sizeof(real) * NL * W), *adot = (real *)malloc(sizeof(real) * NL * W);
+        real *c1 = (real *)malloc(sizeof(real) * NL * W), *c2 = (real *)malloc(sizeof(real) * NL * W);
+        real *zdot = (real *)malloc(sizeof(real) * NL * W);
+        real *mu = (real *)malloc(sizeof(real) * W), *nu = (real *)malloc(sizeof(real) * W);
+        real *mu2 = (real *)malloc(sizeof(real) * W), *nu2 = (real *)malloc(sizeof(real) * W);
+        double local = 0;
+#pragma omp for schedule(dynamic, 1)
+        for (int task = 0; task < M * S; ++task) {
+            const int s = task % S;
+            const int *d = dims + s * (nl + 1);
+            const real *P = params + off[task];
+            real *G = grad_params + off[task];
+            for (int64_t i = 0; i < n; ++i) {
+                if (species[i] != s) continue;
+                for (int k = 0; k < L; ++k) { act[k] = aev[(size_t)i * L + k]; adot[k] = tangent[(size_t)i * L + k]; }
+                const real *Pl = P;
+                for (int l = 0; l < nl; ++l) {
+                    const int in = d[l], out = d[l + 1];
+                    const real *Wl = Pl, *b = Pl + (size_t)out * in;
+                    const real *x = act + (size_t)l * W, *xd = adot + (size_t)l * W;
+                    for (int o = 0; o < out; ++o) {
+                        real z = b[o], zd = 0;
+                        const real *wr = Wl + (size_t)o * in;
+                        for (int k = 0; k < in; ++k) { z += wr[k] * x[k]; zd += wr[k] * xd[k]; }
+                        real f, f1, f2;
+                        if (l < nl - 1) {
+                            const real e = (real)exp((double)(z / celu_alpha));
+                            f = z > 0 ? z : celu_alpha * (e - 1);
+                            f1 = z > 0 ? (real)1 : e;
+                            f2 = z > 0 ? (real)0 : e / celu_alpha;
+                        } else {
+                            f = z; f1 = 1; f2 = 0;
+                        }
+                        act[(size_t)(l + 1) * W + o] = f;
+                        c1[(size_t)(l + 1) * W + o] = f1;
+                        c2[(size_t)(l + 1) * W + o] = f2;
+                        zdot[(size_t)(l + 1) * W + o] = zd;
+                        adot[(size_t)(l + 1) * W + o] = f1 * zd;
+                    }
+                    Pl += (size_t)out * in + out;
+                }
+                local += (double)adot[(size_t)nl * W + 0] / M;
+                for (int o = 0; o < d[nl]; ++o) { mu[o] = (real)1 / M; nu[o] = 0; }
+                for (int l = nl - 1; l >= 0; --l) {
+                    const int in = d[l], out = d[l + 1];
+                    size_t lo = 0;
+                    for (int q = 0; q < l; ++q) lo += (size_t)d[q + 1] * d[q] + d[q + 1];
+                    const real *Wl = P + lo;
+                    real *GW = G + lo, *Gb = G + lo + (size_t)out * in;
+                    const real *x = act + (size_t)l * W, *xd = adot + (size_t)l * W;
+                    for (int k = 0; k < in; ++k) { mu2[k] = 0; nu2[k] = 0; }
+                    for (int o = 0; o < out; ++o) {
+                        const real pp = mu[o] * c1[(size_t)(l + 1) * W + o];
+                        const real qq = mu[o] * c2[(size_t)(l + 1) * W + o] * zdot[(size_t)(l + 1) * W + o] +
+                                        nu[o] * c1[(size_t)(l + 1) * W + o];
+                        const real *wr = Wl + (size_t)o * in;
+                        real *gr = GW + (size_t)o * in;
+                        Gb[o] += qq;
+                        for (int k = 0; k < in; ++k) {
+                            gr[k] += pp * xd[k] + qq * x[k];
+                            mu2[k] += pp * wr[k];
+                            nu2[k] += qq * wr[k];
+                        }
+                    }
+                    real *t = mu; mu = mu2; mu2 = t;
+                    t = nu; nu = nu2; nu2 = t;
+                }
+            }
+        }
+#pragma omp atomic
+        total += local;
+        free(act); free(adot); free(c1); free(c2); free(zdot); free(mu); free(nu); free(mu2); free(nu2);
+    }
+    free(off);
+    return total;
 }
 
 /*

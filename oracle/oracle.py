@@ -114,6 +114,12 @@ class Oracle:
         L.ani_oracle_map_to_central.argtypes = [C.c_int64, vp, vp, vp, vp]
         L.ani_oracle_aev_forward.argtypes = [C.POINTER(Params), vp, vp, vp]
         L.ani_oracle_aev_backward.argtypes = [C.POINTER(Params), vp, vp, vp, vp]
+        L.ani_oracle_aev_jvp.argtypes = [C.POINTER(Params), vp, vp, vp, vp]
+        L.ani_oracle_mlp_tangent_weight_grads.restype = C.c_double
+        L.ani_oracle_mlp_tangent_weight_grads.argtypes = [
+            C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp,
+            C.c_double if kind == "f64" else C.c_float, vp, vp, vp, vp,
+        ]
         L.ani_oracle_aev_backward_virial.argtypes = [C.POINTER(Params), vp, vp, vp, vp, vp]
         L.ani_oracle_mlp.argtypes = [
             C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp,
@@ -216,6 +222,48 @@ class Oracle:
                                              celu_alpha, self._ptr(species), self._ptr(aev), self._ptr(g_atom),
                                              self._ptr(out))
         return out
+
+    def mlp_tangent_weight_grads(self, species, aev, tangent, dims, params, celu_alpha=0.1, n_members=None):
+        """(S, dS/d params) for S = sum_i tangent_i . d atomic_e[i]/d aev_i (second-order pass of force training)."""
+        species = self._i32(species).reshape(-1)
+        n = species.shape[0]
+        dims = np.ascontiguousarray(np.asarray(dims, dtype=np.int32))
+        S, nlp1 = dims.shape
+        aev = self._r(aev).reshape(n, dims[0, 0])
+        tangent = self._r(tangent).reshape(n, dims[0, 0])
+        params = self._r(params)
+        out = np.empty_like(params)
+        val = self.lib.ani_oracle_mlp_tangent_weight_grads(
+            n, S, int(n_members), nlp1 - 1, self._ptr(dims), self._ptr(params), celu_alpha, self._ptr(species),
+            self._ptr(aev), self._ptr(tangent), self._ptr(out))
+        return float(val), out
+
+    def aev_jvp(self, p: Params, species, coords, tangent, cell=None, pbc=None, cell_list=False):
+        """(aev [C,A,L], J t [C,A,L]) for a coordinate-space direction t [C,A,3] (ani_oracle_aev_jvp)."""
+        species = self._i32(species)
+        Cn, A = species.shape
+        n = Cn * A
+        coords = self._r(coords).reshape(n, 3)
+        tangent = self._r(tangent).reshape(n, 3)
+        cell_, pbc_ = self._cell(cell, pbc)
+        if cell_ is not None:
+            wrapped = np.empty_like(coords)
+            self.lib.ani_oracle_map_to_central(n, self._ptr(coords), self._ptr(cell_), self._ptr(pbc_),
+                                               self._ptr(wrapped))
+            coords = wrapped
+        if cell_list:
+            h = self.lib.ani_oracle_nbrs_cell(n, self._ptr(species), self._ptr(coords),
+                                               self._ptr(cell_), self._ptr(pbc_), p.Rcr)
+        else:
+            h = self.lib.ani_oracle_nbrs_brute(Cn, A, self._ptr(species), self._ptr(coords),
+                                                self._ptr(cell_), self._ptr(pbc_), p.Rcr)
+        L = self.lib.ani_oracle_aev_dim(C.byref(p))
+        aev = np.empty((Cn, A, L), dtype=self.dtype)
+        out = np.empty((Cn, A, L), dtype=self.dtype)
+        self.lib.ani_oracle_aev_forward(C.byref(p), h, self._ptr(species), self._ptr(aev))
+        self.lib.ani_oracle_aev_jvp(C.byref(p), h, self._ptr(species), self._ptr(tangent), self._ptr(out))
+        self.lib.ani_oracle_free_nbrs(h)
+        return aev, out
 
     # -- AEV only --------------------------------------------------------------------------
     def aev(self, p: Params, species, coords, cell=None, pbc=None, cell_list=False,

@@ -12,10 +12,11 @@ from torchani_amd.weights import random_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if not os.path.basename(p).startswith(("nbrs_", "wgrads_", "stress_")))   # reference neighbor lists /
+                      if not os.path.basename(p).startswith(("nbrs_", "wgrads_", "stress_", "fgrads_")))   # reference neighbor lists /
 #                                                                                      weight-gradient digests
 WGRAD_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "wgrads_*.npz")))
 STRESS_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "stress_*.npz")))
+FGRAD_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "fgrads_*.npz")))
 WGRAD_BLOCK = 4096
 
 
@@ -77,3 +78,16 @@ def oracle_params(kind, cutoff_fn="cosine"):
 def load_stress(base):
     with np.load(os.path.join(GOLDEN_DIR, "stress_" + base + ".npz")) as z:
         return {k: z[k] for k in z.files}
+
+
+def load_fgrads(base):
+    with np.load(os.path.join(GOLDEN_DIR, "fgrads_" + base + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def fgrad_direction(species):
+    """Coordinate-space direction of tests/golden/gen_golden_fgrads.py (zero on padding atoms)."""
+    C, A = species.shape
+    q = 3.0 * np.arange(C * A, dtype=np.float64)
+    t = np.stack([np.modf(0.37 * q)[0], np.modf(0.61 * q)[0] - 0.5, 0.25 - np.modf(0.13 * q)[0]], axis=-1)
+    return t.reshape(C, A, 3) * (species >= 0)[..., None]

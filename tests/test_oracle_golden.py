@@ -6,8 +6,8 @@ The fixtures in tests/golden were written by tests/golden/gen_golden.py, which i
 import numpy as np
 import pytest
 
-from _util import (GOLDEN_NAMES, STRESS_NAMES, WGRAD_NAMES, load_golden, load_stress, load_wgrads, oracle_networks,
-                   oracle_params, wgrad_digest, wgrad_upstream)
+from _util import (FGRAD_NAMES, GOLDEN_NAMES, STRESS_NAMES, WGRAD_NAMES, fgrad_direction, load_fgrads, load_golden,
+                   load_stress, load_wgrads, oracle_networks, oracle_params, wgrad_digest, wgrad_upstream)
 
 
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
@@ -75,6 +75,29 @@ def test_oracle_virial_matches_reference_scaling_stress(oracle64, base, cell_lis
     # (torch's fp64 CELU backward artefact, see above: ~1e-8 relative)
     assert np.abs(vir - st["virial"]).max() < 2e-8 * max(1.0, np.abs(st["virial"]).max())
     assert np.abs(vir - vir.T).max() < 1e-12   # rotational invariance of the energy
+
+
+@pytest.mark.parametrize("base", FGRAD_NAMES)
+def test_oracle_force_training_gradients_match_reference(oracle64, base):
+    """Second order: J t (the reference's AEV forward-mode derivative = cuaev double backward) and d(t . F)/d params
+    against the reference's create_graph autograd (tests/golden/gen_golden_fgrads.py)."""
+    g, f = load_golden(base), load_fgrads(base)
+    dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
+    t = fgrad_direction(g["species"])
+    aev, jt = oracle64.aev_jvp(p, g["species"], g["coords"].astype(np.float64), t, g["cell"], g["pbc"])
+    C, A = g["species"].shape
+    assert np.abs(jt.reshape(C * A, -1)[g["aev_rows"]] - f["aev_jvp"]).max() < 1e-11 * max(1.0, np.abs(f["aev_jvp"]).max())
+    # Loss = t . F = sum_i (-J t)_i . dE/d aev_i
+    val, grads = oracle64.mlp_tangent_weight_grads(g["species"], aev, -jt, dims, flat, n_members=g["n_members"])
+    assert abs(val - float(f["loss"])) < 1e-9 * max(1.0, abs(float(f["loss"])))
+    sums, dots, heads = wgrad_digest(grads)
+    scale = float(f["grad_abs_max"])
+    assert grads.shape[0] == int(f["n_params"])
+    assert abs(np.abs(grads).max() - scale) < 1e-6 * scale
+    assert np.abs(sums - f["block_sums"]).max() < 1e-6 * scale
+    assert np.abs(dots - f["block_dots"]).max() < 1e-6 * scale
+    assert np.abs(heads - f["block_heads"]).max() < 1e-6 * scale
 
 
 def test_member_energies(oracle64):
