@@ -166,6 +166,15 @@ int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *t
                         int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
                         const float *ent, const float *grad_aev, float *grad_coords, uint32_t *status);
 
+/* Forward-mode derivative of the AEV rows along a coordinate-space direction: daev[i] = sum_k (d aev[i] / d r_k) .
+ * tangent[k]  (tangent: [n_atoms][3]).  This is the reference's cuaev double backward (csrc/aev.cu:1986-2015,
+ * cuaev_double_backward, with the is_double_backward kernel variants :474-766,837-967): training on forces
+ * differentiates grad_coords = J^T grad_aev with respect to grad_aev, and the gradient arriving at the forces is the
+ * direction.  Rows lo <= i < hi of daev are written (rows of padding atoms zeroed). */
+int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms, int64_t lo,
+                   int64_t hi, const int32_t *species, const uint32_t *meta, const float *ent,
+                   const float *tangent, float *daev, uint32_t *status);
+
 /* anihip_aev_backward plus the virial of the back-propagated scalar,
  *   virial[3a + b] = sum over central atoms lo <= i < hi and their neighbors j of (d E_i / d d_ij)[a] * d_ij[b]
  * (fp64 [9], OVERWRITTEN; d_ij = the displacement stored in the row): the reference's "fdotr" virial

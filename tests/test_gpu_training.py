@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from _util import WGRAD_NAMES, load_golden, oracle_networks, oracle_params, seeded_state, wgrad_upstream
+from _util import (FGRAD_NAMES, WGRAD_NAMES, fgrad_direction, load_fgrads, load_golden, oracle_networks, oracle_params,
+                   seeded_state, wgrad_upstream)
 from test_gpu_parity import report
 
 pytestmark = pytest.mark.gpu
@@ -166,3 +167,43 @@ def test_frozen_species_and_inference_unchanged(dev):
     assert all(got)
     assert all(p.grad is None for p in nets.members[1].parameters())
     assert all(p.grad is None for p in nets.members[0].atomics["C"].parameters())
+
+
+@pytest.mark.parametrize("base", FGRAD_NAMES)
+def test_aev_jvp_matches_reference(dev, oracle64, base):
+    """anihip_aev_jvp (the reference's cuaev double backward: J t) against the reference's forward-mode derivative of
+    its AEVComputer (fixture rows) and against the oracle on every row; and the adjoint identity
+    <w, J t> = <J^T w, t> with the HIP backward kernel."""
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.weights import arch_spec
+
+    g, f = load_golden(base), load_fgrads(base)
+    consts = arch_spec(g["kind"])[1]._replace(cutoff_fn=g["cutoff_fn"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
+    t = fgrad_direction(g["species"])
+    _, jt_ref = oracle64.aev_jvp(p, g["species"], g["coords"].astype(np.float64), t, g["cell"], g["pbc"])
+    C, A = g["species"].shape
+    sp32 = torch.from_numpy(g["species"].astype(np.int32)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev).contiguous()
+    cell = None if g["cell"] is None else torch.from_numpy(g["cell"]).to(dev)
+    pbc = None if g["pbc"] is None else tuple(bool(b) for b in g["pbc"])
+    td = torch.from_numpy(t.astype(np.float32)).to(dev)
+    modes = ["batch", "cell"] if C == 1 else ["batch"]
+    for mode in modes:
+        aevc = AEVComputer(consts, neighborlist=mode, row_capacity=256).to(dev)
+        eng = aevc.engine()
+        rows = aevc.neighbor_rows(sp32, x, cell, pbc)
+        jt = eng.jvp(sp32, rows, td)
+        torch.cuda.synchronize()
+        got = jt.cpu().numpy().astype(np.float64)
+        scale = np.abs(jt_ref).max()
+        err = np.abs(got - jt_ref.reshape(C * A, -1)).max()
+        err_fix = np.abs(got[g["aev_rows"]] - f["aev_jvp"]).max()
+        report(f"jvp   {base:22s} {mode:5s} max|J t err| = {err:.2e} (max |J t| {scale:.2f}; fixture rows {err_fix:.2e})")
+        assert err < 2e-5 * max(1.0, scale) and err_fix < 2e-5 * max(1.0, scale)
+        w = torch.from_numpy(np.random.RandomState(5).uniform(-1, 1, (C * A, eng.L)).astype(np.float32)).to(dev)
+        gc = eng.backward(sp32, rows, w)
+        lhs = (w.double() * jt.double()).sum().item()
+        rhs = (gc.double() * td.view(-1, 3).double()).sum().item()
+        assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+        assert torch.all(jt.view(C, A, -1)[sp32 < 0] == 0)

@@ -139,6 +139,7 @@ def lib() -> C.CDLL:
     L.anihip_nbr_refresh.argtypes = [vp, C.POINTER(AevParams), i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.anihip_aev_forward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_aev_backward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.anihip_aev_jvp.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_aev_backward_virial.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.anihip_mlp_workspace_bytes.restype = sz
     L.anihip_mlp_workspace_bytes.argtypes = [C.POINTER(MlpDesc), i64]
@@ -153,7 +154,7 @@ def lib() -> C.CDLL:
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half",
                  "anihip_nbr_from_full", "anihip_nbr_refresh",
-                 "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_mlp_forward_backward",
+                 "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp", "anihip_aev_jvp", "anihip_mlp_forward_backward",
                  "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce"):
         getattr(L, name).restype = C.c_int
     if L.anihip_abi_version() != ABI_VERSION:

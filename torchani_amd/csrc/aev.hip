@@ -219,22 +219,34 @@ __device__ __forceinline__ AtomHdr hdr_decode(uint32_t w)
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NA, int NZ>
-__global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
+// JVP = true turns the kernel into the forward-mode derivative  out = (d aev / d r) . tang  (J t) for a coordinate-space
+// direction tang [n_atoms][3]: the reference's cuaev double backward (csrc/aev.cu:1986-2015 and the is_double_backward
+// kernel variants) -- the derivative of grad_coords = J^T grad_aev with respect to grad_aev, contracted with the
+// gradient arriving at the forces.  Same lane layout and reductions; every neighbor additionally carries
+// r' = u . d', u' = (d' - u r') / r, fc' r' (d' = t_j - t_i), every term is replaced by its directional derivative.
+template <int NA, int NZ, bool JVP>
+__global__ __launch_bounds__(FWD_WPB * WAVE, JVP ? 4 : 7) void k_aev_fwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
-    const float4 *__restrict__ ent, float *__restrict__ aev, uint32_t *__restrict__ slab_mask)
+    const float4 *__restrict__ ent, float *__restrict__ aev, uint32_t *__restrict__ slab_mask,
+    const float *__restrict__ tang)
 {
     static_assert(NA % 4 == 0 && NZ % 4 == 0 && NA * NZ == 32, "angular tiling");
     constexpr int AQ = NA / 4, ZQ = NZ / 4;
     __shared__ float4 s_ang[FWD_WPB][MAXA];   // ux uy uz r
     __shared__ float s_afc[FWD_WPB][MAXA];    // fc(r, Rca)
-    __shared__ float2 s_rad[FWD_WPB][MAXR];   // r, 0.25 fc(r, Rcr)
+    __shared__ float2 s_rad[FWD_WPB][MAXR];   // r, 0.25 fc(r, Rcr)            (JVP: r, 0.25 fc r')
+    __shared__ float4 s_angd[JVP ? FWD_WPB : 1][JVP ? MAXA : 1];   // JVP: u'x u'y u'z r'
+    __shared__ float s_afcd[JVP ? FWD_WPB : 1][JVP ? MAXA : 1];    // JVP: fc'(r, Rca) r'
+    __shared__ float s_radb[JVP ? FWD_WPB : 1][JVP ? MAXR : 1];    // JVP: 0.25 fc'(r, Rcr) r'
 
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();   // scalar LDS bases
     float4 *ang = s_ang[wib];
     float *afc = s_afc[wib];
     float2 *rad = s_rad[wib];
+    float4 *angd = s_angd[JVP ? wib : 0];
+    float *afcd = s_afcd[JVP ? wib : 0];
+    float *radb = s_radb[JVP ? wib : 0];
 
     // per-lane constants
     const int rp = lane >> 3, rsq = lane & 7;  // radial: neighbor slot, shift pair
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
                 const int e = c0 + lane;
                 float4 d = c0 == 0 ? e0 : (c0 == WAVE ? e1 : make_float4(1.f, 0.f, 0.f, 0.f));
                 if (c0 >= 2 * WAVE && e < nR) d = ent[start + e];
-                if (e < nR) {
+                if (!JVP && e < nR) {
                     const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
                     rad[e] = make_float2(r, a.smooth ? 0.25f * smooth_cutoff(r, 1.0f / a.Rcr).x
                                                      : 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f);
@@ -293,6 +305,28 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
                         ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, r);
                         afc[e] = a.smooth ? smooth_cutoff(r, 1.0f / a.Rca).x
                                           : 0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f;
+                    }
+                }
+                if (JVP && e < nR) {
+                    const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z), inv = 1.0f / r;
+                    const float ux = d.x * inv, uy = d.y * inv, uz = d.z * inv;
+                    const float *tj = tang + 3 * (size_t)(__float_as_uint(d.w) & IDX_MASK), *ti = tang + 3 * (size_t)i;
+                    const float tx = tj[0] - ti[0], ty = tj[1] - ti[1], tz = tj[2] - ti[2];
+                    const float rd = ux * tx + uy * ty + uz * tz;
+                    const float pi_rcr = PI_F / a.Rcr, pi_rca = PI_F / a.Rca;
+                    float2 cr = a.smooth ? smooth_cutoff(r, 1.0f / a.Rcr)
+                                         : make_float2(0.5f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.5f,
+                                                       -0.5f * pi_rcr * __builtin_amdgcn_sinf(r * rev_rcr));
+                    rad[e] = make_float2(r, 0.25f * cr.x * rd);
+                    radb[e] = 0.25f * cr.y * rd;
+                    if (e < nA) {
+                        const float2 ca = a.smooth ? smooth_cutoff(r, 1.0f / a.Rca)
+                                                   : make_float2(0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f,
+                                                                 -0.5f * pi_rca * __builtin_amdgcn_sinf(r * rev_rca));
+                        ang[e] = make_float4(ux, uy, uz, r);
+                        angd[e] = make_float4((tx - ux * rd) * inv, (ty - uy * rd) * inv, (tz - uz * rd) * inv, rd);
+                        afc[e] = ca.x;
+                        afcd[e] = ca.y * rd;
                     }
                 }
             }
@@ -338,8 +372,14 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
                     const float2 rf = rad[e];
                     const float f = v ? rf.y : 0.f;
                     const float d0 = rf.x - shfR0, d1 = rf.x - shfR1;
-                    acc0 += __builtin_amdgcn_exp2f(a.kR * d0 * d0) * f;
-                    acc1 += __builtin_amdgcn_exp2f(a.kR * d1 * d1) * f;
+                    if (!JVP) {
+                        acc0 += __builtin_amdgcn_exp2f(a.kR * d0 * d0) * f;
+                        acc1 += __builtin_amdgcn_exp2f(a.kR * d1 * d1) * f;
+                    } else {   // d/dt [0.25 exp(-eta d^2) fc] = exp(..) (0.25 fc' r' - 2 eta d 0.25 fc r')
+                        const float fb = v ? radb[e] : 0.f;
+                        acc0 += __builtin_amdgcn_exp2f(a.kR * d0 * d0) * (fb - 2.0f * a.EtaR * d0 * f);
+                        acc1 += __builtin_amdgcn_exp2f(a.kR * d1 * d1) * (fb - 2.0f * a.EtaR * d1 * f);
+                    }
                 }
                 // 8 slots -> 1: inside the DPP row, then across rows.  Row 0 ends with the totals of
                 // acc0, row 1 with those of acc1 (lanes 8..15 = shift pair rsq).
@@ -386,41 +426,84 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, 7) void k_aev_fwd(
                     const int jmax = nj - 1, kmax = (same ? nj : nk) - 1;
                     PairIter it = pair_begin(p, div, inv_div);
                     pair_get(it, same, nj, rect, half, jmax, kmax, jr, kr);
-                    float4 J = ang[oj + jr], K = ang[ok + kr];
-                    float fj = afc[oj + jr], fk = afc[ok + kr];
-                    for (int t0 = 0; t0 < np; t0 += 16) {
-                        const bool v = it.t < np;
-                        const float4 Jc = J, Kc = K;
-                        const float fcc = v ? 2.0f * fj * fk : 0.f;
-                        if (t0 + 16 < np) {
+                    if (!JVP) {
+                        float4 J = ang[oj + jr], K = ang[ok + kr];
+                        float fj = afc[oj + jr], fk = afc[ok + kr];
+                        for (int t0 = 0; t0 < np; t0 += 16) {
+                            const bool v = it.t < np;
+                            const float4 Jc = J, Kc = K;
+                            const float fcc = v ? 2.0f * fj * fk : 0.f;
+                            if (t0 + 16 < np) {
+                                pair_next(it, div, q16, r16);
+                                pair_get(it, same, nj, rect, half, jmax, kmax, jr, kr);
+                                J = ang[oj + jr];
+                                K = ang[ok + kr];
+                                fj = afc[oj + jr];
+                                fk = afc[ok + kr];
+                            }
+                            const float c = Jc.x * Kc.x + Jc.y * Kc.y + Jc.z * Kc.z;
+                            const float ct = 0.95f * c;
+                            const float st = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ct * ct, 0.f));
+                            const float rm = 0.5f * (Jc.w + Kc.w);
+                            float f1t[ZQ], f2[AQ];
+    #pragma unroll
+                            for (int vz = 0; vz < ZQ; ++vz) {
+                                const float cz = ct * cosZ[vz] + st * sinZ[vz];
+                                const float hh = fmaxf(0.5f + 0.5f * cz, 0.f);
+                                f1t[vz] = __builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(hh)) * fcc;
+                            }
+    #pragma unroll
+                            for (int u = 0; u < AQ; ++u) {
+                                const float d = rm - shfA[u];
+                                f2[u] = __builtin_amdgcn_exp2f(a.kA * d * d);
+                            }
+    #pragma unroll
+                            for (int z = 0; z < NZ; ++z) {
+                                const float f1 = quad_bcast_rt(f1t[z >> 2], z & 3);
+    #pragma unroll
+                                for (int u = 0; u < AQ; ++u) acc[u][z] += f2[u] * f1;
+                            }
+                        }
+                    } else {
+                        for (int t0 = 0; t0 < np; t0 += 16) {
+                            const bool v = it.t < np;
+                            const float4 Jc = ang[oj + jr], Kc = ang[ok + kr], Jd = angd[oj + jr], Kd = angd[ok + kr];
+                            const float fj = afc[oj + jr], fk = afc[ok + kr], fjd = afcd[oj + jr], fkd = afcd[ok + kr];
                             pair_next(it, div, q16, r16);
                             pair_get(it, same, nj, rect, half, jmax, kmax, jr, kr);
-                            J = ang[oj + jr];
-                            K = ang[ok + kr];
-                            fj = afc[oj + jr];
-                            fk = afc[ok + kr];
-                        }
-                        const float c = Jc.x * Kc.x + Jc.y * Kc.y + Jc.z * Kc.z;
-                        const float ct = 0.95f * c;
-                        const float st = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ct * ct, 0.f));
-                        const float rm = 0.5f * (Jc.w + Kc.w);
-                        float f1t[ZQ], f2[AQ];
+                            const float fcc = v ? 2.0f * fj * fk : 0.f;                    // (the 2 of f1 = 2 h^zeta)
+                            const float fccd = v ? 2.0f * (fjd * fk + fj * fkd) : 0.f;
+                            const float c = Jc.x * Kc.x + Jc.y * Kc.y + Jc.z * Kc.z;
+                            const float cd = Jd.x * Kc.x + Jd.y * Kc.y + Jd.z * Kc.z + Jc.x * Kd.x + Jc.y * Kd.y + Jc.z * Kd.z;
+                            const float ct = 0.95f * c;
+                            const float st2 = fmaxf(1.0f - ct * ct, 1e-12f);
+                            const float rst = __builtin_amdgcn_rsqf(st2);
+                            const float st = st2 * rst;
+                            const float thd = -0.95f * cd * rst;                           // d theta / dt
+                            const float rm = 0.5f * (Jc.w + Kc.w), rmd = 0.5f * (Jd.w + Kd.w);
+                            float At[ZQ], Bt[ZQ], f2[AQ], df2[AQ];
 #pragma unroll
-                        for (int vz = 0; vz < ZQ; ++vz) {
-                            const float cz = ct * cosZ[vz] + st * sinZ[vz];
-                            const float hh = fmaxf(0.5f + 0.5f * cz, 0.f);
-                            f1t[vz] = __builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(hh)) * fcc;
-                        }
+                            for (int vz = 0; vz < ZQ; ++vz) {
+                                const float cz = ct * cosZ[vz] + st * sinZ[vz];   // cos(theta - ShfZ)
+                                const float sz = st * cosZ[vz] - ct * sinZ[vz];   // sin(theta - ShfZ)
+                                const float hh = fmaxf(0.5f + 0.5f * cz, 0.f);
+                                const float p1 = __builtin_amdgcn_exp2f((a.Zeta - 1.0f) * __builtin_amdgcn_logf(hh));
+                                const float f1 = hh * p1, df1 = -0.5f * a.Zeta * p1 * sz;  // h^zeta and its theta derivative
+                                At[vz] = df1 * thd * fcc + f1 * fccd;
+                                Bt[vz] = f1 * rmd * fcc;
+                            }
 #pragma unroll
-                        for (int u = 0; u < AQ; ++u) {
-                            const float d = rm - shfA[u];
-                            f2[u] = __builtin_amdgcn_exp2f(a.kA * d * d);
-                        }
+                            for (int u = 0; u < AQ; ++u) {
+                                const float d = rm - shfA[u];
+                                f2[u] = __builtin_amdgcn_exp2f(a.kA * d * d);
+                                df2[u] = -2.0f * a.EtaA * d * f2[u];
+                            }
 #pragma unroll
-                        for (int z = 0; z < NZ; ++z) {
-                            const float f1 = quad_bcast_rt(f1t[z >> 2], z & 3);
+                            for (int z = 0; z < NZ; ++z) {
+                                const float Az = quad_bcast_rt(At[z >> 2], z & 3), Bz = quad_bcast_rt(Bt[z >> 2], z & 3);
 #pragma unroll
-                            for (int u = 0; u < AQ; ++u) acc[u][z] += f2[u] * f1;
+                                for (int u = 0; u < AQ; ++u) acc[u][z] += f2[u] * Az + df2[u] * Bz;
+                            }
                         }
                     }
                     // 16 slots -> 1.  Inside each DPP row (4 slots): two shifted adds leave the row
@@ -814,11 +897,32 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     if (hi == lo) return 0;
     dim3 grid(persistent_blocks(hi - lo, FWD_WPB, 7)), block(FWD_WPB * WAVE);
     if (p->n_shf_a == 8)
-        hipLaunchKernelGGL((k_aev_fwd<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, aev, slab_mask);
+        hipLaunchKernelGGL((k_aev_fwd<8, 4, false>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, aev, slab_mask, (const float *)nullptr);
     else
-        hipLaunchKernelGGL((k_aev_fwd<4, 8>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, aev, slab_mask);
+        hipLaunchKernelGGL((k_aev_fwd<4, 8, false>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, aev, slab_mask, (const float *)nullptr);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    (void)status;
+    return 0;
+}
+
+extern "C" int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
+                              int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
+                              const float *ent, const float *tangent, float *daev, uint32_t *status)
+{
+    ANIHIP_REQUIRE(p && table && species && meta && ent && tangent && daev, "null pointer argument");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    AevArgs a;
+    if (int rc = make_args(p, &a)) return rc;
+    if (hi == lo) return 0;
+    dim3 grid(persistent_blocks(hi - lo, FWD_WPB, 4)), block(FWD_WPB * WAVE);
+    if (p->n_shf_a == 8)
+        hipLaunchKernelGGL((k_aev_fwd<8, 4, true>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, daev, (uint32_t *)nullptr, tangent);
+    else
+        hipLaunchKernelGGL((k_aev_fwd<4, 8, true>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, daev, (uint32_t *)nullptr, tangent);
     ANIHIP_CHECK_HIP(hipGetLastError());
     (void)status;
     return 0;

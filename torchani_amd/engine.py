@@ -247,6 +247,20 @@ class AevEngine:
             _ptr(nbrs.status)))
         return out
 
+    def jvp(self, species: Tensor, nbrs: NeighborRows, tangent: Tensor) -> Tensor:
+        """J t [N, L]: derivative of the AEV rows of nbrs' central atoms along the coordinate direction tangent [N, 3]
+        (anihip_aev_jvp; the reference's cuaev double backward)."""
+        _require_cuda(species, tangent)
+        n = species.numel()
+        t = tangent.detach().to(torch.float32).contiguous()
+        assert t.numel() == 3 * n
+        out = torch.empty((n, self.L), dtype=torch.float32, device=species.device) \
+            if (nbrs.lo == 0 and nbrs.hi == n) else torch.zeros((n, self.L), dtype=torch.float32, device=species.device)
+        _lib.check(_lib.lib().anihip_aev_jvp(
+            _stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi, _ptr(species),
+            _ptr(nbrs.meta), _ptr(nbrs.ent), _ptr(t), _ptr(out), _ptr(nbrs.status)))
+        return out
+
     def backward(self, species: Tensor, nbrs: NeighborRows, grad_aev: Tensor,
                  grad_coords: tp.Optional[Tensor] = None, shard_rows: bool = False,
                  virial: tp.Optional[Tensor] = None) -> Tensor:
