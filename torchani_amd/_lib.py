@@ -154,7 +154,7 @@ def lib() -> C.CDLL:
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half",
                  "anihip_nbr_from_full", "anihip_nbr_refresh",
-                 "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp", "anihip_aev_jvp", "anihip_mlp_forward_backward",
+                 "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp", "anihip_mlp_forward_backward",
                  "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce"):
         getattr(L, name).restype = C.c_int
     if L.anihip_abi_version() != ABI_VERSION:
@@ -166,7 +166,7 @@ def lib() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "anihip_last_error", "anihip_abi_version", "anihip_aev_table_pack", "anihip_nbr_workspace_bytes",
     "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_half_workspace_bytes", "anihip_nbr_from_half", "anihip_nbr_from_full",
-    "anihip_nbr_refresh", "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial",
+    "anihip_nbr_refresh", "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp",
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
     "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
 ]
