@@ -304,6 +304,20 @@ int anihip_mlp_train_forward(void *stream, const anihip_mlp_desc *d, int64_t n_a
                              const int32_t *species, const float *aev, void *workspace, size_t workspace_bytes,
                              float *atomic_e);
 
+/* Second-order pass for training on forces.  For per-atom tangents (tangent: [n_atoms][aev_len]) let
+ *     S = sum_i tangent[i] . d atomic_e[i] / d aev[i]
+ * (with tangent = -J t, J t from anihip_aev_jvp, S = sum_k t_k . F_k for the forces F = -dE/dr: the part of a force
+ * loss that the reference back-propagates through torch.autograd.grad(E, coords, create_graph=True),
+ * tools/training-aev-benchmark.py:136-150).  grads = d S / d (weights, biases) in the layouts of
+ * anihip_mlp_weight_grads (OVERWRITTEN); datomic_e[i] = tangent[i] . d atomic_e[i] / d aev[i] (the directional
+ * derivative of the energies; entries of padding atoms zeroed).  Exact fp32: forward-over-reverse with the
+ * activations a_l, their tangents and both adjoint streams kept in the workspace. */
+size_t anihip_mlp_tangent_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central);
+int anihip_mlp_tangent_weight_grads(void *stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo, int64_t hi,
+                                    const int32_t *species, const float *aev, const float *tangent,
+                                    void *workspace, size_t workspace_bytes, const anihip_species_grads *grads,
+                                    float *datomic_e);
+
 /* Refresh the packed fp32 parameter arrays of an ANIHIP_MLP_FP32 descriptor (the arrays w / wt / bias point to are
  * REWRITTEN in place; padding stays zero) from the torch.nn.Linear tensors after an optimizer step -- one launch
  * instead of re-packing on the host (cf. BmmAtomicNetwork packing once per model, nn/_infer.py:141-161).

@@ -207,3 +207,41 @@ def test_aev_jvp_matches_reference(dev, oracle64, base):
         rhs = (gc.double() * td.view(-1, 3).double()).sum().item()
         assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
         assert torch.all(jt.view(C, A, -1)[sp32 < 0] == 0)
+
+
+@pytest.mark.parametrize("base", FGRAD_NAMES)
+def test_tangent_weight_grads_match_oracle(dev, oracle64, base):
+    """anihip_mlp_tangent_weight_grads: d/d params of S = sum_i v_i . d e_i / d aev_i against the oracle (pinned to the
+    reference's create_graph autograd by tests/golden/fgrads_*.npz), with v = -J t from the HIP JVP kernel -- i.e. the
+    whole second-order chain of a force loss on the GPU."""
+    from torchani_amd.aev import AEVComputer
+
+    g = load_golden(base)
+    dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
+    t = fgrad_direction(g["species"])
+    aev_ref, jt_ref = oracle64.aev_jvp(p, g["species"], g["coords"].astype(np.float64), t, g["cell"], g["pbc"])
+    val_ref, ref = oracle64.mlp_tangent_weight_grads(g["species"], aev_ref, -jt_ref, dims, flat, n_members=8)
+    model = fresh_model(g["kind"], g["seed"], dev, g["cutoff_fn"])
+    model.aev_computer.row_capacity = 256
+    C, A = g["species"].shape
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    sp32 = sp.to(torch.int32)
+    x = torch.from_numpy(g["coords"]).to(dev).contiguous()
+    cell = None if g["cell"] is None else torch.from_numpy(g["cell"]).to(dev)
+    pbc = None if g["pbc"] is None else tuple(bool(b) for b in g["pbc"])
+    aevc = model.aev_computer
+    rows = aevc.neighbor_rows(sp32, x, cell, pbc)
+    eng = aevc.engine()
+    aev = eng.forward(sp32, rows)
+    jt = eng.jvp(sp32, rows, torch.from_numpy(t.astype(np.float32)).to(dev))
+    packed = model.neural_networks._train_pack(dev)
+    gw, gb, de = packed.tangent_weight_grads(sp32, aev, -jt)
+    torch.cuda.synchronize()
+    got = flat_from_lists(gw, gb, packed.M, packed.S, packed.nl)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    s_err = abs(de.double().sum().item() - val_ref)
+    report(f"fgrad {base:22s} max|d(t.F)/dw err| = {err:.2e} (max {scale:.2e})  |t.F err| = {s_err:.2e} (t.F = {val_ref:+.5f})")
+    assert err < 5e-5 * scale
+    assert s_err < 1e-5 * max(1.0, abs(val_ref))

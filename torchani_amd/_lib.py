@@ -149,13 +149,17 @@ def lib() -> C.CDLL:
     L.anihip_mlp_train_workspace_bytes.argtypes = [C.POINTER(MlpDesc), i64]
     L.anihip_mlp_weight_grads.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, vp, sz,
                                           C.POINTER(SpeciesGrads), vp, vp, i32]
+    L.anihip_mlp_tangent_workspace_bytes.restype = sz
+    L.anihip_mlp_tangent_workspace_bytes.argtypes = [C.POINTER(MlpDesc), i64]
+    L.anihip_mlp_tangent_weight_grads.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, vp, sz,
+                                                  C.POINTER(SpeciesGrads), vp]
     L.anihip_mlp_train_forward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, sz, vp]
     L.anihip_mlp_repack.argtypes = [vp, C.POINTER(MlpDesc), vp, vp]
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half",
                  "anihip_nbr_from_full", "anihip_nbr_refresh",
                  "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp", "anihip_mlp_forward_backward",
-                 "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce"):
+                 "anihip_mlp_weight_grads", "anihip_mlp_tangent_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce"):
         getattr(L, name).restype = C.c_int
     if L.anihip_abi_version() != ABI_VERSION:
         raise RuntimeError("libanihip.so ABI version mismatch: rebuild it")
@@ -169,6 +173,7 @@ EXPORTED_SYMBOLS = [
     "anihip_nbr_refresh", "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp",
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
     "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
+    "anihip_mlp_tangent_workspace_bytes", "anihip_mlp_tangent_weight_grads",
 ]
 
 

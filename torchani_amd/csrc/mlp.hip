@@ -34,7 +34,13 @@ constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDS_LD = BM + 4;
 constexpr int GEMM_THREADS = 256;
 
-enum Epilogue { EPI_BIAS_CELU = 0, EPI_DCELU = 1, EPI_SCATTER = 2 };
+enum Epilogue {
+    EPI_BIAS_CELU = 0, EPI_DCELU = 1, EPI_SCATTER = 2,
+    // second-order (tangent) pass of force training, exact-fp32 k_gemm only:
+    EPI_TANGENT = 3,   // v = W adot_prev:        C = zdot = v,  C2 = adot = c'(Y) v            (Y = activations)
+    EPI_ADJ_P = 4,     // v = mu = W^T p_next:    C = p = mu c'(Y),  C2 = mu c''(Y) Z           (Z = zdot)
+    EPI_ADJ_Q = 5      // v = nu = W^T q_next:    C += nu c'(Y)                                 (C holds mu c'' zdot)
+};
 
 struct GemmProblem {
     const float *B;     // fp32 path: [batch][K][ldb]
@@ -62,6 +68,8 @@ struct GemmArgs {
     int64_t ldc;
     const float *Y;        // EPI_DCELU of the training pass (k_gemm): activations read from here, C only written
     int64_t ldy;           //   (NULL: C holds the activations and is overwritten in place)
+    const float *Z;        // tangent pass: zdot (same leading dimension as Y)
+    float *C2;             // tangent pass: second output (same leading dimension as C)
     const int *c_scatter;  // sorted position -> destination row (last backward GEMM) or NULL
     int n_store;           // EPI_SCATTER: only columns < n_store are stored
     int S, batch, ncol_max, nrow_tiles_ub;
@@ -304,6 +312,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs g)
                 const float y = g.Y ? g.Y[(int64_t)(p0 + row) * g.ldy + (int64_t)bb * pr.c_boff + col]
                                     : __builtin_nontemporal_load(cp);
                 *cp = v * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+            } else if (EPI == EPI_TANGENT || EPI == EPI_ADJ_P || EPI == EPI_ADJ_Q) {
+                // celu'(x) and celu''(x) from the stored activation y: x > 0: (1, 0); else (y/alpha + 1, celu'/alpha)
+                const int64_t ic = (int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col;
+                const int64_t iy = (int64_t)(p0 + row) * g.ldy + (int64_t)bb * pr.c_boff + col;
+                const float y = g.Y[iy];
+                const float c1 = y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f;
+                if (EPI == EPI_TANGENT) {
+                    g.C[ic] = v;
+                    g.C2[ic] = c1 * v;
+                } else if (EPI == EPI_ADJ_P) {
+                    g.C[ic] = v * c1;
+                    g.C2[ic] = y > 0.f ? 0.f : v * c1 * g.inv_alpha * g.Z[iy];
+                } else {
+                    g.C[ic] += v * c1;
+                }
             } else {
                 if (col < g.n_store)
                     g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + col] = v;
@@ -1696,12 +1719,54 @@ __global__ __launch_bounds__(256) void k_col_reduce(ColReduceArgs g)
     const float *x = g.X[s] + (cv ? col : 0);
     float acc = 0.f, sacc = 0.f;
     for (int r = 0; r < n_rows; ++r) {
-        const float sc = g.g_atom ? g.g_atom[g.perm[p0 + r]] * g.inv_m : 1.0f;
+        const float sc = (g.g_atom ? g.g_atom[g.perm[p0 + r]] : 1.0f) * g.inv_m;
         acc += sc * x[(int64_t)(p0 + r) * g.ldx];
         sacc += sc;
     }
     if (cv) atomicAdd(g.out[s] + col, acc);
     if (g.extra[s] && ct == 0 && threadIdx.x < g.M) atomicAdd(g.extra[s] + threadIdx.x, sacc);
+}
+
+// output layer of the tangent pass: p = w3 c'(a3) / M,  q = w3 c''(a3) zdot3 / M,  d atomic_e = sum_m w3 . adot3 / M
+struct HeadTangentArgs {
+    const float *w[MAX_S];   // [M][Hp]
+    int Hp[MAX_S];
+    const int *ctl;
+    const int *perm;
+    const float *act, *zd, *ad;   // last hidden layer: activations, zdot, adot  [n][ld]
+    float *P, *Q;
+    int64_t ld;
+    float *datomic_e;             // [n_atoms] or NULL
+    int S, M;
+    float inv_alpha;
+};
+
+__global__ __launch_bounds__(256) void k_head_tangent(HeadTangentArgs h)
+{
+    const int lane = lane_id();
+    const int64_t n = h.ctl[CTL_OFF + h.S];
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    const float invM = 1.0f / (float)h.M;
+    for (int64_t p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += nw) {
+        int s = 0;
+        while (s + 1 < h.S && p >= h.ctl[CTL_OFF + s + 1]) ++s;
+        const int Hp = h.Hp[s];
+        float part = 0.f;
+        for (int m = 0; m < h.M; ++m) {
+            const float *w = h.w[s] + (int64_t)m * Hp;
+            for (int o = lane; o < Hp; o += WAVE) {
+                const int64_t idx = p * h.ld + m * Hp + o;
+                const float y = h.act[idx], zd = h.zd[idx];
+                const float c1 = y > 0.f ? 1.0f : y * h.inv_alpha + 1.0f;
+                const float mu = invM * w[o];
+                h.P[idx] = mu * c1;
+                h.Q[idx] = y > 0.f ? 0.f : mu * c1 * h.inv_alpha * zd;
+                part += mu * h.ad[idx];
+            }
+        }
+        part = wave_sum(part);
+        if (h.datomic_e && lane == 0) h.datomic_e[h.perm[p]] = part;
+    }
 }
 
 // ---- parameter refresh (training) ----------------------------------------------------------------------
@@ -1838,6 +1903,23 @@ static size_t mlp_train_carve(const anihip_mlp_desc *d, int64_t n, char *base, M
     return off;
 }
 
+// tangent pass: the inference workspace + four more buffers per hidden layer (zdot, adot, p, q)
+static size_t mlp_tangent_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWorkspace *w,
+                                float *(*buf)[ANIHIP_MAX_LAYERS] /* [4] */)
+{
+    size_t off = align256(mlp_carve(d, n, base, w));
+    const int nh = d->net[0].n_layers - 1;
+    for (int k = 0; k < 4; ++k)
+        for (int l = 0; l < nh; ++l) {
+            int mx = 0;
+            for (int s = 0; s < d->num_species; ++s) mx = mx > d->net[s].dims[l + 1] ? mx : d->net[s].dims[l + 1];
+            const size_t bytes = sizeof(float) * (size_t)mx * d->n_members * (size_t)(n + 1);
+            if (buf) buf[k][l] = base ? (float *)(base + off) : nullptr;
+            off += align256(bytes);
+        }
+    return off;
+}
+
 }  // namespace anihip
 
 using namespace anihip;
@@ -1913,6 +1995,13 @@ static void launch_gemm(hipStream_t stream, GemmArgs &g, bool f16x3)
         hipLaunchKernelGGL((k_gemm_h<EPI>), dim3((unsigned)total), dim3(GEMM_THREADS), 0, stream, g);
     else
         hipLaunchKernelGGL((k_gemm<EPI>), dim3((unsigned)total), dim3(GEMM_THREADS), 0, stream, g);
+}
+
+template <int EPI>
+static void launch_gemm_fp32(hipStream_t stream, GemmArgs &g)
+{
+    const int64_t total = (int64_t)g.nrow_tiles_ub * g.ncol_max * g.batch;
+    hipLaunchKernelGGL((k_gemm<EPI>), dim3((unsigned)total), dim3(GEMM_THREADS), 0, stream, g);
 }
 
 extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc *d, int64_t n_atoms,
@@ -2409,6 +2498,163 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
             launch_gemm<EPI_SCATTER>(stream, g, false);
         else
             launch_gemm<EPI_DCELU>(stream, g, false);
+    }
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" size_t anihip_mlp_tangent_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central)
+{
+    if (!d || n_central < 0) return 0;
+    return mlp_tangent_carve(d, n_central, nullptr, nullptr, nullptr);
+}
+
+extern "C" int anihip_mlp_tangent_weight_grads(void *stream_, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo,
+                                               int64_t hi, const int32_t *species, const float *aev,
+                                               const float *tangent, void *workspace, size_t workspace_bytes,
+                                               const anihip_species_grads *grads, float *datomic_e)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (int rc = check_desc(d)) return rc;
+    ANIHIP_REQUIRE(species && aev && tangent && workspace && grads && datomic_e, "null pointer argument");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1, L = d->aev_len;
+    for (int s = 0; s < S; ++s)
+        for (int l = 0; l < nl; ++l)
+            ANIHIP_REQUIRE(grads[s].gw[l] && grads[s].gbias[l], "species %d layer %d: null gradient pointer", s, l);
+    for (int s = 0; s < S; ++s) {
+        const anihip_species_net &nn = d->net[s];
+        for (int l = 0; l < nl; ++l) {
+            zero_words_async(stream, grads[s].gw[l], sizeof(float) * (size_t)M * nn.dims[l] * nn.dims[l + 1]);
+            zero_words_async(stream, grads[s].gbias[l], sizeof(float) * (size_t)M * nn.dims[l + 1]);
+        }
+    }
+    const int64_t n = hi - lo;
+    if (n == 0) return 0;
+    ANIHIP_REQUIRE(workspace_bytes >= mlp_tangent_carve(d, n, nullptr, nullptr, nullptr), "workspace too small");
+    MlpWorkspace w;
+    float *buf[4][ANIHIP_MAX_LAYERS];
+    mlp_tangent_carve(d, n, (char *)workspace, &w, buf);
+    float **zd = buf[0], **ad = buf[1], **P = buf[2], **Q = buf[3];
+    const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
+
+    // 1. bucket by species, activations a_l (datomic_e doubles as the array whose padding entries get zeroed)
+    if (int rc = train_forward(stream, d, n_atoms, lo, hi, species, aev, w, datomic_e, nullptr)) return rc;
+    const int nrow_ub = (int)((n + BM - 1) / BM) + S;
+    auto width_max = [&](int l) {
+        int mx = 0;
+        for (int s = 0; s < S; ++s) mx = mx > d->net[s].dims[l] ? mx : d->net[s].dims[l];
+        return mx;
+    };
+    auto gemm_base = [&]() {
+        GemmArgs g{};
+        g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha; g.nrow_tiles_ub = nrow_ub;
+        g.amax_in = g.amax_out = -1;
+        return g;
+    };
+    // 2. tangents: zdot_l = W_l adot_{l-1}, adot_l = c'(z_l) zdot_l   (adot_0 = tangent rows)
+    for (int l = 0; l < nh; ++l) {
+        GemmArgs g = gemm_base();
+        g.C = zd[l]; g.C2 = ad[l]; g.ldc = w.ld[l]; g.Y = w.act[l]; g.ldy = w.ld[l];
+        if (l == 0) {
+            g.A = tangent; g.lda = L; g.a_gather = w.perm; g.batch = 1;
+            g.ncol_max = (width_max(1) * M + BN - 1) / BN;
+        } else {
+            g.A = ad[l - 1]; g.lda = w.ld[l - 1]; g.batch = M;
+            g.ncol_max = (width_max(l + 1) + BN - 1) / BN;
+        }
+        for (int s = 0; s < S; ++s) {
+            const anihip_species_net &nn = d->net[s];
+            GemmProblem &p = g.prob[s];
+            p.B = nn.w[l];
+            if (l == 0) {
+                p.K = nn.dims[0]; p.N = nn.dims[1] * M; p.ldb = p.N;
+            } else {
+                p.K = nn.dims[l]; p.N = nn.dims[l + 1]; p.ldb = p.N;
+                p.a_boff = nn.dims[l]; p.c_boff = nn.dims[l + 1];
+                p.b_stride = (int64_t)p.K * p.N;
+            }
+        }
+        launch_gemm_fp32<EPI_TANGENT>(stream, g);
+    }
+    // 3. output layer: adjoint seeds p, q of the last hidden layer, d atomic_e, d w_out (d b_out = 0)
+    {
+        HeadTangentArgs h{};
+        for (int s = 0; s < S; ++s) { h.w[s] = d->net[s].w[nl - 1]; h.Hp[s] = d->net[s].dims[nl - 1]; }
+        h.ctl = w.ctl; h.perm = w.perm; h.act = w.act[nh - 1]; h.zd = zd[nh - 1]; h.ad = ad[nh - 1];
+        h.P = P[nh - 1]; h.Q = Q[nh - 1]; h.ld = w.ld[nh - 1]; h.datomic_e = datomic_e; h.S = S; h.M = M;
+        h.inv_alpha = inv_alpha;
+        int64_t blocks = (n + 3) / 4;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(k_head_tangent, dim3((unsigned)blocks), dim3(256), 0, stream, h);
+    }
+    const int cr_chunks = (int)((n + CR_ROWS - 1) / CR_ROWS) + S;
+    auto col_reduce = [&](const float *X, int64_t ldx, int l_out, bool weights, float scale) {
+        ColReduceArgs c{};
+        int mx = 0;
+        for (int s = 0; s < S; ++s) {
+            c.X[s] = X;
+            c.ncols[s] = M * d->net[s].dims[l_out];
+            c.out[s] = weights ? grads[s].gw[nl - 1] : grads[s].gbias[l_out - 1];
+            c.extra[s] = nullptr;
+            mx = mx > c.ncols[s] ? mx : c.ncols[s];
+        }
+        c.ldx = ldx; c.ctl = w.ctl; c.perm = w.perm; c.S = S; c.M = M; c.g_atom = nullptr; c.inv_m = scale;
+        c.ct_max = (mx + 255) / 256;
+        hipLaunchKernelGGL(k_col_reduce, dim3((unsigned)(cr_chunks * c.ct_max)), dim3(256), 0, stream, c);
+    };
+    col_reduce(ad[nh - 1], w.ld[nh - 1], nl - 1, true, 1.0f / (float)M);   // d S / d w_out = sum adot_last / M
+
+    // 4. adjoints down the layers; d S / d W_l = p_l adot_{l-1}^T + q_l a_{l-1}^T, d S / d b_l = sum q_l
+    const int wg_chunks = (int)((n + WG_ROWS - 1) / WG_ROWS) + S;
+    for (int l = nh - 1; l >= 0; --l) {
+        col_reduce(Q[l], w.ld[l], l + 1, false, 1.0f);
+        for (int term = 0; term < 2; ++term) {
+            WgradArgs a{};
+            a.ctl = w.ctl; a.S = S;
+            a.x_gather = l == 0 ? w.perm : nullptr;
+            a.batch = l == 0 ? 1 : M;
+            int kmax = 0, nmax = 0;
+            for (int s = 0; s < S; ++s) {
+                const anihip_species_net &nn = d->net[s];
+                WgradProblem &p = a.prob[s];
+                p.D = term == 0 ? P[l] : Q[l]; p.ldd = w.ld[l]; p.dW = grads[s].gw[l];
+                if (l == 0) {
+                    p.X = term == 0 ? tangent : aev; p.ldx = L; p.x_boff = 0; p.K = L; p.k_valid = L;
+                    p.d_boff = 0; p.N = nn.dims[1] * M; p.ldw = L; p.w_bstride = 0;
+                } else {
+                    p.X = term == 0 ? ad[l - 1] : w.act[l - 1]; p.ldx = w.ld[l - 1]; p.x_boff = nn.dims[l];
+                    p.K = nn.dims[l]; p.k_valid = p.K;
+                    p.d_boff = nn.dims[l + 1]; p.N = nn.dims[l + 1]; p.ldw = p.K; p.w_bstride = (int64_t)p.K * p.N;
+                }
+                kmax = kmax > p.K ? kmax : p.K;
+                nmax = nmax > p.N ? nmax : p.N;
+            }
+            a.ki_max = (kmax + 63) / 64;
+            a.nj_max = (nmax + 255) / 256;
+            const int64_t total = (int64_t)wg_chunks * a.batch * a.ki_max * a.nj_max;
+            hipLaunchKernelGGL(k_wgrad, dim3((unsigned)total), dim3(256), 0, stream, a);
+        }
+        if (l == 0) break;
+        for (int pass = 0; pass < 2; ++pass) {   // mu = W^T p -> (p, mu c'' zdot);  nu = W^T q -> q += nu c'
+            GemmArgs g = gemm_base();
+            g.A = pass == 0 ? P[l] : Q[l]; g.lda = w.ld[l]; g.batch = M;
+            g.C = pass == 0 ? P[l - 1] : Q[l - 1]; g.C2 = Q[l - 1]; g.ldc = w.ld[l - 1];
+            g.Y = w.act[l - 1]; g.Z = zd[l - 1]; g.ldy = w.ld[l - 1];
+            g.ncol_max = (width_max(l) + BN - 1) / BN;
+            for (int s = 0; s < S; ++s) {
+                const anihip_species_net &nn = d->net[s];
+                GemmProblem &p = g.prob[s];
+                p.B = nn.wt[l];
+                p.K = nn.dims[l + 1]; p.N = nn.dims[l]; p.ldb = p.N;
+                p.a_boff = nn.dims[l + 1]; p.c_boff = nn.dims[l];
+                p.b_stride = (int64_t)p.K * p.N;
+            }
+            if (pass == 0)
+                launch_gemm_fp32<EPI_ADJ_P>(stream, g);
+            else
+                launch_gemm_fp32<EPI_ADJ_Q>(stream, g);
+        }
     }
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;

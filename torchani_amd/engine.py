@@ -558,6 +558,66 @@ class PackedNetworks:
                                               _ptr(ws), ws.numel(), _ptr(atomic_e)))
         return atomic_e, ws
 
+    def _grad_buffers(self, dev):
+        """One flat fp32 buffer holding every gradient array of anihip_species_grads + the ctypes pointer table."""
+        M, S, nl, d = self.M, self.S, self.nl, self.desc
+        sizes = []
+        for s in range(S):
+            dims = [d.net[s].dims[l] for l in range(nl + 1)]
+            for l in range(nl):
+                sizes += [M * dims[l] * dims[l + 1], M * dims[l + 1]]
+        offs = np.concatenate([[0], np.cumsum([(x + 63) // 64 * 64 for x in sizes])])
+        buf = torch.empty(int(offs[-1]), dtype=torch.float32, device=dev)
+        sg = (_lib.SpeciesGrads * S)()
+        q = 0
+        for s in range(S):
+            for l in range(nl):
+                sg[s].gw[l] = buf.data_ptr() + 4 * int(offs[q])
+                sg[s].gbias[l] = buf.data_ptr() + 4 * int(offs[q + 1])
+                q += 2
+        return buf, sg, sizes, offs
+
+    def _unpack_grads(self, total: Tensor, sizes, offs):
+        """Flat gradient buffer -> gw[m][s][l] [out, in], gb[m][s][l] [out] (views when the widths are unpadded)."""
+        M, S, nl, d = self.M, self.S, self.nl, self.desc
+        gw = [[[None] * nl for _ in range(S)] for _ in range(M)]
+        gb = [[[None] * nl for _ in range(S)] for _ in range(M)]
+        q = 0
+        for s in range(S):
+            dims = [d.net[s].dims[l] for l in range(nl + 1)]
+            for l in range(nl):
+                out, inn = self.shapes[s][l]
+                w = total[int(offs[q]): int(offs[q]) + sizes[q]]
+                b = total[int(offs[q + 1]): int(offs[q + 1]) + sizes[q + 1]]
+                q += 2
+                if l == nl - 1:
+                    wv, bv = w.view(M, 1, dims[l]), b.view(M, 1)
+                else:
+                    wv, bv = w.view(M, dims[l + 1], dims[l]), b.view(M, dims[l + 1])   # nn.Linear layout
+                for m in range(M):
+                    gw[m][s][l] = wv[m, :out, :inn]
+                    gb[m][s][l] = bv[m, :out]
+        return gw, gb
+
+    def tangent_weight_grads(self, species: Tensor, aev: Tensor, tangent: Tensor):
+        """Second-order pass of force training (anihip_mlp_tangent_weight_grads): gradients with respect to every
+        weight and bias of  S = sum_i tangent_i . d atomic_e[i] / d aev_i,  plus the per-atom terms of S [N]."""
+        _require_cuda(species, aev, tangent)
+        n = species.numel()
+        dev = aev.device
+        assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == n * self.aev_len
+        t = tangent.to(torch.float32).contiguous()
+        assert t.numel() == n * self.aev_len
+        buf, sg, sizes, offs = self._grad_buffers(dev)
+        L = _lib.lib()
+        ws = torch.empty(L.anihip_mlp_tangent_workspace_bytes(C.byref(self.desc), n), dtype=torch.uint8, device=dev)
+        de = torch.zeros(n, dtype=torch.float32, device=dev)
+        _lib.check(L.anihip_mlp_tangent_weight_grads(
+            _stream(), C.byref(self.desc), n, 0, n, _ptr(species), _ptr(aev), _ptr(t), _ptr(ws), ws.numel(), sg,
+            _ptr(de)))
+        gw, gb = self._unpack_grads(buf, sizes, offs)
+        return gw, gb, de
+
     def weight_grads(self, species: Tensor, aev: Tensor, grad_atomic_e: Tensor,
                      want_grad_aev: bool = False, chunk: int = 1 << 16, workspace: tp.Optional[Tensor] = None):
         """Training pass (anihip_mlp_weight_grads): gradients of  sum_i grad_atomic_e[i] * atomic_e[i]  with respect
@@ -570,14 +630,7 @@ class PackedNetworks:
         assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == n * self.aev_len
         g_at = grad_atomic_e.to(torch.float32).contiguous().view(-1)
         assert g_at.numel() == n
-        M, S, nl, d = self.M, self.S, self.nl, self.desc
-        # packed gradient buffers, shapes of anihip_species_net.w / bias
-        sizes = []
-        for s in range(S):
-            dims = [d.net[s].dims[l] for l in range(nl + 1)]
-            for l in range(nl):
-                sizes += [M * dims[l] * dims[l + 1], M * dims[l + 1]]
-        offs = np.concatenate([[0], np.cumsum([(x + 63) // 64 * 64 for x in sizes])])
+        d = self.desc
         atomic_e = torch.zeros(n, dtype=torch.float32, device=dev)
         grad_aev = torch.zeros((n, self.aev_len), dtype=torch.float32, device=dev) if want_grad_aev else None
         L = _lib.lib()
@@ -586,14 +639,7 @@ class PackedNetworks:
             chunk = max(n, 1)   # the forward half ran over all atoms at once (train_forward)
         for c0 in range(0, max(n, 1), chunk):
             c1 = min(n, c0 + chunk)
-            buf = torch.empty(int(offs[-1]), dtype=torch.float32, device=dev)
-            sg = (_lib.SpeciesGrads * S)()
-            q = 0
-            for s in range(S):
-                for l in range(nl):
-                    sg[s].gw[l] = buf.data_ptr() + 4 * int(offs[q])
-                    sg[s].gbias[l] = buf.data_ptr() + 4 * int(offs[q + 1])
-                    q += 2
+            buf, sg, sizes, offs = self._grad_buffers(dev)
             need = L.anihip_mlp_train_workspace_bytes(C.byref(d), c1 - c0)
             if workspace is not None:
                 ws = workspace
@@ -606,26 +652,7 @@ class PackedNetworks:
                 _stream(), C.byref(d), n, c0, c1, _ptr(species), _ptr(aev), _ptr(g_at), _ptr(ws),
                 ws.numel(), sg, _ptr(atomic_e), _ptr(grad_aev), 1 if workspace is not None else 0))
             total = buf if total is None else total.add_(buf)
-        # unpack into Linear layout
-        gw = [[[None] * nl for _ in range(S)] for _ in range(M)]
-        gb = [[[None] * nl for _ in range(S)] for _ in range(M)]
-        q = 0
-        for s in range(S):
-            dims = [d.net[s].dims[l] for l in range(nl + 1)]
-            for l in range(nl):
-                out, inn = self.shapes[s][l]
-                w = total[int(offs[q]): int(offs[q]) + sizes[q]]
-                b = total[int(offs[q + 1]): int(offs[q + 1]) + sizes[q + 1]]
-                q += 2
-                if l == nl - 1:
-                    wv = w.view(M, 1, dims[l])                       # [M][Hlast_p]
-                    bv = b.view(M, 1)
-                else:
-                    wv = w.view(M, dims[l + 1], dims[l])   # [M][out_p][in_p]: Linear layout, plain views when unpadded
-                    bv = b.view(M, dims[l + 1])
-                for m in range(M):
-                    gw[m][s][l] = wv[m, :out, :inn]
-                    gb[m][s][l] = bv[m, :out]
+        gw, gb = self._unpack_grads(total, sizes, offs)
         return gw, gb, atomic_e, grad_aev
 
 
