@@ -125,12 +125,14 @@ def test_autograd_training_step(dev, oracle64):
     err = np.abs(got - ref).max()
     report(f"train autograd rand_batch_ani2x  max|grad err| = {err:.2e} (max |grad| {scale:.2e})")
     assert err < 5e-5 * scale
-    # double backward is not implemented: it must raise, not return silently wrong numbers
+    # third order is not implemented: it must raise, not return silently wrong numbers
     aev_g = aev.clone().requires_grad_(True)
     e2 = nets(sp, aev_g).sum()
     (ga,) = torch.autograd.grad(e2, aev_g, create_graph=True)
+    (gp,) = torch.autograd.grad(ga.pow(2).sum(), nets.members[0].atomics["H"].layers[0].weight, create_graph=True)
     with pytest.raises(RuntimeError):
-        ga.pow(2).sum().backward()
+        gp.sum().backward()
+    nets.zero_grad()
     # a short optimisation run
     opt = torch.optim.Adam(nets.parameters(), lr=1e-4)
     losses = []
@@ -245,3 +247,38 @@ def test_tangent_weight_grads_match_oracle(dev, oracle64, base):
     report(f"fgrad {base:22s} max|d(t.F)/dw err| = {err:.2e} (max {scale:.2e})  |t.F err| = {s_err:.2e} (t.F = {val_ref:+.5f})")
     assert err < 5e-5 * scale
     assert s_err < 1e-5 * max(1.0, abs(val_ref))
+
+
+@pytest.mark.parametrize("base", FGRAD_NAMES)
+def test_force_training_autograd_matches_reference(dev, base):
+    """The reference's force-training recipe (tools/training-aev-benchmark.py:136-150) on the HIP engine:
+    forces = -autograd.grad(E, coords, create_graph=True); loss(forces).backward() -> .grad of every parameter, against
+    the digest of the reference's own second-order autograd (tests/golden/fgrads_*.npz)."""
+    from _util import wgrad_digest
+
+    g, f = load_golden(base), load_fgrads(base)
+    model = fresh_model(g["kind"], g["seed"], dev, g["cutoff_fn"])
+    model.aev_computer.row_capacity = 256
+    nets = model.neural_networks
+    nets.requires_grad_(True)
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev).requires_grad_(True)
+    cell = None if g["cell"] is None else torch.from_numpy(g["cell"]).to(dev)
+    pbc = None if g["pbc"] is None else torch.tensor([bool(b) for b in g["pbc"]])
+    t = torch.from_numpy(fgrad_direction(g["species"]).astype(np.float32)).to(dev)
+    aev = model.aev_computer(sp, x, cell, pbc)
+    e = nets(sp, aev).sum()
+    (gx,) = torch.autograd.grad(e, x, create_graph=True)
+    loss = -(gx * t).sum()                      # = sum_k t_k . F_k
+    loss.backward()
+    torch.cuda.synchronize()
+    got = flat_from_params(nets, model.symbols)
+    sums, dots, heads = wgrad_digest(got)
+    scale = float(f["grad_abs_max"])
+    err = max(np.abs(sums - f["block_sums"]).max(), np.abs(dots - f["block_dots"]).max(),
+              np.abs(heads - f["block_heads"]).max())
+    l_err = abs(float(loss.detach()) - float(f["loss"]))
+    report(f"ftrain {base:22s} |loss err| = {l_err:.2e}  max digest err = {err:.2e} (max |grad| {scale:.2e})")
+    assert l_err < 1e-5
+    assert err < 2e-4 * scale     # block sums over 4096 fp32-accumulated entries
+    assert abs(np.abs(got).max() - scale) < 1e-4 * scale

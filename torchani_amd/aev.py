@@ -40,6 +40,27 @@ class _AngularTerms(torch.nn.Module):
         self.cutoff = float(cutoff)
 
 
+class _AEVBackwardFunction(torch.autograd.Function):
+    """grad_aev -> grad_coords = J^T grad_aev as a differentiable function of grad_aev: its own backward is the
+    forward-mode product J u (anihip_aev_jvp), the reference's cuaev double backward (CuaevDoubleAutograd,
+    csrc/cuaev.cpp:141-186, csrc/aev.cu:1986-2015) that training on forces needs.  Like the reference it returns the
+    derivative with respect to grad_aev only (no third order, no second-order term for the coordinates)."""
+
+    @staticmethod
+    def forward(ctx, grad_aev: Tensor, eng, nbrs, species32: Tensor) -> Tensor:
+        g = grad_aev.detach().to(torch.float32).contiguous()
+        ctx.eng, ctx.nbrs, ctx.species32 = eng, nbrs, species32
+        ctx.g_dtype, ctx.g_shape = grad_aev.dtype, grad_aev.shape
+        C, A = species32.shape
+        return eng.backward(species32, nbrs, g).view(C, A, 3)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_force: Tensor):
+        jt = ctx.eng.jvp(ctx.species32, ctx.nbrs, grad_force.contiguous())
+        return jt.view(ctx.g_shape).to(ctx.g_dtype), None, None, None
+
+
 class _AEVFunction(torch.autograd.Function):
     """coords -> aevs with the analytic HIP backward (the role of CuaevAutograd, csrc/cuaev.cpp:120-139)."""
 
@@ -55,12 +76,10 @@ class _AEVFunction(torch.autograd.Function):
         return aev.view(species32.shape[0], species32.shape[1], eng.L).to(coords.dtype)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable   # no AEV double backward yet: raise rather than mislead
     def backward(ctx, grad_aev: Tensor):
-        g = grad_aev.to(torch.float32).contiguous()
-        gc = ctx.eng.backward(ctx.species32, ctx.nbrs, g)
-        C, A = ctx.species32.shape
-        return gc.view(C, A, 3).to(ctx.in_dtype), None, None, None, None
+        # (through a Function of its own so that create_graph=True can differentiate the forces once more)
+        gc = _AEVBackwardFunction.apply(grad_aev, ctx.eng, ctx.nbrs, ctx.species32)
+        return gc.to(ctx.in_dtype), None, None, None, None
 
 
 class _AEVFromRowsFunction(torch.autograd.Function):
@@ -78,12 +97,9 @@ class _AEVFromRowsFunction(torch.autograd.Function):
         return aev.view(species32.shape[0], species32.shape[1], eng.L).to(coords.dtype)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable   # no AEV double backward yet: raise rather than mislead
     def backward(ctx, grad_aev: Tensor):
-        g = grad_aev.to(torch.float32).contiguous()
-        gc = ctx.eng.backward(ctx.species32, ctx.nbrs, g)
-        C, A = ctx.species32.shape
-        return gc.view(C, A, 3).to(ctx.in_dtype), None, None, None
+        gc = _AEVBackwardFunction.apply(grad_aev, ctx.eng, ctx.nbrs, ctx.species32)
+        return gc.to(ctx.in_dtype), None, None, None
 
 
 class AEVComputer(torch.nn.Module):

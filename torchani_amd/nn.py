@@ -56,6 +56,38 @@ class AtomicNetwork(torch.nn.Module):
 _TRAIN_SPLIT_MAX_ATOMS = 1 << 17
 
 
+class _MLPBackwardFunction(torch.autograd.Function):
+    """(grad_out, params) -> grad_aev = grad_out * d e / d aev as a differentiable function of the parameters (and of
+    grad_out): what torch builds under create_graph=True for the eager networks of the reference.  Its backward for
+    an incoming v [C, A, L] is the second-order pass anihip_mlp_tangent_weight_grads: d/d params of
+    sum_i grad_out_i v_i . d e_i / d aev_i.  The second-order term with respect to the AEVs is not propagated."""
+
+    @staticmethod
+    def forward(ctx, grad_out: Tensor, a32: Tensor, species32: Tensor, packed: PackedNetworks, shape,
+                *params: Tensor) -> Tensor:
+        _, g_unit, _ = packed.forward_backward(species32, a32, want_grad=True)
+        go = grad_out.detach().to(torch.float32).reshape(-1, 1)
+        ctx.saved = (a32, species32, packed, g_unit, go)
+        ctx.shape, ctx.go_shape, ctx.go_dtype = shape, grad_out.shape, grad_out.dtype
+        ctx.param_dtypes = [p.dtype for p in params]
+        return (g_unit * go).view(shape)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, v: Tensor):
+        a32, species32, packed, g_unit, go = ctx.saved
+        v32 = v.to(torch.float32).reshape(g_unit.shape)
+        d_go = (v32 * g_unit).sum(dim=-1).view(ctx.go_shape).to(ctx.go_dtype)
+        gw, gb, _ = packed.tangent_weight_grads(species32, a32, (v32 * go).contiguous())
+        flat = []
+        for m in range(packed.M):
+            for s in range(packed.S):
+                for l in range(packed.nl):
+                    flat += [gw[m][s][l], gb[m][s][l]]
+        flat = [t.to(dt) for t, dt in zip(flat, ctx.param_dtypes)]
+        return (d_go, None, None, None, None, *flat)
+
+
 class _MLPFunction(torch.autograd.Function):
     """params = the Linear parameters in the order member -> species -> layer -> (weight, bias)."""
 
@@ -77,6 +109,7 @@ class _MLPFunction(torch.autograd.Function):
         ctx.train = train
         ctx.aev_grad = aevs.requires_grad
         ctx.saved = (a32, species32, packed, ws) if train else None
+        ctx.params = params if train else ()
         ctx.param_dtypes = [p.dtype for p in params]
         ctx.in_dtype = aevs.dtype
         ctx.shape = aevs.shape
@@ -86,7 +119,6 @@ class _MLPFunction(torch.autograd.Function):
         return ae.view(C, A).to(aevs.dtype)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out: Tensor):
         if ctx.want_members:
             raise RuntimeError("ensemble_values=True is not differentiable in the HIP engine")
@@ -94,8 +126,12 @@ class _MLPFunction(torch.autograd.Function):
             # training pass: forward recomputed in exact fp32 with the activations kept, then d/d weights, d/d biases
             # (and d/d aev scaled by the upstream gradient) in one engine call
             a32, species32, packed, ws = ctx.saved
-            gw, gb, _, gaev = packed.weight_grads(species32, a32, grad_out.contiguous(), want_grad_aev=ctx.aev_grad,
-                                                  workspace=ws)
+            # create_graph=True (training on forces): d E / d aev must stay differentiable in the parameters
+            second_order = torch.is_grad_enabled() and ctx.aev_grad
+            gw, gb, _, gaev = packed.weight_grads(species32, a32, grad_out.detach().contiguous(),
+                                                  want_grad_aev=ctx.aev_grad and not second_order, workspace=ws)
+            if second_order:
+                gaev = _MLPBackwardFunction.apply(grad_out, a32, species32, packed, ctx.shape, *ctx.params)
             flat = []
             for m in range(packed.M):
                 for s in range(packed.S):
@@ -106,6 +142,8 @@ class _MLPFunction(torch.autograd.Function):
             return (ga, None, None, None, *flat)
         if ctx.g is None:
             raise RuntimeError("AEVs did not require grad in forward")
+        if torch.is_grad_enabled() and grad_out.requires_grad:
+            raise RuntimeError("second-order gradients need trainable parameters (requires_grad) in the HIP engine")
         g = ctx.g.view(ctx.shape) * grad_out.to(torch.float32).unsqueeze(-1)
         return (g.to(ctx.in_dtype), None, None, None, *([None] * len(ctx.param_dtypes)))
 
