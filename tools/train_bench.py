@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--atoms", type=int, default=24)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--forces", action="store_true", help="energy + force loss (second-order backward)")
     args = ap.parse_args()
     from torchani_amd.models import ANI1x, ANI2x
 
@@ -53,25 +54,34 @@ def main():
     spd, xd = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev)
     n_at = (spd >= 0).sum(dim=1).float()
     target = torch.from_numpy(np.random.RandomState(1).normal(0, 0.1, args.batch).astype(np.float32)).to(dev)
-    acc = dict(aev=0.0, nn=0.0, backward=0.0, optimizer=0.0)
+    true_f = torch.from_numpy(np.random.RandomState(2).normal(0, 0.05, x.shape).astype(np.float32)).to(dev)
+    true_f = true_f * (spd >= 0).unsqueeze(-1)
+    acc = dict(aev=0.0, nn=0.0, force=0.0, backward=0.0, optimizer=0.0)
 
     def step(timed):
         def mark():
             torch.cuda.synchronize()
             return time.perf_counter()
+        xin = xd.clone().requires_grad_(True) if args.forces else xd
         t0 = mark()
-        aev = model.aev_computer(spd, xd)
+        aev = model.aev_computer(spd, xin)
         t1 = mark()
         e = nets(spd, aev)
         t2 = mark()
         loss = (torch.nn.functional.mse_loss(e, target, reduction="none") / n_at.sqrt()).mean()
+        tf = t2
+        if args.forces:   # tools/training-aev-benchmark.py:136-150: forces with create_graph, force coefficient 0.1
+            forces = -torch.autograd.grad(e.sum(), xin, create_graph=True, retain_graph=True)[0]
+            floss = (torch.nn.functional.mse_loss(true_f, forces, reduction="none").sum(dim=(1, 2)) / (3.0 * n_at)).mean()
+            loss = loss + 0.1 * floss
+            tf = mark()
         opt.zero_grad()
         loss.backward()
         t3 = mark()
         opt.step()
         t4 = mark()
         if timed:
-            for k, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            for k, v in zip(acc, (t1 - t0, t2 - t1, tf - t2, t3 - tf, t4 - t3)):
                 acc[k] += v
         return float(loss.detach())
 
@@ -80,7 +90,7 @@ def main():
     losses = [step(True) for _ in range(args.steps)]
     total = sum(acc.values()) / args.steps
     n_real = int((sp >= 0).sum())
-    print(f"config 5: {args.kind} x{args.members}, batch {args.batch} conformers ({n_real} atoms): "
+    print(f"config 5{' (energy+force loss)' if args.forces else ''}: {args.kind} x{args.members}, batch {args.batch} conformers ({n_real} atoms): "
           f"{total * 1e3:.2f} ms/step = {args.batch / total:.0f} conformers/s")
     print("  " + "  ".join(f"{k} {v / args.steps * 1e3:.2f} ms" for k, v in acc.items()))
     print(f"  loss {losses[0]:.5f} -> {losses[-1]:.5f}")
