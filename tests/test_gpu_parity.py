@@ -660,3 +660,39 @@ def test_periodic_replica_and_symmetries_at_scale(dev):
     pm = model.energies_and_forces(spt[:, perm], xt[:, perm], ct, pbc)
     assert (pm.forces - f0[:, perm]).abs().max() < 2e-5
     assert (pm.atomic_energies - a0[:, perm]).abs().max() < 2e-6
+
+
+def test_degenerate_inputs(dev, oracle64):
+    """Edge cases the reference tests as well (tests/test_aev.py padding / isolated atoms): an isolated atom, atoms
+    beyond the cutoff, an all-padding molecule, species that do not occur, and the row-capacity overflow report."""
+    model = get_model("ani2x", 11, dev)
+    dims, flat, sae = oracle_networks("ani2x", 8, 11)
+    p = oracle_params("ani2x")
+    sp = np.array([[0, -1, -1, -1],      # one isolated H
+                   [3, 0, -1, -1],       # O and H 9 A apart: no neighbors at all
+                   [-1, -1, -1, -1],     # nothing
+                   [1, 0, 0, 6]], dtype=np.int64)   # a small cluster incl. Cl
+    x = np.zeros((4, 4, 3), dtype=np.float32)
+    x[1, 1] = [9.0, 0.0, 0.0]
+    x[3] = [[0, 0, 0], [1.0, 0.1, 0], [-0.4, 0.9, 0.2], [0.3, -0.5, 1.6]]
+    ref = oracle64.energy_forces(p, sp, x.astype(np.float64), dims, flat, 8, sae=sae)
+    out = model.energies_and_forces(torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev), check_overflow=True)
+    torch.cuda.synchronize()
+    assert np.abs(out.energies.cpu().numpy() - ref["energies"]).max() < 1e-6
+    assert np.abs(out.atomic_energies.cpu().numpy() - ref["atomic_energies"]).max() < E_ATOM_TOL
+    assert np.abs(out.forces.cpu().numpy() - ref["forces"]).max() < F_TOL
+    f = out.forces.cpu().numpy()
+    assert np.all(f[0] == 0) and np.all(f[1] == 0) and np.all(f[2] == 0)
+    assert out.energies[2].item() == 0.0           # padding contributes nothing, not even self energies
+    # the autograd path agrees on the same input
+    xs = torch.from_numpy(x).to(dev).requires_grad_(True)
+    e = model((torch.from_numpy(sp).to(dev), xs)).energies
+    (gx,) = torch.autograd.grad(e.sum(), xs)
+    assert np.abs(-gx.cpu().numpy() - ref["forces"]).max() < F_TOL
+    # more neighbors than the row capacity: reported, never silently truncated (csrc/aev.cu:229 asserts instead)
+    rs = np.random.RandomState(0)
+    dense = rs.uniform(0, 3.2, (1, 60, 3)).astype(np.float32)
+    spd = torch.zeros((1, 60), dtype=torch.int64, device=dev)
+    small = get_model("ani2x", 11, dev, row_capacity=16)
+    with pytest.raises(RuntimeError, match="overflow"):
+        small.energies_and_forces(spd, torch.from_numpy(dense).to(dev), check_overflow=True)
