@@ -50,7 +50,8 @@ def test_struct_layouts_match_header(lib):
     need = lib.anihip_mlp_workspace_bytes(ctypes.byref(d), n)
     acts = 4 * 8 * (256 + 192 + 160) * (n + 1)
     tiles = (n + 63) // 64 + 8   # tile table of the fused kernel: 16-B entry + 64 atom rows per tile
-    assert acts <= need <= acts + 4 * (n + 1) * (1 + 8) + (16 + 256) * tiles + 64 * 256
+    d0_pad = 4 * 8 * 256 * 64 * 8   # layer 0 doubles as the tile-major d E/d act0 buffer: + 64 rows per species slot
+    assert acts <= need <= acts + d0_pad + 4 * (n + 1) * (1 + 8) + (16 + 256) * tiles + 64 * 256
     # training pass: the activations are kept and every hidden layer gets a gradient buffer of the same size
     assert ctypes.sizeof(_lib.SpeciesGrads) == 2 * 4 * 8
     need_t = lib.anihip_mlp_train_workspace_bytes(ctypes.byref(d), n)

@@ -68,6 +68,8 @@ struct GemmArgs {
     int64_t ldc;
     const float *Y;        // EPI_DCELU of the training pass (k_gemm): activations read from here, C only written
     int64_t ldy;           //   (NULL: C holds the activations and is overwritten in place)
+    int a_tm_members;      // > 0: A is the tile-major d E / d act0 buffer (see tm_species_base), this many members
+    int a_tm_h[MAX_S];     //      and per-species row width H_s
     const float *Z;        // tangent pass: zdot (same leading dimension as Y)
     float *C2;             // tangent pass: second output (same leading dimension as C)
     const int *c_scatter;  // sorted position -> destination row (last backward GEMM) or NULL
@@ -97,6 +99,18 @@ constexpr int CTL_WORDS = 48;
 // atomics off a single address; lives right behind the control block
 constexpr int AMAX_STAGES = 8, AMAX_SLOTS = 32;
 constexpr int AMAX_WORDS = AMAX_STAGES * MAX_S * AMAX_SLOTS;
+
+// Tile-major layout of d E / d act0 between the fused network kernel and the layer-0 backward GEMM: the rows of a
+// species are cut into blocks of 64, and block b of species s stores, member after member, 64 rows x H_s columns
+// contiguously:   offset(s, rel, m, c) = base_s + (((rel >> 6) * M + m) * 64 + (rel & 63)) * H_s + c,
+// base_s = sum_{s' < s} ceil(cnt_s' / 64) * 64 * M * H_s'.  Both kernels then stream whole 16..64-KB blocks instead of
+// 128-B .. 1-KB pieces strided by the 8-KB row of the plain [n][M * H] layout.
+__device__ __forceinline__ int64_t tm_species_base(const int *ctl, const int *H, int M, int s)
+{
+    int64_t base = 0;
+    for (int t = 0; t < s; ++t) base += (int64_t)((ctl[8 * 0 + t] + 63) >> 6) * 64 * M * H[t];   // ctl[CTL_CNT + t]
+    return base;
+}
 
 // ---- species bucketing --------------------------------------------------------------------------
 
@@ -602,7 +616,7 @@ constexpr int H2_STAGE = 4 * H2_PLANE;     // A_hi, A_lo, B_hi, B_lo
 constexpr int GEMM2_THREADS = 512;
 
 template <int NB>
-__device__ __forceinline__ void gemm_h2_kloop(f32x16 (&acc)[8], const gf4 *a_src0, const gf4 *a_src1,
+__device__ __forceinline__ void gemm_h2_kloop(f32x16 (&acc)[8], const gf4 *a_src0, const gf4 *a_src1, int tm_h,
                                               int k_valid, int kp_rad, uint32_t smask, int nk, float sa,
                                               const _Float16 *b_src0, const _Float16 *b_src1, int64_t bh_plane,
                                               _Float16 *sm, int wm, int wn)
@@ -613,9 +627,14 @@ __device__ __forceinline__ void gemm_h2_kloop(f32x16 (&acc)[8], const gf4 *a_src
     const int srow = tid >> 2, piece = tid & 3;   // staging: rows srow and 128 + srow, 16-B piece
     const int fr = lane & 31, fk = lane >> 5;
     const v4f z4 = v4f{0.f, 0.f, 0.f, 0.f};
+    const float tm_inv_h = tm_h ? 1.0f / (float)tm_h : 0.f;
     HStage st;
     auto gload = [&](int kt) {
-        const int acol = kp_rad ? kp_col(kp_rad, kt) : kt * HBK;
+        int acol = kp_rad ? kp_col(kp_rad, kt) : kt * HBK;
+        if (tm_h) {   // tile-major: column kt * 32 = member mm, unit c0; members are 64 * H apart
+            const int mm = (int)(((float)(kt * HBK) + 0.5f) * tm_inv_h);
+            acol = mm * 64 * tm_h + (kt * HBK - mm * tm_h);
+        }
         const bool ok = kp_rad ? piece * 8 < kp_valid(kp_rad, kt) : kt * HBK + piece * 8 < k_valid;
         const int o = ok ? acol / 4 : 0;
         st.a[0][0] = a_src0[o]; st.a[0][1] = a_src0[o + 1];
@@ -799,6 +818,14 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
 
     const gf4 *a_src0 = (const gf4 *)(g.A + s0r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
     const gf4 *a_src1 = (const gf4 *)(g.A + s1r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
+    int tm_h = 0;   // tile-major A (d E / d act0 of the fused kernel): row width of this species
+    if (g.a_tm_members > 0) {
+        tm_h = g.a_tm_h[s];
+        const int64_t base = tm_species_base(ctl, g.a_tm_h, g.a_tm_members, s);
+        const int rel0 = m0 + r0, rel1 = m0 + r1;
+        a_src0 = (const gf4 *)(g.A + base + ((int64_t)(rel0 >> 6) * g.a_tm_members * 64 + (rel0 & 63)) * tm_h + piece * 8);
+        a_src1 = (const gf4 *)(g.A + base + ((int64_t)(rel1 >> 6) * g.a_tm_members * 64 + (rel1 & 63)) * tm_h + piece * 8);
+    }
     // B rows staged by this thread: tile columns srow and srow + 128
     int bn0, bn1;
     if (compact) {
@@ -824,11 +851,11 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
     const uint32_t smask = (EPI == EPI_BIAS_CELU && g.stage_mask) ? tmask : 0u;
     if (!(EPI == EPI_BIAS_CELU && g.stage_mask && tmask == 0u)) {
         switch (nb_act) {
-            case 4: gemm_h2_kloop<4>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
-            case 3: gemm_h2_kloop<3>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
-            case 2: gemm_h2_kloop<2>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
-            case 1: gemm_h2_kloop<1>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
-            default: gemm_h2_kloop<0>(acc, a_src0, a_src1, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+            case 4: gemm_h2_kloop<4>(acc, a_src0, a_src1, tm_h, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+            case 3: gemm_h2_kloop<3>(acc, a_src0, a_src1, tm_h, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+            case 2: gemm_h2_kloop<2>(acc, a_src0, a_src1, tm_h, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+            case 1: gemm_h2_kloop<1>(acc, a_src0, a_src1, tm_h, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
+            default: gemm_h2_kloop<0>(acc, a_src0, a_src1, tm_h, pr.k_valid, kp_a, smask, nk, sa, b_src0, b_src1, pr.bh_plane, sm2, wm, wn); break;
         }
     }
 
@@ -925,6 +952,7 @@ struct FusedArgs {
     const uint32_t *slab_mask; // per atom, or NULL (all slabs)
     float *d0;                 // [n][ld0]: out: d E / d act0 (member m at columns m*H1..)
     int64_t ld0;
+    int d0_tm;                 // d0 in the tile-major layout (tm_species_base) instead of [n][ld0]
     const int *perm;           // sorted position -> atom
     const int4 *tile_tab;      // [tiles_total] {species (-1: empty), first sorted position, rows, slab mask}
     const int *tile_rows;      // [tiles_total][rows per tile] atom of each row (short tiles: last atom repeated)
@@ -1183,6 +1211,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const int m = item / g.tiles_total, s = te.x, n_rows = te.z, p0 = te.y;
         // (slabs 0..5 of this item are on their way to the registers; rem_a = the rest)
         const FusedSpecies &fs = g.sp[s];
+        int64_t tm_base = 0;
+        if (g.d0_tm)
+            for (int t = 0; t < s; ++t) tm_base += (int64_t)((g.ctl[CTL_CNT + t] + 63) >> 6) * 64 * g.M * g.sp[t].H1;
         const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
         // LDS carve (halves): X1 planes [2][ROWS][H2+8] | XU = max(X0 planes [2][ROWS][H1+8], X2 planes)
         const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
@@ -1469,6 +1500,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 for (int nb = 0; nb < NB; ++nb) {
                     if (nb >= n1) continue;
                     float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0(nb);
+                    if (g.d0_tm) {
+                        const int rel = p0 - g.ctl[CTL_OFF + s] + min(row, n_rows - 1);
+                        dst = g.d0 + tm_base + ((int64_t)((rel >> 6) * g.M + m) * 64 + (rel & 63)) * H1 + col0(nb);
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         v4f v;
@@ -1881,7 +1916,8 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
         int mx = 0;
         for (int s = 0; s < d->num_species; ++s) mx = mx > d->net[s].dims[l + 1] ? mx : d->net[s].dims[l + 1];
         int64_t ld = (int64_t)mx * d->n_members;
-        float *a = (float *)take(sizeof(float) * (size_t)ld * (size_t)(n + 1));
+        // (layer 0 doubles as the tile-major d E / d act0 buffer: one partly filled 64-row block per species)
+        float *a = (float *)take(sizeof(float) * (size_t)ld * (size_t)(n + 1 + (l == 0 ? 64 * ANIHIP_MAX_SPECIES : 0)));
         if (w) { w->act[l] = a; w->ld[l] = ld; }
     }
     return off;
@@ -2056,6 +2092,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     }
     if (const char *e = getenv("ANIHIP_NO_FUSED_HIDDEN")) fused = fused && e[0] == '0';
     // 256 x 256 tiles for the layer-0 GEMMs once there are enough rows to fill the chip with them
+    int d0_tm = 0;
     bool big_tiles = h3 && n >= 16384;
     if (const char *e = getenv("ANIHIP_GEMM_TILE")) big_tiles = h3 && e[0] == '2';
     // per-atom slab flags: honoured by the 256 x 256 kernels on slab-ordered planes
@@ -2136,6 +2173,10 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         f.slab_mask = kp_rad > 0 ? slab_mask : nullptr;
         if (const char *e = getenv("ANIHIP_NO_SLAB_MASK")) f.slab_mask = e[0] == '0' ? f.slab_mask : nullptr;
         f.d0 = w.act[0]; f.ld0 = w.ld[0]; f.perm = w.perm;
+        // tile-major hand-over to the 256 x 256 layer-0 backward GEMM (the 128 x 128 kernel of small inputs reads rows)
+        f.d0_tm = (big_tiles && grad_aev) ? 1 : 0;
+        if (const char *e = getenv("ANIHIP_D0_ROWS")) f.d0_tm = e[0] == '0' ? f.d0_tm : 0;
+        d0_tm = f.d0_tm;
         f.tile_tab = w.tile_tab; f.tile_rows = w.tile_rows;
         f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
         f.want_grad = grad_aev ? 1 : 0;
@@ -2230,6 +2271,10 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             g.amax_out = (h3 && l > 0) ? 3 + (nh - l) : -1;
             g.a_static_scale = 1.0f;
             if (l == 0) { g.kp_rad = kp_rad; g.stage_mask = smask; }
+            if (l == 0 && d0_tm) {
+                g.a_tm_members = M;
+                for (int s = 0; s < S; ++s) g.a_tm_h[s] = d->net[s].dims[1];
+            }
             if (l == 0 && h3 && big_tiles) {
                 if (int rc = launch_gemm_big<EPI_SCATTER>(stream, g, n)) return rc;
             } else if (l == 0) {
