@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--forces", action="store_true", help="energy + force loss (second-order backward)")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, backward, Adam) in a HIP graph")
     args = ap.parse_args()
     from torchani_amd.models import ANI1x, ANI2x
 
@@ -49,7 +50,7 @@ def main():
     model = ctor(seed=0, n_members=args.members, device=dev, periodic_table_index=False, neighborlist="batch")
     nets = model.neural_networks
     nets.requires_grad_(True)
-    opt = torch.optim.Adam(nets.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(nets.parameters(), lr=1e-4, capturable=args.graph)
     sp, x = conformers(args.batch, args.atoms)
     spd, xd = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev)
     n_at = (spd >= 0).sum(dim=1).float()
@@ -85,6 +86,44 @@ def main():
                 acc[k] += v
         return float(loss.detach())
 
+    if args.graph:
+        # whole-step capture (PyTorch's "whole network" recipe): every launch of the C ABI goes to torch's current
+        # stream and nothing in the step synchronises with the host, so forward, backward, the parameter refresh and
+        # Adam replay as ONE graph launch
+        def whole():
+            aev = model.aev_computer(spd, xd)
+            e = nets(spd, aev)
+            loss = (torch.nn.functional.mse_loss(e, target, reduction="none") / n_at.sqrt()).mean()
+            loss.backward()
+            opt.step()
+            return loss
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                whole()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = whole()
+        for _ in range(args.warmup):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        first = None
+        for i in range(args.steps):
+            graph.replay()
+            if i == 0:
+                first = float(static_loss.detach())
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        n_real = int((sp >= 0).sum())
+        print(f"config 5, whole step replayed as a HIP graph: {args.kind} x{args.members}, batch {args.batch} conformers "
+              f"({n_real} atoms): {dt * 1e3:.2f} ms/step = {args.batch / dt:.0f} conformers/s; "
+              f"loss {first:.5f} -> {float(static_loss.detach()):.5f}")
+        return
     for _ in range(args.warmup):
         step(False)
     losses = [step(True) for _ in range(args.steps)]
