@@ -179,11 +179,23 @@ class ANI(torch.nn.Module):
 
     def compute_from_external_neighbors(self, species: Tensor, coords: Tensor, neighbor_idxs: Tensor,
                                         shifts: tp.Optional[Tensor], charge: int = 0, atomic: bool = False,
-                                        ensemble_values: bool = False) -> Tensor:
+                                        ensemble_values: bool = False,
+                                        _molecule_idxs: tp.Optional[Tensor] = None) -> Tensor:
         """Entry point for a neighbor list owned by an MD engine: ``neighbor_idxs`` [2, P] and cartesian image
         ``shifts`` [P, 3] (or None); coords must be mapped to the central cell.  Pairs beyond the cutoff (Verlet
         skin) and pairs with padding atoms are dropped by the ingestion kernel (arch.py:171-206)."""
         elem_idxs = self._elem_idxs(species)
+        if _molecule_idxs is not None:
+            # experimental in the reference too (arch.py:194-203): pairs between different molecules of the one
+            # conformation are dropped (discard_inter_molecule_pairs, neighbors.py:31-43)
+            if coords.shape[0] != 1:
+                raise ValueError("molecule_idxs expects only one conformation")
+            if len(_molecule_idxs) != coords.shape[1]:
+                raise ValueError("molecule_idxs must be the same length as num atoms, if passed")
+            mol = _molecule_idxs.to(neighbor_idxs.device)
+            keep = (mol[neighbor_idxs[0]] == mol[neighbor_idxs[1]]).nonzero().view(-1)
+            neighbor_idxs = neighbor_idxs.index_select(1, keep)
+            shifts = None if shifts is None else shifts.index_select(0, keep)
         flat = coords.detach().reshape(-1, 3)
         diff = flat.index_select(0, neighbor_idxs[0]) - flat.index_select(0, neighbor_idxs[1])
         if shifts is not None:
