@@ -720,3 +720,38 @@ def test_external_neighbors_molecule_idxs(dev):
     assert abs(e_all.item() - e_joint.item()) > 1e-2      # the molecules do overlap: the filter matters
     with pytest.raises(ValueError, match="same length"):
         model.compute_from_external_neighbors(sp_cat, x_cat, pairs, None, _molecule_idxs=mol[:-1])
+
+
+def test_grad_helpers(dev):
+    """torchani_amd.grad mirrors torchani/grad.py: single_point dictionary (incl. ensemble statistics), leaf checks of
+    forces(), forces_for_training (differentiable once more), hessians unsupported."""
+    from torchani_amd import grad
+
+    g = load_golden("simple2_ani2x")
+    sp, x, _, _ = to_dev(g, dev)
+    model = get_model("ani2x", g["seed"], dev)
+    out = grad.single_point(model, sp, x, forces=True, atomic_energies=True)
+    assert set(out) == {"energies", "atomic_energies", "forces"} and not x.requires_grad
+    assert np.abs(out["forces"].cpu().numpy() - g["forces"]).max() < F_TOL
+    assert np.abs(out["energies"].double().cpu().numpy() - g["energies"]).max() < 2e-6 * np.abs(g["energies"]).max()
+    ens = grad.single_point(model, sp, x, ensemble_values=True)
+    assert ens["ensemble_values"].shape == (8, sp.shape[0]) and ens["qbcs"].shape == (sp.shape[0],)
+    assert torch.allclose(ens["energies"], out["energies"], atol=1e-3)
+    n_at = (sp >= 0).sum(dim=1).float()
+    assert torch.allclose(ens["qbcs"], ens["ensemble_values"].std(0, unbiased=True) / n_at.sqrt())
+    with pytest.raises(ValueError, match="require grad"):
+        grad.forces(out["energies"], x)
+    with pytest.raises(NotImplementedError):
+        grad.single_point(model, sp, x, hessians=True)
+    # forces_for_training: a graph that reaches the parameters
+    from torchani_amd.models import ANI2x
+
+    m2 = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False)
+    m2.neural_networks.requires_grad_(True)
+    xs = x.clone().requires_grad_(True)
+    e = m2((sp, xs)).energies
+    f = grad.forces_for_training(e, xs)
+    assert f.requires_grad
+    f.pow(2).sum().backward()
+    w = m2.neural_networks.members[0].atomics["H"].layers[0].weight
+    assert w.grad is not None and torch.isfinite(w.grad).all() and w.grad.abs().max() > 0

@@ -1,4 +1,8 @@
-"""Autograd helpers with the reference's names (torchani/grad.py:42-64,263-290)."""
+"""Autograd helpers with the reference's names and behaviour (torchani/grad.py:42-86,263-399).
+
+Hessians (grad.py:86-150,239-260) need second derivatives with respect to the coordinates, which the HIP engine does
+not provide (its second-order pass serves training on forces: parameters only): those entry points raise.
+"""
 from __future__ import annotations
 
 import typing as tp
@@ -7,18 +11,94 @@ import torch
 from torch import Tensor
 
 
-def forces(energies: Tensor, coords: Tensor, retain_graph: tp.Optional[bool] = None) -> Tensor:
-    """forces = -d(sum energies)/d coords (grad.py:57-64)."""
-    (g,) = torch.autograd.grad(energies.sum(), coords, retain_graph=retain_graph)
+def forces(energies: Tensor, coordinates: Tensor, retain_graph: tp.Optional[bool] = None,
+           create_graph: bool = False) -> Tensor:
+    """forces = -d(sum energies)/d coordinates (grad.py:42-64)."""
+    if not coordinates.requires_grad:
+        raise ValueError("'coordinates' passed to `torchani.grad.forces` must require grad")
+    if not coordinates.is_leaf:
+        raise ValueError("'coordinates' passed to `torchani.grad` functions must be a 'leaf' Tensor"
+                         "(i.e. must not have been modified prior to being used as an input).")
+    (g,) = torch.autograd.grad([energies.sum()], [coordinates], retain_graph=retain_graph, create_graph=create_graph)
     return -g
 
 
-def energies_and_forces(model, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
-                        pbc: tp.Optional[Tensor] = None) -> tp.Tuple[Tensor, Tensor]:
-    """(energies, forces) through torch.autograd, restoring coords.requires_grad (grad.py:263-290)."""
-    saved = coords.requires_grad
-    coords.requires_grad_(True)
-    energies = model((species, coords), cell, pbc).energies
-    f = forces(energies, coords)
-    coords.requires_grad_(saved)
-    return energies.detach(), f
+def grads(scalars: Tensor, coords: Tensor, retain_graph: tp.Optional[bool] = None,
+          create_graph: bool = False) -> Tensor:
+    """Alias of forces with the sign flipped (grad.py:68-74)."""
+    return -forces(scalars, coords, retain_graph, create_graph)
+
+
+calc_forces = forces
+calc_grads = grads
+
+
+def forces_for_training(energies: Tensor, coordinates: Tensor) -> Tensor:
+    """Forces that can be differentiated again with respect to the parameters (grad.py:82-83): the engine's
+    double-backward Functions answer with anihip_aev_jvp / anihip_mlp_tangent_weight_grads."""
+    return forces(energies, coordinates, retain_graph=True, create_graph=True)
+
+
+def _no_hessians(*args, **kwargs):
+    raise NotImplementedError("hessians need second derivatives with respect to the coordinates, which the HIP engine "
+                              "does not provide")
+
+
+forces_and_hessians = hessians = energies_forces_and_hessians = vibrational_analysis = _no_hessians
+
+
+def energies_and_forces(model, species: Tensor, coordinates: Tensor, cell: tp.Optional[Tensor] = None,
+                        pbc: tp.Optional[Tensor] = None, charge: int = 0, atomic: bool = False,
+                        ensemble_values: bool = False, keep_vars: bool = False) -> tp.Tuple[Tensor, Tensor]:
+    """(energies, forces) through torch.autograd, restoring coordinates.requires_grad (grad.py:263-290)."""
+    saved = coordinates.requires_grad
+    coordinates.requires_grad_(True)
+    energies = model((species, coordinates), cell, pbc, atomic=atomic, ensemble_values=ensemble_values).energies
+    f = forces(energies, coordinates)
+    coordinates.requires_grad_(saved)
+    if not keep_vars:
+        energies = energies.detach()
+    return energies, f
+
+
+def single_point(model, species: Tensor, coordinates: Tensor, cell: tp.Optional[Tensor] = None,
+                 pbc: tp.Optional[Tensor] = None, charge: int = 0, forces: bool = False, hessians: bool = False,
+                 atomic_energies: bool = False, atomic_charges: bool = False, atomic_charges_grad: bool = False,
+                 ensemble_values: bool = False, keep_vars: bool = False) -> tp.Dict[str, Tensor]:
+    """Properties of a batch of molecules as a dictionary (grad.py:293-399): energies, optional forces, atomic
+    energies, and -- with ensemble_values -- the member values, their standard deviation and the QBC factors."""
+    if hessians:
+        _no_hessians()
+    if atomic_charges or atomic_charges_grad:
+        raise ValueError("Model doesn't support atomic charges")
+    if forces and ensemble_values:
+        raise NotImplementedError("forces of ensemble_values=True are not differentiable in the HIP engine")
+    saved = coordinates.requires_grad
+    if forces:
+        coordinates.requires_grad_(True)
+    energies = model((species, coordinates), cell, pbc, atomic=atomic_energies,
+                     ensemble_values=ensemble_values).energies
+    out: tp.Dict[str, Tensor] = {}
+    if ensemble_values:
+        if atomic_energies:
+            out["atomic_energies"] = energies.mean(dim=0)
+            values = energies.sum(dim=-1)
+        else:
+            values = energies
+        out["energies"] = values.mean(dim=0)
+        single = values.shape[0] == 1
+        out["ensemble_std"] = values.new_zeros(energies.shape) if single else values.std(dim=0, unbiased=True)
+        out["ensemble_values"] = values
+        qbc = values.new_zeros(values.shape).squeeze(0) if single else values.std(0, unbiased=True)
+        out["qbcs"] = qbc / (species >= 0).sum(dim=1, dtype=energies.dtype).sqrt()
+    elif atomic_energies:
+        out["energies"] = energies.sum(dim=-1)
+        out["atomic_energies"] = energies
+    else:
+        out["energies"] = energies
+    if forces:
+        out["forces"] = calc_forces(out["energies"], coordinates)
+    coordinates.requires_grad_(saved)
+    if not keep_vars:
+        out = {k: v.detach() for k, v in out.items()}
+    return out
