@@ -285,3 +285,29 @@ def test_verlet_neighborlist_selection():
         VerletRows(0.0)
     with pytest.raises(ValueError, match="neighborlist"):
         AEVComputer.like_2x(neighborlist="octree")
+
+
+def test_utils_helpers():
+    """torchani_amd.utils mirrors the helpers of torchani/utils.py that callers of the hot path use."""
+    from torchani_amd import utils as u
+
+    assert u.cumsum_from_zero(torch.tensor([3, 1, 4, 1])).tolist() == [0, 3, 4, 8]
+    x = torch.arange(12).view(3, 4)
+    mask = torch.tensor([True, False, True, True])
+    assert torch.equal(u.fast_masked_select(x, mask, 1), x[:, mask])
+    batches = [{"species": torch.tensor([[1, 6]]), "coordinates": torch.zeros(1, 2, 3), "energies": torch.tensor([1.0])},
+               {"species": torch.tensor([[8, 1, 1]], dtype=torch.int32), "coordinates": torch.ones(1, 3, 3),
+                "energies": torch.tensor([2.0])}]
+    p = u.pad_atomic_properties(batches)
+    assert p["species"].tolist() == [[1, 6, -1], [8, 1, 1]] and p["species"].dtype == torch.long
+    assert p["coordinates"].shape == (2, 3, 3) and p["energies"].tolist() == [1.0, 2.0]
+    p["species"][:, 2] = -1
+    assert u.strip_redundant_padding(p)["coordinates"].shape == (2, 2, 3)
+    cell = torch.tensor([[10.0, 0, 0], [2, 9, 0], [0, 0, 8]])
+    xyz = torch.tensor([[-1.0, 20.0, 3.0], [3.0, 4.0, -30.0]])
+    w = u.map_to_central(xyz, cell, torch.tensor([True, True, False]))
+    shift = (w - xyz) @ torch.inverse(cell)
+    assert torch.allclose(shift, shift.round(), atol=1e-5) and torch.all(shift[:, 2] == 0)   # whole lattice vectors
+    frac = w @ torch.inverse(cell)
+    assert torch.all(frac[:, :2] >= -1e-6) and torch.all(frac[:, :2] < 1 + 1e-6)
+    assert u.linspace(0.8, 5.1, 16)[1] == 0.8 + (5.1 - 0.8) / 16
