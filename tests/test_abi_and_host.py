@@ -311,3 +311,21 @@ def test_utils_helpers():
     frac = w @ torch.inverse(cell)
     assert torch.all(frac[:, :2] >= -1e-6) and torch.all(frac[:, :2] < 1 + 1e-6)
     assert u.linspace(0.8, 5.1, 16)[1] == 0.8 + (5.1 - 0.8) / 16
+
+
+def test_builtin_factory_signature():
+    """ANI2x(model_index, neighborlist, strategy, periodic_table_index, device, dtype): the reference's positional
+    order (models.py:165-196); model_index picks one member (models.py:195)."""
+    from torchani_amd.models import ANI1x, ANI2x
+    from torchani_amd.nn import ANINetworks, Ensemble
+
+    full = ANI2x(seed=3)
+    one = ANI2x(2, "cell_list", "cuaev", True, None, None, seed=3)
+    assert isinstance(full.neural_networks, Ensemble) and isinstance(one.neural_networks, ANINetworks)
+    w_full = full.neural_networks.members[2].atomics["O"].layers[1].weight
+    assert torch.equal(one.neural_networks.atomics["O"].layers[1].weight, w_full)
+    assert one.aev_computer.neighbor_mode == "cell" and len(ANI1x(seed=1)) == 8
+    with pytest.raises(ValueError, match="strategy"):
+        ANI2x(strategy="numpy")
+    with pytest.raises(ValueError, match="float32"):
+        ANI2x(dtype=torch.float64)

@@ -359,7 +359,12 @@ def _assemble(kind: str, n_members: int, neighborlist: str, row_capacity: int,
 
 
 def _builtin(kind: str, state_dict, seed, n_members, device, neighborlist, row_capacity,
-             periodic_table_index, cutoff_fn: str = "cosine") -> ANI:
+             periodic_table_index, cutoff_fn: str = "cosine", model_index: tp.Optional[int] = None,
+             strategy: str = "hip", dtype=None) -> ANI:
+    if strategy not in ("hip", "auto", "pyaev", "cuaev", "cuaev-fused", "cuaev-interface"):
+        raise ValueError(f"Unsupported strategy {strategy!r}")   # (every reference strategy maps to the HIP engine)
+    if dtype not in (None, torch.float32):
+        raise ValueError("the HIP engine computes in float32 (energies are reduced in float64)")
     model = _assemble(kind, n_members, neighborlist, row_capacity, periodic_table_index, cutoff_fn)
     if state_dict is None:
         # the published parameters are a download in the reference (arch.py:1185-1220); offline we use
@@ -369,21 +374,24 @@ def _builtin(kind: str, state_dict, seed, n_members, device, neighborlist, row_c
     model.requires_grad_(False)
     if device is not None:
         model = model.to(device)
-    return model
+    # models.py:195: a single member of the ensemble on request
+    return model if model_index is None else model[model_index]
 
 
-def ANI2x(state_dict=None, seed: tp.Optional[int] = None, n_members: int = 8, device=None,
-          neighborlist: str = "auto", row_capacity: int = 128, periodic_table_index: bool = True,
+def ANI2x(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",
+          periodic_table_index: bool = True, device=None, dtype=None, state_dict=None,
+          seed: tp.Optional[int] = None, n_members: int = 8, row_capacity: int = 128,
           cutoff_fn: str = "cosine") -> ANI:
     """ANI-2x architecture: H C N O S F Cl, 1008-dim AEV, 8-member ensemble (models.py:185-196).
     cutoff_fn="smooth" gives the envelope of the reference's newer models (arch.py:1006, CutoffSmooth)."""
     return _builtin("ani2x", state_dict, seed, n_members, device, neighborlist, row_capacity,
-                    periodic_table_index, cutoff_fn)
+                    periodic_table_index, cutoff_fn, model_index, strategy, dtype)
 
 
-def ANI1x(state_dict=None, seed: tp.Optional[int] = None, n_members: int = 8, device=None,
-          neighborlist: str = "auto", row_capacity: int = 128, periodic_table_index: bool = True,
+def ANI1x(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",
+          periodic_table_index: bool = True, device=None, dtype=None, state_dict=None,
+          seed: tp.Optional[int] = None, n_members: int = 8, row_capacity: int = 128,
           cutoff_fn: str = "cosine") -> ANI:
     """ANI-1x architecture: H C N O, 384-dim AEV, 8-member ensemble (models.py:112-119)."""
     return _builtin("ani1x", state_dict, seed, n_members, device, neighborlist, row_capacity,
-                    periodic_table_index, cutoff_fn)
+                    periodic_table_index, cutoff_fn, model_index, strategy, dtype)
