@@ -108,8 +108,9 @@ class AEVComputer(torch.nn.Module):
     def __init__(self, consts: AEVConstants, neighborlist: str = "auto", row_capacity: int = 128,
                  strategy: str = "hip", cutoff_fn: tp.Optional[str] = None, skin: float = 1.0) -> None:
         super().__init__()
-        if strategy not in ("hip", "auto"):
-            # the reference raises ValueError for unknown strategies (aev/_computer.py:127-128)
+        if strategy not in ("hip", "auto", "pyaev", "cuaev", "cuaev-fused", "cuaev-interface"):
+            # the reference raises ValueError for unknown strategies (aev/_computer.py:127-128); its own strategy
+            # names are accepted and all mean the native HIP path here
             raise ValueError(f"Unsupported strategy {strategy!r}: torchani_amd only has the native 'hip' path")
         # one cutoff function for both terms like the native strategies of the reference (aev/_computer.py:91-98);
         # an explicit argument overrides the one carried by the constants
