@@ -119,7 +119,8 @@ class AEVComputer(torch.nn.Module):
             raise ValueError(f"Unsupported cutoff function {self.cutoff_fn!r}: the HIP kernels implement 'cosine' "
                              "(CutoffCosine) and 'smooth' (CutoffSmooth, order 2)")
         modes = {"auto": "auto", "all_pairs": "batch", "cell_list": "cell", "batch": "batch", "cell": "cell",
-                 "adaptive": "auto", "fast_cell_list": "cell", "verlet_cell_list": "cell", "verlet": "auto"}
+                 "adaptive": "auto", "base": "auto", "fast_cell_list": "cell", "verlet_cell_list": "cell",
+                 "verlet": "auto"}
         if neighborlist not in modes:
             raise ValueError(f"Unsupported neighborlist {neighborlist!r}")   # neighbors.py:899-914
         self.neighbor_mode = modes[neighborlist]
