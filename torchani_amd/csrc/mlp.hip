@@ -17,6 +17,12 @@
 //   C. exact fp32 (precision = ANIHIP_MLP_FP32): the same grouped GEMMs on v_mfma_f32_32x32x2_f32 (k_gemm,
 //      128 x 128 x 16 tiles, A transposed on the way into LDS so both fragment reads are conflict-free
 //      ds_read_b32, register-prefetched double buffering).
+//   D. training pass (anihip_mlp_train_forward / anihip_mlp_weight_grads): path C's GEMMs with every activation kept,
+//      the backward into separate gradient buffers, k_wgrad (dW^T = D^T X straight from row-major operands on
+//      v_mfma_f32_32x32x2_f32) and k_col_reduce for the weight / bias gradients, k_repack to refresh the packed
+//      parameters after an optimizer step.
+//   E. second-order pass of force training (anihip_mlp_tangent_weight_grads): tangent forward (EPI_TANGENT),
+//      k_head_tangent, two adjoint GEMMs per layer (EPI_ADJ_P / EPI_ADJ_Q), two k_wgrad launches per layer.
 // All GEMM kernels use an XCD-aware bijective tile order (tiles sharing an A stripe land on one XCD's L2).
 #include <stdlib.h>
 
