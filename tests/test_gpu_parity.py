@@ -755,3 +755,23 @@ def test_grad_helpers(dev):
     f.pow(2).sum().backward()
     w = m2.neural_networks.members[0].atomics["H"].layers[0].weight
     assert w.grad is not None and torch.isfinite(w.grad).all() and w.grad.abs().max() > 0
+
+
+def test_energies_are_run_to_run_deterministic(dev):
+    """neighbor rows, AEVs and per-atom energies are bit-reproducible from run to run (no atomics on
+    that path); forces accumulate with float atomics and may differ in the last bits."""
+    from bench import water_box
+
+    sp, x, cell = water_box(12)
+    model = get_model("ani2x", 13, dev, neighborlist="cell")
+    spt = torch.from_numpy(sp.astype(np.int64)).to(dev)
+    xt, ct = torch.from_numpy(x).to(dev), torch.from_numpy(cell).to(dev)
+    runs = [model.energies_and_forces(spt, xt, ct, (True, True, True)) for _ in range(3)]
+    torch.cuda.synchronize()
+    for r in runs[1:]:
+        assert torch.equal(r.atomic_energies, runs[0].atomic_energies)
+        assert torch.equal(r.energies, runs[0].energies)
+        assert (r.forces - runs[0].forces).abs().max().item() < 1e-6
+    aevc = model.aev_computer
+    a = [aevc(spt, xt, ct, torch.tensor([True, True, True])) for _ in range(2)]
+    assert torch.equal(a[0], a[1])
