@@ -1345,7 +1345,22 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             const float e = __builtin_amdgcn_exp2f(x * ia_log2e);
             d = fminf(e, 1.0f);   // (e > 1 exactly when x > 0; as a select the compare masks of all 32 elements stay
                                   //  live until the backward phases and spill from SGPRs into VGPR lanes)
-            return x > 0.f ? x : __builtin_fmaf(g.alpha, e, -g.alpha);
+            // celu(x) = median(x, alpha (e - 1), 0): for x > 0 the exponential branch lies above x (convexity), for
+            // x < 0 between x and 0 -- one v_med3_f32 instead of a compare and a select
+            return __builtin_amdgcn_fmed3f(x, __builtin_fmaf(g.alpha, e, -g.alpha), 0.f);
+        };
+        // two elements at a time: bias + scale, the exponent argument and alpha (e - 1) as packed fp32 operations
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        auto celu_d2 = [&](float a0, float a1, float osc, float b0, float b1, float &y0, float &y1, float &dd0,
+                           float &dd1) {
+            const v2f x = v2f{a0, a1} * osc + v2f{b0, b1};
+            const v2f t = x * ia_log2e;
+            const v2f e = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            const v2f y = e * g.alpha - g.alpha;
+            dd0 = fminf(e.x, 1.0f);
+            dd1 = fminf(e.y, 1.0f);
+            y0 = __builtin_amdgcn_fmed3f(x.x, y.x, 0.f);
+            y1 = __builtin_amdgcn_fmed3f(x.y, y.y, 0.f);
         };
         float d0f[NE][16];   // celu'(act0) of this lane's elements
         float a0max;         // tile max of |act0|
@@ -1358,11 +1373,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16; r += 2) {
                         const int i = rb * NB + nb;
-                        const float v = celu_d(__builtin_fmaf(acc[i][r], oscale, bias0[nb][r]), d0f[i][r]);
-                        acc[i][r] = v;
-                        vmax = fmaxf(vmax, nb < n1 ? fabsf(v) : 0.f);
+                        float v0, v1;
+                        celu_d2(acc[i][r], acc[i][r + 1], oscale, bias0[nb][r], bias0[nb][r + 1], v0, v1, d0f[i][r],
+                                d0f[i][r + 1]);
+                        acc[i][r] = v0;
+                        acc[i][r + 1] = v1;
+                        vmax = fmaxf(vmax, nb < n1 ? fmaxf(fabsf(v0), fabsf(v1)) : 0.f);
                     }
             a0max = tile_max(vmax);   // (barriers: every wave is past the staging slots)
         }
@@ -1392,10 +1410,13 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16; r += 2) {
                         const int i = rb * NB + nb;
-                        float dloc;
-                        acc[i][r] = celu_d(__builtin_fmaf(acc[i][r], oscale, bias1[nb][r]), C::LAZY ? dloc : d1f[i][r]);
+                        float dl0, dl1, y0, y1;
+                        celu_d2(acc[i][r], acc[i][r + 1], oscale, bias1[nb][r], bias1[nb][r + 1], y0, y1,
+                                C::LAZY ? dl0 : d1f[i][r], C::LAZY ? dl1 : d1f[i][r + 1]);
+                        acc[i][r] = y0;
+                        acc[i][r + 1] = y1;
                     }
             put_acc(X1, x1_plane, ld1, s1, n2);
         }
@@ -1431,12 +1452,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16; r += 2) {
                         const int i = rb * NB + nb;
-                        float dy;
-                        const float y = celu_d(__builtin_fmaf(acc[i][r], osc2, bias2[nb][r]), dy);
-                        e = __builtin_fmaf(nb < n3 ? y : 0.f, w3[nb][r], e);
-                        acc[i][r] = invM * w3[nb][r] * dy;
+                        float y0, y1, dy0, dy1;
+                        celu_d2(acc[i][r], acc[i][r + 1], osc2, bias2[nb][r], bias2[nb][r + 1], y0, y1, dy0, dy1);
+                        e = __builtin_fmaf(nb < n3 ? y0 : 0.f, w3[nb][r], e);
+                        e = __builtin_fmaf(nb < n3 ? y1 : 0.f, w3[nb][r + 1], e);
+                        acc[i][r] = invM * w3[nb][r] * dy0;
+                        acc[i][r + 1] = invM * w3[nb][r + 1] * dy1;
                     }
                 e += __shfl_xor(e, 32);
                 if (fk == 0) s_e[wave * ROWS + rb * 32 + fr] = e;
