@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 4
+#define ANIHIP_ABI_VERSION 5
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -151,20 +151,25 @@ int anihip_nbr_refresh(void *stream, const anihip_aev_params *p, int64_t n_atoms
  * backward kernels (csrc/aev.cu:837-967,474-766).  aev / grad_aev are [n_atoms, L] row-major with
  * L = S*16 + S(S+1)/2*32, layout [radial | angular] (aev/_computer.py:298).  Rows of atoms outside
  * [lo,hi) are not touched; padding atoms inside the range get zero rows.
- * grad_coords [n_atoms,3] is ACCUMULATED into with float atomics (caller zeroes it), i.e.
- * grad_coords += d(sum grad_aev * aev)/d coords  (csrc/aev.cu:1958-1984).
+ * grad_coords [n_atoms,3] is ACCUMULATED into (caller zeroes it), i.e.
+ * grad_coords += d(sum grad_aev * aev)/d coords  (csrc/aev.cu:1958-1984).  The radial part of a pair is finished by
+ * each of its two atoms for itself -- atom i gathers the 16-float block grad_aev[j][species(i)*16 ..] of every
+ * neighbor row j that this call may read, i.e. lo <= j < hi (and, with slab_mask, flagged there) -- so only the
+ * angular part and pairs whose partner row belongs to another shard travel through float atomics.
  *
  * slab_mask (optional, may be NULL; needs ceil(S/2) + S(S+1)/2 <= 32): slab_mask[i] flags the 32-wide
  * "slabs" of row i that can be non-zero -- bit j < ceil(S/2): radial blocks of species 2j, 2j+1; bit
  * ceil(S/2) + P: angular block of species pair P.  An AEV block is identically zero when atom i has no
  * neighbor (pair) of that species inside the cutoff; anihip_mlp_forward_backward skips those slabs.
- * anihip_aev_backward reads grad_aev only inside the flagged slabs. */
+ * anihip_aev_backward(slab_mask != NULL) reads grad_aev only inside flagged slabs (of the rows lo..hi); with
+ * slab_mask == NULL every entry of the rows lo..hi must be valid. */
 int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                        int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
                        const float *ent, float *aev, uint32_t *slab_mask, uint32_t *status);
 int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                         int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
-                        const float *ent, const float *grad_aev, float *grad_coords, uint32_t *status);
+                        const float *ent, const float *grad_aev, const uint32_t *slab_mask, float *grad_coords,
+                        uint32_t *status);
 
 /* Forward-mode derivative of the AEV rows along a coordinate-space direction: daev[i] = sum_k (d aev[i] / d r_k) .
  * tangent[k]  (tangent: [n_atoms][3]).  This is the reference's cuaev double backward (csrc/aev.cu:1986-2015,
@@ -183,8 +188,8 @@ int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const float *table,
  * volume.  It needs neither the cell nor whole molecules, so shards / domains simply add their partial virials. */
 int anihip_aev_backward_virial(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                                int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
-                               const float *ent, const float *grad_aev, float *grad_coords, double *virial,
-                               uint32_t *status);
+                               const float *ent, const float *grad_aev, const uint32_t *slab_mask,
+                               float *grad_coords, double *virial, uint32_t *status);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-species MLP ensemble: replaces mnp::run (csrc/mnp.cpp:238-265; forward :32-136, input-gradient

@@ -531,6 +531,21 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, JVP ? 4 : 7) void k_aev_fwd(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Backward.  One wave per central atom i, three phases:
+//   1. lane = neighbor: geometry + both cutoffs once per neighbor, and the WHOLE radial backward.  The list is full, so
+//      the pair (i, j) contributes  sum_s (g_i[sp_j, s] + g_j[sp_i, s]) d/dr [0.25 exp(-eta (r - s)^2) fc(r)]  to the
+//      force on i: atom i GATHERS the 64-B block g_j[sp_i, :] of every neighbor row and finishes its own radial force;
+//      nothing is pushed to j (no atomics, deterministic).  Only when row j is not available (outside this launch's
+//      rows lo..hi, i.e. owned by another rank, or not flagged in slab_mask) the own term is pushed to j instead.
+//   2. lane = (angular neighbor j, part): the unordered pairs {j, k} of the n angular-range neighbors in the circular
+//      tournament order k = j + 1 + rem (mod n), rem = part + parts * step.  A lane keeps its j for the whole atom
+//      (J-side data and the gradient on j stay in registers); inside one part all k of a step are distinct, so the
+//      gradient on k is a plain LDS read-add-write into the part's plane -- no LDS atomics (a ds_add_f32 costs ~40
+//      LDS cycles per wave on gfx950), no cross-lane reduction.  The species-pair block of dE/dAEV a pair needs is
+//      looked up per lane (8x8 table) and read from the row staged in LDS, so a step mixes all species pairs.
+//   3. lane = angular neighbor: planes summed, one global float atomic per component per neighbor, minus the total
+//      (and the radial force) on the central atom.
+// Only the blocks of the dE/dAEV row that the atom's neighbor species can reach are loaded (5 of 35 for water).
 // VIRIAL: also accumulate  W[a][b] = sum_ij (d E_i / d d_ij)[a] d_ij[b]  (the "fdotr" virial, ase.py:164-168) over the
 // central atoms of this launch: six per-lane running sums (W is symmetric), one double atomic per wave at the end.
 template <int NA, int NZ, bool VIRIAL>
@@ -538,47 +553,75 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
     const float4 *__restrict__ ent, const float *__restrict__ grad_aev, float *__restrict__ grad_coords,
-    double *__restrict__ virial)
+    double *__restrict__ virial, const uint32_t *__restrict__ slab_mask)
 {
     float vxx = 0.f, vyy = 0.f, vzz = 0.f, vxy = 0.f, vxz = 0.f, vyz = 0.f;
-    constexpr int AQ = NA / 4, ZQ = NZ / 4;
-    // per-wave LDS: only the angular-range neighbors need to be shared between lanes
+    constexpr int ZQ = NZ / 4;
     __shared__ float4 s_nb[BWD_WPB][MAXA];    // ux uy uz r
-    __shared__ float4 s_afc[BWD_WPB][MAXA];   // fc, fc', 1/r, bits(j)    (Rca)
-    __shared__ float4 s_g[BWD_WPB][MAXA];     // per-neighbor gradient accumulators (x, y, z, -)
+    __shared__ float4 s_af[BWD_WPB][MAXA];    // fc, fc', 1/r, bits(j | species << 28)    (Rca)
+    __shared__ float s_g[BWD_WPB][3][MAXA];   // gradient on neighbor k accumulated by part: [component][part * n + k]
     __shared__ __attribute__((aligned(16))) float s_stage[BWD_WPB][STAGE_FLOATS];
+    __shared__ uint16_t s_ptab[64];           // byte offset of the angular block of species pair (sj, sk) in a row
 
-    const int wib = threadIdx.x >> 6, lane = lane_id();
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     float4 *nb = s_nb[wib];
-    float4 *afc = s_afc[wib];
-    float4 *g4 = s_g[wib];
-    float *gflat = reinterpret_cast<float *>(g4);   // component q of neighbor e at 4 e + q
+    float4 *af = s_af[wib];
+    float *gx = s_g[wib][0], *gy = s_g[wib][1], *gz = s_g[wib][2];
     float *stage = s_stage[wib];
-
-    const int p = lane >> 2, q = lane & 3;
-    float shfA[AQ], cosZ[ZQ], sinZ[ZQ];
-#pragma unroll
-    for (int u = 0; u < AQ; ++u) shfA[u] = tab[TAB_SHFA + q + 4 * u];
-#pragma unroll
-    for (int v = 0; v < ZQ; ++v) {
-        cosZ[v] = tab[TAB_COSZ + q + 4 * v];
-        sinZ[v] = tab[TAB_SINZ + q + 4 * v];
+    if (threadIdx.x < 64) {
+        const int sj = threadIdx.x >> 3, sk = threadIdx.x & 7;
+        const int l_ = min(sj, sk), h_ = max(sj, sk);
+        const int P = l_ * a.S - ((l_ * (l_ - 1)) >> 1) + (h_ - l_);
+        s_ptab[threadIdx.x] = h_ < a.S ? (uint16_t)((a.radlen + 32 * P) * 4) : (uint16_t)0;
     }
-    float shfR[16];
+    __syncthreads();
+
+    float shfA[NA], cosZ[NZ], sinZ[NZ], shfR[16];   // wave-uniform
 #pragma unroll
-    for (int k = 0; k < 16; ++k) shfR[k] = tab[TAB_SHFR + k];   // wave-uniform
+    for (int u = 0; u < NA; ++u) shfA[u] = tab[TAB_SHFA + u];
+#pragma unroll
+    for (int v = 0; v < NZ; ++v) {
+        cosZ[v] = tab[TAB_COSZ + v];
+        sinZ[v] = tab[TAB_SINZ + v];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) shfR[k] = tab[TAB_SHFR + k];
     const float pi_rcr = PI_F / a.Rcr, pi_rca = PI_F / a.Rca;
     const float rev_rcr = 0.5f / a.Rcr, rev_rca = 0.5f / a.Rca;  // v_sin/v_cos take revolutions
-    const int L4 = a.L >> 2;
+    const int L4 = a.L >> 2, R4 = a.radlen >> 2;
+
+    // "needed block" bookkeeping.  Bit t < 7: radial block of species t; bit 7 + P: angular block of species pair P.
+    // Lane b < 35 decides bit b of an atom's mask from the per-species neighbor counts (ballot).
+    int nd_tj = 7, nd_tk = 7;   // species 7 never occurs: count 0
+    if (lane < 7) {
+        nd_tj = nd_tk = lane;
+    } else {
+        int P = lane - 7, tj = 0;
+        while (tj < a.S && P >= a.S - tj) { P -= a.S - tj; ++tj; }
+        if (tj < a.S) { nd_tj = tj; nd_tk = tj + P; }
+    }
+    // float4 slot f = lane + 64 m of a row belongs to block bit slot_bit[m] (63 = beyond the row)
+    int slot_bit[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int f = lane + WAVE * m;
+        slot_bit[m] = f >= L4 ? 63 : (f < R4 ? (f >> 2) : 7 + ((f - R4) >> 3));
+    }
+    auto need_of = [&](uint64_t pkA_, uint64_t pkF_) -> uint64_t {
+        const int cj = (int)((pkA_ >> (8 * nd_tj)) & 255u), ck = (int)((pkA_ >> (8 * nd_tk)) & 255u);
+        const int cf = (int)((pkF_ >> (8 * nd_tj)) & 255u);
+        const bool nd = lane < 7 ? (cj + cf > 0) : (nd_tj == nd_tk ? cj >= 2 : (cj >= 1 && ck >= 1));
+        return __ballot(nd && lane < 35);
+    };
 
     const int64_t nw = (int64_t)gridDim.x * BWD_WPB;
     int64_t i = lo + blockIdx.x * (int64_t)BWD_WPB + wib;
-    // software pipeline over atoms (as in the forward kernel): the header, the first 128 neighbor entries
-    // and the dE/dAEV row of atom i+nw are in flight while atom i is processed
+    // software pipeline over atoms: the header, the first 128 neighbor entries and the needed blocks of the dE/dAEV
+    // row of atom i+nw are in flight while atom i is processed
     uint32_t hw = hdr_load(meta, species, i, i < hi);
     AtomHdr h = hdr_decode(hw);
     const float4 zero4 = make_float4(1.f, 0.f, 0.f, 0.f);
-    float4 e0 = zero4, e1 = zero4, gr0, gr1, gr2, gr3;
+    float4 e0 = zero4, e1 = zero4, gr0 = zero4, gr1 = zero4, gr2 = zero4, gr3 = zero4;
     // (a macro, not a lambda: captured register arrays would be spilled to scratch)
 #define ANIHIP_BWD_ISSUE(ia, hh)                                                                         \
     {                                                                                                    \
@@ -588,40 +631,55 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
         const int n_ = ok_ ? (hh).nA + (hh).nF : 0;                                                      \
         if (lane < n_) e0 = ent[(hh).start + lane];                                                      \
         if (lane + WAVE < n_) e1 = ent[(hh).start + lane + WAVE];                                        \
+        const uint64_t need_ = ok_ ? need_of((hh).pkA, (hh).pkF) : 0ull;                                 \
         const float4 *g4_ = reinterpret_cast<const float4 *>(grad_aev + (size_t)((ia) < hi ? (ia) : lo) * a.L); \
-        gr0 = g4_[min(lane, L4 - 1)];              /* clamped: rows shorter than 256 float4 (ANI-1x) */  \
-        gr1 = g4_[min(lane + WAVE, L4 - 1)];                                                             \
-        gr2 = g4_[min(lane + 2 * WAVE, L4 - 1)];                                                         \
-        gr3 = g4_[min(lane + 3 * WAVE, L4 - 1)];                                                         \
+        if ((need_ >> slot_bit[0]) & 1ull) gr0 = g4_[lane];                                              \
+        if ((need_ >> slot_bit[1]) & 1ull) gr1 = g4_[lane + WAVE];                                       \
+        if ((need_ >> slot_bit[2]) & 1ull) gr2 = g4_[lane + 2 * WAVE];                                   \
+        if ((need_ >> slot_bit[3]) & 1ull) gr3 = g4_[lane + 3 * WAVE];                                   \
     }
     ANIHIP_BWD_ISSUE(i, h)
     uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
 
     for (; i < hi; i += nw) {
         const int nA = h.nA, nR = h.nA + h.nF;
-        const uint64_t pkA = h.pkA;
         const bool skip = h.sp < 0 || nR == 0;
         const uint32_t start = h.start;
-        float sx = 0.f, sy = 0.f, sz_ = 0.f;   // sum of everything pushed onto neighbors (-> central atom)
+        const int spi = h.sp;
+        float sx = 0.f, sy = 0.f, sz_ = 0.f;   // minus the gradient on the central atom, per lane
         if (!skip) {
             float4 *st4 = reinterpret_cast<float4 *>(stage);
             st4[lane] = gr0;
             st4[lane + WAVE] = gr1;
             st4[lane + 2 * WAVE] = gr2;
             if (lane + 3 * WAVE < L4) st4[lane + 3 * WAVE] = gr3;
+            gx[lane] = 0.f; gx[lane + WAVE] = 0.f;
+            gy[lane] = 0.f; gy[lane + WAVE] = 0.f;
+            gz[lane] = 0.f; gz[lane + WAVE] = 0.f;
             wave_sync();
-            // ---- per-neighbor pass (lane = neighbor): geometry, cutoffs and the WHOLE radial backward.
-            // dE/dr of a neighbor needs only that neighbor: 16 exp2 per lane, no cross-lane reduction.
-            // Far neighbors (r > Rca) are finished here and go straight to the global accumulator.
+            // ---- phase 1 (lane = neighbor) ----
+            const float *grow0 = grad_aev + (size_t)(spi < 0 ? 0 : spi) * 16;
+            const int sbit = spi >> 1;
             for (int c0 = 0; c0 < nR; c0 += WAVE) {
                 const int e = c0 + lane;
                 float4 d = c0 == 0 ? e0 : (c0 == WAVE ? e1 : zero4);
                 if (c0 >= 2 * WAVE && e < nR) d = ent[start + e];
                 const bool ve = e < nR;
-                const float r = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
-                const float inv = 1.0f / r;
-                const float ux = d.x * inv, uy = d.y * inv, uz = d.z * inv;
                 const uint32_t wbits = __float_as_uint(d.w);
+                const int64_t jn = ve ? (int64_t)(wbits & IDX_MASK) : lo;
+                // the neighbor's block for MY species: issued first, consumed at the end of the pass
+                const bool inrow = ve && jn >= lo && jn < hi;
+                float4 G0 = make_float4(0.f, 0.f, 0.f, 0.f), G1 = G0, G2 = G0, G3 = G0;
+                uint32_t jmask = 0xFFFFFFFFu;
+                if (inrow) {
+                    const float4 *gj4 = reinterpret_cast<const float4 *>(grow0 + (size_t)jn * a.L);
+                    G0 = gj4[0]; G1 = gj4[1]; G2 = gj4[2]; G3 = gj4[3];
+                    if (slab_mask) jmask = slab_mask[jn];
+                }
+                const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                const float inv = __builtin_amdgcn_rsqf(r2);
+                const float r = r2 * inv;
+                const float ux = d.x * inv, uy = d.y * inv, uz = d.z * inv;
                 const int t = ve ? (int)(wbits >> 28) : 0;
                 float fcr, dfcr;  // 0.25 fc, 0.25 fc' of the radial cutoff
                 if (a.smooth) {
@@ -631,34 +689,49 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                     fcr = 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f;
                     dfcr = -0.125f * pi_rcr * __builtin_amdgcn_sinf(r * rev_rcr);
                 }
-                float dR = 0.f;
+                const float4 *wo = reinterpret_cast<const float4 *>(stage + t * 16);
+                const float4 W0 = wo[0], W1 = wo[1], W2 = wo[2], W3 = wo[3];
+                const bool gat = inrow && ((jmask >> sbit) & 1u);
+                if (!gat) G0 = G1 = G2 = G3 = make_float4(0.f, 0.f, 0.f, 0.f);   // (never 0 * unwritten memory)
+                float wk[16] = {W0.x + G0.x, W0.y + G0.y, W0.z + G0.z, W0.w + G0.w, W1.x + G1.x, W1.y + G1.y,
+                                W1.z + G1.z, W1.w + G1.w, W2.x + G2.x, W2.y + G2.y, W2.z + G2.z, W2.w + G2.w,
+                                W3.x + G3.x, W3.y + G3.y, W3.z + G3.z, W3.w + G3.w};
+                // d/dr [exp(-eta d^2) fc] = exp(..) (fc' - 2 eta d fc):  dR = fc' sum w e - 2 eta fc sum w e d
+                float A = 0.f, B = 0.f;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const float dd = r - shfR[k];
-                    const float ex = __builtin_amdgcn_exp2f(a.kR * dd * dd);
-                    // d/dr [exp(-eta d^2) fc] = exp(..) (fc' - 2 eta d fc)
-                    dR += stage[t * 16 + k] * ex * (dfcr - 2.0f * a.EtaR * dd * fcr);
+                    const float we = wk[k] * __builtin_amdgcn_exp2f(a.kR * dd * dd);
+                    A += we;
+                    B += we * dd;
                 }
+                float dR = dfcr * A - 2.0f * a.EtaR * fcr * B;
                 dR = ve ? dR : 0.f;
                 const float Gx = dR * ux, Gy = dR * uy, Gz = dR * uz;
+                // an own term that must be PUSHED to an angular-range neighbor travels with the angular part
+                // (plane 0 of the per-neighbor sums) and is counted in phase 3
+                const bool via3 = ve && e < nA && !gat;
+                if (!via3) {
+                    sx += Gx; sy += Gy; sz_ += Gz;
+                    if (VIRIAL) {   // a gathered pair is seen from both of its atoms: half the virial each time
+                        const float vf = gat ? 0.5f : 1.0f;
+                        vxx += vf * Gx * d.x; vyy += vf * Gy * d.y; vzz += vf * Gz * d.z;
+                        vxy += vf * Gx * d.y; vxz += vf * Gx * d.z; vyz += vf * Gy * d.z;
+                    }
+                }
                 if (ve) {
                     if (e < nA) {
                         nb[e] = make_float4(ux, uy, uz, r);
                         const float2 ca = a.smooth ? smooth_cutoff(r, 1.0f / a.Rca)
                                                    : make_float2(0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f,
                                                                  -0.5f * pi_rca * __builtin_amdgcn_sinf(r * rev_rca));
-                        afc[e] = make_float4(ca.x, ca.y, inv, __uint_as_float(wbits & IDX_MASK));
-                        g4[e] = make_float4(Gx, Gy, Gz, 0.f);
-                    } else {
-                        float *gc = grad_coords + 3 * (size_t)(wbits & IDX_MASK);
+                        af[e] = make_float4(ca.x, ca.y, inv, d.w);
+                        if (!gat) { gx[e] = Gx; gy[e] = Gy; gz[e] = Gz; }   // pushed with the angular part (plane 0)
+                    } else if (!gat) {
+                        float *gc = grad_coords + 3 * (size_t)jn;
                         atomicAdd(gc + 0, Gx);
                         atomicAdd(gc + 1, Gy);
                         atomicAdd(gc + 2, Gz);
-                        sx += Gx; sy += Gy; sz_ += Gz;
-                        if (VIRIAL) {
-                            vxx += Gx * d.x; vyy += Gy * d.y; vzz += Gz * d.z;
-                            vxy += Gx * d.y; vxz += Gx * d.z; vyz += Gy * d.z;
-                        }
                     }
                 }
             }
@@ -670,138 +743,118 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
         if (skip) continue;
         wave_sync();
 
-        // ---- angular ----
-        {
-            int P = 0, oj = 0;
-            for (int tj = 0; tj < a.S; ++tj) {
-                const int nj = cnt_of(pkA, tj);
-                int ok = oj;
-                for (int tk = tj; tk < a.S; ++tk, ++P) {
-                    const int nk = cnt_of(pkA, tk);
-                    const bool same = (tk == tj);
-                    const int np = same ? (nj * (nj - 1)) >> 1 : nj * nk;
-                    if (np == 0) {
-                        ok += nk;
-                        continue;
-                    }
-                    // Pair order of a rectangle (two species): the RUN index (constant over `div` consecutive
-                    // pairs) is the smaller group, the other one cycles with period div = size of the larger
-                    // group -- same-address LDS atomics of a wave serialise, so the run side is pre-reduced
-                    // across lanes below and the cycling side repeats as rarely as possible.
-                    const bool sw = !same && nk < nj;
-                    const int na = sw ? nk : nj, oa = sw ? ok : oj, ob = sw ? oj : ok;
-                    const int div = same ? ((nj - 1) >> 1) : (sw ? nj : nk);
-                    const float inv_div = div > 0 ? 1.0f / (float)div : 0.f;
-                    const int rect = same ? nj * div : 0x7FFFFFFF;
-                    const int half = nj >> 1;
-                    const float *blk = stage + a.radlen + P * 32;
-                    float w[AQ][NZ];
+        // ---- phase 2 (lane = (angular neighbor j, part)) ----
+        const int n = nA;
+        const int dv = (n - 1) >> 1;                 // partners per neighbor in the tournament
+        const bool even = (n & 1) == 0;
+        const int nrem = dv + (even ? 1 : 0);        // rem == dv: the n / 2 diameters of an even n
+        const int halfn = n >> 1;
+        const int npl = n < WAVE ? n : WAVE;         // lanes per part
+        int parts = n > 0 ? WAVE / npl : 1;
+        parts = parts > nrem ? (nrem > 0 ? nrem : 1) : parts;
+        const int part = n > 0 ? (int)(((float)lane + 0.5f) / (float)npl) : 0;
+        const int jl = lane - part * npl;
+        const int pbase = part * n;                  // (n > 64: one part, base 0)
+        const int nsteps = nrem > 0 ? (nrem + parts - 1) / parts : 0;
+        for (int jb = 0; jb < n && nsteps > 0; jb += WAVE) {
+            const int j = jb + jl;
+            const bool vj = part < parts && j < n;
+            const int jc = vj ? j : 0;
+            const float4 Jv = nb[jc], FJ = af[jc];
+            const int sj8 = (int)((__float_as_uint(FJ.w) >> 25) & 0x38u);
+            float gjx = 0.f, gjy = 0.f, gjz = 0.f;
+            for (int s = 0; s < nsteps; ++s) {
+                const int rem = part + parts * s;
+                const bool v = vj && (rem < dv || (even && rem == dv && j < halfn));
+                int k = j + 1 + rem;
+                k = k >= n ? k - n : k;
+                k = v ? k : 0;
+                const float4 Kv = nb[k], FK = af[k];
+                const int sk = (int)(__float_as_uint(FK.w) >> 28);
+                const float4 *wb = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(stage) +
+                                                                     s_ptab[sj8 + sk]);
+                const float c = Jv.x * Kv.x + Jv.y * Kv.y + Jv.z * Kv.z;
+                const float ct = 0.95f * c;
+                const float st2 = fmaxf(1.0f - ct * ct, 1e-12f);
+                const float rst = __builtin_amdgcn_rsqf(st2);   // 1 / sin(theta)
+                const float st = st2 * rst;
+                const float rm = 0.5f * (Jv.w + Kv.w);
+                float f1[NZ], df1[NZ];
 #pragma unroll
-                    for (int u = 0; u < AQ; ++u)
-#pragma unroll
-                        for (int z = 0; z < NZ; ++z) w[u][z] = blk[(q + 4 * u) * NZ + z];
-                    // software pipelined: the LDS reads of step s+1 are issued before the arithmetic of s
-                    int jr, kr;
-                    decode_pair2(same, min(p, np - 1), na, div, inv_div, rect, half, jr, kr);
-                    int ej = oa + jr, ek = ob + kr;
-                    float4 J = nb[ej], K = nb[ek], FJ = afc[ej], FK = afc[ek];
-                    for (int t0 = 0; t0 < np; t0 += 16) {
-                        const bool v = t0 + p < np;
-                        const float4 Jc = J, Kc = K, FJc = FJ, FKc = FK;
-                        const int ejc = ej, ekc = ek;
-                        if (t0 + 16 < np) {
-                            decode_pair2(same, min(t0 + 16 + p, np - 1), na, div, inv_div, rect, half, jr, kr);
-                            ej = oa + jr;
-                            ek = ob + kr;
-                            J = nb[ej];
-                            K = nb[ek];
-                            FJ = afc[ej];
-                            FK = afc[ek];
-                        }
-                        const float c = Jc.x * Kc.x + Jc.y * Kc.y + Jc.z * Kc.z;
-                        const float ct = 0.95f * c;
-                        const float st2 = fmaxf(1.0f - ct * ct, 1e-12f);
-                        const float rst = __builtin_amdgcn_rsqf(st2);   // 1 / sin(theta)
-                        const float st = st2 * rst;
-                        const float rm = 0.5f * (Jc.w + Kc.w);
-                        // this lane's quarter of the factors
-                        float f1q[ZQ], df1q[ZQ], f2[AQ], df2[AQ];
-#pragma unroll
-                        for (int vz = 0; vz < ZQ; ++vz) {
-                            const float cz = ct * cosZ[vz] + st * sinZ[vz];   // cos(theta - ShfZ)
-                            const float sz = st * cosZ[vz] - ct * sinZ[vz];   // sin(theta - ShfZ)
-                            const float h = fmaxf(0.5f + 0.5f * cz, 0.f);
-                            const float p1 = __builtin_amdgcn_exp2f((a.Zeta - 1.0f) * __builtin_amdgcn_logf(h));
-                            f1q[vz] = 2.0f * h * p1;          // 2 h^zeta
-                            df1q[vz] = -a.Zeta * p1 * sz;     // d/dtheta
-                        }
-#pragma unroll
-                        for (int u = 0; u < AQ; ++u) {
-                            const float d = rm - shfA[u];
-                            f2[u] = __builtin_amdgcn_exp2f(a.kA * d * d);
-                            df2[u] = -2.0f * a.EtaA * d * f2[u];  // d/d rm
-                        }
-                        // C0 = sum w f1 f2, Cth = sum w f1' f2, CR = sum w f1 f2': contract the angle index z first
-                        // (P_u = sum_z w f1, Q_u = sum_z w f1'), then the few radial shifts of this lane
-                        float Pu[AQ], Qu[AQ];
-#pragma unroll
-                        for (int u = 0; u < AQ; ++u) { Pu[u] = 0.f; Qu[u] = 0.f; }
-#pragma unroll
-                        for (int z = 0; z < NZ; ++z) {
-                            const float f1 = quad_bcast_rt(f1q[z >> 2], z & 3);
-                            const float df1 = quad_bcast_rt(df1q[z >> 2], z & 3);
-#pragma unroll
-                            for (int u = 0; u < AQ; ++u) {
-                                Pu[u] += w[u][z] * f1;
-                                Qu[u] += w[u][z] * df1;
-                            }
-                        }
-                        float C0 = 0.f, Cth = 0.f, CR = 0.f;
-#pragma unroll
-                        for (int u = 0; u < AQ; ++u) {
-                            C0 += Pu[u] * f2[u];
-                            Cth += Qu[u] * f2[u];
-                            CR += Pu[u] * df2[u];
-                        }
-                        C0 = quad_sum(C0);
-                        Cth = quad_sum(Cth);
-                        CR = quad_sum(CR);
-                        const float fcc = v ? FJc.x * FKc.x : 0.f;
-                        const float kth = Cth * fcc * (-0.95f * rst);
-                        const float k1 = 0.5f * CR * fcc + (v ? C0 * FJc.y * FKc.x : 0.f);
-                        const float k2 = 0.5f * CR * fcc + (v ? C0 * FJc.x * FKc.y : 0.f);
-                        // component q of the two gradient vectors (q == 3 idles)
-                        const float uj = q == 0 ? Jc.x : (q == 1 ? Jc.y : Jc.z);
-                        const float uk = q == 0 ? Kc.x : (q == 1 ? Kc.y : Kc.z);
-                        float gj = kth * (uk - c * uj) * FJc.z + k1 * uj;   // (0 for idle pair slots)
-                        const float gk = kth * (uj - c * uk) * FKc.z + k2 * uk;
-                        // run side: segmented sum over the (up to 4) pair slots of this 16-lane DPP row that
-                        // share the neighbor, then one atomic from the last slot of each run
-                        {
-                            const int e1 = __builtin_amdgcn_update_dpp(-1, ejc, 0x114, 0xF, 0xF, false);  // row_shr:4
-                            const float g1 = dpp_perm<0x114>(gj);
-                            gj += e1 == ejc ? g1 : 0.f;
-                            const int e2 = __builtin_amdgcn_update_dpp(-1, ejc, 0x118, 0xF, 0xF, false);  // row_shr:8
-                            const float g2 = dpp_perm<0x118>(gj);
-                            gj += e2 == ejc ? g2 : 0.f;
-                        }
-                        const int en = __builtin_amdgcn_update_dpp(-1, ejc, 0x104, 0xF, 0xF, false);      // row_shl:4
-                        if (q < 3) {
-                            if (en != ejc) atomicAdd(&gflat[4 * ejc + q], gj);  // LDS ds_add_f32
-                            if (v) atomicAdd(&gflat[4 * ekc + q], gk);
-                        }
-                    }
-                    ok += nk;
+                for (int z = 0; z < NZ; ++z) {
+                    const float cz = ct * cosZ[z] + st * sinZ[z];   // cos(theta - ShfZ)
+                    const float sz = st * cosZ[z] - ct * sinZ[z];   // sin(theta - ShfZ)
+                    const float hh = fmaxf(0.5f + 0.5f * cz, 0.f);
+                    const float p1 = __builtin_amdgcn_exp2f((a.Zeta - 1.0f) * __builtin_amdgcn_logf(hh));
+                    f1[z] = 2.0f * hh * p1;          // 2 h^zeta
+                    df1[z] = -a.Zeta * p1 * sz;      // d/dtheta
                 }
-                oj += nj;
+                // contract the radial-shift index first: X_z = sum_a w[a][z] f2[a], Y_z = sum_a w[a][z] f2'[a]
+                float X[NZ], Y[NZ];
+#pragma unroll
+                for (int z = 0; z < NZ; ++z) { X[z] = 0.f; Y[z] = 0.f; }
+#pragma unroll
+                for (int u = 0; u < NA; ++u) {
+                    const float dd = rm - shfA[u];
+                    const float f2 = __builtin_amdgcn_exp2f(a.kA * dd * dd);
+                    const float df2 = -2.0f * a.EtaA * dd * f2;   // d/d rm
+#pragma unroll
+                    for (int zq = 0; zq < ZQ; ++zq) {
+                        const float4 w4 = wb[u * ZQ + zq];
+                        X[4 * zq + 0] += w4.x * f2; Y[4 * zq + 0] += w4.x * df2;
+                        X[4 * zq + 1] += w4.y * f2; Y[4 * zq + 1] += w4.y * df2;
+                        X[4 * zq + 2] += w4.z * f2; Y[4 * zq + 2] += w4.z * df2;
+                        X[4 * zq + 3] += w4.w * f2; Y[4 * zq + 3] += w4.w * df2;
+                    }
+                }
+                // C0 = sum w f1 f2, Cth = sum w f1' f2, CR = sum w f1 f2'
+                float C0 = 0.f, Cth = 0.f, CR = 0.f;
+#pragma unroll
+                for (int z = 0; z < NZ; ++z) {
+                    C0 += X[z] * f1[z];
+                    Cth += X[z] * df1[z];
+                    CR += Y[z] * f1[z];
+                }
+                const float m = v ? 1.0f : 0.0f;
+                const float fcc = m * FJ.x * FK.x;
+                const float kth = Cth * fcc * (-0.95f * rst);
+                const float k1 = 0.5f * CR * fcc + C0 * (m * FJ.y * FK.x);
+                const float k2 = 0.5f * CR * fcc + C0 * (m * FJ.x * FK.y);
+                const float aj = kth * FJ.z, ak = kth * FK.z;
+                gjx += aj * (Kv.x - c * Jv.x) + k1 * Jv.x;
+                gjy += aj * (Kv.y - c * Jv.y) + k1 * Jv.y;
+                gjz += aj * (Kv.z - c * Jv.z) + k1 * Jv.z;
+                const float gkx = ak * (Jv.x - c * Kv.x) + k2 * Kv.x;
+                const float gky = ak * (Jv.y - c * Kv.y) + k2 * Kv.y;
+                const float gkz = ak * (Jv.z - c * Kv.z) + k2 * Kv.z;
+                // inside a part the k of one step are all different: plain read-add-write
+                const int gi = (v ? pbase : 0) + k;
+                const float ox = gx[gi], oy = gy[gi], oz = gz[gi];
+                if (v) {   // (LDS operations of one wave execute in order: the next step sees these)
+                    gx[gi] = ox + gkx;
+                    gy[gi] = oy + gky;
+                    gz[gi] = oz + gkz;
+                }
             }
+            if (vj) {
+                const int gi = pbase + j;
+                gx[gi] += gjx;
+                gy[gi] += gjy;
+                gz[gi] += gjz;
+            }
+            wave_sync();
         }
-        wave_sync();
-        // ---- scatter: +G to each angular-range neighbor, -sum(all G) to the central atom ----
+        // ---- phase 3 (lane = angular neighbor): +G to the neighbor, -sum(all G) to the central atom ----
         for (int e = lane; e < nA; e += WAVE) {
-            const float4 gv = g4[e];
-            const float x = gv.x, y = gv.y, z = gv.z;
-            float *gc = grad_coords + 3 * (size_t)__float_as_uint(afc[e].w);
+            float x = 0.f, y = 0.f, z = 0.f;
+            const int np_ = n <= WAVE ? parts : 1;
+            for (int pp = 0; pp < np_; ++pp) {
+                x += gx[pp * n + e];
+                y += gy[pp * n + e];
+                z += gz[pp * n + e];
+            }
+            const float4 fa = af[e];
+            float *gc = grad_coords + 3 * (size_t)(__float_as_uint(fa.w) & IDX_MASK);
             atomicAdd(gc + 0, x);
             atomicAdd(gc + 1, y);
             atomicAdd(gc + 2, z);
@@ -930,7 +983,7 @@ extern "C" int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const fl
 
 static int aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms, int64_t lo,
                         int64_t hi, const int32_t *species, const uint32_t *meta, const float *ent,
-                        const float *grad_aev, float *grad_coords, double *virial)
+                        const float *grad_aev, float *grad_coords, double *virial, const uint32_t *slab_mask)
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && grad_aev && grad_coords, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
@@ -943,16 +996,16 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
     hipStream_t st = (hipStream_t)stream;
     if (p->n_shf_a == 8 && !virial)
         hipLaunchKernelGGL((k_aev_bwd<8, 4, false>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial);
+                           grad_coords, virial, slab_mask);
     else if (p->n_shf_a == 8)
         hipLaunchKernelGGL((k_aev_bwd<8, 4, true>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial);
+                           grad_coords, virial, slab_mask);
     else if (!virial)
         hipLaunchKernelGGL((k_aev_bwd<4, 8, false>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial);
+                           grad_coords, virial, slab_mask);
     else
         hipLaunchKernelGGL((k_aev_bwd<4, 8, true>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial);
+                           grad_coords, virial, slab_mask);
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -960,18 +1013,21 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
 extern "C" int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table,
                                    int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
                                    const uint32_t *meta, const float *ent, const float *grad_aev,
-                                   float *grad_coords, uint32_t *status)
+                                   const uint32_t *slab_mask, float *grad_coords, uint32_t *status)
 {
     (void)status;
-    return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, nullptr);
+    return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, nullptr,
+                        slab_mask);
 }
 
 extern "C" int anihip_aev_backward_virial(void *stream, const anihip_aev_params *p, const float *table,
                                           int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
                                           const uint32_t *meta, const float *ent, const float *grad_aev,
-                                          float *grad_coords, double *virial, uint32_t *status)
+                                          const uint32_t *slab_mask, float *grad_coords, double *virial,
+                                          uint32_t *status)
 {
     (void)status;
     ANIHIP_REQUIRE(virial, "null pointer argument");
-    return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, virial);
+    return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, virial,
+                        slab_mask);
 }

@@ -263,19 +263,23 @@ class AevEngine:
 
     def backward(self, species: Tensor, nbrs: NeighborRows, grad_aev: Tensor,
                  grad_coords: tp.Optional[Tensor] = None, shard_rows: bool = False,
-                 virial: tp.Optional[Tensor] = None) -> Tensor:
+                 virial: tp.Optional[Tensor] = None, slab_mask: tp.Optional[Tensor] = None) -> Tensor:
         """grad_coords [N,3] += d(sum grad_aev*aev)/d coords for the central atoms of nbrs.
         shard_rows=True: grad_aev holds only the rows lo..hi.
+        slab_mask (int32 [N], as written by forward): grad_aev is valid only inside the flagged slabs of each row
+        (what PackedNetworks.forward_backward leaves behind); None: whole rows are valid.
         virial (optional float64 [3,3], overwritten): sum_ij dE/d d_ij (x) d_ij over those central atoms."""
-        _require_cuda(species, grad_aev)
+        _require_cuda(species, grad_aev, slab_mask)
         n = species.numel()
         assert grad_aev.dtype == torch.float32 and grad_aev.is_contiguous()
         assert grad_aev.numel() == ((nbrs.hi - nbrs.lo) if shard_rows else n) * self.L
+        if slab_mask is not None:
+            assert slab_mask.dtype == torch.int32 and slab_mask.numel() == n and slab_mask.is_contiguous()
         if grad_coords is None:
             grad_coords = torch.zeros((n, 3), dtype=torch.float32, device=species.device)
         args = (_stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
                 _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent),
-                _row_ptr(grad_aev, nbrs.lo if shard_rows else 0, self.L), _ptr(grad_coords))
+                _row_ptr(grad_aev, nbrs.lo if shard_rows else 0, self.L), _ptr(slab_mask), _ptr(grad_coords))
         if virial is None:
             _lib.check(_lib.lib().anihip_aev_backward(*args, _ptr(nbrs.status)))
         else:

@@ -137,7 +137,7 @@ class ANI(torch.nn.Module):
                                                         chunk=self.mlp_chunk, slab_mask=slab_mask,
                                                         shard_rows=True)
         virial = torch.empty((3, 3), dtype=torch.float64, device=c32.device) if stress else None
-        grad_coords = eng.backward(species32, nbrs, grad_aev, shard_rows=True, virial=virial)
+        grad_coords = eng.backward(species32, nbrs, grad_aev, shard_rows=True, virial=virial, slab_mask=slab_mask)
         sae = None
         if self.energy_shifter._enabled:
             sae = self.energy_shifter.self_energies.to(device=c32.device, dtype=torch.float64)
