@@ -66,10 +66,12 @@ typedef struct {
 
 /* Length in floats of the device constant table consumed by the AEV kernels, and a host-side packer:
  * table = ShfR[32] | ShfA[16] | cos(ShfZ)[16] | sin(ShfZ)[16]  (trig evaluated in double on the
- * fp32-rounded ShfZ).  The caller uploads it to the device. */
-#define ANIHIP_AEV_TABLE_FLOATS 80
+ * fp32-rounded ShfZ) | q_R ShfR[16] | q_A ShfA[16] | cos/2 [16] | sin/2 [16] with
+ * q = sqrt(Eta log2 e)  (exp(-Eta x^2) = exp2(-(q x)^2): the kernels keep distances pre-scaled).  The caller uploads
+ * it to the device. */
+#define ANIHIP_AEV_TABLE_FLOATS 144
 int anihip_aev_table_pack(const anihip_aev_params *p, const float *ShfR, const float *ShfA,
-                          const float *ShfZ, float *table_out /* host, 80 floats */);
+                          const float *ShfZ, float *table_out /* host, ANIHIP_AEV_TABLE_FLOATS */);
 
 const char *anihip_last_error(void);
 int anihip_abi_version(void);

@@ -63,7 +63,7 @@ def test_error_reporting_without_gpu(lib):
 
     p = _lib.AevParams(num_species=7, n_shf_r=16, n_shf_a=5, n_shf_z=4, Rcr=5.1, Rca=3.5, EtaR=19.7, EtaA=12.5,
                        Zeta=14.1)
-    z = np.zeros(80, dtype=np.float32)
+    z = np.zeros(_lib.TABLE_FLOATS, dtype=np.float32)
     rc = lib.anihip_aev_table_pack(ctypes.byref(p), z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data)
     assert rc != 0 and b"8x4 or 4x8" in lib.anihip_last_error()
     with pytest.raises(RuntimeError, match="libanihip"):

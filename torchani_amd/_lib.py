@@ -24,7 +24,7 @@ META_WORDS = 6
 STATUS_WORDS = 8
 MAX_ANG = 128
 MAX_RAD = 256
-TABLE_FLOATS = 80
+TABLE_FLOATS = 144
 ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
 MLP_FP32, MLP_F16X3 = 0, 1
 ABI_VERSION = 5

@@ -36,6 +36,7 @@ constexpr float PI_F = 3.14159265358979323846f;
 struct AevArgs {
     int S, NR, L, radlen;
     float Rcr, Rca, kR, kA, EtaR, EtaA, Zeta;
+    float qR, qA;   // sqrt(eta log2 e): exp(-eta x^2) = exp2(-(q x)^2)
     int smooth;  // cutoff_kind: 0 = CutoffCosine, 1 = CutoffSmooth (order 2, eps 1e-10)
 };
 
@@ -582,17 +583,17 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD2_WAVES) void k_aev_fwd2(
     float2 *rad = s_rad[wib];
 
     // exp(-eta x^2) = exp2(-(q x)^2), q = sqrt(eta log2 e)
-    const float qR = sqrtf(a.EtaR * LOG2E), qA = sqrtf(a.EtaA * LOG2E);
+    const float qR = a.qR, qA = a.qA;
     const int rp = lane >> 3, rsq = lane & 7;  // radial: neighbor slot, shift pair
-    const float shfR0 = qR * tab[TAB_SHFR + rsq], shfR1 = qR * tab[TAB_SHFR + rsq + 8];
+    const float shfR0 = tab[TAB_SHFRQ + rsq], shfR1 = tab[TAB_SHFRQ + rsq + 8];
     const int slot = lane >> 1, h = lane & 1;  // angular: pair slot, half
     float shfAq[AH], cZ[ZH], sZ[ZH];
 #pragma unroll
-    for (int u = 0; u < AH; ++u) shfAq[u] = qA * tab[TAB_SHFA + h * AH + u];
+    for (int u = 0; u < AH; ++u) shfAq[u] = tab[TAB_SHFAQ + h * AH + u];
 #pragma unroll
     for (int v = 0; v < ZH; ++v) {   // h(theta) = 0.5 + 0.5 cos(theta - ShfZ),  z = 2 v + h
-        cZ[v] = 0.5f * tab[TAB_COSZ + 2 * v + h];
-        sZ[v] = 0.5f * tab[TAB_SINZ + 2 * v + h];
+        cZ[v] = tab[TAB_COSZH + 2 * v + h];
+        sZ[v] = tab[TAB_SINZH + 2 * v + h];
     }
     const float rev_rcr = 0.5f / a.Rcr, rev_rca = 0.5f / a.Rca;   // v_cos_f32 takes revolutions
     // position of this lane's reduced value inside an angular block: local accumulator w = (lane >> 2) & 15 =
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD2_WAVES) void k_aev_fwd2(
             const bool same = (tk == tj);
             const int np = same ? (nj * (nj - 1)) >> 1 : nj * nk;
             const int div = same ? ((nj - 1) >> 1) : nk;
-            const float inv_div = div > 0 ? 1.0f / (float)div : 0.f;
+            const float inv_div = div > 0 ? __builtin_amdgcn_rcpf((float)div) : 0.f;   // (exact for powers of two)
             const int rect = same ? nj * div : 0x7FFFFFFF;
             const int half = nj >> 1;
             const int q32 = div > 0 ? (int)(32.01f * inv_div) : 0, r32 = 32 - q32 * div;
@@ -755,7 +756,8 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD2_WAVES) void k_aev_fwd2(
 #pragma unroll
                 for (int vp = 0; vp < ZP; ++vp) acc[u][vp] = (v2f){0.f, 0.f};
             PairIter it = pair_begin(slot, div, inv_div);
-            for (int t0 = 0; t0 < np; t0 += 32) {
+            int t0 = 0;
+            do {   // (np >= 1: the block is flagged)
                 // (j, k) of pair it.t inside the two groups; slots past the last pair read the dummy neighbor
                 int jr = it.qd, kr = it.rem;
                 if (same) {   // wave-uniform
@@ -801,7 +803,8 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD2_WAVES) void k_aev_fwd2(
                 for (int u = 0; u < NA; ++u)
 #pragma unroll
                     for (int vp = 0; vp < ZP; ++vp) acc[u][vp] += (v2f){f2[u], f2[u]} * f1[vp];
-            }
+                t0 += 32;
+            } while (t0 < np);
             // 32 slots -> 1 (see the header comment)
             float r16[16];
 #pragma unroll
@@ -871,17 +874,21 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
     }
     __syncthreads();
 
-    float shfA[NA], cosZ[NZ], sinZ[NZ], shfR[16];   // wave-uniform
+    // exp(-eta x^2) = exp2(-(q x)^2) with q = sqrt(eta log2 e): distances and shifts are kept pre-scaled
+    const float qR = a.qR, qA = a.qA;
+    float shfAq[NA], cZh[NZ], sZh[NZ], shfRq[16];   // wave-uniform (scalar registers)
 #pragma unroll
-    for (int u = 0; u < NA; ++u) shfA[u] = tab[TAB_SHFA + u];
+    for (int u = 0; u < NA; ++u) shfAq[u] = tab[TAB_SHFAQ + u];
 #pragma unroll
-    for (int v = 0; v < NZ; ++v) {
-        cosZ[v] = tab[TAB_COSZ + v];
-        sinZ[v] = tab[TAB_SINZ + v];
+    for (int v = 0; v < NZ; ++v) {   // halves: h = 0.5 + 0.5 cos(theta - ShfZ)
+        cZh[v] = tab[TAB_COSZH + v];
+        sZh[v] = tab[TAB_SINZH + v];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) shfR[k] = tab[TAB_SHFR + k];
+    for (int k = 0; k < 16; ++k) shfRq[k] = tab[TAB_SHFRQ + k];
     const float pi_rcr = PI_F / a.Rcr, pi_rca = PI_F / a.Rca;
+    // factors pulled out of the inner sums (see phase 2): d f2 / d rm = kap (q d) f2, d f1 / d theta = -2 zeta p1 (sz / 2)
+    const float kap = -2.0f * a.EtaA / qA, kth0 = 2.0f * 0.95f * a.Zeta, kR2 = -2.0f * a.EtaR / qR;
     const float rev_rcr = 0.5f / a.Rcr, rev_rca = 0.5f / a.Rca;  // v_sin/v_cos take revolutions
     const int L4 = a.L >> 2, R4 = a.radlen >> 2;
 
@@ -992,15 +999,15 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                                 W1.z + G1.z, W1.w + G1.w, W2.x + G2.x, W2.y + G2.y, W2.z + G2.z, W2.w + G2.w,
                                 W3.x + G3.x, W3.y + G3.y, W3.z + G3.z, W3.w + G3.w};
                 // d/dr [exp(-eta d^2) fc] = exp(..) (fc' - 2 eta d fc):  dR = fc' sum w e - 2 eta fc sum w e d
-                float A = 0.f, B = 0.f;
+                const float rq = qR * r;
+                v2f AB = (v2f){0.f, 0.f};   // sum w e, sum w e (q d)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const float dd = r - shfR[k];
-                    const float we = wk[k] * __builtin_amdgcn_exp2f(a.kR * dd * dd);
-                    A += we;
-                    B += we * dd;
+                    const float dq = rq - shfRq[k];
+                    const float we = wk[k] * __builtin_amdgcn_exp2f(-dq * dq);
+                    AB += (v2f){we, we} * (v2f){1.0f, dq};
                 }
-                float dR = dfcr * A - 2.0f * a.EtaR * fcr * B;
+                float dR = dfcr * AB.x + kR2 * fcr * AB.y;
                 dR = ve ? dR : 0.f;
                 const float Gx = dR * ux, Gy = dR * uy, Gz = dR * uz;
                 // an own term that must be PUSHED to an angular-range neighbor travels with the angular part
@@ -1016,7 +1023,7 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                 }
                 if (ve) {
                     if (e < nA) {
-                        nb[e] = make_float4(ux, uy, uz, r);
+                        nb[e] = make_float4(ux, uy, uz, 0.5f * qA * r);
                         const float2 ca = a.smooth ? smooth_cutoff(r, 1.0f / a.Rca)
                                                    : make_float2(0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f,
                                                                  -0.5f * pi_rca * __builtin_amdgcn_sinf(r * rev_rca));
@@ -1073,48 +1080,49 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                 const float st2 = fmaxf(1.0f - ct * ct, 1e-12f);
                 const float rst = __builtin_amdgcn_rsqf(st2);   // 1 / sin(theta)
                 const float st = st2 * rst;
-                const float rm = 0.5f * (Jv.w + Kv.w);
-                float f1[NZ], df1[NZ];
+                const float srq = Jv.w + Kv.w;                  // q rm
+                // f1h = h^zeta (= f1 / 2), f1d = p1 sin(theta - ShfZ) / 2 (= -(d f1 / d theta) / (2 zeta))
+                v2f fd[NZ];
 #pragma unroll
                 for (int z = 0; z < NZ; ++z) {
-                    const float cz = ct * cosZ[z] + st * sinZ[z];   // cos(theta - ShfZ)
-                    const float sz = st * cosZ[z] - ct * sinZ[z];   // sin(theta - ShfZ)
-                    const float hh = fmaxf(0.5f + 0.5f * cz, 0.f);
-                    const float p1 = __builtin_amdgcn_exp2f((a.Zeta - 1.0f) * __builtin_amdgcn_logf(hh));
-                    f1[z] = 2.0f * hh * p1;          // 2 h^zeta
-                    df1[z] = -a.Zeta * p1 * sz;      // d/dtheta
+                    // (h - 0.5, sin(theta - ShfZ) / 2) = ct (cos, -sin) / 2 + st (sin, cos) / 2
+                    const v2f hs = (v2f){ct, ct} * (v2f){cZh[z], -sZh[z]} + (v2f){st, st} * (v2f){sZh[z], cZh[z]};
+                    const float hh = 0.5f + hs.x;
+                    const float p1 = __builtin_amdgcn_exp2f((a.Zeta - 1.0f) * __builtin_amdgcn_logf(__builtin_fabsf(hh)));
+                    fd[z] = (v2f){p1, p1} * (v2f){hh, hs.y};
                 }
-                // contract the radial-shift index first: X_z = sum_a w[a][z] f2[a], Y_z = sum_a w[a][z] f2'[a]
-                float X[NZ], Y[NZ];
+                // contract the radial-shift index first: (X_z, Y_z) = sum_a w[a][z] (f2[a], q d f2[a])
+                v2f XY[NZ];
 #pragma unroll
-                for (int z = 0; z < NZ; ++z) { X[z] = 0.f; Y[z] = 0.f; }
+                for (int z = 0; z < NZ; ++z) XY[z] = (v2f){0.f, 0.f};
 #pragma unroll
                 for (int u = 0; u < NA; ++u) {
-                    const float dd = rm - shfA[u];
-                    const float f2 = __builtin_amdgcn_exp2f(a.kA * dd * dd);
-                    const float df2 = -2.0f * a.EtaA * dd * f2;   // d/d rm
+                    const float dq = srq - shfAq[u];
+                    const float f2 = __builtin_amdgcn_exp2f(-dq * dq);
+                    const v2f F = (v2f){f2, dq * f2};
 #pragma unroll
                     for (int zq = 0; zq < ZQ; ++zq) {
                         const float4 w4 = wb[u * ZQ + zq];
-                        X[4 * zq + 0] += w4.x * f2; Y[4 * zq + 0] += w4.x * df2;
-                        X[4 * zq + 1] += w4.y * f2; Y[4 * zq + 1] += w4.y * df2;
-                        X[4 * zq + 2] += w4.z * f2; Y[4 * zq + 2] += w4.z * df2;
-                        X[4 * zq + 3] += w4.w * f2; Y[4 * zq + 3] += w4.w * df2;
+                        XY[4 * zq + 0] += (v2f){w4.x, w4.x} * F;
+                        XY[4 * zq + 1] += (v2f){w4.y, w4.y} * F;
+                        XY[4 * zq + 2] += (v2f){w4.z, w4.z} * F;
+                        XY[4 * zq + 3] += (v2f){w4.w, w4.w} * F;
                     }
                 }
-                // C0 = sum w f1 f2, Cth = sum w f1' f2, CR = sum w f1 f2'
-                float C0 = 0.f, Cth = 0.f, CR = 0.f;
+                // C0 = sum w f1 f2 = 2 c0h, Cth = sum w f1' f2 = -2 zeta cth, CR = sum w f1 f2' = 2 kap crh
+                v2f cc = (v2f){0.f, 0.f};
+                float crh = 0.f;
 #pragma unroll
                 for (int z = 0; z < NZ; ++z) {
-                    C0 += X[z] * f1[z];
-                    Cth += X[z] * df1[z];
-                    CR += Y[z] * f1[z];
+                    cc += (v2f){XY[z].x, XY[z].x} * fd[z];
+                    crh += XY[z].y * fd[z].x;
                 }
                 const float m = v ? 1.0f : 0.0f;
                 const float fcc = m * FJ.x * FK.x;
-                const float kth = Cth * fcc * (-0.95f * rst);
-                const float k1 = 0.5f * CR * fcc + C0 * (m * FJ.y * FK.x);
-                const float k2 = 0.5f * CR * fcc + C0 * (m * FJ.x * FK.y);
+                const float kth = cc.y * fcc * (kth0 * rst);
+                const float krr = kap * crh * fcc, c02 = 2.0f * m * cc.x;
+                const float k1 = krr + c02 * (FJ.y * FK.x);
+                const float k2 = krr + c02 * (FJ.x * FK.y);
                 const float aj = kth * FJ.z, ak = kth * FK.z;
                 gjx += aj * (Kv.x - c * Jv.x) + k1 * Jv.x;
                 gjy += aj * (Kv.y - c * Jv.y) + k1 * Jv.y;
@@ -1155,8 +1163,9 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
             atomicAdd(gc + 2, z);
             sx += x; sy += y; sz_ += z;
             if (VIRIAL) {
-                const float4 u = nb[e];   // unit vector, r
-                const float dx = u.x * u.w, dy = u.y * u.w, dz = u.z * u.w;
+                const float4 u = nb[e];   // unit vector, 0.5 qA r
+                const float rr = u.w * (2.0f / qA);
+                const float dx = u.x * rr, dy = u.y * rr, dz = u.z * rr;
                 vxx += x * dx; vyy += y * dy; vzz += z * dz;
                 vxy += x * dy; vxz += x * dz; vyz += y * dz;
             }
@@ -1200,6 +1209,14 @@ extern "C" int anihip_aev_table_pack(const anihip_aev_params *p, const float *Sh
         t[TAB_COSZ + k] = (float)cos((double)ShfZ[k]);
         t[TAB_SINZ + k] = (float)sin((double)ShfZ[k]);
     }
+    // pre-scaled copies (wave-uniform operands of the kernels stay in scalar registers)
+    const float qR = sqrtf(p->EtaR * LOG2E), qA = sqrtf(p->EtaA * LOG2E);
+    for (int k = 0; k < p->n_shf_r; ++k) t[TAB_SHFRQ + k] = qR * ShfR[k];
+    for (int k = 0; k < p->n_shf_a; ++k) t[TAB_SHFAQ + k] = qA * ShfA[k];
+    for (int k = 0; k < p->n_shf_z; ++k) {
+        t[TAB_COSZH + k] = 0.5f * t[TAB_COSZ + k];
+        t[TAB_SINZH + k] = 0.5f * t[TAB_SINZ + k];
+    }
     return 0;
 }
 
@@ -1217,6 +1234,8 @@ static int make_args(const anihip_aev_params *p, AevArgs *a)
     a->EtaR = p->EtaR; a->EtaA = p->EtaA; a->Zeta = p->Zeta;
     a->kR = -p->EtaR * LOG2E;
     a->kA = -p->EtaA * LOG2E;
+    a->qR = sqrtf(p->EtaR * LOG2E);
+    a->qA = sqrtf(p->EtaA * LOG2E);
     ANIHIP_REQUIRE(p->cutoff_kind == ANIHIP_CUTOFF_COSINE || p->cutoff_kind == ANIHIP_CUTOFF_SMOOTH,
                    "cutoff_kind must be ANIHIP_CUTOFF_COSINE or ANIHIP_CUTOFF_SMOOTH");
     a->smooth = p->cutoff_kind == ANIHIP_CUTOFF_SMOOTH;

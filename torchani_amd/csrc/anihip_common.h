@@ -17,6 +17,7 @@ constexpr uint32_t SP_PAD = 7u;             // species code of a padding atom in
 
 // offsets into the constant table (anihip_aev_table_pack)
 constexpr int TAB_SHFR = 0, TAB_SHFA = 32, TAB_COSZ = 48, TAB_SINZ = 64;
+constexpr int TAB_SHFRQ = 80, TAB_SHFAQ = 96, TAB_COSZH = 112, TAB_SINZH = 128;   // pre-scaled copies
 
 void set_error(const char *fmt, ...);
 
