@@ -5,7 +5,7 @@
 Workload (BASELINE.json north_star / configs[3]): 8-member ANI-2x ensemble on a 2.3 M-atom periodic water
 box (0.1 atoms/A^3), energies + forces.  It fits one MI355X, so N=1 runs the whole box and N>1 shards
 the SAME box over the ranks (strong scaling): central atoms split contiguously, coordinates replicated,
-one fp64 energy all-reduce + one fp32 force all-reduce over RCCL.  Weights are seeded random parameters
+ONE fp32 all-reduce per step over RCCL (forces + the fp64 energies as exactly-summable fp32 parts).  Weights are seeded random parameters
 of the ANI-2x architecture (the published ones are a download), data is synthetic.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
@@ -112,8 +112,8 @@ def cpu_baseline(n_side: int, seed: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--waters-side", type=int, default=92, help="waters per box edge (92 -> 2,336,064 atoms)")
     ap.add_argument("--cpu-side", type=int, default=36, help="waters per edge of the CPU-baseline sub-box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,13 +171,18 @@ def main():
         torch.distributed.barrier(group)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
+    for k in range(args.steps):
         out = step()
+        marks[k + 1].record()
     torch.cuda.synchronize()
     if group is not None:
         torch.distributed.barrier(group)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if group is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
@@ -207,7 +212,7 @@ def main():
             lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev,
                                             chunk=model.mlp_chunk, shard_rows=True), 2)
     gc = torch.zeros((n_atoms, 3), dtype=torch.float32, device=dev)
-    st["aev_backward"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc, shard_rows=True), reps)
+    st["aev_backward"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc, shard_rows=True, slab_mask=mask), reps)
     meta = nbrs.meta[lo:hi, 1].to(torch.int64) & 0xFFFFFFFF
     n_a = float((meta & 0xFFFF).double().mean())
     n_r = n_a + float((meta >> 16).double().mean())
@@ -215,15 +220,20 @@ def main():
     # algorithmic bytes per atom of the fused AEV forward: angular 3584 + 20 n_a + 8, radial 448 + 8 n_r
     bytes_per_atom = 3584 + 20 * n_a + 8 + 448 + 8 * n_r
     aev_gbs = bytes_per_atom * n_shard / (st["aev_forward"] * 1e-3) / 1e9
+    # backward: read dE/dAEV 3584 + 448, the row 20 n_a + 8 n_r, write 12 (own force) + 12 n_r (pushes)
+    bytes_per_atom_bwd = 3584 + 448 + 20 * n_a + 8 * n_r + 12 + 12 * n_r
+    bwd_gbs = bytes_per_atom_bwd * n_shard / (st["aev_backward"] * 1e-3) / 1e9
     # HBM traffic of the AEV forward kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB per
     # dispatch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) measured on a smaller box of
     # the same density and committed under profiles/; scaled by the atom count of this launch
-    aev_traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_aev_fwd.json")
+    aev_traffic = bwd_traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_aev.json")
     if os.path.exists(pmc_file):
         with open(pmc_file) as fh:
             pm = json.load(fh)
-        aev_traffic = (pm["fetch_size_kb"] * pm["fetch_correction"] + pm["write_size_kb"]) * 1024.0 / pm["n_atoms"] * n_shard
+        per_atom = {k: (v["fetch_size_kb"] * pm["fetch_correction"] + v["write_size_kb"]) * 1024.0 / pm["n_atoms"]
+                    for k, v in pm["kernels"].items()}
+        aev_traffic, bwd_traffic = per_atom["k_aev_fwd2"] * n_shard, per_atom["k_aev_bwd"] * n_shard
     # layer 0 multiplies only the 32-column AEV slabs flagged for an atom (absent neighbor species give
     # identically-zero blocks): executed flops = dense flops with the AEV length replaced by the staged columns
     pop = mask[lo:hi].to(torch.int64) & 0xFFFFFFFF
@@ -248,14 +258,21 @@ def main():
             "workload": f"ANI-2x 8-member ensemble, {n_atoms}-atom periodic water box (0.1 atoms/A^3), "
                         "energy+forces, seeded random weights",
             "n_atoms": n_atoms, "box_A": float(cell_np[0, 0]),
-            "sharding": "central atoms split contiguously over ranks; coords replicated; "
-                        "all-reduce of energy (fp64) and forces (fp32)",
+            "sharding": "central atoms split contiguously over ranks; coords replicated; ONE fp32 all-reduce per "
+                        "step carrying the forces and the fp64 energies as exactly-summable fp32 parts",
         },
+        "ms_per_step_median": median_ms,
         "roofline": {
-            "kernel": "k_aev_fwd<8,4> (fused radial+angular AEV forward)", "bound": "hbm",
+            "kernel": "k_aev_fwd2<8,4> (fused radial+angular AEV forward)", "bound": "hbm",
             "achieved": aev_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": aev_gbs / HBM_PEAK_GBS,
             "traffic": aev_traffic, "algorithmic_bytes_per_atom": bytes_per_atom,
             "mean_radial_neighbors": n_r, "mean_angular_neighbors": n_a, "avg_launch_ms": st["aev_forward"],
+        },
+        "roofline_bwd": {
+            "kernel": "k_aev_bwd<8,4> (analytic AEV backward: radial by symmetric gather, angular pair loop)",
+            "bound": "hbm", "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_gbs / HBM_PEAK_GBS,
+            "traffic": bwd_traffic, "algorithmic_bytes_per_atom": bytes_per_atom_bwd,
+            "avg_launch_ms": st["aev_backward"],
         },
         "roofline_mfma": {
             "kernel": "ensemble fwd + input-gradient bwd: k_mlp_fused (layer 0 over flagged AEV slabs + hidden "
@@ -272,9 +289,24 @@ def main():
         },
         "stages_ms": st,
     }
+    if group is not None:
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, st, group=group)
+        lc = model.last_collective
+        backend = torch.distributed.get_backend(group)
+        res["stages_ms_per_rank"] = per_rank
+        res["collective"] = {
+            "collectives_per_step": lc["collectives_per_step"], "world_size": lc["world_size"],
+            "bytes_per_step": lc["bytes"], "op": "all_reduce(sum, fp32)", "backend": backend,
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+        }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_side, seed=5)
+            ref_file = os.path.join(ROOT, "profiles", "ref_cpu_baseline.json")
+            if os.path.exists(ref_file):   # the reference itself (torchani.grad.energies_and_forces), recorded by
+                with open(ref_file) as fh:   # tools/ref_cpu_baseline.py in the build container (it cannot travel)
+                    res["cpu_baseline_reference"] = json.load(fh)
         print(json.dumps(res))
     if group is not None:
         torch.distributed.barrier(group)

@@ -249,6 +249,14 @@ typedef struct {
  *           row limits of this library (2 * C(128,2) = 16256). */
 #define ANIHIP_MLP_FP32 0
 #define ANIHIP_MLP_F16X3 1
+/* anihip_mlp_desc.flags: algorithm choices of anihip_mlp_forward_backward that the library otherwise makes from the
+ * problem size (tests and benchmarks pin them; results agree to rounding whatever is chosen) */
+#define ANIHIP_MLP_FLAG_NO_FUSED 1u       /* layer-by-layer GEMMs instead of the fused network kernel */
+#define ANIHIP_MLP_FLAG_BIG_TILES 2u      /* 256 x 256 layer-0 tiles (default from 16384 atoms) even for few atoms */
+#define ANIHIP_MLP_FLAG_SMALL_TILES 4u    /* 128 x 128 layer-0 tiles whatever the size */
+#define ANIHIP_MLP_FLAG_NO_SLAB_MASK 8u   /* ignore slab_mask: multiply every AEV slab */
+#define ANIHIP_MLP_FLAG_FUSED_ROWS32 16u  /* fused kernel: 32-atom tiles, two workgroups per CU (default 64 / one) */
+#define ANIHIP_MLP_FLAG_D0_ROWS 32u       /* d E/d act0 handed to the layer-0 backward row-major, not tile-major */
 typedef struct {
     int32_t num_species;
     int32_t n_members;
@@ -256,6 +264,7 @@ typedef struct {
     float celu_alpha;
     int32_t precision; /* ANIHIP_MLP_FP32 or ANIHIP_MLP_F16X3 */
     int32_t aev_radial_len; /* R of the slab order of wh[0] / wth[0] (0 = plain order) */
+    int32_t flags;          /* ANIHIP_MLP_FLAG_* (0 = let the library choose); the library reads no environment */
     anihip_species_net net[ANIHIP_MAX_SPECIES];
 } anihip_mlp_desc;
 

@@ -38,8 +38,8 @@ def test_struct_layouts_match_header(lib):
 
     assert ctypes.sizeof(_lib.AevParams) == 10 * 4
     assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 5 * 4 * 8 + 4 * 4 + 2 * 4 * 8 + 8
-    assert ctypes.sizeof(_lib.MlpDesc) == 6 * 4 + 8 * ctypes.sizeof(_lib.SpeciesNet)
-    assert _lib.MlpDesc.net.offset == 24
+    assert ctypes.sizeof(_lib.MlpDesc) == 8 * 4 + 8 * ctypes.sizeof(_lib.SpeciesNet)   # 7 ints + padding
+    assert _lib.MlpDesc.flags.offset == 24 and _lib.MlpDesc.net.offset == 32
     d = _lib.MlpDesc()
     d.num_species, d.n_members, d.aev_len, d.celu_alpha = 2, 8, 1008, 0.1
     for s in range(2):

@@ -1,0 +1,197 @@
+"""The N > 1 PRODUCT path on one GPU: two ranks (gloo backend, both on cuda:0) call the real
+``model.energies_and_forces(group=...)`` / ``all_reduce_gradients`` / ``bench.py --gpus 2`` and must reproduce the
+single-rank results.  (The reference has no multi-device code; the decomposition is
+torchani_amd/parallel.py.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F_TOL = 1e-4
+E_ATOM_TOL = 1e-5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from torchani_amd.parallel import init_from_env
+
+    r, w, _, group = init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and group is not None
+    return group
+
+
+def _worker_ef(rank, world, port, q):
+    try:
+        group = _setup(rank, world, port)
+        import torch.distributed as dist
+        from _util import load_golden, load_stress, seeded_state
+        from bench import water_box
+        from torchani_amd.models import ANI2x
+
+        dev = torch.device("cuda", 0)
+        out = {}
+        # (a) golden periodic water fixture, batch-mode neighbor rows, with the virial
+        g = load_golden("water_pbc_ani2x")
+        model = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False)
+        sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+        x = torch.from_numpy(g["coords"]).to(dev)
+        cell = torch.from_numpy(g["cell"]).to(dev)
+        pbc = tuple(bool(b) for b in g["pbc"])
+        single = model.energies_and_forces(sp, x, cell, pbc, stress=True)
+        shard = model.energies_and_forces(sp, x, cell, pbc, group=group, stress=True)
+        assert model.last_collective["collectives_per_step"] == 1 and model.last_collective["world_size"] == world
+        out["golden_dE"] = float((shard.energies - single.energies).abs().max())
+        out["golden_dF"] = float((shard.forces - single.forces).abs().max())
+        out["golden_dW"] = float((shard.virial - single.virial).abs().max())
+        out["golden_F_vs_ref"] = float(np.abs(shard.forces.cpu().numpy() - g["forces"]).max())
+        out["golden_E_vs_ref"] = float(np.abs(shard.energies.cpu().numpy() - g["energies"]).max())
+        out["golden_W_vs_ref"] = float(np.abs(shard.virial.cpu().numpy() - load_stress("water_pbc_ani2x")["virial"]).max())
+        # (b) a 3000-atom water box through the cell list: atoms of a shard push onto atoms of the other one
+        sp_np, x_np, cell_np = water_box(10)
+        model2 = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="cell")
+        sp2, x2, cell2 = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+        s1 = model2.energies_and_forces(sp2, x2, cell2, (True, True, True), stress=True)
+        s2 = model2.energies_and_forces(sp2, x2, cell2, (True, True, True), group=group, stress=True)
+        out["box_dE"] = float((s2.energies - s1.energies).abs().max())
+        out["box_dF"] = float((s2.forces - s1.forces).abs().max())
+        out["box_dW"] = float((s2.virial - s1.virial).abs().max())
+        out["box_bytes"] = model2.last_collective["bytes"]
+        # every rank holds the same reduced result
+        chk = torch.stack([s2.energies.sum(), s2.forces.double().abs().sum(), s2.virial.sum()]).cpu()
+        both = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(both, chk, group=group)
+        out["rank_spread"] = float((both[0] - both[1]).abs().max())
+        # (c) batch of molecules that do not straddle ranks: only the 16-byte-per-molecule energy tail is reduced
+        gb = load_golden("rand_batch_ani2x")
+        modelb = ANI2x(state_dict=seeded_state("ani2x", 8, gb["seed"]), device=dev, periodic_table_index=False)
+        spb = torch.from_numpy(gb["species"].astype(np.int64)).to(dev)
+        xb = torch.from_numpy(gb["coords"]).to(dev)
+        assert spb.shape[0] % world == 0
+        b1 = modelb.energies_and_forces(spb, xb)
+        b2 = modelb.energies_and_forces(spb, xb, group=group, reduce_forces=False)
+        lo, hi = rank * spb.shape[0] // world, (rank + 1) * spb.shape[0] // world
+        out["batch_dE"] = float((b2.energies - b1.energies).abs().max())
+        out["batch_dF_own"] = float((b2.forces[lo:hi] - b1.forces[lo:hi]).abs().max())
+        out["batch_bytes"] = modelb.last_collective["bytes"]
+        out["batch_C"] = int(spb.shape[0])
+        torch.cuda.synchronize()
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:   # surface the failure in the parent instead of a queue timeout
+        import traceback
+
+        q.put((rank, {"error": repr(e) + "\n" + traceback.format_exc()}))
+
+
+def _run(worker, world=2, timeout=600):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=timeout) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert "error" not in res[r], res[r]["error"]
+    return res
+
+
+def test_two_ranks_energies_forces_virial_match_single_rank():
+    res = _run(_worker_ef)
+    for r, o in res.items():
+        # sharded == unsharded to fp32 round-off (float atomics reorder the sums), energies exactly summed
+        assert o["golden_dE"] < 1e-9 and o["box_dE"] < 1e-7, o
+        assert o["golden_dF"] < 2e-6 and o["box_dF"] < 2e-6, o
+        assert o["golden_dW"] < 1e-6 and o["box_dW"] < 1e-5, o
+        # and equal to the reference fixture
+        assert o["golden_F_vs_ref"] < F_TOL and o["golden_E_vs_ref"] < E_ATOM_TOL * 10 and o["golden_W_vs_ref"] < 1e-5, o
+        assert o["rank_spread"] == 0.0, o
+        assert o["box_bytes"] == 4 * (3 * 3000 + 4 + 36), o      # forces + energy parts + virial parts, one buffer
+        assert o["batch_dE"] < 1e-9 and o["batch_dF_own"] < 2e-6, o
+        assert o["batch_bytes"] == 16 * o["batch_C"], o
+
+
+def _worker_grads(rank, world, port, q):
+    try:
+        group = _setup(rank, world, port)
+        import torch.distributed as dist
+        from _util import load_golden, seeded_state
+        from torchani_amd.models import ANI2x
+        from torchani_amd.parallel import all_reduce_gradients
+
+        dev = torch.device("cuda", 0)
+        g = load_golden("rand_batch_ani2x")
+        sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+        x = torch.from_numpy(g["coords"]).to(dev)
+        C = sp.shape[0]
+        target = torch.linspace(-1.0, 1.0, C, dtype=torch.float32, device=dev)
+
+        def grads(lo, hi, reduce):
+            model = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False)
+            model.neural_networks.requires_grad_(True)
+            model.set_enabled("energy_shifter", False)
+            e = model((sp[lo:hi], x[lo:hi])).energies
+            loss = ((e.float() - target[lo:hi]) ** 2).sum()
+            loss.backward()
+            params = [p for p in model.neural_networks.parameters()]
+            if reduce:
+                all_reduce_gradients(params, group=group)
+            return torch.cat([p.grad.reshape(-1) for p in params])
+
+        full = grads(0, C, False)
+        lo, hi = rank * C // world, (rank + 1) * C // world
+        part = grads(lo, hi, True)
+        scale = float(full.abs().max())
+        q.put((rank, {"err": float((part - full).abs().max()), "scale": scale}))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+
+        q.put((rank, {"error": repr(e) + "\n" + traceback.format_exc()}))
+
+
+def test_two_ranks_all_reduce_gradients_equals_full_batch():
+    res = _run(_worker_grads)
+    for r, o in res.items():
+        assert o["scale"] > 0 and o["err"] < 2e-5 * o["scale"], o
+
+
+def test_bench_two_ranks_gloo():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run), ranks sharing the GPU over gloo."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--waters-side", "16", "--dist-backend", "gloo", "--no-dense-stage"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["steps"] == 2
+    coll = r["collective"]
+    assert coll["collectives_per_step"] == 1 and coll["world_size"] == 2
+    assert coll["bytes_per_step"] == 4 * (3 * r["config"]["n_atoms"] + 4)
+    assert len(r["stages_ms_per_rank"]) == 2 and all("aev_forward" in s for s in r["stages_ms_per_rank"])

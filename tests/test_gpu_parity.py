@@ -12,6 +12,8 @@ import pytest
 import torch
 
 from _util import GOLDEN_NAMES, load_golden, oracle_networks, oracle_params, seeded_state
+from torchani_amd import _lib
+from torchani_amd.engine import PackedNetworks
 
 pytestmark = pytest.mark.gpu
 
@@ -286,11 +288,11 @@ def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     ae, ga, me = oracle64.mlp(g["species"], aev, dims, flat, n_members=8, want_members=True)
     model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"])
     if precision == "f16x3-unfused":  # layer-by-layer f16x3 GEMMs instead of the fused network kernel
-        monkeypatch.setenv("ANIHIP_NO_FUSED_HIDDEN", "1")
+        monkeypatch.setattr(PackedNetworks, "default_flags", _lib.MLP_FLAG_NO_FUSED)
     if precision == "f16x3-rows32":  # the 32-atom / two-workgroups-per-CU tiling of the fused kernel
-        monkeypatch.setenv("ANIHIP_FUSED_ROWS", "32")
+        monkeypatch.setattr(PackedNetworks, "default_flags", _lib.MLP_FLAG_FUSED_ROWS32)
     if precision == "f16x3-bigtile":  # force the 256x256-tile layer-0 GEMM that large systems use
-        monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
+        monkeypatch.setattr(PackedNetworks, "default_flags", _lib.MLP_FLAG_BIG_TILES)
     model.neural_networks.mlp_precision = precision.split("-")[0]
     sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
     a32 = torch.from_numpy(aev.astype(np.float32)).to(dev).requires_grad_(True)
@@ -339,7 +341,7 @@ def test_energies_and_forces_fused(dev, name):
 def test_energies_and_forces_slab_masks(dev, name, monkeypatch):
     """The large-system configuration of the fused path on the golden cases: 256x256-tile layer-0 GEMMs
     that skip the AEV slabs of absent neighbor species (per-atom slab masks from the AEV kernel)."""
-    monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
+    monkeypatch.setattr(PackedNetworks, "default_flags", _lib.MLP_FLAG_BIG_TILES)
     g = load_golden(name)
     sp, x, cell, pbc = to_dev(g, dev)
     model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"], neighborlist=modes_for(g)[-1], row_capacity=256)
@@ -358,7 +360,7 @@ def test_slab_masks_flag_exactly_the_nonzero_blocks(dev, name, monkeypatch):
     layer-0 GEMMs give the same energies, and the same gradients inside the flagged slabs."""
     from torchani_amd.weights import arch_spec
 
-    monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
+    monkeypatch.setattr(PackedNetworks, "default_flags", _lib.MLP_FLAG_BIG_TILES)
     g = load_golden(name)
     sp, x, cell, pbc = to_dev(g, dev)
     model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"])
@@ -409,7 +411,7 @@ def test_shards_add_up_to_the_whole(dev, name, world, monkeypatch):
     """The multi-GPU decomposition on one device: every rank's shard of the central atoms evaluated alone
     (what a rank does before the all-reduces of models.ANI.energies_and_forces); the partial energies and
     forces must add up to the golden result.  Run in the large-system configuration (slab masks)."""
-    monkeypatch.setenv("ANIHIP_GEMM_TILE", "2")
+    monkeypatch.setattr(PackedNetworks, "default_flags", _lib.MLP_FLAG_BIG_TILES)
     g = load_golden(name)
     sp, x, cell, pbc = to_dev(g, dev)
     model = get_model(g["kind"], g["seed"], dev, cutoff_fn=g["cutoff_fn"], neighborlist=modes_for(g)[-1], row_capacity=256)

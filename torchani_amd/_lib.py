@@ -27,6 +27,9 @@ MAX_RAD = 256
 TABLE_FLOATS = 144
 ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
 MLP_FP32, MLP_F16X3 = 0, 1
+# anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*)
+MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_FUSED_ROWS32, MLP_FLAG_D0_ROWS = \
+    1, 2, 4, 8, 16, 32
 ABI_VERSION = 5
 
 
@@ -79,6 +82,7 @@ class MlpDesc(C.Structure):
         ("celu_alpha", C.c_float),
         ("precision", C.c_int32),
         ("aev_radial_len", C.c_int32),
+        ("flags", C.c_int32),
         ("net", SpeciesNet * MAX_SPECIES),
     ]
 

@@ -967,8 +967,18 @@ struct FusedArgs {
     int tiles_total;           // upper bound of the number of tiles (work items = tiles_total * M)
     float alpha, inv_alpha;
     int want_grad;
-    unsigned long long *trace;   // development aid (env ANIHIP_FUSED_TRACE): [workgroup][16] s_memtime stamps
+    unsigned long long *trace;   // development builds (-DANIHIP_DEV_TRACE, tools/fused_trace.py): [workgroup][16] stamps
 };
+// phase stamps of the fused kernel: compiled out of the shipped library
+#ifdef ANIHIP_DEV_TRACE
+#define ANIHIP_STAMP(ptr, slot)                                              \
+    do {                                                                     \
+        unsigned long long *p_ = (ptr);                                      \
+        if (p_ && tid == 0) p_[slot] = __builtin_readcyclecounter();         \
+    } while (0)
+#else
+#define ANIHIP_STAMP(ptr, slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ float pow2_scale_for(float mx)
 {
@@ -1193,12 +1203,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         }
     };
 
+#ifdef ANIHIP_DEV_TRACE
     if (g.trace && tid == 0) {
         g.trace[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter();
         // placement: HW_REG_HW_ID (cu / sh / se) and HW_REG_XCC_ID, for co-residency analysis
         g.trace[(size_t)blockIdx.x * 16 + 14] = 1 + (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
                                                      ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
     }
+#endif
     // ---- this workgroup's item (member-major order: at any time the chip works on one or two members,
     // whose weights stay resident in every XCD's L2): tile entry and atom rows are independent loads ----
     const int item = blockIdx.x;
@@ -1207,7 +1219,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     const int my_atom = g.tile_rows[(size_t)tile_id * ROWS + srow];
     if (te.x < 0) return;   // (at most num_species empty tiles per member)
     const uint32_t tmask = (uint32_t)te.w;
-    if (g.trace && tid == 0) g.trace[(size_t)blockIdx.x * 16 + 1] = __builtin_readcyclecounter();
+    ANIHIP_STAMP(g.trace ? g.trace + (size_t)blockIdx.x * 16 : nullptr, 1);
     v4f va[FR_GROUP], vb[FR_GROUP];
     arow = g.aev + (int64_t)my_atom * g.L + spc * 4;
     rem_a = tmask;
@@ -1232,7 +1244,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const int n1 = nblk(H1), n2 = nblk(H2), n3 = nblk(H3);
         // accumulator element (rb, nb, r) of this lane <-> tile row rb*32 + fr, column col0(nb) + 8 (r >> 2) + (r & 3)
         auto col0 = [&](int nb) { return (wave + NW * nb) * 32 + 4 * fk; };
+#ifdef ANIHIP_DEV_TRACE
         unsigned long long *trace = g.trace ? g.trace + (size_t)item * 16 : nullptr;
+#endif
 
         f32x16 acc[NE];
         auto zero_acc = [&]() {
@@ -1312,7 +1326,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         store_group(va, slot(0));
         store_group(vb, slot(1));
         __syncthreads();   // slots 0 / 1 published
-        if (trace && tid == 0) trace[2] = __builtin_readcyclecounter();
+        ANIHIP_STAMP(trace, 2);
         // six slabs (two staging slots, 12 k steps) per barrier; the next six are fetched into registers
         // before the MFMAs of the current ones and staged after them
         for (int pr = 0; pr < npair; ++pr) {
@@ -1335,7 +1349,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 __syncthreads();
             }
         }
-        if (trace && tid == 0) trace[3] = __builtin_readcyclecounter();
+        ANIHIP_STAMP(trace, 3);
         // weights of phase 1 start streaming during the layer-0 epilogue
         Ring r1;
         FR_BLOCKS(n2, (fr_ring<NB, NBA, D>(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave, NW)))
@@ -1391,14 +1405,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const float s2 = pow2_scale_for(bnd[2]);                                  // |d act2| <= max |w3| / M
         const float s3 = pow2_scale_for(bnd[3]);                                  // |d act1| <= [2] ||W2||_1
         __syncthreads();
-        if (trace && tid == 0) trace[4] = __builtin_readcyclecounter();
+        ANIHIP_STAMP(trace, 4);
 
         // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
         float bias1[NB][16];   // (per-column parameters travel during the GEMM)
         if (!C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, n2);
         zero_acc();
         FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X0, ld0, x0_plane, r1, H1 >> 4)))
-        if (trace && tid == 0) trace[5] = __builtin_readcyclecounter();
+        ANIHIP_STAMP(trace, 5);
         Ring r2;
         FR_BLOCKS(n3, (fr_ring<NB, NBA, D>(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW)))
         float d1f[NE][16];   // celu'(act1) of this lane's elements
@@ -1421,7 +1435,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             put_acc(X1, x1_plane, ld1, s1, n2);
         }
         __syncthreads();  // X1 complete; every wave is done reading X0 -> XU reusable
-        if (trace && tid == 0) trace[6] = __builtin_readcyclecounter();
+        ANIHIP_STAMP(trace, 6);
 
         // =============== phase 2: act2 = celu(act1 x W2^T + b2); output layer; backward seed ===============
         float bias2[NB][16], w3[NB][16];
@@ -1431,7 +1445,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         }
         zero_acc();
         FR_BLOCKS(n3, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r2, H2 >> 4)))
-        if (trace && tid == 0) trace[7] = __builtin_readcyclecounter();
+        ANIHIP_STAMP(trace, 7);
         Ring r3;
         if (g.want_grad) {
             FR_BLOCKS(n2, (fr_ring<NB, NBA, D>(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave, NW)))
@@ -1473,14 +1487,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             for (int w8 = 0; w8 < NW; ++w8) e += s_e[w8 * ROWS + tid];
             g.member_part[(int64_t)(p0 + tid) * g.M + m] = e;
         }
-        if (trace && tid == 0) trace[9] = __builtin_readcyclecounter();
+        ANIHIP_STAMP(trace, 9);
 
         Ring r4;
         if (g.want_grad) {
             // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
             zero_acc();
             FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X2, ld2, x2_plane, r3, H3 >> 4)))
-            if (trace && tid == 0) trace[10] = __builtin_readcyclecounter();
+            ANIHIP_STAMP(trace, 10);
             FR_BLOCKS(n1, (fr_ring<NB, NBA, D>(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW)))
             if (n2 > 0) {
                 const float osc3 = fs.is2 / s2;
@@ -1515,12 +1529,12 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             }
         }
         __syncthreads();
-        if (trace && tid == 0) trace[11] = __builtin_readcyclecounter();
+        ANIHIP_STAMP(trace, 11);
         // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
         if (g.want_grad && n1 > 0) {
             zero_acc();
             FR_BLOCKS(n1, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r4, H2 >> 4)))
-            if (trace && tid == 0) trace[12] = __builtin_readcyclecounter();
+            ANIHIP_STAMP(trace, 12);
             const float osc4 = fs.is1 / s3;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -1544,7 +1558,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 }
             }
         }
-        if (trace && tid == 0) trace[13] = __builtin_readcyclecounter();
+        ANIHIP_STAMP(trace, 13);
     }
 }
 #undef FR_BLOCKS
@@ -2119,14 +2133,15 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         fused = fused && nn.whf[0] && nn.whf[1] && nn.whf[2] && nn.wthf[1] && nn.wthf[2] && nn.fused_bounds &&
                 fused_dims_supported(nn.dims[1], nn.dims[2], nn.dims[3]);
     }
-    if (const char *e = getenv("ANIHIP_NO_FUSED_HIDDEN")) fused = fused && e[0] == '0';
+    if (d->flags & ANIHIP_MLP_FLAG_NO_FUSED) fused = false;
     // 256 x 256 tiles for the layer-0 GEMMs once there are enough rows to fill the chip with them
     int d0_tm = 0;
     bool big_tiles = h3 && n >= 16384;
-    if (const char *e = getenv("ANIHIP_GEMM_TILE")) big_tiles = h3 && e[0] == '2';
+    if (d->flags & ANIHIP_MLP_FLAG_BIG_TILES) big_tiles = h3;
+    if (d->flags & ANIHIP_MLP_FLAG_SMALL_TILES) big_tiles = false;
     // per-atom slab flags: honoured by the 256 x 256 kernels on slab-ordered planes
     const uint32_t *smask = (big_tiles && kp_rad > 0 && K0p <= 32 * 32) ? slab_mask : nullptr;
-    if (const char *e = getenv("ANIHIP_NO_SLAB_MASK")) smask = e[0] == '0' ? smask : nullptr;
+    if (d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK) smask = nullptr;
 
     // 2. forward through the hidden layers
     for (int l = 0; l < (fused ? 0 : nh); ++l) {
@@ -2178,9 +2193,8 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         FusedArgs f{};
         size_t lds = 0;
         // tiling: 64 atoms x 8 waves, one workgroup per CU (default: 3 % faster on the water box), or
-        // 32 atoms x 4 waves, two per CU (ANIHIP_FUSED_ROWS=32)
-        int rows = 64;
-        if (const char *e = getenv("ANIHIP_FUSED_ROWS")) rows = atoi(e) == 32 ? 32 : 64;
+        // 32 atoms x 4 waves, two per CU (ANIHIP_MLP_FLAG_FUSED_ROWS32)
+        const int rows = (d->flags & ANIHIP_MLP_FLAG_FUSED_ROWS32) ? 32 : 64;
         for (int s = 0; s < S; ++s) {
             const anihip_species_net &nn = d->net[s];
             FusedSpecies &fs = f.sp[s];
@@ -2200,11 +2214,11 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         }
         f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = K0p / 32;
         f.slab_mask = kp_rad > 0 ? slab_mask : nullptr;
-        if (const char *e = getenv("ANIHIP_NO_SLAB_MASK")) f.slab_mask = e[0] == '0' ? f.slab_mask : nullptr;
+        if (d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK) f.slab_mask = nullptr;
         f.d0 = w.act[0]; f.ld0 = w.ld[0]; f.perm = w.perm;
         // tile-major hand-over to the 256 x 256 layer-0 backward GEMM (the 128 x 128 kernel of small inputs reads rows)
         f.d0_tm = (big_tiles && grad_aev) ? 1 : 0;
-        if (const char *e = getenv("ANIHIP_D0_ROWS")) f.d0_tm = e[0] == '0' ? f.d0_tm : 0;
+        if (d->flags & ANIHIP_MLP_FLAG_D0_ROWS) f.d0_tm = 0;
         d0_tm = f.d0_tm;
         f.tile_tab = w.tile_tab; f.tile_rows = w.tile_rows;
         f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
@@ -2217,16 +2231,19 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         hipLaunchKernelGGL(k_tile_table, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, w.ctl, S, w.perm,
                            f.slab_mask, f.n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << f.n_slabs) - 1u), (int)tiles,
                            rows, w.tile_tab, w.tile_rows);
-        const char *trace_path = getenv("ANIHIP_FUSED_TRACE");   // development aid: per-item phase stamps
+#ifdef ANIHIP_DEV_TRACE   // development builds only (tools/fused_trace.py): per-item phase stamps, allocates and synchronises
+        const char *trace_path = getenv("ANIHIP_FUSED_TRACE");
         const size_t trace_words = (size_t)16 * grid;
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipMalloc((void **)&f.trace, sizeof(unsigned long long) * trace_words));
             ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * trace_words));
         }
+#endif
         if (rows == 64)
             hipLaunchKernelGGL((k_mlp_fused<2, 1>), dim3((unsigned)grid), dim3(512), lds, stream, f);
         else
             hipLaunchKernelGGL((k_mlp_fused<1, 2>), dim3((unsigned)grid), dim3(256), lds, stream, f);
+#ifdef ANIHIP_DEV_TRACE
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipStreamSynchronize(stream));
             std::vector<unsigned long long> host(trace_words);
@@ -2237,6 +2254,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                 fclose(fp);
             }
         }
+#endif
         int64_t fb = (n + 255) / 256;
         if (fb > 2048) fb = 2048;
         hipLaunchKernelGGL(k_fused_finish, dim3((unsigned)fb), dim3(256), 0, stream, w.ctl, S, M, w.perm,

@@ -348,6 +348,11 @@ class PackedNetworks:
     """Ensemble parameters in the MFMA-friendly layout of include/anihip.h (members concatenated, widths
     padded to 32, transposed copies for the backward GEMMs); cf. BmmAtomicNetwork, nn/_infer.py:141-161."""
 
+    # anihip_mlp_desc.flags (_lib.MLP_FLAG_*) of forward_backward: ``flags`` of an instance, else this class default
+    # (0 = the library chooses from the problem size).  The library itself reads no environment variables.
+    default_flags: int = 0
+    flags: tp.Optional[int] = None
+
     def __init__(self, weights: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]],
                  biases: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]], aev_len: int, celu_alpha: float,
                  device: torch.device, precision: str = "f16x3", radial_len: tp.Optional[int] = None) -> None:
@@ -521,6 +526,7 @@ class PackedNetworks:
         for c0 in range(lo, hi, step):
             c1 = min(hi, c0 + step)
             ws = self.workspace(c1 - c0)
+            self.desc.flags = PackedNetworks.default_flags if self.flags is None else self.flags
             _lib.check(L.anihip_mlp_forward_backward(
                 _stream(), C.byref(self.desc), n, c0, c1, _ptr(species), _row_ptr(aev, rows0, self.aev_len),
                 _ptr(slab_mask), _ptr(ws), ws.numel(), _ptr(atomic_e),

@@ -23,7 +23,7 @@ from .aev import AEVComputer
 from .constants import GSAES_WB97X_631GD
 from .engine import energy_reduce
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
-from .parallel import shard_range
+from .parallel import join_exact, shard_range, split_exact
 from .tuples import AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
 from .weights import arch_spec, random_state_dict
 
@@ -52,6 +52,7 @@ class ANI(torch.nn.Module):
         self.register_buffer("atomic_numbers", self.species_converter.atomic_numbers.clone())
         self.cutoff = aev_computer.radial.cutoff
         self.mlp_chunk = 1 << 18
+        self.last_collective: tp.Optional[dict] = None   # what the last sharded energies_and_forces all-reduced
 
     # arch.py:263-275 convenience accessors
     @property
@@ -137,18 +138,31 @@ class ANI(torch.nn.Module):
                                                         chunk=self.mlp_chunk, slab_mask=slab_mask,
                                                         shard_rows=True)
         virial = torch.empty((3, 3), dtype=torch.float64, device=c32.device) if stress else None
-        grad_coords = eng.backward(species32, nbrs, grad_aev, shard_rows=True, virial=virial, slab_mask=slab_mask)
+        world = 1 if group is None else torch.distributed.get_world_size(group)
+        # forces are accumulated straight into the buffer that a sharded run all-reduces: [3 n forces | 4 C energy
+        # parts | 36 virial parts]
+        n_tail = (4 * C + (36 if stress else 0)) if world > 1 else 0
+        red = torch.zeros(3 * n + n_tail, dtype=torch.float32, device=c32.device)
+        grad_coords = eng.backward(species32, nbrs, grad_aev, grad_coords=red[:3 * n].view(n, 3), shard_rows=True,
+                                   virial=virial, slab_mask=slab_mask)
         sae = None
         if self.energy_shifter._enabled:
             sae = self.energy_shifter.self_energies.to(device=c32.device, dtype=torch.float64)
         energies = energy_reduce(species32, atomic_e, sae, lo, hi)
         forces = grad_coords.neg_().view(C, A, 3)
-        if group is not None and torch.distributed.get_world_size(group) > 1:
-            torch.distributed.all_reduce(energies, group=group)
-            if virial is not None:
-                torch.distributed.all_reduce(virial, group=group)
-            if reduce_forces:
-                torch.distributed.all_reduce(forces, group=group)
+        if world > 1:
+            # ONE collective per step: the fp64 partial energies (and virial) ride in the fp32 force buffer as four
+            # exactly-summable fp32 parts each (parallel.split_exact), so the sum over ranks is exact and independent
+            # of the reduction order
+            red[3 * n:3 * n + 4 * C] = split_exact(energies).reshape(-1)
+            if stress:
+                red[3 * n + 4 * C:] = split_exact(virial.reshape(-1)).reshape(-1)
+            torch.distributed.all_reduce(red if reduce_forces else red[3 * n:], group=group)
+            energies = join_exact(red[3 * n:3 * n + 4 * C].view(C, 4))
+            if stress:
+                virial = join_exact(red[3 * n + 4 * C:].view(9, 4)).view(3, 3)
+            self.last_collective = {"collectives_per_step": 1, "world_size": world,
+                                    "bytes": 4 * (red.numel() if reduce_forces else n_tail)}
         if check_overflow:
             nbrs.raise_on_overflow()
         aevc._last_neighbors = nbrs

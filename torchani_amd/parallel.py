@@ -5,11 +5,12 @@ The reference has no multi-device code at all; the decompos
     for batches of molecules this is a split over molecules, for one big periodic box a split over the
     atoms of the box; every rank keeps the full coordinate array (37 MB for 2.3 M atoms), so building the
     shard's neighbor rows needs no halo exchange;
-  * energies: each rank reduces its shard in fp64, one scalar-per-molecule all-reduce;
-  * forces: a central atom pushes gradient onto its neighbors, which may belong to other ranks, so a
-    shared system ends with one all-reduce of the [N,3] fp32 force array (27.6 MB at 2.3 M atoms; a few
-    hundred microseconds over xGMI against tens of milliseconds of compute).  Batches whose molecules do
-    not straddle ranks can skip it (reduce_forces=False) and keep only the energy all-reduce;
+  * ONE collective per step: a central atom pushes gradient onto its neighbors, which may belong to other ranks,
+    so a shared system ends with an all-reduce of the [N,3] fp32 force array (27.6 MB at 2.3 M atoms; a few
+    hundred microseconds over xGMI against milliseconds of compute), and the fp64 partial energies (and the
+    virial) ride in the SAME buffer as four exactly-summable fp32 parts each (split_exact / join_exact): the
+    sum over ranks is exact and does not depend on the reduction order.  Batches whose molecules do not
+    straddle ranks reduce only that 16-byte-per-molecule tail (reduce_forces=False);
   * training (BASELINE config 5): minibatches are split over molecules, every rank back-propagates its share with
     the engine's training pass and the weight gradients (13.7 M floats for ANI-2x x 8) are summed with ONE bucketed
     all-reduce of a flat buffer (all_reduce_gradients) -- 55 MB, per-link bound on xGMI like the force all-reduce.
@@ -43,6 +44,31 @@ def shard_range(n: int, group=None, rank: tp.Optional[int] = None, world: tp.Opt
         rank = torch.distributed.get_rank(group)
     b = shard_bounds(n, world)
     return b[rank], b[rank + 1]
+
+
+# An fp64 number x, |x| < 2^31, is written as four fp32 parts on fixed grids 2^12, 2^-8, 2^-28, 2^-48, each part an integer
+# multiple of its grid below 2^19 in magnitude: sums of up to 32 such parts stay below 2^24 grid units, i.e. fp32
+# addition of them is EXACT in any order, and the four sums give x to 2^-49 (1.8e-15) -- how fp64 scalars travel
+# through an fp32 all-reduce.
+_GRIDS = (12, -8, -28, -48)
+EXACT_MAX_WORLD = 32
+
+
+def split_exact(x: torch.Tensor) -> torch.Tensor:
+    """float64 [...] -> float32 [..., 4] exactly-summable parts (see above)."""
+    r = x.to(torch.float64)
+    parts = []
+    for k in _GRIDS:
+        g = 2.0 ** k
+        p = torch.round(r / g) * g
+        parts.append(p)
+        r = r - p
+    return torch.stack(parts, dim=-1).to(torch.float32)
+
+
+def join_exact(parts: torch.Tensor) -> torch.Tensor:
+    """float32 [..., 4] (summed over ranks) -> float64 [...]."""
+    return parts.to(torch.float64).sum(dim=-1)
 
 
 def init_from_env(backend: tp.Optional[str] = None):
