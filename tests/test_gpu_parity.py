@@ -261,7 +261,9 @@ def test_model_from_external_neighbors(dev, name):
     idx = torch.from_numpy(nb["indices"]).to(dev)
     diff = torch.from_numpy(nb["diff_vectors"]).to(dev)
     xx = x.clone().requires_grad_(True)
-    e = model.compute_from_neighbors(sp, xx, (idx, diff.norm(dim=-1), diff))
+    res = model.compute_from_neighbors(sp, xx, (idx, diff.norm(dim=-1), diff))
+    assert res.scalars is None   # EnergiesScalars like the reference (arch.py:353-381)
+    e = res.energies
     (gx,) = torch.autograd.grad(e.sum(), xx)
     assert np.abs(e.detach().double().cpu().numpy() - g["energies"]).max() < 2e-6 * np.abs(g["energies"]).max()
     assert np.abs(-gx.cpu().numpy() - g["forces"]).max() < F_TOL
@@ -272,7 +274,7 @@ def test_model_from_external_neighbors(dev, name):
     extra = torch.tensor([[0], [n - 1]], device=dev)
     far = torch.tensor([[40.0, 0.0, 0.0]], device=dev) - (flat[0] - flat[n - 1]).unsqueeze(0)
     idx2, shifts2 = torch.cat([idx, extra], 1), torch.cat([shifts, far], 0)
-    e2 = model.compute_from_external_neighbors(sp, x, idx2, shifts2)
+    e2 = model.compute_from_external_neighbors(sp, x, idx2, shifts2).energies
     assert torch.allclose(e2, e.detach(), rtol=0, atol=1e-5)
 
 
@@ -476,6 +478,47 @@ def test_hip_graph_replay(dev, name):
     # and back
     out3 = f(x, cell)
     assert np.abs(out3.forces.cpu().numpy() - g["forces"]).max() < F_TOL
+
+
+def test_hip_graph_owns_its_buffers(dev):
+    """A captured graph keeps replaying correctly after (a) a LARGER eager call on the same model (which used to free
+    and reallocate the networks' workspace under the graph) and (b) an in-place parameter update (the graph re-captures
+    with the new weight planes instead of silently using the old ones)."""
+    from torchani_amd.models import ANI2x
+
+    g = load_golden("rand_batch_ani2x")
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False)
+    f = model.graphed(sp, x)
+    ref = f(x).forces.clone()
+    packed = model.neural_networks._pack(dev)
+    ws_ptr = packed._ws.data_ptr()
+    assert packed.pinned == 1
+    # (a) a much larger eager evaluation: 40x the atoms
+    big_sp, big_x = sp.repeat(40, 1), x.repeat(40, 1, 1)
+    model.energies_and_forces(big_sp, big_x)
+    assert packed._ws.data_ptr() == ws_ptr          # the captured workspace was neither freed nor replaced
+    assert torch.equal(f(x).forces, ref) or torch.allclose(f(x).forces, ref, atol=2e-6)
+    # (b) in-place update of one layer
+    with torch.no_grad():
+        lin = next(model.neural_networks.parameters())
+        lin.mul_(1.01)
+    eager = model.energies_and_forces(sp, x)
+    out = f(x)
+    assert f.n_captures == 2
+    assert torch.allclose(out.energies, eager.energies, atol=1e-9) and torch.allclose(out.forces, eager.forces, atol=2e-6)
+    assert not torch.allclose(out.forces, ref, atol=1e-7)   # the update is visible
+
+
+def test_factories_are_loud_about_random_weights(dev):
+    """No state_dict and no seed -> a warning; a state dict that does not match the architecture -> an error
+    (never a silent fall-back to random parameters)."""
+    from torchani_amd.models import ANI2x
+
+    with pytest.warns(UserWarning, match="RANDOM parameters"):
+        ANI2x(device=dev, n_members=1)
+    with pytest.raises(RuntimeError, match="does not provide"):
+        ANI2x(device=dev, state_dict={"unrelated.weight": np.zeros(3, dtype=np.float32)})
 
 
 def test_api_details(dev):
@@ -695,9 +738,24 @@ def test_degenerate_inputs(dev, oracle64):
     rs = np.random.RandomState(0)
     dense = rs.uniform(0, 3.2, (1, 60, 3)).astype(np.float32)
     spd = torch.zeros((1, 60), dtype=torch.int64, device=dev)
-    small = get_model("ani2x", 11, dev, row_capacity=16)
+    from torchani_amd.models import ANI2x
+
+    small = ANI2x(state_dict=seeded_state("ani2x", 8, 11), device=dev, periodic_table_index=False, row_capacity=16)
+    big = get_model("ani2x", 11, dev, row_capacity=256)
+    with pytest.warns(UserWarning, match="retrying with 256"):   # checked by default: one retry at the largest capacity
+        o16 = small.energies_and_forces(spd, torch.from_numpy(dense).to(dev))
+    o256 = big.energies_and_forces(spd, torch.from_numpy(dense).to(dev))
+    assert small.aev_computer.row_capacity == 256 and torch.equal(o16.energies, o256.energies)
+    # ... and an error when even the largest rows cannot hold an atom's neighbors (here > 128 inside the angular cutoff)
+    blob = rs.uniform(0, 1.9, (1, 300, 3)).astype(np.float32)
+    spb = torch.zeros((1, 300), dtype=torch.int64, device=dev)
     with pytest.raises(RuntimeError, match="overflow"):
-        small.energies_and_forces(spd, torch.from_numpy(dense).to(dev), check_overflow=True)
+        big.energies_and_forces(spb, torch.from_numpy(blob).to(dev))
+    with pytest.raises(RuntimeError, match="overflow"):   # the autograd path checks too
+        big((spb, torch.from_numpy(blob).to(dev)))
+    # unchecked on request (graph capture, latency-critical loops): the status word is still there
+    big.energies_and_forces(spb, torch.from_numpy(blob).to(dev), check_overflow=False)
+    assert big.aev_computer.last_neighbors().overflowed()
 
 
 def test_external_neighbors_molecule_idxs(dev):
@@ -714,11 +772,11 @@ def test_external_neighbors_molecule_idxs(dev):
     mol = torch.cat([torch.zeros(n0, dtype=torch.long), torch.ones(n - n0, dtype=torch.long)]).to(dev)
     i, j = torch.triu_indices(n, n, offset=1, device=dev)
     pairs = torch.stack([i, j])
-    e_joint = model.compute_from_external_neighbors(sp_cat, x_cat, pairs, None, _molecule_idxs=mol)
+    e_joint = model.compute_from_external_neighbors(sp_cat, x_cat, pairs, None, _molecule_idxs=mol).energies
     e_sep = model.energies_and_forces(sp[:2], x[:2]).energies
     # (the autograd path returns float32 totals incl. self energies like the reference: one ulp at 3.5 kHa = 2.4e-4)
     assert abs(e_joint.item() - e_sep.sum().item()) < 1e-3
-    e_all = model.compute_from_external_neighbors(sp_cat, x_cat, pairs, None)
+    e_all = model.compute_from_external_neighbors(sp_cat, x_cat, pairs, None).energies
     assert abs(e_all.item() - e_joint.item()) > 1e-2      # the molecules do overlap: the filter matters
     with pytest.raises(ValueError, match="same length"):
         model.compute_from_external_neighbors(sp_cat, x_cat, pairs, None, _molecule_idxs=mol[:-1])

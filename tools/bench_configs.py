@@ -46,7 +46,7 @@ def main():
     sp, x = molecules()
     model = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="batch")
     spd, xd = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev)
-    dt = timeit(lambda: model.energies_and_forces(spd, xd))
+    dt = timeit(lambda: model.energies_and_forces(spd, xd, check_overflow=False))
     print(f"config 2: 256 x 20 atoms, batch mode: {dt * 1e3:.3f} ms/step, {sp.size / dt / 1e6:.2f} M atom*steps/s")
     f = model.graphed(spd, xd)
     dt = timeit(lambda: f(xd))
@@ -54,7 +54,7 @@ def main():
     sp3, x3, cell = water_box(25)
     model3 = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="cell")
     s3, c3, cl = torch.from_numpy(sp3).to(dev), torch.from_numpy(x3).to(dev), torch.from_numpy(cell).to(dev)
-    dt = timeit(lambda: model3.energies_and_forces(s3, c3, cl, (True, True, True)), reps=20)
+    dt = timeit(lambda: model3.energies_and_forces(s3, c3, cl, (True, True, True), check_overflow=False), reps=20)
     print(f"config 3: {sp3.size}-atom periodic water box: {dt * 1e3:.3f} ms/step, {sp3.size / dt / 1e6:.2f} M atom*steps/s")
 
 

@@ -13,6 +13,7 @@ import torch
 from torch import Tensor
 
 from .constants import AEVConstants, aev_constants_1x, aev_constants_2x
+from ._lib import MAX_RAD as _MAX_RAD
 from .engine import AevEngine, NeighborRows, VerletRows
 from .tuples import Neighbors, SpeciesAEV
 
@@ -136,6 +137,9 @@ class AEVComputer(torch.nn.Module):
         self._engine_key: tp.Optional[tuple] = None
         self._last_neighbors: tp.Optional[NeighborRows] = None
         self.strategy = "hip"
+        # forward() reads the builder's status word after queueing its kernels (one host sync per call) and raises on
+        # neighbor-row overflow; set False inside latency-critical loops that check last_neighbors() themselves
+        self.check_overflow = True
 
     # aev/_computer.py:183-191
     @staticmethod
@@ -266,7 +270,16 @@ class AEVComputer(torch.nn.Module):
             raise ValueError("cell and pbc must be given together")
         pbc_t = None if pbc is None else tuple(bool(b) for b in pbc.tolist())
         species32 = elem_idxs.to(torch.int32).contiguous()
-        return _AEVFunction.apply(coords, species32, cell, pbc_t, self)
+        out = _AEVFunction.apply(coords, species32, cell, pbc_t, self)
+        if self.check_overflow and not torch.cuda.is_current_stream_capturing() and self._last_neighbors.overflowed():
+            # a row over capacity was zeroed by the builder: never return such AEVs silently (the reference
+            # asserts on the device, csrc/aev.cu:229); one retry at the largest row capacity first
+            if self.row_capacity < _MAX_RAD:
+                warnings.warn(f"neighbor rows overflowed row_capacity={self.row_capacity}: retrying with {_MAX_RAD}")
+                self.row_capacity = _MAX_RAD
+                out = _AEVFunction.apply(coords, species32, cell, pbc_t, self)
+            self._last_neighbors.raise_on_overflow()
+        return out
 
     def last_neighbors(self) -> tp.Optional[NeighborRows]:
         return self._last_neighbors

@@ -50,6 +50,10 @@ class NeighborRows(tp.NamedTuple):
     lo: int
     hi: int
 
+    def overflowed(self) -> bool:
+        """Synchronising read of the device-side status word: did any row exceed its capacity (and was zeroed)?"""
+        return bool(int(self.status[0].item()) & (_lib.ST_ROW_OVERFLOW | _lib.ST_ENTRY_OVERFLOW))
+
     def raise_on_overflow(self) -> None:
         """Synchronising check of the device-side status words."""
         st = int(self.status[0].item())
@@ -352,6 +356,7 @@ class PackedNetworks:
     # (0 = the library chooses from the problem size).  The library itself reads no environment variables.
     default_flags: int = 0
     flags: tp.Optional[int] = None
+    pinned: int = 0   # live HIP graphs that captured this object's buffers (GraphedEnergiesForces)
 
     def __init__(self, weights: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]],
                  biases: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]], aev_len: int, celu_alpha: float,
@@ -486,6 +491,10 @@ class PackedNetworks:
     def workspace(self, n_central: int) -> Tensor:
         need = _lib.lib().anihip_mlp_workspace_bytes(C.byref(self.desc), n_central)
         if self._ws is None or self._ws.numel() < need:
+            if self.pinned and self._ws is not None:
+                # a captured HIP graph replays into self._ws: never free or replace it; a larger eager call gets a
+                # buffer of its own
+                return torch.empty(need, dtype=torch.uint8, device=self.device)
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 

@@ -14,17 +14,19 @@ Two ways to evaluate:
 from __future__ import annotations
 
 import typing as tp
+import warnings
 
 import numpy as np
 import torch
 from torch import Tensor
 
 from .aev import AEVComputer
+from ._lib import MAX_RAD
 from .constants import GSAES_WB97X_631GD
 from .engine import energy_reduce
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import join_exact, shard_range, split_exact
-from .tuples import AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
+from .tuples import EnergiesScalars, AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
 from .weights import arch_spec, random_state_dict
 
 
@@ -95,9 +97,13 @@ class ANI(torch.nn.Module):
     @torch.no_grad()
     def energies_and_forces(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
                             pbc: tp.Optional[tp.Sequence[bool]] = None, group=None,
-                            reduce_forces: bool = True, check_overflow: bool = False,
+                            reduce_forces: bool = True, check_overflow: bool = True,
                             shard: tp.Optional[tp.Tuple[int, int]] = None, stress: bool = False) -> EnergiesForces:
         """Energies [C] (float64, NN + self energies) and forces [C, A, 3] without autograd.
+
+        check_overflow (default): read the neighbor builder's status word afterwards (one host sync) and raise --
+        after one automatic retry with row_capacity 256 -- if an atom had more neighbors than a row holds; pass
+        False inside latency-critical loops / graph capture and call ``aev_computer.last_neighbors().raise_on_overflow()``.
 
         With a torch.distributed ``group`` (one process per GPU, RCCL) the central atoms are sharded
         contiguously over the ranks; every rank sees all coordinates, evaluates its shard, and the
@@ -112,8 +118,20 @@ class ANI(torch.nn.Module):
         elem_idxs = self._elem_idxs(species)
         species32 = elem_idxs.to(torch.int32).contiguous()
         c32 = coords.detach().to(torch.float32).contiguous()
-        return self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, check_overflow, shard,
-                                              stress)
+        out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard, stress)
+        if check_overflow and not torch.cuda.is_current_stream_capturing():
+            # one host sync after everything is queued: a row over capacity was zeroed by the builder, the result
+            # would be silently wrong (the reference asserts on the device, csrc/aev.cu:229).  Retry once at the
+            # largest row capacity, then raise.
+            aevc = self.aev_computer
+            if aevc.last_neighbors().overflowed():
+                if aevc.row_capacity < MAX_RAD:
+                    warnings.warn(f"neighbor rows overflowed row_capacity={aevc.row_capacity}: retrying with {MAX_RAD}")
+                    aevc.row_capacity = MAX_RAD
+                    out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard,
+                                                         stress)
+                aevc.last_neighbors().raise_on_overflow()
+        return out
 
     def _energies_and_forces_core(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces,
                                   check_overflow, shard, stress: bool = False) -> EnergiesForces:
@@ -176,7 +194,7 @@ class ANI(torch.nn.Module):
 
     # ---- external neighbor lists (arch.py:151-206,354-381) ------------------------------------------
     def compute_from_neighbors(self, elem_idxs: Tensor, coords: Tensor, neighbors, charge: int = 0,
-                               atomic: bool = False, ensemble_values: bool = False) -> Tensor:
+                               atomic: bool = False, ensemble_values: bool = False) -> "EnergiesScalars":
         """Energies from element indices and an already screened half neighbor list (any
         (indices [2, P], distances [P], diff_vectors [P, 3]) tuple in the reference's convention).
         Differentiable with respect to ``coords`` like the reference's native cuAEV entry point."""
@@ -189,12 +207,12 @@ class ANI(torch.nn.Module):
             energies = energies + self.neural_networks(elem_idxs, aevs, atomic, ensemble_values)
         if self.energy_shifter._enabled:
             energies = energies + self.energy_shifter(elem_idxs, atomic=atomic)
-        return energies
+        return EnergiesScalars(energies)   # arch.py:353-381
 
     def compute_from_external_neighbors(self, species: Tensor, coords: Tensor, neighbor_idxs: Tensor,
                                         shifts: tp.Optional[Tensor], charge: int = 0, atomic: bool = False,
                                         ensemble_values: bool = False,
-                                        _molecule_idxs: tp.Optional[Tensor] = None) -> Tensor:
+                                        _molecule_idxs: tp.Optional[Tensor] = None) -> "EnergiesScalars":
         """Entry point for a neighbor list owned by an MD engine: ``neighbor_idxs`` [2, P] and cartesian image
         ``shifts`` [P, 3] (or None); coords must be mapped to the central cell.  Pairs beyond the cutoff (Verlet
         skin) and pairs with padding atoms are dropped by the ingestion kernel (arch.py:171-206)."""
@@ -323,8 +341,10 @@ class GraphedEnergiesForces:
 
     The kernels are launched through the C ABI on torch's current stream, so ``torch.cuda.graph`` records
     them like any other stream work; all buffers come from the graph's private memory pool.  Outputs are static
-    tensors overwritten by every call (clone them to keep a result).  Neighbor-row overflow cannot raise inside
-    a graph: call ``check()`` when convenient."""
+    tensors overwritten by every call (clone them to keep a result).  The graph OWNS what it points at: it keeps
+    the packed weight planes it was captured with alive and pins their workspace (PackedNetworks.pinned), and it
+    re-captures itself when the model's parameters (or active members) have changed since.  Neighbor-row overflow
+    cannot raise inside a graph: call ``check()`` when convenient."""
 
     def __init__(self, model: ANI, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
                  pbc: tp.Optional[tp.Sequence[bool]] = None, warmup: int = 3) -> None:
@@ -335,21 +355,41 @@ class GraphedEnergiesForces:
         self.coords = coords.detach().to(torch.float32).contiguous().clone()
         self.cell = None if cell is None else cell.detach().clone()
         self.pbc = pbc
+        self.warmup = warmup
+        self.n_captures = 0
+        self._packed = None
+        self._capture()
+
+    def _capture(self) -> None:
+        self._release()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):   # packs the weights, sizes the workspaces
+            for _ in range(self.warmup):   # packs the weights, sizes the workspaces
                 self._run()
         torch.cuda.current_stream().wait_stream(side)
+        self._packed = self.model.neural_networks._pack(self.coords.device)   # strong reference: planes + workspace
+        self._packed.pinned += 1
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = self._run()
+        self.n_captures += 1
+
+    def _release(self) -> None:
+        if self._packed is not None:
+            self._packed.pinned -= 1
+            self._packed = None
+
+    def __del__(self):
+        self._release()
 
     def _run(self) -> EnergiesForces:
         return self.model._energies_and_forces_core(self.species32, self.coords, self.cell, self.pbc, None, True,
                                                     False, None)
 
     def __call__(self, coords: Tensor, cell: tp.Optional[Tensor] = None) -> EnergiesForces:
+        if self.model.neural_networks._pack(self.coords.device) is not self._packed:
+            self._capture()   # parameters were updated in place / other members: the old planes are stale
         self.coords.copy_(coords)
         if cell is not None:
             assert self.cell is not None, "the graph was captured without a cell"
@@ -381,10 +421,26 @@ def _builtin(kind: str, state_dict, seed, n_members, device, neighborlist, row_c
         raise ValueError("the HIP engine computes in float32 (energies are reduced in float64)")
     model = _assemble(kind, n_members, neighborlist, row_capacity, periodic_table_index, cutoff_fn)
     if state_dict is None:
-        # the published parameters are a download in the reference (arch.py:1185-1220); offline we use
-        # the same architecture with seeded random parameters
+        # the published parameters are a download in the reference (arch.py:1185-1220) and are not shipped here: an
+        # explicit seed gives the same architecture with seeded random parameters (tests, benchmarks)
+        if seed is None:
+            warnings.warn(f"torchani_amd.{kind.upper().replace('ANI', 'ANI')}: neither state_dict nor seed given -- the "
+                          "model gets RANDOM parameters (seed 0), its energies and forces are meaningless. Pass "
+                          "state_dict=<the trained reference parameters> (torchani.models.ANI2x().state_dict()).",
+                          UserWarning, stacklevel=3)
         state_dict = random_state_dict(kind, n_members, 0 if seed is None else seed)
-    model.load_reference_state_dict(state_dict, strict=False)
+    if n_members == 1:
+        # a single network is not wrapped in an Ensemble (no "members.0." level in its keys): accept the one-member
+        # form of an ensemble state dict too
+        pre = "potentials.nnp.neural_networks."
+        state_dict = {(pre + k[len(pre) + len("members.0."):] if k.startswith(pre + "members.0.") else k): v
+                      for k, v in state_dict.items()}
+    res = model.load_reference_state_dict(state_dict, strict=False)
+    lost = [k for k in res.missing_keys if k.startswith(("potentials.nnp.neural_networks", "energy_shifter"))]
+    if lost:
+        raise RuntimeError(f"state_dict does not provide {len(lost)} network / self-energy tensors (first: {lost[0]}): "
+                           "it is not a state dict of this architecture (a Bmm / infer-converted reference model "
+                           "must be saved before conversion); refusing to run on random weights")
     model.requires_grad_(False)
     if device is not None:
         model = model.to(device)

@@ -25,6 +25,13 @@ class SpeciesEnergies(tp.NamedTuple):
     energies: Tensor
 
 
+class EnergiesScalars(tp.NamedTuple):
+    """Return type of ANI.compute_from_neighbors / compute_from_external_neighbors (torchani/tuples.py:8-10)."""
+
+    energies: Tensor
+    scalars: tp.Optional[Tensor] = None
+
+
 class EnergiesForces(tp.NamedTuple):
     """Result of the fused engine path: energies [C] float64 Hartree, forces [C,A,3] float32 Ha/A,
     atomic_energies [C,A] float32 (network part only, no self energies)."""
