@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--waters-side", type=int, default=92, help="waters per box edge (92 -> 2,336,064 atoms)")
     ap.add_argument("--cpu-side", type=int, default=36, help="waters per edge of the CPU-baseline sub-box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 / config-3 secondary measurements")
     ap.add_argument("--no-dense-stage", action="store_true",
                     help="skip the extra (untimed-region) dense-MLP stage timing, e.g. under rocprofv3 so the "
                          "kernel statistics hold the product configuration only")
@@ -301,6 +302,13 @@ def main():
             "bytes_per_step": lc["bytes"], "op": "all_reduce(sum, fp32)", "backend": backend,
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
         }
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # BASELINE configs 2 / 3 on the parity fixtures' inputs (outside the timed headline region)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs
+
+        torch.cuda.empty_cache()
+        res["secondary"] = bench_configs.measure(dev)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_side, seed=5)

@@ -157,7 +157,10 @@ int anihip_nbr_refresh(void *stream, const anihip_aev_params *p, int64_t n_atoms
  * grad_coords += d(sum grad_aev * aev)/d coords  (csrc/aev.cu:1958-1984).  The radial part of a pair is finished by
  * each of its two atoms for itself -- atom i gathers the 16-float block grad_aev[j][species(i)*16 ..] of every
  * neighbor row j that this call may read, i.e. lo <= j < hi (and, with slab_mask, flagged there) -- so only the
- * angular part and pairs whose partner row belongs to another shard travel through float atomics.
+ * angular part and pairs whose partner row belongs to another shard travel through float atomics.  That needs
+ * SYMMETRIC rows (j in row i <=> i in row j), which every builder of this library produces except
+ * anihip_nbr_from_full (a LAMMPS list names ghost atoms that have no row of their own): pass symmetric = 0 for
+ * those rows and every pair term is pushed to its neighbor instead.
  *
  * slab_mask (optional, may be NULL; needs ceil(S/2) + S(S+1)/2 <= 32): slab_mask[i] flags the 32-wide
  * "slabs" of row i that can be non-zero -- bit j < ceil(S/2): radial blocks of species 2j, 2j+1; bit
@@ -170,8 +173,8 @@ int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *ta
                        const float *ent, float *aev, uint32_t *slab_mask, uint32_t *status);
 int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                         int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
-                        const float *ent, const float *grad_aev, const uint32_t *slab_mask, float *grad_coords,
-                        uint32_t *status);
+                        const float *ent, const float *grad_aev, const uint32_t *slab_mask, int32_t symmetric,
+                        float *grad_coords, uint32_t *status);
 
 /* Forward-mode derivative of the AEV rows along a coordinate-space direction: daev[i] = sum_k (d aev[i] / d r_k) .
  * tangent[k]  (tangent: [n_atoms][3]).  This is the reference's cuaev double backward (csrc/aev.cu:1986-2015,
@@ -191,7 +194,7 @@ int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const float *table,
 int anihip_aev_backward_virial(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                                int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
                                const float *ent, const float *grad_aev, const uint32_t *slab_mask,
-                               float *grad_coords, double *virial, uint32_t *status);
+                               int32_t symmetric, float *grad_coords, double *virial, uint32_t *status);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-species MLP ensemble: replaces mnp::run (csrc/mnp.cpp:238-265; forward :32-136, input-gradient

@@ -12,7 +12,7 @@ from torchani_amd.weights import random_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if not os.path.basename(p).startswith(("nbrs_", "wgrads_", "stress_", "fgrads_")))   # reference neighbor lists /
+                      if not os.path.basename(p).startswith(("nbrs_", "wgrads_", "stress_", "fgrads_", "cfg3_")))   # reference neighbor lists /
 #                                                                                      weight-gradient digests
 WGRAD_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "wgrads_*.npz")))
 STRESS_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "stress_*.npz")))
@@ -73,6 +73,17 @@ def oracle_networks(kind, n_members, seed):
 
 def oracle_params(kind, cutoff_fn="cosine"):
     return orc.params_2x(cutoff_fn) if kind == "ani2x" else orc.params_1x(cutoff_fn)
+
+
+def load_sampled(name):
+    """Large-system fixtures of tests/golden/gen_golden_configs.py (inputs whole, outputs on a sample of atoms)."""
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz")) as z:
+        g = {k: z[k] for k in z.files}
+    g["seed"] = int(g["seed"])
+    g["species"] = g["species"].astype(np.int64)
+    g.setdefault("cell", None)
+    g.setdefault("pbc", None)
+    return g
 
 
 def load_stress(base):

@@ -207,7 +207,7 @@ def test_compute_from_external_half_list(dev, name):
 
 
 @pytest.mark.parametrize("name", ["small_ani2x", "ch4_ani1x"])
-def test_compute_from_full_neighbor_list(dev, name):
+def test_compute_from_full_neighbor_list(dev, oracle64, name):
     """LAMMPS-style full list (aev/_computer.py:420-438, tests/test_cuaev.py:740-790): built here from the
     reference's half list of a non-periodic case (both directions, plus some pairs beyond the cutoff and a
     self pair that must be screened out); atoms left out of ilist get zero rows."""
@@ -245,8 +245,25 @@ def test_compute_from_full_neighbor_list(dev, name):
     rows = np.intersect1d(g["aev_rows"], np.asarray(listed))
     assert np.abs(got[rows] - ref[rows]).max() < AEV_TOL
     assert np.all(got[~mask] == 0)
-    (gx,) = torch.autograd.grad(aev.sum(), xx)
-    assert torch.isfinite(gx).all() and gx.abs().max() > 0
+    # the backward through a full list: rows of unlisted atoms do not exist (not even as somebody's partner), so the
+    # radial gather-by-symmetry must be off; VJP with seeded cotangents == the oracle's with the cotangents of the
+    # unlisted atoms zeroed
+    w = np.random.RandomState(7).uniform(-1.0, 1.0, got.shape)
+    (gx,) = torch.autograd.grad((aev.view(n, -1) * torch.from_numpy(w.astype(np.float32)).to(dev)).sum(), xx)
+    p = oracle_params(g["kind"], g["cutoff_fn"])
+    _, gc_ref = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), grad_aev=w * mask[:, None])
+    scale = max(1.0, np.abs(gc_ref).max())
+    assert np.abs(gx.cpu().numpy().reshape(gc_ref.shape) - gc_ref).max() < 2e-5 * scale
+    # everything listed: the golden VJP itself
+    all_i = torch.arange(n, dtype=torch.int32, device=dev)
+    nn_all = torch.tensor([len(adj[a]) for a in range(n)], dtype=torch.int32, device=dev)
+    jl_all = torch.tensor([j for a in range(n) for j in adj[a]], dtype=torch.int32, device=dev)
+    x2 = x.clone().requires_grad_(True)
+    aev2 = aevc.compute_from_full_nbrlist(sp, x2, all_i, jl_all, nn_all)
+    wg = np.random.RandomState(g["seed"] + 1000).uniform(-1.0, 1.0, tuple(g["species"].shape) + (got.shape[1],))
+    if aev2.shape[0] == g["aev_vjp"].shape[0]:
+        (gx2,) = torch.autograd.grad((aev2 * torch.from_numpy(wg.astype(np.float32)).to(dev)).sum(), x2)
+        assert np.abs(gx2.cpu().numpy() - g["aev_vjp"]).max() < 2e-5 * max(1.0, np.abs(g["aev_vjp"]).max())
 
 
 @pytest.mark.parametrize("name", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x"])
@@ -668,6 +685,45 @@ def test_solvated_box_46k(dev, oracle64):
     ea = np.abs(out.atomic_energies.cpu().numpy()[0, pick] - ae).max()
     report(f"box   water 46875 atoms pbc       max|e_atom err| (1500 sampled atoms) = {ea:.2e}")
     assert ea < E_ATOM_TOL
+    # forces: d E / d aev of every atom from the oracle's networks, back through the oracle's AEV backward
+    _, ga, _ = oracle64.mlp(sp, aev, dims, flat, n_members=8)
+    _, gc = oracle64.aev(oracle_params("ani2x"), sp, x.astype(np.float64), cell, pbc, cell_list=True, grad_aev=ga)
+    fe = np.abs(out.forces.cpu().numpy() + gc).max()
+    report(f"box   water 46875 atoms pbc       max|F err| (all atoms) = {fe:.2e}")
+    assert fe < F_TOL
+
+
+@pytest.mark.parametrize("name", ["cfg3_1hz5_water_ani2x", "cfg3_1c17_ani2x"])
+def test_config3_reference_inputs(dev, name):
+    """BASELINE config 3 on the reference's own structures (tests/golden/gen_golden_configs.py): 1hz5 solvated to 46 357
+    atoms in a periodic box (7 species present in one system: H C N O S + water), and 1C17.pdb (16 649 atoms, no PBC).
+    Per-atom energies AND forces on a 2000-atom sample, totals, against the reference's fp64 values."""
+    from _util import load_sampled
+
+    g = load_sampled(name)
+    model = get_model("ani2x", g["seed"], dev, neighborlist="cell")
+    sp = torch.from_numpy(g["species"]).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev)
+    cell = None if g["cell"] is None else torch.from_numpy(g["cell"]).to(dev)
+    pbc = None if g["pbc"] is None else tuple(bool(b) for b in g["pbc"])
+    out = model.energies_and_forces(sp, x, cell, pbc)
+    torch.cuda.synchronize()
+    pick = g["sample"]
+    ea = np.abs(out.atomic_energies.cpu().numpy()[0, pick] - g["atomic_energies_sample"]).max()
+    fe = np.abs(out.forces.cpu().numpy()[0, pick] - g["forces_sample"]).max()
+    n = sp.shape[1]
+    de = abs(float(out.energies[0]) - float(g["energies"][0]))
+    report(f"cfg3  {name:22s} {n} atoms  max|e_atom err| = {ea:.2e}  |F err| = {fe:.2e}  |E err| = {de:.2e}")
+    assert ea < E_ATOM_TOL and fe < F_TOL
+    assert de < E_ATOM_TOL * np.sqrt(n)
+    f64 = out.forces.double()
+    assert abs(float((f64 ** 2).sum()) - float(g["force_sq_sum"])) < 1e-5 * float(g["force_sq_sum"])
+    # the autograd path on the same input agrees (other kernels' launch configuration: whole rows, no slab masks)
+    xs = x.clone().requires_grad_(True)
+    pbc_t = None if pbc is None else torch.tensor(pbc)
+    e = model((sp, xs), cell, pbc_t).energies
+    (gx,) = torch.autograd.grad(e.sum(), xs)
+    assert np.abs(-gx.cpu().numpy()[0, pick] - g["forces_sample"]).max() < F_TOL
 
 
 def test_periodic_replica_and_symmetries_at_scale(dev):

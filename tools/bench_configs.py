@@ -1,8 +1,11 @@
-"""Throughput of the secondary BASELINE.json configurations on one GPU (development benchmark; the headline
-metric is bench.py):   python tools/bench_configs.py
-  config 2: 256 molecules x ~20 atoms (synthetic H/C/N/O, SURVEY 8d fallback input), batch mode
-  config 3: 46 875-atom periodic water box, cell mode
+"""Throughput of the secondary BASELINE.json configurations on one GPU, on the SAME inputs as the parity fixtures
+(tests/golden/gen_golden_configs.py):   python tools/bench_configs.py [--json]
+  config 2: 256 molecules (frames of dataset/xyz_files/13.xyz + 28.xyz padded to A = 28; 5248 real atoms), batch mode,
+            eager and as a HIP graph replay
+  config 3: 1hz5 solvated to 46 357 atoms in a periodic box, cell mode; 1C17.pdb (16 649 atoms, no PBC)
+bench.py imports ``measure()`` for the "secondary" object of its JSON line (outside the timed headline region).
 """
+import json
 import os
 import sys
 import time
@@ -10,22 +13,9 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import water_box  # noqa: E402
-
-
-def molecules(n_mol=256, n_at=20, seed=2):
-    rs = np.random.RandomState(seed)
-    sp = rs.choice([0, 1, 2, 3], size=(n_mol, n_at), p=[0.5, 0.3, 0.1, 0.1])
-    x = np.zeros((n_mol, n_at, 3), dtype=np.float32)
-    for m in range(n_mol):
-        pts = []
-        while len(pts) < n_at:
-            p = rs.uniform(0, 6.0, 3)
-            if all(np.linalg.norm(p - q) > 0.9 for q in pts):
-                pts.append(p)
-        x[m] = np.asarray(pts, dtype=np.float32)
-    return sp.astype(np.int64), x
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def timeit(fn, warm=5, reps=30):
@@ -39,24 +29,39 @@ def timeit(fn, warm=5, reps=30):
     return (time.perf_counter() - t0) / reps
 
 
-def main():
+def measure(dev=None, reps2=50, reps3=20):
     from torchani_amd.models import ANI2x
 
-    dev = torch.device("cuda:0")
-    sp, x = molecules()
+    dev = dev or torch.device("cuda:0")
+    out = {}
+    with np.load(os.path.join(GOLD, "cfg2_xyz13_28_ani2x.npz")) as z:
+        sp, x = z["species"].astype(np.int64), z["coords"]
+    n_real = int((sp >= 0).sum())
     model = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="batch")
     spd, xd = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev)
-    dt = timeit(lambda: model.energies_and_forces(spd, xd, check_overflow=False))
-    print(f"config 2: 256 x 20 atoms, batch mode: {dt * 1e3:.3f} ms/step, {sp.size / dt / 1e6:.2f} M atom*steps/s")
+    dt = timeit(lambda: model.energies_and_forces(spd, xd, check_overflow=False), reps=reps2)
     f = model.graphed(spd, xd)
-    dt = timeit(lambda: f(xd))
-    print(f"config 2, HIP graph replay:           {dt * 1e3:.3f} ms/step, {sp.size / dt / 1e6:.2f} M atom*steps/s")
-    sp3, x3, cell = water_box(25)
+    dtg = timeit(lambda: f(xd), reps=reps2)
+    out["config2"] = {"workload": f"256 molecules (13.xyz / 28.xyz frames 0-127, A = 28, {n_real} real atoms), batch mode",
+                      "ms_eager": dt * 1e3, "ms_graph_replay": dtg * 1e3, "atom_steps_per_s_graph": n_real / dtg}
     model3 = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="cell")
-    s3, c3, cl = torch.from_numpy(sp3).to(dev), torch.from_numpy(x3).to(dev), torch.from_numpy(cell).to(dev)
-    dt = timeit(lambda: model3.energies_and_forces(s3, c3, cl, (True, True, True), check_overflow=False), reps=20)
-    print(f"config 3: {sp3.size}-atom periodic water box: {dt * 1e3:.3f} ms/step, {sp3.size / dt / 1e6:.2f} M atom*steps/s")
+    for key, name in (("config3", "cfg3_1hz5_water_ani2x"), ("config3_1c17", "cfg3_1c17_ani2x")):
+        with np.load(os.path.join(GOLD, name + ".npz")) as z:
+            sp3, x3 = z["species"].astype(np.int64), z["coords"]
+            cell = z["cell"] if "cell" in z.files else None
+        s3, c3 = torch.from_numpy(sp3).to(dev), torch.from_numpy(x3).to(dev)
+        cl = None if cell is None else torch.from_numpy(cell).to(dev)
+        pbc = None if cell is None else (True, True, True)
+        dt = timeit(lambda: model3.energies_and_forces(s3, c3, cl, pbc, check_overflow=False), reps=reps3)
+        out[key] = {"workload": f"{name}: {sp3.size} atoms, {'periodic' if pbc else 'no PBC'}, cell mode",
+                    "ms_per_step": dt * 1e3, "atom_steps_per_s": sp3.size / dt}
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    res = measure()
+    if "--json" in sys.argv:
+        print(json.dumps(res))
+    else:
+        for k, v in res.items():
+            print(k, json.dumps(v))

@@ -4,12 +4,12 @@ mkdir -p gpurun_out; export TMPDIR=/tmp; REPO=$PWD
 timeout 900 python bench.py > gpurun_out/bench.log 2> gpurun_out/bench.err
 echo "bench exit $?" >> gpurun_out/bench.err; tail -2 gpurun_out/bench.err; cat gpurun_out/bench.log
 rm -rf gpurun_out/prof
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-stage > $REPO/gpurun_out/prof_bench.log 2>&1
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-stage --no-secondary > $REPO/gpurun_out/prof_bench.log 2>&1
 echo "rocprof exit $?"; cd $REPO
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/pmc_$c -o pmc -- python $REPO/bench.py --waters-side 64 --steps 1 --warmup 1 --no-cpu-baseline --no-dense-stage > $REPO/gpurun_out/pmc_$c.log 2>&1
+  cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/pmc_$c -o pmc -- python $REPO/bench.py --waters-side 64 --steps 1 --warmup 1 --no-cpu-baseline --no-dense-stage --no-secondary > $REPO/gpurun_out/pmc_$c.log 2>&1
   echo "pmc $c exit $?"; cd $REPO
 done
 python - <<'PY'

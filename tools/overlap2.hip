@@ -1,0 +1,105 @@
+// Do the matrix pipe and the vector ALU of ONE SIMD overlap across two different waves on gfx950?  (second look at
+// tools/overlapbench.hip, whose MFMA wave issued four independent accumulators back to back.)
+//   hipcc --offload-arch=gfx950 -O3 -o tools/_bin/overlap2 tools/overlap2.hip && tools/_bin/overlap2
+// 512-thread workgroups, one per CU: waves 0-3 ("G") run a GEMM-like stream (two dependent MFMA chains, LDS fragment
+// reads), waves 4-7 ("E") an epilogue-like stream (fma, exp2, min, med3, fp16 split, LDS writes).  Timed: G alone,
+// E alone, both, both with s_setprio on either side, and the SAME total work with every wave doing half G + half E.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float gemm_stream(int iters, const _Float16 *lds, int lane)
+{
+    f16v c0 = {}, c1 = {};
+    const h8 *a = reinterpret_cast<const h8 *>(lds) + lane;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const h8 x = a[(u & 1) * 64], y = a[128 + (u & 1) * 64];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, y, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, x, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(y, x, c1, 0, 0, 0);
+        }
+    }
+    return c0[0] + c1[5];
+}
+
+__device__ __forceinline__ float epi_stream(int iters, _Float16 *lds, int tid)
+{
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.01f * (r + 1) + 1e-4f * tid;
+    float s = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = acc[4 * q + e] * 0.37f + 0.01f;
+                const float ex = __builtin_amdgcn_exp2f(x * 14.4f);
+                const float y = __builtin_amdgcn_fmed3f(x, 0.1f * ex - 0.1f, 0.f);
+                s += fminf(ex, 1.0f);
+                const _Float16 hh = (_Float16)(y * 64.f);
+                hi[e] = hh;
+                lo[e] = (_Float16)__builtin_fmaf(y, 64.f, -(float)hh);
+                acc[4 * q + e] = y + 1e-3f;
+            }
+            *reinterpret_cast<h4 *>(lds + 4096 + tid * 16 + q * 4) = hi;
+            *reinterpret_cast<h4 *>(lds + 4096 + 8192 + tid * 16 + q * 4) = lo;
+        }
+    }
+    return s + acc[3];
+}
+
+// mode bits: 1 = G waves work, 2 = E waves work, 4 = setprio 2 for G, 8 = setprio 2 for E, 16 = mixed (every wave half/half)
+__global__ __launch_bounds__(512) void k(int mode, int iters, float *out, long long *cyc)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 lds[4096 + 2 * 8192];
+    for (int i = threadIdx.x; i < 4096; i += 512) lds[i] = (_Float16)(0.001f * (i & 255));
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float r = 0.f;
+    long long t0 = __builtin_readcyclecounter();
+    if (mode & 16) {
+        r = gemm_stream(iters / 2, lds, lane) + epi_stream(iters * 3 / 2, lds, threadIdx.x);
+    } else if (wave < 4) {
+        if (mode & 4) __builtin_amdgcn_s_setprio(2);
+        if (mode & 1) r = gemm_stream(iters, lds, lane);
+    } else {
+        if (mode & 8) __builtin_amdgcn_s_setprio(2);
+        if (mode & 2) r = epi_stream(iters * 3, lds, threadIdx.x);
+    }
+    long long t1 = __builtin_readcyclecounter();
+    if (r == 12345.678f) out[0] = r;
+    if (lane == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+}
+
+int main()
+{
+    float *out; long long *cyc;
+    hipMalloc(&out, 4); hipMalloc(&cyc, 256 * 8 * 8);
+    const int iters = 2000;
+    const int modes[] = {1, 2, 3, 3 | 4, 3 | 8, 16};
+    const char *names[] = {"G alone", "E alone", "G + E", "G + E, prio G", "G + E, prio E", "mixed in every wave"};
+    for (int i = 0; i < 6; ++i) {
+        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, modes[i], 50, out, cyc);
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, modes[i], iters, out, cyc);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        long long h[2048]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+        double g = 0, e = 0;
+        for (int b = 0; b < 256; ++b) for (int w = 0; w < 8; ++w) (w < 4 ? g : e) += (double)h[b * 8 + w];
+        printf("%-22s %8.3f ms   wave cycles per iteration: G waves %8.1f  E waves %8.1f   (24 MFMA = 768 pipe cycles per G iteration)\n",
+               names[i], ms, g / 1024 / iters, e / 1024 / iters);
+    }
+    return 0;
+}

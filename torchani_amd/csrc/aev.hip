@@ -851,7 +851,7 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
     const float4 *__restrict__ ent, const float *__restrict__ grad_aev, float *__restrict__ grad_coords,
-    double *__restrict__ virial, const uint32_t *__restrict__ slab_mask)
+    double *__restrict__ virial, const uint32_t *__restrict__ slab_mask, int64_t glo, int64_t ghi)
 {
     float vxx = 0.f, vyy = 0.f, vzz = 0.f, vxy = 0.f, vxz = 0.f, vyz = 0.f;
     constexpr int ZQ = NZ / 4;
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                 const uint32_t wbits = __float_as_uint(d.w);
                 const int64_t jn = ve ? (int64_t)(wbits & IDX_MASK) : lo;
                 // the neighbor's block for MY species: issued first, consumed at the end of the pass
-                const bool inrow = ve && jn >= lo && jn < hi;
+                const bool inrow = ve && jn >= glo && jn < ghi;   // (empty range: asymmetric list, push everything)
                 float4 G0 = make_float4(0.f, 0.f, 0.f, 0.f), G1 = G0, G2 = G0, G3 = G0;
                 uint32_t jmask = 0xFFFFFFFFu;
                 if (inrow) {
@@ -1297,7 +1297,8 @@ extern "C" int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const fl
 
 static int aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms, int64_t lo,
                         int64_t hi, const int32_t *species, const uint32_t *meta, const float *ent,
-                        const float *grad_aev, float *grad_coords, double *virial, const uint32_t *slab_mask)
+                        const float *grad_aev, float *grad_coords, double *virial, const uint32_t *slab_mask,
+                        int32_t symmetric)
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && grad_aev && grad_coords, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
@@ -1308,18 +1309,19 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
     dim3 grid(persistent_blocks(hi - lo, BWD_WPB, 4)), block(BWD_WPB * WAVE);
     const float4 *e4 = (const float4 *)ent;
     hipStream_t st = (hipStream_t)stream;
+    const int64_t glo = symmetric ? lo : 0, ghi = symmetric ? hi : 0;   // rows the radial gather may read
     if (p->n_shf_a == 8 && !virial)
         hipLaunchKernelGGL((k_aev_bwd<8, 4, false>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial, slab_mask);
+                           grad_coords, virial, slab_mask, glo, ghi);
     else if (p->n_shf_a == 8)
         hipLaunchKernelGGL((k_aev_bwd<8, 4, true>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial, slab_mask);
+                           grad_coords, virial, slab_mask, glo, ghi);
     else if (!virial)
         hipLaunchKernelGGL((k_aev_bwd<4, 8, false>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial, slab_mask);
+                           grad_coords, virial, slab_mask, glo, ghi);
     else
         hipLaunchKernelGGL((k_aev_bwd<4, 8, true>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial, slab_mask);
+                           grad_coords, virial, slab_mask, glo, ghi);
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1327,21 +1329,22 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
 extern "C" int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table,
                                    int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
                                    const uint32_t *meta, const float *ent, const float *grad_aev,
-                                   const uint32_t *slab_mask, float *grad_coords, uint32_t *status)
+                                   const uint32_t *slab_mask, int32_t symmetric, float *grad_coords,
+                                   uint32_t *status)
 {
     (void)status;
     return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, nullptr,
-                        slab_mask);
+                        slab_mask, symmetric);
 }
 
 extern "C" int anihip_aev_backward_virial(void *stream, const anihip_aev_params *p, const float *table,
                                           int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
                                           const uint32_t *meta, const float *ent, const float *grad_aev,
-                                          const uint32_t *slab_mask, float *grad_coords, double *virial,
-                                          uint32_t *status)
+                                          const uint32_t *slab_mask, int32_t symmetric, float *grad_coords,
+                                          double *virial, uint32_t *status)
 {
     (void)status;
     ANIHIP_REQUIRE(virial, "null pointer argument");
     return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, virial,
-                        slab_mask);
+                        slab_mask, symmetric);
 }

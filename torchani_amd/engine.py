@@ -49,6 +49,7 @@ class NeighborRows(tp.NamedTuple):
     row_cap: int
     lo: int
     hi: int
+    symmetric: bool = True   # j in row i <=> i in row j (false for LAMMPS full lists with ghost atoms)
 
     def overflowed(self) -> bool:
         """Synchronising read of the device-side status word: did any row exceed its capacity (and was zeroed)?"""
@@ -197,7 +198,7 @@ class AevEngine:
         _lib.check(_lib.lib().anihip_nbr_from_full(
             _stream(), C.byref(self.params), n, _ptr(species), _ptr(coords), il.numel(), _ptr(il), _ptr(nn),
             _ptr(start), _ptr(jl), _ptr(meta), _ptr(ent), n * row_cap, _ptr(status)))
-        return NeighborRows(meta, ent, status, row_cap, 0, n)
+        return NeighborRows(meta, ent, status, row_cap, 0, n, symmetric=False)
 
     def refresh_rows(self, species: Tensor, coords: Tensor, coords_build: Tensor, verlet: NeighborRows,
                      lo: int = 0, hi: tp.Optional[int] = None, row_cap: int = 128) -> NeighborRows:
@@ -283,7 +284,8 @@ class AevEngine:
             grad_coords = torch.zeros((n, 3), dtype=torch.float32, device=species.device)
         args = (_stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
                 _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent),
-                _row_ptr(grad_aev, nbrs.lo if shard_rows else 0, self.L), _ptr(slab_mask), _ptr(grad_coords))
+                _row_ptr(grad_aev, nbrs.lo if shard_rows else 0, self.L), _ptr(slab_mask), int(nbrs.symmetric),
+                _ptr(grad_coords))
         if virial is None:
             _lib.check(_lib.lib().anihip_aev_backward(*args, _ptr(nbrs.status)))
         else:
