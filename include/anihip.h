@@ -159,8 +159,11 @@ int anihip_nbr_refresh(void *stream, const anihip_aev_params *p, int64_t n_atoms
  * neighbor row j that this call may read, i.e. lo <= j < hi (and, with slab_mask, flagged there) -- so only the
  * angular part and pairs whose partner row belongs to another shard travel through float atomics.  That needs
  * SYMMETRIC rows (j in row i <=> i in row j), which every builder of this library produces except
- * anihip_nbr_from_full (a LAMMPS list names ghost atoms that have no row of their own): pass symmetric = 0 for
- * those rows and every pair term is pushed to its neighbor instead.
+ * anihip_nbr_from_full (a LAMMPS list names ghost atoms that have no row of their own): leave ANIHIP_BWD_SYMMETRIC out
+ * of `flags` for those rows and every pair term is pushed to its neighbor instead.
+ * ANIHIP_BWD_FIXED_POINT: grad_coords is then int64_t[n_atoms][3] (caller zeroes it) in units of 2^-32; contributions are
+ * added with 64-bit integer atomics, so the result is bit-identical from run to run whatever the order of the waves
+ * (the reference's cuAEV backward is not: float atomics, csrc/aev.cu:700-704).  The caller converts: g = acc * 2^-32.
  *
  * slab_mask (optional, may be NULL; needs ceil(S/2) + S(S+1)/2 <= 32): slab_mask[i] flags the 32-wide
  * "slabs" of row i that can be non-zero -- bit j < ceil(S/2): radial blocks of species 2j, 2j+1; bit
@@ -168,12 +171,14 @@ int anihip_nbr_refresh(void *stream, const anihip_aev_params *p, int64_t n_atoms
  * neighbor (pair) of that species inside the cutoff; anihip_mlp_forward_backward skips those slabs.
  * anihip_aev_backward(slab_mask != NULL) reads grad_aev only inside flagged slabs (of the rows lo..hi); with
  * slab_mask == NULL every entry of the rows lo..hi must be valid. */
+#define ANIHIP_BWD_SYMMETRIC 1   /* rows are symmetric: gather the radial partner blocks instead of pushing */
+#define ANIHIP_BWD_FIXED_POINT 2 /* grad_coords is an int64 fixed-point accumulator (2^-32): reproducible sums */
 int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                        int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
                        const float *ent, float *aev, uint32_t *slab_mask, uint32_t *status);
 int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                         int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
-                        const float *ent, const float *grad_aev, const uint32_t *slab_mask, int32_t symmetric,
+                        const float *ent, const float *grad_aev, const uint32_t *slab_mask, int32_t flags,
                         float *grad_coords, uint32_t *status);
 
 /* Forward-mode derivative of the AEV rows along a coordinate-space direction: daev[i] = sum_k (d aev[i] / d r_k) .
@@ -194,7 +199,7 @@ int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const float *table,
 int anihip_aev_backward_virial(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                                int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
                                const float *ent, const float *grad_aev, const uint32_t *slab_mask,
-                               int32_t symmetric, float *grad_coords, double *virial, uint32_t *status);
+                               int32_t flags, float *grad_coords, double *virial, uint32_t *status);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-species MLP ensemble: replaces mnp::run (csrc/mnp.cpp:238-265; forward :32-136, input-gradient

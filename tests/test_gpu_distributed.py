@@ -75,6 +75,18 @@ def _worker_ef(rank, world, port, q):
         out["box_dF"] = float((s2.forces - s1.forces).abs().max())
         out["box_dW"] = float((s2.virial - s1.virial).abs().max())
         out["box_bytes"] = model2.last_collective["bytes"]
+        # deterministic mode: ONE int64 all-reduce (forces, energy and virial in 2^-32 fixed point); a sharded run is
+        # bit-reproducible (integer sums do not care who adds what, or in which order the ranks are reduced) and equals
+        # the single-rank result to the rounding of the pairs that straddle the shards
+        model2.deterministic_forces = True
+        d1 = model2.energies_and_forces(sp2, x2, cell2, (True, True, True), stress=True)
+        d2 = model2.energies_and_forces(sp2, x2, cell2, (True, True, True), group=group, stress=True)
+        f2 = d2.forces.clone()
+        d3 = model2.energies_and_forces(sp2, x2, cell2, (True, True, True), group=group, stress=True)
+        out["det_equal"] = bool(torch.equal(f2, d3.forces)) and float((d1.forces - f2).abs().max()) < 1e-7
+        out["det_dE"] = float((d1.energies - d2.energies).abs().max())
+        out["det_bytes"] = model2.last_collective["bytes"]
+        model2.deterministic_forces = False
         # every rank holds the same reduced result
         chk = torch.stack([s2.energies.sum(), s2.forces.double().abs().sum(), s2.virial.sum()]).cpu()
         both = [torch.zeros_like(chk) for _ in range(world)]
@@ -128,6 +140,7 @@ def test_two_ranks_energies_forces_virial_match_single_rank():
         # and equal to the reference fixture
         assert o["golden_F_vs_ref"] < F_TOL and o["golden_E_vs_ref"] < E_ATOM_TOL * 10 and o["golden_W_vs_ref"] < 1e-5, o
         assert o["rank_spread"] == 0.0, o
+        assert o["det_equal"] and o["det_dE"] < 1e-8 and o["det_bytes"] == 8 * (3 * 3000 + 1 + 9), o
         assert o["box_bytes"] == 4 * (3 * 3000 + 4 + 36), o      # forces + energy parts + virial parts, one buffer
         assert o["batch_dE"] < 1e-9 and o["batch_dF_own"] < 2e-6, o
         assert o["batch_bytes"] == 16 * o["batch_C"], o

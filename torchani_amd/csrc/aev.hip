@@ -846,7 +846,21 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD2_WAVES) void k_aev_fwd2(
 // Only the blocks of the dE/dAEV row that the atom's neighbor species can reach are loaded (5 of 35 for water).
 // VIRIAL: also accumulate  W[a][b] = sum_ij (d E_i / d d_ij)[a] d_ij[b]  (the "fdotr" virial, ase.py:164-168) over the
 // central atoms of this launch: six per-lane running sums (W is symmetric), one double atomic per wave at the end.
-template <int NA, int NZ, bool VIRIAL>
+// accumulate one gradient component of atom `at`: float atomic, or (FIXED) a 64-bit integer atomic on a fixed-point
+// accumulator in units of 2^-32 -- integer addition is associative, so the result does not depend on the order in which
+// the waves arrive (run-to-run reproducible forces); every value pushed is itself computed in a fixed order
+template <bool FIXED>
+__device__ __forceinline__ void push_grad(float *grad_coords, size_t at, int comp, float v)
+{
+    if (FIXED) {
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(grad_coords) + 3 * at + comp;
+        atomicAdd(acc, (unsigned long long)__float2ll_rn(v * 4294967296.0f));
+    } else {
+        atomicAdd(grad_coords + 3 * at + comp, v);
+    }
+}
+
+template <int NA, int NZ, bool VIRIAL, bool FIXED>
 __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
@@ -1030,10 +1044,9 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                         af[e] = make_float4(ca.x, ca.y, inv, d.w);
                         if (!gat) { gx[e] = Gx; gy[e] = Gy; gz[e] = Gz; }   // pushed with the angular part (plane 0)
                     } else if (!gat) {
-                        float *gc = grad_coords + 3 * (size_t)jn;
-                        atomicAdd(gc + 0, Gx);
-                        atomicAdd(gc + 1, Gy);
-                        atomicAdd(gc + 2, Gz);
+                        push_grad<FIXED>(grad_coords, (size_t)jn, 0, Gx);
+                        push_grad<FIXED>(grad_coords, (size_t)jn, 1, Gy);
+                        push_grad<FIXED>(grad_coords, (size_t)jn, 2, Gz);
                     }
                 }
             }
@@ -1157,10 +1170,10 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
                 z += gz[pp * n + e];
             }
             const float4 fa = af[e];
-            float *gc = grad_coords + 3 * (size_t)(__float_as_uint(fa.w) & IDX_MASK);
-            atomicAdd(gc + 0, x);
-            atomicAdd(gc + 1, y);
-            atomicAdd(gc + 2, z);
+            const size_t jat = (size_t)(__float_as_uint(fa.w) & IDX_MASK);
+            push_grad<FIXED>(grad_coords, jat, 0, x);
+            push_grad<FIXED>(grad_coords, jat, 1, y);
+            push_grad<FIXED>(grad_coords, jat, 2, z);
             sx += x; sy += y; sz_ += z;
             if (VIRIAL) {
                 const float4 u = nb[e];   // unit vector, 0.5 qA r
@@ -1172,10 +1185,9 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
         }
         sx = wave_sum(sx); sy = wave_sum(sy); sz_ = wave_sum(sz_);
         if (lane == 0) {
-            float *gc = grad_coords + 3 * (size_t)i;
-            atomicAdd(gc + 0, -sx);
-            atomicAdd(gc + 1, -sy);
-            atomicAdd(gc + 2, -sz_);
+            push_grad<FIXED>(grad_coords, (size_t)i, 0, -sx);
+            push_grad<FIXED>(grad_coords, (size_t)i, 1, -sy);
+            push_grad<FIXED>(grad_coords, (size_t)i, 2, -sz_);
         }
         wave_sync();
     }
@@ -1298,7 +1310,7 @@ extern "C" int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const fl
 static int aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms, int64_t lo,
                         int64_t hi, const int32_t *species, const uint32_t *meta, const float *ent,
                         const float *grad_aev, float *grad_coords, double *virial, const uint32_t *slab_mask,
-                        int32_t symmetric)
+                        int32_t flags)
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && grad_aev && grad_coords, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
@@ -1309,19 +1321,23 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
     dim3 grid(persistent_blocks(hi - lo, BWD_WPB, 4)), block(BWD_WPB * WAVE);
     const float4 *e4 = (const float4 *)ent;
     hipStream_t st = (hipStream_t)stream;
+    const bool symmetric = (flags & ANIHIP_BWD_SYMMETRIC) != 0, fixed = (flags & ANIHIP_BWD_FIXED_POINT) != 0;
     const int64_t glo = symmetric ? lo : 0, ghi = symmetric ? hi : 0;   // rows the radial gather may read
-    if (p->n_shf_a == 8 && !virial)
-        hipLaunchKernelGGL((k_aev_bwd<8, 4, false>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial, slab_mask, glo, ghi);
-    else if (p->n_shf_a == 8)
-        hipLaunchKernelGGL((k_aev_bwd<8, 4, true>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial, slab_mask, glo, ghi);
-    else if (!virial)
-        hipLaunchKernelGGL((k_aev_bwd<4, 8, false>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial, slab_mask, glo, ghi);
-    else
-        hipLaunchKernelGGL((k_aev_bwd<4, 8, true>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, grad_aev,
-                           grad_coords, virial, slab_mask, glo, ghi);
+#define ANIHIP_LAUNCH_BWD(NA_, NZ_, VIR_, FIX_)                                                                      \
+    hipLaunchKernelGGL((k_aev_bwd<NA_, NZ_, VIR_, FIX_>), grid, block, 0, st, a, table, lo, hi, species, meta, e4,   \
+                       grad_aev, grad_coords, virial, slab_mask, glo, ghi)
+    const int variant = (p->n_shf_a == 8 ? 0 : 4) + (virial ? 2 : 0) + (fixed ? 1 : 0);
+    switch (variant) {
+        case 0: ANIHIP_LAUNCH_BWD(8, 4, false, false); break;
+        case 1: ANIHIP_LAUNCH_BWD(8, 4, false, true); break;
+        case 2: ANIHIP_LAUNCH_BWD(8, 4, true, false); break;
+        case 3: ANIHIP_LAUNCH_BWD(8, 4, true, true); break;
+        case 4: ANIHIP_LAUNCH_BWD(4, 8, false, false); break;
+        case 5: ANIHIP_LAUNCH_BWD(4, 8, false, true); break;
+        case 6: ANIHIP_LAUNCH_BWD(4, 8, true, false); break;
+        default: ANIHIP_LAUNCH_BWD(4, 8, true, true); break;
+    }
+#undef ANIHIP_LAUNCH_BWD
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1329,22 +1345,22 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
 extern "C" int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table,
                                    int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
                                    const uint32_t *meta, const float *ent, const float *grad_aev,
-                                   const uint32_t *slab_mask, int32_t symmetric, float *grad_coords,
+                                   const uint32_t *slab_mask, int32_t flags, float *grad_coords,
                                    uint32_t *status)
 {
     (void)status;
     return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, nullptr,
-                        slab_mask, symmetric);
+                        slab_mask, flags);
 }
 
 extern "C" int anihip_aev_backward_virial(void *stream, const anihip_aev_params *p, const float *table,
                                           int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
                                           const uint32_t *meta, const float *ent, const float *grad_aev,
-                                          const uint32_t *slab_mask, int32_t symmetric, float *grad_coords,
+                                          const uint32_t *slab_mask, int32_t flags, float *grad_coords,
                                           double *virial, uint32_t *status)
 {
     (void)status;
     ANIHIP_REQUIRE(virial, "null pointer argument");
     return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, virial,
-                        slab_mask, symmetric);
+                        slab_mask, flags);
 }

@@ -122,8 +122,11 @@ __device__ __forceinline__ int64_t tm_species_base(const int *ctl, const int *H,
 
 constexpr int SP_CHUNK = 1024;  // atoms per wave in the bucketing kernels
 
-// each wave owns a contiguous chunk: one atomic per species per chunk instead of per 64 atoms
-__global__ void k_sp_count(int64_t lo, int64_t hi, const int32_t *species, int S, int *ctl)
+// Stable counting sort of the atoms lo..hi by species: count per 1024-atom chunk (one wave each) -> exclusive scan
+// over the chunks -> scatter.  No atomics: the sorted order (index order inside a species) and with it the row tiles,
+// their maxima and every rounding downstream are the same from run to run.  chunk_cnt: [n_chunks][MAX_S] ints of
+// scratch (the launcher lends the not yet written member_part buffer).
+__global__ void k_sp_count(int64_t lo, int64_t hi, const int32_t *species, int S, int *chunk_cnt)
 {
     const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t c0 = lo + wave * SP_CHUNK;
@@ -138,49 +141,73 @@ __global__ void k_sp_count(int64_t lo, int64_t hi, const int32_t *species, int S
         for (int t = 0; t < MAX_S; ++t)
             if (t < S) cnt[t] += __popcll(__ballot(sp == t));
     }
-    if (lane_id() == 0) {
+    if (lane_id() < MAX_S) {
+        int v = 0;
 #pragma unroll
-        for (int t = 0; t < MAX_S; ++t)
-            if (t < S && cnt[t]) atomicAdd(&ctl[CTL_CNT + t], cnt[t]);
+        for (int t = 0; t < MAX_S; ++t) v = lane_id() == t ? cnt[t] : v;
+        chunk_cnt[wave * MAX_S + lane_id()] = v;
     }
 }
 
-__global__ void k_sp_offsets(int S, int *ctl)
+// one workgroup: chunk_cnt[c][t] -> number of atoms of species t in the chunks before c; totals / offsets -> ctl
+__global__ __launch_bounds__(256) void k_sp_offsets(int S, int n_chunks, int *chunk_cnt, int *ctl)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int run = 0, trun = 0;
-    for (int t = 0; t < S; ++t) {
-        ctl[CTL_OFF + t] = run;
-        ctl[CTL_TILE + t] = trun;
-        ctl[CTL_CURSOR + t] = run;
-        run += ctl[CTL_CNT + t];
-        trun += (ctl[CTL_CNT + t] + BM - 1) / BM;
+    __shared__ int s_sum[256][MAX_S];
+    const int tid = threadIdx.x;
+    const int per = (n_chunks + 255) / 256;
+    const int c0 = tid * per, c1 = min(n_chunks, c0 + per);
+    int loc[MAX_S];
+#pragma unroll
+    for (int t = 0; t < MAX_S; ++t) loc[t] = 0;
+    for (int c = c0; c < c1; ++c)
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) loc[t] += chunk_cnt[c * MAX_S + t];
+#pragma unroll
+    for (int t = 0; t < MAX_S; ++t) s_sum[tid][t] = loc[t];
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {   // inclusive scan over the threads
+        int add[MAX_S];
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) add[t] = tid >= o ? s_sum[tid - o][t] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) s_sum[tid][t] += add[t];
+        __syncthreads();
     }
-    ctl[CTL_OFF + S] = run;
-    ctl[CTL_TILE + S] = trun;
+    int run[MAX_S];
+#pragma unroll
+    for (int t = 0; t < MAX_S; ++t) run[t] = s_sum[tid][t] - loc[t];   // exclusive
+    for (int c = c0; c < c1; ++c)
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) {
+            const int v = chunk_cnt[c * MAX_S + t];
+            chunk_cnt[c * MAX_S + t] = run[t];
+            run[t] += v;
+        }
+    if (tid == 0) {
+        int tot = 0, trun = 0;
+        for (int t = 0; t < S; ++t) {
+            const int cnt = s_sum[255][t];
+            ctl[CTL_CNT + t] = cnt;
+            ctl[CTL_OFF + t] = tot;
+            ctl[CTL_TILE + t] = trun;
+            tot += cnt;
+            trun += (cnt + BM - 1) / BM;
+        }
+        ctl[CTL_OFF + S] = tot;
+        ctl[CTL_TILE + S] = trun;
+    }
 }
 
-__global__ void k_sp_scatter(int64_t lo, int64_t hi, const int32_t *species, int S, int *ctl, int *perm)
+__global__ void k_sp_scatter(int64_t lo, int64_t hi, const int32_t *species, int S, const int *ctl,
+                             const int *chunk_cnt, int *perm)
 {
     const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t c0 = lo + wave * SP_CHUNK;
     if (c0 >= hi) return;
     int base[MAX_S];
 #pragma unroll
-    for (int t = 0; t < MAX_S; ++t) base[t] = 0;
-    for (int it = 0; it < SP_CHUNK / WAVE; ++it) {
-        const int64_t i = c0 + it * WAVE + lane_id();
-        const int sp = (i < hi) ? species[i] : -1;
-#pragma unroll
-        for (int t = 0; t < MAX_S; ++t)
-            if (t < S) base[t] += __popcll(__ballot(sp == t));
-    }
-#pragma unroll
-    for (int t = 0; t < MAX_S; ++t) {
-        int b = 0;
-        if (t < S && base[t] && lane_id() == 0) b = atomicAdd(&ctl[CTL_CURSOR + t], base[t]);
-        base[t] = __shfl(b, 0);
-    }
+    for (int t = 0; t < MAX_S; ++t) base[t] = t < S ? ctl[CTL_OFF + t] + chunk_cnt[wave * MAX_S + t] : 0;
     for (int it = 0; it < SP_CHUNK / WAVE; ++it) {
         const int64_t i = c0 + it * WAVE + lane_id();
         const int sp = (i < hi) ? species[i] : -1;
@@ -2109,9 +2136,13 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
     const unsigned nblk = (unsigned)((n + 255) / 256);
     const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
-    hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl);
-    hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(64), 0, stream, S, w.ctl);
-    hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, w.perm);
+    {   // (scratch: the per-member energies buffer is written only later)
+        int *chunk_cnt = reinterpret_cast<int *>(w.member_part);
+        const int n_chunks = (int)((n + SP_CHUNK - 1) / SP_CHUNK);
+        hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, chunk_cnt);
+        hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(256), 0, stream, S, n_chunks, chunk_cnt, w.ctl);
+        hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm);
+    }
     hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
                        atomic_e, grad_aev, L, member_e, M, n_atoms);
 
@@ -2351,9 +2382,13 @@ static int train_forward(hipStream_t stream, const anihip_mlp_desc *d, int64_t n
     zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
     const unsigned nblk = (unsigned)((n + 255) / 256);
     const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
-    hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl);
-    hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(64), 0, stream, S, w.ctl);
-    hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, w.perm);
+    {   // (scratch: the per-member energies buffer is written only later)
+        int *chunk_cnt = reinterpret_cast<int *>(w.member_part);
+        const int n_chunks = (int)((n + SP_CHUNK - 1) / SP_CHUNK);
+        hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, chunk_cnt);
+        hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(256), 0, stream, S, n_chunks, chunk_cnt, w.ctl);
+        hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm);
+    }
     hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
                        atomic_e, grad_aev, L, (float *)nullptr, M, n_atoms);
     for (int l = 0; l < nh; ++l) {

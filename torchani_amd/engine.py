@@ -268,12 +268,15 @@ class AevEngine:
 
     def backward(self, species: Tensor, nbrs: NeighborRows, grad_aev: Tensor,
                  grad_coords: tp.Optional[Tensor] = None, shard_rows: bool = False,
-                 virial: tp.Optional[Tensor] = None, slab_mask: tp.Optional[Tensor] = None) -> Tensor:
+                 virial: tp.Optional[Tensor] = None, slab_mask: tp.Optional[Tensor] = None,
+                 fixed_point: bool = False) -> Tensor:
         """grad_coords [N,3] += d(sum grad_aev*aev)/d coords for the central atoms of nbrs.
         shard_rows=True: grad_aev holds only the rows lo..hi.
         slab_mask (int32 [N], as written by forward): grad_aev is valid only inside the flagged slabs of each row
         (what PackedNetworks.forward_backward leaves behind); None: whole rows are valid.
-        virial (optional float64 [3,3], overwritten): sum_ij dE/d d_ij (x) d_ij over those central atoms."""
+        virial (optional float64 [3,3], overwritten): sum_ij dE/d d_ij (x) d_ij over those central atoms.
+        fixed_point=True: grad_coords is an int64 [N,3] accumulator in units of 2^-32 (ANIHIP_BWD_FIXED_POINT): the sums
+        are order-independent, i.e. bit-reproducible; convert with ``fixed_to_float``."""
         _require_cuda(species, grad_aev, slab_mask)
         n = species.numel()
         assert grad_aev.dtype == torch.float32 and grad_aev.is_contiguous()
@@ -281,10 +284,12 @@ class AevEngine:
         if slab_mask is not None:
             assert slab_mask.dtype == torch.int32 and slab_mask.numel() == n and slab_mask.is_contiguous()
         if grad_coords is None:
-            grad_coords = torch.zeros((n, 3), dtype=torch.float32, device=species.device)
+            grad_coords = torch.zeros((n, 3), dtype=torch.int64 if fixed_point else torch.float32, device=species.device)
+        assert grad_coords.dtype == (torch.int64 if fixed_point else torch.float32) and grad_coords.is_contiguous()
+        flags = (_lib.BWD_SYMMETRIC if nbrs.symmetric else 0) | (_lib.BWD_FIXED_POINT if fixed_point else 0)
         args = (_stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
                 _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent),
-                _row_ptr(grad_aev, nbrs.lo if shard_rows else 0, self.L), _ptr(slab_mask), int(nbrs.symmetric),
+                _row_ptr(grad_aev, nbrs.lo if shard_rows else 0, self.L), _ptr(slab_mask), flags,
                 _ptr(grad_coords))
         if virial is None:
             _lib.check(_lib.lib().anihip_aev_backward(*args, _ptr(nbrs.status)))
@@ -293,6 +298,14 @@ class AevEngine:
             assert virial.dtype == torch.float64 and virial.is_contiguous() and virial.numel() == 9
             _lib.check(_lib.lib().anihip_aev_backward_virial(*args, _ptr(virial), _ptr(nbrs.status)))
         return grad_coords
+
+
+FIXED_SCALE = 2.0 ** -32
+
+
+def fixed_to_float(acc: Tensor) -> Tensor:
+    """int64 fixed-point accumulators (units of 2^-32) -> float32."""
+    return (acc.to(torch.float64) * FIXED_SCALE).to(torch.float32)
 
 
 def _pad32(x: int) -> int:

@@ -23,7 +23,7 @@ from torch import Tensor
 from .aev import AEVComputer
 from ._lib import MAX_RAD
 from .constants import GSAES_WB97X_631GD
-from .engine import energy_reduce
+from .engine import FIXED_SCALE, energy_reduce, fixed_to_float
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import join_exact, shard_range, split_exact
 from .tuples import EnergiesScalars, AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
@@ -55,6 +55,10 @@ class ANI(torch.nn.Module):
         self.cutoff = aev_computer.radial.cutoff
         self.mlp_chunk = 1 << 18
         self.last_collective: tp.Optional[dict] = None   # what the last sharded energies_and_forces all-reduced
+        # True: energies_and_forces accumulates forces in int64 fixed point (2^-32 Ha/A): bit-identical results from
+        # run to run and for any number of ranks' reduction order, at the price of 24 instead of 12 bytes per atom of
+        # accumulator traffic (the reference's cuAEV backward is not reproducible: float atomics, csrc/aev.cu:700-704)
+        self.deterministic_forces = False
 
     # arch.py:263-275 convenience accessors
     @property
@@ -157,30 +161,50 @@ class ANI(torch.nn.Module):
                                                         shard_rows=True)
         virial = torch.empty((3, 3), dtype=torch.float64, device=c32.device) if stress else None
         world = 1 if group is None else torch.distributed.get_world_size(group)
-        # forces are accumulated straight into the buffer that a sharded run all-reduces: [3 n forces | 4 C energy
-        # parts | 36 virial parts]
-        n_tail = (4 * C + (36 if stress else 0)) if world > 1 else 0
-        red = torch.zeros(3 * n + n_tail, dtype=torch.float32, device=c32.device)
-        grad_coords = eng.backward(species32, nbrs, grad_aev, grad_coords=red[:3 * n].view(n, 3), shard_rows=True,
-                                   virial=virial, slab_mask=slab_mask)
         sae = None
         if self.energy_shifter._enabled:
             sae = self.energy_shifter.self_energies.to(device=c32.device, dtype=torch.float64)
-        energies = energy_reduce(species32, atomic_e, sae, lo, hi)
-        forces = grad_coords.neg_().view(C, A, 3)
-        if world > 1:
-            # ONE collective per step: the fp64 partial energies (and virial) ride in the fp32 force buffer as four
-            # exactly-summable fp32 parts each (parallel.split_exact), so the sum over ranks is exact and independent
-            # of the reduction order
-            red[3 * n:3 * n + 4 * C] = split_exact(energies).reshape(-1)
-            if stress:
-                red[3 * n + 4 * C:] = split_exact(virial.reshape(-1)).reshape(-1)
-            torch.distributed.all_reduce(red if reduce_forces else red[3 * n:], group=group)
-            energies = join_exact(red[3 * n:3 * n + 4 * C].view(C, 4))
-            if stress:
-                virial = join_exact(red[3 * n + 4 * C:].view(9, 4)).view(3, 3)
-            self.last_collective = {"collectives_per_step": 1, "world_size": world,
-                                    "bytes": 4 * (red.numel() if reduce_forces else n_tail)}
+        if self.deterministic_forces:
+            # order-independent sums: int64 fixed-point accumulators (2^-32) for the forces (ANIHIP_BWD_FIXED_POINT), and
+            # for a sharded run ONE int64 all-reduce that also carries energies and virial at the same resolution
+            n_tail = (C + (9 if stress else 0)) if world > 1 else 0
+            red = torch.zeros(3 * n + n_tail, dtype=torch.int64, device=c32.device)
+            eng.backward(species32, nbrs, grad_aev, grad_coords=red[:3 * n].view(n, 3), shard_rows=True,
+                         virial=virial, slab_mask=slab_mask, fixed_point=True)
+            energies = energy_reduce(species32, atomic_e, sae, lo, hi)
+            if world > 1:
+                red[3 * n:3 * n + C] = torch.round(energies / FIXED_SCALE).to(torch.int64)
+                if stress:
+                    red[3 * n + C:] = torch.round(virial.reshape(-1) / FIXED_SCALE).to(torch.int64)
+                torch.distributed.all_reduce(red if reduce_forces else red[3 * n:], group=group)
+                energies = red[3 * n:3 * n + C].to(torch.float64) * FIXED_SCALE
+                if stress:
+                    virial = (red[3 * n + C:].to(torch.float64) * FIXED_SCALE).view(3, 3)
+                self.last_collective = {"collectives_per_step": 1, "world_size": world,
+                                        "bytes": 8 * (red.numel() if reduce_forces else n_tail)}
+            forces = fixed_to_float(red[:3 * n]).neg_().view(C, A, 3)
+        else:
+            # forces are accumulated straight into the buffer that a sharded run all-reduces: [3 n forces | 4 C energy
+            # parts | 36 virial parts]
+            n_tail = (4 * C + (36 if stress else 0)) if world > 1 else 0
+            red = torch.zeros(3 * n + n_tail, dtype=torch.float32, device=c32.device)
+            grad_coords = eng.backward(species32, nbrs, grad_aev, grad_coords=red[:3 * n].view(n, 3), shard_rows=True,
+                                       virial=virial, slab_mask=slab_mask)
+            energies = energy_reduce(species32, atomic_e, sae, lo, hi)
+            forces = grad_coords.neg_().view(C, A, 3)
+            if world > 1:
+                # ONE collective per step: the fp64 partial energies (and virial) ride in the fp32 force buffer as four
+                # exactly-summable fp32 parts each (parallel.split_exact), so the sum over ranks is exact and
+                # independent of the reduction order
+                red[3 * n:3 * n + 4 * C] = split_exact(energies).reshape(-1)
+                if stress:
+                    red[3 * n + 4 * C:] = split_exact(virial.reshape(-1)).reshape(-1)
+                torch.distributed.all_reduce(red if reduce_forces else red[3 * n:], group=group)
+                energies = join_exact(red[3 * n:3 * n + 4 * C].view(C, 4))
+                if stress:
+                    virial = join_exact(red[3 * n + 4 * C:].view(9, 4)).view(3, 3)
+                self.last_collective = {"collectives_per_step": 1, "world_size": world,
+                                        "bytes": 4 * (red.numel() if reduce_forces else n_tail)}
         if check_overflow:
             nbrs.raise_on_overflow()
         aevc._last_neighbors = nbrs
