@@ -39,11 +39,24 @@ def measure(dev=None, reps2=50, reps3=20):
     n_real = int((sp >= 0).sum())
     model = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="batch")
     spd, xd = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev)
+    model.auto_graph_atoms = 0
     dt = timeit(lambda: model.energies_and_forces(spd, xd, check_overflow=False), reps=reps2)
     f = model.graphed(spd, xd)
     dtg = timeit(lambda: f(xd), reps=reps2)
+    model.auto_graph_atoms = 32768   # the default: energies_and_forces itself replays a graph from the third call on
+    dta = timeit(lambda: model.energies_and_forces(spd, xd), reps=reps2)
     out["config2"] = {"workload": f"256 molecules (13.xyz / 28.xyz frames 0-127, A = 28, {n_real} real atoms), batch mode",
-                      "ms_eager": dt * 1e3, "ms_graph_replay": dtg * 1e3, "atom_steps_per_s_graph": n_real / dtg}
+                      "ms_eager": dt * 1e3, "ms_graph_replay": dtg * 1e3, "ms_default_api": dta * 1e3,
+                      "atom_steps_per_s_graph": n_real / dtg}
+    if os.environ.get("BENCH_CONFIGS_VARIANTS"):   # development: layer-0 tile choice at this size
+        from torchani_amd import _lib
+        from torchani_amd.engine import PackedNetworks
+
+        for nm, fl in (("big_tiles", _lib.MLP_FLAG_BIG_TILES), ("no_fused", _lib.MLP_FLAG_NO_FUSED)):
+            PackedNetworks.default_flags = fl
+            g2 = model.graphed(spd, xd)
+            out["config2"]["ms_graph_" + nm] = timeit(lambda: g2(xd), reps=reps2) * 1e3
+        PackedNetworks.default_flags = 0
     model3 = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="cell")
     for key, name in (("config3", "cfg3_1hz5_water_ani2x"), ("config3_1c17", "cfg3_1c17_ani2x")):
         with np.load(os.path.join(GOLD, name + ".npz")) as z:

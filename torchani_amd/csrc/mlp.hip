@@ -1914,19 +1914,26 @@ __global__ __launch_bounds__(256) void k_repack(RepackArgs g)
 }
 
 // padding atoms inside the shard: zero energy / zero gradient rows
+static inline unsigned zero_pad_blocks(int64_t n)   // one wave per atom, four per block
+{
+    const int64_t b = (n + 3) / 4;
+    return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
 __global__ void k_zero_padding(int64_t lo, int64_t hi, const int32_t *species, float *atomic_e,
                                float *grad_aev, int L, float *member_e, int M, int64_t n_atoms)
 {
+    // one wave per atom (grid-stride), 16-B stores (L is a multiple of 4: aev_len % 16 == 0)
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t i = lo + blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6); i < hi; i += nw) {
         if (species[i] >= 0) continue;
-        if (lane_id() == 0) {
-            atomic_e[i] = 0.f;
-            if (member_e)
-                for (int m = 0; m < M; ++m) member_e[(int64_t)m * n_atoms + i] = 0.f;
+        if (lane_id() == 0) atomic_e[i] = 0.f;
+        if (member_e && lane_id() < M) member_e[(int64_t)lane_id() * n_atoms + i] = 0.f;
+        if (grad_aev) {
+            float4 *row = reinterpret_cast<float4 *>(grad_aev + (size_t)i * L);
+            for (int f = lane_id(); f < (L >> 2); f += WAVE) row[f] = z4;
         }
-        if (grad_aev)
-            for (int f = lane_id(); f < L; f += WAVE) grad_aev[(size_t)i * L + f] = 0.f;
     }
 }
 
@@ -2143,7 +2150,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(256), 0, stream, S, n_chunks, chunk_cnt, w.ctl);
         hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm);
     }
-    hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
+    hipLaunchKernelGGL(k_zero_padding, dim3(zero_pad_blocks(n)), dim3(256), 0, stream, lo, hi, species,
                        atomic_e, grad_aev, L, member_e, M, n_atoms);
 
     const int nrow_ub = (int)((n + BM - 1) / BM) + S;
@@ -2389,7 +2396,7 @@ static int train_forward(hipStream_t stream, const anihip_mlp_desc *d, int64_t n
         hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(256), 0, stream, S, n_chunks, chunk_cnt, w.ctl);
         hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm);
     }
-    hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
+    hipLaunchKernelGGL(k_zero_padding, dim3(zero_pad_blocks(n)), dim3(256), 0, stream, lo, hi, species,
                        atomic_e, grad_aev, L, (float *)nullptr, M, n_atoms);
     for (int l = 0; l < nh; ++l) {
         GemmArgs g{};
@@ -2533,8 +2540,7 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
     if (!forward_done) {
         if (int rc = train_forward(stream, d, n_atoms, lo, hi, species, aev, w, atomic_e, grad_aev)) return rc;
     } else if (grad_aev) {
-        const unsigned nblk = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_zero_padding, dim3(nblk > 2048 ? 2048 : nblk), dim3(256), 0, stream, lo, hi, species,
+        hipLaunchKernelGGL(k_zero_padding, dim3(zero_pad_blocks(n)), dim3(256), 0, stream, lo, hi, species,
                            atomic_e, grad_aev, L, (float *)nullptr, M, n_atoms);
     }
     const int nrow_ub = (int)((n + BM - 1) / BM) + S;

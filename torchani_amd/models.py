@@ -59,6 +59,10 @@ class ANI(torch.nn.Module):
         # run to run and for any number of ranks' reduction order, at the price of 24 instead of 12 bytes per atom of
         # accumulator traffic (the reference's cuAEV backward is not reproducible: float atomics, csrc/aev.cu:700-704)
         self.deterministic_forces = False
+        # energies_and_forces replays systems of at most this many atoms as a HIP graph once the same species tensor
+        # has been seen three times (launch-bound sizes; 0 disables)
+        self.auto_graph_atoms = 32768
+        self._graphs: tp.Dict[tuple, list] = {}
 
     # arch.py:263-275 convenience accessors
     @property
@@ -119,6 +123,9 @@ class ANI(torch.nn.Module):
         """
         if not coords.is_cuda:
             raise ValueError("torchani_amd's engine needs tensors on a ROCm device (no CPU fallback)")
+        out = self._auto_graph_call(species, coords, cell, pbc, group, shard, stress, check_overflow)
+        if out is not None:
+            return out
         elem_idxs = self._elem_idxs(species)
         species32 = elem_idxs.to(torch.int32).contiguous()
         c32 = coords.detach().to(torch.float32).contiguous()
@@ -136,6 +143,43 @@ class ANI(torch.nn.Module):
                                                          stress)
                 aevc.last_neighbors().raise_on_overflow()
         return out
+
+    def _auto_graph_call(self, species, coords, cell, pbc, group, shard, stress, check_overflow):
+        """Small systems are launch-bound (~25 kernels of a few microseconds): from the third call with the SAME species
+        tensor (identity and version -- an MD loop, a batch re-evaluated with new coordinates) and shapes, the step is
+        replayed as one HIP graph (GraphedEnergiesForces); results are copied out of the graph's static buffers.
+        Returns None when the call does not qualify (large system, sharded, stress, capture in progress, ...)."""
+        n = species.numel()
+        if (self.auto_graph_atoms <= 0 or n > self.auto_graph_atoms or group is not None or shard is not None or stress
+                or self.deterministic_forces or self.aev_computer.verlet is not None   # (its displacement check syncs)
+                or torch.cuda.is_current_stream_capturing()):
+            return None
+        pbc_key = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
+        key = (species.data_ptr(), species._version, tuple(species.shape), coords.device, cell is None, pbc_key)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if len(self._graphs) >= 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = ent = [0, None]
+        ent[0] += 1
+        if ent[0] < 3:
+            return None
+        if ent[1] is None:
+            try:
+                ent[1] = GraphedEnergiesForces(self, species, coords, cell, pbc)
+            except RuntimeError as err:   # something on the path cannot be captured: stay eager for good
+                warnings.warn(f"HIP graph capture of energies_and_forces failed ({err}); continuing without graphs")
+                self.auto_graph_atoms = 0
+                self._graphs.clear()
+                return None
+        out = ent[1](coords.detach(), cell)
+        res = EnergiesForces(out.energies.clone(), out.forces.clone(), out.atomic_energies.clone(), None)
+        if check_overflow:
+            nb = self.aev_computer.last_neighbors()
+            if nb.overflowed():   # (let the eager path retry with larger rows / raise)
+                self._graphs.pop(key, None)
+                return None
+        return res
 
     def _energies_and_forces_core(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces,
                                   check_overflow, shard, stress: bool = False) -> EnergiesForces:
