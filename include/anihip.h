@@ -349,6 +349,20 @@ int anihip_mlp_tangent_weight_grads(void *stream, const anihip_mlp_desc *d, int6
  * bias [out]}; out_in: HOST array [S][n_layers][2] with the (out, in) widths of the source tensors. */
 int anihip_mlp_repack(void *stream, const anihip_mlp_desc *d, const void *const *src, const int32_t *out_in);
 
+/* ---------------------------------------------------------------------------------------------
+ * Pair potentials on the neighbor rows: the xTB repulsion term of the reference's ANI-2xr / ANI-2dr models
+ * (potentials/xtb.py:17-77 RepulsionXTB, envelope and per-atom halves of potentials/core.py:155-207):
+ *   e_ij = y_ab / d * exp(-sqrt(alpha_ab) d^k_ab) * fc(r_ij, cutoff),  d = r_ij in Bohr (r clamped to >= 1e-7 A);
+ * pair_table: device float[8][8][4] = {y_ab, sqrt(alpha_ab), k_ab, 0} indexed [species_i][species_j].
+ * atomic_e[i] += sum_j e_ij / 2 for lo <= i < hi (may be NULL); grad_coords [n_atoms][3] += d(sum of those) / d r (may be
+ * NULL); virial [9] fp64 += sum (dE_i / d d_ij) (x) d_ij (may be NULL).  cutoff must not exceed the radial cutoff the rows
+ * were built with.  Symmetric rows (every builder except anihip_nbr_from_full): no atomics, each atom completes its own
+ * entries, deterministic; pass ANIHIP_PAIR_PUSH for asymmetric rows. */
+#define ANIHIP_PAIR_PUSH 1
+int anihip_pair_xtb_repulsion(void *stream, int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                              const uint32_t *meta, const float *ent, const float *pair_table, float cutoff,
+                              int32_t cutoff_kind, int32_t flags, float *atomic_e, float *grad_coords, double *virial);
+
 /* mol_e[c] (fp64) = sum_a atomic_e[c,a] + sae[species[c,a]] over the atoms lo <= c*A+a < hi; padding
  * contributes nothing (sae.py:54-64).  sae may be NULL.  mol_e is overwritten. */
 int anihip_energy_reduce(void *stream, int32_t n_mol, int32_t n_atoms_per_mol, int64_t lo, int64_t hi,

@@ -726,6 +726,54 @@ def test_config3_reference_inputs(dev, name):
     assert np.abs(-gx.cpu().numpy()[0, pick] - g["forces_sample"]).max() < F_TOL
 
 
+@pytest.mark.parametrize("case", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x", "triclinic_pbc_ani2x",
+                                  "cos_water_pbc_ani2x"])
+def test_xtb_repulsion_matches_reference(dev, case):
+    """RepulsionXTB (potentials/xtb.py) on the engine's neighbor rows against the reference's fp64 values
+    (tests/golden/gen_golden_pairs.py): per-atom halves, molecular energies, forces; alone, through the model's autograd
+    path and inside energies_and_forces (NN + pair term), incl. a pair cutoff beyond the AEV's radial cutoff."""
+    from torchani_amd.models import ANI2x
+    from torchani_amd.potentials import RepulsionXTB
+
+    name = case[4:] if case.startswith("cos_") else case
+    g = load_golden(name)
+    ref = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"pairs_{case}.npz")))
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False,
+                  neighborlist=modes_for(g)[-1], row_capacity=256)
+    pot = RepulsionXTB(g["symbols"], cutoff=float(ref["cutoff"]), cutoff_fn=str(ref["cutoff_fn"])).to(dev)
+    sp32 = sp.to(torch.int32).contiguous()
+    rows = model._pair_rows(pot, sp32, x, cell, pbc)   # rows with the pair potential's own cutoff
+    n = sp32.numel()
+    ae = torch.zeros(n, dtype=torch.float32, device=dev)
+    gc = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+    pot.accumulate(sp32, rows, ae, gc)
+    torch.cuda.synchronize()
+    rows.raise_on_overflow()
+    escale = max(1.0, np.abs(ref["atomic_energies"]).max())
+    fscale = max(1.0, np.abs(ref["forces"]).max())
+    ea = np.abs(ae.cpu().numpy().reshape(ref["atomic_energies"].shape) - ref["atomic_energies"]).max()
+    fe = np.abs(-gc.cpu().numpy().reshape(ref["forces"].shape) - ref["forces"]).max()
+    report(f"xtb   {case:24s} max|e_atom err| = {ea:.2e} (scale {escale:.1f})  |F err| = {fe:.2e} (scale {fscale:.1f})")
+    assert ea < 2e-6 * escale and fe < 5e-6 * fscale
+    # inside the model: NN + repulsion
+    model.add_pair_potential("repulsion_xtb", pot)
+    out = model.energies_and_forces(sp, x, cell, pbc)
+    e_ref = g["energies"] + ref["energies"]
+    f_ref = g["forces"] + ref["forces"]
+    assert np.abs(out.energies.cpu().numpy() - e_ref).max() < 1e-5 * max(1.0, np.abs(e_ref).max() * 1e-2) + 2e-6 * escale * sp.shape[1]
+    assert np.abs(out.forces.cpu().numpy() - f_ref).max() < F_TOL + 5e-6 * fscale
+    xs = x.clone().requires_grad_(True)
+    pbc_t = None if pbc is None else torch.tensor(pbc)
+    e = model((sp, xs), cell, pbc_t).energies
+    (gx,) = torch.autograd.grad(e.sum(), xs)
+    assert np.abs(-gx.cpu().numpy() - f_ref).max() < F_TOL + 5e-6 * fscale
+    # switched off again (arch.py:136-142 set_enabled)
+    model.set_enabled("repulsion_xtb", False)
+    out0 = model.energies_and_forces(sp, x, cell, pbc)
+    assert np.abs(out0.forces.cpu().numpy() - g["forces"]).max() < F_TOL
+
+
 def test_periodic_replica_and_symmetries_at_scale(dev):
     """Size-independent properties at ~0.33 M atoms (no oracle at this size): a periodic box replicated 2 x 2 x 2
     has the same per-atom energies and forces as the original box (every atom sees the same environment), the

@@ -14,7 +14,7 @@ import typing as tp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TORCHANI_AMD_LIB") or os.path.join(_HERE, "libanihip.so")
-SOURCES = ["api.hip", "nbr.hip", "aev.hip", "mlp.hip"]
+SOURCES = ["api.hip", "nbr.hip", "aev.hip", "mlp.hip", "pair.hip"]
 HEADERS = ["anihip_common.h", os.path.join("..", "..", "include", "anihip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared"]
 
@@ -28,6 +28,7 @@ TABLE_FLOATS = 144
 ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
 MLP_FP32, MLP_F16X3 = 0, 1
 BWD_SYMMETRIC, BWD_FIXED_POINT = 1, 2   # flags of anihip_aev_backward
+PAIR_PUSH = 1
 # anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*)
 MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_FUSED_ROWS32, MLP_FLAG_D0_ROWS = \
     1, 2, 4, 8, 16, 32
@@ -161,6 +162,8 @@ def lib() -> C.CDLL:
     L.anihip_mlp_train_forward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, sz, vp]
     L.anihip_mlp_repack.argtypes = [vp, C.POINTER(MlpDesc), vp, vp]
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
+    L.anihip_pair_xtb_repulsion.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, C.c_float, i32, i32, vp, vp, vp]
+    L.anihip_pair_xtb_repulsion.restype = C.c_int
     for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half",
                  "anihip_nbr_from_full", "anihip_nbr_refresh",
                  "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp", "anihip_mlp_forward_backward",
@@ -178,7 +181,7 @@ EXPORTED_SYMBOLS = [
     "anihip_nbr_refresh", "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp",
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
     "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
-    "anihip_mlp_tangent_workspace_bytes", "anihip_mlp_tangent_weight_grads",
+    "anihip_mlp_tangent_workspace_bytes", "anihip_mlp_tangent_weight_grads", "anihip_pair_xtb_repulsion",
 ]
 
 

@@ -22,6 +22,7 @@ from torch import Tensor
 
 from .aev import AEVComputer
 from ._lib import MAX_RAD
+from ._lib import MAX_RAD as _lib_MAX_RAD
 from .constants import GSAES_WB97X_631GD
 from .engine import FIXED_SCALE, energy_reduce, fixed_to_float
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
@@ -97,9 +98,39 @@ class ANI(torch.nn.Module):
         if self.potentials["nnp"]._enabled:
             aevs = self.aev_computer(elem_idxs, coords, cell, pbc)
             energies = energies + self.neural_networks(elem_idxs, aevs, atomic, ensemble_values)
+        for name, pot in self.potentials.items():   # pair potentials on the same neighbor rows (arch.py:329-346)
+            if name == "nnp" or not pot._enabled:
+                continue
+            if atomic:
+                raise NotImplementedError("atomic=True with pair potentials: use energies_and_forces")
+            species32 = elem_idxs.to(torch.int32).contiguous()
+            nbrs = self.aev_computer.last_neighbors() if self.potentials["nnp"]._enabled else None
+            if nbrs is None or pot.cutoff > self.aev_computer.radial.cutoff + 1e-6:
+                nbrs = self._pair_rows(pot, species32, coords, cell, pbc)
+            e_pair = pot.compute_from_rows(species32, coords, nbrs)
+            energies = energies + (e_pair.unsqueeze(0) if ensemble_values else e_pair).to(energies.dtype)
         if self.energy_shifter._enabled:
             energies = energies + self.energy_shifter(elem_idxs, atomic=atomic)
         return SpeciesEnergies(elem_idxs, energies)
+
+    def add_pair_potential(self, name: str, pot: torch.nn.Module) -> "ANI":
+        """Add a pair potential (torchani_amd.potentials.RepulsionXTB) under ``potentials[name]`` (Assembler.add_potential,
+        arch.py:870-893); its energies and forces are included in forward and energies_and_forces."""
+        self.potentials[name] = pot
+        return self
+
+    def _pair_rows(self, pot, species32: Tensor, coords: Tensor, cell, pbc, lo: int = 0, hi: tp.Optional[int] = None):
+        """Neighbor rows for a pair potential whose cutoff exceeds the AEV's radial cutoff (or is infinite): a second
+        engine with that cutoff (rows hold at most 256 neighbors per atom)."""
+        from .engine import AevEngine
+
+        rc = min(pot.cutoff, 1.0e3)
+        if pot._own_engine is None or abs(pot._own_engine.consts.Rcr - rc) > 1e-9:
+            pot._own_engine = AevEngine(self.aev_computer.engine().consts._replace(Rcr=rc, Rca=1e-3))
+        pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
+        c32 = coords.detach().to(torch.float32).contiguous()
+        return pot._own_engine.neighbors(species32, c32, cell, pbc_t, lo=lo, hi=hi, mode=self.aev_computer.neighbor_mode,
+                                         row_cap=_lib_MAX_RAD)
 
     # ---- fused path ---------------------------------------------------------------------------------
     @torch.no_grad()
@@ -204,6 +235,7 @@ class ANI(torch.nn.Module):
                                                         chunk=self.mlp_chunk, slab_mask=slab_mask,
                                                         shard_rows=True)
         virial = torch.empty((3, 3), dtype=torch.float64, device=c32.device) if stress else None
+        pair_e, pair_g, pair_w = self._pair_terms(species32, c32, cell, pbc_t, nbrs, lo, hi, stress)
         world = 1 if group is None else torch.distributed.get_world_size(group)
         sae = None
         if self.energy_shifter._enabled:
@@ -215,7 +247,11 @@ class ANI(torch.nn.Module):
             red = torch.zeros(3 * n + n_tail, dtype=torch.int64, device=c32.device)
             eng.backward(species32, nbrs, grad_aev, grad_coords=red[:3 * n].view(n, 3), shard_rows=True,
                          virial=virial, slab_mask=slab_mask, fixed_point=True)
-            energies = energy_reduce(species32, atomic_e, sae, lo, hi)
+            if pair_g is not None:   # (computed without atomics: deterministic as well)
+                red[:3 * n] += torch.round(pair_g.reshape(-1).to(torch.float64) / FIXED_SCALE).to(torch.int64)
+                if stress:
+                    virial += pair_w
+            energies = energy_reduce(species32, atomic_e if pair_e is None else atomic_e + pair_e, sae, lo, hi)
             if world > 1:
                 red[3 * n:3 * n + C] = torch.round(energies / FIXED_SCALE).to(torch.int64)
                 if stress:
@@ -234,7 +270,11 @@ class ANI(torch.nn.Module):
             red = torch.zeros(3 * n + n_tail, dtype=torch.float32, device=c32.device)
             grad_coords = eng.backward(species32, nbrs, grad_aev, grad_coords=red[:3 * n].view(n, 3), shard_rows=True,
                                        virial=virial, slab_mask=slab_mask)
-            energies = energy_reduce(species32, atomic_e, sae, lo, hi)
+            if pair_g is not None:
+                grad_coords += pair_g
+                if stress:
+                    virial += pair_w
+            energies = energy_reduce(species32, atomic_e if pair_e is None else atomic_e + pair_e, sae, lo, hi)
             forces = grad_coords.neg_().view(C, A, 3)
             if world > 1:
                 # ONE collective per step: the fp64 partial energies (and virial) ride in the fp32 force buffer as four
@@ -253,6 +293,22 @@ class ANI(torch.nn.Module):
             nbrs.raise_on_overflow()
         aevc._last_neighbors = nbrs
         return EnergiesForces(energies, forces, atomic_e.view(C, A), virial)
+
+    def _pair_terms(self, species32: Tensor, c32: Tensor, cell, pbc, nbrs, lo: int, hi: int, stress: bool):
+        """Pair-potential part of this rank's central atoms: (per-atom energies [N] or None, gradient [N, 3], virial)."""
+        pots = [(k, p) for k, p in self.potentials.items() if k != "nnp" and p._enabled]
+        if not pots:
+            return None, None, None
+        n = species32.numel()
+        e = torch.zeros(n, dtype=torch.float32, device=c32.device)
+        g = torch.zeros((n, 3), dtype=torch.float32, device=c32.device)
+        w = torch.zeros((3, 3), dtype=torch.float64, device=c32.device) if stress else None
+        for _, pot in pots:
+            rows = nbrs
+            if pot.cutoff > self.aev_computer.radial.cutoff + 1e-6:
+                rows = self._pair_rows(pot, species32, c32, cell, pbc, lo, hi)
+            pot.accumulate(species32, rows, e, g, w)
+        return e, g, w
 
     def ase(self, overwrite: bool = False, stress_kind: str = "fdotr"):
         """ASE calculator for this model (arch.py ``ANI.ase``, torchani/ase.py:32-173)."""
