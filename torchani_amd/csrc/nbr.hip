@@ -462,8 +462,11 @@ __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_batch(
 __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_cell(
     const GridDesc *g, int S, float rcr2, float rca2, int64_t lo, int64_t hi, const float4 *pos4,
     const int *cellid, const int *cell_start, const float4 *pos4s, int row_cap, uint32_t *meta,
-    float4 *ent, uint32_t *status)
+    float4 *ent, uint32_t *status, const int *handled, const int *n_unhandled)
 {
+    // second pass behind k_nbr_cell2: only the atoms of the cells that kernel left (more candidates than it stages, or a
+    // stencil of more than 64 bins); nothing left -> nothing to do
+    if (n_unhandled && *n_unhandled == 0) return;
     __shared__ float4 s_hits[NBR_WPB][MAXR];
     __shared__ int s_pend[NBR_WPB][WAVE];      // inclusive prefix of the bin populations
     __shared__ int s_k0[NBR_WPB][WAVE];        // sorted position of flat candidate x in bin c: x + k0[c]
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_cell(
             if (lane == 0) { meta_i[1] = 0; meta_i[2] = 0; meta_i[3] = 0; meta_i[4] = 0; meta_i[5] = 0; }
             continue;
         }
+        if (handled && handled[c]) continue;
         const float4 pi = pos4[i];
         // bin coordinates, wave-uniform (scalar registers): one division chain per atom
         const int cu = uniform(c);
@@ -545,6 +549,234 @@ __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_cell(
             wave_sync();
         }
         emit_row(h, S, rca2, row_cap, meta_i, ent + row0, status);
+        wave_sync();
+    }
+}
+
+// (helpers of the cell-centric kernel below)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v);
+// rows of one central atom from its hits in the staged candidate list (see k_nbr_cell2)
+__device__ __forceinline__ void emit_from_stage(const float4 *cand, const uint16_t *hidx, int nh, bool overflow, float4 pa,
+                                                int64_t i, int64_t lo, int row_cap, float rca2, uint32_t cls_mask,
+                                                uint32_t *meta, float4 *ent, uint32_t *status)
+{
+    const int lane = lane_id();
+    // ---- classify {r <= Rca, r > Rca} x species over the species that occur in the stencil; packed byte
+    // counters in scalar registers.  Keys of the (at most MAXR / 64 = 4) chunks of hits stay in registers ----
+    uint32_t *meta_i = meta + (size_t)i * META_W;
+    const size_t row0 = (size_t)(i - lo) * row_cap;
+    float4 *row = ent + row0;
+    int key[MAXR / WAVE];
+    float4 dv[MAXR / WAVE];
+#pragma unroll
+    for (int ch = 0; ch < MAXR / WAVE; ++ch) {
+        key[ch] = 16;
+        dv[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ch * WAVE < nh) {   // (wave-uniform)
+            const int e = ch * WAVE + lane;
+            const bool v = e < nh;
+            const float4 q = cand[v ? hidx[e] : 0];
+            const float dx = q.x - pa.x, dy = q.y - pa.y, dz = q.z - pa.z;
+            dv[ch] = make_float4(dx, dy, dz, q.w);
+            key[ch] = v ? (((dx * dx + dy * dy + dz * dz <= rca2) ? 0 : 8) + (int)(__float_as_uint(q.w) >> 28)) : 16;
+        }
+    }
+    uint64_t pk[2] = {0ull, 0ull};
+    bool big = false;   // a class with more than 255 entries
+    for (uint32_t pm = cls_mask; pm; pm &= pm - 1) {
+        const int k = __builtin_ctz(pm);
+        int pop = 0;
+#pragma unroll
+        for (int ch = 0; ch < MAXR / WAVE; ++ch)
+            if (ch * WAVE < nh) pop += __popcll(__ballot(key[ch] == k));
+        big = big || pop > 255;
+        pk[k >> 3] += (uint64_t)(pop & 255) << (8 * (k & 7));
+    }
+    const int nA = (int)((pk[0] * 0x0101010101010101ull) >> 56), nF = (int)((pk[1] * 0x0101010101010101ull) >> 56);
+    if (lane == 0) meta_i[0] = (uint32_t)row0;
+    if (overflow || big || nA + nF > row_cap || nA > MAXA) {
+        if (lane == 0) {
+            atomicOr(&status[0], ANIHIP_ST_ROW_OVERFLOW);
+            meta_i[1] = 0; meta_i[2] = 0; meta_i[3] = 0; meta_i[4] = 0; meta_i[5] = 0;
+        }
+        return;
+    }
+    // first position of every class: byte prefix sums inside a group, the far group behind the angular one
+    const uint64_t base[2] = {pk[0] * 0x0101010101010100ull, pk[1] * 0x0101010101010100ull};
+    int pos[MAXR / WAVE];
+#pragma unroll
+    for (int ch = 0; ch < MAXR / WAVE; ++ch) pos[ch] = -1;
+    for (uint32_t pm = cls_mask; pm; pm &= pm - 1) {
+        const int k = __builtin_ctz(pm);
+        int first = ((k >> 3) ? nA : 0) + (int)((base[k >> 3] >> (8 * (k & 7))) & 255u);
+#pragma unroll
+        for (int ch = 0; ch < MAXR / WAVE; ++ch)
+            if (ch * WAVE < nh) {
+                const uint64_t m = __ballot(key[ch] == k);
+                if (key[ch] == k) pos[ch] = first + mbcnt(m);
+                first += __popcll(m);
+            }
+    }
+#pragma unroll
+    for (int ch = 0; ch < MAXR / WAVE; ++ch)
+        if (pos[ch] >= 0) row[pos[ch]] = dv[ch];
+    if (lane == 0) {
+        meta_i[1] = (uint32_t)nA | ((uint32_t)nF << 16);
+        meta_i[2] = (uint32_t)pk[0]; meta_i[3] = (uint32_t)(pk[0] >> 32);
+        meta_i[4] = (uint32_t)pk[1]; meta_i[5] = (uint32_t)(pk[1] >> 32);
+    }
+
+}
+
+// ---- cell mode, cell-centric: one wave per BIN ---------------------------------------------------------------------
+// All atoms of a bin see the same 27-bin stencil: the wave resolves it once, stages the candidates -- position already
+// shifted by the bin's image -- in LDS (CAND_CAP entries), and every central atom of the bin then sweeps that list from
+// LDS: no per-candidate binary search, one global read of a candidate per BIN instead of per central atom.  Hits are
+// kept as 16-bit positions in the staged list; the row is classified {angular, far} x species over the classes that
+// actually occur (packed byte counters in scalar registers) and written in the same order as k_nbr_cell writes it.
+// Bins with more candidates than the stage holds, or stencils of more than 64 bins (cells thinner than the cutoff),
+// are left to k_nbr_cell (handled[c] = 0, counted in n_unhandled).
+constexpr int NBR2_WPB = 4;
+constexpr int CAND_CAP = 480;   // (with the other tables: 10 KB of LDS per wave, 16 waves per CU)
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(NBR2_WPB * WAVE) void k_nbr_cell2(
+    const GridDesc *g, int S, float rcr2, float rca2, int64_t lo, int64_t hi, const int *cellid,
+    const int *cell_start, const float4 *pos4s, int row_cap, uint32_t *meta, float4 *ent, uint32_t *status,
+    int *handled, int *n_unhandled)
+{
+    __shared__ float4 s_cand[NBR2_WPB][CAND_CAP];
+    __shared__ uint16_t s_hidx[NBR2_WPB][2 * MAXR];
+    __shared__ int s_pend[NBR2_WPB][WAVE];
+    __shared__ int s_k0[NBR2_WPB][WAVE];
+    __shared__ float4 s_shift[NBR2_WPB][WAVE];
+    const int wib = threadIdx.x >> 6, lane = lane_id();
+    float4 *cand = s_cand[wib];
+    uint16_t *hidx = s_hidx[wib];
+    int *pend = s_pend[wib], *k0t = s_k0[wib];
+    float4 *shift = s_shift[wib];
+    // padding atoms are in no bin: empty rows
+    for (int64_t i = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x)
+        if (cellid[i] < 0) {
+            uint32_t *m = meta + (size_t)i * META_W;
+            m[0] = (uint32_t)((size_t)(i - lo) * row_cap);
+            m[1] = 0; m[2] = 0; m[3] = 0; m[4] = 0; m[5] = 0;
+        }
+    const int nb0 = g->nb[0], nb1 = g->nb[1], nb2 = g->nb[2];
+    const int R0 = g->range[0], R1 = g->range[1], R2 = g->range[2];
+    const int p0 = g->pbc[0], p1 = g->pbc[1], p2 = g->pbc[2];
+    float st[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) st[q] = g->step[q];
+    const int n1 = 2 * R1 + 1, n2 = 2 * R2 + 1, ncells = (2 * R0 + 1) * n1 * n2;
+    const float inv_n2 = 1.0f / (float)n2, inv_n1 = 1.0f / (float)n1;
+    const int nbins = nb0 * nb1 * nb2;
+    const int nw = gridDim.x * NBR2_WPB;
+    for (int c = blockIdx.x * NBR2_WPB + wib; c < nbins; c += nw) {
+        const int ab = cell_start[c], ae = cell_start[c + 1];
+        if (ae == ab) continue;
+        // does this rank own any atom of the bin?
+        bool mine = false;
+        for (int a0 = ab; a0 < ae; a0 += WAVE) {
+            const int a = a0 + lane;
+            const int64_t ia = a < ae ? (int64_t)(__float_as_uint(pos4s[a].w) & IDX_MASK) : -1;
+            mine = mine || __ballot(ia >= lo && ia < hi) != 0ull;
+        }
+        if (!mine) continue;
+        // ---- lane = stencil bin (as in k_nbr_cell) ----
+        const int b2 = c % nb2, b1 = (c / nb2) % nb1, b0 = c / (nb2 * nb1);
+        int total = 0, self_base = 0;
+        if (ncells <= WAVE) {
+            const int ci = lane;
+            const int q2 = (int)(((float)ci + 0.5f) * inv_n2);
+            const int q1 = (int)(((float)q2 + 0.5f) * inv_n1);
+            const int o2 = ci - q2 * n2 - R2, o1 = q2 - q1 * n1 - R1, o0 = q1 - R0;
+            int c0 = b0 + o0, c1 = b1 + o1, c2 = b2 + o2;
+            bool ok = ci < ncells;
+            if (p0) c0 = wrap_bin(c0, nb0); else ok = ok && c0 >= 0 && c0 < nb0;
+            if (p1) c1 = wrap_bin(c1, nb1); else ok = ok && c1 >= 0 && c1 < nb1;
+            if (p2) c2 = wrap_bin(c2, nb2); else ok = ok && c2 >= 0 && c2 < nb2;
+            const int cw = ok ? (c0 * nb1 + c1) * nb2 + c2 : 0;
+            const int kbeg = cell_start[cw], kend = cell_start[cw + 1];
+            const int cnt = ok ? kend - kbeg : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                incl += lane >= d ? up : 0;
+            }
+            total = __builtin_amdgcn_readlane(incl, WAVE - 1);
+            pend[lane] = incl;
+            k0t[lane] = kbeg - (incl - cnt);
+            // (same evaluation order as k_nbr_cell: (o0 s0 + o1 s3) first, o2 s6 added to the sum)
+            shift[lane] = make_float4(o0 * st[0] + o1 * st[3] + o2 * st[6], o0 * st[1] + o1 * st[4] + o2 * st[7],
+                                      o0 * st[2] + o1 * st[5] + o2 * st[8], 0.f);
+            // flat position of the central bin's own atoms (the (0,0,0) entry of the stencil)
+            const bool central = ok && o0 == 0 && o1 == 0 && o2 == 0;
+            const uint64_t cm = __ballot(central);
+            self_base = __builtin_amdgcn_readlane(incl - cnt, (int)__builtin_ctzll(cm | (1ull << 63)));
+        }
+        const bool fits = ncells <= WAVE && total <= CAND_CAP;
+        if (lane == 0) {
+            handled[c] = fits ? 1 : 0;
+            if (!fits) atomicAdd(n_unhandled, 1);
+        }
+        if (!fits) continue;
+        wave_sync();
+        // ---- stage the candidates: position + image shift, w = packed (index | species) ----
+        for (int x0 = 0; x0 < total; x0 += WAVE) {
+            const int x = x0 + lane;
+            if (x < total) {
+                int seg = 0;
+#pragma unroll
+                for (int stp = WAVE / 2; stp > 0; stp >>= 1) seg += pend[seg + stp - 1] <= x ? stp : 0;
+                seg = seg < WAVE ? seg : WAVE - 1;
+                const float4 q = pos4s[x + k0t[seg]];
+                const float4 sh = shift[seg];
+                cand[x] = make_float4(q.x + sh.x, q.y + sh.y, q.z + sh.z, q.w);
+            }
+        }
+        // classes a row of this bin can hold: {angular, far} x the species present in the stencil (bits g * 8 + species)
+        uint32_t cls_mask = 0u;
+        wave_sync();
+        for (int x0 = 0; x0 < total; x0 += WAVE)
+            cls_mask |= (x0 + lane < total) ? 1u << (__float_as_uint(cand[x0 + lane].w) >> 28) : 0u;
+        cls_mask = wave_or(cls_mask);
+        cls_mask = __builtin_amdgcn_readfirstlane(cls_mask | (cls_mask << 8));
+        // ---- every owned atom of the bin sweeps the staged list ----
+        for (int a = ab; a < ae; a += 2) {   // two central atoms per sweep: one LDS read of a candidate serves both
+            const int xa = self_base + (a - ab), xb = xa + 1;
+            const float4 pa = cand[xa];                              // the atoms themselves (zero shift)
+            const float4 pb = cand[a + 1 < ae ? xb : xa];
+            const int64_t ia = (int64_t)(__float_as_uint(pa.w) & IDX_MASK), ib = (int64_t)(__float_as_uint(pb.w) & IDX_MASK);
+            const bool da = ia >= lo && ia < hi, db = a + 1 < ae && ib >= lo && ib < hi;
+            if (!da && !db) continue;
+            int nha = 0, nhb = 0;
+            for (int x0 = 0; x0 < total; x0 += WAVE) {
+                const int x = x0 + lane;
+                const float4 q = cand[x < total ? x : 0];
+                const float ax = q.x - pa.x, ay = q.y - pa.y, az = q.z - pa.z;
+                const float bx = q.x - pb.x, by = q.y - pb.y, bz = q.z - pb.z;
+                const bool hita = da && x < total && ax * ax + ay * ay + az * az <= rcr2 && x != xa;
+                const bool hitb = db && x < total && bx * bx + by * by + bz * bz <= rcr2 && x != xb;
+                const uint64_t ma = __ballot(hita), mb = __ballot(hitb);
+                const int posa = nha + mbcnt(ma), posb = nhb + mbcnt(mb);
+                if (hita && posa < MAXR) hidx[posa] = (uint16_t)x;
+                if (hitb && posb < MAXR) hidx[MAXR + posb] = (uint16_t)x;
+                nha += __popcll(ma);
+                nhb += __popcll(mb);
+            }
+            wave_sync();
+            if (da) emit_from_stage(cand, hidx, nha > MAXR ? MAXR : nha, nha > MAXR, pa, ia, lo, row_cap, rca2, cls_mask, meta, ent, status);
+            if (db) emit_from_stage(cand, hidx + MAXR, nhb > MAXR ? MAXR : nhb, nhb > MAXR, pb, ib, lo, row_cap, rca2, cls_mask, meta, ent, status);
+            wave_sync();
+        }
         wave_sync();
     }
 }
@@ -801,10 +1033,19 @@ extern "C" int anihip_nbr_build_cell(void *stream_, const anihip_aev_params *p, 
                        w.sorted_idx);
     hipLaunchKernelGGL(k_bin_sort_gather, dim3((unsigned)((max_cells + 255) / 256)), dim3(256), 0, stream,
                        w.desc, w.cell_start, w.sorted_idx, w.pos4, w.pos4s);
+    // one wave per bin stages the stencil's candidates in LDS for all atoms of the bin; what it leaves (rare: very dense
+    // bins, cells thinner than the cutoff) goes through the per-atom kernel.  cell_fill / scan_tmp are free by now.
+    int *handled = w.cell_fill, *n_unhandled = w.scan_tmp;
+    zero_words_async(stream, n_unhandled, sizeof(int));
+    const int rc = (int)(row_cap > MAXR ? MAXR : row_cap);
+    int64_t bins_blocks = (max_cells + NBR2_WPB - 1) / NBR2_WPB;
+    if (bins_blocks > 256 * 4) bins_blocks = 256 * 4;   // persistent: 16 waves per CU, each strides over the bins
+    hipLaunchKernelGGL(k_nbr_cell2, dim3((unsigned)bins_blocks), dim3(NBR2_WPB * WAVE), 0, stream, w.desc,
+                       p->num_species, p->Rcr * p->Rcr, p->Rca * p->Rca, lo, hi, w.cellid, w.cell_start, w.pos4s, rc,
+                       meta, (float4 *)ent, status, handled, n_unhandled);
     hipLaunchKernelGGL(k_nbr_cell, dim3(nbr_grid_blocks(hi - lo)), dim3(NBR_WPB * WAVE), 0, stream, w.desc,
                        p->num_species, p->Rcr * p->Rcr, p->Rca * p->Rca, lo, hi, w.pos4, w.cellid,
-                       w.cell_start, w.pos4s, (int)(row_cap > MAXR ? MAXR : row_cap), meta, (float4 *)ent,
-                       status);
+                       w.cell_start, w.pos4s, rc, meta, (float4 *)ent, status, handled, n_unhandled);
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }
