@@ -329,3 +329,56 @@ def test_builtin_factory_signature():
         ANI2x(strategy="numpy")
     with pytest.raises(ValueError, match="float32"):
         ANI2x(dtype=torch.float64)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/torchani"), reason="needs the reference tree (build container only)")
+def test_integration_section_a_against_the_live_reference():
+    """INTEGRATION.md section A, as far as it can run without a GPU: a LIVE reference model's state dict loads into
+    torchani_amd.models.ANI2x strictly (every network / self-energy key found, none unexpected), the two hot components
+    can be assigned into the reference model, and the reference's own call path then reaches our AEVComputer, which
+    refuses CPU tensors loudly (there is no fallback)."""
+    import sys
+    import types
+
+    class _Any:
+        def __class_getitem__(cls, k):
+            return cls
+
+    for name in ("h5py", "zarr"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for k in ("File", "Group", "Dataset", "Datatype"):
+                setattr(m, k, type(k, (_Any,), {}))
+            sys.modules[name] = m
+    os.environ["TORCHANI_NO_WARN_EXTENSIONS"] = "1"
+    sys.path.insert(0, "/root/reference")
+    try:
+        import torchani
+        from torchani.arch import Assembler
+        from torchani.utils import SYMBOLS_2X
+
+        asm = Assembler()
+        asm.set_symbols(SYMBOLS_2X)
+        asm.set_global_cutoff_fn("cosine")
+        asm.set_aev_computer(radial="ani2x", angular="ani2x", strategy="pyaev")
+        asm.set_atomic_networks(ctor="ani2x")
+        asm.set_neighborlist("all_pairs")
+        asm.set_gsaes_as_self_energies("wb97x-631gd")
+        ref = asm.assemble(8)
+        import torchani_amd
+
+        amd = torchani_amd.models.ANI2x(state_dict=ref.state_dict())
+        sd_ref, sd_amd = ref.state_dict(), amd.state_dict()
+        nn_keys = [k for k in sd_ref if "neural_networks" in k or "energy_shifter" in k]
+        assert len(nn_keys) == 8 * 7 * 8 + 1
+        for k in nn_keys:
+            assert torch.equal(sd_ref[k].to(sd_amd[k].dtype), sd_amd[k]), k
+        # swap the two hot components into the reference model (tests/test_neighbors.py:311-312 style)
+        ref.potentials["nnp"].aev_computer = amd.aev_computer
+        ref.potentials["nnp"].neural_networks = amd.neural_networks
+        z = torch.tensor([[6, 1, 1, 1, 1]])
+        x = torch.rand(1, 5, 3)
+        with pytest.raises(ValueError, match="ROCm device"):
+            torchani.grad.energies_and_forces(ref, z, x)
+    finally:
+        sys.path.remove("/root/reference")

@@ -1,6 +1,10 @@
 """Phase timeline of k_mlp_fused from the ANIHIP_FUSED_TRACE stamps (development aid).
 
-    ANIHIP_FUSED_TRACE=/tmp/ft.bin python tools/kbench.py --side 40 --stages mlp --mask on --reps 1
+    (the stamps are compiled out of the shipped library: build a development copy first)
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC -shared -DANIHIP_DEV_TRACE \
+          -o tools/_ab/libanihip_trace.so torchani_amd/csrc/*.hip
+    TORCHANI_AMD_LIB=$PWD/tools/_ab/libanihip_trace.so ANIHIP_FUSED_TRACE=/tmp/ft.bin \
+          python tools/kbench.py --side 40 --stages mlp --mask on --reps 1
     python tools/fused_trace.py /tmp/ft.bin
 """
 import sys
