@@ -1,22 +1,17 @@
 // Radial + angular AEV forward and analytic backward for gfx950 (wave64).
 //
-// One wave owns one central atom at a time (persistent waves stride over the shard).  The atom's
-// species-sorted neighbor row (written by nbr.hip) is loaded with one coalesced 16-B load per lane,
-// turned into unit vectors / cutoff factors once per neighbor and staged in the wave's private LDS.
+// One wave owns one central atom at a time (persistent waves stride over the shard).  The atom's species-sorted neighbor
+// row (written by nbr.hip) is loaded with one coalesced 16-B load per lane -- header and entries of the NEXT atom are
+// in flight while the current one is computed -- turned into unit vectors / cutoff factors once per neighbor and staged
+// in the wave's private LDS.  Three kernels:
 //
-//   radial : lane = (neighbor slot p in 0..7, shift pair sq in 0..7); neighbors are visited species by
-//            species, sums stay in registers, one 3-step cross-slot reduction per species.
-//   angular: lane = (pair slot p in 0..15, quarter q in 0..3).  For every species pair block (sj<=sk)
-//            the (j,k) pairs form a dense rectangle / circular-tournament triangle of the sorted row,
-//            so 16 pairs are evaluated per step with a wave-uniform output block: each lane
-//            computes one quarter of the angular factors (2 exp2 for F2, one log2/exp2 for F1), the 4
-//            F1 values are shared inside the quad with DPP, and the 8x4 outer product accumulates in 8
-//            registers.  One cross-slot reduction per block, no LDS/global atomics in the forward,
-//            deterministic.  The finished 1008-float row is staged in LDS and stored with full-width
-//            16-B-per-lane coalesced writes.
-//   backward: same tiling; the per-pair derivative coefficients (sum_w f1 f2, sum_w f1' f2,
-//            sum_w f1 f2') are reduced inside the quad, per-neighbor gradient vectors accumulate in
-//            LDS and leave as one float atomic per component per neighbor.
+//   k_aev_fwd2  forward of the energy / force path: two lanes per (j, k) pair, species-pair blocks with pairs only,
+//               log-domain cutoff product, packed outer product, transpose-reduce.  No atomics.  (Details at the kernel.)
+//   k_aev_bwd   analytic backward: radial part by symmetric gather (each atom finishes its own radial force from the
+//               64-B block of every neighbor's dE/dAEV row), angular part over all neighbor pairs in one tournament
+//               with lane-owned j and plain LDS read-add-write for k, dE/dAEV staged block-wise; the few remaining
+//               global accumulations are float atomics or (ANIHIP_BWD_FIXED_POINT) 64-bit integer atomics.
+//   k_aev_fwd<.., JVP = true>  forward-mode derivative J t (the reference's double backward), four lanes per pair.
 //
 // Maths restated from the reference (paths relative to /root/reference/torchani/):
 //   aev/_terms.py:99-104,171-186 (radial), :34-55,324-325,339-343 (angular), cutoffs.py:80-81,
