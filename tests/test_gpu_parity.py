@@ -538,6 +538,29 @@ def test_factories_are_loud_about_random_weights(dev):
         ANI2x(device=dev, state_dict={"unrelated.weight": np.zeros(3, dtype=np.float32)})
 
 
+def test_ensemble_values_are_differentiable(dev):
+    """Autograd through ensemble_values=True (nn/_containers.py:638-651 is differentiable in the reference): the gradient
+    of a weighted sum of the member energies equals the weighted sum of the single-member models' gradients."""
+    g = load_golden("rand_batch_ani2x")
+    sp, x, _, _ = to_dev(g, dev)
+    model = get_model(g["kind"], g["seed"], dev)
+    model.set_enabled("energy_shifter", False)
+    w = torch.linspace(-1.0, 2.0, 8, device=dev)
+    xs = x.clone().requires_grad_(True)
+    em = model((sp, xs), ensemble_values=True).energies          # [M, C]
+    assert em.shape == (8, sp.shape[0])
+    (gx,) = torch.autograd.grad((em * w[:, None]).sum(), xs)
+    ref = torch.zeros_like(x)
+    for m in range(8):
+        xm = x.clone().requires_grad_(True)
+        e = model[m]((sp, xm)).energies
+        (gm,) = torch.autograd.grad(e.sum(), xm)
+        ref += w[m] * gm
+        assert torch.allclose(e.detach(), em[m].detach(), atol=2e-6)
+    model.set_enabled("energy_shifter", True)
+    assert (gx - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item())
+
+
 def test_api_details(dev):
     """Legacy tuple call, atomic / ensemble_values outputs, active members (nn/_containers.py:590-660)."""
     g = load_golden("simple2_ani2x")

@@ -855,8 +855,11 @@ __device__ __forceinline__ void push_grad(float *grad_coords, size_t at, int com
     }
 }
 
+#ifndef ANIHIP_BWD_WAVES
+#define ANIHIP_BWD_WAVES 4
+#endif
 template <int NA, int NZ, bool VIRIAL, bool FIXED>
-__global__ __launch_bounds__(BWD_WPB * WAVE, 4) void k_aev_bwd(
+__global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
     const float4 *__restrict__ ent, const float *__restrict__ grad_aev, float *__restrict__ grad_coords,
@@ -1313,7 +1316,7 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
     if (int rc = make_args(p, &a)) return rc;
     if (virial) zero_words_async((hipStream_t)stream, virial, 9 * sizeof(double));
     if (hi == lo) return 0;
-    dim3 grid(persistent_blocks(hi - lo, BWD_WPB, 4)), block(BWD_WPB * WAVE);
+    dim3 grid(persistent_blocks(hi - lo, BWD_WPB, ANIHIP_BWD_WAVES)), block(BWD_WPB * WAVE);
     const float4 *e4 = (const float4 *)ent;
     hipStream_t st = (hipStream_t)stream;
     const bool symmetric = (flags & ANIHIP_BWD_SYMMETRIC) != 0, fixed = (flags & ANIHIP_BWD_FIXED_POINT) != 0;

@@ -114,6 +114,8 @@ class _MLPFunction(torch.autograd.Function):
         ctx.in_dtype = aevs.dtype
         ctx.shape = aevs.shape
         ctx.want_members = want_members
+        ctx.member_packs = getattr(packed, "member_packs", None) if (want_members and aevs.requires_grad) else None
+        ctx.saved_members = (a32, species32) if ctx.member_packs is not None else None
         if want_members:
             return me.view(packed.M, C, A).to(aevs.dtype)
         return ae.view(C, A).to(aevs.dtype)
@@ -121,7 +123,19 @@ class _MLPFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         if ctx.want_members:
-            raise RuntimeError("ensemble_values=True is not differentiable in the HIP engine")
+            # grad_out [M, C, A]: d/d aev of sum_m grad_out_m e_m -- the engine returns the input gradient of ONE scalar
+            # per atom, so every member gets a pass of its own (inference only: parameters frozen)
+            if ctx.train or ctx.member_packs is None:
+                raise RuntimeError("ensemble_values=True is differentiable with respect to the AEVs only (frozen "
+                                   "parameters, aevs.requires_grad)")
+            a32, species32 = ctx.saved_members
+            go = grad_out.to(torch.float32)
+            total = None
+            for m, pk in enumerate(ctx.member_packs()):
+                _, gm, _ = pk.forward_backward(species32, a32, want_grad=True)
+                term = gm.view(ctx.shape) * go[m].unsqueeze(-1)
+                total = term if total is None else total + term
+            return (total.to(ctx.in_dtype), None, None, None, *([None] * len(ctx.param_dtypes)))
         if ctx.train:
             # training pass: forward recomputed in exact fp32 with the activations kept, then d/d weights, d/d biases
             # (and d/d aev scaled by the upstream gradient) in one engine call
@@ -209,6 +223,10 @@ class _EngineContainer(torch.nn.Module):
                           and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == aevs.device
                                   for p in params))
         packed = self._train_pack(aevs.device) if trainable_fast else self._pack(aevs.device)
+        if ensemble_values and aevs.requires_grad and not params:
+            # differentiable member energies (nn/_containers.py:638-651 is plain autograd in the reference): the backward
+            # needs every member's own d e_m / d aev, i.e. one single-member pass each
+            packed.member_packs = lambda: [m._pack(aevs.device) for m in self._member_networks()]
         out = _MLPFunction.apply(aevs, species32, packed, ensemble_values, *params)
         # [C, A] (or [M, C, A]); molecular energies are the sum over atoms (nn/_containers.py:417-421)
         return out if atomic else out.sum(dim=-1)
