@@ -1083,25 +1083,28 @@ __device__ __forceinline__ void fr_step(f32x16 (&acc)[RB * NB], const WRing<NB, 
 }
 
 // ring of this wave's column blocks cb, cb + NW, ... of a [N/32][KS] fragment matrix of member m, first D
-// steps in flight
-template <int NB, int NBA, int D>
+// steps in flight.  nblk = the number of blocks the wave really has: EVERY ring register is loaded on every path
+// (missing blocks: the first block again; none at all: block 0) -- inside the item loop of the fused kernel a
+// ring that some path leaves undefined is carried around the loop and holds its registers through the whole item
+template <int NB, int D>
 __device__ __forceinline__ void fr_ring(WRing<NB, D> &r, const _Float16 *w, int64_t member_halves, int m, int KS,
-                                        int cb, int nw)
+                                        int cb, int nw, int lane, int nblk)
 {
-    r.nb_stride = (int64_t)nw * KS * (2 * FRAG);
-    r.base = w + (int64_t)m * member_halves + (int64_t)cb * KS * (2 * FRAG) + (threadIdx.x & 63) * 8;
+    r.nb_stride = nblk >= NB ? (int64_t)nw * KS * (2 * FRAG) : 0;
+    r.base = w + (int64_t)m * member_halves + (int64_t)(nblk > 0 ? cb : 0) * KS * (2 * FRAG) + lane * 8;
 #pragma unroll
-    for (int sl = 0; sl < D; ++sl) r.template load<NBA>(sl, min(sl, KS - 1));
+    for (int sl = 0; sl < D; ++sl) r.template load<NB>(sl, min(sl, KS - 1));
+    r.nb_stride = (int64_t)nw * KS * (2 * FRAG);
 }
 
 // acc += X[rows, K] x B over all KS = K/16 k steps (KS even): whole groups of D steps without a branch, the
 // tail (an even number of steps < D) issues no loads.  xa = hi plane of X, ldx = row stride (halves)
 template <int RB, int NB, int NBA, int D>
 __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *xa, int ldx, int x_plane,
-                                        WRing<NB, D> &rg, int KS)
+                                        WRing<NB, D> &rg, int KS, int lane)
 {
     // the activation fragments of step k + 1 are read from LDS before the MFMAs of step k (two register sets)
-    const int lane = threadIdx.x & 63, fr = lane & 31, fk = lane >> 5;
+    const int fr = lane & 31, fk = lane >> 5;
     const _Float16 *af = xa + fr * ldx + fk * 8;
     const int rbs = 32 * ldx;
     AFrag<RB> xe, xo;
@@ -1147,8 +1150,9 @@ __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const
         if (tile < nt) break;
         tile -= nt;
     }
-    if (s >= S) {
+    if (s >= S) {   // (the fused kernel prefetches the rows of the next item before it looks at its entry: atom 0)
         if (lane == 0) tile_tab[tile0] = make_int4(-1, 0, 0, 0);
+        if (lane < rows_per_tile) tile_rows[(size_t)tile0 * rows_per_tile + lane] = 0;
         return;
     }
     const int n_rows = min(rows_per_tile, cnt - tile * rows_per_tile);
@@ -1183,10 +1187,13 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     _Float16 *fsm = fsm_all + C::FIXED_HALVES;                            // X1 | XU; staging slots 1..3 overlay
     auto slot = [&](int k) { return k == 0 ? slot0 : fsm + (k - 1) * (FR_GROUP * SLAB); };
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 31, fk = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    // (re-derived from an opaque copy of threadIdx.x at the head of every item: hoisted out of the item loop, the
+    // per-lane addresses built from these cost more registers than the kernel has)
+    int tid = threadIdx.x, lane = tid & 63;
+    int fr = lane & 31, fk = lane >> 5;
     // staging role of this thread: row srow, 16-B piece spc (4 of a slab's 32 columns)
-    const int srow = tid >> 3, spc = tid & 7;
+    int srow = tid >> 3, spc = tid & 7;
     const int KS0 = g.n_slabs * 2;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
@@ -1230,35 +1237,83 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         }
     };
 
-#ifdef ANIHIP_DEV_TRACE
-    if (g.trace && tid == 0) {
-        g.trace[(size_t)blockIdx.x * 16 + 0] = __builtin_readcyclecounter();
-        // placement: HW_REG_HW_ID (cu / sh / se) and HW_REG_XCC_ID, for co-residency analysis
-        g.trace[(size_t)blockIdx.x * 16 + 14] = 1 + (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
-                                                     ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
-    }
-#endif
-    // ---- this workgroup's item (member-major order: at any time the chip works on one or two members,
-    // whose weights stay resident in every XCD's L2): tile entry and atom rows are independent loads ----
-    const int item = blockIdx.x;
-    const int tile_id = item % g.tiles_total;
-    const int4 te = g.tile_tab[tile_id];
-    const int my_atom = g.tile_rows[(size_t)tile_id * ROWS + srow];
-    if (te.x < 0) return;   // (at most num_species empty tiles per member)
-    const uint32_t tmask = (uint32_t)te.w;
-    ANIHIP_STAMP(g.trace ? g.trace + (size_t)blockIdx.x * 16 : nullptr, 1);
+    // ---- persistent workgroups: item = blockIdx.x, + gridDim.x, ... (member-major order: at any time the chip
+    // works on one or two members, whose weights stay resident in every XCD's L2).  The dependent chain at the
+    // head of an item (tile entry -> atom rows -> AEV slabs -> first weight fragments, about 9 k clocks of pure
+    // latency when exposed) is issued for item i + 1 while the backward phases of item i run.
+    int n_tiles = 0;   // the non-empty tiles come first in the table
+    for (int t = 0; t < g.S; ++t) n_tiles += (g.ctl[CTL_CNT + t] + ROWS - 1) / ROWS;
+    const int n_items = n_tiles * g.M;
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    typedef WRing<NB, D> Ring0;
+    Ring0 rg;                  // layer-0 weight ring of the item being started
+    uint32_t rem_w = 0u;       // k steps of the layer-0 weight ring not yet requested
+    uint32_t tmask = 0u;
+    int w_odd = 0;
+    auto next_ks = [&]() {    // k step (in the slab order of W0) of the next ring request, clamped
+        const int slab = rem_w ? (int)__builtin_ctz(rem_w) : (31 - (int)__builtin_clz(tmask | 1u));
+        const int ks = 2 * slab + (rem_w ? w_odd : 1);
+        if (w_odd) rem_w &= rem_w - 1u;
+        w_odd ^= 1;
+        return ks;
+    };
+    auto nblk_of = [&](int H) { const int t = (H >> 5) - wave; return t <= 0 ? 0 : (t + NW - 1) / NW; };
     v4f va[FR_GROUP], vb[FR_GROUP];
-    arow = g.aev + (int64_t)my_atom * g.L + spc * 4;
-    rem_a = tmask;
-    fetch_group(va);
-    fetch_group(vb);
+    // slabs 0..5 of an item -> registers (rem_a = the rest)
+    auto prefetch_aev = [&](const int4 &t, int atom) {
+        arow = g.aev + (int64_t)atom * g.L + spc * 4;
+        rem_a = (uint32_t)t.w;
+        fetch_group(va);
+        fetch_group(vb);
+    };
+    // first D weight fragments of layer 0 of an item
+    auto prefetch_w0 = [&](const int4 &t, int it) {
+        const int s = t.x, m = it / n_tiles;
+        const FusedSpecies &fs = g.sp[s];
+        tmask = (uint32_t)t.w;
+        rem_w = tmask;
+        w_odd = 0;
+        // every ring register is written on every path (blocks this wave does not have: block 0 again), or the
+        // ring of the previous item would stay live through the whole item
+        const int n1 = nblk_of(fs.H1);
+        const _Float16 *wm = fs.w0 + (int64_t)m * (fs.H1 >> 5) * KS0 * (2 * FRAG) + lane * 8;
+        rg.nb_stride = n1 >= NB ? (int64_t)NW * KS0 * (2 * FRAG) : 0;
+        rg.base = wm + (int64_t)(n1 > 0 ? wave : 0) * KS0 * (2 * FRAG);
+#pragma unroll
+        for (int sl = 0; sl < D; ++sl) rg.template load<NB>(sl, next_ks());
+        rg.nb_stride = (int64_t)NW * KS0 * (2 * FRAG);
+    };
+    int4 te = g.tile_tab[item % n_tiles];
     {
-        const int m = item / g.tiles_total, s = te.x, n_rows = te.z, p0 = te.y;
-        // (slabs 0..5 of this item are on their way to the registers; rem_a = the rest)
+        const int atom0 = g.tile_rows[(size_t)(item % n_tiles) * ROWS + srow];
+        prefetch_aev(te, atom0);
+        prefetch_w0(te, item);
+    }
+    for (;;) {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63; fr = lane & 31; fk = lane >> 5; srow = tid >> 3; spc = tid & 7;
+        float alpha = g.alpha, inv_alpha = g.inv_alpha;   // (same reason: their vector copies and products)
+        int Mi = g.M;
+        asm volatile("" : "+s"(alpha), "+s"(inv_alpha), "+s"(Mi));
+        // entry and atom rows of the next item (the last item of a workgroup prefetches itself again: loads
+        // stay unconditional)
+        const int item_n = item + (int)gridDim.x < n_items ? item + (int)gridDim.x : item;
+        const int4 te_n = g.tile_tab[item_n % n_tiles];
+        const int atom_n = g.tile_rows[(size_t)(item_n % n_tiles) * ROWS + srow];
+#ifdef ANIHIP_DEV_TRACE
+        if (g.trace && tid == 0) {
+            g.trace[(size_t)item * 16 + 0] = __builtin_readcyclecounter();
+            // placement: HW_REG_HW_ID (cu / sh / se) and HW_REG_XCC_ID, for co-residency analysis
+            g.trace[(size_t)item * 16 + 14] = 1 + (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
+                                                   ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
+        }
+#endif
+        const int m = item / n_tiles, s = te.x, n_rows = te.z, p0 = te.y;
         const FusedSpecies &fs = g.sp[s];
         int64_t tm_base = 0;
         if (g.d0_tm)
-            for (int t = 0; t < s; ++t) tm_base += (int64_t)((g.ctl[CTL_CNT + t] + 63) >> 6) * 64 * g.M * g.sp[t].H1;
+            for (int t = 0; t < s; ++t) tm_base += (int64_t)((g.ctl[CTL_CNT + t] + 63) >> 6) * 64 * Mi * g.sp[t].H1;
         const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
         // LDS carve (halves): X1 planes [2][ROWS][H2+8] | XU = max(X0 planes [2][ROWS][H1+8], X2 planes)
         const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
@@ -1274,6 +1329,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #ifdef ANIHIP_DEV_TRACE
         unsigned long long *trace = g.trace ? g.trace + (size_t)item * 16 : nullptr;
 #endif
+        ANIHIP_STAMP(trace, 1);
 
         f32x16 acc[NE];
         auto zero_acc = [&]() {
@@ -1282,9 +1338,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         };
-        auto tile_max = [&](float vmax) {  // workgroup max of a non-negative value (two barriers)
-            if (tid == 0) s_max = 0u;
-            __syncthreads();
+        auto tile_max = [&](float vmax) {  // workgroup max of a non-negative value (s_max was reset at the head of the item)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
             if (lane == 0) atomicMax(&s_max, __float_as_uint(vmax));
@@ -1333,25 +1387,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         if (!C::LAZY) load_cols(fs.b0 + (int64_t)m * H1, bias0, n1);
         const int nact = __popc(tmask);
         const int npair = (nact + 2 * FR_GROUP - 1) / (2 * FR_GROUP);
-        Ring rg;
-        uint32_t rem_w = tmask;   // k steps of the weight ring not yet requested
-        int w_odd = 0;
-        auto next_ks = [&]() {    // k step (in the slab order of W0) of the next ring request, clamped
-            const int slab = rem_w ? (int)__builtin_ctz(rem_w) : (31 - (int)__builtin_clz(tmask | 1u));
-            const int ks = 2 * slab + (rem_w ? w_odd : 1);
-            if (w_odd) rem_w &= rem_w - 1u;
-            w_odd ^= 1;
-            return ks;
-        };
-        rg.nb_stride = (int64_t)NW * KS0 * (2 * FRAG);
-        rg.base = fs.w0 + (int64_t)m * (H1 >> 5) * KS0 * (2 * FRAG) + (int64_t)wave * KS0 * (2 * FRAG) + lane * 8;
-        if (n1 > 0) {
-#pragma unroll
-            for (int sl = 0; sl < D; ++sl) { FR_BLOCKS(n1, rg.template load<NBA>(sl, next_ks())) }
-        }
+        // (AEV slabs 0..5 and the first D weight fragments were requested during the previous item)
         zero_acc();
         store_group(va, slot(0));
         store_group(vb, slot(1));
+        if (tid == 0) s_max = 0u;
         __syncthreads();   // slots 0 / 1 published
         ANIHIP_STAMP(trace, 2);
         // six slabs (two staging slots, 12 k steps) per barrier; the next six are fetched into registers
@@ -1379,16 +1419,16 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         ANIHIP_STAMP(trace, 3);
         // weights of phase 1 start streaming during the layer-0 epilogue
         Ring r1;
-        FR_BLOCKS(n2, (fr_ring<NB, NBA, D>(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave, NW)))
+        fr_ring<NB, D>(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave, NW, lane, n2);
         // celu and its derivative from one exponential: x > 0: (x, 1), else (alpha (e - 1), e), e = exp(x / alpha)
-        const float ia_log2e = g.inv_alpha * 1.44269504f;
+        const float ia_log2e = inv_alpha * 1.44269504f;
         auto celu_d = [&](float x, float &d) {
             const float e = __builtin_amdgcn_exp2f(x * ia_log2e);
             d = fminf(e, 1.0f);   // (e > 1 exactly when x > 0; as a select the compare masks of all 32 elements stay
                                   //  live until the backward phases and spill from SGPRs into VGPR lanes)
             // celu(x) = median(x, alpha (e - 1), 0): for x > 0 the exponential branch lies above x (convexity), for
             // x < 0 between x and 0 -- one v_med3_f32 instead of a compare and a select
-            return __builtin_amdgcn_fmed3f(x, __builtin_fmaf(g.alpha, e, -g.alpha), 0.f);
+            return __builtin_amdgcn_fmed3f(x, __builtin_fmaf(alpha, e, -alpha), 0.f);
         };
         // two elements at a time: bias + scale, the exponent argument and alpha (e - 1) as packed fp32 operations
         typedef float v2f __attribute__((ext_vector_type(2)));
@@ -1397,7 +1437,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             const v2f x = v2f{a0, a1} * osc + v2f{b0, b1};
             const v2f t = x * ia_log2e;
             const v2f e = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-            const v2f y = e * g.alpha - g.alpha;
+            const v2f y = e * alpha - alpha;
             dd0 = fminf(e.x, 1.0f);
             dd1 = fminf(e.y, 1.0f);
             y0 = __builtin_amdgcn_fmed3f(x.x, y.x, 0.f);
@@ -1438,10 +1478,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         float bias1[NB][16];   // (per-column parameters travel during the GEMM)
         if (!C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, n2);
         zero_acc();
-        FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X0, ld0, x0_plane, r1, H1 >> 4)))
+        FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X0, ld0, x0_plane, r1, H1 >> 4, lane)))
         ANIHIP_STAMP(trace, 5);
         Ring r2;
-        FR_BLOCKS(n3, (fr_ring<NB, NBA, D>(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW)))
+        fr_ring<NB, D>(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW, lane, n3);
         float d1f[NE][16];   // celu'(act1) of this lane's elements
         if (n2 > 0) {
             if (C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, n2);
@@ -1460,6 +1500,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                         acc[i][r + 1] = y1;
                     }
             put_acc(X1, x1_plane, ld1, s1, n2);
+        } else {   // (defined on every path, like the rings)
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d1f[i][r] = 0.f;
         }
         __syncthreads();  // X1 complete; every wave is done reading X0 -> XU reusable
         ANIHIP_STAMP(trace, 6);
@@ -1471,12 +1516,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             load_cols(fs.w3 + (int64_t)m * H3, w3, n3);
         }
         zero_acc();
-        FR_BLOCKS(n3, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r2, H2 >> 4)))
+        FR_BLOCKS(n3, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r2, H2 >> 4, lane)))
         ANIHIP_STAMP(trace, 7);
-        Ring r3;
-        if (g.want_grad) {
-            FR_BLOCKS(n2, (fr_ring<NB, NBA, D>(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave, NW)))
-        }
+        Ring r3;   // (also without want_grad: see fr_ring)
+        fr_ring<NB, D>(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave, NW, lane, n2);
         {
             // e = sum_col act2 * w3 (+ b3): per-lane partial over its columns, the two k halves of a row
             // combined with a lane swap, the waves through LDS in a fixed order (deterministic sum).
@@ -1486,7 +1529,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 load_cols(fs.w3 + (int64_t)m * H3, w3, n3);
             }
             const float osc2 = fs.is2 / s1;
-            const float invM = 1.0f / (float)g.M;
+            const float invM = 1.0f / (float)Mi;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 float e = 0.f;
@@ -1512,7 +1555,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             float e = fs.b3[m];
 #pragma unroll
             for (int w8 = 0; w8 < NW; ++w8) e += s_e[w8 * ROWS + tid];
-            g.member_part[(int64_t)(p0 + tid) * g.M + m] = e;
+            g.member_part[(int64_t)(p0 + tid) * Mi + m] = e;
         }
         ANIHIP_STAMP(trace, 9);
 
@@ -1520,9 +1563,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         if (g.want_grad) {
             // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
             zero_acc();
-            FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X2, ld2, x2_plane, r3, H3 >> 4)))
+            FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X2, ld2, x2_plane, r3, H3 >> 4, lane)))
             ANIHIP_STAMP(trace, 10);
-            FR_BLOCKS(n1, (fr_ring<NB, NBA, D>(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW)))
+        }
+        fr_ring<NB, D>(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW, lane, n1);
+        if (g.want_grad) {
             if (n2 > 0) {
                 const float osc3 = fs.is2 / s2;
                 if constexpr (!C::LAZY) {
@@ -1547,7 +1592,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     const float y = ((float)yh[e] + (float)yl[e]) * inv_s1;
-                                    acc[rb * NB + nb][4 * q + e] *= osc3 * (y > 0.f ? 1.0f : __builtin_fmaf(y, g.inv_alpha, 1.0f));
+                                    acc[rb * NB + nb][4 * q + e] *= osc3 * (y > 0.f ? 1.0f : __builtin_fmaf(y, inv_alpha, 1.0f));
                                 }
                             }
                         }
@@ -1555,13 +1600,22 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 put_acc(X1, x1_plane, ld1, s3, n2);   // (X1: its last readers finished before the previous barrier)
             }
         }
+        // the AEV slabs of the next item travel during phase 4 (requested AFTER the ring: loads complete in
+        // order, and the first MFMAs of phase 4 wait for the ring only)
+        prefetch_aev(te_n, atom_n);
         __syncthreads();
         ANIHIP_STAMP(trace, 11);
         // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
         if (g.want_grad && n1 > 0) {
             zero_acc();
-            FR_BLOCKS(n1, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r4, H2 >> 4)))
-            ANIHIP_STAMP(trace, 12);
+            FR_BLOCKS(n1, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r4, H2 >> 4, lane)))
+        }
+        ANIHIP_STAMP(trace, 12);
+        // every wave is done with the LDS of this item: the next one may stage its slabs.  Its first layer-0
+        // weight fragments travel during the stores below
+        __syncthreads();
+        prefetch_w0(te_n, item_n);
+        if (g.want_grad && n1 > 0) {
             const float osc4 = fs.is1 / s3;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -1572,7 +1626,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0(nb);
                     if (g.d0_tm) {
                         const int rel = p0 - g.ctl[CTL_OFF + s] + min(row, n_rows - 1);
-                        dst = g.d0 + tm_base + ((int64_t)((rel >> 6) * g.M + m) * 64 + (rel & 63)) * H1 + col0(nb);
+                        dst = g.d0 + tm_base + ((int64_t)((rel >> 6) * Mi + m) * 64 + (rel & 63)) * H1 + col0(nb);
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -1586,6 +1640,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             }
         }
         ANIHIP_STAMP(trace, 13);
+        if (item_n == item) break;
+        te = te_n;
+        item = item_n;
     }
 }
 #undef FR_BLOCKS
@@ -1983,7 +2040,9 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
     float *mpart = (float *)take(sizeof(float) * (size_t)(n + 1) * (size_t)d->n_members);
     const size_t tiles = (size_t)((n + 31) / 32) + ANIHIP_MAX_SPECIES;   // (finest tiling of the fused kernel)
     int4 *ttab = (int4 *)take(sizeof(int4) * tiles);
-    int *trows = (int *)take(sizeof(int) * 32 * tiles);
+    // (row lists: 32 per tile at the finest tiling, 64 per tile at the coarsest, which has up to one partly filled tile
+    // per species more rows than atoms)
+    int *trows = (int *)take(sizeof(int) * (32 * tiles + 64 * (size_t)ANIHIP_MAX_SPECIES));
     if (w) {
         w->ctl = ctl; w->amax = (unsigned *)(ctl + CTL_WORDS); w->perm = perm; w->member_part = mpart;
         w->tile_tab = ttab; w->tile_rows = trows;
@@ -2265,13 +2324,23 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         ANIHIP_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t tiles = (n + rows - 1) / rows + S;
         f.tiles_total = (int)tiles;
-        const int64_t grid = tiles * M;   // one workgroup per (member, tile) item; empty ones exit at once
+        // persistent workgroups over the (member, tile) items, as many as are resident at once
+        static int n_cus = 0;
+        if (n_cus == 0) {
+            int dev = 0, v = 0;
+            ANIHIP_CHECK_HIP(hipGetDevice(&dev));
+            ANIHIP_CHECK_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+            n_cus = v > 0 ? v : 256;
+        }
+        const int64_t items = tiles * M;
+        const int64_t resident = (int64_t)n_cus * (2 * lds <= 160 * 1024 ? 2 : 1);
+        const int64_t grid = items < resident ? items : resident;
         hipLaunchKernelGGL(k_tile_table, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, w.ctl, S, w.perm,
                            f.slab_mask, f.n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << f.n_slabs) - 1u), (int)tiles,
                            rows, w.tile_tab, w.tile_rows);
 #ifdef ANIHIP_DEV_TRACE   // development builds only (tools/fused_trace.py): per-item phase stamps, allocates and synchronises
         const char *trace_path = getenv("ANIHIP_FUSED_TRACE");
-        const size_t trace_words = (size_t)16 * grid;
+        const size_t trace_words = (size_t)16 * items;
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipMalloc((void **)&f.trace, sizeof(unsigned long long) * trace_words));
             ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * trace_words));
