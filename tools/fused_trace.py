@@ -15,8 +15,9 @@ STAMPS = [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 13]
 NAMES = ["start->mask", "mask->L0 first group staged", "L0 k-loop", "L0 epilogue", "P1 gemm", "P1 epilogue",
          "P2 gemm", "P2 epilogue+head+seed", "P3 gemm", "P3 epilogue", "P4 gemm", "P4 store"]
 
-t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16).astype(np.int64)
-t = t[(t[:, 0] > 0) & (t[:, 13] > 0)]
+tw = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8, 16).astype(np.int64)   # [item][wave][stamp]
+tw = tw[(tw[:, 0, 0] > 0) & (tw[:, 0, 13] > 0)]
+t = tw[:, 0, :]
 d = np.diff(t[:, STAMPS], axis=1)
 tot = t[:, 13] - t[:, 0]
 print(f"{len(t)} workgroups, total {tot.mean():.0f} ticks (median {np.median(tot):.0f})  [shader clock ticks, wave 0]")
@@ -27,3 +28,10 @@ if t[:, 8].min() > 0 and t[:, 14].min() > 0:
         print(f"{n:32s} mean {x.mean():9.1f}  median {np.median(x):9.1f}")
 for i, n in enumerate(NAMES):
     print(f"  {n:30s} mean {d[:, i].mean():9.1f}  median {np.median(d[:, i]):9.1f}  ({d[:, i].mean() / tot.mean():6.1%})")
+
+# per wave: when does each wave pass each stamp, relative to wave 0's start of the item (mean over items)
+print("per-wave arrival (mean ticks after wave 0 started the item); stamps:", STAMPS)
+for w in range(8):
+    ok = tw[:, w, 13] > 0
+    rel = tw[ok][:, w, :][:, STAMPS] - tw[ok][:, 0, 0][:, None]
+    print(f"  wave {w}: " + " ".join(f"{v:7.0f}" for v in rel.mean(axis=0)))

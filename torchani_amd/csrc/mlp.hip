@@ -790,7 +790,9 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
     const int p0 = ctl[CTL_OFF + s] + m0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    // waves w and w + 4 share a SIMD (tools/simdmap.hip): they take DIFFERENT column halves, so that a partly
+    // filled tile (5 active column blocks = 3 + 2) loads the four SIMDs equally
+    const int wm = wave >> 1, wn = (wave & 1) ^ (wave >> 2);
     const int srow = tid >> 2, piece = tid & 3;
     const int r0 = srow < n_rows ? srow : 0, r1 = srow + 128 < n_rows ? srow + 128 : 0;
     const int64_t s0r = g.a_gather ? (int64_t)g.a_gather[p0 + r0] : (int64_t)(p0 + r0);
@@ -994,18 +996,34 @@ struct FusedArgs {
     int tiles_total;           // upper bound of the number of tiles (work items = tiles_total * M)
     float alpha, inv_alpha;
     int want_grad;
-    unsigned long long *trace;   // development builds (-DANIHIP_DEV_TRACE, tools/fused_trace.py): [workgroup][16] stamps
+    unsigned long long *trace;   // development builds (-DANIHIP_DEV_TRACE, tools/fused_trace.py): [item][wave][16] stamps
 };
 // phase stamps of the fused kernel: compiled out of the shipped library
 #ifdef ANIHIP_DEV_TRACE
 #define ANIHIP_STAMP(ptr, slot)                                              \
     do {                                                                     \
         unsigned long long *p_ = (ptr);                                      \
-        if (p_ && tid == 0) p_[slot] = __builtin_readcyclecounter();         \
+        if (p_ && lane == 0) p_[slot] = __builtin_readcyclecounter();        \
     } while (0)
 #else
 #define ANIHIP_STAMP(ptr, slot) do { } while (0)
 #endif
+
+// max of a non-negative value over the wave, the same in every lane: four DPP steps inside the 16-lane rows, then the
+// four row maxima through SGPRs (a __shfl_xor butterfly is six dependent ds_bpermute round trips)
+__device__ __forceinline__ float wave_max_nonneg(float v)
+{
+#define ANIHIP_DPP_MAX(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xF, 0xF, true)))
+    ANIHIP_DPP_MAX(0xB1);    // quad_perm [1, 0, 3, 2]
+    ANIHIP_DPP_MAX(0x4E);    // quad_perm [2, 3, 0, 1]
+    ANIHIP_DPP_MAX(0x141);   // row_half_mirror
+    ANIHIP_DPP_MAX(0x140);   // row_mirror
+#undef ANIHIP_DPP_MAX
+    const int x = __float_as_int(v);
+    const int m01 = max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16));    // (>= 0: integer order)
+    const int m23 = max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48));
+    return __int_as_float(max(m01, m23));
+}
 
 __device__ __forceinline__ float pow2_scale_for(float mx)
 {
@@ -1052,34 +1070,35 @@ struct AFrag {   // activation fragments {hi, lo} of RB row blocks for one k ste
     }
 };
 
-template <int RB, int NB, int NBA, int D>
-__device__ __forceinline__ void fr_mfma(f32x16 (&acc)[RB * NB], const WRing<NB, D> &rg, int slot, const AFrag<RB> &x)
+template <int RB, int NB, int RBA, int NBA, int D>
+__device__ __forceinline__ void fr_mfma(f32x16 (&acc)[RB * NB], const WRing<NB, D> &rg, int slot, const AFrag<RBA> &x)
 {
 #pragma unroll
     for (int nb = 0; nb < NBA; ++nb)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RBA; ++rb)
             acc[rb * NB + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[slot][nb], x.lo[rb], acc[rb * NB + nb], 0, 0, 0);
 #pragma unroll
     for (int nb = 0; nb < NBA; ++nb)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RBA; ++rb)
             acc[rb * NB + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.lo[slot][nb], x.hi[rb], acc[rb * NB + nb], 0, 0, 0);
 #pragma unroll
     for (int nb = 0; nb < NBA; ++nb)
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RBA; ++rb)
             acc[rb * NB + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[slot][nb], x.hi[rb], acc[rb * NB + nb], 0, 0, 0);
 }
 
-// a = hi-plane fragment address of this lane for row block 0; + a_plane = lo plane; + rb_stride = next row block
-template <int RB, int NB, int NBA, int D>
+// a = hi-plane fragment address of this lane for the wave's first row block; + a_plane = lo plane; + rb_stride = next
+// row block.  RBA x NBA = the part of the wave's RB x NB accumulators that is active in this phase
+template <int RB, int NB, int RBA, int NBA, int D>
 __device__ __forceinline__ void fr_step(f32x16 (&acc)[RB * NB], const WRing<NB, D> &rg, int slot,
                                         const _Float16 *a, int a_plane, int rb_stride)
 {
-    AFrag<RB> x;
+    AFrag<RBA> x;
     x.load(a, a_plane, rb_stride);
-    fr_mfma<RB, NB, NBA, D>(acc, rg, slot, x);
+    fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, slot, x);
 }
 
 // ring of this wave's column blocks cb, cb + NW, ... of a [N/32][KS] fragment matrix of member m, first D
@@ -1099,7 +1118,7 @@ __device__ __forceinline__ void fr_ring(WRing<NB, D> &r, const _Float16 *w, int6
 
 // acc += X[rows, K] x B over all KS = K/16 k steps (KS even): whole groups of D steps without a branch, the
 // tail (an even number of steps < D) issues no loads.  xa = hi plane of X, ldx = row stride (halves)
-template <int RB, int NB, int NBA, int D>
+template <int RB, int NB, int RBA, int NBA, int D>
 __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *xa, int ldx, int x_plane,
                                         WRing<NB, D> &rg, int KS, int lane)
 {
@@ -1107,17 +1126,17 @@ __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *
     const int fr = lane & 31, fk = lane >> 5;
     const _Float16 *af = xa + fr * ldx + fk * 8;
     const int rbs = 32 * ldx;
-    AFrag<RB> xe, xo;
+    AFrag<RBA> xe, xo;
     xe.load(af, x_plane, rbs);
     int k0 = 0;
     for (; k0 + D <= KS; k0 += D) {
 #pragma unroll
         for (int sl = 0; sl < D; sl += 2) {
             xo.load(af + (k0 + sl + 1) * 16, x_plane, rbs);
-            fr_mfma<RB, NB, NBA, D>(acc, rg, sl, xe);
+            fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, sl, xe);
             rg.template load<NBA>(sl, min(k0 + sl + D, KS - 1));
             xe.load(af + min(k0 + sl + 2, KS - 1) * 16, x_plane, rbs);
-            fr_mfma<RB, NB, NBA, D>(acc, rg, sl + 1, xo);
+            fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, sl + 1, xo);
             rg.template load<NBA>(sl + 1, min(k0 + sl + 1 + D, KS - 1));
         }
     }
@@ -1126,10 +1145,39 @@ __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *
     for (int sl = 0; sl < D - 2; sl += 2) {
         if (rem > sl) {
             xo.load(af + (k0 + sl + 1) * 16, x_plane, rbs);
-            fr_mfma<RB, NB, NBA, D>(acc, rg, sl, xe);
+            fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, sl, xe);
             xe.load(af + min(k0 + sl + 2, KS - 1) * 16, x_plane, rbs);
-            fr_mfma<RB, NB, NBA, D>(acc, rg, sl + 1, xo);
+            fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, sl + 1, xo);
         }
+    }
+}
+
+// What a wave of the fused kernel computes in a phase that produces H = 32 nb columns: column blocks cb, cb + NW, ...
+// (nba of them) of the row blocks rb0 .. rb0 + nrb - 1 of the tile.  With 64-row tiles (RB = 2, NB = 1) and 5 to 7
+// column blocks, the 2 nb (row block, column block) units are dealt so that the four SIMDs get the same number:
+// waves w and w + 4 share a SIMD (tools/simdmap.hip), and "wave w takes column block w" leaves SIMDs 0 / 1 with four
+// units and SIMDs 2 / 3 with two when nb = 6 -- every phase, MFMA loop and epilogue alike, then runs at the pace of
+// the full SIMDs.  The first 2 nb - 8 waves keep a whole column block (both row blocks: every weight fragment feeds
+// six MFMAs), the others take one row block of one of the remaining column blocks: 3 + 3 + 3 + 3 units for nb = 6,
+// 3 + 3 + 2 + 2 for nb = 5, 4 + 4 + 3 + 3 for nb = 7.
+struct FusedUnit {
+    int cb, rb0, nrb, nba;
+};
+template <int RB, int NB>
+__device__ __forceinline__ FusedUnit fused_unit(int H, int wave)
+{
+    const int nb = H >> 5;
+    if constexpr (RB == 2 && NB == 1) {
+        const bool deal = nb > 4 && nb < 8;
+        const int whole = deal ? 2 * nb - 8 : nb;   // waves that keep both row blocks of a column block
+        if (wave < whole) return FusedUnit{wave, 0, 2, 1};
+        const int idx = wave - whole, cb = whole + (idx >> 1);
+        if (deal && cb < nb) return FusedUnit{cb, idx & 1, 1, 1};
+        return FusedUnit{0, 0, 0, 0};
+    } else {
+        constexpr int NW = 8 / NB;
+        const int t = nb - wave, n = t <= 0 ? 0 : (t + NW - 1) / NW;
+        return FusedUnit{wave, 0, n > 0 ? RB : 0, n};
     }
 }
 
@@ -1168,10 +1216,11 @@ __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const
     if (lane == 0) tile_tab[tile0] = make_int4(s, p0, n_rows, (int)mk);
 }
 
-// wave-uniform dispatch on the number of column blocks this wave really has in a phase (compile-time inside)
-#define FR_BLOCKS(n, CALL)                       \
-    if ((n) >= NB) { constexpr int NBA = NB; CALL; } \
-    else if ((n) == 1) { constexpr int NBA = 1; CALL; }
+// wave-uniform dispatch on the active part of a wave's accumulators in a phase (compile-time inside)
+#define FR_UNIT(u, CALL)                                                                    \
+    if ((u).nrb == RB && (u).nba >= NB) { constexpr int RBA = RB, NBA = NB; CALL; }         \
+    else if ((u).nrb == RB && (u).nba == 1) { constexpr int RBA = RB, NBA = 1; CALL; }      \
+    else if ((u).nrb == 1) { constexpr int RBA = 1, NBA = 1; CALL; }
 
 template <int RB, int NB>
 __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
@@ -1187,7 +1236,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     _Float16 *fsm = fsm_all + C::FIXED_HALVES;                            // X1 | XU; staging slots 1..3 overlay
     auto slot = [&](int k) { return k == 0 ? slot0 : fsm + (k - 1) * (FR_GROUP * SLAB); };
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (in an SGPR: the unit tests below are scalar branches)
     // (re-derived from an opaque copy of threadIdx.x at the head of every item: hoisted out of the item loop, the
     // per-lane addresses built from these cost more registers than the kernel has)
     int tid = threadIdx.x, lane = tid & 63;
@@ -1258,7 +1307,6 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         w_odd ^= 1;
         return ks;
     };
-    auto nblk_of = [&](int H) { const int t = (H >> 5) - wave; return t <= 0 ? 0 : (t + NW - 1) / NW; };
     v4f va[FR_GROUP], vb[FR_GROUP];
     // slabs 0..5 of an item -> registers (rem_a = the rest)
     auto prefetch_aev = [&](const int4 &t, int atom) {
@@ -1276,10 +1324,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         w_odd = 0;
         // every ring register is written on every path (blocks this wave does not have: block 0 again), or the
         // ring of the previous item would stay live through the whole item
-        const int n1 = nblk_of(fs.H1);
+        const FusedUnit u = fused_unit<RB, NB>(fs.H1, wave);
         const _Float16 *wm = fs.w0 + (int64_t)m * (fs.H1 >> 5) * KS0 * (2 * FRAG) + lane * 8;
-        rg.nb_stride = n1 >= NB ? (int64_t)NW * KS0 * (2 * FRAG) : 0;
-        rg.base = wm + (int64_t)(n1 > 0 ? wave : 0) * KS0 * (2 * FRAG);
+        rg.nb_stride = u.nba >= NB ? (int64_t)NW * KS0 * (2 * FRAG) : 0;
+        rg.base = wm + (int64_t)u.cb * KS0 * (2 * FRAG);
 #pragma unroll
         for (int sl = 0; sl < D; ++sl) rg.template load<NB>(sl, next_ks());
         rg.nb_stride = (int64_t)NW * KS0 * (2 * FRAG);
@@ -1302,16 +1350,17 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const int4 te_n = g.tile_tab[item_n % n_tiles];
         const int atom_n = g.tile_rows[(size_t)(item_n % n_tiles) * ROWS + srow];
 #ifdef ANIHIP_DEV_TRACE
-        if (g.trace && tid == 0) {
-            g.trace[(size_t)item * 16 + 0] = __builtin_readcyclecounter();
+        if (g.trace && lane == 0) {
+            g.trace[((size_t)item * 8 + wave) * 16 + 0] = __builtin_readcyclecounter();
             // placement: HW_REG_HW_ID (cu / sh / se) and HW_REG_XCC_ID, for co-residency analysis
-            g.trace[(size_t)item * 16 + 14] = 1 + (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
+            g.trace[((size_t)item * 8 + wave) * 16 + 14] = 1 + (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
                                                    ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
         }
 #endif
         const int m = item / n_tiles, s = te.x, n_rows = te.z, p0 = te.y;
         const FusedSpecies &fs = g.sp[s];
         int64_t tm_base = 0;
+        const int rel_tile = g.d0_tm ? p0 - g.ctl[CTL_OFF + s] : 0;   // (scalar loads at the head of the item, not in the store phase)
         if (g.d0_tm)
             for (int t = 0; t < s; ++t) tm_base += (int64_t)((g.ctl[CTL_CNT + t] + 63) >> 6) * 64 * Mi * g.sp[t].H1;
         const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
@@ -1321,13 +1370,12 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         _Float16 *X1 = fsm;
         _Float16 *XU = fsm + 2 * ROWS * ld1;
         _Float16 *X0 = XU, *X2 = XU;
-        // number of column blocks (w, w + NW, ...) this wave has in the phases producing H1 / H2 / H3 columns
-        auto nblk = [&](int H) { const int t = (H >> 5) - wave; return t <= 0 ? 0 : (t + NW - 1) / NW; };
-        const int n1 = nblk(H1), n2 = nblk(H2), n3 = nblk(H3);
-        // accumulator element (rb, nb, r) of this lane <-> tile row rb*32 + fr, column col0(nb) + 8 (r >> 2) + (r & 3)
-        auto col0 = [&](int nb) { return (wave + NW * nb) * 32 + 4 * fk; };
+        // this wave's part of the phases producing H1 / H2 / H3 columns (fused_unit)
+        const FusedUnit u1 = fused_unit<RB, NB>(H1, wave), u2 = fused_unit<RB, NB>(H2, wave), u3 = fused_unit<RB, NB>(H3, wave);
+        // accumulator element (rb, nb, r) of this lane <-> tile row (u.rb0 + rb)*32 + fr, column col0(u, nb) + 8 (r >> 2) + (r & 3)
+        auto col0 = [&](const FusedUnit &u, int nb) { return (u.cb + NW * nb) * 32 + 4 * fk; };
 #ifdef ANIHIP_DEV_TRACE
-        unsigned long long *trace = g.trace ? g.trace + (size_t)item * 16 : nullptr;
+        unsigned long long *trace = g.trace ? g.trace + ((size_t)item * 8 + wave) * 16 : nullptr;
 #endif
         ANIHIP_STAMP(trace, 1);
 
@@ -1339,43 +1387,54 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
         };
         auto tile_max = [&](float vmax) {  // workgroup max of a non-negative value (s_max was reset at the head of the item)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            vmax = wave_max_nonneg(vmax);
             if (lane == 0) atomicMax(&s_max, __float_as_uint(vmax));
             __syncthreads();
             return __uint_as_float(s_max);
         };
         // acc * scale -> split planes of X (row stride ldx): this lane's runs of 4 columns of its first nba blocks
-        auto put_acc = [&](_Float16 *X, int plane, int ldx, float scale, int nba) {
+        auto put_acc = [&](_Float16 *X, int plane, int ldx, float scale, const FusedUnit &u) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    if (nb >= nba) continue;
+                    if (rb >= u.nrb || nb >= u.nba) continue;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         h4 hi, lo;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            // hi = fp16(x * scale), lo = fp16(x * scale - hi): two mixed-precision FMAs
-                            const float x = acc[rb * NB + nb][4 * q + e];
-                            const _Float16 h = (_Float16)(x * scale);
-                            hi[e] = h;
-                            lo[e] = (_Float16)__builtin_fmaf(x, scale, -(float)h);
+                        for (int e = 0; e < 4; e += 2) {
+                            // hi = fp16(x * scale) for two elements at once (v_pk_mul_f32, v_cvt_pk_f16_f32),
+                            // lo = fp16(x * scale - hi) as one mixed-precision FMA each (the fp16 hi is an operand)
+                            typedef float v2f_ __attribute__((ext_vector_type(2)));
+                            typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+                            const v2f_ x = v2f_{acc[rb * NB + nb][4 * q + e], acc[rb * NB + nb][4 * q + e + 1]};
+                            const h2_ h = __builtin_convertvector(x * scale, h2_);
+                            hi[e] = h[0];
+                            hi[e + 1] = h[1];
+                            // (written out: left to itself hipcc converts hi back to fp32 and packs again, 2 more
+                            // instructions per pair)
+                            h2_ l;
+                            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]"
+                                : "=v"(l) : "v"(x[0]), "v"(scale), "v"(h));
+                            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                                : "+v"(l) : "v"(x[1]), "v"(scale), "v"(h));
+                            lo[e] = l[0];
+                            lo[e + 1] = l[1];
                         }
-                        _Float16 *d = X + (rb * 32 + fr) * ldx + col0(nb) + 8 * q;
+                        _Float16 *d = X + ((u.rb0 + rb) * 32 + fr) * ldx + col0(u, nb) + 8 * q;
                         *reinterpret_cast<h4 *>(d) = hi;
                         *reinterpret_cast<h4 *>(d + plane) = lo;
                     }
                 }
         };
         // 16 per-column parameters per block of this lane (bias / output weights), as float4 loads
-        auto load_cols = [&](const float *base, float (&v)[NB][16], int nba) {   // (missing blocks: block 0, unused)
+        auto load_cols = [&](const float *base, float (&v)[NB][16], const FusedUnit &u) {   // (missing blocks: block 0, unused)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const v4f t = *(const gf4 *)(base + (nb < nba ? col0(nb) : 4 * fk) + 8 * q);
+                    const v4f t = *(const gf4 *)(base + (nb < u.nba ? col0(u, nb) : 4 * fk) + 8 * q);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[nb][4 * q + e] = t[e];
                 }
@@ -1384,7 +1443,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // =============== layer 0: act0 = celu(aev x W0^T + b0) over the flagged slabs ===============
         const v4f bnd = *(const gf4 *)(fs.bounds + 8 * m);   // operand bounds of this member
         float bias0[NB][16];
-        if (!C::LAZY) load_cols(fs.b0 + (int64_t)m * H1, bias0, n1);
+        if (!C::LAZY) load_cols(fs.b0 + (int64_t)m * H1, bias0, u1);
         const int nact = __popc(tmask);
         const int npair = (nact + 2 * FR_GROUP - 1) / (2 * FR_GROUP);
         // (AEV slabs 0..5 and the first D weight fragments were requested during the previous item)
@@ -1397,17 +1456,23 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // six slabs (two staging slots, 12 k steps) per barrier; the next six are fetched into registers
         // before the MFMAs of the current ones and staged after them
         for (int pr = 0; pr < npair; ++pr) {
-            fetch_group(va);
-            fetch_group(vb);
-            if (n1 > 0) {
+            // (only when another pair follows: the ring requests of the loop below complete in order BEHIND these)
+            if (pr + 1 < npair) {
+                fetch_group(va);
+                fetch_group(vb);
+            }
+            if (u1.nrb > 0) {
                 constexpr int PL = ROWS * FR_SLAB_LD, RBS = 32 * FR_SLAB_LD;
                 // 12 k steps = 2 slots x 3 slabs x 2; ring slot = step % D (12 % D == 0)
 #pragma unroll
                 for (int st = 0; st < 4 * FR_GROUP; ++st) {
                     const _Float16 *a = slot(2 * (pr & 1) + st / (2 * FR_GROUP)) + ((st / 2) % FR_GROUP) * SLAB +
-                                        (st & 1) * 16 + fr * FR_SLAB_LD + fk * 8;
-                    FR_BLOCKS(n1, (fr_step<RB, NB, NBA, D>(acc, rg, st % D, a, PL, RBS),
-                                   rg.template load<NBA>(st % D, next_ks())))
+                                        (st & 1) * 16 + (u1.rb0 * 32 + fr) * FR_SLAB_LD + fk * 8;
+                    // (the steps of the slabs past the tile's last flagged one have zero operands: no MFMAs, the
+                    // ring request stays unconditional)
+                    const bool live = 2 * FR_GROUP * pr + st / 2 < nact;
+                    FR_UNIT(u1, ((live ? fr_step<RB, NB, RBA, NBA, D>(acc, rg, st % D, a, PL, RBS) : (void)0),
+                                 rg.template load<NBA>(st % D, next_ks())))
                 }
             }
             if (pr + 1 < npair) {   // (the last pair's successors are zeros nobody reads)
@@ -1419,7 +1484,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         ANIHIP_STAMP(trace, 3);
         // weights of phase 1 start streaming during the layer-0 epilogue
         Ring r1;
-        fr_ring<NB, D>(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, wave, NW, lane, n2);
+        fr_ring<NB, D>(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, u2.cb, NW, lane, u2.nba);
         // celu and its derivative from one exponential: x > 0: (x, 1), else (alpha (e - 1), e), e = exp(x / alpha)
         const float ia_log2e = inv_alpha * 1.44269504f;
         auto celu_d = [&](float x, float &d) {
@@ -1446,7 +1511,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         float d0f[NE][16];   // celu'(act0) of this lane's elements
         float a0max;         // tile max of |act0|
         {
-            if (C::LAZY) load_cols(fs.b0 + (int64_t)m * H1, bias0, n1);
+            if (C::LAZY) load_cols(fs.b0 + (int64_t)m * H1, bias0, u1);
             const float oscale = fs.is0 * 0.25f;
             float vmax = 0.f;
 #pragma unroll
@@ -1456,17 +1521,22 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const int i = rb * NB + nb;
-                        float v0, v1;
-                        celu_d2(acc[i][r], acc[i][r + 1], oscale, bias0[nb][r], bias0[nb][r + 1], v0, v1, d0f[i][r],
-                                d0f[i][r + 1]);
-                        acc[i][r] = v0;
-                        acc[i][r + 1] = v1;
-                        vmax = fmaxf(vmax, nb < n1 ? fmaxf(fabsf(v0), fabsf(v1)) : 0.f);
+                        if (rb < u1.nrb) {
+                            float v0, v1;
+                            celu_d2(acc[i][r], acc[i][r + 1], oscale, bias0[nb][r], bias0[nb][r + 1], v0, v1, d0f[i][r],
+                                    d0f[i][r + 1]);
+                            acc[i][r] = v0;
+                            acc[i][r + 1] = v1;
+                            vmax = fmaxf(vmax, nb < u1.nba ? fmaxf(fabsf(v0), fabsf(v1)) : 0.f);
+                        } else {   // (defined on every path, like the rings)
+                            d0f[i][r] = 0.f;
+                            d0f[i][r + 1] = 0.f;
+                        }
                     }
             a0max = tile_max(vmax);   // (barriers: every wave is past the staging slots)
         }
         const float s0 = pow2_scale_for(a0max);
-        put_acc(X0, x0_plane, ld0, s0, n1);
+        put_acc(X0, x0_plane, ld0, s0, u1);
         // the scales of the inner GEMM operands follow from a0max and the weight-norm bounds: no more reductions
         const float s1 = pow2_scale_for(__builtin_fmaf(a0max, bnd[0], bnd[1]));   // |act1| <= a0max ||W1||_inf + |b1|
         const float s2 = pow2_scale_for(bnd[2]);                                  // |d act2| <= max |w3| / M
@@ -1476,15 +1546,15 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 
         // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
         float bias1[NB][16];   // (per-column parameters travel during the GEMM)
-        if (!C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, n2);
+        if (!C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, u2);
         zero_acc();
-        FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X0, ld0, x0_plane, r1, H1 >> 4, lane)))
+        FR_UNIT(u2, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X0 + u2.rb0 * 32 * ld0, ld0, x0_plane, r1, H1 >> 4, lane)))
         ANIHIP_STAMP(trace, 5);
         Ring r2;
-        fr_ring<NB, D>(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW, lane, n3);
+        fr_ring<NB, D>(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, u3.cb, NW, lane, u3.nba);
         float d1f[NE][16];   // celu'(act1) of this lane's elements
-        if (n2 > 0) {
-            if (C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, n2);
+        {
+            if (C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, u2);
             const float oscale = fs.is1 / s0;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -1493,18 +1563,18 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const int i = rb * NB + nb;
-                        float dl0, dl1, y0, y1;
-                        celu_d2(acc[i][r], acc[i][r + 1], oscale, bias1[nb][r], bias1[nb][r + 1], y0, y1,
-                                C::LAZY ? dl0 : d1f[i][r], C::LAZY ? dl1 : d1f[i][r + 1]);
-                        acc[i][r] = y0;
-                        acc[i][r + 1] = y1;
+                        if (rb < u2.nrb) {
+                            float dl0, dl1, y0, y1;
+                            celu_d2(acc[i][r], acc[i][r + 1], oscale, bias1[nb][r], bias1[nb][r + 1], y0, y1,
+                                    C::LAZY ? dl0 : d1f[i][r], C::LAZY ? dl1 : d1f[i][r + 1]);
+                            acc[i][r] = y0;
+                            acc[i][r + 1] = y1;
+                        } else {   // (defined on every path, like the rings)
+                            d1f[i][r] = 0.f;
+                            d1f[i][r + 1] = 0.f;
+                        }
                     }
-            put_acc(X1, x1_plane, ld1, s1, n2);
-        } else {   // (defined on every path, like the rings)
-#pragma unroll
-            for (int i = 0; i < NE; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) d1f[i][r] = 0.f;
+            put_acc(X1, x1_plane, ld1, s1, u2);
         }
         __syncthreads();  // X1 complete; every wave is done reading X0 -> XU reusable
         ANIHIP_STAMP(trace, 6);
@@ -1512,43 +1582,55 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // =============== phase 2: act2 = celu(act1 x W2^T + b2); output layer; backward seed ===============
         float bias2[NB][16], w3[NB][16];
         if (!C::LAZY) {
-            load_cols(fs.b2 + (int64_t)m * H3, bias2, n3);
-            load_cols(fs.w3 + (int64_t)m * H3, w3, n3);
+            load_cols(fs.b2 + (int64_t)m * H3, bias2, u3);
+            load_cols(fs.w3 + (int64_t)m * H3, w3, u3);
         }
         zero_acc();
-        FR_BLOCKS(n3, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r2, H2 >> 4, lane)))
+        FR_UNIT(u3, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X1 + u3.rb0 * 32 * ld1, ld1, x1_plane, r2, H2 >> 4, lane)))
         ANIHIP_STAMP(trace, 7);
         Ring r3;   // (also without want_grad: see fr_ring)
-        fr_ring<NB, D>(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, wave, NW, lane, n2);
+        fr_ring<NB, D>(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, u2.cb, NW, lane, u2.nba);
         {
             // e = sum_col act2 * w3 (+ b3): per-lane partial over its columns, the two k halves of a row
             // combined with a lane swap, the waves through LDS in a fixed order (deterministic sum).
             // seed: d act2 = w3 * celu'(act2) / M, kept in the accumulators
             if (C::LAZY) {
-                load_cols(fs.b2 + (int64_t)m * H3, bias2, n3);
-                load_cols(fs.w3 + (int64_t)m * H3, w3, n3);
+                load_cols(fs.b2 + (int64_t)m * H3, bias2, u3);
+                load_cols(fs.w3 + (int64_t)m * H3, w3, u3);
             }
             const float osc2 = fs.is2 / s1;
             const float invM = 1.0f / (float)Mi;
+            float e_loc[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 float e = 0.f;
+                if (rb < u3.nrb) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int i = rb * NB + nb;
-                        float y0, y1, dy0, dy1;
-                        celu_d2(acc[i][r], acc[i][r + 1], osc2, bias2[nb][r], bias2[nb][r + 1], y0, y1, dy0, dy1);
-                        e = __builtin_fmaf(nb < n3 ? y0 : 0.f, w3[nb][r], e);
-                        e = __builtin_fmaf(nb < n3 ? y1 : 0.f, w3[nb][r + 1], e);
-                        acc[i][r] = invM * w3[nb][r] * dy0;
-                        acc[i][r + 1] = invM * w3[nb][r + 1] * dy1;
-                    }
-                e += __shfl_xor(e, 32);
-                if (fk == 0) s_e[wave * ROWS + rb * 32 + fr] = e;
+                        for (int r = 0; r < 16; r += 2) {
+                            const int i = rb * NB + nb;
+                            float y0, y1, dy0, dy1;
+                            celu_d2(acc[i][r], acc[i][r + 1], osc2, bias2[nb][r], bias2[nb][r + 1], y0, y1, dy0, dy1);
+                            e = __builtin_fmaf(nb < u3.nba ? y0 : 0.f, w3[nb][r], e);
+                            e = __builtin_fmaf(nb < u3.nba ? y1 : 0.f, w3[nb][r + 1], e);
+                            acc[i][r] = invM * w3[nb][r] * dy0;
+                            acc[i][r + 1] = invM * w3[nb][r + 1] * dy1;
+                        }
+                    e += __shfl_xor(e, 32);
+                }
+                e_loc[rb] = e;
             }
-            if (g.want_grad) put_acc(X2, x2_plane, ld2, s2, n3);   // (XU: X0 is dead since the last barrier)
+            // every wave writes its partial of every row of the tile (zero for the row blocks it has no unit in)
+#pragma unroll
+            for (int t = 0; t < RB; ++t) {
+                float v = 0.f;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    if (t - u3.rb0 == rb && rb < u3.nrb) v = e_loc[rb];
+                if (fk == 0) s_e[wave * ROWS + t * 32 + fr] = v;
+            }
+            if (g.want_grad) put_acc(X2, x2_plane, ld2, s2, u3);   // (XU: X0 is dead since the last barrier)
         }
         __syncthreads();
         if (tid < n_rows) {
@@ -1563,18 +1645,22 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         if (g.want_grad) {
             // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
             zero_acc();
-            FR_BLOCKS(n2, (fr_gemm<RB, NB, NBA, D>(acc, X2, ld2, x2_plane, r3, H3 >> 4, lane)))
+            FR_UNIT(u2, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X2 + u2.rb0 * 32 * ld2, ld2, x2_plane, r3, H3 >> 4, lane)))
             ANIHIP_STAMP(trace, 10);
         }
-        fr_ring<NB, D>(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, wave, NW, lane, n1);
+        fr_ring<NB, D>(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, u1.cb, NW, lane, u1.nba);
         if (g.want_grad) {
-            if (n2 > 0) {
+            if (u2.nrb > 0) {
                 const float osc3 = fs.is2 / s2;
                 if constexpr (!C::LAZY) {
 #pragma unroll
-                    for (int i = 0; i < NE; ++i)
+                    for (int rb = 0; rb < RB; ++rb) {
+                        if (rb >= u2.nrb) continue;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][r] *= osc3 * d1f[i][r];
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[rb * NB + nb][r] *= osc3 * d1f[rb * NB + nb][r];
+                    }
                 } else {
                     // celu'(act1) from act1 itself, which this lane still finds at its own positions of X1
                     // (celu' = 1 for y > 0, else y / alpha + 1), before d act1 overwrites it
@@ -1583,10 +1669,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
-                            if (nb >= n2) continue;
+                            if (rb >= u2.nrb || nb >= u2.nba) continue;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const _Float16 *d = X1 + (rb * 32 + fr) * ld1 + col0(nb) + 8 * q;
+                                const _Float16 *d = X1 + ((u2.rb0 + rb) * 32 + fr) * ld1 + col0(u2, nb) + 8 * q;
                                 const h4 yh = *reinterpret_cast<const h4 *>(d);
                                 const h4 yl = *reinterpret_cast<const h4 *>(d + x1_plane);
 #pragma unroll
@@ -1597,36 +1683,37 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                             }
                         }
                 }
-                put_acc(X1, x1_plane, ld1, s3, n2);   // (X1: its last readers finished before the previous barrier)
+                put_acc(X1, x1_plane, ld1, s3, u2);   // (X1: its last readers finished before the previous barrier)
             }
         }
-        // the AEV slabs of the next item travel during phase 4 (requested AFTER the ring: loads complete in
-        // order, and the first MFMAs of phase 4 wait for the ring only)
-        prefetch_aev(te_n, atom_n);
         __syncthreads();
         ANIHIP_STAMP(trace, 11);
         // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
-        if (g.want_grad && n1 > 0) {
+        if (g.want_grad && u1.nrb > 0) {
             zero_acc();
-            FR_BLOCKS(n1, (fr_gemm<RB, NB, NBA, D>(acc, X1, ld1, x1_plane, r4, H2 >> 4, lane)))
+            FR_UNIT(u1, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X1 + u1.rb0 * 32 * ld1, ld1, x1_plane, r4, H2 >> 4, lane)))
         }
         ANIHIP_STAMP(trace, 12);
-        // every wave is done with the LDS of this item: the next one may stage its slabs.  Its first layer-0
-        // weight fragments travel during the stores below
+        // the AEV slabs of the next item and its first layer-0 weight fragments travel during the stores below
+        // (requested AFTER the last ring load of this item: loads complete in order, and an HBM miss ahead of a
+        // ring request stalls the MFMA loop that waits for it)
+        prefetch_aev(te_n, atom_n);
+        // every wave is done with the LDS of this item: the next one may stage its slabs
         __syncthreads();
         prefetch_w0(te_n, item_n);
-        if (g.want_grad && n1 > 0) {
+        if (g.want_grad && u1.nrb > 0) {
             const float osc4 = fs.is1 / s3;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const int row = rb * 32 + fr;
+                if (rb >= u1.nrb) continue;
+                const int row = (u1.rb0 + rb) * 32 + fr;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    if (nb >= n1) continue;
-                    float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0(nb);
+                    if (nb >= u1.nba) continue;
+                    float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0(u1, nb);
                     if (g.d0_tm) {
-                        const int rel = p0 - g.ctl[CTL_OFF + s] + min(row, n_rows - 1);
-                        dst = g.d0 + tm_base + ((int64_t)((rel >> 6) * Mi + m) * 64 + (rel & 63)) * H1 + col0(nb);
+                        const int rel = rel_tile + min(row, n_rows - 1);
+                        dst = g.d0 + tm_base + ((int64_t)((rel >> 6) * Mi + m) * 64 + (rel & 63)) * H1 + col0(u1, nb);
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -1645,7 +1732,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         item = item_n;
     }
 }
-#undef FR_BLOCKS
+#undef FR_UNIT
 
 // sum the per-member energies of the fused kernel: atomic_e = mean_m, optional [M][n_atoms] copy
 __global__ void k_fused_finish(const int *ctl, int S, int M, const int *perm, const float *member_part,
@@ -2340,7 +2427,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                            rows, w.tile_tab, w.tile_rows);
 #ifdef ANIHIP_DEV_TRACE   // development builds only (tools/fused_trace.py): per-item phase stamps, allocates and synchronises
         const char *trace_path = getenv("ANIHIP_FUSED_TRACE");
-        const size_t trace_words = (size_t)16 * items;
+        const size_t trace_words = (size_t)16 * 8 * items;   // [item][wave][16]
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipMalloc((void **)&f.trace, sizeof(unsigned long long) * trace_words));
             ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * trace_words));
