@@ -32,6 +32,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32-input MFMA peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak (the f16x3 path issues 3 fp16 MFMA flops per fp32 flop)
+# what an MI355X sustains on a pure v_mfma_f32_32x32x16_f16 stream with LDS operand reads, 2 waves per SIMD
+# (tools/overlap3.hip, "GEMM stream alone": 256 CUs x 8 waves x 96000 MFMAs in 4.04 ms; the shader clock drops to
+# ~1.15 GHz under that load) -- recorded, not re-measured in the bench run
+MFMA_F16_SUSTAINED_TFLOPS = 1590.0
 
 
 def water_box(n_side: int, seed: int = 4, spacing: float = 3.107):
@@ -284,6 +288,8 @@ def main():
             # flops of the EXECUTED (slab-skipped) work against the dense fp16 MFMA peak
             "achieved": 3.0 * mlp_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": 3.0 * mlp_tflops / MFMA_F16_PEAK_TFLOPS,
+            "sustained_mfma_stream_tflops": MFMA_F16_SUSTAINED_TFLOPS,
+            "frac_of_sustained": 3.0 * mlp_tflops / MFMA_F16_SUSTAINED_TFLOPS,
             "fp32_equivalent_tflops": mlp_tflops, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
             "flops_per_atom_executed": flops_atom, "flops_per_atom_dense": flops_dense,
             "mean_active_slabs": mean_slabs,
