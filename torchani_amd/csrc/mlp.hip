@@ -569,7 +569,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
     const int m0 = (row_t - ctl[CTL_TILE + s]) * BM;
     const int n_rows = ctl[CTL_CNT + s] - m0;
     const int p0 = ctl[CTL_OFF + s] + m0;
-    const int nb_act = min(4, (pr.N - n0) >> 5);
+    int nb_act = min(4, (pr.N - n0) >> 5);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float sa = g.amax_in >= 0 ? amax_scale(g.amax, g.amax_in, s) : g.a_static_scale;
@@ -577,6 +577,37 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
 
     // loaders: thread t -> rows t>>2 and 64 + (t>>2), 8 consecutive k (piece t&3) of every plane
     const int srow = tid >> 2, piece = tid & 3;
+
+    // ---- layer-0 backward with slab masks: the tile's 4 column blocks are the (4 col_t .. 4 col_t + 3)-th blocks
+    // flagged in the OR of its atoms' masks (as in k_gemm_h2); column tiles past the last flagged block exit ----
+    int cbw[4] = {(n0 >> 5), (n0 >> 5) + 1, (n0 >> 5) + 2, (n0 >> 5) + 3};   // this tile's column blocks
+    const bool compact = (EPI == EPI_SCATTER) && g.stage_mask;
+    if (compact) {
+        __shared__ int s_tab[5];   // [0] = tile mask, [1..4] = column blocks
+        const int *rows = g.a_gather ? g.a_gather : g.c_scatter;   // sorted position -> atom
+        const int q0 = srow < n_rows ? srow : 0, q1 = srow + 64 < n_rows ? srow + 64 : 0;
+        uint32_t mk = g.stage_mask[rows[p0 + q0]] | g.stage_mask[rows[p0 + q1]];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mk |= (uint32_t)__shfl_xor((int)mk, o);
+        if (tid == 0) s_tab[0] = 0;
+        __syncthreads();
+        if (lane == 0) atomicOr(reinterpret_cast<unsigned *>(&s_tab[0]), mk);
+        __syncthreads();
+        const uint32_t tmask = (uint32_t)s_tab[0];
+        if (4 * col_t >= __popc(tmask)) return;   // (also: atoms without neighbors, nothing to differentiate)
+        if (tid < 4) {
+            uint32_t m = tmask;
+            for (int k = 0; k < 4 * col_t + tid; ++k) m &= m - 1;
+            s_tab[1 + tid] = m ? (int)__builtin_ctz(m) : -1;
+        }
+        __syncthreads();
+        nb_act = 0;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            cbw[nb] = s_tab[1 + nb];
+            if (cbw[nb] >= 0) nb_act = nb + 1;
+        }
+    }
     const gf4 *a_src0, *a_src1;
     {
         const int r0 = srow < n_rows ? srow : 0, r1 = srow + 64 < n_rows ? srow + 64 : 0;
@@ -585,7 +616,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
         a_src0 = (const gf4 *)(g.A + s0r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
         a_src1 = (const gf4 *)(g.A + s1r * g.lda + (int64_t)bb * pr.a_boff + piece * 8);
     }
-    const int bn0 = (n0 + srow < pr.N) ? n0 + srow : n0, bn1 = (n0 + srow + 64 < pr.N) ? n0 + srow + 64 : n0;
+    int bn0 = (n0 + srow < pr.N) ? n0 + srow : n0, bn1 = (n0 + srow + 64 < pr.N) ? n0 + srow + 64 : n0;
+    if (compact) {   // B rows staged by this thread: tile columns srow and srow + 64 of the compacted blocks
+        const int c0 = cbw[srow >> 5], c1 = cbw[2 + (srow >> 5)];
+        bn0 = (c0 >= 0 ? c0 : cbw[0]) * 32 + (srow & 31);
+        bn1 = (c1 >= 0 ? c1 : cbw[0]) * 32 + (srow & 31);
+    }
     const _Float16 *b_src0 = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)bn0 * pr.ldbh + piece * 8;
     const _Float16 *b_src1 = pr.Bh + (int64_t)bb * pr.bh_stride + (int64_t)bn1 * pr.ldbh + piece * 8;
 
@@ -608,7 +644,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         if (nb >= nb_act) continue;
-        const int col = n0 + nb * 32 + fr;
+        const int col = cbw[nb] * 32 + fr;
         float bias = 0.f;
         if (EPI == EPI_BIAS_CELU) bias = pr.bias[(int64_t)bb * pr.bias_stride + col];
 #pragma unroll
@@ -2511,7 +2547,12 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             g.amax_in = h3 ? 3 + (nh - 1 - l) : -1;
             g.amax_out = (h3 && l > 0) ? 3 + (nh - l) : -1;
             g.a_static_scale = 1.0f;
-            if (l == 0) { g.kp_rad = kp_rad; g.stage_mask = smask; }
+            if (l == 0) {
+                // (the layer-0 backward compacts its output columns in both tilings; the forward honours the flags only
+                // in the 256 x 256 kernel)
+                g.kp_rad = kp_rad;
+                g.stage_mask = (h3 && kp_rad > 0 && K0p <= 32 * 32 && !(d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK)) ? slab_mask : nullptr;
+            }
             if (l == 0 && d0_tm) {
                 g.a_tm_members = M;
                 for (int s = 0; s < S; ++s) g.a_tm_h[s] = d->net[s].dims[1];
