@@ -363,6 +363,16 @@ class VerletRows:
         return out
 
 
+_N_CUS: tp.Dict[int, int] = {}
+
+
+def _n_cus(dev: torch.device) -> int:
+    i = dev.index if dev.index is not None else torch.cuda.current_device()
+    if i not in _N_CUS:
+        _N_CUS[i] = int(torch.cuda.get_device_properties(i).multi_processor_count)
+    return _N_CUS[i]
+
+
 class PackedNetworks:
     """Ensemble parameters in the MFMA-friendly layout of include/anihip.h (members concatenated, widths
     padded to 32, transposed copies for the backward GEMMs); cf. BmmAtomicNetwork, nn/_infer.py:141-161."""
@@ -544,9 +554,20 @@ class PackedNetworks:
             assert grad_aev.numel() == rows * self.aev_len
         member_e = torch.zeros((self.M, n), dtype=torch.float32, device=dev) if want_members else None
         L = _lib.lib()
-        # equal chunks (a short last chunk would leave most CUs idle in its tail)
-        nchunk = max(1, -(-(hi - lo) // chunk))
-        step = max(1, -(-(-(-(hi - lo) // nchunk)) // 256) * 256)
+        # equal chunks (a short last chunk would leave most CUs idle in its tail), up to twice the preferred size when
+        # that saves rounds of the 256-row layer-0 backward GEMM: its one-workgroup-per-CU tiles run in whole rounds
+        # over the CUs (a rank's 292 k-atom shard of the 2.3 M-atom box: 2 chunks x 3 rounds -> 1 chunk x 5 rounds)
+        nn_ = hi - lo
+        n_cu = _n_cus(dev)
+
+        def plan(nc: int) -> tp.Tuple[int, int]:
+            st_ = max(1, -(-(-(-nn_ // nc)) // 256) * 256)
+            return nc * -(-(st_ // 256 + self.S) // n_cu), st_
+
+        nc_hi = max(1, -(-nn_ // chunk))
+        cands = range(max(1, -(-nn_ // (2 * chunk))), nc_hi + 3) if want_grad and nn_ >= 65536 else (nc_hi,)
+        nchunk = min(cands, key=lambda nc: (plan(nc)[0], nc))
+        step = plan(nchunk)[1]
         for c0 in range(lo, hi, step):
             c1 = min(hi, c0 + step)
             ws = self.workspace(c1 - c0)
