@@ -74,6 +74,7 @@ struct GemmArgs {
     int64_t ldc;
     const float *Y;        // EPI_DCELU of the training pass (k_gemm): activations read from here, C only written
     int64_t ldy;           //   (NULL: C holds the activations and is overwritten in place)
+    int skinny;            // k_gemm_h2<EPI_SCATTER>: row tiles with <= L0B_MAXNB flagged column blocks belong to k_gemm_l0b
     int a_tm_members;      // > 0: A is the tile-major d E / d act0 buffer (see tm_species_base), this many members
     int a_tm_h[MAX_S];     //      and per-species row width H_s
     const float *Z;        // tangent pass: zdot (same leading dimension as Y)
@@ -111,6 +112,14 @@ constexpr int AMAX_WORDS = AMAX_STAGES * MAX_S * AMAX_SLOTS;
 // contiguously:   offset(s, rel, m, c) = base_s + (((rel >> 6) * M + m) * 64 + (rel & 63)) * H_s + c,
 // base_s = sum_{s' < s} ceil(cnt_s' / 64) * 64 * M * H_s'.  Both kernels then stream whole 16..64-KB blocks instead of
 // 128-B .. 1-KB pieces strided by the 8-KB row of the plain [n][M * H] layout.
+// d E / d act0 from the fused kernel to the layer-0 backward GEMMs, "tile-major": per species, per 64-atom tile, member
+// after member a 64 x H block; INSIDE a block the floats lie in MFMA A-fragment order:
+//   [column block cb][row block rb][k step ks][lane = c8 * 32 + row][8 floats]   (column = 32 cb + 16 ks + 8 c8 + j)
+// i.e. 2-KB units of 32 rows x 16 columns.  The fused kernel's store instruction (32 rows x 2 runs of 4 columns)
+// fills 1 KB of a unit contiguously, a wave of the skinny GEMM reads its whole fragment of a k step as one
+// coalesced 2-KB load, the 256 x 256 GEMM's staging threads read 32-B pieces 32 B apart.
+__device__ __forceinline__ int tm_unit(int cb, int rb, int ks) { return ((cb * 2 + rb) * 2 + ks) * 512; }
+
 __device__ __forceinline__ int64_t tm_species_base(const int *ctl, const int *H, int M, int s)
 {
     int64_t base = 0;
@@ -680,6 +689,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
 // staging stores and L2 traffic per MFMA are halved.  One workgroup per CU (128 KB of LDS, double
 // buffered), two waves per SIMD.
 constexpr int BM2 = 256, BN2 = 256;
+constexpr int L0B_MAXNB = 6;               // most column blocks k_gemm_l0b (below) takes
 constexpr int H2_PLANE = BM2 * HBK;        // halves per plane per stage
 constexpr int H2_STAGE = 4 * H2_PLANE;     // A_hi, A_lo, B_hi, B_lo
 constexpr int GEMM2_THREADS = 512;
@@ -700,9 +710,9 @@ __device__ __forceinline__ void gemm_h2_kloop(f32x16 (&acc)[8], const gf4 *a_src
     HStage st;
     auto gload = [&](int kt) {
         int acol = kp_rad ? kp_col(kp_rad, kt) : kt * HBK;
-        if (tm_h) {   // tile-major: column kt * 32 = member mm, unit c0; members are 64 * H apart
+        if (tm_h) {   // tile-major: column kt * 32 = member mm, column block cb; members are 64 * H apart
             const int mm = (int)(((float)(kt * HBK) + 0.5f) * tm_inv_h);
-            acol = mm * 64 * tm_h + (kt * HBK - mm * tm_h);
+            acol = mm * 64 * tm_h + tm_unit((kt * HBK - mm * tm_h) >> 5, 0, 0);
         }
         const bool ok = kp_rad ? piece * 8 < kp_valid(kp_rad, kt) : kt * HBK + piece * 8 < k_valid;
         const int o = ok ? acol / 4 : 0;
@@ -848,6 +858,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
         __syncthreads();
         tmask = (uint32_t)s_tab[0];
         if (tmask == 0u && EPI == EPI_SCATTER) return;   // atoms without neighbors: nothing to differentiate
+        if (EPI == EPI_SCATTER && g.skinny && __popc(tmask) <= L0B_MAXNB) return;   // k_gemm_l0b's tile
     }
 
     // ---- columns of this tile ----
@@ -894,8 +905,11 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
         tm_h = g.a_tm_h[s];
         const int64_t base = tm_species_base(ctl, g.a_tm_h, g.a_tm_members, s);
         const int rel0 = m0 + r0, rel1 = m0 + r1;
-        a_src0 = (const gf4 *)(g.A + base + ((int64_t)(rel0 >> 6) * g.a_tm_members * 64 + (rel0 & 63)) * tm_h + piece * 8);
-        a_src1 = (const gf4 *)(g.A + base + ((int64_t)(rel1 >> 6) * g.a_tm_members * 64 + (rel1 & 63)) * tm_h + piece * 8);
+        // (row, 8 k values of piece p) = unit (cb, row block, k step p >> 1), lane slot (p & 1) * 32 + row
+        a_src0 = (const gf4 *)(g.A + base + (int64_t)(rel0 >> 6) * g.a_tm_members * 64 * tm_h +
+                               tm_unit(0, (rel0 >> 5) & 1, piece >> 1) + ((piece & 1) * 32 + (rel0 & 31)) * 8);
+        a_src1 = (const gf4 *)(g.A + base + (int64_t)(rel1 >> 6) * g.a_tm_members * 64 * tm_h +
+                               tm_unit(0, (rel1 >> 5) & 1, piece >> 1) + ((piece & 1) * 32 + (rel1 & 31)) * 8);
     }
     // B rows staged by this thread: tile columns srow and srow + 128
     int bn0, bn1;
@@ -957,6 +971,228 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void k_gemm_h2(GemmArgs g)
     }
     }   // column groups
     if (g.amax_out >= 0) amax_update(g.amax, g.amax_out, s, vmax);
+}
+
+// ---- layer-0 backward over FEW flagged slabs (f16x3): 256 rows x (32 NB) columns, NB <= 6 ------------------------
+// With slab masks the output of the layer-0 backward is skinny (water: 5 column blocks against K = 8 H1 = 2048), and the
+// 256 x 256 kernel above spends its stage on staging and re-reading an A tile that every wave uses for two or three
+// column blocks only.  Here the eight waves of a workgroup each own 32 ROWS and ALL flagged column blocks: a wave's A
+// operand (d E / d act0, fp32, tile-major) goes from global memory straight into registers -- lane (row, k half) reads
+// its 8 consecutive k values, converts them to {hi, lo} fp16 fragments in place (v_cvt_pk_f16_f32 + mixed FMAs) -- and
+// only the pre-split B planes (W0 of the flagged slabs, shared by all waves) are staged through LDS: 24 KB per
+// 32-deep stage instead of 64 KB, no A stores, no A fragment reads, every wave issues the same 6 NB MFMAs per stage.
+// Tiles with more than 6 flagged blocks are left to k_gemm_h2 (GemmArgs.skinny tells that kernel to skip the others).
+constexpr int L0B_THREADS = 512;
+constexpr int L0B_PLANE = L0B_MAXNB * 32 * HBK;   // halves per B plane per stage
+constexpr int L0B_STAGE = 2 * L0B_PLANE;          // B_hi, B_lo
+
+struct L0bB {
+    h8 h[2], l[2];   // [row pass]
+};
+
+template <int NB>
+__device__ __forceinline__ void l0b_kloop(f32x16 (&acc)[L0B_MAXNB], const float *arow, int tm_h, int nk, float sa,
+                                          const _Float16 *b_src0, const _Float16 *b_src1, int64_t bh_plane,
+                                          bool st0, bool st1, _Float16 *sm)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int srow = tid >> 2, piece = tid & 3;
+    const int fr = lane & 31, fk = lane >> 5;
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+    // A of stage kt: member mm = 32 kt / tm_h, columns 32 kt - mm tm_h ..; members are 64 tm_h floats apart
+    auto a_off = [&](int kt) {
+        const int k = kt * HBK, mm = (int)(((float)k + 0.5f) / (float)tm_h);
+        return (int64_t)mm * 64 * tm_h + tm_unit((k - mm * tm_h) >> 5, 0, 0);
+    };
+    auto aload = [&](v4f (&a)[4], int kt) {   // two coalesced 2-KB wave loads per k step
+        const gf4 *p = (const gf4 *)(arow + a_off(kt));
+        a[0] = p[0]; a[1] = p[1];        // k step 0: this lane's k = 8 fk .. 8 fk + 7
+        a[2] = p[128]; a[3] = p[129];    // k step 1: the next unit (512 floats on)
+    };
+    auto bload = [&](L0bB &b, int kt) {
+        b.h[0] = *(const gh8 *)(b_src0 + kt * HBK);
+        b.l[0] = *(const gh8 *)(b_src0 + bh_plane + kt * HBK);
+        b.h[1] = *(const gh8 *)(b_src1 + kt * HBK);
+        b.l[1] = *(const gh8 *)(b_src1 + bh_plane + kt * HBK);
+    };
+    auto bstore = [&](const L0bB &b, int buf) {
+        _Float16 *base = sm + buf * L0B_STAGE;
+        if (st0) {
+            const int off = h_off(srow, piece);
+            *reinterpret_cast<h8 *>(base + off) = b.h[0];
+            *reinterpret_cast<h8 *>(base + L0B_PLANE + off) = b.l[0];
+        }
+        if (st1) {
+            const int off = h_off(srow + 128, piece);
+            *reinterpret_cast<h8 *>(base + off) = b.h[1];
+            *reinterpret_cast<h8 *>(base + L0B_PLANE + off) = b.l[1];
+        }
+    };
+    auto compute = [&](int buf, const v4f (&a)[4]) {
+        const _Float16 *base = sm + buf * L0B_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {
+            h8 ahi, alo;
+#pragma unroll
+            for (int c = 0; c < 8; c += 2) {
+                const v4f &src = a[2 * ks + (c >> 2)];
+                const v2f_ x = v2f_{src[c & 3], src[(c & 3) + 1]};
+                const h2_ h = __builtin_convertvector(x * sa, h2_);
+                h2_ l;
+                asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x[0]), "v"(sa), "v"(h));
+                asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x[1]), "v"(sa), "v"(h));
+                ahi[c] = h[0]; ahi[c + 1] = h[1];
+                alo[c] = l[0]; alo[c + 1] = l[1];
+            }
+            const int pc = ks * 2 + fk;
+            h8 bhi[NB], blo[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int bo = h_off(nb * 32 + fr, pc);
+                bhi[nb] = *reinterpret_cast<const h8 *>(base + bo);
+                blo[nb] = *reinterpret_cast<const h8 *>(base + L0B_PLANE + bo);
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[nb], acc[nb], 0, 0, 0);
+        }
+    };
+    // A: three register sets in rotation (the loads of stage kt + 2 are issued while stage kt is computed);
+    // B: one register set a stage ahead of the LDS double buffer
+    v4f a0[4], a1[4], a2[4];
+    L0bB bs;
+    aload(a0, 0);
+    bload(bs, 0);
+    aload(a1, min(1, nk - 1));
+    bstore(bs, 0);
+    bload(bs, min(1, nk - 1));
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 3) {
+        // stage kt (buffer kt & 1): A in a0
+        aload(a2, min(kt + 2, nk - 1));
+        compute(kt & 1, a0);
+        if (kt + 1 < nk) bstore(bs, (kt + 1) & 1);
+        bload(bs, min(kt + 2, nk - 1));
+        __syncthreads();
+        if (kt + 1 < nk) {
+            aload(a0, min(kt + 3, nk - 1));
+            compute((kt + 1) & 1, a1);
+            if (kt + 2 < nk) bstore(bs, kt & 1);
+            bload(bs, min(kt + 3, nk - 1));
+            __syncthreads();
+        }
+        if (kt + 2 < nk) {
+            aload(a1, min(kt + 4, nk - 1));
+            compute(kt & 1, a2);
+            if (kt + 3 < nk) bstore(bs, (kt + 1) & 1);
+            bload(bs, min(kt + 4, nk - 1));
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(L0B_THREADS, 2) void k_gemm_l0b(GemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 sm3[];
+    int *s_tab = reinterpret_cast<int *>(sm3 + 2 * L0B_STAGE);   // [0] = tile mask
+    const int nwg = gridDim.x;
+    int row_t = blockIdx.x;
+    {
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = row_t & 7;
+        row_t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (row_t >> 3);
+    }
+    const int *ctl = g.ctl;
+    int s = 0, cnt = 0;
+    for (; s < g.S; ++s) {
+        cnt = ctl[CTL_CNT + s];
+        const int nt = (cnt + BM2 - 1) / BM2;
+        if (row_t < nt) break;
+        row_t -= nt;
+    }
+    if (s >= g.S) return;
+    const GemmProblem &pr = g.prob[s];
+    const int m0 = row_t * BM2;
+    const int n_rows = cnt - m0;
+    const int p0 = ctl[CTL_OFF + s] + m0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int srow = tid >> 2, piece = tid & 3;
+    const int fr = lane & 31, fk = lane >> 5;
+
+    // slab mask of the row tile: OR over its atoms
+    {
+        const int *rows = g.c_scatter;   // sorted position -> atom
+        const int q0 = srow < n_rows ? srow : 0, q1 = srow + 128 < n_rows ? srow + 128 : 0;
+        uint32_t mk = g.stage_mask[rows[p0 + q0]] | g.stage_mask[rows[p0 + q1]];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mk |= (uint32_t)__shfl_xor((int)mk, o);
+        if (tid == 0) s_tab[0] = 0;
+        __syncthreads();
+        if (lane == 0) atomicOr(reinterpret_cast<unsigned *>(&s_tab[0]), mk);
+        __syncthreads();
+    }
+    const uint32_t tmask = (uint32_t)s_tab[0];
+    const int nb_act = __popc(tmask);
+    if (nb_act == 0 || nb_act > L0B_MAXNB) return;   // (nothing to differentiate / k_gemm_h2's tile)
+    int cbw[L0B_MAXNB];   // K' block index of column block nb
+    {
+        uint32_t m = tmask;
+#pragma unroll
+        for (int nb = 0; nb < L0B_MAXNB; ++nb) {
+            cbw[nb] = m ? (int)__builtin_ctz(m) : -1;
+            m &= m - 1;
+        }
+    }
+    const float sa = g.amax_in >= 0 ? amax_scale(g.amax, g.amax_in, s) : g.a_static_scale;
+    const float out_scale = pr.w_inv_scale / sa;
+
+    // this wave's 32 rows = one row block of a 64-atom tile (a wave past the species end re-reads the tile's first
+    // row block; rows past the end inside a block are allocated, never stored)
+    const int tm_h = g.a_tm_h[s];
+    const int rel = m0 + (wave * 32 < n_rows ? wave * 32 : 0);
+    const float *arow = g.A + tm_species_base(ctl, g.a_tm_h, g.a_tm_members, s) +
+                        (int64_t)(rel >> 6) * g.a_tm_members * 64 * tm_h + tm_unit(0, (rel >> 5) & 1, 0) + lane * 8;
+    // B rows staged by this thread: rows srow and 128 + srow of the compacted blocks
+    const int blk0 = srow >> 5, blk1 = 4 + (srow >> 5);
+    const bool st0 = blk0 < nb_act, st1 = srow < 64 && blk1 < nb_act;
+    const int c0 = st0 ? cbw[blk0 < L0B_MAXNB ? blk0 : 0] : cbw[0];
+    const int c1 = st1 ? cbw[blk1 < L0B_MAXNB ? blk1 : 0] : cbw[0];
+    const _Float16 *b_src0 = pr.Bh + (int64_t)(c0 * 32 + (srow & 31)) * pr.ldbh + piece * 8;
+    const _Float16 *b_src1 = pr.Bh + (int64_t)(c1 * 32 + (srow & 31)) * pr.ldbh + piece * 8;
+
+    f32x16 acc[L0B_MAXNB];
+#pragma unroll
+    for (int q = 0; q < L0B_MAXNB; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const int nk = pr.K / HBK;
+    switch (nb_act) {
+        case 6: l0b_kloop<6>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        case 5: l0b_kloop<5>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        case 4: l0b_kloop<4>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        case 3: l0b_kloop<3>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        case 2: l0b_kloop<2>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        default: l0b_kloop<1>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+    }
+#pragma unroll
+    for (int nb = 0; nb < L0B_MAXNB; ++nb) {
+        if (nb >= nb_act) continue;
+        // K' column -> AEV feature
+        const int feat = g.kp_rad ? kp_col(g.kp_rad, cbw[nb]) + fr : cbw[nb] * 32 + fr;
+        const bool okc = g.kp_rad ? fr < kp_valid(g.kp_rad, cbw[nb]) : true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+            if (row >= n_rows) continue;
+            if (okc && feat < g.n_store) g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + feat] = acc[nb][r] * out_scale;
+        }
+    }
 }
 
 // ---- fused network kernel (f16x3) ---------------------------------------------------------------------
@@ -1747,9 +1983,12 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 for (int nb = 0; nb < NB; ++nb) {
                     if (nb >= u1.nba) continue;
                     float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0(u1, nb);
+                    int s1 = 8, s2 = 16;   // run q of this lane's 4 runs of 4 columns lies (q & 1) s1 + (q >> 1) s2 floats on
                     if (g.d0_tm) {
-                        const int rel = rel_tile + min(row, n_rows - 1);
-                        dst = g.d0 + tm_base + ((int64_t)((rel >> 6) * Mi + m) * 64 + (rel & 63)) * H1 + col0(u1, nb);
+                        // fragment order (tm_unit): run q = k step q >> 1, lane slot (q & 1) * 32 + row, floats 4 fk ..
+                        dst = g.d0 + tm_base + (int64_t)(((rel_tile >> 6) * Mi + m) * 64) * H1 +
+                              tm_unit(u1.cb + NW * nb, ((rel_tile >> 5) & 1) + u1.rb0 + rb, 0) + fr * 8 + 4 * fk;
+                        s1 = 256; s2 = 512;   // (q & 1): the other 32 lane slots of the unit; (q >> 1): the next unit
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -1757,7 +1996,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             v[e] = acc[rb * NB + nb][4 * q + e] * osc4 * d0f[rb * NB + nb][4 * q + e];
-                        if (row < n_rows) *reinterpret_cast<v4f *>(dst + 8 * q) = v;
+                        if (row < n_rows) *reinterpret_cast<v4f *>(dst + (q & 1) * s1 + (q >> 1) * s2) = v;
                     }
                 }
             }
@@ -2278,6 +2517,15 @@ static int launch_gemm_big(hipStream_t stream, GemmArgs &g, int64_t n_rows_total
     ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_h2<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)lds));
     const int64_t total = (int64_t)h.nrow_tiles_ub * h.ncol_max * h.batch;
+    if (EPI == EPI_SCATTER && g.stage_mask && g.a_tm_members > 0 && g.c_scatter && !g.a_gather && h.batch == 1) {
+        // row tiles with few flagged slabs go to the skinny kernel, the others stay here (each kernel works out a
+        // tile's mask and leaves the other kernel's tiles alone)
+        h.skinny = 1;
+        const size_t lds3 = sizeof(_Float16) * 2 * L0B_STAGE + 64;
+        ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_l0b, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds3));
+        hipLaunchKernelGGL(k_gemm_l0b, dim3((unsigned)h.nrow_tiles_ub), dim3(L0B_THREADS), lds3, stream, h);
+    }
     hipLaunchKernelGGL((k_gemm_h2<EPI>), dim3((unsigned)total), dim3(GEMM2_THREADS), lds, stream, h);
     return 0;
 }
