@@ -295,7 +295,7 @@ def test_model_from_external_neighbors(dev, name):
     assert torch.allclose(e2, e.detach(), rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f16x3-rows32", "f16x3-unfused", "f16x3-bigtile", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x3", "f16x3-rows32", "f16x3-unfused", "f16x3-bigtile", "f16x3-bigtile32", "fp32"])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     """Networks alone: reference-exact AEVs in, per-atom energies and d/d aev out, for both GEMM
@@ -312,6 +312,8 @@ def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
         monkeypatch.setattr(PackedNetworks, "default_flags", _lib.MLP_FLAG_FUSED_ROWS32)
     if precision == "f16x3-bigtile":  # force the 256x256-tile layer-0 GEMM that large systems use
         monkeypatch.setattr(PackedNetworks, "default_flags", _lib.MLP_FLAG_BIG_TILES)
+    if precision == "f16x3-bigtile32":  # ... fed by the 32-atom tiling (fragment-order hand-over from half tiles)
+        monkeypatch.setattr(PackedNetworks, "default_flags", _lib.MLP_FLAG_BIG_TILES | _lib.MLP_FLAG_FUSED_ROWS32)
     model.neural_networks.mlp_precision = precision.split("-")[0]
     sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
     a32 = torch.from_numpy(aev.astype(np.float32)).to(dev).requires_grad_(True)
