@@ -24,7 +24,7 @@ for c, key in (("FETCH_SIZE", "fetch_size_kb"), ("WRITE_SIZE", "write_size_kb"))
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != c: continue
             k = row["Kernel_Name"]
-            for name in ("k_aev_fwd2", "k_aev_bwd", "k_mlp_fused", "k_gemm_h2", "k_nbr_cell2"):
+            for name in ("k_aev_fwd2", "k_aev_bwd", "k_mlp_fused", "k_gemm_h2", "k_gemm_l0b", "k_nbr_cell2"):
                 if name + "<" in k or name + "(" in k:
                     acc[name][0] += float(row["Counter_Value"]); acc[name][1] += 1
     for name, (s, n) in acc.items():

@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("gpurun_out/sq_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        for name in ("k_aev_fwd2", "k_aev_bwd", "k_mlp_fused", "k_gemm_h2", "k_nbr_cell2"):
+        for name in ("k_aev_fwd2", "k_aev_bwd", "k_mlp_fused", "k_gemm_h2", "k_gemm_l0b", "k_nbr_cell2"):
             if name + "<" in k or name + "(" in k:
                 a = acc[name][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
 print("SQ counters, rocprofv3 --pmc (tools/gpu_sq.sh: three passes of tools/kbench.py --side 64 --stages fwd,bwd,mlp --mask on;")
