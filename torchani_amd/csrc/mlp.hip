@@ -1961,18 +1961,21 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         __syncthreads();
         ANIHIP_STAMP(trace, 11);
         // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
+        // the first layer-0 weight fragments of the next item: L2 hits, requested ahead of the phase-4 MFMA loop so
+        // that the store phase below is left with the stores and the AEV slabs (it is bound by the CU's vector-memory
+        // throughput)
+        prefetch_w0(te_n, item_n);
         if (g.want_grad && u1.nrb > 0) {
             zero_acc();
             FR_UNIT(u1, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X1 + u1.rb0 * 32 * ld1, ld1, x1_plane, r4, H2 >> 4, lane)))
         }
         ANIHIP_STAMP(trace, 12);
-        // the AEV slabs of the next item and its first layer-0 weight fragments travel during the stores below
-        // (requested AFTER the last ring load of this item: loads complete in order, and an HBM miss ahead of a
-        // ring request stalls the MFMA loop that waits for it)
+        // the AEV slabs of the next item travel during the stores below (requested AFTER the last ring load of this
+        // item: loads complete in order, and an HBM miss ahead of a ring request stalls the MFMA loop that waits
+        // for it)
         prefetch_aev(te_n, atom_n);
         // every wave is done with the LDS of this item: the next one may stage its slabs
         __syncthreads();
-        prefetch_w0(te_n, item_n);
         if (g.want_grad && u1.nrb > 0) {
             const float osc4 = fs.is1 / s3;
 #pragma unroll
