@@ -1424,6 +1424,32 @@ __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *
     }
 }
 
+// layer 0 of the fused kernel: the 12 k steps of one pair of staging slots (2 slots x 3 slabs x 2 steps; 12 % D == 0,
+// ring slot = step % D), A fragments of step k + 1 read from LDS before the MFMAs of step k like fr_gemm.  s0 / s1 =
+// this lane's fragment address in the two slots; the steps of the slabs past the tile's last flagged one (n_live of
+// the pair's 6 are live) have zero operands: no MFMAs, the ring request stays unconditional.
+template <int RB, int NB, int RBA, int NBA, int D, int ROWS, class NextKs>
+__device__ __forceinline__ void fr_l0_pair(f32x16 (&acc)[RB * NB], WRing<NB, D> &rg, const _Float16 *s0,
+                                           const _Float16 *s1, int n_live, NextKs &&next_ks)
+{
+    constexpr int SLAB = 2 * ROWS * FR_SLAB_LD, PL = ROWS * FR_SLAB_LD, RBS = 32 * FR_SLAB_LD;
+    auto addr = [&](int st) {
+        return (st / (2 * FR_GROUP) ? s1 : s0) + ((st / 2) % FR_GROUP) * SLAB + (st & 1) * 16;
+    };
+    AFrag<RBA> xe, xo;
+    xe.load(addr(0), PL, RBS);
+#pragma unroll
+    for (int st = 0; st < 4 * FR_GROUP; st += 2) {
+        const bool live = st / 2 < n_live;
+        xo.load(addr(st + 1), PL, RBS);
+        if (live) fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, st % D, xe);
+        rg.template load<NBA>(st % D, next_ks());
+        if (st + 2 < 4 * FR_GROUP) xe.load(addr(st + 2), PL, RBS);
+        if (live) fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, (st + 1) % D, xo);
+        rg.template load<NBA>((st + 1) % D, next_ks());
+    }
+}
+
 // What a wave of the fused kernel computes in a phase that produces H = 32 nb columns: column blocks cb, cb + NW, ...
 // (nba of them) of the row blocks rb0 .. rb0 + nrb - 1 of the tile.  With 64-row tiles (RB = 2, NB = 1) and 5 to 7
 // column blocks, the 2 nb (row block, column block) units are dealt so that the four SIMDs get the same number:
@@ -1734,18 +1760,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 fetch_group(vb);
             }
             if (u1.nrb > 0) {
-                constexpr int PL = ROWS * FR_SLAB_LD, RBS = 32 * FR_SLAB_LD;
-                // 12 k steps = 2 slots x 3 slabs x 2; ring slot = step % D (12 % D == 0)
-#pragma unroll
-                for (int st = 0; st < 4 * FR_GROUP; ++st) {
-                    const _Float16 *a = slot(2 * (pr & 1) + st / (2 * FR_GROUP)) + ((st / 2) % FR_GROUP) * SLAB +
-                                        (st & 1) * 16 + (u1.rb0 * 32 + fr) * FR_SLAB_LD + fk * 8;
-                    // (the steps of the slabs past the tile's last flagged one have zero operands: no MFMAs, the
-                    // ring request stays unconditional)
-                    const bool live = 2 * FR_GROUP * pr + st / 2 < nact;
-                    FR_UNIT(u1, ((live ? fr_step<RB, NB, RBA, NBA, D>(acc, rg, st % D, a, PL, RBS) : (void)0),
-                                 rg.template load<NBA>(st % D, next_ks())))
-                }
+                const int lo_ = (u1.rb0 * 32 + fr) * FR_SLAB_LD + fk * 8;   // this lane's fragment inside a staged slab
+                const _Float16 *s0 = slot(2 * (pr & 1)) + lo_, *s1 = slot(2 * (pr & 1) + 1) + lo_;
+                const int n_live = nact - 2 * FR_GROUP * pr;
+                FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS>(acc, rg, s0, s1, n_live, next_ks)))
             }
             if (pr + 1 < npair) {   // (the last pair's successors are zeros nobody reads)
                 store_group(va, slot(2 * ((pr + 1) & 1)));
