@@ -1234,7 +1234,9 @@ struct FusedCfg {
     static constexpr bool LAZY = NB == 2;
     static constexpr int SLAB = 2 * ROWS * FR_SLAB_LD;            // halves per staged slab {hi plane, lo plane}
     // fixed part of the dynamic LDS: [0] tile max | energy partials [NW][ROWS] | staging slot 0
-    static constexpr int FIXED_BYTES = 16 + NW * ROWS * 4;
+    // fixed part of the dynamic LDS: [0] tile max | per-species {tile-major base of d0, first sorted position} |
+    // energy partials [NW][ROWS] | staging slot 0
+    static constexpr int FIXED_BYTES = 16 + 128 + NW * ROWS * 4;
     static constexpr int FIXED_HALVES = FIXED_BYTES / 2 + FR_GROUP * SLAB;
     static_assert(THREADS == ROWS * 8, "one 16-B staging piece per thread");
 };
@@ -1529,7 +1531,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     extern __shared__ __attribute__((aligned(16))) _Float16 fsm_all[];
     unsigned *s_tab = reinterpret_cast<unsigned *>(fsm_all);
     unsigned &s_max = s_tab[0];
-    float *s_e = reinterpret_cast<float *>(s_tab + 4);                    // [NW][ROWS]
+    long long *s_tmb = reinterpret_cast<long long *>(s_tab + 4);          // [8] tile-major base of species s in d0
+    int *s_off = reinterpret_cast<int *>(s_tab + 4 + 16);                 // [8] first sorted position of species s
+    float *s_e = reinterpret_cast<float *>(s_tab + 4 + 32);               // [NW][ROWS]
     _Float16 *slot0 = fsm_all + C::FIXED_BYTES / 2;                       // staging slot 0
     _Float16 *fsm = fsm_all + C::FIXED_HALVES;                            // X1 | XU; staging slots 1..3 overlay
     auto slot = [&](int k) { return k == 0 ? slot0 : fsm + (k - 1) * (FR_GROUP * SLAB); };
@@ -1593,6 +1597,17 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     const int n_items = n_tiles * g.M;
     int item = blockIdx.x;
     if (item >= n_items) return;
+    // per-species constants of the items: looked up from LDS at the head of an item instead of scalar-load chains
+    if (threadIdx.x < MAX_S) {
+        const int t_ = threadIdx.x;
+        long long b = 0;
+        for (int t = 0; t < t_ && t < g.S; ++t) b += (long long)((g.ctl[CTL_CNT + t] + 63) >> 6) * 64 * g.M * g.sp[t].H1;
+        s_tmb[t_] = b;
+        s_off[t_] = t_ < g.S ? g.ctl[CTL_OFF + t_] : 0;
+    }
+    __syncthreads();
+    // (member, tile) of the item, advanced by gridDim.x tiles per step without divisions
+    int mem = item / n_tiles, tile = item - mem * n_tiles;
     typedef WRing<NB, D> Ring0;
     Ring0 rg;                  // layer-0 weight ring of the item being started
     uint32_t rem_w = 0u;       // k steps of the layer-0 weight ring not yet requested
@@ -1614,8 +1629,8 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         fetch_group(vb);
     };
     // first D weight fragments of layer 0 of an item
-    auto prefetch_w0 = [&](const int4 &t, int it) {
-        const int s = t.x, m = it / n_tiles;
+    auto prefetch_w0 = [&](const int4 &t, int m) {
+        const int s = t.x;
         const FusedSpecies &fs = g.sp[s];
         tmask = (uint32_t)t.w;
         rem_w = tmask;
@@ -1630,11 +1645,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         for (int sl = 0; sl < D; ++sl) rg.template load<NB>(sl, next_ks());
         rg.nb_stride = (int64_t)NW * KS0 * (2 * FRAG);
     };
-    int4 te = g.tile_tab[item % n_tiles];
+    int4 te = g.tile_tab[tile];
     {
-        const int atom0 = g.tile_rows[(size_t)(item % n_tiles) * ROWS + srow];
+        const int atom0 = g.tile_rows[(size_t)tile * ROWS + srow];
         prefetch_aev(te, atom0);
-        prefetch_w0(te, item);
+        prefetch_w0(te, mem);
     }
     for (;;) {
         asm volatile("" : "+v"(tid));
@@ -1644,9 +1659,12 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         asm volatile("" : "+s"(alpha), "+s"(inv_alpha), "+s"(Mi));
         // entry and atom rows of the next item (the last item of a workgroup prefetches itself again: loads
         // stay unconditional)
-        const int item_n = item + (int)gridDim.x < n_items ? item + (int)gridDim.x : item;
-        const int4 te_n = g.tile_tab[item_n % n_tiles];
-        const int atom_n = g.tile_rows[(size_t)(item_n % n_tiles) * ROWS + srow];
+        int mem_n = mem, tile_n = tile + (int)gridDim.x;
+        while (tile_n >= n_tiles) { tile_n -= n_tiles; ++mem_n; }
+        const bool has_next = mem_n < Mi;
+        if (!has_next) { mem_n = mem; tile_n = tile; }
+        const int4 te_n = g.tile_tab[tile_n];
+        const int atom_n = g.tile_rows[(size_t)tile_n * ROWS + srow];
 #ifdef ANIHIP_DEV_TRACE
         if (g.trace && lane == 0) {
             g.trace[((size_t)item * 8 + wave) * 16 + 0] = __builtin_readcyclecounter();
@@ -1655,12 +1673,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                                                    ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
         }
 #endif
-        const int m = item / n_tiles, s = te.x, n_rows = te.z, p0 = te.y;
+        const int m = mem, s = te.x, n_rows = te.z, p0 = te.y;
         const FusedSpecies &fs = g.sp[s];
-        int64_t tm_base = 0;
-        const int rel_tile = g.d0_tm ? p0 - g.ctl[CTL_OFF + s] : 0;   // (scalar loads at the head of the item, not in the store phase)
-        if (g.d0_tm)
-            for (int t = 0; t < s; ++t) tm_base += (int64_t)((g.ctl[CTL_CNT + t] + 63) >> 6) * 64 * Mi * g.sp[t].H1;
+        const int64_t tm_base = s_tmb[s];
+        const int rel_tile = p0 - s_off[s];
         const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
         // LDS carve (halves): X1 planes [2][ROWS][H2+8] | XU = max(X0 planes [2][ROWS][H1+8], X2 planes)
         const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
@@ -1982,7 +1998,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // the first layer-0 weight fragments of the next item: L2 hits, requested ahead of the phase-4 MFMA loop so
         // that the store phase below is left with the stores and the AEV slabs (it is bound by the CU's vector-memory
         // throughput)
-        prefetch_w0(te_n, item_n);
+        prefetch_w0(te_n, mem_n);
         if (g.want_grad && u1.nrb > 0) {
             zero_acc();
             FR_UNIT(u1, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X1 + u1.rb0 * 32 * ld1, ld1, x1_plane, r4, H2 >> 4, lane)))
@@ -2023,9 +2039,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             }
         }
         ANIHIP_STAMP(trace, 13);
-        if (item_n == item) break;
+        if (!has_next) break;
         te = te_n;
-        item = item_n;
+        mem = mem_n;
+        tile = tile_n;
+        item = mem * n_tiles + tile;
     }
 }
 #undef FR_UNIT
