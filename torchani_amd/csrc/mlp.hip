@@ -1992,13 +1992,13 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 put_acc(X1, x1_plane, ld1, s3, u2);   // (X1: its last readers finished before the previous barrier)
             }
         }
+        // the first layer-0 weight fragments of the next item: L2 hits, requested behind the phase-4 ring (the first
+        // MFMAs of phase 4 do not wait for them) and ahead of its MFMA loop, so that the store phase at the end is left
+        // with the stores and the AEV slabs (it is bound by the CU's vector-memory throughput)
+        prefetch_w0(te_n, mem_n);
         __syncthreads();
         ANIHIP_STAMP(trace, 11);
         // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
-        // the first layer-0 weight fragments of the next item: L2 hits, requested ahead of the phase-4 MFMA loop so
-        // that the store phase below is left with the stores and the AEV slabs (it is bound by the CU's vector-memory
-        // throughput)
-        prefetch_w0(te_n, mem_n);
         if (g.want_grad && u1.nrb > 0) {
             zero_acc();
             FR_UNIT(u1, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X1 + u1.rb0 * 32 * ld1, ld1, x1_plane, r4, H2 >> 4, lane)))
