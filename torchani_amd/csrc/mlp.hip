@@ -991,16 +991,22 @@ struct L0bB {
 };
 
 template <int NB>
-__device__ __forceinline__ void l0b_kloop(f32x16 (&acc)[L0B_MAXNB], const float *arow, int tm_h, int nk, float sa,
-                                          const _Float16 *b_src0, const _Float16 *b_src1, int64_t bh_plane,
-                                          bool st0, bool st1, _Float16 *sm)
+__device__ __forceinline__ void l0b_tile(const GemmArgs &g, const int (&cbw)[L0B_MAXNB], int n_rows, int p0,
+                                         float out_scale, const float *arow, int tm_h, int nk, float sa,
+                                         const _Float16 *b_src0, const _Float16 *b_src1, int64_t bh_plane, bool st0,
+                                         bool st1, _Float16 *sm)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int srow = tid >> 2, piece = tid & 3;
     const int fr = lane & 31, fk = lane >> 5;
     typedef float v2f_ __attribute__((ext_vector_type(2)));
     typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
-    // A of stage kt: member mm = 32 kt / tm_h, columns 32 kt - mm tm_h ..; members are 64 tm_h floats apart
+    f32x16 acc[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    // A of stage kt: member mm = 32 kt / tm_h, column block (32 kt - mm tm_h) / 32; members are 64 tm_h floats apart
     auto a_off = [&](int kt) {
         const int k = kt * HBK, mm = (int)(((float)k + 0.5f) / (float)tm_h);
         return (int64_t)mm * 64 * tm_h + tm_unit((k - mm * tm_h) >> 5, 0, 0);
@@ -1029,71 +1035,85 @@ __device__ __forceinline__ void l0b_kloop(f32x16 (&acc)[L0B_MAXNB], const float 
             *reinterpret_cast<h8 *>(base + L0B_PLANE + off) = b.l[1];
         }
     };
-    auto compute = [&](int buf, const v4f (&a)[4]) {
-        const _Float16 *base = sm + buf * L0B_STAGE;
+    // fp32 -> {hi, lo} fp16 fragment of one k step (8 values per lane)
+    auto split = [&](const v4f &x0, const v4f &x1, h8 &ahi, h8 &alo) {
 #pragma unroll
-        for (int ks = 0; ks < HBK / 16; ++ks) {
-            h8 ahi, alo;
-#pragma unroll
-            for (int c = 0; c < 8; c += 2) {
-                const v4f &src = a[2 * ks + (c >> 2)];
-                const v2f_ x = v2f_{src[c & 3], src[(c & 3) + 1]};
-                const h2_ h = __builtin_convertvector(x * sa, h2_);
-                h2_ l;
-                asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x[0]), "v"(sa), "v"(h));
-                asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x[1]), "v"(sa), "v"(h));
-                ahi[c] = h[0]; ahi[c + 1] = h[1];
-                alo[c] = l[0]; alo[c + 1] = l[1];
-            }
-            const int pc = ks * 2 + fk;
-            h8 bhi[NB], blo[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int bo = h_off(nb * 32 + fr, pc);
-                bhi[nb] = *reinterpret_cast<const h8 *>(base + bo);
-                blo[nb] = *reinterpret_cast<const h8 *>(base + L0B_PLANE + bo);
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[nb], acc[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[nb], acc[nb], 0, 0, 0);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[nb], acc[nb], 0, 0, 0);
+        for (int c = 0; c < 8; c += 2) {
+            const v4f &src = c < 4 ? x0 : x1;
+            const v2f_ x = v2f_{src[c & 3], src[(c & 3) + 1]};
+            const h2_ h = __builtin_convertvector(x * sa, h2_);
+            h2_ l;
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x[0]), "v"(sa), "v"(h));
+            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x[1]), "v"(sa), "v"(h));
+            ahi[c] = h[0]; ahi[c + 1] = h[1];
+            alo[c] = l[0]; alo[c + 1] = l[1];
         }
     };
-    // A: three register sets in rotation (the loads of stage kt + 2 are issued while stage kt is computed);
+    auto bfrags = [&](const _Float16 *base, int ks, h8 (&bhi)[NB], h8 (&blo)[NB]) {
+        const int pc = ks * 2 + fk;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int bo = h_off(nb * 32 + fr, pc);
+            bhi[nb] = *reinterpret_cast<const h8 *>(base + bo);
+            blo[nb] = *reinterpret_cast<const h8 *>(base + L0B_PLANE + bo);
+        }
+    };
+    auto mfmas = [&](const h8 &ahi, const h8 &alo, const h8 (&bhi)[NB], const h8 (&blo)[NB]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo[nb], acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi[nb], acc[nb], 0, 0, 0);
+    };
+    // one 32-deep stage: the B fragments of k step 1 are read from LDS before the MFMAs of k step 0
+    auto compute = [&](int buf, const v4f (&a)[4]) {
+        const _Float16 *base = sm + buf * L0B_STAGE;
+        h8 b0h[NB], b0l[NB], b1h[NB], b1l[NB], ahi, alo;
+        bfrags(base, 0, b0h, b0l);
+        split(a[0], a[1], ahi, alo);
+        bfrags(base, 1, b1h, b1l);
+        mfmas(ahi, alo, b0h, b0l);
+        split(a[2], a[3], ahi, alo);
+        mfmas(ahi, alo, b1h, b1l);
+    };
+    // A: two register sets (the loads of stage kt + 1 travel while stage kt is computed: a stage is ~2 us);
     // B: one register set a stage ahead of the LDS double buffer
-    v4f a0[4], a1[4], a2[4];
+    v4f a0[4], a1[4];
     L0bB bs;
     aload(a0, 0);
     bload(bs, 0);
-    aload(a1, min(1, nk - 1));
     bstore(bs, 0);
     bload(bs, min(1, nk - 1));
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 3) {
-        // stage kt (buffer kt & 1): A in a0
-        aload(a2, min(kt + 2, nk - 1));
-        compute(kt & 1, a0);
-        if (kt + 1 < nk) bstore(bs, (kt + 1) & 1);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // stage kt (buffer 0): A in a0
+        aload(a1, min(kt + 1, nk - 1));
+        compute(0, a0);
+        if (kt + 1 < nk) bstore(bs, 1);
         bload(bs, min(kt + 2, nk - 1));
         __syncthreads();
         if (kt + 1 < nk) {
-            aload(a0, min(kt + 3, nk - 1));
-            compute((kt + 1) & 1, a1);
-            if (kt + 2 < nk) bstore(bs, kt & 1);
+            aload(a0, min(kt + 2, nk - 1));
+            compute(1, a1);
+            if (kt + 2 < nk) bstore(bs, 0);
             bload(bs, min(kt + 3, nk - 1));
             __syncthreads();
         }
-        if (kt + 2 < nk) {
-            aload(a1, min(kt + 4, nk - 1));
-            compute(kt & 1, a2);
-            if (kt + 3 < nk) bstore(bs, (kt + 1) & 1);
-            bload(bs, min(kt + 4, nk - 1));
-            __syncthreads();
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        // K' column -> AEV feature
+        const int feat = g.kp_rad ? kp_col(g.kp_rad, cbw[nb]) + fr : cbw[nb] * 32 + fr;
+        const bool okc = g.kp_rad ? fr < kp_valid(g.kp_rad, cbw[nb]) : true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+            if (row >= n_rows) continue;
+            if (okc && feat < g.n_store) g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + feat] = acc[nb][r] * out_scale;
         }
     }
 }
@@ -1166,32 +1186,14 @@ __global__ __launch_bounds__(L0B_THREADS, 2) void k_gemm_l0b(GemmArgs g)
     const _Float16 *b_src0 = pr.Bh + (int64_t)(c0 * 32 + (srow & 31)) * pr.ldbh + piece * 8;
     const _Float16 *b_src1 = pr.Bh + (int64_t)(c1 * 32 + (srow & 31)) * pr.ldbh + piece * 8;
 
-    f32x16 acc[L0B_MAXNB];
-#pragma unroll
-    for (int q = 0; q < L0B_MAXNB; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
     const int nk = pr.K / HBK;
     switch (nb_act) {
-        case 6: l0b_kloop<6>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
-        case 5: l0b_kloop<5>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
-        case 4: l0b_kloop<4>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
-        case 3: l0b_kloop<3>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
-        case 2: l0b_kloop<2>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
-        default: l0b_kloop<1>(acc, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
-    }
-#pragma unroll
-    for (int nb = 0; nb < L0B_MAXNB; ++nb) {
-        if (nb >= nb_act) continue;
-        // K' column -> AEV feature
-        const int feat = g.kp_rad ? kp_col(g.kp_rad, cbw[nb]) + fr : cbw[nb] * 32 + fr;
-        const bool okc = g.kp_rad ? fr < kp_valid(g.kp_rad, cbw[nb]) : true;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
-            if (row >= n_rows) continue;
-            if (okc && feat < g.n_store) g.C[(int64_t)g.c_scatter[p0 + row] * g.ldc + feat] = acc[nb][r] * out_scale;
-        }
+        case 6: l0b_tile<6>(g, cbw, n_rows, p0, out_scale, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        case 5: l0b_tile<5>(g, cbw, n_rows, p0, out_scale, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        case 4: l0b_tile<4>(g, cbw, n_rows, p0, out_scale, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        case 3: l0b_tile<3>(g, cbw, n_rows, p0, out_scale, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        case 2: l0b_tile<2>(g, cbw, n_rows, p0, out_scale, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
+        default: l0b_tile<1>(g, cbw, n_rows, p0, out_scale, arow, tm_h, nk, sa, b_src0, b_src1, pr.bh_plane, st0, st1, sm3); break;
     }
 }
 
