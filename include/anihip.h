@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 5
+#define ANIHIP_ABI_VERSION 6
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -362,6 +362,27 @@ int anihip_mlp_repack(void *stream, const anihip_mlp_desc *d, const void *const 
 int anihip_pair_xtb_repulsion(void *stream, int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
                               const uint32_t *meta, const float *ent, const float *pair_table, float cutoff,
                               int32_t cutoff_kind, int32_t flags, float *atomic_e, float *grad_coords, double *virial);
+
+/* DFT-D3(BJ) two-body dispersion (potentials/dftd3.py:113-330 TwoBodyDispersionD3, damping :44-110 BeckeJohnsonDamp;
+ * envelope and per-atom halves as above), distances in Bohr:
+ *   CN_i   = sum_j 1 / (1 + exp(-16 (4/3 (Rcov_a + Rcov_b) / d_ij - 1)))                     (all neighbors of the row)
+ *   C6_ij  = sum_ref c6ref L / sum_ref L,  L = exp(-4 ((CN_i - cn_a)^2 + (CN_j - cn_b)^2)) over the references with c6ref > 0
+ *   e_ij   = -(s6 C6 / (d^6 + R^6) + s8 3 C6 q_a q_b / (d^8 + R^8)) fc(r_ij),  R = a1 sqrt(3 q_a q_b) + a2
+ * c6_table: device float[8][8][25][4] = {c6ref, cn_a, cn_b, 0} indexed [species_i][species_j][5 ref_i + ref_j].
+ * The rows must hold ALL atoms 0 .. n_atoms (coordination numbers of every neighbor are needed) and be symmetric;
+ * lo / hi select the central atoms whose energies / gradient rows are accumulated (atomic_e[i] += sum_j e_ij / 2,
+ * grad_coords[i] += d E / d r_i, both complete for i in lo .. hi: nothing is pushed to other atoms, no atomics,
+ * deterministic).  The gradient includes the dependence of C6 on the coordination numbers (the reference gets it from
+ * autograd).  cn, gcn: caller-provided scratch, n_atoms floats each.  virial as above (may be NULL). */
+typedef struct anihip_d3_params {
+    float s6, s8, a1, a2;
+    float cov_radius_bohr[8];   /* per species index */
+    float sqrt_q[8];            /* sqrt of the empirical charge, per species index */
+} anihip_d3_params;
+int anihip_pair_d3(void *stream, int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                   const uint32_t *meta, const float *ent, const float *c6_table, const anihip_d3_params *params,
+                   float cutoff, int32_t cutoff_kind, float *cn, float *gcn, float *atomic_e, float *grad_coords,
+                   double *virial);
 
 /* mol_e[c] (fp64) = sum_a atomic_e[c,a] + sae[species[c,a]] over the atoms lo <= c*A+a < hi; padding
  * contributes nothing (sae.py:54-64).  sae may be NULL.  mol_e is overwritten. */

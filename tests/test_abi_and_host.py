@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header(lib):
@@ -382,3 +382,30 @@ def test_integration_section_a_against_the_live_reference():
             torchani.grad.energies_and_forces(ref, z, x)
     finally:
         sys.path.remove("/root/reference")
+
+
+def test_d3_reference_data_and_class():
+    """The D3 element data shipped with the package (extracted from the reference's resources by
+    tests/golden/gen_golden_d3.py) and the host-side constructor checks of TwoBodyDispersionD3 (dftd3.py:139-214)."""
+    import math
+
+    from torchani_amd.potentials import TwoBodyDispersionD3, d3_reference_data
+
+    d = d3_reference_data()
+    assert d["c6"].shape == (19, 19, 5, 5) and d["cn_a"].shape == d["cn_b"].shape == d["c6"].shape
+    assert abs(d["c6"][1, 1, 0, 0] - 3.0267) < 1e-4           # H-H, both hydrogens free atoms (Grimme et al. 2010)
+    assert np.allclose(d["c6"], d["c6"].transpose(1, 0, 3, 2))   # C6_ab[ref_a][ref_b] = C6_ba[ref_b][ref_a]
+    assert np.allclose(d["cn_a"], d["cn_b"].transpose(1, 0, 3, 2))
+    assert d["functionals"]["wb97x"] == (1.0, 0.2641, 0.0, 5.4959)
+    pot = TwoBodyDispersionD3.from_functional(("H", "C", "N", "O"), "wB97X", cutoff=8.0)
+    assert pot.precalc_coeff6.shape == (4, 4, 5, 5) and pot.cutoff == 8.0 and pot.needs_all_rows
+    assert math.isclose(float(pot.covalent_radii[0]), 0.32 * 1.8897261258369282, rel_tol=1e-6)
+    t = pot.table(torch.device("cpu"))
+    assert t.shape == (8, 8, 25, 4) and float(t[0, 3, 0, 0]) == float(pot.precalc_coeff6[0, 3, 0, 0])
+    assert float(t[5, 5, 0, 0]) == -1.0   # unused element slots: no references
+    with pytest.raises(ValueError):
+        TwoBodyDispersionD3.from_functional(("H", "Xe"), "wb97x")
+    with pytest.raises(ValueError):
+        TwoBodyDispersionD3.from_functional(("H", "O"), "no-such-functional")
+    with pytest.raises(ValueError):
+        TwoBodyDispersionD3(("H", "O"), 1.0, 1.0, 0.4, 4.0, sqrt_empirical_charge=(1.0,))

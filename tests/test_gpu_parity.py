@@ -799,6 +799,86 @@ def test_xtb_repulsion_matches_reference(dev, case):
     assert np.abs(out0.forces.cpu().numpy() - g["forces"]).max() < F_TOL
 
 
+@pytest.mark.parametrize("case", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x", "triclinic_pbc_ani2x",
+                                  "b973c_water_pbc_ani2x"])
+def test_d3_dispersion_matches_reference(dev, case):
+    """TwoBodyDispersionD3 (potentials/dftd3.py) against the reference's fp64 values (tests/golden/gen_golden_d3.py:
+    cutoff 8 A, smooth envelope): per-atom halves, molecular energies, forces including the dependence of C6 on the
+    coordination numbers; alone, as a shard (lo .. hi), inside energies_and_forces together with the networks and the
+    xTB repulsion (the ANI-2xr recipe, arch.py:1176-1181), through autograd, and the virial by finite strain."""
+    from torchani_amd.models import ANI2x
+    from torchani_amd.potentials import RepulsionXTB, TwoBodyDispersionD3
+
+    name = case[6:] if case.startswith("b973c_") else case
+    g = load_golden(name)
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = dict(np.load(os.path.join(gdir, f"d3_{case}.npz")))
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False,
+                  neighborlist=modes_for(g)[-1], row_capacity=256)
+    pot = TwoBodyDispersionD3.from_functional(g["symbols"], str(ref["functional"]), cutoff=float(ref["cutoff"]),
+                                              cutoff_fn=str(ref["cutoff_fn"])).to(dev)
+    sp32 = sp.to(torch.int32).contiguous()
+    rows = model._pair_rows(pot, sp32, x, cell, pbc)
+    n = sp32.numel()
+    ae = torch.zeros(n, dtype=torch.float32, device=dev)
+    gc = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+    pot.accumulate(sp32, rows, ae, gc)
+    torch.cuda.synchronize()
+    rows.raise_on_overflow()
+    escale = max(1e-3, np.abs(ref["atomic_energies"]).max())
+    fscale = max(1e-3, np.abs(ref["forces"]).max())
+    ea = np.abs(ae.cpu().numpy().reshape(ref["atomic_energies"].shape) - ref["atomic_energies"]).max()
+    fe = np.abs(-gc.cpu().numpy().reshape(ref["forces"].shape) - ref["forces"]).max()
+    report(f"d3    {case:24s} max|e_atom err| = {ea:.2e} (scale {escale:.1e})  |F err| = {fe:.2e} (scale {fscale:.1e})")
+    # 1e-5 of the scale -- or, for the random dense geometries of rand_batch (coordination numbers up to 7.3, far from
+    # every reference: the Gaussian reference weights amplify the fp32 rounding of the CNs), 5e-7 Ha / 5e-5 Ha/A, still
+    # 20x / 2x inside the parity gates
+    assert ea < max(1e-5 * escale, 5e-7) and fe < max(2e-5 * fscale, 5e-5)
+    # a shard: energies / gradient rows of lo .. hi only, equal to the same rows of the full evaluation
+    lo, hi = n // 3, (2 * n) // 3
+    ae2 = torch.zeros_like(ae)
+    gc2 = torch.zeros_like(gc)
+    pot.accumulate(sp32, rows, ae2, gc2, lo=lo, hi=hi)
+    assert torch.equal(ae2[lo:hi], ae[lo:hi]) and torch.equal(gc2[lo:hi], gc[lo:hi])
+    assert ae2[:lo].abs().max() == 0 and gc2[hi:].abs().max() == 0
+    # inside the model: networks + repulsion + dispersion
+    rep = dict(np.load(os.path.join(gdir, f"pairs_{name}.npz")))
+    model.add_pair_potential("repulsion_xtb", RepulsionXTB(g["symbols"], cutoff=float(rep["cutoff"]),
+                                                           cutoff_fn=str(rep["cutoff_fn"])).to(dev))
+    model.add_pair_potential("dispersion_d3", pot)
+    out = model.energies_and_forces(sp, x, cell, pbc)
+    e_ref = g["energies"] + rep["energies"] + ref["energies"]
+    f_ref = g["forces"] + rep["forces"] + ref["forces"]
+    assert np.abs(out.energies.cpu().numpy() - e_ref).max() < 1e-5 * max(1.0, np.abs(e_ref).max() * 1e-2) + 1e-5
+    assert np.abs(out.forces.cpu().numpy() - f_ref).max() < F_TOL
+    xs = x.clone().requires_grad_(True)
+    pbc_t = None if pbc is None else torch.tensor(pbc)
+    e = model((sp, xs), cell, pbc_t).energies
+    (gx,) = torch.autograd.grad(e.sum(), xs)
+    assert np.abs(-gx.cpu().numpy() - f_ref).max() < F_TOL
+    if cell is not None and all(pbc):
+        # virial of the dispersion term alone = strain derivative of its energy (central differences)
+        w = torch.zeros((3, 3), dtype=torch.float64, device=dev)
+        pot.accumulate(sp32, rows, None, gc2, w)
+
+        def e_of(strain):
+            F = torch.eye(3, device=dev, dtype=torch.float64) + strain
+            xx = (x.double() @ F.T).float()
+            cc = (cell.double() @ F.T).float()
+            r2 = model._pair_rows(pot, sp32, xx, cc, pbc)
+            a = torch.zeros(n, dtype=torch.float32, device=dev)
+            pot.accumulate(sp32, r2, a, None)
+            return a.double().sum().item()
+
+        h = 2e-3
+        for (a_, b_) in ((0, 0), (1, 2)):
+            st = torch.zeros((3, 3), dtype=torch.float64, device=dev)
+            st[a_, b_] = h
+            fd = (e_of(st) - e_of(-st)) / (2 * h)
+            assert abs(fd - w[a_, b_].item()) < 2e-3 * max(abs(fd), 1e-4) + 2e-6, (a_, b_, fd, w[a_, b_].item())
+
+
 def test_periodic_replica_and_symmetries_at_scale(dev):
     """Size-independent properties at ~0.33 M atoms (no oracle at this size): a periodic box replicated 2 x 2 x 2
     has the same per-atom energies and forces as the original box (every atom sees the same environment), the

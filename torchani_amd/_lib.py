@@ -32,7 +32,7 @@ PAIR_PUSH = 1
 # anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*)
 MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_FUSED_ROWS32, MLP_FLAG_D0_ROWS = \
     1, 2, 4, 8, 16, 32
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class AevParams(C.Structure):
@@ -74,6 +74,12 @@ class SpeciesGrads(C.Structure):
         ("gw", C.c_void_p * MAX_LAYERS),
         ("gbias", C.c_void_p * MAX_LAYERS),
     ]
+
+
+class D3Params(C.Structure):
+    """anihip_d3_params (include/anihip.h)."""
+    _fields_ = [("s6", C.c_float), ("s8", C.c_float), ("a1", C.c_float), ("a2", C.c_float),
+                ("cov_radius_bohr", C.c_float * 8), ("sqrt_q", C.c_float * 8)]
 
 
 class MlpDesc(C.Structure):
@@ -164,6 +170,8 @@ def lib() -> C.CDLL:
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     L.anihip_pair_xtb_repulsion.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, C.c_float, i32, i32, vp, vp, vp]
     L.anihip_pair_xtb_repulsion.restype = C.c_int
+    L.anihip_pair_d3.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, C.POINTER(D3Params), C.c_float, i32, vp, vp, vp, vp, vp]
+    L.anihip_pair_d3.restype = C.c_int
     for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half",
                  "anihip_nbr_from_full", "anihip_nbr_refresh",
                  "anihip_aev_forward", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp", "anihip_mlp_forward_backward",
@@ -182,6 +190,7 @@ EXPORTED_SYMBOLS = [
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
     "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
     "anihip_mlp_tangent_workspace_bytes", "anihip_mlp_tangent_weight_grads", "anihip_pair_xtb_repulsion",
+    "anihip_pair_d3",
 ]
 
 

@@ -305,6 +305,11 @@ class ANI(torch.nn.Module):
         w = torch.zeros((3, 3), dtype=torch.float64, device=c32.device) if stress else None
         for _, pot in pots:
             rows = nbrs
+            if getattr(pot, "needs_all_rows", False):
+                # (coordination numbers of every neighbor: rows of all atoms on every rank, outputs for lo .. hi only)
+                rows = self._pair_rows(pot, species32, c32, cell, pbc, 0, None)
+                pot.accumulate(species32, rows, e, g, w, lo=lo, hi=hi)
+                continue
             if pot.cutoff > self.aev_computer.radial.cutoff + 1e-6:
                 rows = self._pair_rows(pot, species32, c32, cell, pbc, lo, hi)
             pot.accumulate(species32, rows, e, g, w)

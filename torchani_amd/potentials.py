@@ -1,20 +1,24 @@
-"""Pair potentials on the engine's neighbor rows: the xTB repulsion term of the reference's ANI-2xr / ANI-2dr models.
+"""Pair potentials on the engine's neighbor rows: the xTB repulsion and DFT-D3(BJ) dispersion terms of the reference's
+ANI-2xr / ANI-2dr models.
 
 Mirrors torchani/potentials/xtb.py:17-77 (RepulsionXTB: constructor, buffers ``y_ab`` / ``sqrt_alpha_ab`` / ``k_rep_ab``,
-pair energies) and the shared machinery of torchani/potentials/core.py:103-207 (cutoff envelope, ``atomic`` halves, sum
-per molecule).  The arithmetic runs in libanihip (anihip_pair_xtb_repulsion, csrc/pair.hip) on the same rows the AEV
-kernels use; there is no eager fallback.
+pair energies), torchani/potentials/dftd3.py:44-330 (BeckeJohnsonDamp, TwoBodyDispersionD3: constructor,
+``from_functional``, coordination numbers, C6 interpolation, pair energies) and the shared machinery of
+torchani/potentials/core.py:103-207 (cutoff envelope, ``atomic`` halves, sum per molecule).  The arithmetic runs in
+libanihip (anihip_pair_xtb_repulsion, anihip_pair_d3, csrc/pair.hip) on neighbor rows of the engine; there is no eager
+fallback.
 
-Not here: TwoBodyDispersionD3 (potentials/dftd3.py) -- its C6 reference table ships as resources/c6.h5 and h5py is
-not available in this environment -- and the GELU / bias-free networks of the published ANI-2xr / ANI-2dr parameters
-(arch.py:1007-1010; the network kernels implement CELU, which is what ANI-1x / 1ccx / 2x use).
+Not here: the GELU / bias-free networks of the published ANI-2xr / ANI-2dr parameters (arch.py:1007-1010; the network
+kernels implement CELU, which is what ANI-1x / 1ccx / 2x use).
 """
 from __future__ import annotations
 
-import ctypes as C  # noqa: F401
+import ctypes as C
 import math
+import os
 import typing as tp
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -124,3 +128,129 @@ class RepulsionXTB(torch.nn.Module):
 
     def extra_repr(self) -> str:
         return f"symbols={self.symbols}, cutoff={self.cutoff}, cutoff_fn={self.cutoff_fn}"
+
+
+_D3_REFS: tp.Optional[tp.Dict[str, tp.Any]] = None
+
+
+def d3_reference_data() -> tp.Dict[str, tp.Any]:
+    """Grimme's D3 reference data for Z <= 18 (torchani_amd/data/d3_refs.npz, extracted from the reference's
+    resources/c6.h5, atomic_constants.json and functional_d3bj_constants.json by tests/golden/gen_golden_d3.py)."""
+    global _D3_REFS
+    if _D3_REFS is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "d3_refs.npz")
+        with np.load(path) as z:
+            d = {k: z[k] for k in z.files}
+        d["symbols"] = [str(s) for s in d["symbols"]]
+        d["functionals"] = {str(n): tuple(float(v) for v in row)
+                            for n, row in zip(d["functionals"], d["functional_s6_s8_a1_a2"])}
+        _D3_REFS = d
+    return _D3_REFS
+
+
+class TwoBodyDispersionD3(torch.nn.Module):
+    """Two-body DFT-D3 dispersion with Becke-Johnson damping (potentials/dftd3.py:113-330).
+
+    ``sqrt_empirical_charge`` / ``covalent_radii`` (Angstrom) default to the tabulated values of the elements, like the
+    reference's; the C6 reference table covers Z <= 18."""
+
+    ANGSTROM_TO_BOHR = 1.8897261258369282   # torchani/units.py:41
+
+    def __init__(self, symbols: tp.Sequence[str], s6: float, s8: float, damp_a1: float, damp_a2: float,
+                 sqrt_empirical_charge: tp.Sequence[float] = (), covalent_radii: tp.Sequence[float] = (), *,
+                 cutoff_fn: str = "smooth", cutoff: float = math.inf) -> None:
+        super().__init__()
+        if cutoff_fn not in _lib.CUTOFF_KINDS:
+            raise ValueError(f"Unsupported cutoff function {cutoff_fn!r}: the HIP kernels have {sorted(_lib.CUTOFF_KINDS)}")
+        if len(symbols) > 7:
+            raise ValueError("at most 7 elements (the species field of a neighbor row)")
+        ref = d3_reference_data()
+        self.symbols = tuple(symbols)
+        unknown = [s for s in symbols if s not in ref["symbols"]]
+        if unknown:
+            raise ValueError(f"no D3 reference data for {unknown} (the shipped table covers {ref['symbols']})")
+        z = [ref["symbols"].index(s) + 1 for s in symbols]
+        for name, seq in (("sqrt_empirical_charge", sqrt_empirical_charge), ("covalent_radii", covalent_radii)):
+            if seq and len(seq) != len(symbols):
+                raise ValueError(f"len({name}), if provided, must match len(symbols)")   # core.py _validate_elem_seq
+        sq = list(sqrt_empirical_charge) if sqrt_empirical_charge else [float(ref["sqrt_empirical_charge"][k]) for k in z]
+        cov = list(covalent_radii) if covalent_radii else [float(ref["covalent_radius"][k]) for k in z]
+        self._s6, self._s8, self._a1, self._a2 = float(s6), float(s8), float(damp_a1), float(damp_a2)
+        zi = np.asarray(z)
+        self.register_buffer("atomic_numbers", torch.tensor(z))
+        self.register_buffer("precalc_coeff6", torch.from_numpy(ref["c6"][zi][:, zi].copy()))
+        self.register_buffer("precalc_coordnums_a", torch.from_numpy(ref["cn_a"][zi][:, zi].copy()))
+        self.register_buffer("precalc_coordnums_b", torch.from_numpy(ref["cn_b"][zi][:, zi].copy()))
+        _sq = torch.tensor(sq, dtype=torch.float32)
+        self.register_buffer("sqrt_charge_ab", torch.outer(_sq, _sq))
+        self.register_buffer("covalent_radii", torch.tensor([self.ANGSTROM_TO_BOHR * r for r in cov], dtype=torch.float32))
+        self._sqrt_q = [float(v) for v in sq]
+        self.cutoff = float(cutoff)
+        self.cutoff_fn = cutoff_fn
+        self._enabled = True
+        self._table: tp.Optional[Tensor] = None
+        self._own_engine: tp.Optional[AevEngine] = None
+        self.needs_all_rows = True   # coordination numbers of every neighbor: rows of all atoms, not of a shard
+
+    @classmethod
+    def from_functional(cls, symbols: tp.Sequence[str], functional: str, *, cutoff_fn: str = "smooth",
+                        cutoff: float = math.inf) -> "TwoBodyDispersionD3":
+        fn = d3_reference_data()["functionals"]
+        if functional.lower() not in fn:
+            raise ValueError(f"no D3(BJ) constants for functional {functional!r}")
+        s6, s8, a1, a2 = fn[functional.lower()]
+        return cls(symbols, s6=s6, s8=s8, damp_a1=a1, damp_a2=a2, cutoff_fn=cutoff_fn, cutoff=cutoff)
+
+    def table(self, device: torch.device) -> Tensor:
+        """[8, 8, 25, 4] device table {c6 ref, cn_a ref, cn_b ref, 0} (include/anihip.h)."""
+        if self._table is None or self._table.device != device:
+            S = len(self.symbols)
+            t = torch.zeros((8, 8, 25, 4), dtype=torch.float32)
+            t[..., 0] = -1.0   # (missing references are -1 in the reference table: skipped)
+            t[:S, :S, :, 0] = self.precalc_coeff6.cpu().reshape(S, S, 25)
+            t[:S, :S, :, 1] = self.precalc_coordnums_a.cpu().reshape(S, S, 25)
+            t[:S, :S, :, 2] = self.precalc_coordnums_b.cpu().reshape(S, S, 25)
+            self._table = t.to(device).contiguous()
+        return self._table
+
+    def params(self) -> "_lib.D3Params":
+        p = _lib.D3Params()
+        p.s6, p.s8, p.a1, p.a2 = self._s6, self._s8, self._a1, self._a2
+        for k in range(8):
+            p.cov_radius_bohr[k] = float(self.covalent_radii[k]) if k < len(self.symbols) else 0.0
+            p.sqrt_q[k] = self._sqrt_q[k] if k < len(self.symbols) else 0.0
+        return p
+
+    def rows_cutoff(self, rows_rcr: float) -> float:
+        if self.cutoff > rows_rcr + 1e-6 and not math.isinf(self.cutoff):
+            raise ValueError(f"pair cutoff {self.cutoff} exceeds the neighbor rows' cutoff {rows_rcr}")
+        return self.cutoff
+
+    def accumulate(self, species32: Tensor, nbrs: NeighborRows, atomic_e: tp.Optional[Tensor],
+                   grad_coords: tp.Optional[Tensor], virial: tp.Optional[Tensor] = None,
+                   cutoff: tp.Optional[float] = None, lo: tp.Optional[int] = None, hi: tp.Optional[int] = None) -> None:
+        """atomic_e [N] += pair halves, grad_coords [N, 3] += gradient, virial [3, 3] +=, for the central atoms
+        lo .. hi (default: all).  nbrs must hold the rows of ALL atoms and be symmetric."""
+        _require_cuda(species32, atomic_e, grad_coords, virial)
+        n = species32.numel()
+        if not nbrs.symmetric or nbrs.lo != 0 or nbrs.hi != n:
+            raise ValueError("TwoBodyDispersionD3 needs symmetric neighbor rows of all atoms")
+        cut = self.cutoff if cutoff is None else cutoff
+        if math.isinf(cut):
+            cut = 1e30
+        dev = species32.device
+        cn = torch.empty(n, dtype=torch.float32, device=dev)
+        gcn = torch.empty(n, dtype=torch.float32, device=dev)
+        p = self.params()
+        _lib.check(_lib.lib().anihip_pair_d3(
+            _stream(), n, 0 if lo is None else lo, n if hi is None else hi, _ptr(species32), _ptr(nbrs.meta),
+            _ptr(nbrs.ent), _ptr(self.table(dev)), C.byref(p), float(cut), _lib.CUTOFF_KINDS[self.cutoff_fn], _ptr(cn),
+            _ptr(gcn), _ptr(atomic_e), _ptr(grad_coords), _ptr(virial)))
+
+    def compute_from_rows(self, species32: Tensor, coords: Tensor, nbrs: NeighborRows) -> Tensor:
+        """Molecular energies [C] (float64), differentiable with respect to coords."""
+        return _PairEnergy.apply(coords, self, species32, nbrs)
+
+    def extra_repr(self) -> str:
+        return (f"symbols={self.symbols}, s6={self._s6}, s8={self._s8}, a1={self._a1}, a2={self._a2}, "
+                f"cutoff={self.cutoff}, cutoff_fn={self.cutoff_fn}")
