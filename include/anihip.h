@@ -255,6 +255,8 @@ typedef struct {
  *           ~4e-7 per product (fp32: 6e-8) at 16/3 of the fp32-MFMA rate.  Layer-0 inputs use the static
  *           scale 4, valid for |x| < 16376 -- above the largest value an AEV element can take with the
  *           row limits of this library (2 * C(128,2) = 16256). */
+#define ANIHIP_ACT_CELU 0
+#define ANIHIP_ACT_GELU 1
 #define ANIHIP_MLP_FP32 0
 #define ANIHIP_MLP_F16X3 1
 /* anihip_mlp_desc.flags: algorithm choices of anihip_mlp_forward_backward that the library otherwise makes from the
@@ -273,6 +275,8 @@ typedef struct {
     int32_t precision; /* ANIHIP_MLP_FP32 or ANIHIP_MLP_F16X3 */
     int32_t aev_radial_len; /* R of the slab order of wh[0] / wth[0] (0 = plain order) */
     int32_t flags;          /* ANIHIP_MLP_FLAG_* (0 = let the library choose); the library reads no environment */
+    int32_t activation;     /* ANIHIP_ACT_CELU (celu_alpha) or ANIHIP_ACT_GELU (torch.nn.GELU(), exact; energies and
+                             * input gradients through the fused network kernel only: 3 hidden layers <= 256 wide) */
     anihip_species_net net[ANIHIP_MAX_SPECIES];
 } anihip_mlp_desc;
 

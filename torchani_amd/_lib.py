@@ -29,6 +29,7 @@ ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
 MLP_FP32, MLP_F16X3 = 0, 1
 BWD_SYMMETRIC, BWD_FIXED_POINT = 1, 2   # flags of anihip_aev_backward
 PAIR_PUSH = 1
+ACT_CELU, ACT_GELU = 0, 1
 # anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*)
 MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_FUSED_ROWS32, MLP_FLAG_D0_ROWS = \
     1, 2, 4, 8, 16, 32
@@ -91,6 +92,7 @@ class MlpDesc(C.Structure):
         ("precision", C.c_int32),
         ("aev_radial_len", C.c_int32),
         ("flags", C.c_int32),
+        ("activation", C.c_int32),
         ("net", SpeciesNet * MAX_SPECIES),
     ]
 

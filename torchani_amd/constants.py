@@ -10,10 +10,16 @@ import typing as tp
 # utils.py:63-66
 SYMBOLS_1X: tp.Tuple[str, ...] = ("H", "C", "N", "O")
 SYMBOLS_2X: tp.Tuple[str, ...] = ("H", "C", "N", "O", "S", "F", "Cl")
+SYMBOLS_2X_ZNUM_ORDER: tp.Tuple[str, ...] = ("H", "C", "N", "O", "F", "S", "Cl")   # utils.py:65 (ANI-2xr / 2dr)
 ATOMIC_NUMBER: tp.Dict[str, int] = {"H": 1, "C": 6, "N": 7, "O": 8, "F": 9, "S": 16, "Cl": 17}
 PADDING_SPECIES = -1  # utils.py:67-74
 
 # constants.py:88-96, ground-state atomic self energies wB97X/6-31G(d), Hartree
+# constants.py GSAES["b973c-def2mtzvp"] (ground-state atomic energies at the level of theory of ANI-2dr)
+GSAES_B973C_DEF2MTZVP: tp.Dict[str, float] = {
+    "H": -0.506930113968, "C": -37.81441001258, "N": -54.556538547322, "O": -75.029181326588,
+    "F": -99.688618987039, "S": -398.043159341582, "Cl": -460.082223445159,
+}
 GSAES_WB97X_631GD: tp.Dict[str, float] = {
     "C": -37.8338334,
     "Cl": -460.116700600,
@@ -65,6 +71,15 @@ def aev_constants_2x(num_species: int = 7, cutoff_fn: str = "cosine") -> AEVCons
     # aev/_computer.py:550-600; aev/_terms.py:188-207 (radial), :345-366 (angular)
     return AEVConstants(
         num_species, 5.1, 3.5, 19.7, linspace(0.8, 5.1, 16), 12.5, 14.1, linspace(0.8, 3.5, 8),
+        linspace(math.pi / 8, math.pi + math.pi / 8, 4), cutoff_fn,
+    )
+
+
+def aev_constants_simple(num_species: int = 7, cutoff_fn: str = "smooth") -> AEVConstants:
+    # arch.py:992-1046 simple_ani defaults (the AEV of ANI-2xr / ANI-2dr): both term families cover_linearly from 0.9 A,
+    # radial cutoff 5.2 A, smooth envelope
+    return AEVConstants(
+        num_species, 5.2, 3.5, 19.7, linspace(0.9, 5.2, 16), 12.5, 14.1, linspace(0.9, 3.5, 8),
         linspace(math.pi / 8, math.pi + math.pi / 8, 4), cutoff_fn,
     )
 

@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const
     else if ((u).nrb == RB && (u).nba == 1) { constexpr int RBA = RB, NBA = 1; CALL; }      \
     else if ((u).nrb == 1) { constexpr int RBA = 1, NBA = 1; CALL; }
 
-template <int RB, int NB>
+template <int RB, int NB, int ACT>   // ACT: 0 = CELU(alpha), 1 = GELU (exact, erf)
 __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 {
     using C = FusedCfg<RB, NB>;
@@ -1795,26 +1795,27 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         fr_ring<NB, D>(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, u2.cb, NW, lane, u2.nba);
         // celu and its derivative from one exponential: x > 0: (x, 1), else (alpha (e - 1), e), e = exp(x / alpha)
         const float ia_log2e = inv_alpha * 1.44269504f;
-        auto celu_d = [&](float x, float &d) {
-            const float e = __builtin_amdgcn_exp2f(x * ia_log2e);
-            d = fminf(e, 1.0f);   // (e > 1 exactly when x > 0; as a select the compare masks of all 32 elements stay
-                                  //  live until the backward phases and spill from SGPRs into VGPR lanes)
-            // celu(x) = median(x, alpha (e - 1), 0): for x > 0 the exponential branch lies above x (convexity), for
-            // x < 0 between x and 0 -- one v_med3_f32 instead of a compare and a select
-            return __builtin_amdgcn_fmed3f(x, __builtin_fmaf(alpha, e, -alpha), 0.f);
-        };
         // two elements at a time: bias + scale, the exponent argument and alpha (e - 1) as packed fp32 operations
         typedef float v2f __attribute__((ext_vector_type(2)));
         auto celu_d2 = [&](float a0, float a1, float osc, float b0, float b1, float &y0, float &y1, float &dd0,
                            float &dd1) {
             const v2f x = v2f{a0, a1} * osc + v2f{b0, b1};
-            const v2f t = x * ia_log2e;
-            const v2f e = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-            const v2f y = e * alpha - alpha;
-            dd0 = fminf(e.x, 1.0f);
-            dd1 = fminf(e.y, 1.0f);
-            y0 = __builtin_amdgcn_fmed3f(x.x, y.x, 0.f);
-            y1 = __builtin_amdgcn_fmed3f(x.y, y.y, 0.f);
+            if constexpr (ACT == 1) {
+                // gelu(x) = x Phi(x), gelu'(x) = Phi(x) + x phi(x)   (torch.nn.GELU(), approximate = 'none')
+                const v2f ph = v2f{erff(x.x * 0.70710678f), erff(x.y * 0.70710678f)} * 0.5f + 0.5f;
+                const v2f t = x * x * (-0.5f * 1.44269504f);
+                const v2f g2 = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * 0.39894228f;
+                const v2f y = x * ph, d = ph + x * g2;
+                y0 = y.x; y1 = y.y; dd0 = d.x; dd1 = d.y;
+            } else {
+                const v2f t = x * ia_log2e;
+                const v2f e = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                const v2f y = e * alpha - alpha;
+                dd0 = fminf(e.x, 1.0f);
+                dd1 = fminf(e.y, 1.0f);
+                y0 = __builtin_amdgcn_fmed3f(x.x, y.x, 0.f);
+                y1 = __builtin_amdgcn_fmed3f(x.y, y.y, 0.f);
+            }
         };
         float d0f[NE][16];   // celu'(act0) of this lane's elements
         float a0max;         // tile max of |act0|
@@ -2512,6 +2513,7 @@ static int check_desc(const anihip_mlp_desc *d)
     ANIHIP_REQUIRE(d->n_members >= 1 && d->n_members <= 64, "n_members must be 1..64");
     ANIHIP_REQUIRE(d->aev_len % BK == 0, "aev_len must be a multiple of %d", BK);
     ANIHIP_REQUIRE(d->precision == ANIHIP_MLP_FP32 || d->precision == ANIHIP_MLP_F16X3, "unknown precision");
+    ANIHIP_REQUIRE(d->activation == ANIHIP_ACT_CELU || d->activation == ANIHIP_ACT_GELU, "unknown activation");
     ANIHIP_REQUIRE(d->aev_radial_len >= 0 && d->aev_radial_len <= d->aev_len &&
                        (d->aev_radial_len == 0 || (d->aev_len - d->aev_radial_len) % 32 == 0),
                    "aev_radial_len: the angular part must be a multiple of 32 long");
@@ -2643,6 +2645,9 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                 fused_dims_supported(nn.dims[1], nn.dims[2], nn.dims[3]);
     }
     if (d->flags & ANIHIP_MLP_FLAG_NO_FUSED) fused = false;
+    // (the layer-by-layer kernels, the 32-atom tiling and the training passes implement CELU only)
+    ANIHIP_REQUIRE(d->activation == ANIHIP_ACT_CELU || fused,
+                   "GELU networks run through the fused network kernel only: f16x3 precision, 3 hidden layers <= 256 wide");
     // 256 x 256 tiles for the layer-0 GEMMs once there are enough rows to fill the chip with them
     int d0_tm = 0;
     bool big_tiles = h3 && n >= 16384;
@@ -2703,7 +2708,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         size_t lds = 0;
         // tiling: 64 atoms x 8 waves, one workgroup per CU (default: 3 % faster on the water box), or
         // 32 atoms x 4 waves, two per CU (ANIHIP_MLP_FLAG_FUSED_ROWS32)
-        const int rows = (d->flags & ANIHIP_MLP_FLAG_FUSED_ROWS32) ? 32 : 64;
+        const int rows = ((d->flags & ANIHIP_MLP_FLAG_FUSED_ROWS32) && d->activation == ANIHIP_ACT_CELU) ? 32 : 64;
         for (int s = 0; s < S; ++s) {
             const anihip_species_net &nn = d->net[s];
             FusedSpecies &fs = f.sp[s];
@@ -2732,7 +2737,9 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         f.tile_tab = w.tile_tab; f.tile_rows = w.tile_rows;
         f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
         f.want_grad = grad_aev ? 1 : 0;
-        const void *kfn = rows == 64 ? (const void *)k_mlp_fused<2, 1> : (const void *)k_mlp_fused<1, 2>;
+        const bool gelu = d->activation == ANIHIP_ACT_GELU;
+        const void *kfn = rows == 64 ? (gelu ? (const void *)k_mlp_fused<2, 1, 1> : (const void *)k_mlp_fused<2, 1, 0>)
+                                     : (const void *)k_mlp_fused<1, 2, 0>;
         ANIHIP_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t tiles = (n + rows - 1) / rows + S;
         f.tiles_total = (int)tiles;
@@ -2759,9 +2766,12 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         }
 #endif
         if (rows == 64)
-            hipLaunchKernelGGL((k_mlp_fused<2, 1>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+        {
+            if (gelu) hipLaunchKernelGGL((k_mlp_fused<2, 1, 1>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+            else hipLaunchKernelGGL((k_mlp_fused<2, 1, 0>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+        }
         else
-            hipLaunchKernelGGL((k_mlp_fused<1, 2>), dim3((unsigned)grid), dim3(256), lds, stream, f);
+            hipLaunchKernelGGL((k_mlp_fused<1, 2, 0>), dim3((unsigned)grid), dim3(256), lds, stream, f);
 #ifdef ANIHIP_DEV_TRACE
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipStreamSynchronize(stream));
@@ -2941,6 +2951,7 @@ extern "C" int anihip_mlp_train_forward(void *stream_, const anihip_mlp_desc *d,
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
+    ANIHIP_REQUIRE(d->activation == ANIHIP_ACT_CELU, "the training passes implement CELU networks only");
     ANIHIP_REQUIRE(species && aev && workspace && atomic_e, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     const int64_t n = hi - lo;
@@ -2999,6 +3010,7 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
+    ANIHIP_REQUIRE(d->activation == ANIHIP_ACT_CELU, "the training passes implement CELU networks only");
     ANIHIP_REQUIRE(species && aev && grad_atomic_e && workspace && grads && atomic_e, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1, L = d->aev_len;
@@ -3135,6 +3147,7 @@ extern "C" int anihip_mlp_tangent_weight_grads(void *stream_, const anihip_mlp_d
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
+    ANIHIP_REQUIRE(d->activation == ANIHIP_ACT_CELU, "the training passes implement CELU networks only");
     ANIHIP_REQUIRE(species && aev && tangent && workspace && grads && datomic_e, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1, L = d->aev_len;

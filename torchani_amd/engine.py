@@ -385,7 +385,8 @@ class PackedNetworks:
 
     def __init__(self, weights: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]],
                  biases: tp.Sequence[tp.Sequence[tp.Sequence[Tensor]]], aev_len: int, celu_alpha: float,
-                 device: torch.device, precision: str = "f16x3", radial_len: tp.Optional[int] = None) -> None:
+                 device: torch.device, precision: str = "f16x3", radial_len: tp.Optional[int] = None,
+                 activation: str = "celu") -> None:
         """weights[m][s][l]: [out, in] (torch.nn.Linear layout) of member m, species s, layer l.
 
         radial_len: length R of the radial part of the AEV; the layer-0 fp16 planes are then stored in slab
@@ -396,7 +397,12 @@ class PackedNetworks:
         error per product, see include/anihip.h)."""
         if precision not in ("fp32", "f16x3"):
             raise ValueError(f"unknown MLP precision {precision!r}")
+        if activation not in ("celu", "gelu"):
+            raise ValueError(f"unknown activation {activation!r}: the network kernels have celu and gelu")
+        if activation == "gelu" and precision != "f16x3":
+            raise ValueError("GELU networks run through the fused f16x3 network kernel only")
         self.precision = precision
+        self.activation = activation
         M, S = len(weights), len(weights[0])
         nl = len(weights[0][0])
         if not (2 <= nl <= _lib.MAX_LAYERS):
@@ -410,6 +416,7 @@ class PackedNetworks:
         d = _lib.MlpDesc()
         d.num_species, d.n_members, d.aev_len, d.celu_alpha = S, M, aev_len, celu_alpha
         d.precision = _lib.MLP_F16X3 if precision == "f16x3" else _lib.MLP_FP32
+        d.activation = _lib.ACT_GELU if activation == "gelu" else _lib.ACT_CELU
         k0p = _pad32(aev_len)
         if radial_len is None:
             radial_len = 16 * S if aev_len == 16 * S + 16 * S * (S + 1) else 0
@@ -501,8 +508,10 @@ class PackedNetworks:
                 W2 = torch.stack([weights[m][s][2].detach().to(**f32) for m in range(M)])   # [M, H3, H2]
                 b1 = torch.stack([biases[m][s][1].detach().to(**f32) for m in range(M)])
                 w3 = torch.stack([weights[m][s][3].detach().to(**f32).reshape(-1) for m in range(M)])
-                g2 = w3.abs().amax(dim=1) / M
-                g3 = g2 * W2.abs().sum(dim=1).amax(dim=1)
+                # (|celu'| <= 1; max gelu' = 1.1290: the gradient bounds grow by that factor per layer)
+                dmax = 1.13 if activation == "gelu" else 1.0
+                g2 = w3.abs().amax(dim=1) / M * dmax
+                g3 = g2 * W2.abs().sum(dim=1).amax(dim=1) * dmax
                 g4 = g3 * W1.abs().sum(dim=1).amax(dim=1)
                 zero = torch.zeros_like(g2)
                 bounds = torch.stack([W1.abs().sum(dim=2).amax(dim=1), b1.abs().amax(dim=1), g2, g3, g4,

@@ -23,12 +23,12 @@ from torch import Tensor
 from .aev import AEVComputer
 from ._lib import MAX_RAD
 from ._lib import MAX_RAD as _lib_MAX_RAD
-from .constants import GSAES_WB97X_631GD
+from .constants import GSAES_WB97X_631GD  # noqa: F401
 from .engine import FIXED_SCALE, energy_reduce, fixed_to_float
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import join_exact, shard_range, split_exact
 from .tuples import EnergiesScalars, AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
-from .weights import arch_spec, random_state_dict
+from .weights import arch_gsaes, arch_networks, arch_spec, random_state_dict
 
 
 class NNPotential(torch.nn.Module):
@@ -535,10 +535,19 @@ def _assemble(kind: str, n_members: int, neighborlist: str, row_capacity: int,
               periodic_table_index: bool, cutoff_fn: str = "cosine") -> ANI:
     symbols, consts, hidden = arch_spec(kind)
     aevc = AEVComputer(consts, neighborlist=neighborlist, row_capacity=row_capacity, cutoff_fn=cutoff_fn)
-    members = [ANINetworks.build(symbols, consts.out_dim, hidden) for _ in range(n_members)]
+    act, bias = arch_networks(kind)
+    members = [ANINetworks.build(symbols, consts.out_dim, hidden, act, bias) for _ in range(n_members)]
     nets: torch.nn.Module = Ensemble(members) if n_members > 1 else members[0]
-    sae = [GSAES_WB97X_631GD[s] for s in symbols]
-    return ANI(symbols, aevc, nets, sae, periodic_table_index)
+    sae = [arch_gsaes(kind)[s] for s in symbols]
+    model = ANI(symbols, aevc, nets, sae, periodic_table_index)
+    if kind in ("ani2xr", "ani2dr"):   # arch.py:1055-1066: repulsion up to the radial cutoff, dispersion up to 8 A
+        from .potentials import RepulsionXTB, TwoBodyDispersionD3
+
+        model.add_pair_potential("repulsion_xtb", RepulsionXTB(symbols, cutoff=consts.Rcr, cutoff_fn="smooth"))
+        if kind == "ani2dr":
+            model.add_pair_potential("dispersion_d3", TwoBodyDispersionD3.from_functional(
+                symbols, "b973c", cutoff=8.0, cutoff_fn="smooth"))
+    return model
 
 
 def _builtin(kind: str, state_dict, seed, n_members, device, neighborlist, row_capacity,
@@ -585,6 +594,24 @@ def ANI2x(model_index: tp.Optional[int] = None, neighborlist: str = "auto", stra
     cutoff_fn="smooth" gives the envelope of the reference's newer models (arch.py:1006, CutoffSmooth)."""
     return _builtin("ani2x", state_dict, seed, n_members, device, neighborlist, row_capacity,
                     periodic_table_index, cutoff_fn, model_index, strategy, dtype)
+
+
+def ANI2xr(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",
+           periodic_table_index: bool = True, device=None, dtype=None, state_dict=None,
+           seed: tp.Optional[int] = None, n_members: int = 8, row_capacity: int = 128) -> ANI:
+    """ANI-2xr architecture (models.py:252-287): H C N O F S Cl, the AEV of simple_ani (smooth envelope, radial cutoff
+    5.2 A), GELU networks without biases, xTB repulsion."""
+    return _builtin("ani2xr", state_dict, seed, n_members, device, neighborlist, row_capacity,
+                    periodic_table_index, "smooth", model_index, strategy, dtype)
+
+
+def ANI2dr(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",
+           periodic_table_index: bool = True, device=None, dtype=None, state_dict=None,
+           seed: tp.Optional[int] = None, n_members: int = 8, row_capacity: int = 128) -> ANI:
+    """ANI-2dr architecture (models.py:290-325): ANI-2xr + DFT-D3(BJ) dispersion (B97-3c constants, 8 A), self energies
+    of B97-3c / def2-mTZVP."""
+    return _builtin("ani2dr", state_dict, seed, n_members, device, neighborlist, row_capacity,
+                    periodic_table_index, "smooth", model_index, strategy, dtype)
 
 
 def ANI1x(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",

@@ -38,14 +38,15 @@ class AtomicNetwork(torch.nn.Module):
         super().__init__()
         if any(d <= 0 for d in layer_dims):
             raise ValueError("Layer dims must be strict positive integers")
-        if activation != "celu" or not bias:
-            raise ValueError("the HIP ensemble kernels implement CELU(0.1) networks with biases (ANI-1x/2x)")
+        if activation not in ("celu", "gelu"):
+            raise ValueError("the HIP ensemble kernels implement CELU(0.1) (ANI-1x/2x) and GELU (ANI-2xr/2dr) networks")
         dims = tuple(layer_dims)
         self.layers = torch.nn.ModuleList(
-            [torch.nn.Linear(i, o, bias=True) for i, o in zip(dims[:-2], dims[1:-1])])
-        self.final_layer = torch.nn.Linear(dims[-2], dims[-1], bias=True)
-        self.activation = TightCELU()
-        self.has_biases = True
+            [torch.nn.Linear(i, o, bias=bias) for i, o in zip(dims[:-2], dims[1:-1])])
+        self.final_layer = torch.nn.Linear(dims[-2], dims[-1], bias=bias)
+        self.activation = TightCELU() if activation == "celu" else torch.nn.GELU()
+        self.activation_name = activation
+        self.has_biases = bool(bias)
 
     def linears(self) -> tp.List[torch.nn.Linear]:
         return list(self.layers) + [self.final_layer]
@@ -183,17 +184,25 @@ class _EngineContainer(torch.nn.Module):
         cache = self.__dict__.setdefault("_packed_cache", {})   # several member subsets stay packed
         if key not in cache:
             weights = [[[lin.weight for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
-            biases = [[[lin.bias for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
+            # (bias-free networks, nn/_core.py:122: zeros)
+            biases = [[[lin.bias if lin.bias is not None else torch.zeros(lin.out_features, device=lin.weight.device)
+                        for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
             aev_len = weights[0][0][0].shape[1]
+            acts = {getattr(m.atomics[s], "activation_name", "celu") for m in members for s in self.symbols}
+            if len(acts) != 1:
+                raise ValueError(f"all atomic networks of a container must share one activation, got {sorted(acts)}")
             if len(cache) >= 12:   # (parameters updated in place leave stale entries behind)
                 cache.clear()
-            cache[key] = PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, precision)
+            cache[key] = PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, precision, activation=acts.pop())
         return cache[key]
 
     def _train_pack(self, device: torch.device) -> PackedNetworks:
         """fp32 pack read by the training pass; built once per parameter set and refreshed in place (one kernel,
         anihip_mlp_repack) whenever an optimizer step changed the parameters."""
         members = self._member_networks()
+        if any(getattr(m.atomics[s], "activation_name", "celu") != "celu" or not m.atomics[s].has_biases
+               for m in members for s in self.symbols):
+            raise NotImplementedError("the training passes implement CELU networks with biases (ANI-1x / 2x)")
         lins = [[m.atomics[s].linears() for s in self.symbols] for m in members]
         weights = [[[lin.weight for lin in sl] for sl in ml] for ml in lins]
         biases = [[[lin.bias for lin in sl] for sl in ml] for ml in lins]
@@ -217,7 +226,9 @@ class _EngineContainer(torch.nn.Module):
         params: tp.List[Tensor] = []
         if torch.is_grad_enabled():
             lins = [lin for m in self._member_networks() for s in self.symbols for lin in m.atomics[s].linears()]
-            if any(lin.weight.requires_grad or lin.bias.requires_grad for lin in lins):
+            if any(p.requires_grad for lin in lins for p in (lin.weight, lin.bias) if p is not None):
+                if any(lin.bias is None for lin in lins):
+                    raise NotImplementedError("the training passes implement CELU networks with biases (ANI-1x / 2x)")
                 params = [p for lin in lins for p in (lin.weight, lin.bias)]
         trainable_fast = (params and not ensemble_values
                           and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == aevs.device
@@ -264,8 +275,9 @@ class ANINetworks(_EngineContainer):
         return out
 
     @classmethod
-    def build(cls, symbols: tp.Sequence[str], in_dim: int, hidden: tp.Dict[str, tp.Sequence[int]]):
-        return cls({s: AtomicNetwork((in_dim,) + tuple(hidden[s]) + (1,)) for s in symbols})
+    def build(cls, symbols: tp.Sequence[str], in_dim: int, hidden: tp.Dict[str, tp.Sequence[int]],
+              activation: str = "celu", bias: bool = True):
+        return cls({s: AtomicNetwork((in_dim,) + tuple(hidden[s]) + (1,), activation, bias) for s in symbols})
 
     def to_infer_model(self, use_mnp: bool = False) -> "ANINetworks":
         return self  # already the fused native path (reference: nn/_containers.py:423-425)

@@ -8,8 +8,8 @@ torchani/potentials/core.py:103-207 (cutoff envelope, ``atomic`` halves, sum per
 libanihip (anihip_pair_xtb_repulsion, anihip_pair_d3, csrc/pair.hip) on neighbor rows of the engine; there is no eager
 fallback.
 
-Not here: the GELU / bias-free networks of the published ANI-2xr / ANI-2dr parameters (arch.py:1007-1010; the network
-kernels implement CELU, which is what ANI-1x / 1ccx / 2x use).
+(The GELU / bias-free networks of those models run through the fused network kernel, torchani_amd.models.ANI2xr /
+ANI2dr.)
 """
 from __future__ import annotations
 

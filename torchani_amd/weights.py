@@ -13,8 +13,8 @@ import typing as tp
 
 import numpy as np
 
-from .constants import (GSAES_WB97X_631GD, HIDDEN_DIMS_1X, HIDDEN_DIMS_2X, SYMBOLS_1X, SYMBOLS_2X,
-                        aev_constants_1x, aev_constants_2x)
+from .constants import (GSAES_B973C_DEF2MTZVP, GSAES_WB97X_631GD, HIDDEN_DIMS_1X, HIDDEN_DIMS_2X, SYMBOLS_1X, SYMBOLS_2X,
+                        SYMBOLS_2X_ZNUM_ORDER, aev_constants_1x, aev_constants_2x, aev_constants_simple)
 
 NN_PREFIX = "potentials.nnp.neural_networks."
 
@@ -25,7 +25,19 @@ def arch_spec(kind: str):
         return SYMBOLS_2X, aev_constants_2x(), HIDDEN_DIMS_2X
     if kind == "ani1x":
         return SYMBOLS_1X, aev_constants_1x(), HIDDEN_DIMS_1X
+    if kind in ("ani2xr", "ani2dr"):   # models.py:252-320: simple_ani with the ANI-2x widths, GELU, no biases
+        return SYMBOLS_2X_ZNUM_ORDER, aev_constants_simple(), HIDDEN_DIMS_2X
     raise ValueError(f"Unknown architecture {kind!r}")
+
+
+def arch_networks(kind: str) -> tp.Tuple[str, bool]:
+    """(activation, bias) of the atomic networks of a builtin architecture (arch.py:1010-1011 for the -r models)."""
+    return ("gelu", False) if kind in ("ani2xr", "ani2dr") else ("celu", True)
+
+
+def arch_gsaes(kind: str) -> tp.Dict[str, float]:
+    """Self energies (ground-state atomic energies of the model's level of theory, arch.py:1053 / models.py)."""
+    return GSAES_B973C_DEF2MTZVP if kind == "ani2dr" else GSAES_WB97X_631GD
 
 
 def random_state_dict(kind: str = "ani2x", n_members: int = 8, seed: int = 0,
@@ -43,7 +55,8 @@ def random_state_dict(kind: str = "ani2x", n_members: int = 8, seed: int = 0,
                 bound = scale / np.sqrt(dims[l])
                 base = f"{NN_PREFIX}members.{m}.atomics.{sym}.{name}."
                 out[base + "weight"] = rs.uniform(-bound, bound, (dims[l + 1], dims[l])).astype(np.float32)
-                out[base + "bias"] = rs.uniform(-bound, bound, (dims[l + 1],)).astype(np.float32)
+                if arch_networks(kind)[1]:
+                    out[base + "bias"] = rs.uniform(-bound, bound, (dims[l + 1],)).astype(np.float32)
     out["energy_shifter.self_energies"] = np.asarray(
-        [GSAES_WB97X_631GD[s] for s in symbols], dtype=np.float32)
+        [arch_gsaes(kind)[s] for s in symbols], dtype=np.float32)
     return out
