@@ -23,7 +23,9 @@ from torchani.arch import simple_ani  # noqa: E402
 
 from torchani_amd.weights import arch_spec, random_state_dict  # noqa: E402
 
-LOT = {"ani2xr": "wb97x-631gd", "ani2dr": "b973c-def2mtzvp"}
+LOT = {"ani2xr": "wb97x-631gd", "ani2dr": "b973c-def2mtzvp", "anir2s": "r2scan3c-def2mtzvpp"}
+# models.py:325-368: the ANI-2x AEV with the smooth envelope, repulsion without a cutoff
+R2S_KW = dict(repulsion_cutoff=False, cutoff_fn="smooth", radial_start=0.8, angular_start=0.8, radial_cutoff=5.1)
 
 
 def run(kind, name, seed):
@@ -38,7 +40,7 @@ def run(kind, name, seed):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         model = simple_ani(lot=LOT[kind], symbols=symbols, ensemble_size=8, dispersion=kind == "ani2dr", repulsion=True,
-                           periodic_table_index=False)
+                           periodic_table_index=False, **(R2S_KW if kind == "anir2s" else {}))
     state = {k: torch.from_numpy(v) for k, v in random_state_dict(kind, 8, seed).items()}
     missing, unexpected = model.load_state_dict(state, strict=False)
     assert not [k for k in missing if "neural_networks" in k or "energy_shifter" in k], missing[:3]
@@ -60,6 +62,11 @@ def run(kind, name, seed):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for kind in ("ani2xr", "ani2dr"):
         for nm, seed in (("rand_batch_ani2x", 21), ("water_pbc_ani2x", 22), ("small_ani2x", 23)):
-            run(kind, nm, seed)
+            if not only or kind in only:
+                run(kind, nm, seed)
+    for nm, seed in (("rand_batch_ani2x", 24), ("dense90_ani2x", 25)):   # (molecules: the repulsion has no cutoff)
+        if not only or "anir2s" in only:
+            run("anir2s", nm, seed)

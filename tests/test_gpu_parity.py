@@ -879,14 +879,15 @@ def test_d3_dispersion_matches_reference(dev, case):
             assert abs(fd - w[a_, b_].item()) < 2e-3 * max(abs(fd), 1e-4) + 2e-6, (a_, b_, fd, w[a_, b_].item())
 
 
-@pytest.mark.parametrize("kind", ["ani2xr", "ani2dr"])
-@pytest.mark.parametrize("case", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x"])
+@pytest.mark.parametrize("kind,case", [(k, c) for k in ("ani2xr", "ani2dr")
+                                       for c in ("rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x")] +
+                         [("anir2s", "rand_batch_ani2x"), ("anir2s", "dense90_ani2x")])
 def test_ani2xr_family_matches_reference(dev, kind, case):
     """The ANI-2xr / ANI-2dr architecture (models.py:252-325: simple_ani AEV with the smooth envelope, GELU networks
     without biases, xTB repulsion, D3 dispersion and B97-3c self energies for -2dr) against the reference's own builder in
     fp64 with the same seeded parameters (tests/golden/gen_golden_2xr.py): energies and forces through
     energies_and_forces and through autograd."""
-    from torchani_amd.models import ANI2dr, ANI2xr
+    from torchani_amd.models import ANI2dr, ANI2xr, ANIr2s
     from torchani_amd.weights import random_state_dict
 
     ref = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"x2r_{kind}_{case}.npz")))
@@ -894,7 +895,7 @@ def test_ani2xr_family_matches_reference(dev, kind, case):
     x = torch.from_numpy(ref["coords"]).to(dev)
     cell = torch.from_numpy(ref["cell"]).to(dev) if "cell" in ref else None
     pbc = tuple(bool(b) for b in ref["pbc"]) if "pbc" in ref else None
-    factory = ANI2xr if kind == "ani2xr" else ANI2dr
+    factory = {"ani2xr": ANI2xr, "ani2dr": ANI2dr, "anir2s": ANIr2s}[kind]   # (ANI-r2s: models.py:325-368)
     model = factory(state_dict=random_state_dict(kind, 8, int(ref["seed"])), device=dev, periodic_table_index=False,
                     neighborlist="batch" if cell is None or sp.shape[0] > 1 else "auto", row_capacity=256)
     assert [str(s) for s in ref["symbols"]] == list(model.symbols)

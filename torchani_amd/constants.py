@@ -20,6 +20,21 @@ GSAES_B973C_DEF2MTZVP: tp.Dict[str, float] = {
     "H": -0.506930113968, "C": -37.81441001258, "N": -54.556538547322, "O": -75.029181326588,
     "F": -99.688618987039, "S": -398.043159341582, "Cl": -460.082223445159,
 }
+# constants.py GSAES["ccsd(t)star-cbs"] (ANI-1ccx) and GSAES["r2scan3c{,_water,_chcl3,_ch3cn}-def2mtzvpp"] (ANI-r2s)
+GSAES_CCSDT_STAR_CBS: tp.Dict[str, float] = {
+    "H": -0.5, "C": -37.780724507998, "N": -54.515992576387, "O": -74.976148184192,
+    "F": -99.624864557142, "S": -397.646401989238, "Cl": -459.664237510771,
+}
+GSAES_R2SCAN3C: tp.Dict[tp.Optional[str], tp.Dict[str, float]] = {
+    None: {"H": -0.49727168567, "C": -37.832225901872, "N": -54.581004402346, "O": -75.057311846055,
+           "F": -99.726350798961, "S": -398.08097127572, "Cl": -460.113993263966},
+    "water": {"H": -0.494931329259, "C": -37.822388062823, "N": -54.581010824825, "O": -75.059169500763,
+              "F": -99.724273365141, "S": -398.082828534447, "Cl": -460.113806300624},
+    "chcl3": {"H": -0.496899744403, "C": -37.824548433511, "N": -54.57668102908, "O": -75.056821997619,
+              "F": -99.726146486046, "S": -398.085456915563, "Cl": -460.116926115444},
+    "ch3cn": {"H": -0.496684906369, "C": -37.824424218755, "N": -54.57657248763, "O": -75.058406925318,
+              "F": -99.725926489187, "S": -398.084853327694, "Cl": -460.116392553071},
+}
 GSAES_WB97X_631GD: tp.Dict[str, float] = {
     "C": -37.8338334,
     "Cl": -460.116700600,

@@ -13,6 +13,7 @@ Two ways to evaluate:
 """
 from __future__ import annotations
 
+import math
 import typing as tp
 import warnings
 
@@ -540,10 +541,12 @@ def _assemble(kind: str, n_members: int, neighborlist: str, row_capacity: int,
     nets: torch.nn.Module = Ensemble(members) if n_members > 1 else members[0]
     sae = [arch_gsaes(kind)[s] for s in symbols]
     model = ANI(symbols, aevc, nets, sae, periodic_table_index)
-    if kind in ("ani2xr", "ani2dr"):   # arch.py:1055-1066: repulsion up to the radial cutoff, dispersion up to 8 A
+    if kind in ("ani2xr", "ani2dr") or kind.startswith("anir2s"):
+        # arch.py:1055-1066: repulsion up to the radial cutoff (ANI-r2s: without a cutoff), dispersion up to 8 A
         from .potentials import RepulsionXTB, TwoBodyDispersionD3
 
-        model.add_pair_potential("repulsion_xtb", RepulsionXTB(symbols, cutoff=consts.Rcr, cutoff_fn="smooth"))
+        rep_cut = math.inf if kind.startswith("anir2s") else consts.Rcr
+        model.add_pair_potential("repulsion_xtb", RepulsionXTB(symbols, cutoff=rep_cut, cutoff_fn="smooth"))
         if kind == "ani2dr":
             model.add_pair_potential("dispersion_d3", TwoBodyDispersionD3.from_functional(
                 symbols, "b973c", cutoff=8.0, cutoff_fn="smooth"))
@@ -612,6 +615,39 @@ def ANI2dr(model_index: tp.Optional[int] = None, neighborlist: str = "auto", str
     of B97-3c / def2-mTZVP."""
     return _builtin("ani2dr", state_dict, seed, n_members, device, neighborlist, row_capacity,
                     periodic_table_index, "smooth", model_index, strategy, dtype)
+
+
+def ANIr2s(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",
+           periodic_table_index: bool = True, device=None, dtype=None, solvent: tp.Optional[str] = None,
+           state_dict=None, seed: tp.Optional[int] = None, n_members: int = 8, row_capacity: int = 128) -> ANI:
+    """ANI-r2s architecture (models.py:325-368; solvent = None, "water", "chcl3" or "ch3cn" picks the self energies):
+    the ANI-2x AEV with the smooth envelope, GELU networks without biases, xTB repulsion WITHOUT a cutoff (molecules
+    only: the repulsion rows hold every pair of a molecule, at most 256 neighbors per atom)."""
+    if solvent not in (None, "water", "chcl3", "ch3cn"):
+        raise ValueError(f"unknown solvent {solvent!r}")
+    return _builtin("anir2s" + ("" if solvent is None else "_" + solvent), state_dict, seed, n_members, device,
+                    neighborlist, row_capacity, periodic_table_index, "smooth", model_index, strategy, dtype)
+
+
+def ANIr2s_water(**kw) -> ANI:
+    return ANIr2s(solvent="water", **kw)
+
+
+def ANIr2s_chcl3(**kw) -> ANI:
+    return ANIr2s(solvent="chcl3", **kw)
+
+
+def ANIr2s_ch3cn(**kw) -> ANI:
+    return ANIr2s(solvent="ch3cn", **kw)
+
+
+def ANI1ccx(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",
+            periodic_table_index: bool = True, device=None, dtype=None, state_dict=None,
+            seed: tp.Optional[int] = None, n_members: int = 8, row_capacity: int = 128,
+            cutoff_fn: str = "cosine") -> ANI:
+    """ANI-1ccx architecture (models.py:128-162): ANI-1x networks and AEV, CCSD(T)*/CBS self energies."""
+    return _builtin("ani1ccx", state_dict, seed, n_members, device, neighborlist, row_capacity,
+                    periodic_table_index, cutoff_fn, model_index, strategy, dtype)
 
 
 def ANI1x(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",

@@ -13,7 +13,7 @@ import typing as tp
 
 import numpy as np
 
-from .constants import (GSAES_B973C_DEF2MTZVP, GSAES_WB97X_631GD, HIDDEN_DIMS_1X, HIDDEN_DIMS_2X, SYMBOLS_1X, SYMBOLS_2X,
+from .constants import (GSAES_B973C_DEF2MTZVP, GSAES_CCSDT_STAR_CBS, GSAES_R2SCAN3C, GSAES_WB97X_631GD, HIDDEN_DIMS_1X, HIDDEN_DIMS_2X, SYMBOLS_1X, SYMBOLS_2X,
                         SYMBOLS_2X_ZNUM_ORDER, aev_constants_1x, aev_constants_2x, aev_constants_simple)
 
 NN_PREFIX = "potentials.nnp.neural_networks."
@@ -25,19 +25,29 @@ def arch_spec(kind: str):
         return SYMBOLS_2X, aev_constants_2x(), HIDDEN_DIMS_2X
     if kind == "ani1x":
         return SYMBOLS_1X, aev_constants_1x(), HIDDEN_DIMS_1X
+    if kind == "ani1ccx":   # models.py:128-162: the ANI-1x architecture (trained to CCSD(T)*/CBS)
+        return SYMBOLS_1X, aev_constants_1x(), HIDDEN_DIMS_1X
     if kind in ("ani2xr", "ani2dr"):   # models.py:252-320: simple_ani with the ANI-2x widths, GELU, no biases
         return SYMBOLS_2X_ZNUM_ORDER, aev_constants_simple(), HIDDEN_DIMS_2X
+    if kind.startswith("anir2s"):   # models.py:325-368: the ANI-2x AEV with the smooth envelope, GELU, no biases
+        return SYMBOLS_2X, aev_constants_2x(cutoff_fn="smooth"), HIDDEN_DIMS_2X
     raise ValueError(f"Unknown architecture {kind!r}")
 
 
 def arch_networks(kind: str) -> tp.Tuple[str, bool]:
     """(activation, bias) of the atomic networks of a builtin architecture (arch.py:1010-1011 for the -r models)."""
-    return ("gelu", False) if kind in ("ani2xr", "ani2dr") else ("celu", True)
+    return ("gelu", False) if kind in ("ani2xr", "ani2dr") or kind.startswith("anir2s") else ("celu", True)
 
 
 def arch_gsaes(kind: str) -> tp.Dict[str, float]:
     """Self energies (ground-state atomic energies of the model's level of theory, arch.py:1053 / models.py)."""
-    return GSAES_B973C_DEF2MTZVP if kind == "ani2dr" else GSAES_WB97X_631GD
+    if kind == "ani2dr":
+        return GSAES_B973C_DEF2MTZVP
+    if kind == "ani1ccx":
+        return GSAES_CCSDT_STAR_CBS
+    if kind.startswith("anir2s"):   # "anir2s", "anir2s_water", ...
+        return GSAES_R2SCAN3C[kind[7:] or None]
+    return GSAES_WB97X_631GD
 
 
 def random_state_dict(kind: str = "ani2x", n_members: int = 8, seed: int = 0,
