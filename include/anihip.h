@@ -372,7 +372,8 @@ int anihip_pair_xtb_repulsion(void *stream, int64_t n_atoms, int64_t lo, int64_t
  *   CN_i   = sum_j 1 / (1 + exp(-16 (4/3 (Rcov_a + Rcov_b) / d_ij - 1)))                     (all neighbors of the row)
  *   C6_ij  = sum_ref c6ref L / sum_ref L,  L = exp(-4 ((CN_i - cn_a)^2 + (CN_j - cn_b)^2)) over the references with c6ref > 0
  *   e_ij   = -(s6 C6 / (d^6 + R^6) + s8 3 C6 q_a q_b / (d^8 + R^8)) fc(r_ij),  R = a1 sqrt(3 q_a q_b) + a2
- * c6_table: device float[8][8][25][4] = {c6ref, cn_a, cn_b, 0} indexed [species_i][species_j][5 ref_i + ref_j].
+ * c6_table: device float[8][8][25][4] = {c6ref, cn_a, cn_b, -} per [species_i][species_j]: the reference pairs with
+ * c6ref > 0 first (any order), their number in the 4th float of entry 0 (missing references are -1 in Grimme's table).
  * The rows must hold ALL atoms 0 .. n_atoms (coordination numbers of every neighbor are needed) and be symmetric;
  * lo / hi select the central atoms whose energies / gradient rows are accumulated (atomic_e[i] += sum_j e_ij / 2,
  * grad_coords[i] += d E / d r_i, both complete for i in lo .. hi: nothing is pushed to other atoms, no atomics,

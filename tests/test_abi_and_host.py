@@ -402,7 +402,8 @@ def test_d3_reference_data_and_class():
     assert math.isclose(float(pot.covalent_radii[0]), 0.32 * 1.8897261258369282, rel_tol=1e-6)
     t = pot.table(torch.device("cpu"))
     assert t.shape == (8, 8, 25, 4) and float(t[0, 3, 0, 0]) == float(pot.precalc_coeff6[0, 3, 0, 0])
-    assert float(t[5, 5, 0, 0]) == -1.0   # unused element slots: no references
+    assert int(t[0, 0, 0, 3]) == 4 and int(t[0, 3, 0, 3]) == 6 and int(t[3, 3, 0, 3]) == 9   # H-H, H-O, O-O references
+    assert float(t[5, 5, 0, 3]) == 0.0   # unused element slots: no references
     with pytest.raises(ValueError):
         TwoBodyDispersionD3.from_functional(("H", "Xe"), "wb97x")
     with pytest.raises(ValueError):

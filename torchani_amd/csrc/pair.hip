@@ -190,22 +190,21 @@ __global__ __launch_bounds__(256) void k_d3_pair(int64_t n, int64_t lo, int64_t 
             const float cnj = cn[w & IDX_MASK];
             // C6 and d C6 / d CN_i from the 25 reference pairs
             const float4 *t = tab + (si * 8 + sj) * 25;
+            const int nv = (int)t[0].w;   // the pair's references with c6ref > 0 come first (H-H: 4 of the 25)
             // (the weights are formed relative to the largest one: coordination numbers far from every reference --
             // dense random geometries -- give weights below the fp32 range, which the reference's fp64 still resolves;
             // its 1e-35 guards, dftd3.py:322-330, are applied to the rescaled sums)
             float amin = 3.0e38f;
-#pragma unroll 5
-            for (int q = 0; q < 25; ++q) {
+            for (int q = 0; q < nv; ++q) {
                 const float4 ref = t[q];
                 const float da = cni - ref.y, db = cnj - ref.z;
-                amin = fminf(amin, ref.x > 0.f ? D3_K3 * (da * da + db * db) : 3.0e38f);
+                amin = fminf(amin, D3_K3 * (da * da + db * db));
             }
             float W = 0.f, Z = 0.f, dW = 0.f, dZ = 0.f;
-#pragma unroll 5
-            for (int q = 0; q < 25; ++q) {
+            for (int q = 0; q < nv; ++q) {
                 const float4 ref = t[q];
                 const float da = cni - ref.y, db = cnj - ref.z;
-                const float L = ref.x > 0.f ? __expf(amin - D3_K3 * (da * da + db * db)) : 0.f;
+                const float L = __expf(amin - D3_K3 * (da * da + db * db));
                 W += L; Z += ref.x * L;
                 dW += L * da; dZ += ref.x * L * da;
             }

@@ -202,14 +202,19 @@ class TwoBodyDispersionD3(torch.nn.Module):
         return cls(symbols, s6=s6, s8=s8, damp_a1=a1, damp_a2=a2, cutoff_fn=cutoff_fn, cutoff=cutoff)
 
     def table(self, device: torch.device) -> Tensor:
-        """[8, 8, 25, 4] device table {c6 ref, cn_a ref, cn_b ref, 0} (include/anihip.h)."""
+        """[8, 8, 25, 4] device table {c6 ref, cn_a ref, cn_b ref, -}: valid references first, their count in [.., 0, 3]
+        (include/anihip.h)."""
         if self._table is None or self._table.device != device:
             S = len(self.symbols)
             t = torch.zeros((8, 8, 25, 4), dtype=torch.float32)
-            t[..., 0] = -1.0   # (missing references are -1 in the reference table: skipped)
-            t[:S, :S, :, 0] = self.precalc_coeff6.cpu().reshape(S, S, 25)
-            t[:S, :S, :, 1] = self.precalc_coordnums_a.cpu().reshape(S, S, 25)
-            t[:S, :S, :, 2] = self.precalc_coordnums_b.cpu().reshape(S, S, 25)
+            c6 = self.precalc_coeff6.cpu().reshape(S, S, 25)
+            ca = self.precalc_coordnums_a.cpu().reshape(S, S, 25)
+            cb = self.precalc_coordnums_b.cpu().reshape(S, S, 25)
+            for a in range(S):
+                for b in range(S):
+                    ok = torch.nonzero(c6[a, b] > 0.0).reshape(-1)   # (missing references are -1: dftd3.py:318-321)
+                    t[a, b, :len(ok), 0], t[a, b, :len(ok), 1], t[a, b, :len(ok), 2] = c6[a, b, ok], ca[a, b, ok], cb[a, b, ok]
+                    t[a, b, 0, 3] = float(len(ok))
             self._table = t.to(device).contiguous()
         return self._table
 
