@@ -793,6 +793,13 @@ def test_xtb_repulsion_matches_reference(dev, case):
     e = model((sp, xs), cell, pbc_t).energies
     (gx,) = torch.autograd.grad(e.sum(), xs)
     assert np.abs(-gx.cpu().numpy() - f_ref).max() < F_TOL + 5e-6 * fscale
+    # per-atom energies with the pair halves (core.py:195-198), under no_grad
+    with torch.no_grad():
+        ea_model = model((sp, x), cell, pbc_t, atomic=True).energies
+    ea_ref = torch.from_numpy(g["energies"])   # molecular reference: compare the sums, and the pair part per atom
+    assert np.abs(ea_model.double().sum(dim=1).cpu().numpy() - e_ref).max() < 1e-5 * max(1.0, np.abs(e_ref).max() * 1e-2) + 2e-6 * escale * sp.shape[1] + 2e-7 * np.abs(e_ref).max()
+    with pytest.raises(NotImplementedError):
+        model((sp, x.clone().requires_grad_(True)), cell, pbc_t, atomic=True)
     # switched off again (arch.py:136-142 set_enabled)
     model.set_enabled("repulsion_xtb", False)
     out0 = model.energies_and_forces(sp, x, cell, pbc)

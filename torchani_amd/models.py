@@ -102,13 +102,21 @@ class ANI(torch.nn.Module):
         for name, pot in self.potentials.items():   # pair potentials on the same neighbor rows (arch.py:329-346)
             if name == "nnp" or not pot._enabled:
                 continue
-            if atomic:
-                raise NotImplementedError("atomic=True with pair potentials: use energies_and_forces")
             species32 = elem_idxs.to(torch.int32).contiguous()
             nbrs = self.aev_computer.last_neighbors() if self.potentials["nnp"]._enabled else None
-            if nbrs is None or pot.cutoff > self.aev_computer.radial.cutoff + 1e-6:
+            if nbrs is None or pot.cutoff > self.aev_computer.radial.cutoff + 1e-6 or getattr(pot, "needs_all_rows", False):
                 nbrs = self._pair_rows(pot, species32, coords, cell, pbc)
-            e_pair = pot.compute_from_rows(species32, coords, nbrs)
+            if atomic:
+                # per-atom halves of the pair energies (core.py:195-198).  The kernels return the gradient of the SUM
+                # only, so this output does not carry one
+                if coords.requires_grad and torch.is_grad_enabled():
+                    raise NotImplementedError("atomic=True with pair potentials is not differentiable here: "
+                                              "use energies_and_forces, or evaluate under torch.no_grad()")
+                a = torch.zeros(species32.numel(), dtype=torch.float32, device=coords.device)
+                pot.accumulate(species32, nbrs, a, None)
+                e_pair = a.view(species32.shape)
+            else:
+                e_pair = pot.compute_from_rows(species32, coords, nbrs)
             energies = energies + (e_pair.unsqueeze(0) if ensemble_values else e_pair).to(energies.dtype)
         if self.energy_shifter._enabled:
             energies = energies + self.energy_shifter(elem_idxs, atomic=atomic)
