@@ -367,6 +367,25 @@ int anihip_pair_xtb_repulsion(void *stream, int64_t n_atoms, int64_t lo, int64_t
                               const uint32_t *meta, const float *ent, const float *pair_table, float cutoff,
                               int32_t cutoff_kind, int32_t flags, float *atomic_e, float *grad_coords, double *virial);
 
+/* The other closed-form pair potentials of torchani.potentials on the same rows, same outputs and flags; pair_table:
+ * device float[8][8][4] per [species_i][species_j]; distances d in Bohr, r in Angstrom (r clamped to >= 1e-7 A unless
+ * ANIHIP_PAIR_NO_CLAMP, core.py:138-139):
+ *   ANIHIP_PAIR_XTB      {y_ab, sqrt(alpha_ab), k_ab, -}        y / d exp(-sqrt(alpha) d^k)              (xtb.py:17-77)
+ *   ANIHIP_PAIR_ZBL      {Za Zb, (Za^kz + Zb^kz) / k, -, -}     Za Zb / d sum_i c_i exp(-b_i d s)        (zbl.py:10-81)
+ *                        extra: float[8] = c_0..3, b_0..3 (host memory)
+ *   ANIHIP_PAIR_LJ       {4 eps_ab, sigma_ab, c12, c6}          4 eps (c12 x^12 + c6 x^6), x = sigma / r (lj.py:42-108)
+ *   ANIHIP_PAIR_COULOMB  {q_a q_b / dielectric, 1 / eta_ab, -, -}   qq / sqrt(d^2 + 1 / eta^2)   (fixed_coulomb.py:8-75;
+ *                        1 / eta = 0: FixedCoulomb, clamped; FixedMNOK: 2 / (eta_a + eta_b), ANIHIP_PAIR_NO_CLAMP) */
+#define ANIHIP_PAIR_XTB 0
+#define ANIHIP_PAIR_ZBL 1
+#define ANIHIP_PAIR_LJ 2
+#define ANIHIP_PAIR_COULOMB 3
+#define ANIHIP_PAIR_NO_CLAMP 2
+int anihip_pair_analytic(void *stream, int32_t kind, int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                         const uint32_t *meta, const float *ent, const float *pair_table, const float *extra,
+                         float cutoff, int32_t cutoff_kind, int32_t flags, float *atomic_e, float *grad_coords,
+                         double *virial);
+
 /* DFT-D3(BJ) two-body dispersion (potentials/dftd3.py:113-330 TwoBodyDispersionD3, damping :44-110 BeckeJohnsonDamp;
  * envelope and per-atom halves as above), distances in Bohr:
  *   CN_i   = sum_j 1 / (1 + exp(-16 (4/3 (Rcov_a + Rcov_b) / d_ij - 1)))                     (all neighbors of the row)

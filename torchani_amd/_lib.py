@@ -29,6 +29,8 @@ ST_ENTRY_OVERFLOW, ST_ROW_OVERFLOW, ST_GRID_OVERFLOW = 1, 2, 4
 MLP_FP32, MLP_F16X3 = 0, 1
 BWD_SYMMETRIC, BWD_FIXED_POINT = 1, 2   # flags of anihip_aev_backward
 PAIR_PUSH = 1
+PAIR_NO_CLAMP = 2
+PAIR_XTB, PAIR_ZBL, PAIR_LJ, PAIR_COULOMB = 0, 1, 2, 3
 ACT_CELU, ACT_GELU = 0, 1
 # anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*)
 MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_FUSED_ROWS32, MLP_FLAG_D0_ROWS = \
@@ -172,6 +174,8 @@ def lib() -> C.CDLL:
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     L.anihip_pair_xtb_repulsion.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, C.c_float, i32, i32, vp, vp, vp]
     L.anihip_pair_xtb_repulsion.restype = C.c_int
+    L.anihip_pair_analytic.argtypes = [vp, i32, i64, i64, i64, vp, vp, vp, vp, vp, C.c_float, i32, i32, vp, vp, vp]
+    L.anihip_pair_analytic.restype = C.c_int
     L.anihip_pair_d3.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, C.POINTER(D3Params), C.c_float, i32, vp, vp, vp, vp, vp]
     L.anihip_pair_d3.restype = C.c_int
     for name in ("anihip_aev_table_pack", "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_from_half",
@@ -192,7 +196,7 @@ EXPORTED_SYMBOLS = [
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
     "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
     "anihip_mlp_tangent_workspace_bytes", "anihip_mlp_tangent_weight_grads", "anihip_pair_xtb_repulsion",
-    "anihip_pair_d3",
+    "anihip_pair_d3", "anihip_pair_analytic",
 ]
 
 

@@ -1,6 +1,7 @@
-// Pair potentials evaluated on the neighbor rows of nbr.hip: the xTB repulsion term of ANI-2xr / ANI-2dr
-// (reference: torchani/potentials/xtb.py:17-77 RepulsionXTB.pair_energies, with the cutoff envelope and the half-per-atom
-// bookkeeping of potentials/core.py:155-207).
+// Pair potentials evaluated on the neighbor rows of nbr.hip (cutoff envelope and half-per-atom bookkeeping of
+// potentials/core.py:155-207): the analytic family k_pair<KIND> -- xTB repulsion (potentials/xtb.py:17-77), ZBL screened
+// nuclear repulsion (zbl.py:10-81), Lennard-Jones 12 / 6 terms (lj.py:42-108), fixed-charge Coulomb with optional MNOK
+// damping (fixed_coulomb.py:8-75) -- and DFT-D3(BJ) dispersion below.
 //
 // One wave per central atom, lane = neighbor.  The rows are a FULL symmetric list, so atom i finishes everything that
 // concerns itself from its own row: atomic energy sum_j e_ij / 2 (core.py:195-198) and gradient
@@ -12,11 +13,51 @@ namespace anihip {
 
 constexpr float A2B = 1.8897261258369282f;   // torchani/units.py:41
 
-__global__ __launch_bounds__(256) void k_pair_xtb(int64_t lo, int64_t hi, const int32_t *__restrict__ species,
-                                                  const uint32_t *__restrict__ meta, const float4 *__restrict__ ent,
-                                                  const float *__restrict__ tab /* [8][8][4]: y, sqrt(alpha), k, - */,
-                                                  float cutoff, int smooth, int push, float *__restrict__ atomic_e,
-                                                  float *__restrict__ grad_coords, double *__restrict__ virial)
+struct PairExtra {
+    float v[8];   // ZBL: screening coefficients c_0..3 and exponents b_0..3
+};
+
+// bare pair energy (no envelope) and its derivative with respect to r [Angstrom]; p = table entry of the species pair
+template <int KIND>
+__device__ __forceinline__ void pair_eval(const float4 p, const PairExtra &x, float r, float &base, float &dbase)
+{
+    if constexpr (KIND == ANIHIP_PAIR_XTB) {            // {y_ab, sqrt(alpha_ab), k_ab}: y / d exp(-sqrt(alpha) d^k), d [Bohr]
+        const float rb = r * A2B;
+        const float pw = __builtin_amdgcn_exp2f(p.z * __builtin_amdgcn_logf(rb));   // rb^k
+        const float ex = __expf(-p.y * pw);
+        base = p.x / rb * ex;
+        dbase = base * (-1.0f / rb - p.y * p.z * pw / rb) * A2B;
+    } else if constexpr (KIND == ANIHIP_PAIR_ZBL) {     // {Za Zb, (Za^kz + Zb^kz) / k}: Za Zb / d sum_i c_i exp(-b_i d s), d [Bohr]
+        const float rb = r * A2B, xr = rb * p.y;
+        float phi = 0.f, dphi = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = x.v[i] * __expf(-x.v[4 + i] * xr);
+            phi += t;
+            dphi -= x.v[4 + i] * t;
+        }
+        const float cl = p.x / rb;
+        base = cl * phi;
+        dbase = (cl * dphi * p.y - cl / rb * phi) * A2B;
+    } else if constexpr (KIND == ANIHIP_PAIR_LJ) {      // {4 eps_ab, sigma_ab, c12, c6}: 4 eps (c12 x^12 + c6 x^6), x = sigma / r
+        const float ir = 1.0f / r, xs = p.y * ir, x2 = xs * xs, x6 = x2 * x2 * x2, x12 = x6 * x6;
+        base = p.x * (p.z * x12 + p.w * x6);
+        dbase = -p.x * (12.0f * p.z * x12 + 6.0f * p.w * x6) * ir;
+    } else {                                            // Coulomb {q_a q_b / dielectric, 1 / eta_ab}: qq / sqrt(d^2 + 1 / eta^2), d [Bohr]
+        const float rb = r * A2B;
+        const float is = __builtin_amdgcn_rsqf(rb * rb + p.y * p.y);
+        base = p.x * is;
+        dbase = -p.x * rb * is * is * is * A2B;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_pair(int64_t lo, int64_t hi, const int32_t *__restrict__ species,
+                                              const uint32_t *__restrict__ meta, const float4 *__restrict__ ent,
+                                              const float *__restrict__ tab /* [8][8][4] per species pair */,
+                                              PairExtra extra, float cutoff, int smooth, int push, int clamp_r,
+                                              float *__restrict__ atomic_e, float *__restrict__ grad_coords,
+                                              double *__restrict__ virial)
 {
     const int lane = lane_id();
     const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -36,7 +77,7 @@ __global__ __launch_bounds__(256) void k_pair_xtb(int64_t lo, int64_t hi, const 
             const int sj = (int)(w >> 28);
             const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
             const float inv = __builtin_amdgcn_rsqf(r2);
-            const float r = fmaxf(r2 * inv, 1e-7f);   // (core.py:138-139 clamp)
+            const float r = clamp_r ? fmaxf(r2 * inv, 1e-7f) : r2 * inv;   // (core.py:138-139 clamp)
             if (r > cutoff) continue;
             float fc, dfc;   // envelope and its derivative (cutoffs.py:74-101)
             if (smooth) {
@@ -49,13 +90,9 @@ __global__ __launch_bounds__(256) void k_pair_xtb(int64_t lo, int64_t hi, const 
                 dfc = -0.5f * pi_rc * __builtin_amdgcn_sinf(r * rev_rc);
             }
             const float4 p = reinterpret_cast<const float4 *>(tab)[si * 8 + sj];
-            const float rb = r * A2B;                                   // Bohr
-            const float pw = __builtin_amdgcn_exp2f(p.z * __builtin_amdgcn_logf(rb));   // rb^k
-            const float ex = __expf(-p.y * pw);
-            const float base = p.x / rb * ex;                           // y_ab / d * exp(-sqrt(alpha_ab) d^k)
+            float base, dbase;
+            pair_eval<KIND>(p, extra, r, base, dbase);
             const float eij = base * fc;
-            // d/dr [Angstrom]: base' = base (-1/rb - sqrt(alpha) k rb^(k-1)) A2B
-            const float dbase = base * (-1.0f / rb - p.y * p.z * pw / rb) * A2B;
             const float de = dbase * fc + base * dfc;
             e += 0.5f * eij;
             // d r_ij / d r_i = -u_ij, u = d / r;  the pair contributes e_ij / 2 to BOTH atoms: gradient on i = -de u
@@ -320,23 +357,46 @@ __global__ __launch_bounds__(256) void k_d3_cngrad(int64_t lo, int64_t hi, const
 
 using namespace anihip;
 
-extern "C" int anihip_pair_xtb_repulsion(void *stream, int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
-                                         const uint32_t *meta, const float *ent, const float *pair_table, float cutoff,
-                                         int32_t cutoff_kind, int32_t flags, float *atomic_e, float *grad_coords,
-                                         double *virial)
+extern "C" int anihip_pair_analytic(void *stream, int32_t kind, int64_t n_atoms, int64_t lo, int64_t hi,
+                                    const int32_t *species, const uint32_t *meta, const float *ent,
+                                    const float *pair_table, const float *extra, float cutoff, int32_t cutoff_kind,
+                                    int32_t flags, float *atomic_e, float *grad_coords, double *virial)
 {
     ANIHIP_REQUIRE(species && meta && ent && pair_table, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     ANIHIP_REQUIRE(cutoff > 0.f, "cutoff must be positive (the rows hold pairs up to their own radial cutoff)");
     ANIHIP_REQUIRE(cutoff_kind == ANIHIP_CUTOFF_COSINE || cutoff_kind == ANIHIP_CUTOFF_SMOOTH, "unknown cutoff_kind");
+    ANIHIP_REQUIRE(kind >= ANIHIP_PAIR_XTB && kind <= ANIHIP_PAIR_COULOMB, "unknown pair potential kind");
+    ANIHIP_REQUIRE(kind != ANIHIP_PAIR_ZBL || extra, "ZBL needs its 4 + 4 screening constants");
     if (hi == lo) return 0;
     int64_t blocks = (hi - lo + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(k_pair_xtb, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lo, hi, species, meta,
-                       (const float4 *)ent, pair_table, cutoff, cutoff_kind == ANIHIP_CUTOFF_SMOOTH ? 1 : 0,
-                       (flags & ANIHIP_PAIR_PUSH) ? 1 : 0, atomic_e, grad_coords, virial);
+    PairExtra x{};
+    if (extra)
+        for (int k = 0; k < 8; ++k) x.v[k] = extra[k];
+    const int smooth = cutoff_kind == ANIHIP_CUTOFF_SMOOTH ? 1 : 0, push = (flags & ANIHIP_PAIR_PUSH) ? 1 : 0;
+    const int clamp_r = (flags & ANIHIP_PAIR_NO_CLAMP) ? 0 : 1;
+#define ANIHIP_LAUNCH_PAIR(K)                                                                                          \
+    hipLaunchKernelGGL((k_pair<K>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, lo, hi, species, meta,   \
+                       (const float4 *)ent, pair_table, x, cutoff, smooth, push, clamp_r, atomic_e, grad_coords, virial)
+    switch (kind) {
+        case ANIHIP_PAIR_XTB: ANIHIP_LAUNCH_PAIR(ANIHIP_PAIR_XTB); break;
+        case ANIHIP_PAIR_ZBL: ANIHIP_LAUNCH_PAIR(ANIHIP_PAIR_ZBL); break;
+        case ANIHIP_PAIR_LJ: ANIHIP_LAUNCH_PAIR(ANIHIP_PAIR_LJ); break;
+        default: ANIHIP_LAUNCH_PAIR(ANIHIP_PAIR_COULOMB); break;
+    }
+#undef ANIHIP_LAUNCH_PAIR
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+extern "C" int anihip_pair_xtb_repulsion(void *stream, int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                                         const uint32_t *meta, const float *ent, const float *pair_table, float cutoff,
+                                         int32_t cutoff_kind, int32_t flags, float *atomic_e, float *grad_coords,
+                                         double *virial)
+{
+    return anihip_pair_analytic(stream, ANIHIP_PAIR_XTB, n_atoms, lo, hi, species, meta, ent, pair_table, nullptr, cutoff,
+                                cutoff_kind, flags, atomic_e, grad_coords, virial);
 }
 
 extern "C" int anihip_pair_d3(void *stream, int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,

@@ -1,5 +1,6 @@
 """Pair potentials on the engine's neighbor rows: the xTB repulsion and DFT-D3(BJ) dispersion terms of the reference's
-ANI-2xr / ANI-2dr models.
+ANI-2xr / ANI-2dr models, and the other closed-form pair potentials of torchani.potentials (RepulsionZBL, LennardJones /
+RepulsionLJ / DispersionLJ, FixedCoulomb, FixedMNOK).
 
 Mirrors torchani/potentials/xtb.py:17-77 (RepulsionXTB: constructor, buffers ``y_ab`` / ``sqrt_alpha_ab`` / ``k_rep_ab``,
 pair energies), torchani/potentials/dftd3.py:44-330 (BeckeJohnsonDamp, TwoBodyDispersionD3: constructor,
@@ -59,46 +60,49 @@ class _PairEnergy(torch.autograd.Function):
         return (grad.view(Cn, A, 3) * g.view(Cn, 1, 1).to(grad.dtype)).to(ctx.dtype), None, None, None
 
 
-class RepulsionXTB(torch.nn.Module):
-    """xTB repulsion pair potential (potentials/xtb.py:17-77).  ``krep_hydrogen`` applies to H-H pairs only."""
+class _AnalyticPair(torch.nn.Module):
+    """Shared part of the closed-form pair potentials (core.py:103-207 BasePairPotential): a [8, 8, 4] device table of
+    per-element-pair constants evaluated by anihip_pair_analytic (kind = ANIHIP_PAIR_*)."""
 
-    def __init__(self, symbols: tp.Sequence[str], krep_hydrogen: float = 1.0, krep: float = 1.5,
-                 alpha: tp.Sequence[float] = (), yeff: tp.Sequence[float] = (), *, cutoff: float = math.inf,
-                 cutoff_fn: str = "smooth") -> None:
-        super().__init__()
+    kind = _lib.PAIR_XTB
+    clamp_distances = True   # (core.py:138-139; FixedMNOK does not clamp)
+
+    def _init_common(self, symbols: tp.Sequence[str], cutoff: float, cutoff_fn: str) -> None:
         if cutoff_fn not in _lib.CUTOFF_KINDS:
             raise ValueError(f"Unsupported cutoff function {cutoff_fn!r}: the HIP kernels have {sorted(_lib.CUTOFF_KINDS)}")
         if len(symbols) > 7:
             raise ValueError("at most 7 elements (the species field of a neighbor row)")
         self.symbols = tuple(symbols)
-        for name, seq in (("alpha", alpha), ("yeff", yeff)):
-            if seq and len(seq) != len(symbols):
-                raise ValueError(f"len({name}), if provided, must match len(symbols)")   # core.py _validate_elem_seq
-        missing = [s for s in symbols if s not in XTB_REPULSION and not (alpha and yeff)]
-        if missing:
-            raise ValueError(f"no xTB repulsion constants for {missing}: pass alpha and yeff")
-        a = torch.tensor(list(alpha) if alpha else [XTB_REPULSION[s][0] for s in symbols], dtype=torch.float32)
-        y = torch.tensor(list(yeff) if yeff else [XTB_REPULSION[s][1] for s in symbols], dtype=torch.float32)
-        k = torch.full((len(symbols), len(symbols)), float(krep))
-        if "H" in self.symbols:
-            h = self.symbols.index("H")
-            k[h, h] = float(krep_hydrogen)
         self.register_buffer("atomic_numbers", torch.tensor([ATOMIC_NUMBER.get(s, 0) for s in symbols]))
-        self.register_buffer("y_ab", torch.outer(y, y))
-        self.register_buffer("sqrt_alpha_ab", torch.outer(a, a).sqrt())
-        self.register_buffer("k_rep_ab", k)
         self.cutoff = float(cutoff)
         self.cutoff_fn = cutoff_fn
         self._enabled = True
         self._table: tp.Optional[Tensor] = None
         self._own_engine: tp.Optional[AevEngine] = None
 
+    def _elem_seq(self, name: str, seq: tp.Sequence[float], default: tp.Optional[tp.Callable[[str], float]] = None
+                  ) -> tp.List[float]:
+        # _core.py:32-54 _validate_elem_seq
+        if not seq and default is not None:
+            seq = [float(default(s)) for s in self.symbols]
+        if not all(isinstance(v, float) for v in seq):
+            raise ValueError(f"Some values in {name} are not floats")
+        if len(seq) != len(self.symbols):
+            raise ValueError(f"{name} and symbols should have the same len")
+        return list(seq)
+
+    def _pair_constants(self) -> Tensor:
+        """[S, S, 4] host tensor of the kernel's per-pair constants."""
+        raise NotImplementedError
+
+    def _extra(self) -> tp.Optional[np.ndarray]:
+        return None
+
     def table(self, device: torch.device) -> Tensor:
-        """[8, 8, 4] device table {y_ab, sqrt(alpha_ab), k_ab, 0} (include/anihip.h)."""
         if self._table is None or self._table.device != device:
             S = len(self.symbols)
             t = torch.zeros((8, 8, 4), dtype=torch.float32)
-            t[:S, :S, 0], t[:S, :S, 1], t[:S, :S, 2] = self.y_ab.cpu(), self.sqrt_alpha_ab.cpu(), self.k_rep_ab.cpu()
+            t[:S, :S] = self._pair_constants().to(torch.float32)
             self._table = t.to(device).contiguous()
         return self._table
 
@@ -116,11 +120,12 @@ class RepulsionXTB(torch.nn.Module):
         cut = self.cutoff if cutoff is None else cutoff
         if math.isinf(cut):
             cut = 1e30   # the rows decide (with the envelope == 1 up to rounding at finite distances)
-        flags = 0 if nbrs.symmetric else _lib.PAIR_PUSH
-        _lib.check(_lib.lib().anihip_pair_xtb_repulsion(
-            _stream(), species32.numel(), nbrs.lo, nbrs.hi, _ptr(species32), _ptr(nbrs.meta), _ptr(nbrs.ent),
-            _ptr(self.table(species32.device)), float(cut), _lib.CUTOFF_KINDS[self.cutoff_fn], flags, _ptr(atomic_e),
-            _ptr(grad_coords), _ptr(virial)))
+        flags = (0 if nbrs.symmetric else _lib.PAIR_PUSH) | (0 if self.clamp_distances else _lib.PAIR_NO_CLAMP)
+        ex = self._extra()
+        _lib.check(_lib.lib().anihip_pair_analytic(
+            _stream(), self.kind, species32.numel(), nbrs.lo, nbrs.hi, _ptr(species32), _ptr(nbrs.meta), _ptr(nbrs.ent),
+            _ptr(self.table(species32.device)), None if ex is None else ex.ctypes.data, float(cut),
+            _lib.CUTOFF_KINDS[self.cutoff_fn], flags, _ptr(atomic_e), _ptr(grad_coords), _ptr(virial)))
 
     def compute_from_rows(self, species32: Tensor, coords: Tensor, nbrs: NeighborRows) -> Tensor:
         """Molecular energies [C] (float64), differentiable with respect to coords."""
@@ -128,6 +133,153 @@ class RepulsionXTB(torch.nn.Module):
 
     def extra_repr(self) -> str:
         return f"symbols={self.symbols}, cutoff={self.cutoff}, cutoff_fn={self.cutoff_fn}"
+
+
+class RepulsionXTB(_AnalyticPair):
+    """xTB repulsion pair potential (potentials/xtb.py:17-77).  ``krep_hydrogen`` applies to H-H pairs only."""
+
+    kind = _lib.PAIR_XTB
+
+    def __init__(self, symbols: tp.Sequence[str], krep_hydrogen: float = 1.0, krep: float = 1.5,
+                 alpha: tp.Sequence[float] = (), yeff: tp.Sequence[float] = (), *, cutoff: float = math.inf,
+                 cutoff_fn: str = "smooth") -> None:
+        super().__init__()
+        self._init_common(symbols, cutoff, cutoff_fn)
+        for name, seq in (("alpha", alpha), ("yeff", yeff)):
+            if seq and len(seq) != len(symbols):
+                raise ValueError(f"len({name}), if provided, must match len(symbols)")   # core.py _validate_elem_seq
+        missing = [s for s in symbols if s not in XTB_REPULSION and not (alpha and yeff)]
+        if missing:
+            raise ValueError(f"no xTB repulsion constants for {missing}: pass alpha and yeff")
+        a = torch.tensor(list(alpha) if alpha else [XTB_REPULSION[s][0] for s in symbols], dtype=torch.float32)
+        y = torch.tensor(list(yeff) if yeff else [XTB_REPULSION[s][1] for s in symbols], dtype=torch.float32)
+        k = torch.full((len(symbols), len(symbols)), float(krep))
+        if "H" in self.symbols:
+            h = self.symbols.index("H")
+            k[h, h] = float(krep_hydrogen)
+        self.register_buffer("y_ab", torch.outer(y, y))
+        self.register_buffer("sqrt_alpha_ab", torch.outer(a, a).sqrt())
+        self.register_buffer("k_rep_ab", k)
+
+    def _pair_constants(self) -> Tensor:
+        z = torch.zeros_like(self.y_ab.cpu())
+        return torch.stack([self.y_ab.cpu(), self.sqrt_alpha_ab.cpu(), self.k_rep_ab.cpu(), z], dim=-1)
+
+
+class RepulsionZBL(_AnalyticPair):
+    """Ziegler-Biersack-Littmark screened nuclear repulsion (potentials/zbl.py:10-81)."""
+
+    kind = _lib.PAIR_ZBL
+
+    def __init__(self, symbols: tp.Sequence[str], k: float = 0.8853, screen_coeffs: tp.Sequence[float] = (),
+                 screen_exponents: tp.Sequence[float] = (), eff_exponent: float = 0.23,
+                 eff_atomic_nums: tp.Sequence[float] = (), *, cutoff: float = math.inf, cutoff_fn: str = "smooth") -> None:
+        super().__init__()
+        self._init_common(symbols, cutoff, cutoff_fn)
+        z = self._elem_seq("eff_atomic_nums", eff_atomic_nums, lambda s: float(ATOMIC_NUMBER[s]))
+        if len(screen_exponents) != len(screen_coeffs):
+            raise ValueError("screen_exponents and screen_coeffs must have the same len")
+        c = list(screen_coeffs) if screen_coeffs else [0.18175, 0.50986, 0.28022, 0.02817]
+        b = list(screen_exponents) if screen_exponents else [3.19980, 0.94229, 0.40290, 0.20162]
+        if not math.isclose(sum(c), 1.0):
+            raise ValueError("Screen coeffs must sum to 1")
+        if len(c) > 4:
+            raise ValueError("the kernel holds up to 4 screening terms")
+        self.register_buffer("_eff_atomic_nums", torch.tensor(z), persistent=False)
+        self._k, self._kz = float(k), float(eff_exponent)
+        self._screen = np.asarray(c + [0.0] * (4 - len(c)) + b + [0.0] * (4 - len(b)), dtype=np.float32)
+
+    def _pair_constants(self) -> Tensor:
+        z = self._eff_atomic_nums.cpu().to(torch.float64)
+        zz = torch.outer(z, z)
+        s = (z.pow(self._kz).unsqueeze(1) + z.pow(self._kz).unsqueeze(0)) / self._k
+        o = torch.zeros_like(zz)
+        return torch.stack([zz, s, o, o], dim=-1)
+
+    def _extra(self) -> np.ndarray:
+        return self._screen
+
+
+_LJ_EPS = 0.1 / 627.5094738898777   # Hartree (lj.py:14: 0.1 kcal/mol)
+_LJ_SIGMA = 1.5                      # Angstrom
+
+
+class _LJ(_AnalyticPair):
+    """Lennard-Jones terms with Lorentz-Berthelot combination (potentials/lj.py:42-108): sigma in Angstrom, eps in
+    Hartree, defaults sigma = 1.5, eps = 0.1 kcal/mol for every element."""
+
+    kind = _lib.PAIR_LJ
+    c12, c6 = 1.0, -1.0
+
+    def __init__(self, symbols: tp.Sequence[str], eps: tp.Sequence[float] = (), sigma: tp.Sequence[float] = (), *,
+                 cutoff: float = math.inf, cutoff_fn: str = "smooth") -> None:
+        super().__init__()
+        self._init_common(symbols, cutoff, cutoff_fn)
+        self.register_buffer("_eps", torch.tensor(self._elem_seq("eps", eps, lambda s: _LJ_EPS)), persistent=False)
+        self.register_buffer("_sigma", torch.tensor(self._elem_seq("sigma", sigma, lambda s: _LJ_SIGMA)), persistent=False)
+
+    def _pair_constants(self) -> Tensor:
+        e, sg = self._eps.cpu().to(torch.float64), self._sigma.cpu().to(torch.float64)
+        eps_ab = torch.sqrt(torch.outer(e, e))                      # lj.py:84-85
+        sig_ab = (sg.unsqueeze(1) + sg.unsqueeze(0)) / 2            # lj.py:86-87
+        return torch.stack([4 * eps_ab, sig_ab, torch.full_like(eps_ab, self.c12), torch.full_like(eps_ab, self.c6)], dim=-1)
+
+
+class LennardJones(_LJ):
+    """4 eps ((sigma / r)^12 - (sigma / r)^6) (lj.py:102-108)."""
+
+
+class RepulsionLJ(_LJ):
+    """4 eps (sigma / r)^12 (lj.py:95-101)."""
+    c12, c6 = 1.0, 0.0
+
+
+class DispersionLJ(_LJ):
+    """-4 eps (sigma / r)^6 (lj.py:88-94)."""
+    c12, c6 = 0.0, -1.0
+
+
+class FixedCoulomb(_AnalyticPair):
+    """Coulomb energy of fixed per-element charges (potentials/fixed_coulomb.py:8-31)."""
+
+    kind = _lib.PAIR_COULOMB
+
+    def __init__(self, symbols: tp.Sequence[str], dielectric: float = 1.0, charges: tp.Sequence[float] = (), *,
+                 cutoff: float = math.inf, cutoff_fn: str = "smooth") -> None:
+        super().__init__()
+        self._init_common(symbols, cutoff, cutoff_fn)
+        self._dielectric = float(dielectric)
+        self.register_buffer("_charges", torch.tensor(self._elem_seq("charges", charges)), persistent=False)
+
+    def _pair_constants(self) -> Tensor:
+        q = self._charges.cpu().to(torch.float64)
+        qq = torch.outer(q, q) / self._dielectric
+        o = torch.zeros_like(qq)
+        return torch.stack([qq, o, o, o], dim=-1)
+
+
+class FixedMNOK(_AnalyticPair):
+    """Mataga-Nishimoto-Ohno-Klopman damped Coulomb energy of fixed charges (potentials/fixed_coulomb.py:34-75):
+    q_a q_b / sqrt(d^2 + (2 / (eta_a + eta_b))^2); like the reference's, it neither clamps distances nor applies the
+    dielectric constant."""
+
+    kind = _lib.PAIR_COULOMB
+    clamp_distances = False
+
+    def __init__(self, symbols: tp.Sequence[str], dielectric: float = 1.0, charges: tp.Sequence[float] = (),
+                 eta: tp.Sequence[float] = (), *, cutoff: float = math.inf, cutoff_fn: str = "smooth") -> None:
+        super().__init__()
+        self._init_common(symbols, cutoff, cutoff_fn)
+        self._dielectric = float(dielectric)
+        self.register_buffer("_charges", torch.tensor(self._elem_seq("charges", charges)), persistent=False)
+        self.register_buffer("_eta", torch.tensor(self._elem_seq("eta", eta)), persistent=False)
+
+    def _pair_constants(self) -> Tensor:
+        q, eta = self._charges.cpu().to(torch.float64), self._eta.cpu().to(torch.float64)
+        qq = torch.outer(q, q)
+        inv_eta = 2 / (eta.unsqueeze(1) + eta.unsqueeze(0))          # fixed_coulomb.py:62-63
+        o = torch.zeros_like(qq)
+        return torch.stack([qq, inv_eta, o, o], dim=-1)
 
 
 _D3_REFS: tp.Optional[tp.Dict[str, tp.Any]] = None
