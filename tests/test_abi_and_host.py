@@ -410,3 +410,30 @@ def test_d3_reference_data_and_class():
         TwoBodyDispersionD3.from_functional(("H", "O"), "no-such-functional")
     with pytest.raises(ValueError):
         TwoBodyDispersionD3(("H", "O"), 1.0, 1.0, 0.4, 4.0, sqrt_empirical_charge=(1.0,))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/torchani/resources/c6.h5"), reason="reference tree not present")
+def test_d3_data_file_is_the_reference_table():
+    """torchani_amd/data/d3_refs.npz against the reference's resources (build container only): the HDF5 reader of
+    tests/golden/gen_golden_d3.py finds the three datasets of c6.h5 and the shipped slice equals them."""
+    import json
+    import struct
+
+    from torchani_amd.potentials import d3_reference_data
+
+    b = open("/root/reference/torchani/resources/c6.h5", "rb").read()
+    nbytes = 4 * 95 * 95 * 25
+    addrs, i = [], b.find(struct.pack("<Q", nbytes))
+    while i >= 0:
+        if b[i - 10] == 3 and b[i - 9] == 1:
+            addrs.append(struct.unpack("<Q", b[i - 8:i])[0])
+        i = b.find(struct.pack("<Q", nbytes), i + 1)
+    assert len(addrs) == 3
+    tabs = [np.frombuffer(b, dtype="<f4", count=nbytes // 4, offset=a).reshape(95, 95, 5, 5) for a in sorted(addrs)]
+    d = d3_reference_data()
+    for ours, theirs in zip((d["c6"], d["cn_a"], d["cn_b"]), tabs):
+        assert np.array_equal(ours, theirs[:19, :19])
+    ac = json.load(open("/root/reference/torchani/resources/atomic_constants.json"))
+    for z, s_ in enumerate(d["symbols"], start=1):
+        assert abs(d["covalent_radius"][z] - ac[s_]["covalent_radius"]) < 1e-12
+        assert abs(d["sqrt_empirical_charge"][z] - ac[s_]["sqrt_empirical_charge"]) < 1e-12
