@@ -437,3 +437,32 @@ def test_d3_data_file_is_the_reference_table():
     for z, s_ in enumerate(d["symbols"], start=1):
         assert abs(d["covalent_radius"][z] - ac[s_]["covalent_radius"]) < 1e-12
         assert abs(d["sqrt_empirical_charge"][z] - ac[s_]["sqrt_empirical_charge"]) < 1e-12
+
+
+def test_charge_networks_pack_and_normalizer():
+    """ANI-mbis host side (models.py:201-252): the two-output charge networks pack the SECOND row of their final layers
+    (nn/_internal.py:69-93), and ChargeNormalizer reproduces the reference's normalized charges from its raw ones
+    (electro.py:29-87; fixture from tests/golden/gen_golden_mbis.py)."""
+    from torchani_amd.models import ChargeNormalizer
+    from torchani_amd.nn import ANINetworksDiscardFirstScalar
+
+    torch.manual_seed(0)
+    nets = ANINetworksDiscardFirstScalar.build(("H", "C"), 32, {"H": (24, 16), "C": (24, 16)}, "gelu", False, out_dim=2)
+    pk = nets._pack(torch.device("cpu"))
+    d = pk.desc
+    assert d.activation == 1 and [d.net[1].dims[l] for l in range(4)] == [32, 32, 32, 1]
+    wf = next(t for t in pk._keep if t.data_ptr() == d.net[1].w[2])
+    assert torch.equal(wf[0, :16], nets.atomics["C"].final_layer.weight[1].detach())
+    assert set(nets.state_dict()) == {f"atomics.{s}.{n}.weight" for s in "HC" for n in ("layers.0", "layers.1", "final_layer")}
+
+    ref = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mbis_rand_batch_ani2x.npz")))
+    norm = ChargeNormalizer.from_electronegativity_and_hardness([str(s) for s in ref["symbols"]],
+                                                                scale_weights_by_charges_squared=True)
+    q = norm(torch.from_numpy(ref["species"]), torch.from_numpy(ref["raw_charges"]))
+    assert np.abs(q.numpy() - ref["atomic_charges"]).max() < 1e-7     # (fp32 weights against the reference's fp64)
+    assert q.sum(dim=1).abs().max() < 1e-12
+    q1 = norm(torch.from_numpy(ref["species"]), torch.from_numpy(ref["raw_charges"]), charge=1)
+    assert (q1.sum(dim=1) - 1).abs().max() < 1e-12
+    plain = ChargeNormalizer(["H", "C"])
+    qq = plain(torch.tensor([[0, 1, -1]]), torch.tensor([[0.3, 0.1, 0.0]]))
+    assert torch.allclose(qq, torch.tensor([[0.1, -0.1, 0.0]]))

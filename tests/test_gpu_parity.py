@@ -988,6 +988,45 @@ def test_ani2xr_family_matches_reference(dev, kind, case):
         model((sp, x), cell, None if pbc is None else torch.tensor(pbc))
 
 
+@pytest.mark.parametrize("case", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x"])
+def test_animbis_charges_match_reference(dev, case):
+    """ANI-mbis (models.py:201-252): ANI-2x energies plus atomic charges from the two-output GELU charge networks and the
+    electronegativity / hardness normalizer, against the reference's Assembler(cls=ANIq) in fp64 with the same seeded
+    parameters (tests/golden/gen_golden_mbis.py).  The charges add up to the total charge exactly like the reference's."""
+    from torchani_amd.models import ANImbis
+    from torchani_amd.tuples import SpeciesEnergiesAtomicCharges
+    from torchani_amd.weights import random_charge_state_dict, random_state_dict
+
+    ref = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"mbis_{case}.npz")))
+    seed = int(ref["seed"])
+    sd = dict(random_state_dict("ani2x", 8, seed))
+    sd.update({"potentials.nnp.charge_networks." + k: v for k, v in random_charge_state_dict(seed).items()})
+    sp = torch.from_numpy(ref["species"]).to(dev)
+    x = torch.from_numpy(ref["coords"]).to(dev)
+    cell = torch.from_numpy(ref["cell"]).to(dev) if "cell" in ref else None
+    pbc = torch.tensor(ref["pbc"]) if "pbc" in ref else None
+    model = ANImbis(state_dict=sd, device=dev, periodic_table_index=False,
+                    neighborlist="batch" if cell is None or sp.shape[0] > 1 else "auto", row_capacity=256)
+    out = model((sp, x), cell, pbc)
+    torch.cuda.synchronize()
+    assert isinstance(out, SpeciesEnergiesAtomicCharges) and out.atomic_charges.shape == sp.shape
+    n_real = int((ref["species"] >= 0).sum(axis=1).max())
+    ee = np.abs(out.energies.cpu().numpy() - ref["energies"]).max()
+    raw = model.potentials["nnp"].charge_networks(sp, model.aev_computer(sp, x, cell, pbc), atomic=True)
+    re = np.abs(raw.cpu().numpy() - ref["raw_charges"]).max()
+    qe = np.abs(out.atomic_charges.cpu().numpy() - ref["atomic_charges"]).max()
+    report(f"mbis  {case:20s} max|E err| = {ee:.2e} ({n_real} atoms)  |q_raw err| = {re:.2e}  |q err| = {qe:.2e} "
+           f"(|q|max {np.abs(ref['atomic_charges']).max():.2f})")
+    assert ee < E_ATOM_TOL * n_real + 2e-7 * np.abs(ref["energies"]).max()
+    assert re < 2e-5 and qe < 2e-5
+    assert out.atomic_charges.sum(dim=1).abs().max().item() < 1e-5
+    assert (out.atomic_charges[sp < 0] == 0).all()
+    # one member of the ensemble keeps the charge networks (arch.py ANIq.__getitem__ through the Assembler's members)
+    one = model[2]((sp, x), cell, pbc)
+    assert torch.equal(one.atomic_charges, out.atomic_charges)
+    assert torch.equal(model.atomic_charges((sp, x), cell, pbc), out.atomic_charges)
+
+
 def test_periodic_replica_and_symmetries_at_scale(dev):
     """Size-independent properties at ~0.33 M atoms (no oracle at this size): a periodic box replicated 2 x 2 x 2
     has the same per-atom energies and forces as the original box (every atom sees the same environment), the

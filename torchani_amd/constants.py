@@ -20,6 +20,11 @@ GSAES_B973C_DEF2MTZVP: tp.Dict[str, float] = {
     "H": -0.506930113968, "C": -37.81441001258, "N": -54.556538547322, "O": -75.029181326588,
     "F": -99.688618987039, "S": -398.043159341582, "Cl": -460.082223445159,
 }
+# resources/atomic_constants.json: (electronegativity, hardness) in eV, for the charge normalizer of ANI-mbis
+ELECTRONEGATIVITY_HARDNESS: tp.Dict[str, tp.Tuple[float, float]] = {
+    "H": (7.18, 12.84), "C": (6.26, 10.0), "N": (7.27, 14.53), "O": (7.54, 12.16), "F": (10.41, 14.02),
+    "S": (6.22, 8.28), "Cl": (8.29, 9.35),
+}
 # constants.py GSAES["ccsd(t)star-cbs"] (ANI-1ccx) and GSAES["r2scan3c{,_water,_chcl3,_ch3cn}-def2mtzvpp"] (ANI-r2s)
 GSAES_CCSDT_STAR_CBS: tp.Dict[str, float] = {
     "H": -0.5, "C": -37.780724507998, "N": -54.515992576387, "O": -74.976148184192,

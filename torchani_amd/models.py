@@ -42,6 +42,39 @@ class NNPotential(torch.nn.Module):
         self._enabled = True
 
 
+class ChargeNormalizer(torch.nn.Module):
+    """Shift raw atomic charges so that they add up to the total charge (electro.py:29-87): the excess is distributed
+    with per-element weights, optionally scaled by the squared raw charges."""
+
+    def __init__(self, symbols: tp.Sequence[str], weights: tp.Sequence[float] = (),
+                 scale_weights_by_charges_squared: bool = False) -> None:
+        super().__init__()
+        if not weights:
+            weights = [1.0] * len(symbols)
+        self.register_buffer("weights", torch.tensor(list(weights), dtype=torch.float), persistent=False)
+        self.scale_weights_by_charges_squared = scale_weights_by_charges_squared
+
+    @classmethod
+    def from_electronegativity_and_hardness(cls, symbols: tp.Sequence[str], electronegativity: tp.Sequence[float] = (),
+                                            hardness: tp.Sequence[float] = (),
+                                            scale_weights_by_charges_squared: bool = False) -> "ChargeNormalizer":
+        from .constants import ELECTRONEGATIVITY_HARDNESS as EH
+
+        en = list(electronegativity) if electronegativity else [EH[s][0] for s in symbols]
+        hd = list(hardness) if hardness else [EH[s][1] for s in symbols]
+        return cls(symbols, [(e / h) ** 2 for e, h in zip(en, hd)], scale_weights_by_charges_squared)
+
+    def factor(self, elem_idxs: Tensor, raw_charges: Tensor) -> Tensor:
+        w = self.weights.to(raw_charges.dtype)[elem_idxs.clamp(min=0)].masked_fill(elem_idxs == -1, 0.0)
+        if self.scale_weights_by_charges_squared:
+            w = w * raw_charges ** 2
+        return w / torch.sum(w, dim=-1, keepdim=True)
+
+    def forward(self, elem_idxs: Tensor, raw_charges: Tensor, charge: int = 0) -> Tensor:
+        excess = charge - raw_charges.sum(dim=-1, keepdim=True)
+        return raw_charges + excess * self.factor(elem_idxs, raw_charges)
+
+
 class ANI(torch.nn.Module):
     """ANI-style neural network interatomic potential (arch.py:298-349)."""
 
@@ -96,9 +129,11 @@ class ANI(torch.nn.Module):
         energies = coords.new_zeros(elem_idxs.shape if atomic else elem_idxs.shape[:1])
         if ensemble_values:
             energies = energies.unsqueeze(0)
+        extra = None
         if self.potentials["nnp"]._enabled:
             aevs = self.aev_computer(elem_idxs, coords, cell, pbc)
             energies = energies + self.neural_networks(elem_idxs, aevs, atomic, ensemble_values)
+            extra = self._scalars_from_aevs(elem_idxs, aevs, charge)
         for name, pot in self.potentials.items():   # pair potentials on the same neighbor rows (arch.py:329-346)
             if name == "nnp" or not pot._enabled:
                 continue
@@ -120,6 +155,12 @@ class ANI(torch.nn.Module):
             energies = energies + (e_pair.unsqueeze(0) if ensemble_values else e_pair).to(energies.dtype)
         if self.energy_shifter._enabled:
             energies = energies + self.energy_shifter(elem_idxs, atomic=atomic)
+        return self._output(elem_idxs, energies, extra)
+
+    def _scalars_from_aevs(self, elem_idxs: Tensor, aevs: Tensor, charge: int) -> tp.Optional[Tensor]:
+        return None   # (ANIq: atomic charges from the same AEVs)
+
+    def _output(self, elem_idxs: Tensor, energies: Tensor, extra: tp.Optional[Tensor]):
         return SpeciesEnergies(elem_idxs, energies)
 
     def add_pair_potential(self, name: str, pot: torch.nn.Module) -> "ANI":
@@ -397,7 +438,7 @@ class ANI(torch.nn.Module):
     def energies_qbcs(self, species_coordinates, cell=None, pbc=None, unbiased: bool = True,
                       charge: int = 0) -> SpeciesEnergiesQBC:
         """Ensemble-mean energies and query-by-committee factors std_m(E) / sqrt(n_atoms), arch.py:438-486."""
-        elem_idxs, energies = self(species_coordinates, cell, pbc, charge, False, True)
+        elem_idxs, energies = self(species_coordinates, cell, pbc, charge, False, True)[:2]
         if energies.shape[0] == 1:
             qbc = torch.zeros_like(energies).squeeze(0)
         else:
@@ -408,7 +449,7 @@ class ANI(torch.nn.Module):
     def atomic_stdev(self, species_coordinates, cell=None, pbc=None, charge: int = 0,
                      ensemble_values: bool = False, unbiased: bool = True) -> AtomicStdev:
         """Standard deviation of the atomic energies across the ensemble, arch.py:488-516."""
-        elem_idxs, energies = self(species_coordinates, cell, pbc, charge, True, True)
+        elem_idxs, energies = self(species_coordinates, cell, pbc, charge, True, True)[:2]
         if energies.shape[0] == 1:
             stdev = torch.zeros_like(energies).squeeze(0)
         else:
@@ -472,6 +513,50 @@ class ANI(torch.nn.Module):
         """Load a (reference or seeded) state dict given as tensors or numpy arrays."""
         conv = {k: (torch.from_numpy(np.asarray(v)) if not isinstance(v, Tensor) else v) for k, v in state.items()}
         return self.load_state_dict(conv, strict=strict)
+
+
+class ANIq(ANI):
+    """ANI-style model that also predicts atomic charges from separate charge networks on the same AEVs (arch.py:579-692
+    ANIq with SeparateChargesNNPotential, potentials/nnp.py:75-102).  ``forward`` returns SpeciesEnergiesAtomicCharges;
+    the charges are the charge networks' outputs passed through the normalizer."""
+
+    def __init__(self, symbols, aev_computer, neural_networks, self_energies, periodic_table_index: bool = True,
+                 charge_networks: tp.Optional[torch.nn.Module] = None,
+                 charge_normalizer: tp.Optional[torch.nn.Module] = None) -> None:
+        super().__init__(symbols, aev_computer, neural_networks, self_energies, periodic_table_index)
+        if charge_networks is None:
+            raise ValueError("ANIq needs charge_networks (merged charge / energy networks are not implemented)")
+        self.potentials["nnp"].charge_networks = charge_networks
+        self.potentials["nnp"].charge_normalizer = (ChargeNormalizer(symbols) if charge_normalizer is None
+                                                    else charge_normalizer)
+
+    def __getitem__(self, idx: int) -> "ANIq":
+        nets = self.neural_networks
+        member = nets.members[idx] if hasattr(nets, "members") else nets
+        nnp = self.potentials["nnp"]
+        m = ANIq(self.symbols, self.aev_computer, member, self.energy_shifter.self_energies.tolist(),
+                 self.periodic_table_index, nnp.charge_networks, nnp.charge_normalizer)
+        m.energy_shifter._enabled = self.energy_shifter._enabled
+        return m.to(self.atomic_numbers.device)
+
+    def _scalars_from_aevs(self, elem_idxs: Tensor, aevs: Tensor, charge: int) -> Tensor:
+        # potentials/nnp.py:99-102.  The GELU networks run the inference kernels only: the charges carry no gradient
+        nnp = self.potentials["nnp"]
+        with torch.no_grad():
+            qs = nnp.charge_networks(elem_idxs, aevs.detach(), atomic=True)
+            return nnp.charge_normalizer(elem_idxs, qs, charge)
+
+    def _output(self, elem_idxs: Tensor, energies: Tensor, extra: tp.Optional[Tensor]):
+        from .tuples import SpeciesEnergiesAtomicCharges
+
+        qs = energies.new_zeros(elem_idxs.shape) if extra is None else extra.to(energies.dtype)
+        return SpeciesEnergiesAtomicCharges(elem_idxs, energies, qs)
+
+    def atomic_charges(self, species_coordinates, cell: tp.Optional[Tensor] = None,
+                       pbc: tp.Optional[Tensor] = None, charge: int = 0) -> Tensor:
+        """Normalized atomic charges [C, A] (padding atoms: 0)."""
+        with torch.no_grad():
+            return self(species_coordinates, cell, pbc, charge).atomic_charges
 
 
 class GraphedEnergiesForces:
@@ -647,6 +732,35 @@ def ANIr2s_chcl3(**kw) -> ANI:
 
 def ANIr2s_ch3cn(**kw) -> ANI:
     return ANIr2s(solvent="ch3cn", **kw)
+
+
+def ANImbis(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",
+            periodic_table_index: bool = True, device=None, dtype=None, state_dict=None,
+            seed: tp.Optional[int] = None, n_members: int = 8, row_capacity: int = 128) -> ANIq:
+    """ANI-mbis architecture (models.py:201-252): ANI-2x energies + MBIS atomic charges from one set of GELU / bias-free
+    charge networks with two outputs (the second is the charge), normalized with electronegativity / hardness weights
+    scaled by the squared raw charges."""
+    from .nn import ANINetworksDiscardFirstScalar
+    from .weights import random_charge_state_dict
+
+    base = _builtin("ani2x", state_dict, seed, n_members, None, neighborlist, row_capacity, periodic_table_index,
+                    "cosine", None, strategy, dtype)
+    symbols, consts, hidden = arch_spec("ani2x")
+    qnets = ANINetworksDiscardFirstScalar.build(symbols, consts.out_dim, hidden, "gelu", False, out_dim=2)
+    model = ANIq(symbols, base.aev_computer, base.neural_networks,
+                 [float(v) for v in base.energy_shifter.self_energies], periodic_table_index, qnets,
+                 ChargeNormalizer.from_electronegativity_and_hardness(symbols, scale_weights_by_charges_squared=True))
+    sd = state_dict if state_dict is not None else {}
+    pre = "potentials.nnp.charge_networks."
+    qsd = {k[len(pre):]: (torch.from_numpy(np.asarray(v)) if not isinstance(v, Tensor) else v)
+           for k, v in sd.items() if k.startswith(pre)}
+    if not qsd:   # (seeded stand-in for the reference's charge_nn_state_dict.pt download)
+        qsd = {k: torch.from_numpy(v) for k, v in random_charge_state_dict(0 if seed is None else seed).items()}
+    qnets.load_state_dict(qsd, strict=True)
+    model.requires_grad_(False)
+    if device is not None:
+        model = model.to(device)
+    return model if model_index is None else model[model_index]
 
 
 def ANI1ccx(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",

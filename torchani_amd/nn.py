@@ -183,10 +183,17 @@ class _EngineContainer(torch.nn.Module):
                tuple(p.data_ptr() for p in params))
         cache = self.__dict__.setdefault("_packed_cache", {})   # several member subsets stay packed
         if key not in cache:
-            weights = [[[lin.weight for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
+            # (a container may read ONE of several outputs of its final layers, nn/_internal.py:69-93: that row only)
+            oi = [getattr(m, "out_index", 0) for m in members]
+            weights = [[[(lin.weight if li < len(m.atomics[s].linears()) - 1 or lin.out_features == 1
+                          else lin.weight[oi[k]:oi[k] + 1].contiguous())
+                         for li, lin in enumerate(m.atomics[s].linears())] for s in self.symbols]
+                       for k, m in enumerate(members)]
             # (bias-free networks, nn/_core.py:122: zeros)
-            biases = [[[lin.bias if lin.bias is not None else torch.zeros(lin.out_features, device=lin.weight.device)
-                        for lin in m.atomics[s].linears()] for s in self.symbols] for m in members]
+            biases = [[[(torch.zeros(w.shape[0], device=w.device) if lin.bias is None
+                         else (lin.bias if lin.bias.shape[0] == w.shape[0] else lin.bias[oi[k]:oi[k] + 1].contiguous()))
+                        for lin, w in zip(m.atomics[s].linears(), weights[k][si])]
+                       for si, s in enumerate(self.symbols)] for k, m in enumerate(members)]
             aev_len = weights[0][0][0].shape[1]
             acts = {getattr(m.atomics[s], "activation_name", "celu") for m in members for s in self.symbols}
             if len(acts) != 1:
@@ -276,11 +283,19 @@ class ANINetworks(_EngineContainer):
 
     @classmethod
     def build(cls, symbols: tp.Sequence[str], in_dim: int, hidden: tp.Dict[str, tp.Sequence[int]],
-              activation: str = "celu", bias: bool = True):
-        return cls({s: AtomicNetwork((in_dim,) + tuple(hidden[s]) + (1,), activation, bias) for s in symbols})
+              activation: str = "celu", bias: bool = True, out_dim: int = 1):
+        return cls({s: AtomicNetwork((in_dim,) + tuple(hidden[s]) + (out_dim,), activation, bias) for s in symbols})
 
     def to_infer_model(self, use_mnp: bool = False) -> "ANINetworks":
         return self  # already the fused native path (reference: nn/_containers.py:423-425)
+
+
+class ANINetworksDiscardFirstScalar(ANINetworks):
+    """Networks with two outputs of which the SECOND is the container's value (nn/_internal.py:69-93
+    _ANINetworksDiscardFirstScalar: the charge networks of ANI-mbis).  The engine evaluates the selected output row of
+    the final layers like a one-output network."""
+
+    out_index = 1
 
 
 class Ensemble(_EngineContainer):

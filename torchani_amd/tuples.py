@@ -25,6 +25,14 @@ class SpeciesEnergies(tp.NamedTuple):
     energies: Tensor
 
 
+class SpeciesEnergiesAtomicCharges(tp.NamedTuple):
+    """Output of ANIq models (torchani/tuples.py:59-62)."""
+
+    species: Tensor
+    energies: Tensor
+    atomic_charges: Tensor
+
+
 class EnergiesScalars(tp.NamedTuple):
     """Return type of ANI.compute_from_neighbors / compute_from_external_neighbors (torchani/tuples.py:8-10)."""
 

@@ -70,3 +70,19 @@ def random_state_dict(kind: str = "ani2x", n_members: int = 8, seed: int = 0,
     out["energy_shifter.self_energies"] = np.asarray(
         [arch_gsaes(kind)[s] for s in symbols], dtype=np.float32)
     return out
+
+
+def random_charge_state_dict(seed: int = 0) -> tp.Dict[str, np.ndarray]:
+    """Seeded parameters of the ANI-mbis charge networks (ANI-2x widths, two outputs, no biases) under the key names of
+    the reference's charge_nn_state_dict.pt (``atomics.{Sym}.layers.{l}.weight`` / ``final_layer.weight``)."""
+    symbols, consts, hidden = arch_spec("ani2x")
+    rs = np.random.RandomState(1000 + seed)
+    out: tp.Dict[str, np.ndarray] = {}
+    for sym in symbols:
+        dims = (consts.out_dim,) + tuple(hidden[sym]) + (2,)
+        nl = len(dims) - 1
+        for l in range(nl):
+            name = f"layers.{l}" if l < nl - 1 else "final_layer"
+            bound = 3.0 / np.sqrt(dims[l])   # (bias-free GELU layers shrink the signal: keeps the charges ~0.1 e)
+            out[f"atomics.{sym}.{name}.weight"] = rs.uniform(-bound, bound, (dims[l + 1], dims[l])).astype(np.float32)
+    return out
