@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 6
+#define ANIHIP_ABI_VERSION 7
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -95,7 +95,9 @@ size_t anihip_nbr_workspace_bytes(int64_t n_atoms, int64_t max_cells);
 
 /* Batched molecules, all pairs inside each molecule: replaces pairwiseDistance + postProcessNbrList1
  * (csrc/aev.cu:180-249,975-1039) and neighbors.py:187-275 (all_pairs incl. PBC images).
- * cell: device float[9] (rows = lattice vectors) or NULL; pbc_mask bit k = periodic along vector k. */
+ * cell: device float[9] (rows = lattice vectors) or NULL; pbc_mask bit k = periodic along vector k.
+ * anihip_nbr_build_batch and anihip_nbr_build_cell reset the ANIHIP_STATUS_WORDS status words themselves (their first
+ * kernel does); the conversions below (from_half / from_full / refresh) and the AEV calls OR into what they are given. */
 int anihip_nbr_build_batch(void *stream, const anihip_aev_params *p, int32_t n_mol, int32_t n_atoms_per_mol,
                            const int32_t *species, const float *coords, const float *cell,
                            int32_t pbc_mask, int64_t lo, int64_t hi, void *workspace,
@@ -267,6 +269,8 @@ typedef struct {
 #define ANIHIP_MLP_FLAG_NO_SLAB_MASK 8u   /* ignore slab_mask: multiply every AEV slab */
 #define ANIHIP_MLP_FLAG_FUSED_ROWS32 16u  /* fused kernel: 32-atom tiles, two workgroups per CU (default 64 / one) */
 #define ANIHIP_MLP_FLAG_D0_ROWS 32u       /* d E/d act0 handed to the layer-0 backward row-major, not tile-major */
+#define ANIHIP_MLP_FLAG_NO_SMALL_PREP 64u /* <= 16384 atoms: bucketing / tile table / padding rows as separate launches, not one */
+#define ANIHIP_MLP_FLAG_L0B_4WAVE 128u    /* < 16384 atoms: the generic 4-wave 128 x 128 kernel for the layer-0 backward, not the 8-wave one */
 typedef struct {
     int32_t num_species;
     int32_t n_members;
@@ -412,6 +416,13 @@ int anihip_pair_d3(void *stream, int64_t n_atoms, int64_t lo, int64_t hi, const 
  * contributes nothing (sae.py:54-64).  sae may be NULL.  mol_e is overwritten. */
 int anihip_energy_reduce(void *stream, int32_t n_mol, int32_t n_atoms_per_mol, int64_t lo, int64_t hi,
                          const int32_t *species, const float *atomic_e, const double *sae, double *mol_e);
+
+/* The last launch of an energies-and-forces step: anihip_energy_reduce, and grad_coords[0 .. n_grad) (the d E / d coords
+ * that anihip_aev_backward and the pair terms accumulated) negated in place into forces (grad.py:283-290); one launch for
+ * batches of small molecules, where a step is bound by the number of launches. */
+int anihip_energy_forces_finish(void *stream, int32_t n_mol, int32_t n_atoms_per_mol, int64_t lo, int64_t hi,
+                                const int32_t *species, const float *atomic_e, const double *sae, double *mol_e,
+                                float *grad_coords, int64_t n_grad);
 
 #ifdef __cplusplus
 }

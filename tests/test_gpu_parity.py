@@ -358,6 +358,34 @@ def test_energies_and_forces_fused(dev, name):
         assert np.all(out.forces.cpu().numpy()[g["species"] < 0] == 0)
 
 
+@pytest.mark.parametrize("name", ["cfg2_xyz13_28_ani2x", "rand_batch_ani2x", "small_ani2x"])
+def test_small_input_launch_variants_bit_identical(dev, name, monkeypatch):
+    """Below 16384 atoms the bucketing / tile table / padding rows are ONE launch (k_small_prep) and the 128 x 128 layer-0
+    backward takes 1 or 2 flagged column blocks per workgroup instead of 4: the same sorted order and the same reduction
+    order per output element, so energies and (fixed-point) forces are bit-identical to the launch-by-launch path."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")
+    with np.load(path) as z:
+        sp = torch.from_numpy(z["species"].astype(np.int64)).to(dev)
+        x = torch.from_numpy(z["coords"].astype(np.float32)).to(dev)
+    model = get_model("ani2x", 3, dev, neighborlist="batch", row_capacity=256)
+    monkeypatch.setattr(model, "auto_graph_atoms", 0)
+    monkeypatch.setattr(model, "deterministic_forces", True)
+    res = {}
+    for key, fl in (("default", 0), ("l0b_wide", _lib.MLP_FLAG_L0B_4WAVE), ("no_small_prep", _lib.MLP_FLAG_NO_SMALL_PREP),
+                    ("old", _lib.MLP_FLAG_NO_SMALL_PREP | _lib.MLP_FLAG_L0B_4WAVE),
+                    ("rows32", _lib.MLP_FLAG_FUSED_ROWS32), ("rows32_old", _lib.MLP_FLAG_FUSED_ROWS32 | _lib.MLP_FLAG_NO_SMALL_PREP),
+                    ("unfused", _lib.MLP_FLAG_NO_FUSED), ("unfused_old", _lib.MLP_FLAG_NO_FUSED | _lib.MLP_FLAG_NO_SMALL_PREP)):
+        monkeypatch.setattr(PackedNetworks, "default_flags", fl)
+        out = model.energies_and_forces(sp, x, check_overflow=True)
+        res[key] = (out.energies.clone(), out.forces.clone(), out.atomic_energies.clone())
+    torch.cuda.synchronize()
+    for a, b in (("default", "old"), ("l0b_wide", "old"), ("no_small_prep", "old"), ("rows32", "rows32_old"),
+                 ("unfused", "unfused_old")):
+        for u, v in zip(res[a], res[b]):
+            assert torch.equal(u, v), (name, a, b, (u - v).abs().max().item())
+    assert (res["default"][1][sp < 0] == 0).all() and (res["default"][2][sp < 0] == 0).all()
+
+
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_energies_and_forces_slab_masks(dev, name, monkeypatch):
     """The large-system configuration of the fused path on the golden cases: 256x256-tile layer-0 GEMMs

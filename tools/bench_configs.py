@@ -52,7 +52,8 @@ def measure(dev=None, reps2=50, reps3=20):
         from torchani_amd import _lib
         from torchani_amd.engine import PackedNetworks
 
-        for nm, fl in (("big_tiles", _lib.MLP_FLAG_BIG_TILES), ("no_fused", _lib.MLP_FLAG_NO_FUSED),
+        for nm, fl in (("l0b_wide", _lib.MLP_FLAG_L0B_4WAVE), ("no_small_prep", _lib.MLP_FLAG_NO_SMALL_PREP),
+                       ("big_tiles", _lib.MLP_FLAG_BIG_TILES), ("no_fused", _lib.MLP_FLAG_NO_FUSED),
                        ("rows32", _lib.MLP_FLAG_FUSED_ROWS32), ("rows32_big", _lib.MLP_FLAG_FUSED_ROWS32 | _lib.MLP_FLAG_BIG_TILES)):
             PackedNetworks.default_flags = fl
             g2 = model.graphed(spd, xd)

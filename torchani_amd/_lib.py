@@ -35,7 +35,8 @@ ACT_CELU, ACT_GELU = 0, 1
 # anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*)
 MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_FUSED_ROWS32, MLP_FLAG_D0_ROWS = \
     1, 2, 4, 8, 16, 32
-ABI_VERSION = 6
+MLP_FLAG_NO_SMALL_PREP, MLP_FLAG_L0B_4WAVE = 64, 128
+ABI_VERSION = 7
 
 
 class AevParams(C.Structure):
@@ -172,6 +173,8 @@ def lib() -> C.CDLL:
     L.anihip_mlp_train_forward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, sz, vp]
     L.anihip_mlp_repack.argtypes = [vp, C.POINTER(MlpDesc), vp, vp]
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
+    L.anihip_energy_forces_finish.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp, vp, i64]
+    L.anihip_energy_forces_finish.restype = C.c_int
     L.anihip_pair_xtb_repulsion.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, C.c_float, i32, i32, vp, vp, vp]
     L.anihip_pair_xtb_repulsion.restype = C.c_int
     L.anihip_pair_analytic.argtypes = [vp, i32, i64, i64, i64, vp, vp, vp, vp, vp, C.c_float, i32, i32, vp, vp, vp]
@@ -196,7 +199,7 @@ EXPORTED_SYMBOLS = [
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
     "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
     "anihip_mlp_tangent_workspace_bytes", "anihip_mlp_tangent_weight_grads", "anihip_pair_xtb_repulsion",
-    "anihip_pair_d3", "anihip_pair_analytic",
+    "anihip_pair_d3", "anihip_pair_analytic", "anihip_energy_forces_finish",
 ]
 
 

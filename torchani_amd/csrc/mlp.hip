@@ -96,6 +96,16 @@ struct GemmArgs {
     unsigned *amax;            // device [AMAX_STAGES][MAX_S][AMAX_SLOTS] float bits
 };
 
+struct FinishArgs {   // k_fused_finish, or the extra blocks of k_gemm_l0s
+    const int *ctl;
+    const int *perm;
+    const float *member_part;
+    float *atomic_e, *member_e;
+    int64_t n_atoms;
+    int S, M;
+    int first_block;   // k_gemm_l0s: blocks from here on do this instead of a tile (0: none)
+};
+
 // control block layout (ints) in the workspace
 constexpr int CTL_CNT = 0;      // [8]  atoms per species
 constexpr int CTL_CURSOR = 8;   // [8]  scatter cursors
@@ -553,10 +563,22 @@ __device__ __forceinline__ void gemm_h_kloop(f32x16 (&acc)[4], const gf4 *a_src0
     }
 }
 
+#ifdef ANIHIP_DEV_TRACE   // development builds: [workgroup][8] = {shader clock, 100-MHz clock} x {start, loop, epilogue, end}
+__device__ unsigned long long g_gemm_trace[8 * 4096];
+#define GEMM_STAMP(k)                                                                       \
+    if (EPI == EPI_SCATTER && threadIdx.x == 0 && blockIdx.x < 4096) {                      \
+        g_gemm_trace[blockIdx.x * 8 + 2 * (k)] = __builtin_readcyclecounter();              \
+        g_gemm_trace[blockIdx.x * 8 + 2 * (k) + 1] = wall_clock64();                        \
+    }
+#else
+#define GEMM_STAMP(k)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
 {
     __shared__ __attribute__((aligned(16))) _Float16 sm[2 * 4 * H_PLANE];
+    GEMM_STAMP(0)
 
     const int nwg = gridDim.x;
     int id = blockIdx.x;
@@ -574,7 +596,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
     while (s + 1 < g.S && row_t >= ctl[CTL_TILE + s + 1]) ++s;
     const GemmProblem &pr = g.prob[s];
     const int n0 = col_t * BN;
-    if (n0 >= pr.N) return;
+    const bool compact = (EPI == EPI_SCATTER) && g.stage_mask;
+    if (!compact && n0 >= pr.N) return;
     const int m0 = (row_t - ctl[CTL_TILE + s]) * BM;
     const int n_rows = ctl[CTL_CNT + s] - m0;
     const int p0 = ctl[CTL_OFF + s] + m0;
@@ -590,7 +613,6 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
     // ---- layer-0 backward with slab masks: the tile's 4 column blocks are the (4 col_t .. 4 col_t + 3)-th blocks
     // flagged in the OR of its atoms' masks (as in k_gemm_h2); column tiles past the last flagged block exit ----
     int cbw[4] = {(n0 >> 5), (n0 >> 5) + 1, (n0 >> 5) + 2, (n0 >> 5) + 3};   // this tile's column blocks
-    const bool compact = (EPI == EPI_SCATTER) && g.stage_mask;
     if (compact) {
         __shared__ int s_tab[5];   // [0] = tile mask, [1..4] = column blocks
         const int *rows = g.a_gather ? g.a_gather : g.c_scatter;   // sorted position -> atom
@@ -642,6 +664,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
 
     const int nk = pr.K / HBK;
     const int fr = lane & 31, fk = lane >> 5;
+    GEMM_STAMP(1)
     switch (nb_act) {
         case 4: gemm_h_kloop<4>(acc, a_src0, a_src1, pr.k_valid, EPI == EPI_BIAS_CELU ? g.kp_rad : 0, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
         case 3: gemm_h_kloop<3>(acc, a_src0, a_src1, pr.k_valid, EPI == EPI_BIAS_CELU ? g.kp_rad : 0, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
@@ -649,6 +672,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
         default: gemm_h_kloop<1>(acc, a_src0, a_src1, pr.k_valid, EPI == EPI_BIAS_CELU ? g.kp_rad : 0, sa, b_src0, b_src1, pr.bh_plane, nk, sm, wave); break;
     }
 
+    GEMM_STAMP(2)
     float vmax = 0.f;
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -680,6 +704,213 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm_h(GemmArgs g)
         }
     }
     if (g.amax_out >= 0) amax_update(g.amax, g.amax_out, s, vmax);
+    GEMM_STAMP(3)
+}
+
+// ---- layer-0 backward for few atoms: 128 x 128 x 32 tiles, EIGHT waves -------------------------------------------
+// Below the 256 x 256 tiling's threshold the layer-0 backward has only a hundred-odd tiles, one workgroup per CU, and
+// k_gemm_h's four waves (one per SIMD) run a pure latency chain: barrier -> fragment reads -> 24 MFMAs -> barrier,
+// 2.5 k clocks per 32-deep stage of which 0.8 k are MFMA issue (measured with the phase stamps of the development
+// build).  Here the same tile is owned by 4 (rows) x 2 (column halves) waves, two per SIMD, so one wave's MFMAs cover
+// the other's LDS latency, the staging work per thread halves (one row of A and of B per stage), and the destination rows
+// of the scatter are loaded once before the stores instead of between them.  d E / d AEV only, compacted to the flagged
+// column blocks (stage_mask), A = d E / d act0 row-major as the fused kernel leaves it for this path.
+constexpr int L0S_THREADS = 512;
+__device__ __forceinline__ void fused_finish(const FinishArgs &f, int64_t first, int64_t stride);
+
+struct L0sStage {
+    v4f a[2];   // 8 k values of this thread's A row
+    h8 bh, bl;  // 8 k values of this thread's B row, hi / lo plane
+};
+
+constexpr int L0S_BUFS = 3;   // LDS stages: the fragments of stage k + 1 are read while stage k multiplies, stage k + 2 is written
+
+template <int NBW>
+struct L0sFrag {
+    h8 ahi[HBK / 16], alo[HBK / 16], bhi[HBK / 16][NBW], blo[HBK / 16][NBW];
+};
+
+template <int NBW>
+__device__ __forceinline__ void l0s_kloop(f32x16 (&acc)[2], const gf4 *a_src, float sa, const _Float16 *b_src,
+                                          int64_t bh_plane, int nk, _Float16 *sm, int wr, int wc)
+{
+    constexpr int STAGE = 4 * H_PLANE;  // halves per LDS stage: A_hi, A_lo, B_hi, B_lo
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int srow = tid >> 2, piece = tid & 3;
+    const int fr = lane & 31, fk = lane >> 5;
+    auto gload = [&](L0sStage &st, int kt) {
+        st.a[0] = a_src[kt * (HBK / 4)];
+        st.a[1] = a_src[kt * (HBK / 4) + 1];
+        st.bh = *(const gh8 *)(b_src + kt * HBK);
+        st.bl = *(const gh8 *)(b_src + bh_plane + kt * HBK);
+    };
+    auto lstore = [&](const L0sStage &st, int buf) {
+        _Float16 *base = sm + buf * STAGE;
+        h8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float x = st.a[c >> 2][c & 3] * sa;
+            const _Float16 h = (_Float16)x;
+            hi[c] = h;
+            lo[c] = (_Float16)(x - (float)h);
+        }
+        const int off = h_off(srow, piece);
+        *reinterpret_cast<h8 *>(base + off) = hi;
+        *reinterpret_cast<h8 *>(base + H_PLANE + off) = lo;
+        *reinterpret_cast<h8 *>(base + 2 * H_PLANE + off) = st.bh;
+        *reinterpret_cast<h8 *>(base + 3 * H_PLANE + off) = st.bl;
+    };
+    auto fload = [&](L0sFrag<NBW> &f, int buf) {
+        const _Float16 *base = sm + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {
+            const int pc = ks * 2 + fk;
+            const int ao = h_off(wr * 32 + fr, pc);
+            f.ahi[ks] = *reinterpret_cast<const h8 *>(base + ao);
+            f.alo[ks] = *reinterpret_cast<const h8 *>(base + H_PLANE + ao);
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) {
+                const int bo = h_off((wc * 2 + j) * 32 + fr, pc);
+                f.bhi[ks][j] = *reinterpret_cast<const h8 *>(base + 2 * H_PLANE + bo);
+                f.blo[ks][j] = *reinterpret_cast<const h8 *>(base + 3 * H_PLANE + bo);
+            }
+        }
+    };
+    auto mma = [&](const L0sFrag<NBW> &f) {   // small terms first, same order per accumulator as k_gemm_h
+#pragma unroll
+        for (int ks = 0; ks < HBK / 16; ++ks) {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.alo[ks], f.bhi[ks][j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ahi[ks], f.blo[ks][j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ahi[ks], f.bhi[ks][j], acc[j], 0, 0, 0);
+        }
+    };
+    // Stage k lives in LDS buffer k % 3.  Iteration k: read the fragments of stage k + 1 (stored in iteration k - 1, visible
+    // since that iteration's barrier), multiply stage k from registers, convert and store stage k + 2 (its buffer was last
+    // read for stage k - 1, whose fragments are in registers since iteration k - 2), load stage k + 4 from memory: the
+    // only thing a wave waits for inside an iteration is its own MFMA queue.
+    L0sStage s0, s1;
+    L0sFrag<NBW> f0, f1;
+    gload(s0, 0);
+    gload(s1, min(1, nk - 1));
+    lstore(s0, 0);
+    gload(s0, min(2, nk - 1));
+    lstore(s1, 1);
+    gload(s1, min(3, nk - 1));
+    __syncthreads();
+    fload(f0, 0);
+    int b1 = 1, b2 = 2;   // buffers of stages kt + 1 and kt + 2
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 1 < nk) fload(f1, b1);
+        mma(f0);
+        if (kt + 2 < nk) lstore(s0, b2);
+        gload(s0, min(kt + 4, nk - 1));
+        __syncthreads();
+        b1 = b1 == 2 ? 0 : b1 + 1; b2 = b2 == 2 ? 0 : b2 + 1;
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) fload(f0, b1);
+            mma(f1);
+            if (kt + 3 < nk) lstore(s1, b2);
+            gload(s1, min(kt + 5, nk - 1));
+            __syncthreads();
+            b1 = b1 == 2 ? 0 : b1 + 1; b2 = b2 == 2 ? 0 : b2 + 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(L0S_THREADS) void k_gemm_l0s(GemmArgs g, FinishArgs fin)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 sm[];   // L0S_BUFS x 4 planes x H_PLANE halves (96 KB)
+    __shared__ int s_tab[5];   // [0] = tile mask, [1..4] = column blocks
+
+    // the per-atom energies of the fused kernel are independent of this GEMM: a few extra workgroups (the tiles leave half
+    // of the CUs idle) finish them here instead of in a launch of their own in front of this one
+    if (fin.first_block > 0 && (int)blockIdx.x >= fin.first_block) {
+        fused_finish(fin, (int64_t)(blockIdx.x - fin.first_block) * L0S_THREADS + threadIdx.x,
+                     (int64_t)(gridDim.x - fin.first_block) * L0S_THREADS);
+        return;
+    }
+    const int nwg = fin.first_block > 0 ? fin.first_block : (int)gridDim.x;
+    int id = blockIdx.x;
+    {
+        const int qd = nwg >> 3, rm = nwg & 7, xcd = id & 7;
+        id = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (id >> 3);
+    }
+    const int col_t = id % g.ncol_max;
+    const int row_t = id / g.ncol_max;
+    const int *ctl = g.ctl;
+    if (row_t >= ctl[CTL_TILE + g.S]) return;
+    int s = 0;
+    while (s + 1 < g.S && row_t >= ctl[CTL_TILE + s + 1]) ++s;
+    const GemmProblem &pr = g.prob[s];
+    const int m0 = (row_t - ctl[CTL_TILE + s]) * BM;
+    const int n_rows = ctl[CTL_CNT + s] - m0;
+    const int p0 = ctl[CTL_OFF + s] + m0;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 3, wc = wave >> 2;
+    const int srow = tid >> 2, piece = tid & 3;
+    const int arow = srow < n_rows ? srow : 0;
+
+    // the tile's column blocks: the (4 col_t .. 4 col_t + 3)-th blocks flagged in the OR of its atoms' masks
+    {
+        uint32_t mk = g.stage_mask[g.c_scatter[p0 + arow]];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mk |= (uint32_t)__shfl_xor((int)mk, o);
+        if (tid == 0) s_tab[0] = 0;
+        __syncthreads();
+        if (lane == 0) atomicOr(reinterpret_cast<unsigned *>(&s_tab[0]), mk);
+        __syncthreads();
+        const uint32_t tmask = (uint32_t)s_tab[0];
+        if (4 * col_t >= __popc(tmask)) return;   // (also: atoms without neighbors, nothing to differentiate)
+        if (tid < 4) {
+            uint32_t m = tmask;
+            for (int k = 0; k < 4 * col_t + tid; ++k) m &= m - 1;
+            s_tab[1 + tid] = m ? (int)__builtin_ctz(m) : -1;
+        }
+        __syncthreads();
+    }
+    const int cb0 = __builtin_amdgcn_readfirstlane(s_tab[1]);
+    const int cmine = s_tab[1 + (srow >> 5)];                     // block of the B row this thread stages
+    // this wave's two column blocks (-1: none); wave-uniform, and the branches below must look uniform to the compiler
+    const int cw[2] = {__builtin_amdgcn_readfirstlane(s_tab[1 + 2 * wc]), __builtin_amdgcn_readfirstlane(s_tab[2 + 2 * wc])};
+    const int nbw = cw[0] < 0 ? 0 : (cw[1] < 0 ? 1 : 2);
+
+    const float sa = amax_scale(g.amax, g.amax_in, s);
+    const float out_scale = pr.w_inv_scale / sa;
+    const gf4 *a_src = (const gf4 *)(g.A + (int64_t)(p0 + arow) * g.lda + piece * 8);
+    const _Float16 *b_src = pr.Bh + (int64_t)((cmine >= 0 ? cmine : cb0) * 32 + (srow & 31)) * pr.ldbh + piece * 8;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int nk = pr.K / HBK;
+    if (nbw == 2) l0s_kloop<2>(acc, a_src, sa, b_src, pr.bh_plane, nk, sm, wr, wc);
+    else l0s_kloop<1>(acc, a_src, sa, b_src, pr.bh_plane, nk, sm, wr, wc);   // (a wave without a block stages and idles along)
+    if (nbw == 0) return;
+
+    const int fr = lane & 31, fk = lane >> 5;
+    int dst[16];   // destination rows first, the stores do not wait on them one by one
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+        dst[r] = row < n_rows ? g.c_scatter[p0 + row] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j >= nbw) continue;
+        const int cb = cw[j];
+        const int feat = g.kp_rad ? kp_col(g.kp_rad, cb) + fr : cb * 32 + fr;
+        const bool okc = (g.kp_rad ? fr < kp_valid(g.kp_rad, cb) : true) && feat < g.n_store;
+        if (!okc) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (dst[r] >= 0) g.C[(int64_t)dst[r] * g.ldc + feat] = acc[j][r] * out_scale;
+    }
 }
 
 // ---- f16x3 grouped GEMM, 256 x 256 x 32 tiles (layer-0 GEMMs) -----------------------------------------
@@ -1518,6 +1749,178 @@ __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const
     if (lane == 0) tile_tab[tile0] = make_int4(s, p0, n_rows, (int)mk);
 }
 
+// ---- small inputs: the whole preparation in ONE launch ------------------------------------------------------------
+// Below SMALL_PREP_MAX atoms a step is bound by the number of dependent launches, not by work.  Block 0 (16 waves) does what
+// zero_words + k_sp_count + k_sp_offsets + k_sp_scatter + k_tile_table do in five launches: every wave loads its
+// contiguous chunk of species (and slab flags) in one go, counts, the counts are scanned through LDS, the atoms are
+// scattered into an LDS copy of the permutation (same stable order as the chunked kernels: index order inside a species),
+// and the tile table is resolved from LDS.  Blocks 1.. zero the rows of the padding atoms (k_zero_padding).
+constexpr int SMALL_PREP_MAX = 16384;
+constexpr int SMALL_PREP_WAVES = 16;
+constexpr int SMALL_PREP_ITERS = SMALL_PREP_MAX / (SMALL_PREP_WAVES * WAVE);   // 16
+
+__global__ __launch_bounds__(SMALL_PREP_WAVES * WAVE) void k_small_prep(
+    int64_t lo, int64_t hi, const int32_t *species, int S, int *ctl, int *perm, const uint32_t *slab_mask,
+    uint32_t all_slabs, int tiles_total, int rows_per_tile, int4 *tile_tab, int *tile_rows, float *atomic_e,
+    float *grad_aev, int L, float *member_e, int M, int64_t n_atoms)
+{
+    extern __shared__ int s_dyn[];   // [n] permutation, [n] slab flags in sorted order, [tiles] OR of the flags per tile
+    __shared__ int s_cnt[SMALL_PREP_WAVES][MAX_S];
+    __shared__ int s_ctl[CTL_WORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x > 0) {   // padding atoms: zero energy / zero gradient rows, one wave per atom
+        const int64_t nw = (int64_t)(gridDim.x - 1) * SMALL_PREP_WAVES;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t i = lo + (int64_t)(blockIdx.x - 1) * SMALL_PREP_WAVES + wave; i < hi; i += nw) {
+            if (species[i] >= 0) continue;
+            if (lane == 0) atomic_e[i] = 0.f;
+            if (member_e && lane < M) member_e[(int64_t)lane * n_atoms + i] = 0.f;
+            if (grad_aev) {
+                float4 *row = reinterpret_cast<float4 *>(grad_aev + (size_t)i * L);
+                for (int f = lane; f < (L >> 2); f += WAVE) row[f] = z4;
+            }
+        }
+        return;
+    }
+    const int n = (int)(hi - lo);
+    int *s_perm = s_dyn, *s_mask = s_dyn + n;
+    const int chunk = (((n + SMALL_PREP_WAVES - 1) / SMALL_PREP_WAVES) + WAVE - 1) & ~(WAVE - 1);
+    const int c0 = wave * chunk;
+    int sp[SMALL_PREP_ITERS];
+    uint32_t mk[SMALL_PREP_ITERS];
+#pragma unroll
+    for (int it = 0; it < SMALL_PREP_ITERS; ++it) {
+        const int r = c0 + it * WAVE + lane;
+        const bool ok = it * WAVE < chunk && r < n;
+        sp[it] = ok ? species[lo + r] : -1;
+        mk[it] = (ok && slab_mask) ? slab_mask[lo + r] : all_slabs;
+    }
+    // running maxima behind the control block start from zero; the control words themselves are written below
+    for (int q = CTL_WORDS + tid; q < CTL_WORDS + AMAX_WORDS; q += SMALL_PREP_WAVES * WAVE) ctl[q] = 0;
+    if (tid < CTL_WORDS) s_ctl[tid] = 0;
+    int cnt[MAX_S];
+#pragma unroll
+    for (int t = 0; t < MAX_S; ++t) cnt[t] = 0;
+#pragma unroll
+    for (int it = 0; it < SMALL_PREP_ITERS; ++it)
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t)
+            if (t < S) cnt[t] += __popcll(__ballot(sp[it] == t));
+    if (lane < MAX_S) {
+        int v = 0;
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) v = lane == t ? cnt[t] : v;
+        s_cnt[wave][lane] = v;
+    }
+    __syncthreads();
+    // thread t < S: exclusive scan of the waves' counts of species t (16 independent LDS reads), totals -> s_tot
+    __shared__ int s_tot[MAX_S];
+    if (tid < MAX_S) {
+        int c[SMALL_PREP_WAVES], run = 0;
+#pragma unroll
+        for (int w = 0; w < SMALL_PREP_WAVES; ++w) c[w] = s_cnt[w][tid];
+#pragma unroll
+        for (int w = 0; w < SMALL_PREP_WAVES; ++w) {
+            s_cnt[w][tid] = run;
+            run += c[w];
+        }
+        s_tot[tid] = tid < S ? run : 0;
+    }
+    __syncthreads();
+    // every thread: species offsets / first tiles (registers), its wave's scatter bases
+    int base[MAX_S], off[MAX_S + 1], tfirst[MAX_S + 1];
+    {
+        int tot = 0, trun = 0, ftrun = 0;
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) {
+            const int all = s_tot[t];
+            off[t] = tot;
+            tfirst[t] = ftrun;
+            base[t] = tot + s_cnt[wave][t];
+            if (tid == 0 && t < S) {
+                s_ctl[CTL_CNT + t] = all;
+                s_ctl[CTL_OFF + t] = tot;
+                s_ctl[CTL_TILE + t] = trun;
+            }
+            tot += all;
+            trun += (all + BM - 1) / BM;
+            ftrun += (all + rows_per_tile - 1) / rows_per_tile;
+        }
+        off[MAX_S] = tot;
+        tfirst[MAX_S] = ftrun;
+        if (tid == 0) {
+            s_ctl[CTL_OFF + S] = tot;
+            s_ctl[CTL_TILE + S] = trun;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < SMALL_PREP_ITERS; ++it) {
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t)
+            if (t < S) {
+                const uint64_t m = __ballot(sp[it] == t);
+                if (sp[it] == t) {
+                    const int pos = base[t] + mbcnt(m);
+                    s_perm[pos] = (int)lo + c0 + it * WAVE + lane;
+                    s_mask[pos] = (int)mk[it];
+                }
+                base[t] += __popcll(m);
+            }
+    }
+    // (s_tmask: OR of the slab flags of a tile's atoms, behind the two [n] arrays)
+    int *s_tmask = s_dyn + 2 * n;
+    if (tile_tab)
+        for (int q = tid; q < tiles_total; q += SMALL_PREP_WAVES * WAVE) s_tmask[q] = 0;
+    __syncthreads();
+    if (tid < CTL_WORDS) ctl[tid] = s_ctl[tid];
+    const int tot = off[MAX_S];
+    const int shift = rows_per_tile == 64 ? 6 : 5;
+    for (int q = tid; q < tot; q += SMALL_PREP_WAVES * WAVE) {
+        const int atom = s_perm[q];
+        perm[q] = atom;
+        if (tile_tab) {
+            int s = 0;
+#pragma unroll
+            for (int t = 1; t < MAX_S; ++t) s += q >= off[t] ? 1 : 0;   // (empty species share an offset: the last one wins)
+            const int rel = q - off[s];
+            int tf = 0;
+#pragma unroll
+            for (int t = 0; t < MAX_S; ++t) tf = s == t ? tfirst[t] : tf;
+            const int tile = tf + (rel >> shift);
+            tile_rows[(size_t)tile * rows_per_tile + (rel & (rows_per_tile - 1))] = atom;
+            atomicOr(&s_tmask[tile], s_mask[q]);
+        }
+    }
+    if (!tile_tab) return;
+    __syncthreads();
+    // one thread per tile: its entry, and the rows a partial (or empty) tile leaves open
+    for (int tile0 = tid; tile0 < tiles_total; tile0 += SMALL_PREP_WAVES * WAVE) {
+        int s = -1;
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t)
+            if (t < S && tile0 >= tfirst[t] && tile0 < tfirst[t + 1]) s = t;
+        int *rows = tile_rows + (size_t)tile0 * rows_per_tile;
+        if (s < 0) {   // (the fused kernel prefetches the rows of the next item before it looks at its entry: atom 0)
+            tile_tab[tile0] = make_int4(-1, 0, 0, 0);
+            for (int r = 0; r < rows_per_tile; ++r) rows[r] = 0;
+            continue;
+        }
+        int o = 0, tf = 0, c = 0;
+#pragma unroll
+        for (int t = 0; t < MAX_S; ++t) {
+            o = s == t ? off[t] : o;
+            tf = s == t ? tfirst[t] : tf;
+            c = s == t ? off[t + 1] - off[t] : c;
+        }
+        const int tile = tile0 - tf;
+        const int n_rows = min(rows_per_tile, c - tile * rows_per_tile);
+        const int p0 = o + tile * rows_per_tile;
+        tile_tab[tile0] = make_int4(s, p0, n_rows, s_tmask[tile0]);
+        const int last = s_perm[p0 + n_rows - 1];
+        for (int r = n_rows; r < rows_per_tile; ++r) rows[r] = last;
+    }
+}
+
 // wave-uniform dispatch on the active part of a wave's accumulators in a phase (compile-time inside)
 #define FR_UNIT(u, CALL)                                                                    \
     if ((u).nrb == RB && (u).nba >= NB) { constexpr int RBA = RB, NBA = NB; CALL; }         \
@@ -2052,20 +2455,24 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #undef FR_UNIT
 
 // sum the per-member energies of the fused kernel: atomic_e = mean_m, optional [M][n_atoms] copy
-__global__ void k_fused_finish(const int *ctl, int S, int M, const int *perm, const float *member_part,
-                               float *atomic_e, float *member_e, int64_t n_atoms)
+__device__ __forceinline__ void fused_finish(const FinishArgs &f, int64_t first, int64_t stride)
 {
-    const int64_t n = ctl[CTL_OFF + S];
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
-        const int atom = perm[p];
+    const int64_t n = f.ctl[CTL_OFF + f.S];
+    for (int64_t p = first; p < n; p += stride) {
+        const int atom = f.perm[p];
         float e = 0.f;
-        for (int m = 0; m < M; ++m) {
-            const float v = member_part[p * M + m];
+        for (int m = 0; m < f.M; ++m) {
+            const float v = f.member_part[p * f.M + m];
             e += v;
-            if (member_e) member_e[(int64_t)m * n_atoms + atom] = v;
+            if (f.member_e) f.member_e[(int64_t)m * f.n_atoms + atom] = v;
         }
-        atomic_e[atom] = e / (float)M;
+        f.atomic_e[atom] = e / (float)f.M;
     }
+}
+
+__global__ void k_fused_finish(FinishArgs f)
+{
+    fused_finish(f, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 // ---- output layer: energies + seed of the backward pass --------------------------------------------
@@ -2415,7 +2822,49 @@ __global__ __launch_bounds__(256) void k_energy_reduce(int n_mol, int A, int64_t
     __shared__ double part[4];
     if (lane_id() == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&mol_e[mol], part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        const double v = part[0] + part[1] + part[2] + part[3];
+        if (gridDim.y == 1) mol_e[mol] = v;   // (one block per molecule: plain store, mol_e needs no zero fill)
+        else atomicAdd(&mol_e[mol], v);
+    }
+}
+
+// energies + forces = -gradient in one launch (few atoms per molecule): blocks 0 .. n_mol - 1 reduce one molecule each,
+// the others negate 1024 floats of the gradient each
+__global__ __launch_bounds__(256) void k_energy_forces_finish(int n_mol, int A, int64_t lo, int64_t hi,
+                                                              const int32_t *species, const float *atomic_e,
+                                                              const double *sae, double *mol_e, float *grad, int64_t n_grad)
+{
+    if ((int)blockIdx.x >= n_mol) {
+        const int64_t i0 = ((int64_t)blockIdx.x - n_mol) * 1024 + threadIdx.x * 4;
+        if (i0 + 4 <= n_grad && ((uintptr_t)grad & 15) == 0) {
+            float4 *p = reinterpret_cast<float4 *>(grad + i0);
+            const float4 v = *p;
+            *p = make_float4(-v.x, -v.y, -v.z, -v.w);
+        } else {
+            for (int64_t i = i0; i < i0 + 4 && i < n_grad; ++i) grad[i] = -grad[i];
+        }
+        return;
+    }
+    const int mol = blockIdx.x;
+    double acc = 0.0;
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        const int64_t i = (int64_t)mol * A + a;
+        if (i < lo || i >= hi) continue;
+        const int sp = species[i];
+        if (sp < 0) continue;
+        acc += (double)atomic_e[i] + (sae ? sae[sp] : 0.0);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double part[4];
+    if (lane_id() == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) mol_e[mol] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void k_negate(float *x, int64_t n)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) x[i] = -x[i];
 }
 
 struct MlpWorkspace {
@@ -2577,9 +3026,39 @@ template <int EPI>
 static void launch_gemm(hipStream_t stream, GemmArgs &g, bool f16x3)
 {
     const int64_t total = (int64_t)g.nrow_tiles_ub * g.ncol_max * g.batch;
-    if (f16x3)
+    if (f16x3) {
+#ifdef ANIHIP_DEV_TRACE
+        const bool tr = EPI == EPI_SCATTER && getenv("ANIHIP_GEMM_TRACE");
+        if (tr) (void)hipMemsetAsync(g_gemm_trace, 0, sizeof(g_gemm_trace), stream);   // (symbol address: dev builds only)
+#endif
         hipLaunchKernelGGL((k_gemm_h<EPI>), dim3((unsigned)total), dim3(GEMM_THREADS), 0, stream, g);
-    else
+#ifdef ANIHIP_DEV_TRACE
+        if (tr) {
+            static unsigned long long host[8 * 4096];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), sizeof(host));
+            double sum[4] = {0, 0, 0, 0}, cyc[4] = {0, 0, 0, 0};
+            unsigned long long w0 = ~0ull, w1 = 0;
+            int live = 0;
+            for (int b = 0; b < 4096 && b < total; ++b) {
+                const unsigned long long *h = host + 8 * b;
+                if (!h[7]) continue;   // (exited before the end stamp)
+                ++live;
+                for (int k = 0; k < 3; ++k) {
+                    sum[k] += (double)(h[2 * k + 3] - h[2 * k + 1]) * 10.0;   // ns (100 MHz)
+                    cyc[k] += (double)(h[2 * k + 2] - h[2 * k]);
+                }
+                w0 = h[1] < w0 ? h[1] : w0;
+                w1 = h[7] > w1 ? h[7] : w1;
+            }
+            if (live)
+                fprintf(stderr, "k_gemm_h trace: %d live of %lld workgroups; mean ns  prologue %.0f  loop %.0f  epilogue %.0f;"
+                        " mean shader clocks %.0f %.0f %.0f; first start -> last end %.0f ns\n", live, (long long)total,
+                        sum[0] / live, sum[1] / live, sum[2] / live, cyc[0] / live, cyc[1] / live, cyc[2] / live,
+                        (double)(w1 - w0) * 10.0);
+        }
+#endif
+    } else
         hipLaunchKernelGGL((k_gemm<EPI>), dim3((unsigned)total), dim3(GEMM_THREADS), 0, stream, g);
 }
 
@@ -2612,20 +3091,6 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     const int K0p = kp_rad > 0 ? 32 * ((kp_rad + 31) / 32 + (L - kp_rad) / 32) : ((L + 31) / 32) * 32;
     const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
 
-    // 1. bucket by species
-    zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
-    const unsigned nblk = (unsigned)((n + 255) / 256);
-    const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
-    {   // (scratch: the per-member energies buffer is written only later)
-        int *chunk_cnt = reinterpret_cast<int *>(w.member_part);
-        const int n_chunks = (int)((n + SP_CHUNK - 1) / SP_CHUNK);
-        hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, chunk_cnt);
-        hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(256), 0, stream, S, n_chunks, chunk_cnt, w.ctl);
-        hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm);
-    }
-    hipLaunchKernelGGL(k_zero_padding, dim3(zero_pad_blocks(n)), dim3(256), 0, stream, lo, hi, species,
-                       atomic_e, grad_aev, L, member_e, M, n_atoms);
-
     const int nrow_ub = (int)((n + BM - 1) / BM) + S;
     auto ncol_of = [&](int l_out, bool cat) {
         int mx = 0;
@@ -2656,6 +3121,36 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     // per-atom slab flags: honoured by the 256 x 256 kernels on slab-ordered planes
     const uint32_t *smask = (big_tiles && kp_rad > 0 && K0p <= 32 * 32) ? slab_mask : nullptr;
     if (d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK) smask = nullptr;
+
+    // 1. bucket by species (+ the tile table of the fused kernel and the padding rows, one launch for small inputs)
+    const int fused_rows = ((d->flags & ANIHIP_MLP_FLAG_FUSED_ROWS32) && d->activation == ANIHIP_ACT_CELU) ? 32 : 64;
+    const int64_t fused_tiles = (n + fused_rows - 1) / fused_rows + S;
+    const int n_slabs = K0p / 32;
+    const uint32_t *tab_mask = (kp_rad > 0 && !(d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK)) ? slab_mask : nullptr;
+    const uint32_t all_slabs = n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << n_slabs) - 1u);
+    const bool small_prep = n <= SMALL_PREP_MAX && !(d->flags & ANIHIP_MLP_FLAG_NO_SMALL_PREP);
+    if (small_prep) {
+        const size_t lds = sizeof(int) * (2 * (size_t)n + (size_t)fused_tiles);
+        ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_small_prep, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds));
+        int64_t pad_blocks = (n + SMALL_PREP_WAVES - 1) / SMALL_PREP_WAVES;   // one atom per wave
+        if (pad_blocks < 1) pad_blocks = 1;
+        hipLaunchKernelGGL(k_small_prep, dim3((unsigned)(1 + pad_blocks)), dim3(SMALL_PREP_WAVES * WAVE), lds, stream,
+                           lo, hi, species, S, w.ctl, w.perm, tab_mask, all_slabs, (int)fused_tiles, fused_rows,
+                           fused ? w.tile_tab : (int4 *)nullptr, w.tile_rows, atomic_e, grad_aev, L, member_e, M,
+                           n_atoms);
+    } else {
+        zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
+        const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
+        // (scratch: the per-member energies buffer is written only later)
+        int *chunk_cnt = reinterpret_cast<int *>(w.member_part);
+        const int n_chunks = (int)((n + SP_CHUNK - 1) / SP_CHUNK);
+        hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, chunk_cnt);
+        hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(256), 0, stream, S, n_chunks, chunk_cnt, w.ctl);
+        hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm);
+        hipLaunchKernelGGL(k_zero_padding, dim3(zero_pad_blocks(n)), dim3(256), 0, stream, lo, hi, species,
+                           atomic_e, grad_aev, L, member_e, M, n_atoms);
+    }
 
     // 2. forward through the hidden layers
     for (int l = 0; l < (fused ? 0 : nh); ++l) {
@@ -2703,12 +3198,16 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         }
     }
 
+    FinishArgs fin{};
+    // few atoms: the layer-0 backward runs in the 8-wave 128 x 128 kernel (needs the slab flags for its column compaction)
+    const bool use_l0s = grad_aev && h3 && !big_tiles && kp_rad > 0 && K0p <= 32 * 32 && slab_mask &&
+                         !(d->flags & (ANIHIP_MLP_FLAG_NO_SLAB_MASK | ANIHIP_MLP_FLAG_L0B_4WAVE));
     if (fused) {
         FusedArgs f{};
         size_t lds = 0;
         // tiling: 64 atoms x 8 waves, one workgroup per CU (default: 3 % faster on the water box), or
         // 32 atoms x 4 waves, two per CU (ANIHIP_MLP_FLAG_FUSED_ROWS32)
-        const int rows = ((d->flags & ANIHIP_MLP_FLAG_FUSED_ROWS32) && d->activation == ANIHIP_ACT_CELU) ? 32 : 64;
+        const int rows = fused_rows;
         for (int s = 0; s < S; ++s) {
             const anihip_species_net &nn = d->net[s];
             FusedSpecies &fs = f.sp[s];
@@ -2726,9 +3225,8 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             halves += (rows == 64 ? FusedCfg<2, 1>::FIXED_BYTES : FusedCfg<1, 2>::FIXED_BYTES) / 2 + FR_GROUP * slab;   // = FIXED_HALVES
             lds = lds > halves * 2 ? lds : halves * 2;
         }
-        f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = K0p / 32;
-        f.slab_mask = kp_rad > 0 ? slab_mask : nullptr;
-        if (d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK) f.slab_mask = nullptr;
+        f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = n_slabs;
+        f.slab_mask = tab_mask;
         f.d0 = w.act[0]; f.ld0 = w.ld[0]; f.perm = w.perm;
         // tile-major hand-over to the 256 x 256 layer-0 backward GEMM (the 128 x 128 kernel of small inputs reads rows)
         f.d0_tm = (big_tiles && grad_aev) ? 1 : 0;
@@ -2741,7 +3239,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         const void *kfn = rows == 64 ? (gelu ? (const void *)k_mlp_fused<2, 1, 1> : (const void *)k_mlp_fused<2, 1, 0>)
                                      : (const void *)k_mlp_fused<1, 2, 0>;
         ANIHIP_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const int64_t tiles = (n + rows - 1) / rows + S;
+        const int64_t tiles = fused_tiles;
         f.tiles_total = (int)tiles;
         // persistent workgroups over the (member, tile) items, as many as are resident at once
         static int n_cus = 0;
@@ -2754,9 +3252,9 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         const int64_t items = tiles * M;
         const int64_t resident = (int64_t)n_cus * (2 * lds <= 160 * 1024 ? 2 : 1);
         const int64_t grid = items < resident ? items : resident;
-        hipLaunchKernelGGL(k_tile_table, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, w.ctl, S, w.perm,
-                           f.slab_mask, f.n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << f.n_slabs) - 1u), (int)tiles,
-                           rows, w.tile_tab, w.tile_rows);
+        if (!small_prep)
+            hipLaunchKernelGGL(k_tile_table, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, w.ctl, S, w.perm,
+                               f.slab_mask, all_slabs, (int)tiles, rows, w.tile_tab, w.tile_rows);
 #ifdef ANIHIP_DEV_TRACE   // development builds only (tools/fused_trace.py): per-item phase stamps, allocates and synchronises
         const char *trace_path = getenv("ANIHIP_FUSED_TRACE");
         const size_t trace_words = (size_t)16 * 8 * items;   // [item][wave][16]
@@ -2784,10 +3282,13 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             }
         }
 #endif
-        int64_t fb = (n + 255) / 256;
-        if (fb > 2048) fb = 2048;
-        hipLaunchKernelGGL(k_fused_finish, dim3((unsigned)fb), dim3(256), 0, stream, w.ctl, S, M, w.perm,
-                           w.member_part, atomic_e, member_e, n_atoms);
+        fin.ctl = w.ctl; fin.perm = w.perm; fin.member_part = w.member_part; fin.atomic_e = atomic_e;
+        fin.member_e = member_e; fin.n_atoms = n_atoms; fin.S = S; fin.M = M; fin.first_block = 0;
+        if (!use_l0s) {   // (the 8-wave layer-0 backward of small inputs does this in extra workgroups)
+            int64_t fb = (n + 255) / 256;
+            if (fb > 2048) fb = 2048;
+            hipLaunchKernelGGL(k_fused_finish, dim3((unsigned)fb), dim3(256), 0, stream, fin);
+        }
     }
 
     // 3. output layer (+ seed of the backward pass, written in place over the last activations)
@@ -2858,6 +3359,17 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             }
             if (l == 0 && h3 && big_tiles) {
                 if (int rc = launch_gemm_big<EPI_SCATTER>(stream, g, n)) return rc;
+            } else if (l == 0 && use_l0s) {
+                const int64_t total = (int64_t)g.nrow_tiles_ub * g.ncol_max;
+                const size_t lds = sizeof(_Float16) * L0S_BUFS * 4 * H_PLANE;
+                ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_gemm_l0s, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)lds));
+                int64_t fb = 0;
+                if (fused) {
+                    fb = (n + L0S_THREADS - 1) / L0S_THREADS;
+                    fin.first_block = (int)total;
+                }
+                hipLaunchKernelGGL(k_gemm_l0s, dim3((unsigned)(total + fb)), dim3(L0S_THREADS), lds, stream, g, fin);
             } else if (l == 0) {
                 launch_gemm<EPI_SCATTER>(stream, g, h3);
             } else {
@@ -3299,12 +3811,35 @@ extern "C" int anihip_energy_reduce(void *stream_, int32_t n_mol, int32_t A, int
     hipStream_t stream = (hipStream_t)stream_;
     ANIHIP_REQUIRE(species && atomic_e && mol_e, "null pointer argument");
     ANIHIP_REQUIRE(n_mol >= 1 && A >= 1, "bad shape");
-    zero_words_async(stream, mol_e, sizeof(double) * (size_t)n_mol);
     int ny = (A + 256 * 16 - 1) / (256 * 16);
     if (ny < 1) ny = 1;
     if (ny > 1024) ny = 1024;
+    if (ny > 1) zero_words_async(stream, mol_e, sizeof(double) * (size_t)n_mol);
     hipLaunchKernelGGL(k_energy_reduce, dim3((unsigned)n_mol, (unsigned)ny), dim3(256), 0, stream, (int)n_mol,
                        (int)A, lo, hi, species, atomic_e, sae, mol_e);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int anihip_energy_forces_finish(void *stream_, int32_t n_mol, int32_t A, int64_t lo, int64_t hi,
+                                           const int32_t *species, const float *atomic_e, const double *sae,
+                                           double *mol_e, float *grad_coords, int64_t n_grad)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    ANIHIP_REQUIRE(species && atomic_e && mol_e, "null pointer argument");
+    ANIHIP_REQUIRE(n_mol >= 1 && A >= 1 && n_grad >= 0 && (grad_coords || n_grad == 0), "bad shape");
+    if (A <= 256 * 16) {   // (one block per molecule is enough: everything in one launch)
+        const int64_t nblk = (n_grad + 1023) / 1024;
+        hipLaunchKernelGGL(k_energy_forces_finish, dim3((unsigned)(n_mol + nblk)), dim3(256), 0, stream, (int)n_mol, (int)A,
+                           lo, hi, species, atomic_e, sae, mol_e, grad_coords, n_grad);
+    } else {
+        if (int rc = anihip_energy_reduce(stream_, n_mol, A, lo, hi, species, atomic_e, sae, mol_e)) return rc;
+        if (n_grad > 0) {
+            int64_t nblk = (n_grad + 1023) / 1024;
+            if (nblk > 4096) nblk = 4096;
+            hipLaunchKernelGGL(k_negate, dim3((unsigned)nblk), dim3(256), 0, stream, grad_coords, n_grad);
+        }
+    }
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -83,9 +83,8 @@ __device__ void inv3(const double *m, double *o)
 
 // ---- setup -------------------------------------------------------------------------------------
 
-__global__ void k_desc_init(GridDesc *g, const float *cell, int pbc_mask, float cutoff)
+__device__ void desc_fill(GridDesc *g, const float *cell, int pbc_mask, float cutoff)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int q = 0; q < 9; ++q) g->cell[q] = cell ? (double)cell[q] : ((q % 4 == 0) ? 1.0 : 0.0);
     inv3(g->cell, g->inv);
     for (int k = 0; k < 3; ++k) {
@@ -101,6 +100,14 @@ __global__ void k_desc_init(GridDesc *g, const float *cell, int pbc_mask, float 
         g->range[k] = 0;
     }
     g->ncell = 1;
+}
+
+// first kernel of a build: the descriptor, and the status words start from zero
+__global__ void k_desc_init(GridDesc *g, const float *cell, int pbc_mask, float cutoff, uint32_t *status)
+{
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x < ANIHIP_STATUS_WORDS) status[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) desc_fill(g, cell, pbc_mask, cutoff);
 }
 
 // fractional bounding box of the real atoms (needed along non-periodic axes only)
@@ -174,22 +181,30 @@ __global__ void k_grid_setup(GridDesc *g, float cutoff, int64_t max_cells, uint3
 
 // ---- batch mode: packed (wrapped) positions -------------------------------------------------------
 
-__global__ void k_prep_batch(const GridDesc *g, int64_t n, const int32_t *species, const float *coords,
-                             float4 *pos4)
+// (also the first kernel of a batch build: block 0 writes the descriptor k_nbr_batch reads and resets the status words;
+// the wrap itself works from the caller's cell so that it does not have to wait for a descriptor kernel)
+__global__ void k_prep_batch(GridDesc *g, int64_t n, const int32_t *species, const float *coords, float4 *pos4,
+                             const float *cell, int pbc_mask, float cutoff, uint32_t *status)
 {
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < ANIHIP_STATUS_WORDS) status[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) desc_fill(g, cell, pbc_mask, cutoff);
+    }
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
-    if (g->pbc[0] | g->pbc[1] | g->pbc[2]) {
+    if (cell && (pbc_mask & 7)) {
         // utils.py:237-255 map_to_central, in double
-        double f[3];
+        double c[9], inv[9], f[3];
+        for (int q = 0; q < 9; ++q) c[q] = (double)cell[q];
+        inv3(c, inv);
         for (int k = 0; k < 3; ++k) {
-            f[k] = (double)x * g->inv[0 + k] + (double)y * g->inv[3 + k] + (double)z * g->inv[6 + k];
-            if (g->pbc[k]) f[k] -= floor(f[k]);
+            f[k] = (double)x * inv[0 + k] + (double)y * inv[3 + k] + (double)z * inv[6 + k];
+            if ((pbc_mask >> k) & 1) f[k] -= floor(f[k]);
         }
-        x = (float)(f[0] * g->cell[0] + f[1] * g->cell[3] + f[2] * g->cell[6]);
-        y = (float)(f[0] * g->cell[1] + f[1] * g->cell[4] + f[2] * g->cell[7]);
-        z = (float)(f[0] * g->cell[2] + f[1] * g->cell[5] + f[2] * g->cell[8]);
+        x = (float)(f[0] * c[0] + f[1] * c[3] + f[2] * c[6]);
+        y = (float)(f[0] * c[1] + f[1] * c[4] + f[2] * c[7]);
+        z = (float)(f[0] * c[2] + f[1] * c[5] + f[2] * c[8]);
     }
     int sp = species[i];
     uint32_t w = ((uint32_t)i & IDX_MASK) | ((sp < 0 ? SP_PAD : (uint32_t)sp) << 28);
@@ -985,9 +1000,8 @@ extern "C" int anihip_nbr_build_batch(void *stream_, const anihip_aev_params *p,
     ANIHIP_REQUIRE(row_cap >= 1 && (hi - lo) * row_cap < ((int64_t)1 << 32), "bad ent_capacity");
     NbrWorkspace w;
     carve(&w, (char *)workspace, n, 1);
-    hipLaunchKernelGGL(k_desc_init, dim3(1), dim3(64), 0, stream, w.desc, cell, pbc_mask, p->Rcr);
     hipLaunchKernelGGL(k_prep_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w.desc, n,
-                       species, coords, w.pos4);
+                       species, coords, w.pos4, cell, pbc_mask, p->Rcr, status);
     hipLaunchKernelGGL(k_nbr_batch, dim3(nbr_grid_blocks(hi - lo)), dim3(NBR_WPB * WAVE), 0, stream,
                        w.desc, p->num_species, p->Rcr * p->Rcr, p->Rca * p->Rca, (int)A, lo, hi, w.pos4,
                        (int)(row_cap > MAXR ? MAXR : row_cap), meta, (float4 *)ent, status);
@@ -1015,7 +1029,7 @@ extern "C" int anihip_nbr_build_cell(void *stream_, const anihip_aev_params *p, 
     carve(&w, (char *)workspace, n, max_cells);
     const unsigned nblk = (unsigned)((n + 255) / 256);
     const unsigned cblk = (unsigned)((max_cells + 1 + 1023) / 1024);
-    hipLaunchKernelGGL(k_desc_init, dim3(1), dim3(64), 0, stream, w.desc, cell, pbc_mask, p->Rcr);
+    hipLaunchKernelGGL(k_desc_init, dim3(1), dim3(64), 0, stream, w.desc, cell, pbc_mask, p->Rcr, status);
     const bool all_pbc = cell && ((pbc_mask & 7) == 7);
     if (!all_pbc)
         hipLaunchKernelGGL(k_bbox, dim3(nblk > 1024 ? 1024 : nblk), dim3(256), 0, stream, w.desc, n,

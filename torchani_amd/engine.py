@@ -134,7 +134,8 @@ class AevEngine:
         n_central = max(hi - lo, 0)
         meta = torch.empty((n, _lib.META_WORDS), dtype=torch.int32, device=dev)
         ent = torch.empty((max(n_central, 1) * row_cap, 4), dtype=torch.float32, device=dev)
-        status = torch.zeros(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
+        # (the two builders reset the status words in their first kernel, include/anihip.h; an empty range returns early)
+        status = (torch.empty if n_central > 0 else torch.zeros)(_lib.STATUS_WORDS, dtype=torch.int32, device=dev)
         L = _lib.lib()
         if mode == "batch":
             ws = torch.empty(L.anihip_nbr_workspace_bytes(n, 1), dtype=torch.uint8, device=dev)
@@ -732,4 +733,21 @@ def energy_reduce(species: Tensor, atomic_e: Tensor, sae: tp.Optional[Tensor], l
         assert sae.dtype == torch.float64
     _lib.check(_lib.lib().anihip_energy_reduce(
         _stream(), Cn, A, lo, hi, _ptr(species), _ptr(atomic_e), _ptr(sae), _ptr(out)))
+    return out
+
+
+def energy_forces_finish(species: Tensor, atomic_e: Tensor, sae: tp.Optional[Tensor], grad_coords: Tensor, lo: int = 0,
+                         hi: tp.Optional[int] = None) -> Tensor:
+    """energy_reduce, and ``grad_coords`` (float32, contiguous) negated IN PLACE into forces, in one launch for batches of
+    small molecules (anihip_energy_forces_finish).  Returns the molecular energies [C] in float64."""
+    _require_cuda(species, atomic_e, sae, grad_coords)
+    Cn, A = species.shape
+    hi = Cn * A if hi is None else hi
+    assert grad_coords.dtype == torch.float32 and grad_coords.is_contiguous()
+    if sae is not None:
+        assert sae.dtype == torch.float64
+    out = torch.empty(Cn, dtype=torch.float64, device=species.device)
+    _lib.check(_lib.lib().anihip_energy_forces_finish(
+        _stream(), Cn, A, lo, hi, _ptr(species), _ptr(atomic_e), _ptr(sae), _ptr(out), _ptr(grad_coords),
+        grad_coords.numel()))
     return out

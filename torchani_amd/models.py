@@ -25,7 +25,7 @@ from .aev import AEVComputer
 from ._lib import MAX_RAD
 from ._lib import MAX_RAD as _lib_MAX_RAD
 from .constants import GSAES_WB97X_631GD  # noqa: F401
-from .engine import FIXED_SCALE, energy_reduce, fixed_to_float
+from .engine import FIXED_SCALE, energy_forces_finish, energy_reduce, fixed_to_float
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import join_exact, shard_range, split_exact
 from .tuples import EnergiesScalars, AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
@@ -278,7 +278,8 @@ class ANI(torch.nn.Module):
         # layer-0 GEMMs skip the others
         slab_mask = None
         if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
-            slab_mask = torch.zeros(n, dtype=torch.int32, device=c32.device)
+            # (the AEV kernel writes the flags of every central atom; the others are read by nobody, zero for tidiness)
+            slab_mask = (torch.empty if (lo == 0 and hi == n) else torch.zeros)(n, dtype=torch.int32, device=c32.device)
         # AEV rows and their gradients exist for this rank's central atoms only ([hi - lo, L] buffers)
         aev = eng.forward(species32, nbrs, slab_mask=slab_mask, shard_rows=True)
         atomic_e, grad_aev, _ = packed.forward_backward(species32, aev, lo=lo, hi=hi, want_grad=True,
@@ -287,9 +288,7 @@ class ANI(torch.nn.Module):
         virial = torch.empty((3, 3), dtype=torch.float64, device=c32.device) if stress else None
         pair_e, pair_g, pair_w = self._pair_terms(species32, c32, cell, pbc_t, nbrs, lo, hi, stress)
         world = 1 if group is None else torch.distributed.get_world_size(group)
-        sae = None
-        if self.energy_shifter._enabled:
-            sae = self.energy_shifter.self_energies.to(device=c32.device, dtype=torch.float64)
+        sae = self._sae64(c32.device) if self.energy_shifter._enabled else None
         if self.deterministic_forces:
             # order-independent sums: int64 fixed-point accumulators (2^-32) for the forces (ANIHIP_BWD_FIXED_POINT), and
             # for a sharded run ONE int64 all-reduce that also carries energies and virial at the same resolution
@@ -324,8 +323,10 @@ class ANI(torch.nn.Module):
                 grad_coords += pair_g
                 if stress:
                     virial += pair_w
-            energies = energy_reduce(species32, atomic_e if pair_e is None else atomic_e + pair_e, sae, lo, hi)
-            forces = grad_coords.neg_().view(C, A, 3)
+            # (energies and the sign flip of the gradient share the last launch of the step)
+            energies = energy_forces_finish(species32, atomic_e if pair_e is None else atomic_e + pair_e, sae,
+                                            grad_coords, lo, hi)
+            forces = grad_coords.view(C, A, 3)
             if world > 1:
                 # ONE collective per step: the fp64 partial energies (and virial) ride in the fp32 force buffer as four
                 # exactly-summable fp32 parts each (parallel.split_exact), so the sum over ranks is exact and
@@ -343,6 +344,16 @@ class ANI(torch.nn.Module):
             nbrs.raise_on_overflow()
         aevc._last_neighbors = nbrs
         return EnergiesForces(energies, forces, atomic_e.view(C, A), virial)
+
+    def _sae64(self, device) -> Tensor:
+        """Self energies as float64 on ``device``, converted once per value of the buffer (a launch per step otherwise)."""
+        src = self.energy_shifter.self_energies
+        key = (src.data_ptr(), src._version, src.dtype, device)
+        hit = self.__dict__.get("_sae64_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, src.detach().to(device=device, dtype=torch.float64).clone())
+            self.__dict__["_sae64_cache"] = hit
+        return hit[1]
 
     def _pair_terms(self, species32: Tensor, c32: Tensor, cell, pbc, nbrs, lo: int, hi: int, stress: bool):
         """Pair-potential part of this rank's central atoms: (per-atom energies [N] or None, gradient [N, 3], virial)."""
@@ -593,10 +604,15 @@ class GraphedEnergiesForces:
         torch.cuda.current_stream().wait_stream(side)
         self._packed = self.model.neural_networks._pack(self.coords.device)   # strong reference: planes + workspace
         self._packed.pinned += 1
+        self._sae = self._current_sae()   # (the float64 copy of the self energies the graph reads)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.out = self._run()
         self.n_captures += 1
+
+    def _current_sae(self) -> tp.Optional[Tensor]:
+        m = self.model
+        return m._sae64(self.coords.device) if m.energy_shifter._enabled else None
 
     def _release(self) -> None:
         if self._packed is not None:
@@ -611,7 +627,8 @@ class GraphedEnergiesForces:
                                                     False, None)
 
     def __call__(self, coords: Tensor, cell: tp.Optional[Tensor] = None) -> EnergiesForces:
-        if self.model.neural_networks._pack(self.coords.device) is not self._packed:
+        if (self.model.neural_networks._pack(self.coords.device) is not self._packed
+                or self._current_sae() is not self._sae):
             self._capture()   # parameters were updated in place / other members: the old planes are stale
         self.coords.copy_(coords)
         if cell is not None:

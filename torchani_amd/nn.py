@@ -11,6 +11,7 @@ weight gradients, csrc/mnp.cpp:138-232, it trains through eager autograd).  Firs
 """
 from __future__ import annotations
 
+import operator
 import os
 import typing as tp
 import warnings
@@ -163,6 +164,21 @@ class _MLPFunction(torch.autograd.Function):
         return (g.to(ctx.in_dtype), None, None, None, *([None] * len(ctx.param_dtypes)))
 
 
+# bumped whenever a parameter or a submodule is registered on any torch.nn.Module (incl. attribute assignment): cached
+# parameter lists of the containers below are valid while it stands still
+_STRUCT_EPOCH = [0]
+_VERSION_OF = operator.attrgetter("_version")
+_DATA_PTR_OF = operator.methodcaller("data_ptr")
+
+
+def _bump_struct_epoch(*_args) -> None:
+    _STRUCT_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_struct_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_struct_epoch)
+
+
 class _EngineContainer(torch.nn.Module):
     """Shared machinery of ANINetworks / Ensemble: parameter packing cache + engine call.
 
@@ -175,12 +191,23 @@ class _EngineContainer(torch.nn.Module):
     def _member_networks(self) -> tp.List["ANINetworks"]:
         raise NotImplementedError
 
-    def _pack(self, device: torch.device) -> PackedNetworks:
+    def _param_list(self) -> tp.Tuple[tp.List["ANINetworks"], tp.List[torch.nn.Parameter]]:
+        """Active member containers and their parameters.  Walking the module tree costs ~0.4 ms for 8 x 7 networks, more
+        than a whole step of a small batch, so the flat list is kept until the member selection changes or ANY module
+        in the process registers a parameter / submodule (_STRUCT_EPOCH, bumped by torch's registration hooks)."""
         members = self._member_networks()
-        params = [p for m in members for p in m.parameters()]
+        stamp = (tuple(id(m) for m in members), _STRUCT_EPOCH[0])
+        hit = self.__dict__.get("_plist")
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, [p for m in members for p in m.parameters()])
+            self.__dict__["_plist"] = hit
+        return members, hit[1]
+
+    def _pack(self, device: torch.device) -> PackedNetworks:
+        members, params = self._param_list()
         precision = getattr(self, "mlp_precision", None) or os.environ.get("TORCHANI_AMD_MLP_PRECISION", "f16x3")
-        key = (device, precision, tuple(id(m) for m in members), tuple(p._version for p in params),
-               tuple(p.data_ptr() for p in params))
+        # (in-place updates bump _version, .to() / .data = ... change data_ptr; ~0.1 ms for 448 tensors)
+        key = (device, precision, tuple(map(id, members)), tuple(map(_VERSION_OF, params)), tuple(map(_DATA_PTR_OF, params)))
         cache = self.__dict__.setdefault("_packed_cache", {})   # several member subsets stay packed
         if key not in cache:
             # (a container may read ONE of several outputs of its final layers, nn/_internal.py:69-93: that row only)
