@@ -466,3 +466,25 @@ def test_charge_networks_pack_and_normalizer():
     plain = ChargeNormalizer(["H", "C"])
     qq = plain(torch.tensor([[0, 1, -1]]), torch.tensor([[0.3, 0.1, 0.0]]))
     assert torch.allclose(qq, torch.tensor([[0.1, -0.1, 0.0]]))
+
+
+def test_layer0_tile_hint_from_composition():
+    """ANI._tile_hint: 128-row layer-0 backward tiles between 16 384 and 65 536 atoms when four or more elements are
+    present, the library's default otherwise; cached per species tensor (held, so its address is not recycled)."""
+    import warnings
+
+    from torchani_amd import _lib
+    from torchani_amd.models import ANI2x
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ANI2x(seed=0, n_members=1)
+    rs = np.random.RandomState(0)
+    organic = torch.from_numpy(rs.randint(0, 5, (1, 20000)))
+    water = torch.from_numpy(rs.randint(0, 2, (1, 20000)))
+    padded = torch.cat([organic[:, :9000], -torch.ones((1, 11000), dtype=torch.long)], dim=1)
+    assert m._tile_hint(organic, organic, 20000) == _lib.MLP_FLAG_SMALL_TILES
+    assert m._n_elem_cache[2] is organic
+    assert m._tile_hint(water, water, 20000) == 0
+    assert m._tile_hint(padded, padded, 20000) == _lib.MLP_FLAG_SMALL_TILES
+    assert m._tile_hint(organic, organic, 16383) == 0 and m._tile_hint(organic, organic, 65536) == 0

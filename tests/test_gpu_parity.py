@@ -557,6 +557,34 @@ def test_hip_graph_owns_its_buffers(dev):
     assert not torch.allclose(out.forces, ref, atol=1e-7)   # the update is visible
 
 
+def test_auto_graph_follows_the_species_tensor_not_its_address(dev):
+    """energies_and_forces replays a HIP graph from the third call with the SAME species tensor.  A stream of batches,
+    each in a fresh species tensor of the same shape (the caching allocator hands the freed address to the next one), must
+    never be served from a graph captured for an earlier batch; an MD-like loop over one tensor still gets its graph."""
+    from torchani_amd.models import ANI2x
+
+    g = load_golden("rand_batch_ani2x")
+    sp0, x, _, _ = to_dev(g, dev)
+    model = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False)
+    rs = np.random.RandomState(0)
+    real = (sp0 >= 0)
+    for it in range(6):
+        perm = torch.from_numpy(rs.permutation(7)).to(dev)
+        sp = torch.where(real, perm[sp0.clamp(min=0)], sp0)      # another batch: same shape, other elements
+        got = model.energies_and_forces(sp, x)
+        e, f = got.energies.clone(), got.forces.clone()
+        model.auto_graph_atoms, keep = 0, model.auto_graph_atoms
+        ref = model.energies_and_forces(sp, x)
+        model.auto_graph_atoms = keep
+        assert torch.allclose(e, ref.energies, atol=1e-9) and torch.allclose(f, ref.forces, atol=2e-6), it
+        del sp, got
+    assert all(ent[1] is None for ent in model._graphs.values())   # (no tensor was seen three times)
+    for _ in range(4):
+        out = model.energies_and_forces(sp0, x)
+    assert any(ent[1] is not None for ent in model._graphs.values())
+    assert np.abs(out.forces.cpu().numpy() - g["forces"]).max() < F_TOL
+
+
 def test_factories_are_loud_about_random_weights(dev):
     """No state_dict and no seed -> a warning; a state dict that does not match the architecture -> an error
     (never a silent fall-back to random parameters)."""

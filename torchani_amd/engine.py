@@ -536,13 +536,15 @@ class PackedNetworks:
     def forward_backward(self, species: Tensor, aev: Tensor, lo: int = 0, hi: tp.Optional[int] = None,
                          want_grad: bool = True, want_members: bool = False, chunk: int = 1 << 18,
                          atomic_e: tp.Optional[Tensor] = None, grad_aev: tp.Optional[Tensor] = None,
-                         slab_mask: tp.Optional[Tensor] = None, shard_rows: bool = False
+                         slab_mask: tp.Optional[Tensor] = None, shard_rows: bool = False, tile_hint: int = 0
                          ) -> tp.Tuple[Tensor, tp.Optional[Tensor], tp.Optional[Tensor]]:
         """Per-atom ensemble-mean energies [N], d e/d aev [N,L] (optional), member energies [M,N].
 
         slab_mask (int32 [N] from AevEngine.forward): the layer-0 GEMMs skip AEV slabs no atom of a row tile
         flags; grad_aev is then only defined inside the flagged slabs (all AevEngine.backward reads).
-        shard_rows=True: aev (and the returned / given grad_aev) hold only the rows lo..hi."""
+        shard_rows=True: aev (and the returned / given grad_aev) hold only the rows lo..hi.
+        tile_hint: _lib.MLP_FLAG_SMALL_TILES / MLP_FLAG_BIG_TILES from a caller that knows the composition (used unless the
+        instance / class flags already choose a layer-0 tiling)."""
         _require_cuda(species, aev, slab_mask)
         if slab_mask is not None:
             assert slab_mask.dtype == torch.int32 and slab_mask.numel() == species.numel()
@@ -581,7 +583,10 @@ class PackedNetworks:
         for c0 in range(lo, hi, step):
             c1 = min(hi, c0 + step)
             ws = self.workspace(c1 - c0)
-            self.desc.flags = PackedNetworks.default_flags if self.flags is None else self.flags
+            fl = PackedNetworks.default_flags if self.flags is None else self.flags
+            if not fl & (_lib.MLP_FLAG_SMALL_TILES | _lib.MLP_FLAG_BIG_TILES):
+                fl |= tile_hint
+            self.desc.flags = fl
             _lib.check(L.anihip_mlp_forward_backward(
                 _stream(), C.byref(self.desc), n, c0, c1, _ptr(species), _row_ptr(aev, rows0, self.aev_len),
                 _ptr(slab_mask), _ptr(ws), ws.numel(), _ptr(atomic_e),

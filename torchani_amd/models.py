@@ -25,6 +25,7 @@ from .aev import AEVComputer
 from ._lib import MAX_RAD
 from ._lib import MAX_RAD as _lib_MAX_RAD
 from .constants import GSAES_WB97X_631GD  # noqa: F401
+from . import _lib
 from .engine import FIXED_SCALE, energy_forces_finish, energy_reduce, fixed_to_float
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import join_exact, shard_range, split_exact
@@ -210,7 +211,9 @@ class ANI(torch.nn.Module):
         elem_idxs = self._elem_idxs(species)
         species32 = elem_idxs.to(torch.int32).contiguous()
         c32 = coords.detach().to(torch.float32).contiguous()
-        out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard, stress)
+        n_central = species32.numel() if group is None and shard is None else 0   # (shards: the library's default)
+        hint = 0 if torch.cuda.is_current_stream_capturing() else self._tile_hint(species, species32, n_central)
+        out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard, stress, hint)
         if check_overflow and not torch.cuda.is_current_stream_capturing():
             # one host sync after everything is queued: a row over capacity was zeroed by the builder, the result
             # would be silently wrong (the reference asserts on the device, csrc/aev.cu:229).  Retry once at the
@@ -221,7 +224,7 @@ class ANI(torch.nn.Module):
                     warnings.warn(f"neighbor rows overflowed row_capacity={aevc.row_capacity}: retrying with {MAX_RAD}")
                     aevc.row_capacity = MAX_RAD
                     out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard,
-                                                         stress)
+                                                         stress, hint)
                 aevc.last_neighbors().raise_on_overflow()
         return out
 
@@ -241,7 +244,9 @@ class ANI(torch.nn.Module):
         if ent is None:
             if len(self._graphs) >= 4:
                 self._graphs.pop(next(iter(self._graphs)))
-            self._graphs[key] = ent = [0, None]
+            # (the entry keeps the species tensor alive: while it exists no other tensor can show up under its address, so
+            # an equal key always means the same tensor with the same contents)
+            self._graphs[key] = ent = [0, None, species]
         ent[0] += 1
         if ent[0] < 3:
             return None
@@ -262,8 +267,25 @@ class ANI(torch.nn.Module):
                 return None
         return res
 
+    def _tile_hint(self, species: Tensor, elem_idxs: Tensor, n_central: int) -> int:
+        """Layer-0 backward tiling for mid-size systems.  From 16 384 atoms on the library tiles 256 rows; that is right
+        for water-like compositions (few AEV slabs per tile: the skinny kernel, faster at every size measured), but
+        with four or more elements present the 128-row 8-wave kernel is 13-18 % faster per step at 16 k - 46 k atoms
+        (1C17, solvated 1hz5: DESIGN.md section 6), where 256-row tiles are too few to balance over the CUs.  The number of
+        elements present costs one host sync per distinct ``species`` tensor: cached by identity and version, with a
+        reference to the tensor so that its address cannot be handed to another one meanwhile."""
+        if not 16384 <= n_central < 65536:
+            return 0
+        key = (species.data_ptr(), species._version, tuple(species.shape))
+        hit = self.__dict__.get("_n_elem_cache")
+        if hit is None or hit[0] != key:
+            present = torch.bincount(elem_idxs.reshape(-1).clamp(min=-1) + 1, minlength=len(self.symbols) + 1)[1:]
+            hit = (key, int((present > 0).sum()), species)
+            self.__dict__["_n_elem_cache"] = hit
+        return _lib.MLP_FLAG_SMALL_TILES if hit[1] >= 4 else 0
+
     def _energies_and_forces_core(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces,
-                                  check_overflow, shard, stress: bool = False) -> EnergiesForces:
+                                  check_overflow, shard, stress: bool = False, tile_hint: int = 0) -> EnergiesForces:
         """The stream-ordered part of energies_and_forces (element indices int32, coords fp32 contiguous):
         no host synchronisation unless check_overflow, so it can be captured into a HIP graph."""
         C, A = species32.shape
@@ -284,7 +306,7 @@ class ANI(torch.nn.Module):
         aev = eng.forward(species32, nbrs, slab_mask=slab_mask, shard_rows=True)
         atomic_e, grad_aev, _ = packed.forward_backward(species32, aev, lo=lo, hi=hi, want_grad=True,
                                                         chunk=self.mlp_chunk, slab_mask=slab_mask,
-                                                        shard_rows=True)
+                                                        shard_rows=True, tile_hint=tile_hint)
         virial = torch.empty((3, 3), dtype=torch.float64, device=c32.device) if stress else None
         pair_e, pair_g, pair_w = self._pair_terms(species32, c32, cell, pbc_t, nbrs, lo, hi, stress)
         world = 1 if group is None else torch.distributed.get_world_size(group)
@@ -590,6 +612,7 @@ class GraphedEnergiesForces:
         self.cell = None if cell is None else cell.detach().clone()
         self.pbc = pbc
         self.warmup = warmup
+        self.tile_hint = model._tile_hint(self.species32, self.species32, self.species32.numel())
         self.n_captures = 0
         self._packed = None
         self._capture()
@@ -624,7 +647,7 @@ class GraphedEnergiesForces:
 
     def _run(self) -> EnergiesForces:
         return self.model._energies_and_forces_core(self.species32, self.coords, self.cell, self.pbc, None, True,
-                                                    False, None)
+                                                    False, None, tile_hint=self.tile_hint)
 
     def __call__(self, coords: Tensor, cell: tp.Optional[Tensor] = None) -> EnergiesForces:
         if (self.model.neural_networks._pack(self.coords.device) is not self._packed
