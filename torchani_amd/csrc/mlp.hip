@@ -5,7 +5,8 @@
 // nonzero()/index_select like nn/_containers.py:406-416).  Then, by network shape and precision:
 //
 //   A. split-fp16 ("f16x3", default), three hidden layers of width <= 256 (ANI-1x / ANI-2x):
-//        k_tile_table -> k_mlp_fused<RB,NB> -> k_fused_finish -> k_gemm_h2<EPI_SCATTER> / k_gemm_h<EPI_SCATTER>
+//        >= 16384 atoms: k_tile_table -> k_mlp_fused<RB,NB> -> k_fused_finish -> k_gemm_l0b + k_gemm_h2<EPI_SCATTER>
+//        fewer:          k_small_prep (bucketing + tile table + padding rows) -> k_mlp_fused -> k_gemm_l0s (+ finish)
 //      one fused kernel from the AEV rows to d E / d act0 (layer 0 only over the AEV slabs flagged non-zero,
 //      activations in LDS, weights streamed from L2 in MFMA fragment order), then the layer-0 backward
 //      GEMM over the flagged slabs.  See the comment block above k_mlp_fused.
