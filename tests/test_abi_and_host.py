@@ -488,3 +488,33 @@ def test_layer0_tile_hint_from_composition():
     assert m._tile_hint(water, water, 20000) == 0
     assert m._tile_hint(padded, padded, 20000) == _lib.MLP_FLAG_SMALL_TILES
     assert m._tile_hint(organic, organic, 16383) == 0 and m._tile_hint(organic, organic, 65536) == 0
+
+
+def test_cached_parameter_list_follows_the_modules():
+    """_EngineContainer._param_list keeps the flat parameter list between calls (walking the module tree costs more than
+    a small step) and rebuilds it when a parameter or submodule is registered anywhere, when the active members change,
+    and when a conversion swaps the Parameter objects behind the hooks' back."""
+    import warnings
+
+    from torchani_amd.models import ANI2x
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        nets = ANI2x(seed=0, n_members=2).neural_networks
+    _, p0 = nets._param_list()
+    assert nets._param_list()[1] is p0 and len(p0) == 2 * 7 * 8
+    lin = nets.members[1].atomics["C"].final_layer
+    lin.weight = torch.nn.Parameter(torch.zeros_like(lin.weight))        # attribute assignment -> registration hook
+    _, p1 = nets._param_list()
+    assert p1 is not p0 and any(q is lin.weight for q in p1)
+    nets.set_active_members([1])
+    _, p2 = nets._param_list()
+    assert len(p2) == 7 * 8 and any(q is lin.weight for q in p2)
+    nets.set_active_members([0, 1])
+    torch.__future__.set_overwrite_module_params_on_conversion(True)
+    try:
+        nets.double()
+    finally:
+        torch.__future__.set_overwrite_module_params_on_conversion(False)
+    _, p3 = nets._param_list()
+    assert p3[0] is next(iter(nets.members[0].parameters())) and p3[0].dtype == torch.float64

@@ -97,7 +97,7 @@ class ANI(torch.nn.Module):
         self.deterministic_forces = False
         # energies_and_forces replays systems of at most this many atoms as a HIP graph once the same species tensor
         # has been seen three times (launch-bound sizes; 0 disables)
-        self.auto_graph_atoms = 32768
+        self.auto_graph_atoms = 65536
         self._graphs: tp.Dict[tuple, list] = {}
 
     # arch.py:263-275 convenience accessors

@@ -198,7 +198,9 @@ class _EngineContainer(torch.nn.Module):
         members = self._member_networks()
         stamp = (tuple(id(m) for m in members), _STRUCT_EPOCH[0])
         hit = self.__dict__.get("_plist")
-        if hit is None or hit[0] != stamp:
+        # (Module._apply with torch.__future__.set_overwrite_module_params_on_conversion(True) swaps the Parameter objects
+        # through the _parameters dicts, past the hooks: it swaps all of them, so looking at the first one is enough)
+        if hit is None or hit[0] != stamp or (hit[1] and next(iter(members[0].parameters()), None) is not hit[1][0]):
             hit = (stamp, [p for m in members for p in m.parameters()])
             self.__dict__["_plist"] = hit
         return members, hit[1]
