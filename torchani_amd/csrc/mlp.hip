@@ -1753,19 +1753,27 @@ __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const
 // ---- small inputs: the whole preparation in ONE launch ------------------------------------------------------------
 // Below SMALL_PREP_MAX atoms a step is bound by the number of dependent launches, not by work.  Block 0 (16 waves) does what
 // zero_words + k_sp_count + k_sp_offsets + k_sp_scatter + k_tile_table do in five launches: every wave loads its
-// contiguous chunk of species (and slab flags) in one go, counts, the counts are scanned through LDS, the atoms are
-// scattered into an LDS copy of the permutation (same stable order as the chunked kernels: index order inside a species),
-// and the tile table is resolved from LDS.  Blocks 1.. zero the rows of the padding atoms (k_zero_padding).
+// contiguous chunk of species (and slab flags) in one go and counts, the counts are scanned through LDS, and every atom
+// goes from its register straight to its sorted position (same stable order as the chunked kernels: index order inside
+// a species): permutation, row of its tile, the tile's slab flags (an LDS OR); one thread per tile then writes the table
+// entry.  Three barriers, ~10 us.  Blocks 1.. zero the rows of the padding atoms (k_zero_padding).
 constexpr int SMALL_PREP_MAX = 16384;
 constexpr int SMALL_PREP_WAVES = 16;
 constexpr int SMALL_PREP_ITERS = SMALL_PREP_MAX / (SMALL_PREP_WAVES * WAVE);   // 16
+
+#ifdef ANIHIP_DEV_TRACE   // development builds: 100-MHz clock stamps of block 0's phases
+__device__ unsigned long long g_prep_trace[16];
+#define PREP_STAMP(k) if (threadIdx.x == 0) g_prep_trace[k] = wall_clock64();
+#else
+#define PREP_STAMP(k)
+#endif
 
 __global__ __launch_bounds__(SMALL_PREP_WAVES * WAVE) void k_small_prep(
     int64_t lo, int64_t hi, const int32_t *species, int S, int *ctl, int *perm, const uint32_t *slab_mask,
     uint32_t all_slabs, int tiles_total, int rows_per_tile, int4 *tile_tab, int *tile_rows, float *atomic_e,
     float *grad_aev, int L, float *member_e, int M, int64_t n_atoms)
 {
-    extern __shared__ int s_dyn[];   // [n] permutation, [n] slab flags in sorted order, [tiles] OR of the flags per tile
+    extern __shared__ int s_dyn[];   // [tiles] OR of the slab flags per tile
     __shared__ int s_cnt[SMALL_PREP_WAVES][MAX_S];
     __shared__ int s_ctl[CTL_WORDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1783,8 +1791,9 @@ __global__ __launch_bounds__(SMALL_PREP_WAVES * WAVE) void k_small_prep(
         }
         return;
     }
+    PREP_STAMP(0)
     const int n = (int)(hi - lo);
-    int *s_perm = s_dyn, *s_mask = s_dyn + n;
+    int *s_tmask = s_dyn;   // [tiles] OR of the slab flags of a tile's atoms
     const int chunk = (((n + SMALL_PREP_WAVES - 1) / SMALL_PREP_WAVES) + WAVE - 1) & ~(WAVE - 1);
     const int c0 = wave * chunk;
     int sp[SMALL_PREP_ITERS];
@@ -1799,20 +1808,25 @@ __global__ __launch_bounds__(SMALL_PREP_WAVES * WAVE) void k_small_prep(
     // running maxima behind the control block start from zero; the control words themselves are written below
     for (int q = CTL_WORDS + tid; q < CTL_WORDS + AMAX_WORDS; q += SMALL_PREP_WAVES * WAVE) ctl[q] = 0;
     if (tid < CTL_WORDS) s_ctl[tid] = 0;
+    if (tile_tab)
+        for (int q = tid; q < tiles_total; q += SMALL_PREP_WAVES * WAVE) s_tmask[q] = 0;
     int cnt[MAX_S];
 #pragma unroll
     for (int t = 0; t < MAX_S; ++t) cnt[t] = 0;
 #pragma unroll
-    for (int it = 0; it < SMALL_PREP_ITERS; ++it)
+    for (int it = 0; it < SMALL_PREP_ITERS; ++it) {
+        if (it * WAVE >= chunk) break;
 #pragma unroll
         for (int t = 0; t < MAX_S; ++t)
             if (t < S) cnt[t] += __popcll(__ballot(sp[it] == t));
+    }
     if (lane < MAX_S) {
         int v = 0;
 #pragma unroll
         for (int t = 0; t < MAX_S; ++t) v = lane == t ? cnt[t] : v;
         s_cnt[wave][lane] = v;
     }
+    PREP_STAMP(1)
     __syncthreads();
     // thread t < S: exclusive scan of the waves' counts of species t (16 independent LDS reads), totals -> s_tot
     __shared__ int s_tot[MAX_S];
@@ -1827,7 +1841,9 @@ __global__ __launch_bounds__(SMALL_PREP_WAVES * WAVE) void k_small_prep(
         }
         s_tot[tid] = tid < S ? run : 0;
     }
+    PREP_STAMP(2)
     __syncthreads();
+    PREP_STAMP(3)
     // every thread: species offsets / first tiles (registers), its wave's scatter bases
     int base[MAX_S], off[MAX_S + 1], tfirst[MAX_S + 1];
     {
@@ -1854,54 +1870,53 @@ __global__ __launch_bounds__(SMALL_PREP_WAVES * WAVE) void k_small_prep(
             s_ctl[CTL_TILE + S] = trun;
         }
     }
+    // scatter: sorted position of every atom (index order inside a species), and with it straight to memory: the
+    // permutation, the atom's row of its tile, the tile's slab flags (LDS OR); the atom that closes a species also fills
+    // the rows its last tile leaves open with itself (what k_tile_table's clamped read does)
+    const int shift = rows_per_tile == 64 ? 6 : 5;
 #pragma unroll
     for (int it = 0; it < SMALL_PREP_ITERS; ++it) {
+        if (it * WAVE >= chunk) break;
+        int pos = 0, my_off = 0, my_tf = 0, my_end = 0;
 #pragma unroll
         for (int t = 0; t < MAX_S; ++t)
             if (t < S) {
                 const uint64_t m = __ballot(sp[it] == t);
                 if (sp[it] == t) {
-                    const int pos = base[t] + mbcnt(m);
-                    s_perm[pos] = (int)lo + c0 + it * WAVE + lane;
-                    s_mask[pos] = (int)mk[it];
+                    pos = base[t] + mbcnt(m);
+                    my_off = off[t];
+                    my_tf = tfirst[t];
+                    my_end = off[t + 1];
                 }
                 base[t] += __popcll(m);
             }
-    }
-    // (s_tmask: OR of the slab flags of a tile's atoms, behind the two [n] arrays)
-    int *s_tmask = s_dyn + 2 * n;
-    if (tile_tab)
-        for (int q = tid; q < tiles_total; q += SMALL_PREP_WAVES * WAVE) s_tmask[q] = 0;
-    __syncthreads();
-    if (tid < CTL_WORDS) ctl[tid] = s_ctl[tid];
-    const int tot = off[MAX_S];
-    const int shift = rows_per_tile == 64 ? 6 : 5;
-    for (int q = tid; q < tot; q += SMALL_PREP_WAVES * WAVE) {
-        const int atom = s_perm[q];
-        perm[q] = atom;
-        if (tile_tab) {
-            int s = 0;
-#pragma unroll
-            for (int t = 1; t < MAX_S; ++t) s += q >= off[t] ? 1 : 0;   // (empty species share an offset: the last one wins)
-            const int rel = q - off[s];
-            int tf = 0;
-#pragma unroll
-            for (int t = 0; t < MAX_S; ++t) tf = s == t ? tfirst[t] : tf;
-            const int tile = tf + (rel >> shift);
-            tile_rows[(size_t)tile * rows_per_tile + (rel & (rows_per_tile - 1))] = atom;
-            atomicOr(&s_tmask[tile], s_mask[q]);
+        if (sp[it] >= 0) {
+            const int atom = (int)lo + c0 + it * WAVE + lane;
+            perm[pos] = atom;
+            if (tile_tab) {
+                const int rel = pos - my_off, tile = my_tf + (rel >> shift);
+                int *rows = tile_rows + (size_t)tile * rows_per_tile;
+                rows[rel & (rows_per_tile - 1)] = atom;
+                atomicOr(&s_tmask[tile], (int)mk[it]);
+                if (pos == my_end - 1)
+                    for (int r = (rel & (rows_per_tile - 1)) + 1; r < rows_per_tile; ++r) rows[r] = atom;
+            }
         }
     }
-    if (!tile_tab) return;
+    PREP_STAMP(4)
     __syncthreads();
-    // one thread per tile: its entry, and the rows a partial (or empty) tile leaves open
+    PREP_STAMP(5)
+    if (tid < CTL_WORDS) ctl[tid] = s_ctl[tid];
+    if (!tile_tab) return;
+    // one thread per tile: its entry (and atom 0 for the rows of the tiles past the last species: the fused kernel
+    // prefetches the rows of the next item before it looks at its entry)
     for (int tile0 = tid; tile0 < tiles_total; tile0 += SMALL_PREP_WAVES * WAVE) {
         int s = -1;
 #pragma unroll
         for (int t = 0; t < MAX_S; ++t)
             if (t < S && tile0 >= tfirst[t] && tile0 < tfirst[t + 1]) s = t;
-        int *rows = tile_rows + (size_t)tile0 * rows_per_tile;
-        if (s < 0) {   // (the fused kernel prefetches the rows of the next item before it looks at its entry: atom 0)
+        if (s < 0) {
+            int *rows = tile_rows + (size_t)tile0 * rows_per_tile;
             tile_tab[tile0] = make_int4(-1, 0, 0, 0);
             for (int r = 0; r < rows_per_tile; ++r) rows[r] = 0;
             continue;
@@ -1914,12 +1929,9 @@ __global__ __launch_bounds__(SMALL_PREP_WAVES * WAVE) void k_small_prep(
             c = s == t ? off[t + 1] - off[t] : c;
         }
         const int tile = tile0 - tf;
-        const int n_rows = min(rows_per_tile, c - tile * rows_per_tile);
-        const int p0 = o + tile * rows_per_tile;
-        tile_tab[tile0] = make_int4(s, p0, n_rows, s_tmask[tile0]);
-        const int last = s_perm[p0 + n_rows - 1];
-        for (int r = n_rows; r < rows_per_tile; ++r) rows[r] = last;
+        tile_tab[tile0] = make_int4(s, o + tile * rows_per_tile, min(rows_per_tile, c - tile * rows_per_tile), s_tmask[tile0]);
     }
+    PREP_STAMP(8)
 }
 
 // wave-uniform dispatch on the active part of a wave's accumulators in a phase (compile-time inside)
@@ -3131,7 +3143,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     const uint32_t all_slabs = n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << n_slabs) - 1u);
     const bool small_prep = n <= SMALL_PREP_MAX && !(d->flags & ANIHIP_MLP_FLAG_NO_SMALL_PREP);
     if (small_prep) {
-        const size_t lds = sizeof(int) * (2 * (size_t)n + (size_t)fused_tiles);
+        const size_t lds = sizeof(int) * (size_t)fused_tiles;
         ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_small_prep, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds));
         int64_t pad_blocks = (n + SMALL_PREP_WAVES - 1) / SMALL_PREP_WAVES;   // one atom per wave
@@ -3140,6 +3152,16 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                            lo, hi, species, S, w.ctl, w.perm, tab_mask, all_slabs, (int)fused_tiles, fused_rows,
                            fused ? w.tile_tab : (int4 *)nullptr, w.tile_rows, atomic_e, grad_aev, L, member_e, M,
                            n_atoms);
+#ifdef ANIHIP_DEV_TRACE
+        if (getenv("ANIHIP_PREP_TRACE")) {
+            unsigned long long h[16];
+            (void)hipStreamSynchronize(stream);
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prep_trace), sizeof(h));
+            fprintf(stderr, "k_small_prep block 0, ns since start: load+count %llu, barrier+scan %llu, barrier %llu, bases+scatter %llu,"
+                    " barrier %llu, tile table %llu\n", (h[1] - h[0]) * 10, (h[2] - h[0]) * 10, (h[3] - h[0]) * 10,
+                    (h[4] - h[0]) * 10, (h[5] - h[0]) * 10, (h[8] - h[0]) * 10);
+        }
+#endif
     } else {
         zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
         const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
