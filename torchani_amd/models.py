@@ -229,7 +229,7 @@ class ANI(torch.nn.Module):
         return out
 
     def _auto_graph_call(self, species, coords, cell, pbc, group, shard, stress, check_overflow):
-        """Small systems are launch-bound (~25 kernels of a few microseconds): from the third call with the SAME species
+        """Small systems are launch-bound (a dozen kernels of a few microseconds): from the third call with the SAME species
         tensor (identity and version -- an MD loop, a batch re-evaluated with new coordinates) and shapes, the step is
         replayed as one HIP graph (GraphedEnergiesForces); results are copied out of the graph's static buffers.
         Returns None when the call does not qualify (large system, sharded, stress, capture in progress, ...)."""
@@ -538,7 +538,7 @@ class ANI(torch.nn.Module):
     def graphed(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
                 pbc: tp.Optional[tp.Sequence[bool]] = None) -> "GraphedEnergiesForces":
         """Capture energies_and_forces for this (species, shapes, pbc) into a HIP graph and return a callable
-        ``f(coords, cell=None) -> EnergiesForces`` that replays it: one graph launch instead of ~25 kernel
+        ``f(coords, cell=None) -> EnergiesForces`` that replays it: one graph launch instead of a dozen kernel
         launches, for launch-bound sizes (batches of small molecules, MD of small systems)."""
         return GraphedEnergiesForces(self, species, coords, cell, pbc)
 
