@@ -518,3 +518,35 @@ def test_cached_parameter_list_follows_the_modules():
         torch.__future__.set_overwrite_module_params_on_conversion(False)
     _, p3 = nets._param_list()
     assert p3[0] is next(iter(nets.members[0].parameters())) and p3[0].dtype == torch.float64
+
+
+def test_simple_ani_builder_host_side():
+    """models.simple_ani mirrors arch.py:992-1066: AEV constants from cover_linearly, per-element widths of the chosen
+    recipe, self energies of the level of theory, pair potentials on request; what the kernels do not cover is refused."""
+    import math
+    import warnings
+
+    from torchani_amd.constants import GSAES
+    from torchani_amd.models import simple_ani
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = simple_ani(("H", "C", "N", "O"), "wB97X-631Gd", ensemble_size=2, seed=3)
+    c = m.aev_computer.constants()
+    assert np.allclose((c.Rcr, c.Rca, c.EtaR, c.EtaA, c.Zeta), (5.2, 3.5, 19.7, 12.5, 14.1), rtol=1e-7) and c.cutoff_fn == "smooth"
+    assert len(c.ShfR) == 16 and abs(c.ShfR[1] - (0.9 + 4.3 / 16)) < 1e-6 and abs(c.ShfZ[0] - math.pi / 8) < 1e-6   # (fp32 buffers)
+    assert c.out_dim == 4 * 16 + 10 * 32
+    assert [tuple(p.shape) for p in m.neural_networks.members[1].atomics["C"].parameters()] == \
+        [(224, 384), (192, 224), (160, 192), (1, 160)]
+    assert list(m.potentials) == ["nnp", "repulsion_xtb"] and m.potentials["repulsion_xtb"].cutoff == 5.2
+    assert np.allclose(m.energy_shifter.self_energies.numpy(), [GSAES["wb97x-631gd"][s] for s in "HCNO"])
+    m2 = simple_ani(("H", "O"), "b973c-def2mtzvp", dispersion=True, repulsion_cutoff=False, seed=1)
+    assert list(m2.potentials) == ["nnp", "repulsion_xtb", "dispersion_d3"] and math.isinf(m2.potentials["repulsion_xtb"].cutoff)
+    same = simple_ani(("H", "O"), "b973c-def2mtzvp", seed=1).state_dict()
+    again = simple_ani(("H", "O"), "b973c-def2mtzvp", seed=1).state_dict()
+    assert all(torch.equal(same[k], again[k]) for k in same)
+    for bad in (dict(sections=6), dict(radial_shifts=32), dict(container="SingleNN"), dict(activation="tanh")):
+        with pytest.raises(ValueError):
+            simple_ani(("H", "C"), "wb97x-631gd", **bad)
+    with pytest.raises(KeyError):
+        simple_ani(("H", "C"), "hf-sto3g")

@@ -1083,6 +1083,39 @@ def test_animbis_charges_match_reference(dev, case):
     assert torch.equal(model.atomic_charges((sp, x), cell, pbc), out.atomic_charges)
 
 
+@pytest.mark.parametrize("case", ["chno", "chno1x"])
+def test_simple_ani_builder_matches_reference(dev, case):
+    """models.simple_ani (arch.py:992-1066) against the reference's builder in fp64 with the same seeded parameters
+    (tests/golden/gen_golden_simple.py): a four-element model with the default recipe (ANI-2x widths, GELU, no biases,
+    smooth envelope, xTB repulsion, two members) and one with the ANI-1x recipe (CELU with biases, cosine cutoff, 4 x 8
+    angular grid, no repulsion)."""
+    from torchani_amd.models import simple_ani
+
+    ref = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"simple_{case}.npz")))
+    kw = dict(ensemble_size=2) if case == "chno" else dict(
+        ensemble_size=1, container_ctor="like_1x", activation="celu", bias=True, cutoff_fn="cosine", angular_shifts=4,
+        sections=8, angular_precision=8.0, angular_zeta=32.0, radial_precision=16.0, repulsion=False)
+    model = simple_ani([str(s) for s in ref["symbols"]], "wb97x-631gd", seed=int(ref["seed"]), device=dev,
+                       periodic_table_index=False, neighborlist="batch", **kw)
+    assert model.aev_computer.engine().L == int(ref["aev_dim"])
+    assert np.allclose(model.energy_shifter.self_energies.cpu().numpy(), ref["self_energies"])
+    sp = torch.from_numpy(ref["species"]).to(dev)
+    x = torch.from_numpy(ref["coords"]).to(dev)
+    out = model.energies_and_forces(sp, x)
+    torch.cuda.synchronize()
+    n_real = int((ref["species"] >= 0).sum(axis=1).max())
+    fscale = max(1.0, np.abs(ref["forces"]).max())
+    ee = np.abs(out.energies.cpu().numpy() - ref["energies"]).max()
+    fe = np.abs(out.forces.cpu().numpy() - ref["forces"]).max()
+    report(f"simple_ani {case:7s} max|E err| = {ee:.2e} ({n_real} atoms)  |F err| = {fe:.2e} (|F|max {fscale:.2f})")
+    assert ee < E_ATOM_TOL * n_real and fe < F_TOL * fscale
+    if case == "chno1x":   # CELU with biases: the autograd / training path works on a builder-made model too
+        xs = x.clone().requires_grad_(True)
+        e = model((sp, xs)).energies
+        (gx,) = torch.autograd.grad(e.sum(), xs)
+        assert np.abs(-gx.cpu().numpy() - ref["forces"]).max() < F_TOL * fscale
+
+
 def test_periodic_replica_and_symmetries_at_scale(dev):
     """Size-independent properties at ~0.33 M atoms (no oracle at this size): a periodic box replicated 2 x 2 x 2
     has the same per-atom energies and forces as the original box (every atom sees the same environment), the

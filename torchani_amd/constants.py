@@ -50,6 +50,23 @@ GSAES_WB97X_631GD: tp.Dict[str, float] = {
     "S": -398.0814169,
 }
 
+# constants.py:78-190 GSAES: ground-state atomic energies (Hartree) by level of theory, the elements the engine supports
+GSAES: tp.Dict[str, tp.Dict[str, float]] = {
+    "b973c-def2mtzvp": {"H": -0.506930113968, "C": -37.81441001258, "N": -54.556538547322, "O": -75.029181326588, "F": -99.688618987039, "S": -398.043159341582, "Cl": -460.082223445159},
+    "wb97x-631gd": {"H": -0.4993212, "C": -37.8338334, "N": -54.5732825, "O": -75.0424519, "F": -99.6949007, "S": -398.0814169, "Cl": -460.1167006},
+    "wb97md3bj-def2tzvpp": {"H": -0.498639663159, "C": -37.870597534068, "N": -54.621568655507, "O": -75.111870707635, "F": -99.784869113871, "S": -398.158126819835, "Cl": -460.197921425433},
+    "wb97mv-def2tzvpp": {"H": -0.494111111003, "C": -37.844395699666, "N": -54.590952163069, "O": -75.076760965132, "F": -99.745234404775, "S": -398.089446664032, "Cl": -460.124987825603},
+    "ccsd(t)star-cbs": {"H": -0.5, "C": -37.780724507998, "N": -54.515992576387, "O": -74.976148184192, "F": -99.624864557142, "S": -397.646401989238, "Cl": -459.664237510771},
+    "dsd_blyp_d3bj-def2tzvp": {"H": -0.4990340388250001, "C": -37.812711066967, "F": -99.795668645591, "Cl": -460.052391015914},
+    "wb97m_d3bj-def2tzvppd": {"H": -0.4987605100487531, "C": -37.87264507233593, "N": -54.62327513368922, "O": -75.11317840410095, "F": -99.78611622985483, "S": -398.1599636677874, "Cl": -460.1988762285739},
+    "revpbe_d3bj-def2tzvp": {"H": -0.504124985686, "C": -37.845615868613, "N": -54.587739850180995, "O": -75.071223222771, "S": -398.041639842051},
+    "wb97x-def2tzvpp": {"H": -0.5013925, "C": -37.8459781, "N": -54.5915914, "O": -75.0768759, "F": -99.7471707, "S": -398.1079973, "Cl": -460.1467777},
+    "r2scan3c-def2mtzvpp": {"H": -0.49727168567, "C": -37.832225901872, "N": -54.581004402346, "O": -75.057311846055, "F": -99.726350798961, "S": -398.08097127572, "Cl": -460.113993263966},
+    "r2scan3c_water-def2mtzvpp": {"H": -0.494931329259, "C": -37.822388062823, "N": -54.581010824825, "O": -75.059169500763, "F": -99.724273365141, "S": -398.082828534447, "Cl": -460.113806300624},
+    "r2scan3c_chcl3-def2mtzvpp": {"H": -0.496899744403, "C": -37.824548433511, "N": -54.57668102908, "O": -75.056821997619, "F": -99.726146486046, "S": -398.085456915563, "Cl": -460.116926115444},
+    "r2scan3c_ch3cn-def2mtzvpp": {"H": -0.496684906369, "C": -37.824424218755, "N": -54.57657248763, "O": -75.058406925318, "F": -99.725926489187, "S": -398.084853327694, "Cl": -460.116392553071},
+}
+
 
 def linspace(start: float, stop: float, steps: int) -> tp.Tuple[float, ...]:
     """End-point-excluding linspace used for all ANI shifts (utils.py:101-107)."""

@@ -803,6 +803,79 @@ def ANImbis(model_index: tp.Optional[int] = None, neighborlist: str = "auto", st
     return model if model_index is None else model[model_index]
 
 
+def simple_ani(symbols: tp.Sequence[str], lot: str, ensemble_size: int = 1, radial_start: float = 0.9,
+               angular_start: float = 0.9, radial_cutoff: float = 5.2, angular_cutoff: float = 3.5,
+               radial_shifts: int = 16, angular_shifts: int = 8, sections: int = 4, radial_precision: float = 19.7,
+               angular_precision: float = 12.5, angular_zeta: float = 14.1, cutoff_fn: str = "smooth",
+               dispersion: bool = False, repulsion: bool = True, container_ctor: str = "default",
+               container: str = "ANINetworks", activation: str = "gelu", bias: bool = False, strategy: str = "auto",
+               periodic_table_index: bool = True, neighborlist: str = "auto", repulsion_cutoff: bool = True,
+               seed: tp.Optional[int] = None, state_dict=None, device=None, row_capacity: int = 128) -> ANI:
+    """The reference's flexible builder (arch.py:992-1066) on the HIP engine: symmetry functions that cover the radial /
+    angular range linearly (ANIRadial / ANIAngular.cover_linearly, aev/_terms.py:189-207,346-366), ANINetworks of the
+    ANI-2x ("default", "like_2x") or ANI-1x ("like_1x") widths, self energies of the level of theory ``lot``
+    (constants.GSAES), optionally the xTB repulsion and the D3 dispersion of that functional.  Like the reference's, the
+    networks start from random parameters (``seed`` makes them reproducible; ``state_dict`` loads trained ones).
+
+    What the kernels cover (a ValueError names anything else): 16 radial shifts, an 8 x 4 or 4 x 8 angular grid (shifts x
+    sections), at most 7 elements, three hidden layers of at most 256 units, CELU (with biases: trainable here) or GELU."""
+    from .constants import ATOMIC_NUMBER, GSAES, HIDDEN_DIMS_1X, HIDDEN_DIMS_2X, AEVConstants, linspace
+    from .weights import random_network_state_dict
+
+    symbols = tuple(symbols)
+    if not 1 <= len(symbols) <= 7 or any(s not in ATOMIC_NUMBER for s in symbols) or len(set(symbols)) != len(symbols):
+        raise ValueError(f"simple_ani: 1 to 7 distinct elements out of {sorted(ATOMIC_NUMBER)}, got {symbols}")
+    if radial_shifts != 16 or (angular_shifts, sections) not in ((8, 4), (4, 8)):
+        raise ValueError("the AEV kernels cover radial_shifts=16 with angular_shifts x sections = 8 x 4 or 4 x 8 "
+                         f"(got {radial_shifts}, {angular_shifts} x {sections})")
+    if container != "ANINetworks" or container_ctor not in ("default", "like_2x", "like_1x"):
+        raise ValueError("the network kernels cover container='ANINetworks' with container_ctor 'default' / 'like_2x' / "
+                         f"'like_1x' (got {container!r}, {container_ctor!r}): SingleNN and shared-layer containers are not "
+                         "implemented")
+    if activation not in ("celu", "gelu"):
+        raise ValueError(f"activation 'celu' or 'gelu', got {activation!r}")
+    if cutoff_fn not in ("cosine", "smooth"):
+        raise ValueError(f"cutoff_fn 'cosine' or 'smooth', got {cutoff_fn!r}")
+    if strategy not in ("hip", "auto", "pyaev", "cuaev", "cuaev-fused", "cuaev-interface"):
+        raise ValueError(f"Unsupported strategy {strategy!r}")
+    if lot.lower() not in GSAES:
+        raise KeyError(f"no ground-state atomic energies for the level of theory {lot!r}: {sorted(GSAES)}")
+    gsaes = GSAES[lot.lower()]
+    angle_start = math.pi / sections / 2
+    consts = AEVConstants(len(symbols), float(radial_cutoff), float(angular_cutoff), float(radial_precision),
+                          linspace(radial_start, radial_cutoff, radial_shifts), float(angular_precision),
+                          float(angular_zeta), linspace(angular_start, angular_cutoff, angular_shifts),
+                          linspace(angle_start, math.pi + angle_start, sections), cutoff_fn)
+    # nn/_containers.py:479-544: per-element widths, (160, 128, 96) / (128, 112, 96) for elements without an entry
+    table, other = (HIDDEN_DIMS_1X, (128, 112, 96)) if container_ctor == "like_1x" else (HIDDEN_DIMS_2X, (160, 128, 96))
+    hidden = {s: table.get(s, other) for s in symbols}
+    aevc = AEVComputer(consts, neighborlist=neighborlist, row_capacity=row_capacity, cutoff_fn=cutoff_fn)
+    members = [ANINetworks.build(symbols, consts.out_dim, hidden, activation, bias) for _ in range(ensemble_size)]
+    nets: torch.nn.Module = Ensemble(members) if ensemble_size > 1 else members[0]
+    model = ANI(symbols, aevc, nets, [gsaes[s] for s in symbols], periodic_table_index)
+    if repulsion:
+        from .potentials import RepulsionXTB
+
+        model.add_pair_potential("repulsion_xtb", RepulsionXTB(
+            symbols, cutoff=float(radial_cutoff) if repulsion_cutoff else math.inf, cutoff_fn="smooth"))
+    if dispersion:
+        from .potentials import TwoBodyDispersionD3
+
+        model.add_pair_potential("dispersion_d3", TwoBodyDispersionD3.from_functional(
+            symbols, lot.split("-")[0], cutoff=8.0, cutoff_fn="smooth"))
+    if state_dict is not None:
+        res = model.load_reference_state_dict(state_dict, strict=False)
+        lost = [k for k in res.missing_keys if k.startswith("potentials.nnp.neural_networks")]
+        if lost:
+            raise RuntimeError(f"state_dict does not provide {len(lost)} network tensors (first: {lost[0]})")
+    elif seed is not None:
+        model.load_reference_state_dict(random_network_state_dict(symbols, consts.out_dim, hidden, ensemble_size, seed,
+                                                                  bias), strict=False)
+    if device is not None:
+        model = model.to(device)
+    return model
+
+
 def ANI1ccx(model_index: tp.Optional[int] = None, neighborlist: str = "auto", strategy: str = "hip",
             periodic_table_index: bool = True, device=None, dtype=None, state_dict=None,
             seed: tp.Optional[int] = None, n_members: int = 8, row_capacity: int = 128,

@@ -86,3 +86,24 @@ def random_charge_state_dict(seed: int = 0) -> tp.Dict[str, np.ndarray]:
             bound = 3.0 / np.sqrt(dims[l])   # (bias-free GELU layers shrink the signal: keeps the charges ~0.1 e)
             out[f"atomics.{sym}.{name}.weight"] = rs.uniform(-bound, bound, (dims[l + 1], dims[l])).astype(np.float32)
     return out
+
+
+def random_network_state_dict(symbols: tp.Sequence[str], in_dim: int, hidden: tp.Mapping[str, tp.Sequence[int]],
+                              n_members: int = 1, seed: int = 0, bias: bool = True, out_dim: int = 1,
+                              scale: float = 1.0) -> tp.Dict[str, np.ndarray]:
+    """Seeded fp32 parameters (uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) like torch.nn.Linear's default) for ANINetworks of
+    any supported shape, under the reference's key names; one member: no ``members.{m}.`` level (arch.py:967-975)."""
+    rs = np.random.RandomState(seed)
+    out: tp.Dict[str, np.ndarray] = {}
+    for m in range(n_members):
+        for sym in symbols:
+            dims = (in_dim,) + tuple(hidden[sym]) + (out_dim,)
+            nl = len(dims) - 1
+            for l in range(nl):
+                name = f"layers.{l}" if l < nl - 1 else "final_layer"
+                bound = scale / np.sqrt(dims[l])
+                base = f"{NN_PREFIX}{f'members.{m}.' if n_members > 1 else ''}atomics.{sym}.{name}."
+                out[base + "weight"] = rs.uniform(-bound, bound, (dims[l + 1], dims[l])).astype(np.float32)
+                if bias:
+                    out[base + "bias"] = rs.uniform(-bound, bound, (dims[l + 1],)).astype(np.float32)
+    return out
