@@ -550,3 +550,34 @@ def test_simple_ani_builder_host_side():
             simple_ani(("H", "C"), "wb97x-631gd", **bad)
     with pytest.raises(KeyError):
         simple_ani(("H", "C"), "hf-sto3g")
+
+
+def test_dipoles_and_raw_normalizer():
+    """electro.DipoleComputer / compute_dipole against the reference's values for the reference's charges (fixture), on CPU
+    tensors; BaseChargeNormalizer passes the raw charges through; simple_aniq(normalize=False) uses it."""
+    import warnings
+
+    from torchani_amd.electro import BaseChargeNormalizer, DipoleComputer, compute_dipole
+    from torchani_amd.models import simple_aniq
+
+    ref = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "simple_chnoq.npz")))
+    z, x, q = (torch.from_numpy(ref[k]) for k in ("atomic_numbers", "coords", "atomic_charges"))
+    for frame in ("center_of_mass", "center_of_geometry", "origin"):
+        mu = compute_dipole(z, x.double(), q, frame)
+        assert mu.shape == (z.shape[0], 3) and np.abs(mu.numpy() - ref["dipole_" + frame]).max() < 1e-12, frame
+    # neutral molecules: the dipole does not depend on the frame
+    assert np.abs(ref["dipole_origin"] - ref["dipole_center_of_mass"]).max() < 1e-9
+    custom = DipoleComputer(masses=[0.0, 2.0] + [1.0] * 16, reference="center_of_mass", dtype=torch.float64)
+    mu = custom(torch.tensor([[1, 8, -1]]), torch.tensor([[[0.0, 0, 0], [3.0, 0, 0], [9.0, 9, 9]]], dtype=torch.float64),
+                torch.tensor([[1.0, 0.0, 0.0]], dtype=torch.float64))
+    assert torch.allclose(mu, torch.tensor([[-1.0, 0.0, 0.0]], dtype=torch.float64))   # (center of mass at x = 1)
+    with pytest.raises(ValueError):
+        DipoleComputer(reference="nucleus")
+    raw = torch.tensor([[0.3, -0.1]])
+    assert torch.equal(BaseChargeNormalizer()(torch.tensor([[0, 1]]), raw), raw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = simple_aniq(("H", "O"), "wb97x-631gd", normalize=False, seed=2)
+    assert type(m.potentials["nnp"].charge_normalizer) is BaseChargeNormalizer
+    assert set(k.split(".")[2] for k in m.state_dict() if k.startswith("potentials.nnp.") and "networks" in k) == \
+        {"neural_networks", "charge_networks"}

@@ -27,6 +27,7 @@ from ._lib import MAX_RAD as _lib_MAX_RAD
 from .constants import GSAES_WB97X_631GD  # noqa: F401
 from . import _lib
 from .engine import FIXED_SCALE, energy_forces_finish, energy_reduce, fixed_to_float
+from .electro import BaseChargeNormalizer, ChargeNormalizer  # noqa: F401
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import join_exact, shard_range, split_exact
 from .tuples import EnergiesScalars, AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
@@ -41,39 +42,6 @@ class NNPotential(torch.nn.Module):
         self.aev_computer = aev_computer
         self.neural_networks = neural_networks
         self._enabled = True
-
-
-class ChargeNormalizer(torch.nn.Module):
-    """Shift raw atomic charges so that they add up to the total charge (electro.py:29-87): the excess is distributed
-    with per-element weights, optionally scaled by the squared raw charges."""
-
-    def __init__(self, symbols: tp.Sequence[str], weights: tp.Sequence[float] = (),
-                 scale_weights_by_charges_squared: bool = False) -> None:
-        super().__init__()
-        if not weights:
-            weights = [1.0] * len(symbols)
-        self.register_buffer("weights", torch.tensor(list(weights), dtype=torch.float), persistent=False)
-        self.scale_weights_by_charges_squared = scale_weights_by_charges_squared
-
-    @classmethod
-    def from_electronegativity_and_hardness(cls, symbols: tp.Sequence[str], electronegativity: tp.Sequence[float] = (),
-                                            hardness: tp.Sequence[float] = (),
-                                            scale_weights_by_charges_squared: bool = False) -> "ChargeNormalizer":
-        from .constants import ELECTRONEGATIVITY_HARDNESS as EH
-
-        en = list(electronegativity) if electronegativity else [EH[s][0] for s in symbols]
-        hd = list(hardness) if hardness else [EH[s][1] for s in symbols]
-        return cls(symbols, [(e / h) ** 2 for e, h in zip(en, hd)], scale_weights_by_charges_squared)
-
-    def factor(self, elem_idxs: Tensor, raw_charges: Tensor) -> Tensor:
-        w = self.weights.to(raw_charges.dtype)[elem_idxs.clamp(min=0)].masked_fill(elem_idxs == -1, 0.0)
-        if self.scale_weights_by_charges_squared:
-            w = w * raw_charges ** 2
-        return w / torch.sum(w, dim=-1, keepdim=True)
-
-    def forward(self, elem_idxs: Tensor, raw_charges: Tensor, charge: int = 0) -> Tensor:
-        excess = charge - raw_charges.sum(dim=-1, keepdim=True)
-        return raw_charges + excess * self.factor(elem_idxs, raw_charges)
 
 
 class ANI(torch.nn.Module):
@@ -815,7 +783,8 @@ def simple_ani(symbols: tp.Sequence[str], lot: str, ensemble_size: int = 1, radi
     angular range linearly (ANIRadial / ANIAngular.cover_linearly, aev/_terms.py:189-207,346-366), ANINetworks of the
     ANI-2x ("default", "like_2x") or ANI-1x ("like_1x") widths, self energies of the level of theory ``lot``
     (constants.GSAES), optionally the xTB repulsion and the D3 dispersion of that functional.  Like the reference's, the
-    networks start from random parameters (``seed`` makes them reproducible; ``state_dict`` loads trained ones).
+    networks start from random parameters (``seed`` makes them reproducible; ``state_dict`` loads trained ones).  CELU
+    networks with biases come back trainable (the training passes cover those); GELU / bias-free ones are frozen.
 
     What the kernels cover (a ValueError names anything else): 16 radial shifts, an 8 x 4 or 4 x 8 angular grid (shifts x
     sections), at most 7 elements, three hidden layers of at most 256 units, CELU (with biases: trainable here) or GELU."""
@@ -871,6 +840,66 @@ def simple_ani(symbols: tp.Sequence[str], lot: str, ensemble_size: int = 1, radi
     elif seed is not None:
         model.load_reference_state_dict(random_network_state_dict(symbols, consts.out_dim, hidden, ensemble_size, seed,
                                                                   bias), strict=False)
+    if activation != "celu" or not bias:
+        model.requires_grad_(False)   # (the training passes cover CELU networks with biases: the others are inference models)
+    if device is not None:
+        model = model.to(device)
+    return model
+
+
+def simple_aniq(symbols: tp.Sequence[str], lot: str, ensemble_size: int = 1, radial_start: float = 0.9,
+                angular_start: float = 0.9, radial_cutoff: float = 5.2, angular_cutoff: float = 3.5,
+                radial_shifts: int = 16, angular_shifts: int = 8, sections: int = 4, radial_precision: float = 19.7,
+                angular_precision: float = 12.5, angular_zeta: float = 14.1, cutoff_fn: str = "smooth",
+                dispersion: bool = False, repulsion: bool = True, container_ctor: str = "default",
+                charge_container_ctor: str = "default", container: str = "ANINetworks",
+                charge_container: str = "ANINetworks", activation: str = "gelu", bias: bool = False,
+                strategy: str = "auto", merge_charge_networks: bool = False,
+                scale_charge_normalizer_weights: bool = True, dummy_energies: bool = False, use_cuda_ops: bool = False,
+                periodic_table_index: bool = True, neighborlist: str = "auto", normalize: bool = True,
+                seed: tp.Optional[int] = None, state_dict=None, device=None, row_capacity: int = 128) -> ANIq:
+    """The reference's flexible builder for models that also output atomic charges (arch.py:1069-1185), with SEPARATE charge
+    networks (one more set of ANINetworks on the same AEVs) and the electronegativity / hardness normalizer
+    (``normalize=False``: raw charges).  ``merge_charge_networks`` and ``dummy_energies`` are not implemented."""
+    from .constants import HIDDEN_DIMS_1X, HIDDEN_DIMS_2X
+    from .weights import NN_PREFIX, random_network_state_dict
+
+    if merge_charge_networks or dummy_energies:
+        raise ValueError("simple_aniq: merge_charge_networks / dummy_energies are not implemented (separate charge networks "
+                         "next to real energy networks only)")
+    if charge_container != "ANINetworks" or charge_container_ctor not in ("default", "like_2x", "like_1x"):
+        raise ValueError("charge_container='ANINetworks' with charge_container_ctor 'default' / 'like_2x' / 'like_1x' "
+                         f"(got {charge_container!r}, {charge_container_ctor!r})")
+    base = simple_ani(symbols, lot, ensemble_size, radial_start, angular_start, radial_cutoff, angular_cutoff, radial_shifts,
+                      angular_shifts, sections, radial_precision, angular_precision, angular_zeta, cutoff_fn, dispersion,
+                      repulsion, container_ctor, container, activation, bias, strategy, periodic_table_index, neighborlist,
+                      True, seed, None, None, row_capacity)
+    symbols = tuple(symbols)
+    in_dim = base.aev_computer.constants().out_dim
+    table, other = ((HIDDEN_DIMS_1X, (128, 112, 96)) if charge_container_ctor == "like_1x"
+                    else (HIDDEN_DIMS_2X, (160, 128, 96)))
+    hidden = {s: table.get(s, other) for s in symbols}
+    qnets = ANINetworks.build(symbols, in_dim, hidden, activation, bias)
+    normalizer = (ChargeNormalizer.from_electronegativity_and_hardness(
+        symbols, scale_weights_by_charges_squared=scale_charge_normalizer_weights) if normalize else BaseChargeNormalizer())
+    model = ANIq(symbols, base.aev_computer, base.neural_networks, [float(v) for v in base.energy_shifter.self_energies],
+                 periodic_table_index, qnets, normalizer)
+    for name, pot in base.potentials.items():
+        if name != "nnp":
+            model.add_pair_potential(name, pot)
+    qpre = "potentials.nnp.charge_networks."
+    if state_dict is not None:
+        res = model.load_reference_state_dict(state_dict, strict=False)
+        lost = [k for k in res.missing_keys if k.startswith(("potentials.nnp.neural_networks", qpre))]
+        if lost:
+            raise RuntimeError(f"state_dict does not provide {len(lost)} network tensors (first: {lost[0]})")
+    elif seed is not None:
+        q = random_network_state_dict(symbols, in_dim, hidden, 1, 1000 + seed, bias)
+        model.load_reference_state_dict({qpre + k[len(NN_PREFIX):]: v for k, v in q.items()}, strict=False)
+    if activation != "celu" or not bias:
+        model.requires_grad_(False)
+    else:
+        qnets.requires_grad_(False)   # (charges come from the inference kernels, whatever the networks)
     if device is not None:
         model = model.to(device)
     return model
