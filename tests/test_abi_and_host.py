@@ -581,3 +581,32 @@ def test_dipoles_and_raw_normalizer():
     assert type(m.potentials["nnp"].charge_normalizer) is BaseChargeNormalizer
     assert set(k.split(".")[2] for k in m.state_dict() if k.startswith("potentials.nnp.") and "networks" in k) == \
         {"neural_networks", "charge_networks"}
+
+
+def test_units_module():
+    """torchani_amd.units carries the reference's conversion helpers (units.py:41-197) with the same values: known figures
+    here, every public name against the live reference where it is present (the build container)."""
+    import importlib.util
+
+    from torchani_amd import units
+
+    assert abs(units.hartree2kcalpermol(1.0) - 627.5094738898777) < 1e-9
+    assert abs(units.hartree2ev(1.0) - 27.211386024367243) < 1e-12 and abs(units.ea2debye(0.2081943) - 1.0) < 1e-12
+    assert 17091 < units.sqrt_mhessian2invcm(1.0) < 17093 and 4.35 < units.mhessian2fconst(1.0) < 4.37
+    assert abs(units.bohr2angstrom(units.angstrom2bohr(2.5)) - 2.5) < 1e-15
+    x = torch.tensor([1.0, -2.0], dtype=torch.float64)
+    assert torch.allclose(units.hartree2kjoulepermol(x), x * units.HARTREE_TO_KJOULEPERMOL)
+    path = "/root/reference/torchani/units.py"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    spec = importlib.util.spec_from_file_location("_ref_units", path)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    names = [n for n in dir(ref) if not n.startswith("_") and n not in ("math",)]
+    assert len(names) > 30
+    for n in names:
+        a, b = getattr(ref, n), getattr(units, n)
+        if callable(a):
+            assert a(1.2345) == b(1.2345), n
+        else:
+            assert a == b, n
