@@ -102,3 +102,24 @@ def fgrad_direction(species):
     q = 3.0 * np.arange(C * A, dtype=np.float64)
     t = np.stack([np.modf(0.37 * q)[0], np.modf(0.61 * q)[0] - 0.5, 0.25 - np.modf(0.13 * q)[0]], axis=-1)
     return t.reshape(C, A, 3) * (species >= 0)[..., None]
+
+
+def import_reference():
+    """Make ``import torchani`` find the reference tree (build container only): stub modules for its optional imports that
+    are not installed here (h5py, zarr).  CPU tests only -- nothing on the GPU box may depend on it."""
+    import sys
+    import types
+
+    class _Any:
+        def __class_getitem__(cls, k):
+            return cls
+
+    for name in ("h5py", "zarr"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for k in ("File", "Group", "Dataset", "Datatype"):
+                setattr(m, k, type(k, (_Any,), {}))
+            sys.modules[name] = m
+    os.environ["TORCHANI_NO_WARN_EXTENSIONS"] = "1"
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")

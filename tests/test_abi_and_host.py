@@ -610,3 +610,44 @@ def test_units_module():
             assert a(1.2345) == b(1.2345), n
         else:
             assert a == b, n
+
+
+def test_xyz_io_round_trip_and_reference(tmp_path):
+    """torchani_amd.io.read_xyz / write_xyz (io.py:22-176): round trips with padding and a cell, the padding placeholder,
+    the error cases; the reference's own reader on its in-tree files where the tree is present (the build container)."""
+    from torchani_amd.io import TorchaniIOError, read_xyz, write_xyz
+
+    sp = torch.tensor([[8, 1, 1, -1], [6, 1, 1, 1]])
+    x = torch.arange(24, dtype=torch.float64).reshape(2, 4, 3) / 7
+    cell = torch.tensor([[10.0, 0, 0], [0, 11.5, 0], [0.25, 0, 12.0]], dtype=torch.float64)
+    f = tmp_path / "a.xyz"
+    write_xyz(sp, x, f, cell=cell)
+    sp2, x2, cell2, pbc2 = read_xyz(f, dtype=torch.float64)
+    assert torch.equal(sp2, sp) and torch.allclose(x2[sp >= 0], x[sp >= 0], atol=1e-10) and (x2[sp < 0] == 0).all()
+    assert torch.allclose(cell2, cell) and pbc2.tolist() == [True, True, True]
+    write_xyz(sp, x, f, pad=True)                        # padding atoms written as element 100 ("Fm")
+    text = f.read_text().splitlines()
+    assert text[0] == "4" and text[5].startswith("Fm 0.0000000000") and 'pbc="F F F"' in text[1]
+    sp3, x3, cell3, pbc3, comments = read_xyz(f, dtype=torch.float64, return_comments=True)
+    assert torch.equal(sp3, sp) and cell3 is None and pbc3 is None and len(comments) == 2
+    assert read_xyz(f, detect_padding=False)[0][0, 3].item() == 100
+    (tmp_path / "n.xyz").write_text("2\n\n1 0 0 0\n8 0 0 1\n>\n1\ncomment\nCl 1 2 3\n")   # numbers, divider, symbols
+    spn, xn, _, _ = read_xyz(tmp_path / "n.xyz")
+    assert spn.tolist() == [[1, 8], [17, -1]] and xn[1, 0].tolist() == [1.0, 2.0, 3.0]
+    (tmp_path / "bad.xyz").write_text('1\nfoo\nH 0 0 0\n1\nLattice="1 0 0 0 1 0 0 0 1"\nH 0 0 0\n')
+    with pytest.raises(TorchaniIOError):
+        read_xyz(tmp_path / "bad.xyz")
+    with pytest.raises(ValueError):
+        write_xyz(sp[0], x[0], f)
+    ref_file = "/root/reference/dataset/xyz_files/13.xyz"
+    if not os.path.exists(ref_file):
+        pytest.skip("reference tree not present")
+    from _util import import_reference   # (stub modules for the reference's optional imports)
+    import_reference()
+    from torchani.io import read_xyz as ref_read
+    for path in (ref_file, "/root/reference/tests/resources/water-0.8nm.xyz", "/root/reference/tests/resources/small.xyz"):
+        if not os.path.exists(path):
+            continue
+        a, b = read_xyz(path, dtype=torch.float64), ref_read(path, dtype=torch.float64)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), path
+        assert (a[2] is None) == (b[2] is None) and (a[2] is None or torch.equal(a[2], b[2])), path
