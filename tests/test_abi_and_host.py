@@ -651,3 +651,21 @@ def test_xyz_io_round_trip_and_reference(tmp_path):
         a, b = read_xyz(path, dtype=torch.float64), ref_read(path, dtype=torch.float64)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), path
         assert (a[2] is None) == (b[2] is None) and (a[2] is None or torch.equal(a[2], b[2])), path
+
+
+def test_symbol_number_mass_converters():
+    """utils: the reference's small converter modules (utils.py:257-473) under their names."""
+    from torchani_amd import utils as u
+
+    assert u.AtomicNumbersToChemicalSymbols()(torch.tensor([6, 1, 1, -1, 17])) == ["C", "H", "H", "Cl"]
+    assert u.IntsToChemicalSymbols(["H", "C", "N", "O"])(torch.tensor([3, 0, 0, -1])) == ["O", "H", "H"]
+    assert u.ChemicalSymbolsToAtomicNumbers()(["C", "S", "O", "F", "H"]).tolist() == [6, 16, 8, 9, 1]
+    conv = u.ChemicalSymbolsToInts(["H", "C", "N", "O", "S", "F", "Cl"])
+    assert conv(["C", "S", "O", "F", "H", "H"]).tolist() == [1, 4, 3, 5, 0, 0] and len(conv) == 7
+    with pytest.raises(ValueError):
+        u.ChemicalSymbolsToInts("HCNO")
+    m = u.atomic_numbers_to_masses(torch.tensor([[8, 1, 1, -1]]), dtype=torch.float64)
+    assert torch.allclose(m, torch.tensor([[15.999, 1.008, 1.008, 0.0]], dtype=torch.float64)) and u.get_atomic_masses is u.atomic_numbers_to_masses
+    with pytest.raises(ValueError):
+        u.atomic_numbers_to_masses(torch.tensor([[26]]))      # (no iron in the default table: pass masses=)
+    assert u.sort_by_atomic_num(["Cl", "H", "O", "C"]) == ("H", "C", "O", "Cl") and u.sort_by_atomic_num("N") == ("N",)

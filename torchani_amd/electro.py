@@ -81,8 +81,9 @@ class DipoleComputer(torch.nn.Module):
         mask = species == -1
         if self._center_of_mass:
             assert not (species == 0).any(), "Input should be atomic numbers"
-            w = self.atomic_masses.to(coordinates.dtype)[species.clamp(min=0)].masked_fill(mask, 0.0)
-            if ((w == 0) & ~mask).any():
+            known = species < self.atomic_masses.numel()
+            w = self.atomic_masses.to(coordinates.dtype)[species.clamp(min=0) * known].masked_fill(mask, 0.0)
+            if (~known).any() or ((w == 0) & ~mask).any():
                 raise ValueError("no mass for some of the atomic numbers: pass masses=")
         else:
             w = (~mask).to(coordinates.dtype)

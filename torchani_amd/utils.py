@@ -9,7 +9,7 @@ import typing as tp
 import torch
 from torch import Tensor
 
-from .constants import ATOMIC_NUMBER, PADDING_SPECIES, SYMBOLS_1X, SYMBOLS_2X, linspace  # noqa: F401
+from .constants import ATOMIC_NUMBER, PADDING_SPECIES, SYMBOLS_1X, SYMBOLS_2X, SYMBOLS_2X_ZNUM_ORDER, linspace  # noqa: F401
 
 # utils.py:67-74: padding values per property
 PADDING: tp.Dict[str, float] = {"species": PADDING_SPECIES, "numbers": PADDING_SPECIES, "atomic_numbers": PADDING_SPECIES,
@@ -78,3 +78,111 @@ def map_to_central(coordinates: Tensor, cell: Tensor, pbc: Tensor) -> Tensor:
     frac = coordinates @ torch.inverse(cell)
     frac = frac - frac.floor() * pbc.to(frac.dtype)
     return frac @ cell
+
+
+# ---- symbol / number / mass converters (utils.py:257-473) ------------------------------------------------------------
+class _NumbersToSymbols(torch.nn.Module):
+    def __init__(self, table: tp.Mapping[int, str]) -> None:
+        super().__init__()
+        self.symbol_dict = dict(table)
+
+    def forward(self, species: Tensor) -> tp.List[str]:
+        """1-D tensor of numbers -> list of symbols, padding (-1) left out."""
+        assert species.dim() == 1, "Only 1D tensors supported"
+        return [self.symbol_dict[int(x)] for x in species.tolist() if x != -1]
+
+    def __len__(self) -> int:
+        return len(self.symbol_dict)
+
+
+class _SymbolsToNumbers(torch.nn.Module):
+    def __init__(self, table: tp.Mapping[str, int], device=None) -> None:
+        super().__init__()
+        self.symbol_dict = dict(table)
+        self.register_buffer("_dummy", torch.empty(0, device=device), persistent=False)
+
+    def forward(self, species: tp.Sequence[str]) -> Tensor:
+        """Sequence of chemical symbols -> int64 tensor (on the module's device)."""
+        return torch.tensor([self.symbol_dict[x] for x in species], dtype=torch.long, device=self._dummy.device)
+
+    def __len__(self) -> int:
+        return len(self.symbol_dict)
+
+
+class AtomicNumbersToChemicalSymbols(_NumbersToSymbols):
+    """tensor([6, 1, 1, 1]) -> ['C', 'H', 'H', 'H'] (utils.py:277-305)."""
+
+    def __init__(self) -> None:
+        from .io import PERIODIC_TABLE
+
+        super().__init__({z: s for z, s in enumerate(PERIODIC_TABLE) if s})
+
+
+class IntsToChemicalSymbols(_NumbersToSymbols):
+    """Element indices of a model -> symbols: IntsToChemicalSymbols(['H', 'C', 'N', 'O'])(tensor([3, 0, 0, -1])) ->
+    ['O', 'H', 'H'] (utils.py:308-333)."""
+
+    def __init__(self, symbols: tp.Sequence[str]) -> None:
+        if isinstance(symbols, str):
+            raise ValueError("symbols must be a sequence of str, but it can't be a str")
+        super().__init__(dict(enumerate(symbols)))
+
+
+class ChemicalSymbolsToAtomicNumbers(_SymbolsToNumbers):
+    """['C', 'S', 'O'] -> tensor([6, 16, 8]) (utils.py:356-373)."""
+
+    def __init__(self, device=None) -> None:
+        from .io import PERIODIC_TABLE
+
+        super().__init__({s: z for z, s in enumerate(PERIODIC_TABLE) if s}, device=device)
+
+
+class ChemicalSymbolsToInts(_SymbolsToNumbers):
+    """Symbols -> element indices of a model built for ``symbols`` (utils.py:376-403)."""
+
+    def __init__(self, symbols: tp.Sequence[str], device=None) -> None:
+        if isinstance(symbols, str):
+            raise ValueError("symbols must be a sequence of str, but it can't be a str")
+        super().__init__({s: i for i, s in enumerate(symbols)}, device=device)
+
+
+class AtomicNumbersToMasses(torch.nn.Module):
+    """Atomic numbers -> masses in amu, padding -> 0 (utils.py:406-439).  ``masses`` is indexed by atomic number; the default
+    table covers the elements the engine supports."""
+
+    def __init__(self, masses: tp.Iterable[float] = (), device=None, dtype=None) -> None:
+        super().__init__()
+        masses = list(masses)
+        if not masses:
+            from .electro import ATOMIC_MASS_BY_Z
+
+            masses = [0.0] * (max(ATOMIC_MASS_BY_Z) + 1)
+            for z, m in ATOMIC_MASS_BY_Z.items():
+                masses[z] = m
+        self.register_buffer("atomic_masses", torch.tensor(masses, device=device, dtype=dtype), persistent=False)
+
+    def forward(self, atomic_numbers: Tensor) -> Tensor:
+        assert not (atomic_numbers == 0).any(), "Input should be atomic numbers"
+        mask = atomic_numbers == -1
+        known = atomic_numbers < self.atomic_masses.numel()
+        m = self.atomic_masses[atomic_numbers.clamp(min=0) * known].masked_fill(mask, 0.0)
+        if (~known).any() or ((m == 0) & ~mask).any():
+            raise ValueError("no mass for some of the atomic numbers: pass masses=")
+        return m
+
+
+def atomic_numbers_to_masses(atomic_numbers: Tensor, dtype: torch.dtype = torch.float) -> Tensor:
+    """Convenience wrapper over AtomicNumbersToMasses (utils.py:442-456)."""
+    return AtomicNumbersToMasses(device=atomic_numbers.device, dtype=dtype)(atomic_numbers)
+
+
+get_atomic_masses = atomic_numbers_to_masses   # (the reference's older name)
+
+
+def sort_by_atomic_num(it: tp.Iterable[str]) -> tp.Tuple[str, ...]:
+    """Chemical symbols sorted by atomic number (utils.py:463-473)."""
+    from .io import PERIODIC_TABLE
+
+    if isinstance(it, str):
+        it = (it,)
+    return tuple(sorted(it, key=PERIODIC_TABLE.index))
