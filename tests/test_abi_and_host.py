@@ -669,3 +669,36 @@ def test_symbol_number_mass_converters():
     with pytest.raises(ValueError):
         u.atomic_numbers_to_masses(torch.tensor([[26]]))      # (no iron in the default table: pass masses=)
     assert u.sort_by_atomic_num(["Cl", "H", "O", "C"]) == ("H", "C", "O", "Cl") and u.sort_by_atomic_num("N") == ("N",)
+
+
+def test_cutoff_modules():
+    """torchani_amd.cutoffs: the reference's envelope classes (cutoffs.py:17-143) as host-side callables, and as arguments
+    wherever a cutoff_fn is taken (mapped to the kernels' names; envelopes the kernels lack are refused)."""
+    import math
+
+    from torchani_amd import cutoffs as c
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.potentials import RepulsionXTB
+
+    r = torch.linspace(0.0, 5.2, 27, dtype=torch.float64)
+    assert torch.allclose(c.CutoffCosine()(r, 5.2), 0.5 * torch.cos(r * math.pi / 5.2) + 0.5)
+    s = c.CutoffSmooth()(r, 5.2)
+    assert abs(s[0].item() - 1.0) < 1e-15 and s[-1].item() < 1e-300 and (s[1:] < s[:-1]).all()
+    assert torch.allclose(c.CutoffBiweight()(r, 5.2), (1 - (r / 5.2) ** 2) ** 2) and (c.CutoffDummy()(r, 5.2) == 1).all()
+    assert c.CutoffSmooth(order=4).is_same(c.CutoffSmooth(4)) and not c.CutoffSmooth().is_same(c.CutoffCosine())
+    assert isinstance(c.parse_cutoff_fn("triweight"), c.CutoffTriweight) and c.parse_cutoff_fn("global", c.CutoffCosine())._kernel_name == "cosine"
+    with pytest.raises(ValueError):
+        c.parse_cutoff_fn("gaussian")
+    assert AEVComputer.like_2x(cutoff_fn=c.CutoffSmooth()).cutoff_fn == "smooth"
+    assert RepulsionXTB(("H", "O"), cutoff=5.2, cutoff_fn=c.CutoffCosine()).cutoff_fn == "cosine"
+    for bad in (c.CutoffSmooth(order=4), c.CutoffBiweight(), c.CutoffDummy()):
+        with pytest.raises(ValueError):
+            AEVComputer.like_2x(cutoff_fn=bad)
+    if not os.path.exists("/root/reference/torchani/cutoffs.py"):
+        pytest.skip("reference tree not present")
+    from _util import import_reference
+    import_reference()
+    from torchani import cutoffs as rc
+    for name in ("CutoffDummy", "CutoffBiweight", "CutoffTriweight", "CutoffCosine", "CutoffSmooth"):
+        assert torch.equal(getattr(c, name)()(r, 5.2), getattr(rc, name)()(r, 5.2)), name
+    assert torch.equal(c.CutoffSmooth(3, 1e-6)(r, 3.5), rc.CutoffSmooth(3, 1e-6)(r, 3.5))

@@ -115,7 +115,9 @@ class AEVComputer(torch.nn.Module):
             raise ValueError(f"Unsupported strategy {strategy!r}: torchani_amd only has the native 'hip' path")
         # one cutoff function for both terms like the native strategies of the reference (aev/_computer.py:91-98);
         # an explicit argument overrides the one carried by the constants
-        self.cutoff_fn = consts.cutoff_fn if cutoff_fn is None else str(cutoff_fn)
+        from .cutoffs import kernel_name   # (a name or a torchani_amd.cutoffs.Cutoff object)
+
+        self.cutoff_fn = kernel_name(consts.cutoff_fn if cutoff_fn is None else cutoff_fn)
         if self.cutoff_fn not in ("cosine", "smooth"):
             raise ValueError(f"Unsupported cutoff function {self.cutoff_fn!r}: the HIP kernels implement 'cosine' "
                              "(CutoffCosine) and 'smooth' (CutoffSmooth, order 2)")

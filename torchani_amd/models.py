@@ -803,6 +803,9 @@ def simple_ani(symbols: tp.Sequence[str], lot: str, ensemble_size: int = 1, radi
                          "implemented")
     if activation not in ("celu", "gelu"):
         raise ValueError(f"activation 'celu' or 'gelu', got {activation!r}")
+    from .cutoffs import kernel_name
+
+    cutoff_fn = kernel_name(cutoff_fn)   # (a name or a cutoffs.Cutoff object)
     if cutoff_fn not in ("cosine", "smooth"):
         raise ValueError(f"cutoff_fn 'cosine' or 'smooth', got {cutoff_fn!r}")
     if strategy not in ("hip", "auto", "pyaev", "cuaev", "cuaev-fused", "cuaev-interface"):

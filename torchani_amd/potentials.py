@@ -67,7 +67,10 @@ class _AnalyticPair(torch.nn.Module):
     kind = _lib.PAIR_XTB
     clamp_distances = True   # (core.py:138-139; FixedMNOK does not clamp)
 
-    def _init_common(self, symbols: tp.Sequence[str], cutoff: float, cutoff_fn: str) -> None:
+    def _init_common(self, symbols: tp.Sequence[str], cutoff: float, cutoff_fn) -> None:
+        from .cutoffs import kernel_name   # (a name or a torchani_amd.cutoffs.Cutoff object)
+
+        cutoff_fn = kernel_name(cutoff_fn)
         if cutoff_fn not in _lib.CUTOFF_KINDS:
             raise ValueError(f"Unsupported cutoff function {cutoff_fn!r}: the HIP kernels have {sorted(_lib.CUTOFF_KINDS)}")
         if len(symbols) > 7:
