@@ -702,3 +702,67 @@ def test_cutoff_modules():
     for name in ("CutoffDummy", "CutoffBiweight", "CutoffTriweight", "CutoffCosine", "CutoffSmooth"):
         assert torch.equal(getattr(c, name)()(r, 5.2), getattr(rc, name)()(r, 5.2)), name
     assert torch.equal(c.CutoffSmooth(3, 1e-6)(r, 3.5), rc.CutoffSmooth(3, 1e-6)(r, 3.5))
+
+
+def test_numerical_hessians_and_vibrational_analysis():
+    """grad.numerical_hessians assembles central differences of forces correctly (checked on CPU against the exact Hessian of
+    an analytic toy potential, with padding), and grad.vibrational_analysis reproduces a diatomic's closed form and, where
+    the reference tree is present, the reference's function on the same Hessian for every mode kind and unit."""
+    import math
+    from collections import namedtuple
+
+    from torchani_amd import units
+    from torchani_amd.grad import numerical_hessians, vibrational_analysis
+
+    def energy(sp, x):      # anharmonic pair springs between all real atoms of each molecule
+        e = x.new_zeros(x.shape[0])
+        for c in range(x.shape[0]):
+            idx = (sp[c] >= 0).nonzero().view(-1)
+            i, j = torch.triu_indices(len(idx), len(idx), 1).unbind()
+            d = (x[c, idx[i]] - x[c, idx[j]]).norm(dim=-1)
+            e[c] = ((d - 1.1) ** 2 + 0.3 * (d - 1.1) ** 3).sum()
+        return e
+
+    class Toy:
+        def energies_and_forces(self, sp, x, cell=None, pbc=None):
+            x = x.detach().requires_grad_(True)
+            e = energy(sp, x)
+            return namedtuple("Out", "energies forces")(e.detach(), -torch.autograd.grad(e.sum(), x)[0])
+
+    torch.manual_seed(0)
+    sp = torch.tensor([[0, 1, 1, -1], [1, 0, 0, 0]])
+    x = torch.randn(2, 4, 3, dtype=torch.float64)
+    h = numerical_hessians(Toy(), sp, x, step=1e-4)
+    assert h.shape == (2, 12, 12) and h.dtype == torch.float64 and torch.equal(h, h.transpose(1, 2))
+    for c in range(2):
+        exact = torch.autograd.functional.hessian(lambda y: energy(sp[c:c + 1], y.view(1, 4, 3)).sum(), x[c].reshape(-1))
+        assert (h[c] - exact).abs().max() < 1e-6, c
+    assert (h[0, 9:, :] == 0).all() and (h[0, :, 9:] == 0).all()          # (padding atom of molecule 0)
+    with pytest.raises(ValueError):
+        numerical_hessians(Toy(), sp, x, step=0.0)
+    # diatomic: one stretch at sqrt(k / mu) / (2 pi), five zero modes
+    k, m1, m2 = 0.7, 1.008, 15.999
+    u = torch.tensor([1.0, 0.0, 0.0, -1.0, 0.0, 0.0], dtype=torch.float64)
+    hess = (k * torch.outer(u, u)).unsqueeze(0)
+    masses = torch.tensor([[m1, m2]], dtype=torch.float64)
+    va = vibrational_analysis(masses, hess)
+    mu = m1 * m2 / (m1 + m2)
+    assert abs(va.freqs[-1].item() - units.sqrt_mhessian2invcm(math.sqrt(k / mu) / (2 * math.pi))) < 1e-8
+    rm = 1.0 / (mu * (1 / m1 ** 2 + 1 / m2 ** 2))     # (Gaussian's reduced mass: 1 / |mass-deweighted mode|^2)
+    assert va.freqs[:5].abs().max() < 1e-3 and abs(va.rmasses[-1].item() - rm) < 1e-10
+    assert abs(va.fconstants[-1].item() - units.mhessian2fconst(k / mu) * rm) < 1e-9 and va.modes.shape == (6, 2, 3)
+    with pytest.raises(ValueError):
+        vibrational_analysis(masses, hess, unit="THz")
+    if not os.path.exists("/root/reference/torchani/grad.py"):
+        pytest.skip("reference tree not present")
+    from _util import import_reference
+    import_reference()
+    from torchani.grad import vibrational_analysis as ref_va
+    a = torch.randn(9, 9, dtype=torch.float64)
+    hess3 = (a @ a.t() - 2.0 * torch.eye(9, dtype=torch.float64)).unsqueeze(0)      # (some negative eigenvalues too)
+    masses3 = torch.tensor([[15.999, 1.008, 1.008]], dtype=torch.float64)
+    for kind in ("mdu", "mdn", "mwn"):
+        for unit in ("cm^-1", "meV"):
+            mine, ref = vibrational_analysis(masses3, hess3, kind, unit), ref_va(masses3, hess3, kind, unit)
+            for p, q in zip(mine, ref):
+                assert torch.allclose(p, q, rtol=1e-10, atol=1e-10), (kind, unit)
