@@ -766,3 +766,27 @@ def test_numerical_hessians_and_vibrational_analysis():
             mine, ref = vibrational_analysis(masses3, hess3, kind, unit), ref_va(masses3, hess3, kind, unit)
             for p, q in zip(mine, ref):
                 assert torch.allclose(p, q, rtol=1e-10, atol=1e-10), (kind, unit)
+
+
+def test_single_point_atomic_charges_host_logic():
+    """grad.single_point(atomic_charges=True) hands out the charges of models whose forward returns them (grad.py:345-353) and
+    says so when a model has none; checked with stand-in models on CPU (the real ones need the GPU)."""
+    from torchani_amd.grad import single_point
+    from torchani_amd.tuples import SpeciesEnergies, SpeciesEnergiesAtomicCharges
+
+    sp = torch.tensor([[0, 1, -1]])
+    x = torch.zeros(1, 3, 3)
+
+    def with_q(sc, cell=None, pbc=None, atomic=False, ensemble_values=False):
+        return SpeciesEnergiesAtomicCharges(sc[0], sc[1].sum(dim=(1, 2)), torch.tensor([[0.25, -0.25, 0.0]]))
+
+    def without_q(sc, cell=None, pbc=None, atomic=False, ensemble_values=False):
+        return SpeciesEnergies(sc[0], sc[1].sum(dim=(1, 2)))
+
+    out = single_point(with_q, sp, x, atomic_charges=True)
+    assert set(out) == {"energies", "atomic_charges"} and out["atomic_charges"].tolist() == [[0.25, -0.25, 0.0]]
+    assert set(single_point(with_q, sp, x)) == {"energies"}
+    with pytest.raises(ValueError, match="atomic charges"):
+        single_point(without_q, sp, x, atomic_charges=True)
+    with pytest.raises(NotImplementedError):
+        single_point(with_q, sp, x, atomic_charges=True, atomic_charges_grad=True)

@@ -138,16 +138,21 @@ def single_point(model, species: Tensor, coordinates: Tensor, cell: tp.Optional[
     energies, and -- with ensemble_values -- the member values, their standard deviation and the QBC factors."""
     if hessians:
         _no_hessians()
-    if atomic_charges or atomic_charges_grad:
-        raise ValueError("Model doesn't support atomic charges")
+    if atomic_charges_grad:
+        raise NotImplementedError("atomic charges carry no gradient here (the charge networks run the inference kernels)")
     if forces and ensemble_values:
         raise NotImplementedError("forces of ensemble_values=True are not differentiable in the HIP engine")
     saved = coordinates.requires_grad
     if forces:
         coordinates.requires_grad_(True)
-    energies = model((species, coordinates), cell, pbc, atomic=atomic_energies,
-                     ensemble_values=ensemble_values).energies
+    result = model((species, coordinates), cell, pbc, atomic=atomic_energies, ensemble_values=ensemble_values)
+    energies = result.energies
     out: tp.Dict[str, Tensor] = {}
+    if atomic_charges:   # (ANIq models: models.ANImbis, models.simple_aniq)
+        if not hasattr(result, "atomic_charges"):
+            coordinates.requires_grad_(saved)
+            raise ValueError("Model doesn't support atomic charges")
+        out["atomic_charges"] = result.atomic_charges
     if ensemble_values:
         if atomic_energies:
             out["atomic_energies"] = energies.mean(dim=0)
