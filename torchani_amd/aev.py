@@ -6,6 +6,7 @@ loads unchanged.  ``strategy`` is always the native HIP path: there is no pyaev 
 """
 from __future__ import annotations
 
+import math
 import typing as tp
 import warnings
 
@@ -39,6 +40,93 @@ class _AngularTerms(torch.nn.Module):
         self.register_buffer("shifts", torch.tensor(list(shifts), dtype=torch.float))
         self.register_buffer("sections", torch.tensor(list(sections), dtype=torch.float))
         self.cutoff = float(cutoff)
+
+
+class ANIRadial(_RadialTerms):
+    """The ANI two-body expansion 0.25 exp(-eta (r - s)^2) fc(r) as an object (aev/_terms.py:131-241): the hyper-parameters
+    an ``Assembler`` / ``AEVComputer.from_terms`` builds the engine's table from, and -- ``module(distances)`` -- a host-side
+    evaluation of the terms on any tensor, [pairs] -> [pairs, shifts] (the kernels never call it)."""
+
+    def __init__(self, eta: float, shifts: tp.Sequence[float], cutoff: float, cutoff_fn="cosine") -> None:
+        from .cutoffs import parse_cutoff_fn
+
+        super().__init__(eta, shifts, cutoff)
+        self.cutoff_fn = parse_cutoff_fn(cutoff_fn)
+        self.num_feats = len(self.shifts)
+
+    def compute(self, distances: Tensor) -> Tensor:
+        return 0.25 * torch.exp(-self.eta * (distances - self.shifts.view(1, -1)) ** 2)
+
+    def forward(self, distances: Tensor) -> Tensor:
+        assert distances.dim() == 1
+        return self.compute(distances.view(-1, 1)) * self.cutoff_fn(distances, self.cutoff).view(-1, 1)
+
+    @classmethod
+    def cover_linearly(cls, start: float = 0.9, cutoff: float = 5.2, eta: float = 19.7, num_shifts: int = 16,
+                       cutoff_fn="cosine") -> "ANIRadial":
+        """``num_shifts`` shifts from ``start`` up to (excluding) ``cutoff`` (aev/_terms.py:189-207)."""
+        from .constants import linspace
+
+        return cls(eta, linspace(start, cutoff, num_shifts), cutoff, cutoff_fn)
+
+    @classmethod
+    def like_1x(cls, start: float = 0.9, cutoff: float = 5.2, eta: float = 16.0, num_shifts: int = 16,
+                cutoff_fn="cosine") -> "ANIRadial":
+        return cls.cover_linearly(start, cutoff, eta, num_shifts, cutoff_fn)
+
+    @classmethod
+    def like_2x(cls, start: float = 0.8, cutoff: float = 5.1, eta: float = 19.7, num_shifts: int = 16,
+                cutoff_fn="cosine") -> "ANIRadial":
+        return cls.cover_linearly(start, cutoff, eta, num_shifts, cutoff_fn)
+
+
+class ANIAngular(_AngularTerms):
+    """The ANI three-body expansion (aev/_terms.py:244-410): 2 ((1 + cos(theta - theta_s)) / 2)^zeta exp(-eta ((r1 + r2) / 2 -
+    s)^2) fc(r1) fc(r2), theta = acos(0.95 cos_angle); ``module(tri_distances [2, T], tri_vectors [2, T, 3])`` evaluates it
+    on the host, -> [T, shifts * sections] (shift-major, the layout of an AEV's angular block)."""
+
+    def __init__(self, eta: float, zeta: float, shifts: tp.Sequence[float], sections: tp.Sequence[float], cutoff: float,
+                 cutoff_fn="cosine") -> None:
+        from .cutoffs import parse_cutoff_fn
+
+        super().__init__(eta, zeta, shifts, sections, cutoff)
+        self.cutoff_fn = parse_cutoff_fn(cutoff_fn)
+        self.num_feats = len(self.shifts) * len(self.sections)
+
+    def compute_radial(self, distances_ji: Tensor, distances_jk: Tensor) -> Tensor:
+        return torch.exp(-self.eta * ((distances_ji + distances_jk) / 2 - self.shifts.view(1, -1)) ** 2)
+
+    def compute_cos_angles(self, cos_angles: Tensor) -> Tensor:
+        return 2 * ((1 + torch.cos(torch.acos(0.95 * cos_angles) - self.sections.view(1, -1))) / 2) ** self.zeta
+
+    def forward(self, tri_distances: Tensor, tri_vectors: Tensor) -> Tensor:
+        assert tri_distances.dim() == 2 and tri_vectors.shape == (2, tri_distances.shape[1], 3)
+        fc = self.cutoff_fn(tri_distances, self.cutoff)
+        d = tri_distances.view(2, -1, 1)
+        cos_angles = (tri_vectors[0] * tri_vectors[1]).sum(-1, keepdim=True) / torch.clamp(d[0] * d[1], min=1e-10)
+        terms = self.compute_radial(d[0], d[1]).unsqueeze(2) * self.compute_cos_angles(cos_angles).unsqueeze(1)
+        return terms.reshape(-1, self.num_feats) * (fc[0] * fc[1]).view(-1, 1)
+
+    @classmethod
+    def cover_linearly(cls, start: float = 0.9, cutoff: float = 3.5, eta: float = 12.5, zeta: float = 14.1,
+                       num_shifts: int = 8, num_sections: int = 4, cutoff_fn="cosine") -> "ANIAngular":
+        """Shifts like ANIRadial.cover_linearly, ``num_sections`` angles from pi / (2 n) in steps of pi / n
+        (aev/_terms.py:346-366)."""
+        from .constants import linspace
+
+        a0 = math.pi / num_sections / 2
+        return cls(eta, zeta, linspace(start, cutoff, num_shifts), linspace(a0, math.pi + a0, num_sections), cutoff,
+                   cutoff_fn)
+
+    @classmethod
+    def like_1x(cls, start: float = 0.9, cutoff: float = 3.5, eta: float = 8.0, zeta: float = 32.0, num_shifts: int = 4,
+                num_sections: int = 8, cutoff_fn="cosine") -> "ANIAngular":
+        return cls.cover_linearly(start, cutoff, eta, zeta, num_shifts, num_sections, cutoff_fn)
+
+    @classmethod
+    def like_2x(cls, start: float = 0.8, cutoff: float = 3.5, eta: float = 12.5, zeta: float = 14.1, num_shifts: int = 8,
+                num_sections: int = 4, cutoff_fn="cosine") -> "ANIAngular":
+        return cls.cover_linearly(start, cutoff, eta, zeta, num_shifts, num_sections, cutoff_fn)
 
 
 class _AEVBackwardFunction(torch.autograd.Function):
@@ -160,6 +248,20 @@ class AEVComputer(torch.nn.Module):
     @classmethod
     def like_1x(cls, num_species: int = 4, cutoff_fn: str = "cosine", **kw) -> "AEVComputer":
         return cls(aev_constants_1x(num_species, cutoff_fn), **kw)
+
+    @classmethod
+    def from_terms(cls, radial: _RadialTerms, angular: _AngularTerms, num_species: int, cutoff_fn="cosine",
+                   **kw) -> "AEVComputer":
+        """From ANIRadial / ANIAngular objects (the reference's AEVComputer(radial=, angular=, num_species=, cutoff_fn=),
+        aev/_computer.py:73-129): their hyper-parameters become the engine's table; one envelope for both terms."""
+        if angular.cutoff > radial.cutoff:
+            raise ValueError("Angular cutoff must be smaller or equal to radial cutoff")
+        if angular.cutoff <= 0 or radial.cutoff <= 0:
+            raise ValueError("Cutoffs must be strictly positive")
+        return cls(AEVConstants(num_species, radial.cutoff, angular.cutoff, float(radial.eta.item()),
+                                tuple(radial.shifts.double().tolist()), float(angular.eta.item()),
+                                float(angular.zeta.item()), tuple(angular.shifts.double().tolist()),
+                                tuple(angular.sections.double().tolist()), cutoff_fn), **kw)
 
     @classmethod
     def from_constants(cls, radial_cutoff: float, angular_cutoff: float, radial_eta: float,

@@ -315,6 +315,9 @@ class TwoBodyDispersionD3(torch.nn.Module):
                  sqrt_empirical_charge: tp.Sequence[float] = (), covalent_radii: tp.Sequence[float] = (), *,
                  cutoff_fn: str = "smooth", cutoff: float = math.inf) -> None:
         super().__init__()
+        from .cutoffs import kernel_name   # (a name or a torchani_amd.cutoffs.Cutoff object)
+
+        cutoff_fn = kernel_name(cutoff_fn)
         if cutoff_fn not in _lib.CUTOFF_KINDS:
             raise ValueError(f"Unsupported cutoff function {cutoff_fn!r}: the HIP kernels have {sorted(_lib.CUTOFF_KINDS)}")
         if len(symbols) > 7:
