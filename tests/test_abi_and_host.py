@@ -876,3 +876,18 @@ def test_assembler_and_term_objects():
     for k in sd_r:
         if "aev_computer" in k or k in ("atomic_numbers", "energy_shifter.self_energies"):
             assert torch.allclose(sd_r[k].double(), sd_a[k].double()), k
+
+
+def test_package_namespace_follows_the_reference():
+    """``import torchani_amd as torchani``: the submodules and convenience names of torchani/__init__.py that exist here
+    resolve (lazily), unknown names raise AttributeError."""
+    import torchani_amd as t
+
+    for mod in ("nn", "aev", "arch", "utils", "models", "units", "electro", "cutoffs", "sae", "constants", "grad", "io",
+                "potentials"):
+        assert getattr(t, mod).__name__ == f"torchani_amd.{mod}"
+    for name in ("AEVComputer", "ANINetworks", "ANIModel", "Ensemble", "SpeciesConverter", "SelfEnergy", "single_point"):
+        assert callable(getattr(t, name))
+    assert t.sae.SelfEnergy is t.SelfEnergy and t.ANIModel is t.ANINetworks
+    with pytest.raises(AttributeError):
+        t.neurochem

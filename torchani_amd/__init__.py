@@ -6,7 +6,8 @@ Ensemble, SpeciesConverter, SpeciesEnergies, models.ANI1x / models.ANI2x, grad.e
 from . import constants, weights  # noqa: F401  (import-light; no torch needed)
 
 __all__ = ["AEVComputer", "ANINetworks", "ANIModel", "Ensemble", "SpeciesConverter", "SpeciesEnergies",
-           "SpeciesAEV", "AtomicNetwork", "models", "grad", "parallel"]
+           "SpeciesAEV", "AtomicNetwork", "models", "grad", "parallel", "arch", "units", "io", "cutoffs", "electro", "utils",
+           "potentials", "ase", "md", "sae", "single_point", "SelfEnergy"]
 
 
 def __getattr__(name):
@@ -14,7 +15,8 @@ def __getattr__(name):
     # tests) can use torchani_amd.constants / .weights without importing torch
     import importlib
 
-    if name in ("models", "grad", "parallel", "engine", "aev", "nn", "tuples", "_lib"):
+    if name in ("models", "grad", "parallel", "engine", "aev", "nn", "tuples", "_lib", "arch", "units", "io", "cutoffs",
+                "electro", "utils", "potentials", "ase", "md", "ops", "sae"):
         return importlib.import_module(f".{name}", __name__)
     table = {
         "AEVComputer": ("aev", "AEVComputer"),
@@ -25,6 +27,8 @@ def __getattr__(name):
         "AtomicNetwork": ("nn", "AtomicNetwork"),
         "SpeciesEnergies": ("tuples", "SpeciesEnergies"),
         "SpeciesAEV": ("tuples", "SpeciesAEV"),
+        "single_point": ("grad", "single_point"),   # (torchani/__init__.py exports these at the top level)
+        "SelfEnergy": ("nn", "SelfEnergy"),
     }
     if name in table:
         mod, attr = table[name]
