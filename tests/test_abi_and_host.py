@@ -924,3 +924,19 @@ def test_transforms_module():
     from torchani import transforms as R
     ref = R.Compose([R.SubtractSAE(sym, sae), R.AtomicNumbersToIndices(sym)])({k: v.clone() for k, v in batch.items()})
     assert torch.equal(ref["species"], out["species"]) and torch.allclose(ref["energies"], out["energies"])
+
+
+def test_pair_potential_standalone_host_logic():
+    """Pair potentials called on their own (core.py:37-67): atomic numbers are mapped to the potential's element indices on
+    the host, unknown elements and CPU tensors are refused (the evaluation itself is a GPU test)."""
+    from torchani_amd.potentials import RepulsionXTB, TwoBodyDispersionD3
+
+    pot = RepulsionXTB(("H", "C", "O"), cutoff=5.2)
+    z = torch.tensor([[8, 1, 1, -1], [6, 1, 1, 1]])
+    assert pot._to_elem_idxs(z, True).tolist() == [[2, 0, 0, -1], [1, 0, 0, 0]] and pot._to_elem_idxs(z, False) is z
+    with pytest.raises(ValueError, match="Unsupported element"):
+        pot._to_elem_idxs(torch.tensor([[2, 1]]), True)
+    with pytest.raises(ValueError, match="ROCm device"):
+        pot(z, torch.zeros(2, 4, 3))
+    d3 = TwoBodyDispersionD3.from_functional(("H", "O"), "b973c", cutoff=8.0)
+    assert d3._to_elem_idxs(torch.tensor([[8, 1, 1]]), True).tolist() == [[1, 0, 0]]

@@ -60,7 +60,51 @@ class _PairEnergy(torch.autograd.Function):
         return (grad.view(Cn, A, 3) * g.view(Cn, 1, 1).to(grad.dtype)).to(ctx.dtype), None, None, None
 
 
-class _AnalyticPair(torch.nn.Module):
+class _Standalone:
+    """``potential(species, coords, cell, pbc, atomic=False, atomic_nums_input=True)`` without a model around it
+    (core.py:37-67 Potential.forward): the potential builds its own neighbor rows with its own cutoff and evaluates
+    itself on them.  Molecular energies [C] (float64, differentiable with respect to coords) or per-atom halves [C, A]."""
+
+    def _standalone_rows(self, species32: Tensor, coords: Tensor, cell, pbc) -> NeighborRows:
+        from .constants import aev_constants_2x
+
+        rc = min(self.cutoff, 1.0e3)
+        if self._own_engine is None or abs(self._own_engine.consts.Rcr - rc) > 1e-9:
+            self._own_engine = AevEngine(aev_constants_2x(len(self.symbols))._replace(Rcr=rc, Rca=1e-3))
+        pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
+        mode = "cell" if (species32.shape[0] == 1 and species32.shape[1] > 512) else "batch"
+        return self._own_engine.neighbors(species32, coords.detach().to(torch.float32).contiguous(), cell, pbc_t, mode=mode,
+                                          row_cap=_lib.MAX_RAD)
+
+    def _to_elem_idxs(self, species: Tensor, atomic_nums_input: bool) -> Tensor:
+        """Atomic numbers -> this potential's element indices (padding -1 stays); unknown elements raise."""
+        if not atomic_nums_input:
+            return species
+        lut = torch.full((120,), -1, dtype=torch.long)
+        lut[self.atomic_numbers.cpu()] = torch.arange(len(self.symbols))
+        elem = lut.to(species.device)[species.clamp(min=-1)]     # (-1 indexes the last, unused slot)
+        if (elem[species != -1] == -1).any():
+            raise ValueError(f"Unsupported element in {torch.unique(species).tolist()}: this potential knows {self.symbols}")
+        return elem
+
+    def forward(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None, pbc=None, atomic: bool = False,
+                ensemble_values: bool = False, atomic_nums_input: bool = True) -> Tensor:
+        if not coords.is_cuda:
+            raise ValueError("torchani_amd's pair potentials need tensors on a ROCm device (no CPU fallback)")
+        if species.dim() != 2 or coords.shape != (species.shape[0], species.shape[1], 3):
+            raise ValueError("expected species [C, A] and coords [C, A, 3]")
+        species32 = self._to_elem_idxs(species, atomic_nums_input).to(torch.int32).contiguous()
+        rows = self._standalone_rows(species32, coords, cell, pbc)
+        if atomic:
+            a = torch.zeros(species32.numel(), dtype=torch.float32, device=coords.device)
+            self.accumulate(species32, rows, a, None)
+            e = a.view(species32.shape)
+        else:
+            e = self.compute_from_rows(species32, coords, rows)
+        return e.unsqueeze(0) if ensemble_values else e
+
+
+class _AnalyticPair(_Standalone, torch.nn.Module):
     """Shared part of the closed-form pair potentials (core.py:103-207 BasePairPotential): a [8, 8, 4] device table of
     per-element-pair constants evaluated by anihip_pair_analytic (kind = ANIHIP_PAIR_*)."""
 
@@ -303,7 +347,7 @@ def d3_reference_data() -> tp.Dict[str, tp.Any]:
     return _D3_REFS
 
 
-class TwoBodyDispersionD3(torch.nn.Module):
+class TwoBodyDispersionD3(_Standalone, torch.nn.Module):
     """Two-body DFT-D3 dispersion with Becke-Johnson damping (potentials/dftd3.py:113-330).
 
     ``sqrt_empirical_charge`` / ``covalent_radii`` (Angstrom) default to the tabulated values of the elements, like the
