@@ -940,3 +940,21 @@ def test_pair_potential_standalone_host_logic():
         pot(z, torch.zeros(2, 4, 3))
     d3 = TwoBodyDispersionD3.from_functional(("H", "O"), "b973c", cutoff=8.0)
     assert d3._to_elem_idxs(torch.tensor([[8, 1, 1]]), True).tolist() == [[1, 0, 0]]
+
+
+def test_model_strategy_and_infer_conversions_are_accepted():
+    """ANI.set_strategy / to_infer_model (arch.py:145-148,208-217): the reference's calls go through (there is one native
+    path), unknown strategies raise like the reference's."""
+    import warnings
+
+    from torchani_amd.models import ANI2x
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ANI2x(seed=0, n_members=2)
+    for s in ("pyaev", "cuaev", "cuaev-fused", "cuaev-interface", "auto"):
+        m.set_strategy(s)
+    nets = m.neural_networks
+    assert m.to_infer_model(use_mnp=True) is m and m.neural_networks is nets and m.aev_computer.strategy == "hip"
+    with pytest.raises(ValueError):
+        m.set_strategy("tpu")

@@ -351,7 +351,8 @@ class AEVComputer(torch.nn.Module):
     _compute_cuaev_with_full_nbrlist = compute_from_full_nbrlist   # the reference's (private) name
 
     def set_strategy(self, strategy: str) -> None:
-        if strategy not in ("hip", "auto"):
+        # (aev/_computer.py:131-149: the reference's names are accepted like in the constructor, all mean the HIP path)
+        if strategy not in ("hip", "auto", "pyaev", "cuaev", "cuaev-fused", "cuaev-interface"):
             raise ValueError(f"Unsupported strategy {strategy!r}")
 
     def forward(self, elem_idxs, coords: tp.Optional[Tensor] = None, cell: tp.Optional[Tensor] = None,

@@ -84,6 +84,16 @@ class ANI(torch.nn.Module):
         else:
             self.potentials[key]._enabled = val
 
+    def set_strategy(self, strategy: str) -> None:
+        """arch.py:145-148: forwarded to the AEV computer (every reference strategy name means the HIP engine here)."""
+        self.aev_computer.set_strategy(strategy)
+
+    def to_infer_model(self, use_mnp: bool = False) -> "ANI":
+        """arch.py:208-217: the reference swaps its networks for a batched-matmul / C++ inference container; the
+        containers here always run the fused native kernels, so this returns the model as it is."""
+        self.potentials["nnp"].neural_networks = self.neural_networks.to_infer_model(use_mnp=use_mnp)
+        return self
+
     def _elem_idxs(self, species: Tensor) -> Tensor:
         return self.species_converter(species, nop=not self.periodic_table_index)
 
