@@ -958,3 +958,53 @@ def test_model_strategy_and_infer_conversions_are_accepted():
     assert m.to_infer_model(use_mnp=True) is m and m.neural_networks is nets and m.aev_computer.strategy == "hip"
     with pytest.raises(ValueError):
         m.set_strategy("tpu")
+
+
+def test_sae_estimation():
+    """sae_estimation.exact_saes recovers the self energies a synthetic dataset was built from (also with an intercept),
+    approx_saes moves towards them; plain lists of batches and objects with a ``transform`` attribute both work; the
+    reference's functions on the same dataset where the tree is present."""
+    from torchani_amd.sae_estimation import approx_saes, exact_saes
+
+    sym, true = ("H", "C", "O"), torch.tensor([-0.5, -37.8, -75.0])
+    znum = torch.tensor([1, 6, 8])
+    g = torch.Generator().manual_seed(0)
+
+    def batch():
+        idx = torch.randint(-1, 3, (16, 9), generator=g)
+        sp = torch.where(idx >= 0, znum[idx.clamp(min=0)], idx)
+        e = torch.stack([(idx == k).sum(-1) for k in range(3)], 1).float() @ true
+        return {"species": sp, "energies": e.double()}
+
+    data = [batch() for _ in range(6)]
+    m, b = exact_saes(data, sym)
+    assert b is None and torch.allclose(m, true, atol=1e-3)
+    for d in data:
+        d["energies"] += 1.25
+    m2, b2 = exact_saes(data, sym, fit_intercept=True)
+    assert torch.allclose(m2, true, atol=2e-3) and abs(b2.item() - 1.25) < 2e-2
+    assert data[0]["species"].max() == 8                                   # (the batches are left as they were)
+
+    class DS(list):   # the reference's BatchedDataset protocol: batches come out through .transform
+        transform = staticmethod(lambda p: p)
+
+        def __iter__(self):
+            return (self.transform({k: v.clone() for k, v in p.items()}) for p in list.__iter__(self))
+
+    ds = DS(batch() for _ in range(6))
+    keep = ds.transform
+    m3, _ = exact_saes(ds, sym, fraction=0.5)
+    assert torch.allclose(m3, true, atol=1e-3) and ds.transform is keep
+    m4, b4 = approx_saes(ds, sym, max_epochs=200, lr=2e-3)
+    assert b4 is None and (m4 - true).abs().max() < (torch.ones(3) - true).abs().max()
+    if not os.path.exists("/root/reference/torchani/sae_estimation.py"):
+        pytest.skip("reference tree not present")
+    from _util import import_reference
+    import_reference()
+    from torchani.sae_estimation import approx_saes as ref_approx
+    from torchani.sae_estimation import exact_saes as ref_exact
+    assert torch.allclose(ref_exact(ds, sym)[0], exact_saes(ds, sym)[0], atol=1e-4)
+    torch.manual_seed(0)
+    a = ref_approx(ds, sym, max_epochs=3, lr=1e-3, fit_intercept=True)
+    b = approx_saes(ds, sym, max_epochs=3, lr=1e-3, fit_intercept=True)
+    assert torch.allclose(a[0], b[0], atol=1e-5) and torch.allclose(a[1], b[1], atol=1e-5)

@@ -7,7 +7,7 @@ from . import constants, weights  # noqa: F401  (import-light; no torch needed)
 
 __all__ = ["AEVComputer", "ANINetworks", "ANIModel", "Ensemble", "SpeciesConverter", "SpeciesEnergies",
            "SpeciesAEV", "AtomicNetwork", "models", "grad", "parallel", "arch", "units", "io", "cutoffs", "electro", "utils",
-           "potentials", "ase", "md", "sae", "transforms", "single_point", "SelfEnergy"]
+           "potentials", "ase", "md", "sae", "sae_estimation", "transforms", "single_point", "SelfEnergy"]
 
 
 def __getattr__(name):
@@ -16,7 +16,7 @@ def __getattr__(name):
     import importlib
 
     if name in ("models", "grad", "parallel", "engine", "aev", "nn", "tuples", "_lib", "arch", "units", "io", "cutoffs",
-                "electro", "utils", "potentials", "ase", "md", "ops", "sae", "transforms"):
+                "electro", "utils", "potentials", "ase", "md", "ops", "sae", "transforms", "sae_estimation"):
         return importlib.import_module(f".{name}", __name__)
     table = {
         "AEVComputer": ("aev", "AEVComputer"),
