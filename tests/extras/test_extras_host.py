@@ -1,0 +1,277 @@
+"""Host-side conveniences of torchani_amd.extras (outside the hot path; SURVEY 2.1 marks them out of scope)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from torchani_amd import _lib
+
+    _lib.build()
+    return _lib.lib()
+
+
+def test_dipoles_and_raw_normalizer():
+    """electro.DipoleComputer / compute_dipole against the reference's values for the reference's charges (fixture), on CPU
+    tensors; BaseChargeNormalizer passes the raw charges through; simple_aniq(normalize=False) uses it."""
+    import warnings
+
+    from torchani_amd.extras.electro import BaseChargeNormalizer, DipoleComputer, compute_dipole
+    from torchani_amd.models import simple_aniq
+
+    ref = dict(np.load(os.path.join(ROOT, "tests", "golden", "simple_chnoq.npz")))
+    z, x, q = (torch.from_numpy(ref[k]) for k in ("atomic_numbers", "coords", "atomic_charges"))
+    for frame in ("center_of_mass", "center_of_geometry", "origin"):
+        mu = compute_dipole(z, x.double(), q, frame)
+        assert mu.shape == (z.shape[0], 3) and np.abs(mu.numpy() - ref["dipole_" + frame]).max() < 1e-12, frame
+    # neutral molecules: the dipole does not depend on the frame
+    assert np.abs(ref["dipole_origin"] - ref["dipole_center_of_mass"]).max() < 1e-9
+    custom = DipoleComputer(masses=[0.0, 2.0] + [1.0] * 16, reference="center_of_mass", dtype=torch.float64)
+    mu = custom(torch.tensor([[1, 8, -1]]), torch.tensor([[[0.0, 0, 0], [3.0, 0, 0], [9.0, 9, 9]]], dtype=torch.float64),
+                torch.tensor([[1.0, 0.0, 0.0]], dtype=torch.float64))
+    assert torch.allclose(mu, torch.tensor([[-1.0, 0.0, 0.0]], dtype=torch.float64))   # (center of mass at x = 1)
+    with pytest.raises(ValueError):
+        DipoleComputer(reference="nucleus")
+    raw = torch.tensor([[0.3, -0.1]])
+    assert torch.equal(BaseChargeNormalizer()(torch.tensor([[0, 1]]), raw), raw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = simple_aniq(("H", "O"), "wb97x-631gd", normalize=False, seed=2)
+    assert type(m.potentials["nnp"].charge_normalizer) is BaseChargeNormalizer
+    assert set(k.split(".")[2] for k in m.state_dict() if k.startswith("potentials.nnp.") and "networks" in k) == \
+        {"neural_networks", "charge_networks"}
+
+
+def test_xyz_io_round_trip_and_reference(tmp_path):
+    """torchani_amd.io.read_xyz / write_xyz (io.py:22-176): round trips with padding and a cell, the padding placeholder,
+    the error cases; the reference's own reader on its in-tree files where the tree is present (the build container)."""
+    from torchani_amd.extras.io import TorchaniIOError, read_xyz, write_xyz
+
+    sp = torch.tensor([[8, 1, 1, -1], [6, 1, 1, 1]])
+    x = torch.arange(24, dtype=torch.float64).reshape(2, 4, 3) / 7
+    cell = torch.tensor([[10.0, 0, 0], [0, 11.5, 0], [0.25, 0, 12.0]], dtype=torch.float64)
+    f = tmp_path / "a.xyz"
+    write_xyz(sp, x, f, cell=cell)
+    sp2, x2, cell2, pbc2 = read_xyz(f, dtype=torch.float64)
+    assert torch.equal(sp2, sp) and torch.allclose(x2[sp >= 0], x[sp >= 0], atol=1e-10) and (x2[sp < 0] == 0).all()
+    assert torch.allclose(cell2, cell) and pbc2.tolist() == [True, True, True]
+    write_xyz(sp, x, f, pad=True)                        # padding atoms written as element 100 ("Fm")
+    text = f.read_text().splitlines()
+    assert text[0] == "4" and text[5].startswith("Fm 0.0000000000") and 'pbc="F F F"' in text[1]
+    sp3, x3, cell3, pbc3, comments = read_xyz(f, dtype=torch.float64, return_comments=True)
+    assert torch.equal(sp3, sp) and cell3 is None and pbc3 is None and len(comments) == 2
+    assert read_xyz(f, detect_padding=False)[0][0, 3].item() == 100
+    (tmp_path / "n.xyz").write_text("2\n\n1 0 0 0\n8 0 0 1\n>\n1\ncomment\nCl 1 2 3\n")   # numbers, divider, symbols
+    spn, xn, _, _ = read_xyz(tmp_path / "n.xyz")
+    assert spn.tolist() == [[1, 8], [17, -1]] and xn[1, 0].tolist() == [1.0, 2.0, 3.0]
+    (tmp_path / "bad.xyz").write_text('1\nfoo\nH 0 0 0\n1\nLattice="1 0 0 0 1 0 0 0 1"\nH 0 0 0\n')
+    with pytest.raises(TorchaniIOError):
+        read_xyz(tmp_path / "bad.xyz")
+    with pytest.raises(ValueError):
+        write_xyz(sp[0], x[0], f)
+    ref_file = "/root/reference/dataset/xyz_files/13.xyz"
+    if not os.path.exists(ref_file):
+        pytest.skip("reference tree not present")
+    from _util import import_reference   # (stub modules for the reference's optional imports)
+    import_reference()
+    from torchani.io import read_xyz as ref_read
+    for path in (ref_file, "/root/reference/tests/resources/water-0.8nm.xyz", "/root/reference/tests/resources/small.xyz"):
+        if not os.path.exists(path):
+            continue
+        a, b = read_xyz(path, dtype=torch.float64), ref_read(path, dtype=torch.float64)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), path
+        assert (a[2] is None) == (b[2] is None) and (a[2] is None or torch.equal(a[2], b[2])), path
+
+
+def test_symbol_number_mass_converters():
+    """utils: the reference's small converter modules (utils.py:257-473) under their names."""
+    from torchani_amd import utils as u
+
+    assert u.AtomicNumbersToChemicalSymbols()(torch.tensor([6, 1, 1, -1, 17])) == ["C", "H", "H", "Cl"]
+    assert u.IntsToChemicalSymbols(["H", "C", "N", "O"])(torch.tensor([3, 0, 0, -1])) == ["O", "H", "H"]
+    assert u.ChemicalSymbolsToAtomicNumbers()(["C", "S", "O", "F", "H"]).tolist() == [6, 16, 8, 9, 1]
+    conv = u.ChemicalSymbolsToInts(["H", "C", "N", "O", "S", "F", "Cl"])
+    assert conv(["C", "S", "O", "F", "H", "H"]).tolist() == [1, 4, 3, 5, 0, 0] and len(conv) == 7
+    with pytest.raises(ValueError):
+        u.ChemicalSymbolsToInts("HCNO")
+    m = u.atomic_numbers_to_masses(torch.tensor([[8, 1, 1, -1]]), dtype=torch.float64)
+    assert torch.allclose(m, torch.tensor([[15.999, 1.008, 1.008, 0.0]], dtype=torch.float64)) and u.get_atomic_masses is u.atomic_numbers_to_masses
+    with pytest.raises(ValueError):
+        u.atomic_numbers_to_masses(torch.tensor([[26]]))      # (no iron in the default table: pass masses=)
+    assert u.sort_by_atomic_num(["Cl", "H", "O", "C"]) == ("H", "C", "O", "Cl") and u.sort_by_atomic_num("N") == ("N",)
+
+
+def test_assembler_and_term_objects():
+    """torchani_amd.arch.Assembler builds the same modules as the fixed factories from the reference's step-by-step protocol
+    (arch.py:743-990); ANIRadial / ANIAngular carry the hyper-parameters and evaluate the terms on the host.  Where the
+    reference tree is present: its terms on the same inputs, and the state dict of its Assembler's model, key by key."""
+    import warnings
+
+    from torchani_amd.aev import AEVComputer, ANIAngular, ANIRadial
+    from torchani_amd.extras.arch import ANIq, Assembler
+    from torchani_amd.extras.electro import ChargeNormalizer
+    from torchani_amd.models import ANI2x
+    from torchani_amd.potentials import RepulsionXTB, TwoBodyDispersionD3
+
+    def recipe(asm_cls, **extra):
+        asm = asm_cls(periodic_table_index=False, **extra)
+        asm.set_symbols(("H", "C", "N", "O", "S", "F", "Cl"))
+        asm.set_global_cutoff_fn("cosine")
+        asm.set_aev_computer(radial="ani2x", angular="ani2x", strategy="pyaev")
+        asm.set_atomic_networks(ctor="ani2x")
+        asm.set_neighborlist("all_pairs")
+        asm.set_gsaes_as_self_energies("wb97x-631gd")
+        return asm
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fixed = ANI2x(seed=0)
+    asm = recipe(Assembler)
+    built = asm.assemble(8)
+    sd_a, sd_b = built.state_dict(), fixed.state_dict()
+    assert set(sd_a) == set(sd_b) and all(sd_a[k].shape == sd_b[k].shape for k in sd_a)
+    for k in sd_a:
+        if "aev_computer" in k or k in ("atomic_numbers", "energy_shifter.self_energies"):
+            assert torch.equal(sd_a[k], sd_b[k]), k
+    assert all(p.requires_grad for p in built.neural_networks.parameters())         # (CELU with biases: trainable)
+    asm.add_potential(RepulsionXTB, "repulsion_xtb", cutoff=5.1)
+    asm.add_potential(TwoBodyDispersionD3, "dispersion_d3", cutoff=8.0, kwargs={"functional": "b973c"})
+    with pytest.raises(ValueError):
+        asm.add_potential(RepulsionXTB, "repulsion_xtb")
+    both = asm.assemble(2)
+    assert list(both.potentials) == ["nnp", "repulsion_xtb", "dispersion_d3"] and both.potentials["dispersion_d3"].cutoff == 8.0
+    assert both.potentials["repulsion_xtb"].cutoff_fn == "cosine"                      # (the global envelope)
+    q = recipe(Assembler, cls=ANIq)
+    q.set_charge_networks(ctor="ani2x", kwargs={"bias": False, "activation": "gelu", "out_dim": 1},
+                          normalizer=ChargeNormalizer.from_electronegativity_and_hardness(q.symbols))
+    mq = q.assemble(1)
+    assert isinstance(mq, ANIq) and not any(p.requires_grad for p in mq.potentials["nnp"].charge_networks.parameters())
+    for bad in (lambda a: a.set_atomic_networks(ctor="like_dr"), lambda a: a.set_aev_computer("ani2x", "ani3x"),
+                lambda a: a.set_atomic_networks(ctor="ani2x", kwargs={"activation": "tanh"})):
+        a = recipe(Assembler)
+        with pytest.raises(ValueError):
+            bad(a)
+            a.assemble(1)
+    with pytest.raises(RuntimeError):
+        Assembler(symbols=("H",)).assemble(1)
+    # term objects
+    r, a = ANIRadial.cover_linearly(0.9, 5.2, 19.7, 16, "smooth"), ANIAngular.like_1x()
+    assert r.num_feats == 16 and a.num_feats == 32 and AEVComputer.from_terms(r, ANIAngular.like_2x(), 4).out_dim == 384
+    d = torch.linspace(0.5, 6.0, 12, dtype=torch.float64)
+    assert r(d).shape == (12, 16) and (r(d)[d >= 5.2] == 0).all() is not None
+    with pytest.raises(ValueError):
+        AEVComputer.from_terms(ANIRadial.like_2x(cutoff=3.0), ANIAngular.like_2x(), 4)
+    if not os.path.exists("/root/reference/torchani/arch.py"):
+        pytest.skip("reference tree not present")
+    from _util import import_reference
+    import_reference()
+    from torchani.aev import ANIAngular as RefAngular
+    from torchani.aev import ANIRadial as RefRadial
+    from torchani.arch import Assembler as RefAssembler
+    torch.manual_seed(0)
+    td, tv = torch.rand(2, 40, dtype=torch.float64) * 3.4 + 0.4, torch.randn(2, 40, 3, dtype=torch.float64)
+    tv = tv / tv.norm(dim=-1, keepdim=True) * td.unsqueeze(-1)
+    for name, kw in (("like_1x", {}), ("like_2x", {}), ("cover_linearly", dict(cutoff_fn="smooth"))):
+        mine, ref = getattr(ANIRadial, name)(**kw).double(), getattr(RefRadial, name)(**kw).double()
+        assert torch.allclose(mine(d), ref(d), rtol=1e-12, atol=1e-14), name
+        mine, ref = getattr(ANIAngular, name)(**kw).double(), getattr(RefAngular, name)(**kw).double()
+        assert torch.allclose(mine(td, tv), ref(td, tv), rtol=1e-10, atol=1e-14), name
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_model = recipe(RefAssembler).assemble(8)
+    sd_r = ref_model.state_dict()
+    assert set(sd_r) == set(sd_a), sorted(set(sd_r) ^ set(sd_a))[:5]
+    assert all(sd_r[k].shape == sd_a[k].shape for k in sd_r)
+    for k in sd_r:
+        if "aev_computer" in k or k in ("atomic_numbers", "energy_shifter.self_energies"):
+            assert torch.allclose(sd_r[k].double(), sd_a[k].double()), k
+
+
+def test_transforms_module():
+    """torchani_amd.transforms: the host-side batch transforms of the reference (transforms.py:43-230) on CPU tensors; the
+    reference's classes on the same batch where the tree is present."""
+    from collections import namedtuple
+
+    from torchani_amd.extras import transforms as T
+
+    sym, sae = ("H", "C", "O"), (-0.5, -37.8, -75.0)
+    batch = {"species": torch.tensor([[8, 1, 1, -1], [6, 1, 1, 1]]), "coordinates": torch.zeros(2, 4, 3),
+             "energies": torch.tensor([-76.3, -39.2], dtype=torch.float64), "forces": torch.ones(2, 4, 3)}
+    pipe = T.Compose([T.SubtractSAE(sym, sae), T.identity, T.AtomicNumbersToIndices(sym)])
+    out = pipe({k: v.clone() for k, v in batch.items()})
+    assert torch.allclose(out["energies"], torch.tensor([-76.3 + 76.0, -39.2 + 39.3], dtype=torch.float64))
+    assert out["species"].tolist() == [[2, 0, 0, -1], [1, 0, 0, 0]] and pipe.atomic_numbers.tolist() == [1, 6, 8]
+    assert "SubtractSAE" in repr(pipe) and T.Identity().atomic_numbers is None
+    with pytest.raises(ValueError):
+        T.Compose([T.SubtractSAE(sym, sae), T.AtomicNumbersToIndices(("H", "O"))])
+
+    class Model:   # stand-in for an engine-backed model
+        def energies_and_forces(self, sp, x):
+            return namedtuple("Out", "energies forces")(torch.full((sp.shape[0],), 2.0), torch.full_like(x, 0.25))
+
+    o2 = T.SubtractModel(Model())({k: v.clone() for k, v in batch.items()})
+    assert torch.allclose(o2["energies"], batch["energies"] - 2.0) and torch.allclose(o2["forces"], batch["forces"] - 0.25)
+    if not os.path.exists("/root/reference/torchani/transforms.py"):
+        pytest.skip("reference tree not present")
+    from _util import import_reference
+    import_reference()
+    from torchani import transforms as R
+    ref = R.Compose([R.SubtractSAE(sym, sae), R.AtomicNumbersToIndices(sym)])({k: v.clone() for k, v in batch.items()})
+    assert torch.equal(ref["species"], out["species"]) and torch.allclose(ref["energies"], out["energies"])
+
+
+def test_sae_estimation():
+    """sae_estimation.exact_saes recovers the self energies a synthetic dataset was built from (also with an intercept),
+    approx_saes moves towards them; plain lists of batches and objects with a ``transform`` attribute both work; the
+    reference's functions on the same dataset where the tree is present."""
+    from torchani_amd.extras.sae_estimation import approx_saes, exact_saes
+
+    sym, true = ("H", "C", "O"), torch.tensor([-0.5, -37.8, -75.0])
+    znum = torch.tensor([1, 6, 8])
+    g = torch.Generator().manual_seed(0)
+
+    def batch():
+        idx = torch.randint(-1, 3, (16, 9), generator=g)
+        sp = torch.where(idx >= 0, znum[idx.clamp(min=0)], idx)
+        e = torch.stack([(idx == k).sum(-1) for k in range(3)], 1).float() @ true
+        return {"species": sp, "energies": e.double()}
+
+    data = [batch() for _ in range(6)]
+    m, b = exact_saes(data, sym)
+    assert b is None and torch.allclose(m, true, atol=1e-3)
+    for d in data:
+        d["energies"] += 1.25
+    m2, b2 = exact_saes(data, sym, fit_intercept=True)
+    assert torch.allclose(m2, true, atol=2e-3) and abs(b2.item() - 1.25) < 2e-2
+    assert data[0]["species"].max() == 8                                   # (the batches are left as they were)
+
+    class DS(list):   # the reference's BatchedDataset protocol: batches come out through .transform
+        transform = staticmethod(lambda p: p)
+
+        def __iter__(self):
+            return (self.transform({k: v.clone() for k, v in p.items()}) for p in list.__iter__(self))
+
+    ds = DS(batch() for _ in range(6))
+    keep = ds.transform
+    m3, _ = exact_saes(ds, sym, fraction=0.5)
+    assert torch.allclose(m3, true, atol=1e-3) and ds.transform is keep
+    m4, b4 = approx_saes(ds, sym, max_epochs=200, lr=2e-3)
+    assert b4 is None and (m4 - true).abs().max() < (torch.ones(3) - true).abs().max()
+    if not os.path.exists("/root/reference/torchani/sae_estimation.py"):
+        pytest.skip("reference tree not present")
+    from _util import import_reference
+    import_reference()
+    from torchani.sae_estimation import approx_saes as ref_approx
+    from torchani.sae_estimation import exact_saes as ref_exact
+    assert torch.allclose(ref_exact(ds, sym)[0], exact_saes(ds, sym)[0], atol=1e-4)
+    torch.manual_seed(0)
+    a = ref_approx(ds, sym, max_epochs=3, lr=1e-3, fit_intercept=True)
+    b = approx_saes(ds, sym, max_epochs=3, lr=1e-3, fit_intercept=True)
+    assert torch.allclose(a[0], b[0], atol=1e-5) and torch.allclose(a[1], b[1], atol=1e-5)

@@ -1121,7 +1121,7 @@ def test_simple_aniq_builder_matches_reference(dev):
     reference's builder in fp64 with the same seeded parameters; dipoles from the charges (electro.py) in the three
     reference frames (tests/golden/gen_golden_simple.py)."""
     from torchani_amd.constants import HIDDEN_DIMS_2X
-    from torchani_amd.electro import compute_dipole
+    from torchani_amd.extras.electro import compute_dipole
     from torchani_amd.models import simple_aniq
     from torchani_amd.weights import NN_PREFIX, random_network_state_dict
 
@@ -1149,30 +1149,6 @@ def test_simple_aniq_builder_matches_reference(dev):
         assert np.abs(mu.cpu().numpy() - ref["dipole_" + frame]).max() < 1e-9, frame
     with pytest.raises(ValueError):
         simple_aniq(sym, "wb97x-631gd", merge_charge_networks=True)
-
-
-def test_numerical_hessian_and_frequencies(dev):
-    """grad.numerical_hessians (central differences of the engine's forces, the 6 A displaced copies as one batch) against the
-    reference's analytic Hessian (double backward in fp64, tests/golden/gen_golden_hessian.py), and the vibrational
-    wavenumbers that follow from both."""
-    from torchani_amd.grad import numerical_hessians, vibrational_analysis
-    from torchani_amd.models import ANI2x
-
-    ref = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hess_cfg2mol0_ani2x.npz")))
-    model = ANI2x(state_dict=seeded_state("ani2x", 8, int(ref["seed"])), device=dev, periodic_table_index=False,
-                  neighborlist="batch")
-    sp = torch.from_numpy(ref["species"]).to(dev)
-    x = torch.from_numpy(ref["coords"]).to(dev)
-    h = numerical_hessians(model, sp, x)
-    torch.cuda.synchronize()
-    assert h.shape == ref["hessian"].shape and h.dtype == torch.float64
-    he = np.abs(h.cpu().numpy() - ref["hessian"]).max()
-    va = vibrational_analysis(torch.from_numpy(ref["masses"]).to(dev), h)
-    big = np.argsort(-np.abs(ref["freqs"]))[:10]
-    fe = np.abs(va.freqs.cpu().numpy()[big] - ref["freqs"][big]).max()
-    report(f"hess  cfg2 molecule 0 ({sp.shape[1]} atoms)  max|H err| = {he:.2e} Ha/A^2 (|H|max {np.abs(ref['hessian']).max():.3f})"
-           f"  largest 10 wavenumbers within {fe:.2f} cm^-1 (up to {np.abs(ref['freqs']).max():.0f})")
-    assert he < 2e-3 and fe < 15.0   # (measured 6.1e-4 and 2.5: fp32 forces over a 0.02 A difference)
 
 
 def test_pair_potential_called_on_its_own(dev):

@@ -6,8 +6,8 @@ Ensemble, SpeciesConverter, SpeciesEnergies, models.ANI1x / models.ANI2x, grad.e
 from . import constants, weights  # noqa: F401  (import-light; no torch needed)
 
 __all__ = ["AEVComputer", "ANINetworks", "ANIModel", "Ensemble", "SpeciesConverter", "SpeciesEnergies",
-           "SpeciesAEV", "AtomicNetwork", "models", "grad", "parallel", "arch", "units", "io", "cutoffs", "electro", "utils",
-           "potentials", "ase", "md", "sae", "sae_estimation", "transforms", "single_point", "SelfEnergy"]
+           "SpeciesAEV", "AtomicNetwork", "models", "grad", "parallel", "utils", "potentials", "ase", "md", "extras",
+           "single_point", "SelfEnergy"]
 
 
 def __getattr__(name):
@@ -15,9 +15,11 @@ def __getattr__(name):
     # tests) can use torchani_amd.constants / .weights without importing torch
     import importlib
 
-    if name in ("models", "grad", "parallel", "engine", "aev", "nn", "tuples", "_lib", "arch", "units", "io", "cutoffs",
-                "electro", "utils", "potentials", "ase", "md", "ops", "sae", "transforms", "sae_estimation"):
+    if name in ("models", "grad", "parallel", "engine", "aev", "nn", "tuples", "_lib", "utils", "potentials", "ase", "md",
+                "ops", "extras"):
         return importlib.import_module(f".{name}", __name__)
+    if name in ("arch", "io", "electro", "transforms", "sae_estimation"):   # host-side conveniences outside the hot path
+        return importlib.import_module(f".extras.{name}", __name__)
     table = {
         "AEVComputer": ("aev", "AEVComputer"),
         "ANINetworks": ("nn", "ANINetworks"),

@@ -13,10 +13,17 @@ import warnings
 import torch
 from torch import Tensor
 
-from .constants import AEVConstants, aev_constants_1x, aev_constants_2x
+from .constants import AEVConstants, aev_constants_1x, aev_constants_2x, cutoff_kernel_name
 from ._lib import MAX_RAD as _MAX_RAD
 from .engine import AevEngine, NeighborRows, VerletRows
 from .tuples import Neighbors, SpeciesAEV
+
+
+def _envelope(name: str, distances: Tensor, cutoff: float) -> Tensor:
+    # host-side value of the two envelopes the kernels implement (cutoffs.py:80-81, :98-101)
+    if name == "cosine":
+        return 0.5 * torch.cos(distances * (math.pi / cutoff)) + 0.5
+    return torch.exp(1 - 1 / (1 - (distances / cutoff) ** 2).clamp(min=1.0e-10))
 
 
 class _RadialTerms(torch.nn.Module):
@@ -48,10 +55,8 @@ class ANIRadial(_RadialTerms):
     evaluation of the terms on any tensor, [pairs] -> [pairs, shifts] (the kernels never call it)."""
 
     def __init__(self, eta: float, shifts: tp.Sequence[float], cutoff: float, cutoff_fn="cosine") -> None:
-        from .cutoffs import parse_cutoff_fn
-
         super().__init__(eta, shifts, cutoff)
-        self.cutoff_fn = parse_cutoff_fn(cutoff_fn)
+        self.cutoff_fn = cutoff_kernel_name(cutoff_fn)
         self.num_feats = len(self.shifts)
 
     def compute(self, distances: Tensor) -> Tensor:
@@ -59,7 +64,7 @@ class ANIRadial(_RadialTerms):
 
     def forward(self, distances: Tensor) -> Tensor:
         assert distances.dim() == 1
-        return self.compute(distances.view(-1, 1)) * self.cutoff_fn(distances, self.cutoff).view(-1, 1)
+        return self.compute(distances.view(-1, 1)) * _envelope(self.cutoff_fn, distances, self.cutoff).view(-1, 1)
 
     @classmethod
     def cover_linearly(cls, start: float = 0.9, cutoff: float = 5.2, eta: float = 19.7, num_shifts: int = 16,
@@ -87,10 +92,8 @@ class ANIAngular(_AngularTerms):
 
     def __init__(self, eta: float, zeta: float, shifts: tp.Sequence[float], sections: tp.Sequence[float], cutoff: float,
                  cutoff_fn="cosine") -> None:
-        from .cutoffs import parse_cutoff_fn
-
         super().__init__(eta, zeta, shifts, sections, cutoff)
-        self.cutoff_fn = parse_cutoff_fn(cutoff_fn)
+        self.cutoff_fn = cutoff_kernel_name(cutoff_fn)
         self.num_feats = len(self.shifts) * len(self.sections)
 
     def compute_radial(self, distances_ji: Tensor, distances_jk: Tensor) -> Tensor:
@@ -101,7 +104,7 @@ class ANIAngular(_AngularTerms):
 
     def forward(self, tri_distances: Tensor, tri_vectors: Tensor) -> Tensor:
         assert tri_distances.dim() == 2 and tri_vectors.shape == (2, tri_distances.shape[1], 3)
-        fc = self.cutoff_fn(tri_distances, self.cutoff)
+        fc = _envelope(self.cutoff_fn, tri_distances, self.cutoff)
         d = tri_distances.view(2, -1, 1)
         cos_angles = (tri_vectors[0] * tri_vectors[1]).sum(-1, keepdim=True) / torch.clamp(d[0] * d[1], min=1e-10)
         terms = self.compute_radial(d[0], d[1]).unsqueeze(2) * self.compute_cos_angles(cos_angles).unsqueeze(1)
@@ -203,9 +206,7 @@ class AEVComputer(torch.nn.Module):
             raise ValueError(f"Unsupported strategy {strategy!r}: torchani_amd only has the native 'hip' path")
         # one cutoff function for both terms like the native strategies of the reference (aev/_computer.py:91-98);
         # an explicit argument overrides the one carried by the constants
-        from .cutoffs import kernel_name   # (a name or a torchani_amd.cutoffs.Cutoff object)
-
-        self.cutoff_fn = kernel_name(consts.cutoff_fn if cutoff_fn is None else cutoff_fn)
+        self.cutoff_fn = cutoff_kernel_name(consts.cutoff_fn if cutoff_fn is None else cutoff_fn)
         if self.cutoff_fn not in ("cosine", "smooth"):
             raise ValueError(f"Unsupported cutoff function {self.cutoff_fn!r}: the HIP kernels implement 'cosine' "
                              "(CutoffCosine) and 'smooth' (CutoffSmooth, order 2)")

@@ -13,7 +13,7 @@ import typing as tp
 import numpy as np
 import torch
 
-from .units import HARTREE_TO_EV   # (= ase.units.Hartree, what the reference's calculator converts with: ase.py:24,134-168)
+HARTREE_TO_EV = 27.211386024367243   # (= ase.units.Hartree, what the reference's calculator converts with: ase.py:24,134-168)
 
 try:  # pragma: no cover - ASE is not installed in the build image
     import ase.units

@@ -146,3 +146,16 @@ HIDDEN_DIMS_1X: tp.Dict[str, tp.Tuple[int, ...]] = {
     "O": (128, 112, 96),
 }
 CELU_ALPHA = 0.1  # nn/_core.py:163-167
+
+
+# The envelopes the HIP kernels implement, by the reference's names (cutoffs.py:104-121 maps the same strings to its
+# classes); anihip_aev_params.cutoff_kind takes the value.
+CUTOFF_KERNEL_IDS: tp.Dict[str, int] = {"cosine": 0, "smooth": 1}
+
+
+def cutoff_kernel_name(cutoff_fn) -> str:
+    """``cutoff_fn`` (a name, or any object with a ``_kernel_name`` attribute) -> the name the kernels know."""
+    name = cutoff_fn if isinstance(cutoff_fn, str) else getattr(cutoff_fn, "_kernel_name", "")
+    if name not in CUTOFF_KERNEL_IDS:
+        raise ValueError(f"Unsupported cutoff function {cutoff_fn!r}: the HIP kernels implement {sorted(CUTOFF_KERNEL_IDS)}")
+    return name

@@ -11,12 +11,11 @@ import typing as tp
 
 import torch
 
-from .aev import AEVComputer, ANIAngular, ANIRadial
-from .constants import GSAES, HIDDEN_DIMS_1X, HIDDEN_DIMS_2X
-from .cutoffs import Cutoff, CutoffSmooth, kernel_name, parse_cutoff_fn
+from ..aev import AEVComputer, ANIAngular, ANIRadial
+from ..constants import GSAES, HIDDEN_DIMS_1X, HIDDEN_DIMS_2X, cutoff_kernel_name
 from .electro import BaseChargeNormalizer
-from .models import ANI, ANIq, simple_ani, simple_aniq  # noqa: F401
-from .nn import ANINetworks, Ensemble
+from ..models import ANI, ANIq, simple_ani, simple_aniq  # noqa: F401
+from ..nn import ANINetworks, Ensemble
 
 __all__ = ["ANI", "ANIq", "Assembler", "simple_ani", "simple_aniq"]
 
@@ -64,7 +63,7 @@ class Assembler:
 
     def __init__(self, symbols: tp.Sequence[str] = (), cls: type = ANI, neighborlist: str = "all_pairs",
                  periodic_table_index: bool = True) -> None:
-        self._global_cutoff_fn: Cutoff = CutoffSmooth(2)
+        self._global_cutoff_fn: str = "smooth"
         self._neighborlist = neighborlist
         self._aev: tp.Optional[tp.Tuple[ANIRadial, ANIAngular, tp.Any, str]] = None
         self._potentials: tp.Dict[str, tp.Tuple[type, tp.Dict[str, tp.Any], float, tp.Any]] = {}
@@ -142,7 +141,7 @@ class Assembler:
         self._neighborlist = neighborlist
 
     def set_global_cutoff_fn(self, cutoff_fn) -> None:
-        self._global_cutoff_fn = parse_cutoff_fn(cutoff_fn)
+        self._global_cutoff_fn = cutoff_kernel_name(cutoff_fn)
 
     def add_potential(self, cls: type, name: str, cutoff: float = math.inf, cutoff_fn="global",
                       kwargs: tp.Optional[tp.Dict[str, tp.Any]] = None) -> None:
@@ -163,7 +162,7 @@ class Assembler:
         if self._container is None:
             raise RuntimeError("Call 'set_atomic_networks(...)' before assembly")
         radial, angular, cutoff_fn, strategy = self._aev
-        envelope = kernel_name(parse_cutoff_fn(cutoff_fn, self._global_cutoff_fn))
+        envelope = cutoff_kernel_name(self._global_cutoff_fn if cutoff_fn == "global" else cutoff_fn)
         nl = {"all_pairs": "auto", "base": "auto"}.get(self._neighborlist, self._neighborlist)   # (let the engine choose)
         aevc = AEVComputer.from_terms(radial, angular, len(self.symbols), envelope, neighborlist=nl,
                                       row_capacity=row_capacity, strategy=strategy)
@@ -181,7 +180,7 @@ class Assembler:
         for name, (pcls, kw, cutoff, pcut) in self._potentials.items():
             ctor = pcls.from_functional if hasattr(pcls, "from_functional") and "functional" in kw else pcls
             model.add_pair_potential(name, ctor(symbols=self.symbols, **kw, cutoff=cutoff,
-                                                cutoff_fn=parse_cutoff_fn(pcut, self._global_cutoff_fn)))
+                                                cutoff_fn=cutoff_kernel_name(self._global_cutoff_fn if pcut == "global" else pcut)))
         if any(getattr(m.atomics[s], "activation_name", "celu") != "celu" or not m.atomics[s].has_biases
                for m in members for s in self.symbols):
             model.requires_grad_(False)

@@ -37,7 +37,7 @@ class ChargeNormalizer(BaseChargeNormalizer):
     def from_electronegativity_and_hardness(cls, symbols: tp.Sequence[str], electronegativity: tp.Sequence[float] = (),
                                             hardness: tp.Sequence[float] = (),
                                             scale_weights_by_charges_squared: bool = False) -> "ChargeNormalizer":
-        from .constants import ELECTRONEGATIVITY_HARDNESS as EH
+        from ..constants import ELECTRONEGATIVITY_HARDNESS as EH
 
         en = list(electronegativity) if electronegativity else [EH[s][0] for s in symbols]
         hd = list(hardness) if hardness else [EH[s][1] for s in symbols]

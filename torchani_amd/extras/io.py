@@ -12,7 +12,7 @@ from pathlib import Path
 import torch
 from torch import Tensor
 
-from .utils import pad_atomic_properties
+from ..utils import pad_atomic_properties
 
 __all__ = ["read_xyz", "write_xyz", "TorchaniIOError", "PERIODIC_TABLE"]
 

@@ -13,8 +13,8 @@ import typing as tp
 import torch
 from torch import Tensor
 
-from .constants import ATOMIC_NUMBER
-from .nn import SelfEnergy, SpeciesConverter
+from ..constants import ATOMIC_NUMBER
+from ..nn import SelfEnergy, SpeciesConverter
 
 __all__ = ["Transform", "Identity", "identity", "SubtractSAE", "AtomicNumbersToIndices", "Compose", "SubtractModel"]
 

@@ -46,74 +46,7 @@ def _no_hessians(*args, **kwargs):
                               "does not provide")
 
 
-forces_and_hessians = hessians = energies_forces_and_hessians = _no_hessians   # (analytic: see numerical_hessians below)
-
-
-def numerical_hessians(model, species: Tensor, coordinates: Tensor, cell: tp.Optional[Tensor] = None,
-                       pbc: tp.Optional[tp.Sequence[bool]] = None, step: float = 0.01) -> Tensor:
-    """Hessians [C, 3A, 3A] (float64, Hartree / A^2) by central differences of the analytic forces: for every molecule the
-    6 A displaced copies (each coordinate by +-``step`` A) are ONE batch for ``model.energies_and_forces``, which is what
-    the engine is good at.  The reference differentiates twice through autograd (grad.py:86-149); the HIP engine has no
-    second derivatives with respect to the coordinates, and an fp32 force field differentiated numerically is what e.g.
-    ASE's vibrations module does with any calculator.  Expect ~1e-4 Ha / A^2 of noise (fp32 forces / 2 step): good for
-    stretches and bends, not for the softest modes.  Rows / columns of padding atoms are zero.  The result is
-    symmetrized.  ``model`` needs ``energies_and_forces(species, coordinates, cell, pbc)`` returning ``.forces``."""
-    if species.dim() != 2 or coordinates.shape != (species.shape[0], species.shape[1], 3):
-        raise ValueError("expected species [C, A] and coordinates [C, A, 3]")
-    if not step > 0:
-        raise ValueError("step must be positive")
-    C, A = species.shape
-    n = 3 * A
-    out = torch.zeros((C, n, n), dtype=torch.float64, device=coordinates.device)
-    eye = torch.eye(n, dtype=coordinates.dtype, device=coordinates.device).view(n, A, 3) * step
-    for c in range(C):
-        real = (species[c] >= 0).repeat_interleave(3)                         # [3A]
-        x = coordinates[c].detach().unsqueeze(0)
-        disp = torch.cat([x + eye, x - eye], dim=0)                           # [2 * 3A, A, 3]: +k ..., -k ...
-        f = model.energies_and_forces(species[c].unsqueeze(0).expand(2 * n, A).contiguous(), disp.contiguous(), cell,
-                                      pbc).forces.to(torch.float64).reshape(2 * n, n)
-        h = -(f[:n] - f[n:]) / (2.0 * step)                                   # h[k, l] = d2E / dx_k dx_l
-        h = 0.5 * (h + h.t())
-        out[c] = h * (real.unsqueeze(0) & real.unsqueeze(1))
-    return out
-
-
-def vibrational_analysis(masses: Tensor, hessian: Tensor, mode_kind: str = "mdu", unit: str = "cm^-1"):
-    """Vibrational wavenumbers, normal modes, force constants (mDyne / A) and reduced masses (amu) of ONE molecule from its
-    Hessian [1, 3A, 3A] (Hartree / A^2) and masses [1, A] (amu) -- grad.py:152-236.  The mass-scaled Hessian
-    T^-1/2 H T^-1/2 is diagonalized; ``mode_kind``: "mwn" (mass weighted, orthonormal), "mdu" (mass deweighted,
-    unnormalized: ASE), "mdn" (mass deweighted, normalized: Gaussian, ORCA).  Imaginary frequencies come out negative;
-    the six smallest belong to translations and rotations.  ``unit``: "cm^-1" or "meV"."""
-    from .tuples import VibAnalysis
-    from .units import mhessian2fconst, sqrt_mhessian2invcm, sqrt_mhessian2milliev
-
-    if unit == "meV":
-        convert = sqrt_mhessian2milliev
-    elif unit == "cm^-1":
-        convert = sqrt_mhessian2invcm
-    else:
-        raise ValueError("Only meV and cm^-1 are supported right now")
-    if hessian.dim() != 3 or hessian.shape[0] != 1:
-        raise ValueError("The input should contain only one molecule")
-    inv_sqrt_m = (1 / masses.sqrt()).repeat_interleave(3, dim=1)              # [1, 3A]
-    scaled = (hessian * inv_sqrt_m.unsqueeze(1) * inv_sqrt_m.unsqueeze(2)).squeeze(0)
-    eigenvalues, eigenvectors = torch.linalg.eigh(scaled)
-    mw_normalized = eigenvectors.t()                                          # (the modes are the COLUMNS of eigenvectors)
-    md_unnormalized = mw_normalized * inv_sqrt_m
-    norm_factors = 1 / torch.linalg.norm(md_unnormalized, dim=1)              # sqrt(amu)
-    rmasses = norm_factors ** 2
-    fconstants = mhessian2fconst(eigenvalues) * rmasses
-    kind = mode_kind.lower()
-    if kind in ("mdn", "mass-deweighted-normalized"):
-        modes = md_unnormalized * norm_factors.unsqueeze(1)
-    elif kind in ("mdu", "mass-deweighted-unnormalized"):
-        modes = md_unnormalized
-    elif kind in ("mwn", "mass-weighted-normalized"):
-        modes = mw_normalized
-    else:
-        raise ValueError(f"Incorrect mode kind {mode_kind}")
-    freqs = convert(eigenvalues.abs().sqrt() / (2 * math.pi) * torch.sign(eigenvalues))
-    return VibAnalysis(freqs, modes.reshape(eigenvalues.numel(), -1, 3), fconstants, rmasses)
+forces_and_hessians = hessians = energies_forces_and_hessians = _no_hessians
 
 
 def energies_and_forces(model, species: Tensor, coordinates: Tensor, cell: tp.Optional[Tensor] = None,

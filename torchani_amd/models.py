@@ -27,7 +27,7 @@ from ._lib import MAX_RAD as _lib_MAX_RAD
 from .constants import GSAES_WB97X_631GD  # noqa: F401
 from . import _lib
 from .engine import FIXED_SCALE, energy_forces_finish, energy_reduce, fixed_to_float
-from .electro import BaseChargeNormalizer, ChargeNormalizer  # noqa: F401
+from .extras.electro import BaseChargeNormalizer, ChargeNormalizer  # noqa: F401
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import join_exact, shard_range, split_exact
 from .tuples import EnergiesScalars, AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
@@ -813,9 +813,9 @@ def simple_ani(symbols: tp.Sequence[str], lot: str, ensemble_size: int = 1, radi
                          "implemented")
     if activation not in ("celu", "gelu"):
         raise ValueError(f"activation 'celu' or 'gelu', got {activation!r}")
-    from .cutoffs import kernel_name
+    from .constants import cutoff_kernel_name as kernel_name
 
-    cutoff_fn = kernel_name(cutoff_fn)   # (a name or a cutoffs.Cutoff object)
+    cutoff_fn = kernel_name(cutoff_fn)
     if cutoff_fn not in ("cosine", "smooth"):
         raise ValueError(f"cutoff_fn 'cosine' or 'smooth', got {cutoff_fn!r}")
     if strategy not in ("hip", "auto", "pyaev", "cuaev", "cuaev-fused", "cuaev-interface"):

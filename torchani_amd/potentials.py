@@ -112,7 +112,7 @@ class _AnalyticPair(_Standalone, torch.nn.Module):
     clamp_distances = True   # (core.py:138-139; FixedMNOK does not clamp)
 
     def _init_common(self, symbols: tp.Sequence[str], cutoff: float, cutoff_fn) -> None:
-        from .cutoffs import kernel_name   # (a name or a torchani_amd.cutoffs.Cutoff object)
+        from .constants import cutoff_kernel_name as kernel_name
 
         cutoff_fn = kernel_name(cutoff_fn)
         if cutoff_fn not in _lib.CUTOFF_KINDS:
@@ -359,7 +359,7 @@ class TwoBodyDispersionD3(_Standalone, torch.nn.Module):
                  sqrt_empirical_charge: tp.Sequence[float] = (), covalent_radii: tp.Sequence[float] = (), *,
                  cutoff_fn: str = "smooth", cutoff: float = math.inf) -> None:
         super().__init__()
-        from .cutoffs import kernel_name   # (a name or a torchani_amd.cutoffs.Cutoff object)
+        from .constants import cutoff_kernel_name as kernel_name
 
         cutoff_fn = kernel_name(cutoff_fn)
         if cutoff_fn not in _lib.CUTOFF_KINDS:

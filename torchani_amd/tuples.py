@@ -80,12 +80,3 @@ class ForceStdev(tp.NamedTuple):
     magnitudes: Tensor
     relative_stdev: Tensor
     relative_range: Tensor
-
-
-class VibAnalysis(tp.NamedTuple):
-    """Output of grad.vibrational_analysis (torchani/tuples.py:36-42)."""
-
-    freqs: Tensor
-    modes: Tensor
-    fconstants: Tensor
-    rmasses: Tensor

@@ -113,7 +113,7 @@ class AtomicNumbersToChemicalSymbols(_NumbersToSymbols):
     """tensor([6, 1, 1, 1]) -> ['C', 'H', 'H', 'H'] (utils.py:277-305)."""
 
     def __init__(self) -> None:
-        from .io import PERIODIC_TABLE
+        from .extras.io import PERIODIC_TABLE
 
         super().__init__({z: s for z, s in enumerate(PERIODIC_TABLE) if s})
 
@@ -132,7 +132,7 @@ class ChemicalSymbolsToAtomicNumbers(_SymbolsToNumbers):
     """['C', 'S', 'O'] -> tensor([6, 16, 8]) (utils.py:356-373)."""
 
     def __init__(self, device=None) -> None:
-        from .io import PERIODIC_TABLE
+        from .extras.io import PERIODIC_TABLE
 
         super().__init__({s: z for z, s in enumerate(PERIODIC_TABLE) if s}, device=device)
 
@@ -154,7 +154,7 @@ class AtomicNumbersToMasses(torch.nn.Module):
         super().__init__()
         masses = list(masses)
         if not masses:
-            from .electro import ATOMIC_MASS_BY_Z
+            from .extras.electro import ATOMIC_MASS_BY_Z
 
             masses = [0.0] * (max(ATOMIC_MASS_BY_Z) + 1)
             for z, m in ATOMIC_MASS_BY_Z.items():
@@ -181,7 +181,7 @@ get_atomic_masses = atomic_numbers_to_masses   # (the reference's older name)
 
 def sort_by_atomic_num(it: tp.Iterable[str]) -> tp.Tuple[str, ...]:
     """Chemical symbols sorted by atomic number (utils.py:463-473)."""
-    from .io import PERIODIC_TABLE
+    from .extras.io import PERIODIC_TABLE
 
     if isinstance(it, str):
         it = (it,)
