@@ -624,3 +624,34 @@ def test_model_strategy_and_infer_conversions_are_accepted():
     assert m.to_infer_model(use_mnp=True) is m and m.neural_networks is nets and m.aev_computer.strategy == "hip"
     with pytest.raises(ValueError):
         m.set_strategy("tpu")
+
+
+def test_member_models_keep_pair_potentials_and_graph_stamp():
+    """model[idx] / model_index= keep every pair potential with its enabled flag (the reference deep-copies the whole model,
+    arch.py:252-261); the external-neighbor entry points refuse enabled pair potentials instead of dropping them; the
+    auto-graph key changes with the configuration."""
+    from torchani_amd.models import ANI2dr
+
+    full = ANI2dr(seed=0, n_members=2)
+    member = full[1]
+    assert set(member.potentials.keys()) == set(full.potentials.keys()) and len(full.potentials) == 3
+    for k in full.potentials:
+        if k != "nnp":
+            assert member.potentials[k] is full.potentials[k]
+    assert len(member) == 1 and member.neural_networks is full.neural_networks.members[1]
+    full.set_enabled("dispersion_d3", False)
+    assert not full[0].potentials["dispersion_d3"]._enabled
+    full.set_enabled("dispersion_d3", True)
+    assert set(ANI2dr(seed=0, n_members=2, model_index=0).potentials.keys()) == set(full.potentials.keys())
+    sp = torch.zeros((1, 2), dtype=torch.long)
+    x = torch.zeros((1, 2, 3))
+    with pytest.raises(NotImplementedError, match="pair potentials"):
+        full.compute_from_neighbors(sp, x, (torch.zeros((2, 1), dtype=torch.long), torch.ones(1), torch.ones(1, 3)))
+    s0 = full._config_stamp()
+    full.set_enabled("repulsion_xtb", False)
+    s1 = full._config_stamp()
+    full.aev_computer.row_capacity = 256
+    assert s0 != s1 and s1 != full._config_stamp()
+    # the D3 parameter block is built from host copies (no device reads: legal during stream capture) and cached
+    d3 = full.potentials["dispersion_d3"]
+    assert d3.params() is d3.params() and abs(d3.params().cov_radius_bohr[0] - float(d3.covalent_radii[0])) < 1e-6

@@ -1357,3 +1357,28 @@ def test_energies_are_run_to_run_deterministic(dev):
     parts = [det._energies_and_forces_core(spt.to(torch.int32), xt, ct, (True, True, True), None, True, False, (r, 3))
              for r in range(3)]
     assert (sum(p.forces for p in parts) - druns[0].forces).abs().max().item() < 1e-7
+
+
+def test_member_model_keeps_pair_potentials(dev):
+    """ANI2dr(...)[k] (and model_index=k) evaluates repulsion and dispersion like the full model restricted to member k
+    (the reference deep-copies the whole model, arch.py:252-261)."""
+    from torchani_amd.models import ANI2dr
+
+    g = load_golden("small_ani2x") if "small_ani2x" in GOLDEN_NAMES else load_golden(GOLDEN_NAMES[0])
+    sp, x, cell, pbc = to_dev(g, dev)
+    full = ANI2dr(seed=0, device=dev, periodic_table_index=False)
+    member = full[3]
+    assert set(member.potentials.keys()) == {"nnp", "repulsion_xtb", "dispersion_d3"}
+    a = member.energies_and_forces(sp, x, cell, pbc)
+    bare = member.energies_and_forces(sp, x, cell, pbc)   # (second call: same path, warmed)
+    full.set_active_members([3])
+    b = full.energies_and_forces(sp, x, cell, pbc)
+    full.set_active_members(list(range(8)))
+    assert torch.allclose(a.energies, b.energies, atol=1e-9) and torch.allclose(a.forces, b.forces, atol=1e-7)
+    assert torch.equal(a.energies, bare.energies)
+    member.set_enabled("repulsion_xtb", False)
+    member.set_enabled("dispersion_d3", False)
+    c = member.energies_and_forces(sp, x, cell, pbc)
+    member.set_enabled("repulsion_xtb", True)
+    member.set_enabled("dispersion_d3", True)
+    assert (a.energies - c.energies).abs().max() > 1e-6, "the pair potentials did not contribute"

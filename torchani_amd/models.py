@@ -132,6 +132,8 @@ class ANI(torch.nn.Module):
             else:
                 e_pair = pot.compute_from_rows(species32, coords, nbrs)
             energies = energies + (e_pair.unsqueeze(0) if ensemble_values else e_pair).to(energies.dtype)
+        if self.aev_computer.check_overflow and not torch.cuda.is_current_stream_capturing():
+            self._raise_on_pair_overflow()
         if self.energy_shifter._enabled:
             energies = energies + self.energy_shifter(elem_idxs, atomic=atomic)
         return self._output(elem_idxs, energies, extra)
@@ -158,8 +160,20 @@ class ANI(torch.nn.Module):
             pot._own_engine = AevEngine(self.aev_computer.engine().consts._replace(Rcr=rc, Rca=1e-3))
         pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
         c32 = coords.detach().to(torch.float32).contiguous()
-        return pot._own_engine.neighbors(species32, c32, cell, pbc_t, lo=lo, hi=hi, mode=self.aev_computer.neighbor_mode,
+        rows = pot._own_engine.neighbors(species32, c32, cell, pbc_t, lo=lo, hi=hi, mode=self.aev_computer.neighbor_mode,
                                          row_cap=_lib_MAX_RAD)
+        pot._last_rows = rows   # (checked with the AEV's rows: an overflowed row was zeroed by the builder)
+        return rows
+
+    def _pair_rows_overflowed(self) -> bool:
+        return any(getattr(pot, "_last_rows", None) is not None and pot._last_rows.overflowed()
+                   for k, pot in self.potentials.items() if k != "nnp" and pot._enabled)
+
+    def _raise_on_pair_overflow(self) -> None:
+        for k, pot in self.potentials.items():
+            if k != "nnp" and pot._enabled and getattr(pot, "_last_rows", None) is not None and pot._last_rows.overflowed():
+                raise RuntimeError(f"pair potential {k!r}: an atom has more than {_lib_MAX_RAD} neighbors inside its cutoff "
+                                   f"({pot.cutoff} A; rows hold at most {_lib_MAX_RAD}): its energies would be wrong")
 
     # ---- fused path ---------------------------------------------------------------------------------
     @torch.no_grad()
@@ -204,6 +218,7 @@ class ANI(torch.nn.Module):
                     out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard,
                                                          stress, hint)
                 aevc.last_neighbors().raise_on_overflow()
+            self._raise_on_pair_overflow()
         return out
 
     def _auto_graph_call(self, species, coords, cell, pbc, group, shard, stress, check_overflow):
@@ -217,7 +232,8 @@ class ANI(torch.nn.Module):
                 or torch.cuda.is_current_stream_capturing()):
             return None
         pbc_key = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
-        key = (species.data_ptr(), species._version, tuple(species.shape), coords.device, cell is None, pbc_key)
+        key = (species.data_ptr(), species._version, tuple(species.shape), coords.device, cell is None, pbc_key,
+               self._config_stamp())
         ent = self._graphs.get(key)
         if ent is None:
             if len(self._graphs) >= 4:
@@ -240,10 +256,18 @@ class ANI(torch.nn.Module):
         res = EnergiesForces(out.energies.clone(), out.forces.clone(), out.atomic_energies.clone(), None)
         if check_overflow:
             nb = self.aev_computer.last_neighbors()
-            if nb.overflowed():   # (let the eager path retry with larger rows / raise)
+            if nb.overflowed() or self._pair_rows_overflowed():   # (let the eager path retry with larger rows / raise)
                 self._graphs.pop(key, None)
                 return None
         return res
+
+    def _config_stamp(self) -> tuple:
+        """Everything besides the inputs and the parameters that a captured step depends on: a change of any of it must
+        not replay an old graph."""
+        aevc = self.aev_computer
+        pots = tuple((k, id(p), bool(p._enabled), getattr(p, "_version_stamp", 0)) for k, p in self.potentials.items())
+        return (pots, bool(self.energy_shifter._enabled), aevc.row_capacity, aevc.neighbor_mode, self.mlp_chunk,
+                id(self.neural_networks))
 
     def _tile_hint(self, species: Tensor, elem_idxs: Tensor, n_central: int) -> int:
         """Layer-0 backward tiling for mid-size systems.  From 16 384 atoms on the library tiles 256 rows; that is right
@@ -389,6 +413,12 @@ class ANI(torch.nn.Module):
         (indices [2, P], distances [P], diff_vectors [P, 3]) tuple in the reference's convention).
         Differentiable with respect to ``coords`` like the reference's native cuAEV entry point."""
         assert charge == 0, "Model only supports neutral molecules"
+        pair = [k for k, pot in self.potentials.items() if k != "nnp" and pot._enabled]
+        if pair:
+            # the reference loops over every enabled potential here (arch.py:353-381); the pair kernels of this package
+            # run on the engine's own rows (D3 needs the rows of all atoms), not on an external half list
+            raise NotImplementedError(f"compute_from_neighbors with enabled pair potentials {pair}: evaluate through "
+                                      "forward / energies_and_forces, or set_enabled(name, False) first")
         energies = coords.new_zeros(elem_idxs.shape if atomic else elem_idxs.shape[:1])
         if ensemble_values:
             energies = energies.unsqueeze(0)
@@ -438,8 +468,19 @@ class ANI(torch.nn.Module):
         member = nets.members[idx] if hasattr(nets, "members") else nets
         m = ANI(self.symbols, self.aev_computer, member, self.energy_shifter.self_energies.tolist(),
                 self.periodic_table_index)
-        m.energy_shifter._enabled = self.energy_shifter._enabled
+        self._carry_over(m)
         return m.to(self.atomic_numbers.device)
+
+    def _carry_over(self, m: "ANI") -> None:
+        """What model[idx] keeps besides the member's networks: every other potential (shared modules) with its enabled
+        flag, like the reference's deep copy of the whole model (arch.py:252-261)."""
+        for name, pot in self.potentials.items():
+            if name != "nnp":
+                m.potentials[name] = pot
+        m.potentials["nnp"]._enabled = self.potentials["nnp"]._enabled
+        m.energy_shifter._enabled = self.energy_shifter._enabled
+        for attr in ("mlp_chunk", "deterministic_forces", "auto_graph_atoms"):
+            setattr(m, attr, getattr(self, attr))
 
     def atomic_energies(self, species_coordinates, cell=None, pbc=None, charge: int = 0,
                         ensemble_values: bool = False) -> SpeciesEnergies:
@@ -547,7 +588,7 @@ class ANIq(ANI):
         nnp = self.potentials["nnp"]
         m = ANIq(self.symbols, self.aev_computer, member, self.energy_shifter.self_energies.tolist(),
                  self.periodic_table_index, nnp.charge_networks, nnp.charge_normalizer)
-        m.energy_shifter._enabled = self.energy_shifter._enabled
+        self._carry_over(m)
         return m.to(self.atomic_numbers.device)
 
     def _scalars_from_aevs(self, elem_idxs: Tensor, aevs: Tensor, charge: int) -> Tensor:
@@ -641,6 +682,7 @@ class GraphedEnergiesForces:
     def check(self) -> None:
         """Raise if a neighbor row overflowed in the last replay (host sync)."""
         self.model.aev_computer.last_neighbors().raise_on_overflow()
+        self.model._raise_on_pair_overflow()
 
 
 def _assemble(kind: str, n_members: int, neighborlist: str, row_capacity: int,

@@ -73,8 +73,10 @@ class _Standalone:
             self._own_engine = AevEngine(aev_constants_2x(len(self.symbols))._replace(Rcr=rc, Rca=1e-3))
         pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
         mode = "cell" if (species32.shape[0] == 1 and species32.shape[1] > 512) else "batch"
-        return self._own_engine.neighbors(species32, coords.detach().to(torch.float32).contiguous(), cell, pbc_t, mode=mode,
+        rows = self._own_engine.neighbors(species32, coords.detach().to(torch.float32).contiguous(), cell, pbc_t, mode=mode,
                                           row_cap=_lib.MAX_RAD)
+        self._last_rows = rows
+        return rows
 
     def _to_elem_idxs(self, species: Tensor, atomic_nums_input: bool) -> Tensor:
         """Atomic numbers -> this potential's element indices (padding -1 stays); unknown elements raise."""
@@ -101,6 +103,9 @@ class _Standalone:
             e = a.view(species32.shape)
         else:
             e = self.compute_from_rows(species32, coords, rows)
+        if not torch.cuda.is_current_stream_capturing() and rows.overflowed():   # (the builder zeroed the row)
+            raise RuntimeError(f"{type(self).__name__}: an atom has more than {_lib.MAX_RAD} neighbors inside the cutoff "
+                               f"({self.cutoff} A); rows hold at most {_lib.MAX_RAD}")
         return e.unsqueeze(0) if ensemble_values else e
 
 
@@ -387,6 +392,8 @@ class TwoBodyDispersionD3(_Standalone, torch.nn.Module):
         self.register_buffer("sqrt_charge_ab", torch.outer(_sq, _sq))
         self.register_buffer("covalent_radii", torch.tensor([self.ANGSTROM_TO_BOHR * r for r in cov], dtype=torch.float32))
         self._sqrt_q = [float(v) for v in sq]
+        self._cov_bohr = [float(self.ANGSTROM_TO_BOHR * r) for r in cov]   # host copy: params() must not sync the device
+        self._params: tp.Optional["_lib.D3Params"] = None
         self.cutoff = float(cutoff)
         self.cutoff_fn = cutoff_fn
         self._enabled = True
@@ -421,12 +428,14 @@ class TwoBodyDispersionD3(_Standalone, torch.nn.Module):
         return self._table
 
     def params(self) -> "_lib.D3Params":
-        p = _lib.D3Params()
-        p.s6, p.s8, p.a1, p.a2 = self._s6, self._s8, self._a1, self._a2
-        for k in range(8):
-            p.cov_radius_bohr[k] = float(self.covalent_radii[k]) if k < len(self.symbols) else 0.0
-            p.sqrt_q[k] = self._sqrt_q[k] if k < len(self.symbols) else 0.0
-        return p
+        if self._params is None:   # built once from host copies (no device reads: legal during stream capture)
+            p = _lib.D3Params()
+            p.s6, p.s8, p.a1, p.a2 = self._s6, self._s8, self._a1, self._a2
+            for k in range(8):
+                p.cov_radius_bohr[k] = self._cov_bohr[k] if k < len(self.symbols) else 0.0
+                p.sqrt_q[k] = self._sqrt_q[k] if k < len(self.symbols) else 0.0
+            self._params = p
+        return self._params
 
     def rows_cutoff(self, rows_rcr: float) -> float:
         if self.cutoff > rows_rcr + 1e-6 and not math.isinf(self.cutoff):
