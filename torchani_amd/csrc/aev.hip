@@ -194,9 +194,11 @@ struct AtomHdr {
 __device__ __forceinline__ uint32_t hdr_load(const uint32_t *meta, const int32_t *species, int64_t i, bool ok)
 {
     const int lane = lane_id();
+    // ONE load instruction: lanes 0..5 the meta words, lane 6 the species.  (Two predicated loads into the same register
+    // make the second wait for the first -- s_waitcnt vmcnt(0) right behind the issue, i.e. no prefetch at all.)
+    const uint32_t *src = lane == META_W ? reinterpret_cast<const uint32_t *>(species + i) : meta + (size_t)i * META_W + lane;
     uint32_t w = 0;
-    if (ok && lane < META_W) w = meta[(size_t)i * META_W + lane];
-    if (ok && lane == META_W) w = (uint32_t)species[i];
+    if (ok && lane <= META_W) w = *src;
     return w;
 }
 __device__ __forceinline__ AtomHdr hdr_decode(uint32_t w)
@@ -824,6 +826,469 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD2_WAVES) void k_aev_fwd2(
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_aev_fwd3 (round 3): ONE lane per (j, k) pair and a FLAT slot assignment over all species-pair blocks of the atom.
+//   * k_aev_fwd2 walks the species-pair blocks one after the other, 32 two-lane pair slots at a time: on the water box
+//     an atom has 53 + 58 + 12 pairs (HH, HO, OO) in 2 + 2 + 1 = 5 iterations of 91 instructions -- 77 % of the slots
+//     hold a pair -- and every block pays its own 32-slot transpose-reduce.  Both lanes of a slot repeat the pair's
+//     geometry (index decode, two LDS reads, dot product, sqrt).
+//   * here a lane owns a pair slot for the whole atom: block b of the atom gets ns_b = pad4(ceil(np_b / I)) of the 64
+//     slots (I = iterations, the smallest for which the blocks fit; a slot walks I consecutive pairs of ITS block), the
+//     lane evaluates all NA Gaussians and all NZ angle factors of its pair -- every constant is wave-uniform now and
+//     lives in scalar registers -- and keeps the whole NA x NZ block of sums (32 registers).  The same atom takes
+//     ceil(123 / 64) = 2 iterations, 96 % of the slots busy, the geometry once per pair.
+//   * the 64 x 32 sums leave through LDS as a SEGMENTED reduction, 16 values per round: every lane writes its row
+//     (stride 20 floats: conflict-free 16-B accesses), lane group g = lane / 4 adds the four rows 4 g .. 4 g + 3 (blocks
+//     are padded to multiples of four slots, so a group never straddles two blocks), a two-step segmented scan over the
+//     four groups of a DPP row (v += [same block] row_shr:4 / :8) and a three-entry LDS table of the rows' trailing sums
+//     carry the partial sums to the LAST group of every block, whose four lanes store 64 B of the AEV row.  No atomics,
+//     fixed order, any number of blocks for the price of one reduction.
+//   * atoms whose blocks do not fit 64 slots (many species with a few pairs each) are done in batches of blocks.
+// The radial part, the log-domain cutoff product and the dummy neighbor are those of k_aev_fwd2.
+#ifndef ANIHIP_FWD3_WAVES
+#define ANIHIP_FWD3_WAVES 4
+#endif
+#ifndef ANIHIP_FWD3_REC
+#define ANIHIP_FWD3_REC 0
+#endif
+#ifndef ANIHIP_ABL
+#define ANIHIP_ABL 0   // development: phases switched off for timing (results are wrong)
+#endif
+// sum over the wave of small non-negative integers held by the lanes: scan inside the DPP rows, four readlanes
+__device__ __forceinline__ int wave_isum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) +
+           __builtin_amdgcn_readlane(v, 63);
+}
+// slots of a block of np pairs walked in I iterations: ceil(np / I) rounded up to a multiple of four (np <= 8128, I <= 127)
+__device__ __forceinline__ int block_slots(int np, int I, float inv_I)
+{
+    int c = (int)(((float)np + 0.5f) * inv_I);   // floor(np / I) (the half keeps the product off the integers)
+    c += (c * I < np) ? 1 : 0;
+    return (c + 3) & ~3;
+}
+
+template <int NA, int NZ>
+__global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
+    AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
+    const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
+    const float4 *__restrict__ ent, float *__restrict__ aev, uint32_t *__restrict__ slab_mask)
+{
+    static_assert(NA % 4 == 0 && NZ % 4 == 0 && NA * NZ == 32, "angular tiling");
+    constexpr int ZP = NZ / 2;          // packed pairs of angle shifts
+    constexpr int RS = 20;              // floats per row of the reduction buffer: 16 values + 4 (bank spread)
+    constexpr int XOFF = 64 * RS;       // trailing sums of DPP rows 0..2: 3 x 16 floats
+    __shared__ float4 s_ang[FWD_WPB][MAXA + 1];   // ux uy uz, 0.5 qA r          (entry nA = dummy)
+    __shared__ float s_lfc[FWD_WPB][MAXA + 2];    // log2 fc(r, Rca) + 0.5       (dummy: -inf)
+    __shared__ __attribute__((aligned(16))) float s_red[FWD_WPB][XOFF + 48];   // reduction rows (radial terms, then pair sums)
+    __shared__ __attribute__((aligned(16))) float s_rst[FWD_WPB][MAX_S * 16];  // radial part of the row until it is stored
+
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
+    float4 *ang = s_ang[wib];
+    float *lfc = s_lfc[wib];
+    float *red = s_red[wib];
+    float *rst = s_rst[wib];
+
+    const float qR = a.qR, qA = a.qA;
+    float shfAq[NA], cZ[NZ], sZ[NZ];           // wave-uniform: scalar registers
+#pragma unroll
+    for (int u = 0; u < NA; ++u) shfAq[u] = tab[TAB_SHFAQ + u];
+#pragma unroll
+    for (int z = 0; z < NZ; ++z) {   // h(theta) = 0.5 + 0.5 cos(theta - ShfZ)
+        cZ[z] = tab[TAB_COSZH + z];
+        sZ[z] = tab[TAB_SINZH + z];
+    }
+    // Gaussian recurrence of the pair loop (see there): shifts equally spaced, and no exponent beyond fp32's range
+    const float gD = shfAq[1] - shfAq[0], gq = __builtin_amdgcn_exp2f(-2.0f * gD * gD);
+    bool gauss_rec = gD > 0.f;
+#pragma unroll
+    for (int u = 1; u + 1 < NA; ++u) gauss_rec = gauss_rec && __builtin_fabsf((shfAq[u + 1] - shfAq[u]) - gD) < 1e-4f * gD;
+    {
+        const float xm = fmaxf(__builtin_fabsf(qA * a.Rca - shfAq[NA / 2 - 1]), __builtin_fabsf(shfAq[NA / 2 - 1]));
+        gauss_rec = gauss_rec && xm * xm < 100.f && 2.0f * gD * xm < 100.f;
+    }
+    const float rev_rcr = 0.5f / a.Rcr, rev_rca = 0.5f / a.Rca;   // v_cos_f32 takes revolutions
+    const int row = lane >> 4;
+    const int rq = lane >> 2;                     // radial sums: row group (value quad = w4)
+    const int w4 = lane & 3;                      // reduction: value quad of a round
+    const bool row_last = (lane & 15) >= 12;      // last lane group of its DPP row
+
+    // "needed block" bookkeeping: bit t < 7 radial block of species t, bit 7 + P angular block of species pair P;
+    // lane b < 35 decides bit b and (b >= 7) is the BLOCK LANE of species pair P = b - 7
+    int nd_tj = 7, nd_tk = 7;
+    if (lane < 7) {
+        nd_tj = nd_tk = lane;
+    } else {
+        int P = lane - 7, tj = 0;
+        while (tj < a.S && P >= a.S - tj) { P -= a.S - tj; ++tj; }
+        if (tj < a.S) { nd_tj = tj; nd_tk = tj + P; }
+    }
+    const bool blk_same = nd_tj == nd_tk;
+    const int L4 = a.L >> 2, R4 = a.radlen >> 2;
+    const int rslabs = (a.S + 1) >> 1;
+
+    const int64_t nw = (int64_t)gridDim.x * FWD_WPB;
+    int64_t i = lo + blockIdx.x * (int64_t)FWD_WPB + wib;
+    uint32_t hw = hdr_load(meta, species, i, i < hi);
+    AtomHdr hd = hdr_decode(hw);
+    const float4 dummy4 = make_float4(1.f, 0.f, 0.f, 0.f);
+    // the first 128 entries of the row travel one atom ahead.  Every lane loads (index clamped into the row): a load under
+    // a per-lane condition merges with the old value afterwards, and that move waits for the load on the spot
+    float4 e0 = dummy4, e1 = dummy4;
+    if (i < hi && hd.sp >= 0 && hd.nA + hd.nF > 0) {
+        const int nl = hd.nA + hd.nF - 1;
+        e0 = ent[hd.start + min(lane, nl)];
+        e1 = ent[hd.start + min(lane + WAVE, nl)];
+    }
+    uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
+    // Memory order of an atom: [loads for the NEXT atom] ... arithmetic ... [wait for those loads] [ALL stores of this atom].
+    // Vector-memory operations retire in order and the compiler waits with vmcnt(0) for whatever it cannot count, so a
+    // load consumed after stores were issued drains those stores first (HBM write latency, once per atom and wave).  With
+    // the stores last and the prefetched registers "used" right before them, nothing in the loop ever waits for a store:
+    // an atom's 4 KB row drains while the next atom is computed.
+#define ANIHIP_FWD3_ARRIVED()                                                                                         \
+    asm volatile("" ::"v"(e0.x), "v"(e0.y), "v"(e0.z), "v"(e0.w), "v"(e1.x), "v"(e1.y), "v"(e1.z), "v"(e1.w), "v"(hw_next) \
+                 : "memory")
+    ANIHIP_FWD3_ARRIVED();
+
+    for (; i < hi; i += nw) {
+        float *out = aev + (size_t)i * a.L;
+        const int nA = hd.nA, nR = hd.nA + hd.nF;
+        const uint64_t pkA = hd.pkA, pkF = hd.pkF;
+        const bool padding = hd.sp < 0;
+        const uint32_t start = hd.start;
+
+        // ---- per-neighbor precompute -> LDS, and the whole radial part ----
+        // lane = neighbor: its 16 radial terms 0.25 fc exp(-eta (r - s)^2) = exp2(-(qR r - s')^2 + log2(0.25 fc)) go to the
+        // lane's reduction row; the rows are sorted by species inside the angular-range group and inside the far group,
+        // so the radial block of species t is the sum of two row ranges: lane (rq, w4) adds every 16th row of them for the
+        // value quad w4, the 16 row groups are combined with two DPP rotations and two permlane swaps, and the block waits
+        // in rst for the stores at the end of the atom.  (The previous layout -- lane = 8 neighbor slots x 8 shift pairs,
+        // one species after the other -- spent 43 instructions per 8 neighbors, a third of the kernel.)
+        uint64_t need = 0ull;
+        const int cj = (int)((pkA >> (8 * nd_tj)) & 255u), ck = (int)((pkA >> (8 * nd_tk)) & 255u);
+        if (!padding) {
+            const int cf = (int)((pkF >> (8 * nd_tj)) & 255u);
+            const bool nd = lane < 7 ? (cj + cf > 0) : (blk_same ? cj >= 2 : (cj >= 1 && ck >= 1));
+            need = __ballot(nd && lane < 35);
+            const uint64_t prA_ = pkA * 0x0101010101010100ull, prF_ = pkF * 0x0101010101010100ull;
+            if (lane < 4) *reinterpret_cast<float4 *>(red + XOFF + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero row
+            for (int c0 = 0; c0 < nR; c0 += WAVE) {
+                const int e = c0 + lane;
+                float4 d = c0 == 0 ? e0 : (c0 == WAVE ? e1 : dummy4);
+                if (c0 >= 2 * WAVE && e < nR) d = ent[start + e];   // (> 128 neighbors: rare, waits on the spot)
+                if (e < nR) {
+                    const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+                    const float inv = __builtin_amdgcn_rsqf(r2);
+                    const float r = r2 * inv;
+                    const float fcr = a.smooth ? 0.25f * smooth_cutoff(r, 1.0f / a.Rcr).x
+                                               : 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f;
+                    const float lfr = __builtin_amdgcn_logf(fcr), xq = qR * r;
+                    const float *shf = tab + TAB_SHFRQ;
+                    asm volatile("" : "+s"(shf));   // (re-read the 16 shifts per atom: held across the atom they spill)
+                    float4 *mine4 = reinterpret_cast<float4 *>(red + lane * RS);
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        float g[4];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const float dd = xq - shf[4 * c4 + m];
+                            g[m] = __builtin_amdgcn_exp2f(lfr - dd * dd);
+                        }
+                        mine4[c4] = make_float4(g[0], g[1], g[2], g[3]);
+                    }
+                    if (e < nA) {
+                        ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, 0.5f * qA * r);
+                        float lf;
+                        if (a.smooth) {   // log2 exp(1 - 1 / m)
+                            const float q_ = r / a.Rca;
+                            lf = (1.0f - 1.0f / fmaxf(SMOOTH_EPS, (1.0f - q_) * (1.0f + q_))) * LOG2E;
+                        } else {
+                            lf = __builtin_amdgcn_logf(0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f);
+                        }
+                        lfc[e] = lf + 0.5f;
+                    }
+                }
+                if (c0 == 0 && lane == 0) {
+                    ang[nA] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    lfc[nA] = -__builtin_inff();
+                }
+                wave_sync();
+                for (uint32_t rm_ = (ANIHIP_ABL == 2 || ANIHIP_ABL == 7 ? 0u : (uint32_t)need & 0x7Fu); rm_; rm_ &= rm_ - 1) {
+                    const int t = __builtin_ctz(rm_);
+                    // rows of species t inside this window of 64 rows: [a0, a1) of the angular group, [f0, f1) of the far group
+                    const int oA = cnt_of(prA_, t) - c0, oF = nA + cnt_of(prF_, t) - c0;
+                    const int a0 = min(max(oA, 0), WAVE), a1 = min(max(oA + cnt_of(pkA, t), 0), WAVE);
+                    const int f0 = min(max(oF, 0), WAVE), f1 = min(max(oF + cnt_of(pkF, t), 0), WAVE);
+                    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int rb = a0; rb < a1; rb += 16) {
+                        const int rr_ = rb + rq;
+                        const float4 v = *reinterpret_cast<const float4 *>(red + (rr_ < a1 ? rr_ * RS : XOFF) + 4 * w4);
+                        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+                    }
+                    for (int rb = f0; rb < f1; rb += 16) {
+                        const int rr_ = rb + rq;
+                        const float4 v = *reinterpret_cast<const float4 *>(red + (rr_ < f1 ? rr_ * RS : XOFF) + 4 * w4);
+                        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+                    }
+                    // 16 row groups -> 1: rotations inside the DPP row, then across the rows two values per swap
+                    sm.x += dpp_perm<0x128>(sm.x); sm.y += dpp_perm<0x128>(sm.y);   // row_ror:8
+                    sm.z += dpp_perm<0x128>(sm.z); sm.w += dpp_perm<0x128>(sm.w);
+                    sm.x += dpp_perm<0x124>(sm.x); sm.y += dpp_perm<0x124>(sm.y);   // row_ror:4
+                    sm.z += dpp_perm<0x124>(sm.z); sm.w += dpp_perm<0x124>(sm.w);
+                    float xy = sum16(sm.x, sm.y), zw = sum16(sm.z, sm.w);
+                    xy = sum32(xy, xy);   // row 0: total of .x, row 1: total of .y
+                    zw = sum32(zw, zw);   // row 0: total of .z, row 1: total of .w
+                    if ((lane & 15) < 4 && row < 2) {   // lanes 0..3 (row 0) and 16..19 (row 1): value quad w4 = lane & 3
+                        float *o = rst + t * 16 + 4 * w4 + row;
+                        if (c0 == 0) {
+                            o[0] = xy;
+                            o[2] = zw;
+                        } else {
+                            o[0] += xy;
+                            o[2] += zw;
+                        }
+                    }
+                }
+                wave_sync();
+            }
+        }
+        // ---- prefetch the next atom ----
+        hd = hdr_decode(hw_next);
+        {
+            const int64_t in = i + nw;
+            if (in < hi && hd.sp >= 0 && hd.nA + hd.nF > 0) {   // (wave-uniform; else the registers keep stale, unused values)
+                const int nl = hd.nA + hd.nF - 1;
+                e0 = ent[hd.start + min(lane, nl)];
+                e1 = ent[hd.start + min(lane + WAVE, nl)];
+            }
+            hw_next = hdr_load(meta, species, in + nw, in + nw < hi);
+        }
+        // results that wait for the end of the atom: radial part in LDS (rst), the angular blocks of the last batch in the
+        // neighbor table's LDS (dead by then: ang[lane] / ang[64 + lane] of the lanes flagged hold_last, destination hold_dst)
+        bool hold_last = false;
+        float *hold_dst = out;
+        if (!padding) {
+        const uint64_t prA = pkA * 0x0101010101010100ull;
+
+        // ---- angular ----
+        uint32_t remaining = ANIHIP_ABL == 1 || ANIHIP_ABL == 7 ? 0u : (uint32_t)(need >> 7);
+        if (remaining) {
+            // block lanes: pairs of the block, where its two groups start in the row
+            const bool is_blk = (need >> lane) & 1ull && lane >= 7;
+            const int np_b = is_blk ? (blk_same ? (cj * (cj - 1)) >> 1 : cj * ck) : 0;
+            const int oj_b = (int)((prA >> (8 * nd_tj)) & 255u), ok_b = (int)((prA >> (8 * nd_tk)) & 255u);
+            const int word_b = oj_b | (ok_b << 8) | (cj << 16) | (ck << 24);
+            const int T = (nA * (nA - 1)) >> 1;
+            int I = (T + 63) >> 6;   // (>= 1: a block is flagged)
+            float inv_I = __builtin_amdgcn_rcpf((float)I);
+            int slots_b = block_slots(np_b, I, inv_I);
+            if (wave_isum(slots_b) > 64) {   // padding pushed the blocks over the wave: one more iteration if that fits
+                const float inv_I1 = __builtin_amdgcn_rcpf((float)(I + 1));
+                const int s1 = block_slots(np_b, I + 1, inv_I1);
+                if (wave_isum(s1) <= 64) {
+                    I += 1;
+                    inv_I = inv_I1;
+                    slots_b = s1;
+                }   // (else: batches of blocks, I iterations each)
+            }
+            while (remaining) {
+                // -- deal the slots of this batch: blocks in ascending order while they fit --
+                int s_run = 0, myblk = 0, mys0 = 0;   // myblk: block LANE (7 + P), 0 = none
+                while (remaining) {
+                    const int P = __builtin_ctz(remaining);
+                    const int ns = __builtin_amdgcn_readlane(slots_b, 7 + P);
+                    if (s_run + ns > 64) break;
+                    const bool mine = lane >= s_run;
+                    myblk = mine ? 7 + P : myblk;
+                    mys0 = mine ? s_run : mys0;
+                    s_run += ns;
+                    remaining &= remaining - 1;
+                }
+                myblk = lane < s_run ? myblk : 0;
+                // -- the lane's block: group offsets and sizes, pair iterator --
+                const int word = __builtin_amdgcn_ds_bpermute(myblk << 2, word_b);
+                const bool same = __builtin_amdgcn_ds_bpermute(myblk << 2, (int)blk_same) != 0;
+                const int oj = word & 255, ok = (word >> 8) & 255, nj = (word >> 16) & 255, nk = (word >> 24) & 255;
+                const int np = myblk ? (same ? (nj * (nj - 1)) >> 1 : nj * nk) : 0;
+                const int div = same ? ((nj - 1) >> 1) : nk;
+                const float inv_div = div > 0 ? __builtin_amdgcn_rcpf((float)div) : 0.f;
+                const int rect = same ? nj * div : 0x7FFFFFFF;
+                const int half = nj >> 1;
+                int t = (lane - mys0) * I;
+                int qd = (int)(((float)t + 0.5f) * inv_div);
+                int rem = t - qd * div;
+                v2f acc[NA][ZP];
+#pragma unroll
+                for (int u = 0; u < NA; ++u)
+#pragma unroll
+                    for (int vp = 0; vp < ZP; ++vp) acc[u][vp] = (v2f){0.f, 0.f};
+                for (int it = 0; it < (ANIHIP_ABL == 4 || ANIHIP_ABL == 5 ? 0 : I); ++it) {
+                    // (j, k) of pair t inside the two groups; slots past the last pair read the dummy neighbor
+                    int k2 = qd + 1 + rem;
+                    k2 = (int)min((uint32_t)k2, (uint32_t)(k2 - nj));   // k2 >= nj ? k2 - nj : k2
+                    const bool diam = t >= rect;
+                    const int jr = (same && diam) ? t - rect : qd;
+                    const int kr = same ? (diam ? t - rect + half : k2) : rem;
+                    const bool v = t < np;
+                    const int ej = v ? oj + jr : nA, ek = v ? ok + kr : nA;
+                    const float4 J = ang[ej], K = ang[ek];
+                    const float lf = lfc[ej] + lfc[ek];
+                    // advance to the next pair of the block
+                    t += 1;
+                    rem += 1;
+                    {
+                        const bool carry = rem >= div;
+                        rem = carry ? 0 : rem;
+                        qd += carry ? 1 : 0;
+                    }
+                    const float c = J.x * K.x + J.y * K.y + J.z * K.z;
+                    const float ct = 0.95f * c;
+                    const float st = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ct * ct, 0.f));
+                    const float sr = J.w + K.w;
+                    v2f f1[ZP];
+#pragma unroll
+                    for (int vp = 0; vp < ZP; ++vp) {
+                        const float h0 = 0.5f + ct * cZ[2 * vp] + st * sZ[2 * vp];
+                        const float h1 = 0.5f + ct * cZ[2 * vp + 1] + st * sZ[2 * vp + 1];
+                        f1[vp] = (v2f){__builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(__builtin_fabsf(h0)) + lf),
+                                       __builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(__builtin_fabsf(h1)) + lf)};
+                    }
+                    float f2[NA];
+                    if (ANIHIP_FWD3_REC) {
+                        // equally spaced shifts s_u = s_c + (u - c) D:  g_u = exp2(-(x - (u - c) D)^2),  x = sr - s_c, and
+                        // g_(u+1) / g_u = exp2(2 D x_u - D^2) =: r_u  with  r_(u+1) = r_u exp2(-2 D^2): three exponentials
+                        // and 2 (NA - 2) + 1 multiplications instead of NA exponentials (a product of at most NA / 2
+                        // rounded factors: 3e-7 relative)
+                        constexpr int C = NA / 2 - 1;
+                        const float x = sr - shfAq[C];
+                        const float e = (2.0f * gD) * x - gD * gD;
+                        f2[C] = __builtin_amdgcn_exp2f(-x * x);
+                        float ru = __builtin_amdgcn_exp2f(e), rd = __builtin_amdgcn_exp2f(-e);
+#pragma unroll
+                        for (int u = C + 1; u < NA; ++u) {
+                            f2[u] = f2[u - 1] * ru;
+                            ru *= gq;
+                        }
+#pragma unroll
+                        for (int u = C - 1; u >= 0; --u) {
+                            rd *= gq;
+                            f2[u] = f2[u + 1] * rd;
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < NA; ++u) {
+                            const float dd = sr - shfAq[u];
+                            f2[u] = __builtin_amdgcn_exp2f(-dd * dd);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < NA; ++u)
+#pragma unroll
+                        for (int vp = 0; vp < ZP; ++vp) acc[u][vp] += (v2f){f2[u], f2[u]} * f1[vp];
+                }
+                // -- segmented reduction of the 64 x 32 sums, 16 values per round --
+                // same-block predicates between lane groups (all four slots of a group belong to one block)
+                const int b_m4 = __builtin_amdgcn_update_dpp(0, myblk, 0x114, 0xF, 0xF, true);   // group - 1 (0 at the row start)
+                const int b_m8 = __builtin_amdgcn_update_dpp(0, myblk, 0x118, 0xF, 0xF, true);   // group - 2
+                const int b_p4 = __builtin_amdgcn_update_dpp(0, myblk, 0x104, 0xF, 0xF, true);   // group + 1 (0 at the row end)
+                const float m1 = (myblk && b_m4 == myblk) ? 1.f : 0.f, m2 = (myblk && b_m8 == myblk) ? 1.f : 0.f;
+                const int e0b = __builtin_amdgcn_readlane(myblk, 15), e1b = __builtin_amdgcn_readlane(myblk, 31),
+                          e2b = __builtin_amdgcn_readlane(myblk, 47);
+                const int n1b = __builtin_amdgcn_readlane(myblk, 16), n2b = __builtin_amdgcn_readlane(myblk, 32),
+                          n3b = __builtin_amdgcn_readlane(myblk, 48);
+                const float c0 = (myblk && row >= 1 && e0b == myblk) ? 1.f : 0.f;
+                const float c1 = (myblk && row >= 2 && e1b == myblk) ? 1.f : 0.f;
+                const float c2 = (myblk && row >= 3 && e2b == myblk) ? 1.f : 0.f;
+                const int nxt = row_last ? (row == 0 ? n1b : row == 1 ? n2b : row == 2 ? n3b : 0) : b_p4;
+                const bool blk_last = myblk && nxt != myblk;
+                float *dst = out + a.radlen + (myblk - 7) * 32 + 4 * w4;
+                if (ANIHIP_ABL == 3 || ANIHIP_ABL == 5) {   // (keep the sums alive without the reduction)
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int u = 0; u < NA; ++u)
+#pragma unroll
+                        for (int vp = 0; vp < ZP; ++vp) sacc += acc[u][vp].x + acc[u][vp].y;
+                    if (sacc == 12345.678f) dst[0] = sacc;
+                }
+#pragma unroll
+                for (int rr = 0; rr < (ANIHIP_ABL == 3 || ANIHIP_ABL == 5 ? 0 : 2); ++rr) {
+                    float4 *mine4 = reinterpret_cast<float4 *>(red + lane * RS);
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {   // values 16 rr + 4 c4 .. + 3 of the block, value = u * NZ + z
+                        const int v0 = 16 * rr + 4 * c4, u = v0 / NZ, z0 = v0 % NZ;
+                        mine4[c4] = make_float4(acc[u][z0 / 2].x, acc[u][z0 / 2].y, acc[u][z0 / 2 + 1].x, acc[u][z0 / 2 + 1].y);
+                    }
+                    wave_sync();
+                    const float4 *g4 = reinterpret_cast<const float4 *>(red + (lane & ~3) * RS + 4 * w4);   // row 4 g, quad w4
+                    const float4 r0 = g4[0], r1 = g4[RS / 4], r2 = g4[2 * (RS / 4)], r3 = g4[3 * (RS / 4)];
+                    float4 p = make_float4((r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y),
+                                           (r0.z + r1.z) + (r2.z + r3.z), (r0.w + r1.w) + (r2.w + r3.w));
+                    // segmented inclusive scan over the four groups of the DPP row
+                    p.x += m1 * dpp_perm<0x114>(p.x); p.y += m1 * dpp_perm<0x114>(p.y);
+                    p.z += m1 * dpp_perm<0x114>(p.z); p.w += m1 * dpp_perm<0x114>(p.w);
+                    p.x += m2 * dpp_perm<0x118>(p.x); p.y += m2 * dpp_perm<0x118>(p.y);
+                    p.z += m2 * dpp_perm<0x118>(p.z); p.w += m2 * dpp_perm<0x118>(p.w);
+                    // trailing sums of rows 0..2 carry into the later rows of the same block
+                    if (row_last && row < 3) *reinterpret_cast<float4 *>(red + XOFF + row * 16 + 4 * w4) = p;
+                    wave_sync();
+                    const float4 x0 = *reinterpret_cast<const float4 *>(red + XOFF + 4 * w4);
+                    const float4 x1 = *reinterpret_cast<const float4 *>(red + XOFF + 16 + 4 * w4);
+                    const float4 x2 = *reinterpret_cast<const float4 *>(red + XOFF + 32 + 4 * w4);
+                    p.x += c0 * x0.x + c1 * x1.x + c2 * x2.x;
+                    p.y += c0 * x0.y + c1 * x1.y + c2 * x2.y;
+                    p.z += c0 * x0.z + c1 * x1.z + c2 * x2.z;
+                    p.w += c0 * x0.w + c1 * x1.w + c2 * x2.w;
+                    if (remaining) {   // (blocks that did not fit the wave: an earlier batch stores on the spot)
+                        if (blk_last) *reinterpret_cast<float4 *>(dst + 16 * rr) = p;
+                    } else {
+                        ang[64 * rr + lane] = p;
+                    }
+                    wave_sync();
+                }
+                hold_last = blk_last;
+                hold_dst = dst;
+            }
+        }
+        }   // !padding
+        wave_sync();
+        // ---- the next atom's data has had this atom's arithmetic to arrive; then all stores of the row ----
+        ANIHIP_FWD3_ARRIVED();
+        if (!(ANIHIP_ABL == 6 || ANIHIP_ABL == 7) || i == lo) {
+            float4 *out4 = reinterpret_cast<float4 *>(out);
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {   // float4 slot f of the row belongs to block bit sb
+                const int f = lane + WAVE * m;
+                const int sb = f < R4 ? (f >> 2) : 7 + ((f - R4) >> 3);
+                const bool nd = (need >> sb) & 1ull;
+                if (m == 0 && f < R4) {   // radial part: 16-B stores from the staged row
+                    const float4 rv = *reinterpret_cast<const float4 *>(rst + 4 * (lane & 31));
+                    out4[f] = make_float4(nd ? rv.x : 0.f, nd ? rv.y : 0.f, nd ? rv.z : 0.f, nd ? rv.w : 0.f);
+                } else if (f < L4 && !nd) {
+                    out4[f] = z4;
+                }
+            }
+        }
+        if (hold_last && (ANIHIP_ABL != 6 || i == lo)) {
+            *reinterpret_cast<float4 *>(hold_dst) = ang[lane];
+            *reinterpret_cast<float4 *>(hold_dst + 16) = ang[64 + lane];
+        }
+        if (slab_mask && lane == 0) {   // 32-wide slabs of this row that are not identically zero (include/anihip.h)
+            const uint32_t r7 = (uint32_t)need & 0x7Fu;
+            const uint32_t pr = (r7 | (r7 >> 1)) & 0x55u;   // bit 2 s: species 2 s or 2 s + 1 present
+            const uint32_t rs = (pr & 1u) | ((pr >> 1) & 2u) | ((pr >> 2) & 4u) | ((pr >> 3) & 8u);
+            slab_mask[i] = rs | ((uint32_t)(need >> 7) << rslabs);
+        }
+        wave_sync();
+    }
+#undef ANIHIP_FWD3_ARRIVED
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Backward.  One wave per central atom i, three phases:
 //   1. lane = neighbor: geometry + both cutoffs once per neighbor, and the WHOLE radial backward.  The list is full, so
 //      the pair (i, j) contributes  sum_s (g_i[sp_j, s] + g_j[sp_i, s]) d/dr [0.25 exp(-eta (r - s)^2) fc(r)]  to the
@@ -1272,6 +1737,7 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
     if (hi == lo) return 0;
+#ifdef ANIHIP_USE_FWD2
     dim3 grid(persistent_blocks(hi - lo, FWD_WPB, ANIHIP_FWD2_WAVES)), block(FWD_WPB * WAVE);
     if (p->n_shf_a == 8)
         hipLaunchKernelGGL((k_aev_fwd2<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
@@ -1279,6 +1745,15 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     else
         hipLaunchKernelGGL((k_aev_fwd2<4, 8>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
                            meta, (const float4 *)ent, aev, slab_mask);
+#else
+    dim3 grid(persistent_blocks(hi - lo, FWD_WPB, ANIHIP_FWD3_WAVES)), block(FWD_WPB * WAVE);
+    if (p->n_shf_a == 8)
+        hipLaunchKernelGGL((k_aev_fwd3<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, aev, slab_mask);
+    else
+        hipLaunchKernelGGL((k_aev_fwd3<4, 8>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
+                           meta, (const float4 *)ent, aev, slab_mask);
+#endif
     ANIHIP_CHECK_HIP(hipGetLastError());
     (void)status;
     return 0;
