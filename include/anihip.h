@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 7
+#define ANIHIP_ABI_VERSION 8
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -62,7 +62,12 @@ typedef struct {
     float Rcr, Rca;
     float EtaR, EtaA, Zeta;
     int32_t cutoff_kind; /* ANIHIP_CUTOFF_COSINE | ANIHIP_CUTOFF_SMOOTH (use_cos_cutoff = false) */
+    int32_t flags;       /* ANIHIP_AEV_*: written by anihip_aev_table_pack from the shift arrays, zero before that */
 } anihip_aev_params;
+
+/* flags: the angular radial shifts ShfA are equally spaced and narrow enough for fp32 exponents -- the forward kernel
+ * then evaluates its NA Gaussians per neighbor pair by a three-exponential recurrence instead of NA exponentials. */
+#define ANIHIP_AEV_UNIFORM_SHFA 1
 
 /* Length in floats of the device constant table consumed by the AEV kernels, and a host-side packer:
  * table = ShfR[32] | ShfA[16] | cos(ShfZ)[16] | sin(ShfZ)[16]  (trig evaluated in double on the
@@ -70,7 +75,7 @@ typedef struct {
  * q = sqrt(Eta log2 e)  (exp(-Eta x^2) = exp2(-(q x)^2): the kernels keep distances pre-scaled).  The caller uploads
  * it to the device. */
 #define ANIHIP_AEV_TABLE_FLOATS 144
-int anihip_aev_table_pack(const anihip_aev_params *p, const float *ShfR, const float *ShfA,
+int anihip_aev_table_pack(anihip_aev_params *p /* flags are set */, const float *ShfR, const float *ShfA,
                           const float *ShfZ, float *table_out /* host, ANIHIP_AEV_TABLE_FLOATS */);
 
 const char *anihip_last_error(void);

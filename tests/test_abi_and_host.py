@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_struct_layouts_match_header(lib):
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header(lib):
     dereferences an anihip_mlp_desc)."""
     from torchani_amd import _lib
 
-    assert ctypes.sizeof(_lib.AevParams) == 10 * 4
+    assert ctypes.sizeof(_lib.AevParams) == 11 * 4
     assert ctypes.sizeof(_lib.SpeciesNet) == 4 + 5 * 4 + 5 * 4 * 8 + 4 * 4 + 2 * 4 * 8 + 8
     assert ctypes.sizeof(_lib.MlpDesc) == 8 * 4 + 8 * ctypes.sizeof(_lib.SpeciesNet)   # 7 ints + padding
     assert _lib.MlpDesc.flags.offset == 24 and _lib.MlpDesc.net.offset == 32

@@ -1382,3 +1382,27 @@ def test_member_model_keeps_pair_potentials(dev):
     member.set_enabled("repulsion_xtb", True)
     member.set_enabled("dispersion_d3", True)
     assert (a.energies - c.energies).abs().max() > 1e-6, "the pair potentials did not contribute"
+
+
+def test_aev_with_unequally_spaced_shifts(dev, oracle64):
+    """AEVComputer constants whose angular radial shifts are NOT equally spaced (from_constants accepts any, aev/_computer.py:
+    602-666): anihip_aev_table_pack leaves ANIHIP_AEV_UNIFORM_SHFA clear and the forward kernel evaluates every Gaussian
+    directly; equally spaced shifts set the flag (three-exponential recurrence).  Both against the oracle."""
+    from oracle import oracle as orc
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.weights import arch_spec
+
+    g = load_golden("rand_batch_ani2x")
+    base = arch_spec("ani2x")[1]
+    sp, x, cell, pbc = to_dev(g, dev)
+    for shfa, want_flag in ((tuple(0.8 + 0.3375 * k + 0.05 * (k % 3) for k in range(8)), 0), (base.ShfA, 1)):
+        consts = base._replace(ShfA=tuple(float(v) for v in shfa))
+        aevc = AEVComputer(consts, neighborlist="batch", row_capacity=256).to(dev)
+        aev = aevc(sp, x, cell, None).cpu().numpy()
+        assert (aevc.engine().params.flags & 1) == want_flag
+        p = orc.make_params(7, consts.Rcr, consts.Rca, consts.EtaR, consts.EtaA, consts.Zeta, consts.ShfR, consts.ShfA,
+                            consts.ShfZ, "cosine")
+        ref = oracle64.aev(p, g["species"], g["coords"].astype(np.float64))
+        err = np.abs(aev - ref).max()
+        report(f"aev   custom ShfA (uniform={want_flag})   max|aev err| = {err:.2e}")
+        assert err < AEV_TOL

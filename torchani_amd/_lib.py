@@ -36,7 +36,7 @@ ACT_CELU, ACT_GELU = 0, 1
 MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_FUSED_ROWS32, MLP_FLAG_D0_ROWS = \
     1, 2, 4, 8, 16, 32
 MLP_FLAG_NO_SMALL_PREP, MLP_FLAG_L0B_4WAVE = 64, 128
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class AevParams(C.Structure):
@@ -51,6 +51,7 @@ class AevParams(C.Structure):
         ("EtaA", C.c_float),
         ("Zeta", C.c_float),
         ("cutoff_kind", C.c_int32),
+        ("flags", C.c_int32),   # ANIHIP_AEV_*: set by anihip_aev_table_pack
     ]
 
 

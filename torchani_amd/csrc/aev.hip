@@ -848,7 +848,10 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD2_WAVES) void k_aev_fwd2(
 #define ANIHIP_FWD3_WAVES 4
 #endif
 #ifndef ANIHIP_FWD3_REC
-#define ANIHIP_FWD3_REC 0
+#define ANIHIP_FWD3_REC 1   // 0: never use the Gaussian recurrence (development A/B)
+#endif
+#ifndef ANIHIP_FWD3_RADIAL
+#define ANIHIP_FWD3_RADIAL 0   // 0: lane = 8 neighbor slots x 8 shift pairs, 1: lane = neighbor + segmented row sums
 #endif
 #ifndef ANIHIP_ABL
 #define ANIHIP_ABL 0   // development: phases switched off for timing (results are wrong)
@@ -871,7 +874,19 @@ __device__ __forceinline__ int block_slots(int np, int I, float inv_I)
     return (c + 3) & ~3;
 }
 
-template <int NA, int NZ>
+#ifdef ANIHIP_TRACE
+// development: per-phase shader-clock sums of wave 0 of every block (s_memtime stamps), read back by anihip_dev_trace_read
+__device__ unsigned long long g_fwd3_trace[2048][10];
+#define TR_STAMP(k_)                                                       \
+    {                                                                      \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+        if (wib == 0) tr_sum[k_] += now_ - tr_last;                        \
+        tr_last = now_;                                                    \
+    }
+#else
+#define TR_STAMP(k_)
+#endif
+template <int NA, int NZ, bool REC>
 __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
@@ -901,18 +916,18 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         cZ[z] = tab[TAB_COSZH + z];
         sZ[z] = tab[TAB_SINZH + z];
     }
-    // Gaussian recurrence of the pair loop (see there): shifts equally spaced, and no exponent beyond fp32's range
+    // Gaussian recurrence of the pair loop (REC: equally spaced shifts, checked by anihip_aev_table_pack)
     const float gD = shfAq[1] - shfAq[0], gq = __builtin_amdgcn_exp2f(-2.0f * gD * gD);
-    bool gauss_rec = gD > 0.f;
-#pragma unroll
-    for (int u = 1; u + 1 < NA; ++u) gauss_rec = gauss_rec && __builtin_fabsf((shfAq[u + 1] - shfAq[u]) - gD) < 1e-4f * gD;
-    {
-        const float xm = fmaxf(__builtin_fabsf(qA * a.Rca - shfAq[NA / 2 - 1]), __builtin_fabsf(shfAq[NA / 2 - 1]));
-        gauss_rec = gauss_rec && xm * xm < 100.f && 2.0f * gD * xm < 100.f;
-    }
     const float rev_rcr = 0.5f / a.Rcr, rev_rca = 0.5f / a.Rca;   // v_cos_f32 takes revolutions
     const int row = lane >> 4;
     const int rq = lane >> 2;                     // radial sums: row group (value quad = w4)
+#if !ANIHIP_FWD3_RADIAL
+    float2 *rad = reinterpret_cast<float2 *>(red);   // qR r, 0.25 fc(r, Rcr): dead before the first reduction
+    const int rp = lane >> 3, rsq = lane & 7;        // radial: neighbor slot, shift pair
+    const float shfR0 = tab[TAB_SHFRQ + rsq], shfR1 = tab[TAB_SHFRQ + rsq + 8];
+    const bool rad_writer = (lane & 8) && row < 2;
+    const int rad_o = row * 8 + rsq;
+#endif
     const int w4 = lane & 3;                      // reduction: value quad of a round
     const bool row_last = (lane & 15) >= 12;      // last lane group of its DPP row
 
@@ -954,7 +969,11 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                  : "memory")
     ANIHIP_FWD3_ARRIVED();
 
+#ifdef ANIHIP_TRACE
+    unsigned long long tr_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
+#endif
     for (; i < hi; i += nw) {
+        TR_STAMP(9)   // loop overhead / tail of the previous atom
         float *out = aev + (size_t)i * a.L;
         const int nA = hd.nA, nR = hd.nA + hd.nF;
         const uint64_t pkA = hd.pkA, pkF = hd.pkF;
@@ -986,6 +1005,9 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                     const float r = r2 * inv;
                     const float fcr = a.smooth ? 0.25f * smooth_cutoff(r, 1.0f / a.Rcr).x
                                                : 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f;
+#if !ANIHIP_FWD3_RADIAL
+                    rad[e] = make_float2(qR * r, fcr);
+#else
                     const float lfr = __builtin_amdgcn_logf(fcr), xq = qR * r;
                     const float *shf = tab + TAB_SHFRQ;
                     asm volatile("" : "+s"(shf));   // (re-read the 16 shifts per atom: held across the atom they spill)
@@ -1000,6 +1022,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                         }
                         mine4[c4] = make_float4(g[0], g[1], g[2], g[3]);
                     }
+#endif
                     if (e < nA) {
                         ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, 0.5f * qA * r);
                         float lf;
@@ -1016,7 +1039,9 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                     ang[nA] = make_float4(0.f, 0.f, 0.f, 0.f);
                     lfc[nA] = -__builtin_inff();
                 }
+#if ANIHIP_FWD3_RADIAL
                 wave_sync();
+                TR_STAMP(0)   // neighbor terms
                 for (uint32_t rm_ = (ANIHIP_ABL == 2 || ANIHIP_ABL == 7 ? 0u : (uint32_t)need & 0x7Fu); rm_; rm_ &= rm_ - 1) {
                     const int t = __builtin_ctz(rm_);
                     // rows of species t inside this window of 64 rows: [a0, a1) of the angular group, [f0, f1) of the far group
@@ -1054,8 +1079,39 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                     }
                 }
                 wave_sync();
+#endif
             }
+#if !ANIHIP_FWD3_RADIAL
+            wave_sync();
+            TR_STAMP(0)   // neighbor terms
+            // radial, lane = (8 neighbor slots) x (8 shift pairs), one species after the other
+            const uint64_t prA2 = pkA * 0x0101010101010100ull, prF2 = pkF * 0x0101010101010100ull;
+            for (uint32_t rm_ = (ANIHIP_ABL == 2 || ANIHIP_ABL == 7 ? 0u : (uint32_t)need & 0x7Fu); rm_; rm_ &= rm_ - 1) {
+                const int t = __builtin_ctz(rm_);
+                const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t), n = cA + cF;
+                const int oA = cnt_of(prA2, t), oF = nA + cnt_of(prF2, t);
+                float acc0 = 0.f, acc1 = 0.f;
+                for (int b_ = 0; b_ < n; b_ += 8) {
+                    const int idx = b_ + rp;
+                    const bool v = idx < n;
+                    int e = idx < cA ? oA + idx : oF + (idx - cA);
+                    e = v ? e : 0;
+                    const float2 rf = rad[e];
+                    const float f = v ? rf.y : 0.f;
+                    const float d0 = rf.x - shfR0, d1 = rf.x - shfR1;
+                    acc0 += __builtin_amdgcn_exp2f(-d0 * d0) * f;
+                    acc1 += __builtin_amdgcn_exp2f(-d1 * d1) * f;
+                }
+                acc0 = row_shr_add<8>(acc0);
+                acc1 = row_shr_add<8>(acc1);
+                float x = sum16(acc0, acc1);
+                x = sum32(x, x);
+                if (rad_writer) rst[t * 16 + rad_o] = x;
+            }
+            wave_sync();   // (the radial list is dead from here on: the reduction rows overwrite it)
+#endif
         }
+        TR_STAMP(1)   // radial sums
         // ---- prefetch the next atom ----
         hd = hdr_decode(hw_next);
         {
@@ -1074,6 +1130,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         if (!padding) {
         const uint64_t prA = pkA * 0x0101010101010100ull;
 
+        TR_STAMP(2)   // prefetch issue
         // ---- angular ----
         uint32_t remaining = ANIHIP_ABL == 1 || ANIHIP_ABL == 7 ? 0u : (uint32_t)(need >> 7);
         if (remaining) {
@@ -1109,6 +1166,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                     remaining &= remaining - 1;
                 }
                 myblk = lane < s_run ? myblk : 0;
+                TR_STAMP(3)   // slot dealing
                 // -- the lane's block: group offsets and sizes, pair iterator --
                 const int word = __builtin_amdgcn_ds_bpermute(myblk << 2, word_b);
                 const bool same = __builtin_amdgcn_ds_bpermute(myblk << 2, (int)blk_same) != 0;
@@ -1126,6 +1184,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                 for (int u = 0; u < NA; ++u)
 #pragma unroll
                     for (int vp = 0; vp < ZP; ++vp) acc[u][vp] = (v2f){0.f, 0.f};
+                TR_STAMP(4)   // pair iterator setup
                 for (int it = 0; it < (ANIHIP_ABL == 4 || ANIHIP_ABL == 5 ? 0 : I); ++it) {
                     // (j, k) of pair t inside the two groups; slots past the last pair read the dummy neighbor
                     int k2 = qd + 1 + rem;
@@ -1158,7 +1217,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                                        __builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(__builtin_fabsf(h1)) + lf)};
                     }
                     float f2[NA];
-                    if (ANIHIP_FWD3_REC) {
+                    if (REC) {
                         // equally spaced shifts s_u = s_c + (u - c) D:  g_u = exp2(-(x - (u - c) D)^2),  x = sr - s_c, and
                         // g_(u+1) / g_u = exp2(2 D x_u - D^2) =: r_u  with  r_(u+1) = r_u exp2(-2 D^2): three exponentials
                         // and 2 (NA - 2) + 1 multiplications instead of NA exponentials (a product of at most NA / 2
@@ -1190,6 +1249,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
 #pragma unroll
                         for (int vp = 0; vp < ZP; ++vp) acc[u][vp] += (v2f){f2[u], f2[u]} * f1[vp];
                 }
+                TR_STAMP(5)   // pair loop
                 // -- segmented reduction of the 64 x 32 sums, 16 values per round --
                 // same-block predicates between lane groups (all four slots of a group belong to one block)
                 const int b_m4 = __builtin_amdgcn_update_dpp(0, myblk, 0x114, 0xF, 0xF, true);   // group - 1 (0 at the row start)
@@ -1255,8 +1315,10 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         }
         }   // !padding
         wave_sync();
+        TR_STAMP(6)   // reduction
         // ---- the next atom's data has had this atom's arithmetic to arrive; then all stores of the row ----
         ANIHIP_FWD3_ARRIVED();
+        TR_STAMP(7)   // wait for the prefetch
         if (!(ANIHIP_ABL == 6 || ANIHIP_ABL == 7) || i == lo) {
             float4 *out4 = reinterpret_cast<float4 *>(out);
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1284,7 +1346,12 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
             slab_mask[i] = rs | ((uint32_t)(need >> 7) << rslabs);
         }
         wave_sync();
+        TR_STAMP(8)   // stores issued
     }
+#ifdef ANIHIP_TRACE
+    if (wib == 0 && lane == 0 && blockIdx.x < 2048)
+        for (int q_ = 0; q_ < 10; ++q_) g_fwd3_trace[blockIdx.x][q_] = tr_sum[q_];
+#endif
 #undef ANIHIP_FWD3_ARRIVED
 }
 
@@ -1670,7 +1737,7 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
 
 using namespace anihip;
 
-extern "C" int anihip_aev_table_pack(const anihip_aev_params *p, const float *ShfR, const float *ShfA,
+extern "C" int anihip_aev_table_pack(anihip_aev_params *p, const float *ShfR, const float *ShfA,
                                      const float *ShfZ, float *t)
 {
     ANIHIP_REQUIRE(p && ShfR && ShfA && ShfZ && t, "null pointer argument");
@@ -1691,6 +1758,17 @@ extern "C" int anihip_aev_table_pack(const anihip_aev_params *p, const float *Sh
     for (int k = 0; k < p->n_shf_z; ++k) {
         t[TAB_COSZH + k] = 0.5f * t[TAB_COSZ + k];
         t[TAB_SINZH + k] = 0.5f * t[TAB_SINZ + k];
+    }
+    // Gaussian recurrence of the forward pair loop (k_aev_fwd3): equally spaced ShfA, and exponents inside fp32's range
+    // for every scaled mean distance 0 .. qA Rca the kernel can meet
+    p->flags = 0;
+    {
+        const int n = p->n_shf_a, c = n / 2 - 1;
+        const float D = t[TAB_SHFAQ + 1] - t[TAB_SHFAQ];
+        bool ok = D > 0.f;
+        for (int k = 1; k + 1 < n; ++k) ok = ok && fabsf((t[TAB_SHFAQ + k + 1] - t[TAB_SHFAQ + k]) - D) < 1e-4f * D;
+        const float xm = fmaxf(fabsf(qA * p->Rca - t[TAB_SHFAQ + c]), fabsf(t[TAB_SHFAQ + c]));
+        if (ok && xm * xm < 100.f && 2.0f * D * xm < 100.f) p->flags |= ANIHIP_AEV_UNIFORM_SHFA;
     }
     return 0;
 }
@@ -1747,12 +1825,16 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
                            meta, (const float4 *)ent, aev, slab_mask);
 #else
     dim3 grid(persistent_blocks(hi - lo, FWD_WPB, ANIHIP_FWD3_WAVES)), block(FWD_WPB * WAVE);
-    if (p->n_shf_a == 8)
-        hipLaunchKernelGGL((k_aev_fwd3<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, aev, slab_mask);
-    else
-        hipLaunchKernelGGL((k_aev_fwd3<4, 8>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, aev, slab_mask);
+    const bool rec = (p->flags & ANIHIP_AEV_UNIFORM_SHFA) != 0 && ANIHIP_FWD3_REC;
+#define ANIHIP_LAUNCH_FWD3(NA_, NZ_, REC_)                                                                              \
+    hipLaunchKernelGGL((k_aev_fwd3<NA_, NZ_, REC_>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species, meta, \
+                       (const float4 *)ent, aev, slab_mask)
+    if (p->n_shf_a == 8) {
+        if (rec) ANIHIP_LAUNCH_FWD3(8, 4, true); else ANIHIP_LAUNCH_FWD3(8, 4, false);
+    } else {
+        if (rec) ANIHIP_LAUNCH_FWD3(4, 8, true); else ANIHIP_LAUNCH_FWD3(4, 8, false);
+    }
+#undef ANIHIP_LAUNCH_FWD3
 #endif
     ANIHIP_CHECK_HIP(hipGetLastError());
     (void)status;
@@ -1837,3 +1919,10 @@ extern "C" int anihip_aev_backward_virial(void *stream, const anihip_aev_params 
     return aev_backward(stream, p, table, n_atoms, lo, hi, species, meta, ent, grad_aev, grad_coords, virial,
                         slab_mask, flags);
 }
+
+#ifdef ANIHIP_TRACE
+extern "C" int anihip_dev_trace_read(unsigned long long *dst /* host, 2048 x 10 */)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(anihip::g_fwd3_trace), sizeof(unsigned long long) * 2048 * 10);
+}
+#endif
