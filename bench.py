@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--cpu-side", type=int, default=36, help="waters per edge of the CPU-baseline sub-box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-2 / config-3 secondary measurements")
+    ap.add_argument("--parity-sample", type=int, default=512,
+                    help="atoms of the headline box checked against the fp64 oracle after the timed loop (N = 1; 0 = skip)")
     ap.add_argument("--no-dense-stage", action="store_true",
                     help="skip the extra (untimed-region) dense-MLP stage timing, e.g. under rocprofv3 so the "
                          "kernel statistics hold the product configuration only")
@@ -195,6 +197,17 @@ def main():
         elapsed = float(t.item())
     model.aev_computer.last_neighbors().raise_on_overflow()
     assert torch.isfinite(out.energies).all() and torch.isfinite(out.forces).all()
+    # ---- is the headline result RIGHT?  Sampled atoms of the full box against the fp64 oracle (outside the timed region):
+    # the cluster within 2 Rcr of an atom reproduces its energy and force in the periodic box exactly (oracle/sampled_parity.py)
+    parity = None
+    if world == 1 and args.parity_sample > 0:
+        from oracle.sampled_parity import sampled_parity
+
+        sd_np = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        parity = sampled_parity(species, coords, cell, out.atomic_energies, out.forces, sd_np, "ani2x", 8,
+                                n_sample=args.parity_sample, seed=7)
+        assert parity["max_dE_atom"] <= parity["gate_dE_atom"] and parity["max_dF"] <= parity["gate_dF"], \
+            f"headline result disagrees with the oracle: {parity}"
 
     # ---- per-stage device timing on this rank's shard (outside the timed region) -----------------------
     lo, hi = shard_range(n_atoms, group)
@@ -296,6 +309,7 @@ def main():
             "dense_fp32_equivalent_tflops": mlp_tflops_dense,   # all 32 slabs multiplied (no masks)
         },
         "stages_ms": st,
+        "parity_sample": parity,
     }
     if group is not None:
         per_rank = [None] * world

@@ -1406,3 +1406,82 @@ def test_aev_with_unequally_spaced_shifts(dev, oracle64):
         err = np.abs(aev - ref).max()
         report(f"aev   custom ShfA (uniform={want_flag})   max|aev err| = {err:.2e}")
         assert err < AEV_TOL
+
+
+def _stress_state(case, seed=11):
+    """ANI-2x x 8 parameter sets that stress the split-fp16 network arithmetic (its power-of-two scales come from
+    weight-norm BOUNDS, include/anihip.h: anihip_mlp_desc.fused_bounds) away from the uniform +-1/sqrt(fan_in) init."""
+    from torchani_amd.weights import NN_PREFIX, random_state_dict
+
+    sd = {k: v.copy() for k, v in random_state_dict("ani2x", 8, seed).items()}
+    rs = np.random.RandomState(seed + 1)
+    layer_of = lambda k: 3 if ".final_layer." in k else int(k.split(".layers.")[1].split(".")[0])   # noqa: E731
+    if case.startswith("scale"):
+        sc = {"scale_small": (0.125, 0.125, 0.125, 0.125), "scale_large": (8.0, 8.0, 8.0, 8.0),
+              "scale_mixed": (8.0, 0.125, 8.0, 0.125)}[case]
+        for k in sd:
+            if k.startswith(NN_PREFIX):
+                sd[k] = (sd[k] * np.float32(sc[layer_of(k)])).astype(np.float32)
+    elif case == "student_t":
+        for k in sd:
+            if k.startswith(NN_PREFIX) and k.endswith("weight"):
+                bound = 1.0 / np.sqrt(sd[k].shape[1])
+                sd[k] = (rs.standard_t(3, size=sd[k].shape) * bound / np.sqrt(3.0)).astype(np.float32)
+    elif case == "outlier_row":
+        for sym, layer, r in (("H", 1, 7), ("O", 0, 100), ("C", 2, 3)):
+            k = f"{NN_PREFIX}members.3.atomics.{sym}.layers.{layer}.weight"
+            sd[k][r] *= np.float32(100.0)
+    else:
+        raise ValueError(case)
+    return sd
+
+
+@pytest.mark.parametrize("case", ["scale_small", "scale_large", "scale_mixed", "student_t", "outlier_row"])
+@pytest.mark.parametrize("name", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x"])
+def test_network_arithmetic_under_weight_distribution_stress(dev, oracle64, name, case):
+    """The f16x3 (split-fp16 MFMA) ensemble against the fp64 oracle for parameters that are NOT the benchmark's uniform
+    init: per-layer scales 1/8 and 8 (and alternating), a heavy-tailed Student-t(3) init, one member with rows 100 x
+    larger.  Gates: the north_star's 1e-5 Ha / 1e-4 Ha/A, relative to the largest reference value when that exceeds 1
+    (an 8 x per layer scale multiplies the energies by ~4000: no fp32 path holds 1e-5 Ha absolute there, the fp32
+    reference included)."""
+    from oracle import oracle as orc
+    from torchani_amd.models import ANI2x
+    from torchani_amd.weights import arch_spec
+
+    g = load_golden(name)
+    sd = _stress_state(case)
+    sp, x, cell, pbc = to_dev(g, dev)
+    model = ANI2x(state_dict=sd, device=dev, periodic_table_index=False)
+    out = model.energies_and_forces(sp, x, cell, pbc)
+    symbols, _, _ = arch_spec("ani2x")
+    dims, flat = orc.pack_networks(sd, symbols, 8)
+    ref = oracle64.energy_forces(oracle_params("ani2x"), g["species"], g["coords"].astype(np.float64), dims, flat, 8,
+                                 sae=None, cell=g["cell"], pbc=pbc)
+    e_ref, f_ref = ref["atomic_energies"], ref["forces"]
+    real = g["species"] >= 0
+    ea = np.abs(out.atomic_energies.cpu().numpy() - e_ref)[real].max()
+    fe = np.abs(out.forces.cpu().numpy() - f_ref)[real].max()
+    emag, fmag = np.abs(e_ref[real]).max(), np.abs(f_ref[real]).max()
+    report(f"stress {case:12s} {name:18s} |e_atom err| = {ea:.2e} (|e|max {emag:.2e})  |F err| = {fe:.2e} (|F|max {fmag:.2e})")
+    assert ea <= E_ATOM_TOL * max(1.0, emag) and fe <= F_TOL * max(1.0, fmag)
+
+
+def test_headline_scale_sampled_parity(dev):
+    """>= 1 M atoms (several network chunks, 32-bit row offsets, bin-local coordinates in a 220 A box): 256 sampled atoms of
+    a 1 073 733-atom periodic water box against the fp64 oracle on the 10.2 A clusters around them (oracle/sampled_parity.py;
+    bench.py runs the same check at 2.34 M atoms after its timed loop)."""
+    from bench import water_box
+    from oracle.sampled_parity import sampled_parity
+
+    sp_np, x_np, cell_np = water_box(71)   # 71^3 waters
+    model = get_model("ani2x", 23, dev, neighborlist="cell")
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    out = model.energies_and_forces(sp, x, cell, (True, True, True), check_overflow=True)
+    assert sp.numel() > 1_000_000 and torch.isfinite(out.forces).all()
+    res = sampled_parity(sp, x, cell, out.atomic_energies, out.forces, seeded_state("ani2x", 8, 23), "ani2x", 8,
+                         n_sample=256, seed=3)
+    report(f"box   water {sp.numel()} atoms pbc  sampled n={res['n']}: max|e_atom err| = {res['max_dE_atom']:.2e}  "
+           f"max|F err| = {res['max_dF']:.2e}  ({res['seconds']:.0f} s oracle)")
+    assert res["max_dE_atom"] < E_ATOM_TOL and res["max_dF"] < F_TOL
+    del out
+    torch.cuda.empty_cache()
