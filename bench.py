@@ -132,7 +132,9 @@ def main():
                          "GPU to exercise the N>1 code path without RCCL); implies --share-gpu")
     ap.add_argument("--emulate-shard", default=None, metavar="RANK/WORLD",
                     help="development aid (N=1 only): time what rank RANK of WORLD does in a step, without "
-                         "the all-reduces -- prints ms/step and exits")
+                         "the collective -- prints ms/step and exits")
+    ap.add_argument("--shuffle", action="store_true",
+                    help="permute the atom order of the box (the spatial shards must not depend on it)")
     args = ap.parse_args()
 
     from torchani_amd import _lib
@@ -150,6 +152,9 @@ def main():
 
     sp_np, x_np, cell_np = water_box(args.waters_side)
     n_atoms = sp_np.shape[1]
+    if args.shuffle:
+        perm = np.random.RandomState(11).permutation(n_atoms)
+        sp_np, x_np = np.ascontiguousarray(sp_np[:, perm]), np.ascontiguousarray(x_np[:, perm])
     species = torch.from_numpy(sp_np).to(dev)
     coords = torch.from_numpy(x_np).to(dev)
     cell = torch.from_numpy(cell_np).to(dev)
@@ -157,8 +162,11 @@ def main():
     model = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="cell", row_capacity=128)
 
     def step():
-        # (overflow is checked once after the timed loop instead of with a host sync per step)
-        return model.energies_and_forces(species, coords, cell, pbc, group=group, check_overflow=False)
+        # (overflow is checked once after the timed loop instead of with a host sync per step).  N > 1: spatial shards,
+        # every rank ends the step with the total energy and the forces of the atoms it owns (reduce_forces=False: no
+        # gather of the other ranks' forces -- a domain-decomposed MD step does not need them)
+        return model.energies_and_forces(species, coords, cell, pbc, group=group, check_overflow=False,
+                                         reduce_forces=False)
 
     if args.emulate_shard:
         r, wd = (int(v) for v in args.emulate_shard.split("/"))
@@ -169,7 +177,9 @@ def main():
         for _ in range(args.steps):
             model.energies_and_forces(species, coords, cell, pbc, shard=(r, wd), check_overflow=False)
         torch.cuda.synchronize()
-        print(f"shard {r}/{wd}: {(time.perf_counter() - t0) / args.steps * 1e3:.3f} ms/step (no collectives)")
+        lc = model.last_collective
+        print(f"shard {r}/{wd}{' (shuffled input)' if args.shuffle else ''}: {(time.perf_counter() - t0) / args.steps * 1e3:.3f} "
+              f"ms/step (no collective); local system {lc['n_local']} atoms = {lc['n_owned']} owned + {lc['n_halo']} halo")
         return
 
     for _ in range(args.warmup):
@@ -210,18 +220,25 @@ def main():
             f"headline result disagrees with the oracle: {parity}"
 
     # ---- per-stage device timing on this rank's shard (outside the timed region) -----------------------
-    lo, hi = shard_range(n_atoms, group)
     eng = model.aev_computer.engine()
     sp32 = species.to(torch.int32).contiguous()
+    lo, hi = 0, n_atoms
+    n_local = n_atoms
+    coords_l = coords
+    if group is not None:   # this rank's local system [left halo | owned | right halo] of the spatial shards
+        part = model._spatial_partition(sp32, coords, cell, pbc, rank, world)
+        sp32 = part.local(sp32).view(1, -1).contiguous()
+        coords_l = part.local(coords, 3).view(1, -1, 3).contiguous()
+        lo, hi, n_local = part.n_left, part.n_left + part.n_owned, part.n_local
     packed = model.neural_networks._pack(dev)
     st = {}
     reps = 3
-    nbrs = eng.neighbors(sp32, coords, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
-    st["neighbors"] = time_stage(lambda: eng.neighbors(sp32, coords, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128), reps)
-    mask = torch.zeros(n_atoms, dtype=torch.int32, device=dev)   # per-atom slab flags, as in the product path
+    nbrs = eng.neighbors(sp32, coords_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
+    st["neighbors"] = time_stage(lambda: eng.neighbors(sp32, coords_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128), reps)
+    mask = torch.zeros(n_local, dtype=torch.int32, device=dev)   # per-atom slab flags, as in the product path
     aev = eng.forward(sp32, nbrs, slab_mask=mask, shard_rows=True)   # [hi - lo, L], as in the product path
     st["aev_forward"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev, slab_mask=mask, shard_rows=True), reps)
-    ae = torch.zeros(n_atoms, dtype=torch.float32, device=dev)
+    ae = torch.zeros(n_local, dtype=torch.float32, device=dev)
     gaev = torch.zeros_like(aev)
     st["mlp_fwd_bwd"] = time_stage(
         lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk,
@@ -230,7 +247,7 @@ def main():
         st["mlp_fwd_bwd_dense"] = time_stage(
             lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev,
                                             chunk=model.mlp_chunk, shard_rows=True), 2)
-    gc = torch.zeros((n_atoms, 3), dtype=torch.float32, device=dev)
+    gc = torch.zeros((n_local, 3), dtype=torch.float32, device=dev)
     st["aev_backward"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc, shard_rows=True, slab_mask=mask), reps)
     meta = nbrs.meta[lo:hi, 1].to(torch.int64) & 0xFFFFFFFF
     n_a = float((meta & 0xFFFF).double().mean())
@@ -257,8 +274,9 @@ def main():
     # identically-zero blocks): executed flops = dense flops with the AEV length replaced by the staged columns
     pop = mask[lo:hi].to(torch.int64) & 0xFFFFFFFF
     mean_slabs = float(sum(((pop >> b) & 1).double().mean() for b in range(32)))
-    flops_dense = mlp_flops_per_atom(sp_np.reshape(-1))
-    flops_atom = mlp_flops_per_atom(sp_np.reshape(-1), l0_cols=32.0 * mean_slabs)
+    sp_owned = sp32.reshape(-1)[lo:hi].cpu().numpy()
+    flops_dense = mlp_flops_per_atom(sp_owned)
+    flops_atom = mlp_flops_per_atom(sp_owned, l0_cols=32.0 * mean_slabs)
     mlp_tflops = flops_atom * n_shard / (st["mlp_fwd_bwd"] * 1e-3) / 1e12
     mlp_tflops_dense = (flops_dense * n_shard / (st["mlp_fwd_bwd_dense"] * 1e-3) / 1e12
                         if "mlp_fwd_bwd_dense" in st else None)
@@ -277,8 +295,10 @@ def main():
             "workload": f"ANI-2x 8-member ensemble, {n_atoms}-atom periodic water box (0.1 atoms/A^3), "
                         "energy+forces, seeded random weights",
             "n_atoms": n_atoms, "box_A": float(cell_np[0, 0]),
-            "sharding": "central atoms split contiguously over ranks; coords replicated; ONE fp32 all-reduce per "
-                        "step carrying the forces and the fp64 energies as exactly-summable fp32 parts",
+            "sharding": "spatial slabs of the coordinate-sorted order (any input order), each rank works on its slab + a "
+                        "5.1 A halo; ONE all-gather per step of the halo force rows and the partial energies; forces "
+                        "stay with the rank that owns the atoms",
+            "shuffled_input": bool(args.shuffle),
         },
         "ms_per_step_median": median_ms,
         "roofline": {
@@ -319,7 +339,8 @@ def main():
         res["stages_ms_per_rank"] = per_rank
         res["collective"] = {
             "collectives_per_step": lc["collectives_per_step"], "world_size": lc["world_size"],
-            "bytes_per_step": lc["bytes"], "op": "all_reduce(sum, fp32)", "backend": backend,
+            "bytes_per_step": lc["bytes"], "op": lc.get("op", "all_reduce(sum, fp32)"), "backend": backend,
+            "local_atoms": lc.get("n_local"), "owned_atoms": lc.get("n_owned"), "halo_atoms": lc.get("n_halo"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
         }
     if rank == 0 and world == 1 and not args.no_secondary:

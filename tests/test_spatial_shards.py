@@ -1,0 +1,138 @@
+"""Spatial shards (torchani_amd/parallel.py SpatialShards): host-side plan on CPU tensors, no engine needed.
+  * the owned ranges partition the atoms for ANY input order, each is a slab along the chosen axis;
+  * the local system of a rank contains every atom within the cutoff of its owned atoms (minimum image);
+  * the message plan is consistent: what a holder keeps for an owner lands on the right owned rows;
+  * a 2- and 3-rank gloo run of ``exchange`` reproduces the single-rank sums of random pair pushes."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _box(n, L, seed, shuffle=True):
+    rs = np.random.RandomState(seed)
+    x = rs.uniform(0.0, 1.0, (n, 3)) * np.array(L)
+    if not shuffle:
+        x = x[np.argsort(x[:, int(np.argmax(L))])]
+    return torch.from_numpy(x.astype(np.float32))
+
+
+def _min_image_pairs(x, L, pbc, rc):
+    d = x[:, None, :].double() - x[None, :, :].double()
+    for k in range(3):
+        if pbc[k]:
+            d[..., k] -= L[k] * torch.round(d[..., k] / L[k])
+    r2 = (d * d).sum(-1)
+    m = r2 < rc * rc
+    m.fill_diagonal_(False)
+    return m
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("pbc", [(True, True, True), (False, False, False), (False, True, True)])
+def test_plan_covers_neighbors_and_is_consistent(world, pbc):
+    from torchani_amd.parallel import SpatialShards
+
+    L = [40.0, 17.0, 15.0]
+    n = 1500
+    x = _box(n, L, 0)
+    cell = torch.diag(torch.tensor(L))
+    rc = 5.1
+    near = _min_image_pairs(x, L, pbc, rc)
+    parts = [SpatialShards(x, cell, pbc, world, r, rc) for r in range(world)]
+    assert parts[0].axis == 0 and parts[0].periodic == pbc[0]   # the longest edge, with or without PBC along it
+    owned_all = torch.cat([p.owned_idx for p in parts])
+    assert sorted(owned_all.tolist()) == list(range(n))            # a partition of the atoms, whatever their order
+    for p in parts:
+        loc = set(p.local_idx.tolist())
+        assert len(loc) == p.n_local                                # no atom twice in a local system
+        need = torch.nonzero(near[p.owned_idx].any(dim=0)).reshape(-1).tolist()
+        assert set(need) <= loc, "a neighbor of an owned atom is missing from the local system"
+        assert p.messages == parts[0].messages and p.halo == parts[0].halo
+    # every halo row of every holder appears in exactly one run, and the run points at the same atom on the owner's side
+    for holder, hrow, owner, orow, cnt in parts[0].messages:
+        h, o = parts[holder], parts[owner]
+        lrow = hrow if hrow < h.n_left else h.n_owned + hrow        # halo row -> local row of the holder
+        assert torch.equal(h.local_idx[lrow:lrow + cnt], o.local_idx[o.n_left + orow:o.n_left + orow + cnt])
+    for p in parts:
+        rows = sum(c for hd, _, _, _, c in p.messages if hd == p.rank)
+        assert rows == p.n_left + p.n_right
+    if world == 8 and all(pbc):
+        assert max(p.n_local for p in parts) < 0.45 * n             # slabs: 1/8 owned + two 5.1 A halos of a 40 A box
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        sys.path.insert(0, ROOT)
+        import torch.distributed as dist
+        from torchani_amd.parallel import SpatialShards
+
+        dist.init_process_group("gloo")
+        L = [30.0, 12.0, 12.0]
+        n, rc = 600, 5.1
+        x = _box(n, L, 3)                                           # shuffled input order
+        cell = torch.diag(torch.tensor(L))
+        pbc = (True, True, True)
+        near = _min_image_pairs(x, L, pbc, rc)
+        w = torch.from_numpy(np.random.RandomState(5).standard_normal((n, n, 3)).astype(np.float32))
+        # "forces": central atom i pushes w[i, j] onto every neighbor j and -w[i, j] onto itself; energies e_i
+        ref = torch.zeros(n, 3, dtype=torch.float64)
+        for i in range(n):
+            js = torch.nonzero(near[i]).reshape(-1)
+            ref[js] += w[i, js].double()
+            ref[i] -= w[i, js].double().sum(0)
+        e_ref = float(torch.arange(n, dtype=torch.float64).mul(1e-3).add(0.123456789012345).sum())
+        part = SpatialShards(x, cell, pbc, world, rank, rc)
+        inv = {a: k for k, a in enumerate(part.local_idx.tolist())}
+        rows = torch.zeros(part.n_local, 3, dtype=torch.float32)
+        e_part = 0.0
+        for a in part.owned_idx.tolist():
+            js = torch.nonzero(near[a]).reshape(-1).tolist()
+            for j in js:
+                rows[inv[j]] += w[a, j]
+                rows[inv[a]] -= w[a, j]
+            e_part += a * 1e-3 + 0.123456789012345
+        rows, tot = part.exchange(rows, torch.tensor([e_part], dtype=torch.float64), dist.group.WORLD)
+        full = part.gather_owned(rows, dist.group.WORLD)
+        mine = part.scatter_owned(rows)
+        err = float((full.double() - ref).abs().max())
+        err_own = float((mine[part.owned_idx].double() - ref[part.owned_idx]).abs().max())
+        q.put((rank, {"err": err, "err_own": err_own, "dE": abs(float(tot[0]) - e_ref), "bytes": part.last_bytes,
+                      "n_local": part.n_local}))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+
+        q.put((rank, {"error": repr(e) + "\n" + traceback.format_exc()}))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_over_gloo_equals_single_rank(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert "error" not in res[r], res[r]["error"]
+        assert res[r]["err"] < 2e-5 and res[r]["err_own"] < 2e-5 and res[r]["dE"] < 1e-9, res[r]

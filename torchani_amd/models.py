@@ -292,6 +292,9 @@ class ANI(torch.nn.Module):
         no host synchronisation unless check_overflow, so it can be captured into a HIP graph."""
         C, A = species32.shape
         n = C * A
+        if (group is not None or shard is not None) and self._spatial_ok(C, n):
+            return self._energies_and_forces_spatial(species32, c32, cell, pbc, group, reduce_forces, check_overflow, shard,
+                                                     stress, tile_hint)
         lo, hi = shard_range(n, group) if shard is None else shard_range(n, rank=shard[0], world=shard[1])
         aevc = self.aev_computer
         eng = aevc.engine()
@@ -368,6 +371,110 @@ class ANI(torch.nn.Module):
             nbrs.raise_on_overflow()
         aevc._last_neighbors = nbrs
         return EnergiesForces(energies, forces, atomic_e.view(C, A), virial)
+
+    # ---- one big system on several ranks: spatial shards + halo (parallel.SpatialShards) ---------------------------
+    partition = "spatial"   # "index": contiguous index ranges + one all-reduce of the whole force array (round-2 scheme)
+
+    def _spatial_ok(self, C: int, n: int) -> bool:
+        """Slab decomposition applies to ONE system evaluated through its own pair search, with every pair potential
+        inside the AEV's radial cutoff (a wider potential, or D3's coordination numbers, would need a wider halo)."""
+        if self.partition != "spatial" or C != 1 or n < 2 or self.aev_computer.verlet is not None:
+            return False
+        rc = self.aev_computer.radial.cutoff
+        return all(k == "nnp" or not p._enabled or (p.cutoff <= rc + 1e-6 and not getattr(p, "needs_all_rows", False))
+                   for k, p in self.potentials.items())
+
+    def _spatial_partition(self, species32: Tensor, c32: Tensor, cell, pbc_t, rank: int, world: int):
+        from .parallel import SpatialShards
+
+        # (the species only decide where padding atoms are sorted -- last, out of everybody's halo; a stale placement costs
+        # balance, not correctness, so the key follows the coordinates alone)
+        key = (c32.data_ptr(), c32._version, tuple(c32.shape), None if cell is None else (cell.data_ptr(), cell._version),
+               pbc_t, rank, world)
+        hit = self.__dict__.get("_spatial_cache")
+        if hit is None or hit[0] != key:
+            # (the entry keeps the tensors alive, so an equal key means the same coordinates, not a recycled address)
+            hit = (key, SpatialShards(c32, cell, pbc_t, world, rank, self.aev_computer.radial.cutoff, species32),
+                   c32, cell, species32)
+            self.__dict__["_spatial_cache"] = hit
+        return hit[1]
+
+    def _energies_and_forces_spatial(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces, check_overflow,
+                                     shard, stress: bool, tile_hint: int) -> EnergiesForces:
+        """energies_and_forces of ONE system sharded spatially: this rank evaluates the central atoms of its slab on the
+        local system [left halo | owned | right halo], one all-gather of the halo force rows (+ partial energy / virial)
+        completes its owned atoms' forces.  reduce_forces=True additionally gathers every rank's owned forces and
+        per-atom energies (input order); False leaves them distributed (rows of other ranks are zero)."""
+        n = species32.numel()
+        if shard is None:
+            rank, world = torch.distributed.get_rank(group), torch.distributed.get_world_size(group)
+        else:
+            rank, world = shard
+        pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
+        part = self._spatial_partition(species32, c32, cell, pbc_t, rank, world)
+        sp_l = part.local(species32).view(1, -1).contiguous()
+        x_l = part.local(c32, 3).view(1, -1, 3).contiguous()
+        nl = part.n_local
+        lo, hi = part.n_left, part.n_left + part.n_owned
+        aevc = self.aev_computer
+        eng = aevc.engine()
+        dev = c32.device
+        nbrs = aevc.neighbor_rows(sp_l, x_l, cell, pbc_t, lo=lo, hi=hi)
+        packed = self.neural_networks._pack(dev)
+        slab_mask = None
+        if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
+            slab_mask = torch.zeros(nl, dtype=torch.int32, device=dev)
+        aev = eng.forward(sp_l, nbrs, slab_mask=slab_mask, shard_rows=True)
+        atomic_e, grad_aev, _ = packed.forward_backward(sp_l, aev, lo=lo, hi=hi, want_grad=True, chunk=self.mlp_chunk,
+                                                        slab_mask=slab_mask, shard_rows=True, tile_hint=tile_hint)
+        virial = torch.empty((3, 3), dtype=torch.float64, device=dev) if stress else None
+        pair_e, pair_g, pair_w = self._pair_terms(sp_l, x_l, cell, pbc_t, nbrs, lo, hi, stress)
+        sae = self._sae64(dev) if self.energy_shifter._enabled else None
+        e_atom = atomic_e if pair_e is None else atomic_e + pair_e
+        fixed = self.deterministic_forces
+        if fixed:
+            rows = torch.zeros((nl, 3), dtype=torch.int64, device=dev)
+            eng.backward(sp_l, nbrs, grad_aev, grad_coords=rows, shard_rows=True, virial=virial, slab_mask=slab_mask,
+                         fixed_point=True)
+            if pair_g is not None:
+                rows += torch.round(pair_g.to(torch.float64) / FIXED_SCALE).to(torch.int64)
+            energies = energy_reduce(sp_l, e_atom, sae, lo, hi)
+            rows.neg_()
+        else:
+            rows = torch.zeros((nl, 3), dtype=torch.float32, device=dev)
+            eng.backward(sp_l, nbrs, grad_aev, grad_coords=rows, shard_rows=True, virial=virial, slab_mask=slab_mask)
+            if pair_g is not None:
+                rows += pair_g
+            energies = energy_forces_finish(sp_l, e_atom, sae, rows, lo, hi)   # (negates rows: forces)
+        if stress and pair_w is not None:
+            virial += pair_w
+        tail = energies if not stress else torch.cat([energies, virial.reshape(-1)])
+        if group is not None and world > 1:
+            if fixed:
+                rows, tot = part.exchange(rows, torch.round(tail / FIXED_SCALE).to(torch.int64), group)
+                tot = tot.to(torch.float64) * FIXED_SCALE
+            else:
+                rows, tot = part.exchange(rows, tail, group)
+            energies = tot[:1].clone()
+            if stress:
+                virial = tot[1:].reshape(3, 3).clone()
+            n_coll, nbytes = 1, part.last_bytes
+        else:
+            n_coll, nbytes = 0, 0
+        f_l = fixed_to_float(rows) if fixed else rows
+        if group is not None and world > 1 and reduce_forces:
+            both = part.gather_owned(torch.cat([f_l, e_atom.view(-1, 1)], dim=1), group)   # ONE gather: forces + e_atom
+            forces, ae = both[:, :3].contiguous(), both[:, 3].contiguous()
+            n_coll, nbytes = n_coll + 1, nbytes + 16 * max(part.bounds[r + 1] - part.bounds[r] for r in range(world))
+        else:
+            forces, ae = part.scatter_owned(f_l), part.scatter_owned(e_atom)
+        self.last_collective = {"collectives_per_step": n_coll, "world_size": world, "bytes": nbytes,
+                                "op": "all_gather(halo force rows + partial energy)", "n_local": nl,
+                                "n_owned": part.n_owned, "n_halo": part.n_left + part.n_right}
+        if check_overflow:
+            nbrs.raise_on_overflow()
+        aevc._last_neighbors = nbrs
+        return EnergiesForces(energies, forces.view(1, n, 3), ae.view(1, n), virial)
 
     def _sae64(self, device) -> Tensor:
         """Self energies as float64 on ``device``, converted once per value of the buffer (a launch per step otherwise)."""
