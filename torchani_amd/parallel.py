@@ -164,21 +164,38 @@ class SpatialShards:
         length = [depth[k] if periodic[k] else ext[k] for k in range(3)]
         axis = max(range(3), key=lambda k: length[k])
         self.axis, self.periodic = axis, periodic[axis]
-        if self.periodic:
-            f = frac[:, axis] - torch.floor(frac[:, axis])           # [0, 1)
-            span = depth[axis]
-        else:
-            span = max(ext[axis], 1e-9)
-            f = (x64[:, axis] - lo_c[axis]) / span
+        def unit(k: int) -> torch.Tensor:                            # position along axis k scaled to [0, 1)
+            if periodic[k]:
+                return frac[:, k] - torch.floor(frac[:, k])
+            return ((x64[:, k] - lo_c[k]) / max(ext[k], 1e-9)).clamp(max=1.0 - 1e-12)
+
+        span = depth[axis] if self.periodic else max(ext[axis], 1e-9)
+        # Sort key: layers of a quarter cutoff along the slab axis, and inside a layer cells of about one cutoff along the other
+        # two axes -- the cell-sorted order SURVEY 8(e) asks for.  Atoms that are close in space end up close in memory
+        # (neighbor gathers and force pushes hit nearby rows), while the order stays monotone in the layer index, so a
+        # rank's halo is a contiguous run of layers before and behind its range.
+        nb = [1, 1, 1]
+        for k in range(3):
+            width = 0.25 * self.cutoff if k == axis else self.cutoff
+            nb[k] = int(max(1, min(1 << 20, length[k] // max(width, 1e-6))))
+        o1, o2 = [k for k in range(3) if k != axis]
+        kx = torch.floor(unit(axis) * nb[axis]).to(torch.int64).clamp(max=nb[axis] - 1)
+        k1 = torch.floor(unit(o1) * nb[o1]).to(torch.int64).clamp(max=nb[o1] - 1)
+        k2 = torch.floor(unit(o2) * nb[o2]).to(torch.int64).clamp(max=nb[o2] - 1)
+        key = (kx * nb[o1] + k1) * nb[o2] + k2
         if species is not None:                                      # padding atoms last: nobody's neighbors
-            f = torch.where(species.reshape(-1) >= 0, f, torch.full_like(f, 2.0))
-        fs, order = torch.sort(f, stable=True)
+            pad = species.reshape(-1) < 0
+            key = torch.where(pad, torch.full_like(key, nb[0] * nb[1] * nb[2]), key)
+            kx = torch.where(pad, torch.full_like(kx, 2 * nb[axis]), kx)
+        _, order = torch.sort(key, stable=True)
+        fs = kx[order].to(torch.float64) / nb[axis]                  # lower edge of every sorted atom's layer
         self.order = order                                           # sorted position -> input atom
         self.bounds = shard_bounds(n, world)
         delta = min(self.cutoff / span, 1.0)
         b = torch.tensor(self.bounds, device=dev)
-        q_lo = fs[b[:-1].clamp(max=n - 1)] - delta                   # lower end of every rank's left halo
-        q_hi = fs[(b[1:] - 1).clamp(min=0)] + delta                  # upper end of every rank's right halo
+        eps = 0.25 / nb[axis]
+        q_lo = fs[b[:-1].clamp(max=n - 1)] - delta - eps             # below the layer of the first owned atom
+        q_hi = fs[(b[1:] - 1).clamp(min=0)] + 1.0 / nb[axis] + delta + eps   # above the layer of the last one
         if self.periodic:
             q = torch.cat([q_lo, q_lo + 1.0, q_hi, q_hi - 1.0])
         else:
