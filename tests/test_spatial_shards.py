@@ -135,4 +135,4 @@ def test_exchange_over_gloo_equals_single_rank(world):
         p.join(timeout=60)
     for r in range(world):
         assert "error" not in res[r], res[r]["error"]
-        assert res[r]["err"] < 2e-5 and res[r]["err_own"] < 2e-5 and res[r]["dE"] < 1e-9, res[r]
+        assert res[r]["err"] < 1e-4 and res[r]["err_own"] < 1e-4 and res[r]["dE"] < 1e-9, res[r]   # (fp32 sums of ~80 N(0, 1) pushes)
