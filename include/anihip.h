@@ -131,6 +131,18 @@ int anihip_nbr_from_half(void *stream, const anihip_aev_params *p, int64_t n_ato
                          void *workspace, size_t workspace_bytes, uint32_t *meta, float *ent,
                          int64_t ent_capacity, uint32_t *status);
 
+/* The reverse direction: the reference's half-list format from neighbor rows -- what cell_list::cell_list returns
+ * (csrc/cell_list.cpp:342-354: idx [2, P] i64, dist [P], diff [P, 3], every pair once; call site neighbors.py:285-294), so
+ * that anihip_nbr_build_cell + this call replace torch.ops.cell_list.cell_list for FastCellList / model.neighborlist
+ * consumers.  Rows lo..hi emit their pairs with j > i (and one of each +-image pair of an atom with itself), in row order:
+ * deterministic.  diff = r_i - r_j (+ image shift), the reference's sign (neighbors.py:105-112).  lo = 0, hi = n_atoms
+ * gives the complete list.  idx is [2][capacity]; *n_pairs (device) receives the number of pairs whatever the capacity
+ * (call with capacity 0 to size the outputs).  Workspace: anihip_nbr_rows_to_half_workspace_bytes(hi - lo). */
+size_t anihip_nbr_rows_to_half_workspace_bytes(int64_t n_central);
+int anihip_nbr_rows_to_half(void *stream, int64_t n_atoms, int64_t lo, int64_t hi, const uint32_t *meta, const float *ent,
+                            void *workspace, size_t workspace_bytes, int64_t capacity, int64_t *idx, float *dist,
+                            float *diff, int64_t *n_pairs /* device */);
+
 /* Rows from an externally supplied FULL neighbor list in the LAMMPS convention (local + ghost atoms, every ghost
  * with its own coordinates; cuaev::run_with_full_nbrlist -> postProcessNbrList2, csrc/cuaev.cpp:226-244,
  * csrc/aev.cu:1048-1126, call site aev/_computer.py:420-438): listed atom ilist[g] has the numneigh[g] neighbors
@@ -288,6 +300,29 @@ typedef struct {
                              * input gradients through the fused network kernel only: 3 hidden layers <= 256 wide) */
     anihip_species_net net[ANIHIP_MAX_SPECIES];
 } anihip_mlp_desc;
+
+/* Packing a model behind the ABI (replaces what BmmEnsemble / MNPNetworks do at construction, nn/_infer.py:141-161,
+ * 263-372: stacking the members' Linear parameters for the batched kernels; mnp::run takes them as Tensor lists,
+ * csrc/mnp.cpp:238-248).  The caller describes the networks, asks for the buffer size, and hands over the parameters of
+ * every (member m, species s, layer l) as torch.nn.Linear lays them out: weights[(m * S + s) * n_layers + l] -> float
+ * [out][in] (in = aev_len for l = 0, else out_dims[s][l - 1]), biases[...] -> float [out]; device or host pointers.
+ * anihip_mlp_pack fills out_buffer (device memory, or host memory with dst_on_device = 0 -- then nothing touches a GPU)
+ * with every layout above -- fp32 arrays, transposed copies, {hi, lo} fp16 planes in slab order, MFMA fragment order,
+ * fused_bounds -- and writes the descriptor whose pointers refer to out_buffer.  The buffer must stay alive and
+ * unchanged while the descriptor is in use; the call synchronises the stream once (model load, not the hot path). */
+typedef struct {
+    int32_t n_members, num_species, n_layers;   /* n_layers = Linear layers per network incl. the final one (2..4) */
+    int32_t aev_len;
+    int32_t aev_radial_len; /* R of the slab order; -1: 16 S when aev_len has the ANI form 16 S + 32 S (S + 1) / 2, else 0 */
+    int32_t precision;      /* ANIHIP_MLP_FP32 | ANIHIP_MLP_F16X3 */
+    int32_t activation;     /* ANIHIP_ACT_CELU | ANIHIP_ACT_GELU */
+    float celu_alpha;
+    int32_t out_dims[ANIHIP_MAX_SPECIES][ANIHIP_MAX_LAYERS]; /* unpadded output width of every layer; the last is 1 */
+} anihip_mlp_shape;
+size_t anihip_mlp_pack_bytes(const anihip_mlp_shape *shape);   /* 0 + anihip_last_error() for a shape the kernels refuse */
+int anihip_mlp_pack(void *stream, const anihip_mlp_shape *shape, const float *const *weights, const float *const *biases,
+                    int32_t src_on_device, void *out_buffer, size_t out_bytes, int32_t dst_on_device,
+                    anihip_mlp_desc *out_desc);
 
 /* Workspace for n central atoms (activations of every hidden layer for all members, species-sorted
  * index lists). */

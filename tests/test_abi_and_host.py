@@ -175,10 +175,36 @@ def test_species_converter_and_self_energy():
     assert torch.allclose(e, torch.tensor([-38.3, -1.5]))  # padding contributes nothing (sae.py:61)
 
 
-def test_packed_network_layout_cpu():
-    """PackedNetworks (host packing into the layout of include/anihip.h) checked on CPU tensors."""
+def _check_pack_against_reference(W, B, K0, precision="f16x3", activation="celu", radial_len=None):
+    """anihip_mlp_pack (through PackedNetworks, host buffer) == the torch restatement of the layouts, bit for bit."""
+    from _pack_reference import pack_reference
     from torchani_amd.engine import PackedNetworks
 
+    pk = PackedNetworks(W, B, K0, 0.1, torch.device("cpu"), precision=precision, activation=activation,
+                        radial_len=radial_len)
+    ref, scales, rlen = pack_reference(W, B, K0, precision, radial_len, activation)
+    d = pk.desc
+    assert pk.radial_len == rlen == d.aev_radial_len
+    names = {"w": "w", "wt": "wt", "bias": "bias", "wh": "wh", "wth": "wth", "whf": "whf", "wthf": "wthf"}
+    seen = 0
+    for (s_, name, l), t in ref.items():
+        if name == "bounds":
+            got = pk.array(d.net[s_].fused_bounds, t.shape)
+            assert torch.allclose(got, t, rtol=2e-6, atol=0), (s_, name)   # (sums of |w| in another order)
+            continue
+        ptr = getattr(d.net[s_], names[name])[l]
+        assert ptr, (s_, name, l)
+        got = pk.array(ptr, t.shape, t.dtype)
+        assert torch.equal(got, t), (s_, name, l)
+        seen += 1
+    for (s_, l), sc in scales.items():
+        assert d.net[s_].wh_scale[l] == sc
+    assert seen > 0
+    return pk
+
+
+def test_packed_network_layout_cpu():
+    """The C-ABI packer (anihip_mlp_pack into a HOST buffer: no GPU involved) on networks whose widths need padding."""
     rs = np.random.RandomState(0)
     M, S, K0 = 2, 2, 32
     hid = [(40, 24), (33, 16)]  # widths that need padding to 64/32 and 64/32
@@ -186,37 +212,26 @@ def test_packed_network_layout_cpu():
            zip((K0,) + hid[s], hid[s] + (1,))] for s in range(S)] for m in range(M)]
     B = [[[torch.from_numpy(rs.randn(w.shape[0]).astype(np.float32)) for w in W[m][s]] for s in range(S)]
          for m in range(M)]
-    pk = PackedNetworks(W, B, K0, 0.1, torch.device("cpu"), precision="f16x3")
+    pk = _check_pack_against_reference(W, B, K0)
     d = pk.desc
     assert [d.net[0].dims[l] for l in range(4)] == [32, 64, 32, 1]
     assert [d.net[1].dims[l] for l in range(4)] == [32, 64, 32, 1]
     # layer 0 of species 1: w [K0, M*H1p], column m*H1p+o = W[m][1][0][o, :]
-    w0 = next(t for t in pk._keep if t.data_ptr() == d.net[1].w[0])
-    assert w0.shape == (32, 2 * 64)
+    w0 = pk.array(d.net[1].w[0], (32, 2 * 64))
     assert torch.equal(w0[:, 64 + 5], W[1][1][0][5]) and torch.all(w0[:, 64 + 33:] == 0)
-    wt0 = next(t for t in pk._keep if t.data_ptr() == d.net[1].wt[0])
-    assert wt0.shape == (128, 32) and torch.equal(wt0[64 + 5, :32], W[1][1][0][5])
-    # hidden layer 1 of species 0: w [M][H1p][H2p] = W^T padded, wt = W padded
-    w1 = next(t for t in pk._keep if t.data_ptr() == d.net[0].w[1])
-    wt1 = next(t for t in pk._keep if t.data_ptr() == d.net[0].wt[1])
-    assert w1.shape == (2, 64, 32) and wt1.shape == (2, 32, 64)
-    assert torch.equal(w1[1, :40, :24], W[1][0][1].t()) and torch.equal(wt1[1, :24, :40], W[1][0][1])
-    assert torch.all(w1[:, 40:, :] == 0) and torch.all(w1[:, :, 24:] == 0)
-    # f16x3 planes: hi + lo reproduces scale * weight to ~2^-22, forward planes shaped like wt
-    wh1 = next(t for t in pk._keep if t.data_ptr() == d.net[0].wh[1])
+    # f16x3 planes: hi + lo reproduces scale * weight to ~2^-22
+    wt1 = pk.array(d.net[0].wt[1], (2, 32, 64))
+    wh1 = pk.array(d.net[0].wh[1], (2, 2, 32, 64), torch.float16)
     sc = d.net[0].wh_scale[1]
-    assert wh1.dtype == torch.float16 and wh1.shape == (2, 2, 32, 64) and 2 ** 13 <= sc * wt1.abs().max() < 2 ** 14
+    assert 2 ** 13 <= sc * wt1.abs().max() < 2 ** 14
     rec = (wh1[0].float() + wh1[1].float()) / sc
     assert (rec - wt1).abs().max() <= 2.0 ** -21 * wt1.abs().max()
-    wth0 = next(t for t in pk._keep if t.data_ptr() == d.net[1].wth[0])
-    assert wth0.shape == (2, 32, 128)
-    wf = next(t for t in pk._keep if t.data_ptr() == d.net[0].w[2])
-    assert wf.shape == (2, 32) and torch.equal(wf[0, :24], W[0][0][2][0]) and torch.all(wf[:, 24:] == 0)
+    _check_pack_against_reference(W, B, K0, precision="fp32")
 
 
 def test_packed_network_slab_order_cpu():
     """Layer-0 fp16 planes in slab order (include/anihip.h): radial part padded to a multiple of 32, then
-    the angular part, for the ANI-2x shape (S = 7: 112 -> 128, K0p = 1024)."""
+    the angular part, for the ANI-2x shape (S = 7: 112 -> 128, K0p = 1024); four-layer networks with fused bounds."""
     from torchani_amd.engine import PackedNetworks
 
     rs = np.random.RandomState(1)
@@ -224,12 +239,11 @@ def test_packed_network_slab_order_cpu():
     W = [[[torch.from_numpy(rs.randn(o, i).astype(np.float32)) for i, o in ((K0, 32), (32, 32), (32, 1))]
           for s in range(S)] for m in range(M)]
     B = [[[torch.zeros(w.shape[0]) for w in W[m][s]] for s in range(S)] for m in range(M)]
-    pk = PackedNetworks(W, B, K0, 0.1, torch.device("cpu"), precision="f16x3")
+    pk = _check_pack_against_reference(W, B, K0)
     d = pk.desc
     assert pk.radial_len == 112 and d.aev_radial_len == 112
-    wh0 = next(t for t in pk._keep if t.data_ptr() == d.net[3].wh[0])
-    wth0 = next(t for t in pk._keep if t.data_ptr() == d.net[3].wth[0])
-    assert wh0.shape == (2, 32, 1024) and wth0.shape == (2, 1024, 32)
+    wh0 = pk.array(d.net[3].wh[0], (2, 32, 1024), torch.float16)
+    wth0 = pk.array(d.net[3].wth[0], (2, 1024, 32), torch.float16)
     sc = d.net[3].wh_scale[0]
     rec = (wh0[0].float() + wh0[1].float()) / sc
     ref = W[0][3][0]
@@ -244,6 +258,50 @@ def test_packed_network_slab_order_cpu():
            for s in range(2)]]
     B2 = [[[torch.zeros(w.shape[0]) for w in W2[0][s]] for s in range(2)]]
     assert PackedNetworks(W2, B2, 64, 0.1, torch.device("cpu")).radial_len == 0
+    # the ANI-2x shape itself (4 layers, 2 members, padded widths, GELU bound factors): every layout incl. fused_bounds
+    hid = {0: (256, 192, 160), 1: (224, 192, 160), 2: (192, 160, 128), 3: (192, 160, 128), 4: (160, 128, 96),
+           5: (160, 128, 96), 6: (160, 128, 96)}
+    W4 = [[[torch.from_numpy((rs.randn(o, i) / np.sqrt(i)).astype(np.float32)) for i, o in
+            zip((K0,) + hid[s], hid[s] + (1,))] for s in range(S)] for m in range(2)]
+    B4 = [[[torch.from_numpy(rs.randn(w.shape[0]).astype(np.float32) * 0.1) for w in W4[m][s]] for s in range(S)]
+          for m in range(2)]
+    _check_pack_against_reference(W4, B4, K0)
+    _check_pack_against_reference(W4, B4, K0, activation="gelu")
+
+
+def test_mlp_pack_through_raw_ctypes(lib):
+    """The network half of the ABI from ctypes alone (what a reference-side binding would do in place of mnp::run's
+    Tensor lists, csrc/mnp.cpp:238-248): shape struct -> anihip_mlp_pack_bytes -> anihip_mlp_pack into a host buffer ->
+    a descriptor whose pointers lie inside that buffer; bad shapes are refused with a message."""
+    from torchani_amd import _lib
+
+    rs = np.random.RandomState(3)
+    M, S, nl, K0 = 2, 1, 3, 64
+    outs = (48, 32, 1)
+    sh = _lib.MlpShape()
+    sh.n_members, sh.num_species, sh.n_layers, sh.aev_len, sh.aev_radial_len = M, S, nl, K0, -1
+    sh.precision, sh.activation, sh.celu_alpha = _lib.MLP_F16X3, _lib.ACT_CELU, 0.1
+    for l, o in enumerate(outs):
+        sh.out_dims[0][l] = o
+    ws = [rs.randn(o, i).astype(np.float32) for m in range(M) for i, o in zip((K0,) + outs[:-1], outs)]
+    bs = [rs.randn(w.shape[0]).astype(np.float32) for w in ws]
+    wp = (ctypes.c_void_p * len(ws))(*[w.ctypes.data for w in ws])
+    bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+    need = lib.anihip_mlp_pack_bytes(ctypes.byref(sh))
+    assert need > 4 * sum(w.size for w in ws)
+    buf = np.zeros(need, dtype=np.uint8)
+    desc = _lib.MlpDesc()
+    assert lib.anihip_mlp_pack(None, ctypes.byref(sh), wp, bp, 0, buf.ctypes.data, need, 0, ctypes.byref(desc)) == 0
+    assert desc.n_members == M and desc.net[0].n_layers == nl and [desc.net[0].dims[l] for l in range(4)] == [64, 64, 32, 1]
+    lo, hi = buf.ctypes.data, buf.ctypes.data + need
+    for arr in (desc.net[0].w, desc.net[0].bias, desc.net[0].wh, desc.net[0].whf):
+        assert lo <= arr[0] < hi
+    w1 = np.frombuffer(buf, dtype=np.float32, count=M * 64 * 32, offset=desc.net[0].wt[1] - lo).reshape(M, 32, 64)
+    assert np.array_equal(w1[1, :32, :48], ws[nl + 1])           # wt of layer 1, member 1 = its nn.Linear weight
+    assert lib.anihip_mlp_pack(None, ctypes.byref(sh), wp, bp, 0, buf.ctypes.data, need - 1, 0, ctypes.byref(desc)) != 0
+    assert b"anihip_mlp_pack_bytes" in lib.anihip_last_error()
+    sh.out_dims[0][nl - 1] = 2
+    assert lib.anihip_mlp_pack_bytes(ctypes.byref(sh)) == 0 and b"one output" in lib.anihip_last_error()
 
 
 def test_shard_bounds():
@@ -451,7 +509,7 @@ def test_charge_networks_pack_and_normalizer():
     pk = nets._pack(torch.device("cpu"))
     d = pk.desc
     assert d.activation == 1 and [d.net[1].dims[l] for l in range(4)] == [32, 32, 32, 1]
-    wf = next(t for t in pk._keep if t.data_ptr() == d.net[1].w[2])
+    wf = pk.array(d.net[1].w[2], (1, 32))
     assert torch.equal(wf[0, :16], nets.atomics["C"].final_layer.weight[1].detach())
     assert set(nets.state_dict()) == {f"atomics.{s}.{n}.weight" for s in "HC" for n in ("layers.0", "layers.1", "final_layer")}
 

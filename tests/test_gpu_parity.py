@@ -1485,3 +1485,43 @@ def test_headline_scale_sampled_parity(dev):
     assert res["max_dE_atom"] < E_ATOM_TOL and res["max_dF"] < F_TOL
     del out
     torch.cuda.empty_cache()
+
+
+def _canonical_pairs(idx, diff):
+    """(i, j, diff) rows with i < j (or the lexicographically positive image of an atom with itself), sorted."""
+    i, j, d = idx[0].copy(), idx[1].copy(), diff.astype(np.float64).copy()
+    swap = i > j
+    i[swap], j[swap] = idx[1][swap], idx[0][swap]
+    d[swap] *= -1.0
+    same = i == j
+    first = np.where(np.abs(d[:, 0]) > 1e-6, d[:, 0], np.where(np.abs(d[:, 1]) > 1e-6, d[:, 1], d[:, 2]))
+    d[same & (first < 0)] *= -1.0
+    key = np.lexsort((np.round(d[:, 2], 3), np.round(d[:, 1], 3), np.round(d[:, 0], 3), j, i))
+    return i[key], j[key], d[key]
+
+
+@pytest.mark.parametrize("name", ["water_pbc_ani2x", "triclinic_pbc_ani2x", "small_ani2x"])
+def test_cell_list_half_list_matches_reference(dev, name):
+    """torchani_amd.aev.cell_list (anihip_nbr_build_cell + anihip_nbr_rows_to_half) against the reference's own half list
+    of the fixture (tests/golden/nbrs_*.npz from gen_golden_nbrs.py): the same set of (i, j, image) pairs, distances and
+    displacement vectors; and the list feeds compute_from_neighbors like the reference's."""
+    from torchani_amd.aev import AEVComputer, cell_list
+    from torchani_amd.weights import arch_spec
+
+    g = load_golden(name)
+    nb = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"nbrs_{name}.npz"))
+    consts = arch_spec(g["kind"])[1]
+    sp, x, cell, pbc = to_dev(g, dev)
+    assert sp.shape[0] == 1
+    pbc_t = None if pbc is None else torch.tensor(pbc)
+    got = cell_list(consts.Rcr, sp, x, cell, pbc_t)
+    gi, gj, gd = _canonical_pairs(got.indices.cpu().numpy(), got.diff_vectors.cpu().numpy())
+    ri, rj, rd = _canonical_pairs(nb["indices"], nb["diff_vectors"])
+    assert len(gi) == len(ri), f"{len(gi)} pairs, the reference has {len(ri)}"
+    assert np.array_equal(gi, ri) and np.array_equal(gj, rj)
+    assert np.abs(gd - rd).max() < 5e-5
+    assert np.abs(got.distances.cpu().numpy() - got.diff_vectors.norm(dim=1).cpu().numpy()).max() < 1e-6
+    report(f"half  {name:22s} cell_list -> {len(gi)} pairs == reference's list, max|diff err| = {np.abs(gd - rd).max():.1e}")
+    aevc = AEVComputer(consts, row_capacity=256).to(dev)
+    aev = aevc.compute_from_neighbors(sp, x, got).cpu().numpy().reshape(sp.numel(), -1)
+    assert np.abs(aev[g["aev_rows"]] - g["aev"]).max() < AEV_TOL

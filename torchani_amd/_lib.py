@@ -14,7 +14,7 @@ import typing as tp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TORCHANI_AMD_LIB") or os.path.join(_HERE, "libanihip.so")
-SOURCES = ["api.hip", "nbr.hip", "aev.hip", "mlp.hip", "pair.hip"]
+SOURCES = ["api.hip", "nbr.hip", "aev.hip", "mlp.hip", "pair.hip", "pack.hip"]
 HEADERS = ["anihip_common.h", os.path.join("..", "..", "include", "anihip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared"]
 
@@ -101,6 +101,13 @@ class MlpDesc(C.Structure):
     ]
 
 
+class MlpShape(C.Structure):
+    """anihip_mlp_shape (include/anihip.h): what anihip_mlp_pack needs to know about the networks."""
+    _fields_ = [("n_members", C.c_int32), ("num_species", C.c_int32), ("n_layers", C.c_int32), ("aev_len", C.c_int32),
+                ("aev_radial_len", C.c_int32), ("precision", C.c_int32), ("activation", C.c_int32),
+                ("celu_alpha", C.c_float), ("out_dims", (C.c_int32 * MAX_LAYERS) * MAX_SPECIES)]
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -153,6 +160,10 @@ def lib() -> C.CDLL:
     L.anihip_nbr_half_workspace_bytes.argtypes = [i64]
     L.anihip_nbr_from_half.argtypes = [vp, C.POINTER(AevParams), i64, vp, i64, vp, vp, i64, i64, vp, sz, vp, vp,
                                        i64, vp]
+    L.anihip_nbr_rows_to_half_workspace_bytes.restype = sz
+    L.anihip_nbr_rows_to_half_workspace_bytes.argtypes = [i64]
+    L.anihip_nbr_rows_to_half.restype = C.c_int
+    L.anihip_nbr_rows_to_half.argtypes = [vp, i64, i64, i64, vp, vp, vp, sz, i64, vp, vp, vp, vp]
     L.anihip_nbr_from_full.argtypes = [vp, C.POINTER(AevParams), i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]
     L.anihip_nbr_refresh.argtypes = [vp, C.POINTER(AevParams), i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.anihip_aev_forward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
@@ -161,6 +172,10 @@ def lib() -> C.CDLL:
     L.anihip_aev_backward_virial.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     L.anihip_mlp_workspace_bytes.restype = sz
     L.anihip_mlp_workspace_bytes.argtypes = [C.POINTER(MlpDesc), i64]
+    L.anihip_mlp_pack_bytes.restype = sz
+    L.anihip_mlp_pack_bytes.argtypes = [C.POINTER(MlpShape)]
+    L.anihip_mlp_pack.restype = C.c_int
+    L.anihip_mlp_pack.argtypes = [vp, C.POINTER(MlpShape), vp, vp, i32, vp, sz, i32, C.POINTER(MlpDesc)]
     L.anihip_mlp_forward_backward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, vp, sz, vp,
                                               vp, vp]
     L.anihip_mlp_train_workspace_bytes.restype = sz
@@ -200,7 +215,8 @@ EXPORTED_SYMBOLS = [
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
     "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
     "anihip_mlp_tangent_workspace_bytes", "anihip_mlp_tangent_weight_grads", "anihip_pair_xtb_repulsion",
-    "anihip_pair_d3", "anihip_pair_analytic", "anihip_energy_forces_finish",
+    "anihip_pair_d3", "anihip_pair_analytic", "anihip_energy_forces_finish", "anihip_mlp_pack_bytes", "anihip_mlp_pack",
+    "anihip_nbr_rows_to_half_workspace_bytes", "anihip_nbr_rows_to_half",
 ]
 
 

@@ -393,3 +393,32 @@ class AEVComputer(torch.nn.Module):
     def extra_repr(self) -> str:
         return (f"num_species={self.num_species}, out_dim={self.out_dim}, strategy=hip, "
                 f"neighborlist={self.neighbor_mode}, row_capacity={self.row_capacity}")
+
+
+_cell_list_engines: tp.Dict[float, AevEngine] = {}
+
+
+def cell_list(cutoff: float, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
+              pbc: tp.Optional[Tensor] = None) -> Neighbors:
+    """Half neighbor list of ONE system from the engine's cell-list rows, in the reference's format -- the counterpart of
+    ``torch.ops.cell_list.cell_list(cutoff, species, coords, cell, pbc)`` behind ``FastCellList`` (csrc/cell_list.cpp:
+    342-354, neighbors.py:278-294): Neighbors(indices [2, P] int64, distances [P], diff_vectors [P, 3]) with every pair
+    inside ``cutoff`` once, dummy atoms (species -1) dropped, diff = r[indices[0]] - r[indices[1]] (+ image shift).
+    Not differentiable (the reference recomputes diff from the coordinates for autograd, neighbors.py:105-112)."""
+    from .constants import aev_constants_2x
+    from .engine import rows_to_half
+
+    if not coords.is_cuda:
+        raise ValueError("torchani_amd's neighbor builders need tensors on a ROCm device (no CPU fallback)")
+    if species.dim() != 2 or species.shape[0] != 1 or coords.shape != (1, species.shape[1], 3):
+        raise ValueError("cell_list handles one system at a time: species [1, A], coords [1, A, 3] (neighbors.py:373-381)")
+    eng = _cell_list_engines.get(float(cutoff))
+    if eng is None:
+        eng = _cell_list_engines[float(cutoff)] = AevEngine(aev_constants_2x(7)._replace(Rcr=float(cutoff), Rca=1e-3))
+    pbc_t = None if (pbc is None or cell is None) else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
+    sp32 = species.clamp(min=-1, max=0).to(torch.int32).contiguous()   # (only "dummy or not" matters for the pair search)
+    rows = eng.neighbors(sp32, coords.detach().to(torch.float32).contiguous(), cell, pbc_t, mode="cell",
+                         row_cap=_MAX_RAD)
+    rows.raise_on_overflow()
+    idx, dist, diff = rows_to_half(rows, species.shape[1])
+    return Neighbors(idx, dist.to(coords.dtype), diff.to(coords.dtype))

@@ -1100,6 +1100,141 @@ extern "C" int anihip_nbr_from_half(void *stream_, const anihip_aev_params *p, i
     return 0;
 }
 
+// ---- rows -> the reference's half list ------------------------------------------------------------------
+// cell_list::cell_list returns (idx [2, P] i64, dist [P], diff [P, 3]) with every pair once (csrc/cell_list.cpp:342-354,
+// consumed by neighbors.py:285-294).  A full row holds a pair twice -- {r_j - r_i, j} in row i and {r_i - r_j, i} in row
+// j -- so row i emits its entries with j > i, and of an atom's own periodic images (j == i, both signs in the same row)
+// the displacement whose first non-zero component is positive; diff = r_i - r_j (+ image shift) = minus the entry, the
+// reference's sign (neighbors.py:105-112).  Pass 1 counts per atom, a scan turns counts into offsets (per-atom order =
+// row order: deterministic), pass 2 writes.
+__device__ __forceinline__ bool half_keep(int64_t i, const float4 e)
+{
+    const int64_t j = (int64_t)(__float_as_uint(e.w) & IDX_MASK);
+    if (j != i) return j > i;
+    return e.x > 0.f || (e.x == 0.f && (e.y > 0.f || (e.y == 0.f && e.z > 0.f)));
+}
+
+__global__ __launch_bounds__(256) void k_half_count(int64_t lo, int64_t hi, const uint32_t *meta, const float4 *ent,
+                                                   int64_t *counts)
+{
+    for (int64_t i = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t *m = meta + (size_t)i * META_W;
+        const int n = (int)(m[1] & 0xFFFFu) + (int)(m[1] >> 16);
+        int c = 0;
+        for (int k = 0; k < n; ++k) c += half_keep(i, ent[m[0] + k]) ? 1 : 0;
+        counts[i - lo] = c;
+    }
+}
+
+// exclusive scan of n int64 values in place, n_pairs = total: blocks of 1024 (sums -> one block scans the sums -> offsets)
+__global__ __launch_bounds__(256) void k_scan_blocks(int64_t n, int64_t *v, int64_t *block_sums)
+{
+    __shared__ int64_t s_part[256];
+    const int64_t base = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    int64_t x[4], run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = base + k < n ? v[base + k] : 0;
+        run += x[k];
+    }
+    s_part[threadIdx.x] = run;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int64_t t = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int64_t excl = s_part[threadIdx.x] - run;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) v[base + k] = excl;
+        excl += x[k];
+    }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = s_part[255];
+}
+__global__ __launch_bounds__(256) void k_scan_sums(int64_t nb, int64_t *block_sums, int64_t *total)
+{
+    __shared__ int64_t s_part[256];
+    __shared__ int64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nb; b0 += 256) {
+        const int64_t i = b0 + threadIdx.x;
+        const int64_t x = i < nb ? block_sums[i] : 0;
+        s_part[threadIdx.x] = x;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int64_t t = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+            __syncthreads();
+            s_part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) block_sums[i] = s_carry + s_part[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry += s_part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ __launch_bounds__(256) void k_half_write(int64_t lo, int64_t hi, const uint32_t *meta, const float4 *ent,
+                                                   const int64_t *offs, const int64_t *block_sums, int64_t capacity,
+                                                   int64_t *idx, float *dist, float *diff)
+{
+    for (int64_t i = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t *m = meta + (size_t)i * META_W;
+        const int n = (int)(m[1] & 0xFFFFu) + (int)(m[1] >> 16);
+        int64_t p = offs[i - lo] + block_sums[(i - lo) >> 10];
+        for (int k = 0; k < n; ++k) {
+            const float4 e = ent[m[0] + k];
+            if (!half_keep(i, e)) continue;
+            if (p < capacity) {
+                idx[p] = i;
+                idx[capacity + p] = (int64_t)(__float_as_uint(e.w) & IDX_MASK);
+                diff[3 * p] = -e.x;
+                diff[3 * p + 1] = -e.y;
+                diff[3 * p + 2] = -e.z;
+                dist[p] = sqrtf(e.x * e.x + e.y * e.y + e.z * e.z);
+            }
+            ++p;
+        }
+    }
+}
+
+extern "C" size_t anihip_nbr_rows_to_half_workspace_bytes(int64_t n_central)
+{
+    const int64_t n = n_central > 0 ? n_central : 1;
+    return (size_t)(8 * (n + (n + 1023) / 1024 + 8));
+}
+
+extern "C" int anihip_nbr_rows_to_half(void *stream_, int64_t n_atoms, int64_t lo, int64_t hi, const uint32_t *meta,
+                                       const float *ent, void *workspace, size_t workspace_bytes, int64_t capacity,
+                                       int64_t *idx, float *dist, float *diff, int64_t *n_pairs)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    ANIHIP_REQUIRE(meta && ent && workspace && n_pairs, "null pointer argument");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    ANIHIP_REQUIRE(capacity >= 0 && (capacity == 0 || (idx && dist && diff)), "null output with capacity > 0");
+    const int64_t n = hi - lo;
+    ANIHIP_REQUIRE(workspace_bytes >= anihip_nbr_rows_to_half_workspace_bytes(n), "workspace too small");
+    int64_t *counts = (int64_t *)workspace, *sums = counts + (n > 0 ? n : 1);
+    if (n == 0) {
+        zero_words_async(stream, n_pairs, 8);
+        return 0;
+    }
+    const int64_t nb = (n + 1023) / 1024;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_half_count, dim3((unsigned)blocks), dim3(256), 0, stream, lo, hi, meta, (const float4 *)ent, counts);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nb), dim3(256), 0, stream, n, counts, sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, stream, nb, sums, n_pairs);
+    if (capacity > 0)
+        hipLaunchKernelGGL(k_half_write, dim3((unsigned)blocks), dim3(256), 0, stream, lo, hi, meta, (const float4 *)ent,
+                           counts, sums, capacity, idx, dist, diff);
+    ANIHIP_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 extern "C" int anihip_nbr_refresh(void *stream_, const anihip_aev_params *p, int64_t n, int64_t lo, int64_t hi,
                                   const int32_t *species, const float *coords, const float *coords_build,
                                   const uint32_t *verlet_meta, const float *verlet_ent, uint32_t *meta, float *ent,

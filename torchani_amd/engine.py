@@ -65,6 +65,25 @@ class NeighborRows(tp.NamedTuple):
                 "one species; raise row_capacity (max 256)")
 
 
+def rows_to_half(nbrs: NeighborRows, n_atoms: int) -> tp.Tuple[Tensor, Tensor, Tensor]:
+    """Neighbor rows -> the reference's half list (indices [2, P] int64, distances [P], diff_vectors [P, 3] = r_i - r_j
+    (+ shift)): what ``torch.ops.cell_list.cell_list`` / ``FastCellList`` return (csrc/cell_list.cpp:342-354,
+    neighbors.py:285-294).  anihip_nbr_rows_to_half, two calls: count, then write (one host sync for P)."""
+    L = _lib.lib()
+    dev = nbrs.meta.device
+    ws = torch.empty(L.anihip_nbr_rows_to_half_workspace_bytes(nbrs.hi - nbrs.lo), dtype=torch.uint8, device=dev)
+    npairs = torch.zeros(1, dtype=torch.int64, device=dev)
+    args = (_stream(), n_atoms, nbrs.lo, nbrs.hi, _ptr(nbrs.meta), _ptr(nbrs.ent), _ptr(ws), ws.numel())
+    _lib.check(L.anihip_nbr_rows_to_half(*args, 0, None, None, None, _ptr(npairs)))
+    P = int(npairs.item())
+    idx = torch.empty((2, P), dtype=torch.int64, device=dev)
+    dist = torch.empty(P, dtype=torch.float32, device=dev)
+    diff = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    if P:
+        _lib.check(L.anihip_nbr_rows_to_half(*args, P, _ptr(idx), _ptr(dist), _ptr(diff), _ptr(npairs)))
+    return idx, dist, diff
+
+
 class AevEngine:
     """Neighbor rows + AEV forward/backward for one set of AEV constants."""
 
@@ -413,115 +432,57 @@ class PackedNetworks:
         self.M, self.S, self.nl, self.aev_len = M, S, nl, aev_len
         self.device = device
         self.shapes = [[tuple(weights[0][s][l].shape) for l in range(nl)] for s in range(S)]   # unpadded [out, in]
-        self._keep: tp.List[Tensor] = []
-        d = _lib.MlpDesc()
-        d.num_species, d.n_members, d.aev_len, d.celu_alpha = S, M, aev_len, celu_alpha
-        d.precision = _lib.MLP_F16X3 if precision == "f16x3" else _lib.MLP_FP32
-        d.activation = _lib.ACT_GELU if activation == "gelu" else _lib.ACT_CELU
-        k0p = _pad32(aev_len)
-        if radial_len is None:
-            radial_len = 16 * S if aev_len == 16 * S + 16 * S * (S + 1) else 0
-        if precision != "f16x3" or radial_len <= 0 or (aev_len - radial_len) % 32 != 0:
-            radial_len = 0
-        self.radial_len = d.aev_radial_len = radial_len
-        # slab order: column of the padded layer-0 reduction index <- AEV feature
-        rpad = _pad32(radial_len)
-        k0h = rpad + (aev_len - radial_len) if radial_len else k0p
-        slab_cols = torch.cat([torch.arange(radial_len), rpad + torch.arange(aev_len - radial_len)]).to(device) \
-            if radial_len else torch.arange(aev_len, device=device)
-        f32 = dict(dtype=torch.float32, device=device)
+        # The layouts are produced by the library itself (anihip_mlp_pack, csrc/pack.hip): the same call a caller without
+        # this package makes.  Parameters are handed over as contiguous fp32 tensors where they live (device or host).
+        sh = _lib.MlpShape()
+        sh.n_members, sh.num_species, sh.n_layers, sh.aev_len = M, S, nl, aev_len
+        sh.aev_radial_len = -1 if radial_len is None else int(radial_len)
+        sh.precision = _lib.MLP_F16X3 if precision == "f16x3" else _lib.MLP_FP32
+        sh.activation = _lib.ACT_GELU if activation == "gelu" else _lib.ACT_CELU
+        sh.celu_alpha = celu_alpha
         for s in range(S):
-            net = d.net[s]
-            net.n_layers = nl
-            dims = [aev_len] + [_pad32(weights[0][s][l].shape[0]) for l in range(nl - 1)] + [1]
             if weights[0][s][nl - 1].shape[0] != 1:
                 raise ValueError("final layer must have one output")
-            for l, v in enumerate(dims):
-                net.dims[l] = v
             for l in range(nl):
-                kin, kout = dims[l], dims[l + 1]
-                Ws = []
-                Bs = []
-                for m in range(M):
-                    W = weights[m][s][l].detach().to(**f32)
-                    b = biases[m][s][l].detach().to(**f32)
-                    Wp = torch.zeros((kout, kin), **f32)
-                    Wp[: W.shape[0], : W.shape[1]] = W
-                    bp = torch.zeros((kout,), **f32)
-                    bp[: b.shape[0]] = b
-                    Ws.append(Wp)
-                    Bs.append(bp)
-                Wst = torch.stack(Ws)   # [M, out_p, in_p]
-                bst = torch.stack(Bs)   # [M, out_p]
-                if l == nl - 1:
-                    w = Wst.reshape(M, kin).contiguous()
-                    wt = None
-                    bias = bst.reshape(M).contiguous()
-                elif l == 0:
-                    cat = Wst.reshape(M * kout, kin)              # row m*H1p+o
-                    w = cat.t().contiguous()                      # [K0, M*H1p]
-                    wt = torch.zeros((M * kout, k0p), **f32)      # [M*H1p, K0p]
-                    wt[:, :kin] = cat
-                    bias = bst.reshape(M * kout).contiguous()
-                else:
-                    w = Wst.transpose(1, 2).contiguous()          # [M, in_p, out_p]
-                    wt = Wst.contiguous()                         # [M, out_p, in_p]
-                    bias = bst.contiguous()
-                self._keep += [w, bias] + ([wt] if wt is not None else [])
-                net.w[l] = w.data_ptr()
-                net.bias[l] = bias.data_ptr()
-                net.wt[l] = wt.data_ptr() if wt is not None else None
-                if precision == "f16x3" and wt is not None:
-                    # power-of-two scale putting the largest weight into [2^13, 2^14); planes {hi, lo}
-                    amax = float(Wst.abs().max())
-                    scale = 2.0 ** (13 - int(np.floor(np.log2(amax)))) if amax > 0 else 1.0
-                    if l == 0:
-                        fwd_src = torch.zeros((M * kout, k0h), **f32)   # wt, columns in slab order
-                        fwd_src[:, slab_cols] = cat
-                        bwd_src = fwd_src.t().contiguous()              # [K0h, M*H1p]
-                    else:
-                        fwd_src, bwd_src = wt, w
-                    planes = []
-                    for src in (fwd_src, bwd_src):
-                        x = src * scale
-                        hi = x.to(torch.float16)
-                        lo = (x - hi.to(torch.float32)).to(torch.float16)
-                        planes.append(torch.stack([hi, lo]).contiguous())
-                    self._keep += planes
-                    net.wh[l] = planes[0].data_ptr()
-                    net.wth[l] = planes[1].data_ptr()
-                    net.wh_scale[l] = scale
-                    # MFMA fragment order for the fused network kernel (include/anihip.h):
-                    # planes [2][M][N][K] -> [M][N/32][K/16][2][h*32 + r][8]
-                    # (layer 0: forward planes only, viewed per member: [2][M*H1p][K0h] -> [2][M][H1p][K0h])
-                    frags = []
-                    for pl in (planes if l >= 1 else [planes[0].view(2, M, kout, k0h)]):
-                        N_, K_ = pl.shape[2], pl.shape[3]
-                        f = pl.view(2, M, N_ // 32, 32, K_ // 16, 2, 8).permute(1, 2, 4, 0, 5, 3, 6)
-                        frags.append(f.contiguous())
-                    self._keep += frags
-                    net.whf[l] = frags[0].data_ptr()
-                    if l >= 1:
-                        net.wthf[l] = frags[1].data_ptr()
-            if precision == "f16x3" and nl == 4:
-                # operand bounds of the fused kernel's inner GEMMs (include/anihip.h), per member
-                W1 = torch.stack([weights[m][s][1].detach().to(**f32) for m in range(M)])   # [M, H2, H1]
-                W2 = torch.stack([weights[m][s][2].detach().to(**f32) for m in range(M)])   # [M, H3, H2]
-                b1 = torch.stack([biases[m][s][1].detach().to(**f32) for m in range(M)])
-                w3 = torch.stack([weights[m][s][3].detach().to(**f32).reshape(-1) for m in range(M)])
-                # (|celu'| <= 1; max gelu' = 1.1290: the gradient bounds grow by that factor per layer)
-                dmax = 1.13 if activation == "gelu" else 1.0
-                g2 = w3.abs().amax(dim=1) / M * dmax
-                g3 = g2 * W2.abs().sum(dim=1).amax(dim=1) * dmax
-                g4 = g3 * W1.abs().sum(dim=1).amax(dim=1)
-                zero = torch.zeros_like(g2)
-                bounds = torch.stack([W1.abs().sum(dim=2).amax(dim=1), b1.abs().amax(dim=1), g2, g3, g4,
-                                      zero, zero, zero], dim=1).contiguous()
-                self._keep.append(bounds)
-                net.fused_bounds = bounds.data_ptr()
+                sh.out_dims[s][l] = int(weights[0][s][l].shape[0])
+        src, on_dev = [], None
+        wp, bp = (C.c_void_p * (M * S * nl))(), (C.c_void_p * (M * S * nl))()
+        for m in range(M):
+            for s in range(S):
+                for l in range(nl):
+                    W = weights[m][s][l].detach().to(torch.float32).contiguous()
+                    b = biases[m][s][l].detach().to(torch.float32).contiguous()
+                    if tuple(W.shape) != self.shapes[s][l] or b.numel() != W.shape[0]:
+                        raise ValueError("every member must have the same layer shapes")
+                    if on_dev is None:
+                        on_dev = W.is_cuda
+                    if W.is_cuda != on_dev or b.is_cuda != on_dev:
+                        raise ValueError("parameters must all live on the host or all on a device")
+                    src += [W, b]
+                    wp[(m * S + s) * nl + l], bp[(m * S + s) * nl + l] = W.data_ptr(), b.data_ptr()
+        L = _lib.lib()
+        need = L.anihip_mlp_pack_bytes(C.byref(sh))
+        if need == 0:
+            raise ValueError("libanihip: " + L.anihip_last_error().decode())
+        self._buf = torch.empty(need, dtype=torch.uint8, device=device)
+        d = _lib.MlpDesc()
+        if on_dev:
+            torch.cuda.current_stream(src[0].device).synchronize()   # (the library reads the parameters with blocking copies)
+        stream = _stream() if self._buf.is_cuda else None
+        _lib.check(L.anihip_mlp_pack(stream, C.byref(sh), wp, bp, 1 if on_dev else 0, _ptr(self._buf), need,
+                                     1 if self._buf.is_cuda else 0, C.byref(d)))
+        del src
+        self.radial_len = d.aev_radial_len
         self.desc = d
         self._ws: tp.Optional[Tensor] = None
         self._train_ws: tp.Optional[Tensor] = None
+
+    def array(self, ptr: int, shape: tp.Sequence[int], dtype: torch.dtype = torch.float32) -> Tensor:
+        """View of one packed array (a pointer of ``desc``) inside the buffer anihip_mlp_pack filled."""
+        off = int(ptr) - self._buf.data_ptr()
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        assert 0 <= off and off + n <= self._buf.numel(), "pointer outside the packed buffer"
+        return self._buf[off:off + n].view(dtype).view(*shape)
 
     def workspace(self, n_central: int) -> Tensor:
         need = _lib.lib().anihip_mlp_workspace_bytes(C.byref(self.desc), n_central)
