@@ -73,6 +73,25 @@ def measure(dev=None, reps2=50, reps3=20):
     return out
 
 
+def measure_config5(steps: int = 10):
+    """BASELINE config 5: one training step on a minibatch of 2560 conformers (tools/train_bench.py: the recipe of the
+    reference's tools/training-aev-benchmark.py:71-170 -- MSE(E) / sqrt(n_atoms), Adam lr 1e-4), ANI-2x x 8 members and
+    the reference's own single ANI-1x network (csrc/README.md:106-112 publishes 9.45 ms per 2560-batch on a V100 for it)."""
+    import train_bench
+
+    out = {}
+    for tag, argv in (("ani2x_x8_eager", ["--kind", "ani2x", "--members", "8"]),
+                      ("ani2x_x8_graph", ["--kind", "ani2x", "--members", "8", "--graph"]),
+                      ("ani1x_x1_eager", ["--kind", "ani1x", "--members", "1"]),
+                      ("ani1x_x1_graph", ["--kind", "ani1x", "--members", "1", "--graph"])):
+        out[tag] = train_bench.run(train_bench.parse(argv + ["--steps", str(steps), "--warmup", "3"]), quiet=True)
+        torch.cuda.empty_cache()
+    out["workload"] = ("2560 synthetic ANI-1x-like conformers (H C N O, 2-24 atoms, padded), energy loss MSE / sqrt(n_atoms), "
+                       "Adam lr 1e-4; eager = AEV / networks / backward / optimizer timed separately, graph = the whole step "
+                       "replayed as one HIP graph")
+    return out
+
+
 if __name__ == "__main__":
     res = measure()
     if "--json" in sys.argv:

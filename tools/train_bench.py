@@ -32,7 +32,7 @@ def conformers(n_mol, n_at, seed=5):
     return sp, x
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="ani1x")
     ap.add_argument("--members", type=int, default=1)
@@ -42,7 +42,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--forces", action="store_true", help="energy + force loss (second-order backward)")
     ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, backward, Adam) in a HIP graph")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(args, quiet=False):
+    """One configuration; returns the numbers that are printed (bench.py's secondary.config5 calls this)."""
     from torchani_amd.models import ANI1x, ANI2x
 
     dev = torch.device("cuda:0")
@@ -120,20 +124,27 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         n_real = int((sp >= 0).sum())
-        print(f"config 5, whole step replayed as a HIP graph: {args.kind} x{args.members}, batch {args.batch} conformers "
-              f"({n_real} atoms): {dt * 1e3:.2f} ms/step = {args.batch / dt:.0f} conformers/s; "
-              f"loss {first:.5f} -> {float(static_loss.detach()):.5f}")
-        return
+        if not quiet:
+            print(f"config 5, whole step replayed as a HIP graph: {args.kind} x{args.members}, batch {args.batch} conformers "
+                  f"({n_real} atoms): {dt * 1e3:.2f} ms/step = {args.batch / dt:.0f} conformers/s; "
+                  f"loss {first:.5f} -> {float(static_loss.detach()):.5f}")
+        return {"ms_per_step": dt * 1e3, "conformers_per_s": args.batch / dt, "atoms": n_real,
+                "loss_first": first, "loss_last": float(static_loss.detach())}
     for _ in range(args.warmup):
         step(False)
     losses = [step(True) for _ in range(args.steps)]
     total = sum(acc.values()) / args.steps
     n_real = int((sp >= 0).sum())
-    print(f"config 5{' (energy+force loss)' if args.forces else ''}: {args.kind} x{args.members}, batch {args.batch} conformers ({n_real} atoms): "
-          f"{total * 1e3:.2f} ms/step = {args.batch / total:.0f} conformers/s")
-    print("  " + "  ".join(f"{k} {v / args.steps * 1e3:.2f} ms" for k, v in acc.items()))
-    print(f"  loss {losses[0]:.5f} -> {losses[-1]:.5f}")
+    if not quiet:
+        print(f"config 5{' (energy+force loss)' if args.forces else ''}: {args.kind} x{args.members}, batch {args.batch} conformers ({n_real} atoms): "
+              f"{total * 1e3:.2f} ms/step = {args.batch / total:.0f} conformers/s")
+        print("  " + "  ".join(f"{k} {v / args.steps * 1e3:.2f} ms" for k, v in acc.items()))
+        print(f"  loss {losses[0]:.5f} -> {losses[-1]:.5f}")
+    out = {"ms_per_step": total * 1e3, "conformers_per_s": args.batch / total, "atoms": n_real,
+           "loss_first": losses[0], "loss_last": losses[-1]}
+    out.update({f"ms_{k}": v / args.steps * 1e3 for k, v in acc.items()})
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    run(parse())
