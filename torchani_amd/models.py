@@ -466,6 +466,8 @@ class ANI(torch.nn.Module):
             both = part.gather_owned(torch.cat([f_l, e_atom.view(-1, 1)], dim=1), group)   # ONE gather: forces + e_atom
             forces, ae = both[:, :3].contiguous(), both[:, 3].contiguous()
             n_coll, nbytes = n_coll + 1, nbytes + 16 * max(part.bounds[r + 1] - part.bounds[r] for r in range(world))
+        elif group is None:   # shard=(rank, world) without a group: the rank's partial sums, halo pushes included
+            forces, ae = part.scatter_local(f_l), part.scatter_owned(e_atom)
         else:
             forces, ae = part.scatter_owned(f_l), part.scatter_owned(e_atom)
         self.last_collective = {"collectives_per_step": n_coll, "world_size": world, "bytes": nbytes,

@@ -292,6 +292,14 @@ class SpatialShards:
         out[self.owned_idx] = local_rows[self.n_left:self.n_left + self.n_owned]
         return out
 
+    def scatter_local(self, local_rows: torch.Tensor) -> torch.Tensor:
+        """[n_local, ...] -> [N, ...] in input order with EVERY local row (halo rows too): a rank's partial result before
+        the exchange, as ``energies_and_forces(shard=(rank, world))`` returns it -- the partials of all ranks add up to
+        the whole."""
+        out = torch.zeros((self.n,) + tuple(local_rows.shape[1:]), dtype=local_rows.dtype, device=local_rows.device)
+        out[self.local_idx] = local_rows
+        return out
+
     def gather_owned(self, local_rows: torch.Tensor, group) -> torch.Tensor:
         """All ranks' owned rows, [N, ...] in input order on every rank (one all-gather of equal, padded pieces)."""
         width = int(local_rows[0].numel()) if local_rows.dim() > 1 else 1
