@@ -5,8 +5,8 @@
 // in flight while the current one is computed -- turned into unit vectors / cutoff factors once per neighbor and staged
 // in the wave's private LDS.  Three kernels:
 //
-//   k_aev_fwd2  forward of the energy / force path: two lanes per (j, k) pair, species-pair blocks with pairs only,
-//               log-domain cutoff product, packed outer product, transpose-reduce.  No atomics.  (Details at the kernel.)
+//   k_aev_fwd3  forward of the energy / force path: one lane per (j, k) pair over a flat slot assignment of all species-pair
+//               blocks, log-domain cutoff product, packed outer product, segmented reduction through LDS.  No atomics.
 //   k_aev_bwd   analytic backward: radial part by symmetric gather (each atom finishes its own radial force from the
 //               64-B block of every neighbor's dE/dAEV row), angular part over all neighbor pairs in one tournament
 //               with lane-owned j and plain LDS read-add-write for k, dE/dAEV staged block-wise; the few remaining
@@ -528,302 +528,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, JVP ? 4 : 7) void k_aev_fwd(
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Forward of the energy / force path (the JVP keeps the four-lanes-per-pair kernel above).
-//   * lane = (pair slot 0..31, half h): two lanes per (j, k) pair.  Half h evaluates the angle factors of the shifts
-//     z = h, 2 + h, ... and HALF of the radial-shift Gaussians, the other half arrives by one DPP swap inside the lane
-//     pair; the NA x NZ/2 outer product accumulates as NA*NZ/4 packed (v_pk_fma_f32) registers.
-//   * the cutoff product rides in the exponent: f1 fc_j fc_k 2 = exp2(zeta log2 h + lfc_j + lfc_k) with
-//     lfc = log2 fc + 1/2 per neighbor, and pair slots past the end of a block read a dummy neighbor whose lfc is
-//     -inf, so nothing is masked or multiplied afterwards.  Distances are stored pre-scaled (0.5 sqrt(eta log2 e) r),
-//     which makes a Gaussian  exp2(-(r_j' + r_k' - s')^2): sub, mul, exp.
-//   * only the species (pairs) that occur among the neighbors are visited: a 35-bit "needed block" word per atom
-//     (ballot over the per-species counts) drives the radial and angular loops (s_ff1) and the zero fill of the rest
-//     of the row (four predicated 16-B stores); group offsets are byte prefix sums from one 64-bit multiply.
-//   * block reduction over the 32 slots by a transpose-reduce (permlane32/16 swaps, then DPP inside the row): every
-//     level halves the registers, lane l ends with output 2 ((l >> 2) & 15) + h of the block; one 128-B store.
 typedef float v2f __attribute__((ext_vector_type(2)));
-
-// l <-> l ^ 8 inside a DPP row: lanes with bit 3 clear end with p[l] + p[l ^ 8], the others with q[l] + q[l ^ 8]
-__device__ __forceinline__ float xor8_combine(float p, float q, bool hi8)
-{
-    const float t = hi8 ? q : p, u = hi8 ? p : q;
-    return t + dpp_perm<0x128>(u);   // row_ror:8
-}
-// the same for l <-> l ^ 4 (row_shr:4 into banks 1, 3 and row_shl:4 into banks 0, 2)
-__device__ __forceinline__ float xor4_combine(float p, float q, bool hi4)
-{
-    const float t = hi4 ? q : p, u = hi4 ? p : q;
-    const float x1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x114, 0xF, 0xA, false));
-    const float x2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x104, 0xF, 0x5, false));
-    return t + x1 + x2;
-}
-
-#ifndef ANIHIP_FWD2_WAVES
-#define ANIHIP_FWD2_WAVES 5
-#endif
-template <int NA, int NZ>
-__global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD2_WAVES) void k_aev_fwd2(
-    AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
-    const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
-    const float4 *__restrict__ ent, float *__restrict__ aev, uint32_t *__restrict__ slab_mask)
-{
-    static_assert(NA % 4 == 0 && NZ % 4 == 0 && NA * NZ == 32, "angular tiling");
-    constexpr int AH = NA / 2, ZH = NZ / 2, ZP = ZH / 2;   // own Gaussians, own angle shifts, packed pairs of them
-    __shared__ float4 s_ang[FWD_WPB][MAXA + 1];   // ux uy uz, 0.5 qA r          (entry nA = dummy)
-    __shared__ float s_lfc[FWD_WPB][MAXA + 1];    // log2 fc(r, Rca) + 0.5       (dummy: -inf)
-    __shared__ float2 s_rad[FWD_WPB][MAXR];       // qR r, 0.25 fc(r, Rcr)
-
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
-    float4 *ang = s_ang[wib];
-    float *lfc = s_lfc[wib];
-    float2 *rad = s_rad[wib];
-
-    // exp(-eta x^2) = exp2(-(q x)^2), q = sqrt(eta log2 e)
-    const float qR = a.qR, qA = a.qA;
-    const int rp = lane >> 3, rsq = lane & 7;  // radial: neighbor slot, shift pair
-    const float shfR0 = tab[TAB_SHFRQ + rsq], shfR1 = tab[TAB_SHFRQ + rsq + 8];
-    const int slot = lane >> 1, h = lane & 1;  // angular: pair slot, half
-    float shfAq[AH], cZ[ZH], sZ[ZH];
-#pragma unroll
-    for (int u = 0; u < AH; ++u) shfAq[u] = tab[TAB_SHFAQ + h * AH + u];
-#pragma unroll
-    for (int v = 0; v < ZH; ++v) {   // h(theta) = 0.5 + 0.5 cos(theta - ShfZ),  z = 2 v + h
-        cZ[v] = tab[TAB_COSZH + 2 * v + h];
-        sZ[v] = tab[TAB_SINZH + 2 * v + h];
-    }
-    const float rev_rcr = 0.5f / a.Rcr, rev_rca = 0.5f / a.Rca;   // v_cos_f32 takes revolutions
-    // position of this lane's reduced value inside an angular block: local accumulator w = (lane >> 2) & 15 =
-    // u * ZH + v holds Gaussian u ^ (h AH) (own ones first) and angle shift 2 v + h
-    const int wv = (lane >> 2) & 15;
-    const int ang_pos = (((wv / ZH) ^ (h * AH)) * NZ) + 2 * (wv % ZH) + h;
-    const bool ang_writer = (lane & 2) == 0;
-    const bool hi8 = (lane & 8) != 0, hi4 = (lane & 4) != 0;
-    const int row = lane >> 4;
-    const bool rad_writer = (lane & 8) && row < 2;
-    const int rad_o = row * 8 + rsq;
-
-    // "needed block" bookkeeping (as in the backward kernel): bit t < 7 radial block of species t, bit 7 + P angular
-    // block of species pair P; lane b < 35 decides bit b
-    int nd_tj = 7, nd_tk = 7;
-    if (lane < 7) {
-        nd_tj = nd_tk = lane;
-    } else {
-        int P = lane - 7, tj = 0;
-        while (tj < a.S && P >= a.S - tj) { P -= a.S - tj; ++tj; }
-        if (tj < a.S) { nd_tj = tj; nd_tk = tj + P; }
-    }
-    const int L4 = a.L >> 2, R4 = a.radlen >> 2;
-    int slot_bit[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int f = lane + WAVE * m;
-        slot_bit[m] = f >= L4 ? 63 : (f < R4 ? (f >> 2) : 7 + ((f - R4) >> 3));
-    }
-    const int rslabs = (a.S + 1) >> 1;
-
-    const int64_t nw = (int64_t)gridDim.x * FWD_WPB;
-    int64_t i = lo + blockIdx.x * (int64_t)FWD_WPB + wib;
-    uint32_t hw = hdr_load(meta, species, i, i < hi);
-    AtomHdr hd = hdr_decode(hw);
-    float4 e0 = make_float4(1.f, 0.f, 0.f, 0.f), e1 = e0;
-    if (i < hi && hd.sp >= 0) {
-        if (lane < hd.nA + hd.nF) e0 = ent[hd.start + lane];
-        if (lane + WAVE < hd.nA + hd.nF) e1 = ent[hd.start + lane + WAVE];
-    }
-    uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
-
-    for (; i < hi; i += nw) {
-        float *out = aev + (size_t)i * a.L;
-        const int nA = hd.nA, nR = hd.nA + hd.nF;
-        const uint64_t pkA = hd.pkA, pkF = hd.pkF;
-        const bool padding = hd.sp < 0;
-        const uint32_t start = hd.start;
-
-        // ---- per-neighbor precompute -> LDS ----
-        if (!padding) {
-            for (int c0 = 0; c0 < nR; c0 += WAVE) {
-                const int e = c0 + lane;
-                float4 d = c0 == 0 ? e0 : (c0 == WAVE ? e1 : make_float4(1.f, 0.f, 0.f, 0.f));
-                if (c0 >= 2 * WAVE && e < nR) d = ent[start + e];
-                if (e < nR) {
-                    const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
-                    const float inv = __builtin_amdgcn_rsqf(r2);
-                    const float r = r2 * inv;
-                    rad[e] = make_float2(qR * r, a.smooth ? 0.25f * smooth_cutoff(r, 1.0f / a.Rcr).x
-                                                          : 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f);
-                    if (e < nA) {
-                        ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, 0.5f * qA * r);
-                        float lf;
-                        if (a.smooth) {   // log2 exp(1 - 1 / m)
-                            const float q_ = r / a.Rca;
-                            lf = (1.0f - 1.0f / fmaxf(SMOOTH_EPS, (1.0f - q_) * (1.0f + q_))) * LOG2E;
-                        } else {
-                            lf = __builtin_amdgcn_logf(0.5f * __builtin_amdgcn_cosf(r * rev_rca) + 0.5f);
-                        }
-                        lfc[e] = lf + 0.5f;
-                    }
-                }
-            }
-            if (lane == 0) {
-                ang[nA] = make_float4(0.f, 0.f, 0.f, 0.f);
-                lfc[nA] = -__builtin_inff();
-            }
-        }
-        // ---- prefetch the next atom ----
-        hd = hdr_decode(hw_next);
-        {
-            const int64_t in = i + nw;
-            e0 = make_float4(1.f, 0.f, 0.f, 0.f);
-            e1 = e0;
-            if (in < hi && hd.sp >= 0) {
-                if (lane < hd.nA + hd.nF) e0 = ent[hd.start + lane];
-                if (lane + WAVE < hd.nA + hd.nF) e1 = ent[hd.start + lane + WAVE];
-            }
-            hw_next = hdr_load(meta, species, in + nw, in + nw < hi);
-        }
-        // ---- which blocks can be non-zero; zero the others ----
-        uint64_t need = 0ull;
-        if (!padding) {
-            const int cj = (int)((pkA >> (8 * nd_tj)) & 255u), ck = (int)((pkA >> (8 * nd_tk)) & 255u);
-            const int cf = (int)((pkF >> (8 * nd_tj)) & 255u);
-            const bool nd = lane < 7 ? (cj + cf > 0) : (nd_tj == nd_tk ? cj >= 2 : (cj >= 1 && ck >= 1));
-            need = __ballot(nd && lane < 35);
-        }
-        {
-            float4 *out4 = reinterpret_cast<float4 *>(out);
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-                if (slot_bit[m] != 63 && !((need >> slot_bit[m]) & 1ull)) out4[lane + WAVE * m] = z4;
-        }
-        if (slab_mask && lane == 0) {   // 32-wide slabs of this row that are not identically zero (include/anihip.h)
-            const uint32_t r7 = (uint32_t)need & 0x7Fu;
-            const uint32_t pr = (r7 | (r7 >> 1)) & 0x55u;   // bit 2 s: species 2 s or 2 s + 1 present
-            const uint32_t rs = (pr & 1u) | ((pr >> 1) & 2u) | ((pr >> 2) & 4u) | ((pr >> 3) & 8u);
-            slab_mask[i] = rs | ((uint32_t)(need >> 7) << rslabs);
-        }
-        if (padding) continue;
-        wave_sync();
-        // offsets of the species groups inside the angular / far parts of the row: byte prefix sums
-        const uint64_t prA = pkA * 0x0101010101010100ull, prF = pkF * 0x0101010101010100ull;
-
-        // ---- radial: species with neighbors only ----
-        for (uint32_t rm_ = (uint32_t)need & 0x7Fu; rm_; rm_ &= rm_ - 1) {
-            const int t = __builtin_ctz(rm_);
-            const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t), n = cA + cF;
-            const int oA = cnt_of(prA, t), oF = nA + cnt_of(prF, t);
-            float acc0 = 0.f, acc1 = 0.f;
-            for (int b = 0; b < n; b += 8) {
-                const int idx = b + rp;
-                const bool v = idx < n;
-                int e = idx < cA ? oA + idx : oF + (idx - cA);
-                e = v ? e : 0;
-                const float2 rf = rad[e];
-                const float f = v ? rf.y : 0.f;
-                const float d0 = rf.x - shfR0, d1 = rf.x - shfR1;
-                acc0 += __builtin_amdgcn_exp2f(-d0 * d0) * f;
-                acc1 += __builtin_amdgcn_exp2f(-d1 * d1) * f;
-            }
-            // 8 slots -> 1: inside the DPP row, then across rows.  Row 0 ends with the totals of
-            // acc0, row 1 with those of acc1 (lanes 8..15 = shift pair rsq).
-            acc0 = row_shr_add<8>(acc0);
-            acc1 = row_shr_add<8>(acc1);
-            float x = sum16(acc0, acc1);
-            x = sum32(x, x);
-            if (rad_writer) out[t * 16 + rad_o] = x;
-        }
-
-        // ---- angular: species pairs with at least one (j, k) pair only ----
-        for (uint32_t am = (uint32_t)(need >> 7); am; am &= am - 1) {
-            const int P = __builtin_ctz(am);
-            const int tj = __builtin_amdgcn_readlane(nd_tj, 7 + P), tk = __builtin_amdgcn_readlane(nd_tk, 7 + P);
-            const int nj = cnt_of(pkA, tj), nk = cnt_of(pkA, tk);
-            const int oj = cnt_of(prA, tj), ok = cnt_of(prA, tk);
-            const bool same = (tk == tj);
-            const int np = same ? (nj * (nj - 1)) >> 1 : nj * nk;
-            const int div = same ? ((nj - 1) >> 1) : nk;
-            const float inv_div = div > 0 ? __builtin_amdgcn_rcpf((float)div) : 0.f;   // (exact for powers of two)
-            const int rect = same ? nj * div : 0x7FFFFFFF;
-            const int half = nj >> 1;
-            const int q32 = div > 0 ? (int)(32.01f * inv_div) : 0, r32 = 32 - q32 * div;
-            v2f acc[NA][ZP];
-#pragma unroll
-            for (int u = 0; u < NA; ++u)
-#pragma unroll
-                for (int vp = 0; vp < ZP; ++vp) acc[u][vp] = (v2f){0.f, 0.f};
-            PairIter it = pair_begin(slot, div, inv_div);
-            int t0 = 0;
-            do {   // (np >= 1: the block is flagged)
-                // (j, k) of pair it.t inside the two groups; slots past the last pair read the dummy neighbor
-                int jr = it.qd, kr = it.rem;
-                if (same) {   // wave-uniform
-                    int k2 = it.qd + 1 + it.rem;
-                    k2 = (int)min((uint32_t)k2, (uint32_t)(k2 - nj));   // k2 >= nj ? k2 - nj : k2
-                    const bool diam = it.t >= rect;
-                    jr = diam ? it.t - rect : it.qd;
-                    kr = diam ? it.t - rect + half : k2;
-                }
-                const bool v = it.t < np;
-                const int ej = v ? oj + jr : nA, ek = v ? ok + kr : nA;
-                const float4 J = ang[ej], K = ang[ek];
-                const float lf = lfc[ej] + lfc[ek];
-                // advance to the pair 32 further on
-                it.t += 32;
-                it.rem += r32;
-                it.qd += q32;
-                {
-                    const bool carry = it.rem >= div;
-                    it.rem -= carry ? div : 0;
-                    it.qd += carry ? 1 : 0;
-                }
-                const float c = J.x * K.x + J.y * K.y + J.z * K.z;
-                const float ct = 0.95f * c;
-                const float st = __builtin_amdgcn_sqrtf(fmaxf(1.0f - ct * ct, 0.f));
-                const float sr = J.w + K.w;
-                v2f f1[ZP];
-#pragma unroll
-                for (int vp = 0; vp < ZP; ++vp) {
-                    const float h0 = 0.5f + ct * cZ[2 * vp] + st * sZ[2 * vp];
-                    const float h1 = 0.5f + ct * cZ[2 * vp + 1] + st * sZ[2 * vp + 1];
-                    f1[vp] = (v2f){__builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(__builtin_fabsf(h0)) + lf),
-                                   __builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(__builtin_fabsf(h1)) + lf)};
-                }
-                float f2[NA];
-#pragma unroll
-                for (int u = 0; u < AH; ++u) {
-                    const float dd = sr - shfAq[u];
-                    f2[u] = __builtin_amdgcn_exp2f(-dd * dd);
-                    f2[AH + u] = dpp_perm<0xB1>(f2[u]);   // the partner lane's Gaussians
-                }
-#pragma unroll
-                for (int u = 0; u < NA; ++u)
-#pragma unroll
-                    for (int vp = 0; vp < ZP; ++vp) acc[u][vp] += (v2f){f2[u], f2[u]} * f1[vp];
-                t0 += 32;
-            } while (t0 < np);
-            // 32 slots -> 1 (see the header comment)
-            float r16[16];
-#pragma unroll
-            for (int u = 0; u < NA; ++u)
-#pragma unroll
-                for (int vp = 0; vp < ZP; ++vp) {
-                    r16[u * ZH + 2 * vp] = acc[u][vp].x;
-                    r16[u * ZH + 2 * vp + 1] = acc[u][vp].y;
-                }
-            float A8[8], B4[4];
-#pragma unroll
-            for (int w = 0; w < 8; ++w) A8[w] = sum32(r16[w], r16[w + 8]);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) B4[w] = sum16(A8[w], A8[w + 4]);
-            const float C0 = xor8_combine(B4[0], B4[2], hi8), C1 = xor8_combine(B4[1], B4[3], hi8);
-            float D = xor4_combine(C0, C1, hi4);
-            D += dpp_perm<0x4E>(D);   // l ^ 2
-            if (ang_writer) out[a.radlen + P * 32 + ang_pos] = D;
-        }
-        wave_sync();
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // k_aev_fwd3 (round 3): ONE lane per (j, k) pair and a FLAT slot assignment over all species-pair blocks of the atom.
@@ -843,18 +548,12 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD2_WAVES) void k_aev_fwd2(
 //     carry the partial sums to the LAST group of every block, whose four lanes store 64 B of the AEV row.  No atomics,
 //     fixed order, any number of blocks for the price of one reduction.
 //   * atoms whose blocks do not fit 64 slots (many species with a few pairs each) are done in batches of blocks.
-// The radial part, the log-domain cutoff product and the dummy neighbor are those of k_aev_fwd2.
+// (k_aev_fwd2, the round-2 kernel described in the first bullet, is gone: 4.28 ms against 4.06 ms on the 2.34 M-atom box.)
 #ifndef ANIHIP_FWD3_WAVES
 #define ANIHIP_FWD3_WAVES 4
 #endif
 #ifndef ANIHIP_FWD3_REC
 #define ANIHIP_FWD3_REC 1   // 0: never use the Gaussian recurrence (development A/B)
-#endif
-#ifndef ANIHIP_FWD3_RADIAL
-#define ANIHIP_FWD3_RADIAL 0   // 0: lane = 8 neighbor slots x 8 shift pairs, 1: lane = neighbor + segmented row sums
-#endif
-#ifndef ANIHIP_ABL
-#define ANIHIP_ABL 0   // development: phases switched off for timing (results are wrong)
 #endif
 // sum over the wave of small non-negative integers held by the lanes: scan inside the DPP rows, four readlanes
 __device__ __forceinline__ int wave_isum(int v)
@@ -920,14 +619,11 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
     const float gD = shfAq[1] - shfAq[0], gq = __builtin_amdgcn_exp2f(-2.0f * gD * gD);
     const float rev_rcr = 0.5f / a.Rcr, rev_rca = 0.5f / a.Rca;   // v_cos_f32 takes revolutions
     const int row = lane >> 4;
-    const int rq = lane >> 2;                     // radial sums: row group (value quad = w4)
-#if !ANIHIP_FWD3_RADIAL
     float2 *rad = reinterpret_cast<float2 *>(red);   // qR r, 0.25 fc(r, Rcr): dead before the first reduction
     const int rp = lane >> 3, rsq = lane & 7;        // radial: neighbor slot, shift pair
     const float shfR0 = tab[TAB_SHFRQ + rsq], shfR1 = tab[TAB_SHFRQ + rsq + 8];
     const bool rad_writer = (lane & 8) && row < 2;
     const int rad_o = row * 8 + rsq;
-#endif
     const int w4 = lane & 3;                      // reduction: value quad of a round
     const bool row_last = (lane & 15) >= 12;      // last lane group of its DPP row
 
@@ -980,21 +676,13 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         const bool padding = hd.sp < 0;
         const uint32_t start = hd.start;
 
-        // ---- per-neighbor precompute -> LDS, and the whole radial part ----
-        // lane = neighbor: its 16 radial terms 0.25 fc exp(-eta (r - s)^2) = exp2(-(qR r - s')^2 + log2(0.25 fc)) go to the
-        // lane's reduction row; the rows are sorted by species inside the angular-range group and inside the far group,
-        // so the radial block of species t is the sum of two row ranges: lane (rq, w4) adds every 16th row of them for the
-        // value quad w4, the 16 row groups are combined with two DPP rotations and two permlane swaps, and the block waits
-        // in rst for the stores at the end of the atom.  (The previous layout -- lane = 8 neighbor slots x 8 shift pairs,
-        // one species after the other -- spent 43 instructions per 8 neighbors, a third of the kernel.)
+        // ---- per-neighbor precompute -> LDS ----
         uint64_t need = 0ull;
         const int cj = (int)((pkA >> (8 * nd_tj)) & 255u), ck = (int)((pkA >> (8 * nd_tk)) & 255u);
         if (!padding) {
             const int cf = (int)((pkF >> (8 * nd_tj)) & 255u);
             const bool nd = lane < 7 ? (cj + cf > 0) : (blk_same ? cj >= 2 : (cj >= 1 && ck >= 1));
             need = __ballot(nd && lane < 35);
-            const uint64_t prA_ = pkA * 0x0101010101010100ull, prF_ = pkF * 0x0101010101010100ull;
-            if (lane < 4) *reinterpret_cast<float4 *>(red + XOFF + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero row
             for (int c0 = 0; c0 < nR; c0 += WAVE) {
                 const int e = c0 + lane;
                 float4 d = c0 == 0 ? e0 : (c0 == WAVE ? e1 : dummy4);
@@ -1005,24 +693,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                     const float r = r2 * inv;
                     const float fcr = a.smooth ? 0.25f * smooth_cutoff(r, 1.0f / a.Rcr).x
                                                : 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f;
-#if !ANIHIP_FWD3_RADIAL
                     rad[e] = make_float2(qR * r, fcr);
-#else
-                    const float lfr = __builtin_amdgcn_logf(fcr), xq = qR * r;
-                    const float *shf = tab + TAB_SHFRQ;
-                    asm volatile("" : "+s"(shf));   // (re-read the 16 shifts per atom: held across the atom they spill)
-                    float4 *mine4 = reinterpret_cast<float4 *>(red + lane * RS);
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        float g[4];
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const float dd = xq - shf[4 * c4 + m];
-                            g[m] = __builtin_amdgcn_exp2f(lfr - dd * dd);
-                        }
-                        mine4[c4] = make_float4(g[0], g[1], g[2], g[3]);
-                    }
-#endif
                     if (e < nA) {
                         ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, 0.5f * qA * r);
                         float lf;
@@ -1039,54 +710,12 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                     ang[nA] = make_float4(0.f, 0.f, 0.f, 0.f);
                     lfc[nA] = -__builtin_inff();
                 }
-#if ANIHIP_FWD3_RADIAL
-                wave_sync();
-                TR_STAMP(0)   // neighbor terms
-                for (uint32_t rm_ = (ANIHIP_ABL == 2 || ANIHIP_ABL == 7 ? 0u : (uint32_t)need & 0x7Fu); rm_; rm_ &= rm_ - 1) {
-                    const int t = __builtin_ctz(rm_);
-                    // rows of species t inside this window of 64 rows: [a0, a1) of the angular group, [f0, f1) of the far group
-                    const int oA = cnt_of(prA_, t) - c0, oF = nA + cnt_of(prF_, t) - c0;
-                    const int a0 = min(max(oA, 0), WAVE), a1 = min(max(oA + cnt_of(pkA, t), 0), WAVE);
-                    const int f0 = min(max(oF, 0), WAVE), f1 = min(max(oF + cnt_of(pkF, t), 0), WAVE);
-                    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
-                    for (int rb = a0; rb < a1; rb += 16) {
-                        const int rr_ = rb + rq;
-                        const float4 v = *reinterpret_cast<const float4 *>(red + (rr_ < a1 ? rr_ * RS : XOFF) + 4 * w4);
-                        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
-                    }
-                    for (int rb = f0; rb < f1; rb += 16) {
-                        const int rr_ = rb + rq;
-                        const float4 v = *reinterpret_cast<const float4 *>(red + (rr_ < f1 ? rr_ * RS : XOFF) + 4 * w4);
-                        sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
-                    }
-                    // 16 row groups -> 1: rotations inside the DPP row, then across the rows two values per swap
-                    sm.x += dpp_perm<0x128>(sm.x); sm.y += dpp_perm<0x128>(sm.y);   // row_ror:8
-                    sm.z += dpp_perm<0x128>(sm.z); sm.w += dpp_perm<0x128>(sm.w);
-                    sm.x += dpp_perm<0x124>(sm.x); sm.y += dpp_perm<0x124>(sm.y);   // row_ror:4
-                    sm.z += dpp_perm<0x124>(sm.z); sm.w += dpp_perm<0x124>(sm.w);
-                    float xy = sum16(sm.x, sm.y), zw = sum16(sm.z, sm.w);
-                    xy = sum32(xy, xy);   // row 0: total of .x, row 1: total of .y
-                    zw = sum32(zw, zw);   // row 0: total of .z, row 1: total of .w
-                    if ((lane & 15) < 4 && row < 2) {   // lanes 0..3 (row 0) and 16..19 (row 1): value quad w4 = lane & 3
-                        float *o = rst + t * 16 + 4 * w4 + row;
-                        if (c0 == 0) {
-                            o[0] = xy;
-                            o[2] = zw;
-                        } else {
-                            o[0] += xy;
-                            o[2] += zw;
-                        }
-                    }
-                }
-                wave_sync();
-#endif
             }
-#if !ANIHIP_FWD3_RADIAL
             wave_sync();
             TR_STAMP(0)   // neighbor terms
             // radial, lane = (8 neighbor slots) x (8 shift pairs), one species after the other
             const uint64_t prA2 = pkA * 0x0101010101010100ull, prF2 = pkF * 0x0101010101010100ull;
-            for (uint32_t rm_ = (ANIHIP_ABL == 2 || ANIHIP_ABL == 7 ? 0u : (uint32_t)need & 0x7Fu); rm_; rm_ &= rm_ - 1) {
+            for (uint32_t rm_ = (uint32_t)need & 0x7Fu; rm_; rm_ &= rm_ - 1) {
                 const int t = __builtin_ctz(rm_);
                 const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t), n = cA + cF;
                 const int oA = cnt_of(prA2, t), oF = nA + cnt_of(prF2, t);
@@ -1109,7 +738,6 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                 if (rad_writer) rst[t * 16 + rad_o] = x;
             }
             wave_sync();   // (the radial list is dead from here on: the reduction rows overwrite it)
-#endif
         }
         TR_STAMP(1)   // radial sums
         // ---- prefetch the next atom ----
@@ -1132,7 +760,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
 
         TR_STAMP(2)   // prefetch issue
         // ---- angular ----
-        uint32_t remaining = ANIHIP_ABL == 1 || ANIHIP_ABL == 7 ? 0u : (uint32_t)(need >> 7);
+        uint32_t remaining = (uint32_t)(need >> 7);
         if (remaining) {
             // block lanes: pairs of the block, where its two groups start in the row
             const bool is_blk = (need >> lane) & 1ull && lane >= 7;
@@ -1185,7 +813,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
 #pragma unroll
                     for (int vp = 0; vp < ZP; ++vp) acc[u][vp] = (v2f){0.f, 0.f};
                 TR_STAMP(4)   // pair iterator setup
-                for (int it = 0; it < (ANIHIP_ABL == 4 || ANIHIP_ABL == 5 ? 0 : I); ++it) {
+                for (int it = 0; it < I; ++it) {
                     // (j, k) of pair t inside the two groups; slots past the last pair read the dummy neighbor
                     int k2 = qd + 1 + rem;
                     k2 = (int)min((uint32_t)k2, (uint32_t)(k2 - nj));   // k2 >= nj ? k2 - nj : k2
@@ -1266,16 +894,8 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                 const int nxt = row_last ? (row == 0 ? n1b : row == 1 ? n2b : row == 2 ? n3b : 0) : b_p4;
                 const bool blk_last = myblk && nxt != myblk;
                 float *dst = out + a.radlen + (myblk - 7) * 32 + 4 * w4;
-                if (ANIHIP_ABL == 3 || ANIHIP_ABL == 5) {   // (keep the sums alive without the reduction)
-                    float sacc = 0.f;
 #pragma unroll
-                    for (int u = 0; u < NA; ++u)
-#pragma unroll
-                        for (int vp = 0; vp < ZP; ++vp) sacc += acc[u][vp].x + acc[u][vp].y;
-                    if (sacc == 12345.678f) dst[0] = sacc;
-                }
-#pragma unroll
-                for (int rr = 0; rr < (ANIHIP_ABL == 3 || ANIHIP_ABL == 5 ? 0 : 2); ++rr) {
+                for (int rr = 0; rr < 2; ++rr) {
                     float4 *mine4 = reinterpret_cast<float4 *>(red + lane * RS);
 #pragma unroll
                     for (int c4 = 0; c4 < 4; ++c4) {   // values 16 rr + 4 c4 .. + 3 of the block, value = u * NZ + z
@@ -1319,7 +939,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         // ---- the next atom's data has had this atom's arithmetic to arrive; then all stores of the row ----
         ANIHIP_FWD3_ARRIVED();
         TR_STAMP(7)   // wait for the prefetch
-        if (!(ANIHIP_ABL == 6 || ANIHIP_ABL == 7) || i == lo) {
+        {
             float4 *out4 = reinterpret_cast<float4 *>(out);
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -1335,7 +955,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                 }
             }
         }
-        if (hold_last && (ANIHIP_ABL != 6 || i == lo)) {
+        if (hold_last) {
             *reinterpret_cast<float4 *>(hold_dst) = ang[lane];
             *reinterpret_cast<float4 *>(hold_dst + 16) = ang[64 + lane];
         }
@@ -1815,15 +1435,6 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
     if (hi == lo) return 0;
-#ifdef ANIHIP_USE_FWD2
-    dim3 grid(persistent_blocks(hi - lo, FWD_WPB, ANIHIP_FWD2_WAVES)), block(FWD_WPB * WAVE);
-    if (p->n_shf_a == 8)
-        hipLaunchKernelGGL((k_aev_fwd2<8, 4>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, aev, slab_mask);
-    else
-        hipLaunchKernelGGL((k_aev_fwd2<4, 8>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species,
-                           meta, (const float4 *)ent, aev, slab_mask);
-#else
     dim3 grid(persistent_blocks(hi - lo, FWD_WPB, ANIHIP_FWD3_WAVES)), block(FWD_WPB * WAVE);
     const bool rec = (p->flags & ANIHIP_AEV_UNIFORM_SHFA) != 0 && ANIHIP_FWD3_REC;
 #define ANIHIP_LAUNCH_FWD3(NA_, NZ_, REC_)                                                                              \
@@ -1835,7 +1446,6 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
         if (rec) ANIHIP_LAUNCH_FWD3(4, 8, true); else ANIHIP_LAUNCH_FWD3(4, 8, false);
     }
 #undef ANIHIP_LAUNCH_FWD3
-#endif
     ANIHIP_CHECK_HIP(hipGetLastError());
     (void)status;
     return 0;
