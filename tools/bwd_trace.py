@@ -1,0 +1,45 @@
+"""Per-phase shader-clock breakdown of k_aev_bwd (library built with -DANIHIP_TRACE; development)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import water_box  # noqa: E402
+
+NAMES = ["loop head", "stage own row", "phase 1 (terms, radial gather)", "prefetch issue", "phase 2 (angular pairs)",
+         "phase 3 (atomics)"]
+
+
+def main():
+    from torchani_amd import _lib
+    from torchani_amd.models import ANI2x
+
+    dev = torch.device("cuda:0")
+    sp_np, x_np, cell_np = water_box(int(sys.argv[1]) if len(sys.argv) > 1 else 64)
+    sp32 = torch.from_numpy(sp_np).to(dev).to(torch.int32).contiguous()
+    model = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="cell")
+    eng = model.aev_computer.engine()
+    nbrs = eng.neighbors(sp32, torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev), (True, True, True), mode="cell")
+    n = sp32.numel()
+    mask = torch.zeros(n, dtype=torch.int32, device=dev)
+    aev = eng.forward(sp32, nbrs, slab_mask=mask)
+    gaev = torch.randn_like(aev) * 1e-3
+    gc = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        eng.backward(sp32, nbrs, gaev, gc, slab_mask=mask)
+    torch.cuda.synchronize()
+    buf = np.zeros((2048, 10), dtype=np.uint64)
+    assert _lib.lib().anihip_dev_trace_read(buf.ctypes.data_as(C.c_void_p)) == 0
+    used = buf[buf.sum(axis=1) > 0].astype(np.float64)
+    per_wave_atoms = n / (used.shape[0] * 4)
+    tot = used.sum(axis=1).mean()
+    print(f"k_aev_bwd: blocks {used.shape[0]}  atoms per wave {per_wave_atoms:.1f}  clocks per atom (wave 0) {tot / per_wave_atoms:.0f}")
+    for k, nm in enumerate(NAMES):
+        print(f"  {nm:32s} {used[:, k].mean() / per_wave_atoms:8.0f} clocks/atom  {100 * used[:, k].mean() / tot:5.1f} %")
+
+
+if __name__ == "__main__":
+    main()

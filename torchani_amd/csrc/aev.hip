@@ -67,6 +67,13 @@ __device__ __forceinline__ float quad_bcast_rt(float v, int q)
 }
 
 __device__ __forceinline__ int cnt_of(uint64_t pk, int t) { return (int)((pk >> (8 * t)) & 255u); }
+// byte (sh / 8) of a wave-uniform 64-bit word for a per-lane bit shift sh = 0, 8, .. 56, in 32-bit operations (a per-lane
+// 64-bit shift of a scalar pair keeps two more registers alive per use)
+__device__ __forceinline__ int byte_at(uint64_t pk, int sh)
+{
+    const uint32_t w = sh < 32 ? (uint32_t)pk : (uint32_t)(pk >> 32);
+    return (int)((w >> (sh & 31)) & 255u);
+}
 
 // (j,k) of the t-th pair of a block: rectangle for two different species, circular tournament for
 // pairs inside one species (every unordered pair exactly once, no sqrt / triangular-index decode)
@@ -1012,11 +1019,14 @@ __device__ __forceinline__ void push_grad(float *grad_coords, size_t at, int com
 #endif
 template <int NA, int NZ, bool VIRIAL, bool FIXED>
 __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
-    AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
+    AevArgs a, const float *__restrict__ tab, int64_t lo64, int64_t hi64,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
     const float4 *__restrict__ ent, const float *__restrict__ grad_aev, float *__restrict__ grad_coords,
-    double *__restrict__ virial, const uint32_t *__restrict__ slab_mask, int64_t glo, int64_t ghi)
+    double *__restrict__ virial, const uint32_t *__restrict__ slab_mask, int64_t glo64, int64_t ghi64)
 {
+    // (32-bit atom indices inside the kernel -- rows hold 28-bit neighbor indices anyway: a 64-bit "less than" is a vector
+    // compare whose operands end up spilled)
+    const int lo = (int)lo64, hi = (int)hi64, glo = (int)glo64, ghi = (int)ghi64;
     float vxx = 0.f, vyy = 0.f, vzz = 0.f, vxy = 0.f, vxz = 0.f, vyz = 0.f;
     constexpr int ZQ = NZ / 4;
     __shared__ float4 s_nb[BWD_WPB][MAXA];    // ux uy uz r
@@ -1066,55 +1076,64 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
         while (tj < a.S && P >= a.S - tj) { P -= a.S - tj; ++tj; }
         if (tj < a.S) { nd_tj = tj; nd_tk = tj + P; }
     }
-    // float4 slot f = lane + 64 m of a row belongs to block bit slot_bit[m] (63 = beyond the row)
-    int slot_bit[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int f = lane + WAVE * m;
-        slot_bit[m] = f >= L4 ? 63 : (f < R4 ? (f >> 2) : 7 + ((f - R4) >> 3));
-    }
+    int nd_pack = (8 * nd_tj) | ((8 * nd_tk) << 8);   // bit shifts of the lane's two count bytes, one register
+    // float4 slot f = lane + 64 m of a row belongs to block bit slot_of(f) (63 = beyond the row); worked out where it is
+    // used -- four registers held across the atom otherwise
+    auto slot_of = [&](int f) -> int { return f >= L4 ? 63 : (f < R4 ? (f >> 2) : 7 + ((f - R4) >> 3)); };
     auto need_of = [&](uint64_t pkA_, uint64_t pkF_) -> uint64_t {
-        const int cj = (int)((pkA_ >> (8 * nd_tj)) & 255u), ck = (int)((pkA_ >> (8 * nd_tk)) & 255u);
-        const int cf = (int)((pkF_ >> (8 * nd_tj)) & 255u);
-        const bool nd = lane < 7 ? (cj + cf > 0) : (nd_tj == nd_tk ? cj >= 2 : (cj >= 1 && ck >= 1));
+        // (opaque: what the compiler derives from the shifts -- byte masks, comparisons -- is loop invariant, gets hoisted
+        // out of the atom loop and spilled; the reload then sits behind the prefetch loads and waits for them)
+        asm volatile("" : "+v"(nd_pack));
+        const int sj = nd_pack & 255, sk = nd_pack >> 8;
+        const int cj = byte_at(pkA_, sj), ck = byte_at(pkA_, sk), cf = byte_at(pkF_, sj);
+        const bool nd = lane < 7 ? (cj + cf > 0) : (sj == sk ? cj >= 2 : (cj >= 1 && ck >= 1));
         return __ballot(nd && lane < 35);
     };
 
-    const int64_t nw = (int64_t)gridDim.x * BWD_WPB;
-    int64_t i = lo + blockIdx.x * (int64_t)BWD_WPB + wib;
+    const int nw = (int)gridDim.x * BWD_WPB;
+    int i = lo + (int)blockIdx.x * BWD_WPB + wib;
     // software pipeline over atoms: the header, the first 128 neighbor entries and the needed blocks of the dE/dAEV
     // row of atom i+nw are in flight while atom i is processed
     uint32_t hw = hdr_load(meta, species, i, i < hi);
     AtomHdr h = hdr_decode(hw);
-    const float4 zero4 = make_float4(1.f, 0.f, 0.f, 0.f);
-    float4 e0 = zero4, e1 = zero4, gr0 = zero4, gr1 = zero4, gr2 = zero4, gr3 = zero4;
+    // (the prefetched values are kept as 128-bit vector values, not float4 structs: a struct is split into four scalars
+    // that the register allocator places apart, and the 16-byte load then goes to a temporary tuple whose copy-out waits
+    // for the load right behind its issue)
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const v4f_ zero4 = {1.f, 0.f, 0.f, 0.f};
+    v4f_ e0 = zero4, gr0 = zero4, gr1 = zero4, gr2 = zero4, gr3 = zero4;   // (e0: the first 64 entries of the row)
     // (a macro, not a lambda: captured register arrays would be spilled to scratch)
 #define ANIHIP_BWD_ISSUE(ia, hh)                                                                         \
     {                                                                                                    \
-        e0 = zero4;                                                                                      \
-        e1 = zero4;                                                                                      \
+        /* every lane loads, index clamped into the row: a load under a per-lane condition is merged with the old value  \
+           afterwards, and that move waits for the load right behind its issue (no prefetch at all) */          \
         const bool ok_ = (ia) < hi && (hh).sp >= 0 && (hh).nA + (hh).nF > 0;                             \
         const int n_ = ok_ ? (hh).nA + (hh).nF : 0;                                                      \
-        if (lane < n_) e0 = ent[(hh).start + lane];                                                      \
-        if (lane + WAVE < n_) e1 = ent[(hh).start + lane + WAVE];                                        \
+        if (n_ > 0) {                                                                                    \
+            e0 = *reinterpret_cast<const v4f_ *>(ent + (hh).start + min(lane, n_ - 1));                  \
+        }                                                                                                \
         const uint64_t need_ = ok_ ? need_of((hh).pkA, (hh).pkF) : 0ull;                                 \
-        const float4 *g4_ = reinterpret_cast<const float4 *>(grad_aev + (size_t)((ia) < hi ? (ia) : lo) * a.L); \
-        if ((need_ >> slot_bit[0]) & 1ull) gr0 = g4_[lane];                                              \
-        if ((need_ >> slot_bit[1]) & 1ull) gr1 = g4_[lane + WAVE];                                       \
-        if ((need_ >> slot_bit[2]) & 1ull) gr2 = g4_[lane + 2 * WAVE];                                   \
-        if ((need_ >> slot_bit[3]) & 1ull) gr3 = g4_[lane + 3 * WAVE];                                   \
+        const v4f_ *g4_ = reinterpret_cast<const v4f_ *>(grad_aev + (size_t)((ia) < hi ? (ia) : lo) * a.L); \
+        if ((need_ >> slot_of(lane)) & 1ull) gr0 = g4_[lane];                                              \
+        if ((need_ >> slot_of(lane + WAVE)) & 1ull) gr1 = g4_[lane + WAVE];                                       \
+        if ((need_ >> slot_of(lane + 2 * WAVE)) & 1ull) gr2 = g4_[lane + 2 * WAVE];                                   \
+        if ((need_ >> slot_of(lane + 3 * WAVE)) & 1ull) gr3 = g4_[lane + 3 * WAVE];                                   \
     }
     ANIHIP_BWD_ISSUE(i, h)
     uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
+#ifdef ANIHIP_TRACE
+    unsigned long long tr_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
+#endif
 
     for (; i < hi; i += nw) {
+        TR_STAMP(0)   // loop head
         const int nA = h.nA, nR = h.nA + h.nF;
         const bool skip = h.sp < 0 || nR == 0;
         const uint32_t start = h.start;
         const int spi = h.sp;
         float sx = 0.f, sy = 0.f, sz_ = 0.f;   // minus the gradient on the central atom, per lane
         if (!skip) {
-            float4 *st4 = reinterpret_cast<float4 *>(stage);
+            v4f_ *st4 = reinterpret_cast<v4f_ *>(stage);
             st4[lane] = gr0;
             st4[lane + WAVE] = gr1;
             st4[lane + 2 * WAVE] = gr2;
@@ -1123,16 +1142,17 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
             gy[lane] = 0.f; gy[lane + WAVE] = 0.f;
             gz[lane] = 0.f; gz[lane + WAVE] = 0.f;
             wave_sync();
+            TR_STAMP(1)   // stage own dE/dAEV row
             // ---- phase 1 (lane = neighbor) ----
             const float *grow0 = grad_aev + (size_t)(spi < 0 ? 0 : spi) * 16;
             const int sbit = spi >> 1;
             for (int c0 = 0; c0 < nR; c0 += WAVE) {
                 const int e = c0 + lane;
-                float4 d = c0 == 0 ? e0 : (c0 == WAVE ? e1 : zero4);
-                if (c0 >= 2 * WAVE && e < nR) d = ent[start + e];
+                v4f_ d = c0 == 0 ? e0 : zero4;
+                if (c0 >= WAVE && e < nR) d = *reinterpret_cast<const v4f_ *>(ent + start + e);   // (> 64 neighbors: waits here)
                 const bool ve = e < nR;
                 const uint32_t wbits = __float_as_uint(d.w);
-                const int64_t jn = ve ? (int64_t)(wbits & IDX_MASK) : lo;
+                const int jn = ve ? (int)(wbits & IDX_MASK) : lo;
                 // the neighbor's block for MY species: issued first, consumed at the end of the pass
                 const bool inrow = ve && jn >= glo && jn < ghi;   // (empty range: asymmetric list, push everything)
                 float4 G0 = make_float4(0.f, 0.f, 0.f, 0.f), G1 = G0, G2 = G0, G3 = G0;
@@ -1203,10 +1223,12 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
         }
         // prefetch the next atom
         h = hdr_decode(hw_next);
+        TR_STAMP(2)   // phase 1: neighbor terms, radial gather
         ANIHIP_BWD_ISSUE(i + nw, h)
         hw_next = hdr_load(meta, species, i + 2 * nw, i + 2 * nw < hi);
         if (skip) continue;
         wave_sync();
+        TR_STAMP(3)   // prefetch issue
 
         // ---- phase 2 (lane = (angular neighbor j, part)) ----
         const int n = nA;
@@ -1310,7 +1332,12 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
             }
             wave_sync();
         }
+        TR_STAMP(4)   // phase 2: angular pairs
         // ---- phase 3 (lane = angular neighbor): +G to the neighbor, -sum(all G) to the central atom ----
+        // Vector-memory operations retire in order and the compiler waits with vmcnt(0) for what it cannot count: the next
+        // atom's prefetched registers are "used" HERE, before this atom's atomics are issued, so that the top of the loop
+        // has nothing left to wait for (it would wait for the atomics' round trip to L2 otherwise, once per atom and wave).
+        asm volatile("" ::"v"(e0), "v"(gr0), "v"(gr1), "v"(gr2), "v"(gr3), "v"(hw_next) : "memory");
         for (int e = lane; e < nA; e += WAVE) {
             float x = 0.f, y = 0.f, z = 0.f;
             const int np_ = n <= WAVE ? parts : 1;
@@ -1340,7 +1367,12 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
             push_grad<FIXED>(grad_coords, (size_t)i, 2, -sz_);
         }
         wave_sync();
+        TR_STAMP(5)   // phase 3: atomics issued
     }
+#ifdef ANIHIP_TRACE
+    if (wib == 0 && lane == 0 && blockIdx.x < 2048)
+        for (int q_ = 0; q_ < 10; ++q_) g_fwd3_trace[blockIdx.x][q_] = tr_sum[q_];
+#endif
     if (VIRIAL) {
         vxx = wave_sum(vxx); vyy = wave_sum(vyy); vzz = wave_sum(vzz);
         vxy = wave_sum(vxy); vxz = wave_sum(vxz); vyz = wave_sum(vyz);

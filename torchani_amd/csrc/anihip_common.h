@@ -48,11 +48,20 @@ __device__ __forceinline__ int mbcnt(uint64_t m)
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// sum over the 64 lanes, the same value in every lane.  Scan inside the 16-lane DPP rows (four shifted adds on the VALU), then
+// the four row totals through scalar registers: a dozen instructions.  (Six __shfl_xor steps are six ds_bpermute round
+// trips through the LDS crossbar, ~100 clocks each and dependent: the AEV backward spends three of these sums per atom.)
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // per-wave LDS hand-off between lanes: keep the compiler from reordering LDS traffic around it
