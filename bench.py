@@ -273,13 +273,13 @@ def main():
     # dispatch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) measured on a smaller box of
     # the same density and committed under profiles/; scaled by the atom count of this launch
     aev_traffic = bwd_traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_aev.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_aev.json")
     if os.path.exists(pmc_file):
         with open(pmc_file) as fh:
             pm = json.load(fh)
         per_atom = {k: (v["fetch_size_kb"] * pm["fetch_correction"] + v["write_size_kb"]) * 1024.0 / pm["n_atoms"]
                     for k, v in pm["kernels"].items()}
-        aev_traffic, bwd_traffic = per_atom["k_aev_fwd2"] * n_shard, per_atom["k_aev_bwd"] * n_shard
+        aev_traffic, bwd_traffic = per_atom["k_aev_fwd3"] * n_shard, per_atom["k_aev_bwd"] * n_shard
     # layer 0 multiplies only the 32-column AEV slabs flagged for an atom (absent neighbor species give
     # identically-zero blocks): executed flops = dense flops with the AEV length replaced by the staged columns
     pop = mask[lo:hi].to(torch.int64) & 0xFFFFFFFF
@@ -312,7 +312,7 @@ def main():
         },
         "ms_per_step_median": median_ms,
         "roofline": {
-            "kernel": "k_aev_fwd2<8,4> (fused radial+angular AEV forward)", "bound": "hbm",
+            "kernel": "k_aev_fwd3<8,4,rec> (fused radial+angular AEV forward)", "bound": "hbm",
             "achieved": aev_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": aev_gbs / HBM_PEAK_GBS,
             "traffic": aev_traffic, "algorithmic_bytes_per_atom": bytes_per_atom,
             "mean_radial_neighbors": n_r, "mean_angular_neighbors": n_a, "avg_launch_ms": st["aev_forward"],
