@@ -136,3 +136,28 @@ def test_exchange_over_gloo_equals_single_rank(world):
     for r in range(world):
         assert "error" not in res[r], res[r]["error"]
         assert res[r]["err"] < 1e-4 and res[r]["err_own"] < 1e-4 and res[r]["dE"] < 1e-9, res[r]   # (fp32 sums of ~80 N(0, 1) pushes)
+
+
+def test_plan_triclinic_cell():
+    """A sheared cell: neighbors by brute force over the 27 images; the slab axis is the one with the deepest lattice planes."""
+    from torchani_amd.parallel import SpatialShards
+
+    cell = torch.tensor([[34.0, 0.0, 0.0], [6.0, 14.0, 0.0], [-3.0, 4.0, 13.0]])
+    n, rc, world = 900, 5.1, 4
+    f = torch.from_numpy(np.random.RandomState(4).uniform(0, 1, (n, 3)).astype(np.float32))
+    x = f @ cell
+    d = x[:, None, :].double() - x[None, :, :].double()
+    near = torch.zeros((n, n), dtype=torch.bool)
+    for a in (-1, 0, 1):
+        for b in (-1, 0, 1):
+            for c in (-1, 0, 1):
+                sh = (a * cell[0] + b * cell[1] + c * cell[2]).double()
+                near |= ((d + sh) ** 2).sum(-1) < rc * rc
+    near.fill_diagonal_(False)
+    parts = [SpatialShards(x, cell, (True, True, True), world, r, rc) for r in range(world)]
+    assert parts[0].axis == 0
+    assert sorted(torch.cat([p.owned_idx for p in parts]).tolist()) == list(range(n))
+    for p in parts:
+        need = torch.nonzero(near[p.owned_idx].any(dim=0)).reshape(-1).tolist()
+        assert set(need) <= set(p.local_idx.tolist())
+        assert p.n_local < n

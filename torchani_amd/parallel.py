@@ -150,12 +150,13 @@ class SpatialShards:
         x64 = x.to(torch.float64)
         if cell is not None and any(periodic):
             c64 = cell.detach().to(device=dev, dtype=torch.float64)
-            frac = x64 @ torch.linalg.inv(c64)                       # fractional coordinates (rows of cell = lattice vectors)
-            # spacing of the lattice planes along each axis: volume / area of the face spanned by the other two vectors
-            vol = torch.abs(torch.det(c64))
+            # fractional coordinates x = f C  ->  f_k = x . (reciprocal vector k); closed form for 3 x 3 (no solver library)
             cr = torch.stack([torch.linalg.cross(c64[1], c64[2]), torch.linalg.cross(c64[2], c64[0]),
                               torch.linalg.cross(c64[0], c64[1])])
-            depth = (vol / torch.linalg.norm(cr, dim=1)).tolist()
+            det = (c64[0] * cr[0]).sum()
+            frac = (x64 @ cr.t()) / det
+            # spacing of the lattice planes along each axis: volume / area of the face spanned by the other two vectors
+            depth = (torch.abs(det) / torch.linalg.norm(cr, dim=1)).tolist()
         else:
             frac, depth = None, [0.0, 0.0, 0.0]
         lo_c, hi_c = x64.min(dim=0).values, x64.max(dim=0).values
