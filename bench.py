@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--emulate-shard", default=None, metavar="RANK/WORLD",
                     help="development aid (N=1 only): time what rank RANK of WORLD does in a step, without "
                          "the collective -- prints ms/step and exits")
+    ap.add_argument("--partition-skin", type=float, default=1.0,
+                    help="N > 1: skin (Angstrom) of the spatial shards' halos; the partition is reused until an atom moved skin/2")
     ap.add_argument("--shuffle", action="store_true",
                     help="permute the atom order of the box (the spatial shards must not depend on it)")
     args = ap.parse_args()
@@ -170,6 +172,10 @@ def main():
     cell = torch.from_numpy(cell_np).to(dev)
     pbc = (True, True, True)
     model = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist="cell", row_capacity=128)
+    # Spatial shards are cut with a skin, as an MD driver would run them: halos 1 A wider, and the partition is kept until an
+    # atom has moved 0.5 A (the coordinates of this bench are static, so it is cut once, in warmup; the cost of cutting it
+    # is reported as collective.partition_ms)
+    model.partition_skin = args.partition_skin
 
     def step():
         # (overflow is checked once after the timed loop instead of with a host sync per step).  N > 1: spatial shards,
@@ -190,6 +196,30 @@ def main():
         lc = model.last_collective
         print(f"shard {r}/{wd}{' (shuffled input)' if args.shuffle else ''}: {(time.perf_counter() - t0) / args.steps * 1e3:.3f} "
               f"ms/step (no collective); local system {lc['n_local']} atoms = {lc['n_owned']} owned + {lc['n_halo']} halo")
+        # the stages of that rank's step on its local system
+        eng = model.aev_computer.engine()
+        sp32 = species.to(torch.int32).contiguous()
+        part = model._spatial_partition(sp32, coords, cell, pbc, r, wd)
+        sp_l = part.local(sp32).view(1, -1).contiguous()
+        x_l = part.local(coords, 3).view(1, -1, 3).contiguous()
+        lo, hi, nl = part.n_left, part.n_left + part.n_owned, part.n_local
+        packed = model.neural_networks._pack(dev)
+        st = {f"partition (cut once per skin {model.partition_skin} A of motion)": time_stage(
+            lambda: type(part)(coords, cell, pbc, wd, r, model.aev_computer.radial.cutoff, sp32, skin=model.partition_skin), 3)}
+        st["gather local system"] = time_stage(lambda: (part.local(sp32), part.local(coords, 3)), 3)
+        nbrs = eng.neighbors(sp_l, x_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
+        st["neighbors"] = time_stage(lambda: eng.neighbors(sp_l, x_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128), 3)
+        mask = torch.zeros(nl, dtype=torch.int32, device=dev)
+        aev = eng.forward(sp_l, nbrs, slab_mask=mask, shard_rows=True)
+        st["aev_forward"] = time_stage(lambda: eng.forward(sp_l, nbrs, out=aev, slab_mask=mask, shard_rows=True), 3)
+        ae = torch.zeros(nl, dtype=torch.float32, device=dev)
+        gaev = torch.zeros_like(aev)
+        st["mlp_fwd_bwd"] = time_stage(lambda: packed.forward_backward(sp_l, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev,
+                                                                       chunk=model.mlp_chunk, slab_mask=mask, shard_rows=True), 3)
+        gc = torch.zeros((nl, 3), dtype=torch.float32, device=dev)
+        st["aev_backward"] = time_stage(lambda: eng.backward(sp_l, nbrs, gaev, gc, shard_rows=True, slab_mask=mask), 3)
+        st["scatter results"] = time_stage(lambda: (part.scatter_local(gc), part.scatter_owned(ae)), 3)
+        print("  stages ms: " + "  ".join(f"{k} {v:.3f}" for k, v in st.items()))
         return
 
     for _ in range(args.warmup):
@@ -345,11 +375,17 @@ def main():
         lc = model.last_collective
         backend = torch.distributed.get_backend(group)
         res["stages_ms_per_rank"] = per_rank
+        part_ms = time_stage(lambda: type(part)(coords, cell, pbc, world, rank, model.aev_computer.radial.cutoff,
+                                                species.to(torch.int32).view(-1), skin=model.partition_skin), 3)
         res["collective"] = {
             "collectives_per_step": lc["collectives_per_step"], "world_size": lc["world_size"],
             "bytes_per_step": lc["bytes"], "op": lc.get("op", "all_reduce(sum, fp32)"), "backend": backend,
             "local_atoms": lc.get("n_local"), "owned_atoms": lc.get("n_owned"), "halo_atoms": lc.get("n_halo"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+            # cutting the partition (sort + halo plan) is NOT part of every step: it is reused until an atom has moved
+            # skin / 2 (models.ANI.partition_skin); the timed steps run on halos that are skin wider for it
+            "partition_ms": part_ms, "partition_skin_A": model.partition_skin,
+            "partition_reuse": "until an atom has moved skin/2; static coordinates here, so cut once in warmup",
         }
     if rank == 0 and world == 1 and not args.no_secondary:
         # BASELINE configs 2 / 3 on the parity fixtures' inputs (outside the timed headline region)

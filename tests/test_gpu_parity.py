@@ -479,6 +479,48 @@ def test_shards_add_up_to_the_whole(dev, name, world, monkeypatch):
     assert np.abs(e.cpu().numpy() - g["energies"]).max() < E_ATOM_TOL * max(1.0, np.sqrt(n_real))
 
 
+def test_partition_skin_reuses_the_shards_while_atoms_move(dev):
+    """MD use of the spatial shards: with partition_skin the partition is cut once and kept while no atom has moved more
+    than skin / 2; the shards' partial results must still add up to the whole-system result at the moved coordinates, and
+    a larger move must cut a new partition."""
+    box, n = 36.0, 4000
+    rs = np.random.RandomState(11)
+    x0 = torch.from_numpy(rs.uniform(0, box, (1, n, 3)).astype(np.float32)).to(dev)
+    sp = torch.from_numpy(rs.choice([0, 1, 2, 3], size=(1, n), p=[0.5, 0.3, 0.1, 0.1])).to(dev)
+    # (a random gas has close contacts; the comparison is shard-sum against whole, both through the same kernels)
+    cell = torch.eye(3, device=dev) * box
+    pbc = (True, True, True)
+    model = get_model("ani1x", 0, dev, neighborlist="cell", row_capacity=320)   # (its own instance: the skin is set on it)
+    model.partition_skin = 1.0
+    world = 3
+    parts = []
+    for step, scale in enumerate((0.0, 0.3, 0.45, 2.0)):
+        d = torch.from_numpy(rs.normal(size=(1, n, 3)).astype(np.float32)).to(dev)
+        x = x0 + scale * d / d.norm(dim=-1, keepdim=True)
+        whole = model.energies_and_forces(sp, x, cell, pbc)
+        e = torch.zeros(1, dtype=torch.float64, device=dev)
+        f = torch.zeros_like(x)
+        for rank in range(world):
+            out = model.energies_and_forces(sp, x, cell, pbc, shard=(rank, world), check_overflow=True)
+            e += out.energies
+            f += out.forces
+            if rank == world - 1:
+                parts.append(model.__dict__["_spatial_cache"][1])
+        assert float((f - whole.forces).abs().max()) < 2e-4 * max(1.0, float(whole.forces.abs().max()))
+        assert abs(float(e - whole.energies)) < 1e-6 * n
+    # (the cache holds one rank's partition at a time, so within a step every rank cuts its own; across steps the last
+    # rank's partition is the one the next step's first lookup sees -- rank differs, so it is cut again: check the
+    # single-rank behaviour directly)
+    model.__dict__.pop("_spatial_cache", None)
+    a = model._spatial_partition(sp.view(-1).int(), x0.view(-1, 3), cell, pbc, 1, world)
+    x1 = x0 + 0.3
+    x1[..., 1:] -= 0.3
+    b = model._spatial_partition(sp.view(-1).int(), x1.view(-1, 3), cell, pbc, 1, world)
+    x2 = x0 + 0.6
+    c = model._spatial_partition(sp.view(-1).int(), x2.view(-1, 3), cell, pbc, 1, world)
+    assert b is a and c is not a
+
+
 @pytest.mark.parametrize("name", ["ch4_ani1x", "rand_batch_ani2x", "water_pbc_ani2x"])
 def test_autograd_path_equals_fused(dev, name):
     """model((species, coords)) + torch.autograd == fused engine path (same kernels underneath)."""

@@ -161,3 +161,53 @@ def test_plan_triclinic_cell():
         need = torch.nonzero(near[p.owned_idx].any(dim=0)).reshape(-1).tolist()
         assert set(need) <= set(p.local_idx.tolist())
         assert p.n_local < n
+
+
+def test_padding_atoms_are_in_nobodys_halo():
+    from torchani_amd.parallel import SpatialShards
+
+    """Padding atoms (species -1) sort last; a periodic wrap of the first rank's left halo must reach the last REAL atoms."""
+    torch.manual_seed(3)
+    n, box, rc = 600, 30.0, 5.1
+    x = torch.rand(n, 3) * box
+    sp = torch.randint(0, 4, (n,))
+    sp[torch.randperm(n)[:50]] = -1
+    cell = torch.eye(3) * box
+    for world in (2, 3):
+        parts = [SpatialShards(x, cell, (True, True, True), world, r, rc, species=sp) for r in range(world)]
+        for part in parts:
+            assert part.n_real == n - 50
+            halo = torch.cat([part.local_idx[:part.n_left], part.local_idx[part.n_left + part.n_owned:]])
+            assert bool((sp[halo] >= 0).all())
+            # every real neighbor of an owned real atom is in the local system
+            own = part.owned_idx[sp[part.owned_idx] >= 0]
+            d = x[own][:, None, :] - x[None, :, :]
+            d = d - box * torch.round(d / box)
+            near = ((d * d).sum(-1) < rc * rc) & (sp[None, :] >= 0)
+            have = torch.zeros(n, dtype=torch.bool)
+            have[part.local_idx] = True
+            assert bool(have[near.any(dim=0)].all())
+        assert sorted(torch.cat([p.owned_idx for p in parts]).tolist()) == list(range(n))
+
+
+def test_skin_keeps_the_partition_valid_while_atoms_move():
+    from torchani_amd.parallel import SpatialShards
+
+    torch.manual_seed(4)
+    n, box, rc, skin = 800, 32.0, 5.1, 1.0
+    x = torch.rand(n, 3) * box
+    cell = torch.eye(3) * box
+    part = SpatialShards(x, cell, (True, True, True), 3, 1, rc, skin=skin)
+    assert not SpatialShards(x, cell, (True, True, True), 3, 1, rc).still_valid(x)
+    step = torch.nn.functional.normalize(torch.randn(n, 3), dim=1) * (0.49 * skin)
+    moved = x + step
+    assert part.still_valid(moved)
+    assert not part.still_valid(x + 1.1 * step)
+    # with every atom moved by just under skin / 2, every neighbor of an owned atom is still in the local system
+    own = part.owned_idx
+    d = moved[own][:, None, :] - moved[None, :, :]
+    d = d - box * torch.round(d / box)
+    near = (d * d).sum(-1) < rc * rc
+    have = torch.zeros(n, dtype=torch.bool)
+    have[part.local_idx] = True
+    assert bool(have[near.any(dim=0)].all())

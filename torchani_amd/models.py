@@ -374,6 +374,7 @@ class ANI(torch.nn.Module):
 
     # ---- one big system on several ranks: spatial shards + halo (parallel.SpatialShards) ---------------------------
     partition = "spatial"   # "index": contiguous index ranges + one all-reduce of the whole force array (round-2 scheme)
+    partition_skin = 0.0    # > 0 (Angstrom): halos that much wider, the partition is kept until an atom has moved skin / 2
 
     def _spatial_ok(self, C: int, n: int) -> bool:
         """Slab decomposition applies to ONE system evaluated through its own pair search, with every pair potential
@@ -392,10 +393,18 @@ class ANI(torch.nn.Module):
         key = (c32.data_ptr(), c32._version, tuple(c32.shape), None if cell is None else (cell.data_ptr(), cell._version),
                pbc_t, rank, world)
         hit = self.__dict__.get("_spatial_cache")
+        if hit is not None and hit[0] != key and self.partition_skin > 0.0 and hit[0][2] == key[2] and \
+                hit[0][4:] == key[4:] and (cell is None) == (hit[5] is None) and \
+                (cell is None or torch.equal(hit[5], cell)) and hit[1].still_valid(c32):
+            # moved coordinates, same box, nobody further than skin / 2 from where the partition was cut: keep it (every
+            # rank sees the same coordinates, so every rank takes the same decision)
+            hit = (key, hit[1], c32, cell, species32, hit[5])
+            self.__dict__["_spatial_cache"] = hit
         if hit is None or hit[0] != key:
             # (the entry keeps the tensors alive, so an equal key means the same coordinates, not a recycled address)
-            hit = (key, SpatialShards(c32, cell, pbc_t, world, rank, self.aev_computer.radial.cutoff, species32),
-                   c32, cell, species32)
+            hit = (key, SpatialShards(c32, cell, pbc_t, world, rank, self.aev_computer.radial.cutoff, species32,
+                                      skin=self.partition_skin),
+                   c32, cell, species32, None if cell is None else cell.clone())
             self.__dict__["_spatial_cache"] = hit
         return hit[1]
 

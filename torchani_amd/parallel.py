@@ -17,6 +17,7 @@ The reference has no multi-device code at all; the decompos
 """
 from __future__ import annotations
 
+import math
 import os
 import typing as tp
 
@@ -141,36 +142,36 @@ class SpatialShards:
     2 * world boundary searches (one small device-to-host copy when the partition is built)."""
 
     def __init__(self, coords: torch.Tensor, cell: tp.Optional[torch.Tensor], pbc: tp.Optional[tp.Sequence[bool]],
-                 world: int, rank: int, cutoff: float, species: tp.Optional[torch.Tensor] = None) -> None:
-        x = coords.detach().reshape(-1, 3)
+                 world: int, rank: int, cutoff: float, species: tp.Optional[torch.Tensor] = None, skin: float = 0.0) -> None:
+        """skin > 0: the halos are cut ``cutoff + skin`` wide, so the partition stays valid while no atom has moved more than
+        skin / 2 since it was built (``still_valid``; an MD driver rebuilds it every few dozen steps instead of every step)."""
+        x = coords.detach().reshape(-1, 3).to(torch.float32)
         n = x.shape[0]
         dev = x.device
-        self.n, self.world, self.rank, self.cutoff = n, world, rank, float(cutoff)
+        self.n, self.world, self.rank, self.cutoff, self.skin = n, world, rank, float(cutoff), float(skin)
+        reach = self.cutoff + self.skin
         periodic = [bool(b) for b in pbc] if (pbc is not None and cell is not None) else [False, False, False]
-        x64 = x.to(torch.float64)
+        # ---- geometry of the box on the host (9 + 6 numbers: the first of the two host syncs of a partition) ----
+        mm = torch.aminmax(x, dim=0)
+        head = torch.cat([(cell.detach().to(device=dev, dtype=torch.float32).reshape(-1) if cell is not None
+                           else torch.zeros(9, device=dev)), mm.min, mm.max]).cpu().to(torch.float64)
+        lo_c, hi_c = head[9:12], head[12:15]
+        ext = (hi_c - lo_c).tolist()
+        depth = [0.0, 0.0, 0.0]
+        rec = torch.zeros((3, 3), dtype=torch.float64)
         if cell is not None and any(periodic):
-            c64 = cell.detach().to(device=dev, dtype=torch.float64)
+            c64 = head[:9].reshape(3, 3)
             # fractional coordinates x = f C  ->  f_k = x . (reciprocal vector k); closed form for 3 x 3 (no solver library)
             cr = torch.stack([torch.linalg.cross(c64[1], c64[2]), torch.linalg.cross(c64[2], c64[0]),
                               torch.linalg.cross(c64[0], c64[1])])
-            det = (c64[0] * cr[0]).sum()
-            frac = (x64 @ cr.t()) / det
+            det = float((c64[0] * cr[0]).sum())
+            rec = cr / det
             # spacing of the lattice planes along each axis: volume / area of the face spanned by the other two vectors
-            depth = (torch.abs(det) / torch.linalg.norm(cr, dim=1)).tolist()
-        else:
-            frac, depth = None, [0.0, 0.0, 0.0]
-        lo_c, hi_c = x64.min(dim=0).values, x64.max(dim=0).values
-        ext = (hi_c - lo_c).tolist()
+            depth = (abs(det) / torch.linalg.norm(cr, dim=1)).tolist()
         # the slab axis: the deepest periodic axis of the cell, else the longest edge of the bounding box
         length = [depth[k] if periodic[k] else ext[k] for k in range(3)]
         axis = max(range(3), key=lambda k: length[k])
         self.axis, self.periodic = axis, periodic[axis]
-        def unit(k: int) -> torch.Tensor:                            # position along axis k scaled to [0, 1)
-            if periodic[k]:
-                return frac[:, k] - torch.floor(frac[:, k])
-            return ((x64[:, k] - lo_c[k]) / max(ext[k], 1e-9)).clamp(max=1.0 - 1e-12)
-
-        span = depth[axis] if self.periodic else max(ext[axis], 1e-9)
         # Sort key: layers of a quarter cutoff along the slab axis, and inside a layer cells of about one cutoff along the other
         # two axes -- the cell-sorted order SURVEY 8(e) asks for.  Atoms that are close in space end up close in memory
         # (neighbor gathers and force pushes hit nearby rows), while the order stays monotone in the layer index, so a
@@ -178,57 +179,79 @@ class SpatialShards:
         nb = [1, 1, 1]
         for k in range(3):
             width = 0.25 * self.cutoff if k == axis else self.cutoff
-            nb[k] = int(max(1, min(1 << 20, length[k] // max(width, 1e-6))))
+            nb[k] = int(max(1, min(1 << 10 if k != axis else 1 << 20, length[k] // max(width, 1e-6))))
+        # unit coordinates of all three axes in ONE matrix product: u = x A + t, periodic axes wrapped into [0, 1)
+        A = torch.zeros((3, 3), dtype=torch.float64)
+        t = torch.zeros(3, dtype=torch.float64)
+        for k in range(3):
+            if periodic[k]:
+                A[:, k] = rec[k]
+            else:
+                A[k, k] = 1.0 / max(ext[k], 1e-9)
+                t[k] = -float(lo_c[k]) / max(ext[k], 1e-9)
+        u = x @ A.to(device=dev, dtype=torch.float32) + t.to(device=dev, dtype=torch.float32)
+        per = torch.tensor(periodic, device=dev)
+        u = torch.where(per, u - torch.floor(u), u).clamp_(0.0, 1.0 - 1e-6)
+        nbt = torch.tensor(nb, device=dev, dtype=torch.float32)
+        kk = (u * nbt).to(torch.int32)
+        kk = torch.minimum(kk, torch.tensor(nb, device=dev, dtype=torch.int32) - 1)
         o1, o2 = [k for k in range(3) if k != axis]
-        kx = torch.floor(unit(axis) * nb[axis]).to(torch.int64).clamp(max=nb[axis] - 1)
-        k1 = torch.floor(unit(o1) * nb[o1]).to(torch.int64).clamp(max=nb[o1] - 1)
-        k2 = torch.floor(unit(o2) * nb[o2]).to(torch.int64).clamp(max=nb[o2] - 1)
-        key = (kx * nb[o1] + k1) * nb[o2] + k2
+        kx = kk[:, axis]
+        key = (kx * nb[o1] + kk[:, o1]) * nb[o2] + kk[:, o2]          # (< 2^20 * 2^10 * 2^10 / ... fits int32 for real boxes)
         if species is not None:                                      # padding atoms last: nobody's neighbors
             pad = species.reshape(-1) < 0
-            key = torch.where(pad, torch.full_like(key, nb[0] * nb[1] * nb[2]), key)
-            kx = torch.where(pad, torch.full_like(kx, 2 * nb[axis]), kx)
-        _, order = torch.sort(key, stable=True)
-        fs = kx[order].to(torch.float64) / nb[axis]                  # lower edge of every sorted atom's layer
+            key = torch.where(pad, torch.full_like(key, 0x7FFFFFFF), key)
+            kx = torch.where(pad, torch.full_like(kx, 2 * nb[axis] + 2), kx)
+        key, order = torch.sort(key, stable=True)
+        kxs = kx[order]                                              # layer of every sorted position (non-decreasing)
         self.order = order                                           # sorted position -> input atom
         self.bounds = shard_bounds(n, world)
-        delta = min(self.cutoff / span, 1.0)
+        # ---- halos, in whole layers: everything within ceil(reach / layer width) + 1 layers of the first / last owned layer ----
+        nl_ = nb[axis]
+        # (a neighbor of an atom in layer k lies in layer >= k - ceil(reach / width): whole layers, plus a hair for the fp32 binning)
+        dl = int(min(nl_, math.ceil(reach * nl_ / max(length[axis], 1e-9) + 1e-3)))
         b = torch.tensor(self.bounds, device=dev)
-        eps = 0.25 / nb[axis]
-        q_lo = fs[b[:-1].clamp(max=n - 1)] - delta - eps             # below the layer of the first owned atom
-        q_hi = fs[(b[1:] - 1).clamp(min=0)] + 1.0 / nb[axis] + delta + eps   # above the layer of the last one
-        if self.periodic:
-            q = torch.cat([q_lo, q_lo + 1.0, q_hi, q_hi - 1.0])
-        else:
-            q = torch.cat([q_lo, q_lo, q_hi, q_hi])
-        left = torch.searchsorted(fs, q[:2 * world], right=False)
-        right = torch.searchsorted(fs, q[2 * world:], right=True)
-        host = torch.cat([left, right]).cpu().tolist()               # (the one host sync of a partition)
+        lo_i, hi_i = b[:-1], b[1:]
+        n_real = torch.searchsorted(kxs, torch.tensor([nl_], device=dev, dtype=torch.int32), right=False)   # padding starts here
+        k_lo = kxs[lo_i.clamp(max=n - 1)].to(torch.int64)
+        k_hi = kxs[(hi_i - 1).clamp(min=0)].to(torch.int64)
+        q = torch.cat([k_lo - dl, k_lo - dl + nl_, k_hi + dl, k_hi + dl - nl_]).clamp(min=-1, max=2 * nl_ + 1).to(torch.int32)
+        left = torch.searchsorted(kxs, q[:2 * world].contiguous(), right=False)
+        right = torch.searchsorted(kxs, q[2 * world:].contiguous(), right=True)
+        host = torch.cat([left, right, k_lo, k_hi, n_real]).cpu().tolist()   # (the second host sync of a partition)
+        self.n_real = nr_ = int(host[-1])
         self.halo = []                                               # per rank: (n_left, n_right)
         for r in range(world):
             lo, hi = self.bounds[r], self.bounds[r + 1]
-            own = hi - lo
+            lo_r, hi_r = min(lo, nr_), min(hi, nr_)                  # the rank's real (non-padding) positions
+            own = hi_r - lo_r
             if own == 0:
                 self.halo.append((0, 0))
                 continue
-            nl = lo - min(host[r], lo)
-            nr = max(host[2 * world + r], hi) - hi
+            kl, kh = host[4 * world + r], host[5 * world + r]
+            nl = lo_r - min(host[r], lo_r)
+            nr = min(max(host[2 * world + r], hi_r), nr_) - hi_r
             if self.periodic:
-                if float(q_lo[r]) < 0.0:                             # wraps below 0: everything from the wrapped bound up
-                    nl = lo + (n - host[world + r])
-                if float(q_hi[r]) >= 1.0:
-                    nr = (n - hi) + host[3 * world + r]
-            nl = min(nl, n - own)
-            nr = min(nr, n - own - nl)
+                if kl - dl < 0:                                      # wraps below layer 0: everything from the wrapped layer up
+                    nl = lo_r + (nr_ - min(host[world + r], nr_))
+                if kh + dl >= nl_:
+                    nr = (nr_ - hi_r) + min(host[3 * world + r], nr_)
+            nl = min(nl, nr_ - own)
+            nr = min(nr, nr_ - own - nl)
             self.halo.append((nl, nr))
         self.n_left, self.n_right = self.halo[rank]
         self.lo, self.hi = self.bounds[rank], self.bounds[rank + 1]
         self.n_owned = self.hi - self.lo
         self.n_local = self.n_left + self.n_owned + self.n_right
-        pos = (torch.arange(self.n_local, device=dev) + (self.lo - self.n_left)) % max(n, 1)
+        m = max(nr_, 1)
+        ar = torch.arange(max(self.n_left, self.n_right, 1), device=dev)
+        pos = torch.cat([(ar[:self.n_left] + (min(self.lo, nr_) - self.n_left)) % m,
+                         torch.arange(self.lo, self.hi, device=dev),
+                         (ar[:self.n_right] + min(self.hi, nr_)) % m])
         self.local_pos = pos                                         # local row -> sorted position
         self.local_idx = order[pos]                                  # local row -> input atom
         self.owned_idx = self.local_idx[self.n_left:self.n_left + self.n_owned]
+        self.x_build = x.clone() if self.skin > 0.0 else None
         # ---- who holds halo rows of whom: runs (holder, first halo row of the holder, owner, first owned row, count) ----
         self.halo_rows_max = max((a + c for a, c in self.halo), default=0)
         self.messages = self._plan()
@@ -240,20 +263,28 @@ class SpatialShards:
         self.recv_src = torch.cat(src) if src else torch.zeros(0, dtype=torch.long, device=dev)
         self.recv_dst = torch.cat(dst) if dst else torch.zeros(0, dtype=torch.long, device=dev)
 
+    def still_valid(self, coords: torch.Tensor) -> bool:
+        """Has every atom stayed within skin / 2 of where it was when the partition was built?  (One reduction + one host
+        sync; always False for partitions built without a skin.)"""
+        if self.x_build is None:
+            return False
+        d = coords.detach().reshape(-1, 3).to(torch.float32) - self.x_build
+        return bool(((d * d).sum(dim=1).max() < (0.5 * self.skin) ** 2).item())
+
     def _plan(self) -> tp.List[tp.Tuple[int, int, int, int, int]]:
         """Halo rows of every rank cut into runs by the rank that owns them.  Halo row h of a holder (0 .. n_left + n_right,
         left halo first) is sorted position (lo - n_left + h) for the left part and (hi + h - n_left) for the right part,
-        modulo n."""
-        n, out = self.n, []
+        modulo the number of real atoms (padding atoms are sorted last and are in nobody's halo)."""
+        m, out = max(self.n_real, 1), []
         for holder in range(self.world):
             nl, nr = self.halo[holder]
-            lo, hi = self.bounds[holder], self.bounds[holder + 1]
+            lo, hi = min(self.bounds[holder], self.n_real), min(self.bounds[holder + 1], self.n_real)
             for first_pos, first_row, count in ((lo - nl, 0, nl), (hi, nl, nr)):
                 done = 0
                 while done < count:
-                    p = (first_pos + done) % n
+                    p = (first_pos + done) % m
                     owner = max(0, min(self.world - 1, _bisect(self.bounds, p)))
-                    run = min(count - done, self.bounds[owner + 1] - p)
+                    run = min(count - done, min(self.bounds[owner + 1], self.n_real) - p)
                     out.append((holder, first_row + done, owner, p - self.bounds[owner], run))
                     done += run
         return out
