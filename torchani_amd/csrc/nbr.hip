@@ -568,79 +568,93 @@ __global__ __launch_bounds__(NBR_WPB * WAVE) void k_nbr_cell(
     }
 }
 
-// (helpers of the cell-centric kernel below)
-__device__ __forceinline__ uint32_t wave_or(uint32_t v);
-// rows of one central atom from its hits in the staged candidate list (see k_nbr_cell2)
-__device__ __forceinline__ void emit_from_stage(const float4 *cand, const uint16_t *hidx, int nh, bool overflow, float4 pa,
-                                                int64_t i, int64_t lo, int row_cap, float rca2, uint32_t cls_mask,
-                                                uint32_t *meta, float4 *ent, uint32_t *status)
+// rows of the (up to) two central atoms of a sweep from their hits in the staged candidate list (see k_nbr_cell2); the two
+// atoms go through every step together, so that the dependent chain hit index -> candidate -> class -> ballot -> rank of
+// one atom fills the gaps of the other's
+template <int NAT, int NCH>
+__device__ __forceinline__ void emit_from_stage(const float4 *cand, const uint16_t *hidx, const int (&nh_)[NAT],
+                                                const bool (&act)[NAT], const float4 (&pa)[NAT], const int64_t (&ia)[NAT],
+                                                int64_t lo, int row_cap, float rca2, uint32_t cls_mask, uint32_t *meta,
+                                                float4 *ent, uint32_t *status)
 {
     const int lane = lane_id();
-    // ---- classify {r <= Rca, r > Rca} x species over the species that occur in the stencil; packed byte
-    // counters in scalar registers.  Keys of the (at most MAXR / 64 = 4) chunks of hits stay in registers ----
-    uint32_t *meta_i = meta + (size_t)i * META_W;
-    const size_t row0 = (size_t)(i - lo) * row_cap;
-    float4 *row = ent + row0;
-    int key[MAXR / WAVE];
-    float4 dv[MAXR / WAVE];
+    constexpr int CAP = NCH * WAVE;   // hits this instantiation handles per atom (<= MAXR)
+    // ---- classify {r <= Rca, r > Rca} x species over the species that occur in the stencil.  Keys of the NCH chunks
+    // of hits stay in registers ----
+    int nh[NAT];
+    bool over[NAT];
+    int key[NAT][NCH];
+    float4 dv[NAT][NCH];
 #pragma unroll
-    for (int ch = 0; ch < MAXR / WAVE; ++ch) {
-        key[ch] = 16;
-        dv[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ch * WAVE < nh) {   // (wave-uniform)
-            const int e = ch * WAVE + lane;
-            const bool v = e < nh;
-            const float4 q = cand[v ? hidx[e] : 0];
-            const float dx = q.x - pa.x, dy = q.y - pa.y, dz = q.z - pa.z;
-            dv[ch] = make_float4(dx, dy, dz, q.w);
-            key[ch] = v ? (((dx * dx + dy * dy + dz * dz <= rca2) ? 0 : 8) + (int)(__float_as_uint(q.w) >> 28)) : 16;
-        }
-    }
-    uint64_t pk[2] = {0ull, 0ull};
-    bool big = false;   // a class with more than 255 entries
-    for (uint32_t pm = cls_mask; pm; pm &= pm - 1) {
-        const int k = __builtin_ctz(pm);
-        int pop = 0;
+    for (int t = 0; t < NAT; ++t) {
+        over[t] = nh_[t] > CAP;
+        nh[t] = act[t] ? (over[t] ? CAP : nh_[t]) : 0;
 #pragma unroll
-        for (int ch = 0; ch < MAXR / WAVE; ++ch)
-            if (ch * WAVE < nh) pop += __popcll(__ballot(key[ch] == k));
-        big = big || pop > 255;
-        pk[k >> 3] += (uint64_t)(pop & 255) << (8 * (k & 7));
-    }
-    const int nA = (int)((pk[0] * 0x0101010101010101ull) >> 56), nF = (int)((pk[1] * 0x0101010101010101ull) >> 56);
-    if (lane == 0) meta_i[0] = (uint32_t)row0;
-    if (overflow || big || nA + nF > row_cap || nA > MAXA) {
-        if (lane == 0) {
-            atomicOr(&status[0], ANIHIP_ST_ROW_OVERFLOW);
-            meta_i[1] = 0; meta_i[2] = 0; meta_i[3] = 0; meta_i[4] = 0; meta_i[5] = 0;
-        }
-        return;
-    }
-    // first position of every class: byte prefix sums inside a group, the far group behind the angular one
-    const uint64_t base[2] = {pk[0] * 0x0101010101010100ull, pk[1] * 0x0101010101010100ull};
-    int pos[MAXR / WAVE];
-#pragma unroll
-    for (int ch = 0; ch < MAXR / WAVE; ++ch) pos[ch] = -1;
-    for (uint32_t pm = cls_mask; pm; pm &= pm - 1) {
-        const int k = __builtin_ctz(pm);
-        int first = ((k >> 3) ? nA : 0) + (int)((base[k >> 3] >> (8 * (k & 7))) & 255u);
-#pragma unroll
-        for (int ch = 0; ch < MAXR / WAVE; ++ch)
-            if (ch * WAVE < nh) {
-                const uint64_t m = __ballot(key[ch] == k);
-                if (key[ch] == k) pos[ch] = first + mbcnt(m);
-                first += __popcll(m);
+        for (int ch = 0; ch < NCH; ++ch) {
+            key[t][ch] = 16;
+            dv[t][ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ch * WAVE < nh[t]) {   // (wave-uniform)
+                const int e = ch * WAVE + lane;
+                const bool v = e < nh[t];
+                const float4 q = cand[v ? hidx[t * MAXR + e] : 0];
+                const float dx = q.x - pa[t].x, dy = q.y - pa[t].y, dz = q.z - pa[t].z;
+                dv[t][ch] = make_float4(dx, dy, dz, q.w);
+                key[t][ch] = v ? (((dx * dx + dy * dy + dz * dz <= rca2) ? 0 : 8) + (int)(__float_as_uint(q.w) >> 28)) : 16;
             }
+        }
+    }
+    // ---- ONE pass over the classes in row order (angular group by species, then the far group by species): the position
+    // of a hit is the number of hits of earlier classes + its rank inside its class; the class sizes go to packed byte
+    // counters in scalar registers ----
+    uint64_t pk[NAT][2];
+    int run[NAT], pos[NAT][NCH];
+    bool big[NAT];   // a class with more than 255 entries
+#pragma unroll
+    for (int t = 0; t < NAT; ++t) {
+        pk[t][0] = 0ull; pk[t][1] = 0ull;
+        run[t] = 0;
+        big[t] = false;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) pos[t][ch] = -1;
+    }
+    for (uint32_t pm = cls_mask; pm; pm &= pm - 1) {
+        const int k = __builtin_ctz(pm);
+#pragma unroll
+        for (int t = 0; t < NAT; ++t) {
+            int pop = 0;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                if (ch * WAVE < nh[t]) {
+                    const uint64_t m = __ballot(key[t][ch] == k);
+                    if (key[t][ch] == k) pos[t][ch] = run[t] + pop + mbcnt(m);
+                    pop += __popcll(m);
+                }
+            run[t] += pop;
+            big[t] = big[t] || pop > 255;
+            pk[t][k >> 3] += (uint64_t)(pop & 255) << (8 * (k & 7));
+        }
     }
 #pragma unroll
-    for (int ch = 0; ch < MAXR / WAVE; ++ch)
-        if (pos[ch] >= 0) row[pos[ch]] = dv[ch];
-    if (lane == 0) {
-        meta_i[1] = (uint32_t)nA | ((uint32_t)nF << 16);
-        meta_i[2] = (uint32_t)pk[0]; meta_i[3] = (uint32_t)(pk[0] >> 32);
-        meta_i[4] = (uint32_t)pk[1]; meta_i[5] = (uint32_t)(pk[1] >> 32);
+    for (int t = 0; t < NAT; ++t) {
+        if (!act[t]) continue;
+        uint32_t *meta_i = meta + (size_t)ia[t] * META_W;
+        const size_t row0 = (size_t)(ia[t] - lo) * row_cap;
+        float4 *row = ent + row0;
+        const int nA = (int)((pk[t][0] * 0x0101010101010101ull) >> 56), nF = (int)((pk[t][1] * 0x0101010101010101ull) >> 56);
+        const bool bad = over[t] || big[t] || nA + nF > row_cap || nA > MAXA;
+        if (bad && lane == 0) atomicOr(&status[0], ANIHIP_ST_ROW_OVERFLOW);
+        if (!bad) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                if (pos[t][ch] >= 0) row[pos[t][ch]] = dv[t][ch];
+        }
+        if (lane == 0) {   // (24-byte rows: three 8-byte stores)
+            uint2 *m2 = reinterpret_cast<uint2 *>(meta_i);
+            m2[0] = make_uint2((uint32_t)row0, bad ? 0u : ((uint32_t)nA | ((uint32_t)nF << 16)));
+            m2[1] = bad ? make_uint2(0u, 0u) : make_uint2((uint32_t)pk[t][0], (uint32_t)(pk[t][0] >> 32));
+            m2[2] = bad ? make_uint2(0u, 0u) : make_uint2((uint32_t)pk[t][1], (uint32_t)(pk[t][1] >> 32));
+        }
     }
-
 }
 
 // ---- cell mode, cell-centric: one wave per BIN ---------------------------------------------------------------------
@@ -652,7 +666,20 @@ __device__ __forceinline__ void emit_from_stage(const float4 *cand, const uint16
 // Bins with more candidates than the stage holds, or stencils of more than 64 bins (cells thinner than the cutoff),
 // are left to k_nbr_cell (handled[c] = 0, counted in n_unhandled).
 constexpr int NBR2_WPB = 4;
-constexpr int CAND_CAP = 480;   // (with the other tables: 10 KB of LDS per wave, 16 waves per CU)
+constexpr int CAND_CAP = 448;   // (7 KB + 1 KB of hit positions, which the staging tables share: 8 KB of LDS per wave,
+                                // 20 waves per CU)
+#ifdef ANIHIP_TRACE
+// development: per-phase shader-clock sums of wave 0 of every block (s_memtime stamps), read by anihip_dev_nbr_trace_read
+__device__ unsigned long long g_nbr_trace[1024][10];
+#define NTR_STAMP(k_)                                                      \
+    {                                                                      \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+        if (wib == 0) tr_sum[k_] += now_ - tr_last;                        \
+        tr_last = now_;                                                    \
+    }
+#else
+#define NTR_STAMP(k_)
+#endif
 
 __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 {
@@ -661,21 +688,19 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(NBR2_WPB * WAVE) void k_nbr_cell2(
+__global__ __launch_bounds__(NBR2_WPB * WAVE, 5) void k_nbr_cell2(
     const GridDesc *g, int S, float rcr2, float rca2, int64_t lo, int64_t hi, const int *cellid,
     const int *cell_start, const float4 *pos4s, int row_cap, uint32_t *meta, float4 *ent, uint32_t *status,
     int *handled, int *n_unhandled)
 {
     __shared__ float4 s_cand[NBR2_WPB][CAND_CAP];
-    __shared__ uint16_t s_hidx[NBR2_WPB][2 * MAXR];
-    __shared__ int s_pend[NBR2_WPB][WAVE];
-    __shared__ int s_k0[NBR2_WPB][WAVE];
-    __shared__ float4 s_shift[NBR2_WPB][WAVE];
+    __shared__ uint16_t s_hidx[NBR2_WPB][2 * MAXR];   // hit positions of the two central atoms of a sweep; while a bin is
+                                                      // being staged: the prefix sums and first atoms of its stencil bins
+    static_assert(2 * MAXR * sizeof(uint16_t) >= 2 * WAVE * sizeof(int), "staging tables share the hit list's LDS");
     const int wib = threadIdx.x >> 6, lane = lane_id();
     float4 *cand = s_cand[wib];
     uint16_t *hidx = s_hidx[wib];
-    int *pend = s_pend[wib], *k0t = s_k0[wib];
-    float4 *shift = s_shift[wib];
+    int *pend = reinterpret_cast<int *>(s_hidx[wib]), *k0t = pend + WAVE;
     // padding atoms are in no bin: empty rows
     for (int64_t i = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x)
         if (cellid[i] < 0) {
@@ -693,9 +718,16 @@ __global__ __launch_bounds__(NBR2_WPB * WAVE) void k_nbr_cell2(
     const float inv_n2 = 1.0f / (float)n2, inv_n1 = 1.0f / (float)n1;
     const int nbins = nb0 * nb1 * nb2;
     const int nw = gridDim.x * NBR2_WPB;
+#ifdef ANIHIP_TRACE
+    unsigned long long tr_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int c = blockIdx.x * NBR2_WPB + wib; c < nbins; c += nw) {
+        NTR_STAMP(0)   // loop tail
         const int ab = cell_start[c], ae = cell_start[c + 1];
         if (ae == ab) continue;
+#ifdef ANIHIP_TRACE
+        if (wib == 0) tr_sum[8] += 1;
+#endif
         // does this rank own any atom of the bin?
         bool mine = false;
         for (int a0 = ab; a0 < ae; a0 += WAVE) {
@@ -729,9 +761,6 @@ __global__ __launch_bounds__(NBR2_WPB * WAVE) void k_nbr_cell2(
             total = __builtin_amdgcn_readlane(incl, WAVE - 1);
             pend[lane] = incl;
             k0t[lane] = kbeg - (incl - cnt);
-            // (same evaluation order as k_nbr_cell: (o0 s0 + o1 s3) first, o2 s6 added to the sum)
-            shift[lane] = make_float4(o0 * st[0] + o1 * st[3] + o2 * st[6], o0 * st[1] + o1 * st[4] + o2 * st[7],
-                                      o0 * st[2] + o1 * st[5] + o2 * st[8], 0.f);
             // flat position of the central bin's own atoms (the (0,0,0) entry of the stencil)
             const bool central = ok && o0 == 0 && o1 == 0 && o2 == 0;
             const uint64_t cm = __ballot(central);
@@ -744,56 +773,113 @@ __global__ __launch_bounds__(NBR2_WPB * WAVE) void k_nbr_cell2(
         }
         if (!fits) continue;
         wave_sync();
+        NTR_STAMP(1)   // ownership test, stencil, prefix sum
         // ---- stage the candidates: position + image shift, w = packed (index | species) ----
-        for (int x0 = 0; x0 < total; x0 += WAVE) {
-            const int x = x0 + lane;
-            if (x < total) {
-                int seg = 0;
+        {
+            // all global reads of the stage first (one per 64 candidates, CAND_CAP / 64 at most), then the LDS writes: the
+            // reads of a bin are in flight together instead of one round trip per 64 candidates
+            constexpr int NST = CAND_CAP / WAVE;
+            float4 qs[NST];
 #pragma unroll
-                for (int stp = WAVE / 2; stp > 0; stp >>= 1) seg += pend[seg + stp - 1] <= x ? stp : 0;
-                seg = seg < WAVE ? seg : WAVE - 1;
-                const float4 q = pos4s[x + k0t[seg]];
-                const float4 sh = shift[seg];
-                cand[x] = make_float4(q.x + sh.x, q.y + sh.y, q.z + sh.z, q.w);
+            for (int it = 0; it < NST; ++it) {
+                const int x = it * WAVE + lane;
+                qs[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (it * WAVE < total) {   // (wave-uniform)
+                    const int xc = x < total ? x : total - 1;
+                    int seg = 0;
+#pragma unroll
+                    for (int stp = WAVE / 2; stp > 0; stp >>= 1) seg += pend[seg + stp - 1] <= xc ? stp : 0;
+                    seg = seg < WAVE ? seg : WAVE - 1;
+                    const float4 q = pos4s[xc + k0t[seg]];
+                    // image shift of stencil bin `seg` (same evaluation order as k_nbr_cell: (o0 s0 + o1 s3) first, o2 s6
+                    // added to the sum)
+                    const int q2 = (int)(((float)seg + 0.5f) * inv_n2);
+                    const int q1 = (int)(((float)q2 + 0.5f) * inv_n1);
+                    const int o2 = seg - q2 * n2 - R2, o1 = q2 - q1 * n1 - R1, o0 = q1 - R0;
+                    qs[it] = make_float4(q.x + (o0 * st[0] + o1 * st[3] + o2 * st[6]), q.y + (o0 * st[1] + o1 * st[4] + o2 * st[7]),
+                                         q.z + (o0 * st[2] + o1 * st[5] + o2 * st[8]), q.w);
+                }
             }
+#pragma unroll
+            for (int it = 0; it < NST; ++it)
+                if (it * WAVE + lane < total) cand[it * WAVE + lane] = qs[it];
         }
         // classes a row of this bin can hold: {angular, far} x the species present in the stencil (bits g * 8 + species)
         uint32_t cls_mask = 0u;
-        wave_sync();
+        wave_sync();   // (also: the staging tables are dead, the sweeps may write hit positions over them)
         for (int x0 = 0; x0 < total; x0 += WAVE)
             cls_mask |= (x0 + lane < total) ? 1u << (__float_as_uint(cand[x0 + lane].w) >> 28) : 0u;
         cls_mask = wave_or(cls_mask);
         cls_mask = __builtin_amdgcn_readfirstlane(cls_mask | (cls_mask << 8));
+        NTR_STAMP(2)   // staging + class mask
         // ---- every owned atom of the bin sweeps the staged list ----
         for (int a = ab; a < ae; a += 2) {   // two central atoms per sweep: one LDS read of a candidate serves both
             const int xa = self_base + (a - ab), xb = xa + 1;
             const float4 pa = cand[xa];                              // the atoms themselves (zero shift)
             const float4 pb = cand[a + 1 < ae ? xb : xa];
-            const int64_t ia = (int64_t)(__float_as_uint(pa.w) & IDX_MASK), ib = (int64_t)(__float_as_uint(pb.w) & IDX_MASK);
+            // (the same LDS word in every lane: through a scalar register, so that everything derived from the atom index --
+            // the ownership tests, the row addresses, the class counters of the rows -- is scalar work)
+            const int64_t ia = (int64_t)((uint32_t)uniform((int)__float_as_uint(pa.w)) & IDX_MASK);
+            const int64_t ib = (int64_t)((uint32_t)uniform((int)__float_as_uint(pb.w)) & IDX_MASK);
             const bool da = ia >= lo && ia < hi, db = a + 1 < ae && ib >= lo && ib < hi;
             if (!da && !db) continue;
             int nha = 0, nhb = 0;
+            // (branch-free: the predicates are combined as masks, the next 64 candidates are read ahead of this step's work)
+            float4 q = cand[lane < total ? lane : 0];
             for (int x0 = 0; x0 < total; x0 += WAVE) {
-                const int x = x0 + lane;
-                const float4 q = cand[x < total ? x : 0];
+                const int x = x0 + lane, xn = x + WAVE;
+                const float4 qn = cand[xn < total ? xn : 0];
                 const float ax = q.x - pa.x, ay = q.y - pa.y, az = q.z - pa.z;
                 const float bx = q.x - pb.x, by = q.y - pb.y, bz = q.z - pb.z;
-                const bool hita = da && x < total && ax * ax + ay * ay + az * az <= rcr2 && x != xa;
-                const bool hitb = db && x < total && bx * bx + by * by + bz * bz <= rcr2 && x != xb;
+                const float d2a = ax * ax + ay * ay + az * az, d2b = bx * bx + by * by + bz * bz;
+                const bool inr = x < total;
+                const bool hita = (int)da & (int)inr & (int)(d2a <= rcr2) & (int)(x != xa);
+                const bool hitb = (int)db & (int)inr & (int)(d2b <= rcr2) & (int)(x != xb);
                 const uint64_t ma = __ballot(hita), mb = __ballot(hitb);
                 const int posa = nha + mbcnt(ma), posb = nhb + mbcnt(mb);
-                if (hita && posa < MAXR) hidx[posa] = (uint16_t)x;
-                if (hitb && posb < MAXR) hidx[MAXR + posb] = (uint16_t)x;
+                if ((int)hita & (int)(posa < MAXR)) hidx[posa] = (uint16_t)x;
+                if ((int)hitb & (int)(posb < MAXR)) hidx[MAXR + posb] = (uint16_t)x;
                 nha += __popcll(ma);
                 nhb += __popcll(mb);
+                q = qn;
             }
             wave_sync();
-            if (da) emit_from_stage(cand, hidx, nha > MAXR ? MAXR : nha, nha > MAXR, pa, ia, lo, row_cap, rca2, cls_mask, meta, ent, status);
-            if (db) emit_from_stage(cand, hidx + MAXR, nhb > MAXR ? MAXR : nhb, nhb > MAXR, pb, ib, lo, row_cap, rca2, cls_mask, meta, ent, status);
+            NTR_STAMP(3)   // sweeps
+            {
+                const int nh2[2] = {nha, nhb};
+                const bool act2[2] = {da, db};
+                const float4 p2[2] = {pa, pb};
+                const int64_t i2[2] = {ia, ib};
+                if (max(nha, nhb) <= 2 * WAVE) {   // (nearly always: both atoms together, two chunks of hits each)
+                    emit_from_stage<2, 2>(cand, hidx, nh2, act2, p2, i2, lo, row_cap, rca2, cls_mask, meta, ent, status);
+                } else {
+                    {
+                        const int nh1[1] = {nha};
+                        const bool act1[1] = {da};
+                        const float4 p1[1] = {pa};
+                        const int64_t i1[1] = {ia};
+                        emit_from_stage<1, MAXR / WAVE>(cand, hidx, nh1, act1, p1, i1, lo, row_cap, rca2, cls_mask, meta, ent,
+                                                        status);
+                    }
+                    {
+                        const int nh1[1] = {nhb};
+                        const bool act1[1] = {db};
+                        const float4 p1[1] = {pb};
+                        const int64_t i1[1] = {ib};
+                        emit_from_stage<1, MAXR / WAVE>(cand, hidx + MAXR, nh1, act1, p1, i1, lo, row_cap, rca2, cls_mask, meta,
+                                                        ent, status);
+                    }
+                }
+            }
             wave_sync();
+            NTR_STAMP(4)   // rows
         }
         wave_sync();
     }
+#ifdef ANIHIP_TRACE
+    if (wib == 0 && lane == 0 && blockIdx.x < 1024)
+        for (int q_ = 0; q_ < 10; ++q_) g_nbr_trace[blockIdx.x][q_] = tr_sum[q_];
+#endif
 }
 
 // ---- rows from an external FULL neighbor list (LAMMPS style: local + ghost atoms with explicit coordinates) ----
@@ -1053,7 +1139,7 @@ extern "C" int anihip_nbr_build_cell(void *stream_, const anihip_aev_params *p, 
     zero_words_async(stream, n_unhandled, sizeof(int));
     const int rc = (int)(row_cap > MAXR ? MAXR : row_cap);
     int64_t bins_blocks = (max_cells + NBR2_WPB - 1) / NBR2_WPB;
-    if (bins_blocks > 256 * 4) bins_blocks = 256 * 4;   // persistent: 16 waves per CU, each strides over the bins
+    if (bins_blocks > 256 * 5) bins_blocks = 256 * 5;   // persistent: 20 waves per CU, each strides over the bins
     hipLaunchKernelGGL(k_nbr_cell2, dim3((unsigned)bins_blocks), dim3(NBR2_WPB * WAVE), 0, stream, w.desc,
                        p->num_species, p->Rcr * p->Rcr, p->Rca * p->Rca, lo, hi, w.cellid, w.cell_start, w.pos4s, rc,
                        meta, (float4 *)ent, status, handled, n_unhandled);
@@ -1278,3 +1364,10 @@ extern "C" int anihip_nbr_from_full(void *stream_, const anihip_aev_params *p, i
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+#ifdef ANIHIP_TRACE
+extern "C" int anihip_dev_nbr_trace_read(unsigned long long *dst /* host, 1024 x 10 */)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(anihip::g_nbr_trace), sizeof(unsigned long long) * 1024 * 10);
+}
+#endif
