@@ -314,12 +314,15 @@ class ANI(torch.nn.Module):
                                                         shard_rows=True, tile_hint=tile_hint)
         virial = torch.empty((3, 3), dtype=torch.float64, device=c32.device) if stress else None
         pair_e, pair_g, pair_w = self._pair_terms(species32, c32, cell, pbc_t, nbrs, lo, hi, stress)
+        from .parallel import FORCE_COLLECTIVES
+
         world = 1 if group is None else torch.distributed.get_world_size(group)
+        several = world > 1 or (group is not None and FORCE_COLLECTIVES)
         sae = self._sae64(c32.device) if self.energy_shifter._enabled else None
         if self.deterministic_forces:
             # order-independent sums: int64 fixed-point accumulators (2^-32) for the forces (ANIHIP_BWD_FIXED_POINT), and
             # for a sharded run ONE int64 all-reduce that also carries energies and virial at the same resolution
-            n_tail = (C + (9 if stress else 0)) if world > 1 else 0
+            n_tail = (C + (9 if stress else 0)) if several else 0
             red = torch.zeros(3 * n + n_tail, dtype=torch.int64, device=c32.device)
             eng.backward(species32, nbrs, grad_aev, grad_coords=red[:3 * n].view(n, 3), shard_rows=True,
                          virial=virial, slab_mask=slab_mask, fixed_point=True)
@@ -328,7 +331,7 @@ class ANI(torch.nn.Module):
                 if stress:
                     virial += pair_w
             energies = energy_reduce(species32, atomic_e if pair_e is None else atomic_e + pair_e, sae, lo, hi)
-            if world > 1:
+            if several:
                 red[3 * n:3 * n + C] = torch.round(energies / FIXED_SCALE).to(torch.int64)
                 if stress:
                     red[3 * n + C:] = torch.round(virial.reshape(-1) / FIXED_SCALE).to(torch.int64)
@@ -342,7 +345,7 @@ class ANI(torch.nn.Module):
         else:
             # forces are accumulated straight into the buffer that a sharded run all-reduces: [3 n forces | 4 C energy
             # parts | 36 virial parts]
-            n_tail = (4 * C + (36 if stress else 0)) if world > 1 else 0
+            n_tail = (4 * C + (36 if stress else 0)) if several else 0
             red = torch.zeros(3 * n + n_tail, dtype=torch.float32, device=c32.device)
             grad_coords = eng.backward(species32, nbrs, grad_aev, grad_coords=red[:3 * n].view(n, 3), shard_rows=True,
                                        virial=virial, slab_mask=slab_mask)
@@ -354,7 +357,7 @@ class ANI(torch.nn.Module):
             energies = energy_forces_finish(species32, atomic_e if pair_e is None else atomic_e + pair_e, sae,
                                             grad_coords, lo, hi)
             forces = grad_coords.view(C, A, 3)
-            if world > 1:
+            if several:
                 # ONE collective per step: the fp64 partial energies (and virial) ride in the fp32 force buffer as four
                 # exactly-summable fp32 parts each (parallel.split_exact), so the sum over ranks is exact and
                 # independent of the reduction order
@@ -458,7 +461,10 @@ class ANI(torch.nn.Module):
         if stress and pair_w is not None:
             virial += pair_w
         tail = energies if not stress else torch.cat([energies, virial.reshape(-1)])
-        if group is not None and world > 1:
+        from .parallel import FORCE_COLLECTIVES
+
+        several = world > 1 or FORCE_COLLECTIVES
+        if group is not None and several:
             if fixed:
                 rows, tot = part.exchange(rows, torch.round(tail / FIXED_SCALE).to(torch.int64), group)
                 tot = tot.to(torch.float64) * FIXED_SCALE
@@ -471,7 +477,7 @@ class ANI(torch.nn.Module):
         else:
             n_coll, nbytes = 0, 0
         f_l = fixed_to_float(rows) if fixed else rows
-        if group is not None and world > 1 and reduce_forces:
+        if group is not None and several and reduce_forces:
             both = part.gather_owned(torch.cat([f_l, e_atom.view(-1, 1)], dim=1), group)   # ONE gather: forces + e_atom
             forces, ae = both[:, :3].contiguous(), both[:, 3].contiguous()
             n_coll, nbytes = n_coll + 1, nbytes + 16 * max(part.bounds[r + 1] - part.bounds[r] for r in range(world))

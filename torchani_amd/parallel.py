@@ -72,13 +72,18 @@ def join_exact(parts: torch.Tensor) -> torch.Tensor:
     return parts.to(torch.float64).sum(dim=-1)
 
 
+# development aid: TORCHANI_AMD_FORCE_GROUP=1 creates the process group and runs every collective of a step even at world
+# size 1 -- the only way to execute the RCCL calls themselves on a box with a single GPU (tools/gpu_rccl_world1.sh)
+FORCE_COLLECTIVES = os.environ.get("TORCHANI_AMD_FORCE_GROUP") == "1"
+
+
 def init_from_env(backend: tp.Optional[str] = None):
     """Initialise torch.distributed from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, world, local_rank, group-or-None)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    if world == 1 and not FORCE_COLLECTIVES:
         return rank, world, local, None
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
