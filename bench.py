@@ -200,10 +200,11 @@ def main():
         eng = model.aev_computer.engine()
         sp32 = species.to(torch.int32).contiguous()
         part = model._spatial_partition(sp32, coords, cell, pbc, r, wd)
-        sp_l = part.local(sp32).view(1, -1).contiguous()
+        sp_e, order = model._engine_species(sp32)   # (the kernels' species numbering, models.ANI.compact_species)
+        sp_l = part.local(sp_e).view(1, -1).contiguous()
         x_l = part.local(coords, 3).view(1, -1, 3).contiguous()
         lo, hi, nl = part.n_left, part.n_left + part.n_owned, part.n_local
-        packed = model.neural_networks._pack(dev)
+        packed = model.neural_networks._pack(dev, order)
         st = {f"partition (cut once per skin {model.partition_skin} A of motion)": time_stage(
             lambda: type(part)(coords, cell, pbc, wd, r, model.aev_computer.radial.cutoff, sp32, skin=model.partition_skin), 3)}
         st["gather local system"] = time_stage(lambda: (part.local(sp32), part.local(coords, 3)), 3)
@@ -262,15 +263,18 @@ def main():
     # ---- per-stage device timing on this rank's shard (outside the timed region) -----------------------
     eng = model.aev_computer.engine()
     sp32 = species.to(torch.int32).contiguous()
+    sp_given = sp32
+    sp32, sp_order = model._engine_species(sp32)   # (the kernels' species numbering, models.ANI.compact_species)
     lo, hi = 0, n_atoms
     n_local = n_atoms
     coords_l = coords
     if group is not None:   # this rank's local system [left halo | owned | right halo] of the spatial shards
-        part = model._spatial_partition(sp32, coords, cell, pbc, rank, world)
+        part = model._spatial_partition(sp_given, coords, cell, pbc, rank, world)
         sp32 = part.local(sp32).view(1, -1).contiguous()
+        sp_given = part.local(sp_given).view(1, -1).contiguous()
         coords_l = part.local(coords, 3).view(1, -1, 3).contiguous()
         lo, hi, n_local = part.n_left, part.n_left + part.n_owned, part.n_local
-    packed = model.neural_networks._pack(dev)
+    packed = model.neural_networks._pack(dev, sp_order)
     st = {}
     reps = 3
     nbrs = eng.neighbors(sp32, coords_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
@@ -314,7 +318,7 @@ def main():
     # identically-zero blocks): executed flops = dense flops with the AEV length replaced by the staged columns
     pop = mask[lo:hi].to(torch.int64) & 0xFFFFFFFF
     mean_slabs = float(sum(((pop >> b) & 1).double().mean() for b in range(32)))
-    sp_owned = sp32.reshape(-1)[lo:hi].cpu().numpy()
+    sp_owned = sp_given.reshape(-1)[lo:hi].cpu().numpy()
     flops_dense = mlp_flops_per_atom(sp_owned)
     flops_atom = mlp_flops_per_atom(sp_owned, l0_cols=32.0 * mean_slabs)
     mlp_tflops = flops_atom * n_shard / (st["mlp_fwd_bwd"] * 1e-3) / 1e12

@@ -713,3 +713,49 @@ def test_member_models_keep_pair_potentials_and_graph_stamp():
     # the D3 parameter block is built from host copies (no device reads: legal during stream capture) and cached
     d3 = full.potentials["dispersion_d3"]
     assert d3.params() is d3.params() and abs(d3.params().cov_radius_bohr[0] - float(d3.covalent_radii[0])) < 1e-6
+
+
+def test_species_column_map():
+    """engine.species_column_map: column c of the AEV layout written with relabelled species is column map[c] of the
+    reference layout (aev/_computer.py: radial blocks by species, angular blocks by the triu index of the species pair)."""
+    from torchani_amd.engine import species_column_map
+
+    S, nr, nb = 7, 16, 32
+    L = S * nr + nb * S * (S + 1) // 2
+
+    def triu(a, b):
+        return a * S - (a * (a - 1)) // 2 + (b - a)
+
+    ref = {}
+    for sp in range(S):
+        for k in range(nr):
+            ref[sp * nr + k] = ("r", (sp,), k)
+    for a in range(S):
+        for b in range(a, S):
+            for t in range(nb):
+                ref[S * nr + triu(a, b) * nb + t] = ("a", (a, b), t)
+    for order in ((0, 3, 1, 2, 4, 5, 6), (6, 5, 4, 3, 2, 1, 0), tuple(range(S))):
+        m = species_column_map(S, S * nr, L, order)
+        assert sorted(m.tolist()) == list(range(L))
+        for c in range(L):
+            kind, sp, t = ref[c]
+            assert ref[int(m[c])] == (kind, tuple(sorted(order[x] for x in sp)), t)
+
+
+def test_no_inline_asm_valu_to_mfma_hazard():
+    """gfx950: two wait states between a VALU write of a VGPR and an MFMA reading it.  The compiler counts them for its own
+    instructions, not behind asm(): k_gemm_l0b's first MFMA of a k step used to read the lo fragment one wait state
+    behind the v_fma_mixhi_f16 that wrote it (wrong dE/dAEV in the first flagged slab of 4-slab tiles).  Disassemble the
+    library that was built and check every such pair (tools/isa_hazards.py)."""
+    import importlib.util
+
+    from torchani_amd import _lib
+
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isa_hazards.py")
+    spec = importlib.util.spec_from_file_location("isa_hazards", tools)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(os.path.join(mod.LLVM, "llvm-objdump")):
+        pytest.skip("no llvm-objdump")
+    checked, bad = mod.check(_lib.LIB_PATH)
+    assert checked > 0 and not bad, bad

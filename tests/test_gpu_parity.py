@@ -6,6 +6,7 @@ held to 2e-5 absolute (the reference's own cuAEV-vs-pyaev gate is 5e-5, tests/te
 Modelled on tests/test_cuaev.py:152-798 of the reference (differential tests of the native path).
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -477,6 +478,85 @@ def test_shards_add_up_to_the_whole(dev, name, world, monkeypatch):
     assert np.abs(f.cpu().numpy() - g["forces"]).max() < F_TOL
     n_real = int((g["species"] >= 0).sum())
     assert np.abs(e.cpu().numpy() - g["energies"]).max() < E_ATOM_TOL * max(1.0, np.sqrt(n_real))
+
+
+@pytest.mark.parametrize("pair", [(0, 3), (0, 1), (2, 3), (4, 5), (1, 1)])
+def test_skinny_layer0_backward_for_every_slab_count(dev, pair):
+    """k_gemm_l0b (layer-0 backward of row tiles with <= 6 flagged AEV slabs) against the row-major hand-over + k_gemm_h2 on
+    two-species systems whose species share a radial slab or not (4 / 5 flagged slabs; one species: 2): the same sums in
+    the same order, bit for bit.  (With 4 column blocks the kernel's first MFMA of a k step read a register one wait
+    state behind the inline-assembly instruction that wrote it -- tools/isa_hazards.py.)"""
+    from bench import water_box
+
+    sp_np, x_np, cell_np = water_box(18)   # 17 496 atoms: 256-row tiles from 16 384 on
+    x, cell = torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    base = torch.from_numpy(sp_np).to(dev)
+    sp = torch.where(base == 0, pair[0], pair[1]).to(torch.int32)
+    model = get_model("ani2x", 0, dev, neighborlist="cell")
+    eng = model.aev_computer.engine()
+    packed = model.neural_networks._pack(dev)
+    nbrs = eng.neighbors(sp, x, cell, (True, True, True), mode="cell", row_cap=160)
+    mask = torch.zeros(sp.numel(), dtype=torch.int32, device=dev)
+    aev = eng.forward(sp, nbrs, slab_mask=mask)
+    got = {}
+    try:
+        for name, flags in (("skinny", 0), ("rows", _lib.MLP_FLAG_D0_ROWS)):
+            packed.flags = flags
+            ga = torch.zeros_like(aev)
+            e, _, _ = packed.forward_backward(sp, aev, grad_aev=ga, slab_mask=mask)
+            got[name] = (e.clone(), ga.clone())
+    finally:
+        packed.flags = None
+    n_slabs = bin(int(mask[0].item()) & 0xFFFFFFFF).count("1")
+    assert n_slabs == (2 if pair[0] == pair[1] else 4 if pair[0] >> 1 == pair[1] >> 1 else 5)
+    assert float(got["rows"][1].abs().max()) > 1e-4
+    assert torch.equal(got["skinny"][0], got["rows"][0])
+    assert torch.equal(got["skinny"][1], got["rows"][1])
+
+
+def test_present_species_first_relabelling(dev):
+    """models.ANI.compact_species: a large system's species are numbered "present ones first" inside the engine (water under
+    ANI-2x: one radial AEV slab instead of two half-empty ones) with the first-layer weights permuted to match.  Same
+    energies and forces as with the reference numbering (the sums run over the slabs in a different order: fp32
+    rounding), one flagged slab fewer, and the sharded path adds up to the same."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from bench import water_box
+
+    sp_np, x_np, cell_np = water_box(30)   # 81 000 atoms
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    pbc = (True, True, True)
+    model = get_model("ani2x", 0, dev, neighborlist="cell", row_capacity=160)   # (its own instance)
+    try:
+        model.compact_species = False
+        ref = model.energies_and_forces(sp, x, cell, pbc)
+        model.compact_species = True
+        sp32 = sp.to(torch.int32)
+        sp_e, order = model._engine_species(sp32)
+        assert order == (0, 3, 1, 2, 4, 5, 6)
+        assert sorted(torch.unique(sp_e).tolist()) == [0, 1]
+        out = model.energies_and_forces(sp, x, cell, pbc)
+        assert float((out.atomic_energies - ref.atomic_energies).abs().max()) < 5e-7
+        assert float((out.forces - ref.forces).abs().max()) < 2e-6
+        assert abs(float(out.energies - ref.energies)) < 1e-7 * sp.numel()
+        # one flagged slab fewer per atom
+        eng = model.aev_computer.engine()
+        for species_e, want in ((sp32, 5.0), (sp_e, 4.0)):
+            nbrs = eng.neighbors(species_e, x, cell, pbc, mode="cell", row_cap=160)
+            mask = torch.zeros(sp.numel(), dtype=torch.int32, device=dev)
+            eng.forward(species_e, nbrs, slab_mask=mask)
+            pop = mask.to(torch.int64) & 0xFFFFFFFF
+            n_slabs = float(sum(((pop >> b) & 1).double().mean() for b in range(32)))
+            assert abs(n_slabs - want) < 0.05, (n_slabs, want)
+        # shards of the relabelled system add up to the whole
+        e = torch.zeros(1, dtype=torch.float64, device=dev)
+        f = torch.zeros_like(x)
+        for rank in range(2):
+            part = model.energies_and_forces(sp, x, cell, pbc, shard=(rank, 2))
+            e += part.energies
+            f += part.forces
+        assert float((f - ref.forces).abs().max()) < 2e-6 and abs(float(e - ref.energies)) < 1e-7 * sp.numel()
+    finally:
+        model.compact_species = True
 
 
 def test_partition_skin_reuses_the_shards_while_atoms_move(dev):

@@ -1280,6 +1280,11 @@ __device__ __forceinline__ void l0b_tile(const GemmArgs &g, const int (&cbw)[L0B
             ahi[c] = h[0]; ahi[c + 1] = h[1];
             alo[c] = l[0]; alo[c + 1] = l[1];
         }
+        // gfx950 needs two wait states between a VALU write of a VGPR and an MFMA that reads it; the compiler inserts them
+        // for instructions it knows, not behind inline assembly -- and the first MFMA of a k step reads `alo` (with four
+        // column blocks it was scheduled right behind the last v_fma_mixhi and multiplied a stale register: d E / d AEV of
+        // the tile's FIRST flagged slab off by ~2 %).  The nop is tied to `alo`, so it stays between the two.
+        asm volatile("s_nop 1" : "+v"(alo));
     };
     auto bfrags = [&](const _Float16 *base, int ks, h8 (&bhi)[NB], h8 (&blo)[NB]) {
         const int pc = ks * 2 + fk;

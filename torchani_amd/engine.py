@@ -393,6 +393,29 @@ def _n_cus(dev: torch.device) -> int:
     return _N_CUS[i]
 
 
+def species_column_map(num_species: int, radial_len: int, aev_len: int, order: tp.Sequence[int]) -> np.ndarray:
+    """AEV column of the reference layout (aev/_computer.py: radial blocks by species, angular blocks by the triu index of
+    the species pair) for every column of the SAME layout written with the species relabelled ``new = order.index(old)``:
+    ``aev_relabelled[:, c] == aev_reference[:, map[c]]``.  Used to permute the input rows of the layer-0 weights when the
+    engine numbers the species of a system "present ones first" (models.ANI.compact_species)."""
+    S = num_species
+    nr, pairs = radial_len // S, S * (S + 1) // 2
+    nb = (aev_len - radial_len) // pairs
+    assert nr * S == radial_len and radial_len + nb * pairs == aev_len and sorted(order) == list(range(S))
+
+    def triu(a: int, b: int) -> int:   # index of the pair (a <= b) in row-major upper-triangular order
+        return a * S - (a * (a - 1)) // 2 + (b - a)
+
+    out = np.empty(aev_len, dtype=np.int64)
+    for s_new in range(S):
+        out[s_new * nr:(s_new + 1) * nr] = order[s_new] * nr + np.arange(nr)
+    for a in range(S):
+        for b in range(a, S):
+            oa, ob = sorted((order[a], order[b]))
+            out[radial_len + triu(a, b) * nb:radial_len + (triu(a, b) + 1) * nb] = radial_len + triu(oa, ob) * nb + np.arange(nb)
+    return out
+
+
 class PackedNetworks:
     """Ensemble parameters in the MFMA-friendly layout of include/anihip.h (members concatenated, widths
     padded to 32, transposed copies for the backward GEMMs); cf. BmmAtomicNetwork, nn/_infer.py:141-161."""

@@ -205,7 +205,8 @@ class ANI(torch.nn.Module):
         c32 = coords.detach().to(torch.float32).contiguous()
         n_central = species32.numel() if group is None and shard is None else 0   # (shards: the library's default)
         hint = 0 if torch.cuda.is_current_stream_capturing() else self._tile_hint(species, species32, n_central)
-        out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard, stress, hint)
+        out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard, stress, hint,
+                                             species)
         if check_overflow and not torch.cuda.is_current_stream_capturing():
             # one host sync after everything is queued: a row over capacity was zeroed by the builder, the result
             # would be silently wrong (the reference asserts on the device, csrc/aev.cu:229).  Retry once at the
@@ -216,7 +217,7 @@ class ANI(torch.nn.Module):
                     warnings.warn(f"neighbor rows overflowed row_capacity={aevc.row_capacity}: retrying with {MAX_RAD}")
                     aevc.row_capacity = MAX_RAD
                     out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard,
-                                                         stress, hint)
+                                                         stress, hint, species)
                 aevc.last_neighbors().raise_on_overflow()
             self._raise_on_pair_overflow()
         return out
@@ -286,21 +287,65 @@ class ANI(torch.nn.Module):
             self.__dict__["_n_elem_cache"] = hit
         return _lib.MLP_FLAG_SMALL_TILES if hit[1] >= 4 else 0
 
+    # ---- species numbered "present ones first" inside the engine ------------------------------------------------------
+    compact_species = True   # large systems: relabel the species so that the AEV blocks of absent species come last
+
+    def _engine_species(self, species32: Tensor, key_tensor: tp.Optional[Tensor] = None
+                        ) -> tp.Tuple[Tensor, tp.Optional[tp.Tuple[int, ...]]]:
+        """The species indices the kernels work with, and their order (None: as given).
+
+        The layer-0 GEMMs skip the 32-column AEV slabs no atom of a tile has a neighbor for.  Radial blocks are 16 columns
+        per species, two species to a slab: water under ANI-2x (H = 0, O = 3 of H C N O S F Cl) touches two half-empty
+        radial slabs.  Relabelling the species of a SYSTEM "present ones first" (H -> 0, O -> 1) puts its radial blocks
+        side by side -- 4 flagged slabs instead of 5 -- and costs nothing but a permutation of the first-layer weights
+        (nn.ANINetworks._pack(species_order=...)): the AEV rows are internal to energies_and_forces, nobody sees their
+        column order.  Only for systems large enough that the one host read of the species histogram (cached per species
+        tensor) does not matter, and only while the networks are the only consumer of the neighbor rows' species codes.
+        key_tensor: the caller's own species tensor (any dtype) the cache entry is tied to, like _tile_hint."""
+        n = species32.numel()
+        key_tensor = species32 if key_tensor is None else key_tensor
+        if (not self.compact_species or n < 65536 or self.aev_computer.verlet is not None
+                or any(k != "nnp" and p._enabled for k, p in self.potentials.items())):
+            return species32, None
+        key = (key_tensor.data_ptr(), key_tensor._version, tuple(key_tensor.shape))
+        hit = self.__dict__.get("_species_order_cache")
+        if hit is None or hit[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                return species32, None   # (needs a host read: not inside a graph capture)
+            S = self.aev_computer.num_species
+            present = torch.bincount(species32.reshape(-1).clamp(min=0), minlength=S)[:S]
+            present[0] -= (species32 < 0).sum()   # (padding atoms were counted as species 0)
+            have = (present > 0).tolist()
+            order = tuple([s for s in range(S) if have[s]] + [s for s in range(S) if not have[s]])
+            # worth it only if the present species then share fewer radial slabs (two species per slab)
+            n_have = sum(have)
+            if order == tuple(range(S)) or (n_have + 1) // 2 >= len({s >> 1 for s in range(S) if have[s]}):
+                hit = (key, key_tensor, None, None)
+            else:
+                lut = torch.full((S + 1,), -1, dtype=torch.int32, device=species32.device)
+                lut[1 + torch.tensor(order, device=species32.device)] = torch.arange(S, dtype=torch.int32, device=species32.device)
+                hit = (key, key_tensor, order, lut[(species32 + 1).long()].contiguous())
+            self.__dict__["_species_order_cache"] = hit
+        return (species32 if hit[2] is None else hit[3]), hit[2]
+
     def _energies_and_forces_core(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces,
-                                  check_overflow, shard, stress: bool = False, tile_hint: int = 0) -> EnergiesForces:
+                                  check_overflow, shard, stress: bool = False, tile_hint: int = 0,
+                                  species_key: tp.Optional[Tensor] = None) -> EnergiesForces:
         """The stream-ordered part of energies_and_forces (element indices int32, coords fp32 contiguous):
         no host synchronisation unless check_overflow, so it can be captured into a HIP graph."""
         C, A = species32.shape
         n = C * A
         if (group is not None or shard is not None) and self._spatial_ok(C, n):
             return self._energies_and_forces_spatial(species32, c32, cell, pbc, group, reduce_forces, check_overflow, shard,
-                                                     stress, tile_hint)
+                                                     stress, tile_hint, species_key)
         lo, hi = shard_range(n, group) if shard is None else shard_range(n, rank=shard[0], world=shard[1])
         aevc = self.aev_computer
         eng = aevc.engine()
         pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
+        given = species32
+        species32, order = self._engine_species(given, species_key)   # (`given` indexes the self energies)
         nbrs = aevc.neighbor_rows(species32, c32, cell, pbc_t, lo=lo, hi=hi)
-        packed = self.neural_networks._pack(c32.device)
+        packed = self.neural_networks._pack(c32.device, order)
         # per-atom flags of the AEV slabs that are not identically zero (absent neighbor species): the
         # layer-0 GEMMs skip the others
         slab_mask = None
@@ -330,7 +375,7 @@ class ANI(torch.nn.Module):
                 red[:3 * n] += torch.round(pair_g.reshape(-1).to(torch.float64) / FIXED_SCALE).to(torch.int64)
                 if stress:
                     virial += pair_w
-            energies = energy_reduce(species32, atomic_e if pair_e is None else atomic_e + pair_e, sae, lo, hi)
+            energies = energy_reduce(given, atomic_e if pair_e is None else atomic_e + pair_e, sae, lo, hi)
             if several:
                 red[3 * n:3 * n + C] = torch.round(energies / FIXED_SCALE).to(torch.int64)
                 if stress:
@@ -354,7 +399,7 @@ class ANI(torch.nn.Module):
                 if stress:
                     virial += pair_w
             # (energies and the sign flip of the gradient share the last launch of the step)
-            energies = energy_forces_finish(species32, atomic_e if pair_e is None else atomic_e + pair_e, sae,
+            energies = energy_forces_finish(given, atomic_e if pair_e is None else atomic_e + pair_e, sae,
                                             grad_coords, lo, hi)
             forces = grad_coords.view(C, A, 3)
             if several:
@@ -412,7 +457,8 @@ class ANI(torch.nn.Module):
         return hit[1]
 
     def _energies_and_forces_spatial(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces, check_overflow,
-                                     shard, stress: bool, tile_hint: int) -> EnergiesForces:
+                                     shard, stress: bool, tile_hint: int, species_key: tp.Optional[Tensor] = None
+                                     ) -> EnergiesForces:
         """energies_and_forces of ONE system sharded spatially: this rank evaluates the central atoms of its slab on the
         local system [left halo | owned | right halo], one all-gather of the halo force rows (+ partial energy / virial)
         completes its owned atoms' forces.  reduce_forces=True additionally gathers every rank's owned forces and
@@ -424,7 +470,9 @@ class ANI(torch.nn.Module):
             rank, world = shard
         pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
         part = self._spatial_partition(species32, c32, cell, pbc_t, rank, world)
-        sp_l = part.local(species32).view(1, -1).contiguous()
+        sp_e, order = self._engine_species(species32, species_key)   # (sp_given indexes the self energies)
+        sp_given = part.local(species32).view(1, -1).contiguous()
+        sp_l = sp_given if order is None else part.local(sp_e).view(1, -1).contiguous()
         x_l = part.local(c32, 3).view(1, -1, 3).contiguous()
         nl = part.n_local
         lo, hi = part.n_left, part.n_left + part.n_owned
@@ -432,7 +480,7 @@ class ANI(torch.nn.Module):
         eng = aevc.engine()
         dev = c32.device
         nbrs = aevc.neighbor_rows(sp_l, x_l, cell, pbc_t, lo=lo, hi=hi)
-        packed = self.neural_networks._pack(dev)
+        packed = self.neural_networks._pack(dev, order)
         slab_mask = None
         if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
             slab_mask = torch.zeros(nl, dtype=torch.int32, device=dev)
@@ -450,14 +498,14 @@ class ANI(torch.nn.Module):
                          fixed_point=True)
             if pair_g is not None:
                 rows += torch.round(pair_g.to(torch.float64) / FIXED_SCALE).to(torch.int64)
-            energies = energy_reduce(sp_l, e_atom, sae, lo, hi)
+            energies = energy_reduce(sp_given, e_atom, sae, lo, hi)
             rows.neg_()
         else:
             rows = torch.zeros((nl, 3), dtype=torch.float32, device=dev)
             eng.backward(sp_l, nbrs, grad_aev, grad_coords=rows, shard_rows=True, virial=virial, slab_mask=slab_mask)
             if pair_g is not None:
                 rows += pair_g
-            energies = energy_forces_finish(sp_l, e_atom, sae, rows, lo, hi)   # (negates rows: forces)
+            energies = energy_forces_finish(sp_given, e_atom, sae, rows, lo, hi)   # (negates rows: forces)
         if stress and pair_w is not None:
             virial += pair_w
         tail = energies if not stress else torch.cat([energies, virial.reshape(-1)])

@@ -205,11 +205,17 @@ class _EngineContainer(torch.nn.Module):
             self.__dict__["_plist"] = hit
         return members, hit[1]
 
-    def _pack(self, device: torch.device) -> PackedNetworks:
+    def _pack(self, device: torch.device, species_order: tp.Optional[tp.Tuple[int, ...]] = None) -> PackedNetworks:
+        """species_order (models.ANI.compact_species): the pack for a system whose species the engine numbers
+        ``new = species_order.index(old)`` -- network s' is the one of species_order[s'], with the input rows of its first
+        layer permuted to the AEV columns of the relabelled species (engine.species_column_map)."""
         members, params = self._param_list()
         precision = getattr(self, "mlp_precision", None) or os.environ.get("TORCHANI_AMD_MLP_PRECISION", "f16x3")
+        if species_order is not None and tuple(species_order) == tuple(range(len(self.symbols))):
+            species_order = None
         # (in-place updates bump _version, .to() / .data = ... change data_ptr; ~0.1 ms for 448 tensors)
-        key = (device, precision, tuple(map(id, members)), tuple(map(_VERSION_OF, params)), tuple(map(_DATA_PTR_OF, params)))
+        key = (device, precision, tuple(map(id, members)), tuple(map(_VERSION_OF, params)), tuple(map(_DATA_PTR_OF, params)),
+               species_order)
         cache = self.__dict__.setdefault("_packed_cache", {})   # several member subsets stay packed
         if key not in cache:
             # (a container may read ONE of several outputs of its final layers, nn/_internal.py:69-93: that row only)
@@ -224,6 +230,16 @@ class _EngineContainer(torch.nn.Module):
                         for lin, w in zip(m.atomics[s].linears(), weights[k][si])]
                        for si, s in enumerate(self.symbols)] for k, m in enumerate(members)]
             aev_len = weights[0][0][0].shape[1]
+            if species_order is not None:
+                from .engine import species_column_map
+
+                S = len(self.symbols)
+                if aev_len != 16 * S + 32 * (S * (S + 1) // 2):
+                    raise ValueError("species_order needs the ANI layout of the AEV (16 radial, 32 angular terms per block)")
+                cmap = torch.from_numpy(species_column_map(S, 16 * S, aev_len, species_order))
+                weights = [[[(w[:, cmap.to(w.device)].contiguous() if li == 0 else w) for li, w in enumerate(wm[old])]
+                            for old in species_order] for wm in weights]
+                biases = [[bm[old] for old in species_order] for bm in biases]
             acts = {getattr(m.atomics[s], "activation_name", "celu") for m in members for s in self.symbols}
             if len(acts) != 1:
                 raise ValueError(f"all atomic networks of a container must share one activation, got {sorted(acts)}")
