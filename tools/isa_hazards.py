@@ -55,13 +55,20 @@ def instructions(code):
 
 
 def check(lib_path):
-    """(pairs checked, list of violations)"""
+    """(pairs checked, list of violations).  (a) VALU write -> MFMA read: two wait states."""
     checked, bad = 0, []
     for code in code_objects(lib_path):
         ins = list(instructions(code))
         for k, (kern, line) in enumerate(ins):
             if not line.startswith(INLINE_ASM_VALU):
                 continue
+            # (b) a transcendental result needs a wait state before a VALU instruction reads it (trans forwarding hazard)
+            if k > 0 and re.match(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_", ins[k - 1][1]):
+                checked += 1
+                tdst = re.match(r"v(\d+)", ins[k - 1][1].split()[1])
+                srcs = [int(v) for v in re.findall(r"\bv(\d+)\b", line.split(None, 2)[2])] if len(line.split(None, 2)) > 2 else []
+                if tdst and int(tdst.group(1)) in srcs:
+                    bad.append((kern, 0, ins[k - 1][1], line))
             reg = int(re.match(r"v(\d+)", line.split()[1]).group(1))
             wait = 0
             for kern2, nxt in ins[k + 1:k + 10]:

@@ -300,18 +300,20 @@ class ANI(torch.nn.Module):
         side by side -- 4 flagged slabs instead of 5 -- and costs nothing but a permutation of the first-layer weights
         (nn.ANINetworks._pack(species_order=...)): the AEV rows are internal to energies_and_forces, nobody sees their
         column order.  Only for systems large enough that the one host read of the species histogram (cached per species
-        tensor) does not matter, and only while the networks are the only consumer of the neighbor rows' species codes.
+        tensor, as for _tile_hint: from 16 384 atoms on) does not matter, and only while the networks are the only consumer of the neighbor rows' species codes.
         key_tensor: the caller's own species tensor (any dtype) the cache entry is tied to, like _tile_hint."""
         n = species32.numel()
         key_tensor = species32 if key_tensor is None else key_tensor
-        if (not self.compact_species or n < 65536 or self.aev_computer.verlet is not None
+        if (not self.compact_species or n < 16384 or self.aev_computer.verlet is not None
                 or any(k != "nnp" and p._enabled for k, p in self.potentials.items())):
+            return species32, None
+        if torch.cuda.is_current_stream_capturing():
+            # (a capture must own the tensors it records -- GraphedEnergiesForces asks before it captures and passes its
+            # own copy down; anything else that captures gets the numbering as given)
             return species32, None
         key = (key_tensor.data_ptr(), key_tensor._version, tuple(key_tensor.shape))
         hit = self.__dict__.get("_species_order_cache")
         if hit is None or hit[0] != key:
-            if torch.cuda.is_current_stream_capturing():
-                return species32, None   # (needs a host read: not inside a graph capture)
             S = self.aev_computer.num_species
             present = torch.bincount(species32.reshape(-1).clamp(min=0), minlength=S)[:S]
             present[0] -= (species32 < 0).sum()   # (padding atoms were counted as species 0)
@@ -330,7 +332,9 @@ class ANI(torch.nn.Module):
 
     def _energies_and_forces_core(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces,
                                   check_overflow, shard, stress: bool = False, tile_hint: int = 0,
-                                  species_key: tp.Optional[Tensor] = None) -> EnergiesForces:
+                                  species_key: tp.Optional[Tensor] = None,
+                                  engine_species: tp.Optional[tp.Tuple[Tensor, tp.Optional[tp.Tuple[int, ...]]]] = None
+                                  ) -> EnergiesForces:
         """The stream-ordered part of energies_and_forces (element indices int32, coords fp32 contiguous):
         no host synchronisation unless check_overflow, so it can be captured into a HIP graph."""
         C, A = species32.shape
@@ -343,7 +347,8 @@ class ANI(torch.nn.Module):
         eng = aevc.engine()
         pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
         given = species32
-        species32, order = self._engine_species(given, species_key)   # (`given` indexes the self energies)
+        # (the kernels' numbering of the species; `given` indexes the self energies)
+        species32, order = engine_species if engine_species is not None else self._engine_species(given, species_key)
         nbrs = aevc.neighbor_rows(species32, c32, cell, pbc_t, lo=lo, hi=hi)
         packed = self.neural_networks._pack(c32.device, order)
         # per-atom flags of the AEV slabs that are not identically zero (absent neighbor species): the
@@ -651,7 +656,7 @@ class ANI(torch.nn.Module):
                 m.potentials[name] = pot
         m.potentials["nnp"]._enabled = self.potentials["nnp"]._enabled
         m.energy_shifter._enabled = self.energy_shifter._enabled
-        for attr in ("mlp_chunk", "deterministic_forces", "auto_graph_atoms"):
+        for attr in ("mlp_chunk", "deterministic_forces", "auto_graph_atoms", "compact_species", "partition", "partition_skin"):
             setattr(m, attr, getattr(self, attr))
 
     def atomic_energies(self, species_coordinates, cell=None, pbc=None, charge: int = 0,
@@ -804,6 +809,10 @@ class GraphedEnergiesForces:
         self.pbc = pbc
         self.warmup = warmup
         self.tile_hint = model._tile_hint(self.species32, self.species32, self.species32.numel())
+        # the kernels' species numbering (ANI.compact_species): worked out here, outside the capture, and OWNED by this
+        # object like every other tensor the graph reads
+        sp_e, self.species_order = model._engine_species(self.species32)
+        self.engine_species32 = sp_e if self.species_order is None else sp_e.clone()
         self.n_captures = 0
         self._packed = None
         self._capture()
@@ -816,7 +825,7 @@ class GraphedEnergiesForces:
             for _ in range(self.warmup):   # packs the weights, sizes the workspaces
                 self._run()
         torch.cuda.current_stream().wait_stream(side)
-        self._packed = self.model.neural_networks._pack(self.coords.device)   # strong reference: planes + workspace
+        self._packed = self.model.neural_networks._pack(self.coords.device, self.species_order)   # strong reference: planes + workspace
         self._packed.pinned += 1
         self._sae = self._current_sae()   # (the float64 copy of the self energies the graph reads)
         self.graph = torch.cuda.CUDAGraph()
@@ -838,10 +847,11 @@ class GraphedEnergiesForces:
 
     def _run(self) -> EnergiesForces:
         return self.model._energies_and_forces_core(self.species32, self.coords, self.cell, self.pbc, None, True,
-                                                    False, None, tile_hint=self.tile_hint)
+                                                    False, None, tile_hint=self.tile_hint,
+                                                    engine_species=(self.engine_species32, self.species_order))
 
     def __call__(self, coords: Tensor, cell: tp.Optional[Tensor] = None) -> EnergiesForces:
-        if (self.model.neural_networks._pack(self.coords.device) is not self._packed
+        if (self.model.neural_networks._pack(self.coords.device, self.species_order) is not self._packed
                 or self._current_sae() is not self._sae):
             self._capture()   # parameters were updated in place / other members: the old planes are stale
         self.coords.copy_(coords)
