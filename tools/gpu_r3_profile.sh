@@ -9,13 +9,13 @@ echo "rocprof exit $?"; cd $REPO
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 "$f"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/pmc_$c -o pmc -- python $REPO/bench.py --waters-side 64 --steps 1 --warmup 1 --no-cpu-baseline --no-dense-stage --no-secondary --parity-sample 0 > $REPO/gpurun_out/pmc_$c.log 2>&1
+  cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/pmc_$c -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dense-stage --no-secondary --parity-sample 0 > $REPO/gpurun_out/pmc_$c.log 2>&1
   echo "pmc $c exit $?"; cd $REPO
 done
 python - <<'PY'
 import csv, glob, json, collections
-out = {"n_atoms": 3 * 64 ** 3, "fetch_correction": 2.0, "kernels": {},
-       "workload": "bench.py --waters-side 64 (786432-atom periodic water box, same density as the headline box)",
+out = {"n_atoms": 2336064, "fetch_correction": 2.0, "kernels": {},
+       "workload": "bench.py at the headline size (2336064-atom periodic water box)",
        "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/gpu_r3_profile.sh), mean KB per "
                  "dispatch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md"}
 for c, key in (("FETCH_SIZE", "fetch_size_kb"), ("WRITE_SIZE", "write_size_kb")):
