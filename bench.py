@@ -268,7 +268,9 @@ def main():
     lo, hi = 0, n_atoms
     n_local = n_atoms
     coords_l = coords
-    if group is not None:   # this rank's local system [left halo | owned | right halo] of the spatial shards
+    sorted_copy = group is None and model._wants_locality_sort(sp_given, coords, cell, pbc, species)
+    if group is not None or sorted_copy:   # this rank's local system [left halo | owned | right halo] of the spatial
+        # shards (one GPU, incoherent atom order: the cell-sorted copy the step works on, models.ANI.locality_sort)
         part = model._spatial_partition(sp_given, coords, cell, pbc, rank, world)
         sp32 = part.local(sp32).view(1, -1).contiguous()
         sp_given = part.local(sp_given).view(1, -1).contiguous()
@@ -342,7 +344,7 @@ def main():
             "sharding": "spatial slabs of the coordinate-sorted order (any input order), each rank works on its slab + a "
                         "5.1 A halo; ONE all-gather per step of the halo force rows and the partial energies; forces "
                         "stay with the rank that owns the atoms",
-            "shuffled_input": bool(args.shuffle),
+            "shuffled_input": bool(args.shuffle), "evaluated_on_cell_sorted_copy": bool(sorted_copy),
         },
         "ms_per_step_median": median_ms,
         "roofline": {

@@ -514,6 +514,41 @@ def test_skinny_layer0_backward_for_every_slab_count(dev, pair):
     assert torch.equal(got["skinny"][1], got["rows"][1])
 
 
+def test_locality_sort_of_a_shuffled_system(dev):
+    """ANI.locality_sort = "auto": a large single system given in an incoherent atom order is evaluated on a cell-sorted
+    copy (spatial machinery with one rank) -- same energies and forces, atom by atom, as the coherent order gives; a
+    lattice-ordered input is left alone."""
+    from bench import water_box
+
+    sp_np, x_np, cell_np = water_box(28)   # 65 856 atoms
+    n = sp_np.shape[1]
+    perm = np.random.RandomState(5).permutation(n)
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    sp_s, x_s = torch.from_numpy(sp_np[:, perm]).to(dev), torch.from_numpy(np.ascontiguousarray(x_np[:, perm])).to(dev)
+    pbc = (True, True, True)
+    model = get_model("ani2x", 0, dev, neighborlist="cell", row_capacity=192)   # (its own instance)
+    try:
+        model.locality_sort = "never"
+        ref = model.energies_and_forces(sp, x, cell, pbc)
+        model.locality_sort = "auto"
+        assert not model._wants_locality_sort(sp.to(torch.int32), x, cell, pbc, sp)
+        assert model._wants_locality_sort(sp_s.to(torch.int32), x_s, cell, pbc, sp_s)
+        out = model.energies_and_forces(sp_s, x_s, cell, pbc)
+        assert model.last_collective["n_owned"] == n and model.last_collective["n_halo"] == 0   # (went through the sorted copy)
+        p = torch.from_numpy(perm).to(dev)
+        assert float((out.forces - ref.forces[:, p]).abs().max()) < 2e-6
+        assert float((out.atomic_energies - ref.atomic_energies[:, p]).abs().max()) < 5e-7
+        assert abs(float(out.energies - ref.energies)) < 1e-7 * n
+        # moved coordinates (a new tensor): the sorted order is kept, results still right
+        moved = x_s + 0.02 * torch.randn_like(x_s)
+        a = model.energies_and_forces(sp_s, moved, cell, pbc)
+        model.locality_sort = "never"
+        b = model.energies_and_forces(sp_s, moved, cell, pbc)
+        assert float((a.forces - b.forces).abs().max()) < 2e-6 and abs(float(a.energies - b.energies)) < 1e-7 * n
+    finally:
+        model.locality_sort = "auto"
+
+
 def test_present_species_first_relabelling(dev):
     """models.ANI.compact_species: a large system's species are numbered "present ones first" inside the engine (water under
     ANI-2x: one radial AEV slab instead of two half-empty ones) with the first-layer weights permuted to match.  Same

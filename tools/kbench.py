@@ -19,12 +19,33 @@ def main():
     ap.add_argument("--stages", default="nbr,fwd,bwd,mlp")
     ap.add_argument("--mask", default="both", choices=["on", "off", "both"], help="slab masks in the mlp stage")
     ap.add_argument("--chunk", type=int, default=1 << 18, help="atoms per network chunk")
+    ap.add_argument("--order", default="lattice", help="atom order: lattice (as generated), shuffle, layers (quarter-cutoff "
+                    "layers along x, then cutoff cells), brick:<B> (bricks of B x B x B cutoff cells, cells inside in z-fastest order)")
     args = ap.parse_args()
     from torchani_amd.models import ANI2x
 
     dev = torch.device("cuda:0")
     sp_np, x_np, cell_np = water_box(args.side)
     n = sp_np.shape[1]
+    if args.order != "lattice":
+        import numpy as np
+
+        x = x_np.reshape(-1, 3)
+        box = float(cell_np[0, 0])
+        if args.order == "shuffle":
+            perm = np.random.RandomState(1).permutation(n)
+        elif args.order == "layers":
+            k0 = np.floor(x[:, 0] / (5.1 / 4)).astype(np.int64)
+            k1 = np.floor(x[:, 1] / 5.1).astype(np.int64)
+            k2 = np.floor(x[:, 2] / 5.1).astype(np.int64)
+            perm = np.argsort((k0 * 1024 + k1) * 1024 + k2, kind="stable")
+        else:
+            B = int(args.order.split(":")[1])
+            c = np.floor(x / (box / np.floor(box / 5.1))).astype(np.int64)
+            b, w = c // B, c % B
+            key = ((((b[:, 0] * 256 + b[:, 1]) * 256 + b[:, 2]) * 64 + w[:, 0]) * 64 + w[:, 1]) * 64 + w[:, 2]
+            perm = np.argsort(key, kind="stable")
+        sp_np, x_np = np.ascontiguousarray(sp_np[:, perm]), np.ascontiguousarray(x_np[:, perm])
     sp32 = torch.from_numpy(sp_np).to(dev).to(torch.int32).contiguous()
     coords = torch.from_numpy(x_np).to(dev)
     cell = torch.from_numpy(cell_np).to(dev)
@@ -48,7 +69,7 @@ def main():
     if "fwd" in st:
         out["fwd"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev, slab_mask=mask), args.reps)
     if "bwd" in st:
-        out["bwd"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc), args.reps)
+        out["bwd"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc, slab_mask=mask), args.reps)   # (as in the product path)
     if "mlp" in st:
         if args.mask != "on":
             out["mlp_dense"] = time_stage(lambda: packed.forward_backward(sp32, aev, atomic_e=ae, grad_aev=gaev),

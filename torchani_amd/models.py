@@ -339,6 +339,10 @@ class ANI(torch.nn.Module):
         no host synchronisation unless check_overflow, so it can be captured into a HIP graph."""
         C, A = species32.shape
         n = C * A
+        if (group is None and shard is None and C == 1 and n >= 65536 and self.locality_sort != "never"
+                and not torch.cuda.is_current_stream_capturing() and self._spatial_ok(C, n)
+                and self._wants_locality_sort(species32, c32, cell, pbc, species_key)):
+            shard = (0, 1)   # one "rank" owning everything: the spatial path works on the cell-sorted copy
         if (group is not None or shard is not None) and self._spatial_ok(C, n):
             return self._energies_and_forces_spatial(species32, c32, cell, pbc, group, reduce_forces, check_overflow, shard,
                                                      stress, tile_hint, species_key)
@@ -429,6 +433,29 @@ class ANI(torch.nn.Module):
     partition = "spatial"   # "index": contiguous index ranges + one all-reduce of the whole force array (round-2 scheme)
     partition_skin = 0.0    # > 0 (Angstrom): halos that much wider, the partition is kept until an atom has moved skin / 2
 
+    # The AEV backward gathers 64 B of every neighbor's gradient row: with atoms in a spatially coherent order (an MD
+    # engine's, a lattice's) those rows are in cache, with a shuffled order they are not -- 7.8 instead of 4.7 ms at 2.34 M
+    # atoms (tools/kbench.py --order shuffle).  "auto": a large single system whose order is NOT coherent is evaluated on
+    # a cell-sorted copy (the spatial-shard machinery with one rank: gather, kernels, scatter back; the sorted order is
+    # kept until an atom has moved half a cell).  "always" / "never" force the choice.
+    locality_sort = "auto"
+
+    def _wants_locality_sort(self, species32: Tensor, c32: Tensor, cell, pbc, key_tensor: tp.Optional[Tensor]) -> bool:
+        if self.locality_sort == "always":
+            return True
+        key_tensor = species32 if key_tensor is None else key_tensor
+        key = (key_tensor.data_ptr(), key_tensor._version, tuple(key_tensor.shape))
+        hit = self.__dict__.get("_locality_cache")
+        if hit is None or hit[0] != key:
+            pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
+            part = self._spatial_partition(species32.view(-1), c32, cell, pbc_t, 0, 1)
+            # neighbors in the cell-sorted order that are also near each other in the given order
+            # (a random order puts 2 / 256 of them within n / 256 places; a lattice or an MD engine's order most of them)
+            near = ((part.order[1:] - part.order[:-1]).abs() < max(64, species32.numel() // 256)).float().mean()
+            hit = (key, key_tensor, bool(float(near) < 0.05))
+            self.__dict__["_locality_cache"] = hit
+        return hit[2]
+
     def _spatial_ok(self, C: int, n: int) -> bool:
         """Slab decomposition applies to ONE system evaluated through its own pair search, with every pair potential
         inside the AEV's radial cutoff (a wider potential, or D3's coordination numbers, would need a wider halo)."""
@@ -446,7 +473,7 @@ class ANI(torch.nn.Module):
         key = (c32.data_ptr(), c32._version, tuple(c32.shape), None if cell is None else (cell.data_ptr(), cell._version),
                pbc_t, rank, world)
         hit = self.__dict__.get("_spatial_cache")
-        if hit is not None and hit[0] != key and self.partition_skin > 0.0 and hit[0][2] == key[2] and \
+        if hit is not None and hit[0] != key and (self.partition_skin > 0.0 or world == 1) and hit[0][2] == key[2] and \
                 hit[0][4:] == key[4:] and (cell is None) == (hit[5] is None) and \
                 (cell is None or torch.equal(hit[5], cell)) and hit[1].still_valid(c32):
             # moved coordinates, same box, nobody further than skin / 2 from where the partition was cut: keep it (every
@@ -455,8 +482,9 @@ class ANI(torch.nn.Module):
             self.__dict__["_spatial_cache"] = hit
         if hit is None or hit[0] != key:
             # (the entry keeps the tensors alive, so an equal key means the same coordinates, not a recycled address)
-            hit = (key, SpatialShards(c32, cell, pbc_t, world, rank, self.aev_computer.radial.cutoff, species32,
-                                      skin=self.partition_skin),
+            # (one rank has no halo: any order is correct, the skin only says when the order has stopped being local)
+            skin = self.partition_skin if world > 1 else max(self.partition_skin, self.aev_computer.radial.cutoff)
+            hit = (key, SpatialShards(c32, cell, pbc_t, world, rank, self.aev_computer.radial.cutoff, species32, skin=skin),
                    c32, cell, species32, None if cell is None else cell.clone())
             self.__dict__["_spatial_cache"] = hit
         return hit[1]
@@ -656,7 +684,7 @@ class ANI(torch.nn.Module):
                 m.potentials[name] = pot
         m.potentials["nnp"]._enabled = self.potentials["nnp"]._enabled
         m.energy_shifter._enabled = self.energy_shifter._enabled
-        for attr in ("mlp_chunk", "deterministic_forces", "auto_graph_atoms", "compact_species", "partition", "partition_skin"):
+        for attr in ("mlp_chunk", "deterministic_forces", "auto_graph_atoms", "compact_species", "partition", "partition_skin", "locality_sort"):
             setattr(m, attr, getattr(self, attr))
 
     def atomic_energies(self, species_coordinates, cell=None, pbc=None, charge: int = 0,
