@@ -55,10 +55,10 @@ extern "C" {
 /* Scalar AEV hyper-parameters; replaces the CuaevComputer constructor arguments
  * (csrc/cuaev.cpp:248: Rcr, Rca, EtaR, ShfR, EtaA, Zeta, ShfA, ShfZ, num_species, use_cos_cutoff). */
 typedef struct {
-    int32_t num_species; /* S <= 8 */
-    int32_t n_shf_r;     /* must be 16 */
-    int32_t n_shf_a;     /* n_shf_a * n_shf_z must be 32, both multiples of 4 */
-    int32_t n_shf_z;
+    int32_t num_species; /* S <= 7 */
+    int32_t n_shf_r;     /* <= 32.  16 with an 8 x 4 (ANI-2x) or 4 x 8 (ANI-1x) angular grid: the tuned kernels, with slab */
+    int32_t n_shf_a;     /* <= 16   masks and the forward-mode derivative; any other grid: the general kernels           */
+    int32_t n_shf_z;     /* <= 16   (csrc/aev_generic.hip; cuAEV is templated on these lengths, csrc/aev.cu:1687-1777)    */
     float Rcr, Rca;
     float EtaR, EtaA, Zeta;
     int32_t cutoff_kind; /* ANIHIP_CUTOFF_COSINE | ANIHIP_CUTOFF_SMOOTH (use_cos_cutoff = false) */

@@ -61,11 +61,14 @@ def test_struct_layouts_match_header(lib):
 def test_error_reporting_without_gpu(lib):
     from torchani_amd import _lib
 
-    p = _lib.AevParams(num_species=7, n_shf_r=16, n_shf_a=5, n_shf_z=4, Rcr=5.1, Rca=3.5, EtaR=19.7, EtaA=12.5,
+    # (any grid up to 32 radial shifts and 16 x 16 angular terms is accepted since the general kernels exist)
+    p = _lib.AevParams(num_species=7, n_shf_r=16, n_shf_a=17, n_shf_z=4, Rcr=5.1, Rca=3.5, EtaR=19.7, EtaA=12.5,
                        Zeta=14.1)
     z = np.zeros(_lib.TABLE_FLOATS, dtype=np.float32)
     rc = lib.anihip_aev_table_pack(ctypes.byref(p), z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data)
-    assert rc != 0 and b"8x4 or 4x8" in lib.anihip_last_error()
+    assert rc != 0 and b"n_shf_a <= 16" in lib.anihip_last_error()
+    ok = _lib.AevParams(num_species=7, n_shf_r=16, n_shf_a=5, n_shf_z=4, Rcr=5.1, Rca=3.5, EtaR=19.7, EtaA=12.5, Zeta=14.1)
+    assert lib.anihip_aev_table_pack(ctypes.byref(ok), z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data) == 0
     with pytest.raises(RuntimeError, match="libanihip"):
         _lib.check(rc)
 

@@ -153,6 +153,106 @@ def test_aev_forward_and_backward(dev, name):
         assert np.all(vjp.cpu().numpy()[g["species"] < 0] == 0)
 
 
+GRID_CASES = ["r8_a4z4_batch", "r24_a10z8_pbc", "r5_a3z5_dense"]
+
+
+@pytest.mark.parametrize("name", GRID_CASES)
+def test_general_symmetry_function_grids(dev, name):
+    """AEVComputer.from_constants with grids other than 16 / 8x4 / 4x8 (csrc/aev_generic.hip; the reference's templated
+    cuAEV kernels, csrc/aev.cu:1687-1777): AEV rows and the coordinate gradient of a seeded linear functional against the
+    reference's own numbers (tests/golden/gen_golden_grids.py); the virial and the fixed-point accumulation against the
+    float path; a sharded backward (central atoms lo..hi) adds up to the whole."""
+    from torchani_amd.aev import AEVComputer
+
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"grid_{name}.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    aevc = AEVComputer.from_constants(float(g["Rcr"]), float(g["Rca"]), float(g["EtaR"]), g["ShfR"].tolist(), float(g["EtaA"]),
+                                      float(g["Zeta"]), g["ShfA"].tolist(), g["ShfZ"].tolist(), int(g["num_species"]),
+                                      cutoff_fn=str(g["cutoff_fn"]), row_capacity=256).to(dev)
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev)
+    cell = torch.from_numpy(g["cell"]).to(dev) if "cell" in g else None
+    pbc = torch.from_numpy(g["pbc"]) if "pbc" in g else None
+    w = torch.from_numpy(g["cotangent"]).to(dev)
+    xx = x.clone().requires_grad_(True)
+    aev = aevc(sp, xx, cell, pbc)
+    (vjp,) = torch.autograd.grad((aev * w).sum(), xx)
+    torch.cuda.synchronize()
+    aevc.last_neighbors().raise_on_overflow()
+    err = np.abs(aev.detach().cpu().numpy() - g["aev"]).max()
+    verr = np.abs(vjp.cpu().numpy() - g["aev_vjp"]).max()
+    vmag = np.abs(g["aev_vjp"]).max()
+    report(f"grid  {name:22s} max|aev err| = {err:.2e}   vjp err = {verr:.2e} (|vjp|max {vmag:.1f})")
+    assert err < AEV_TOL * max(1.0, np.abs(g["aev"]).max())
+    assert verr < 2e-5 * max(1.0, vmag)
+    assert np.all(aev.detach().cpu().numpy()[g["species"] < 0] == 0)
+    assert np.all(vjp.cpu().numpy()[g["species"] < 0] == 0)
+    # engine level: virial, fixed point, shards
+    eng = aevc.engine()
+    sp32 = sp.to(torch.int32)
+    pbc_t = None if pbc is None else tuple(bool(b) for b in pbc.tolist())
+    nbrs = eng.neighbors(sp32, x, cell, pbc_t, mode="batch", row_cap=256)
+    n = sp32.numel()
+    wf = w.reshape(n, -1).contiguous()
+    vir = torch.zeros((3, 3), dtype=torch.float64, device=dev)
+    gc = eng.backward(sp32, nbrs, wf, virial=vir)
+    assert float((gc.view_as(vjp) - vjp).abs().max()) < 1e-5 * max(1.0, vmag)
+    # the virial of a translation-invariant scalar: W = sum_k g_k (x) r_k for an isolated system (no images)
+    if cell is None:
+        want = torch.einsum("nk,nb->kb", gc.double(), x.reshape(n, 3).double())
+        assert float((vir - want).abs().max()) < 2e-4 * max(1.0, float(want.abs().max()))
+    acc = torch.zeros((n, 3), dtype=torch.int64, device=dev)
+    eng.backward(sp32, nbrs, wf, grad_coords=acc, fixed_point=True)
+    from torchani_amd.engine import fixed_to_float
+    assert float((fixed_to_float(acc) - gc).abs().max()) < 1e-5 * max(1.0, vmag)
+    tot = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+    for lo, hi in ((0, n // 3), (n // 3, n)):
+        part = eng.neighbors(sp32, x, cell, pbc_t, lo=lo, hi=hi, mode="batch", row_cap=256)
+        a_part = eng.forward(sp32, part, shard_rows=True)
+        assert float((a_part - aev.detach().reshape(n, -1)[lo:hi]).abs().max()) < 1e-6
+        eng.backward(sp32, part, wf[lo:hi].contiguous(), grad_coords=tot, shard_rows=True)
+    assert float((tot - gc).abs().max()) < 1e-5 * max(1.0, vmag)
+
+
+def test_model_on_a_general_grid(dev):
+    """A whole potential -- neighbor rows, general-grid AEVs, 3-member ensemble, analytic forces, self energies -- assembled
+    from AEVComputer.from_constants with an 8 / 4x4 grid (192 columns) against the fp64 oracle: the networks take the
+    dense layer-0 path (no slab structure), the AEV kernels the general ones."""
+    from oracle import oracle as orc
+    from oracle.oracle import Oracle
+
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.models import ANI
+    from torchani_amd.nn import ANINetworks, Ensemble
+
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grid_r8_a4z4_batch.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    symbols = ("H", "C", "N", "O")
+    aevc = AEVComputer.from_constants(float(g["Rcr"]), float(g["Rca"]), float(g["EtaR"]), g["ShfR"].tolist(), float(g["EtaA"]),
+                                      float(g["Zeta"]), g["ShfA"].tolist(), g["ShfZ"].tolist(), 4, row_capacity=256)
+    hidden = {"H": (64, 48, 32), "C": (64, 32, 32), "N": (32, 32, 32), "O": (48, 32, 32)}
+    torch.manual_seed(7)
+    nets = Ensemble([ANINetworks.build(symbols, aevc.out_dim, hidden) for _ in range(3)])
+    sae = [-0.5, -37.8, -54.6, -75.0]
+    model = ANI(symbols, aevc, nets, sae, periodic_table_index=False).to(dev)
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev)
+    out = model.energies_and_forces(sp, x)
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    dims, flat = orc.pack_networks(sd, symbols, 3)
+    p = orc.make_params(4, float(g["Rcr"]), float(g["Rca"]), float(g["EtaR"]), float(g["EtaA"]), float(g["Zeta"]),
+                        g["ShfR"].tolist(), g["ShfA"].tolist(), g["ShfZ"].tolist(), "cosine")
+    ref = Oracle("f64").energy_forces(p, g["species"], g["coords"], dims, flat, 3, sae=np.asarray(sae))
+    assert np.abs(out.atomic_energies.cpu().numpy() - ref["atomic_energies"]).max() < E_ATOM_TOL
+    assert np.abs(out.forces.cpu().numpy() - ref["forces"]).max() < F_TOL
+    assert np.abs(out.energies.cpu().numpy() - ref["energies"]).max() < 1e-5
+    # the same through autograd
+    from torchani_amd.grad import energies_and_forces
+    e, f = energies_and_forces(model, sp, x)
+    assert np.abs(f.cpu().numpy() - ref["forces"]).max() < F_TOL
+
+
 NBR_CASES = ["simple2_ani2x", "rand_batch_ani2x", "water_pbc_ani2x", "triclinic_pbc_ani2x", "small_ani2x",
              "ch4_ani1x"]
 

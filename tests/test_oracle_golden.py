@@ -3,6 +3,8 @@
 The fixtures in tests/golden were written by tests/golden/gen_golden.py, which imports the reference
 (fp64, pyaev) -- so agreement here to ~1e-12 means the C restatement IS the reference's arithmetic.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -137,3 +139,26 @@ def test_f32_port_close_to_f64(oracle64):
     out = o32.energy_forces(p, g["species"], g["coords"], dims, flat, 8, sae=sae)
     assert np.abs(out["atomic_energies"] - g["atomic_energies"]).max() < 2e-5
     assert np.abs(out["forces"] - g["forces"]).max() < 2e-5
+
+
+GRID_CASES = ["r8_a4z4_batch", "r24_a10z8_pbc", "r5_a3z5_dense"]
+
+
+def load_grid(name):
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"grid_{name}.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize("name", GRID_CASES)
+def test_oracle_on_general_grids(oracle64, name):
+    """Symmetry-function grids other than the published ones (AEVComputer.from_constants, aev/_computer.py:602-666; the
+    templated cuAEV kernels, csrc/aev.cu:1687-1777): the oracle against the reference's own AEVs and vector-Jacobian
+    products (tests/golden/gen_golden_grids.py) -- this pins the checker of the general HIP kernels."""
+    from oracle import oracle as orc
+
+    g = load_grid(name)
+    p = orc.make_params(int(g["num_species"]), float(g["Rcr"]), float(g["Rca"]), float(g["EtaR"]), float(g["EtaA"]),
+                        float(g["Zeta"]), g["ShfR"].tolist(), g["ShfA"].tolist(), g["ShfZ"].tolist(), str(g["cutoff_fn"]))
+    aev, vjp = oracle64.aev(p, g["species"], g["coords"], g.get("cell"), g.get("pbc"), grad_aev=g["cotangent"].astype(np.float64))
+    assert np.abs(aev - g["aev"]).max() < 2e-12 * max(1.0, np.abs(g["aev"]).max())
+    assert np.abs(vjp - g["aev_vjp"]).max() < 2e-11 * max(1.0, np.abs(g["aev_vjp"]).max())

@@ -14,7 +14,7 @@ import typing as tp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TORCHANI_AMD_LIB") or os.path.join(_HERE, "libanihip.so")
-SOURCES = ["api.hip", "nbr.hip", "aev.hip", "mlp.hip", "pair.hip", "pack.hip"]
+SOURCES = ["api.hip", "nbr.hip", "aev.hip", "aev_generic.hip", "mlp.hip", "pair.hip", "pack.hip"]
 HEADERS = ["anihip_common.h", os.path.join("..", "..", "include", "anihip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared"]
 

@@ -1385,6 +1385,19 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
     }
 }
 
+// any other grid: aev_generic.hip
+int aev_forward_generic(hipStream_t stream, const anihip_aev_params *p, const float *table, int64_t lo, int64_t hi,
+                        const int32_t *species, const uint32_t *meta, const float *ent, float *aev);
+int aev_backward_generic(hipStream_t stream, const anihip_aev_params *p, const float *table, int64_t lo, int64_t hi,
+                         const int32_t *species, const uint32_t *meta, const float *ent, const float *grad_aev,
+                         float *grad_coords, double *virial, bool fixed);
+
+// the grids the tuned kernels are built for: 16 radial shifts, 8 x 4 (ANI-2x) or 4 x 8 (ANI-1x) angular terms
+static bool tuned_grid(const anihip_aev_params *p)
+{
+    return p->n_shf_r == 16 && ((p->n_shf_a == 8 && p->n_shf_z == 4) || (p->n_shf_a == 4 && p->n_shf_z == 8));
+}
+
 }  // namespace anihip
 
 using namespace anihip;
@@ -1393,9 +1406,10 @@ extern "C" int anihip_aev_table_pack(anihip_aev_params *p, const float *ShfR, co
                                      const float *ShfZ, float *t)
 {
     ANIHIP_REQUIRE(p && ShfR && ShfA && ShfZ && t, "null pointer argument");
-    ANIHIP_REQUIRE(p->n_shf_r == 16, "n_shf_r must be 16 (got %d)", p->n_shf_r);
-    ANIHIP_REQUIRE(p->n_shf_a * p->n_shf_z == 32 && p->n_shf_a % 4 == 0 && p->n_shf_z % 4 == 0,
-                   "n_shf_a x n_shf_z must be 8x4 or 4x8 (got %dx%d)", p->n_shf_a, p->n_shf_z);
+    ANIHIP_REQUIRE(p->n_shf_r >= 1 && p->n_shf_r <= 32 && p->n_shf_a >= 1 && p->n_shf_a <= 16 && p->n_shf_z >= 1 &&
+                       p->n_shf_z <= 16,
+                   "symmetry-function grid outside n_shf_r <= 32, n_shf_a <= 16, n_shf_z <= 16 (got %d, %d x %d)",
+                   p->n_shf_r, p->n_shf_a, p->n_shf_z);
     for (int k = 0; k < ANIHIP_AEV_TABLE_FLOATS; ++k) t[k] = 0.f;
     for (int k = 0; k < p->n_shf_r; ++k) t[TAB_SHFR + k] = ShfR[k];
     for (int k = 0; k < p->n_shf_a; ++k) t[TAB_SHFA + k] = ShfA[k];
@@ -1403,6 +1417,8 @@ extern "C" int anihip_aev_table_pack(anihip_aev_params *p, const float *ShfR, co
         t[TAB_COSZ + k] = (float)cos((double)ShfZ[k]);
         t[TAB_SINZ + k] = (float)sin((double)ShfZ[k]);
     }
+    p->flags = 0;
+    if (!tuned_grid(p)) return 0;   // (the general kernels read the plain shifts)
     // pre-scaled copies (wave-uniform operands of the kernels stay in scalar registers)
     const float qR = sqrtf(p->EtaR * LOG2E), qA = sqrtf(p->EtaA * LOG2E);
     for (int k = 0; k < p->n_shf_r; ++k) t[TAB_SHFRQ + k] = qR * ShfR[k];
@@ -1413,7 +1429,6 @@ extern "C" int anihip_aev_table_pack(anihip_aev_params *p, const float *ShfR, co
     }
     // Gaussian recurrence of the forward pair loop (k_aev_fwd3): equally spaced ShfA, and exponents inside fp32's range
     // for every scaled mean distance 0 .. qA Rca the kernel can meet
-    p->flags = 0;
     {
         const int n = p->n_shf_a, c = n / 2 - 1;
         const float D = t[TAB_SHFAQ + 1] - t[TAB_SHFAQ];
@@ -1464,6 +1479,10 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     ANIHIP_REQUIRE(!slab_mask || (p->num_species + 1) / 2 + p->num_species * (p->num_species + 1) / 2 <= 32,
                    "slab_mask needs at most 32 slabs (num_species <= 7)");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    if (!tuned_grid(p)) {
+        ANIHIP_REQUIRE(!slab_mask, "slab masks exist for the 16 / 8x4 / 4x8 grids only");
+        return aev_forward_generic((hipStream_t)stream, p, table, lo, hi, species, meta, ent, aev);
+    }
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
     if (hi == lo) return 0;
@@ -1489,6 +1508,7 @@ extern "C" int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const fl
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && tangent && daev, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    ANIHIP_REQUIRE(tuned_grid(p), "the forward-mode derivative is built for the 16 / 8x4 / 4x8 grids only");
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
     if (hi == lo) return 0;
@@ -1511,6 +1531,12 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && grad_aev && grad_coords, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    if (!tuned_grid(p)) {
+        ANIHIP_REQUIRE(!slab_mask, "slab masks exist for the 16 / 8x4 / 4x8 grids only");
+        if (virial) zero_words_async((hipStream_t)stream, virial, 9 * sizeof(double));
+        return aev_backward_generic((hipStream_t)stream, p, table, lo, hi, species, meta, ent, grad_aev, grad_coords, virial,
+                                    (flags & ANIHIP_BWD_FIXED_POINT) != 0);
+    }
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
     if (virial) zero_words_async((hipStream_t)stream, virial, 9 * sizeof(double));

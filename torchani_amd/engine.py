@@ -98,10 +98,13 @@ class AevEngine:
             raise ValueError(f"Unsupported cutoff function {consts.cutoff_fn!r}: the HIP kernels have "
                              f"{sorted(_lib.CUTOFF_KINDS)}")
         p.cutoff_kind = _lib.CUTOFF_KINDS[consts.cutoff_fn]
-        if p.n_shf_r != 16 or (p.n_shf_a, p.n_shf_z) not in ((8, 4), (4, 8)) or not 1 <= p.num_species <= 7:
+        if not (1 <= p.n_shf_r <= 32 and 1 <= p.n_shf_a <= 16 and 1 <= p.n_shf_z <= 16 and 1 <= p.num_species <= 7):
             raise ValueError(
-                "HIP AEV kernels support 16 radial shifts, 8x4 (ANI-2x) or 4x8 (ANI-1x) angular grids and "
-                f"up to 7 species; got nR={p.n_shf_r}, nA x nZ={p.n_shf_a}x{p.n_shf_z}, S={p.num_species}")
+                "HIP AEV kernels support up to 32 radial shifts, angular grids up to 16 x 16 and up to 7 species; "
+                f"got nR={p.n_shf_r}, nA x nZ={p.n_shf_a}x{p.n_shf_z}, S={p.num_species}")
+        # the published grids (16 radial shifts, 8x4 = ANI-2x or 4x8 = ANI-1x angular terms) run through the tuned kernels
+        # with slab masks and the forward-mode derivative; any other grid through the general kernels (csrc/aev_generic.hip)
+        self.tuned = p.n_shf_r == 16 and (p.n_shf_a, p.n_shf_z) in ((8, 4), (4, 8))
         self.params = p
         self.L = consts.out_dim
         self._host_table: tp.Optional[np.ndarray] = None
@@ -244,6 +247,8 @@ class AevEngine:
     @property
     def n_slabs(self) -> int:
         """Number of 32-wide slabs of an AEV row in slab order (include/anihip.h)."""
+        if not self.tuned:
+            return 1 << 30   # (no slab structure: nobody may ask for masks)
         S = self.params.num_species
         return (S + 1) // 2 + S * (S + 1) // 2
 
