@@ -1,3 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/i_tests.log
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/i_tests.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/i_smoke.log 2>&1
