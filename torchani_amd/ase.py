@@ -56,8 +56,14 @@ class Calculator(_Base):
     def calculate(self, atoms=None, properties=("energy",), system_changes=all_changes) -> None:
         super().calculate(atoms, properties, system_changes)
         assert self.atoms is not None
-        species = torch.as_tensor(np.asarray(self.atoms.get_atomic_numbers()), dtype=torch.long,
-                                  device=self.device).unsqueeze(0)
+        # the SAME species tensor for as long as the atomic numbers stay the same: the model keeps per-system decisions
+        # (species numbering, tile hints, atom-order probe, HIP graphs of small systems) tied to that tensor
+        numbers = np.asarray(self.atoms.get_atomic_numbers())
+        held = self.__dict__.get("_species_held")
+        if held is None or held[0].shape != numbers.shape or not np.array_equal(held[0], numbers):
+            held = (numbers.copy(), torch.as_tensor(numbers, dtype=torch.long, device=self.device).unsqueeze(0))
+            self.__dict__["_species_held"] = held
+        species = held[1]
         coords = torch.as_tensor(np.asarray(self.atoms.get_positions()), dtype=torch.float32, device=self.device)
         cell_obj = self.atoms.get_cell(complete=True)
         cell = torch.as_tensor(np.asarray(getattr(cell_obj, "array", cell_obj)), dtype=torch.float32,
