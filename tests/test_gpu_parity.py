@@ -690,6 +690,18 @@ def test_present_species_first_relabelling(dev):
             e += part.energies
             f += part.forces
         assert float((f - ref.forces).abs().max()) < 2e-6 and abs(float(e - ref.energies)) < 1e-7 * sp.numel()
+        # three elements spread over three radial slabs (H, N, Cl -> two slabs), with padding atoms in the system
+        sp3 = torch.where(sp == 0, 0, 2)
+        sp3[0, ::7] = 6
+        sp3[0, 5::97] = -1
+        model.compact_species = False
+        ref3 = model.energies_and_forces(sp3, x, cell, pbc)
+        model.compact_species = True
+        assert model._engine_species(sp3.to(torch.int32))[1] == (0, 2, 6, 1, 3, 4, 5)
+        out3 = model.energies_and_forces(sp3, x, cell, pbc)
+        assert float((out3.forces - ref3.forces).abs().max()) < 2e-6
+        assert float((out3.atomic_energies - ref3.atomic_energies).abs().max()) < 5e-7
+        assert bool((out3.forces[sp3 < 0] == 0).all()) and bool((out3.atomic_energies[sp3 < 0] == 0).all())
         # a HIP graph of the step owns its relabelled species (and the matching weight pack): replays agree, also after
         # another system has taken the model's species cache
         graph = model.graphed(sp, x, cell, pbc)
