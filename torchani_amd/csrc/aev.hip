@@ -22,6 +22,20 @@
 
 namespace anihip {
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b mod 8) and every XCD has its own L2: with
+// "workgroup b takes atoms 4 b .. 4 b + 3" the neighbors that consecutive atoms share are fetched into all eight L2s.
+// Remapped, the workgroups of one XCD take a contiguous run of atoms in every sweep of the grid.
+__device__ __forceinline__ int xcd_block()
+{
+#ifdef ANIHIP_NO_XCD_MAP
+    return (int)blockIdx.x;
+#else
+    const int nb = (int)gridDim.x;
+    if (nb & 7) return (int)blockIdx.x;
+    return ((int)blockIdx.x & 7) * (nb >> 3) + ((int)blockIdx.x >> 3);
+#endif
+}
+
 constexpr int FWD_WPB = 4;
 constexpr int BWD_WPB = 4;
 constexpr int STAGE_FLOATS = 1024;  // >= L (S<=7: 1008)
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, JVP ? 4 : 7) void k_aev_fwd(
     const int rad_o = row * 8 + rsq;
 
     const int64_t nw = (int64_t)gridDim.x * FWD_WPB;
-    int64_t i = lo + blockIdx.x * (int64_t)FWD_WPB + wib;
+    int64_t i = lo + xcd_block() * (int64_t)FWD_WPB + wib;
     // software pipeline over atoms: header of atom i+nw and the first 128 entries of atom i+nw are in
     // flight while atom i is being computed
     uint32_t hw = hdr_load(meta, species, i, i < hi);
@@ -649,7 +663,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
     const int rslabs = (a.S + 1) >> 1;
 
     const int64_t nw = (int64_t)gridDim.x * FWD_WPB;
-    int64_t i = lo + blockIdx.x * (int64_t)FWD_WPB + wib;
+    int64_t i = lo + xcd_block() * (int64_t)FWD_WPB + wib;
     uint32_t hw = hdr_load(meta, species, i, i < hi);
     AtomHdr hd = hdr_decode(hw);
     const float4 dummy4 = make_float4(1.f, 0.f, 0.f, 0.f);
@@ -1091,7 +1105,7 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
     };
 
     const int nw = (int)gridDim.x * BWD_WPB;
-    int i = lo + (int)blockIdx.x * BWD_WPB + wib;
+    int i = lo + xcd_block() * BWD_WPB + wib;
     // software pipeline over atoms: the header, the first 128 neighbor entries and the needed blocks of the dE/dAEV
     // row of atom i+nw are in flight while atom i is processed
     uint32_t hw = hdr_load(meta, species, i, i < hi);
