@@ -211,3 +211,61 @@ def test_skin_keeps_the_partition_valid_while_atoms_move():
     have = torch.zeros(n, dtype=torch.bool)
     have[part.local_idx] = True
     assert bool(have[near.any(dim=0)].all())
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_boxes_cells_and_pbc(seed):
+    """Randomised sweep over sizes (1 .. 600 atoms), world sizes, open / periodic / MIXED boundary conditions, triclinic cells
+    (a periodic cell vector leaning along an open axis is what made Cartesian slabs wrong), planar systems, padding atoms
+    and skins: every atom is owned once, every neighbor of an owned atom -- through any periodic image -- is in the local
+    system, padding atoms are in nobody's halo."""
+    from torchani_amd.parallel import SpatialShards
+
+    rs = np.random.RandomState(seed)
+    for trial in range(120):
+        n = int(rs.choice([1, 2, 3, 7, 40, 200, 600]))
+        world = int(rs.choice([1, 2, 3, 5, 8]))
+        rc = float(rs.choice([2.0, 5.1]))
+        skin = float(rs.choice([0.0, 0.0, 1.0]))
+        if rs.rand() < 0.6:
+            L = rs.uniform(2 * rc + 0.5, 30.0, 3)
+            cell = np.diag(L)
+            if rs.rand() < 0.5:
+                cell[1, 0] = rs.uniform(-0.3, 0.3) * L[0]
+                cell[2, 0] = rs.uniform(-0.3, 0.3) * L[0]
+                cell[2, 1] = rs.uniform(-0.3, 0.3) * L[1]
+            x = rs.uniform(-0.2, 1.2, (n, 3)) @ cell
+            pbc = tuple(bool(b) for b in (rs.rand(3) < 0.7)) if rs.rand() < 0.5 else (True, True, True)
+            pbc = pbc if any(pbc) else (True, True, True)
+        else:
+            cell, pbc = None, None
+            ext = rs.uniform(0.0, 25.0, 3)
+            if rs.rand() < 0.2:
+                ext[rs.randint(3)] = 0.0
+            x = rs.uniform(0, 1, (n, 3)) * ext
+        sp = rs.randint(0, 4, n)
+        if rs.rand() < 0.4 and n > 2:
+            sp[rs.rand(n) < 0.2] = -1
+        xt = torch.from_numpy(x.astype(np.float32))
+        ct = None if cell is None else torch.from_numpy(cell.astype(np.float32))
+        parts = [SpatialShards(xt, ct, pbc, world, r, rc, species=torch.from_numpy(sp), skin=skin) for r in range(world)]
+        assert sorted(torch.cat([p.owned_idx for p in parts]).tolist()) == list(range(n))
+        shifts = [np.zeros(3)]
+        if cell is not None:
+            rng = [(-1, 0, 1) if pbc[k] else (0,) for k in range(3)]
+            shifts = [a * cell[0] + b * cell[1] + c * cell[2] for a in rng[0] for b in rng[1] for c in rng[2]]
+        real = sp >= 0
+        for p in parts:
+            have = np.zeros(n, bool)
+            have[p.local_idx.numpy()] = True
+            own = p.owned_idx.numpy()
+            own = own[real[own]]
+            if own.size == 0:
+                continue
+            near = np.zeros(n, bool)
+            for sh in shifts:
+                d = x[None, :, :] + sh[None, None, :] - x[own][:, None, :]
+                near |= ((d * d).sum(-1) <= rc * rc).any(axis=0)
+            assert have[near & real].all(), (trial, n, world, pbc)
+            halo = np.concatenate([p.local_idx[:p.n_left].numpy(), p.local_idx[p.n_left + p.n_owned:].numpy()])
+            assert real[halo].all()

@@ -156,25 +156,34 @@ class SpatialShards:
         self.n, self.world, self.rank, self.cutoff, self.skin = n, world, rank, float(cutoff), float(skin)
         reach = self.cutoff + self.skin
         periodic = [bool(b) for b in pbc] if (pbc is not None and cell is not None) else [False, False, False]
-        # ---- geometry of the box on the host (9 + 6 numbers: the first of the two host syncs of a partition) ----
-        mm = torch.aminmax(x, dim=0)
-        head = torch.cat([(cell.detach().to(device=dev, dtype=torch.float32).reshape(-1) if cell is not None
-                           else torch.zeros(9, device=dev)), mm.min, mm.max]).cpu().to(torch.float64)
-        lo_c, hi_c = head[9:12], head[12:15]
-        ext = (hi_c - lo_c).tolist()
-        depth = [0.0, 0.0, 0.0]
-        rec = torch.zeros((3, 3), dtype=torch.float64)
+        # ---- coordinates the slabs and cells are cut in ----
+        # With a cell: FRACTIONAL coordinates f_k = x . b_k (b_k: reciprocal vectors) for all three axes, periodic or not --
+        # f_k does not change under a translation by the OTHER cell vectors, so the periodic images of an atom stay in its
+        # layer (a Cartesian slab axis would not do when a periodic cell vector leans along it), and two atoms are at least
+        # |delta f_k| x (spacing of the lattice planes) apart.  Without one: Cartesian axes.
+        depth = [1.0, 1.0, 1.0]
         if cell is not None and any(periodic):
-            c64 = head[:9].reshape(3, 3)
-            # fractional coordinates x = f C  ->  f_k = x . (reciprocal vector k); closed form for 3 x 3 (no solver library)
+            c64 = cell.detach().to(torch.float64).cpu().reshape(3, 3)   # (host read of nine numbers)
+            # x = f C  ->  f_k = x . (reciprocal vector k); closed form for 3 x 3 (no solver library)
             cr = torch.stack([torch.linalg.cross(c64[1], c64[2]), torch.linalg.cross(c64[2], c64[0]),
                               torch.linalg.cross(c64[0], c64[1])])
             det = float((c64[0] * cr[0]).sum())
             rec = cr / det
             # spacing of the lattice planes along each axis: volume / area of the face spanned by the other two vectors
             depth = (abs(det) / torch.linalg.norm(cr, dim=1)).tolist()
-        # the slab axis: the deepest periodic axis of the cell, else the longest edge of the bounding box
-        length = [depth[k] if periodic[k] else ext[k] for k in range(3)]
+            f = x @ rec.T.to(device=dev, dtype=torch.float32)
+        else:
+            periodic = [False, False, False]
+            f = x
+        lo_f, ext_f = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+        if not all(periodic):   # (bounding box of the open axes: a host read of six numbers)
+            mm = torch.aminmax(f, dim=0)
+            mn, mx = mm.min.cpu().to(torch.float64).tolist(), mm.max.cpu().to(torch.float64).tolist()
+            for k in range(3):
+                if not periodic[k]:
+                    lo_f[k], ext_f[k] = mn[k], max(mx[k] - mn[k], 1e-9)
+        # the slab axis: the one along which the system is deepest
+        length = [depth[k] * ext_f[k] for k in range(3)]
         axis = max(range(3), key=lambda k: length[k])
         self.axis, self.periodic = axis, periodic[axis]
         # Sort key: layers of a quarter cutoff along the slab axis, and inside a layer cells of about one cutoff along the other
@@ -185,17 +194,13 @@ class SpatialShards:
         for k in range(3):
             width = 0.25 * self.cutoff if k == axis else self.cutoff
             nb[k] = int(max(1, min(1 << 10 if k != axis else 1 << 20, length[k] // max(width, 1e-6))))
-        # unit coordinates of all three axes in ONE matrix product: u = x A + t, periodic axes wrapped into [0, 1)
-        A = torch.zeros((3, 3), dtype=torch.float64)
-        t = torch.zeros(3, dtype=torch.float64)
-        for k in range(3):
-            if periodic[k]:
-                A[:, k] = rec[k]
-            else:
-                A[k, k] = 1.0 / max(ext[k], 1e-9)
-                t[k] = -float(lo_c[k]) / max(ext[k], 1e-9)
-        u = x @ A.to(device=dev, dtype=torch.float32) + t.to(device=dev, dtype=torch.float32)
+        while nb[0] * nb[1] * nb[2] >= 1 << 31:   # (32-bit keys; a system a hundred kilometres long gets coarser cells)
+            k = max((k for k in range(3) if k != axis), key=lambda k: nb[k])
+            k = k if nb[k] > 1 else axis
+            nb[k] = (nb[k] + 1) // 2
+        # unit coordinates: periodic axes wrapped into [0, 1), open axes scaled by their bounding box
         per = torch.tensor(periodic, device=dev)
+        u = (f - torch.tensor(lo_f, device=dev, dtype=torch.float32)) / torch.tensor(ext_f, device=dev, dtype=torch.float32)
         u = torch.where(per, u - torch.floor(u), u).clamp_(0.0, 1.0 - 1e-6)
         nbt = torch.tensor(nb, device=dev, dtype=torch.float32)
         kk = (u * nbt).to(torch.int32)
