@@ -269,3 +269,22 @@ def test_random_boxes_cells_and_pbc(seed):
             assert have[near & real].all(), (trial, n, world, pbc)
             halo = np.concatenate([p.local_idx[:p.n_left].numpy(), p.local_idx[p.n_left + p.n_owned:].numpy()])
             assert real[halo].all()
+        # the exchange, emulated without a process group: what every rank pushed onto an atom arrives at its owner
+        if world > 1:
+            H = parts[0].halo_rows_max
+            rows = [torch.from_numpy(rs.normal(size=(p.n_local, 3)).astype(np.float32)) for p in parts]
+            want = torch.zeros(n, 3)
+            gathered = []
+            for p, rw in zip(parts, rows):
+                want.index_add_(0, p.local_idx, rw)
+                send = torch.zeros(H, 3)
+                send[:p.n_left] = rw[:p.n_left]
+                send[p.n_left:p.n_left + p.n_right] = rw[p.n_left + p.n_owned:]
+                gathered.append(send)
+            gathered = torch.cat(gathered)
+            for p, rw in zip(parts, rows):
+                assert p.messages == parts[0].messages
+                out = rw.clone()
+                if p.recv_src.numel():
+                    out.index_add_(0, p.recv_dst, gathered[p.recv_src])
+                assert torch.allclose(out[p.n_left:p.n_left + p.n_owned], want[p.owned_idx], atol=1e-5)
