@@ -214,6 +214,65 @@ def test_general_symmetry_function_grids(dev, name):
     assert float((tot - gc).abs().max()) < 1e-5 * max(1.0, vmag)
 
 
+def test_general_grids_random_sweep(dev):
+    """Randomised grids (1 .. 32 radial shifts, angular grids 1x1 .. 16x16, 1 .. 7 species, both envelopes), dense and sparse
+    clusters and periodic boxes: AEV rows and the gradient of a seeded functional from csrc/aev_generic.hip against the fp64
+    oracle (which is pinned to the reference on general grids by tests/test_oracle_golden.py)."""
+    from oracle import oracle as orc
+    from oracle.oracle import Oracle
+
+    from torchani_amd.aev import AEVComputer
+
+    o64 = Oracle("f64")
+    rs = np.random.RandomState(31)
+    for trial in range(24):
+        S = int(rs.randint(1, 8))
+        nR, nA, nZ = int(rs.choice([1, 3, 8, 16, 17, 32])), int(rs.choice([1, 2, 5, 8, 16])), int(rs.choice([1, 3, 4, 9, 16]))
+        if (nR, nA, nZ) in ((16, 8, 4), (16, 4, 8)):
+            nR = 8   # (the published grids take the tuned kernels: tested elsewhere)
+        Rcr, Rca = float(rs.uniform(3.5, 5.5)), float(rs.uniform(2.5, 3.5))
+        EtaR, EtaA, Zeta = float(rs.uniform(4, 25)), float(rs.uniform(4, 15)), float(rs.choice([1.0, 8.0, 14.1, 32.0]))
+        ShfR = np.linspace(0.8, Rcr - 0.3, nR).astype(np.float32)
+        ShfA = np.linspace(0.8, Rca - 0.3, nA).astype(np.float32)
+        ShfZ = ((np.arange(nZ) + 0.5) * np.pi / nZ).astype(np.float32)
+        cut = "smooth" if rs.rand() < 0.4 else "cosine"
+        C, A = (1, int(rs.choice([2, 30, 70]))) if rs.rand() < 0.6 else (3, 14)
+        box = float(rs.uniform(3.0, 7.0)) if A < 50 else 5.5
+        x = np.zeros((C, A, 3), dtype=np.float32)
+        sp = rs.randint(0, S, (C, A)).astype(np.int32)
+        for c in range(C):
+            pts = []
+            while len(pts) < A:
+                q = rs.uniform(0, box, 3)
+                if all(np.linalg.norm(q - w_) > 0.7 for w_ in pts):
+                    pts.append(q)
+            x[c] = np.asarray(pts, dtype=np.float32)
+        if C > 1:
+            sp[1, A - 3:] = -1
+        cell = pbc = None
+        if C == 1 and rs.rand() < 0.5:
+            cell = (np.eye(3) * max(box, 2 * Rcr + 0.2)).astype(np.float32)
+            cell[1, 0] = 0.7
+            pbc = (True, True, bool(rs.rand() < 0.5))
+        aevc = AEVComputer.from_constants(Rcr, Rca, EtaR, ShfR.tolist(), EtaA, Zeta, ShfA.tolist(), ShfZ.tolist(), S,
+                                          cutoff_fn=cut, row_capacity=256).to(dev)
+        p = orc.make_params(S, np.float32(Rcr), np.float32(Rca), EtaR, EtaA, Zeta, ShfR.tolist(), ShfA.tolist(), ShfZ.tolist(), cut)
+        L = aevc.out_dim
+        w = rs.uniform(-1, 1, (C, A, L)).astype(np.float32)
+        ref_aev, ref_vjp = o64.aev(p, sp, x, cell, pbc, grad_aev=w.astype(np.float64))
+        xx = torch.from_numpy(x).to(dev).requires_grad_(True)
+        cell_t = None if cell is None else torch.from_numpy(cell).to(dev)
+        pbc_t = None if pbc is None else torch.tensor(pbc)
+        aev = aevc(torch.from_numpy(sp.astype(np.int64)).to(dev), xx, cell_t, pbc_t)
+        (vjp,) = torch.autograd.grad((aev * torch.from_numpy(w).to(dev)).sum(), xx)
+        torch.cuda.synchronize()
+        aevc.last_neighbors().raise_on_overflow()
+        scale_a, scale_v = max(1.0, np.abs(ref_aev).max()), max(1.0, np.abs(ref_vjp).max())
+        err = np.abs(aev.detach().cpu().numpy() - ref_aev).max() / scale_a
+        verr = np.abs(vjp.cpu().numpy() - ref_vjp).max() / scale_v
+        assert err < AEV_TOL and verr < 3e-5, (trial, S, nR, nA, nZ, cut, C, A, pbc, err, verr)
+
+
 def test_model_on_a_general_grid(dev):
     """A whole potential -- neighbor rows, general-grid AEVs, 3-member ensemble, analytic forces, self energies -- assembled
     from AEVComputer.from_constants with an 8 / 4x4 grid (192 columns) against the fp64 oracle: the networks take the
@@ -1765,6 +1824,37 @@ def test_headline_scale_sampled_parity(dev):
     assert res["max_dE_atom"] < E_ATOM_TOL and res["max_dF"] < F_TOL
     del out
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("elements", [(0, 1), (0, 3), (1, 2, 3), (0, 2, 6), (0, 1, 2, 3), (2, 4, 5, 6), (0, 1, 2, 3, 4, 5, 6)])
+def test_large_systems_of_any_composition_against_the_oracle(dev, elements):
+    """The large-system product path -- 256-row tiles, slab masks, skinny layer-0 backward with 2 .. 6+ flagged slabs (the
+    4-slab case multiplied a stale register until round 3), species numbered present-ones-first, the spatial path -- on a
+    17 496-atom periodic box whose atoms are given the listed elements at random: sampled atoms against the fp64 oracle on
+    the clusters around them; shuffled and sharded evaluation agree with it."""
+    from bench import water_box
+    from oracle.sampled_parity import sampled_parity
+
+    sp_np, x_np, cell_np = water_box(18)
+    rs = np.random.RandomState(sum(elements))
+    sp_np = rs.choice(np.asarray(elements), size=sp_np.shape).astype(sp_np.dtype)
+    model = get_model("ani2x", 29, dev, neighborlist="cell", row_capacity=192)
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    pbc = (True, True, True)
+    out = model.energies_and_forces(sp, x, cell, pbc, check_overflow=True)
+    res = sampled_parity(sp, x, cell, out.atomic_energies, out.forces, seeded_state("ani2x", 8, 29), "ani2x", 8,
+                         n_sample=24, seed=5)
+    report(f"box   elements {elements} {sp.numel()} atoms: max|e_atom err| = {res['max_dE_atom']:.2e}  max|F err| = {res['max_dF']:.2e}")
+    # (element soups on water coordinates have forces of tens of Ha/A: gates relative to the largest force)
+    fmax = max(1.0, float(out.forces.abs().max()))
+    assert res["max_dE_atom"] < E_ATOM_TOL * max(1.0, float(out.atomic_energies.abs().max())) and res["max_dF"] < F_TOL * fmax
+    e = torch.zeros(1, dtype=torch.float64, device=dev)
+    f = torch.zeros_like(x)
+    for rank in range(3):
+        part = model.energies_and_forces(sp, x, cell, pbc, shard=(rank, 3))
+        e += part.energies
+        f += part.forces
+    assert float((f - out.forces).abs().max()) < 5e-6 * fmax and abs(float(e - out.energies)) < 1e-7 * sp.numel() * fmax
 
 
 def _canonical_pairs(idx, diff):
