@@ -673,7 +673,8 @@ def test_skinny_layer0_backward_for_every_slab_count(dev, pair):
     assert torch.equal(got["skinny"][1], got["rows"][1])
 
 
-def test_locality_sort_of_a_shuffled_system(dev):
+@pytest.mark.parametrize("periodic", [True, False])
+def test_locality_sort_of_a_shuffled_system(dev, periodic):
     """ANI.locality_sort = "auto": a large single system given in an incoherent atom order is evaluated on a cell-sorted
     copy (spatial machinery with one rank) -- same energies and forces, atom by atom, as the coherent order gives; a
     lattice-ordered input is left alone."""
@@ -685,6 +686,8 @@ def test_locality_sort_of_a_shuffled_system(dev):
     sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
     sp_s, x_s = torch.from_numpy(sp_np[:, perm]).to(dev), torch.from_numpy(np.ascontiguousarray(x_np[:, perm])).to(dev)
     pbc = (True, True, True)
+    if not periodic:   # (a droplet: no cell, open boundaries)
+        cell, pbc = None, None
     model = get_model("ani2x", 0, dev, neighborlist="cell", row_capacity=192)   # (its own instance)
     try:
         model.locality_sort = "never"
