@@ -304,7 +304,7 @@ class ANI(torch.nn.Module):
         key_tensor: the caller's own species tensor (any dtype) the cache entry is tied to, like _tile_hint."""
         n = species32.numel()
         key_tensor = species32 if key_tensor is None else key_tensor
-        if (not self.compact_species or n < 16384 or self.aev_computer.verlet is not None
+        if (not self.compact_species or n < 16384
                 or any(k != "nnp" and p._enabled for k, p in self.potentials.items())):
             return species32, None
         if torch.cuda.is_current_stream_capturing():
