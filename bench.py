@@ -145,6 +145,7 @@ def main():
                          "the collective -- prints ms/step and exits")
     ap.add_argument("--partition-skin", type=float, default=1.0,
                     help="N > 1: skin (Angstrom) of the spatial shards' halos; the partition is reused until an atom moved skin/2")
+    ap.add_argument("--mlp-chunk", type=int, default=0, help="development aid: atoms per launch group of the network stage")
     ap.add_argument("--shuffle", action="store_true",
                     help="permute the atom order of the box (the spatial shards must not depend on it)")
     args = ap.parse_args()
@@ -176,6 +177,8 @@ def main():
     # atom has moved 0.5 A (the coordinates of this bench are static, so it is cut once, in warmup; the cost of cutting it
     # is reported as collective.partition_ms)
     model.partition_skin = args.partition_skin
+    if args.mlp_chunk > 0:
+        model.mlp_chunk = args.mlp_chunk
 
     def step():
         # (overflow is checked once after the timed loop instead of with a host sync per step).  N > 1: spatial shards,

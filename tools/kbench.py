@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--stages", default="nbr,fwd,bwd,mlp")
     ap.add_argument("--mask", default="both", choices=["on", "off", "both"], help="slab masks in the mlp stage")
-    ap.add_argument("--chunk", type=int, default=1 << 18, help="atoms per network chunk")
+    ap.add_argument("--chunk", type=int, default=1 << 20, help="atoms per network chunk")
     ap.add_argument("--compact", action="store_true", help="species numbered present-ones-first (models.ANI.compact_species)")
     ap.add_argument("--order", default="lattice", help="atom order: lattice (as generated), shuffle, layers (quarter-cutoff "
                     "layers along x, then cutoff cells), brick:<B> (bricks of B x B x B cutoff cells, cells inside in z-fastest order)")

@@ -523,7 +523,7 @@ class PackedNetworks:
         return self._ws
 
     def forward_backward(self, species: Tensor, aev: Tensor, lo: int = 0, hi: tp.Optional[int] = None,
-                         want_grad: bool = True, want_members: bool = False, chunk: int = 1 << 18,
+                         want_grad: bool = True, want_members: bool = False, chunk: int = 1 << 20,
                          atomic_e: tp.Optional[Tensor] = None, grad_aev: tp.Optional[Tensor] = None,
                          slab_mask: tp.Optional[Tensor] = None, shard_rows: bool = False, tile_hint: int = 0
                          ) -> tp.Tuple[Tensor, tp.Optional[Tensor], tp.Optional[Tensor]]:
