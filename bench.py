@@ -1,12 +1,16 @@
 """Headline benchmark: ANI-2x energy+forces throughput (atom*steps/s) on a periodic water box.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is
+one of the ranks; started plainly with --gpus N it launches the N ranks itself (torch.distributed.run on 127.0.0.1) and
+passes their JSON line through.
 
 Workload (BASELINE.json north_star / configs[3]): 8-member ANI-2x ensemble on a 2.3 M-atom periodic water
 box (0.1 atoms/A^3), energies + forces.  It fits one MI355X, so N=1 runs the whole box and N>1 shards
-the SAME box over the ranks (strong scaling): central atoms split contiguously, coordinates replicated,
-ONE fp32 all-reduce per step over RCCL (forces + the fp64 energies as exactly-summable fp32 parts).  Weights are seeded random parameters
-of the ANI-2x architecture (the published ones are a download), data is synthetic.
+the SAME box over the ranks (strong scaling): spatial slabs of the cell-sorted order, every rank works on its slab + halo,
+ONE all-to-all per step over RCCL (halo force rows to the slab neighbours, the fp64 partial energies to everybody).
+Weights are seeded random parameters of the ANI-2x architecture (the published ones are a download), data is synthetic.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline      : the fused radial+angular AEV forward kernel against the HBM roofline
@@ -20,6 +24,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -150,6 +156,18 @@ def main():
                     help="permute the atom order of the box (the spatial shards must not depend on it)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # started plainly: launch the ranks (one process per GPU) and hand their output through
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: RCCL between processes needs it on this driver)
+        sys.exit(subprocess.call(cmd, env=env))
+
     from torchani_amd import _lib
     from torchani_amd.models import ANI2x
     from torchani_amd.parallel import init_from_env, shard_range
@@ -184,6 +202,11 @@ def main():
         # (overflow is checked once after the timed loop instead of with a host sync per step).  N > 1: spatial shards,
         # every rank ends the step with the total energy and the forces of the atoms it owns (reduce_forces=False: no
         # gather of the other ranks' forces -- a domain-decomposed MD step does not need them)
+        if group is not None:
+            # an MD driver hands over NEW coordinates every step: bump the tensor's version so that the step pays what a
+            # moving system pays -- the partition's validity flags (queued on the device, read one step late) -- instead of
+            # hitting the "same tensor, same version" shortcut of a static input
+            coords.add_(0.0)
         return model.energies_and_forces(species, coords, cell, pbc, group=group, check_overflow=False,
                                          reduce_forces=False)
 
@@ -245,6 +268,7 @@ def main():
     elapsed = time.perf_counter() - t0
     step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    elapsed_rank = elapsed
     if group is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=group)
@@ -345,8 +369,9 @@ def main():
                         "energy+forces, seeded random weights",
             "n_atoms": n_atoms, "box_A": float(cell_np[0, 0]),
             "sharding": "spatial slabs of the coordinate-sorted order (any input order), each rank works on its slab + a "
-                        "5.1 A halo; ONE all-gather per step of the halo force rows and the partial energies; forces "
-                        "stay with the rank that owns the atoms",
+                        "5.1 A halo; ONE all-to-all per step: halo force rows to the slab neighbours only, partial "
+                        "energies to every rank; forces stay with the rank that owns the atoms (not gathered); the "
+                        "partition's validity is checked every step on the device and read one step late (no host sync)",
             "shuffled_input": bool(args.shuffle), "evaluated_on_cell_sorted_copy": bool(sorted_copy),
         },
         "ms_per_step_median": median_ms,
@@ -384,11 +409,19 @@ def main():
         lc = model.last_collective
         backend = torch.distributed.get_backend(group)
         res["stages_ms_per_rank"] = per_rank
+        seen = [None] * world
+        props = torch.cuda.get_device_properties(dev)
+        torch.distributed.all_gather_object(seen, {
+            "rank": rank, "local_rank": local, "device": f"cuda:{dev.index}", "name": props.name, "pid": os.getpid(),
+            "peers": list(part.peers), "local_atoms": part.n_local, "owned_atoms": part.n_owned,
+            "sent_bytes_per_step": lc["bytes"], "ms_per_step_this_rank": elapsed_rank / args.steps * 1e3}, group=group)
         part_ms = time_stage(lambda: type(part)(coords, cell, pbc, world, rank, model.aev_computer.radial.cutoff,
                                                 species.to(torch.int32).view(-1), skin=model.partition_skin), 3)
         res["collective"] = {
             "collectives_per_step": lc["collectives_per_step"], "world_size": lc["world_size"],
             "bytes_per_step": lc["bytes"], "op": lc.get("op", "all_reduce(sum, fp32)"), "backend": backend,
+            "ranks_seen": seen, "forces": "left with the owning rank (reduce_forces=False), not gathered",
+            "validity_check": "every timed step: device flags, read one step late (coords.add_(0.0) bumps the tensor version)",
             "local_atoms": lc.get("n_local"), "owned_atoms": lc.get("n_owned"), "halo_atoms": lc.get("n_halo"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
             # cutting the partition (sort + halo plan) is NOT part of every step: it is reused until an atom has moved

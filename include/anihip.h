@@ -287,6 +287,7 @@ typedef struct {
 #define ANIHIP_MLP_FLAG_FUSED_ROWS32 16u  /* fused kernel: 32-atom tiles, two workgroups per CU (default 64 / one) */
 #define ANIHIP_MLP_FLAG_D0_ROWS 32u       /* d E/d act0 handed to the layer-0 backward row-major, not tile-major */
 #define ANIHIP_MLP_FLAG_NO_SMALL_PREP 64u /* <= 16384 atoms: bucketing / tile table / padding rows as separate launches, not one */
+#define ANIHIP_MLP_FLAG_TILE_OWNER 256u   /* fused kernel: a workgroup takes a tile through all members (default: member-major sweep) */
 #define ANIHIP_MLP_FLAG_L0B_4WAVE 128u    /* < 16384 atoms: the generic 4-wave 128 x 128 kernel for the layer-0 backward, not the 8-wave one */
 typedef struct {
     int32_t num_species;

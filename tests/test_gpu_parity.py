@@ -811,14 +811,28 @@ def test_partition_skin_reuses_the_shards_while_atoms_move(dev):
     # (the cache holds one rank's partition at a time, so within a step every rank cuts its own; across steps the last
     # rank's partition is the one the next step's first lookup sees -- rank differs, so it is cut again: check the
     # single-rank behaviour directly)
+    # The decision is taken WITHOUT a host synchronisation, one step late (SpatialShards.check_async / poll): a step queues
+    # the flags for its coordinates and reads the previous step's.
     model.__dict__.pop("_spatial_cache", None)
-    a = model._spatial_partition(sp.view(-1).int(), x0.view(-1, 3), cell, pbc, 1, world)
+    sp32 = sp.view(-1).int()
+    a = model._spatial_partition(sp32, x0.view(-1, 3), cell, pbc, 1, world)
     x1 = x0 + 0.3
     x1[..., 1:] -= 0.3
-    b = model._spatial_partition(sp.view(-1).int(), x1.view(-1, 3), cell, pbc, 1, world)
-    x2 = x0 + 0.6
-    c = model._spatial_partition(sp.view(-1).int(), x2.view(-1, 3), cell, pbc, 1, world)
-    assert b is a and c is not a
+    b = model._spatial_partition(sp32, x1.view(-1, 3), cell, pbc, 1, world)            # moved 0.3 A: kept
+    x2 = x0 + 0.26                                                                       # moved 0.45 A >= 0.8 x skin / 2
+    c = model._spatial_partition(sp32, x2.view(-1, 3), cell, pbc, 1, world)            # ... found out one step late: kept
+    x3 = x2 + 0.0
+    d = model._spatial_partition(sp32, x3.view(-1, 3), cell, pbc, 1, world)            # renewed now
+    assert b is a and c is a and d is not a
+    x4 = x3 + 0.4                                                                        # 0.69 A > skin / 2 in ONE step:
+    e = model._spatial_partition(sp32, x4.view(-1, 3), cell, pbc, 1, world)            # that step ran on the old halo ...
+    assert e is d
+    with pytest.raises(RuntimeError, match="partition_skin"):                           # ... and the next one says so
+        model._spatial_partition(sp32, (x4 + 0.0).view(-1, 3), cell, pbc, 1, world)
+    # another species tensor (other padding atoms) never reuses the partition
+    model.__dict__.pop("_spatial_cache", None)
+    a = model._spatial_partition(sp32, x0.view(-1, 3), cell, pbc, 1, world)
+    assert model._spatial_partition(sp32.clone(), x0.view(-1, 3), cell, pbc, 1, world) is not a
 
 
 @pytest.mark.parametrize("name", ["ch4_ani1x", "rand_batch_ani2x", "water_pbc_ani2x"])

@@ -67,6 +67,38 @@ def test_plan_covers_neighbors_and_is_consistent(world, pbc):
         assert max(p.n_local for p in parts) < 0.62 * n             # slabs: 1/8 owned + two (5.1 A + a layer) halos of a 40 A box
 
 
+@pytest.mark.parametrize("periodic", [True, False])
+def test_force_rows_travel_between_slab_neighbours_only(periodic):
+    """Slabs thicker than the reach (here 15 A against 5.1 A + skin): a rank exchanges force rows with the rank before and
+    the rank behind it in the slab order and with nobody else (SpatialShards.peers), and the async validity flags say
+    "renew" at 0.8 x skin / 2 of motion and "invalid" at skin / 2 -- without the caller synchronising."""
+    from torchani_amd.parallel import SpatialShards
+
+    L = [120.0, 12.0, 12.0]
+    x = _box(2400, L, 1)
+    cell = torch.diag(torch.tensor(L))
+    pbc = (periodic,) * 3
+    world = 8
+    parts = [SpatialShards(x, cell, pbc, world, r, 5.1, skin=1.0) for r in range(world)]
+    for p in parts:
+        want = {(p.rank - 1) % world, (p.rank + 1) % world} if periodic else {r for r in (p.rank - 1, p.rank + 1) if 0 <= r < world}
+        assert set(p.peers) == want, (p.rank, p.peers)
+        assert sum(c > 0 for c in p.send_counts) <= 2 and sum(c > 0 for c in p.recv_counts) <= 2
+    p = parts[3]
+    assert p.poll() == (False, False)                       # nothing pending
+    p.check_async(x, cell)
+    assert p.poll() == (False, False)                       # nobody moved
+    y = x.clone()
+    y[7, 1] += 0.45                                          # 0.45 A > 0.8 x 0.5 A: renew next step, this step still fine
+    p.check_async(y, cell)
+    assert p.poll() == (True, False)
+    y[7, 1] += 0.1                                           # 0.55 A > skin / 2: the step that used the partition is not covered
+    p.check_async(y, cell)
+    assert p.poll() == (True, True)
+    p.check_async(x, cell * 1.01)                            # a changed box always renews
+    assert p.poll()[0]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -271,20 +303,24 @@ def test_random_boxes_cells_and_pbc(seed):
             assert real[halo].all()
         # the exchange, emulated without a process group: what every rank pushed onto an atom arrives at its owner
         if world > 1:
-            H = parts[0].halo_rows_max
             rows = [torch.from_numpy(rs.normal(size=(p.n_local, 3)).astype(np.float32)) for p in parts]
             want = torch.zeros(n, 3)
-            gathered = []
+            sent = {}   # (holder, owner) -> the rows the holder sends to the owner, in its send order
             for p, rw in zip(parts, rows):
                 want.index_add_(0, p.local_idx, rw)
-                send = torch.zeros(H, 3)
-                send[:p.n_left] = rw[:p.n_left]
-                send[p.n_left:p.n_left + p.n_right] = rw[p.n_left + p.n_owned:]
-                gathered.append(send)
-            gathered = torch.cat(gathered)
+                assert sum(p.send_counts) == p.n_left + p.n_right == p.send_rows.numel()
+                off = 0
+                for o in range(world):
+                    sent[(p.rank, o)] = rw[p.send_rows[off:off + p.send_counts[o]]]
+                    off += p.send_counts[o]
             for p, rw in zip(parts, rows):
                 assert p.messages == parts[0].messages
+                # every rank receives what the others send it, nothing else, and force rows only travel between ranks
+                # whose slabs touch (the rank's neighbours in the slab order; everybody when the slabs are thinner than the reach)
+                assert p.recv_counts == [parts[h].send_counts[p.rank] for h in range(world)]
+                assert all(o != p.rank for o in p.peers)
+                got = torch.cat([sent[(h, p.rank)] for h in range(world)])
                 out = rw.clone()
-                if p.recv_src.numel():
-                    out.index_add_(0, p.recv_dst, gathered[p.recv_src])
+                if p.recv_dst.numel():
+                    out.index_add_(0, p.recv_dst, got)
                 assert torch.allclose(out[p.n_left:p.n_left + p.n_owned], want[p.owned_idx], atol=1e-5)

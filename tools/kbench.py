@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--stages", default="nbr,fwd,bwd,mlp")
     ap.add_argument("--mask", default="both", choices=["on", "off", "both"], help="slab masks in the mlp stage")
     ap.add_argument("--chunk", type=int, default=1 << 20, help="atoms per network chunk")
+    ap.add_argument("--mlp-flags", type=int, default=0, help="anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*) of the network stage")
     ap.add_argument("--compact", action="store_true", help="species numbered present-ones-first (models.ANI.compact_species)")
     ap.add_argument("--order", default="lattice", help="atom order: lattice (as generated), shuffle, layers (quarter-cutoff "
                     "layers along x, then cutoff cells), brick:<B> (bricks of B x B x B cutoff cells, cells inside in z-fastest order)")
@@ -58,6 +59,8 @@ def main():
         model.compact_species = True
         sp32, order = model._engine_species(sp32)
     packed = model.neural_networks._pack(dev, order)
+    if args.mlp_flags:
+        packed.flags = args.mlp_flags
     nbrs = eng.neighbors(sp32, coords, cell, pbc, mode="cell")
     mask = torch.zeros(n, dtype=torch.int32, device=dev)
     aev = eng.forward(sp32, nbrs, slab_mask=mask)

@@ -1509,6 +1509,7 @@ struct FusedArgs {
     int tiles_total;           // upper bound of the number of tiles (work items = tiles_total * M)
     float alpha, inv_alpha;
     int want_grad;
+    int owner;                 // item order: 0 = member-major sweep over the tiles; 1 = a workgroup OWNS a tile through all members
     unsigned long long *trace;   // development builds (-DANIHIP_DEV_TRACE, tools/fused_trace.py): [item][wave][16] stamps
 };
 // phase stamps of the fused kernel: compiled out of the shipped library
@@ -2019,7 +2020,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     for (int t = 0; t < g.S; ++t) n_tiles += (g.ctl[CTL_CNT + t] + ROWS - 1) / ROWS;
     const int n_items = n_tiles * g.M;
     int item = blockIdx.x;
-    if (item >= n_items) return;
+    if (item >= (g.owner ? n_tiles : n_items)) return;
     // per-species constants of the items: looked up from LDS at the head of an item instead of scalar-load chains
     if (threadIdx.x < MAX_S) {
         const int t_ = threadIdx.x;
@@ -2031,6 +2032,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     __syncthreads();
     // (member, tile) of the item, advanced by gridDim.x tiles per step without divisions
     int mem = item / n_tiles, tile = item - mem * n_tiles;
+    if (g.owner) { mem = 0; tile = item; item = tile * g.M; }
     typedef WRing<NB, D> Ring0;
     Ring0 rg;                  // layer-0 weight ring of the item being started
     uint32_t rem_w = 0u;       // k steps of the layer-0 weight ring not yet requested
@@ -2083,8 +2085,15 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // entry and atom rows of the next item (the last item of a workgroup prefetches itself again: loads
         // stay unconditional)
         int mem_n = mem, tile_n = tile + (int)gridDim.x;
-        while (tile_n >= n_tiles) { tile_n -= n_tiles; ++mem_n; }
-        const bool has_next = mem_n < Mi;
+        bool has_next;
+        if (g.owner) {   // the same tile's next member, then the next tile of this workgroup
+            mem_n = mem + 1; tile_n = tile;
+            if (mem_n >= Mi) { mem_n = 0; tile_n = tile + (int)gridDim.x; }
+            has_next = tile_n < n_tiles;
+        } else {
+            while (tile_n >= n_tiles) { tile_n -= n_tiles; ++mem_n; }
+            has_next = mem_n < Mi;
+        }
         if (!has_next) { mem_n = mem; tile_n = tile; }
         const int4 te_n = g.tile_tab[tile_n];
         const int atom_n = g.tile_rows[(size_t)tile_n * ROWS + srow];
@@ -2467,7 +2476,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         te = te_n;
         mem = mem_n;
         tile = tile_n;
-        item = mem * n_tiles + tile;
+        item = g.owner ? tile * Mi + mem : mem * n_tiles + tile;
     }
 }
 #undef FR_UNIT
@@ -3263,6 +3272,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         f.tile_tab = w.tile_tab; f.tile_rows = w.tile_rows;
         f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
         f.want_grad = grad_aev ? 1 : 0;
+        f.owner = (d->flags & ANIHIP_MLP_FLAG_TILE_OWNER) ? 1 : 0;
         const bool gelu = d->activation == ANIHIP_ACT_GELU;
         const void *kfn = rows == 64 ? (gelu ? (const void *)k_mlp_fused<2, 1, 1> : (const void *)k_mlp_fused<2, 1, 0>)
                                      : (const void *)k_mlp_fused<1, 2, 0>;
@@ -3279,7 +3289,8 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         }
         const int64_t items = tiles * M;
         const int64_t resident = (int64_t)n_cus * (2 * lds <= 160 * 1024 ? 2 : 1);
-        const int64_t grid = items < resident ? items : resident;
+        const int64_t units = f.owner ? tiles : items;
+        const int64_t grid = units < resident ? units : resident;
         if (!small_prep)
             hipLaunchKernelGGL(k_tile_table, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, w.ctl, S, w.perm,
                                f.slab_mask, all_slabs, (int)tiles, rows, w.tile_tab, w.tile_rows);

@@ -451,7 +451,7 @@ class ANI(torch.nn.Module):
         hit = self.__dict__.get("_locality_cache")
         if hit is None or hit[0] != key:
             pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
-            part = self._spatial_partition(species32.view(-1), c32, cell, pbc_t, 0, 1)
+            part = self._spatial_partition(species32.view(-1), c32, cell, pbc_t, 0, 1, key_tensor)
             # neighbors in the cell-sorted order that are also near each other in the given order
             # (a random order puts 2 / 256 of them within n / 256 places; a lattice or an MD engine's order most of them)
             near = ((part.order[1:] - part.order[:-1]).abs() < max(64, species32.numel() // 256)).float().mean()
@@ -468,27 +468,46 @@ class ANI(torch.nn.Module):
         return all(k == "nnp" or not p._enabled or (p.cutoff <= rc + 1e-6 and not getattr(p, "needs_all_rows", False))
                    for k, p in self.potentials.items())
 
-    def _spatial_partition(self, species32: Tensor, c32: Tensor, cell, pbc_t, rank: int, world: int):
+    def _spatial_partition(self, species32: Tensor, c32: Tensor, cell, pbc_t, rank: int, world: int,
+                           species_key: tp.Optional[Tensor] = None):
+        """This rank's SpatialShards for the given coordinates: cut once and kept while it is valid.
+
+        Same coordinate tensor (identity and version), same species, same box: the cached partition, no device work.  Moved
+        coordinates with ``partition_skin`` > 0: the partition is kept until an atom has moved 0.8 x skin / 2 since it was
+        cut -- decided WITHOUT a host synchronisation: every step queues the validity flags for its coordinates
+        (SpatialShards.check_async) and reads the flags of the PREVIOUS step (poll), like the overflow word of the neighbor
+        rows.  Every rank sees the same coordinates and takes the same decision.  Should an atom have outrun the whole skin
+        within that one step of lag, the late read raises (the step before it was evaluated with too narrow a halo)."""
         from .parallel import SpatialShards
 
-        # (the species only decide where padding atoms are sorted -- last, out of everybody's halo; a stale placement costs
-        # balance, not correctness, so the key follows the coordinates alone)
+        spk = species32 if species_key is None else species_key
+        # (the species decide which atoms are padding: those are sorted last and kept out of every halo, so a partition cut
+        # for one species tensor must not serve another)
         key = (c32.data_ptr(), c32._version, tuple(c32.shape), None if cell is None else (cell.data_ptr(), cell._version),
-               pbc_t, rank, world)
+               pbc_t, rank, world, spk.data_ptr(), spk._version, tuple(spk.shape))
         hit = self.__dict__.get("_spatial_cache")
         if hit is not None and hit[0] != key and (self.partition_skin > 0.0 or world == 1) and hit[0][2] == key[2] and \
-                hit[0][4:] == key[4:] and (cell is None) == (hit[5] is None) and \
-                (cell is None or torch.equal(hit[5], cell)) and hit[1].still_valid(c32):
-            # moved coordinates, same box, nobody further than skin / 2 from where the partition was cut: keep it (every
-            # rank sees the same coordinates, so every rank takes the same decision)
-            hit = (key, hit[1], c32, cell, species32, hit[5])
-            self.__dict__["_spatial_cache"] = hit
+                hit[0][4:] == key[4:] and (cell is None) == (hit[3] is None):
+            part = hit[1]
+            renew, invalid = part.poll()   # (what the previous step found out about ITS coordinates)
+            if invalid and world > 1:
+                self.__dict__["_spatial_cache"] = None
+                raise RuntimeError(
+                    "spatial shards: an atom moved more than partition_skin / 2 = "
+                    f"{0.5 * self.partition_skin:.3f} A before the partition was renewed -- the previous step was evaluated "
+                    "with too narrow a halo. Use a larger partition_skin (or a smaller time step).")
+            if not renew:
+                # moved coordinates, same box, nobody further than 0.8 x skin / 2 from where the partition was cut (as of the
+                # previous step): keep it, and queue the same question for these coordinates
+                part.check_async(c32, cell)
+                hit = (key, part, c32, cell, spk)
+                self.__dict__["_spatial_cache"] = hit
         if hit is None or hit[0] != key:
             # (the entry keeps the tensors alive, so an equal key means the same coordinates, not a recycled address)
             # (one rank has no halo: any order is correct, the skin only says when the order has stopped being local)
             skin = self.partition_skin if world > 1 else max(self.partition_skin, self.aev_computer.radial.cutoff)
             hit = (key, SpatialShards(c32, cell, pbc_t, world, rank, self.aev_computer.radial.cutoff, species32, skin=skin),
-                   c32, cell, species32, None if cell is None else cell.clone())
+                   c32, cell, spk)
             self.__dict__["_spatial_cache"] = hit
         return hit[1]
 
@@ -505,7 +524,7 @@ class ANI(torch.nn.Module):
         else:
             rank, world = shard
         pbc_t = None if pbc is None else tuple(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc))
-        part = self._spatial_partition(species32, c32, cell, pbc_t, rank, world)
+        part = self._spatial_partition(species32, c32, cell, pbc_t, rank, world, species_key)
         sp_e, order = self._engine_species(species32, species_key)   # (sp_given indexes the self energies)
         sp_given = part.local(species32).view(1, -1).contiguous()
         sp_l = sp_given if order is None else part.local(sp_e).view(1, -1).contiguous()
@@ -570,7 +589,8 @@ class ANI(torch.nn.Module):
         else:
             forces, ae = part.scatter_owned(f_l), part.scatter_owned(e_atom)
         self.last_collective = {"collectives_per_step": n_coll, "world_size": world, "bytes": nbytes,
-                                "op": "all_gather(halo force rows + partial energy)", "n_local": nl,
+                                "op": "all_to_all(halo force rows -> slab neighbours, partial energy -> all)", "n_local": nl,
+                                "peers": list(part.peers),
                                 "n_owned": part.n_owned, "n_halo": part.n_left + part.n_right}
         if check_overflow:
             nbrs.raise_on_overflow()

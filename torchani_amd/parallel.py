@@ -223,8 +223,10 @@ class SpatialShards:
         b = torch.tensor(self.bounds, device=dev)
         lo_i, hi_i = b[:-1], b[1:]
         n_real = torch.searchsorted(kxs, torch.tensor([nl_], device=dev, dtype=torch.int32), right=False)   # padding starts here
-        k_lo = kxs[lo_i.clamp(max=n - 1)].to(torch.int64)
-        k_hi = kxs[(hi_i - 1).clamp(min=0)].to(torch.int64)
+        # (layer bounds of a rank at its REAL positions: a range that ends in padding would otherwise take the padding
+        # layer for its last layer and, under PBC, every remaining atom for its right halo)
+        k_lo = kxs[torch.minimum(lo_i, n_real).clamp(max=n - 1)].to(torch.int64)
+        k_hi = kxs[(torch.minimum(hi_i, n_real) - 1).clamp(min=0)].to(torch.int64)
         q = torch.cat([k_lo - dl, k_lo - dl + nl_, k_hi + dl, k_hi + dl - nl_]).clamp(min=-1, max=2 * nl_ + 1).to(torch.int32)
         left = torch.searchsorted(kxs, q[:2 * world].contiguous(), right=False)
         right = torch.searchsorted(kxs, q[2 * world:].contiguous(), right=True)
@@ -262,16 +264,34 @@ class SpatialShards:
         self.local_idx = order[pos]                                  # local row -> input atom
         self.owned_idx = self.local_idx[self.n_left:self.n_left + self.n_owned]
         self.x_build = x.clone() if self.skin > 0.0 else None
+        self._cell_build = None if cell is None else cell.detach().clone()
         # ---- who holds halo rows of whom: runs (holder, first halo row of the holder, owner, first owned row, count) ----
         self.halo_rows_max = max((a + c for a, c in self.halo), default=0)
         self.messages = self._plan()
-        src, dst = [], []
+        # Exchange tables: a rank SENDS the halo rows it holds to the rank that owns them and to nobody else (for slabs
+        # these are its one or two neighbours in the slab order), message after message in the order of the plan; it
+        # RECEIVES, from every holder of its atoms, rows in the order that holder sends them.
+        send, dst = [[] for _ in range(world)], [[] for _ in range(world)]
         for holder, hrow, owner, orow, cnt in self.messages:
-            if owner == rank and cnt > 0:
-                src.append(torch.arange(cnt, device=dev) + (holder * self.halo_rows_max + hrow))
-                dst.append(torch.arange(cnt, device=dev) + (self.n_left + orow))
-        self.recv_src = torch.cat(src) if src else torch.zeros(0, dtype=torch.long, device=dev)
-        self.recv_dst = torch.cat(dst) if dst else torch.zeros(0, dtype=torch.long, device=dev)
+            if cnt <= 0:
+                continue
+            if holder == rank:   # halo row h is local row h (left part) or n_owned + h (right part)
+                h = torch.arange(hrow, hrow + cnt, device=dev)
+                send[owner].append(torch.where(h < self.n_left, h, h + self.n_owned))
+            if owner == rank:
+                dst[holder].append(torch.arange(cnt, device=dev) + (self.n_left + orow))
+        empty = torch.zeros(0, dtype=torch.long, device=dev)
+        self.send_counts = [int(sum(t.numel() for t in send[o])) for o in range(world)]    # rows for owner o
+        self.recv_counts = [int(sum(t.numel() for t in dst[h])) for h in range(world)]     # rows from holder h
+        self.send_rows = torch.cat([t for o in range(world) for t in send[o]] or [empty])  # local rows, in send order
+        self.recv_dst = torch.cat([t for h in range(world) for t in dst[h]] or [empty])    # local rows, in receive order
+        self.peers = sorted({o for o in range(world) if o != rank and (self.send_counts[o] or self.recv_counts[o])})
+        # (where the received row words and the tails sit in the receive buffer [rows of holder 0 | tail 0 | rows of holder 1 | ...],
+        # as device tensors, so that unpacking needs no host work that depends on device data)
+        rc = torch.tensor(self.recv_counts, dtype=torch.long)
+        self._recv_word_holder = torch.repeat_interleave(torch.arange(world), 3 * rc).to(dev)
+        self._recv_rows_end = (3 * rc).cumsum(0).to(dev)
+        self._check = None        # pending asynchronous validity check (check_async)
 
     def still_valid(self, coords: torch.Tensor) -> bool:
         """Has every atom stayed within skin / 2 of where it was when the partition was built?  (One reduction + one host
@@ -280,6 +300,52 @@ class SpatialShards:
             return False
         d = coords.detach().reshape(-1, 3).to(torch.float32) - self.x_build
         return bool(((d * d).sum(dim=1).max() < (0.5 * self.skin) ** 2).item())
+
+    # The per-step question "is the partition still good?" without a host synchronisation in the steady state: the flags
+    # are computed on the device, copied to pinned host memory behind an event, and READ ONE STEP LATE (like the neighbor
+    # builder's overflow word).  Two thresholds make the lag safe: the partition is renewed as soon as an atom has moved
+    # SOFT x skin / 2 (0.8: rebuilt at the next step), and a step is only WRONG once an atom has moved skin / 2 itself -- the
+    # step in between is covered as long as no atom moves 0.1 skin in one step (0.1 A for the default 1 A skin: twenty
+    # times a hydrogen's motion in a 0.5 fs step); if it did, the late read raises instead of returning silently.
+    SOFT = 0.8
+
+    def check_async(self, coords: torch.Tensor, cell: tp.Optional[torch.Tensor]) -> None:
+        """Queue the validity flags for ``coords`` on the current stream: word 0 = some atom moved SOFT x skin / 2 since the
+        cut (or the cell changed) -> renew the partition at the next step; word 1 = some atom moved skin / 2 -> the step that
+        used this partition with these coordinates cannot be trusted.  No host synchronisation: ``poll`` reads them later."""
+        if self.x_build is None:
+            self._check = None
+            return
+        d = coords.detach().reshape(-1, 3).to(torch.float32) - self.x_build
+        # effective displacement: the largest motion of an atom, plus half of what the periodic images moved with the cell
+        # (two atoms each d apart from where they were and an image shifted by |delta cell| change a distance by <= 2 d + |delta cell|)
+        d_eff = (d * d).sum(dim=1).max().sqrt()
+        changed = torch.zeros((), dtype=torch.bool, device=d_eff.device)
+        if cell is not None and self._cell_build is not None:
+            dc = cell.detach().to(self._cell_build.dtype).reshape(3, 3) - self._cell_build.reshape(3, 3)
+            d_eff = d_eff + 0.5 * torch.linalg.norm(dc, dim=1).sum().to(d_eff.dtype)
+            changed = (dc != 0).any()
+        lim = 0.5 * self.skin
+        flags = torch.stack([(d_eff >= lim * self.SOFT) | changed, d_eff >= lim]).to(torch.int32)
+        if flags.is_cuda:
+            host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+            host.copy_(flags, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._check = (host, ev)
+        else:
+            self._check = (flags, None)
+
+    def poll(self) -> tp.Tuple[bool, bool]:
+        """(renew, invalid) of the LAST ``check_async`` (False, False if none is pending).  Waits for that check's event only
+        -- work queued a step ago, long finished unless the host runs a whole step ahead of the device."""
+        if self._check is None:
+            return False, False
+        host, ev = self._check
+        self._check = None
+        if ev is not None:
+            ev.synchronize()
+        return bool(host[0]), bool(host[1])
 
     def _plan(self) -> tp.List[tp.Tuple[int, int, int, int, int]]:
         """Halo rows of every rank cut into runs by the rank that owns them.  Halo row h of a holder (0 .. n_left + n_right,
@@ -306,26 +372,42 @@ class SpatialShards:
 
     def exchange(self, rows: torch.Tensor, tail: tp.Optional[torch.Tensor], group) -> tp.Tuple[torch.Tensor, tp.Optional[torch.Tensor]]:
         """rows [n_local, 3] (fp32 or int64): partial per-atom sums of this rank; tail: a small fp64 (or int64) vector to be
-        SUMMED over the ranks (partial energies, virial).  ONE all-gather; returns (rows with the other ranks' pushes onto
-        this rank's owned atoms added, summed tail).  Bytes sent per rank: ``last_bytes``."""
-        world, H = self.world, self.halo_rows_max
+        SUMMED over the ranks (partial energies, virial).  ONE collective, an all-to-all with uneven pieces: a rank sends the
+        halo rows it holds to the rank that owns them -- its neighbours in the slab order, nobody else gets force rows --
+        and its tail to everybody (a few words; fp64 carried as pairs of fp32 words), so that every rank adds the same W
+        partial sums in the same order.  Returns (rows with the other ranks' pushes onto this rank's owned atoms added,
+        summed tail).  Bytes sent per rank: ``last_bytes``; ranks force rows travel to / from: ``peers``."""
+        world = self.world
         nt = 0 if tail is None else tail.numel()
         wide = rows.dtype == torch.int64
-        per = 3 * H + (nt if wide else 2 * nt)
-        send = torch.zeros(per, dtype=rows.dtype, device=rows.device)
-        nl, nr = self.n_left, self.n_right
-        send[:3 * nl] = rows[:nl].reshape(-1)
-        send[3 * nl:3 * (nl + nr)] = rows[nl + self.n_owned:].reshape(-1)
+        ntw = nt if wide else 2 * nt                       # words of the tail in the rows' dtype
+        tw = None
         if nt:
-            send[3 * H:] = tail if wide else tail.to(torch.float64).contiguous().view(torch.float32)
-        got = _all_gather(send, world, group).view(world, per)
-        if self.recv_src.numel():
-            rows.index_add_(0, self.recv_dst, got[:, :3 * H].reshape(world * H, 3)[self.recv_src])
+            tw = tail.reshape(-1) if wide else tail.to(torch.float64).contiguous().view(torch.float32).reshape(-1)
+        halo = rows[self.send_rows].reshape(-1)           # [3 * rows sent], grouped by owner
+        pieces, off = [], 0
+        for o in range(world):
+            c = 3 * self.send_counts[o]
+            pieces.append(halo[off:off + c])
+            if nt:
+                pieces.append(tw)
+            off += c
+        send = torch.cat(pieces) if pieces else rows.new_zeros(0)
+        in_split = [3 * self.send_counts[o] + ntw for o in range(world)]
+        out_split = [3 * self.recv_counts[h] + ntw for h in range(world)]
+        got = _all_to_all(send, in_split, out_split, group)
+        # unpack: [rows from holder 0 | tail 0 | rows from holder 1 | tail 1 | ...]
         total = None
         if nt:
-            parts = got[:, 3 * H:] if wide else got[:, 3 * H:].contiguous().view(torch.float64).view(world, nt)
+            hh = torch.arange(world, device=got.device)
+            idx = ((self._recv_rows_end + hh * ntw).view(-1, 1) + torch.arange(ntw, device=got.device).view(1, -1)).reshape(-1)
+            parts = got[idx].view(world, ntw)
+            parts = parts if wide else parts.contiguous().view(torch.float64).view(world, nt)
             total = parts.sum(dim=0)   # (the same W numbers in the same order on every rank: identical results)
-        self.last_bytes = per * send.element_size()
+        if self.recv_dst.numel():
+            k = torch.arange(self._recv_word_holder.numel(), device=got.device)
+            rows.index_add_(0, self.recv_dst, got[k + self._recv_word_holder * ntw].view(-1, 3))
+        self.last_bytes = int(sum(in_split) - in_split[self.rank]) * send.element_size()
         return rows, total
 
     def scatter_owned(self, local_rows: torch.Tensor, fill: float = 0.0) -> torch.Tensor:
@@ -373,4 +455,17 @@ def _all_gather(send: torch.Tensor, world: int, group) -> torch.Tensor:
         return host.to(send.device)
     got = torch.empty(world * flat.numel(), dtype=flat.dtype, device=flat.device)
     torch.distributed.all_gather_into_tensor(got, flat, group=group)
+    return got
+
+
+def _all_to_all(send: torch.Tensor, in_split: tp.Sequence[int], out_split: tp.Sequence[int], group) -> torch.Tensor:
+    """all_to_all_single with uneven pieces (RCCL: grouped point-to-point sends, only the non-empty pairs move data).  The
+    gloo backend (CPU tests, single-GPU development runs with several ranks on one device) is staged through the host."""
+    n_out = int(sum(out_split))
+    if send.is_cuda and torch.distributed.get_backend(group) == "gloo":
+        host = torch.empty(n_out, dtype=send.dtype)
+        torch.distributed.all_to_all_single(host, send.cpu(), list(out_split), list(in_split), group=group)
+        return host.to(send.device)
+    got = torch.empty(n_out, dtype=send.dtype, device=send.device)
+    torch.distributed.all_to_all_single(got, send.contiguous(), list(out_split), list(in_split), group=group)
     return got
