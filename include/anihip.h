@@ -254,7 +254,9 @@ typedef struct {
      * [member][N/32][K/16][2 planes][64 lanes][8 halves] (lane l <-> output n = 32 cb + (l & 31),
      * k = 16 ks + 8 (l >> 5) + j) for the fused network kernel, which streams them straight into
      * registers: whf[l] for layers 0..n_layers-2 (layer 0 per member: N = H1p, K = K0p in the order of
-     * wh[0]), wthf[l] for layers 1..n_layers-2.  NULL disables the fused kernel. */
+     * wh[0]), wthf[l] for layers 1..n_layers-2, and (4-layer networks) wthf[0] = layer 0 transposed, per member: N = K0p
+     * in the order of wh[0] (a column block = one AEV slab), K = H1p -- the layer-0 backward inside the fused kernel.
+     * whf / wthf[1..] NULL disables the fused kernel, wthf[0] NULL its layer-0 backward phase. */
     const void *whf[ANIHIP_MAX_LAYERS];
     const void *wthf[ANIHIP_MAX_LAYERS];
     /* optional, fused kernel of 4-layer networks: per member 8 floats ([5..7] = 0) that bound the operands
@@ -288,6 +290,8 @@ typedef struct {
 #define ANIHIP_MLP_FLAG_D0_ROWS 32u       /* d E/d act0 handed to the layer-0 backward row-major, not tile-major */
 #define ANIHIP_MLP_FLAG_NO_SMALL_PREP 64u /* <= 16384 atoms: bucketing / tile table / padding rows as separate launches, not one */
 #define ANIHIP_MLP_FLAG_TILE_OWNER 256u   /* fused kernel: a workgroup takes a tile through all members (default: member-major sweep) */
+#define ANIHIP_MLP_FLAG_FUSED_L0B 512u    /* layer-0 backward inside the fused kernel whatever the size (default: from 65536 atoms) */
+#define ANIHIP_MLP_FLAG_NO_FUSED_L0B 1024u /* ... never: d E/d act0 through HBM + a layer-0 backward GEMM launch */
 #define ANIHIP_MLP_FLAG_L0B_4WAVE 128u    /* < 16384 atoms: the generic 4-wave 128 x 128 kernel for the layer-0 backward, not the 8-wave one */
 typedef struct {
     int32_t num_species;

@@ -83,6 +83,12 @@ def pack_reference(weights, biases, aev_len, precision="f16x3", radial_len=None,
                 out[(s, "whf", l)] = frags[0]
                 if l >= 1:
                     out[(s, "wthf", l)] = frags[1]
+                elif nl == 4:
+                    # layer 0, transposed, member by member: planes [2][M][N = K0h][K = H1p] in fragment order (the layer-0
+                    # backward inside the fused kernel: a column block is one AEV slab, k runs over the member's hidden columns)
+                    tp = planes[1].view(2, k0h, M, kout).permute(0, 2, 1, 3).contiguous()
+                    f = tp.view(2, M, k0h // 32, 32, kout // 16, 2, 8).permute(1, 2, 4, 0, 5, 3, 6)
+                    out[(s, "wthf", 0)] = f.contiguous()
         if precision == "f16x3" and nl == 4:
             W1 = torch.stack([weights[m][s][1].detach().to(**f32) for m in range(M)])   # [M, H2, H1]
             W2 = torch.stack([weights[m][s][2].detach().to(**f32) for m in range(M)])   # [M, H3, H2]

@@ -232,5 +232,28 @@ def test_bench_two_ranks_gloo():
     coll = r["collective"]
     assert coll["collectives_per_step"] == 1 and coll["world_size"] == 2
     assert coll["owned_atoms"] == r["config"]["n_atoms"] // 2 and coll["local_atoms"] <= r["config"]["n_atoms"]
-    assert coll["bytes_per_step"] == 4 * (3 * coll["halo_atoms"] + 2) or coll["bytes_per_step"] >= 8   # halo rows + energy
+    # what a rank sends: its halo rows to their owner + the partial energy (two fp32 words) to the other rank
+    assert coll["bytes_per_step"] == 4 * (3 * coll["halo_atoms"] + 2)
     assert len(r["stages_ms_per_rank"]) == 2 and all("aev_forward" in s for s in r["stages_ms_per_rank"])
+    seen = coll["ranks_seen"]
+    assert sorted(s["rank"] for s in seen) == [0, 1] and len({s["pid"] for s in seen}) == 2
+    assert seen[0]["peers"] == [1] and seen[1]["peers"] == [0]
+    return r
+
+
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` with no RANK / WORLD_SIZE in the environment -- the spelling the driver uses -- starts
+    the two ranks itself (here over gloo on the one GPU) and prints the ranks' one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--waters-side", "16",
+           "--dist-backend", "gloo", "--no-dense-stage"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["value"] > 0
+    coll = r["collective"]
+    assert coll["world_size"] == 2 and coll["collectives_per_step"] == 1 and len(coll["ranks_seen"]) == 2
+    assert "read one step late" in coll["validity_check"]

@@ -673,6 +673,58 @@ def test_skinny_layer0_backward_for_every_slab_count(dev, pair):
     assert torch.equal(got["skinny"][1], got["rows"][1])
 
 
+@pytest.mark.parametrize("elements", [(0, 3), (0, 1), (1, 1), (0, 2, 6), (0, 1, 2, 3), (0, 1, 2, 3, 4, 5, 6)])
+def test_layer0_backward_inside_the_fused_kernel(dev, elements):
+    """Phase 5 of k_mlp_fused (round 4: a workgroup owns a tile through all members and adds the members' d E / d AEV in
+    place, default from 65 536 atoms) against the d act0 hand-over + layer-0 backward GEMM, forced on a 17 496-atom box for
+    1 .. 7 elements (2 .. 32 flagged slabs per tile: one to eight passes of four column blocks): identical per-atom
+    energies (the forward phases are the same arithmetic), d E / d AEV within 2e-6 of its largest entry (members summed one
+    after the other instead of inside one K = M x H1 reduction), and the whole path against the fp64 oracle."""
+    from bench import water_box
+    from oracle.sampled_parity import sampled_parity
+    from torchani_amd.engine import PackedNetworks
+
+    sp_np, x_np, cell_np = water_box(18)
+    rs = np.random.RandomState(7 + sum(elements))
+    sp_np = rs.choice(np.asarray(elements), size=sp_np.shape).astype(sp_np.dtype)
+    x, cell = torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    sp64 = torch.from_numpy(sp_np).to(dev)
+    sp = sp64.to(torch.int32)
+    model = get_model("ani2x", 31, dev, neighborlist="cell", row_capacity=192)
+    eng = model.aev_computer.engine()
+    packed = model.neural_networks._pack(dev)
+    nbrs = eng.neighbors(sp, x, cell, (True, True, True), mode="cell", row_cap=192)
+    mask = torch.zeros(sp.numel(), dtype=torch.int32, device=dev)
+    aev = eng.forward(sp, nbrs, slab_mask=mask)
+    got = {}
+    try:
+        for name, flags in (("inside", _lib.MLP_FLAG_FUSED_L0B), ("gemm", _lib.MLP_FLAG_NO_FUSED_L0B)):
+            packed.flags = flags
+            ga = torch.zeros_like(aev)
+            e, _, _ = packed.forward_backward(sp, aev, grad_aev=ga, slab_mask=mask)
+            got[name] = (e.clone(), ga.clone())
+    finally:
+        packed.flags = None
+    scale = float(got["gemm"][1].abs().max())
+    assert scale > 1e-4
+    assert torch.equal(got["inside"][0], got["gemm"][0])
+    err = float((got["inside"][1] - got["gemm"][1]).abs().max())
+    report(f"l0b   elements {elements}: max|d(dE/dAEV)| = {err:.2e} of {scale:.2e}")
+    assert err < 2e-6 * scale
+    # the whole path (neighbors, AEV, networks with phase 5, AEV backward) against the oracle
+    old = PackedNetworks.default_flags
+    try:
+        PackedNetworks.default_flags = _lib.MLP_FLAG_FUSED_L0B
+        out = model.energies_and_forces(sp64, x, cell, (True, True, True), check_overflow=True)
+    finally:
+        PackedNetworks.default_flags = old
+    res = sampled_parity(sp64, x, cell, out.atomic_energies, out.forces, seeded_state("ani2x", 8, 31), "ani2x", 8,
+                         n_sample=16, seed=5)
+    fmax = max(1.0, float(out.forces.abs().max()))
+    report(f"l0b   elements {elements}: max|e_atom err| = {res['max_dE_atom']:.2e}  max|F err| = {res['max_dF']:.2e} (largest force {fmax:.1f})")
+    assert res["max_dE_atom"] < 1e-6 * max(1.0, float(out.atomic_energies.abs().max())) and res["max_dF"] < 5e-6 * fmax
+
+
 @pytest.mark.parametrize("periodic", [True, False])
 def test_locality_sort_of_a_shuffled_system(dev, periodic):
     """ANI.locality_sort = "auto": a large single system given in an incoherent atom order is evaluated on a cell-sorted

@@ -36,6 +36,7 @@ ACT_CELU, ACT_GELU = 0, 1
 MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_FUSED_ROWS32, MLP_FLAG_D0_ROWS = \
     1, 2, 4, 8, 16, 32
 MLP_FLAG_NO_SMALL_PREP, MLP_FLAG_L0B_4WAVE, MLP_FLAG_TILE_OWNER = 64, 128, 256
+MLP_FLAG_FUSED_L0B, MLP_FLAG_NO_FUSED_L0B = 512, 1024
 ABI_VERSION = 8
 
 

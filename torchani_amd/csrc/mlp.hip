@@ -6,6 +6,7 @@
 //
 //   A. split-fp16 ("f16x3", default), three hidden layers of width <= 256 (ANI-1x / ANI-2x):
 //        >= 16384 atoms: k_tile_table -> k_mlp_fused<RB,NB> -> k_fused_finish -> k_gemm_l0b + k_gemm_h2<EPI_SCATTER>
+//        >= 65536 atoms: k_tile_table -> k_mlp_fused<2,1,ACT,L0B = true> (layer-0 backward inside: phase 5) -> k_fused_finish
 //        fewer:          k_small_prep (bucketing + tile table + padding rows) -> k_mlp_fused -> k_gemm_l0s (+ finish)
 //      one fused kernel from the AEV rows to d E / d act0 (layer 0 only over the AEV slabs flagged non-zero,
 //      activations in LDS, weights streamed from L2 in MFMA fragment order), then the layer-0 backward
@@ -28,6 +29,8 @@
 #include <stdlib.h>
 
 #include "anihip_common.h"
+
+#include <type_traits>
 #include <vector>
 #include <cstdio>
 
@@ -1457,6 +1460,7 @@ __global__ __launch_bounds__(L0B_THREADS, 2) void k_gemm_l0b(GemmArgs g)
 //   <1, 2>: 32 atoms, 4 waves, 60 KB LDS, TWO workgroups per CU that drift out of phase, so the epilogues
 //           (VALU) of one overlap the GEMM phases (matrix pipe) of the other, at twice the L2 weight traffic.
 constexpr int FR_MAXH = 256;      // largest padded hidden width (8 column blocks)
+constexpr int64_t FUSED_L0B_MIN_ATOMS = 65536;   // layer-0 backward inside the fused kernel from this many atoms on
 constexpr int FRAG = 512;         // halves per fragment plane: 64 lanes x 8
 constexpr int FR_SLAB_LD = 40;    // halves per staged slab row (32 + 8: conflict-free ds_read_b128)
 constexpr int FR_GROUP = 3;       // slabs per staging slot
@@ -1475,7 +1479,7 @@ struct FusedCfg {
     // fixed part of the dynamic LDS: [0] tile max | energy partials [NW][ROWS] | staging slot 0
     // fixed part of the dynamic LDS: [0] tile max | per-species {tile-major base of d0, first sorted position} |
     // energy partials [NW][ROWS] | staging slot 0
-    static constexpr int FIXED_BYTES = 16 + 128 + NW * ROWS * 4;
+    static constexpr int FIXED_BYTES = 16 + 128 + NW * ROWS * 4 + 2 * ROWS * 4;   // ... | atoms of the tile rows [2][ROWS]
     static constexpr int FIXED_HALVES = FIXED_BYTES / 2 + FR_GROUP * SLAB;
     static_assert(THREADS == ROWS * 8, "one 16-B staging piece per thread");
 };
@@ -1484,6 +1488,7 @@ struct FusedSpecies {
     int H1, H2, H3;                          // padded widths
     // fragment-ordered planes, per member: [N/32][K/16][2][64][8]
     const _Float16 *w0, *w1, *w2, *w2t, *w1t;  // (N,K) = (H1,K0p), (H2,H1), (H3,H2), (H2,H3), (H1,H2)
+    const _Float16 *w0t;                       // (N,K) = (K0p, H1): layer 0 transposed (l0b), or NULL
     float is0, is1, is2;                     // 1 / weight scales of layers 0, 1 and 2
     const float *b0, *b1, *b2;               // [M*H1], [M][H2], [M][H3]
     const float *w3, *b3;                    // output layer [M][H3], [M]
@@ -1509,8 +1514,10 @@ struct FusedArgs {
     int tiles_total;           // upper bound of the number of tiles (work items = tiles_total * M)
     float alpha, inv_alpha;
     int want_grad;
+    int l0b;                   // layer-0 backward inside the kernel (needs owner = 1): d E / d AEV -> grad_aev, no d0
+    float *grad_aev;           // [n_atoms][L] (l0b): the tile's flagged slabs of its atoms' rows, summed over the members
     int owner;                 // item order: 0 = member-major sweep over the tiles; 1 = a workgroup OWNS a tile through all members
-    unsigned long long *trace;   // development builds (-DANIHIP_DEV_TRACE, tools/fused_trace.py): [item][wave][16] stamps
+    unsigned long long *trace;   // development builds (-DANIHIP_DEV_TRACE, tools/fused_trace.py): [item][wave][32] stamps
 };
 // phase stamps of the fused kernel: compiled out of the shipped library
 #ifdef ANIHIP_DEV_TRACE
@@ -1635,8 +1642,7 @@ __device__ __forceinline__ void fr_ring(WRing<NB, D> &r, const _Float16 *w, int6
 template <int RB, int NB, int RBA, int NBA, int D>
 __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *xa, int ldx, int x_plane,
                                         WRing<NB, D> &rg, int KS, int lane)
-{
-    // the activation fragments of step k + 1 are read from LDS before the MFMAs of step k (two register sets)
+{    // the activation fragments of step k + 1 are read from LDS before the MFMAs of step k (two register sets)
     const int fr = lane & 31, fk = lane >> 5;
     const _Float16 *af = xa + fr * ldx + fk * 8;
     const int rbs = 32 * ldx;
@@ -1946,9 +1952,11 @@ __global__ __launch_bounds__(SMALL_PREP_WAVES * WAVE) void k_small_prep(
     else if ((u).nrb == RB && (u).nba == 1) { constexpr int RBA = RB, NBA = 1; CALL; }      \
     else if ((u).nrb == 1) { constexpr int RBA = 1, NBA = 1; CALL; }
 
-template <int RB, int NB, int ACT>   // ACT: 0 = CELU(alpha), 1 = GELU (exact, erf)
+// L0B: the layer-0 backward as phase 5 of the kernel (owner order, d E / d AEV accumulated in place; RB = 2, NB = 1 only)
+template <int RB, int NB, int ACT, bool L0B>   // ACT: 0 = CELU(alpha), 1 = GELU (exact, erf)
 __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 {
+    static_assert(!L0B || (RB == 2 && NB == 1), "phase 5 is written for 64-row tiles on 8 waves");
     using C = FusedCfg<RB, NB>;
     constexpr int NW = C::NW, ROWS = C::ROWS, D = C::DEPTH, SLAB = C::SLAB, NE = RB * NB;
     typedef WRing<NB, D> Ring;
@@ -1958,6 +1966,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     long long *s_tmb = reinterpret_cast<long long *>(s_tab + 4);          // [8] tile-major base of species s in d0
     int *s_off = reinterpret_cast<int *>(s_tab + 4 + 16);                 // [8] first sorted position of species s
     float *s_e = reinterpret_cast<float *>(s_tab + 4 + 32);               // [NW][ROWS]
+    int *s_orow = reinterpret_cast<int *>(s_tab + 4 + 32 + NW * ROWS);    // [2][ROWS] atom of every row of this / the next item's tile
     _Float16 *slot0 = fsm_all + C::FIXED_BYTES / 2;                       // staging slot 0
     _Float16 *fsm = fsm_all + C::FIXED_HALVES;                            // X1 | XU; staging slots 1..3 overlay
     auto slot = [&](int k) { return k == 0 ? slot0 : fsm + (k - 1) * (FR_GROUP * SLAB); };
@@ -2071,8 +2080,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         rg.nb_stride = (int64_t)NW * KS0 * (2 * FRAG);
     };
     int4 te = g.tile_tab[tile];
+    int par = 0;   // which half of s_orow holds the current item's rows
     {
         const int atom0 = g.tile_rows[(size_t)tile * ROWS + srow];
+        if (spc == 0) s_orow[srow] = atom0;   // (read behind the barriers of the item's phases)
         prefetch_aev(te, atom0);
         prefetch_w0(te, mem);
     }
@@ -2099,9 +2110,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const int atom_n = g.tile_rows[(size_t)tile_n * ROWS + srow];
 #ifdef ANIHIP_DEV_TRACE
         if (g.trace && lane == 0) {
-            g.trace[((size_t)item * 8 + wave) * 16 + 0] = __builtin_readcyclecounter();
+            g.trace[((size_t)item * 8 + wave) * 32 + 0] = __builtin_readcyclecounter();
             // placement: HW_REG_HW_ID (cu / sh / se) and HW_REG_XCC_ID, for co-residency analysis
-            g.trace[((size_t)item * 8 + wave) * 16 + 14] = 1 + (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
+            g.trace[((size_t)item * 8 + wave) * 32 + 14] = 1 + (((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) |
                                                    ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
         }
 #endif
@@ -2121,7 +2132,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // accumulator element (rb, nb, r) of this lane <-> tile row (u.rb0 + rb)*32 + fr, column col0(u, nb) + 8 (r >> 2) + (r & 3)
         auto col0 = [&](const FusedUnit &u, int nb) { return (u.cb + NW * nb) * 32 + 4 * fk; };
 #ifdef ANIHIP_DEV_TRACE
-        unsigned long long *trace = g.trace ? g.trace + ((size_t)item * 8 + wave) * 16 : nullptr;
+        unsigned long long *trace = g.trace ? g.trace + ((size_t)item * 8 + wave) * 32 : nullptr;
 #endif
         ANIHIP_STAMP(trace, 1);
 
@@ -2190,6 +2201,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const v4f bnd = *(const gf4 *)(fs.bounds + 8 * m);   // operand bounds of this member
         float bias0[NB][16];
         if (!C::LAZY) load_cols(fs.b0 + (int64_t)m * H1, bias0, u1);
+        const uint32_t tmask_cur = tmask;   // (prefetch_w0 moves tmask on to the next item's)
         const int nact = __popc(tmask);
         const int npair = (nact + 2 * FR_GROUP - 1) / (2 * FR_GROUP);
         // (AEV slabs 0..5 and the first D weight fragments were requested during the previous item)
@@ -2431,12 +2443,152 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         prefetch_w0(te_n, mem_n);
         __syncthreads();
         ANIHIP_STAMP(trace, 11);
-        // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global ===============
+        // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global, or -> LDS for phase 5 ===============
         if (g.want_grad && u1.nrb > 0) {
             zero_acc();
             FR_UNIT(u1, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X1 + u1.rb0 * 32 * ld1, ld1, x1_plane, r4, H2 >> 4, lane)))
         }
         ANIHIP_STAMP(trace, 12);
+        if constexpr (L0B) {
+            {
+            // =============== phase 5 (l0b): d E / d AEV += d act0 x W0 over the tile's flagged slabs ===============
+            // d act0 goes into LDS as split planes (X0's place: the last readers of XU finished before the barrier ahead of
+            // phase 4) instead of to HBM, and the layer-0 backward GEMM runs here: a column block is one flagged AEV slab,
+            // K = this member's H1 columns.  The workgroup OWNS the tile through all members (owner order), so the sum
+            // over the members is a plain read-add-write of the same lane on the same address, member after member in
+            // a fixed order: no atomics, no d act0 round trip through HBM, no separate GEMM launch.
+            const float s4 = pow2_scale_for(fs.bounds[8 * m + 4] * (ACT == 1 ? 1.13f : 1.0f));   // |d act0| <= [4] max act'
+            // Work of a pass: FOUR flagged slabs x both row blocks x K, dealt so that every SIMD's two waves (w, w + 4) share a
+            // slab: wave w takes the FIRST half of the k steps, wave w + 4 the second, each for both row blocks (every weight
+            // fragment crosses the CU's 64 B/clk L2 port once and feeds six MFMAs).  The two partial tiles meet in LDS (X1's
+            // place, dead since phase 4): a wave hands over the row block it does not own and finishes the other --
+            // w: rows 0..31, w + 4: rows 32..63 -- with the read-add-write on the AEV gradient rows.
+            const int KS5 = H1 >> 4, KH0 = (KS5 >> 2) << 1;
+            const int half = wave >> 2;
+            const int kbeg = half ? KH0 : 0, KH = half ? KS5 - KH0 : KH0;   // (both even)
+            const int64_t mh5 = (int64_t)g.n_slabs * KS5 * (2 * FRAG);
+            auto nth_slab = [&](int c) {   // c-th flagged slab of the tile (scalar), -1 past the end
+                uint32_t mk = tmask_cur;
+                for (int t = 0; t < c; ++t) mk &= mk - 1u;
+                return mk ? (int)__builtin_ctz(mk) : -1;
+            };
+            Ring r5;
+            auto ring5 = [&](int sl_) {   // the first D fragments of this wave's k range of slab sl_
+                r5.nb_stride = 0;
+                r5.base = fs.w0t + (int64_t)m * mh5 + ((int64_t)sl_ * KS5 + kbeg) * (2 * FRAG) + lane * 8;
+#pragma unroll
+                for (int sl = 0; sl < D; ++sl) r5.template load<NB>(sl, min(sl, KH - 1));
+            };
+            int slab = nth_slab(wave & 3);
+            ring5(max(slab, 0));   // (travels during the epilogue below)
+            ANIHIP_STAMP(trace, 16);
+            if (g.want_grad && u1.nrb > 0) {
+                const float osc4 = fs.is1 / s3;
+#pragma unroll
+                for (int i = 0; i < NE; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= osc4 * d0f[i][r];
+                put_acc(X0, x0_plane, ld0, s4, u1);
+            }
+            ANIHIP_STAMP(trace, 17);
+            __syncthreads();   // d act0 complete
+            ANIHIP_STAMP(trace, 13);
+            if (g.want_grad) {
+                const float osc5 = fs.is0 / s4;
+                // The finished 32 x 32 tile of a wave (row block `half` of its slab) leaves through a second, wave-private LDS
+                // tile so that a store instruction covers 8 rows x 128 contiguous bytes -- whole cache lines -- instead of the
+                // MFMA layout's 32 rows x 32 bytes (1.1 ms per step at the headline size went into those partial-line
+                // stores): lane -> row 8 p + (lane >> 3), 16-byte piece lane & 7, p = 0..3.
+                const int piece = lane & 7;
+                float *orow[4];
+                bool rok[4];
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    const int row = half * 32 + p4 * 8 + (lane >> 3);
+                    orow[p4] = g.grad_aev + (int64_t)s_orow[par * ROWS + row] * g.L + 4 * piece;
+                    rok[p4] = row < n_rows;    // (short tiles repeat their last atom: one writer per row only)
+                }
+                v4f *xch = reinterpret_cast<v4f *>(slot0);   // [wave][q][lane]: partial sums handed to the partner wave (slot 0 | X1)
+                // this wave's finished tile, 32 rows x 32 floats: in the PARTNER's hand-over block, which only this wave reads
+                // (d act0 in XU must stay whole for the further passes of tiles with more than four flagged slabs); the
+                // 16-byte pieces of a row are XOR-swizzled with row >> 1, conflict-free for the MFMA-layout writes and the
+                // row-major reads alike
+                float *tile5 = reinterpret_cast<float *>(xch + (wave ^ 4) * 4 * 64);
+                auto t5 = [&](int row, int pc) { return tile5 + row * 32 + (((pc ^ (row >> 1)) & 7) << 2); };
+                // (the last pass -- the only one of a water tile -- is peeled: what it prefetches for the next item must not be
+                // defined under a condition inside a loop, or it is carried around the loop in registers)
+                auto pass = [&](int c0, auto last_) {
+                    constexpr bool LAST = decltype(last_)::value;
+                    const bool live = slab >= 0;
+                    const int sl = max(slab, 0);
+                    const int col5 = g.kp_rad ? kp_col(g.kp_rad, sl) : 32 * sl;
+                    const int nv5 = g.kp_rad ? kp_valid(g.kp_rad, sl) : min(32, (int)g.L - 32 * sl);
+                    // what the members before this one left in the rows (this wave wrote it: L2 hits), requested ahead of the
+                    // MFMA loop
+                    v4f prev[4];
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) {
+                        // (lanes with nothing to read -- the first member, waves without a slab -- read a line that is hot in
+                        // L2: loads return in order, and a miss to HBM here would hold up the weight ring's requests behind it)
+                        const bool ok = live && rok[p4] && m > 0 && 4 * piece < nv5;
+                        prev[p4] = *(const gf4 *)(ok ? orow[p4] + col5 : fs.bounds);
+                        if (!ok) prev[p4] = v4f{0.f, 0.f, 0.f, 0.f};
+                    }
+                    zero_acc();
+                    ANIHIP_STAMP(trace, 19);
+                    if (live) fr_gemm<RB, NB, RB, 1, D>(acc, X0 + kbeg * 16, ld0, x0_plane, r5, KH, lane);
+                    ANIHIP_STAMP(trace, 20);
+                    const int slab_n = nth_slab(c0 + 4 + (wave & 3));
+                    if constexpr (LAST) {
+                        // the next item's AEV slabs: behind the last ring request of this item (loads return in order: a
+                        // miss to HBM ahead of a ring request would stall the MFMA loop), ahead of the hand-over and the stores
+                        prefetch_aev(te_n, atom_n);
+                    } else {
+                        ring5(max(slab_n, 0));
+                    }
+                    // hand the other row block's partial sums to the partner wave, take this one's
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v4f t;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = half ? acc[0][4 * q + e] : acc[1][4 * q + e];
+                        xch[(wave * 4 + q) * 64 + lane] = t;
+                    }
+                    __syncthreads();
+                    ANIHIP_STAMP(trace, 21);
+                    v4f fin[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4f t = xch[((wave ^ 4) * 4 + q) * 64 + lane];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) fin[q][e] = (half ? acc[1][4 * q + e] : acc[0][4 * q + e]) + t[e];
+                    }
+                    // (wave-private from here on: the LDS serves a wave's accesses in order)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f *>(t5(fr, 2 * q + fk)) = fin[q];   // (row fr, columns 8 q + 4 fk ..)
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) {
+                        const v4f t = *reinterpret_cast<const v4f *>(t5(p4 * 8 + (lane >> 3), piece));
+                        v4f v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(t[e], osc5, prev[p4][e]);
+                        if (live && rok[p4] && 4 * piece < nv5) *reinterpret_cast<v4f *>(orow[p4] + col5) = v;
+                    }
+                    if constexpr (!LAST) __syncthreads();   // (the hand-over buffer and the tiles are written again in the next pass)
+                    slab = slab_n;
+                };
+                int c0 = 0;
+                for (; c0 + 4 < nact; c0 += 4) pass(c0, std::false_type{});
+                pass(c0, std::true_type{});
+            } else {
+                prefetch_aev(te_n, atom_n);
+            }
+            ANIHIP_STAMP(trace, 8);
+            if (spc == 0) s_orow[(par ^ 1) * ROWS + srow] = atom_n;
+            // every wave is done with the LDS of this item: the next one may stage its slabs
+            __syncthreads();
+            }
+        } else {
         // the AEV slabs of the next item travel during the stores below (requested AFTER the last ring load of this
         // item: loads complete in order, and an HBM miss ahead of a ring request stalls the MFMA loop that waits
         // for it)
@@ -2471,8 +2623,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 }
             }
         }
-        ANIHIP_STAMP(trace, 13);
+        }
+        ANIHIP_STAMP(trace, 15);
         if (!has_next) break;
+        par ^= 1;
         te = te_n;
         mem = mem_n;
         tile = tile_n;
@@ -3235,9 +3389,24 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         }
     }
 
+    // Layer-0 backward INSIDE the fused kernel (its phase 5): a workgroup owns a tile through all members and adds the
+    // members' d E / d AEV in place -- no d act0 round trip through HBM (8 KB per atom written and read back), no layer-0
+    // backward launch.  Tiles are then the unit of work (not tile x member items), so it needs enough of them to balance
+    // over the CUs: from 65536 atoms on (1024 tiles).  Smaller inputs keep the member-major sweep + a backward GEMM.
+    bool fused_l0b = fused && grad_aev && fused_rows == 64 && kp_rad > 0 && n >= FUSED_L0B_MIN_ATOMS &&
+                     !(d->flags & (ANIHIP_MLP_FLAG_NO_FUSED_L0B | ANIHIP_MLP_FLAG_SMALL_TILES));
+    // (phase 5 hands partial sums between waves through 32 KB of LDS in X1's place: 2 planes x 64 rows x (H2 + 8) halves)
+    auto l0b_ok = [&](int s) { return d->net[s].wthf[0] != nullptr && d->net[s].dims[2] >= 128; };
+    for (int s = 0; s < S && fused_l0b; ++s) fused_l0b = l0b_ok(s);
+    if (d->flags & ANIHIP_MLP_FLAG_FUSED_L0B) {   // (forced, e.g. by the tests on small inputs)
+        fused_l0b = fused && grad_aev && fused_rows == 64 && kp_rad > 0;
+        for (int s = 0; s < S && fused_l0b; ++s) fused_l0b = l0b_ok(s);
+        ANIHIP_REQUIRE(fused_l0b, "ANIHIP_MLP_FLAG_FUSED_L0B needs the fused kernel (64-row tiles), slab-ordered planes and wthf[0]");
+    }
+
     FinishArgs fin{};
     // few atoms: the layer-0 backward runs in the 8-wave 128 x 128 kernel (needs the slab flags for its column compaction)
-    const bool use_l0s = grad_aev && h3 && !big_tiles && kp_rad > 0 && K0p <= 32 * 32 && slab_mask &&
+    const bool use_l0s = grad_aev && !fused_l0b && h3 && !big_tiles && kp_rad > 0 && K0p <= 32 * 32 && slab_mask &&
                          !(d->flags & (ANIHIP_MLP_FLAG_NO_SLAB_MASK | ANIHIP_MLP_FLAG_L0B_4WAVE));
     if (fused) {
         FusedArgs f{};
@@ -3252,6 +3421,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             fs.w0 = (const _Float16 *)nn.whf[0];
             fs.w1 = (const _Float16 *)nn.whf[1]; fs.w2 = (const _Float16 *)nn.whf[2];
             fs.w2t = (const _Float16 *)nn.wthf[2]; fs.w1t = (const _Float16 *)nn.wthf[1];
+            fs.w0t = (const _Float16 *)nn.wthf[0];
             fs.is0 = 1.0f / nn.wh_scale[0]; fs.is1 = 1.0f / nn.wh_scale[1]; fs.is2 = 1.0f / nn.wh_scale[2];
             fs.b0 = nn.bias[0]; fs.b1 = nn.bias[1]; fs.b2 = nn.bias[2]; fs.w3 = nn.w[3]; fs.b3 = nn.bias[3];
             fs.bounds = nn.fused_bounds;
@@ -3273,9 +3443,13 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
         f.want_grad = grad_aev ? 1 : 0;
         f.owner = (d->flags & ANIHIP_MLP_FLAG_TILE_OWNER) ? 1 : 0;
+        f.l0b = fused_l0b ? 1 : 0;
+        f.grad_aev = grad_aev;
+        if (fused_l0b) { f.owner = 1; f.d0 = nullptr; }
         const bool gelu = d->activation == ANIHIP_ACT_GELU;
-        const void *kfn = rows == 64 ? (gelu ? (const void *)k_mlp_fused<2, 1, 1> : (const void *)k_mlp_fused<2, 1, 0>)
-                                     : (const void *)k_mlp_fused<1, 2, 0>;
+        const void *kfn = rows == 64 ? (fused_l0b ? (gelu ? (const void *)k_mlp_fused<2, 1, 1, true> : (const void *)k_mlp_fused<2, 1, 0, true>)
+                                                  : (gelu ? (const void *)k_mlp_fused<2, 1, 1, false> : (const void *)k_mlp_fused<2, 1, 0, false>))
+                                     : (const void *)k_mlp_fused<1, 2, 0, false>;
         ANIHIP_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t tiles = fused_tiles;
         f.tiles_total = (int)tiles;
@@ -3296,7 +3470,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                                f.slab_mask, all_slabs, (int)tiles, rows, w.tile_tab, w.tile_rows);
 #ifdef ANIHIP_DEV_TRACE   // development builds only (tools/fused_trace.py): per-item phase stamps, allocates and synchronises
         const char *trace_path = getenv("ANIHIP_FUSED_TRACE");
-        const size_t trace_words = (size_t)16 * 8 * items;   // [item][wave][16]
+        const size_t trace_words = (size_t)32 * 8 * items;   // [item][wave][32]
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipMalloc((void **)&f.trace, sizeof(unsigned long long) * trace_words));
             ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * trace_words));
@@ -3304,11 +3478,14 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
 #endif
         if (rows == 64)
         {
-            if (gelu) hipLaunchKernelGGL((k_mlp_fused<2, 1, 1>), dim3((unsigned)grid), dim3(512), lds, stream, f);
-            else hipLaunchKernelGGL((k_mlp_fused<2, 1, 0>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+            if (fused_l0b) {
+                if (gelu) hipLaunchKernelGGL((k_mlp_fused<2, 1, 1, true>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+                else hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, true>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+            } else if (gelu) hipLaunchKernelGGL((k_mlp_fused<2, 1, 1, false>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+            else hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, false>), dim3((unsigned)grid), dim3(512), lds, stream, f);
         }
         else
-            hipLaunchKernelGGL((k_mlp_fused<1, 2, 0>), dim3((unsigned)grid), dim3(256), lds, stream, f);
+            hipLaunchKernelGGL((k_mlp_fused<1, 2, 0, false>), dim3((unsigned)grid), dim3(256), lds, stream, f);
 #ifdef ANIHIP_DEV_TRACE
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipStreamSynchronize(stream));
@@ -3348,7 +3525,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     }
 
     // 4. backward to the AEV rows
-    if (grad_aev) {
+    if (grad_aev && !fused_l0b) {
         for (int l = fused ? 0 : nh - 1; l >= 0; --l) {
             GemmArgs g{};
             g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha;

@@ -86,7 +86,8 @@ size_t layout(const Geometry &g, Offsets *off)
                 o.wh[l] = take(2 * 2 * M * kout * kred);
                 o.wth[l] = take(2 * 2 * M * kout * kred);
                 o.whf[l] = take(2 * 2 * M * kout * kred);
-                if (l >= 1) o.wthf[l] = take(2 * 2 * M * kout * kred);
+                // (layer 0: the transposed planes per member, [M][K0h][H1p], for the layer-0 backward inside the fused kernel)
+                if (l >= 1 || g.fused) o.wthf[l] = take(2 * 2 * M * kout * kred);
             }
         }
         if (g.fused) o.bounds = take(4 * 8 * (size_t)g.M);
@@ -246,6 +247,18 @@ extern "C" int anihip_mlp_pack(void *stream, const anihip_mlp_shape *sh, const f
             net.whf[l] = base + o.whf[l];
             if (l >= 1) {
                 to_fragments(wth, M, kin, kout, (_Float16 *)(buf + o.wthf[l]));
+                net.wthf[l] = base + o.wthf[l];
+            } else if (g.fused) {
+                // W0 transposed, member by member: planes [2][M][N = K0h (slab order)][K = H1p] -> fragments, so that a
+                // column block of the layer-0 backward is one AEV slab and its k steps run over the member's H1 columns
+                std::vector<_Float16> tp(2 * n_el);
+                const size_t ld = (size_t)M * kout;
+                for (int pl = 0; pl < 2; ++pl)
+                    for (int m = 0; m < M; ++m)
+                        for (int c = 0; c < kred; ++c)
+                            for (int h = 0; h < kout; ++h)
+                                tp[pl * n_el + ((size_t)m * kred + c) * kout + h] = wth[pl * n_el + (size_t)c * ld + (size_t)m * kout + h];
+                to_fragments(tp.data(), M, kred, kout, (_Float16 *)(buf + o.wthf[l]));
                 net.wthf[l] = base + o.wthf[l];
             }
         }
