@@ -284,7 +284,7 @@ def main():
         sd_np = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
         parity = sampled_parity(species, coords, cell, out.atomic_energies, out.forces, sd_np, "ani2x", 8,
                                 n_sample=args.parity_sample, seed=7)
-        assert parity["max_dE_atom"] <= parity["gate_dE_atom"] and parity["max_dF"] <= parity["gate_dF"], \
+        assert parity["max_dE_atom"] <= parity["regression_gate_dE_atom"] and parity["max_dF"] <= parity["regression_gate_dF"], \
             f"headline result disagrees with the oracle: {parity}"
 
     # ---- per-stage device timing on this rank's shard (outside the timed region) -----------------------

@@ -77,4 +77,6 @@ def sampled_parity(species, coords, cell, atomic_energies, forces, state_dict: t
         max_df = max(max_df, float(np.abs(ref["forces"][:, 0] - f_dev[b0:b0 + batch]).max()))
     return {"n": int(len(centers)), "max_dE_atom": max_de, "max_dF": max_df, "cluster_atoms_mean": float(np.mean(sizes)),
             "radius_A": 2.0 * consts.Rcr, "oracle": "oracle/ani_oracle.c fp64, non-periodic clusters around the sampled atoms",
-            "gate_dE_atom": 1e-5, "gate_dF": 1e-4, "seconds": time.perf_counter() - t0}
+            "gate_dE_atom": 1e-5, "gate_dF": 1e-4,
+            # (regression gates ~20x the measured error, as in tests/test_gpu_parity.py: a kernel bug inside the parity gates fails these)
+            "regression_gate_dE_atom": 1e-6, "regression_gate_dF": 5e-6, "seconds": time.perf_counter() - t0}

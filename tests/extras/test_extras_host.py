@@ -192,86 +192,3 @@ def test_assembler_and_term_objects():
     for k in sd_r:
         if "aev_computer" in k or k in ("atomic_numbers", "energy_shifter.self_energies"):
             assert torch.allclose(sd_r[k].double(), sd_a[k].double()), k
-
-
-def test_transforms_module():
-    """torchani_amd.transforms: the host-side batch transforms of the reference (transforms.py:43-230) on CPU tensors; the
-    reference's classes on the same batch where the tree is present."""
-    from collections import namedtuple
-
-    from torchani_amd.extras import transforms as T
-
-    sym, sae = ("H", "C", "O"), (-0.5, -37.8, -75.0)
-    batch = {"species": torch.tensor([[8, 1, 1, -1], [6, 1, 1, 1]]), "coordinates": torch.zeros(2, 4, 3),
-             "energies": torch.tensor([-76.3, -39.2], dtype=torch.float64), "forces": torch.ones(2, 4, 3)}
-    pipe = T.Compose([T.SubtractSAE(sym, sae), T.identity, T.AtomicNumbersToIndices(sym)])
-    out = pipe({k: v.clone() for k, v in batch.items()})
-    assert torch.allclose(out["energies"], torch.tensor([-76.3 + 76.0, -39.2 + 39.3], dtype=torch.float64))
-    assert out["species"].tolist() == [[2, 0, 0, -1], [1, 0, 0, 0]] and pipe.atomic_numbers.tolist() == [1, 6, 8]
-    assert "SubtractSAE" in repr(pipe) and T.Identity().atomic_numbers is None
-    with pytest.raises(ValueError):
-        T.Compose([T.SubtractSAE(sym, sae), T.AtomicNumbersToIndices(("H", "O"))])
-
-    class Model:   # stand-in for an engine-backed model
-        def energies_and_forces(self, sp, x):
-            return namedtuple("Out", "energies forces")(torch.full((sp.shape[0],), 2.0), torch.full_like(x, 0.25))
-
-    o2 = T.SubtractModel(Model())({k: v.clone() for k, v in batch.items()})
-    assert torch.allclose(o2["energies"], batch["energies"] - 2.0) and torch.allclose(o2["forces"], batch["forces"] - 0.25)
-    if not os.path.exists("/root/reference/torchani/transforms.py"):
-        pytest.skip("reference tree not present")
-    from _util import import_reference
-    import_reference()
-    from torchani import transforms as R
-    ref = R.Compose([R.SubtractSAE(sym, sae), R.AtomicNumbersToIndices(sym)])({k: v.clone() for k, v in batch.items()})
-    assert torch.equal(ref["species"], out["species"]) and torch.allclose(ref["energies"], out["energies"])
-
-
-def test_sae_estimation():
-    """sae_estimation.exact_saes recovers the self energies a synthetic dataset was built from (also with an intercept),
-    approx_saes moves towards them; plain lists of batches and objects with a ``transform`` attribute both work; the
-    reference's functions on the same dataset where the tree is present."""
-    from torchani_amd.extras.sae_estimation import approx_saes, exact_saes
-
-    sym, true = ("H", "C", "O"), torch.tensor([-0.5, -37.8, -75.0])
-    znum = torch.tensor([1, 6, 8])
-    g = torch.Generator().manual_seed(0)
-
-    def batch():
-        idx = torch.randint(-1, 3, (16, 9), generator=g)
-        sp = torch.where(idx >= 0, znum[idx.clamp(min=0)], idx)
-        e = torch.stack([(idx == k).sum(-1) for k in range(3)], 1).float() @ true
-        return {"species": sp, "energies": e.double()}
-
-    data = [batch() for _ in range(6)]
-    m, b = exact_saes(data, sym)
-    assert b is None and torch.allclose(m, true, atol=1e-3)
-    for d in data:
-        d["energies"] += 1.25
-    m2, b2 = exact_saes(data, sym, fit_intercept=True)
-    assert torch.allclose(m2, true, atol=2e-3) and abs(b2.item() - 1.25) < 2e-2
-    assert data[0]["species"].max() == 8                                   # (the batches are left as they were)
-
-    class DS(list):   # the reference's BatchedDataset protocol: batches come out through .transform
-        transform = staticmethod(lambda p: p)
-
-        def __iter__(self):
-            return (self.transform({k: v.clone() for k, v in p.items()}) for p in list.__iter__(self))
-
-    ds = DS(batch() for _ in range(6))
-    keep = ds.transform
-    m3, _ = exact_saes(ds, sym, fraction=0.5)
-    assert torch.allclose(m3, true, atol=1e-3) and ds.transform is keep
-    m4, b4 = approx_saes(ds, sym, max_epochs=200, lr=2e-3)
-    assert b4 is None and (m4 - true).abs().max() < (torch.ones(3) - true).abs().max()
-    if not os.path.exists("/root/reference/torchani/sae_estimation.py"):
-        pytest.skip("reference tree not present")
-    from _util import import_reference
-    import_reference()
-    from torchani.sae_estimation import approx_saes as ref_approx
-    from torchani.sae_estimation import exact_saes as ref_exact
-    assert torch.allclose(ref_exact(ds, sym)[0], exact_saes(ds, sym)[0], atol=1e-4)
-    torch.manual_seed(0)
-    a = ref_approx(ds, sym, max_epochs=3, lr=1e-3, fit_intercept=True)
-    b = approx_saes(ds, sym, max_epochs=3, lr=1e-3, fit_intercept=True)
-    assert torch.allclose(a[0], b[0], atol=1e-5) and torch.allclose(a[1], b[1], atol=1e-5)

@@ -761,4 +761,20 @@ def test_no_inline_asm_valu_to_mfma_hazard():
     if not os.path.exists(os.path.join(mod.LLVM, "llvm-objdump")):
         pytest.skip("no llvm-objdump")
     checked, bad = mod.check(_lib.LIB_PATH)
-    assert checked > 0 and not bad, bad
+    assert checked > 1000 and not bad, bad
+    # the checker itself: every rule fires on a bare producer -> consumer pair and accepts the padded one
+    cases = [
+        ("v_fma_mixhi_f16 v7, v17, v144, -v3 op_sel:[0,0,1]", "v_mfma_f32_32x32x16_f16 v[18:33], v[4:7], v[46:49], v[18:33]", 2),
+        ("v_exp_f32_e32 v5, v4", "v_mul_f32_e32 v6, v5, v5", 1),
+        ("v_add_f32_e32 v9, v1, v2", "v_mov_b32_dpp v3, v9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", 2),
+        ("v_add_f32_e32 v9, v1, v2", "v_readlane_b32 s4, v9, 16", 1),
+        ("v_mov_b32_e32 v9, v1", "v_permlane32_swap_b32_e32 v9, v10", 2),
+    ]
+    for prod, cons, need in cases:
+        for pad in range(need + 1):
+            seq = [("k", prod)] + ([("k", f"s_nop {pad - 1}")] if pad else []) + [("k", cons)]
+            n_, bad_ = mod.check_instructions(seq)
+            assert n_ == 1 and (len(bad_) == 1) == (pad < need), (prod, cons, pad, bad_)
+    # an unrelated register, or an instruction in between, is no hazard
+    assert mod.check_instructions([("k", "v_exp_f32_e32 v5, v4"), ("k", "v_mul_f32_e32 v6, v7, v7")]) == (0, [])
+    assert mod.check_instructions([("k", "v_exp_f32_e32 v5, v4"), ("k", "v_mov_b32_e32 v8, v1"), ("k", "v_mul_f32_e32 v6, v5, v5")])[1] == []

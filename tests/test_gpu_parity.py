@@ -18,9 +18,17 @@ from torchani_amd.engine import PackedNetworks
 
 pytestmark = pytest.mark.gpu
 
+# north_star's gates (BASELINE.json): what "matches the reference" means
 AEV_TOL = 2e-5
 E_ATOM_TOL = 1e-5
 F_TOL = 1e-4
+# REGRESSION gates, ~20x what the engine measures on these cases (per-atom energies <= 7e-8 Ha, forces <= 2.5e-7 Ha/A,
+# AEV vector-Jacobian products <= 2e-6 of the largest entry): a kernel bug that stays inside the parity gates -- round 3's
+# missing wait state gave 2 % wrong dE/dAEV, |dF| = 9e-5 -- must fail HERE.  (The reference gates its own cuAEV at its
+# noise floor too: tests/test_cuaev.py:169.)
+E_ATOM_REG = 1e-6
+F_REG = 5e-6
+VJP_REG_REL = 5e-6
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
                       "parity_report.txt")
 
@@ -150,6 +158,7 @@ def test_aev_forward_and_backward(dev, name):
         report(f"aev   {name:22s} {mode:5s} max|aev err| = {err:.2e}   vjp err = {verr:.2e} (|vjp|max {vmag:.1f})")
         assert err < AEV_TOL
         assert verr < 2e-5 * max(1.0, vmag)
+        assert verr <= VJP_REG_REL * max(1.0, vmag), "regression gate (module header): AEV backward"
         assert np.all(vjp.cpu().numpy()[g["species"] < 0] == 0)
 
 
@@ -497,6 +506,37 @@ def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     assert np.all(e.detach().cpu().numpy()[pad] == 0) and np.all(gr.cpu().numpy()[pad] == 0)
 
 
+def test_general_grid_on_a_large_system(dev):
+    """A from_constants grid (8 radial / 4 x 4 angular terms) on a 17 496-atom H / O box: large enough for the species
+    relabelling of models.ANI._engine_species (water under H C N O would be relabelled (0, 3, 1, 2)), which only applies to
+    the 16 / 32-column ANI layout -- a general grid must be left alone (it used to raise in the packer).  The fused path
+    must agree with the autograd path, which never relabels."""
+    from bench import water_box
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.grad import energies_and_forces
+    from torchani_amd.models import ANI
+    from torchani_amd.nn import ANINetworks, Ensemble
+
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grid_r8_a4z4_batch.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    symbols = ("H", "C", "N", "O")
+    aevc = AEVComputer.from_constants(float(g["Rcr"]), float(g["Rca"]), float(g["EtaR"]), g["ShfR"].tolist(), float(g["EtaA"]),
+                                      float(g["Zeta"]), g["ShfA"].tolist(), g["ShfZ"].tolist(), 4, row_capacity=256,
+                                      neighborlist="cell")
+    torch.manual_seed(9)
+    nets = Ensemble([ANINetworks.build(symbols, aevc.out_dim, {"H": (64, 48, 32), "C": (64, 32, 32), "N": (32, 32, 32),
+                                                               "O": (48, 32, 32)}) for _ in range(2)])
+    model = ANI(symbols, aevc, nets, [-0.5, -37.8, -54.6, -75.0], periodic_table_index=False).to(dev)
+    sp_np, x_np, cell_np = water_box(18)   # species 0 (H) and 3 (O)
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    pbc = (True, True, True)
+    assert model._engine_species(sp.to(torch.int32))[1] is None
+    out = model.energies_and_forces(sp, x, cell, pbc, check_overflow=True)
+    e, f = energies_and_forces(model, sp, x, cell, torch.tensor(pbc))
+    assert abs(float(out.energies - e)) < 1e-7 * sp.numel()
+    assert float((out.forces - f).abs().max()) < 5e-6 * max(1.0, float(f.abs().max()))
+
+
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_energies_and_forces_fused(dev, name):
     g = load_golden(name)
@@ -513,6 +553,7 @@ def test_energies_and_forces_fused(dev, name):
                f"  |F err| = {fe:.2e}")
         assert ea < E_ATOM_TOL
         assert fe < F_TOL
+        assert ea <= E_ATOM_REG and fe <= F_REG, "regression gate (module header)"
         # totals are accumulated in fp64 from fp32 per-atom energies: error grows at most like n * eps
         assert et < E_ATOM_TOL * max(1.0, np.sqrt(n_real))
         assert np.all(out.forces.cpu().numpy()[g["species"] < 0] == 0)
@@ -560,6 +601,7 @@ def test_energies_and_forces_slab_masks(dev, name, monkeypatch):
     fe = np.abs(out.forces.cpu().numpy() - g["forces"]).max()
     report(f"slab  {name:22s} max|e_atom err| = {ea:.2e}  |F err| = {fe:.2e}")
     assert ea < E_ATOM_TOL and fe < F_TOL
+    assert ea <= E_ATOM_REG and fe <= F_REG, "regression gate (module header)"
     assert np.all(out.forces.cpu().numpy()[g["species"] < 0] == 0)
 
 
@@ -635,6 +677,7 @@ def test_shards_add_up_to_the_whole(dev, name, world, monkeypatch):
     torch.cuda.synchronize()
     assert np.abs(ae.cpu().numpy() - g["atomic_energies"]).max() < E_ATOM_TOL
     assert np.abs(f.cpu().numpy() - g["forces"]).max() < F_TOL
+    assert np.abs(ae.cpu().numpy() - g["atomic_energies"]).max() <= E_ATOM_REG and np.abs(f.cpu().numpy() - g["forces"]).max() <= F_REG
     n_real = int((g["species"] >= 0).sum())
     assert np.abs(e.cpu().numpy() - g["energies"]).max() < E_ATOM_TOL * max(1.0, np.sqrt(n_real))
 
@@ -1891,6 +1934,7 @@ def test_headline_scale_sampled_parity(dev):
     report(f"box   water {sp.numel()} atoms pbc  sampled n={res['n']}: max|e_atom err| = {res['max_dE_atom']:.2e}  "
            f"max|F err| = {res['max_dF']:.2e}  ({res['seconds']:.0f} s oracle)")
     assert res["max_dE_atom"] < E_ATOM_TOL and res["max_dF"] < F_TOL
+    assert res["max_dE_atom"] <= E_ATOM_REG and res["max_dF"] <= F_REG, "regression gate (module header)"
     del out
     torch.cuda.empty_cache()
 
@@ -1917,6 +1961,7 @@ def test_large_systems_of_any_composition_against_the_oracle(dev, elements):
     # (element soups on water coordinates have forces of tens of Ha/A: gates relative to the largest force)
     fmax = max(1.0, float(out.forces.abs().max()))
     assert res["max_dE_atom"] < E_ATOM_TOL * max(1.0, float(out.atomic_energies.abs().max())) and res["max_dF"] < F_TOL * fmax
+    assert res["max_dE_atom"] <= E_ATOM_REG * max(1.0, float(out.atomic_energies.abs().max())) and res["max_dF"] <= F_REG * fmax
     e = torch.zeros(1, dtype=torch.float64, device=dev)
     f = torch.zeros_like(x)
     for rank in range(3):

@@ -54,32 +54,97 @@ def instructions(code):
             yield kernel, line
 
 
+def _regs(tok):
+    """VGPR numbers named by one operand token ('v7', 'v[4:7]', '-v3', '|v2|'); empty for anything else."""
+    m = re.fullmatch(r"[-|]*v(\d+)\|?", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"[-|]*v\[(\d+):(\d+)\]\|?", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def _operands(line):
+    parts = line.split(None, 1)
+    if len(parts) < 2:
+        return []
+    body = re.split(r"\s+(?:op_sel|op_sel_hi|neg_lo|neg_hi|quad_perm|row_|bank_mask|bound_ctrl|offset|clamp|mul:|div:|cbsz|abid|blgp|sc0|sc1|nt|fi:)", parts[1])[0]
+    return [t.strip() for t in body.split(",")]
+
+
+TRANS = re.compile(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
+VALU = re.compile(r"v_(?!mfma|readlane|readfirstlane|nop)")
+DPP = re.compile(r"(quad_perm|row_shl|row_shr|row_ror|row_mirror|row_half_mirror|row_bcast|wave_shl|wave_shr|wave_rol|wave_ror|row_newbcast|row_share|row_xmask)")
+
+
+def _states(nxt):
+    return int(nxt.split()[1]) + 1 if nxt.startswith("s_nop") else 1
+
+
 def check(lib_path):
-    """(pairs checked, list of violations).  (a) VALU write -> MFMA read: two wait states."""
+    """(pairs checked, violations).  Walks EVERY instruction of every gfx950 kernel of the library -- compiler-scheduled
+    code and the inline-assembly sites (csrc/mlp.hip: v_fma_mix{lo,hi}_f16, s_nop) alike -- for the data hazards the hardware
+    does not interlock (gfx950 ISA guide / LLVM's GCNHazardRecognizer), by the number of wait states between producer and
+    consumer (an instruction in between = 1, s_nop N = N + 1):
+      (a) VALU write of a VGPR -> MFMA reading it as A / B operand: 2      [round 3's k_gemm_l0b bug: 1 behind inline asm]
+      (b) transcendental (v_exp / log / rcp / rsq / sqrt / sin / cos) result -> non-transcendental VALU reading it: 1
+      (c) VALU write of a VGPR -> DPP instruction reading it: 2
+      (d) VALU write of a VGPR -> v_readlane / v_readfirstlane of it: 1
+      (e) VALU write of a VGPR -> v_permlane{16,32}_swap using it: 2
+    hipcc pads these for the code it schedules itself; behind asm() it cannot see the producer."""
     checked, bad = 0, []
     for code in code_objects(lib_path):
-        ins = list(instructions(code))
+        c, b = check_instructions(list(instructions(code)))
+        checked += c
+        bad += b
+    return checked, bad
+
+
+def check_instructions(ins):
+    """The walk of ``check`` over a list of (kernel name, instruction text)."""
+    checked, bad = 0, []
+    if True:
         for k, (kern, line) in enumerate(ins):
-            if not line.startswith(INLINE_ASM_VALU):
+            if not VALU.match(line) or line.startswith("v_cmp"):
                 continue
-            # (b) a transcendental result needs a wait state before a VALU instruction reads it (trans forwarding hazard)
-            if k > 0 and re.match(r"v_(exp|log|rcp|rsq|sqrt|sin|cos)_", ins[k - 1][1]):
-                checked += 1
-                tdst = re.match(r"v(\d+)", ins[k - 1][1].split()[1])
-                srcs = [int(v) for v in re.findall(r"\bv(\d+)\b", line.split(None, 2)[2])] if len(line.split(None, 2)) > 2 else []
-                if tdst and int(tdst.group(1)) in srcs:
-                    bad.append((kern, 0, ins[k - 1][1], line))
-            reg = int(re.match(r"v(\d+)", line.split()[1]).group(1))
+            ops = _operands(line)
+            dst = _regs(ops[0]) if ops else set()
+            if not dst:
+                continue
+            is_trans = bool(TRANS.match(line))
             wait = 0
-            for kern2, nxt in ins[k + 1:k + 10]:
-                if nxt.startswith("v_mfma"):
-                    spans = re.findall(r"v\[(\d+):(\d+)\]", nxt)
-                    if any(int(a) <= reg <= int(b) for a, b in spans[1:3]):   # (A and B operands; span 0 is the result)
-                        checked += 1
-                        if wait < 2:
-                            bad.append((kern, wait, line, nxt))
+            for kern2, nxt in ins[k + 1:k + 4]:
+                if kern2 != kern or nxt.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
                     break
-                wait += int(nxt.split()[1]) + 1 if nxt.startswith("s_nop") else 1
+                if nxt.startswith("s_nop"):
+                    wait += _states(nxt)
+                    continue
+                nops = _operands(nxt)
+                srcs = set().union(*[_regs(t) for t in nops[1:]]) if len(nops) > 1 else set()
+                need, what = 0, None
+                if nxt.startswith("v_mfma"):
+                    ab = set().union(*[_regs(t) for t in nops[1:3]])
+                    if dst & ab:
+                        need, what = 2, "VALU -> MFMA A/B"
+                elif nxt.startswith(("v_readlane", "v_readfirstlane")):
+                    if dst & srcs:
+                        need, what = 1, "VALU -> readlane"
+                elif nxt.startswith("v_permlane") and "swap" in nxt:
+                    if dst & set().union(*[_regs(t) for t in nops]):
+                        need, what = 2, "VALU -> permlane swap"
+                elif DPP.search(nxt) and nxt.startswith("v_"):
+                    if dst & srcs:
+                        need, what = 2, "VALU -> DPP"
+                elif is_trans and VALU.match(nxt) and not TRANS.match(nxt):
+                    if dst & srcs:
+                        need, what = 1, "trans -> VALU"
+                if what:
+                    checked += 1
+                    if wait < need:
+                        bad.append((kern, wait, what + ": " + line, nxt))
+                # a consumer that overwrites the register ends the producer's reach
+                if nops and (_regs(nops[0]) & dst) and not nxt.startswith(("v_mfma",)):
+                    break
+                wait += 1
     return checked, bad
 
 
@@ -89,5 +154,6 @@ if __name__ == "__main__":
     n, bad = check(path)
     for kern, wait, a, b in bad:
         print(f"{kern}: {wait} wait state(s) between\n    {a}\n    {b}")
-    print(f"{n} inline-assembly VALU -> MFMA pairs checked, {len(bad)} with fewer than two wait states")
+    print(f"{n} producer -> consumer pairs checked (VALU -> MFMA / DPP / readlane / permlane-swap, trans -> VALU), "
+          f"{len(bad)} with too few wait states")
     sys.exit(1 if bad else 0)

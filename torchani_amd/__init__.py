@@ -18,7 +18,7 @@ def __getattr__(name):
     if name in ("models", "grad", "parallel", "engine", "aev", "nn", "tuples", "_lib", "utils", "potentials", "ase", "md",
                 "ops", "extras"):
         return importlib.import_module(f".{name}", __name__)
-    if name in ("arch", "io", "electro", "transforms", "sae_estimation"):   # host-side conveniences outside the hot path
+    if name in ("arch", "io", "electro"):   # host-side conveniences outside the hot path
         return importlib.import_module(f".extras.{name}", __name__)
     table = {
         "AEVComputer": ("aev", "AEVComputer"),

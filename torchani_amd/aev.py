@@ -195,7 +195,13 @@ class _AEVFromRowsFunction(torch.autograd.Function):
 
 
 class AEVComputer(torch.nn.Module):
-    """Atomic environment vectors [C, A, S*16 + S(S+1)/2*32] on the MI355X engine."""
+    """Atomic environment vectors [C, A, S*16 + S(S+1)/2*32] on the MI355X engine.
+
+    Arithmetic: the kernels compute in fp32 (binning and energy sums in fp64).  float64 coordinates are ACCEPTED like the
+    reference's (its pyaev and cuAEV run in the input dtype, csrc/aev.cu:1742-1746) but are converted to fp32 on the way in,
+    and the AEVs / gradients are cast back to float64 on the way out: fp64 in the interface, fp32-class accuracy in the
+    numbers (AEV within ~3e-6 of the fp64 reference).  There is no fp64 kernel variant; the fp64 statement of the path is
+    the test oracle (oracle/ani_oracle.c)."""
 
     def __init__(self, consts: AEVConstants, neighborlist: str = "auto", row_capacity: int = 128,
                  strategy: str = "hip", cutoff_fn: tp.Optional[str] = None, skin: float = 1.0) -> None:

@@ -1,3 +1,4 @@
 """Host-side conveniences under the reference's names that are NOT part of the hot path (SURVEY 2.1 rows 16-22:
-xyz io, dataset transforms, self-energy estimation, charge normalizers / dipoles, the Assembler).  No kernels, no engine
+xyz io, charge normalizers / dipoles, the Assembler; the dataset transforms and the self-energy estimation of earlier rounds
+were removed in round 4 -- out of scope, and the transforms were too close to a restatement of the reference's file).  No kernels, no engine
 logic; kept for callers that want the reference's spelling.  Their tests live in tests/extras/."""

@@ -1,8 +1,11 @@
 """Autograd helpers with the reference's names and behaviour (torchani/grad.py:42-86,263-399).
 
 Hessians (grad.py:86-150,239-260) need second derivatives with respect to the coordinates, which the HIP engine does
-not provide (its second-order pass serves training on forces: parameters only): those entry points raise;
-``numerical_hessians`` differentiates the analytic forces numerically instead, ``vibrational_analysis`` is the reference's.
+not provide (its second-order pass serves training on forces: parameters only): ``hessians`` / ``forces_and_hessians``
+raise and say so.  NOT here (removed in round 3 as outside the hot path, SURVEY section 2 "OUT OF SCOPE"): the reference's
+``vibrational_analysis`` / ``VibAnalysis`` (grad.py:153-236), a numerical Hessian, and the modules ``torchani.units``,
+``torchani.cutoffs`` (the cutoff envelopes live in the AEV kernels: ``AEVComputer(..., cutoff_fn="cosine" | "smooth")``,
+``constants.cutoff_kernel_name``) and ``torchani.sae`` (``nn.SelfEnergy`` is the energy shifter of the models).
 """
 from __future__ import annotations
 

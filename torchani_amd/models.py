@@ -310,6 +310,11 @@ class ANI(torch.nn.Module):
         if (not self.compact_species or n < 16384
                 or any(k != "nnp" and p._enabled for k, p in self.potentials.items())):
             return species32, None
+        aevc = self.aev_computer
+        if (len(aevc.radial.shifts), len(aevc.angular.shifts) * len(aevc.angular.sections)) != (16, 32):
+            # (a general symmetry-function grid has no 16 / 32-column blocks to line up with the 32-column slabs, and the
+            # packer's column permutation is written for them: nn.ANINetworks._pack(species_order=...) would refuse)
+            return species32, None
         if torch.cuda.is_current_stream_capturing():
             # (a capture must own the tensors it records -- GraphedEnergiesForces asks before it captures and passes its
             # own copy down; anything else that captures gets the numbering as given)
