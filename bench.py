@@ -308,9 +308,13 @@ def main():
     reps = 3
     nbrs = eng.neighbors(sp32, coords_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
     st["neighbors"] = time_stage(lambda: eng.neighbors(sp32, coords_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128), reps)
-    mask = torch.zeros(n_local, dtype=torch.int32, device=dev)   # per-atom slab flags, as in the product path
-    aev = eng.forward(sp32, nbrs, slab_mask=mask, shard_rows=True)   # [hi - lo, L], as in the product path
-    st["aev_forward"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev, slab_mask=mask, shard_rows=True), reps)
+    # rows [hi - lo, L] and per-atom slab flags in the engine's kept buffers, updated in place: the product path
+    aev, mask = eng.forward_update(sp32, nbrs)
+    st["aev_forward"] = time_stage(lambda: eng.forward_update(sp32, nbrs), reps)
+    if not args.no_dense_stage:   # (for comparison: every row written in full into a buffer of the caller, as AEVComputer.forward does)
+        full = torch.empty_like(aev)
+        st["aev_forward_full_rows"] = time_stage(lambda: eng.forward(sp32, nbrs, out=full, shard_rows=True), reps)
+        del full
     ae = torch.zeros(n_local, dtype=torch.float32, device=dev)
     gaev = torch.zeros_like(aev)
     st["mlp_fwd_bwd"] = time_stage(

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_struct_layouts_match_header(lib):

@@ -506,6 +506,51 @@ def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     assert np.all(e.detach().cpu().numpy()[pad] == 0) and np.all(gr.cpu().numpy()[pad] == 0)
 
 
+def test_aev_rows_updated_in_place(dev):
+    """AevEngine.forward_update (anihip_aev_forward_update): the rows kept by the engine and updated in place are, after
+    every call, bit for bit the rows anihip_aev_forward writes into a fresh buffer -- whatever happened to the system in
+    between: other elements (other slabs flagged: the old ones must be zeroed, the new ones written), atoms turned into
+    padding, atoms that lost all their neighbors, the first use."""
+    from bench import water_box
+
+    sp_np, x_np, cell_np = water_box(10)   # 3000 atoms
+    x, cell = torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    model = get_model("ani2x", 3, dev, neighborlist="cell")
+    eng = model.aev_computer.engine()
+    rs = np.random.RandomState(1)
+    n = sp_np.size
+    base = torch.from_numpy(sp_np).to(dev).to(torch.int32)
+    far = x.clone()
+    far[0, ::7] += torch.tensor([0.0, 0.0, 1000.0], device=dev)   # (open boundaries below: these atoms are alone)
+    steps = [
+        (base, x, (True, True, True)),
+        (torch.where(base == 0, 1, 2).to(torch.int32), x, (True, True, True)),
+        (torch.from_numpy(rs.choice([0, 1, 2, 3, 4, 5, 6], size=(1, n))).to(dev).to(torch.int32), x, (True, True, True)),
+        (torch.where(torch.from_numpy(rs.rand(1, n) < 0.3).to(dev), -1, base).to(torch.int32), x, (True, True, True)),
+        (base, far, (False, False, False)),
+        (base, x, (True, True, True)),
+    ]
+    for k, (sp, xx, pbc) in enumerate(steps):
+        nbrs = eng.neighbors(sp, xx, cell, pbc, mode="cell", row_cap=160)
+        kept, kept_mask = eng.forward_update(sp, nbrs, shard_rows=False)
+        mask = torch.zeros(n, dtype=torch.int32, device=dev)
+        fresh = eng.forward(sp, nbrs, slab_mask=mask)
+        assert torch.equal(kept, fresh), (k, float((kept - fresh).abs().max()))
+        assert torch.equal(kept_mask, mask), k
+        if k == 0:
+            first = kept.data_ptr()
+        assert kept.data_ptr() == first   # (the same buffers every time)
+    # and through the model: energies_and_forces with kept rows == with fresh rows, bit for bit, call after call
+    sp64 = base.to(torch.int64)
+    model.keep_aev_rows = False
+    ref = [model.energies_and_forces(sp64, xx, cell, (True, True, True)) for xx in (x, x + 0.05, x)]
+    model.keep_aev_rows = True
+    got = [model.energies_and_forces(sp64, xx, cell, (True, True, True)) for xx in (x, x + 0.05, x)]
+    for a, b in zip(ref, got):
+        assert torch.equal(a.atomic_energies, b.atomic_energies) and torch.equal(a.energies, b.energies)
+        assert float((a.forces - b.forces).abs().max()) < 2e-6   # (float atomics in the AEV backward)
+
+
 def test_general_grid_on_a_large_system(dev):
     """A from_constants grid (8 radial / 4 x 4 angular terms) on a 17 496-atom H / O box: large enough for the species
     relabelling of models.ANI._engine_species (water under H C N O would be relabelled (0, 3, 1, 2)), which only applies to
@@ -533,7 +578,7 @@ def test_general_grid_on_a_large_system(dev):
     assert model._engine_species(sp.to(torch.int32))[1] is None
     out = model.energies_and_forces(sp, x, cell, pbc, check_overflow=True)
     e, f = energies_and_forces(model, sp, x, cell, torch.tensor(pbc))
-    assert abs(float(out.energies - e)) < 1e-7 * sp.numel()
+    assert abs(float(out.energies - e)) < 0.05   # (the autograd path returns the total in fp32: one ulp of 4.4e5 Ha is 0.03)
     assert float((out.forces - f).abs().max()) < 5e-6 * max(1.0, float(f.abs().max()))
 
 

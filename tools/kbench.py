@@ -76,6 +76,9 @@ def main():
         out["nbr"] = time_stage(lambda: eng.neighbors(sp32, coords, cell, pbc, mode="cell"), args.reps)
     if "fwd" in st:
         out["fwd"] = time_stage(lambda: eng.forward(sp32, nbrs, out=aev, slab_mask=mask), args.reps)
+    if "fwdu" in st:   # rows updated in place in the engine's kept buffers (the product path of energies_and_forces)
+        eng.forward_update(sp32, nbrs, shard_rows=False)
+        out["fwd_update"] = time_stage(lambda: eng.forward_update(sp32, nbrs, shard_rows=False), args.reps)
     if "bwd" in st:
         out["bwd"] = time_stage(lambda: eng.backward(sp32, nbrs, gaev, gc, slab_mask=mask), args.reps)   # (as in the product path)
     if "mlp" in st:
@@ -89,6 +92,8 @@ def main():
     line = f"atoms={n} n_r={n_r:.1f} n_a={n_a:.1f} | " + " ".join(f"{k}={v:.3f}ms" for k, v in out.items())
     if "fwd" in out:
         line += f" | fwd {bpa * n / out['fwd'] / 1e6:.0f} GB/s ({bpa * n / out['fwd'] / 1e6 / 8000:.1%} of 8 TB/s)"
+    if "fwd_update" in out:
+        line += f" | fwd_update {bpa * n / out['fwd_update'] / 1e6:.0f} GB/s ({bpa * n / out['fwd_update'] / 1e6 / 8000:.1%} of 8 TB/s on the same algorithmic bytes)"
     if "mlp" in out:
         line += f" | mlp {mlp_flops_per_atom(sp_np.reshape(-1)) * n / out['mlp'] / 1e9:.1f} TFLOP/s"
     print(line)

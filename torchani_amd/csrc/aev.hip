@@ -47,6 +47,8 @@ struct AevArgs {
     float Rcr, Rca, kR, kA, EtaR, EtaA, Zeta;
     float qR, qA;   // sqrt(eta log2 e): exp(-eta x^2) = exp2(-(q x)^2)
     int smooth;  // cutoff_kind: 0 = CutoffCosine, 1 = CutoffSmooth (order 2, eps 1e-10)
+    int update;  // k_aev_fwd3: rows are UPDATED in place -- slab_mask[i] on entry = the slabs of row i that may hold non-zero
+                 // data from the previous call on these buffers; only those and the slabs flagged now are written
 };
 
 // CutoffSmooth (cutoffs.py:84-101, csrc/aev.cu:150-178): fc = exp(1 - 1/max(eps, 1 - (r/Rc)^2)); 1 - q^2 is formed
@@ -676,6 +678,10 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         e1 = ent[hd.start + min(lane + WAVE, nl)];
     }
     uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
+    // rows updated in place (a.update): what the previous call left in this row, one atom ahead like the header (wave-uniform
+    // address: a scalar load); otherwise every slab counts as dirty and the whole row is written
+    uint32_t pm = (a.update && i < hi) ? slab_mask[i] : 0xFFFFFFFFu;
+    uint32_t pm_next = (a.update && i + nw < hi) ? slab_mask[i + nw] : 0xFFFFFFFFu;
     // Memory order of an atom: [loads for the NEXT atom] ... arithmetic ... [wait for those loads] [ALL stores of this atom].
     // Vector-memory operations retire in order and the compiler waits with vmcnt(0) for whatever it cannot count, so a
     // load consumed after stores were issued drains those stores first (HBM write latency, once per atom and wave).  With
@@ -772,6 +778,9 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
             }
             hw_next = hdr_load(meta, species, in + nw, in + nw < hi);
         }
+        const uint32_t prev_m = pm;
+        pm = pm_next;
+        pm_next = (a.update && i + 2 * nw < hi) ? slab_mask[i + 2 * nw] : 0xFFFFFFFFu;
         // results that wait for the end of the atom: radial part in LDS (rst), the angular blocks of the last batch in the
         // neighbor table's LDS (dead by then: ang[lane] / ang[64 + lane] of the lanes flagged hold_last, destination hold_dst)
         bool hold_last = false;
@@ -960,18 +969,33 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         // ---- the next atom's data has had this atom's arithmetic to arrive; then all stores of the row ----
         ANIHIP_FWD3_ARRIVED();
         TR_STAMP(7)   // wait for the prefetch
+        // 32-wide slabs of this row that are not identically zero (include/anihip.h)
+        uint32_t now_m;
         {
+            const uint32_t r7 = (uint32_t)need & 0x7Fu;
+            const uint32_t pr = (r7 | (r7 >> 1)) & 0x55u;   // bit 2 s: species 2 s or 2 s + 1 present
+            const uint32_t rs = (pr & 1u) | ((pr >> 1) & 2u) | ((pr >> 2) & 4u) | ((pr >> 3) & 8u);
+            now_m = rs | ((uint32_t)(need >> 7) << rslabs);
+        }
+        {
+            // Zero fill: a slab that is not flagged now needs zeros only if it may still hold data (prev_m: every slab when
+            // the row is written for the first time, else the flags the previous call left) -- 27 of a water atom's 32 slabs
+            // are never flagged, 3.4 KB of its 4 KB row that an update in place does not write again.  Inside a flagged
+            // radial slab the 16 columns of an absent species are zeroed as before.
             float4 *out4 = reinterpret_cast<float4 *>(out);
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t touch = prev_m | now_m;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {   // float4 slot f of the row belongs to block bit sb
+            for (int m = 0; m < 4; ++m) {   // float4 slot f of the row belongs to block bit sb, slab sl
                 const int f = lane + WAVE * m;
                 const int sb = f < R4 ? (f >> 2) : 7 + ((f - R4) >> 3);
+                const int sl = f < R4 ? (f >> 3) : rslabs + ((f - R4) >> 3);
                 const bool nd = (need >> sb) & 1ull;
                 if (m == 0 && f < R4) {   // radial part: 16-B stores from the staged row
                     const float4 rv = *reinterpret_cast<const float4 *>(rst + 4 * (lane & 31));
-                    out4[f] = make_float4(nd ? rv.x : 0.f, nd ? rv.y : 0.f, nd ? rv.z : 0.f, nd ? rv.w : 0.f);
-                } else if (f < L4 && !nd) {
+                    if ((touch >> sl) & 1u)
+                        out4[f] = make_float4(nd ? rv.x : 0.f, nd ? rv.y : 0.f, nd ? rv.z : 0.f, nd ? rv.w : 0.f);
+                } else if (f < L4 && !nd && ((prev_m >> sl) & 1u)) {
                     out4[f] = z4;
                 }
             }
@@ -980,12 +1004,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
             *reinterpret_cast<float4 *>(hold_dst) = ang[lane];
             *reinterpret_cast<float4 *>(hold_dst + 16) = ang[64 + lane];
         }
-        if (slab_mask && lane == 0) {   // 32-wide slabs of this row that are not identically zero (include/anihip.h)
-            const uint32_t r7 = (uint32_t)need & 0x7Fu;
-            const uint32_t pr = (r7 | (r7 >> 1)) & 0x55u;   // bit 2 s: species 2 s or 2 s + 1 present
-            const uint32_t rs = (pr & 1u) | ((pr >> 1) & 2u) | ((pr >> 2) & 4u) | ((pr >> 3) & 8u);
-            slab_mask[i] = rs | ((uint32_t)(need >> 7) << rslabs);
-        }
+        if (slab_mask && lane == 0) slab_mask[i] = now_m;
         wave_sync();
         TR_STAMP(8)   // stores issued
     }
@@ -1484,10 +1503,10 @@ static int persistent_blocks(int64_t n_central, int wpb, int blocks_per_cu)
     return (int)b;
 }
 
-extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table,
-                                  int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
-                                  const uint32_t *meta, const float *ent, float *aev, uint32_t *slab_mask,
-                                  uint32_t *status)
+static int aev_forward(void *stream, const anihip_aev_params *p, const float *table,
+                       int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                       const uint32_t *meta, const float *ent, float *aev, uint32_t *slab_mask,
+                       uint32_t *status, bool update)
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && aev, "null pointer argument");
     ANIHIP_REQUIRE(!slab_mask || (p->num_species + 1) / 2 + p->num_species * (p->num_species + 1) / 2 <= 32,
@@ -1499,6 +1518,7 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     }
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
+    a.update = update ? 1 : 0;
     if (hi == lo) return 0;
     dim3 grid(persistent_blocks(hi - lo, FWD_WPB, ANIHIP_FWD3_WAVES)), block(FWD_WPB * WAVE);
     const bool rec = (p->flags & ANIHIP_AEV_UNIFORM_SHFA) != 0 && ANIHIP_FWD3_REC;
@@ -1514,6 +1534,24 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
     ANIHIP_CHECK_HIP(hipGetLastError());
     (void)status;
     return 0;
+}
+
+extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table,
+                                  int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                                  const uint32_t *meta, const float *ent, float *aev, uint32_t *slab_mask,
+                                  uint32_t *status)
+{
+    return aev_forward(stream, p, table, n_atoms, lo, hi, species, meta, ent, aev, slab_mask, status, false);
+}
+
+extern "C" int anihip_aev_forward_update(void *stream, const anihip_aev_params *p, const float *table,
+                                         int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
+                                         const uint32_t *meta, const float *ent, float *aev, uint32_t *slab_mask,
+                                         uint32_t *status)
+{
+    ANIHIP_REQUIRE(slab_mask, "anihip_aev_forward_update needs the slab flags of the previous call (slab_mask)");
+    ANIHIP_REQUIRE(p && tuned_grid(p), "rows are updated in place on the 16 / 8x4 / 4x8 grids only");
+    return aev_forward(stream, p, table, n_atoms, lo, hi, species, meta, ent, aev, slab_mask, status, true);
 }
 
 extern "C" int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,

@@ -277,6 +277,29 @@ class AevEngine:
             _ptr(nbrs.status)))
         return out
 
+    def forward_update(self, species: Tensor, nbrs: NeighborRows, shard_rows: bool = True) -> tp.Tuple[Tensor, Tensor]:
+        """(AEV rows, slab flags) for the central atoms of nbrs in buffers the engine KEEPS between calls and updates in
+        place (anihip_aev_forward_update): a row is zero outside its flagged slabs, and those zeros are written once -- a
+        later call only touches the slabs that were or are flagged (0.6 KB instead of 4 KB per water atom and step).  The
+        pair is valid until the next call of this method; one pair is kept (same number of atoms and central range, else a
+        fresh one).  For the hot loop of energies_and_forces; ``forward`` hands out buffers of the caller's own."""
+        _require_cuda(species)
+        n = species.numel()
+        rows = (nbrs.hi - nbrs.lo) if shard_rows else n
+        key = (n, nbrs.lo, nbrs.hi, rows, species.device)
+        hit = self.__dict__.get("_rows_kept")
+        if hit is None or hit[0] != key:
+            self.__dict__["_rows_kept"] = None   # (release the old pair before the new one is allocated)
+            hit = (key, torch.zeros((rows, self.L), dtype=torch.float32, device=species.device),
+                   torch.zeros(n, dtype=torch.int32, device=species.device))
+            self.__dict__["_rows_kept"] = hit
+        _, out, mask = hit
+        _lib.check(_lib.lib().anihip_aev_forward_update(
+            _stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
+            _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent), _row_ptr(out, nbrs.lo if shard_rows else 0, self.L),
+            _ptr(mask), _ptr(nbrs.status)))
+        return out, mask
+
     def jvp(self, species: Tensor, nbrs: NeighborRows, tangent: Tensor) -> Tensor:
         """J t [N, L]: derivative of the AEV rows of nbrs' central atoms along the coordinate direction tangent [N, 3]
         (anihip_aev_jvp; the reference's cuaev double backward)."""

@@ -290,6 +290,11 @@ class ANI(torch.nn.Module):
             self.__dict__["_n_elem_cache"] = hit
         return _lib.MLP_FLAG_SMALL_TILES if hit[1] >= 4 else 0
 
+    # The AEV rows of energies_and_forces are internal: they live in buffers the engine keeps between steps and updates in
+    # place (AevEngine.forward_update: zeros are written once, a step rewrites only the slabs that were or are flagged --
+    # 0.6 KB instead of 4 KB per water atom).  False: a fresh, fully written buffer per call.
+    keep_aev_rows = True
+
     # ---- species numbered "present ones first" inside the engine ------------------------------------------------------
     compact_species = True   # large systems: relabel the species so that the AEV blocks of absent species come last
 
@@ -366,11 +371,17 @@ class ANI(torch.nn.Module):
         # per-atom flags of the AEV slabs that are not identically zero (absent neighbor species): the
         # layer-0 GEMMs skip the others
         slab_mask = None
-        if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
-            # (the AEV kernel writes the flags of every central atom; the others are read by nobody, zero for tidiness)
-            slab_mask = (torch.empty if (lo == 0 and hi == n) else torch.zeros)(n, dtype=torch.int32, device=c32.device)
         # AEV rows and their gradients exist for this rank's central atoms only ([hi - lo, L] buffers)
-        aev = eng.forward(species32, nbrs, slab_mask=slab_mask, shard_rows=True)
+        if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
+            if self.keep_aev_rows and not torch.cuda.is_current_stream_capturing():
+                # rows and flags in the engine's kept buffers, updated in place (AevEngine.forward_update)
+                aev, slab_mask = eng.forward_update(species32, nbrs)
+            else:
+                # (the AEV kernel writes the flags of every central atom; the others are read by nobody, zero for tidiness)
+                slab_mask = (torch.empty if (lo == 0 and hi == n) else torch.zeros)(n, dtype=torch.int32, device=c32.device)
+                aev = eng.forward(species32, nbrs, slab_mask=slab_mask, shard_rows=True)
+        else:
+            aev = eng.forward(species32, nbrs, slab_mask=slab_mask, shard_rows=True)
         atomic_e, grad_aev, _ = packed.forward_backward(species32, aev, lo=lo, hi=hi, want_grad=True,
                                                         chunk=self.mlp_chunk, slab_mask=slab_mask,
                                                         shard_rows=True, tile_hint=tile_hint)
@@ -543,8 +554,13 @@ class ANI(torch.nn.Module):
         packed = self.neural_networks._pack(dev, order)
         slab_mask = None
         if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
-            slab_mask = torch.zeros(nl, dtype=torch.int32, device=dev)
-        aev = eng.forward(sp_l, nbrs, slab_mask=slab_mask, shard_rows=True)
+            if self.keep_aev_rows and not torch.cuda.is_current_stream_capturing():
+                aev, slab_mask = eng.forward_update(sp_l, nbrs)   # (kept buffers, updated in place)
+            else:
+                slab_mask = torch.zeros(nl, dtype=torch.int32, device=dev)
+                aev = eng.forward(sp_l, nbrs, slab_mask=slab_mask, shard_rows=True)
+        else:
+            aev = eng.forward(sp_l, nbrs, slab_mask=slab_mask, shard_rows=True)
         atomic_e, grad_aev, _ = packed.forward_backward(sp_l, aev, lo=lo, hi=hi, want_grad=True, chunk=self.mlp_chunk,
                                                         slab_mask=slab_mask, shard_rows=True, tile_hint=tile_hint)
         virial = torch.empty((3, 3), dtype=torch.float64, device=dev) if stress else None
