@@ -189,7 +189,12 @@ int anihip_nbr_refresh(void *stream, const anihip_aev_params *p, int64_t n_atoms
  * ceil(S/2) + P: angular block of species pair P.  An AEV block is identically zero when atom i has no
  * neighbor (pair) of that species inside the cutoff; anihip_mlp_forward_backward skips those slabs.
  * anihip_aev_backward(slab_mask != NULL) reads grad_aev only inside flagged slabs (of the rows lo..hi); with
- * slab_mask == NULL every entry of the rows lo..hi must be valid. */
+ * slab_mask == NULL every entry of the rows lo..hi must be valid.
+ * Any OTHER grid (n_shf_r <= 32, n_shf_a, n_shf_z <= 16: the general kernels; rows of at most 1024 columns): the flags
+ * are those of the PLAIN 32-column slabs of the row -- bit j <=> columns 32 j .. 32 j + 31 can be non-zero (a block of a
+ * present species or species pair flags every slab it overlaps) -- which is the order anihip_mlp_pack gives the layer-0
+ * planes of such networks (aev_radial_len = 0).  The general backward reads only blocks of present species and takes
+ * no flags.  anihip_aev_jvp serves every grid as well (ABI 9). */
 #define ANIHIP_BWD_SYMMETRIC 1   /* rows are symmetric: gather the radial partner blocks instead of pushing */
 #define ANIHIP_BWD_FIXED_POINT 2 /* grad_coords is an int64 fixed-point accumulator (2^-32): reproducible sums */
 int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,

@@ -41,17 +41,24 @@ def reference_aev(grid, species, coords32, cell, pbc, seed):
     aev = aevc(torch.as_tensor(species, dtype=torch.long), x, cell_t, pbc_t)
     w = np.random.RandomState(seed).uniform(-1.0, 1.0, tuple(aev.shape)).astype(np.float32).astype(np.float64)   # (fp32-representable)
     (vjp,) = torch.autograd.grad((aev * torch.as_tensor(w)).sum(), x)
-    return aev.detach().numpy(), w, vjp.numpy()
+    # forward-mode derivative J t along the direction of gen_golden_fgrads.direction (what the reference's cuaev double
+    # backward returns, csrc/aev.cu:1986-2015): pins the JVP of the general kernels
+    from gen_golden_fgrads import direction
+    C, A = np.asarray(species).shape
+    t = torch.as_tensor(direction(C, A)) * (torch.as_tensor(species, dtype=torch.long) >= 0).unsqueeze(-1)
+    _, jt = torch.autograd.functional.jvp(lambda y: aevc(torch.as_tensor(species, dtype=torch.long), y, cell_t, pbc_t),
+                                          x.detach(), t)
+    return aev.detach().numpy(), w, vjp.numpy(), jt.detach().numpy()
 
 
 def save(name, grid, species, coords32, cell, pbc, seed):
-    aev, w, vjp = reference_aev(grid, species, coords32, cell, pbc, seed)
+    aev, w, vjp, jt = reference_aev(grid, species, coords32, cell, pbc, seed)
     S, Rcr, Rca, EtaR, ShfR, EtaA, Zeta, ShfA, ShfZ, cut = GRIDS[grid]
     out = dict(num_species=np.asarray(S), Rcr=np.float32(Rcr), Rca=np.float32(Rca), EtaR=np.float32(EtaR),
                ShfR=np.asarray(ShfR, dtype=np.float32), EtaA=np.float32(EtaA), Zeta=np.float32(Zeta),
                ShfA=np.asarray(ShfA, dtype=np.float32), ShfZ=np.asarray(ShfZ, dtype=np.float32), cutoff_fn=np.asarray(cut),
                species=np.asarray(species, dtype=np.int32), coords=coords32, aev=aev, cotangent=w.astype(np.float32),
-               aev_vjp=vjp)
+               aev_vjp=vjp, aev_jvp=jt)
     if cell is not None:
         out["cell"] = np.asarray(cell, dtype=np.float32)
         out["pbc"] = np.asarray(pbc, dtype=bool)

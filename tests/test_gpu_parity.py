@@ -221,6 +221,29 @@ def test_general_symmetry_function_grids(dev, name):
         assert float((a_part - aev.detach().reshape(n, -1)[lo:hi]).abs().max()) < 1e-6
         eng.backward(sp32, part, wf[lo:hi].contiguous(), grad_coords=tot, shard_rows=True)
     assert float((tot - gc).abs().max()) < 1e-5 * max(1.0, vmag)
+    # forward-mode derivative J t (anihip_aev_jvp on a general grid: the JVP instantiation of k_aev_fwd_gen) against the
+    # reference's own (fixture), the adjoint identity <w, J t> = <J^T w, t> with the backward kernel, zero rows for padding
+    from _util import fgrad_direction
+    td = torch.from_numpy(fgrad_direction(g["species"]).astype(np.float32)).to(dev)
+    jt = eng.jvp(sp32, nbrs, td)
+    jscale = np.abs(g["aev_jvp"]).max()
+    jerr = np.abs(jt.cpu().numpy().astype(np.float64).reshape(g["aev_jvp"].shape) - g["aev_jvp"]).max()
+    report(f"grid  {name:22s} max|J t err| = {jerr:.2e} (max |J t| {jscale:.2f})")
+    assert jerr < 2e-5 * max(1.0, jscale)
+    lhs = (wf.double() * jt.double()).sum().item()
+    rhs = (gc.double() * td.view(-1, 3).double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    assert torch.all(jt.view(sp.shape[0], sp.shape[1], -1)[sp < 0] == 0)
+    # slab flags of the plain 32-column slabs: exactly the slabs that hold a non-zero entry or belong to a present block
+    mask = torch.zeros(n, dtype=torch.int32, device=dev)
+    a_m = eng.forward(sp32, nbrs, slab_mask=mask)
+    assert torch.equal(a_m, aev.detach().reshape(n, -1).float()) or float((a_m - aev.detach().reshape(n, -1)).abs().max()) < 1e-6
+    L = a_m.shape[1]
+    pad_cols = (-L) % 32
+    nz = torch.nn.functional.pad(a_m != 0, (0, pad_cols)).view(n, -1, 32).any(dim=2)   # [n, slabs]
+    bits = ((mask.to(torch.int64).view(n, 1) & 0xFFFFFFFF) >> torch.arange(nz.shape[1], device=dev).view(1, -1)) & 1
+    assert bool((bits.bool() | ~nz).all()), "a slab with a non-zero entry is not flagged"
+    assert bool((bits.sum(dim=1)[sp32.view(-1) < 0] == 0).all())
 
 
 def test_general_grids_random_sweep(dev):
@@ -504,6 +527,108 @@ def test_mlp_ensemble(dev, oracle64, name, precision, monkeypatch):
     assert g_err < 1e-6 + 1e-5 * np.abs(ga).max()
     pad = g["species"] < 0
     assert np.all(e.detach().cpu().numpy()[pad] == 0) and np.all(gr.cpu().numpy()[pad] == 0)
+
+
+def test_force_training_on_a_general_grid(dev, oracle64):
+    """The reference's force-training recipe (forces = -autograd.grad(E, coords, create_graph=True); loss(forces).backward(),
+    tools/training-aev-benchmark.py:136-150) on a from_constants grid: until round 4 the general kernels had no
+    forward-mode derivative and this raised.  Parameter gradients against the oracle's second-order chain (pinned to the
+    reference on the same grids: test_oracle_golden.test_oracle_on_general_grids)."""
+    from _util import fgrad_direction
+    from oracle import oracle as orc
+
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.models import ANI
+    from torchani_amd.nn import ANINetworks, Ensemble
+
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "grid_r8_a4z4_batch.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    symbols = ("H", "C", "N", "O")
+    aevc = AEVComputer.from_constants(float(g["Rcr"]), float(g["Rca"]), float(g["EtaR"]), g["ShfR"].tolist(), float(g["EtaA"]),
+                                      float(g["Zeta"]), g["ShfA"].tolist(), g["ShfZ"].tolist(), 4, row_capacity=256)
+    hidden = {"H": (64, 48, 32), "C": (64, 32, 32), "N": (32, 32, 32), "O": (48, 32, 32)}
+    torch.manual_seed(11)
+    M = 2
+    nets = Ensemble([ANINetworks.build(symbols, aevc.out_dim, hidden) for _ in range(M)])
+    model = ANI(symbols, aevc, nets, [0.0, 0.0, 0.0, 0.0], periodic_table_index=False).to(dev)
+    nets.requires_grad_(True)
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev).requires_grad_(True)
+    t_np = fgrad_direction(g["species"])
+    t = torch.from_numpy(t_np.astype(np.float32)).to(dev)
+    aev = model.aev_computer(sp, x)
+    e = nets(sp, aev).sum()
+    (gx,) = torch.autograd.grad(e, x, create_graph=True)
+    loss = -(gx * t).sum()                      # = sum_k t_k . F_k
+    loss.backward()
+    torch.cuda.synchronize()
+    # the oracle: S = sum_i v_i . d e_i / d aev_i with v = -J t, differentiated with respect to every parameter
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    dims, flat = orc.pack_networks(sd, symbols, M)
+    p = orc.make_params(4, float(g["Rcr"]), float(g["Rca"]), float(g["EtaR"]), float(g["EtaA"]), float(g["Zeta"]),
+                        g["ShfR"].tolist(), g["ShfA"].tolist(), g["ShfZ"].tolist(), "cosine")
+    aev_ref, jt_ref = oracle64.aev_jvp(p, g["species"], g["coords"].astype(np.float64), t_np)
+    val_ref, ref = oracle64.mlp_tangent_weight_grads(g["species"], aev_ref, -jt_ref, dims, flat, n_members=M)
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach().cpu().numpy()
+             for k, v in model.named_parameters()}
+    _, got = orc.pack_networks({k: grads.get(k, v) for k, v in sd.items()}, symbols, M)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    report(f"ftrain general grid 8 / 4x4: |loss err| = {abs(float(loss.detach()) - val_ref):.2e}  max|d(t.F)/dw err| = {err:.2e} (max {scale:.2e})")
+    assert abs(float(loss.detach()) - val_ref) < 1e-5 * max(1.0, abs(val_ref))
+    assert scale > 0 and err < 5e-5 * scale
+
+
+def test_general_grid_slab_flags_through_the_networks(dev, oracle64):
+    """A general grid whose networks run through the fused kernel (three hidden layers, widths >= 128 in the middle so that
+    the layer-0 backward can run inside it): the flags of the plain 32-column slabs from k_aev_fwd_gen make layer 0 skip the
+    slabs of absent species -- same energies as without flags, forces against the oracle, also with phase 5 forced."""
+    from bench import water_box
+    from oracle import oracle as orc
+
+    from torchani_amd.aev import AEVComputer
+    from torchani_amd.models import ANI
+    from torchani_amd.nn import ANINetworks, Ensemble
+
+    symbols = ("H", "C", "N", "O")
+    aevc = AEVComputer.from_constants(5.1, 3.5, 19.7, np.linspace(0.8, 4.8, 12).tolist(), 12.5, 14.1,
+                                      np.linspace(0.8, 3.1, 6).tolist(), ((np.arange(4) + 0.5) * np.pi / 4).tolist(), 4,
+                                      row_capacity=192, neighborlist="cell")   # 48 + 10 x 24 = 288 columns = 9 slabs
+    torch.manual_seed(13)
+    M = 2
+    nets = Ensemble([ANINetworks.build(symbols, aevc.out_dim, {s: (160, 128, 96) for s in symbols}) for _ in range(M)])
+    model = ANI(symbols, aevc, nets, [0.0, 0.0, 0.0, 0.0], periodic_table_index=False).to(dev)
+    sp_np, x_np, cell_np = water_box(10)   # 3000 atoms, species 0 and 3
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    pbc = (True, True, True)
+    eng, packed = model.aev_computer.engine(), model.neural_networks._pack(dev)
+    assert model._plain_slabs(eng, packed)
+    out = model.energies_and_forces(sp, x, cell, pbc, check_overflow=True)
+    old = PackedNetworks.default_flags
+    try:
+        PackedNetworks.default_flags = _lib.MLP_FLAG_NO_SLAB_MASK
+        dense = model.energies_and_forces(sp, x, cell, pbc)
+        PackedNetworks.default_flags = _lib.MLP_FLAG_FUSED_L0B
+        inside = model.energies_and_forces(sp, x, cell, pbc)
+    finally:
+        PackedNetworks.default_flags = old
+    assert float((out.atomic_energies - dense.atomic_energies).abs().max()) < 2e-7   # (other k steps share a tile scale)
+    assert float((out.forces - dense.forces).abs().max()) < 2e-6 and float((inside.forces - dense.forces).abs().max()) < 2e-6
+    # and the flags did skip slabs: water under H C N O has no C / N neighbors
+    nbrs = model.aev_computer.last_neighbors()
+    mask = torch.zeros(sp.numel(), dtype=torch.int32, device=dev)
+    eng.forward(sp.to(torch.int32), nbrs, slab_mask=mask)
+    assert 0 < bin(int(mask[0].item()) & 0xFFFFFFFF).count("1") < 9
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    dims, flat = orc.pack_networks(sd, symbols, M)
+    p = orc.make_params(4, 5.1, 3.5, 19.7, 12.5, 14.1, np.linspace(0.8, 4.8, 12).tolist(), np.linspace(0.8, 3.1, 6).tolist(),
+                        ((np.arange(4) + 0.5) * np.pi / 4).tolist(), "cosine")
+    ref = oracle64.energy_forces(p, sp_np, x_np.astype(np.float64), dims, flat, M, sae=np.zeros(4), cell=cell_np,
+                                 pbc=pbc, cell_list=True)
+    ea = np.abs(out.atomic_energies.cpu().numpy() - ref["atomic_energies"]).max()
+    fe = np.abs(out.forces.cpu().numpy() - ref["forces"]).max()
+    report(f"grid  12 / 6x4 water 3000 atoms, flagged slabs: max|e_atom err| = {ea:.2e}  |F err| = {fe:.2e}")
+    assert ea <= E_ATOM_REG and fe <= F_REG
 
 
 def test_aev_rows_updated_in_place(dev):

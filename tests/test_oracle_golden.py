@@ -162,3 +162,9 @@ def test_oracle_on_general_grids(oracle64, name):
     aev, vjp = oracle64.aev(p, g["species"], g["coords"], g.get("cell"), g.get("pbc"), grad_aev=g["cotangent"].astype(np.float64))
     assert np.abs(aev - g["aev"]).max() < 2e-12 * max(1.0, np.abs(g["aev"]).max())
     assert np.abs(vjp - g["aev_vjp"]).max() < 2e-11 * max(1.0, np.abs(g["aev_vjp"]).max())
+    # the forward-mode derivative J t (the reference's torch.autograd.functional.jvp of the same computer; the role of the
+    # cuaev double backward, csrc/aev.cu:1986-2015): pins the checker of the general kernels' JVP instantiation
+    from _util import fgrad_direction
+    t = fgrad_direction(g["species"])
+    _, jt = oracle64.aev_jvp(p, g["species"], g["coords"].astype(np.float64), t, g.get("cell"), g.get("pbc"))
+    assert np.abs(jt.reshape(g["aev_jvp"].shape) - g["aev_jvp"]).max() < 2e-11 * max(1.0, np.abs(g["aev_jvp"]).max())

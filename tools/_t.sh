@@ -1,1 +1,2 @@
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "general_grid_on_a_large" 2>&1 | tail -30
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "general or grid or rows_updated" 2>&1 | tail -30
+grep "^grid\|^ftrain general" gpurun_out/parity_report.txt | tail -12

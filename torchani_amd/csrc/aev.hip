@@ -1420,7 +1420,8 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
 
 // any other grid: aev_generic.hip
 int aev_forward_generic(hipStream_t stream, const anihip_aev_params *p, const float *table, int64_t lo, int64_t hi,
-                        const int32_t *species, const uint32_t *meta, const float *ent, float *aev);
+                        const int32_t *species, const uint32_t *meta, const float *ent, float *aev, const float *tangent,
+                        uint32_t *slab_mask);
 int aev_backward_generic(hipStream_t stream, const anihip_aev_params *p, const float *table, int64_t lo, int64_t hi,
                          const int32_t *species, const uint32_t *meta, const float *ent, const float *grad_aev,
                          float *grad_coords, double *virial, bool fixed);
@@ -1509,13 +1510,13 @@ static int aev_forward(void *stream, const anihip_aev_params *p, const float *ta
                        uint32_t *status, bool update)
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && aev, "null pointer argument");
+    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
+    if (!tuned_grid(p)) {   // (general grids: flags of the plain 32-column slabs, rows of at most 1024 columns)
+        ANIHIP_REQUIRE(!update, "rows are updated in place on the 16 / 8x4 / 4x8 grids only");
+        return aev_forward_generic((hipStream_t)stream, p, table, lo, hi, species, meta, ent, aev, nullptr, slab_mask);
+    }
     ANIHIP_REQUIRE(!slab_mask || (p->num_species + 1) / 2 + p->num_species * (p->num_species + 1) / 2 <= 32,
                    "slab_mask needs at most 32 slabs (num_species <= 7)");
-    ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
-    if (!tuned_grid(p)) {
-        ANIHIP_REQUIRE(!slab_mask, "slab masks exist for the 16 / 8x4 / 4x8 grids only");
-        return aev_forward_generic((hipStream_t)stream, p, table, lo, hi, species, meta, ent, aev);
-    }
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
     a.update = update ? 1 : 0;
@@ -1560,7 +1561,8 @@ extern "C" int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const fl
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && tangent && daev, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
-    ANIHIP_REQUIRE(tuned_grid(p), "the forward-mode derivative is built for the 16 / 8x4 / 4x8 grids only");
+    if (!tuned_grid(p))   // any other grid: the JVP instantiation of the general kernel
+        return aev_forward_generic((hipStream_t)stream, p, table, lo, hi, species, meta, ent, daev, tangent, nullptr);
     AevArgs a;
     if (int rc = make_args(p, &a)) return rc;
     if (hi == lo) return 0;

@@ -108,25 +108,53 @@ __device__ __forceinline__ void gen_stage_row(const GenArgs &a, const GenHdr &h,
 // ======================================================================================================================
 // forward
 // ======================================================================================================================
+// JVP: instead of the row, its derivative along the coordinate direction `tangent` [n_atoms][3] (J t: the reference's
+// cuaev double backward, csrc/aev.cu:1986-2015, templated there on any grid as well).  With d = r_j - r_i of a neighbor:
+// d' = t_j - t_i, r' = u . d', u' = (d' - u r') / r; every radial / angular term is replaced by its derivative along that
+// motion (oracle/ani_oracle.c ani_oracle_aev_jvp states the same chain rule in fp64).
+// slab_mask (optional, rows of at most 1024 columns): bit j of slab_mask[i] <=> columns 32 j .. 32 j + 31 of row i can be
+// non-zero -- PLAIN column order (a general grid has no 16 / 32-column blocks to line up with slabs: a block of a present
+// species (pair) flags every slab it overlaps); the networks' layer 0 skips the slabs no atom of a tile flags.
+template <bool JVP>
 __global__ __launch_bounds__(GEN_WPB * WAVE) void k_aev_fwd_gen(GenArgs a, const float *__restrict__ tab, int64_t lo,
                                                                 int64_t hi, const int32_t *__restrict__ species,
                                                                 const uint32_t *__restrict__ meta,
-                                                                const float4 *__restrict__ ent, float *__restrict__ aev)
+                                                                const float4 *__restrict__ ent, float *__restrict__ aev,
+                                                                const float *__restrict__ tangent,
+                                                                uint32_t *__restrict__ slab_mask)
 {
     __shared__ float4 s_ur[GEN_WPB][MAXR];
     __shared__ float2 s_fca[GEN_WPB][MAXR];
     __shared__ float2 s_fcr[GEN_WPB][MAXR];
     __shared__ int s_j[GEN_WPB][MAXR];
+    __shared__ float4 s_td[JVP ? GEN_WPB : 1][JVP ? MAXR : 1];   // u', r' of every neighbor (JVP)
     const int wib = threadIdx.x >> 6, lane = lane_id();
     const GenStage st{s_ur[wib], s_fca[wib], s_fcr[wib], s_j[wib]};
+    float4 *td = s_td[JVP ? wib : 0];
     const int64_t nw = (int64_t)gridDim.x * GEN_WPB;
     const int nAZ = a.nA * a.nZ;
+    auto flag_cols = [&](int c0, int c1) {   // slabs overlapped by the columns c0 .. c1 - 1
+        const int j0 = c0 >> 5, j1 = (c1 - 1) >> 5;
+        return (j1 >= 31 ? 0xFFFFFFFFu : ((1u << (j1 + 1)) - 1u)) & ~((1u << j0) - 1u);
+    };
     for (int64_t i = lo + blockIdx.x * (int64_t)GEN_WPB + wib; i < hi; i += nw) {
         float *out = aev + (size_t)i * a.L;   // (the caller's pointer is that of row 0, also for a shard's [hi - lo, L] buffer)
         GenHdr h = gen_hdr(meta, i);
         if (species[i] < 0) { h.nA = 0; h.nF = 0; h.pkA = 0ull; h.pkF = 0ull; }
+        uint32_t flags = 0u;
         // (every element of the row is written exactly once: blocks without a neighbor (pair) as zeros)
         if (h.nA + h.nF > 0) gen_stage_row(a, h, ent, st);
+        if (JVP && h.nA + h.nF > 0) {
+            const float tix = tangent[3 * i], tiy = tangent[3 * i + 1], tiz = tangent[3 * i + 2];
+            for (int e = lane; e < h.nA + h.nF; e += WAVE) {
+                const size_t jn = (size_t)st.jat[e];
+                const float4 U = st.ur[e];
+                const float dx = tangent[3 * jn] - tix, dy = tangent[3 * jn + 1] - tiy, dz = tangent[3 * jn + 2] - tiz;
+                const float rd = U.x * dx + U.y * dy + U.z * dz, ir = 1.0f / U.w;
+                td[e] = make_float4((dx - U.x * rd) * ir, (dy - U.y * rd) * ir, (dz - U.z * rd) * ir, rd);
+            }
+            wave_sync();
+        }
         // ---- radial: element (s, k) = sum over the neighbors of species s (its angular-range run and its far run) ----
         int offA = 0, offF = h.nA;
         for (int s = 0; s < a.S; ++s) {
@@ -139,12 +167,15 @@ __global__ __launch_bounds__(GEN_WPB * WAVE) void k_aev_fwd_gen(GenArgs a, const
                     for (int q = lane; q < cA + cF; q += WAVE) {
                         const int e = q < cA ? offA + q : offF + (q - cA);
                         const float dr = st.ur[e].w - sh;
-                        acc += 0.25f * __builtin_amdgcn_exp2f(-a.EtaR * G_LOG2E * dr * dr) * st.fcr[e].x;
+                        const float ex = 0.25f * __builtin_amdgcn_exp2f(-a.EtaR * G_LOG2E * dr * dr);
+                        if (JVP) acc += (ex * st.fcr[e].y - 2.0f * a.EtaR * dr * ex * st.fcr[e].x) * td[e].w;
+                        else acc += ex * st.fcr[e].x;
                     }
                     const float tot = wave_sum(acc);
                     if (lane == k) keep = tot;
                 }
                 if (lane < a.nR) out[s * a.nR + lane] = keep;
+                flags |= flag_cols(s * a.nR, (s + 1) * a.nR);
             } else if (lane < a.nR) {
                 out[s * a.nR + lane] = 0.f;
             }
@@ -174,23 +205,40 @@ __global__ __launch_bounds__(GEN_WPB * WAVE) void k_aev_fwd_gen(GenArgs a, const
                         if (v) gen_pair(same, t, n1, n2, j, k);
                         const int e1 = o1 + j, e2 = (same ? o1 : o2) + k;
                         const float4 U1 = st.ur[v ? e1 : 0], U2 = st.ur[v ? e2 : 0];
-                        const float fcc = v ? st.fca[e1].x * st.fca[e2].x : 0.f;
+                        const float2 F1 = st.fca[v ? e1 : 0], F2 = st.fca[v ? e2 : 0];
+                        const float fcc = v ? F1.x * F2.x : 0.f;
                         const float ct = 0.95f * (U1.x * U2.x + U1.y * U2.y + U1.z * U2.z);
                         const float sn = sqrtf(fmaxf(1.0f - ct * ct, 0.f));
                         const float rm = 0.5f * (U1.w + U2.w);
-                        float f2[GEN_MAXA];
+                        // JVP: derivatives of cos, sin, the mean distance and the cutoff product along the motion
+                        float ctd = 0.f, snd = 0.f, rmd = 0.f, fcd = 0.f;
+                        if (JVP) {
+                            const float4 T1 = td[v ? e1 : 0], T2 = td[v ? e2 : 0];
+                            ctd = 0.95f * (T1.x * U2.x + T1.y * U2.y + T1.z * U2.z + U1.x * T2.x + U1.y * T2.y + U1.z * T2.z);
+                            snd = -ct * ctd / sn;   // (sn >= 0.31: |cos| is scaled by 0.95)
+                            rmd = 0.5f * (T1.w + T2.w);
+                            fcd = v ? F1.y * T1.w * F2.x + F1.x * F2.y * T2.w : 0.f;
+                        }
+                        float f2[GEN_MAXA], g2[JVP ? GEN_MAXA : 1];   // f2 = Gaussian x cutoffs; g2 = its derivative (JVP)
 #pragma unroll
                         for (int u = 0; u < GEN_MAXA; ++u) {
                             const float dr = rm - tab[TAB_SHFA + (u < a.nA ? u : 0)];
-                            f2[u] = __builtin_amdgcn_exp2f(-a.EtaA * G_LOG2E * dr * dr) * fcc;
+                            const float ga = __builtin_amdgcn_exp2f(-a.EtaA * G_LOG2E * dr * dr);
+                            f2[u] = ga * fcc;
+                            if (JVP) g2[u] = ga * (fcd - 2.0f * a.EtaA * dr * rmd * fcc);
                         }
                         for (int z = 0; z < a.nZ; ++z) {
-                            const float hh = 0.5f + 0.5f * (ct * tab[TAB_COSZ + z] + sn * tab[TAB_SINZ + z]);
-                            const float f1 = 2.0f * __builtin_amdgcn_exp2f(a.Zeta * __builtin_amdgcn_logf(fmaxf(hh, 1e-30f)));
+                            const float cz = tab[TAB_COSZ + z], sz = tab[TAB_SINZ + z];
+                            const float hh = fmaxf(0.5f + 0.5f * (ct * cz + sn * sz), 1e-30f);
+                            const float lg = __builtin_amdgcn_logf(hh);
+                            const float f1 = 2.0f * __builtin_amdgcn_exp2f(a.Zeta * lg);
+                            // d f1 / dt = 2 Zeta h^(Zeta - 1) h',  h' = (cos' cos ShfZ + sin' sin ShfZ) / 2
+                            const float f1d = JVP ? a.Zeta * __builtin_amdgcn_exp2f((a.Zeta - 1.0f) * lg) * (ctd * cz + snd * sz) : 0.f;
 #pragma unroll
                             for (int u = 0; u < GEN_MAXA; ++u) {
                                 if (u < a.nA) {   // (wave-uniform)
-                                    const float tot = wave_sum(v ? f1 * f2[u] : 0.f);
+                                    const float term = JVP ? f1d * f2[u] + f1 * g2[u] : f1 * f2[u];
+                                    const float tot = wave_sum(v ? term : 0.f);
                                     const int q = u * a.nZ + z;
 #pragma unroll
                                     for (int c = 0; c < (GEN_MAXA * GEN_MAXZ) / WAVE; ++c)
@@ -202,11 +250,14 @@ __global__ __launch_bounds__(GEN_WPB * WAVE) void k_aev_fwd_gen(GenArgs a, const
 #pragma unroll
                     for (int c = 0; c < (GEN_MAXA * GEN_MAXZ) / WAVE; ++c)
                         if (c * WAVE + lane < nAZ) blk[c * WAVE + lane] = keep[c];
+                    const int c0 = a.radlen + gen_triu(a.S, s1, s2) * nAZ;
+                    flags |= flag_cols(c0, c0 + nAZ);
                 }
                 o2 += n2;
             }
             o1 += n1;
         }
+        if (slab_mask && lane == 0) slab_mask[i] = flags;
         wave_sync();
     }
 }
@@ -397,13 +448,20 @@ static int gen_args(const anihip_aev_params *p, GenArgs *a)
 
 // (called by anihip_aev_forward / anihip_aev_backward* of aev.hip for grids the tuned kernels do not cover)
 int aev_forward_generic(hipStream_t stream, const anihip_aev_params *p, const float *table, int64_t lo, int64_t hi,
-                        const int32_t *species, const uint32_t *meta, const float *ent, float *aev)
+                        const int32_t *species, const uint32_t *meta, const float *ent, float *aev, const float *tangent,
+                        uint32_t *slab_mask)
 {
     GenArgs a;
     if (int rc = gen_args(p, &a)) return rc;
+    ANIHIP_REQUIRE(!slab_mask || a.L <= 32 * 32, "slab masks need rows of at most 1024 columns (got %d)", a.L);
     if (hi == lo) return 0;
-    hipLaunchKernelGGL(k_aev_fwd_gen, dim3(gen_blocks(hi - lo)), dim3(GEN_WPB * WAVE), 0, stream, a, table, lo, hi,
-                       species, meta, (const float4 *)ent, aev);
+    const dim3 grid(gen_blocks(hi - lo)), block(GEN_WPB * WAVE);
+    if (tangent)
+        hipLaunchKernelGGL(k_aev_fwd_gen<true>, grid, block, 0, stream, a, table, lo, hi, species, meta, (const float4 *)ent, aev,
+                           tangent, slab_mask);
+    else
+        hipLaunchKernelGGL(k_aev_fwd_gen<false>, grid, block, 0, stream, a, table, lo, hi, species, meta, (const float4 *)ent,
+                           aev, tangent, slab_mask);
     ANIHIP_CHECK_HIP(hipGetLastError());
     return 0;
 }

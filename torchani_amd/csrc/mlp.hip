@@ -3307,7 +3307,10 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     const int fused_rows = ((d->flags & ANIHIP_MLP_FLAG_FUSED_ROWS32) && d->activation == ANIHIP_ACT_CELU) ? 32 : 64;
     const int64_t fused_tiles = (n + fused_rows - 1) / fused_rows + S;
     const int n_slabs = K0p / 32;
-    const uint32_t *tab_mask = (kp_rad > 0 && !(d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK)) ? slab_mask : nullptr;
+    // per-atom slab flags for the fused kernel's tile masks: the ANI slab order (kp_rad > 0: anihip_aev_forward's flags for
+    // the 16 / 32-column grids) or, for any other row layout, the plain 32-column slabs (kp_rad = 0: the flags of the
+    // general AEV kernel; rows of at most 1024 columns)
+    const uint32_t *tab_mask = ((kp_rad > 0 || (h3 && K0p <= 32 * 32)) && !(d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK)) ? slab_mask : nullptr;
     const uint32_t all_slabs = n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << n_slabs) - 1u);
     const bool small_prep = n <= SMALL_PREP_MAX && !(d->flags & ANIHIP_MLP_FLAG_NO_SMALL_PREP);
     if (small_prep) {
@@ -3393,15 +3396,15 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     // members' d E / d AEV in place -- no d act0 round trip through HBM (8 KB per atom written and read back), no layer-0
     // backward launch.  Tiles are then the unit of work (not tile x member items), so it needs enough of them to balance
     // over the CUs: from 65536 atoms on (1024 tiles).  Smaller inputs keep the member-major sweep + a backward GEMM.
-    bool fused_l0b = fused && grad_aev && fused_rows == 64 && kp_rad > 0 && n >= FUSED_L0B_MIN_ATOMS &&
+    bool fused_l0b = fused && grad_aev && fused_rows == 64 && n >= FUSED_L0B_MIN_ATOMS &&
                      !(d->flags & (ANIHIP_MLP_FLAG_NO_FUSED_L0B | ANIHIP_MLP_FLAG_SMALL_TILES));
     // (phase 5 hands partial sums between waves through 32 KB of LDS in X1's place: 2 planes x 64 rows x (H2 + 8) halves)
     auto l0b_ok = [&](int s) { return d->net[s].wthf[0] != nullptr && d->net[s].dims[2] >= 128; };
     for (int s = 0; s < S && fused_l0b; ++s) fused_l0b = l0b_ok(s);
     if (d->flags & ANIHIP_MLP_FLAG_FUSED_L0B) {   // (forced, e.g. by the tests on small inputs)
-        fused_l0b = fused && grad_aev && fused_rows == 64 && kp_rad > 0;
+        fused_l0b = fused && grad_aev && fused_rows == 64;
         for (int s = 0; s < S && fused_l0b; ++s) fused_l0b = l0b_ok(s);
-        ANIHIP_REQUIRE(fused_l0b, "ANIHIP_MLP_FLAG_FUSED_L0B needs the fused kernel (64-row tiles), slab-ordered planes and wthf[0]");
+        ANIHIP_REQUIRE(fused_l0b, "ANIHIP_MLP_FLAG_FUSED_L0B needs the fused kernel (64-row tiles), wthf[0] and second hidden layers of >= 128 columns");
     }
 
     FinishArgs fin{};

@@ -248,7 +248,7 @@ class AevEngine:
     def n_slabs(self) -> int:
         """Number of 32-wide slabs of an AEV row in slab order (include/anihip.h)."""
         if not self.tuned:
-            return 1 << 30   # (no slab structure: nobody may ask for masks)
+            return -(-self.L // 32)   # (a general grid: plain 32-column slabs of the row)
         S = self.params.num_species
         return (S + 1) // 2 + S * (S + 1) // 2
 
@@ -548,20 +548,22 @@ class PackedNetworks:
     def forward_backward(self, species: Tensor, aev: Tensor, lo: int = 0, hi: tp.Optional[int] = None,
                          want_grad: bool = True, want_members: bool = False, chunk: int = 1 << 20,
                          atomic_e: tp.Optional[Tensor] = None, grad_aev: tp.Optional[Tensor] = None,
-                         slab_mask: tp.Optional[Tensor] = None, shard_rows: bool = False, tile_hint: int = 0
-                         ) -> tp.Tuple[Tensor, tp.Optional[Tensor], tp.Optional[Tensor]]:
+                         slab_mask: tp.Optional[Tensor] = None, shard_rows: bool = False, tile_hint: int = 0,
+                         plain_slabs: bool = False) -> tp.Tuple[Tensor, tp.Optional[Tensor], tp.Optional[Tensor]]:
         """Per-atom ensemble-mean energies [N], d e/d aev [N,L] (optional), member energies [M,N].
 
         slab_mask (int32 [N] from AevEngine.forward): the layer-0 GEMMs skip AEV slabs no atom of a row tile
-        flags; grad_aev is then only defined inside the flagged slabs (all AevEngine.backward reads).
+        flags; grad_aev is then only defined inside the flagged slabs (all AevEngine.backward reads).  The flags must
+        be in the order of this pack's layer-0 planes: the ANI slab order of the 16 / 32-column grids (radial_len > 0),
+        or -- plain_slabs=True, general grids, radial_len == 0 -- the plain 32-column slabs of the row.
         shard_rows=True: aev (and the returned / given grad_aev) hold only the rows lo..hi.
         tile_hint: _lib.MLP_FLAG_SMALL_TILES / MLP_FLAG_BIG_TILES from a caller that knows the composition (used unless the
         instance / class flags already choose a layer-0 tiling)."""
         _require_cuda(species, aev, slab_mask)
         if slab_mask is not None:
             assert slab_mask.dtype == torch.int32 and slab_mask.numel() == species.numel()
-            if self.radial_len == 0:
-                slab_mask = None
+            if (self.radial_len == 0) != plain_slabs or (plain_slabs and (self.aev_len > 1024 or self.precision != "f16x3")):
+                slab_mask = None   # (flags in another order than the planes': multiply every slab)
         n = species.numel()
         hi = n if hi is None else hi
         rows = (hi - lo) if shard_rows else n

@@ -295,6 +295,12 @@ class ANI(torch.nn.Module):
     # 0.6 KB instead of 4 KB per water atom).  False: a fresh, fully written buffer per call.
     keep_aev_rows = True
 
+    @staticmethod
+    def _plain_slabs(eng, packed) -> bool:
+        """A general symmetry-function grid (AEVComputer.from_constants) whose networks run through the fused kernel: the
+        general AEV kernel flags the plain 32-column slabs of a row that can be non-zero and layer 0 skips the others."""
+        return (not eng.tuned) and packed.radial_len == 0 and packed.precision == "f16x3" and eng.L <= 1024 and eng.L % 4 == 0
+
     # ---- species numbered "present ones first" inside the engine ------------------------------------------------------
     compact_species = True   # large systems: relabel the species so that the AEV blocks of absent species come last
 
@@ -372,7 +378,8 @@ class ANI(torch.nn.Module):
         # layer-0 GEMMs skip the others
         slab_mask = None
         # AEV rows and their gradients exist for this rank's central atoms only ([hi - lo, L] buffers)
-        if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
+        plain = self._plain_slabs(eng, packed)
+        if packed.radial_len == 16 * eng.params.num_species and eng.tuned and eng.n_slabs <= 32:
             if self.keep_aev_rows and not torch.cuda.is_current_stream_capturing():
                 # rows and flags in the engine's kept buffers, updated in place (AevEngine.forward_update)
                 aev, slab_mask = eng.forward_update(species32, nbrs)
@@ -381,10 +388,14 @@ class ANI(torch.nn.Module):
                 slab_mask = (torch.empty if (lo == 0 and hi == n) else torch.zeros)(n, dtype=torch.int32, device=c32.device)
                 aev = eng.forward(species32, nbrs, slab_mask=slab_mask, shard_rows=True)
         else:
+            if plain:   # a general grid: flags of the plain 32-column slabs from the general AEV kernel
+                slab_mask = torch.zeros(n, dtype=torch.int32, device=c32.device)
             aev = eng.forward(species32, nbrs, slab_mask=slab_mask, shard_rows=True)
         atomic_e, grad_aev, _ = packed.forward_backward(species32, aev, lo=lo, hi=hi, want_grad=True,
                                                         chunk=self.mlp_chunk, slab_mask=slab_mask,
-                                                        shard_rows=True, tile_hint=tile_hint)
+                                                        shard_rows=True, tile_hint=tile_hint, plain_slabs=plain)
+        if plain:
+            slab_mask = None   # (the general AEV backward reads the blocks of present species only: no flags needed)
         virial = torch.empty((3, 3), dtype=torch.float64, device=c32.device) if stress else None
         pair_e, pair_g, pair_w = self._pair_terms(species32, c32, cell, pbc_t, nbrs, lo, hi, stress)
         from .parallel import FORCE_COLLECTIVES
@@ -553,16 +564,22 @@ class ANI(torch.nn.Module):
         nbrs = aevc.neighbor_rows(sp_l, x_l, cell, pbc_t, lo=lo, hi=hi)
         packed = self.neural_networks._pack(dev, order)
         slab_mask = None
-        if packed.radial_len == 16 * eng.params.num_species and eng.n_slabs <= 32:
+        plain = self._plain_slabs(eng, packed)
+        if packed.radial_len == 16 * eng.params.num_species and eng.tuned and eng.n_slabs <= 32:
             if self.keep_aev_rows and not torch.cuda.is_current_stream_capturing():
                 aev, slab_mask = eng.forward_update(sp_l, nbrs)   # (kept buffers, updated in place)
             else:
                 slab_mask = torch.zeros(nl, dtype=torch.int32, device=dev)
                 aev = eng.forward(sp_l, nbrs, slab_mask=slab_mask, shard_rows=True)
         else:
+            if plain:
+                slab_mask = torch.zeros(nl, dtype=torch.int32, device=dev)
             aev = eng.forward(sp_l, nbrs, slab_mask=slab_mask, shard_rows=True)
         atomic_e, grad_aev, _ = packed.forward_backward(sp_l, aev, lo=lo, hi=hi, want_grad=True, chunk=self.mlp_chunk,
-                                                        slab_mask=slab_mask, shard_rows=True, tile_hint=tile_hint)
+                                                        slab_mask=slab_mask, shard_rows=True, tile_hint=tile_hint,
+                                                        plain_slabs=plain)
+        if plain:
+            slab_mask = None
         virial = torch.empty((3, 3), dtype=torch.float64, device=dev) if stress else None
         pair_e, pair_g, pair_w = self._pair_terms(sp_l, x_l, cell, pbc_t, nbrs, lo, hi, stress)
         sae = self._sae64(dev) if self.energy_shifter._enabled else None
