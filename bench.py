@@ -232,7 +232,7 @@ def main():
         lo, hi, nl = part.n_left, part.n_left + part.n_owned, part.n_local
         packed = model.neural_networks._pack(dev, order)
         st = {f"partition (cut once per skin {model.partition_skin} A of motion)": time_stage(
-            lambda: type(part)(coords, cell, pbc, wd, r, model.aev_computer.radial.cutoff, sp32, skin=model.partition_skin), 3)}
+            lambda: type(part)(coords, cell, pbc, wd, r, model._spatial_reach(), sp32, skin=model.partition_skin), 3)}
         st["gather local system"] = time_stage(lambda: (part.local(sp32), part.local(coords, 3)), 3)
         nbrs = eng.neighbors(sp_l, x_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
         st["neighbors"] = time_stage(lambda: eng.neighbors(sp_l, x_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128), 3)
@@ -419,7 +419,7 @@ def main():
             "rank": rank, "local_rank": local, "device": f"cuda:{dev.index}", "name": props.name, "pid": os.getpid(),
             "peers": list(part.peers), "local_atoms": part.n_local, "owned_atoms": part.n_owned,
             "sent_bytes_per_step": lc["bytes"], "ms_per_step_this_rank": elapsed_rank / args.steps * 1e3}, group=group)
-        part_ms = time_stage(lambda: type(part)(coords, cell, pbc, world, rank, model.aev_computer.radial.cutoff,
+        part_ms = time_stage(lambda: type(part)(coords, cell, pbc, world, rank, model._spatial_reach(),
                                                 species.to(torch.int32).view(-1), skin=model.partition_skin), 3)
         res["collective"] = {
             "collectives_per_step": lc["collectives_per_step"], "world_size": lc["world_size"],

@@ -113,6 +113,29 @@ def _worker_ef(rank, world, port, q):
         both = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(both, chk, group=group)
         out["rank_spread"] = float((both[0] - both[1]).abs().max())
+        # (d) potentials wider than the AEV's cutoff on spatial shards: ANI-2dr = networks + xTB repulsion (5.2 A) + DFT-D3
+        # dispersion (8 A, coordination numbers: a halo of three cutoffs), on a box three times as long as it is wide so
+        # that the 24 A halos do not simply cover everything.  ONE collective; D3 is evaluated for the local system only.
+        from torchani_amd.models import ANI2dr
+
+        spw, xw, cw = water_box(12)
+        L0 = float(cw[0, 0])
+        xs = np.concatenate([xw + np.array([k * L0, 0.0, 0.0], dtype=np.float32) for k in range(3)], axis=1)
+        sps = np.concatenate([spw] * 3, axis=1)
+        cells = cw.copy()
+        cells[0, 0] = 3 * L0
+        m2d = ANI2dr(seed=5, device=dev, periodic_table_index=False, neighborlist="cell", row_capacity=160)
+        spd, xd, celld = torch.from_numpy(sps).to(dev), torch.from_numpy(xs).to(dev), torch.from_numpy(cells).to(dev)
+        d_one = m2d.energies_and_forces(spd, xd, celld, (True, True, True), stress=True)
+        d_two = m2d.energies_and_forces(spd, xd, celld, (True, True, True), group=group, reduce_forces=False, stress=True)
+        own = (d_two.forces.abs().sum(dim=2) > 0).reshape(-1)
+        out["d3_coll"] = m2d.last_collective["collectives_per_step"]
+        out["d3_op"] = m2d.last_collective["op"]
+        out["d3_local"] = (m2d.last_collective["n_local"], m2d.last_collective["n_owned"], int(spd.numel()))
+        out["d3_dE"] = float((d_two.energies - d_one.energies).abs().max())
+        out["d3_dF"] = float((d_two.forces[0, own] - d_one.forces[0, own]).abs().max())
+        out["d3_dW"] = float((d_two.virial - d_one.virial).abs().max())
+        out["d3_Fmax"] = float(d_one.forces.abs().max())
         # (c) batch of molecules that do not straddle ranks: only the 16-byte-per-molecule energy tail is reduced
         gb = load_golden("rand_batch_ani2x")
         modelb = ANI2x(state_dict=seeded_state("ani2x", 8, gb["seed"]), device=dev, periodic_table_index=False)
@@ -168,6 +191,10 @@ def test_two_ranks_energies_forces_virial_match_single_rank():
         assert o["owned_dF"] < 2e-6 and o["owned_n"] >= 1490 and o["owned_coll"] == 1, o
         assert o["index_dF"] < 2e-6 and o["index_bytes"] == 4 * (3 * 3000 + 4 + 36), o   # forces + energy + virial parts
         assert o["batch_dE"] < 1e-9 and o["batch_dF_own"] < 2e-6, o
+        # ANI-2dr on spatial shards: one all-to-all, a local system smaller than the box, the single-rank numbers
+        assert o["d3_coll"] == 1 and o["d3_op"].startswith("all_to_all"), o
+        assert o["d3_local"][1] == o["d3_local"][2] // 2 and o["d3_local"][0] < o["d3_local"][2], o
+        assert o["d3_dE"] < 1e-7 * o["d3_local"][2] and o["d3_dF"] < 5e-6 * max(1.0, o["d3_Fmax"]) and o["d3_dW"] < 1e-4, o
         assert o["batch_bytes"] == 16 * o["batch_C"], o
 
 

@@ -486,14 +486,28 @@ class ANI(torch.nn.Module):
             self.__dict__["_locality_cache"] = hit
         return hit[2]
 
+    def _spatial_reach(self) -> float:
+        """How far beyond its slab a rank must see for every enabled potential (Angstrom; inf: cannot be cut into slabs).
+
+        Networks: the AEV's radial cutoff.  An analytic pair potential on rows of the owned atoms: its own cutoff (what it
+        pushes onto halo atoms travels with the halo force rows).  D3 (``needs_all_rows``): THREE cutoffs -- its kernel
+        gathers the complete gradient on an owned atom k from k's neighbors j (one cutoff), whose d E / d CN_j sums over
+        j's own neighbors m (two), whose coordination numbers CN_m count m's neighbors (three); with all of that inside
+        the local system the owned atoms' D3 energies and forces are exact and need nothing from another rank."""
+        reach = self.aev_computer.radial.cutoff
+        for k, p in self.potentials.items():
+            if k == "nnp" or not p._enabled:
+                continue
+            reach = max(reach, (3.0 if getattr(p, "needs_all_rows", False) else 1.0) * float(p.cutoff))
+        return reach
+
     def _spatial_ok(self, C: int, n: int) -> bool:
-        """Slab decomposition applies to ONE system evaluated through its own pair search, with every pair potential
-        inside the AEV's radial cutoff (a wider potential, or D3's coordination numbers, would need a wider halo)."""
+        """Slab decomposition applies to ONE system evaluated through its own pair search, with every enabled potential
+        of finite range (the halo is as wide as the widest of them needs, _spatial_reach; a cutoff-free potential falls
+        back to index ranges + one all-reduce of the whole force array)."""
         if self.partition != "spatial" or C != 1 or n < 2 or self.aev_computer.verlet is not None:
             return False
-        rc = self.aev_computer.radial.cutoff
-        return all(k == "nnp" or not p._enabled or (p.cutoff <= rc + 1e-6 and not getattr(p, "needs_all_rows", False))
-                   for k, p in self.potentials.items())
+        return math.isfinite(self._spatial_reach())
 
     def _spatial_partition(self, species32: Tensor, c32: Tensor, cell, pbc_t, rank: int, world: int,
                            species_key: tp.Optional[Tensor] = None):
@@ -533,7 +547,7 @@ class ANI(torch.nn.Module):
             # (the entry keeps the tensors alive, so an equal key means the same coordinates, not a recycled address)
             # (one rank has no halo: any order is correct, the skin only says when the order has stopped being local)
             skin = self.partition_skin if world > 1 else max(self.partition_skin, self.aev_computer.radial.cutoff)
-            hit = (key, SpatialShards(c32, cell, pbc_t, world, rank, self.aev_computer.radial.cutoff, species32, skin=skin),
+            hit = (key, SpatialShards(c32, cell, pbc_t, world, rank, self._spatial_reach(), species32, skin=skin),
                    c32, cell, spk)
             self.__dict__["_spatial_cache"] = hit
         return hit[1]
