@@ -1,1 +1,2 @@
-timeout 900 python -m pytest tests/test_gpu_distributed.py -x -q -k "two_ranks_energies" 2>&1 | tail -30
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "layer0_backward_inside or mlp_ensemble or fused or skinny or large_systems" 2>&1 | tail -3
+VARIANTS="base" bash tools/gpu_ab_libs.sh

@@ -1638,7 +1638,11 @@ __device__ __forceinline__ void fr_ring(WRing<NB, D> &r, const _Float16 *w, int6
 }
 
 // acc += X[rows, K] x B over all KS = K/16 k steps (KS even): whole groups of D steps without a branch, the
-// tail (an even number of steps < D) issues no loads.  xa = hi plane of X, ldx = row stride (halves)
+// tail (an even number of steps <= D) issues no loads.  A group requests the D steps behind it, clamped to the last one:
+// the group loop stops as soon as the ring holds everything that is left (k0 + D >= KS), so a reduction length that is
+// a multiple of D (KS = 12, 6: half of the phases of the water networks) issues no repeated request at all -- each
+// repeat moves 2 KB per wave through the CU's 64 B/clk return path and queues ahead of whatever the next phase asks
+// for first.  xa = hi plane of X, ldx = row stride (halves)
 template <int RB, int NB, int RBA, int NBA, int D>
 __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *xa, int ldx, int x_plane,
                                         WRing<NB, D> &rg, int KS, int lane)
@@ -1649,7 +1653,7 @@ __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *
     AFrag<RBA> xe, xo;
     xe.load(af, x_plane, rbs);
     int k0 = 0;
-    for (; k0 + D <= KS; k0 += D) {
+    for (; k0 + D < KS; k0 += D) {
 #pragma unroll
         for (int sl = 0; sl < D; sl += 2) {
             xo.load(af + (k0 + sl + 1) * 16, x_plane, rbs);
@@ -1660,9 +1664,9 @@ __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *
             rg.template load<NBA>(sl + 1, min(k0 + sl + 1 + D, KS - 1));
         }
     }
-    const int rem = KS - k0;
+    const int rem = KS - k0;   // (<= D steps, all of them in the ring)
 #pragma unroll
-    for (int sl = 0; sl < D - 2; sl += 2) {
+    for (int sl = 0; sl < D; sl += 2) {
         if (rem > sl) {
             xo.load(af + (k0 + sl + 1) * 16, x_plane, rbs);
             fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, sl, xe);
@@ -1676,10 +1680,15 @@ __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *
 // ring slot = step % D), A fragments of step k + 1 read from LDS before the MFMAs of step k like fr_gemm.  s0 / s1 =
 // this lane's fragment address in the two slots; the steps of the slabs past the tile's last flagged one (n_live of
 // the pair's 6 are live) have zero operands: no MFMAs, the ring request stays unconditional.
-template <int RB, int NB, int RBA, int NBA, int D, int ROWS, class NextKs>
+// STEPS / REQS: the general form walks all 12 steps and requests a fragment behind every one of them (clamped repeats once
+// the tile's steps are used up); a tile with at most FOUR flagged slabs -- every tile of a water box -- has 8 steps, 6 of
+// them in the ring when the loop starts: the short form walks 8 steps and requests 2 (the repeats it leaves out were 20 KB
+// per wave and item through the CU's 64 B/clk return path)
+template <int RB, int NB, int RBA, int NBA, int D, int ROWS, int STEPS, int REQS, class NextKs>
 __device__ __forceinline__ void fr_l0_pair(f32x16 (&acc)[RB * NB], WRing<NB, D> &rg, const _Float16 *s0,
                                            const _Float16 *s1, int n_live, NextKs &&next_ks)
 {
+    static_assert(STEPS % 2 == 0 && STEPS <= 4 * FR_GROUP && REQS % 2 == 0 && REQS <= STEPS && STEPS <= D + REQS, "ring coverage");
     constexpr int SLAB = 2 * ROWS * FR_SLAB_LD, PL = ROWS * FR_SLAB_LD, RBS = 32 * FR_SLAB_LD;
     auto addr = [&](int st) {
         return (st / (2 * FR_GROUP) ? s1 : s0) + ((st / 2) % FR_GROUP) * SLAB + (st & 1) * 16;
@@ -1687,14 +1696,14 @@ __device__ __forceinline__ void fr_l0_pair(f32x16 (&acc)[RB * NB], WRing<NB, D> 
     AFrag<RBA> xe, xo;
     xe.load(addr(0), PL, RBS);
 #pragma unroll
-    for (int st = 0; st < 4 * FR_GROUP; st += 2) {
+    for (int st = 0; st < STEPS; st += 2) {
         const bool live = st / 2 < n_live;
         xo.load(addr(st + 1), PL, RBS);
         if (live) fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, st % D, xe);
-        rg.template load<NBA>(st % D, next_ks());
-        if (st + 2 < 4 * FR_GROUP) xe.load(addr(st + 2), PL, RBS);
+        if (st < REQS) rg.template load<NBA>(st % D, next_ks());
+        if (st + 2 < STEPS) xe.load(addr(st + 2), PL, RBS);
         if (live) fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, (st + 1) % D, xo);
-        rg.template load<NBA>((st + 1) % D, next_ks());
+        if (st < REQS) rg.template load<NBA>((st + 1) % D, next_ks());
     }
 }
 
@@ -2223,7 +2232,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 const int lo_ = (u1.rb0 * 32 + fr) * FR_SLAB_LD + fk * 8;   // this lane's fragment inside a staged slab
                 const _Float16 *s0 = slot(2 * (pr & 1)) + lo_, *s1 = slot(2 * (pr & 1) + 1) + lo_;
                 const int n_live = nact - 2 * FR_GROUP * pr;
-                FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS>(acc, rg, s0, s1, n_live, next_ks)))
+                if (nact <= 4) {   // (wave-uniform)
+                    FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS, 8, 2>(acc, rg, s0, s1, n_live, next_ks)))
+                } else {
+                    FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS, 4 * FR_GROUP, 4 * FR_GROUP>(acc, rg, s0, s1, n_live, next_ks)))
+                }
             }
             if (pr + 1 < npair) {   // (the last pair's successors are zeros nobody reads)
                 store_group(va, slot(2 * ((pr + 1) & 1)));
@@ -2463,7 +2476,8 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             // fragment crosses the CU's 64 B/clk L2 port once and feeds six MFMAs).  The two partial tiles meet in LDS (X1's
             // place, dead since phase 4): a wave hands over the row block it does not own and finishes the other --
             // w: rows 0..31, w + 4: rows 32..63 -- with the read-add-write on the AEV gradient rows.
-            const int KS5 = H1 >> 4, KH0 = (KS5 >> 2) << 1;
+            // (first half: 6 steps when there are 12 or more -- a ring's depth, so that wave issues no repeated request)
+            const int KS5 = H1 >> 4, KH0 = KS5 >= 12 ? 6 : (KS5 >> 2) << 1;
             const int half = wave >> 2;
             const int kbeg = half ? KH0 : 0, KH = half ? KS5 - KH0 : KH0;   // (both even)
             const int64_t mh5 = (int64_t)g.n_slabs * KS5 * (2 * FRAG);
