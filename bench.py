@@ -236,9 +236,8 @@ def main():
         st["gather local system"] = time_stage(lambda: (part.local(sp32), part.local(coords, 3)), 3)
         nbrs = eng.neighbors(sp_l, x_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128)
         st["neighbors"] = time_stage(lambda: eng.neighbors(sp_l, x_l, cell, pbc, lo=lo, hi=hi, mode="cell", row_cap=128), 3)
-        mask = torch.zeros(nl, dtype=torch.int32, device=dev)
-        aev = eng.forward(sp_l, nbrs, slab_mask=mask, shard_rows=True)
-        st["aev_forward"] = time_stage(lambda: eng.forward(sp_l, nbrs, out=aev, slab_mask=mask, shard_rows=True), 3)
+        aev, mask = eng.forward_update(sp_l, nbrs)   # (kept rows, updated in place: the product path)
+        st["aev_forward"] = time_stage(lambda: eng.forward_update(sp_l, nbrs), 3)
         ae = torch.zeros(nl, dtype=torch.float32, device=dev)
         gaev = torch.zeros_like(aev)
         st["mlp_fwd_bwd"] = time_stage(lambda: packed.forward_backward(sp_l, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev,

@@ -938,6 +938,32 @@ def test_layer0_backward_inside_the_fused_kernel(dev, elements):
     assert res["max_dE_atom"] < 1e-6 * max(1.0, float(out.atomic_energies.abs().max())) and res["max_dF"] < 5e-6 * fmax
 
 
+def test_layer0_backward_inside_the_fused_kernel_gelu(dev):
+    """The same for the GELU / bias-free networks of the ANI-2xr family (k_mlp_fused<2, 1, GELU, L0B>): energies and forces
+    with phase 5 forced equal those of the hand-over path on a 17 496-atom H / O box (the -r models' pair potentials off:
+    networks only)."""
+    from bench import water_box
+    from torchani_amd.models import ANI2xr
+
+    sp_np, x_np, cell_np = water_box(18)
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    model = ANI2xr(seed=3, device=dev, periodic_table_index=False, neighborlist="cell", row_capacity=192)
+    model.set_enabled("repulsion_xtb", False)
+    old = PackedNetworks.default_flags
+    try:
+        PackedNetworks.default_flags = _lib.MLP_FLAG_NO_FUSED_L0B
+        ref = model.energies_and_forces(sp, x, cell, (True, True, True), check_overflow=True)
+        PackedNetworks.default_flags = _lib.MLP_FLAG_FUSED_L0B
+        out = model.energies_and_forces(sp, x, cell, (True, True, True))
+    finally:
+        PackedNetworks.default_flags = old
+    assert torch.equal(out.atomic_energies, ref.atomic_energies)
+    fmax = float(ref.forces.abs().max())
+    err = float((out.forces - ref.forces).abs().max())
+    report(f"l0b   GELU (ANI-2xr networks): max|dF| = {err:.2e} of {fmax:.2e}")
+    assert fmax > 1e-3 and err < 2e-6 * max(1.0, fmax)
+
+
 @pytest.mark.parametrize("periodic", [True, False])
 def test_locality_sort_of_a_shuffled_system(dev, periodic):
     """ANI.locality_sort = "auto": a large single system given in an incoherent atom order is evaluated on a cell-sorted
