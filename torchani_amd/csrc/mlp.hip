@@ -2277,7 +2277,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         {
             if (C::LAZY) load_cols(fs.b0 + (int64_t)m * H1, bias0, u1);
             const float oscale = fs.is0 * 0.25f;
-            float vmax = 0.f;
+            // tile maximum of |act0| for the split scale: act0 >= -alpha (CELU) / >= -0.17 (GELU), so max(floor, max act0)
+            // bounds it -- one v_max3_f32 per element pair instead of two |.| and three max (a quarter of this epilogue's
+            // VALU instructions went into the absolute values)
+            float vmax = ACT == 1 ? 0.17f : alpha;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -2291,7 +2294,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                                     d0f[i][r + 1]);
                             acc[i][r] = v0;
                             acc[i][r + 1] = v1;
-                            vmax = fmaxf(vmax, nb < u1.nba ? fmaxf(fabsf(v0), fabsf(v1)) : 0.f);
+                            if (NB == 1 || nb < u1.nba) vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(v0, v1));
                         } else {   // (defined on every path, like the rings)
                             d0f[i][r] = 0.f;
                             d0f[i][r + 1] = 0.f;
