@@ -282,3 +282,64 @@ def test_force_training_autograd_matches_reference(dev, base):
     assert l_err < 1e-5
     assert err < 2e-4 * scale     # block sums over 4096 fp32-accumulated entries
     assert abs(np.abs(got).max() - scale) < 1e-4 * scale
+
+
+@pytest.mark.parametrize("base", ["rand_batch_ani2x", "water_pbc_ani2x"])
+def test_training_the_gelu_networks_of_the_2xr_family(dev, base):
+    """Round 4: the training passes also serve the GELU / bias-free networks of ANI-2xr / 2dr (the reference trains them
+    through plain autograd, arch.py:992-1066, nn/_core.py:146-167): they keep the pre-activations (GELU' cannot be
+    recovered from x Phi(x)) and the bias slots of the engine stay empty.  Energy loss and force loss (create_graph=True)
+    against the digests of the reference's own first- and second-order autograd (tests/golden/x2rtrain_*.npz)."""
+    from _util import wgrad_digest, wgrad_upstream
+    from torchani_amd.models import ANI2xr
+
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"x2rtrain_{base}.npz")) as z:
+        f = {k: z[k] for k in z.files}
+    g = load_golden(base)
+    model = ANI2xr(seed=int(f["seed"]), device=dev, periodic_table_index=False, row_capacity=256)
+    nets = model.neural_networks
+    nets.requires_grad_(True)
+    symbols = [str(s) for s in f["symbols"]]
+    sp = torch.from_numpy(f["species"]).to(dev)
+    cell = None if g["cell"] is None else torch.from_numpy(g["cell"]).to(dev)
+    pbc = None if g["pbc"] is None else torch.tensor([bool(b) for b in g["pbc"]])
+    C, A = sp.shape
+
+    def flat():
+        out = []
+        for member in nets.members:
+            for sym in symbols:
+                for lin in member.atomics[sym].linears():
+                    assert lin.bias is None
+                    gr = lin.weight.grad if lin.weight.grad is not None else torch.zeros_like(lin.weight)
+                    out.append(gr.detach().cpu().numpy().astype(np.float64).reshape(-1))
+        return np.concatenate(out)
+
+    def check(tag, got, loss, loss_ref):
+        sums, dots, heads = wgrad_digest(got)
+        scale = float(f[f"{tag}_abs_max"])
+        err = max(np.abs(sums - f[f"{tag}_sums"]).max(), np.abs(dots - f[f"{tag}_dots"]).max(),
+                  np.abs(heads - f[f"{tag}_heads"]).max())
+        report(f"x2rtrain {base:20s} {tag}: |loss err| = {abs(loss - loss_ref):.2e}  max digest err = {err:.2e} (max |grad| {scale:.2e})")
+        assert abs(loss - loss_ref) < 1e-5
+        assert err < 2e-4 * scale and abs(np.abs(got).max() - scale) < 1e-4 * scale
+
+    # energy loss
+    x = torch.from_numpy(g["coords"]).to(dev)
+    aev = model.aev_computer(sp, x, cell, pbc)
+    atomic = nets(sp, aev, atomic=True)
+    loss = (atomic * torch.from_numpy(wgrad_upstream(C, A).astype(np.float32)).to(dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert f["n_params"] == sum(p.numel() for p in nets.parameters())
+    check("e", flat(), float(loss.detach()), float(f["loss_e"]))
+    nets.zero_grad(set_to_none=True)
+    # force loss
+    xx = torch.from_numpy(g["coords"]).to(dev).requires_grad_(True)
+    t = torch.from_numpy(fgrad_direction(f["species"]).astype(np.float32)).to(dev)
+    e = nets(sp, model.aev_computer(sp, xx, cell, pbc)).sum()
+    (gx,) = torch.autograd.grad(e, xx, create_graph=True)
+    lossf = -(gx * t).sum()
+    lossf.backward()
+    torch.cuda.synchronize()
+    check("f", flat(), float(lossf.detach()), float(f["loss_f"]))

@@ -83,6 +83,12 @@ struct GemmArgs {
     int a_tm_h[MAX_S];     //      and per-species row width H_s
     const float *Z;        // tangent pass: zdot (same leading dimension as Y)
     float *C2;             // tangent pass: second output (same leading dimension as C)
+    // training passes of GELU networks (act = ANIHIP_ACT_GELU): GELU' cannot be recovered from the stored activation
+    // (x Phi(x) is not monotonic), so the forward keeps the PRE-activations too: Xout (EPI_BIAS_CELU, laid out like C) and
+    // the passes that need activation derivatives read them back: X (laid out like Y)
+    int act;
+    const float *X;
+    float *Xout;
     const int *c_scatter;  // sorted position -> destination row (last backward GEMM) or NULL
     int n_store;           // EPI_SCATTER: only columns < n_store are stored
     int S, batch, ncol_max, nrow_tiles_ub;
@@ -251,6 +257,22 @@ __device__ __forceinline__ float celu(float x, float alpha, float inv_alpha)
     // nn/_core.py:163-167 : celu(x, 0.1) = max(0,x) + min(0, alpha (exp(x/alpha) - 1))
     return x > 0.f ? x : alpha * (__expf(x * inv_alpha) - 1.0f);
 }
+// torch.nn.GELU() (approximate = 'none'): x Phi(x); derivatives Phi + x phi and phi (2 - x^2)
+__device__ __forceinline__ float gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678f)); }
+// first and second derivative of the activation: CELU from the stored activation y (x > 0: (1, 0); else (y / alpha + 1,
+// that / alpha)), GELU from the stored pre-activation x
+__device__ __forceinline__ void act_derivs(int act, float y, float x, float inv_alpha, float &c1, float &c2)
+{
+    if (act == ANIHIP_ACT_GELU) {
+        const float ph = 0.5f * (1.0f + erff(x * 0.70710678f));
+        const float pd = 0.39894228f * __expf(-0.5f * x * x);
+        c1 = ph + x * pd;
+        c2 = pd * (2.0f - x * x);
+    } else {
+        c1 = y > 0.f ? 1.0f : y * inv_alpha + 1.0f;
+        c2 = y > 0.f ? 0.f : c1 * inv_alpha;
+    }
+}
 
 // K loop of one 128 x (32 NB) tile: register-prefetched global loads, double-buffered LDS, one
 // barrier per K step; NB is compile-time so the MFMA stream has no branches.
@@ -374,26 +396,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_gemm(GemmArgs g)
             if (row >= n_rows) continue;
             float v = acc[nb][r];
             if (EPI == EPI_BIAS_CELU) {
-                g.C[(int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col] =
-                    celu(v + bias, g.alpha, g.inv_alpha);
+                const int64_t ic = (int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col;
+                const float x = v + bias;
+                g.C[ic] = g.act == ANIHIP_ACT_GELU ? gelu(x) : celu(x, g.alpha, g.inv_alpha);
+                if (g.Xout) g.Xout[ic] = x;
             } else if (EPI == EPI_DCELU) {
-                // stored activation y = celu(x):  celu'(x) = 1 (y > 0)  or  exp(x/alpha) = y/alpha + 1
+                // stored activation y = celu(x):  celu'(x) = 1 (y > 0)  or  exp(x/alpha) = y/alpha + 1   (GELU: from x)
                 float *cp = g.C + (int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col;
-                const float y = g.Y ? g.Y[(int64_t)(p0 + row) * g.ldy + (int64_t)bb * pr.c_boff + col]
-                                    : __builtin_nontemporal_load(cp);
-                *cp = v * (y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f);
+                const int64_t iy = (int64_t)(p0 + row) * g.ldy + (int64_t)bb * pr.c_boff + col;
+                const float y = g.Y ? g.Y[iy] : __builtin_nontemporal_load(cp);
+                float c1, c2;
+                act_derivs(g.act, y, g.X ? g.X[iy] : 0.f, g.inv_alpha, c1, c2);
+                *cp = v * c1;
             } else if (EPI == EPI_TANGENT || EPI == EPI_ADJ_P || EPI == EPI_ADJ_Q) {
-                // celu'(x) and celu''(x) from the stored activation y: x > 0: (1, 0); else (y/alpha + 1, celu'/alpha)
+                // act'(x) and act''(x): CELU from the stored activation y, GELU from the stored pre-activation
                 const int64_t ic = (int64_t)(p0 + row) * g.ldc + (int64_t)bb * pr.c_boff + col;
                 const int64_t iy = (int64_t)(p0 + row) * g.ldy + (int64_t)bb * pr.c_boff + col;
-                const float y = g.Y[iy];
-                const float c1 = y > 0.f ? 1.0f : y * g.inv_alpha + 1.0f;
+                float c1, c2;
+                act_derivs(g.act, g.Y[iy], g.X ? g.X[iy] : 0.f, g.inv_alpha, c1, c2);
                 if (EPI == EPI_TANGENT) {
                     g.C[ic] = v;
                     g.C2[ic] = c1 * v;
                 } else if (EPI == EPI_ADJ_P) {
                     g.C[ic] = v * c1;
-                    g.C2[ic] = y > 0.f ? 0.f : v * c1 * g.inv_alpha * g.Z[iy];
+                    g.C2[ic] = v * c2 * g.Z[iy];
                 } else {
                     g.C[ic] += v * c1;
                 }
@@ -2693,6 +2719,8 @@ struct HeadArgs {
     int want_grad;
     unsigned *amax;   // f16x3: running max table (or NULL)
     int amax_out;
+    int act_kind;          // ANIHIP_ACT_*: GELU reads the derivative from the pre-activations
+    const float *zpre;     // [n][ld] pre-activations of the last hidden layer (GELU training passes)
 };
 
 __global__ __launch_bounds__(256) void k_head(HeadArgs h)
@@ -2724,7 +2752,9 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs h)
                 const float y = row[m * Hp + o];
                 part += y * w[o];
                 if (h.want_grad) {
-                    const float gq = up * w[o] * (y > 0.f ? 1.0f : y * h.inv_alpha + 1.0f);
+                    float c1, c2;
+                    act_derivs(h.act_kind, y, h.zpre ? h.zpre[p * h.ld + m * Hp + o] : 0.f, h.inv_alpha, c1, c2);
+                    const float gq = up * w[o] * c1;
                     srow[m * Hp + o] = gq;
                     gmax = fmaxf(gmax, fabsf(gq));
                 }
@@ -2910,6 +2940,8 @@ struct HeadTangentArgs {
     float *datomic_e;             // [n_atoms] or NULL
     int S, M;
     float inv_alpha;
+    int act_kind;
+    const float *zpre;            // pre-activations of the last hidden layer (GELU)
 };
 
 __global__ __launch_bounds__(256) void k_head_tangent(HeadTangentArgs h)
@@ -2928,10 +2960,11 @@ __global__ __launch_bounds__(256) void k_head_tangent(HeadTangentArgs h)
             for (int o = lane; o < Hp; o += WAVE) {
                 const int64_t idx = p * h.ld + m * Hp + o;
                 const float y = h.act[idx], zd = h.zd[idx];
-                const float c1 = y > 0.f ? 1.0f : y * h.inv_alpha + 1.0f;
+                float c1, c2;
+                act_derivs(h.act_kind, y, h.zpre ? h.zpre[idx] : 0.f, h.inv_alpha, c1, c2);
                 const float mu = invM * w[o];
                 h.P[idx] = mu * c1;
-                h.Q[idx] = y > 0.f ? 0.f : mu * c1 * h.inv_alpha * zd;
+                h.Q[idx] = mu * c2 * zd;
                 part += mu * h.ad[idx];
             }
         }
@@ -3066,6 +3099,7 @@ __global__ void k_negate(float *x, int64_t n)
 }
 
 struct MlpWorkspace {
+    float *zp[ANIHIP_MAX_LAYERS];   // training passes of GELU networks: pre-activations of the hidden layers (else NULL)
     int *ctl;
     unsigned *amax;
     float *member_part;
@@ -3110,11 +3144,28 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
     return off;
 }
 
+// pre-activation buffers of the hidden layers behind offset `off` (GELU training passes only; CELU: none)
+static size_t carve_zp(const anihip_mlp_desc *d, int64_t n, char *base, size_t off, MlpWorkspace *w)
+{
+    const int nh = d->net[0].n_layers - 1;
+    for (int l = 0; l < ANIHIP_MAX_LAYERS; ++l)
+        if (w) w->zp[l] = nullptr;
+    if (d->activation != ANIHIP_ACT_GELU) return off;
+    for (int l = 0; l < nh; ++l) {
+        int mx = 0;
+        for (int s = 0; s < d->num_species; ++s) mx = mx > d->net[s].dims[l + 1] ? mx : d->net[s].dims[l + 1];
+        if (w) w->zp[l] = base ? (float *)(base + off) : nullptr;
+        off += align256(sizeof(float) * (size_t)mx * d->n_members * (size_t)(n + 1));
+    }
+    return off;
+}
+
 // training pass: the inference workspace + one gradient buffer per hidden layer (the activations are kept)
 static size_t mlp_train_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWorkspace *w,
                               float **dlt /* [ANIHIP_MAX_LAYERS] */)
 {
     size_t off = align256(mlp_carve(d, n, base, w));
+    off = carve_zp(d, n, base, off, w);
     const int nh = d->net[0].n_layers - 1;
     for (int l = 0; l < nh; ++l) {
         int mx = 0;
@@ -3131,6 +3182,7 @@ static size_t mlp_tangent_carve(const anihip_mlp_desc *d, int64_t n, char *base,
                                 float *(*buf)[ANIHIP_MAX_LAYERS] /* [4] */)
 {
     size_t off = align256(mlp_carve(d, n, base, w));
+    off = carve_zp(d, n, base, off, w);
     const int nh = d->net[0].n_layers - 1;
     for (int k = 0; k < 4; ++k)
         for (int l = 0; l < nh; ++l) {
@@ -3648,6 +3700,7 @@ static int train_forward(hipStream_t stream, const anihip_mlp_desc *d, int64_t n
         g.nrow_tiles_ub = (int)((n + BM - 1) / BM) + S;
         g.amax_in = g.amax_out = -1;
         g.C = w.act[l]; g.ldc = w.ld[l];
+        g.act = d->activation; g.Xout = w.zp[l];
         int wmax = 0;
         for (int s = 0; s < S; ++s) wmax = wmax > d->net[s].dims[l + 1] ? wmax : d->net[s].dims[l + 1];
         if (l == 0) {
@@ -3688,6 +3741,7 @@ static void train_head(hipStream_t stream, const anihip_mlp_desc *d, int64_t n_a
     h.seed = seed; h.g_atom = g_atom;
     h.atomic_e = atomic_e; h.member_e = nullptr; h.n_atoms = n_atoms; h.S = S; h.M = d->n_members;
     h.inv_alpha = 1.0f / d->celu_alpha; h.want_grad = seed ? 1 : 0; h.amax = nullptr; h.amax_out = 0;
+    h.act_kind = d->activation; h.zpre = w.zp[nh - 1];
     int64_t blocks = (n + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(k_head, dim3((unsigned)blocks), dim3(256), 0, stream, h);
@@ -3699,7 +3753,6 @@ extern "C" int anihip_mlp_train_forward(void *stream_, const anihip_mlp_desc *d,
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
-    ANIHIP_REQUIRE(d->activation == ANIHIP_ACT_CELU, "the training passes implement CELU networks only");
     ANIHIP_REQUIRE(species && aev && workspace && atomic_e, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     const int64_t n = hi - lo;
@@ -3758,7 +3811,6 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
-    ANIHIP_REQUIRE(d->activation == ANIHIP_ACT_CELU, "the training passes implement CELU networks only");
     ANIHIP_REQUIRE(species && aev && grad_atomic_e && workspace && grads && atomic_e, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1, L = d->aev_len;
@@ -3799,6 +3851,7 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
         GemmArgs g{};
         g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha; g.nrow_tiles_ub = nrow_ub;
         g.amax_in = g.amax_out = -1;
+        g.act = d->activation;
         return g;
     };
 
@@ -3859,6 +3912,7 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
             g.ncol_max = (((L + 31) / 32) * 32 + BN - 1) / BN;
         } else {
             g.batch = M; g.C = dlt[l - 1]; g.ldc = w.ld[l - 1]; g.Y = w.act[l - 1]; g.ldy = w.ld[l - 1];
+            g.X = w.zp[l - 1];
             g.ncol_max = (width_max(l) + BN - 1) / BN;
         }
         for (int s = 0; s < S; ++s) {
@@ -3895,7 +3949,6 @@ extern "C" int anihip_mlp_tangent_weight_grads(void *stream_, const anihip_mlp_d
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
-    ANIHIP_REQUIRE(d->activation == ANIHIP_ACT_CELU, "the training passes implement CELU networks only");
     ANIHIP_REQUIRE(species && aev && tangent && workspace && grads && datomic_e, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1, L = d->aev_len;
@@ -3930,12 +3983,13 @@ extern "C" int anihip_mlp_tangent_weight_grads(void *stream_, const anihip_mlp_d
         GemmArgs g{};
         g.ctl = w.ctl; g.S = S; g.alpha = alpha; g.inv_alpha = inv_alpha; g.nrow_tiles_ub = nrow_ub;
         g.amax_in = g.amax_out = -1;
+        g.act = d->activation;
         return g;
     };
     // 2. tangents: zdot_l = W_l adot_{l-1}, adot_l = c'(z_l) zdot_l   (adot_0 = tangent rows)
     for (int l = 0; l < nh; ++l) {
         GemmArgs g = gemm_base();
-        g.C = zd[l]; g.C2 = ad[l]; g.ldc = w.ld[l]; g.Y = w.act[l]; g.ldy = w.ld[l];
+        g.C = zd[l]; g.C2 = ad[l]; g.ldc = w.ld[l]; g.Y = w.act[l]; g.ldy = w.ld[l]; g.X = w.zp[l];
         if (l == 0) {
             g.A = tangent; g.lda = L; g.a_gather = w.perm; g.batch = 1;
             g.ncol_max = (width_max(1) * M + BN - 1) / BN;
@@ -3963,7 +4017,7 @@ extern "C" int anihip_mlp_tangent_weight_grads(void *stream_, const anihip_mlp_d
         for (int s = 0; s < S; ++s) { h.w[s] = d->net[s].w[nl - 1]; h.Hp[s] = d->net[s].dims[nl - 1]; }
         h.ctl = w.ctl; h.perm = w.perm; h.act = w.act[nh - 1]; h.zd = zd[nh - 1]; h.ad = ad[nh - 1];
         h.P = P[nh - 1]; h.Q = Q[nh - 1]; h.ld = w.ld[nh - 1]; h.datomic_e = datomic_e; h.S = S; h.M = M;
-        h.inv_alpha = inv_alpha;
+        h.inv_alpha = inv_alpha; h.act_kind = d->activation; h.zpre = w.zp[nh - 1];
         int64_t blocks = (n + 3) / 4;
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(k_head_tangent, dim3((unsigned)blocks), dim3(256), 0, stream, h);
@@ -4020,7 +4074,7 @@ extern "C" int anihip_mlp_tangent_weight_grads(void *stream_, const anihip_mlp_d
             GemmArgs g = gemm_base();
             g.A = pass == 0 ? P[l] : Q[l]; g.lda = w.ld[l]; g.batch = M;
             g.C = pass == 0 ? P[l - 1] : Q[l - 1]; g.C2 = Q[l - 1]; g.ldc = w.ld[l - 1];
-            g.Y = w.act[l - 1]; g.Z = zd[l - 1]; g.ldy = w.ld[l - 1];
+            g.Y = w.act[l - 1]; g.Z = zd[l - 1]; g.ldy = w.ld[l - 1]; g.X = w.zp[l - 1];
             g.ncol_max = (width_max(l) + BN - 1) / BN;
             for (int s = 0; s < S; ++s) {
                 const anihip_species_net &nn = d->net[s];

@@ -470,8 +470,9 @@ class PackedNetworks:
             raise ValueError(f"unknown MLP precision {precision!r}")
         if activation not in ("celu", "gelu"):
             raise ValueError(f"unknown activation {activation!r}: the network kernels have celu and gelu")
-        if activation == "gelu" and precision != "f16x3":
-            raise ValueError("GELU networks run through the fused f16x3 network kernel only")
+        # (GELU: inference runs through the fused f16x3 kernel only -- anihip_mlp_forward_backward refuses an fp32 GELU pack --;
+        # an fp32 GELU pack serves the TRAINING passes, which keep the pre-activations: train_forward, weight_grads,
+        # tangent_weight_grads)
         self.precision = precision
         self.activation = activation
         M, S = len(weights), len(weights[0])

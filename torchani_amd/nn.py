@@ -58,6 +58,21 @@ class AtomicNetwork(torch.nn.Module):
 _TRAIN_SPLIT_MAX_ATOMS = 1 << 17
 
 
+def _flat_param_grads(packed: PackedNetworks, gw, gb) -> tp.List[Tensor]:
+    """The engine's gradients in the order of the parameters handed to the Functions: member -> species -> layer ->
+    (weight, bias), without the biases a bias-free network does not have."""
+    has_bias = getattr(packed, "has_bias", None)
+    flat, k = [], 0
+    for m in range(packed.M):
+        for s in range(packed.S):
+            for l in range(packed.nl):
+                flat.append(gw[m][s][l])
+                if has_bias is None or has_bias[k]:
+                    flat.append(gb[m][s][l])
+                k += 1
+    return flat
+
+
 class _MLPBackwardFunction(torch.autograd.Function):
     """(grad_out, params) -> grad_aev = grad_out * d e / d aev as a differentiable function of the parameters (and of
     grad_out): what torch builds under create_graph=True for the eager networks of the reference.  Its backward for
@@ -67,7 +82,8 @@ class _MLPBackwardFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, grad_out: Tensor, a32: Tensor, species32: Tensor, packed: PackedNetworks, shape,
                 *params: Tensor) -> Tensor:
-        _, g_unit, _ = packed.forward_backward(species32, a32, want_grad=True)
+        infer = getattr(packed, "infer_pack", None)
+        _, g_unit, _ = (infer() if infer is not None else packed).forward_backward(species32, a32, want_grad=True)
         go = grad_out.detach().to(torch.float32).reshape(-1, 1)
         ctx.saved = (a32, species32, packed, g_unit, go)
         ctx.shape, ctx.go_shape, ctx.go_dtype = shape, grad_out.shape, grad_out.dtype
@@ -81,11 +97,7 @@ class _MLPBackwardFunction(torch.autograd.Function):
         v32 = v.to(torch.float32).reshape(g_unit.shape)
         d_go = (v32 * g_unit).sum(dim=-1).view(ctx.go_shape).to(ctx.go_dtype)
         gw, gb, _ = packed.tangent_weight_grads(species32, a32, (v32 * go).contiguous())
-        flat = []
-        for m in range(packed.M):
-            for s in range(packed.S):
-                for l in range(packed.nl):
-                    flat += [gw[m][s][l], gb[m][s][l]]
+        flat = _flat_param_grads(packed, gw, gb)
         flat = [t.to(dt) for t, dt in zip(flat, ctx.param_dtypes)]
         return (d_go, None, None, None, None, *flat)
 
@@ -148,11 +160,7 @@ class _MLPFunction(torch.autograd.Function):
                                                   want_grad_aev=ctx.aev_grad and not second_order, workspace=ws)
             if second_order:
                 gaev = _MLPBackwardFunction.apply(grad_out, a32, species32, packed, ctx.shape, *ctx.params)
-            flat = []
-            for m in range(packed.M):
-                for s in range(packed.S):
-                    for l in range(packed.nl):
-                        flat += [gw[m][s][l], gb[m][s][l]]
+            flat = _flat_param_grads(packed, gw, gb)
             flat = [t.to(dt) for t, dt in zip(flat, ctx.param_dtypes)]
             ga = gaev.view(ctx.shape).to(ctx.in_dtype) if gaev is not None else None
             return (ga, None, None, None, *flat)
@@ -252,20 +260,30 @@ class _EngineContainer(torch.nn.Module):
         """fp32 pack read by the training pass; built once per parameter set and refreshed in place (one kernel,
         anihip_mlp_repack) whenever an optimizer step changed the parameters."""
         members = self._member_networks()
-        if any(getattr(m.atomics[s], "activation_name", "celu") != "celu" or not m.atomics[s].has_biases
-               for m in members for s in self.symbols):
-            raise NotImplementedError("the training passes implement CELU networks with biases (ANI-1x / 2x)")
+        acts = {getattr(m.atomics[s], "activation_name", "celu") for m in members for s in self.symbols}
+        if len(acts) != 1:
+            raise ValueError(f"all atomic networks of a container must share one activation, got {sorted(acts)}")
         lins = [[m.atomics[s].linears() for s in self.symbols] for m in members]
         weights = [[[lin.weight for lin in sl] for sl in ml] for ml in lins]
-        biases = [[[lin.bias for lin in sl] for sl in ml] for ml in lins]
-        params = [p for ml in lins for sl in ml for lin in sl for p in (lin.weight, lin.bias)]
+        # (bias-free networks -- the GELU networks of the ANI-2xr family, nn/_core.py:122 -- train against zero biases that
+        # live as long as the pack: the engine's passes return their "gradients", which nobody receives)
+        zeros = self.__dict__.setdefault("_zero_biases", {})
+
+        def zero_bias(lin):
+            k = (id(lin), device)
+            if k not in zeros or zeros[k].shape[0] != lin.weight.shape[0]:
+                zeros[k] = torch.zeros(lin.weight.shape[0], dtype=torch.float32, device=device)
+            return zeros[k]
+
+        biases = [[[lin.bias if lin.bias is not None else zero_bias(lin) for lin in sl] for sl in ml] for ml in lins]
+        params = [p for ml in lins for sl in ml for lin in sl for p in (lin.weight, lin.bias) if p is not None]
         key = (device, tuple(p.data_ptr() for p in params), tuple(tuple(p.shape) for p in params))
         versions = tuple(p._version for p in params)
         cache = self.__dict__.setdefault("_train_cache", {})
         if key not in cache:
             cache.clear()
             aev_len = weights[0][0][0].shape[1]
-            cache[key] = [PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, "fp32"), versions]
+            cache[key] = [PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, "fp32", activation=acts.pop()), versions]
         elif cache[key][1] != versions:
             cache[key][0].refresh(weights, biases)
             cache[key][1] = versions
@@ -279,13 +297,18 @@ class _EngineContainer(torch.nn.Module):
         if torch.is_grad_enabled():
             lins = [lin for m in self._member_networks() for s in self.symbols for lin in m.atomics[s].linears()]
             if any(p.requires_grad for lin in lins for p in (lin.weight, lin.bias) if p is not None):
-                if any(lin.bias is None for lin in lins):
-                    raise NotImplementedError("the training passes implement CELU networks with biases (ANI-1x / 2x)")
-                params = [p for lin in lins for p in (lin.weight, lin.bias)]
+                params = [p for lin in lins for p in (lin.weight, lin.bias) if p is not None]
         trainable_fast = (params and not ensemble_values
                           and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == aevs.device
                                   for p in params))
         packed = self._train_pack(aevs.device) if trainable_fast else self._pack(aevs.device)
+        # which (weight, bias) slots of the engine's member -> species -> layer order have a parameter behind them
+        packed.has_bias = [lin.bias is not None for m in self._member_networks() for s in self.symbols
+                           for lin in m.atomics[s].linears()]
+        if trainable_fast and packed.activation == "gelu":
+            # (the input gradient that force training differentiates once more comes from the inference pack: an fp32 GELU
+            # pack only serves the training passes)
+            packed.infer_pack = lambda: self._pack(aevs.device)
         if ensemble_values and aevs.requires_grad and not params:
             # differentiable member energies (nn/_containers.py:638-651 is plain autograd in the reference): the backward
             # needs every member's own d e_m / d aev, i.e. one single-member pass each
