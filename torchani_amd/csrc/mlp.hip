@@ -2505,10 +2505,12 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             // fragment crosses the CU's 64 B/clk L2 port once and feeds six MFMAs).  The two partial tiles meet in LDS (X1's
             // place, dead since phase 4): a wave hands over the row block it does not own and finishes the other --
             // w: rows 0..31, w + 4: rows 32..63 -- with the read-add-write on the AEV gradient rows.
-            // (first half: 6 steps when there are 12 or more -- a ring's depth, so that wave issues no repeated request)
-            const int KS5 = H1 >> 4, KH0 = KS5 >= 12 ? 6 : (KS5 >> 2) << 1;
+            // (one of the two gets 6 steps when there are 12 or more -- a ring's depth, so that wave issues no repeated request;
+            // it is wave w + 4, which the SIMD's arbiter lets through the phases before this one ~1.5 k clocks behind wave w:
+            // the shorter share evens the two out at the hand-over)
+            const int KS5 = H1 >> 4, KH1 = KS5 >= 12 ? 6 : KS5 - ((KS5 >> 2) << 1);
             const int half = wave >> 2;
-            const int kbeg = half ? KH0 : 0, KH = half ? KS5 - KH0 : KH0;   // (both even)
+            const int kbeg = half ? KS5 - KH1 : 0, KH = half ? KH1 : KS5 - KH1;   // (both even)
             const int64_t mh5 = (int64_t)g.n_slabs * KS5 * (2 * FRAG);
             auto nth_slab = [&](int c) {   // c-th flagged slab of the tile (scalar), -1 past the end
                 uint32_t mk = tmask_cur;
