@@ -1487,6 +1487,10 @@ __global__ __launch_bounds__(L0B_THREADS, 2) void k_gemm_l0b(GemmArgs g)
 //           (VALU) of one overlap the GEMM phases (matrix pipe) of the other, at twice the L2 weight traffic.
 constexpr int FR_MAXH = 256;      // largest padded hidden width (8 column blocks)
 constexpr int64_t FUSED_L0B_MIN_ATOMS = 65536;   // layer-0 backward inside the fused kernel from this many atoms on
+#ifndef ANIHIP_OWNER_GROUP
+#define ANIHIP_OWNER_GROUP 1
+#endif
+constexpr int FUSED_OWNER_GROUP = ANIHIP_OWNER_GROUP;   // tiles a workgroup takes through the members together (owner order)
 constexpr int FRAG = 512;         // halves per fragment plane: 64 lanes x 8
 constexpr int FR_SLAB_LD = 40;    // halves per staged slab row (32 + 8: conflict-free ds_read_b128)
 constexpr int FR_GROUP = 3;       // slabs per staging slot
@@ -1542,7 +1546,7 @@ struct FusedArgs {
     int want_grad;
     int l0b;                   // layer-0 backward inside the kernel (needs owner = 1): d E / d AEV -> grad_aev, no d0
     float *grad_aev;           // [n_atoms][L] (l0b): the tile's flagged slabs of its atoms' rows, summed over the members
-    int owner;                 // item order: 0 = member-major sweep over the tiles; 1 = a workgroup OWNS a tile through all members
+    int owner;                 // item order: 0 = member-major sweep over the tiles; G > 0: a workgroup OWNS its tiles, taken in groups of G
     unsigned long long *trace;   // development builds (-DANIHIP_DEV_TRACE, tools/fused_trace.py): [item][wave][32] stamps
 };
 // phase stamps of the fused kernel: compiled out of the shipped library
@@ -2076,7 +2080,16 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     __syncthreads();
     // (member, tile) of the item, advanced by gridDim.x tiles per step without divisions
     int mem = item / n_tiles, tile = item - mem * n_tiles;
-    if (g.owner) { mem = 0; tile = item; item = tile * g.M; }
+    // owner order: the workgroup's tiles b, b + grid, ... can be taken in GROUPS of g.owner of them -- member after member
+    // over the tiles of a group -- so that a member's weights enter the XCD's L2 once per group and member instead of once
+    // per tile and member.  Measured at the headline size (groups of 1 / 2 / 4 / 8): the same time (30.2-30.6 ms), and with
+    // groups of 4 MORE counted fetches, 14.0 instead of 12.2 GB per launch -- the tile's AEV slabs and d E/d AEV rows
+    // come back after four items instead of one and find less of themselves in L2.  Default: groups of one tile.
+    int gj = 0, gsz = 1;   // position inside the group, tiles of the group
+    if (g.owner) {
+        mem = 0; tile = item; item = tile * g.M;
+        gsz = min(g.owner, (n_tiles - 1 - tile) / (int)gridDim.x + 1);
+    }
     typedef WRing<NB, D> Ring0;
     Ring0 rg;                  // layer-0 weight ring of the item being started
     uint32_t rem_w = 0u;       // k steps of the layer-0 weight ring not yet requested
@@ -2132,9 +2145,18 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // stay unconditional)
         int mem_n = mem, tile_n = tile + (int)gridDim.x;
         bool has_next;
-        if (g.owner) {   // the same tile's next member, then the next tile of this workgroup
-            mem_n = mem + 1; tile_n = tile;
-            if (mem_n >= Mi) { mem_n = 0; tile_n = tile + (int)gridDim.x; }
+        int gj_n = gj, gsz_n = gsz;
+        if (g.owner) {   // the group's next tile, then the group's first tile with the next member, then the next group
+            mem_n = mem; tile_n = tile + (int)gridDim.x; gj_n = gj + 1;
+            if (gj_n >= gsz) {
+                gj_n = 0;
+                if (mem + 1 < Mi) {
+                    mem_n = mem + 1; tile_n = tile - (gsz - 1) * (int)gridDim.x;
+                } else {
+                    mem_n = 0;   // (tile_n is the first tile behind the group)
+                    gsz_n = min(g.owner, (n_tiles - 1 - tile_n) / (int)gridDim.x + 1);
+                }
+            }
             has_next = tile_n < n_tiles;
         } else {
             while (tile_n >= n_tiles) { tile_n -= n_tiles; ++mem_n; }
@@ -2675,6 +2697,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         te = te_n;
         mem = mem_n;
         tile = tile_n;
+        gj = gj_n; gsz = gsz_n;
         item = g.owner ? tile * Mi + mem : mem * n_tiles + tile;
     }
 }
@@ -3519,7 +3542,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         f.owner = (d->flags & ANIHIP_MLP_FLAG_TILE_OWNER) ? 1 : 0;
         f.l0b = fused_l0b ? 1 : 0;
         f.grad_aev = grad_aev;
-        if (fused_l0b) { f.owner = 1; f.d0 = nullptr; }
+        if (fused_l0b) { f.owner = FUSED_OWNER_GROUP; f.d0 = nullptr; }
         const bool gelu = d->activation == ANIHIP_ACT_GELU;
         const void *kfn = rows == 64 ? (fused_l0b ? (gelu ? (const void *)k_mlp_fused<2, 1, 1, true> : (const void *)k_mlp_fused<2, 1, 0, true>)
                                                   : (gelu ? (const void *)k_mlp_fused<2, 1, 1, false> : (const void *)k_mlp_fused<2, 1, 0, false>))
