@@ -349,7 +349,11 @@ def main():
                     for k, v in pm["kernels"].items()}
         aev_traffic, bwd_traffic = per_atom["k_aev_fwd3"] * n_shard, per_atom["k_aev_bwd"] * n_shard
         # (the network stage: every kernel of it that the counter file knows, per atom of a launch)
-        mlp_traffic = sum(per_atom.get(k, 0.0) for k in ("k_mlp_fused", "k_gemm_l0b", "k_gemm_h2")) * n_shard
+        # (the counter file holds means per DISPATCH; the network kernels run once per launch group: dispatches per step =
+        # their dispatch count over that of a kernel that runs once per step)
+        once = max(1, pm["kernels"]["k_aev_bwd"].get("dispatches_FETCH_SIZE", 1))
+        mlp_traffic = sum(per_atom.get(k, 0.0) * pm["kernels"][k].get("dispatches_FETCH_SIZE", once) / once
+                          for k in ("k_mlp_fused", "k_gemm_l0b", "k_gemm_h2") if k in pm["kernels"]) * n_shard
     # layer 0 multiplies only the 32-column AEV slabs flagged for an atom (absent neighbor species give
     # identically-zero blocks): executed flops = dense flops with the AEV length replaced by the staged columns
     pop = mask[lo:hi].to(torch.int64) & 0xFFFFFFFF

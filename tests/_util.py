@@ -12,7 +12,7 @@ from torchani_amd.weights import random_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN_NAMES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                      if not os.path.basename(p).startswith(("nbrs_", "wgrads_", "stress_", "fgrads_", "cfg3_", "pairs_", "pairs2_", "d3_", "x2r_", "mbis_", "simple_", "hess_", "grid_")))   # reference neighbor lists /
+                      if not os.path.basename(p).startswith(("nbrs_", "wgrads_", "stress_", "fgrads_", "cfg3_", "pairs_", "pairs2_", "d3_", "x2r_", "x2rtrain_", "mbis_", "simple_", "hess_", "grid_")))   # reference neighbor lists /
 #                                                                                      weight-gradient digests
 WGRAD_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "wgrads_*.npz")))
 STRESS_NAMES = sorted(os.path.basename(p)[7:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "stress_*.npz")))
