@@ -1510,7 +1510,11 @@ struct FusedCfg {
     // fixed part of the dynamic LDS: [0] tile max | per-species {tile-major base of d0, first sorted position} |
     // energy partials [NW][ROWS] | staging slot 0
     static constexpr int FIXED_BYTES = 16 + 128 + NW * ROWS * 4 + 2 * ROWS * 4;   // ... | atoms of the tile rows [2][ROWS]
-    static constexpr int FIXED_HALVES = FIXED_BYTES / 2 + FR_GROUP * SLAB;
+    // slot 0 doubles as the home of a tile's KEPT layer-0 operand (owner order, tiles with <= 4 flagged slabs): four slabs,
+    // {hi, lo} planes, unpadded 64-byte rows whose 16-byte pieces are XOR-swizzled with (row >> 2) & 3
+    static constexpr int KEEP_SLABS = 4, SLABU = 2 * ROWS * 32;
+    static constexpr int SLOT0 = FR_GROUP * SLAB > KEEP_SLABS * SLABU ? FR_GROUP * SLAB : KEEP_SLABS * SLABU;
+    static constexpr int FIXED_HALVES = FIXED_BYTES / 2 + SLOT0;
     static_assert(THREADS == ROWS * 8, "one 16-B staging piece per thread");
 };
 
@@ -1714,13 +1718,17 @@ __device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *
 // the tile's steps are used up); a tile with at most FOUR flagged slabs -- every tile of a water box -- has 8 steps, 6 of
 // them in the ring when the loop starts: the short form walks 8 steps and requests 2 (the repeats it leaves out were 20 KB
 // per wave and item through the CU's 64 B/clk return path)
-template <int RB, int NB, int RBA, int NBA, int D, int ROWS, int STEPS, int REQS, class NextKs>
+// KEPT: the operand is the tile's kept copy (FusedCfg::SLABU layout: unpadded rows, swizzled pieces) -- s0 / s1 = this
+// lane's fragment address for the even / odd k step of slab 0
+template <int RB, int NB, int RBA, int NBA, int D, int ROWS, int STEPS, int REQS, bool KEPT = false, class NextKs>
 __device__ __forceinline__ void fr_l0_pair(f32x16 (&acc)[RB * NB], WRing<NB, D> &rg, const _Float16 *s0,
                                            const _Float16 *s1, int n_live, NextKs &&next_ks)
 {
     static_assert(STEPS % 2 == 0 && STEPS <= 4 * FR_GROUP && REQS % 2 == 0 && REQS <= STEPS && STEPS <= D + REQS, "ring coverage");
-    constexpr int SLAB = 2 * ROWS * FR_SLAB_LD, PL = ROWS * FR_SLAB_LD, RBS = 32 * FR_SLAB_LD;
+    constexpr int SLAB = KEPT ? 2 * ROWS * 32 : 2 * ROWS * FR_SLAB_LD, PL = KEPT ? ROWS * 32 : ROWS * FR_SLAB_LD,
+                  RBS = KEPT ? 32 * 32 : 32 * FR_SLAB_LD;
     auto addr = [&](int st) {
+        if (KEPT) return ((st & 1) ? s1 : s0) + (st / 2) * SLAB;
         return (st / (2 * FR_GROUP) ? s1 : s0) + ((st / 2) % FR_GROUP) * SLAB + (st & 1) * 16;
     };
     AFrag<RBA> xe, xo;
@@ -2060,6 +2068,24 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         }
     };
 
+    // the same into the tile's KEPT copy (C::SLABU layout), slabs base .. base + 2 of the tile's first KEEP_SLABS
+    auto store_kept = [&](const v4f (&v)[FR_GROUP], int base) {
+#pragma unroll
+        for (int j = 0; j < FR_GROUP; ++j) {
+            if (base + j >= C::KEEP_SLABS) continue;
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 h = (_Float16)(v[j][e] * 4.0f);
+                hi[e] = h;
+                lo[e] = (_Float16)__builtin_fmaf(v[j][e], 4.0f, -(float)h);
+            }
+            _Float16 *d = slot0 + (base + j) * C::SLABU + srow * 32 + ((((spc >> 1) ^ (srow >> 2)) & 3) << 3) + (spc & 1) * 4;
+            *reinterpret_cast<h4 *>(d) = hi;
+            *reinterpret_cast<h4 *>(d + ROWS * 32) = lo;
+        }
+    };
+
     // ---- persistent workgroups: item = blockIdx.x, + gridDim.x, ... (member-major order: at any time the chip
     // works on one or two members, whose weights stay resident in every XCD's L2).  The dependent chain at the
     // head of an item (tile entry -> atom rows -> AEV slabs -> first weight fragments, about 9 k clocks of pure
@@ -2110,6 +2136,15 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         fetch_group(va);
         fetch_group(vb);
     };
+    // (an item that needs no slabs still DEFINES the registers: a path that leaves them undefined would carry the previous
+    // item's values around the item loop and hold 24 VGPRs through every phase)
+    auto no_aev = [&]() {
+#pragma unroll
+        for (int j = 0; j < FR_GROUP; ++j) {
+            va[j] = v4f{0.f, 0.f, 0.f, 0.f};
+            vb[j] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    };
     // first D weight fragments of layer 0 of an item
     auto prefetch_w0 = [&](const int4 &t, int m) {
         const int s = t.x;
@@ -2128,6 +2163,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         rg.nb_stride = (int64_t)NW * KS0 * (2 * FRAG);
     };
     int4 te = g.tile_tab[tile];
+    int staged_tile = -1;   // the tile whose layer-0 operand slot 0 keeps (L0B, <= KEEP_SLABS flagged slabs), or -1
     int par = 0;   // which half of s_orow holds the current item's rows
     {
         const int atom0 = g.tile_rows[(size_t)tile * ROWS + srow];
@@ -2263,8 +2299,22 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const int npair = (nact + 2 * FR_GROUP - 1) / (2 * FR_GROUP);
         // (AEV slabs 0..5 and the first D weight fragments were requested during the previous item)
         zero_acc();
-        store_group(va, slot(0));
-        store_group(vb, slot(1));
+        // Owner order (L0B) with at most KEEP_SLABS flagged slabs -- every tile of a water box: the split planes of the tile's
+        // AEV slabs are the same for all eight members, so they are staged ONCE, into slot 0 in an unpadded swizzled layout
+        // (four slabs in the place of three padded ones), and the items of the other members neither fetch nor convert
+        // nor store them again (3.6 KB per atom of fetches and ~1 k clocks per item)
+        const bool keep = L0B && nact <= C::KEEP_SLABS;
+        if (keep) {
+            if (staged_tile != tile) {
+                store_kept(va, 0);
+                store_kept(vb, FR_GROUP);
+                staged_tile = tile;
+            }
+        } else {
+            store_group(va, slot(0));
+            store_group(vb, slot(1));
+            staged_tile = -1;
+        }
         if (tid == 0) s_max = 0u;
         __syncthreads();   // slots 0 / 1 published
         ANIHIP_STAMP(trace, 2);
@@ -2280,7 +2330,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 const int lo_ = (u1.rb0 * 32 + fr) * FR_SLAB_LD + fk * 8;   // this lane's fragment inside a staged slab
                 const _Float16 *s0 = slot(2 * (pr & 1)) + lo_, *s1 = slot(2 * (pr & 1) + 1) + lo_;
                 const int n_live = nact - 2 * FR_GROUP * pr;
-                if (nact <= 4) {   // (wave-uniform)
+                if (keep) {   // (wave-uniform) the kept copy: this lane's pieces for the even / odd k step of a slab
+                    const int rowk = u1.rb0 * 32 + fr, sw = (rowk >> 2) & 3;
+                    const _Float16 *k0 = slot0 + rowk * 32 + ((fk ^ sw) << 3), *k1 = slot0 + rowk * 32 + (((2 + fk) ^ sw) << 3);
+                    FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS, 8, 2, true>(acc, rg, k0, k1, n_live, next_ks)))
+                } else if (nact <= 4) {   // (wave-uniform)
                     FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS, 8, 2>(acc, rg, s0, s1, n_live, next_ks)))
                 } else {
                     FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS, 4 * FR_GROUP, 4 * FR_GROUP>(acc, rg, s0, s1, n_live, next_ks)))
@@ -2575,7 +2629,8 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     orow[p4] = g.grad_aev + (int64_t)s_orow[par * ROWS + row] * g.L + 4 * piece;
                     rok[p4] = row < n_rows;    // (short tiles repeat their last atom: one writer per row only)
                 }
-                v4f *xch = reinterpret_cast<v4f *>(slot0);   // [wave][q][lane]: partial sums handed to the partner wave (slot 0 | X1)
+                v4f *xch = reinterpret_cast<v4f *>(X1);   // [wave][q][lane]: partial sums handed to the partner wave (X1's place:
+                                                          // 32 KB, dead since phase 4; slot 0 keeps the tile's layer-0 operand)
                 // this wave's finished tile, 32 rows x 32 floats: in the PARTNER's hand-over block, which only this wave reads
                 // (d act0 in XU must stay whole for the further passes of tiles with more than four flagged slabs); the
                 // 16-byte pieces of a row are XOR-swizzled with row >> 1, conflict-free for the MFMA-layout writes and the
@@ -2609,7 +2664,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     if constexpr (LAST) {
                         // the next item's AEV slabs: behind the last ring request of this item (loads return in order: a
                         // miss to HBM ahead of a ring request would stall the MFMA loop), ahead of the hand-over and the stores
-                        prefetch_aev(te_n, atom_n);
+                        // (not when the next item is another member of this tile and the tile's operand is kept in LDS)
+                        if (!(tile_n == tile && keep)) prefetch_aev(te_n, atom_n);
+                        else no_aev();
                     } else {
                         ring5(max(slab_n, 0));
                     }
@@ -2648,7 +2705,8 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 for (; c0 + 4 < nact; c0 += 4) pass(c0, std::false_type{});
                 pass(c0, std::true_type{});
             } else {
-                prefetch_aev(te_n, atom_n);
+                if (!(tile_n == tile && keep)) prefetch_aev(te_n, atom_n);
+                else no_aev();
             }
             ANIHIP_STAMP(trace, 8);
             if (spc == 0) s_orow[(par ^ 1) * ROWS + srow] = atom_n;
@@ -3526,7 +3584,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             size_t halves = 2 * (size_t)rows * (fs.H2 + 8) + 2 * (size_t)rows * (xu + 8);
             const size_t slab = 2 * (size_t)rows * FR_SLAB_LD;
             if (halves < 3 * FR_GROUP * slab) halves = 3 * FR_GROUP * slab;   // staging slots 1..3
-            halves += (rows == 64 ? FusedCfg<2, 1>::FIXED_BYTES : FusedCfg<1, 2>::FIXED_BYTES) / 2 + FR_GROUP * slab;   // = FIXED_HALVES
+            halves += rows == 64 ? FusedCfg<2, 1>::FIXED_HALVES : FusedCfg<1, 2>::FIXED_HALVES;
             lds = lds > halves * 2 ? lds : halves * 2;
         }
         f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = n_slabs;
