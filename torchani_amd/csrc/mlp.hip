@@ -2103,6 +2103,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         s_tmb[t_] = b;
         s_off[t_] = t_ < g.S ? g.ctl[CTL_OFF + t_] : 0;
     }
+    if (threadIdx.x == 0) s_max = 0u;   // (tile maximum: reset again by every item once it has been read)
     __syncthreads();
     // (member, tile) of the item, advanced by gridDim.x tiles per step without divisions
     int mem = item / n_tiles, tile = item - mem * n_tiles;
@@ -2304,8 +2305,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // (four slabs in the place of three padded ones), and the items of the other members neither fetch nor convert
         // nor store them again (3.6 KB per atom of fetches and ~1 k clocks per item)
         const bool keep = L0B && nact <= C::KEEP_SLABS;
+        bool staged = true;
         if (keep) {
-            if (staged_tile != tile) {
+            staged = staged_tile != tile;
+            if (staged) {
                 store_kept(va, 0);
                 store_kept(vb, FR_GROUP);
                 staged_tile = tile;
@@ -2315,8 +2318,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             store_group(vb, slot(1));
             staged_tile = -1;
         }
-        if (tid == 0) s_max = 0u;
-        __syncthreads();   // slots 0 / 1 published
+        // (s_max is reset behind the barrier that follows its last read, below; an item that staged nothing has nothing to
+        // publish either: the barrier at the end of the previous item already separates the two)
+        if (staged) __syncthreads();   // slots 0 / 1 published
         ANIHIP_STAMP(trace, 2);
         // six slabs (two staging slots, 12 k steps) per barrier; the next six are fetched into registers
         // before the MFMAs of the current ones and staged after them
@@ -2411,6 +2415,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const float s2 = pow2_scale_for(bnd[2]);                                  // |d act2| <= max |w3| / M
         const float s3 = pow2_scale_for(bnd[3]);                                  // |d act1| <= [2] ||W2||_1
         __syncthreads();
+        if (tid == 0) s_max = 0u;   // (every thread has read the tile maximum; the next item's atomics are many barriers away)
         ANIHIP_STAMP(trace, 4);
 
         // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
