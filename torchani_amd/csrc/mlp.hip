@@ -2715,8 +2715,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             }
             ANIHIP_STAMP(trace, 8);
             if (spc == 0) s_orow[(par ^ 1) * ROWS + srow] = atom_n;
-            // every wave is done with the LDS of this item: the next one may stage its slabs
-            __syncthreads();
+            // every wave is done with the LDS of this item: the next one may stage its slabs -- unless it stages nothing (another
+            // member of this tile, operand kept): its first LDS writes are the act0 planes behind its own layer-0 loop and
+            // tile-maximum barrier, and what this item still reads (the hand-over blocks in X1's place) is not touched before
+            // the next phase-1 epilogue
+            if (!(tile_n == tile && keep)) __syncthreads();
             }
         } else {
         // the AEV slabs of the next item travel during the stores below (requested AFTER the last ring load of this
