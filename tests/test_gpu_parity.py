@@ -631,6 +631,31 @@ def test_general_grid_slab_flags_through_the_networks(dev, oracle64):
     assert ea <= E_ATOM_REG and fe <= F_REG
 
 
+def test_steady_state_step_does_not_synchronize(dev):
+    """zero host synchronisations on the steady-state path.  After the caches are warm (species validity,
+    species relabelling, tile hint, locality test: each reads the device ONCE per species tensor), an energies_and_forces
+    call with check_overflow=False queues its kernels and returns -- torch's sync debug mode turns any synchronising call
+    into an error.  (Round 4 found the last one: SpeciesConverter's validity check, a .max() per call like the reference's.)"""
+    from bench import water_box
+
+    sp_np, x_np, cell_np = water_box(29)   # 73 167 atoms: the large-system path (kept AEV rows, phase 5)
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    model = get_model("ani2x", 0, dev, neighborlist="cell")
+    pbc = (True, True, True)
+    for k in range(3):
+        ref = model.energies_and_forces(sp, x + 0.001 * k, cell, pbc, check_overflow=False)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = model.energies_and_forces(sp, x + 0.002, cell, pbc, check_overflow=False)
+        small = model.energies_and_forces(sp, x + 0.003, cell, pbc, check_overflow=False)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert float((out.forces - ref.forces).abs().max()) < 1e-5 and torch.isfinite(small.energies).all()
+    model.aev_computer.last_neighbors().raise_on_overflow()
+
+
 def test_aev_rows_updated_in_place(dev):
     """AevEngine.forward_update (anihip_aev_forward_update): the rows kept by the engine and updated in place are, after
     every call, bit for bit the rows anihip_aev_forward writes into a fresh buffer -- whatever happened to the system in

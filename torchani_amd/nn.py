@@ -419,14 +419,22 @@ class SpeciesConverter(torch.nn.Module):
         if isinstance(atomic_nums, tuple):
             warnings.warn("The tuple call signature is deprecated; use idxs = converter(atomic_nums)")
             return (self.forward(atomic_nums[0]), atomic_nums[1])
+        # The validity check reads the device (the reference syncs here too, nn/_containers.py:727-733): once per species
+        # TENSOR -- identity and version, the entry keeps the tensor alive so that its address cannot be handed to another
+        # one meanwhile -- so that an MD loop that passes the same species tensor step after step never waits for the device
+        key = (atomic_nums.data_ptr(), atomic_nums._version, tuple(atomic_nums.shape), atomic_nums.dtype, bool(nop))
+        hit = self.__dict__.get("_checked")
+        checked = hit is not None and hit[0] == key
         if nop:
-            if atomic_nums.max() >= len(self.atomic_numbers):
+            if not checked and atomic_nums.max() >= len(self.atomic_numbers):
                 raise ValueError(f"Unsupported element idx in {atomic_nums}")
+            self.__dict__["_checked"] = (key, atomic_nums)
             return atomic_nums
         elem_idxs = self.conv_tensor[atomic_nums.clamp(min=-1)]  # -1 indexes the last (unused, -1) slot
-        if (elem_idxs[atomic_nums != -1] == -1).any():
+        if not checked and (elem_idxs[atomic_nums != -1] == -1).any():
             raise ValueError(f"Model doesn't support some elements in input. Input elements include: "
                              f"{torch.unique(atomic_nums)} Supported elements are: {self.atomic_numbers}")
+        self.__dict__["_checked"] = (key, atomic_nums)
         return elem_idxs
 
 
