@@ -631,6 +631,30 @@ def test_general_grid_slab_flags_through_the_networks(dev, oracle64):
     assert ea <= E_ATOM_REG and fe <= F_REG
 
 
+def test_padding_atoms_in_a_large_system(dev):
+    """Padding (species -1) in a system large enough for the chunked species bucketing (> 16 384 atoms; the padding rows are
+    zeroed by k_sp_scatter since round 4): the padded atoms get zero energies and forces, the others what the same system
+    WITHOUT the padded atoms gives."""
+    from bench import water_box
+
+    sp_np, x_np, cell_np = water_box(18)   # 17 496 atoms
+    n = sp_np.shape[1]
+    keep = (np.arange(n) % 7) != 3
+    sp_pad = sp_np.copy()
+    sp_pad[0, ~keep] = -1
+    model = get_model("ani2x", 2, dev, neighborlist="cell", row_capacity=192)
+    cell = torch.from_numpy(cell_np).to(dev)
+    pbc = (True, True, True)
+    a = model.energies_and_forces(torch.from_numpy(sp_pad).to(dev), torch.from_numpy(x_np).to(dev), cell, pbc, check_overflow=True)
+    b = model.energies_and_forces(torch.from_numpy(np.ascontiguousarray(sp_np[:, keep])).to(dev),
+                                  torch.from_numpy(np.ascontiguousarray(x_np[:, keep])).to(dev), cell, pbc, check_overflow=True)
+    kt = torch.from_numpy(keep).to(dev)
+    assert float(a.atomic_energies[0, ~kt].abs().max()) == 0.0 and float(a.forces[0, ~kt].abs().max()) == 0.0
+    assert float((a.atomic_energies[0, kt] - b.atomic_energies[0]).abs().max()) < 2e-7
+    assert float((a.forces[0, kt] - b.forces[0]).abs().max()) < 2e-6
+    assert abs(float(a.energies - b.energies)) < 1e-7 * n
+
+
 def test_steady_state_step_does_not_synchronize(dev):
     """zero host synchronisations on the steady-state path.  After the caches are warm (species validity,
     species relabelling, tile hint, locality test: each reads the device ONCE per species tensor), an energies_and_forces

@@ -228,8 +228,12 @@ __global__ __launch_bounds__(256) void k_sp_offsets(int S, int n_chunks, int *ch
     }
 }
 
+// (the outputs of PADDING atoms -- per-atom energy, gradient row, member energies -- are zeroed here as well: a wave that
+// meets one zeroes it with all its lanes; a system without padding pays one ballot per 64 atoms instead of the separate
+// k_zero_padding launch, 50 us at 2.3 M atoms)
 __global__ void k_sp_scatter(int64_t lo, int64_t hi, const int32_t *species, int S, const int *ctl,
-                             const int *chunk_cnt, int *perm)
+                             const int *chunk_cnt, int *perm, float *atomic_e, float *grad_aev, int L, float *member_e,
+                             int M, int64_t n_atoms)
 {
     const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t c0 = lo + wave * SP_CHUNK;
@@ -247,6 +251,15 @@ __global__ void k_sp_scatter(int64_t lo, int64_t hi, const int32_t *species, int
                 if (sp == t) perm[base[t] + mbcnt(m)] = (int)i;
                 base[t] += __popcll(m);
             }
+        for (uint64_t pad = __ballot(i < hi && sp < 0); pad; pad &= pad - 1) {
+            const int64_t ip = c0 + it * WAVE + (int)__builtin_ctzll(pad);
+            if (lane_id() == 0 && atomic_e) atomic_e[ip] = 0.f;
+            if (member_e && lane_id() < M) member_e[(int64_t)lane_id() * n_atoms + ip] = 0.f;
+            if (grad_aev) {
+                float4 *row = reinterpret_cast<float4 *>(grad_aev + (size_t)ip * L);
+                for (int f = lane_id(); f < (L >> 2); f += WAVE) row[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
     }
 }
 
@@ -3501,8 +3514,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         const int n_chunks = (int)((n + SP_CHUNK - 1) / SP_CHUNK);
         hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, chunk_cnt);
         hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(256), 0, stream, S, n_chunks, chunk_cnt, w.ctl);
-        hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm);
-        hipLaunchKernelGGL(k_zero_padding, dim3(zero_pad_blocks(n)), dim3(256), 0, stream, lo, hi, species,
+        hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm,
                            atomic_e, grad_aev, L, member_e, M, n_atoms);
     }
 
@@ -3781,10 +3793,9 @@ static int train_forward(hipStream_t stream, const anihip_mlp_desc *d, int64_t n
         const int n_chunks = (int)((n + SP_CHUNK - 1) / SP_CHUNK);
         hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, chunk_cnt);
         hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(256), 0, stream, S, n_chunks, chunk_cnt, w.ctl);
-        hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm);
+        hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm,
+                           atomic_e, grad_aev, L, (float *)nullptr, M, n_atoms);
     }
-    hipLaunchKernelGGL(k_zero_padding, dim3(zero_pad_blocks(n)), dim3(256), 0, stream, lo, hi, species,
-                       atomic_e, grad_aev, L, (float *)nullptr, M, n_atoms);
     for (int l = 0; l < nh; ++l) {
         GemmArgs g{};
         g.ctl = w.ctl; g.S = S; g.alpha = d->celu_alpha; g.inv_alpha = 1.0f / d->celu_alpha;
