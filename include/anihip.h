@@ -200,16 +200,18 @@ int anihip_nbr_refresh(void *stream, const anihip_aev_params *p, int64_t n_atoms
 int anihip_aev_forward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                        int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
                        const float *ent, float *aev, uint32_t *slab_mask, uint32_t *status);
-/* The same rows UPDATED IN PLACE (ABI 9; the 16 / 8x4 / 4x8 grids): aev and slab_mask are the buffers of the previous call
- * (any system of the same n_atoms -- which atom a row described does not matter), slab_mask[i] on entry = the slabs of
- * row i that may hold non-zero data.  Only those slabs and the ones flagged now are written: an atom of a water box flags
+/* The same rows UPDATED IN PLACE (ABI 9; the 16 / 8x4 / 4x8 grids): aev is the buffer of the previous call (any system
+ * of the same n_atoms -- which atom a row described does not matter), prev_mask[i] = the slabs of row i that may hold
+ * non-zero data (the slab_mask that call wrote; the caller alternates between two flag buffers: prev_mask is only read,
+ * slab_mask only written, they must not be the same buffer).  Only those slabs and the ones flagged now are written: an atom of a water box flags
  * 4-5 of its 32 slabs step after step, so an MD loop writes 0.6 KB of each 4 KB row instead of all of it (the rest is
  * zeros nobody has to write again).  The rows are complete afterwards, exactly as anihip_aev_forward leaves them.
- * First use: aev zero-filled, slab_mask zero-filled (or: aev anything, slab_mask all ones).  No reference counterpart
+ * First use: aev zero-filled, prev_mask zero-filled (or: aev anything, prev_mask all ones).  No reference counterpart
  * (csrc/aev.cu:1732 allocates and zero-fills a fresh tensor per call). */
 int anihip_aev_forward_update(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                               int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
-                              const float *ent, float *aev, uint32_t *slab_mask, uint32_t *status);
+                              const float *ent, float *aev, const uint32_t *prev_mask, uint32_t *slab_mask,
+                              uint32_t *status);
 int anihip_aev_backward(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,
                         int64_t lo, int64_t hi, const int32_t *species, const uint32_t *meta,
                         const float *ent, const float *grad_aev, const uint32_t *slab_mask, int32_t flags,

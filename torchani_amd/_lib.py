@@ -168,7 +168,7 @@ def lib() -> C.CDLL:
     L.anihip_nbr_from_full.argtypes = [vp, C.POINTER(AevParams), i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp]
     L.anihip_nbr_refresh.argtypes = [vp, C.POINTER(AevParams), i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     L.anihip_aev_forward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
-    L.anihip_aev_forward_update.argtypes = L.anihip_aev_forward.argtypes
+    L.anihip_aev_forward_update.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp]
     L.anihip_aev_backward.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, i32, vp, vp]
     L.anihip_aev_jvp.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, vp]
     L.anihip_aev_backward_virial.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, i32, vp, vp, vp]

@@ -612,7 +612,8 @@ template <int NA, int NZ, bool REC>
 __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
-    const float4 *__restrict__ ent, float *__restrict__ aev, uint32_t *__restrict__ slab_mask)
+    const float4 *__restrict__ ent, float *__restrict__ aev, uint32_t *__restrict__ slab_mask,
+    const uint32_t *__restrict__ prev_mask)
 {
     static_assert(NA % 4 == 0 && NZ % 4 == 0 && NA * NZ == 32, "angular tiling");
     constexpr int ZP = NZ / 2;          // packed pairs of angle shifts
@@ -680,8 +681,9 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
     uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
     // rows updated in place (a.update): what the previous call left in this row, one atom ahead like the header (wave-uniform
     // address: a scalar load); otherwise every slab counts as dirty and the whole row is written
-    uint32_t pm = (a.update && i < hi) ? slab_mask[i] : 0xFFFFFFFFu;
-    uint32_t pm_next = (a.update && i + nw < hi) ? slab_mask[i + nw] : 0xFFFFFFFFu;
+    // (prev_mask is a buffer of its own, never written here: wave-uniform reads of it are scalar loads)
+    uint32_t pm = (a.update && i < hi) ? prev_mask[i] : 0xFFFFFFFFu;
+    uint32_t pm_next = (a.update && i + nw < hi) ? prev_mask[i + nw] : 0xFFFFFFFFu;
     // Memory order of an atom: [loads for the NEXT atom] ... arithmetic ... [wait for those loads] [ALL stores of this atom].
     // Vector-memory operations retire in order and the compiler waits with vmcnt(0) for whatever it cannot count, so a
     // load consumed after stores were issued drains those stores first (HBM write latency, once per atom and wave).  With
@@ -780,7 +782,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         }
         const uint32_t prev_m = pm;
         pm = pm_next;
-        pm_next = (a.update && i + 2 * nw < hi) ? slab_mask[i + 2 * nw] : 0xFFFFFFFFu;
+        pm_next = (a.update && i + 2 * nw < hi) ? prev_mask[i + 2 * nw] : 0xFFFFFFFFu;
         // results that wait for the end of the atom: radial part in LDS (rst), the angular blocks of the last batch in the
         // neighbor table's LDS (dead by then: ang[lane] / ang[64 + lane] of the lanes flagged hold_last, destination hold_dst)
         bool hold_last = false;
@@ -1507,7 +1509,7 @@ static int persistent_blocks(int64_t n_central, int wpb, int blocks_per_cu)
 static int aev_forward(void *stream, const anihip_aev_params *p, const float *table,
                        int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
                        const uint32_t *meta, const float *ent, float *aev, uint32_t *slab_mask,
-                       uint32_t *status, bool update)
+                       uint32_t *status, bool update, const uint32_t *prev_mask = nullptr)
 {
     ANIHIP_REQUIRE(p && table && species && meta && ent && aev, "null pointer argument");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
@@ -1525,7 +1527,7 @@ static int aev_forward(void *stream, const anihip_aev_params *p, const float *ta
     const bool rec = (p->flags & ANIHIP_AEV_UNIFORM_SHFA) != 0 && ANIHIP_FWD3_REC;
 #define ANIHIP_LAUNCH_FWD3(NA_, NZ_, REC_)                                                                              \
     hipLaunchKernelGGL((k_aev_fwd3<NA_, NZ_, REC_>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species, meta, \
-                       (const float4 *)ent, aev, slab_mask)
+                       (const float4 *)ent, aev, slab_mask, prev_mask)
     if (p->n_shf_a == 8) {
         if (rec) ANIHIP_LAUNCH_FWD3(8, 4, true); else ANIHIP_LAUNCH_FWD3(8, 4, false);
     } else {
@@ -1547,12 +1549,13 @@ extern "C" int anihip_aev_forward(void *stream, const anihip_aev_params *p, cons
 
 extern "C" int anihip_aev_forward_update(void *stream, const anihip_aev_params *p, const float *table,
                                          int64_t n_atoms, int64_t lo, int64_t hi, const int32_t *species,
-                                         const uint32_t *meta, const float *ent, float *aev, uint32_t *slab_mask,
-                                         uint32_t *status)
+                                         const uint32_t *meta, const float *ent, float *aev, const uint32_t *prev_mask,
+                                         uint32_t *slab_mask, uint32_t *status)
 {
-    ANIHIP_REQUIRE(slab_mask, "anihip_aev_forward_update needs the slab flags of the previous call (slab_mask)");
+    ANIHIP_REQUIRE(slab_mask && prev_mask && slab_mask != prev_mask,
+                   "anihip_aev_forward_update needs the slab flags of the previous call (prev_mask) and a second buffer for this call's");
     ANIHIP_REQUIRE(p && tuned_grid(p), "rows are updated in place on the 16 / 8x4 / 4x8 grids only");
-    return aev_forward(stream, p, table, n_atoms, lo, hi, species, meta, ent, aev, slab_mask, status, true);
+    return aev_forward(stream, p, table, n_atoms, lo, hi, species, meta, ent, aev, slab_mask, status, true, prev_mask);
 }
 
 extern "C" int anihip_aev_jvp(void *stream, const anihip_aev_params *p, const float *table, int64_t n_atoms,

@@ -290,14 +290,17 @@ class AevEngine:
         hit = self.__dict__.get("_rows_kept")
         if hit is None or hit[0] != key:
             self.__dict__["_rows_kept"] = None   # (release the old pair before the new one is allocated)
-            hit = (key, torch.zeros((rows, self.L), dtype=torch.float32, device=species.device),
-                   torch.zeros(n, dtype=torch.int32, device=species.device))
+            # (two flag buffers, alternating: the kernel reads the previous call's and writes this call's)
+            hit = [key, torch.zeros((rows, self.L), dtype=torch.float32, device=species.device),
+                   torch.zeros(n, dtype=torch.int32, device=species.device),
+                   torch.zeros(n, dtype=torch.int32, device=species.device)]
             self.__dict__["_rows_kept"] = hit
-        _, out, mask = hit
+        _, out, prev, mask = hit
         _lib.check(_lib.lib().anihip_aev_forward_update(
             _stream(), C.byref(self.params), _ptr(self.table(species.device)), n, nbrs.lo, nbrs.hi,
             _ptr(species), _ptr(nbrs.meta), _ptr(nbrs.ent), _row_ptr(out, nbrs.lo if shard_rows else 0, self.L),
-            _ptr(mask), _ptr(nbrs.status)))
+            _ptr(prev), _ptr(mask), _ptr(nbrs.status)))
+        hit[2], hit[3] = mask, prev
         return out, mask
 
     def jvp(self, species: Tensor, nbrs: NeighborRows, tangent: Tensor) -> Tensor:
