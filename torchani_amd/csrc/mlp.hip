@@ -2499,8 +2499,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                             const int i = rb * NB + nb;
                             float y0, y1, dy0, dy1;
                             celu_d2(acc[i][r], acc[i][r + 1], osc2, bias2[nb][r], bias2[nb][r + 1], y0, y1, dy0, dy1);
-                            e = __builtin_fmaf(nb < u3.nba ? y0 : 0.f, w3[nb][r], e);
-                            e = __builtin_fmaf(nb < u3.nba ? y1 : 0.f, w3[nb][r + 1], e);
+                            // (NB = 1: a wave inside this loop owns its one column block; the select is for the 2-block tiling)
+                            e = __builtin_fmaf((NB == 1 || nb < u3.nba) ? y0 : 0.f, w3[nb][r], e);
+                            e = __builtin_fmaf((NB == 1 || nb < u3.nba) ? y1 : 0.f, w3[nb][r + 1], e);
                             acc[i][r] = invM * w3[nb][r] * dy0;
                             acc[i][r + 1] = invM * w3[nb][r + 1] * dy1;
                         }
