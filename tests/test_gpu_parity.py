@@ -1734,10 +1734,15 @@ def test_ani2xr_family_matches_reference(dev, kind, case):
     # (the module path returns energies in the dtype of the coordinates, like the reference: fp32 totals of ~ -2400 Ha)
     assert np.abs(e.detach().cpu().numpy() - ref["energies"]).max() < E_ATOM_TOL * n_real + 2e-7 * np.abs(ref["energies"]).max()
     assert np.abs(-gx.cpu().numpy() - ref["forces"]).max() < F_TOL * fscale
-    # the training passes are CELU-only: a trainable GELU model says so instead of computing something else
+    # a trainable GELU model goes through the training passes (bias-free layers, GELU derivatives from the kept
+    # pre-activations): same energies, and the graph reaches the parameters (test_gpu_training.py pins the gradients)
     model.neural_networks.requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        model((sp, x), cell, None if pbc is None else torch.tensor(pbc))
+    et = model((sp, x), cell, None if pbc is None else torch.tensor(pbc)).energies
+    assert et.requires_grad
+    assert np.abs(et.detach().cpu().numpy() - ref["energies"]).max() < E_ATOM_TOL * n_real + 2e-7 * np.abs(ref["energies"]).max()
+    et.sum().backward()
+    w = model.neural_networks.members[0].atomics["H"].layers[0].weight
+    assert w.grad is not None and torch.isfinite(w.grad).all() and float(w.grad.abs().max()) > 0
 
 
 @pytest.mark.parametrize("case", ["rand_batch_ani2x", "water_pbc_ani2x", "small_ani2x"])
