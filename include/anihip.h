@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 9
+#define ANIHIP_ABI_VERSION 10
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -347,8 +347,13 @@ int anihip_mlp_pack(void *stream, const anihip_mlp_shape *shape, const float *co
                     anihip_mlp_desc *out_desc);
 
 /* Workspace for n central atoms (activations of every hidden layer for all members, species-sorted
- * index lists). */
+ * index lists): enough for every entry point below that takes a workspace. */
 size_t anihip_mlp_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central);
+/* What ONE anihip_mlp_forward_backward call over n_central atoms with this descriptor (its flags included) touches
+ * (ABI 10): the fused network kernel keeps the activations in LDS, so its calls need the index lists, the tile table and
+ * the per-member energies (~100 B per atom) plus -- below 65536 atoms, where the layer-0 backward is a GEMM of its own --
+ * d E / d act0 (8 KB per atom for ANI-2x); want_grad = (grad_aev != NULL).  Never more than anihip_mlp_workspace_bytes. */
+size_t anihip_mlp_forward_backward_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central, int32_t want_grad);
 
 /* atomic_e[i] = mean over members of net_{m,species(i)}(aev[i]) for lo <= i < hi (0 for padding);
  * if grad_aev != NULL also grad_aev[i] = d atomic_e[i] / d aev[i] (rows of padding atoms zeroed).

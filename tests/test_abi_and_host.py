@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_struct_layouts_match_header(lib):
@@ -52,6 +52,8 @@ def test_struct_layouts_match_header(lib):
     tiles = (n + 63) // 64 + 8   # tile table of the fused kernel: 16-B entry + 64 atom rows per tile
     d0_pad = 4 * 8 * 256 * 64 * 8   # layer 0 doubles as the tile-major d E/d act0 buffer: + 64 rows per species slot
     assert acts <= need <= acts + d0_pad + 4 * (n + 1) * (1 + 8) + (16 + 256) * tiles + 64 * 256
+    # one forward_backward call of a descriptor the fused kernel cannot serve (no fp16 planes here): the same buffers
+    assert lib.anihip_mlp_forward_backward_workspace_bytes(ctypes.byref(d), n, 1) == need
     # training pass: the activations are kept and every hidden layer gets a gradient buffer of the same size
     assert ctypes.sizeof(_lib.SpeciesGrads) == 2 * 4 * 8
     need_t = lib.anihip_mlp_train_workspace_bytes(ctypes.byref(d), n)

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--stages", default="nbr,fwd,bwd,mlp")
     ap.add_argument("--mask", default="both", choices=["on", "off", "both"], help="slab masks in the mlp stage")
-    ap.add_argument("--chunk", type=int, default=1 << 20, help="atoms per network chunk")
+    ap.add_argument("--chunk", type=int, default=0, help="atoms per launch group of the network stage (0: the engine's rule)")
     ap.add_argument("--mlp-flags", type=int, default=0, help="anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*) of the network stage")
     ap.add_argument("--compact", action="store_true", help="species numbered present-ones-first (models.ANI.compact_species)")
     ap.add_argument("--order", default="lattice", help="atom order: lattice (as generated), shuffle, layers (quarter-cutoff "
@@ -87,7 +87,7 @@ def main():
                                           args.reps)
     if "mlp" in st and args.mask != "off":
         out["mlp"] = time_stage(lambda: packed.forward_backward(sp32, aev, atomic_e=ae, grad_aev=gaev,
-                                                                slab_mask=mask, chunk=args.chunk), args.reps)
+                                                                slab_mask=mask, chunk=args.chunk or None), args.reps)
     bpa = 3584 + 20 * n_a + 8 + 448 + 8 * n_r
     line = f"atoms={n} n_r={n_r:.1f} n_a={n_a:.1f} | " + " ".join(f"{k}={v:.3f}ms" for k, v in out.items())
     if "fwd" in out:

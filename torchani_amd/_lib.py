@@ -37,7 +37,7 @@ MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MA
     1, 2, 4, 8, 16, 32
 MLP_FLAG_NO_SMALL_PREP, MLP_FLAG_L0B_4WAVE, MLP_FLAG_TILE_OWNER = 64, 128, 256
 MLP_FLAG_FUSED_L0B, MLP_FLAG_NO_FUSED_L0B = 512, 1024
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class AevParams(C.Structure):
@@ -174,6 +174,8 @@ def lib() -> C.CDLL:
     L.anihip_aev_backward_virial.argtypes = [vp, C.POINTER(AevParams), vp, i64, i64, i64, vp, vp, vp, vp, vp, i32, vp, vp, vp]
     L.anihip_mlp_workspace_bytes.restype = sz
     L.anihip_mlp_workspace_bytes.argtypes = [C.POINTER(MlpDesc), i64]
+    L.anihip_mlp_forward_backward_workspace_bytes.restype = sz
+    L.anihip_mlp_forward_backward_workspace_bytes.argtypes = [C.POINTER(MlpDesc), i64, C.c_int32]
     L.anihip_mlp_pack_bytes.restype = sz
     L.anihip_mlp_pack_bytes.argtypes = [C.POINTER(MlpShape)]
     L.anihip_mlp_pack.restype = C.c_int
@@ -214,7 +216,7 @@ EXPORTED_SYMBOLS = [
     "anihip_last_error", "anihip_abi_version", "anihip_aev_table_pack", "anihip_nbr_workspace_bytes",
     "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_half_workspace_bytes", "anihip_nbr_from_half", "anihip_nbr_from_full",
     "anihip_nbr_refresh", "anihip_aev_forward", "anihip_aev_forward_update", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp",
-    "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
+    "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
     "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
     "anihip_mlp_tangent_workspace_bytes", "anihip_mlp_tangent_weight_grads", "anihip_pair_xtb_repulsion",
     "anihip_pair_d3", "anihip_pair_analytic", "anihip_energy_forces_finish", "anihip_mlp_pack_bytes", "anihip_mlp_pack",

@@ -3217,7 +3217,9 @@ struct MlpWorkspace {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWorkspace *w)
+// n_act: hidden-layer buffers carved (-1: all of them, what the layer-by-layer kernels and the training passes use; the fused
+// kernel needs act[0] for its d E / d act0 hand-over, and none at all with the layer-0 backward inside)
+static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWorkspace *w, int n_act = -1)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -3242,6 +3244,10 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
         int mx = 0;
         for (int s = 0; s < d->num_species; ++s) mx = mx > d->net[s].dims[l + 1] ? mx : d->net[s].dims[l + 1];
         int64_t ld = (int64_t)mx * d->n_members;
+        if (n_act >= 0 && l >= n_act) {
+            if (w) { w->act[l] = nullptr; w->ld[l] = ld; }
+            continue;
+        }
         // (layer 0 doubles as the tile-major d E / d act0 buffer: one partly filled 64-row block per species)
         float *a = (float *)take(sizeof(float) * (size_t)ld * (size_t)(n + 1 + (l == 0 ? 64 * ANIHIP_MAX_SPECIES : 0)));
         if (w) { w->act[l] = a; w->ld[l] = ld; }
@@ -3347,6 +3353,55 @@ static bool fused_dims_supported(int H1, int H2, int H3)
     return H1 <= FR_MAXH && H2 <= FR_MAXH && H3 <= FR_MAXH;
 }
 
+// Which kernels one anihip_mlp_forward_backward call over n central atoms runs -- decided from the descriptor, n and
+// whether d E / d AEV is wanted alone, so that the workspace query and the call agree.
+struct FbPlan {
+    bool fused;       // k_mlp_fused (f16x3, three hidden layers of width <= 256, at most 32 AEV slabs)
+    bool fused_l0b;   // ... with the layer-0 backward as its phase 5 (no d E / d act0 buffer)
+    bool big_tiles;   // 256 x 256 tiles for the layer-0 GEMMs outside the fused kernel
+    int fused_rows;   // atoms per tile of the fused kernel
+    int n_act;        // hidden-layer buffers of the workspace this call touches (mlp_carve)
+};
+static FbPlan fb_plan(const anihip_mlp_desc *d, int64_t n, bool want_grad)
+{
+    FbPlan p{};
+    const int S = d->num_species, nh = d->net[0].n_layers - 1, L = d->aev_len;
+    const bool h3 = d->precision == ANIHIP_MLP_F16X3;
+    const int kp_rad = h3 ? d->aev_radial_len : 0;
+    const int K0p = kp_rad > 0 ? 32 * ((kp_rad + 31) / 32 + (L - kp_rad) / 32) : ((L + 31) / 32) * 32;
+    p.fused = h3 && nh == 3 && K0p <= 32 * 32 && L % 4 == 0;
+    for (int s = 0; s < S && p.fused; ++s) {
+        const anihip_species_net &nn = d->net[s];
+        p.fused = p.fused && nn.whf[0] && nn.whf[1] && nn.whf[2] && nn.wthf[1] && nn.wthf[2] && nn.fused_bounds &&
+                  fused_dims_supported(nn.dims[1], nn.dims[2], nn.dims[3]);
+    }
+    if (d->flags & ANIHIP_MLP_FLAG_NO_FUSED) p.fused = false;
+    // 256 x 256 tiles for the layer-0 GEMMs once there are enough rows to fill the chip with them
+    p.big_tiles = h3 && n >= 16384;
+    if (d->flags & ANIHIP_MLP_FLAG_BIG_TILES) p.big_tiles = h3;
+    if (d->flags & ANIHIP_MLP_FLAG_SMALL_TILES) p.big_tiles = false;
+    p.fused_rows = ((d->flags & ANIHIP_MLP_FLAG_FUSED_ROWS32) && d->activation == ANIHIP_ACT_CELU) ? 32 : 64;
+    // Layer-0 backward INSIDE the fused kernel (its phase 5): a workgroup owns a tile through all members and adds the
+    // members' d E / d AEV in place -- no d act0 round trip through HBM (8 KB per atom written and read back), no layer-0
+    // backward launch.  Tiles are then the unit of work (not tile x member items), so it needs enough of them to balance
+    // over the CUs: from 65536 atoms on (1024 tiles).  Smaller inputs keep the member-major sweep + a backward GEMM.
+    // (phase 5 hands partial sums between waves through 32 KB of LDS in X1's place: 2 planes x 64 rows x (H2 + 8) halves)
+    auto l0b_ok = [&](int s) { return d->net[s].wthf[0] != nullptr && d->net[s].dims[2] >= 128; };
+    p.fused_l0b = p.fused && want_grad && p.fused_rows == 64 && n >= FUSED_L0B_MIN_ATOMS &&
+                  !(d->flags & (ANIHIP_MLP_FLAG_NO_FUSED_L0B | ANIHIP_MLP_FLAG_SMALL_TILES));
+    if (d->flags & ANIHIP_MLP_FLAG_FUSED_L0B)   // (forced, e.g. by the tests on small inputs; the call checks that it can)
+        p.fused_l0b = p.fused && want_grad && p.fused_rows == 64;
+    for (int s = 0; s < S && p.fused_l0b; ++s) p.fused_l0b = l0b_ok(s);
+    p.n_act = !p.fused ? nh : ((want_grad && !p.fused_l0b) ? 1 : 0);
+    return p;
+}
+
+extern "C" size_t anihip_mlp_forward_backward_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central, int want_grad)
+{
+    if (!d || n_central < 0 || d->net[0].n_layers < 2 || d->net[0].n_layers > ANIHIP_MAX_LAYERS) return 0;
+    return mlp_carve(d, n_central, nullptr, nullptr, fb_plan(d, n_central, want_grad != 0).n_act);
+}
+
 template <int EPI>
 static int launch_gemm_big(hipStream_t stream, GemmArgs &g, int64_t n_rows_total)
 {
@@ -3435,9 +3490,11 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     const int64_t n = hi - lo;
     if (n == 0) return 0;
-    ANIHIP_REQUIRE(workspace_bytes >= mlp_carve(d, n, nullptr, nullptr), "workspace too small");
+    const FbPlan plan = fb_plan(d, n, grad_aev != nullptr);
+    ANIHIP_REQUIRE(workspace_bytes >= mlp_carve(d, n, nullptr, nullptr, plan.n_act),
+                   "workspace too small (anihip_mlp_forward_backward_workspace_bytes)");
     MlpWorkspace w;
-    mlp_carve(d, n, (char *)workspace, &w);
+    mlp_carve(d, n, (char *)workspace, &w, plan.n_act);
     const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1;
     const int L = d->aev_len;
     const bool h3 = d->precision == ANIHIP_MLP_F16X3;
@@ -3458,27 +3515,19 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
 
     // fused network kernel (f16x3, three hidden layers of width <= 256, at most 32 AEV slabs): one kernel
     // from the AEV rows to d E / d act0, then the layer-0 backward GEMM
-    bool fused = h3 && nh == 3 && K0p <= 32 * 32 && L % 4 == 0;
-    for (int s = 0; s < S && fused; ++s) {
-        const anihip_species_net &nn = d->net[s];
-        fused = fused && nn.whf[0] && nn.whf[1] && nn.whf[2] && nn.wthf[1] && nn.wthf[2] && nn.fused_bounds &&
-                fused_dims_supported(nn.dims[1], nn.dims[2], nn.dims[3]);
-    }
-    if (d->flags & ANIHIP_MLP_FLAG_NO_FUSED) fused = false;
+    const bool fused = plan.fused;
     // (the layer-by-layer kernels, the 32-atom tiling and the training passes implement CELU only)
     ANIHIP_REQUIRE(d->activation == ANIHIP_ACT_CELU || fused,
                    "GELU networks run through the fused network kernel only: f16x3 precision, 3 hidden layers <= 256 wide");
     // 256 x 256 tiles for the layer-0 GEMMs once there are enough rows to fill the chip with them
     int d0_tm = 0;
-    bool big_tiles = h3 && n >= 16384;
-    if (d->flags & ANIHIP_MLP_FLAG_BIG_TILES) big_tiles = h3;
-    if (d->flags & ANIHIP_MLP_FLAG_SMALL_TILES) big_tiles = false;
+    const bool big_tiles = plan.big_tiles;
     // per-atom slab flags: honoured by the 256 x 256 kernels on slab-ordered planes
     const uint32_t *smask = (big_tiles && kp_rad > 0 && K0p <= 32 * 32) ? slab_mask : nullptr;
     if (d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK) smask = nullptr;
 
     // 1. bucket by species (+ the tile table of the fused kernel and the padding rows, one launch for small inputs)
-    const int fused_rows = ((d->flags & ANIHIP_MLP_FLAG_FUSED_ROWS32) && d->activation == ANIHIP_ACT_CELU) ? 32 : 64;
+    const int fused_rows = plan.fused_rows;
     const int64_t fused_tiles = (n + fused_rows - 1) / fused_rows + S;
     const int n_slabs = K0p / 32;
     // per-atom slab flags for the fused kernel's tile masks: the ANI slab order (kp_rad > 0: anihip_aev_forward's flags for
@@ -3565,20 +3614,10 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         }
     }
 
-    // Layer-0 backward INSIDE the fused kernel (its phase 5): a workgroup owns a tile through all members and adds the
-    // members' d E / d AEV in place -- no d act0 round trip through HBM (8 KB per atom written and read back), no layer-0
-    // backward launch.  Tiles are then the unit of work (not tile x member items), so it needs enough of them to balance
-    // over the CUs: from 65536 atoms on (1024 tiles).  Smaller inputs keep the member-major sweep + a backward GEMM.
-    bool fused_l0b = fused && grad_aev && fused_rows == 64 && n >= FUSED_L0B_MIN_ATOMS &&
-                     !(d->flags & (ANIHIP_MLP_FLAG_NO_FUSED_L0B | ANIHIP_MLP_FLAG_SMALL_TILES));
-    // (phase 5 hands partial sums between waves through 32 KB of LDS in X1's place: 2 planes x 64 rows x (H2 + 8) halves)
-    auto l0b_ok = [&](int s) { return d->net[s].wthf[0] != nullptr && d->net[s].dims[2] >= 128; };
-    for (int s = 0; s < S && fused_l0b; ++s) fused_l0b = l0b_ok(s);
-    if (d->flags & ANIHIP_MLP_FLAG_FUSED_L0B) {   // (forced, e.g. by the tests on small inputs)
-        fused_l0b = fused && grad_aev && fused_rows == 64;
-        for (int s = 0; s < S && fused_l0b; ++s) fused_l0b = l0b_ok(s);
+    // layer-0 backward inside the fused kernel (fb_plan)
+    const bool fused_l0b = plan.fused_l0b;
+    if (d->flags & ANIHIP_MLP_FLAG_FUSED_L0B)
         ANIHIP_REQUIRE(fused_l0b, "ANIHIP_MLP_FLAG_FUSED_L0B needs the fused kernel (64-row tiles), wthf[0] and second hidden layers of >= 128 columns");
-    }
 
     FinishArgs fin{};
     // few atoms: the layer-0 backward runs in the 8-wave 128 x 128 kernel (needs the slab flags for its column compaction)

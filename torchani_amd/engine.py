@@ -539,8 +539,11 @@ class PackedNetworks:
         assert 0 <= off and off + n <= self._buf.numel(), "pointer outside the packed buffer"
         return self._buf[off:off + n].view(dtype).view(*shape)
 
-    def workspace(self, n_central: int) -> Tensor:
-        need = _lib.lib().anihip_mlp_workspace_bytes(C.byref(self.desc), n_central)
+    def workspace(self, n_central: int, want_grad: bool = True) -> Tensor:
+        """Scratch of one anihip_mlp_forward_backward call over n_central atoms: what the kernels that call runs touch
+        (with the layer-0 backward inside the fused kernel ~100 B per atom: index lists, tile table, per-member energies;
+        19.5 KB per atom for the layer-by-layer kernels of an ANI-2x pack)."""
+        need = _lib.lib().anihip_mlp_forward_backward_workspace_bytes(C.byref(self.desc), n_central, int(want_grad))
         if self._ws is None or self._ws.numel() < need:
             if self.pinned and self._ws is not None:
                 # a captured HIP graph replays into self._ws: never free or replace it; a larger eager call gets a
@@ -550,7 +553,7 @@ class PackedNetworks:
         return self._ws
 
     def forward_backward(self, species: Tensor, aev: Tensor, lo: int = 0, hi: tp.Optional[int] = None,
-                         want_grad: bool = True, want_members: bool = False, chunk: int = 1 << 20,
+                         want_grad: bool = True, want_members: bool = False, chunk: tp.Optional[int] = None,
                          atomic_e: tp.Optional[Tensor] = None, grad_aev: tp.Optional[Tensor] = None,
                          slab_mask: tp.Optional[Tensor] = None, shard_rows: bool = False, tile_hint: int = 0,
                          plain_slabs: bool = False) -> tp.Tuple[Tensor, tp.Optional[Tensor], tp.Optional[Tensor]]:
@@ -589,6 +592,17 @@ class PackedNetworks:
         # over the CUs (a rank's 292 k-atom shard of the 2.3 M-atom box: 2 chunks x 3 rounds -> 1 chunk x 5 rounds)
         nn_ = hi - lo
         n_cu = _n_cus(dev)
+        fl = PackedNetworks.default_flags if self.flags is None else self.flags
+        if not fl & (_lib.MLP_FLAG_SMALL_TILES | _lib.MLP_FLAG_BIG_TILES):
+            fl |= tile_hint
+        self.desc.flags = fl   # (before the workspace queries: the flags choose the kernels)
+        if chunk is None:
+            # ONE call when its scratch is small -- the fused kernel with the layer-0 backward inside keeps everything but
+            # ~100 B per atom in LDS: one persistent launch and one tail instead of one per 2^20 atoms (-0.5 ms per step at
+            # 2.34 M atoms) -- else launch groups of 2^20 atoms (19.5 KB of activations per atom for an ANI-2x pack)
+            chunk = 1 << 20
+            if nn_ > chunk and L.anihip_mlp_forward_backward_workspace_bytes(C.byref(self.desc), nn_, int(want_grad)) <= 512 * nn_:
+                chunk = nn_
 
         def plan(nc: int) -> tp.Tuple[int, int]:
             st_ = max(1, -(-(-(-nn_ // nc)) // 256) * 256)
@@ -600,11 +614,7 @@ class PackedNetworks:
         step = plan(nchunk)[1]
         for c0 in range(lo, hi, step):
             c1 = min(hi, c0 + step)
-            ws = self.workspace(c1 - c0)
-            fl = PackedNetworks.default_flags if self.flags is None else self.flags
-            if not fl & (_lib.MLP_FLAG_SMALL_TILES | _lib.MLP_FLAG_BIG_TILES):
-                fl |= tile_hint
-            self.desc.flags = fl
+            ws = self.workspace(c1 - c0, want_grad)
             _lib.check(L.anihip_mlp_forward_backward(
                 _stream(), C.byref(self.desc), n, c0, c1, _ptr(species), _row_ptr(aev, rows0, self.aev_len),
                 _ptr(slab_mask), _ptr(ws), ws.numel(), _ptr(atomic_e),

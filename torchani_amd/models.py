@@ -57,10 +57,10 @@ class ANI(torch.nn.Module):
         self.energy_shifter = SelfEnergy(symbols, self_energies)
         self.register_buffer("atomic_numbers", self.species_converter.atomic_numbers.clone())
         self.cutoff = aev_computer.radial.cutoff
-        # atoms per launch group of the network stage: its workspace is ~8.5 KB per atom of a group (d E/d act0 of 8 members),
-        # and every group costs a dozen small launches (species bucketing, tile table, ...): 2^20 atoms = 9 GB, 0.7 ms per
-        # step less than 2^18 at 2.34 M atoms (tools/gpu_chunk_ab.sh)
-        self.mlp_chunk = 1 << 20
+        # atoms per launch group of the network stage; None = PackedNetworks.forward_backward's rule: ONE call when its
+        # scratch is small (from 65536 atoms on the fused kernel keeps everything but ~100 B per atom in LDS), else groups of
+        # 2^20 atoms (8.5 KB of d E/d act0 per atom of a group; a dozen small launches per group)
+        self.mlp_chunk: tp.Optional[int] = None
         self.last_collective: tp.Optional[dict] = None   # what the last sharded energies_and_forces all-reduced
         # True: energies_and_forces accumulates forces in int64 fixed point (2^-32 Ha/A): bit-identical results from
         # run to run and for any number of ranks' reduction order, at the price of 24 instead of 12 bytes per atom of
