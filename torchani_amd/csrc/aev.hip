@@ -712,17 +712,40 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
             const int cf = (int)((pkF >> (8 * nd_tj)) & 255u);
             const bool nd = lane < 7 ? (cj + cf > 0) : (blk_same ? cj >= 2 : (cj >= 1 && ck >= 1));
             need = __ballot(nd && lane < 35);
+            // The radial list is kept GROUPED BY SPECIES, every group padded to a multiple of 8 entries with fc = 0 (the row
+            // itself is sorted {angular, far} x species): the radial loop below then walks 8 consecutive entries per step
+            // with no index arithmetic and no validity select (17 -> 8 vector instructions per step, 8 steps per water atom).
+            // Entry e of the row goes to e + shift, the shift of its {class, species} segment: two compare-selects per
+            // present species (the last segment whose start is <= e wins; wave-uniform bounds, scalar loop).
+            const uint64_t prA2 = pkA * 0x0101010101010100ull, prF2 = pkF * 0x0101010101010100ull;
+            int rad_total = 0;
+            auto rad_pos = [&](int e) {
+                int shA = 0, shF = 0, base = 0;
+                for (uint32_t m_ = (uint32_t)need & 0x7Fu; m_; m_ &= m_ - 1) {
+                    const int t = __builtin_ctz(m_);
+                    const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t);
+                    const int oA = cnt_of(prA2, t), oF = nA + cnt_of(prF2, t);
+                    shA = e >= oA ? base - oA : shA;
+                    shF = e >= oF ? base + cA - oF : shF;
+                    base += (cA + cF + 7) & ~7;
+                }
+                rad_total = base;
+                return e + (e < nA ? shA : shF);
+            };
+            const int pos0 = rad_pos(lane);
+            for (int k = 0; k < rad_total; k += WAVE) rad[k + lane] = make_float2(0.f, 0.f);   // (<= 256 + 49 of 664 entries)
             for (int c0 = 0; c0 < nR; c0 += WAVE) {
                 const int e = c0 + lane;
                 float4 d = c0 == 0 ? e0 : (c0 == WAVE ? e1 : dummy4);
                 if (c0 >= 2 * WAVE && e < nR) d = ent[start + e];   // (> 128 neighbors: rare, waits on the spot)
+                const int pos = c0 == 0 ? pos0 : rad_pos(e);
                 if (e < nR) {
                     const float r2 = d.x * d.x + d.y * d.y + d.z * d.z;
                     const float inv = __builtin_amdgcn_rsqf(r2);
                     const float r = r2 * inv;
                     const float fcr = a.smooth ? 0.25f * smooth_cutoff(r, 1.0f / a.Rcr).x
                                                : 0.125f * __builtin_amdgcn_cosf(r * rev_rcr) + 0.125f;
-                    rad[e] = make_float2(qR * r, fcr);
+                    rad[pos] = make_float2(qR * r, fcr);
                     if (e < nA) {
                         ang[e] = make_float4(d.x * inv, d.y * inv, d.z * inv, 0.5f * qA * r);
                         float lf;
@@ -742,24 +765,19 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
             }
             wave_sync();
             TR_STAMP(0)   // neighbor terms
-            // radial, lane = (8 neighbor slots) x (8 shift pairs), one species after the other
-            const uint64_t prA2 = pkA * 0x0101010101010100ull, prF2 = pkF * 0x0101010101010100ull;
+            // radial, lane = (8 neighbor slots) x (8 shift pairs), one species group of the list after the other
+            const float2 *rgrp = rad + rp;
             for (uint32_t rm_ = (uint32_t)need & 0x7Fu; rm_; rm_ &= rm_ - 1) {
                 const int t = __builtin_ctz(rm_);
-                const int cA = cnt_of(pkA, t), cF = cnt_of(pkF, t), n = cA + cF;
-                const int oA = cnt_of(prA2, t), oF = nA + cnt_of(prF2, t);
+                const int n8 = (cnt_of(pkA, t) + cnt_of(pkF, t) + 7) & ~7;
                 float acc0 = 0.f, acc1 = 0.f;
-                for (int b_ = 0; b_ < n; b_ += 8) {
-                    const int idx = b_ + rp;
-                    const bool v = idx < n;
-                    int e = idx < cA ? oA + idx : oF + (idx - cA);
-                    e = v ? e : 0;
-                    const float2 rf = rad[e];
-                    const float f = v ? rf.y : 0.f;
+                for (int b_ = 0; b_ < n8; b_ += 8) {
+                    const float2 rf = rgrp[b_];
                     const float d0 = rf.x - shfR0, d1 = rf.x - shfR1;
-                    acc0 += __builtin_amdgcn_exp2f(-d0 * d0) * f;
-                    acc1 += __builtin_amdgcn_exp2f(-d1 * d1) * f;
+                    acc0 += __builtin_amdgcn_exp2f(-d0 * d0) * rf.y;
+                    acc1 += __builtin_amdgcn_exp2f(-d1 * d1) * rf.y;
                 }
+                rgrp += n8;
                 acc0 = row_shr_add<8>(acc0);
                 acc1 = row_shr_add<8>(acc1);
                 float x = sum16(acc0, acc1);
@@ -839,13 +857,11 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                 int t = (lane - mys0) * I;
                 int qd = (int)(((float)t + 0.5f) * inv_div);
                 int rem = t - qd * div;
+                // (no zero fill of the 32 sums: the first pair of a slot writes them, the others add -- the zero fill was 64
+                // moves per batch, the compiler cleared the registers once for the loop and once for "no iteration")
                 v2f acc[NA][ZP];
-#pragma unroll
-                for (int u = 0; u < NA; ++u)
-#pragma unroll
-                    for (int vp = 0; vp < ZP; ++vp) acc[u][vp] = (v2f){0.f, 0.f};
                 TR_STAMP(4)   // pair iterator setup
-                for (int it = 0; it < I; ++it) {
+                auto pair_step = [&](auto first_) {
                     // (j, k) of pair t inside the two groups; slots past the last pair read the dummy neighbor
                     int k2 = qd + 1 + rem;
                     k2 = (int)min((uint32_t)k2, (uint32_t)(k2 - nj));   // k2 >= nj ? k2 - nj : k2
@@ -907,8 +923,13 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
 #pragma unroll
                     for (int u = 0; u < NA; ++u)
 #pragma unroll
-                        for (int vp = 0; vp < ZP; ++vp) acc[u][vp] += (v2f){f2[u], f2[u]} * f1[vp];
-                }
+                        for (int vp = 0; vp < ZP; ++vp) {
+                            if constexpr (decltype(first_)::value) acc[u][vp] = (v2f){f2[u], f2[u]} * f1[vp];
+                            else acc[u][vp] += (v2f){f2[u], f2[u]} * f1[vp];
+                        }
+                };
+                pair_step(std::true_type{});   // (I >= 1: a block is flagged)
+                for (int it = 1; it < I; ++it) pair_step(std::false_type{});
                 TR_STAMP(5)   // pair loop
                 // -- segmented reduction of the 64 x 32 sums, 16 values per round --
                 // same-block predicates between lane groups (all four slots of a group belong to one block)
