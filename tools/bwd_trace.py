@@ -34,9 +34,12 @@ def main():
     buf = np.zeros((2048, 10), dtype=np.uint64)
     assert _lib.lib().anihip_dev_trace_read(buf.ctypes.data_as(C.c_void_p)) == 0
     used = buf[buf.sum(axis=1) > 0].astype(np.float64)
-    per_wave_atoms = n / (used.shape[0] * 4)
+    per_wave_atoms = n / (used.shape[0] * 16)   # (mean: the waves of a workgroup share its atoms through a queue)
     tot = used.sum(axis=1).mean()
     print(f"k_aev_bwd: blocks {used.shape[0]}  atoms per wave {per_wave_atoms:.1f}  clocks per atom (wave 0) {tot / per_wave_atoms:.0f}")
+    tw = used.sum(axis=1)
+    print(f"  per-wave totals (wave 0 of every block): min {tw.min() / tw.mean():.3f}  max {tw.max() / tw.mean():.3f} of the mean, "
+          f"std {tw.std() / tw.mean():.4f}")
     for k, nm in enumerate(NAMES):
         print(f"  {nm:32s} {used[:, k].mean() / per_wave_atoms:8.0f} clocks/atom  {100 * used[:, k].mean() / tot:5.1f} %")
 

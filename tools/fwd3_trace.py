@@ -31,9 +31,12 @@ def main():
     assert rc == 0
     used = buf[buf.sum(axis=1) > 0].astype(np.float64)
     n_atoms = sp32.numel()
-    per_wave_atoms = n_atoms / (used.shape[0] * 4)
+    per_wave_atoms = n_atoms / (used.shape[0] * 16)   # (mean: the waves of a workgroup share its atoms through a queue)
     tot = used.sum(axis=1).mean()
     print(f"blocks {used.shape[0]}  atoms per wave {per_wave_atoms:.1f}  clocks per atom (wave 0) {tot / per_wave_atoms:.0f}")
+    tw = used.sum(axis=1)
+    print(f"  per-wave totals (wave 0 of every block): min {tw.min() / tw.mean():.3f}  max {tw.max() / tw.mean():.3f} of the mean, "
+          f"std {tw.std() / tw.mean():.4f}")
     for k, nm in enumerate(NAMES):
         print(f"  {nm:16s} {used[:, k].mean() / per_wave_atoms:8.0f} clocks/atom  {100 * used[:, k].mean() / tot:5.1f} %")
 

@@ -36,8 +36,32 @@ __device__ __forceinline__ int xcd_block()
 #endif
 }
 
-constexpr int FWD_WPB = 4;
-constexpr int BWD_WPB = 4;
+// The persistent waves of the tuned AEV kernels take their atoms from a QUEUE of their workgroup.  A workgroup is a whole
+// CU's worth of waves (QW = 16: four per SIMD, one workgroup per CU) and owns the atoms  first + 16 b + r + 16 blocks k
+// (r = 0..15, k = 0, 1, ..: the same 16-atom groups at a stride of all workgroups as with a fixed share per wave); position
+// p = 16 k + r of that list goes to whichever wave asks next -- an LDS counter, one returning ds_add of lane 0 per atom,
+// issued an atom ahead.  With a FIXED share per wave the waves of a SIMD finish far apart (the issue arbiter favours the
+// oldest wave: wave totals from 0.74 to 1.30 of their mean, tools/fwd3_trace.py) and the SIMD spends the last fifth of
+// the kernel with three, two, one wave(s) to hide latencies with; from the queue all of a CU's waves work until its atoms
+// run out (totals within 1 %).  (A device-wide counter does the same for the whole chip but its atomics execute in memory
+// -- the L2s of the eight XCDs are not coherent -- at ~10 ns each, serialised: 0.6 M requests per launch were slower than the
+// imbalance they removed.)
+constexpr int QW = 16;
+struct AtomQueue {
+    uint32_t *ctr;        // LDS: the next position nobody has taken
+    int64_t base, stride;
+    int lane;
+    uint32_t v;           // lane 0: the position a request in flight returns
+    __device__ __forceinline__ AtomQueue(uint32_t *c, int64_t first, int block, int blocks, int lane_)
+        : ctr(c), base(first + (int64_t)block * QW), stride((int64_t)blocks * QW), lane(lane_), v(0u) {}
+    __device__ __forceinline__ int64_t atom(uint32_t p) const { return base + (int64_t)(p >> 4) * stride + (p & 15u); }
+    __device__ __forceinline__ void request() { if (lane == 0) v = atomicAdd(ctr, 1u); }
+    __device__ __forceinline__ int64_t granted() const { return atom((uint32_t)__builtin_amdgcn_readfirstlane((int)v)); }
+};
+
+constexpr int FWD_WPB = 4;      // k_aev_fwd (tangent pass)
+constexpr int FWD3_WPB = QW;    // k_aev_fwd3
+constexpr int BWD_WPB = QW;     // k_aev_bwd
 constexpr int STAGE_FLOATS = 1024;  // >= L (S<=7: 1008)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float PI_F = 3.14159265358979323846f;
@@ -592,7 +616,7 @@ __device__ __forceinline__ int wave_isum(int v)
 __device__ __forceinline__ int block_slots(int np, int I, float inv_I)
 {
     int c = (int)(((float)np + 0.5f) * inv_I);   // floor(np / I) (the half keeps the product off the integers)
-    c += (c * I < np) ? 1 : 0;
+    c += (__mul24(c, I) < np) ? 1 : 0;   // (24-bit multiply: full rate; v_mul_lo_u32 issues at a quarter of it)
     return (c + 3) & ~3;
 }
 
@@ -609,7 +633,7 @@ __device__ unsigned long long g_fwd3_trace[2048][10];
 #define TR_STAMP(k_)
 #endif
 template <int NA, int NZ, bool REC>
-__global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
+__global__ __launch_bounds__(FWD3_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
     AevArgs a, const float *__restrict__ tab, int64_t lo, int64_t hi,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
     const float4 *__restrict__ ent, float *__restrict__ aev, uint32_t *__restrict__ slab_mask,
@@ -619,10 +643,10 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
     constexpr int ZP = NZ / 2;          // packed pairs of angle shifts
     constexpr int RS = 20;              // floats per row of the reduction buffer: 16 values + 4 (bank spread)
     constexpr int XOFF = 64 * RS;       // trailing sums of DPP rows 0..2: 3 x 16 floats
-    __shared__ float4 s_ang[FWD_WPB][MAXA + 1];   // ux uy uz, 0.5 qA r          (entry nA = dummy)
-    __shared__ float s_lfc[FWD_WPB][MAXA + 2];    // log2 fc(r, Rca) + 0.5       (dummy: -inf)
-    __shared__ __attribute__((aligned(16))) float s_red[FWD_WPB][XOFF + 48];   // reduction rows (radial terms, then pair sums)
-    __shared__ __attribute__((aligned(16))) float s_rst[FWD_WPB][MAX_S * 16];  // radial part of the row until it is stored
+    __shared__ float4 s_ang[FWD3_WPB][MAXA + 1];   // ux uy uz, 0.5 qA r          (entry nA = dummy)
+    __shared__ float s_lfc[FWD3_WPB][MAXA + 2];    // log2 fc(r, Rca) + 0.5       (dummy: -inf)
+    __shared__ __attribute__((aligned(16))) float s_red[FWD3_WPB][XOFF + 48];   // reduction rows (radial terms, then pair sums)
+    __shared__ __attribute__((aligned(16))) float s_rst[FWD3_WPB][MAX_S * 16];  // radial part of the row until it is stored
 
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     float4 *ang = s_ang[wib];
@@ -665,8 +689,12 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
     const int L4 = a.L >> 2, R4 = a.radlen >> 2;
     const int rslabs = (a.S + 1) >> 1;
 
-    const int64_t nw = (int64_t)gridDim.x * FWD_WPB;
-    int64_t i = lo + xcd_block() * (int64_t)FWD_WPB + wib;
+    // atoms from the workgroup's queue (AtomQueue); the first three positions of a wave are its own
+    __shared__ uint32_t s_queue;
+    if (threadIdx.x == 0) s_queue = 3u * FWD3_WPB;
+    __syncthreads();
+    AtomQueue q(&s_queue, lo, xcd_block(), (int)gridDim.x, lane);
+    int64_t i = q.atom(wib), i1 = q.atom(FWD3_WPB + wib), i2 = q.atom(2 * FWD3_WPB + wib);
     uint32_t hw = hdr_load(meta, species, i, i < hi);
     AtomHdr hd = hdr_decode(hw);
     const float4 dummy4 = make_float4(1.f, 0.f, 0.f, 0.f);
@@ -678,12 +706,12 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         e0 = ent[hd.start + min(lane, nl)];
         e1 = ent[hd.start + min(lane + WAVE, nl)];
     }
-    uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
+    uint32_t hw_next = hdr_load(meta, species, i1, i1 < hi);
     // rows updated in place (a.update): what the previous call left in this row, one atom ahead like the header (wave-uniform
     // address: a scalar load); otherwise every slab counts as dirty and the whole row is written
     // (prev_mask is a buffer of its own, never written here: wave-uniform reads of it are scalar loads)
     uint32_t pm = (a.update && i < hi) ? prev_mask[i] : 0xFFFFFFFFu;
-    uint32_t pm_next = (a.update && i + nw < hi) ? prev_mask[i + nw] : 0xFFFFFFFFu;
+    uint32_t pm_next = (a.update && i1 < hi) ? prev_mask[i1] : 0xFFFFFFFFu;
     // Memory order of an atom: [loads for the NEXT atom] ... arithmetic ... [wait for those loads] [ALL stores of this atom].
     // Vector-memory operations retire in order and the compiler waits with vmcnt(0) for whatever it cannot count, so a
     // load consumed after stores were issued drains those stores first (HBM write latency, once per atom and wave).  With
@@ -697,7 +725,7 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
 #ifdef ANIHIP_TRACE
     unsigned long long tr_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
 #endif
-    for (; i < hi; i += nw) {
+    for (; i < hi; i = i1, i1 = i2, i2 = q.granted()) {
         TR_STAMP(9)   // loop overhead / tail of the previous atom
         float *out = aev + (size_t)i * a.L;
         const int nA = hd.nA, nR = hd.nA + hd.nF;
@@ -789,18 +817,18 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
         TR_STAMP(1)   // radial sums
         // ---- prefetch the next atom ----
         hd = hdr_decode(hw_next);
+        q.request();   // (the position of the atom after i2: granted by the end of this atom)
         {
-            const int64_t in = i + nw;
-            if (in < hi && hd.sp >= 0 && hd.nA + hd.nF > 0) {   // (wave-uniform; else the registers keep stale, unused values)
+            if (i1 < hi && hd.sp >= 0 && hd.nA + hd.nF > 0) {   // (wave-uniform; else the registers keep stale, unused values)
                 const int nl = hd.nA + hd.nF - 1;
                 e0 = ent[hd.start + min(lane, nl)];
                 e1 = ent[hd.start + min(lane + WAVE, nl)];
             }
-            hw_next = hdr_load(meta, species, in + nw, in + nw < hi);
+            hw_next = hdr_load(meta, species, i2, i2 < hi);
         }
         const uint32_t prev_m = pm;
         pm = pm_next;
-        pm_next = (a.update && i + 2 * nw < hi) ? prev_mask[i + 2 * nw] : 0xFFFFFFFFu;
+        pm_next = (a.update && i2 < hi) ? prev_mask[i2] : 0xFFFFFFFFu;
         // results that wait for the end of the atom: radial part in LDS (rst), the angular blocks of the last batch in the
         // neighbor table's LDS (dead by then: ang[lane] / ang[64 + lane] of the lanes flagged hold_last, destination hold_dst)
         bool hold_last = false;
@@ -854,9 +882,9 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
                 const float inv_div = div > 0 ? __builtin_amdgcn_rcpf((float)div) : 0.f;
                 const int rect = same ? nj * div : 0x7FFFFFFF;
                 const int half = nj >> 1;
-                int t = (lane - mys0) * I;
+                int t = __mul24(lane - mys0, I);
                 int qd = (int)(((float)t + 0.5f) * inv_div);
-                int rem = t - qd * div;
+                int rem = t - __mul24(qd, div);
                 // (no zero fill of the 32 sums: the first pair of a slot writes them, the others add -- the zero fill was 64
                 // moves per batch, the compiler cleared the registers once for the loop and once for "no iteration")
                 v2f acc[NA][ZP];
@@ -1008,8 +1036,10 @@ __global__ __launch_bounds__(FWD_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3(
             float4 *out4 = reinterpret_cast<float4 *>(out);
             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
             const uint32_t touch = prev_m | now_m;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {   // float4 slot f of the row belongs to block bit sb, slab sl
+            // (an update whose flags did not lose a slab -- the steady state of a simulation -- has nothing to clear outside
+            // the radial part: one pass instead of four, wave-uniform)
+            const int m_end = (prev_m & ~now_m) == 0u ? 1 : 4;
+            for (int m = 0; m < m_end; ++m) {   // float4 slot f of the row belongs to block bit sb, slab sl
                 const int f = lane + WAVE * m;
                 const int sb = f < R4 ? (f >> 2) : 7 + ((f - R4) >> 3);
                 const int sl = f < R4 ? (f >> 3) : rslabs + ((f - R4) >> 3);
@@ -1090,6 +1120,7 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
     __shared__ float s_g[BWD_WPB][3][MAXA];   // gradient on neighbor k accumulated by part: [component][part * n + k]
     __shared__ __attribute__((aligned(16))) float s_stage[BWD_WPB][STAGE_FLOATS];
     __shared__ uint16_t s_ptab[64];           // byte offset of the angular block of species pair (sj, sk) in a row
+    __shared__ uint32_t s_queue;              // AtomQueue: the next position of this workgroup's atom list
 
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = lane_id();
     float4 *nb = s_nb[wib];
@@ -1101,6 +1132,7 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
         const int l_ = min(sj, sk), h_ = max(sj, sk);
         const int P = l_ * a.S - ((l_ * (l_ - 1)) >> 1) + (h_ - l_);
         s_ptab[threadIdx.x] = h_ < a.S ? (uint16_t)((a.radlen + 32 * P) * 4) : (uint16_t)0;
+        if (threadIdx.x == 0) s_queue = 3u * BWD_WPB;
     }
     __syncthreads();
 
@@ -1146,10 +1178,12 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
         return __ballot(nd && lane < 35);
     };
 
-    const int nw = (int)gridDim.x * BWD_WPB;
-    int i = lo + xcd_block() * BWD_WPB + wib;
+    // atoms from the workgroup's queue (AtomQueue); the first three positions of a wave are its own
+    // (s_queue is set before the barrier above)
+    AtomQueue q(&s_queue, lo, xcd_block(), (int)gridDim.x, lane);
+    int i = (int)q.atom(wib), i1 = (int)q.atom(BWD_WPB + wib), i2 = (int)q.atom(2 * BWD_WPB + wib);
     // software pipeline over atoms: the header, the first 128 neighbor entries and the needed blocks of the dE/dAEV
-    // row of atom i+nw are in flight while atom i is processed
+    // row of the wave's next atom are in flight while atom i is processed
     uint32_t hw = hdr_load(meta, species, i, i < hi);
     AtomHdr h = hdr_decode(hw);
     // (the prefetched values are kept as 128-bit vector values, not float4 structs: a struct is split into four scalars
@@ -1176,12 +1210,12 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
         if ((need_ >> slot_of(lane + 3 * WAVE)) & 1ull) gr3 = g4_[lane + 3 * WAVE];                                   \
     }
     ANIHIP_BWD_ISSUE(i, h)
-    uint32_t hw_next = hdr_load(meta, species, i + nw, i + nw < hi);
+    uint32_t hw_next = hdr_load(meta, species, i1, i1 < hi);
 #ifdef ANIHIP_TRACE
     unsigned long long tr_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
 #endif
 
-    for (; i < hi; i += nw) {
+    for (; i < hi; i = i1, i1 = i2, i2 = (int)q.granted()) {
         TR_STAMP(0)   // loop head
         const int nA = h.nA, nR = h.nA + h.nF;
         const bool skip = h.sp < 0 || nR == 0;
@@ -1280,8 +1314,9 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
         // prefetch the next atom
         h = hdr_decode(hw_next);
         TR_STAMP(2)   // phase 1: neighbor terms, radial gather
-        ANIHIP_BWD_ISSUE(i + nw, h)
-        hw_next = hdr_load(meta, species, i + 2 * nw, i + 2 * nw < hi);
+        q.request();   // (the position of the atom after i2: granted by the end of this atom)
+        ANIHIP_BWD_ISSUE(i1, h)
+        hw_next = hdr_load(meta, species, i2, i2 < hi);
         if (skip) continue;
         wave_sync();
         TR_STAMP(3)   // prefetch issue
@@ -1544,7 +1579,8 @@ static int aev_forward(void *stream, const anihip_aev_params *p, const float *ta
     if (int rc = make_args(p, &a)) return rc;
     a.update = update ? 1 : 0;
     if (hi == lo) return 0;
-    dim3 grid(persistent_blocks(hi - lo, FWD_WPB, ANIHIP_FWD3_WAVES)), block(FWD_WPB * WAVE);
+    // (one workgroup of 16 waves per CU: ANIHIP_FWD3_WAVES per SIMD)
+    dim3 grid(persistent_blocks(hi - lo, FWD3_WPB, ANIHIP_FWD3_WAVES * 4 / FWD3_WPB)), block(FWD3_WPB * WAVE);
     const bool rec = (p->flags & ANIHIP_AEV_UNIFORM_SHFA) != 0 && ANIHIP_FWD3_REC;
 #define ANIHIP_LAUNCH_FWD3(NA_, NZ_, REC_)                                                                              \
     hipLaunchKernelGGL((k_aev_fwd3<NA_, NZ_, REC_>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species, meta, \
@@ -1619,7 +1655,7 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
     if (int rc = make_args(p, &a)) return rc;
     if (virial) zero_words_async((hipStream_t)stream, virial, 9 * sizeof(double));
     if (hi == lo) return 0;
-    dim3 grid(persistent_blocks(hi - lo, BWD_WPB, ANIHIP_BWD_WAVES)), block(BWD_WPB * WAVE);
+    dim3 grid(persistent_blocks(hi - lo, BWD_WPB, ANIHIP_BWD_WAVES * 4 / BWD_WPB)), block(BWD_WPB * WAVE);
     const float4 *e4 = (const float4 *)ent;
     hipStream_t st = (hipStream_t)stream;
     const bool symmetric = (flags & ANIHIP_BWD_SYMMETRIC) != 0, fixed = (flags & ANIHIP_BWD_FIXED_POINT) != 0;
