@@ -665,9 +665,11 @@ __device__ __forceinline__ void emit_from_stage(const float4 *cand, const uint16
 // actually occur (packed byte counters in scalar registers) and written in the same order as k_nbr_cell writes it.
 // Bins with more candidates than the stage holds, or stencils of more than 64 bins (cells thinner than the cutoff),
 // are left to k_nbr_cell (handled[c] = 0, counted in n_unhandled).
-constexpr int NBR2_WPB = 4;
-constexpr int CAND_CAP = 448;   // (7 KB + 1 KB of hit positions, which the staging tables share: 8 KB of LDS per wave,
-                                // 20 waves per CU)
+// ONE workgroup of 16 waves per CU whose waves take the workgroup's bins (b, b + blocks, ... in groups of 16) from an LDS
+// counter: with a fixed share per wave the waves of a SIMD finish far apart (the issue arbiter favours the oldest) and
+// the tail of the kernel runs on a few waves per SIMD (as in the AEV kernels, aev.hip AtomQueue).
+constexpr int NBR2_WPB = 16;
+constexpr int CAND_CAP = 448;   // (7 KB + 1 KB of hit positions, which the staging tables share: 8 KB of LDS per wave)
 #ifdef ANIHIP_TRACE
 // development: per-phase shader-clock sums of wave 0 of every block (s_memtime stamps), read by anihip_dev_nbr_trace_read
 __device__ unsigned long long g_nbr_trace[1024][10];
@@ -688,7 +690,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(NBR2_WPB * WAVE, 5) void k_nbr_cell2(
+__global__ __launch_bounds__(NBR2_WPB * WAVE, 4) void k_nbr_cell2(
     const GridDesc *g, int S, float rcr2, float rca2, int64_t lo, int64_t hi, const int *cellid,
     const int *cell_start, const float4 *pos4s, int row_cap, uint32_t *meta, float4 *ent, uint32_t *status,
     int *handled, int *n_unhandled)
@@ -718,10 +720,17 @@ __global__ __launch_bounds__(NBR2_WPB * WAVE, 5) void k_nbr_cell2(
     const float inv_n2 = 1.0f / (float)n2, inv_n1 = 1.0f / (float)n1;
     const int nbins = nb0 * nb1 * nb2;
     const int nw = gridDim.x * NBR2_WPB;
+    // position p of the workgroup's bin list = bin (p / 16) * all waves + 16 * workgroup + p % 16; the first one is the wave's own
+    __shared__ uint32_t s_queue;
+    if (threadIdx.x == 0) s_queue = NBR2_WPB;
+    __syncthreads();
+    auto bin_at = [&](uint32_t p) { return (int)(p / NBR2_WPB) * nw + (int)blockIdx.x * NBR2_WPB + (int)(p % NBR2_WPB); };
+    uint32_t qv = 0u;   // lane 0: the position the request in flight returns
 #ifdef ANIHIP_TRACE
     unsigned long long tr_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_last = __builtin_amdgcn_s_memtime();
 #endif
-    for (int c = blockIdx.x * NBR2_WPB + wib; c < nbins; c += nw) {
+    for (int c = bin_at(wib); c < nbins; c = bin_at((uint32_t)__builtin_amdgcn_readfirstlane((int)qv))) {
+        if (lane == 0) qv = atomicAdd(&s_queue, 1u);   // (the bin after this one: granted long before the bin is done)
         NTR_STAMP(0)   // loop tail
         const int ab = cell_start[c], ae = cell_start[c + 1];
         if (ae == ab) continue;
@@ -1139,7 +1148,7 @@ extern "C" int anihip_nbr_build_cell(void *stream_, const anihip_aev_params *p, 
     zero_words_async(stream, n_unhandled, sizeof(int));
     const int rc = (int)(row_cap > MAXR ? MAXR : row_cap);
     int64_t bins_blocks = (max_cells + NBR2_WPB - 1) / NBR2_WPB;
-    if (bins_blocks > 256 * 5) bins_blocks = 256 * 5;   // persistent: 20 waves per CU, each strides over the bins
+    if (bins_blocks > 256) bins_blocks = 256;   // persistent: one workgroup of 16 waves per CU
     hipLaunchKernelGGL(k_nbr_cell2, dim3((unsigned)bins_blocks), dim3(NBR2_WPB * WAVE), 0, stream, w.desc,
                        p->num_species, p->Rcr * p->Rcr, p->Rca * p->Rca, lo, hi, w.cellid, w.cell_start, w.pos4s, rc,
                        meta, (float4 *)ent, status, handled, n_unhandled);
