@@ -12,7 +12,9 @@ import numpy as np
 
 tw = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 8, 32).astype(np.int64)   # [item][wave][stamp]
 END = 15
-tw = tw[(tw[:, 0, 0] > 0) & (tw[:, 0, END] > 0)]
+keep = (tw[:, 0, 0] > 0) & (tw[:, 0, END] > 0)
+item_of = np.nonzero(keep)[0]
+tw = tw[keep]
 l0b = bool((tw[:, 0, 13] > 0).all())   # phase 5 (layer-0 backward inside the kernel) stamps 13 and 8
 if l0b:
     STAMPS = [0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 12, 16, 17, 13, 19, 20, 21, 8, END]
@@ -38,3 +40,23 @@ for w in range(8):
     ok = tw[:, w, END] > 0
     rel = tw[ok][:, w, :][:, STAMPS] - tw[ok][:, 0, 0][:, None]
     print(f"  wave {w}: " + " ".join(f"{v:7.0f}" for v in rel.mean(axis=0)))
+
+# owner order (layer-0 backward inside): workgroup b owns tiles b, b + grid, ...; how far apart do the workgroups finish?
+if l0b:
+    grid = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    wg = (item_of // 8) % grid
+    first = np.full(grid, np.iinfo(np.int64).max)
+    last = np.zeros(grid, dtype=np.int64)
+    np.minimum.at(first, wg, tw[:, 0, 0])
+    np.maximum.at(last, wg, tw[:, 0, END])
+    n_items = np.bincount(wg, minlength=grid)
+    dur = (last - first).astype(np.float64)
+    ok = n_items > 0
+    print(f"workgroups {ok.sum()}: items per workgroup {n_items[ok].min()}..{n_items[ok].max()}; busy span (first start -> last end, own clock) "
+          f"min {dur[ok].min() / dur[ok].mean():.4f}  max {dur[ok].max() / dur[ok].mean():.4f} of the mean {dur[ok].mean():.0f} ticks, std {dur[ok].std() / dur[ok].mean():.4f}")
+    # per XCD (slot 14 low word: HW_ID; high word: XCC_ID)
+    xcc = (tw[:, 0, 14] >> 32) & 0xF
+    for x in np.unique(xcc):
+        m = xcc == x
+        tt = (tw[m][:, 0, END] - tw[m][:, 0, 0])
+        print(f"  XCC {int(x)}: {m.sum()} items, mean item {tt.mean():.0f} ticks")
