@@ -2400,25 +2400,31 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             // bounds it -- one v_max3_f32 per element pair instead of two |.| and three max (a quarter of this epilogue's
             // VALU instructions went into the absolute values)
             float vmax = ACT == 1 ? 0.17f : alpha;
+            // (ONE branch per row block, not per element pair: with the test inside the pair loop the compiler emitted a
+            // scalar branch between any two pairs and their dependent chains -- fma, mul, exp, fma, med3 -- ran one after
+            // the other; inside one block the scheduler interleaves them)
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < RB; ++rb) {
+                if (rb < u1.nrb) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int i = rb * NB + nb;
-                        if (rb < u1.nrb) {
+                        for (int r = 0; r < 16; r += 2) {
+                            const int i = rb * NB + nb;
                             float v0, v1;
                             celu_d2(acc[i][r], acc[i][r + 1], oscale, bias0[nb][r], bias0[nb][r + 1], v0, v1, d0f[i][r],
                                     d0f[i][r + 1]);
                             acc[i][r] = v0;
                             acc[i][r + 1] = v1;
                             if (NB == 1 || nb < u1.nba) vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(v0, v1));
-                        } else {   // (defined on every path, like the rings)
-                            d0f[i][r] = 0.f;
-                            d0f[i][r + 1] = 0.f;
                         }
-                    }
+                } else {   // (defined on every path, like the rings)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) d0f[rb * NB + nb][r] = 0.f;
+                }
+            }
             a0max = tile_max(vmax);   // (barriers: every wave is past the staging slots)
         }
         const float s0 = pow2_scale_for(a0max);
@@ -2444,23 +2450,26 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             if (C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, u2);
             const float oscale = fs.is1 / s0;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < RB; ++rb) {
+                if (rb < u2.nrb) {   // (one branch per row block: see the layer-0 epilogue)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int i = rb * NB + nb;
-                        if (rb < u2.nrb) {
+                        for (int r = 0; r < 16; r += 2) {
+                            const int i = rb * NB + nb;
                             float dl0, dl1, y0, y1;
                             celu_d2(acc[i][r], acc[i][r + 1], oscale, bias1[nb][r], bias1[nb][r + 1], y0, y1,
                                     C::LAZY ? dl0 : d1f[i][r], C::LAZY ? dl1 : d1f[i][r + 1]);
                             acc[i][r] = y0;
                             acc[i][r + 1] = y1;
-                        } else {   // (defined on every path, like the rings)
-                            d1f[i][r] = 0.f;
-                            d1f[i][r + 1] = 0.f;
                         }
-                    }
+                } else {   // (defined on every path, like the rings)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) d1f[rb * NB + nb][r] = 0.f;
+                }
+            }
             put_acc(X1, x1_plane, ld1, s1, u2);
         }
         __syncthreads();  // X1 complete; every wave is done reading X0 -> XU reusable
