@@ -987,6 +987,56 @@ def test_layer0_backward_inside_the_fused_kernel(dev, elements):
     assert res["max_dE_atom"] < 1e-6 * max(1.0, float(out.atomic_energies.abs().max())) and res["max_dF"] < 5e-6 * fmax
 
 
+def test_forward_backward_workspace_is_what_the_call_touches(dev):
+    """anihip_mlp_forward_backward_workspace_bytes (ABI 10): a call runs in EXACTLY the bytes the query reports -- behind
+    them a guard region keeps its pattern -- for the three shapes of the call: layer-0 backward inside the fused kernel
+    (forced here; the default from 65 536 atoms: ~100 B per atom), the d act0 hand-over (8 KB per atom of the first
+    hidden layer only), and no gradient at all; one byte less is refused.  The general query stays an upper bound."""
+    import ctypes as C
+
+    from bench import water_box
+
+    sp_np, x_np, cell_np = water_box(18)
+    sp = torch.from_numpy(sp_np).to(dev).to(torch.int32)
+    x, cell = torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    model = get_model("ani2x", 31, dev, neighborlist="cell", row_capacity=192)
+    eng = model.aev_computer.engine()
+    packed = model.neural_networks._pack(dev)
+    nbrs = eng.neighbors(sp, x, cell, (True, True, True), mode="cell", row_cap=192)
+    aev = eng.forward(sp, nbrs)
+    n = sp.numel()
+    L = _lib.lib()
+    full = L.anihip_mlp_workspace_bytes(C.byref(packed.desc), n)
+    ref_e = None
+    try:
+        for name, flags, want_grad in (("inside", _lib.MLP_FLAG_FUSED_L0B, True), ("hand-over", _lib.MLP_FLAG_NO_FUSED_L0B, True),
+                                       ("energies only", 0, False)):
+            packed.desc.flags = flags
+            need = L.anihip_mlp_forward_backward_workspace_bytes(C.byref(packed.desc), n, int(want_grad))
+            assert 0 < need <= full
+            if name == "inside":
+                assert need < 400 * n + (1 << 20)      # index lists, tile table, per-member energies
+            if name == "hand-over":
+                assert 8 * 256 * 4 * n <= need < 8 * 256 * 4 * n + 400 * n + (4 << 20)   # + d E / d act0 of 8 members
+            guard = 4096
+            ws = torch.full((need + guard,), 0xA5, dtype=torch.uint8, device=dev)
+            ae = torch.zeros(n, dtype=torch.float32, device=dev)
+            ga = torch.zeros_like(aev) if want_grad else None
+            args = lambda nbytes: (torch.cuda.current_stream().cuda_stream, C.byref(packed.desc), n, 0, n, sp.data_ptr(), aev.data_ptr(), None, ws.data_ptr(),
+                                   nbytes, ae.data_ptr(), ga.data_ptr() if want_grad else None, None)
+            assert L.anihip_mlp_forward_backward(*args(need - 1)) != 0 and b"workspace too small" in L.anihip_last_error()
+            _lib.check(L.anihip_mlp_forward_backward(*args(need)))
+            torch.cuda.synchronize()
+            assert bool((ws[need:] == 0xA5).all()), name
+            if ref_e is None:
+                ref_e = ae.clone()
+            assert torch.equal(ae, ref_e), name       # (the forward phases are the same arithmetic in all three)
+            report(f"ws    {name:14s}: {need / n:8.1f} B per atom (general query: {full / n:.1f})")
+    finally:
+        packed.desc.flags = 0
+        packed.flags = None
+
+
 def test_layer0_backward_inside_the_fused_kernel_gelu(dev):
     """The same for the GELU / bias-free networks of the ANI-2xr family (k_mlp_fused<2, 1, GELU, L0B>): energies and forces
     with phase 5 forced equal those of the hand-over path on a 17 496-atom H / O box (the -r models' pair potentials off:
