@@ -1273,7 +1273,10 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
                                 W1.z + G1.z, W1.w + G1.w, W2.x + G2.x, W2.y + G2.y, W2.z + G2.z, W2.w + G2.w,
                                 W3.x + G3.x, W3.y + G3.y, W3.z + G3.z, W3.w + G3.w};
                 // d/dr [exp(-eta d^2) fc] = exp(..) (fc' - 2 eta d fc):  dR = fc' sum w e - 2 eta fc sum w e d
-                const float rq = qR * r;
+                float rq = qR * r;
+                // (opaque: left alone the compiler folds q r - s_k into one FMA with TWO scalar operands, which the vector ALU
+                // cannot take -- one more move per shift, 16 per pass)
+                asm volatile("" : "+v"(rq));
                 v2f AB = (v2f){0.f, 0.f};   // sum w e, sum w e (q d)
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
