@@ -742,7 +742,7 @@ __global__ __launch_bounds__(FWD3_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3
             need = __ballot(nd && lane < 35);
             // The radial list is kept GROUPED BY SPECIES, every group padded to a multiple of 8 entries with fc = 0 (the row
             // itself is sorted {angular, far} x species): the radial loop below then walks 8 consecutive entries per step
-            // with no index arithmetic and no validity select (17 -> 8 vector instructions per step, 8 steps per water atom).
+            // with no index arithmetic and no validity select (17 -> 9 vector instructions per step, 8 steps per water atom).
             // Entry e of the row goes to e + shift, the shift of its {class, species} segment: two compare-selects per
             // present species (the last segment whose start is <= e wins; wave-uniform bounds, scalar loop).
             const uint64_t prA2 = pkA * 0x0101010101010100ull, prF2 = pkF * 0x0101010101010100ull;
@@ -1583,7 +1583,7 @@ static int aev_forward(void *stream, const anihip_aev_params *p, const float *ta
     a.update = update ? 1 : 0;
     if (hi == lo) return 0;
     // (one workgroup of 16 waves per CU: ANIHIP_FWD3_WAVES per SIMD)
-    dim3 grid(persistent_blocks(hi - lo, FWD3_WPB, ANIHIP_FWD3_WAVES * 4 / FWD3_WPB)), block(FWD3_WPB * WAVE);
+    dim3 grid(persistent_blocks(hi - lo, FWD3_WPB, (ANIHIP_FWD3_WAVES * 4 + FWD3_WPB - 1) / FWD3_WPB)), block(FWD3_WPB * WAVE);
     const bool rec = (p->flags & ANIHIP_AEV_UNIFORM_SHFA) != 0 && ANIHIP_FWD3_REC;
 #define ANIHIP_LAUNCH_FWD3(NA_, NZ_, REC_)                                                                              \
     hipLaunchKernelGGL((k_aev_fwd3<NA_, NZ_, REC_>), grid, block, 0, (hipStream_t)stream, a, table, lo, hi, species, meta, \
@@ -1658,7 +1658,7 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
     if (int rc = make_args(p, &a)) return rc;
     if (virial) zero_words_async((hipStream_t)stream, virial, 9 * sizeof(double));
     if (hi == lo) return 0;
-    dim3 grid(persistent_blocks(hi - lo, BWD_WPB, ANIHIP_BWD_WAVES * 4 / BWD_WPB)), block(BWD_WPB * WAVE);
+    dim3 grid(persistent_blocks(hi - lo, BWD_WPB, (ANIHIP_BWD_WAVES * 4 + BWD_WPB - 1) / BWD_WPB)), block(BWD_WPB * WAVE);
     const float4 *e4 = (const float4 *)ent;
     hipStream_t st = (hipStream_t)stream;
     const bool symmetric = (flags & ANIHIP_BWD_SYMMETRIC) != 0, fixed = (flags & ANIHIP_BWD_FIXED_POINT) != 0;
