@@ -211,3 +211,54 @@ def test_many_small_blocks_run_in_batches():
     rng = np.random.default_rng(2)
     n_batches, _ = check([2, 2, 2, 2, 2, 2, 2], rng)   # 28 blocks of 1-4 pairs: 28 x 4 padded slots > 64
     assert n_batches >= 2
+
+
+def rad_positions(cA, cF):
+    """The kernel's rad_pos (aev.hip): entry e of a row sorted {angular, far} x species goes to e + the shift of its segment;
+    the radial list is then grouped by species, every group padded to a multiple of 8 entries."""
+    S = len(cA)
+    nA, nR = int(sum(cA)), int(sum(cA) + sum(cF))
+    prA = np.concatenate([[0], np.cumsum(cA)[:-1]]).astype(int)
+    prF = np.concatenate([[0], np.cumsum(cF)[:-1]]).astype(int)
+    need = [t for t in range(S) if cA[t] + cF[t] > 0]
+    e = np.arange(((nR + 63) // 64) * 64)
+    shA, shF, base = np.zeros_like(e), np.zeros_like(e), 0
+    groups = {}
+    for t in need:                      # (scalar loop over the present species, ascending)
+        oA, oF = prA[t], nA + prF[t]
+        shA = np.where(e >= oA, base - oA, shA)
+        shF = np.where(e >= oF, base + cA[t] - oF, shF)
+        groups[t] = (base, cA[t] + cF[t])
+        base += (cA[t] + cF[t] + 7) & ~7
+    pos = e + np.where(e < nA, shA, shF)
+    return pos[:nR], groups, base
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_radial_list_grouped_by_species(seed):
+    rng = np.random.RandomState(seed)
+    S = int(rng.randint(1, 8))
+    dens = rng.choice([0.0, 0.3, 1.0], size=S)
+    cA = (rng.poisson(6, size=S) * (rng.rand(S) < dens)).astype(int)
+    cF = (rng.poisson(14, size=S) * (rng.rand(S) < dens)).astype(int)
+    if cA.sum() + cF.sum() == 0:
+        cF[0] = 1
+    if cA.sum() > 128 or (cA + cF).sum() > 256:
+        pytest.skip("beyond the row limits")
+    pos, groups, total = rad_positions(cA, cF)
+    nA = cA.sum()
+    # species of every row entry: angular part sorted by species, then the far part sorted by species
+    sp_of = np.concatenate([np.repeat(np.arange(S), cA), np.repeat(np.arange(S), cF)])
+    assert len(np.unique(pos)) == len(pos) and pos.min() >= 0 and pos.max() < total   # a placement without collisions
+    for t, (base, n) in groups.items():
+        mine = np.sort(pos[sp_of == t])
+        assert (mine == base + np.arange(n)).all()                # the species' entries fill the head of its group ...
+        assert base % 8 == 0                                       # ... groups start on multiples of 8 (the 8-slot steps)
+    assert total <= len(pos) + 7 * len(groups) and total % 8 == 0 and total <= 256 + 49
+    # inside a group the angular entries come first, in row order (the order of summation of the radial sums is fixed)
+    for t, (base, n) in groups.items():
+        a = pos[:nA][sp_of[:nA] == t]
+        f = pos[nA:][sp_of[nA:] == t]
+        assert (np.diff(a) == 1).all() and (np.diff(f) == 1).all()
+        if len(a) and len(f):
+            assert a.max() + 1 == f.min()
