@@ -443,6 +443,16 @@ def test_integration_section_a_against_the_live_reference():
         x = torch.rand(1, 5, 3)
         with pytest.raises(ValueError, match="ROCm device"):
             torchani.grad.energies_and_forces(ref, z, x)
+        # the autograd helpers have the reference's signatures (names, order, defaults; this package's extra keywords come
+        # BEHIND them) and its result type
+        import inspect
+
+        for fn in ("forces", "grads", "forces_for_training", "energies_and_forces", "single_point"):
+            pr = list(inspect.signature(getattr(torchani.grad, fn)).parameters.values())
+            pa = list(inspect.signature(getattr(torchani_amd.grad, fn)).parameters.values())
+            assert [(p.name, p.default) for p in pa[:len(pr)]] == [(p.name, p.default) for p in pr], fn
+        assert torchani_amd.tuples.EnergiesForces._fields == torchani.tuples.EnergiesForces._fields
+        assert set(torchani_amd.grad.__all__) <= set(torchani.grad.__all__)
     finally:
         sys.path.remove("/root/reference")
 

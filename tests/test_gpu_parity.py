@@ -1214,11 +1214,33 @@ def test_partition_skin_reuses_the_shards_while_atoms_move(dev):
     x3 = x2 + 0.0
     d = model._spatial_partition(sp32, x3.view(-1, 3), cell, pbc, 1, world)            # renewed now
     assert b is a and c is a and d is not a
-    x4 = x3 + 0.4                                                                        # 0.69 A > skin / 2 in ONE step:
-    e = model._spatial_partition(sp32, x4.view(-1, 3), cell, pbc, 1, world)            # that step ran on the old halo ...
-    assert e is d
-    with pytest.raises(RuntimeError, match="partition_skin"):                           # ... and the next one says so
-        model._spatial_partition(sp32, (x4 + 0.0).view(-1, 3), cell, pbc, 1, world)
+    # the FIRST moved step behind a cut has no flags of a previous step to go by: it reads its own at once (same-step guard)
+    x4 = x3 + 0.4                                                                        # 0.69 A > skin / 2 in ONE step
+    e = model._spatial_partition(sp32, x4.view(-1, 3), cell, pbc, 1, world)
+    assert e is not d                                                                    # ... renewed in the same step
+    # in a steady loop the flags are read one step late: a jump inside ONE step runs on the old halo and the NEXT call raises
+    x5 = x4 + 0.01
+    f5 = model._spatial_partition(sp32, x5.view(-1, 3), cell, pbc, 1, world)           # (verified at once, flags queued)
+    x6 = x5 + 0.4
+    f6 = model._spatial_partition(sp32, x6.view(-1, 3), cell, pbc, 1, world)           # the flags of x5 say "fine": kept
+    assert f5 is e and f6 is e
+    with pytest.raises(RuntimeError, match="partition_skin"):                           # ... and the next call says so
+        model._spatial_partition(sp32, (x6 + 0.0).view(-1, 3), cell, pbc, 1, world)
+    # ... or check_partition() behind the last step of a loop
+    model.__dict__.pop("_spatial_cache", None)
+    a = model._spatial_partition(sp32, x0.view(-1, 3), cell, pbc, 1, world)
+    model._spatial_partition(sp32, (x0 + 0.01).view(-1, 3), cell, pbc, 1, world)
+    assert model._spatial_partition(sp32, (x0 + 0.4).view(-1, 3), cell, pbc, 1, world) is a
+    with pytest.raises(RuntimeError, match="partition_skin"):
+        model.check_partition()
+    # partition_check = "strict": every step reads its own flags before it is evaluated -- never a stale halo
+    model.partition_check = "strict"
+    a = model._spatial_partition(sp32, x0.view(-1, 3), cell, pbc, 1, world)
+    b = model._spatial_partition(sp32, (x0 + 0.01).view(-1, 3), cell, pbc, 1, world)
+    c = model._spatial_partition(sp32, (x0 + 0.4).view(-1, 3), cell, pbc, 1, world)
+    assert b is a and c is not a
+    model.check_partition()
+    model.partition_check = "lagged"
     # another species tensor (other padding atoms) never reuses the partition
     model.__dict__.pop("_spatial_cache", None)
     a = model._spatial_partition(sp32, x0.view(-1, 3), cell, pbc, 1, world)
@@ -1239,7 +1261,8 @@ def test_autograd_path_equals_fused(dev, name):
     assert not x.requires_grad
     assert np.abs(f.cpu().numpy() - g["forces"]).max() < F_TOL
     assert torch.allclose(f, out.forces, atol=2e-6)
-    assert np.abs(e.double().cpu().numpy() - g["energies"]).max() < 2e-6 * np.abs(g["energies"]).max()
+    assert e.requires_grad   # (the reference's tuple: energies keep their graph, grad.py:263-290)
+    assert np.abs(e.detach().double().cpu().numpy() - g["energies"]).max() < 2e-6 * np.abs(g["energies"]).max()
     # NN-only energies with the shifter disabled (arch.py:136-142)
     model.set_enabled("energy_shifter", False)
     e_nn = model((sp, x), cell, pbc_t).energies

@@ -284,6 +284,41 @@ def test_force_training_autograd_matches_reference(dev, base):
     assert abs(np.abs(got).max() - scale) < 1e-4 * scale
 
 
+def test_force_training_through_grad_energies_and_forces(dev):
+    """grad.energies_and_forces(..., create_graph=True) -- the reference's signature, grad.py:263-290 -- returns forces that
+    can be trained on: the parameter gradients of a force loss equal those of the hand-written recipe above."""
+    from torchani_amd.grad import energies_and_forces
+    from torchani_amd.tuples import EnergiesForces
+
+    base = FGRAD_NAMES[0]
+    g = load_golden(base)
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    cell = None if g["cell"] is None else torch.from_numpy(g["cell"]).to(dev)
+    pbc = None if g["pbc"] is None else torch.tensor([bool(b) for b in g["pbc"]])
+    t = torch.from_numpy(fgrad_direction(g["species"]).astype(np.float32)).to(dev)
+    got = []
+    for route in ("helper", "manual"):
+        model = fresh_model(g["kind"], g["seed"], dev, g["cutoff_fn"])
+        model.aev_computer.row_capacity = 256
+        nets = model.neural_networks
+        nets.requires_grad_(True)
+        x = torch.from_numpy(g["coords"]).to(dev)
+        if route == "helper":
+            out = energies_and_forces(model, sp, x, cell, pbc, create_graph=True)
+            assert isinstance(out, EnergiesForces) and out.forces.requires_grad and not x.requires_grad
+            energies, forces = out
+            loss = (forces * t).sum()
+        else:
+            x.requires_grad_(True)
+            e = model((sp, x), cell, pbc).energies.sum()
+            (gx,) = torch.autograd.grad(e, x, create_graph=True)
+            loss = -(gx * t).sum()
+        loss.backward()
+        got.append(flat_from_params(nets, model.symbols))
+    scale = np.abs(got[1]).max()
+    assert scale > 0 and np.abs(got[0] - got[1]).max() < 1e-6 * scale
+
+
 @pytest.mark.parametrize("base", ["rand_batch_ani2x", "water_pbc_ani2x"])
 def test_training_the_gelu_networks_of_the_2xr_family(dev, base):
     """Round 4: the training passes also serve the GELU / bias-free networks of ANI-2xr / 2dr (the reference trains them

@@ -3395,7 +3395,9 @@ static FbPlan fb_plan(const anihip_mlp_desc *d, int64_t n, bool want_grad)
     // backward launch.  Tiles are then the unit of work (not tile x member items), so it needs enough of them to balance
     // over the CUs: from 65536 atoms on (1024 tiles).  Smaller inputs keep the member-major sweep + a backward GEMM.
     // (phase 5 hands partial sums between waves through 32 KB of LDS in X1's place: 2 planes x 64 rows x (H2 + 8) halves)
-    auto l0b_ok = [&](int s) { return d->net[s].wthf[0] != nullptr && d->net[s].dims[2] >= 128; };
+    // (... and its k range is cut in two halves of >= 2 steps each for the two waves of a SIMD: first hidden layers of >= 64
+    // columns -- with 32 the first half would be empty and its ring would read in front of the member's planes)
+    auto l0b_ok = [&](int s) { return d->net[s].wthf[0] != nullptr && d->net[s].dims[2] >= 128 && d->net[s].dims[1] >= 64; };
     p.fused_l0b = p.fused && want_grad && p.fused_rows == 64 && n >= FUSED_L0B_MIN_ATOMS &&
                   !(d->flags & (ANIHIP_MLP_FLAG_NO_FUSED_L0B | ANIHIP_MLP_FLAG_SMALL_TILES));
     if (d->flags & ANIHIP_MLP_FLAG_FUSED_L0B)   // (forced, e.g. by the tests on small inputs; the call checks that it can)

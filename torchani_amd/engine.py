@@ -286,7 +286,8 @@ class AevEngine:
         _require_cuda(species)
         n = species.numel()
         rows = (nbrs.hi - nbrs.lo) if shard_rows else n
-        key = (n, nbrs.lo, nbrs.hi, rows, species.device)
+        # (the stream is part of the key: the kept pair is ordered by the stream that updates it, another stream gets its own)
+        key = (n, nbrs.lo, nbrs.hi, rows, species.device, _stream())
         hit = self.__dict__.get("_rows_kept")
         if hit is None or hit[0] != key:
             self.__dict__["_rows_kept"] = None   # (release the old pair before the new one is allocated)
@@ -302,6 +303,41 @@ class AevEngine:
             _ptr(prev), _ptr(mask), _ptr(nbrs.status)))
         hit[2], hit[3] = mask, prev
         return out, mask
+
+    def release_rows(self) -> None:
+        """Free the buffers ``forward_update`` keeps (4 KB per central atom + two flag words per atom); the next call
+        allocates and fills a fresh pair."""
+        self.__dict__["_rows_kept"] = None
+        self.__dict__["_rows_seen"] = None
+
+    def rows_wanted(self, n: int, lo: int, hi: int, device: torch.device) -> bool:
+        """Policy of the callers that MAY keep rows (models.ANI.energies_and_forces): a kept pair pays off from the second
+        consecutive call with the same atom count and central range on -- a call whose sizes differ from the previous call's
+        (batched screening, one-off evaluations) works on buffers of its own, pins nothing and memsets nothing."""
+        key = (n, lo, hi, device, _stream())
+        seen = self.__dict__.get("_rows_seen")
+        self.__dict__["_rows_seen"] = key
+        if seen != key:
+            if self.__dict__.get("_rows_kept") is not None:
+                self.__dict__["_rows_kept"] = None   # (sizes changed: the old pair is of no use any more)
+            return False
+        return True
+
+    def __getstate__(self):
+        # kept rows / flags are scratch tied to this object and its stream: never copied or pickled with it
+        state = dict(self.__dict__)
+        state.pop("_rows_kept", None)
+        state.pop("_rows_seen", None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = object.__new__(type(self))
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def jvp(self, species: Tensor, nbrs: NeighborRows, tangent: Tensor) -> Tensor:
         """J t [N, L]: derivative of the AEV rows of nbrs' central atoms along the coordinate direction tangent [N, 3]

@@ -15,6 +15,8 @@ import typing as tp
 import torch
 from torch import Tensor
 
+from .tuples import EnergiesForces
+
 
 def forces(energies: Tensor, coordinates: Tensor, retain_graph: tp.Optional[bool] = None,
            create_graph: bool = False) -> Tensor:
@@ -33,6 +35,9 @@ def grads(scalars: Tensor, coords: Tensor, retain_graph: tp.Optional[bool] = Non
     """Alias of forces with the sign flipped (grad.py:68-74)."""
     return -forces(scalars, coords, retain_graph, create_graph)
 
+
+__all__ = ["single_point", "forces_for_training", "energies_and_forces", "forces", "grads", "calc_forces", "calc_grads",
+           "hessians", "forces_and_hessians", "energies_forces_and_hessians"]   # (the last three raise: see the module docstring)
 
 calc_forces = forces
 calc_grads = grads
@@ -53,17 +58,33 @@ forces_and_hessians = hessians = energies_forces_and_hessians = _no_hessians
 
 
 def energies_and_forces(model, species: Tensor, coordinates: Tensor, cell: tp.Optional[Tensor] = None,
-                        pbc: tp.Optional[Tensor] = None, charge: int = 0, atomic: bool = False,
-                        ensemble_values: bool = False, keep_vars: bool = False) -> tp.Tuple[Tensor, Tensor]:
-    """(energies, forces) through torch.autograd, restoring coordinates.requires_grad (grad.py:263-290)."""
+                        pbc: tp.Optional[Tensor] = None, retain_graph: tp.Optional[bool] = None,
+                        create_graph: bool = False, charge: int = 0, atomic: bool = False,
+                        ensemble_values: bool = False, keep_vars: bool = True) -> EnergiesForces:
+    """``EnergiesForces(energies, forces)`` through torch.autograd, restoring coordinates.requires_grad: the signature, the
+    leaf check and the result of the reference (grad.py:263-290) -- ``retain_graph`` / ``create_graph`` go to the force
+    derivative (``create_graph=True``: forces that can be trained on, tools/training-aev-benchmark.py:139-140), the energies
+    keep their graph like the reference's.  A standalone pair potential (``torchani_amd.potentials``) is called as
+    ``model(species, coordinates, cell, pbc)``.  The keywords behind ``create_graph`` are extensions of this package:
+    ``atomic`` / ``ensemble_values`` are handed to the model, ``keep_vars=False`` detaches the energies."""
+    from .potentials import _Standalone
+
     saved = coordinates.requires_grad
     coordinates.requires_grad_(True)
-    energies = model((species, coordinates), cell, pbc, atomic=atomic, ensemble_values=ensemble_values).energies
-    f = forces(energies, coordinates)
+    if not coordinates.is_leaf:
+        raise ValueError("'coordinates' passed to `torchani.grad` functions must be a 'leaf' Tensor"
+                         "(i.e. must not have been modified prior to being used as an input).")
+    if isinstance(model, _Standalone):
+        energies = model(species, coordinates, cell, pbc)
+    elif atomic or ensemble_values:
+        energies = model((species, coordinates), cell, pbc, atomic=atomic, ensemble_values=ensemble_values).energies
+    else:
+        energies = model((species, coordinates), cell, pbc).energies
+    f = forces(energies, coordinates, retain_graph=retain_graph, create_graph=create_graph)
     coordinates.requires_grad_(saved)
     if not keep_vars:
         energies = energies.detach()
-    return energies, f
+    return EnergiesForces(energies, f)
 
 
 def single_point(model, species: Tensor, coordinates: Tensor, cell: tp.Optional[Tensor] = None,

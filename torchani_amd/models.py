@@ -30,7 +30,7 @@ from .engine import FIXED_SCALE, energy_forces_finish, energy_reduce, fixed_to_f
 from .extras.electro import BaseChargeNormalizer, ChargeNormalizer  # noqa: F401
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import join_exact, shard_range, split_exact
-from .tuples import EnergiesScalars, AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, EnergiesForces, SpeciesEnergies
+from .tuples import EnergiesScalars, AtomicStdev, ForceMagnitudes, ForceStdev, SpeciesEnergiesQBC, SpeciesForces, FusedEnergiesForces, SpeciesEnergies
 from .weights import arch_gsaes, arch_networks, arch_spec, random_state_dict
 
 
@@ -183,7 +183,7 @@ class ANI(torch.nn.Module):
     def energies_and_forces(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
                             pbc: tp.Optional[tp.Sequence[bool]] = None, group=None,
                             reduce_forces: bool = True, check_overflow: bool = True,
-                            shard: tp.Optional[tp.Tuple[int, int]] = None, stress: bool = False) -> EnergiesForces:
+                            shard: tp.Optional[tp.Tuple[int, int]] = None, stress: bool = False) -> FusedEnergiesForces:
         """Energies [C] (float64, NN + self energies) and forces [C, A, 3] without autograd.
 
         check_overflow (default): read the neighbor builder's status word afterwards (one host sync) and raise --
@@ -257,7 +257,7 @@ class ANI(torch.nn.Module):
                 self._graphs.clear()
                 return None
         out = ent[1](coords.detach(), cell)
-        res = EnergiesForces(out.energies.clone(), out.forces.clone(), out.atomic_energies.clone(), None)
+        res = FusedEnergiesForces(out.energies.clone(), out.forces.clone(), out.atomic_energies.clone(), None)
         if check_overflow:
             nb = self.aev_computer.last_neighbors()
             if nb.overflowed() or self._pair_rows_overflowed():   # (let the eager path retry with larger rows / raise)
@@ -292,8 +292,13 @@ class ANI(torch.nn.Module):
 
     # The AEV rows of energies_and_forces are internal: they live in buffers the engine keeps between steps and updates in
     # place (AevEngine.forward_update: zeros are written once, a step rewrites only the slabs that were or are flagged --
-    # 0.6 KB instead of 4 KB per water atom).  False: a fresh, fully written buffer per call.
+    # 0.6 KB instead of 4 KB per water atom) -- from the second consecutive call with the same atom count and central range
+    # on (AevEngine.rows_wanted: calls whose sizes change every time pin and memset nothing); ``release_aev_rows()`` frees
+    # them (4 KB per central atom, 9.4 GB at 2.34 M atoms).  False: a fresh, fully written buffer per call.
     keep_aev_rows = True
+
+    def release_aev_rows(self) -> None:
+        self.aev_computer.engine().release_rows()
 
     @staticmethod
     def _plain_slabs(eng, packed) -> bool:
@@ -353,7 +358,7 @@ class ANI(torch.nn.Module):
                                   check_overflow, shard, stress: bool = False, tile_hint: int = 0,
                                   species_key: tp.Optional[Tensor] = None,
                                   engine_species: tp.Optional[tp.Tuple[Tensor, tp.Optional[tp.Tuple[int, ...]]]] = None
-                                  ) -> EnergiesForces:
+                                  ) -> FusedEnergiesForces:
         """The stream-ordered part of energies_and_forces (element indices int32, coords fp32 contiguous):
         no host synchronisation unless check_overflow, so it can be captured into a HIP graph."""
         C, A = species32.shape
@@ -380,8 +385,9 @@ class ANI(torch.nn.Module):
         # AEV rows and their gradients exist for this rank's central atoms only ([hi - lo, L] buffers)
         plain = self._plain_slabs(eng, packed)
         if packed.radial_len == 16 * eng.params.num_species and eng.tuned and eng.n_slabs <= 32:
-            if self.keep_aev_rows and not torch.cuda.is_current_stream_capturing():
-                # rows and flags in the engine's kept buffers, updated in place (AevEngine.forward_update)
+            if self.keep_aev_rows and not torch.cuda.is_current_stream_capturing() and eng.rows_wanted(n, lo, hi, c32.device):
+                # rows and flags in the engine's kept buffers, updated in place (AevEngine.forward_update): from the second
+                # consecutive call with these sizes on
                 aev, slab_mask = eng.forward_update(species32, nbrs)
             else:
                 # (the AEV kernel writes the flags of every central atom; the others are read by nobody, zero for tidiness)
@@ -457,7 +463,7 @@ class ANI(torch.nn.Module):
         if check_overflow:
             nbrs.raise_on_overflow()
         aevc._last_neighbors = nbrs
-        return EnergiesForces(energies, forces, atomic_e.view(C, A), virial)
+        return FusedEnergiesForces(energies, forces, atomic_e.view(C, A), virial)
 
     # ---- one big system on several ranks: spatial shards + halo (parallel.SpatialShards) ---------------------------
     partition = "spatial"   # "index": contiguous index ranges + one all-reduce of the whole force array (round-2 scheme)
@@ -501,6 +507,29 @@ class ANI(torch.nn.Module):
             reach = max(reach, (3.0 if getattr(p, "needs_all_rows", False) else 1.0) * float(p.cutoff))
         return reach
 
+    # How a kept partition (partition_skin > 0, more than one rank) is verified.  "lagged": every step queues the validity
+    # flags of its coordinates on the device and reads those of the PREVIOUS step -- no host synchronisation in a steady MD
+    # loop; a step is renewed one step after an atom has moved 0.8 x skin / 2, and a jump of more than the rest of the skin
+    # inside ONE step (frame replay, Monte-Carlo moves, optimizer jumps, a changed cell) is only noticed by the NEXT call,
+    # which raises -- call ``check_partition()`` behind the last step of such a loop.  The first moved step after a cut is
+    # always verified at once.  "strict": every step reads its own flags before it is evaluated (one host synchronisation
+    # per step) and renews the partition in the same step: never a stale halo, for drivers that move atoms arbitrarily.
+    partition_check = "lagged"
+
+    def check_partition(self) -> None:
+        """Raise if the LAST spatially sharded step was evaluated on a partition its coordinates had outrun (the flags that
+        step queued are otherwise read by the next call; ``partition_check = "lagged"``)."""
+        hit = self.__dict__.get("_spatial_cache")
+        if hit is None:
+            return
+        _, invalid = hit[1].poll()
+        if invalid and hit[1].world > 1:
+            self.__dict__["_spatial_cache"] = None
+            raise RuntimeError("spatial shards: an atom moved more than partition_skin / 2 = "
+                               f"{0.5 * self.partition_skin:.3f} A before the partition was renewed -- the last step was "
+                               "evaluated with too narrow a halo. Use a larger partition_skin, a smaller step, or "
+                               "partition_check = 'strict'.")
+
     def _spatial_ok(self, C: int, n: int) -> bool:
         """Slab decomposition applies to ONE system evaluated through its own pair search, with every enabled potential
         of finite range (the halo is as wide as the widest of them needs, _spatial_reach; a cutoff-free potential falls
@@ -530,7 +559,14 @@ class ANI(torch.nn.Module):
         if hit is not None and hit[0] != key and (self.partition_skin > 0.0 or world == 1) and hit[0][2] == key[2] and \
                 hit[0][4:] == key[4:] and (cell is None) == (hit[3] is None):
             part = hit[1]
-            renew, invalid = part.poll()   # (what the previous step found out about ITS coordinates)
+            if world > 1 and (self.partition_check == "strict" or not part.check_pending):
+                # same-step guard: nothing is known yet about coordinates that moved since the cut (the first moved step
+                # after it; a caller that is not in a steady loop), or the caller wants every step verified before it is
+                # evaluated -- read the flags of THESE coordinates now (one host synchronisation) and renew at once
+                part.poll()
+                renew, invalid = part.check_now(c32, cell)[0], False
+            else:
+                renew, invalid = part.poll()   # (what the previous step found out about ITS coordinates)
             if invalid and world > 1:
                 self.__dict__["_spatial_cache"] = None
                 raise RuntimeError(
@@ -554,7 +590,7 @@ class ANI(torch.nn.Module):
 
     def _energies_and_forces_spatial(self, species32: Tensor, c32: Tensor, cell, pbc, group, reduce_forces, check_overflow,
                                      shard, stress: bool, tile_hint: int, species_key: tp.Optional[Tensor] = None
-                                     ) -> EnergiesForces:
+                                     ) -> FusedEnergiesForces:
         """energies_and_forces of ONE system sharded spatially: this rank evaluates the central atoms of its slab on the
         local system [left halo | owned | right halo], one all-gather of the halo force rows (+ partial energy / virial)
         completes its owned atoms' forces.  reduce_forces=True additionally gathers every rank's owned forces and
@@ -580,7 +616,7 @@ class ANI(torch.nn.Module):
         slab_mask = None
         plain = self._plain_slabs(eng, packed)
         if packed.radial_len == 16 * eng.params.num_species and eng.tuned and eng.n_slabs <= 32:
-            if self.keep_aev_rows and not torch.cuda.is_current_stream_capturing():
+            if self.keep_aev_rows and not torch.cuda.is_current_stream_capturing() and eng.rows_wanted(nl, lo, hi, dev):
                 aev, slab_mask = eng.forward_update(sp_l, nbrs)   # (kept buffers, updated in place)
             else:
                 slab_mask = torch.zeros(nl, dtype=torch.int32, device=dev)
@@ -647,7 +683,7 @@ class ANI(torch.nn.Module):
         if check_overflow:
             nbrs.raise_on_overflow()
         aevc._last_neighbors = nbrs
-        return EnergiesForces(energies, forces.view(1, n, 3), ae.view(1, n), virial)
+        return FusedEnergiesForces(energies, forces.view(1, n, 3), ae.view(1, n), virial)
 
     def _sae64(self, device) -> Tensor:
         """Self energies as float64 on ``device``, converted once per value of the buffer (a launch per step otherwise)."""
@@ -759,7 +795,7 @@ class ANI(torch.nn.Module):
                 m.potentials[name] = pot
         m.potentials["nnp"]._enabled = self.potentials["nnp"]._enabled
         m.energy_shifter._enabled = self.energy_shifter._enabled
-        for attr in ("mlp_chunk", "deterministic_forces", "auto_graph_atoms", "compact_species", "partition", "partition_skin", "locality_sort"):
+        for attr in ("mlp_chunk", "deterministic_forces", "auto_graph_atoms", "compact_species", "partition", "partition_skin", "partition_check", "locality_sort"):
             setattr(m, attr, getattr(self, attr))
 
     def atomic_energies(self, species_coordinates, cell=None, pbc=None, charge: int = 0,
@@ -837,7 +873,7 @@ class ANI(torch.nn.Module):
     def graphed(self, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor] = None,
                 pbc: tp.Optional[tp.Sequence[bool]] = None) -> "GraphedEnergiesForces":
         """Capture energies_and_forces for this (species, shapes, pbc) into a HIP graph and return a callable
-        ``f(coords, cell=None) -> EnergiesForces`` that replays it: one graph launch instead of a dozen kernel
+        ``f(coords, cell=None) -> FusedEnergiesForces`` that replays it: one graph launch instead of a dozen kernel
         launches, for launch-bound sizes (batches of small molecules, MD of small systems)."""
         return GraphedEnergiesForces(self, species, coords, cell, pbc)
 
@@ -948,12 +984,12 @@ class GraphedEnergiesForces:
     def __del__(self):
         self._release()
 
-    def _run(self) -> EnergiesForces:
+    def _run(self) -> FusedEnergiesForces:
         return self.model._energies_and_forces_core(self.species32, self.coords, self.cell, self.pbc, None, True,
                                                     False, None, tile_hint=self.tile_hint,
                                                     engine_species=(self.engine_species32, self.species_order))
 
-    def __call__(self, coords: Tensor, cell: tp.Optional[Tensor] = None) -> EnergiesForces:
+    def __call__(self, coords: Tensor, cell: tp.Optional[Tensor] = None) -> FusedEnergiesForces:
         if (self.model.neural_networks._pack(self.coords.device, self.species_order) is not self._packed
                 or self._current_sae() is not self._sae):
             self._capture()   # parameters were updated in place / other members: the old planes are stale

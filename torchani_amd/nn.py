@@ -308,11 +308,13 @@ class _EngineContainer(torch.nn.Module):
         if trainable_fast and packed.activation == "gelu":
             # (the input gradient that force training differentiates once more comes from the inference pack: an fp32 GELU
             # pack only serves the training passes)
-            packed.infer_pack = lambda: self._pack(aevs.device)
+            dev_ = aevs.device   # (only the device: a closure over `aevs` would keep the tensor and its graph alive)
+            packed.infer_pack = lambda: self._pack(dev_)
         if ensemble_values and aevs.requires_grad and not params:
             # differentiable member energies (nn/_containers.py:638-651 is plain autograd in the reference): the backward
             # needs every member's own d e_m / d aev, i.e. one single-member pass each
-            packed.member_packs = lambda: [m._pack(aevs.device) for m in self._member_networks()]
+            dev_m = aevs.device
+            packed.member_packs = lambda: [m._pack(dev_m) for m in self._member_networks()]
         out = _MLPFunction.apply(aevs, species32, packed, ensemble_values, *params)
         # [C, A] (or [M, C, A]); molecular energies are the sum over atoms (nn/_containers.py:417-421)
         return out if atomic else out.sum(dim=-1)
@@ -415,6 +417,8 @@ class SpeciesConverter(torch.nn.Module):
         self.register_buffer("conv_tensor", conv)
         self.atomic_numbers = torch.tensor([ATOMIC_NUMBER[s] for s in symbols], dtype=torch.long)
 
+    RECHECK_EVERY = 64   # calls with the same species tensor between two validity checks (one host read each)
+
     def forward(self, atomic_nums, nop: bool = False):
         if isinstance(atomic_nums, tuple):
             warnings.warn("The tuple call signature is deprecated; use idxs = converter(atomic_nums)")
@@ -422,9 +426,16 @@ class SpeciesConverter(torch.nn.Module):
         # The validity check reads the device (the reference syncs here too, nn/_containers.py:727-733): once per species
         # TENSOR -- identity and version, the entry keeps the tensor alive so that its address cannot be handed to another
         # one meanwhile -- so that an MD loop that passes the same species tensor step after step never waits for the device
+        # (identity + version only see writes made THROUGH torch: a buffer shared with numpy -- torch.from_numpy, as ASE and MD
+        # drivers hand them over -- or written through .data can change behind the same key, so every RECHECK_EVERY-th call
+        # with the same tensor validates again; mutate species tensors with torch in-place operations, or pass a new tensor)
         key = (atomic_nums.data_ptr(), atomic_nums._version, tuple(atomic_nums.shape), atomic_nums.dtype, bool(nop))
         hit = self.__dict__.get("_checked")
         checked = hit is not None and hit[0] == key
+        calls = self.__dict__.get("_checked_calls", 0) + 1 if checked else 0
+        if calls >= self.RECHECK_EVERY:
+            checked, calls = False, 0
+        self.__dict__["_checked_calls"] = calls
         if nop:
             if not checked and atomic_nums.max() >= len(self.atomic_numbers):
                 raise ValueError(f"Unsupported element idx in {atomic_nums}")

@@ -309,13 +309,9 @@ class SpatialShards:
     # times a hydrogen's motion in a 0.5 fs step); if it did, the late read raises instead of returning silently.
     SOFT = 0.8
 
-    def check_async(self, coords: torch.Tensor, cell: tp.Optional[torch.Tensor]) -> None:
-        """Queue the validity flags for ``coords`` on the current stream: word 0 = some atom moved SOFT x skin / 2 since the
-        cut (or the cell changed) -> renew the partition at the next step; word 1 = some atom moved skin / 2 -> the step that
-        used this partition with these coordinates cannot be trusted.  No host synchronisation: ``poll`` reads them later."""
-        if self.x_build is None:
-            self._check = None
-            return
+    def _flags(self, coords: torch.Tensor, cell: tp.Optional[torch.Tensor]) -> torch.Tensor:
+        """int32[2] on the device: word 0 = some atom moved SOFT x skin / 2 since the cut (or the cell changed), word 1 = some
+        atom moved skin / 2."""
         d = coords.detach().reshape(-1, 3).to(torch.float32) - self.x_build
         # effective displacement: the largest motion of an atom, plus half of what the periodic images moved with the cell
         # (two atoms each d apart from where they were and an image shifted by |delta cell| change a distance by <= 2 d + |delta cell|)
@@ -326,7 +322,24 @@ class SpatialShards:
             d_eff = d_eff + 0.5 * torch.linalg.norm(dc, dim=1).sum().to(d_eff.dtype)
             changed = (dc != 0).any()
         lim = 0.5 * self.skin
-        flags = torch.stack([(d_eff >= lim * self.SOFT) | changed, d_eff >= lim]).to(torch.int32)
+        return torch.stack([(d_eff >= lim * self.SOFT) | changed, d_eff >= lim]).to(torch.int32)
+
+    def check_now(self, coords: torch.Tensor, cell: tp.Optional[torch.Tensor]) -> tp.Tuple[bool, bool]:
+        """(renew, invalid) for ``coords`` themselves, read at once (one host synchronisation): the same-step guard of callers
+        that are not in a steady loop -- the first moved step after a cut, ``ANI.partition_check = "strict"``."""
+        if self.x_build is None:
+            return True, True
+        f = self._flags(coords, cell).tolist()
+        return bool(f[0]), bool(f[1])
+
+    def check_async(self, coords: torch.Tensor, cell: tp.Optional[torch.Tensor]) -> None:
+        """Queue the validity flags for ``coords`` on the current stream: word 0 = some atom moved SOFT x skin / 2 since the
+        cut (or the cell changed) -> renew the partition at the next step; word 1 = some atom moved skin / 2 -> the step that
+        used this partition with these coordinates cannot be trusted.  No host synchronisation: ``poll`` reads them later."""
+        if self.x_build is None:
+            self._check = None
+            return
+        flags = self._flags(coords, cell)
         if flags.is_cuda:
             host = torch.empty(2, dtype=torch.int32, pin_memory=True)
             host.copy_(flags, non_blocking=True)
@@ -335,6 +348,10 @@ class SpatialShards:
             self._check = (host, ev)
         else:
             self._check = (flags, None)
+
+    @property
+    def check_pending(self) -> bool:
+        return self._check is not None
 
     def poll(self) -> tp.Tuple[bool, bool]:
         """(renew, invalid) of the LAST ``check_async`` (False, False if none is pending).  Waits for that check's event only

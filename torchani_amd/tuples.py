@@ -41,7 +41,14 @@ class EnergiesScalars(tp.NamedTuple):
 
 
 class EnergiesForces(tp.NamedTuple):
-    """Result of the fused engine path: energies [C] float64 Hartree, forces [C,A,3] float32 Ha/A,
+    """What grad.energies_and_forces returns: the reference's two-field tuple (torchani/tuples.py:13-15)."""
+
+    energies: Tensor
+    forces: Tensor
+
+
+class FusedEnergiesForces(tp.NamedTuple):
+    """Result of the fused engine path (ANI.energies_and_forces): energies [C] float64 Hartree, forces [C,A,3] float32 Ha/A,
     atomic_energies [C,A] float32 (network part only, no self energies)."""
 
     energies: Tensor
