@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 10
+#define ANIHIP_ABI_VERSION 11
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -379,14 +379,28 @@ int anihip_mlp_forward_backward(void *stream, const anihip_mlp_desc *d, int64_t 
  *                       for the output layer): per member torch.nn.Linear's [out][in] layout at the padded widths, so
  *                       unpadded networks (ANI-2x) read their gradients in place
  *   grads[s].gbias[l] = d Loss / d bias[l] of species s, same shape as bias[l]
- * (padded rows/columns come out zero).  All gradient arrays are OVERWRITTEN.  atomic_e is written as in
- * anihip_mlp_forward_backward; grad_aev (optional) = d Loss / d aev rows, i.e. already scaled by grad_atomic_e.
- * Arithmetic: exact fp32 on v_mfma_f32_32x32x2_f32 whatever desc.precision says (only w / wt / bias are read);
- * sums over atoms use float atomics, so the last bits depend on the execution order.
+ * (padded rows/columns come out zero).  The gradient arrays are OVERWRITTEN, or -- accumulate != 0 -- ADDED to (the caller
+ * zeroes them: gradient accumulation over several calls, optimizers that own one flat gradient buffer).  atomic_e is written
+ * as in anihip_mlp_forward_backward; grad_aev (optional) = d Loss / d aev rows, i.e. already scaled by grad_atomic_e.
+ * Arithmetic, by descriptor (sums over atoms use float atomics either way: the last bits depend on the execution order):
+ *   ANIHIP_MLP_FP32 (any shape, CELU or GELU): exact fp32 on v_mfma_f32_32x32x2_f32, layer by layer; only w / wt / bias are read.
+ *   ANIHIP_MLP_F16X3, CELU, three hidden layers <= 256 wide (ANI-1x / ANI-2x) -- the FAST training path (round 5): the forward
+ *     and the backward down to d e / d z0 run as ONE launch of the fused network kernel (split-fp16 MFMA, the arithmetic of
+ *     inference: per-atom energies within 1e-7 Ha of fp64) for a unit upstream gradient, leaving activations and d e / d z in
+ *     the workspace; the weight gradients dW_l = sum_atoms g_a (d e / d z_l)^T x_{l-1} are one launch per layer on
+ *     v_mfma_f32_32x32x16_bf16 with both operands split three ways into bf16 on the fly (six products: 2^-24 relative, no
+ *     operand scales), the bias gradients one column reduction per layer.  A call that asks for grad_aev takes the exact-fp32
+ *     backward instead (on the activations of whichever forward ran).
+ * member_stride (fast path only; 0 = the packed [M][...] arrays above): gw[l] / gbias[l] point at MEMBER 0's arrays and
+ * member m's lie member_stride floats further on each -- the layout of a flat parameter buffer in torch's parameter order
+ * (member -> species -> layer -> weight, bias), so an optimizer that owns ONE flat gradient buffer receives the gradients
+ * where its update kernel reads them (needs accumulate != 0 and unpadded widths).
  */
 typedef struct {
     float *gw[ANIHIP_MAX_LAYERS];
     float *gbias[ANIHIP_MAX_LAYERS];
+    int64_t member_stride;
+    int32_t accumulate;
 } anihip_species_grads;
 
 size_t anihip_mlp_train_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central);
@@ -395,9 +409,10 @@ int anihip_mlp_weight_grads(void *stream, const anihip_mlp_desc *d, int64_t n_at
                             void *workspace, size_t workspace_bytes, const anihip_species_grads *grads /* [num_species] */,
                             float *atomic_e, float *grad_aev, int32_t forward_done);
 
-/* The two halves of a training step as autograd needs them (forward now, backward later): the exact-fp32 forward
- * that leaves the species buckets and every hidden activation in the workspace (anihip_mlp_train_workspace_bytes),
- * writing atomic_e.  A later anihip_mlp_weight_grads call with forward_done != 0 and the SAME descriptor, range,
+/* The two halves of a training step as autograd needs them (forward now, backward later): the forward that leaves the
+ * species buckets and every hidden activation (fast path: also d e / d z of every layer) in the workspace
+ * (anihip_mlp_train_workspace_bytes), writing atomic_e -- exact fp32 layer by layer, or the fused split-fp16 kernel, by
+ * descriptor as above.  A later anihip_mlp_weight_grads call with forward_done != 0 and the SAME descriptor, range,
  * species, aev and (untouched) workspace skips its own forward. */
 int anihip_mlp_train_forward(void *stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo, int64_t hi,
                              const int32_t *species, const float *aev, void *workspace, size_t workspace_bytes,
@@ -417,12 +432,29 @@ int anihip_mlp_tangent_weight_grads(void *stream, const anihip_mlp_desc *d, int6
                                     void *workspace, size_t workspace_bytes, const anihip_species_grads *grads,
                                     float *datomic_e);
 
-/* Refresh the packed fp32 parameter arrays of an ANIHIP_MLP_FP32 descriptor (the arrays w / wt / bias point to are
- * REWRITTEN in place; padding stays zero) from the torch.nn.Linear tensors after an optimizer step -- one launch
- * instead of re-packing on the host (cf. BmmAtomicNetwork packing once per model, nn/_infer.py:141-161).
+/* Refresh the packed parameter arrays of a descriptor IN PLACE (padding stays zero) from the torch.nn.Linear tensors after
+ * an optimizer step -- one or two launches instead of re-packing on the host (cf. BmmAtomicNetwork packing once per model,
+ * nn/_infer.py:141-161).  ANIHIP_MLP_FP32: w / wt / bias.  ANIHIP_MLP_F16X3 (round 5): every layout anihip_mlp_pack derives
+ * -- w / wt / bias, the {hi, lo} fp16 planes wh / wth, their fragment orders whf / wthf, fused_bounds -- with the
+ * power-of-two weight scales the pack was built with (wh_scale is not changed): should a weight have outgrown the fp16
+ * range of its layer's scale, bit 0 of *status (device int32, optional, never cleared here) is set and the caller packs
+ * again on the host.
  * src: DEVICE array of 2 * M * S * n_layers pointers ordered member, species, layer, {weight [out][in] row-major,
  * bias [out]}; out_in: HOST array [S][n_layers][2] with the (out, in) widths of the source tensors. */
-int anihip_mlp_repack(void *stream, const anihip_mlp_desc *d, const void *const *src, const int32_t *out_in);
+#define ANIHIP_REPACK_FUSED_ONLY 1   /* F16X3: only what the fused network kernel and the fast training pass read -- bias, output
+                                        layer, whf, wthf of the hidden layers, fused_bounds; w / wt / wh / wth / wthf[0] go stale */
+int anihip_mlp_repack(void *stream, const anihip_mlp_desc *d, const void *const *src, const int32_t *out_in,
+                      int32_t *status, int32_t flags);
+
+/* One Adam update over flat buffers (torch.optim.Adam with amsgrad = False, maximize = False: the optimizer of the
+ * reference's training recipe, tools/training-aev-benchmark.py:88; weight_decay is torch's L2 form, grad += wd * param):
+ *   m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  param -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * with t = *step + 1; *step (DEVICE int32: updates done so far) is incremented behind the update, so a captured HIP graph
+ * of a training step advances it on every replay.  One launch over n parameters (28 bytes of traffic each) instead of a
+ * dozen foreach launches over the model's 448 tensors; buffers 16-byte aligned.  zero_grads != 0: the gradients are zeroed
+ * behind the update (the weight-gradient kernels of the next step ADD into them: no memset launch per step). */
+int anihip_adam_step(void *stream, float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int32_t *step, int32_t zero_grads);
 
 /* ---------------------------------------------------------------------------------------------
  * Pair potentials on the neighbor rows: the xTB repulsion term of the reference's ANI-2xr / ANI-2dr models

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 11
 
 
 def test_struct_layouts_match_header(lib):
@@ -55,7 +55,7 @@ def test_struct_layouts_match_header(lib):
     # one forward_backward call of a descriptor the fused kernel cannot serve (no fp16 planes here): the same buffers
     assert lib.anihip_mlp_forward_backward_workspace_bytes(ctypes.byref(d), n, 1) == need
     # training pass: the activations are kept and every hidden layer gets a gradient buffer of the same size
-    assert ctypes.sizeof(_lib.SpeciesGrads) == 2 * 4 * 8
+    assert ctypes.sizeof(_lib.SpeciesGrads) == 2 * 4 * 8 + 8 + 8   # + member_stride, accumulate (+ padding)
     need_t = lib.anihip_mlp_train_workspace_bytes(ctypes.byref(d), n)
     assert need + acts <= need_t <= need + acts + 4 * 256
 
@@ -102,8 +102,13 @@ def test_argument_validation_without_gpu(lib):
     assert rc != 0 and b"null descriptor" in lib.anihip_last_error()
     rc = lib.anihip_mlp_train_forward(None, None, 10, 0, 10, addr, addr, addr, 4096, addr)
     assert rc != 0 and b"null descriptor" in lib.anihip_last_error()
-    rc = lib.anihip_mlp_repack(None, None, addr, addr)
+    rc = lib.anihip_mlp_repack(None, None, addr, addr, None, 0)
     assert rc != 0 and b"null descriptor" in lib.anihip_last_error()
+    one = ctypes.c_float(0.5)
+    rc = lib.anihip_adam_step(None, addr, addr, addr, None, 16, one, one, one, one, one, addr, 1)
+    assert rc != 0 and b"null pointer" in lib.anihip_last_error()
+    rc = lib.anihip_adam_step(None, addr, addr, addr, addr, 16, one, ctypes.c_float(1.5), one, one, one, addr, 1)
+    assert rc != 0 and b"hyper-parameters" in lib.anihip_last_error()
     d = _lib.MlpDesc()
     d.num_species, d.n_members, d.aev_len, d.celu_alpha, d.precision = 9, 8, 1008, 0.1, _lib.MLP_F16X3
     rc = lib.anihip_mlp_forward_backward(None, ctypes.byref(d), 10, 0, 10, addr, addr, None, addr, 4096, addr, None,

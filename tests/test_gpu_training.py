@@ -97,6 +97,229 @@ def test_weight_grads_match_oracle(dev, oracle64, base, precision):
     assert np.abs(e2.cpu().numpy() - ae).max() < 3e-7
 
 
+@pytest.mark.parametrize("base", WGRAD_NAMES)
+def test_fast_training_pass_matches_oracle(dev, oracle64, base):
+    """Round 5, the fast training path (include/anihip.h, anihip_mlp_weight_grads of an F16X3 pack): forward + unit-gradient
+    backward in ONE launch of the fused kernel's TRAIN instantiation, weight gradients on bf16 x 3 MFMA with the upstream
+    gradient as a row scale, bias gradients by column reduction -- against the fp64 oracle, at the tolerance of the
+    exact-fp32 passes; the two halves (train_forward now, weight_grads later) and the one-call form; gradients written
+    straight into a flat per-member buffer (member_stride / accumulate) equal the packed ones."""
+    g = load_golden(base)
+    dims, flat, _ = oracle_networks(g["kind"], g["n_members"], g["seed"])
+    p = oracle_params(g["kind"], g["cutoff_fn"])
+    aev = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), g["cell"], g["pbc"])
+    a32 = aev.astype(np.float32)
+    C, A = g["species"].shape
+    up = wgrad_upstream(C, A).astype(np.float32)
+    ref = oracle64.mlp_weight_grads(g["species"], a32.astype(np.float64), up.astype(np.float64), dims, flat, n_members=8)
+    ae, _, _ = oracle64.mlp(g["species"], a32.astype(np.float64), dims, flat, n_members=8)
+    model = fresh_model(g["kind"], g["seed"], dev, g["cutoff_fn"])
+    nets = model.neural_networks
+    nets.requires_grad_(True)
+    assert nets._fast_trainable()
+    packed = nets._train_pack(dev, fast=True)
+    assert packed.precision == "f16x3" and packed.fast_training()
+    sp32 = torch.from_numpy(g["species"].astype(np.int32)).to(dev)
+    at = torch.from_numpy(a32).to(dev).view(C * A, -1)
+    upd = torch.from_numpy(up).to(dev)
+    e_fwd, ws = packed.train_forward(sp32, at)
+    gw, gb, e, _ = packed.weight_grads(sp32, at, upd, workspace=ws)
+    torch.cuda.synchronize()
+    got = flat_from_lists(gw, gb, packed.M, packed.S, packed.nl)
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref).max()
+    e_err = np.abs(e_fwd.cpu().numpy() - ae).max()
+    report(f"fast train {base:22s} max|dL/dw err| = {err:.2e} (max |dL/dw| {scale:.2e})  |e_atom err| = {e_err:.2e}")
+    assert err < WG_REL_TOL * scale
+    assert e_err < 3e-7
+    # one call (its own forward), in three chunks: the chunks' gradients are summed
+    gw2, gb2, e2, _ = packed.weight_grads(sp32, at, upd, chunk=max(7, (C * A) // 3))
+    got2 = flat_from_lists(gw2, gb2, packed.M, packed.S, packed.nl)
+    assert np.abs(got2 - ref).max() < WG_REL_TOL * scale
+    assert np.abs(e2.cpu().numpy() - ae).max() < 3e-7
+    # the same into a flat buffer in torch's parameter order (member -> species -> layer -> weight, bias), ACCUMULATED: twice
+    # (needs widths that are multiples of 32: ANI-2x; ANI-1x's 144- and 112-wide layers are padded in the engine)
+    if any(packed.desc.net[s_].dims[l + 1] != packed.shapes[s_][l][0] for s_ in range(packed.S) for l in range(packed.nl - 1)):
+        with pytest.raises(ValueError, match="multiples of 32"):
+            packed.flat_grad_target([[0] * packed.nl] * packed.S, [[0] * packed.nl] * packed.S, 1)
+        return
+    params = [q for q in nets.parameters()]
+    sizes = [q.numel() for q in params]
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    flat_g = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
+    M, S, nl = packed.M, packed.S, packed.nl
+    per = 2 * S * nl
+    base_ptr = flat_g.data_ptr()
+    w_ptr = [[base_ptr + 4 * int(offs[(s_ * nl + l) * 2]) for l in range(nl)] for s_ in range(S)]
+    b_ptr = [[base_ptr + 4 * int(offs[(s_ * nl + l) * 2 + 1]) for l in range(nl)] for s_ in range(S)]
+    tgt = packed.flat_grad_target(w_ptr, b_ptr, int(offs[per]))
+    for _ in range(2):
+        _, ws = packed.train_forward(sp32, at)
+        packed.weight_grads(sp32, at, upd, workspace=ws, target=tgt)
+    torch.cuda.synchronize()
+    fg = flat_g.cpu().numpy().astype(np.float64)
+    # (flat_from_lists orders member -> species -> layer -> weight, bias as well)
+    assert fg.shape == ref.shape
+    assert np.abs(0.5 * fg - ref).max() < WG_REL_TOL * scale
+
+
+def test_device_repack_of_a_split_fp16_pack_equals_the_host_packer(dev):
+    """anihip_mlp_repack of an F16X3 descriptor (round 5) rewrites every layout on the device: after the parameters changed,
+    the refreshed buffer equals, byte for byte outside the operand bounds, what anihip_mlp_pack builds on the host from the new
+    values (same weight scales: the change keeps every layer's largest weight in its binade)."""
+    from torchani_amd.engine import PackedNetworks
+
+    model = fresh_model("ani2x", 3, dev)
+    nets = model.neural_networks
+    nets.requires_grad_(True)
+    packed = nets._train_pack(dev, fast=True)
+    rs = torch.Generator(device="cpu").manual_seed(5)
+    with torch.no_grad():
+        for q in nets.parameters():
+            q.mul_(1.0 + 0.02 * (torch.rand(q.shape, generator=rs) - 0.5).to(dev))   # (in place: versions bump)
+    again = nets._train_pack(dev, fast=True)
+    assert again is packed and packed.stale_layouts   # refreshed in place (the fused kernel's layouts only), not rebuilt
+    members = nets._member_networks()
+    lins = [[m.atomics[s].linears() for s in nets.symbols] for m in members]
+    weights = [[[lin.weight for lin in sl] for sl in ml] for ml in lins]
+    biases = [[[lin.bias for lin in sl] for sl in ml] for ml in lins]
+    packed.refresh(weights, biases)   # ... and now every layout
+    torch.cuda.synchronize()
+    assert not packed.stale_layouts and not packed.scale_overflowed()
+    fresh = PackedNetworks(weights, biases, packed.aev_len, 0.1, dev, "f16x3")
+    M, nl, K0 = packed.M, packed.nl, packed.aev_len
+    K0p = (K0 + 31) // 32 * 32
+    K0h = 128 + (K0 - 112)   # (ANI-2x: radial part padded to 128)
+    compared = 0
+    for s in range(packed.S):
+        a, b = packed.desc.net[s], fresh.desc.net[s]
+        bd_a = packed.array(a.fused_bounds, (8 * M,))
+        bd_b = fresh.array(b.fused_bounds, (8 * M,))
+        assert torch.all(bd_a >= bd_b) and torch.allclose(bd_a, bd_b, rtol=3e-4)   # (upper bounds, a hair above the host's)
+        for l in range(nl):
+            kin, kout = a.dims[l], a.dims[l + 1]
+            if l == nl - 1:
+                assert torch.equal(packed.array(a.w[l], (M * kin,)), fresh.array(b.w[l], (M * kin,)))
+                assert torch.equal(packed.array(a.bias[l], (M,)), fresh.array(b.bias[l], (M,)))
+                continue
+            n_w, n_wt = M * kin * kout, M * kout * (K0p if l == 0 else kin)
+            assert torch.equal(packed.array(a.w[l], (n_w,)), fresh.array(b.w[l], (n_w,)))
+            assert torch.equal(packed.array(a.wt[l], (n_wt,)), fresh.array(b.wt[l], (n_wt,)))
+            assert torch.equal(packed.array(a.bias[l], (M * kout,)), fresh.array(b.bias[l], (M * kout,)))
+            if a.wh_scale[l] != b.wh_scale[l]:
+                continue   # (the host packer chose a new scale for the changed weights: other planes, equally valid)
+            n_h = 2 * M * kout * (K0h if l == 0 else kin)
+            for name in ("wh", "wth", "whf", "wthf"):
+                pa, pb = getattr(a, name)[l], getattr(b, name)[l]
+                assert bool(pa) == bool(pb)
+                if pa:
+                    assert torch.equal(packed.array(pa, (n_h,), torch.float16), fresh.array(pb, (n_h,), torch.float16)), (s, l, name)
+                    compared += 1
+    assert compared >= 3 * 4 * packed.S // 2   # (most layers keep their scale under a 1 % change)
+
+
+@pytest.mark.parametrize("weight_decay", [0.0, 0.01])
+def test_fused_adam_matches_torch_adam(dev, weight_decay):
+    """torchani_amd.optim.Adam (anihip_adam_step: one launch over flat buffers, step count on the device) follows
+    torch.optim.Adam to 1e-6 relative over 25 steps of random gradients; the parameters keep their values when they are
+    re-homed into the flat buffer; step() leaves the gradients zeroed (zero_grad_in_step)."""
+    from torchani_amd.optim import Adam
+
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    shapes = [(256, 1008), (256,), (192, 256), (192,), (1, 160), (1,), (7, 5, 3)]
+    init = [torch.randn(sh, generator=gen) * 0.3 for sh in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    ours = Adam(pa, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
+    theirs = torch.optim.Adam(pb, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=weight_decay)
+    for a, t in zip(pa, init):
+        assert torch.equal(a.detach().cpu(), t)
+    flat = ours._flat[0]
+    assert all(a.grad is v for a, v in zip(pa, flat.grad_views))
+    for step in range(25):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            gr = (torch.randn(a.shape, generator=gen) * (10.0 ** ((step % 5) - 3))).to(dev)
+            if step % 3 == 0 and i == 2:
+                a.grad = gr.clone()           # a gradient that arrives as a tensor of its own (autograd's default route)
+            else:
+                a.grad.copy_(gr)
+            b.grad = gr.clone()
+        ours.step()
+        theirs.step()
+        assert all(a.grad is v for a, v in zip(pa, flat.grad_views))
+        assert float(flat.grad.abs().max()) == 0.0
+    torch.cuda.synchronize()
+    assert int(flat.step.item()) == 25
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    sd = ours.state_dict()
+    ours.load_state_dict(sd)
+
+
+def test_training_step_with_the_flat_optimizer(dev, oracle64):
+    """The reference's recipe (tools/training-aev-benchmark.py:88,120-135) with torchani_amd.optim.Adam in torch.optim.Adam's
+    place: the containers find their parameters' gradients in ONE flat buffer and the weight-gradient kernels add straight
+    into it (autograd accumulates nothing), .grad of every parameter equals the oracle's gradient, the losses of a short run
+    follow those of torch.optim.Adam on the exact-fp32 passes, and nets.zero_grad(set_to_none=True) -- gradients back through
+    autograd -- still trains."""
+    from torchani_amd.optim import Adam
+
+    g = load_golden("rand_batch_ani2x")
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev)
+    C, A = g["species"].shape
+    target = torch.from_numpy(np.linspace(-0.3, 0.4, C)).to(dev)
+    runs = {}
+    for kind in ("fused", "torch"):
+        model = fresh_model("ani2x", g["seed"], dev)
+        nets = model.neural_networks
+        nets.requires_grad_(True)
+        aev = model.aev_computer(sp, x).detach()
+        if kind == "fused":
+            opt = Adam(nets.parameters(), lr=1e-4)
+        else:
+            nets.train_precision = "fp32"
+            opt = torch.optim.Adam(nets.parameters(), lr=1e-4)
+        losses = []
+        for it in range(6):
+            opt.zero_grad()
+            e = nets(sp, aev).double()
+            loss = ((e - target) ** 2).sum()
+            loss.backward()
+            if it == 0 and kind == "fused":
+                pk = nets._train_pack(dev, fast=True)
+                assert pk.flat_target is not None, "the gradients did not take the direct route"
+                dims, flat, _ = oracle_networks("ani2x", 8, g["seed"])
+                a64 = aev.cpu().numpy().astype(np.float64).reshape(C * A, -1)
+                ae, _, _ = oracle64.mlp(g["species"], a64, dims, flat, n_members=8, want_grad=False)
+                e_ref = ae.reshape(C, A).sum(axis=1)
+                up = np.repeat(2.0 * (e_ref - target.cpu().numpy())[:, None], A, axis=1)
+                ref = oracle64.mlp_weight_grads(g["species"], a64, up, dims, flat, n_members=8)
+                got = flat_from_params(nets, nets.symbols)
+                scale = np.abs(ref).max()
+                err = np.abs(got - ref).max()
+                report(f"train flat-optimizer rand_batch_ani2x  max|grad err| = {err:.2e} (max |grad| {scale:.2e})")
+                assert err < 5e-5 * scale
+            opt.step()
+            losses.append(float(loss.detach()))
+        runs[kind] = losses
+        if kind == "fused":
+            # gradients set to None: they come back through autograd as tensors, step() gathers them into the flat buffer
+            nets.zero_grad(set_to_none=True)
+            e = nets(sp, aev).double()
+            loss = ((e - target) ** 2).sum()
+            loss.backward()
+            assert all(q.grad is not None for q in nets.parameters())
+            opt.step()
+            e2 = nets(sp, aev).double()
+            assert float(((e2 - target) ** 2).sum()) < float(loss)
+    report("train flat-optimizer losses " + " ".join(f"{v:.5f}" for v in runs["fused"]) + "   torch.optim.Adam / fp32: "
+           + " ".join(f"{v:.5f}" for v in runs["torch"]))
+    assert runs["fused"][-1] < 0.7 * runs["fused"][0]
+    for a, b in zip(runs["fused"], runs["torch"]):
+        assert abs(a - b) < 2e-4 * max(1.0, abs(b))
+
+
 def test_autograd_training_step(dev, oracle64):
     """loss.backward() through the containers fills .grad of every Linear parameter (what the reference's training
     loop relies on, tools/training-aev-benchmark.py:120-135), and a few Adam steps reduce the loss."""

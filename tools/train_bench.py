@@ -42,6 +42,10 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--forces", action="store_true", help="energy + force loss (second-order backward)")
     ap.add_argument("--graph", action="store_true", help="capture the whole step (forward, backward, Adam) in a HIP graph")
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
+                    help="fused: torchani_amd.optim.Adam (one launch over flat buffers, gradients written in place); torch: torch.optim.Adam")
+    ap.add_argument("--train-precision", default="f16x3", choices=["f16x3", "fp32"],
+                    help="f16x3: fused forward+backward kernel and bf16x3 weight gradients; fp32: the exact-fp32 layer-by-layer passes")
     return ap.parse_args(argv)
 
 
@@ -54,7 +58,13 @@ def run(args, quiet=False):
     model = ctor(seed=0, n_members=args.members, device=dev, periodic_table_index=False, neighborlist="batch")
     nets = model.neural_networks
     nets.requires_grad_(True)
-    opt = torch.optim.Adam(nets.parameters(), lr=1e-4, capturable=args.graph)
+    nets.train_precision = getattr(args, "train_precision", "f16x3")
+    if getattr(args, "optimizer", "fused") == "fused":
+        from torchani_amd.optim import Adam
+
+        opt = Adam(nets.parameters(), lr=1e-4)
+    else:
+        opt = torch.optim.Adam(nets.parameters(), lr=1e-4, capturable=args.graph)
     sp, x = conformers(args.batch, args.atoms)
     spd, xd = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev)
     n_at = (spd >= 0).sum(dim=1).float()

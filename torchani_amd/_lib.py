@@ -14,8 +14,8 @@ import typing as tp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TORCHANI_AMD_LIB") or os.path.join(_HERE, "libanihip.so")
-SOURCES = ["api.hip", "nbr.hip", "aev.hip", "aev_generic.hip", "mlp.hip", "pair.hip", "pack.hip"]
-HEADERS = ["anihip_common.h", os.path.join("..", "..", "include", "anihip.h")]
+SOURCES = ["api.hip", "nbr.hip", "aev.hip", "aev_generic.hip", "mlp.hip", "pair.hip", "pack.hip", "train.hip"]
+HEADERS = ["anihip_common.h", "train.h", os.path.join("..", "..", "include", "anihip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared"]
 
 MAX_SPECIES = 8
@@ -37,7 +37,8 @@ MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MA
     1, 2, 4, 8, 16, 32
 MLP_FLAG_NO_SMALL_PREP, MLP_FLAG_L0B_4WAVE, MLP_FLAG_TILE_OWNER = 64, 128, 256
 MLP_FLAG_FUSED_L0B, MLP_FLAG_NO_FUSED_L0B = 512, 1024
-ABI_VERSION = 10
+ABI_VERSION = 11
+REPACK_FUSED_ONLY = 1
 
 
 class AevParams(C.Structure):
@@ -79,6 +80,8 @@ class SpeciesGrads(C.Structure):
     _fields_ = [
         ("gw", C.c_void_p * MAX_LAYERS),
         ("gbias", C.c_void_p * MAX_LAYERS),
+        ("member_stride", C.c_int64),
+        ("accumulate", C.c_int32),
     ]
 
 
@@ -191,7 +194,9 @@ def lib() -> C.CDLL:
     L.anihip_mlp_tangent_weight_grads.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, vp, sz,
                                                   C.POINTER(SpeciesGrads), vp]
     L.anihip_mlp_train_forward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, sz, vp]
-    L.anihip_mlp_repack.argtypes = [vp, C.POINTER(MlpDesc), vp, vp]
+    L.anihip_mlp_repack.argtypes = [vp, C.POINTER(MlpDesc), vp, vp, vp, i32]
+    L.anihip_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, i32]
+    L.anihip_adam_step.restype = C.c_int
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     L.anihip_energy_forces_finish.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp, vp, i64]
     L.anihip_energy_forces_finish.restype = C.c_int
@@ -217,7 +222,7 @@ EXPORTED_SYMBOLS = [
     "anihip_nbr_build_batch", "anihip_nbr_build_cell", "anihip_nbr_half_workspace_bytes", "anihip_nbr_from_half", "anihip_nbr_from_full",
     "anihip_nbr_refresh", "anihip_aev_forward", "anihip_aev_forward_update", "anihip_aev_backward", "anihip_aev_backward_virial", "anihip_aev_jvp",
     "anihip_mlp_workspace_bytes", "anihip_mlp_forward_backward_workspace_bytes", "anihip_mlp_forward_backward", "anihip_mlp_train_workspace_bytes",
-    "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_energy_reduce",
+    "anihip_mlp_weight_grads", "anihip_mlp_train_forward", "anihip_mlp_repack", "anihip_adam_step", "anihip_energy_reduce",
     "anihip_mlp_tangent_workspace_bytes", "anihip_mlp_tangent_weight_grads", "anihip_pair_xtb_repulsion",
     "anihip_pair_d3", "anihip_pair_analytic", "anihip_energy_forces_finish", "anihip_mlp_pack_bytes", "anihip_mlp_pack",
     "anihip_nbr_rows_to_half_workspace_bytes", "anihip_nbr_rows_to_half",

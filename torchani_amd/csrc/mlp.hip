@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "anihip_common.h"
+#include "train.h"
 
 #include <type_traits>
 #include <vector>
@@ -116,12 +117,7 @@ struct FinishArgs {   // k_fused_finish, or the extra blocks of k_gemm_l0s
     int first_block;   // k_gemm_l0s: blocks from here on do this instead of a tile (0: none)
 };
 
-// control block layout (ints) in the workspace
-constexpr int CTL_CNT = 0;      // [8]  atoms per species
-constexpr int CTL_CURSOR = 8;   // [8]  scatter cursors
-constexpr int CTL_OFF = 16;     // [9]  first sorted position of each species
-constexpr int CTL_TILE = 32;    // [9]  first row tile of each species
-constexpr int CTL_WORDS = 48;
+// (control block layout of the workspace: CTL_* in train.h)
 // running |max| of every intermediate tensor (per stage, per species), spread over slots to keep the
 // atomics off a single address; lives right behind the control block
 constexpr int AMAX_STAGES = 8, AMAX_SLOTS = 32;
@@ -1565,6 +1561,12 @@ struct FusedArgs {
     float *grad_aev;           // [n_atoms][L] (l0b): the tile's flagged slabs of its atoms' rows, summed over the members
     int owner;                 // item order: 0 = member-major sweep over the tiles; G > 0: a workgroup OWNS its tiles, taken in groups of G
     unsigned long long *trace;   // development builds (-DANIHIP_DEV_TRACE, tools/fused_trace.py): [item][wave][32] stamps
+    // TRAIN instantiation (anihip_mlp_train_forward of a split-fp16 pack): everything the weight gradients need leaves the
+    // kernel as fp32 rows in sorted order, member m at columns m * H: the activations of the three hidden layers and
+    // d e / d (pre-activation) of layers 2 and 1 for a unit upstream gradient (layer 0's is d0)
+    float *tr_act[3];
+    float *tr_dlt[3];          // ([0] unused: d0)
+    int64_t tr_ld[3];
 };
 // phase stamps of the fused kernel: compiled out of the shipped library
 #ifdef ANIHIP_DEV_TRACE
@@ -1790,11 +1792,25 @@ __device__ __forceinline__ FusedUnit fused_unit(int H, int wave)
 // Tile table of the fused kernel: one wave per tile resolves (species, rows, atoms, OR of the atoms' slab
 // masks) once, so that the member workgroups of a tile start from two independent loads instead of a chain of
 // five dependent ones.
+// ani_species > 0 (no per-atom flags, the whole system in one call, ANI layout of the AEV row: 16 radial columns per species,
+// then one 32-column block per species pair): the slabs of species (pairs) that do not occur in the system at all are zero for
+// every atom -- a superset of each atom's flags that costs nothing (the training batches: H C N O flag 12 of 32 slabs).
 __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const int *perm,
                                                     const uint32_t *slab_mask, uint32_t all_slabs,
                                                     int tiles_total, int rows_per_tile, int4 *tile_tab,
-                                                    int *tile_rows)
+                                                    int *tile_rows, int ani_species = 0)
 {
+    if (!slab_mask && ani_species > 0) {
+        const int nrs = (16 * ani_species + 31) / 32;
+        uint32_t mk = 0u;
+        for (int a = 0; a < ani_species; ++a) {
+            if (ctl[CTL_CNT + a] <= 0) continue;
+            mk |= 1u << (a >> 1);
+            for (int b = a; b < ani_species; ++b)
+                if (ctl[CTL_CNT + b] > 0) mk |= 1u << (nrs + a * ani_species - a * (a - 1) / 2 + (b - a));
+        }
+        all_slabs &= mk;
+    }
     const int tile0 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile0 >= tiles_total) return;
     int tile = tile0, s = 0, cnt = 0;
@@ -2013,10 +2029,13 @@ __global__ __launch_bounds__(SMALL_PREP_WAVES * WAVE) void k_small_prep(
     else if ((u).nrb == 1) { constexpr int RBA = 1, NBA = 1; CALL; }
 
 // L0B: the layer-0 backward as phase 5 of the kernel (owner order, d E / d AEV accumulated in place; RB = 2, NB = 1 only)
-template <int RB, int NB, int ACT, bool L0B>   // ACT: 0 = CELU(alpha), 1 = GELU (exact, erf)
+// TRAIN: the forward half of a training step -- the hidden activations and the backward's per-layer gradients are also
+// written to global memory (FusedArgs::tr_*), from the registers of the epilogues that produce them
+template <int RB, int NB, int ACT, bool L0B, bool TRAIN = false>   // ACT: 0 = CELU(alpha), 1 = GELU (exact, erf)
 __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 {
     static_assert(!L0B || (RB == 2 && NB == 1), "phase 5 is written for 64-row tiles on 8 waves");
+    static_assert(!TRAIN || (!L0B && ACT == 0 && NB == 1), "the training instantiation: CELU, d act0 to global memory");
     using C = FusedCfg<RB, NB>;
     constexpr int NW = C::NW, ROWS = C::ROWS, D = C::DEPTH, SLAB = C::SLAB, NE = RB * NB;
     typedef WRing<NB, D> Ring;
@@ -2304,6 +2323,25 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 }
         };
 
+        // TRAIN: this lane's accumulator elements as fp32 rows [sorted position][member m's H columns] (runs of four columns)
+        auto store_rows = [&](float *base, int64_t ld, int H, const FusedUnit &u) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (rb >= u.nrb || nb >= u.nba) continue;
+                    const int row = (u.rb0 + rb) * 32 + fr;
+                    float *dst = base + (int64_t)(p0 + min(row, n_rows - 1)) * ld + (int64_t)m * H + col0(u, nb);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v4f v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[rb * NB + nb][4 * q + e];
+                        if (row < n_rows) *reinterpret_cast<v4f *>(dst + 8 * q) = v;
+                    }
+                }
+        };
+
         // =============== layer 0: act0 = celu(aev x W0^T + b0) over the flagged slabs ===============
         const v4f bnd = *(const gf4 *)(fs.bounds + 8 * m);   // operand bounds of this member
         float bias0[NB][16];
@@ -2425,6 +2463,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                         for (int r = 0; r < 16; ++r) d0f[rb * NB + nb][r] = 0.f;
                 }
             }
+            if constexpr (TRAIN) store_rows(g.tr_act[0], g.tr_ld[0], H1, u1);
             a0max = tile_max(vmax);   // (barriers: every wave is past the staging slots)
         }
         const float s0 = pow2_scale_for(a0max);
@@ -2470,6 +2509,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                         for (int r = 0; r < 16; ++r) d1f[rb * NB + nb][r] = 0.f;
                 }
             }
+            if constexpr (TRAIN) store_rows(g.tr_act[1], g.tr_ld[1], H2, u2);
             put_acc(X1, x1_plane, ld1, s1, u2);
         }
         __syncthreads();  // X1 complete; every wave is done reading X0 -> XU reusable
@@ -2513,6 +2553,12 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                             e = __builtin_fmaf((NB == 1 || nb < u3.nba) ? y1 : 0.f, w3[nb][r + 1], e);
                             acc[i][r] = invM * w3[nb][r] * dy0;
                             acc[i][r + 1] = invM * w3[nb][r + 1] * dy1;
+                            if constexpr (TRAIN) {   // act2 leaves from here (the accumulators take the backward seed)
+                                const int row = (u3.rb0 + rb) * 32 + fr;
+                                float *dst = g.tr_act[2] + (int64_t)(p0 + min(row, n_rows - 1)) * g.tr_ld[2] + (int64_t)m * H3 +
+                                             col0(u3, nb) + 8 * (r >> 2) + (r & 3);
+                                if (row < n_rows) *reinterpret_cast<float2 *>(dst) = make_float2(y0, y1);
+                            }
                         }
                     e += __shfl_xor(e, 32);
                 }
@@ -2527,6 +2573,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     if (t - u3.rb0 == rb && rb < u3.nrb) v = e_loc[rb];
                 if (fk == 0) s_e[wave * ROWS + t * 32 + fr] = v;
             }
+            if constexpr (TRAIN) store_rows(g.tr_dlt[2], g.tr_ld[2], H3, u3);
             if (g.want_grad) put_acc(X2, x2_plane, ld2, s2, u3);   // (XU: X0 is dead since the last barrier)
         }
         __syncthreads();
@@ -2580,6 +2627,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                             }
                         }
                 }
+                if constexpr (TRAIN) store_rows(g.tr_dlt[1], g.tr_ld[1], H2, u2);
                 put_acc(X1, x1_plane, ld1, s3, u2);   // (X1: its last readers finished before the previous barrier)
             }
         }
@@ -3019,6 +3067,10 @@ struct ColReduceArgs {
     const float *g_atom;   // scale source (NULL: 1)
     float inv_m;
     int S, M, ct_max;
+    // out_mstride > 0: the destination arrays are per member, out_mstride floats apart: column c belongs to member
+    // c / n_per[s] (anihip_species_grads.member_stride; 0: one packed [M][n_per] array)
+    int64_t out_mstride;
+    int n_per[MAX_S];
 };
 
 __global__ __launch_bounds__(256) void k_col_reduce(ColReduceArgs g)
@@ -3038,8 +3090,16 @@ __global__ __launch_bounds__(256) void k_col_reduce(ColReduceArgs g)
         acc += sc * x[(int64_t)(p0 + r) * g.ldx];
         sacc += sc;
     }
-    if (cv) atomicAdd(g.out[s] + col, acc);
-    if (g.extra[s] && ct == 0 && threadIdx.x < g.M) atomicAdd(g.extra[s] + threadIdx.x, sacc);
+    if (cv) {
+        int64_t at = col;
+        if (g.out_mstride > 0) {
+            const int mem = col / g.n_per[s];
+            at = (int64_t)mem * g.out_mstride + (col - mem * g.n_per[s]);
+        }
+        atomicAdd(g.out[s] + at, acc);
+    }
+    if (g.extra[s] && ct == 0 && threadIdx.x < g.M)
+        atomicAdd(g.extra[s] + (g.out_mstride > 0 ? (int64_t)threadIdx.x * g.out_mstride : (int64_t)threadIdx.x), sacc);
 }
 
 // output layer of the tangent pass: p = w3 c'(a3) / M,  q = w3 c''(a3) zdot3 / M,  d atomic_e = sum_m w3 . adot3 / M
@@ -3880,6 +3940,92 @@ static int train_forward(hipStream_t stream, const anihip_mlp_desc *d, int64_t n
     return 0;
 }
 
+// Does the training pass of this descriptor run through the fused network kernel?  A split-fp16 CELU pack of the shape the
+// fused kernel covers (three hidden layers <= 256 wide, <= 32 AEV slabs, every fragment-ordered plane present).
+static bool train_fused(const anihip_mlp_desc *d)
+{
+    if (d->precision != ANIHIP_MLP_F16X3 || d->activation != ANIHIP_ACT_CELU || d->net[0].n_layers != 4) return false;
+    anihip_mlp_desc c = *d;
+    c.flags = 0;
+    return fb_plan(&c, 1 << 16, true).fused;
+}
+
+// First half of a training step on the fast path: species buckets, tile table, ONE k_mlp_fused<.., TRAIN> launch (split-fp16
+// MFMA like inference: forward AND the backward down to d e / d z0 for a unit upstream gradient -- the backward does not
+// depend on the loss, only its per-atom scale does, and that enters the weight-gradient GEMMs as a row scale), per-atom
+// energies.  Left in the workspace: act[0..2] (hidden activations) and dlt[0..2] (d e / d pre-activation), fp32 rows in
+// sorted order.
+static int train_forward_fused(hipStream_t stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t lo, int64_t hi,
+                               const int32_t *species, const float *aev, MlpWorkspace &w, float **dlt, float *atomic_e)
+{
+    const int S = d->num_species, M = d->n_members, L = d->aev_len;
+    const int64_t n = hi - lo;
+    const int kp_rad = d->aev_radial_len;
+    const int K0p = kp_rad > 0 ? 32 * ((kp_rad + 31) / 32 + (L - kp_rad) / 32) : ((L + 31) / 32) * 32;
+    const int n_slabs = K0p / 32;
+    const uint32_t all_slabs = n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << n_slabs) - 1u);
+    constexpr int rows = 64;
+    zero_words_async(stream, w.ctl, sizeof(int) * (CTL_WORDS + AMAX_WORDS));
+    const unsigned cblk = (unsigned)((n + 4 * SP_CHUNK - 1) / (4 * SP_CHUNK));
+    {
+        int *chunk_cnt = reinterpret_cast<int *>(w.member_part);
+        const int n_chunks = (int)((n + SP_CHUNK - 1) / SP_CHUNK);
+        hipLaunchKernelGGL(k_sp_count, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, chunk_cnt);
+        hipLaunchKernelGGL(k_sp_offsets, dim3(1), dim3(256), 0, stream, S, n_chunks, chunk_cnt, w.ctl);
+        hipLaunchKernelGGL(k_sp_scatter, dim3(cblk), dim3(256), 0, stream, lo, hi, species, S, w.ctl, chunk_cnt, w.perm,
+                           atomic_e, (float *)nullptr, L, (float *)nullptr, M, n_atoms);
+    }
+    const int64_t tiles = (n + rows - 1) / rows + S;
+    // (species that do not occur in the system flag nothing: valid when the call covers the whole system)
+    const int ani_species = (lo == 0 && hi == n_atoms && kp_rad == 16 * S && kp_rad > 0) ? S : 0;
+    hipLaunchKernelGGL(k_tile_table, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, w.ctl, S, w.perm,
+                       (const uint32_t *)nullptr, all_slabs, (int)tiles, rows, w.tile_tab, w.tile_rows, ani_species);
+    FusedArgs f{};
+    size_t lds = 0;
+    for (int s = 0; s < S; ++s) {
+        const anihip_species_net &nn = d->net[s];
+        FusedSpecies &fs = f.sp[s];
+        fs.H1 = nn.dims[1]; fs.H2 = nn.dims[2]; fs.H3 = nn.dims[3];
+        fs.w0 = (const _Float16 *)nn.whf[0];
+        fs.w1 = (const _Float16 *)nn.whf[1]; fs.w2 = (const _Float16 *)nn.whf[2];
+        fs.w2t = (const _Float16 *)nn.wthf[2]; fs.w1t = (const _Float16 *)nn.wthf[1];
+        fs.w0t = (const _Float16 *)nn.wthf[0];
+        fs.is0 = 1.0f / nn.wh_scale[0]; fs.is1 = 1.0f / nn.wh_scale[1]; fs.is2 = 1.0f / nn.wh_scale[2];
+        fs.b0 = nn.bias[0]; fs.b1 = nn.bias[1]; fs.b2 = nn.bias[2]; fs.w3 = nn.w[3]; fs.b3 = nn.bias[3];
+        fs.bounds = nn.fused_bounds;
+        const size_t xu = fs.H1 > fs.H3 ? fs.H1 : fs.H3;
+        size_t halves = 2 * (size_t)rows * (fs.H2 + 8) + 2 * (size_t)rows * (xu + 8);
+        const size_t slab = 2 * (size_t)rows * FR_SLAB_LD;
+        if (halves < 3 * FR_GROUP * slab) halves = 3 * FR_GROUP * slab;
+        halves += FusedCfg<2, 1>::FIXED_HALVES;
+        lds = lds > halves * 2 ? lds : halves * 2;
+    }
+    f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = n_slabs;
+    f.slab_mask = nullptr;
+    f.d0 = dlt[0]; f.ld0 = w.ld[0]; f.d0_tm = 0; f.perm = w.perm;
+    f.tile_tab = w.tile_tab; f.tile_rows = w.tile_rows;
+    f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = d->celu_alpha; f.inv_alpha = 1.0f / d->celu_alpha;
+    f.want_grad = 1; f.owner = 0; f.l0b = 0; f.grad_aev = nullptr;
+    f.tiles_total = (int)tiles;
+    for (int l = 0; l < 3; ++l) { f.tr_act[l] = w.act[l]; f.tr_ld[l] = w.ld[l]; f.tr_dlt[l] = dlt[l]; }
+    const void *kfn = (const void *)k_mlp_fused<2, 1, 0, false, true>;
+    ANIHIP_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int dev = 0, n_cus = 0;
+    ANIHIP_CHECK_HIP(hipGetDevice(&dev));
+    ANIHIP_CHECK_HIP(hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cus <= 0) n_cus = 256;
+    const int64_t items = tiles * M;
+    const int64_t grid = items < n_cus ? items : n_cus;
+    hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, false, true>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+    FinishArgs fin{};
+    fin.ctl = w.ctl; fin.perm = w.perm; fin.member_part = w.member_part; fin.atomic_e = atomic_e;
+    fin.member_e = nullptr; fin.n_atoms = n_atoms; fin.S = S; fin.M = M; fin.first_block = 0;
+    int64_t fb = (n + 255) / 256;
+    if (fb > 2048) fb = 2048;
+    hipLaunchKernelGGL(k_fused_finish, dim3((unsigned)fb), dim3(256), 0, stream, fin);
+    return 0;
+}
+
 static void train_head(hipStream_t stream, const anihip_mlp_desc *d, int64_t n_atoms, int64_t n, MlpWorkspace &w,
                        float *seed, const float *g_atom, float *atomic_e)
 {
@@ -3914,6 +4060,13 @@ extern "C" int anihip_mlp_train_forward(void *stream_, const anihip_mlp_desc *d,
     MlpWorkspace w;
     float *dlt[ANIHIP_MAX_LAYERS];
     mlp_train_carve(d, n, (char *)workspace, &w, dlt);
+    if (train_fused(d)) {
+        if (int rc = train_forward_fused(stream, d, n_atoms, lo, hi, species, aev, w, dlt, atomic_e)) return rc;
+        ANIHIP_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    ANIHIP_REQUIRE(d->precision == ANIHIP_MLP_FP32 || d->activation == ANIHIP_ACT_CELU,
+                   "training passes of GELU networks need an ANIHIP_MLP_FP32 descriptor");
     if (int rc = train_forward(stream, d, n_atoms, lo, hi, species, aev, w, atomic_e, nullptr)) return rc;
     train_head(stream, d, n_atoms, n, w, nullptr, nullptr, atomic_e);
     ANIHIP_CHECK_HIP(hipGetLastError());
@@ -3921,13 +4074,12 @@ extern "C" int anihip_mlp_train_forward(void *stream_, const anihip_mlp_desc *d,
 }
 
 extern "C" int anihip_mlp_repack(void *stream_, const anihip_mlp_desc *d, const void *const *src,
-                                 const int32_t *out_in)
+                                 const int32_t *out_in, int32_t *status, int32_t flags)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
     ANIHIP_REQUIRE(src && out_in, "null pointer argument");
-    ANIHIP_REQUIRE(d->precision == ANIHIP_MLP_FP32, "only fp32 descriptors can be refreshed in place (the fp16 "
-                                                    "planes of an F16X3 descriptor would go stale)");
+    if (d->precision == ANIHIP_MLP_F16X3) return repack_f16(stream, d, src, out_in, status, flags);
     RepackArgs a{};
     a.src = (const float *const *)src;
     a.S = d->num_species; a.M = d->n_members; a.nl = d->net[0].n_layers;
@@ -3970,8 +4122,18 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
     for (int s = 0; s < S; ++s)
         for (int l = 0; l < nl; ++l)
             ANIHIP_REQUIRE(grads[s].gw[l] && grads[s].gbias[l], "species %d layer %d: null gradient pointer", s, l);
-    // gradients are overwritten: zero, then accumulate with atomics
-    for (int s = 0; s < S; ++s) {
+    // (a caller that wants d Loss / d aev as well gets the exact-fp32 backward; it runs on the activations of either forward)
+    const bool fast = train_fused(d) && !grad_aev;
+    const int64_t mstride = grads[0].member_stride;
+    const bool accumulate = grads[0].accumulate != 0;
+    for (int s = 0; s < S; ++s)
+        ANIHIP_REQUIRE(grads[s].member_stride == mstride && (grads[s].accumulate != 0) == accumulate,
+                       "member_stride / accumulate must be the same for every species");
+    ANIHIP_REQUIRE(mstride >= 0 && (mstride == 0 || fast),
+                   "per-member gradient arrays (member_stride) are written by the split-fp16 training pass only");
+    ANIHIP_REQUIRE(mstride == 0 || accumulate, "per-member gradient arrays are accumulated into (the caller zeroes them)");
+    // gradients are overwritten (zero, then accumulate with atomics) unless the caller accumulates
+    for (int s = 0; s < S && !accumulate; ++s) {
         const anihip_species_net &nn = d->net[s];
         for (int l = 0; l < nl; ++l) {
             const size_t nw = (size_t)M * nn.dims[l] * nn.dims[l + 1], nb = (size_t)M * nn.dims[l + 1];
@@ -3986,6 +4148,80 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
     float *dlt[ANIHIP_MAX_LAYERS];
     mlp_train_carve(d, n, (char *)workspace, &w, dlt);
     const float alpha = d->celu_alpha, inv_alpha = 1.0f / d->celu_alpha;
+
+    if (fast) {
+        // Fast path: forward + unit-gradient backward by the fused kernel (anihip_mlp_train_forward, or here), then per layer
+        // ONE column reduction (bias gradients) and ONE bf16 x 3 weight-gradient launch, both scaling the rows of
+        // d e / d z by the upstream d Loss / d atomic_e of their atoms.  No GEMM runs in this call.
+        if (!forward_done)
+            if (int rc = train_forward_fused(stream, d, n_atoms, lo, hi, species, aev, w, dlt, atomic_e)) return rc;
+        const int cr_chunks = (int)((n + CR_ROWS - 1) / CR_ROWS) + S;
+        for (int l = nl - 1; l >= 0; --l) {
+            const bool output_layer = l == nl - 1;
+            ColReduceArgs c{};
+            int mx = 0;
+            for (int s = 0; s < S; ++s) {
+                const int width = d->net[s].dims[output_layer ? nl - 1 : l + 1];
+                c.X[s] = output_layer ? w.act[nh - 1] : dlt[l];
+                c.ncols[s] = M * width;
+                c.n_per[s] = width;
+                c.out[s] = output_layer ? grads[s].gw[nl - 1] : grads[s].gbias[l];
+                c.extra[s] = output_layer ? grads[s].gbias[nl - 1] : nullptr;
+                mx = mx > c.ncols[s] ? mx : c.ncols[s];
+            }
+            c.ldx = output_layer ? w.ld[nh - 1] : w.ld[l];
+            c.ctl = w.ctl; c.perm = w.perm; c.S = S; c.M = M;
+            c.g_atom = grad_atomic_e;
+            c.inv_m = output_layer ? 1.0f / (float)M : 1.0f;   // (d e / d z of the hidden layers carries the 1 / M already)
+            c.ct_max = (mx + 255) / 256;
+            c.out_mstride = mstride;
+            // (the bias gradients of the hidden layers are column sums of the rows the weight-gradient kernel stages anyway)
+            if (output_layer) {
+                hipLaunchKernelGGL(k_col_reduce, dim3((unsigned)(cr_chunks * c.ct_max)), dim3(256), 0, stream, c);
+                continue;
+            }
+            WgradB3Args a{};
+            a.ctl = w.ctl; a.perm = w.perm; a.S = S; a.g_atom = grad_atomic_e;
+            a.x_gather = l == 0 ? w.perm : nullptr;
+            a.batch = l == 0 ? 1 : M;
+            int kmax = 0, nmax = 0;
+            for (int s = 0; s < S; ++s) {
+                const anihip_species_net &nn = d->net[s];
+                WgradB3Problem &p = a.prob[s];
+                p.D = dlt[l]; p.ldd = w.ld[l]; p.dW = grads[s].gw[l];
+                p.n_per = nn.dims[l + 1];
+                p.ldw = nn.dims[l];
+                p.w_mstride = mstride > 0 ? mstride : (int64_t)nn.dims[l] * nn.dims[l + 1];
+                if (l == 0) {
+                    p.X = aev; p.ldx = L; p.x_boff = 0; p.k_valid = L; p.d_boff = 0; p.N = nn.dims[1] * M;
+                } else {
+                    p.X = w.act[l - 1]; p.ldx = w.ld[l - 1]; p.x_boff = nn.dims[l]; p.k_valid = nn.dims[l];
+                    p.d_boff = nn.dims[l + 1]; p.N = nn.dims[l + 1];
+                }
+                kmax = kmax > p.k_valid ? kmax : p.k_valid;
+                nmax = nmax > p.N ? nmax : p.N;
+            }
+            a.ki_max = (kmax + 127) / 128;
+            a.nj_max = (nmax + 127) / 128;
+            for (int s = 0; s < S; ++s) {
+                a.gbias[s] = grads[s].gbias[l];
+                a.b_mstride[s] = mstride > 0 ? mstride : (int64_t)d->net[s].dims[l + 1];   // (packed: [M][n_per])
+            }
+            // atoms per workgroup: enough workgroups for several rounds over the chip's 512 slots (the tail of the last
+            // round is what an uneven split costs), few enough that the float atomics of the partial tiles stay cheap
+            {
+                const int64_t tiles = (int64_t)a.batch * a.ki_max * a.nj_max;
+#ifndef ANIHIP_WB_TARGET_WGS
+#define ANIHIP_WB_TARGET_WGS 3072
+#endif
+                int64_t rows = (n * tiles / ANIHIP_WB_TARGET_WGS + 255) / 256 * 256;
+                a.rows_per_chunk = (int)(rows < 512 ? 512 : (rows > 4096 ? 4096 : rows));
+            }
+            launch_wgrad_b3(stream, a, n);
+        }
+        ANIHIP_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
 
     // 1.-2. bucket by species, forward in exact fp32 with the activations kept (or reuse anihip_mlp_train_forward's)
     if (!forward_done) {
@@ -4103,6 +4339,9 @@ extern "C" int anihip_mlp_tangent_weight_grads(void *stream_, const anihip_mlp_d
     hipStream_t stream = (hipStream_t)stream_;
     if (int rc = check_desc(d)) return rc;
     ANIHIP_REQUIRE(species && aev && tangent && workspace && grads && datomic_e, "null pointer argument");
+    for (int s = 0; s < d->num_species; ++s)
+        ANIHIP_REQUIRE(grads[s].member_stride == 0 && grads[s].accumulate == 0,
+                       "the second-order pass overwrites packed [M][...] gradient arrays (member_stride = accumulate = 0)");
     ANIHIP_REQUIRE(0 <= lo && lo <= hi && hi <= n_atoms, "central range outside 0..n_atoms");
     const int S = d->num_species, M = d->n_members, nl = d->net[0].n_layers, nh = nl - 1, L = d->aev_len;
     for (int s = 0; s < S; ++s)

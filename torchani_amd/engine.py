@@ -657,9 +657,11 @@ class PackedNetworks:
                 _row_ptr(grad_aev, rows0, self.aev_len) if want_grad else None, _ptr(member_e)))
         return atomic_e, (grad_aev if want_grad else None), member_e
 
-    def refresh(self, weights, biases) -> None:
-        """Re-read the parameter values (same shapes as at construction) into the packed fp32 arrays with one kernel
-        (anihip_mlp_repack); only for precision="fp32" packs, which is what the training pass reads."""
+    def refresh(self, weights, biases, fused_only: bool = False) -> None:
+        """Re-read the parameter values (same shapes as at construction) into the packed arrays on the device
+        (anihip_mlp_repack): w / wt / bias of an fp32 pack, every layout -- fp32 arrays, {hi, lo} fp16 planes, fragment
+        orders, fused_bounds -- of an f16x3 pack (with the weight scales it was built with; ``scale_overflowed()`` tells,
+        one call late, whether a weight has outgrown them)."""
         M, S, nl = self.M, self.S, self.nl
         ptrs = [t.data_ptr() for m in range(M) for s in range(S) for l in range(nl)
                 for t in (weights[m][s][l], biases[m][s][l])]
@@ -675,8 +677,43 @@ class PackedNetworks:
             self._src_tab = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
             self._src_key = key
             self._out_in = np.asarray(self.shapes, dtype=np.int32).reshape(-1).copy()
+        status = None
+        if self.precision == "f16x3":
+            if getattr(self, "_repack_status", None) is None:
+                self._repack_status = torch.zeros(1, dtype=torch.int32, device=self.device)
+                self._repack_poll = None
+            status = self._repack_status
+        # fused_only (f16x3): what the fused kernel and the fast training pass read; the layer-by-layer layouts go stale until
+        # a full refresh (self.stale_layouts)
+        flags = _lib.REPACK_FUSED_ONLY if (fused_only and self.precision == "f16x3") else 0
+        self.stale_layouts = bool(flags)
         _lib.check(_lib.lib().anihip_mlp_repack(_stream(), C.byref(self.desc), _ptr(self._src_tab),
-                                                self._out_in.ctypes.data))
+                                                self._out_in.ctypes.data, _ptr(status), flags))
+        if status is not None and not torch.cuda.is_current_stream_capturing() and self._repack_poll is None:
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(status, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._repack_poll = (host, ev)
+
+    def scale_overflowed(self) -> bool:
+        """Did a refresh find a weight outside the fp16 range of its layer's scale?  Reads what the PREVIOUS refresh queued
+        (no wait unless the host runs a whole step ahead); the caller then packs again on the host (new scales)."""
+        poll = getattr(self, "_repack_poll", None)
+        if poll is None or torch.cuda.is_current_stream_capturing():
+            return False
+        host, ev = poll
+        if not ev.query():
+            return False
+        self._repack_poll = None
+        return bool(host[0])
+
+    def fast_training(self) -> bool:
+        """Do the training passes of this pack run through the fused network kernel (anihip.h: ANIHIP_MLP_F16X3, CELU, three
+        hidden layers <= 256 wide)?"""
+        return (self.precision == "f16x3" and self.activation == "celu" and self.nl == 4
+                and all(self.desc.net[s].dims[l] <= 256 for s in range(self.S) for l in (1, 2, 3))
+                and self.aev_len <= 1024)
 
     def train_forward(self, species: Tensor, aev: Tensor) -> tp.Tuple[Tensor, Tensor]:
         """First half of a training step: exact-fp32 forward that keeps the activations.  Returns (atomic_e [N],
@@ -752,8 +789,23 @@ class PackedNetworks:
         gw, gb = self._unpack_grads(buf, sizes, offs)
         return gw, gb, de
 
+    def flat_grad_target(self, w_ptr, b_ptr, member_stride: int):
+        """anihip_species_grads table for gradients that go straight into a flat buffer (torchani_amd.optim.Adam):
+        w_ptr[s][l] / b_ptr[s][l] = device addresses of MEMBER 0's weight / bias gradient, member m's lie member_stride floats
+        further on; accumulated into (the optimizer zeroes the buffer).  Needs unpadded widths."""
+        sg = (_lib.SpeciesGrads * self.S)()
+        for s in range(self.S):
+            for l in range(self.nl):
+                out, inn = self.shapes[s][l]
+                if self.desc.net[s].dims[l] != inn or (l < self.nl - 1 and self.desc.net[s].dims[l + 1] != out):
+                    raise ValueError("flat gradient targets need layer widths that are multiples of 32")
+                sg[s].gw[l], sg[s].gbias[l] = int(w_ptr[s][l]), int(b_ptr[s][l])
+            sg[s].member_stride, sg[s].accumulate = int(member_stride), 1
+        return sg
+
     def weight_grads(self, species: Tensor, aev: Tensor, grad_atomic_e: Tensor,
-                     want_grad_aev: bool = False, chunk: int = 1 << 16, workspace: tp.Optional[Tensor] = None):
+                     want_grad_aev: bool = False, chunk: int = 1 << 16, workspace: tp.Optional[Tensor] = None,
+                     target=None):
         """Training pass (anihip_mlp_weight_grads): gradients of  sum_i grad_atomic_e[i] * atomic_e[i]  with respect
         to every weight and bias, returned in torch.nn.Linear layout: gw[m][s][l] [out, in], gb[m][s][l] [out];
         plus atomic_e [N] and, optionally, d Loss / d aev [N, L].  Replaces torch autograd through
@@ -773,7 +825,10 @@ class PackedNetworks:
             chunk = max(n, 1)   # the forward half ran over all atoms at once (train_forward)
         for c0 in range(0, max(n, 1), chunk):
             c1 = min(n, c0 + chunk)
-            buf, sg, sizes, offs = self._grad_buffers(dev)
+            if target is not None:   # (flat_grad_target: accumulated in place, nothing to unpack)
+                buf, sg, sizes, offs = None, target, None, None
+            else:
+                buf, sg, sizes, offs = self._grad_buffers(dev)
             need = L.anihip_mlp_train_workspace_bytes(C.byref(d), c1 - c0)
             if workspace is not None:
                 ws = workspace
@@ -785,7 +840,10 @@ class PackedNetworks:
             _lib.check(L.anihip_mlp_weight_grads(
                 _stream(), C.byref(d), n, c0, c1, _ptr(species), _ptr(aev), _ptr(g_at), _ptr(ws),
                 ws.numel(), sg, _ptr(atomic_e), _ptr(grad_aev), 1 if workspace is not None else 0))
-            total = buf if total is None else total.add_(buf)
+            if buf is not None:
+                total = buf if total is None else total.add_(buf)
+        if target is not None:
+            return None, None, atomic_e, grad_aev
         gw, gb = self._unpack_grads(total, sizes, offs)
         return gw, gb, atomic_e, grad_aev
 

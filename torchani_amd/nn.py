@@ -121,6 +121,7 @@ class _MLPFunction(torch.autograd.Function):
             ae, g, me = packed.forward_backward(species32, a32, want_grad=need_grad, want_members=want_members)
         ctx.g = g
         ctx.train = train
+        ctx.flat_target = getattr(packed, "flat_target", None) if train else None
         ctx.aev_grad = aevs.requires_grad
         ctx.saved = (a32, species32, packed, ws) if train else None
         ctx.params = params if train else ()
@@ -156,8 +157,14 @@ class _MLPFunction(torch.autograd.Function):
             a32, species32, packed, ws = ctx.saved
             # create_graph=True (training on forces): d E / d aev must stay differentiable in the parameters
             second_order = torch.is_grad_enabled() and ctx.aev_grad
+            target = ctx.flat_target if not second_order else None
             gw, gb, _, gaev = packed.weight_grads(species32, a32, grad_out.detach().contiguous(),
-                                                  want_grad_aev=ctx.aev_grad and not second_order, workspace=ws)
+                                                  want_grad_aev=ctx.aev_grad and not second_order, workspace=ws,
+                                                  target=target)
+            if target is not None:
+                # the gradients were ADDED to the flat buffer the parameters' .grad are views of (torchani_amd.optim.Adam):
+                # nothing for autograd to accumulate
+                return (None, None, None, None, *([None] * len(ctx.param_dtypes)))
             if second_order:
                 gaev = _MLPBackwardFunction.apply(grad_out, a32, species32, packed, ctx.shape, *ctx.params)
             flat = _flat_param_grads(packed, gw, gb)
@@ -256,9 +263,27 @@ class _EngineContainer(torch.nn.Module):
             cache[key] = PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, precision, activation=acts.pop())
         return cache[key]
 
-    def _train_pack(self, device: torch.device) -> PackedNetworks:
-        """fp32 pack read by the training pass; built once per parameter set and refreshed in place (one kernel,
-        anihip_mlp_repack) whenever an optimizer step changed the parameters."""
+    # "f16x3" (default): CELU networks of the fused kernel's shape train on the fast path -- forward and backward in ONE
+    # launch of the fused split-fp16 kernel, weight gradients on bf16 x 3 MFMA (include/anihip.h) -- whenever the AEVs need no
+    # gradient (energy training; training on forces differentiates the AEVs and takes the exact-fp32 passes).  "fp32": always
+    # the exact-fp32 layer-by-layer passes of rounds 1-4.
+    train_precision = "f16x3"
+
+    def _fast_trainable(self) -> bool:
+        members = self._member_networks()
+        for m in members:
+            for sname in self.symbols:
+                net = m.atomics[sname]
+                lins = net.linears()
+                if (getattr(net, "activation_name", "celu") != "celu" or len(lins) != 4 or lins[-1].out_features != 1
+                        or any(lin.bias is None for lin in lins) or any(lin.out_features > 256 for lin in lins[:-1])
+                        or lins[0].in_features > 1024 or lins[0].in_features % 16):
+                    return False
+        return True
+
+    def _train_pack(self, device: torch.device, fast: bool = False) -> PackedNetworks:
+        """Pack read by the training pass (fp32, or -- fast -- split-fp16); built once per parameter set and refreshed in place
+        on the device (anihip_mlp_repack) whenever an optimizer step changed the parameters."""
         members = self._member_networks()
         acts = {getattr(m.atomics[s], "activation_name", "celu") for m in members for s in self.symbols}
         if len(acts) != 1:
@@ -277,17 +302,60 @@ class _EngineContainer(torch.nn.Module):
 
         biases = [[[lin.bias if lin.bias is not None else zero_bias(lin) for lin in sl] for sl in ml] for ml in lins]
         params = [p for ml in lins for sl in ml for lin in sl for p in (lin.weight, lin.bias) if p is not None]
-        key = (device, tuple(p.data_ptr() for p in params), tuple(tuple(p.shape) for p in params))
+        precision = "f16x3" if fast else "fp32"
+        key = (device, precision, tuple(p.data_ptr() for p in params), tuple(tuple(p.shape) for p in params))
         versions = tuple(p._version for p in params)
         cache = self.__dict__.setdefault("_train_cache", {})
+        if key in cache and cache[key][0].scale_overflowed():
+            del cache[key]   # (a weight outgrew the fp16 range of its layer's scale: pack again, new scales)
         if key not in cache:
-            cache.clear()
+            for k in [k for k in cache if k[2:] != key[2:] or k[0] != device]:   # (other parameter sets; both precisions may stay)
+                del cache[k]
             aev_len = weights[0][0][0].shape[1]
-            cache[key] = [PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, "fp32", activation=acts.pop()), versions]
+            cache[key] = [PackedNetworks(weights, biases, aev_len, CELU_ALPHA, device, precision, activation=acts.pop()), versions]
         elif cache[key][1] != versions:
-            cache[key][0].refresh(weights, biases)
+            # (a fast pack serves the fused kernel and the fast training pass only: their layouts alone are refreshed)
+            cache[key][0].refresh(weights, biases, fused_only=fast)
             cache[key][1] = versions
         return cache[key][0]
+
+    def _flat_target(self, packed: PackedNetworks, params: tp.List[Tensor]):
+        """The engine's gradient table when every parameter's .grad is (still) its view of ONE flat gradient buffer of a
+        torchani_amd.optim.Adam -- the weight-gradient kernels then add straight into that buffer and autograd receives
+        nothing -- else None (the gradients go through autograd as tensors)."""
+        tag0 = getattr(params[0], "_anihip_flat", None)
+        grp = tag0[0]() if tag0 is not None else None
+        if grp is None:
+            return None
+        views = grp.grad_views
+        for p in params:
+            tag = getattr(p, "_anihip_flat", None)
+            if tag is None or tag[0]() is not grp or p.grad is not views[tag[1]]:
+                return None
+        key = (id(grp), id(packed), len(params))
+        hit = self.__dict__.get("_flat_target_cache")
+        if hit is not None and hit[0] == key and hit[2] is grp:
+            return hit[1]
+        M, S, nl = packed.M, packed.S, packed.nl
+        per = 2 * S * nl
+        if len(params) != M * per:
+            return None
+        base = [params[i].grad.data_ptr() for i in range(per)]
+        stride = sum(params[i].numel() for i in range(per))
+        if M > 1:
+            sb = params[per].grad.data_ptr() - base[0]
+            if sb <= 0 or sb % 4 or any(params[m * per + i].grad.data_ptr() - base[i] != m * sb
+                                        for m in range(1, M) for i in range(per)):
+                return None
+            stride = sb // 4
+        w_ptr = [[base[(s_ * nl + l) * 2] for l in range(nl)] for s_ in range(S)]
+        b_ptr = [[base[(s_ * nl + l) * 2 + 1] for l in range(nl)] for s_ in range(S)]
+        try:
+            tgt = packed.flat_grad_target(w_ptr, b_ptr, stride)
+        except ValueError:
+            return None
+        self.__dict__["_flat_target_cache"] = (key, tgt, grp)
+        return tgt
 
     def _run(self, elem_idxs: Tensor, aevs: Tensor, atomic: bool, ensemble_values: bool) -> Tensor:
         if not aevs.is_cuda:
@@ -301,7 +369,10 @@ class _EngineContainer(torch.nn.Module):
         trainable_fast = (params and not ensemble_values
                           and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == aevs.device
                                   for p in params))
-        packed = self._train_pack(aevs.device) if trainable_fast else self._pack(aevs.device)
+        # (the fast training path returns no d Loss / d aev: training on forces keeps the exact-fp32 passes)
+        fast = bool(trainable_fast and not aevs.requires_grad and self.train_precision == "f16x3" and self._fast_trainable())
+        packed = self._train_pack(aevs.device, fast) if trainable_fast else self._pack(aevs.device)
+        packed.flat_target = self._flat_target(packed, params) if fast else None
         # which (weight, bias) slots of the engine's member -> species -> layer order have a parameter behind them
         packed.has_bias = [lin.bias is not None for m in self._member_networks() for s in self.symbols
                            for lin in m.atomics[s].linears()]
