@@ -149,6 +149,10 @@ def main():
     ap.add_argument("--emulate-shard", default=None, metavar="RANK/WORLD",
                     help="development aid (N=1 only): time what rank RANK of WORLD does in a step, without "
                          "the collective -- prints ms/step and exits")
+    ap.add_argument("--emulate-option-c", action="store_true",
+                    help="with --emulate-shard: cost SURVEY 8(e) option C instead -- a REDUNDANT halo of twice the reach, the "
+                         "rank evaluates its owned atoms AND the halo atoms within one reach of them, so every force on an owned "
+                         "atom is complete locally and the only collective is an all-reduce of the scalar energy")
     ap.add_argument("--partition-skin", type=float, default=1.0,
                     help="N > 1: skin (Angstrom) of the spatial shards' halos; the partition is reused until an atom moved skin/2")
     ap.add_argument("--mlp-chunk", type=int, default=0, help="development aid: atoms per launch group of the network stage")
@@ -170,7 +174,7 @@ def main():
 
     from torchani_amd import _lib
     from torchani_amd.models import ANI2x
-    from torchani_amd.parallel import init_from_env, shard_range
+    from torchani_amd.parallel import exchange_transport, init_from_env, shard_range
 
     rank, world, local, group = init_from_env(args.dist_backend)
     if args.dist_backend == "gloo":
@@ -227,9 +231,18 @@ def main():
         sp32 = species.to(torch.int32).contiguous()
         part = model._spatial_partition(sp32, coords, cell, pbc, r, wd)
         sp_e, order = model._engine_species(sp32)   # (the kernels' species numbering, models.ANI.compact_species)
+        lo, hi, nl = part.n_left, part.n_left + part.n_owned, part.n_local
+        if args.emulate_option_c:
+            # option C: the local system reaches TWICE as far (everything an owned atom's force depends on), and the central
+            # atoms are the owned ones plus the halo atoms within one reach of the slab -- the halo is sorted by layer along the
+            # slab axis, so at uniform density those are the inner half of each side
+            part = type(part)(coords, cell, pbc, wd, r, 2.0 * model._spatial_reach() + model.partition_skin, sp32,
+                              skin=model.partition_skin)
+            lo, hi, nl = part.n_left - part.n_left // 2, part.n_left + part.n_owned + part.n_right // 2, part.n_local
+            print(f"  option C (redundant halo, scalar all-reduce only): local system {nl} atoms, central atoms {hi - lo} "
+                  f"for {part.n_owned} owned")
         sp_l = part.local(sp_e).view(1, -1).contiguous()
         x_l = part.local(coords, 3).view(1, -1, 3).contiguous()
-        lo, hi, nl = part.n_left, part.n_left + part.n_owned, part.n_local
         packed = model.neural_networks._pack(dev, order)
         st = {f"partition (cut once per skin {model.partition_skin} A of motion)": time_stage(
             lambda: type(part)(coords, cell, pbc, wd, r, model._spatial_reach(), sp32, skin=model.partition_skin), 3)}
@@ -246,6 +259,8 @@ def main():
         st["aev_backward"] = time_stage(lambda: eng.backward(sp_l, nbrs, gaev, gc, shard_rows=True, slab_mask=mask), 3)
         st["scatter results"] = time_stage(lambda: (part.scatter_local(gc), part.scatter_owned(ae)), 3)
         print("  stages ms: " + "  ".join(f"{k} {v:.3f}" for k, v in st.items()))
+        per_step = sum(v for k, v in st.items() if not k.startswith("partition"))
+        print(f"  sum of the per-step stages: {per_step:.3f} ms")
         return
 
     for _ in range(args.warmup):
@@ -276,13 +291,20 @@ def main():
     assert torch.isfinite(out.energies).all() and torch.isfinite(out.forces).all()
     # ---- is the headline result RIGHT?  Sampled atoms of the full box against the fp64 oracle (outside the timed region):
     # the cluster within 2 Rcr of an atom reproduces its energy and force in the periodic box exactly (oracle/sampled_parity.py)
+    # N > 1: rank 0 checks atoms it OWNS (forces stay with their owners; the clusters are cut from the whole box, which every
+    # rank holds), a quarter of the sample so that the other ranks do not wait long at the final barrier
     parity = None
-    if world == 1 and args.parity_sample > 0:
+    if rank == 0 and args.parity_sample > 0:
         from oracle.sampled_parity import sampled_parity
 
         sd_np = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        owned = None
+        if group is not None:
+            owned = model.__dict__["_spatial_cache"][1].owned_idx.cpu().numpy()   # (the partition of the last step)
         parity = sampled_parity(species, coords, cell, out.atomic_energies, out.forces, sd_np, "ani2x", 8,
-                                n_sample=args.parity_sample, seed=7)
+                                n_sample=args.parity_sample if group is None else max(32, args.parity_sample // 4), seed=7,
+                                candidates=owned)
+        parity["atoms_sampled_from"] = "the whole box" if group is None else f"the {len(owned)} atoms rank 0 owns"
         assert parity["max_dE_atom"] <= parity["regression_gate_dE_atom"] and parity["max_dF"] <= parity["regression_gate_dF"], \
             f"headline result disagrees with the oracle: {parity}"
 
@@ -338,16 +360,16 @@ def main():
     # HBM traffic of the AEV forward kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB per
     # dispatch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) measured on a smaller box of
     # the same density and committed under profiles/; scaled by the atom count of this launch
-    aev_traffic = bwd_traffic = mlp_traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r04_pmc_l0b.json")
-    if not os.path.exists(pmc_file):
-        pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_aev.json")
+    aev_traffic = bwd_traffic = mlp_traffic = nbr_traffic = None
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc.json", "r04_pmc_l0b.json", "r03_pmc_aev.json"))
+                     if os.path.exists(f)), "")
     if os.path.exists(pmc_file):
         with open(pmc_file) as fh:
             pm = json.load(fh)
         per_atom = {k: (v["fetch_size_kb"] * pm["fetch_correction"] + v["write_size_kb"]) * 1024.0 / pm["n_atoms"]
                     for k, v in pm["kernels"].items()}
         aev_traffic, bwd_traffic = per_atom["k_aev_fwd3"] * n_shard, per_atom["k_aev_bwd"] * n_shard
+        nbr_traffic = per_atom["k_nbr_cell2"] * n_shard if "k_nbr_cell2" in per_atom else None
         # (the network stage: every kernel of it that the counter file knows, per atom of a launch)
         # (the counter file holds means per DISPATCH; the network kernels run once per launch group: dispatches per step =
         # their dispatch count over that of a kernel that runs once per step)
@@ -387,22 +409,49 @@ def main():
         },
         "ms_per_step_median": median_ms,
         "roofline": {
-            "kernel": "k_aev_fwd3<8,4,rec> (fused radial+angular AEV forward)", "bound": "hbm",
+            # what the step runs: the engine keeps the rows between steps and the kernel rewrites only the slabs that were or
+            # are flagged (anihip_aev_forward_update).  `achieved` prices the launch at the ALGORITHMIC bytes of SURVEY 8(d)
+            # -- the dense 4032-B row of every atom -- which this variant no longer moves: it is an algorithmic-throughput
+            # figure (the kernel is VALU-issue-bound); the bytes that do move are `traffic`, their rate `achieved_counter_GBps`.
+            # `full_rows` is the same kernel writing every row in full into a caller's buffer (AEVComputer.forward): the
+            # like-for-like figure against the section-8(d) bytes.
+            "kernel": "k_aev_fwd3<8,4,rec,UPDATE> (fused radial+angular AEV forward; rows kept by the engine and updated in "
+                      "place: only flagged 32-column slabs are rewritten)", "bound": "hbm",
             "achieved": aev_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": aev_gbs / HBM_PEAK_GBS,
             "traffic": aev_traffic, "algorithmic_bytes_per_atom": bytes_per_atom,
+            "achieved_counter_GBps": (aev_traffic / (st["aev_forward"] * 1e-3) / 1e9) if aev_traffic else None,
+            "full_rows": ({"kernel": "k_aev_fwd3<8,4,rec> writing all 1008 columns of every row",
+                           "avg_launch_ms": st["aev_forward_full_rows"],
+                           "achieved": bytes_per_atom * n_shard / (st["aev_forward_full_rows"] * 1e-3) / 1e9,
+                           "frac": bytes_per_atom * n_shard / (st["aev_forward_full_rows"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                          if "aev_forward_full_rows" in st else None),
             "mean_radial_neighbors": n_r, "mean_angular_neighbors": n_a, "avg_launch_ms": st["aev_forward"],
         },
         "roofline_bwd": {
             "kernel": "k_aev_bwd<8,4> (analytic AEV backward: radial by symmetric gather, angular pair loop)",
             "bound": "hbm", "achieved": bwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_gbs / HBM_PEAK_GBS,
             "traffic": bwd_traffic, "algorithmic_bytes_per_atom": bytes_per_atom_bwd,
+            "achieved_counter_GBps": (bwd_traffic / (st["aev_backward"] * 1e-3) / 1e9) if bwd_traffic else None,
             "avg_launch_ms": st["aev_backward"],
+        },
+        "roofline_nbr": {
+            # neighbor rows (binning + k_nbr_cell2 + finish): per central atom 16 B of packed position in, 24 B of row
+            # metadata and 16 B per radial neighbor out; the launch duration is the whole STAGE (events
+            # around anihip_nbr_build_cell), of which k_nbr_cell2 is ~80 % (profiles/: kernel statistics of the same command)
+            "kernel": "neighbor stage: k_bin_* + k_nbr_cell2 (one wave per bin, candidates staged in LDS)", "bound": "hbm",
+            "algorithmic_bytes_per_atom": 16.0 + 24.0 + 16.0 * n_r,
+            "achieved": (16.0 + 24.0 + 16.0 * n_r) * n_shard / (st["neighbors"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": (16.0 + 24.0 + 16.0 * n_r) * n_shard / (st["neighbors"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": nbr_traffic,
+            "achieved_counter_GBps": (nbr_traffic / (st["neighbors"] * 1e-3) / 1e9) if nbr_traffic else None,
+            "avg_launch_ms": st["neighbors"],
         },
         "roofline_mfma": {
             "kernel": "ensemble fwd + input-gradient bwd: k_mlp_fused<2,1,CELU,L0B> (layer 0 over flagged AEV slabs + hidden "
                       "stack + backward + layer-0 backward as phase 5: a workgroup owns a tile through all members), "
                       f"precision {packed.precision}",
             "traffic": mlp_traffic,   # HBM bytes of the stage per step from the committed counter file (round 3: 51.8e9)
+            "achieved_counter_GBps": (mlp_traffic / (st["mlp_fwd_bwd"] * 1e-3) / 1e9) if mlp_traffic else None,
             "bound": "mfma",
             # the split-fp16 path issues 3 fp16 MFMA flops per fp32 flop it replaces: price the ISSUED fp16
             # flops of the EXECUTED (slab-skipped) work against the dense fp16 MFMA peak
@@ -415,6 +464,7 @@ def main():
         },
         "stages_ms": st,
         "parity_sample": parity,
+        "energy_Ha": float(out.energies.reshape(-1)[0]),   # (total energy of the box: the same number at every N)
     }
     if group is not None:
         per_rank = [None] * world
@@ -434,6 +484,9 @@ def main():
             "collectives_per_step": lc["collectives_per_step"], "world_size": lc["world_size"],
             "bytes_per_step": lc["bytes"], "op": lc.get("op", "all_reduce(sum, fp32)"), "backend": backend,
             "ranks_seen": seen, "forces": "left with the owning rank (reduce_forces=False), not gathered",
+            # "collective": ONE all_to_all_single with uneven pieces; "p2p": the same pieces as batched isend / irecv -- the
+            # fallback every rank takes if the collective's first call raises (fell_back = its error message)
+            "transport": exchange_transport(),
             "validity_check": "every timed step: device flags, read one step late (coords.add_(0.0) bumps the tensor version)",
             "local_atoms": lc.get("n_local"), "owned_atoms": lc.get("n_owned"), "halo_atoms": lc.get("n_halo"),
             "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,

@@ -303,13 +303,11 @@ typedef struct {
 #define ANIHIP_MLP_FLAG_BIG_TILES 2u      /* 256 x 256 layer-0 tiles (default from 16384 atoms) even for few atoms */
 #define ANIHIP_MLP_FLAG_SMALL_TILES 4u    /* 128 x 128 layer-0 tiles whatever the size */
 #define ANIHIP_MLP_FLAG_NO_SLAB_MASK 8u   /* ignore slab_mask: multiply every AEV slab */
-#define ANIHIP_MLP_FLAG_FUSED_ROWS32 16u  /* fused kernel: 32-atom tiles, two workgroups per CU (default 64 / one) */
+/* (16, 64, 128, 256: development switches of rounds 1-4 -- 32-atom tiles, separate preparation launches, the 4-wave
+ * layer-0 backward, tile-owner order without phase 5 -- retired in ABI 11; setting them changes nothing) */
 #define ANIHIP_MLP_FLAG_D0_ROWS 32u       /* d E/d act0 handed to the layer-0 backward row-major, not tile-major */
-#define ANIHIP_MLP_FLAG_NO_SMALL_PREP 64u /* <= 16384 atoms: bucketing / tile table / padding rows as separate launches, not one */
-#define ANIHIP_MLP_FLAG_TILE_OWNER 256u   /* fused kernel: a workgroup takes a tile through all members (default: member-major sweep) */
 #define ANIHIP_MLP_FLAG_FUSED_L0B 512u    /* layer-0 backward inside the fused kernel whatever the size (default: from 65536 atoms) */
 #define ANIHIP_MLP_FLAG_NO_FUSED_L0B 1024u /* ... never: d E/d act0 through HBM + a layer-0 backward GEMM launch */
-#define ANIHIP_MLP_FLAG_L0B_4WAVE 128u    /* < 16384 atoms: the generic 4-wave 128 x 128 kernel for the layer-0 backward, not the 8-wave one */
 typedef struct {
     int32_t num_species;
     int32_t n_members;

@@ -46,9 +46,12 @@ def cut_clusters(species, coords, cell, centers: np.ndarray, radius: float):
 
 
 def sampled_parity(species, coords, cell, atomic_energies, forces, state_dict: tp.Mapping[str, np.ndarray], kind: str = "ani2x",
-                   n_members: int = 8, n_sample: int = 512, seed: int = 0, batch: int = 128) -> tp.Dict[str, tp.Any]:
+                   n_members: int = 8, n_sample: int = 512, seed: int = 0, batch: int = 128,
+                   candidates: tp.Optional[np.ndarray] = None) -> tp.Dict[str, tp.Any]:
     """Compare ``atomic_energies`` [N] (NN part, ensemble mean) and ``forces`` [N, 3] of a periodic system with the fp64
-    oracle on ``n_sample`` random real atoms.  Returns {n, max_dE_atom, max_dF, cluster_atoms_mean, seconds}."""
+    oracle on ``n_sample`` random real atoms -- of ``candidates`` (atom indices) when given: a rank of a sharded run holds
+    the results of the atoms it OWNS, the clusters are cut from the whole box (which every rank has).
+    Returns {n, max_dE_atom, max_dF, cluster_atoms_mean, seconds}."""
     import time
 
     import torch
@@ -62,6 +65,8 @@ def sampled_parity(species, coords, cell, atomic_energies, forces, state_dict: t
     o64 = orc.Oracle("f64")
     sp = species.reshape(-1)
     real = torch.nonzero(sp >= 0).reshape(-1).cpu().numpy()
+    if candidates is not None:
+        real = np.intersect1d(real, np.asarray(candidates, dtype=np.int64))
     rs = np.random.RandomState(seed)
     centers = np.sort(rs.choice(real, size=min(n_sample, len(real)), replace=False))
     e_dev = atomic_energies.reshape(-1)[torch.from_numpy(centers).to(atomic_energies.device)].double().cpu().numpy()

@@ -265,7 +265,47 @@ def test_bench_two_ranks_gloo():
     seen = coll["ranks_seen"]
     assert sorted(s["rank"] for s in seen) == [0, 1] and len({s["pid"] for s in seen}) == 2
     assert seen[0]["peers"] == [1] and seen[1]["peers"] == [0]
-    return r
+    # the N > 1 line carries correctness evidence: rank 0's owned atoms against the fp64 oracle
+    par = r["parity_sample"]
+    assert par is not None and "rank 0 owns" in par["atoms_sampled_from"]
+    assert par["max_dE_atom"] <= par["regression_gate_dE_atom"] and par["max_dF"] <= par["regression_gate_dF"]
+
+
+def test_bench_eight_ranks_gloo_equals_one_rank():
+    """First contact with 8 ranks, as far as one GPU goes: ``bench.py --gpus 8`` (eight processes sharing the GPU over gloo,
+    a 41 472-atom box: slabs of 9.3 A against a reach of 6.1 A) -- every rank is seen, force rows travel to the two slab
+    neighbours only, the bytes are what the plan says, rank 0's oracle sample of atoms it owns is inside the regression gates,
+    and the total energy equals the single-rank run's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--steps", "2", "--warmup", "2", "--waters-side", "24", "--no-dense-stage", "--no-secondary", "--no-cpu-baseline"]
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--parity-sample", "0"] + common,
+                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p1.returncode == 0, p1.stdout[-2000:] + p1.stderr[-4000:]
+    one = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][0])
+    p8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo",
+                         "--parity-sample", "128"] + common, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p8.returncode == 0, p8.stdout[-2000:] + p8.stderr[-4000:]
+    lines = [ln for ln in p8.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p8.stdout[-2000:]
+    r = json.loads(lines[0])
+    n = r["config"]["n_atoms"]
+    assert r["n_gpus"] == 8 and n == one["config"]["n_atoms"] == 3 * 24 ** 3
+    coll = r["collective"]
+    assert coll["world_size"] == 8 and coll["collectives_per_step"] == 1
+    assert coll["transport"]["transport"] == "collective" and coll["transport"]["fell_back"] is None
+    seen = sorted(coll["ranks_seen"], key=lambda s_: s_["rank"])
+    assert [s_["rank"] for s_ in seen] == list(range(8)) and len({s_["pid"] for s_ in seen}) == 8
+    assert sum(s_["owned_atoms"] for s_ in seen) == n
+    for s_ in seen:
+        assert sorted(s_["peers"]) == sorted({(s_["rank"] - 1) % 8, (s_["rank"] + 1) % 8}), s_
+        halo = s_["local_atoms"] - s_["owned_atoms"]
+        # halo force rows (3 fp32 words each) to their owners + the partial energy (two fp32 words) to the 7 other ranks
+        assert s_["sent_bytes_per_step"] == 4 * (3 * halo + 2 * 7), s_
+    par = r["parity_sample"]
+    assert par is not None and par["n"] == 32 and "rank 0 owns" in par["atoms_sampled_from"]
+    assert par["max_dE_atom"] <= par["regression_gate_dE_atom"] and par["max_dF"] <= par["regression_gate_dF"]
+    assert abs(r["energy_Ha"] - one["energy_Ha"]) < 1e-7 * n
 
 
 def test_bench_launches_its_own_ranks():

@@ -107,12 +107,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, transport="collective"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         sys.path.insert(0, ROOT)
         import torch.distributed as dist
+        import torchani_amd.parallel as par
         from torchani_amd.parallel import SpatialShards
+
+        if transport == "p2p":
+            par._EXCHANGE["transport"] = "p2p"
+        elif transport == "fallback":   # the collective raises on its first call: every rank must switch to p2p and go on
+            def broken(*a, **k):
+                raise RuntimeError("all_to_all_single: uneven splits are not supported (simulated)")
+            dist.all_to_all_single = broken
 
         dist.init_process_group("gloo")
         L = [30.0, 12.0, 12.0]
@@ -145,7 +153,7 @@ def _worker(rank, world, port, q):
         err = float((full.double() - ref).abs().max())
         err_own = float((mine[part.owned_idx].double() - ref[part.owned_idx]).abs().max())
         q.put((rank, {"err": err, "err_own": err_own, "dE": abs(float(tot[0]) - e_ref), "bytes": part.last_bytes,
-                      "n_local": part.n_local}))
+                      "n_local": part.n_local, "transport": par.exchange_transport()}))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:
@@ -154,12 +162,14 @@ def _worker(rank, world, port, q):
         q.put((rank, {"error": repr(e) + "\n" + traceback.format_exc()}))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_exchange_over_gloo_equals_single_rank(world):
+@pytest.mark.parametrize("world,transport", [(2, "collective"), (3, "collective"), (3, "p2p"), (2, "fallback")])
+def test_exchange_over_gloo_equals_single_rank(world, transport):
+    """... through ONE all_to_all_single, through the same pieces as batched isend / irecv, and when the collective raises on
+    its first call (every rank falls back to isend / irecv and says so)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))
@@ -168,6 +178,9 @@ def test_exchange_over_gloo_equals_single_rank(world):
     for r in range(world):
         assert "error" not in res[r], res[r]["error"]
         assert res[r]["err"] < 1e-4 and res[r]["err_own"] < 1e-4 and res[r]["dE"] < 1e-9, res[r]   # (fp32 sums of ~80 N(0, 1) pushes)
+        tr = res[r]["transport"]
+        assert tr["transport"] == ("collective" if transport == "collective" else "p2p")
+        assert (tr["fell_back"] is not None) == (transport == "fallback")
 
 
 def test_plan_triclinic_cell():

@@ -52,9 +52,7 @@ def measure(dev=None, reps2=50, reps3=20):
         from torchani_amd import _lib
         from torchani_amd.engine import PackedNetworks
 
-        for nm, fl in (("l0b_wide", _lib.MLP_FLAG_L0B_4WAVE), ("no_small_prep", _lib.MLP_FLAG_NO_SMALL_PREP),
-                       ("big_tiles", _lib.MLP_FLAG_BIG_TILES), ("no_fused", _lib.MLP_FLAG_NO_FUSED),
-                       ("rows32", _lib.MLP_FLAG_FUSED_ROWS32), ("rows32_big", _lib.MLP_FLAG_FUSED_ROWS32 | _lib.MLP_FLAG_BIG_TILES)):
+        for nm, fl in (("big_tiles", _lib.MLP_FLAG_BIG_TILES), ("no_fused", _lib.MLP_FLAG_NO_FUSED)):
             PackedNetworks.default_flags = fl
             g2 = model.graphed(spd, xd)
             out["config2"]["ms_graph_" + nm] = timeit(lambda: g2(xd), reps=reps2) * 1e3
@@ -80,15 +78,20 @@ def measure_config5(steps: int = 10):
     import train_bench
 
     out = {}
+    old = ["--optimizer", "torch", "--train-precision", "fp32"]   # rounds 1-4: exact-fp32 passes + torch.optim.Adam
     for tag, argv in (("ani2x_x8_eager", ["--kind", "ani2x", "--members", "8"]),
                       ("ani2x_x8_graph", ["--kind", "ani2x", "--members", "8", "--graph"]),
+                      ("ani2x_x8_graph_fp32_torch_adam", ["--kind", "ani2x", "--members", "8", "--graph"] + old),
                       ("ani1x_x1_eager", ["--kind", "ani1x", "--members", "1"]),
-                      ("ani1x_x1_graph", ["--kind", "ani1x", "--members", "1", "--graph"])):
+                      ("ani1x_x1_graph", ["--kind", "ani1x", "--members", "1", "--graph"]),
+                      ("ani1x_x1_graph_fp32_torch_adam", ["--kind", "ani1x", "--members", "1", "--graph"] + old)):
         out[tag] = train_bench.run(train_bench.parse(argv + ["--steps", str(steps), "--warmup", "3"]), quiet=True)
         torch.cuda.empty_cache()
     out["workload"] = ("2560 synthetic ANI-1x-like conformers (H C N O, 2-24 atoms, padded), energy loss MSE / sqrt(n_atoms), "
                        "Adam lr 1e-4; eager = AEV / networks / backward / optimizer timed separately, graph = the whole step "
-                       "replayed as one HIP graph")
+                       "replayed as one HIP graph; default = the fast path of round 5 (fused split-fp16 forward + backward kernel, "
+                       "bf16x3 weight gradients, torchani_amd.optim.Adam: one launch, gradients written in place), "
+                       "*_fp32_torch_adam = the exact-fp32 layer-by-layer passes with torch.optim.Adam (rounds 1-4) in the same run")
     return out
 
 

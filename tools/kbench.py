@@ -27,6 +27,7 @@ def main():
     from torchani_amd.models import ANI2x
 
     dev = torch.device("cuda:0")
+    torch.manual_seed(0)
     sp_np, x_np, cell_np = water_box(args.side)
     n = sp_np.shape[1]
     if args.order != "lattice":
@@ -96,6 +97,8 @@ def main():
         line += f" | fwd_update {bpa * n / out['fwd_update'] / 1e6:.0f} GB/s ({bpa * n / out['fwd_update'] / 1e6 / 8000:.1%} of 8 TB/s on the same algorithmic bytes)"
     if "mlp" in out:
         line += f" | mlp {mlp_flops_per_atom(sp_np.reshape(-1)) * n / out['mlp'] / 1e9:.1f} TFLOP/s"
+        # (checksums: library variants that only reschedule instructions must print the same digits)
+        line += f" | sum(e)={float(ae.double().sum()):.9f} sum|dE/dAEV|={float(gaev.double().abs().sum()):.7f}"
     print(line)
 
 

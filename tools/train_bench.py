@@ -32,6 +32,30 @@ def conformers(n_mol, n_at, seed=5):
     return sp, x
 
 
+def step_flops(sp, kind, members):
+    """MFMA work of one energy-training step on the fast path, from the batch's species: fp32-equivalent flops (2 per
+    multiply-add of the mathematical GEMMs: layer 0 over the AEV slabs of species (pairs) that occur in the batch, hidden
+    layers forward and backward, weight gradients over the whole AEV) and the bf16 / fp16 flops actually issued (the
+    fused kernel's three-product split, the weight-gradient kernel's six products)."""
+    from torchani_amd.weights import arch_spec
+
+    symbols, consts, hidden = arch_spec(kind)
+    S = len(symbols)
+    present = [int((sp == s).sum()) for s in range(S)]
+    n_present = sum(1 for c in present if c > 0)
+    rad_slabs = len({s // 2 for s in range(S) if present[s] > 0})
+    slabs = rad_slabs + n_present * (n_present + 1) // 2 if consts.out_dim == 16 * S + 32 * (S * (S + 1) // 2) else -(-consts.out_dim // 32)
+    fb = wg = 0.0
+    for s, sym in enumerate(symbols):
+        h1, h2, h3 = hidden[sym]
+        r = lambda v: -(-v // 32) * 32   # (the kernels work on widths padded to 32)
+        h1, h2, h3 = r(h1), r(h2), r(h3)
+        fb += present[s] * members * 2.0 * (32 * slabs * h1 + 2 * h1 * h2 + 2 * h2 * h3 + h3)
+        wg += present[s] * members * 2.0 * (consts.out_dim * h1 + h1 * h2 + h2 * h3 + h3)
+    return {"fp32_equivalent": fb + wg, "issued": 3.0 * fb + 6.0 * wg, "flagged_slabs": slabs,
+            "forward_backward_fp32_equivalent": fb, "weight_grads_fp32_equivalent": wg}
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--kind", default="ani1x")
@@ -138,8 +162,19 @@ def run(args, quiet=False):
             print(f"config 5, whole step replayed as a HIP graph: {args.kind} x{args.members}, batch {args.batch} conformers "
                   f"({n_real} atoms): {dt * 1e3:.2f} ms/step = {args.batch / dt:.0f} conformers/s; "
                   f"loss {first:.5f} -> {float(static_loss.detach()):.5f}")
-        return {"ms_per_step": dt * 1e3, "conformers_per_s": args.batch / dt, "atoms": n_real,
-                "loss_first": first, "loss_last": float(static_loss.detach())}
+        out = {"ms_per_step": dt * 1e3, "conformers_per_s": args.batch / dt, "atoms": n_real,
+               "loss_first": first, "loss_last": float(static_loss.detach())}
+        if nets.train_precision == "f16x3" and not args.forces:
+            fl = step_flops(sp, args.kind, args.members)
+            out["roofline"] = {"bound": "mfma", "kernels": "k_mlp_fused<2,1,CELU,TRAIN> (f16x3) + k_wgrad_b3 x 3 (bf16x3)",
+                               "achieved": fl["issued"] / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                               "frac": fl["issued"] / dt / 1e12 / 2500.0,
+                               "fp32_equivalent_tflops": fl["fp32_equivalent"] / dt / 1e12, "fp32_mfma_peak": 157.3,
+                               "flagged_slabs": fl["flagged_slabs"],
+                               "note": "whole graphed step (AEV, networks forward + backward, weight gradients, Adam, parameter "
+                                       "refresh) in the denominator; issued = 3 fp16 MFMA flops per fp32 flop of the fused "
+                                       "kernel, 6 bf16 per fp32 flop of the weight gradients"}
+        return out
     for _ in range(args.warmup):
         step(False)
     losses = [step(True) for _ in range(args.steps)]

@@ -33,9 +33,7 @@ PAIR_NO_CLAMP = 2
 PAIR_XTB, PAIR_ZBL, PAIR_LJ, PAIR_COULOMB = 0, 1, 2, 3
 ACT_CELU, ACT_GELU = 0, 1
 # anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*)
-MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_FUSED_ROWS32, MLP_FLAG_D0_ROWS = \
-    1, 2, 4, 8, 16, 32
-MLP_FLAG_NO_SMALL_PREP, MLP_FLAG_L0B_4WAVE, MLP_FLAG_TILE_OWNER = 64, 128, 256
+MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_D0_ROWS = 1, 2, 4, 8, 32
 MLP_FLAG_FUSED_L0B, MLP_FLAG_NO_FUSED_L0B = 512, 1024
 ABI_VERSION = 11
 REPACK_FUSED_ONLY = 1

@@ -3449,7 +3449,7 @@ static FbPlan fb_plan(const anihip_mlp_desc *d, int64_t n, bool want_grad)
     p.big_tiles = h3 && n >= 16384;
     if (d->flags & ANIHIP_MLP_FLAG_BIG_TILES) p.big_tiles = h3;
     if (d->flags & ANIHIP_MLP_FLAG_SMALL_TILES) p.big_tiles = false;
-    p.fused_rows = ((d->flags & ANIHIP_MLP_FLAG_FUSED_ROWS32) && d->activation == ANIHIP_ACT_CELU) ? 32 : 64;
+    p.fused_rows = 64;   // (the 32-atom / two-workgroups-per-CU tiling of rounds 1-4 was 3 % slower and spilled 300 registers: removed in round 5)
     // Layer-0 backward INSIDE the fused kernel (its phase 5): a workgroup owns a tile through all members and adds the
     // members' d E / d AEV in place -- no d act0 round trip through HBM (8 KB per atom written and read back), no layer-0
     // backward launch.  Tiles are then the unit of work (not tile x member items), so it needs enough of them to balance
@@ -3458,10 +3458,13 @@ static FbPlan fb_plan(const anihip_mlp_desc *d, int64_t n, bool want_grad)
     // (... and its k range is cut in two halves of >= 2 steps each for the two waves of a SIMD: first hidden layers of >= 64
     // columns -- with 32 the first half would be empty and its ring would read in front of the member's planes)
     auto l0b_ok = [&](int s) { return d->net[s].wthf[0] != nullptr && d->net[s].dims[2] >= 128 && d->net[s].dims[1] >= 64; };
-    p.fused_l0b = p.fused && want_grad && p.fused_rows == 64 && n >= FUSED_L0B_MIN_ATOMS &&
+    // (CELU networks: the GELU instantiation with phase 5 spilled registers and served ANI-2xr on > 65 536 atoms only --
+    // removed in round 5, those systems take the d act0 hand-over + layer-0 backward GEMM)
+    const bool celu = d->activation == ANIHIP_ACT_CELU;
+    p.fused_l0b = p.fused && want_grad && celu && n >= FUSED_L0B_MIN_ATOMS &&
                   !(d->flags & (ANIHIP_MLP_FLAG_NO_FUSED_L0B | ANIHIP_MLP_FLAG_SMALL_TILES));
     if (d->flags & ANIHIP_MLP_FLAG_FUSED_L0B)   // (forced, e.g. by the tests on small inputs; the call checks that it can)
-        p.fused_l0b = p.fused && want_grad && p.fused_rows == 64;
+        p.fused_l0b = p.fused && want_grad && celu;
     for (int s = 0; s < S && p.fused_l0b; ++s) p.fused_l0b = l0b_ok(s);
     p.n_act = !p.fused ? nh : ((want_grad && !p.fused_l0b) ? 1 : 0);
     return p;
@@ -3606,7 +3609,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     // general AEV kernel; rows of at most 1024 columns)
     const uint32_t *tab_mask = ((kp_rad > 0 || (h3 && K0p <= 32 * 32)) && !(d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK)) ? slab_mask : nullptr;
     const uint32_t all_slabs = n_slabs >= 32 ? 0xFFFFFFFFu : ((1u << n_slabs) - 1u);
-    const bool small_prep = n <= SMALL_PREP_MAX && !(d->flags & ANIHIP_MLP_FLAG_NO_SMALL_PREP);
+    const bool small_prep = n <= SMALL_PREP_MAX;
     if (small_prep) {
         const size_t lds = sizeof(int) * (size_t)fused_tiles;
         ANIHIP_CHECK_HIP(hipFuncSetAttribute((const void *)k_small_prep, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3688,17 +3691,16 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
     // layer-0 backward inside the fused kernel (fb_plan)
     const bool fused_l0b = plan.fused_l0b;
     if (d->flags & ANIHIP_MLP_FLAG_FUSED_L0B)
-        ANIHIP_REQUIRE(fused_l0b, "ANIHIP_MLP_FLAG_FUSED_L0B needs the fused kernel (64-row tiles), wthf[0] and second hidden layers of >= 128 columns");
+        ANIHIP_REQUIRE(fused_l0b, "ANIHIP_MLP_FLAG_FUSED_L0B needs the fused kernel with CELU networks, wthf[0], first hidden layers of >= 64 and second hidden layers of >= 128 columns");
 
     FinishArgs fin{};
     // few atoms: the layer-0 backward runs in the 8-wave 128 x 128 kernel (needs the slab flags for its column compaction)
     const bool use_l0s = grad_aev && !fused_l0b && h3 && !big_tiles && kp_rad > 0 && K0p <= 32 * 32 && slab_mask &&
-                         !(d->flags & (ANIHIP_MLP_FLAG_NO_SLAB_MASK | ANIHIP_MLP_FLAG_L0B_4WAVE));
+                         !(d->flags & ANIHIP_MLP_FLAG_NO_SLAB_MASK);
     if (fused) {
         FusedArgs f{};
         size_t lds = 0;
-        // tiling: 64 atoms x 8 waves, one workgroup per CU (default: 3 % faster on the water box), or
-        // 32 atoms x 4 waves, two per CU (ANIHIP_MLP_FLAG_FUSED_ROWS32)
+        // tiling: 64 atoms x 8 waves, one workgroup per CU
         const int rows = fused_rows;
         for (int s = 0; s < S; ++s) {
             const anihip_species_net &nn = d->net[s];
@@ -3715,7 +3717,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             size_t halves = 2 * (size_t)rows * (fs.H2 + 8) + 2 * (size_t)rows * (xu + 8);
             const size_t slab = 2 * (size_t)rows * FR_SLAB_LD;
             if (halves < 3 * FR_GROUP * slab) halves = 3 * FR_GROUP * slab;   // staging slots 1..3
-            halves += rows == 64 ? FusedCfg<2, 1>::FIXED_HALVES : FusedCfg<1, 2>::FIXED_HALVES;
+            halves += FusedCfg<2, 1>::FIXED_HALVES;
             lds = lds > halves * 2 ? lds : halves * 2;
         }
         f.ctl = w.ctl; f.amax = w.amax; f.aev = aev; f.L = L; f.kp_rad = kp_rad; f.n_slabs = n_slabs;
@@ -3728,14 +3730,13 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         f.tile_tab = w.tile_tab; f.tile_rows = w.tile_rows;
         f.member_part = w.member_part; f.S = S; f.M = M; f.alpha = alpha; f.inv_alpha = inv_alpha;
         f.want_grad = grad_aev ? 1 : 0;
-        f.owner = (d->flags & ANIHIP_MLP_FLAG_TILE_OWNER) ? 1 : 0;
+        f.owner = 0;   // (member-major sweep; the layer-0 backward inside the kernel switches to owner order below)
         f.l0b = fused_l0b ? 1 : 0;
         f.grad_aev = grad_aev;
         if (fused_l0b) { f.owner = FUSED_OWNER_GROUP; f.d0 = nullptr; }
         const bool gelu = d->activation == ANIHIP_ACT_GELU;
-        const void *kfn = rows == 64 ? (fused_l0b ? (gelu ? (const void *)k_mlp_fused<2, 1, 1, true> : (const void *)k_mlp_fused<2, 1, 0, true>)
-                                                  : (gelu ? (const void *)k_mlp_fused<2, 1, 1, false> : (const void *)k_mlp_fused<2, 1, 0, false>))
-                                     : (const void *)k_mlp_fused<1, 2, 0, false>;
+        const void *kfn = fused_l0b ? (const void *)k_mlp_fused<2, 1, 0, true>
+                                    : (gelu ? (const void *)k_mlp_fused<2, 1, 1, false> : (const void *)k_mlp_fused<2, 1, 0, false>);
         ANIHIP_CHECK_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const int64_t tiles = fused_tiles;
         f.tiles_total = (int)tiles;
@@ -3762,16 +3763,9 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * trace_words));
         }
 #endif
-        if (rows == 64)
-        {
-            if (fused_l0b) {
-                if (gelu) hipLaunchKernelGGL((k_mlp_fused<2, 1, 1, true>), dim3((unsigned)grid), dim3(512), lds, stream, f);
-                else hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, true>), dim3((unsigned)grid), dim3(512), lds, stream, f);
-            } else if (gelu) hipLaunchKernelGGL((k_mlp_fused<2, 1, 1, false>), dim3((unsigned)grid), dim3(512), lds, stream, f);
-            else hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, false>), dim3((unsigned)grid), dim3(512), lds, stream, f);
-        }
-        else
-            hipLaunchKernelGGL((k_mlp_fused<1, 2, 0, false>), dim3((unsigned)grid), dim3(256), lds, stream, f);
+        if (fused_l0b) hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, true>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+        else if (gelu) hipLaunchKernelGGL((k_mlp_fused<2, 1, 1, false>), dim3((unsigned)grid), dim3(512), lds, stream, f);
+        else hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, false>), dim3((unsigned)grid), dim3(512), lds, stream, f);
 #ifdef ANIHIP_DEV_TRACE
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipStreamSynchronize(stream));

@@ -405,6 +405,12 @@ class VerletRows:
     changed); in between, rows come from anihip_nbr_refresh.  Like the reference, the displacement check is a
     host-synchronising reduction."""
 
+    # From this many atoms on the list is simply REBUILT every step: the O(N) cell-list search of this engine costs about
+    # what a refresh costs -- a refresh reads the (longer) skin rows back, updates, screens and re-sorts them -- and beyond the
+    # crossover measured with tools/md_bench.py (profiles/r05_md_bench.txt) the refresh is the slower of the two.  The skin
+    # then buys nothing and costs nothing: same rows, same results.
+    rebuild_above = 400_000
+
     def __init__(self, skin: float = 1.0) -> None:
         if skin <= 0.0:
             raise ValueError("skin must be a positive float")
@@ -412,6 +418,7 @@ class VerletRows:
         self.reset_cached_values()
         self.n_builds = 0
         self.n_reuses = 0
+        self.n_direct = 0   # steps that took the plain pair search (rebuild_above)
 
     def reset_cached_values(self) -> None:
         self._wide: tp.Optional[AevEngine] = None
@@ -430,6 +437,9 @@ class VerletRows:
 
     def rows(self, eng: AevEngine, species: Tensor, coords: Tensor, cell: tp.Optional[Tensor], pbc, lo: int, hi: int,
              mode: str, row_cap: int) -> NeighborRows:
+        if species.numel() >= self.rebuild_above and mode == "cell":
+            self.n_direct += 1
+            return eng.neighbors(species, coords, cell, pbc, lo=lo, hi=hi, mode=mode, row_cap=row_cap)
         cell_d = None if cell is None else cell.detach().to(device=coords.device, dtype=torch.float32)
         key = (eng.consts, tuple(species.shape), None if pbc is None else tuple(bool(b) for b in pbc), mode)
         if not self._can_use_prev_list(coords, cell_d, key):

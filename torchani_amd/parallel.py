@@ -475,14 +475,57 @@ def _all_gather(send: torch.Tensor, world: int, group) -> torch.Tensor:
     return got
 
 
+# How the uneven all-to-all of SpatialShards.exchange travels: "collective" = ONE all_to_all_single (RCCL: grouped
+# point-to-point sends, only the non-empty pairs move data), "p2p" = the same pieces as paired isend / irecv in one batch
+# (torch.distributed.batch_isend_irecv: an ncclGroup of sends and receives).  The collective is the default; should its
+# first call raise -- uneven splits over RCCL had never met a peer when this was written -- every rank falls back to "p2p"
+# (the failure is in the call's argument checking, the same on every rank) and stays there.  TORCHANI_AMD_EXCHANGE=p2p
+# forces it from the start.
+_EXCHANGE = {"transport": os.environ.get("TORCHANI_AMD_EXCHANGE", "collective"), "fell_back": None}
+
+
+def exchange_transport() -> tp.Dict[str, tp.Optional[str]]:
+    """{"transport": "collective" | "p2p", "fell_back": the collective's error message if it raised}."""
+    return dict(_EXCHANGE)
+
+
+def _p2p_exchange(got: torch.Tensor, send: torch.Tensor, in_split: tp.Sequence[int], out_split: tp.Sequence[int], group) -> None:
+    rank = torch.distributed.get_rank(group)
+    world = torch.distributed.get_world_size(group)
+    so = [0]
+    for c in in_split:
+        so.append(so[-1] + int(c))
+    ro = [0]
+    for c in out_split:
+        ro.append(ro[-1] + int(c))
+    got[ro[rank]:ro[rank + 1]] = send[so[rank]:so[rank + 1]]   # (own piece)
+    ops = []
+    for peer in range(world):
+        if peer == rank:
+            continue
+        g_peer = torch.distributed.get_global_rank(group, peer) if group is not None else peer
+        if out_split[peer]:
+            ops.append(torch.distributed.P2POp(torch.distributed.irecv, got[ro[peer]:ro[peer + 1]], g_peer, group))
+        if in_split[peer]:
+            ops.append(torch.distributed.P2POp(torch.distributed.isend, send[so[peer]:so[peer + 1]], g_peer, group))
+    if ops:
+        for req in torch.distributed.batch_isend_irecv(ops):
+            req.wait()
+
+
 def _all_to_all(send: torch.Tensor, in_split: tp.Sequence[int], out_split: tp.Sequence[int], group) -> torch.Tensor:
-    """all_to_all_single with uneven pieces (RCCL: grouped point-to-point sends, only the non-empty pairs move data).  The
-    gloo backend (CPU tests, single-GPU development runs with several ranks on one device) is staged through the host."""
+    """all_to_all_single with uneven pieces (RCCL: grouped point-to-point sends, only the non-empty pairs move data), or the
+    same pieces as batched isend / irecv (_EXCHANGE).  The gloo backend (CPU tests, single-GPU development runs with several
+    ranks on one device) is staged through the host."""
     n_out = int(sum(out_split))
-    if send.is_cuda and torch.distributed.get_backend(group) == "gloo":
-        host = torch.empty(n_out, dtype=send.dtype)
-        torch.distributed.all_to_all_single(host, send.cpu(), list(out_split), list(in_split), group=group)
-        return host.to(send.device)
-    got = torch.empty(n_out, dtype=send.dtype, device=send.device)
-    torch.distributed.all_to_all_single(got, send.contiguous(), list(out_split), list(in_split), group=group)
-    return got
+    stage = send.is_cuda and torch.distributed.get_backend(group) == "gloo"
+    src = send.cpu() if stage else send.contiguous()
+    got = torch.empty(n_out, dtype=send.dtype, device=src.device)
+    if _EXCHANGE["transport"] == "collective":
+        try:
+            torch.distributed.all_to_all_single(got, src, list(out_split), list(in_split), group=group)
+            return got.to(send.device) if stage else got
+        except (RuntimeError, ValueError, NotImplementedError) as err:   # (argument / support errors: raised on every rank alike)
+            _EXCHANGE["transport"], _EXCHANGE["fell_back"] = "p2p", f"{type(err).__name__}: {str(err)[:200]}"
+    _p2p_exchange(got, src, in_split, out_split, group)
+    return got.to(send.device) if stage else got
