@@ -406,10 +406,13 @@ class VerletRows:
     host-synchronising reduction."""
 
     # From this many atoms on the list is simply REBUILT every step: the O(N) cell-list search of this engine costs about
-    # what a refresh costs -- a refresh reads the (longer) skin rows back, updates, screens and re-sorts them -- and beyond the
-    # crossover measured with tools/md_bench.py (profiles/r05_md_bench.txt) the refresh is the slower of the two.  The skin
-    # then buys nothing and costs nothing: same rows, same results.
-    rebuild_above = 400_000
+    # what a refresh costs -- a refresh reads the (longer) skin rows back, updates, screens and re-sorts them.  Measured with
+    # tools/md_bench.py --force-verlet (profiles/r05_md_bench.txt, ms per MD step, rebuild vs refresh): 192 k atoms 3.46 / 3.55,
+    # 332 k 5.96 / 6.32, 527 k 9.00 / 9.42, 786 k 13.11 / 13.59, 2.34 M 36.8 / 39.4 (round 4) -- the refresh is 3-7 % SLOWER
+    # at every size measured, so the crossover lies below them; above it the skin buys nothing and now costs nothing (same
+    # rows, same results: 36.97 / 36.90 ms at 2.34 M).  Below it (molecules, small boxes) the reference's semantics are
+    # kept: pair search only when an atom has moved skin / 2.
+    rebuild_above = 100_000
 
     def __init__(self, skin: float = 1.0) -> None:
         if skin <= 0.0:
