@@ -4205,10 +4205,11 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
             // round is what an uneven split costs), few enough that the float atomics of the partial tiles stay cheap
             {
                 const int64_t tiles = (int64_t)a.batch * a.ki_max * a.nj_max;
-#ifndef ANIHIP_WB_TARGET_WGS
-#define ANIHIP_WB_TARGET_WGS 3072
-#endif
-                int64_t rows = (n * tiles / ANIHIP_WB_TARGET_WGS + 255) / 256 * 256;
+                // (measured on the config-5 batch, profiles/r05_train_*: the wide layer-0 launch likes ~1500 workgroups -- more
+                // chunks cost more atomics than their finer tail saves --, the small hidden layers ~650: each of their
+                // workgroups ends in 16 K atomics for few stages of work)
+                const int64_t target_wgs = tiles >= 64 ? 1536 : 640;
+                int64_t rows = (n * tiles / target_wgs + 255) / 256 * 256;
                 a.rows_per_chunk = (int)(rows < 512 ? 512 : (rows > 4096 ? 4096 : rows));
             }
             launch_wgrad_b3(stream, a, n);
