@@ -4205,10 +4205,11 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
             // round is what an uneven split costs), few enough that the float atomics of the partial tiles stay cheap
             {
                 const int64_t tiles = (int64_t)a.batch * a.ki_max * a.nj_max;
-                // (measured on the config-5 batch, profiles/r05_train_*: the wide layer-0 launch likes ~1500 workgroups -- more
-                // chunks cost more atomics than their finer tail saves --, the small hidden layers ~650: each of their
-                // workgroups ends in 16 K atomics for few stages of work)
-                const int64_t target_wgs = tiles >= 64 ? 1536 : 640;
+                // (measured on the config-5 batch, whole graphed step: 3072 workgroups for every layer 3.24 ms, 1536 3.20,
+                // 6144 3.30, 12288 3.40 -- more chunks cost more atomics than their finer tail saves; 1536 for the wide layer-0
+                // launch with 640 for the small hidden layers 3.37: those are chains of dependent stages and want MANY short
+                // workgroups)
+                const int64_t target_wgs = tiles >= 64 ? 1536 : 3072;
                 int64_t rows = (n * tiles / target_wgs + 255) / 256 * 256;
                 a.rows_per_chunk = (int)(rows < 512 ? 512 : (rows > 4096 ? 4096 : rows));
             }
