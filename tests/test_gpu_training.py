@@ -218,6 +218,34 @@ def test_device_repack_of_a_split_fp16_pack_equals_the_host_packer(dev):
     assert compared >= 3 * 4 * packed.S // 2   # (most layers keep their scale under a 1 % change)
 
 
+def test_split_fp16_pack_is_rebuilt_when_a_weight_outgrows_its_scale(dev):
+    """The device refresh keeps the power-of-two weight scales of the pack (largest weight in [2^13, 2^14) of the fp16 range):
+    a layer whose weights grew sixteen-fold no longer fits, the refresh says so in its status word (read one call late), and
+    the container packs again on the host -- energies stay right throughout the calls that follow."""
+    g = load_golden("rand_batch_ani2x")
+    model = fresh_model("ani2x", g["seed"], dev)
+    nets = model.neural_networks
+    nets.requires_grad_(True)
+    sp = torch.from_numpy(g["species"].astype(np.int64)).to(dev)
+    x = torch.from_numpy(g["coords"]).to(dev)
+    aev = model.aev_computer(sp, x).detach()
+    first = nets._train_pack(dev, fast=True)
+    with torch.no_grad():
+        nets.members[2].atomics["C"].layers[1].weight.mul_(16.0)
+    e_ref = None
+    packs = []
+    for _ in range(3):
+        e = nets(sp, aev)
+        torch.cuda.synchronize()
+        packs.append(nets._train_pack(dev, fast=True))
+        with torch.no_grad():   # (bump a version so that the next call refreshes / polls again)
+            nets.members[0].atomics["H"].layers[0].bias.add_(0.0)
+    assert packs[-1] is not first, "the pack was not rebuilt after a weight left the fp16 range of its scale"
+    nets.train_precision = "fp32"
+    e_ref = nets(sp, aev)
+    assert torch.isfinite(e).all() and float((e - e_ref).abs().max()) < 1e-5 * max(1.0, float(e_ref.abs().max()))
+
+
 @pytest.mark.parametrize("weight_decay", [0.0, 0.01])
 def test_fused_adam_matches_torch_adam(dev, weight_decay):
     """torchani_amd.optim.Adam (anihip_adam_step: one launch over flat buffers, step count on the device) follows
