@@ -156,6 +156,10 @@ def main():
     ap.add_argument("--partition-skin", type=float, default=1.0,
                     help="N > 1: skin (Angstrom) of the spatial shards' halos; the partition is reused until an atom moved skin/2")
     ap.add_argument("--mlp-chunk", type=int, default=0, help="development aid: atoms per launch group of the network stage")
+    ap.add_argument("--two-product-backward", action="store_true",
+                    help="NOT the default arithmetic: the backward GEMMs of the network kernel with two products instead of "
+                         "three (ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS); the line is labelled and its parity sample is held to "
+                         "north_star's gates (1e-5 Ha, 1e-4 Ha/A) instead of this package's regression gates")
     ap.add_argument("--shuffle", action="store_true",
                     help="permute the atom order of the box (the spatial shards must not depend on it)")
     args = ap.parse_args()
@@ -199,6 +203,7 @@ def main():
     # atom has moved 0.5 A (the coordinates of this bench are static, so it is cut once, in warmup; the cost of cutting it
     # is reported as collective.partition_ms)
     model.partition_skin = args.partition_skin
+    model.two_product_backward = bool(args.two_product_backward)
     if args.mlp_chunk > 0:
         model.mlp_chunk = args.mlp_chunk
 
@@ -305,7 +310,8 @@ def main():
                                 n_sample=args.parity_sample if group is None else max(32, args.parity_sample // 4), seed=7,
                                 candidates=owned)
         parity["atoms_sampled_from"] = "the whole box" if group is None else f"the {len(owned)} atoms rank 0 owns"
-        assert parity["max_dE_atom"] <= parity["regression_gate_dE_atom"] and parity["max_dF"] <= parity["regression_gate_dF"], \
+        gates = ("gate_dE_atom", "gate_dF") if args.two_product_backward else ("regression_gate_dE_atom", "regression_gate_dF")
+        assert parity["max_dE_atom"] <= parity[gates[0]] and parity["max_dF"] <= parity[gates[1]], \
             f"headline result disagrees with the oracle: {parity}"
 
     # ---- per-stage device timing on this rank's shard (outside the timed region) -----------------------
@@ -340,7 +346,8 @@ def main():
     gaev = torch.zeros_like(aev)
     st["mlp_fwd_bwd"] = time_stage(
         lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk,
-                                        slab_mask=mask, shard_rows=True), reps)
+                                        slab_mask=mask, shard_rows=True,
+                                        tile_hint=_lib.MLP_FLAG_BWD_TWO_PRODUCTS if args.two_product_backward else 0), reps)
     if not args.no_dense_stage:
         st["mlp_fwd_bwd_dense"] = time_stage(
             lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev,
@@ -406,6 +413,8 @@ def main():
                         "energies to every rank; forces stay with the rank that owns the atoms (not gathered); the "
                         "partition's validity is checked every step on the device and read one step late (no host sync)",
             "shuffled_input": bool(args.shuffle), "evaluated_on_cell_sorted_copy": bool(sorted_copy),
+            # (False: the default arithmetic.  True: NOT the default -- see --two-product-backward)
+            "two_product_backward": bool(args.two_product_backward),
         },
         "ms_per_step_median": median_ms,
         "roofline": {

@@ -308,6 +308,11 @@ typedef struct {
 #define ANIHIP_MLP_FLAG_D0_ROWS 32u       /* d E/d act0 handed to the layer-0 backward row-major, not tile-major */
 #define ANIHIP_MLP_FLAG_FUSED_L0B 512u    /* layer-0 backward inside the fused kernel whatever the size (default: from 65536 atoms) */
 #define ANIHIP_MLP_FLAG_NO_FUSED_L0B 1024u /* ... never: d E/d act0 through HBM + a layer-0 backward GEMM launch */
+#define ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS 2048u /* OFF by default.  With the layer-0 backward inside the fused kernel (>= 65536 atoms,
+                                                 * CELU): its backward GEMMs leave out (weight lo) x (gradient hi), i.e. use the weights
+                                                 * rounded to fp16 -- energies unchanged, d E/d AEV and the forces differ from the default's
+                                                 * by ~1e-6 Ha/A (inside the 1e-4 Ha/A gate of the parity tests, OUTSIDE their 5e-6 regression
+                                                 * gate), a sixth fewer MFMAs */
 typedef struct {
     int32_t num_species;
     int32_t n_members;

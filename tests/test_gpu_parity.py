@@ -976,6 +976,34 @@ def test_layer0_backward_inside_the_fused_kernel(dev, elements):
     assert res["max_dE_atom"] < 1e-6 * max(1.0, float(out.atomic_energies.abs().max())) and res["max_dF"] < 5e-6 * fmax
 
 
+def test_two_product_backward_is_off_by_default_and_inside_the_parity_gate(dev):
+    """ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS (``model.two_product_backward``; OFF by default): the backward GEMMs of the
+    large-system network kernel leave out (weight lo) x (gradient hi).  Energies are bit-identical to the default's, d E / d AEV
+    differs by ~2^-12 relative in places -- forces inside north_star's 1e-4 Ha/A against the oracle, and measurably OUTSIDE
+    what the default achieves, which is why it is not the default."""
+    from bench import water_box
+    from oracle.sampled_parity import sampled_parity
+
+    sp_np, x_np, cell_np = water_box(28)   # 65 856 atoms: the layer-0 backward runs inside the fused kernel
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    model = get_model("ani2x", 31, dev, neighborlist="cell", row_capacity=192)
+    assert model.two_product_backward is False
+    ref = model.energies_and_forces(sp, x, cell, (True, True, True), check_overflow=True)
+    model.two_product_backward = True
+    try:
+        out = model.energies_and_forces(sp, x, cell, (True, True, True), check_overflow=True)
+    finally:
+        model.two_product_backward = False
+    assert torch.equal(out.atomic_energies, ref.atomic_energies)
+    diff = float((out.forces - ref.forces).abs().max())
+    sd = seeded_state("ani2x", 8, 31)
+    res2 = sampled_parity(sp, x, cell, out.atomic_energies, out.forces, sd, "ani2x", 8, n_sample=24, seed=3)
+    res3 = sampled_parity(sp, x, cell, ref.atomic_energies, ref.forces, sd, "ani2x", 8, n_sample=24, seed=3)
+    report(f"bwd2  two-product backward: max|dF| against the oracle {res2['max_dF']:.2e} Ha/A (three products: {res3['max_dF']:.2e}); "
+           f"max|F2 - F3| = {diff:.2e}")
+    assert 0.0 < diff and res2["max_dF"] < 1e-4 and res3["max_dF"] < 5e-6 * max(1.0, float(ref.forces.abs().max()))
+
+
 def test_forward_backward_workspace_is_what_the_call_touches(dev):
     """anihip_mlp_forward_backward_workspace_bytes (ABI 10): a call runs in EXACTLY the bytes the query reports -- behind
     them a guard region keeps its pattern -- for the three shapes of the call: layer-0 backward inside the fused kernel

@@ -642,8 +642,10 @@ class PackedNetworks:
         nn_ = hi - lo
         n_cu = _n_cus(dev)
         fl = PackedNetworks.default_flags if self.flags is None else self.flags
-        if not fl & (_lib.MLP_FLAG_SMALL_TILES | _lib.MLP_FLAG_BIG_TILES):
-            fl |= tile_hint
+        tiles = _lib.MLP_FLAG_SMALL_TILES | _lib.MLP_FLAG_BIG_TILES
+        if not fl & tiles:
+            fl |= tile_hint & tiles
+        fl |= tile_hint & ~tiles   # (other switches a caller hands over with the hint, e.g. MLP_FLAG_BWD_TWO_PRODUCTS)
         self.desc.flags = fl   # (before the workspace queries: the flags choose the kernels)
         if chunk is None:
             # ONE call when its scratch is small -- the fused kernel with the layer-0 backward inside keeps everything but

@@ -208,6 +208,8 @@ class ANI(torch.nn.Module):
         c32 = coords.detach().to(torch.float32).contiguous()
         n_central = species32.numel() if group is None and shard is None else 0   # (shards: the library's default)
         hint = 0 if torch.cuda.is_current_stream_capturing() else self._tile_hint(species, species32, n_central)
+        if self.two_product_backward:
+            hint |= _lib.MLP_FLAG_BWD_TWO_PRODUCTS
         out = self._energies_and_forces_core(species32, c32, cell, pbc, group, reduce_forces, False, shard, stress, hint,
                                              species)
         if check_overflow and not torch.cuda.is_current_stream_capturing():
@@ -296,6 +298,11 @@ class ANI(torch.nn.Module):
     # on (AevEngine.rows_wanted: calls whose sizes change every time pin and memset nothing); ``release_aev_rows()`` frees
     # them (4 KB per central atom, 9.4 GB at 2.34 M atoms).  False: a fresh, fully written buffer per call.
     keep_aev_rows = True
+
+    # OFF by default (anihip.h, ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS): the backward GEMMs of the large-system network kernel
+    # (>= 65 536 atoms) with two products instead of three -- energies unchanged, forces within ~1e-6 Ha/A of the default's
+    # (inside the 1e-4 Ha/A parity gate, outside this package's 5e-6 regression gate), a sixth fewer MFMAs.
+    two_product_backward = False
 
     def release_aev_rows(self) -> None:
         self.aev_computer.engine().release_rows()
@@ -795,7 +802,7 @@ class ANI(torch.nn.Module):
                 m.potentials[name] = pot
         m.potentials["nnp"]._enabled = self.potentials["nnp"]._enabled
         m.energy_shifter._enabled = self.energy_shifter._enabled
-        for attr in ("mlp_chunk", "deterministic_forces", "auto_graph_atoms", "compact_species", "partition", "partition_skin", "partition_check", "locality_sort"):
+        for attr in ("mlp_chunk", "deterministic_forces", "auto_graph_atoms", "compact_species", "partition", "partition_skin", "partition_check", "locality_sort", "two_product_backward"):
             setattr(m, attr, getattr(self, attr))
 
     def atomic_energies(self, species_coordinates, cell=None, pbc=None, charge: int = 0,
