@@ -281,14 +281,37 @@ class _EngineContainer(torch.nn.Module):
                     return False
         return True
 
+    def _plan(self) -> tp.Dict[str, tp.Any]:
+        """What a training step needs to know about the module tree -- the Linear layers member -> species -> layer, their
+        parameters, which of them have biases, whether the fast path can serve them -- gathered ONCE per structure (walking
+        8 x 7 x 4 modules costs ~0.5 ms per call, as much as the kernels of a small batch; _STRUCT_EPOCH is bumped by torch's
+        registration hooks whenever any module gains a parameter or submodule)."""
+        members = self._member_networks()
+        stamp = (tuple(id(m) for m in members), _STRUCT_EPOCH[0])
+        hit = self.__dict__.get("_plan_cache")
+        if hit is not None and hit[0] == stamp:
+            first = hit[1]["params"][0] if hit[1]["params"] else None
+            # (Module._apply with set_overwrite_module_params_on_conversion swaps the Parameter objects past the hooks)
+            if first is None or next(iter(members[0].parameters()), None) is first:
+                return hit[1]
+        lins = [[m.atomics[s].linears() for s in self.symbols] for m in members]
+        flat = [lin for ml in lins for sl in ml for lin in sl]
+        plan = {"lins": lins, "flat": flat,
+                "params": [p for lin in flat for p in (lin.weight, lin.bias) if p is not None],
+                "has_bias": [lin.bias is not None for lin in flat],
+                "acts": {getattr(m.atomics[s], "activation_name", "celu") for m in members for s in self.symbols},
+                "fast_trainable": self._fast_trainable()}
+        self.__dict__["_plan_cache"] = (stamp, plan)
+        return plan
+
     def _train_pack(self, device: torch.device, fast: bool = False) -> PackedNetworks:
         """Pack read by the training pass (fp32, or -- fast -- split-fp16); built once per parameter set and refreshed in place
         on the device (anihip_mlp_repack) whenever an optimizer step changed the parameters."""
-        members = self._member_networks()
-        acts = {getattr(m.atomics[s], "activation_name", "celu") for m in members for s in self.symbols}
+        plan = self._plan()
+        acts = set(plan["acts"])
         if len(acts) != 1:
             raise ValueError(f"all atomic networks of a container must share one activation, got {sorted(acts)}")
-        lins = [[m.atomics[s].linears() for s in self.symbols] for m in members]
+        lins = plan["lins"]
         weights = [[[lin.weight for lin in sl] for sl in ml] for ml in lins]
         # (bias-free networks -- the GELU networks of the ANI-2xr family, nn/_core.py:122 -- train against zero biases that
         # live as long as the pack: the engine's passes return their "gradients", which nobody receives)
@@ -301,10 +324,10 @@ class _EngineContainer(torch.nn.Module):
             return zeros[k]
 
         biases = [[[lin.bias if lin.bias is not None else zero_bias(lin) for lin in sl] for sl in ml] for ml in lins]
-        params = [p for ml in lins for sl in ml for lin in sl for p in (lin.weight, lin.bias) if p is not None]
+        params = plan["params"]
         precision = "f16x3" if fast else "fp32"
-        key = (device, precision, tuple(p.data_ptr() for p in params), tuple(tuple(p.shape) for p in params))
-        versions = tuple(p._version for p in params)
+        key = (device, precision, tuple(map(_DATA_PTR_OF, params)), len(params))   # (shapes are fixed by the structure stamp)
+        versions = tuple(map(_VERSION_OF, params))
         cache = self.__dict__.setdefault("_train_cache", {})
         if key in cache and cache[key][0].scale_overflowed():
             del cache[key]   # (a weight outgrew the fp16 range of its layer's scale: pack again, new scales)
@@ -362,20 +385,18 @@ class _EngineContainer(torch.nn.Module):
             raise ValueError("torchani_amd's network containers need tensors on a ROCm device")
         species32 = elem_idxs.to(torch.int32).contiguous()
         params: tp.List[Tensor] = []
-        if torch.is_grad_enabled():
-            lins = [lin for m in self._member_networks() for s in self.symbols for lin in m.atomics[s].linears()]
-            if any(p.requires_grad for lin in lins for p in (lin.weight, lin.bias) if p is not None):
-                params = [p for lin in lins for p in (lin.weight, lin.bias) if p is not None]
+        plan = self._plan()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in plan["params"]):
+            params = plan["params"]
         trainable_fast = (params and not ensemble_values
                           and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == aevs.device
                                   for p in params))
         # (the fast training path returns no d Loss / d aev: training on forces keeps the exact-fp32 passes)
-        fast = bool(trainable_fast and not aevs.requires_grad and self.train_precision == "f16x3" and self._fast_trainable())
+        fast = bool(trainable_fast and not aevs.requires_grad and self.train_precision == "f16x3" and plan["fast_trainable"])
         packed = self._train_pack(aevs.device, fast) if trainable_fast else self._pack(aevs.device)
         packed.flat_target = self._flat_target(packed, params) if fast else None
         # which (weight, bias) slots of the engine's member -> species -> layer order have a parameter behind them
-        packed.has_bias = [lin.bias is not None for m in self._member_networks() for s in self.symbols
-                           for lin in m.atomics[s].linears()]
+        packed.has_bias = plan["has_bias"]
         if trainable_fast and packed.activation == "gelu":
             # (the input gradient that force training differentiates once more comes from the inference pack: an fp32 GELU
             # pack only serves the training passes)
