@@ -512,6 +512,26 @@ def main():
         torch.cuda.empty_cache()
         res["secondary"] = bench_configs.measure(dev)
         res["secondary"]["config5"] = bench_configs.measure_config5()
+        if not args.two_product_backward and args.parity_sample > 0:
+            # NOT the default arithmetic, reported beside it: the same box with the backward GEMMs of the network kernel on two
+            # products (ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS, model.two_product_backward)
+            from oracle.sampled_parity import sampled_parity
+
+            model.two_product_backward = True
+            for _ in range(3):
+                out2 = step()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(10):
+                out2 = step()
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t2) / 10 * 1e3
+            model.two_product_backward = False
+            par2 = sampled_parity(species, coords, cell, out2.atomic_energies, out2.forces, sd_np, "ani2x", 8, n_sample=128, seed=7)
+            res["secondary"]["two_product_backward"] = {
+                "default": False, "ms_per_step": ms2, "atom_steps_per_s": n_atoms / ms2 * 1e3,
+                "max_dE_atom": par2["max_dE_atom"], "max_dF": par2["max_dF"], "n_sample": par2["n"],
+                "note": "opt-in: forces within north_star's 1e-4 Ha/A, outside this package's 5e-6 Ha/A regression gate"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_side, seed=5)

@@ -282,6 +282,10 @@ def test_fused_adam_matches_torch_adam(dev, weight_decay):
         assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
     sd = ours.state_dict()
     ours.load_state_dict(sd)
+    # a parameter that left the flat buffer is noticed, not silently skipped
+    pa[1].data = pa[1].data.clone()
+    with pytest.raises(RuntimeError, match="flat buffer"):
+        ours.step()
 
 
 def test_training_step_with_the_flat_optimizer(dev, oracle64):

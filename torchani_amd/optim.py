@@ -69,6 +69,15 @@ class _FlatGroup:
                 self.offsets.append(off)
                 off += k
 
+    def check_homes(self) -> None:
+        """The update kernel writes the flat buffer: every parameter must still be its view of it (``model.to(...)``,
+        ``p.data = ...`` or a dtype change move a parameter out -- the optimizer would then update memory nobody reads)."""
+        base = self.flat.data_ptr()
+        for p, off in zip(self.params, self.offsets):
+            if p.data_ptr() != base + 4 * off:
+                raise RuntimeError("torchani_amd.optim.Adam: a parameter no longer lives in the optimizer's flat buffer (moved to "
+                                   "another device / dtype, or its .data was replaced): build a new optimizer for the model")
+
     def gather_stray_grads(self) -> None:
         """Gradients that arrived as tensors of their own (autograd's default route): into the flat buffer, views restored."""
         for i, p in enumerate(self.params):
@@ -123,6 +132,7 @@ class Adam(torch.optim.Optimizer):
                 loss = closure()
         L = _lib.lib()
         for group, f in zip(self.param_groups, self._flat):
+            f.check_homes()
             f.gather_stray_grads()
             b1, b2 = group["betas"]
             stream = torch.cuda.current_stream(f.flat.device).cuda_stream
