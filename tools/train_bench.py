@@ -35,7 +35,7 @@ def conformers(n_mol, n_at, seed=5):
 def step_flops(sp, kind, members):
     """MFMA work of one energy-training step on the fast path, from the batch's species: fp32-equivalent flops (2 per
     multiply-add of the mathematical GEMMs: layer 0 over the AEV slabs of species (pairs) that occur in the batch, hidden
-    layers forward and backward, weight gradients over the whole AEV) and the bf16 / fp16 flops actually issued (the
+    layers forward and backward, weight gradients over the same slabs) and the bf16 / fp16 flops actually issued (the
     fused kernel's three-product split, the weight-gradient kernel's six products)."""
     from torchani_amd.weights import arch_spec
 
@@ -51,7 +51,8 @@ def step_flops(sp, kind, members):
         r = lambda v: -(-v // 32) * 32   # (the kernels work on widths padded to 32)
         h1, h2, h3 = r(h1), r(h2), r(h3)
         fb += present[s] * members * 2.0 * (32 * slabs * h1 + 2 * h1 * h2 + 2 * h2 * h3 + h3)
-        wg += present[s] * members * 2.0 * (consts.out_dim * h1 + h1 * h2 + h2 * h3 + h3)
+        # (the layer-0 weight gradients run over the same flagged slabs: the columns of absent species are zero)
+        wg += present[s] * members * 2.0 * (32 * slabs * h1 + h1 * h2 + h2 * h3 + h3)
     return {"fp32_equivalent": fb + wg, "issued": 3.0 * fb + 6.0 * wg, "flagged_slabs": slabs,
             "forward_backward_fp32_equivalent": fb, "weight_grads_fp32_equivalent": wg}
 

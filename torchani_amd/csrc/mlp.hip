@@ -4209,6 +4209,10 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
             }
             a.ki_max = (kmax + 127) / 128;
             a.nj_max = (nmax + 127) / 128;
+            // layer 0 of a whole system: only the AEV slabs of species (pairs) that occur in it (train.h)
+            a.ani_species = S;
+            a.x_slab_rad = (l == 0 && lo == 0 && hi == n_atoms && d->aev_radial_len == 16 * S && S * (S + 1) / 2 + (16 * S + 31) / 32 <= 32)
+                               ? d->aev_radial_len : 0;
             for (int s = 0; s < S; ++s) {
                 a.gbias[s] = grads[s].gbias[l];
                 a.b_mstride[s] = mstride > 0 ? mstride : (int64_t)d->net[s].dims[l + 1];   // (packed: [M][n_per])

@@ -33,6 +33,11 @@ struct WgradB3Args {
     const float *g_atom;   // upstream d Loss / d atomic_e per ATOM: row p of D is scaled by g_atom[perm[p]]
     int S, batch, ki_max, nj_max;
     int rows_per_chunk;    // atoms per workgroup (multiple of 32): partial tiles of the chunks meet in dW through float atomics
+    // layer 0 of a whole system in the ANI layout of the AEV row (x_slab_rad = its radial length = 16 per species, then one
+    // 32-column block per species pair): the columns of species (pairs) that do not occur in the system are zero for every
+    // atom, so their gradient columns are zero -- the X tiles run over the COMPACTED list of the slabs that can be non-zero
+    // (H C N O under ANI-2x: 12 of 32 slabs, 3 column tiles instead of 8).  0: plain columns
+    int x_slab_rad, ani_species;
     // bias gradients on the way (workgroups of the first X tile only): gbias[s][member][j] += sum_a g_a D[a][j]
     float *gbias[MAX_S];
     int64_t b_mstride[MAX_S];   // floats between the members' bias gradients

@@ -72,7 +72,31 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
     if (!found) return;
     const WgradB3Problem &pr = g.prob[s];
     const int i0 = ki * WB_T, j0 = nj * WB_T;
-    if (i0 >= pr.k_valid || j0 >= pr.N) return;
+    // X columns: plain, or the compacted list of the AEV slabs that can be non-zero (layer 0, ANI layout; scalar work)
+    uint32_t act = 0u;
+    const int rad = g.x_slab_rad, nrs = (rad + 31) >> 5;
+    if (rad > 0) {
+        for (int a = 0; a < g.ani_species; ++a) {
+            if (g.ctl[CTL_CNT + a] <= 0) continue;
+            act |= 1u << (a >> 1);
+            for (int b = a; b < g.ani_species; ++b)
+                if (g.ctl[CTL_CNT + b] > 0) act |= 1u << (nrs + a * g.ani_species - a * (a - 1) / 2 + (b - a));
+        }
+    }
+    const int k_cols = rad > 0 ? 32 * __popc(act) : pr.k_valid;   // columns of the (compacted) X index
+    if (i0 >= k_cols || j0 >= pr.N) return;
+    // compacted column c -> (AEV column, is it a column of the row); plain: the identity
+    auto x_column = [&](int c, int &col) {
+        if (rad <= 0) { col = c; return c < pr.k_valid; }
+        uint32_t mk = act;
+        for (int t = 0; t < (c >> 5); ++t) mk &= mk - 1u;
+        if (!mk) { col = 0; return false; }
+        const int slab = (int)__builtin_ctz(mk);
+        const int start = slab < nrs ? 32 * slab : rad + 32 * (slab - nrs);
+        const int valid = slab == nrs - 1 ? rad - 32 * (nrs - 1) : 32;
+        col = start + (c & 31);
+        return (c & 31) < valid && col < pr.k_valid;
+    };
     const int n_rows = min(g.rows_per_chunk, g.ctl[CTL_CNT + s] - m0);
     const int p0 = g.ctl[CTL_OFF + s] + m0;
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
@@ -87,9 +111,10 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
     for (int u = 0; u < 2; ++u) {
         const int c = 4 * (cg0 + 16 * u);
         dok[u] = j0 + c < pr.N;
-        xok[u] = i0 + c < pr.k_valid;
         dcol[u] = dok[u] ? j0 + c : 0;
-        xcol[u] = xok[u] ? i0 + c : 0;
+        int col;
+        xok[u] = x_column(i0 + c, col);   // (four consecutive columns lie inside one slab: the first decides)
+        xcol[u] = xok[u] ? col : 0;
     }
     v4f rd[2][2], rx[2][2];   // [column group][row of the pair]
     float ga[2];
@@ -142,7 +167,7 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     // 32-column blocks of this wave that exist (wave-uniform)
     const int nbv = max(0, min(2, (pr.N - (j0 + wn * 64) + 31) >> 5));
-    const int kbv = max(0, min(2, (pr.k_valid - (i0 + wk * 64) + 31) >> 5));
+    const int kbv = max(0, min(2, (k_cols - (i0 + wk * 64) + 31) >> 5));
     const bool active = nbv > 0 && kbv > 0;
     // fragment of a block: column (lane & 31), eight atoms 8 (lane >> 5) .. of the k step
     const int fcol = lane & 31, fk = lane >> 5;
@@ -211,8 +236,8 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (kb >= kbv) continue;
-            const int i = i0 + wk * 64 + kb * 32 + fcol;
-            if (i >= pr.k_valid) continue;
+            int i;
+            if (!x_column(i0 + wk * 64 + kb * 32 + fcol, i)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = j0 + wn * 64 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
