@@ -3092,9 +3092,16 @@ __global__ __launch_bounds__(256) void k_col_reduce(ColReduceArgs g)
     const int p0 = g.ctl[CTL_OFF + s] + m0;
     const bool cv = col < g.ncols[s];
     const float *x = g.X[s] + (cv ? col : 0);
+    // the rows' scales first (two dependent loads each: perm, then the atom's upstream gradient), once per block, so that the
+    // row loop below is a chain of independent loads
+    __shared__ float s_scale[CR_ROWS];
+    if (threadIdx.x < CR_ROWS)
+        s_scale[threadIdx.x] = threadIdx.x < n_rows ? (g.g_atom ? g.g_atom[g.perm[p0 + threadIdx.x]] : 1.0f) * g.inv_m : 0.f;
+    __syncthreads();
     float acc = 0.f, sacc = 0.f;
+#pragma unroll 8
     for (int r = 0; r < n_rows; ++r) {
-        const float sc = (g.g_atom ? g.g_atom[g.perm[p0 + r]] : 1.0f) * g.inv_m;
+        const float sc = s_scale[r];
         acc += sc * x[(int64_t)(p0 + r) * g.ldx];
         sacc += sc;
     }
