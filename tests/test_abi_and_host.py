@@ -568,6 +568,31 @@ def test_layer0_tile_hint_from_composition():
     assert m._tile_hint(organic, organic, 16383) == 0 and m._tile_hint(organic, organic, 65536) == 0
 
 
+def test_overflow_check_is_skipped_only_where_rows_cannot_overflow():
+    """ANI._overflow_impossible: the default check_overflow=True reads the builder's status word (a host synchronisation) unless
+    no row CAN overflow -- molecules without periodic images whose A - 1 atoms fit every row."""
+    import warnings
+
+    from torchani_amd.models import ANI2x
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = ANI2x(seed=0, n_members=1, neighborlist="batch", row_capacity=64)
+    small, wide = torch.zeros((256, 28), dtype=torch.long), torch.zeros((4, 200), dtype=torch.long)
+    cell = torch.eye(3) * 30.0
+    assert m._overflow_impossible(small, None, None)
+    assert m._overflow_impossible(small, cell, (False, False, False))
+    assert not m._overflow_impossible(small, cell, (True, True, True))      # periodic images add neighbors
+    assert not m._overflow_impossible(wide, None, None)                      # 199 possible neighbors > 64 slots
+    m.aev_computer.row_capacity = 256
+    assert not m._overflow_impossible(wide, None, None)                      # ... and > the 128 angular slots
+    assert m._overflow_impossible(torch.zeros((4, 129), dtype=torch.long), None, None)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mc = ANI2x(seed=0, n_members=1, neighborlist="cell")
+    assert not mc._overflow_impossible(small[:1], None, None)                # (the grid of cell mode has a status of its own)
+
+
 def test_cached_parameter_list_follows_the_modules():
     """_EngineContainer._param_list keeps the flat parameter list between calls (walking the module tree costs more than
     a small step) and rebuilds it when a parameter or submodule is registered anywhere, when the active members change,

@@ -168,6 +168,20 @@ class ANI(torch.nn.Module):
         pot._last_rows = rows   # (checked with the AEV's rows: an overflowed row was zeroed by the builder)
         return rows
 
+    def _overflow_impossible(self, species: Tensor, cell, pbc) -> bool:
+        """Can a neighbor row of this call overflow at all?  Without periodic images an atom's neighbors are atoms of its own
+        molecule: with A - 1 <= min(row capacity, 128 angular slots) -- every batch of small molecules -- no row of the network's
+        builder or of a pair potential (256 slots) can, and the status word need not be read (the default
+        ``check_overflow=True`` then costs no host synchronisation: BASELINE config 2 through the default API)."""
+        if species.dim() != 2:
+            return False
+        if cell is not None and pbc is not None and any(bool(b) for b in (pbc.tolist() if isinstance(pbc, Tensor) else pbc)):
+            return False
+        aevc = self.aev_computer
+        if aevc.neighbor_mode not in ("batch", "auto"):
+            return False
+        return species.shape[1] - 1 <= min(int(aevc.row_capacity), _lib.MAX_ANG)
+
     def _pair_rows_overflowed(self) -> bool:
         return any(getattr(pot, "_last_rows", None) is not None and pot._last_rows.overflowed()
                    for k, pot in self.potentials.items() if k != "nnp" and pot._enabled)
@@ -200,6 +214,8 @@ class ANI(torch.nn.Module):
         """
         if not coords.is_cuda:
             raise ValueError("torchani_amd's engine needs tensors on a ROCm device (no CPU fallback)")
+        if check_overflow and self._overflow_impossible(species, cell, pbc):
+            check_overflow = False   # (nothing to read: no host synchronisation for batches of small molecules)
         out = self._auto_graph_call(species, coords, cell, pbc, group, shard, stress, check_overflow)
         if out is not None:
             return out
