@@ -122,6 +122,7 @@ class _MLPFunction(torch.autograd.Function):
         ctx.g = g
         ctx.train = train
         ctx.flat_target = getattr(packed, "flat_target", None) if train else None
+        ctx.flat_verify = getattr(packed, "flat_verify", None) if ctx.flat_target is not None else None
         ctx.aev_grad = aevs.requires_grad
         ctx.saved = (a32, species32, packed, ws) if train else None
         ctx.params = params if train else ()
@@ -158,6 +159,13 @@ class _MLPFunction(torch.autograd.Function):
             # create_graph=True (training on forces): d E / d aev must stay differentiable in the parameters
             second_order = torch.is_grad_enabled() and ctx.aev_grad
             target = ctx.flat_target if not second_order else None
+            if target is not None and ctx.flat_verify is not None:
+                ps, views = ctx.flat_verify
+                for i, p_ in enumerate(ps):
+                    tag = getattr(p_, "_anihip_flat", None)
+                    if tag is None or p_.grad is not views[tag[1]]:
+                        raise RuntimeError("the parameters' .grad were detached from the optimizer's flat gradient buffer between "
+                                           "forward and backward (zero_grad(set_to_none=True)?): call forward again")
             gw, gb, _, gaev = packed.weight_grads(species32, a32, grad_out.detach().contiguous(),
                                                   want_grad_aev=ctx.aev_grad and not second_order, workspace=ws,
                                                   target=target)
@@ -297,6 +305,9 @@ class _EngineContainer(torch.nn.Module):
         lins = [[m.atomics[s].linears() for s in self.symbols] for m in members]
         flat = [lin for ml in lins for sl in ml for lin in sl]
         plan = {"lins": lins, "flat": flat,
+                "weights": [[[lin.weight for lin in sl] for sl in ml] for ml in lins],
+                "biases": [[[lin.bias for lin in sl] for sl in ml] for ml in lins],
+                "checked_ptrs": None,   # data_ptr tuple for which dtype / layout / device of every parameter were verified
                 "params": [p for lin in flat for p in (lin.weight, lin.bias) if p is not None],
                 "has_bias": [lin.bias is not None for lin in flat],
                 "acts": {getattr(m.atomics[s], "activation_name", "celu") for m in members for s in self.symbols},
@@ -312,7 +323,7 @@ class _EngineContainer(torch.nn.Module):
         if len(acts) != 1:
             raise ValueError(f"all atomic networks of a container must share one activation, got {sorted(acts)}")
         lins = plan["lins"]
-        weights = [[[lin.weight for lin in sl] for sl in ml] for ml in lins]
+        weights = plan["weights"]
         # (bias-free networks -- the GELU networks of the ANI-2xr family, nn/_core.py:122 -- train against zero biases that
         # live as long as the pack: the engine's passes return their "gradients", which nobody receives)
         zeros = self.__dict__.setdefault("_zero_biases", {})
@@ -323,7 +334,9 @@ class _EngineContainer(torch.nn.Module):
                 zeros[k] = torch.zeros(lin.weight.shape[0], dtype=torch.float32, device=device)
             return zeros[k]
 
-        biases = [[[lin.bias if lin.bias is not None else zero_bias(lin) for lin in sl] for sl in ml] for ml in lins]
+        biases = plan["biases"]
+        if not all(plan["has_bias"]):
+            biases = [[[lin.bias if lin.bias is not None else zero_bias(lin) for lin in sl] for sl in ml] for ml in lins]
         params = plan["params"]
         precision = "f16x3" if fast else "fp32"
         key = (device, precision, tuple(map(_DATA_PTR_OF, params)), len(params))   # (shapes are fixed by the structure stamp)
@@ -358,6 +371,7 @@ class _EngineContainer(torch.nn.Module):
         key = (id(grp), id(packed), len(params))
         hit = self.__dict__.get("_flat_target_cache")
         if hit is not None and hit[0] == key and hit[2] is grp:
+            packed.flat_target_views = views
             return hit[1]
         M, S, nl = packed.M, packed.S, packed.nl
         per = 2 * S * nl
@@ -378,6 +392,7 @@ class _EngineContainer(torch.nn.Module):
         except ValueError:
             return None
         self.__dict__["_flat_target_cache"] = (key, tgt, grp)
+        packed.flat_target_views = views
         return tgt
 
     def _run(self, elem_idxs: Tensor, aevs: Tensor, atomic: bool, ensemble_values: bool) -> Tensor:
@@ -388,9 +403,15 @@ class _EngineContainer(torch.nn.Module):
         plan = self._plan()
         if torch.is_grad_enabled() and any(p.requires_grad for p in plan["params"]):
             params = plan["params"]
-        trainable_fast = (params and not ensemble_values
-                          and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == aevs.device
-                                  for p in params))
+        trainable_fast = False
+        if params and not ensemble_values:
+            # (dtype, layout and device of 448 tensors: verified once per set of storages -- a .to() or a re-homing optimizer
+            # changes the addresses --, 0.3 ms per call otherwise)
+            ptrs = (aevs.device, tuple(map(_DATA_PTR_OF, params)))
+            if plan["checked_ptrs"] is None or plan["checked_ptrs"][0] != ptrs:
+                ok = all(p.dtype == torch.float32 and p.is_contiguous() and p.device == aevs.device for p in params)
+                plan["checked_ptrs"] = (ptrs, ok)
+            trainable_fast = plan["checked_ptrs"][1]
         # (the fast training path returns no d Loss / d aev: training on forces keeps the exact-fp32 passes)
         fast = bool(trainable_fast and not aevs.requires_grad and self.train_precision == "f16x3" and plan["fast_trainable"])
         packed = self._train_pack(aevs.device, fast) if trainable_fast else self._pack(aevs.device)
@@ -407,7 +428,17 @@ class _EngineContainer(torch.nn.Module):
             # needs every member's own d e_m / d aev, i.e. one single-member pass each
             dev_m = aevs.device
             packed.member_packs = lambda: [m._pack(dev_m) for m in self._member_networks()]
-        out = _MLPFunction.apply(aevs, species32, packed, ensemble_values, *params)
+        fn_params = params
+        if packed.flat_target is not None:
+            # the gradients go straight into the optimizer's flat buffer: autograd need not carry 448 parameters through the
+            # graph (0.6 ms per forward, several ms per backward of engine work) -- ONE stand-in input makes the backward run
+            hook = self.__dict__.get("_grad_hook")
+            if hook is None or hook.device != aevs.device:
+                hook = torch.zeros(1, device=aevs.device, requires_grad=True)
+                self.__dict__["_grad_hook"] = hook
+            fn_params = [hook]
+            packed.flat_verify = (params, packed.flat_target_views)
+        out = _MLPFunction.apply(aevs, species32, packed, ensemble_values, *fn_params)
         # [C, A] (or [M, C, A]); molecular energies are the sum over atoms (nn/_containers.py:417-421)
         return out if atomic else out.sum(dim=-1)
 

@@ -73,7 +73,11 @@ class _FlatGroup:
         """The update kernel writes the flat buffer: every parameter must still be its view of it (``model.to(...)``,
         ``p.data = ...`` or a dtype change move a parameter out -- the optimizer would then update memory nobody reads)."""
         base = self.flat.data_ptr()
-        for p, off in zip(self.params, self.offsets):
+        # (every 16th call all of them, in between the first and the last: a model moved as a whole moves those too)
+        self._homes_calls = getattr(self, "_homes_calls", -1) + 1
+        idx = range(len(self.params)) if self._homes_calls % 16 == 0 else (0, len(self.params) - 1)
+        for i in idx:
+            p, off = self.params[i], self.offsets[i]
             if p.data_ptr() != base + 4 * off:
                 raise RuntimeError("torchani_amd.optim.Adam: a parameter no longer lives in the optimizer's flat buffer (moved to "
                                    "another device / dtype, or its .data was replaced): build a new optimizer for the model")
