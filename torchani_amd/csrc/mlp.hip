@@ -2689,7 +2689,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 for (int sl = 0; sl < D; ++sl) r5.template load<NB>(sl, min(sl, KH - 1));
             };
             int slab = nth_slab(wave & 3);
-            ring5(max(slab, 0));   // (travels during the epilogue below)
+            ring5(max(slab, 0));   // (travels during the epilogue below; requested behind it instead: no faster, measured)
             ANIHIP_STAMP(trace, 16);
             if (g.want_grad && u1.nrb > 0) {
                 const float osc4 = fs.is1 / s3;
