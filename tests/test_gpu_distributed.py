@@ -324,3 +324,19 @@ def test_bench_launches_its_own_ranks():
     coll = r["collective"]
     assert coll["world_size"] == 2 and coll["collectives_per_step"] == 1 and len(coll["ranks_seen"]) == 2
     assert "read one step late" in coll["validity_check"]
+
+
+@pytest.mark.parametrize("transport", ["collective", "p2p"])
+def test_rccl_calls_of_the_step_run_on_this_gpu(transport):
+    """The collectives of the N > 1 step as RCCL executes them (backend "nccl", a process group of world size 1 with the
+    collectives forced: tools/rccl_world1.py): the spatial exchange in fp32 and as int64 fixed-point words, the gather of
+    owned rows and the index-range all-reduce reproduce the plain single-GPU energies, forces and virial -- through the
+    one all_to_all_single and through the paired isend / irecv fallback."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TORCHANI_AMD_FORCE_GROUP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TORCHANI_AMD_EXCHANGE=transport)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "rccl_world1.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "world-1 collectives ok" in p.stdout and p.stdout.count("partition ") == 4, p.stdout[-2000:]
+    assert f"transport {transport}" in p.stdout, p.stdout[-2000:]

@@ -44,7 +44,11 @@ def main():
     objs = [None]
     torch.distributed.all_gather_object(objs, {"rank": rank}, group=group)
     torch.distributed.barrier(group)
-    print("RCCL", ".".join(str(v) for v in torch.cuda.nccl.version()), "world-1 collectives ok", objs)
+    from torchani_amd.parallel import exchange_transport
+
+    tr = exchange_transport()
+    print("RCCL", ".".join(str(v) for v in torch.cuda.nccl.version()), "world-1 collectives ok", objs,
+          "transport", tr["transport"], "fell back:", tr["fell_back"])
     torch.distributed.destroy_process_group()
 
 
