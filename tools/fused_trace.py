@@ -60,3 +60,20 @@ if l0b:
         m = xcc == x
         tt = (tw[m][:, 0, END] - tw[m][:, 0, 0])
         print(f"  XCC {int(x)}: {m.sum()} items, mean item {tt.mean():.0f} ticks")
+
+# sub-stamps inside the epilogues (round 5): for every wave, the time between consecutive stamps; mean over waves and items,
+# and the spread of the waves' arrival at the stamp (max - min over the 8 waves of an item)
+SUB = [("L0 epilogue", [3, 22, 23, 24, 25, 4], ["ring request + biases", "celu pairs", "tile max (atomic + barrier)", "split + LDS planes", "barrier"]),
+       ("P1 epilogue", [5, 26, 27, 6], ["ring request + celu pairs", "split + LDS planes", "barrier"]),
+       ("P2 epilogue", [7, 28, 29, 9], ["ring request + celu pairs + head", "split + LDS planes", "barrier + energies"]),
+       ("P3 epilogue", [10, 30, 31, 11], ["ring request + celu' scale", "split + LDS planes", "barrier"])]
+if (tw[:, :, 22] > 0).all():
+    for title, st, names in SUB:
+        ok = (tw[:, :, st] > 0).all(axis=(1, 2))
+        x = tw[ok][:, :, st]                      # [item][wave][stamp]
+        dd = np.diff(x, axis=2)
+        print(f"{title}: per-wave segment times (mean over the 8 waves; [min .. max] of the per-wave means), arrival spread at the segment's end")
+        for i, n in enumerate(names):
+            per_wave = dd[:, :, i].mean(axis=0)
+            spread = (x[:, :, i + 1].max(axis=1) - x[:, :, i + 1].min(axis=1)).mean()
+            print(f"    {n:34s} {per_wave.mean():8.1f}  [{per_wave.min():8.1f} .. {per_wave.max():8.1f}]   spread {spread:7.1f}")

@@ -2442,6 +2442,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         float a0max;         // tile max of |act0|
         {
             load_cols(fs.b0 + (int64_t)m * H1, bias0, u1);
+            ANIHIP_STAMP(trace, 22);
             const float oscale = fs.is0 * 0.25f;
             // tile maximum of |act0| for the split scale: act0 >= -alpha (CELU) / >= -0.17 (GELU), so max(floor, max act0)
             // bounds it -- one v_max3_f32 per element pair instead of two |.| and three max (a quarter of this epilogue's
@@ -2473,10 +2474,13 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 }
             }
             if constexpr (TRAIN) store_rows(g.tr_act[0], g.tr_ld[0], H1, u1);
+            ANIHIP_STAMP(trace, 23);
             a0max = tile_max(vmax);   // (barriers: every wave is past the staging slots)
+            ANIHIP_STAMP(trace, 24);
         }
         const float s0 = pow2_scale_for(a0max);
         put_acc(X0, x0_plane, ld0, s0, u1);
+        ANIHIP_STAMP(trace, 25);
         // the scales of the inner GEMM operands follow from a0max and the weight-norm bounds: no more reductions
         const float s1 = pow2_scale_for(__builtin_fmaf(a0max, bnd[0], bnd[1]));   // |act1| <= a0max ||W1||_inf + |b1|
         const float s2 = pow2_scale_for(bnd[2]);                                  // |d act2| <= max |w3| / M
@@ -2519,7 +2523,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 }
             }
             if constexpr (TRAIN) store_rows(g.tr_act[1], g.tr_ld[1], H2, u2);
+            ANIHIP_STAMP(trace, 26);
             put_acc(X1, x1_plane, ld1, s1, u2);
+            ANIHIP_STAMP(trace, 27);
         }
         __syncthreads();  // X1 complete; every wave is done reading X0 -> XU reusable
         ANIHIP_STAMP(trace, 6);
@@ -2584,7 +2590,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 if (fk == 0) s_e[wave * ROWS + t * 32 + fr] = v;
             }
             if constexpr (TRAIN) store_rows(g.tr_dlt[2], g.tr_ld[2], H3, u3);
+            ANIHIP_STAMP(trace, 28);
             if (g.want_grad) put_acc(X2, x2_plane, ld2, s2, u3);   // (XU: X0 is dead since the last barrier)
+            ANIHIP_STAMP(trace, 29);
         }
         __syncthreads();
         if (tid < n_rows) {
@@ -2638,7 +2646,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                         }
                 }
                 if constexpr (TRAIN) store_rows(g.tr_dlt[1], g.tr_ld[1], H2, u2);
+                ANIHIP_STAMP(trace, 30);
                 put_acc(X1, x1_plane, ld1, s3, u2);   // (X1: its last readers finished before the previous barrier)
+                ANIHIP_STAMP(trace, 31);
             }
         }
         // the first layer-0 weight fragments of the next item: L2 hits, requested behind the phase-4 ring (the first
