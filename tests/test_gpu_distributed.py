@@ -213,14 +213,21 @@ def _worker_grads(rank, world, port, q):
         C = sp.shape[0]
         target = torch.linspace(-1.0, 1.0, C, dtype=torch.float32, device=dev)
 
-        def grads(lo, hi, reduce):
+        def grads(lo, hi, reduce, flat=False):
             model = ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False)
             model.neural_networks.requires_grad_(True)
             model.set_enabled("energy_shifter", False)
+            params = [p for p in model.neural_networks.parameters()]
+            if flat:   # the gradients as views of the flat optimizer's one buffer: that buffer is the bucket
+                from torchani_amd.optim import Adam
+                from torchani_amd.parallel import _one_flat_group
+
+                opt = Adam(params, lr=1e-4)
             e = model((sp[lo:hi], x[lo:hi])).energies
             loss = ((e.float() - target[lo:hi]) ** 2).sum()
             loss.backward()
-            params = [p for p in model.neural_networks.parameters()]
+            if flat:
+                assert _one_flat_group(params) is opt._flat[0]
             if reduce:
                 all_reduce_gradients(params, group=group)
             return torch.cat([p.grad.reshape(-1) for p in params])
@@ -228,8 +235,9 @@ def _worker_grads(rank, world, port, q):
         full = grads(0, C, False)
         lo, hi = rank * C // world, (rank + 1) * C // world
         part = grads(lo, hi, True)
+        part_flat = grads(lo, hi, True, flat=True)
         scale = float(full.abs().max())
-        q.put((rank, {"err": float((part - full).abs().max()), "scale": scale}))
+        q.put((rank, {"err": float((part - full).abs().max()), "err_flat": float((part_flat - full).abs().max()), "scale": scale}))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:
@@ -241,7 +249,7 @@ def _worker_grads(rank, world, port, q):
 def test_two_ranks_all_reduce_gradients_equals_full_batch():
     res = _run(_worker_grads)
     for r, o in res.items():
-        assert o["scale"] > 0 and o["err"] < 2e-5 * o["scale"], o
+        assert o["scale"] > 0 and o["err"] < 2e-5 * o["scale"] and o["err_flat"] < 2e-5 * o["scale"], o
 
 
 def test_bench_two_ranks_gloo():

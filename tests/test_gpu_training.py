@@ -279,7 +279,7 @@ def test_fused_adam_matches_torch_adam(dev, weight_decay):
     torch.cuda.synchronize()
     assert int(flat.step.item()) == 25
     for a, b in zip(pa, pb):
-        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+        assert float((a.detach() - b.detach()).abs().max()) <= 1e-6 * float(b.detach().abs().max())
     sd = ours.state_dict()
     ours.load_state_dict(sd)
     # a parameter that left the flat buffer is noticed, not silently skipped

@@ -97,7 +97,9 @@ class _FlatGroup:
 
 class Adam(torch.optim.Optimizer):
     """``torchani_amd.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)``: torch.optim.Adam's update
-    (amsgrad / maximize / foreach / capturable / differentiable are not options: one fused launch, always capturable)."""
+    (amsgrad / maximize / foreach / capturable / differentiable are not options: one fused launch, always capturable).
+    The hyper-parameters of a group are read at every ``step()`` (learning-rate schedulers work as usual) and passed by value:
+    a CAPTURED step replays the values it was captured with -- capture again after a scheduler changed them."""
 
     def __init__(self, params, lr: float = 1e-3, betas: tp.Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, zero_grad_in_step: bool = True) -> None:
@@ -121,7 +123,10 @@ class Adam(torch.optim.Optimizer):
         super().add_param_group(param_group)
         if hasattr(self, "_flat"):   # (called by the constructor before _flat exists)
             ps = [p for p in self.param_groups[-1]["params"] if p.requires_grad]
+            if not ps:
+                raise ValueError("a parameter group without trainable parameters")
             self._flat.append(_FlatGroup(ps))
+            torch.autograd.graph.increment_version(ps)
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for f in self._flat:

@@ -106,6 +106,17 @@ def all_reduce_gradients(parameters: tp.Iterable[torch.nn.Parameter], group=None
     params = [p for p in parameters if p.requires_grad]
     if not params:
         return
+    flat_group = _one_flat_group(params)
+    if flat_group is not None:
+        # torchani_amd.optim.Adam keeps the gradients of its parameters as views of ONE buffer: that buffer is the bucket
+        stage = flat_group.grad.is_cuda and torch.distributed.get_backend(group) == "gloo"
+        buf = flat_group.grad.cpu() if stage else flat_group.grad
+        torch.distributed.all_reduce(buf, group=group)
+        if average:
+            buf /= torch.distributed.get_world_size(group)
+        if stage:
+            flat_group.grad.copy_(buf)
+        return
     dev, dtype = params[0].device, params[0].dtype
     flat = torch.zeros(sum(p.numel() for p in params), dtype=dtype, device=dev)
     off = 0
@@ -124,6 +135,19 @@ def all_reduce_gradients(parameters: tp.Iterable[torch.nn.Parameter], group=None
         else:
             p.grad.copy_(g)
         off += p.numel()
+
+
+def _one_flat_group(params: tp.List[torch.nn.Parameter]):
+    """The flat parameter group of torchani_amd.optim.Adam that holds exactly these parameters, every gradient still its view
+    of the group's buffer -- or None."""
+    tag = getattr(params[0], "_anihip_flat", None)
+    f = tag[0]() if tag is not None else None
+    if f is None or len(f.params) != len(params):
+        return None
+    for i, p in enumerate(params):
+        if f.params[i] is not p or p.grad is not f.grad_views[i]:
+            return None
+    return f
 
 
 # ---- spatial shards of ONE big system (SURVEY 8e: slabs of the cell-sorted order + a cutoff-wide halo) -------------------
