@@ -2271,7 +2271,21 @@ def test_headline_scale_sampled_parity(dev):
            f"max|F err| = {res['max_dF']:.2e}  ({res['seconds']:.0f} s oracle)")
     assert res["max_dE_atom"] < E_ATOM_TOL and res["max_dF"] < F_TOL
     assert res["max_dE_atom"] <= E_ATOM_REG and res["max_dF"] <= F_REG, "regression gate (module header)"
-    del out
+    # size-independent properties at this size: no net force on a periodic system (every pair and triple term pushes its
+    # atoms with forces that cancel), and the same answer for the box translated by a vector that is no multiple of anything
+    # (other bins, other bin-local coordinates, other images)
+    n = sp.numel()
+    net = out.forces.double().sum(dim=1).abs().max()
+    fsum = out.forces.double().abs().sum()
+    shift = torch.tensor([1.234, -2.5, 3.75], dtype=x.dtype, device=dev)
+    moved = model.energies_and_forces(sp, x + shift, cell, (True, True, True), check_overflow=True)
+    dE = abs(float(moved.energies - out.energies))
+    dF = float((moved.forces - out.forces).abs().max())
+    report(f"box   water {n} atoms pbc  net force {float(net):.2e} Ha/A (sum |F| {float(fsum):.2e});  translated box: "
+           f"|dE| = {dE:.2e} Ha, max|dF| = {dF:.2e} Ha/A")
+    assert float(net) < 1e-8 * float(fsum)
+    assert dE < 1e-9 * n and dF < F_REG
+    del out, moved
     torch.cuda.empty_cache()
 
 
