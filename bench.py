@@ -308,7 +308,10 @@ def main():
             owned = model.__dict__["_spatial_cache"][1].owned_idx.cpu().numpy()   # (the partition of the last step)
         parity = sampled_parity(species, coords, cell, out.atomic_energies, out.forces, sd_np, "ani2x", 8,
                                 n_sample=args.parity_sample if group is None else max(32, args.parity_sample // 4), seed=7,
-                                candidates=owned)
+                                candidates=owned,
+                                # (a rank started by torch.distributed.run inherits OMP_NUM_THREADS=1; the other ranks wait at
+                                # the final barrier meanwhile: the oracle gets the host's cores but two per rank)
+                                threads=None if group is None else max(1, (os.cpu_count() or 1) - 2 * world))
         parity["atoms_sampled_from"] = "the whole box" if group is None else f"the {len(owned)} atoms rank 0 owns"
         gates = ("gate_dE_atom", "gate_dF") if args.two_product_backward else ("regression_gate_dE_atom", "regression_gate_dF")
         assert parity["max_dE_atom"] <= parity[gates[0]] and parity["max_dF"] <= parity[gates[1]], \

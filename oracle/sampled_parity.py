@@ -47,11 +47,13 @@ def cut_clusters(species, coords, cell, centers: np.ndarray, radius: float):
 
 def sampled_parity(species, coords, cell, atomic_energies, forces, state_dict: tp.Mapping[str, np.ndarray], kind: str = "ani2x",
                    n_members: int = 8, n_sample: int = 512, seed: int = 0, batch: int = 128,
-                   candidates: tp.Optional[np.ndarray] = None) -> tp.Dict[str, tp.Any]:
+                   candidates: tp.Optional[np.ndarray] = None, threads: tp.Optional[int] = None) -> tp.Dict[str, tp.Any]:
     """Compare ``atomic_energies`` [N] (NN part, ensemble mean) and ``forces`` [N, 3] of a periodic system with the fp64
     oracle on ``n_sample`` random real atoms -- of ``candidates`` (atom indices) when given: a rank of a sharded run holds
     the results of the atoms it OWNS, the clusters are cut from the whole box (which every rank has).
-    Returns {n, max_dE_atom, max_dF, cluster_atoms_mean, seconds}."""
+    ``threads``: OpenMP threads of the oracle for this call (a rank started by torch.distributed.run inherits
+    OMP_NUM_THREADS=1: 128 clusters then take a minute on one core while the other ranks wait at a barrier).
+    Returns {n, max_dE_atom, max_dF, cluster_atoms_mean, seconds, oracle_threads}."""
     import time
 
     import torch
@@ -63,6 +65,10 @@ def sampled_parity(species, coords, cell, atomic_energies, forces, state_dict: t
     p = orc.params_2x() if kind == "ani2x" else orc.params_1x()
     dims, flat = orc.pack_networks(state_dict, symbols, n_members)
     o64 = orc.Oracle("f64")
+    threads_before = o64.num_threads()
+    if threads:
+        o64.set_threads(int(threads))
+    threads_used = o64.num_threads()
     sp = species.reshape(-1)
     real = torch.nonzero(sp >= 0).reshape(-1).cpu().numpy()
     if candidates is not None:
@@ -80,7 +86,9 @@ def sampled_parity(species, coords, cell, atomic_energies, forces, state_dict: t
         ref = o64.energy_forces(p, S, X, dims, flat, n_members, sae=None)
         max_de = max(max_de, float(np.abs(ref["atomic_energies"][:, 0] - e_dev[b0:b0 + batch]).max()))
         max_df = max(max_df, float(np.abs(ref["forces"][:, 0] - f_dev[b0:b0 + batch]).max()))
-    return {"n": int(len(centers)), "max_dE_atom": max_de, "max_dF": max_df, "cluster_atoms_mean": float(np.mean(sizes)),
+    if threads:
+        o64.set_threads(threads_before)
+    return {"n": int(len(centers)), "oracle_threads": threads_used, "max_dE_atom": max_de, "max_dF": max_df, "cluster_atoms_mean": float(np.mean(sizes)),
             "radius_A": 2.0 * consts.Rcr, "oracle": "oracle/ani_oracle.c fp64, non-periodic clusters around the sampled atoms",
             "gate_dE_atom": 1e-5, "gate_dF": 1e-4,
             # (regression gates ~20x the measured error, as in tests/test_gpu_parity.py: a kernel bug inside the parity gates fails these)

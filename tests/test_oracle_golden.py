@@ -168,3 +168,30 @@ def test_oracle_on_general_grids(oracle64, name):
     t = fgrad_direction(g["species"])
     _, jt = oracle64.aev_jvp(p, g["species"], g["coords"].astype(np.float64), t, g.get("cell"), g.get("pbc"))
     assert np.abs(jt.reshape(g["aev_jvp"].shape) - g["aev_jvp"]).max() < 2e-11 * max(1.0, np.abs(g["aev_jvp"]).max())
+
+
+def test_sampled_parity_clusters_reproduce_the_periodic_oracle(oracle64):
+    """oracle/sampled_parity.py, the check behind bench.py's `parity_sample` and the large-system tests, against the oracle
+    itself: the non-periodic cluster within 2 Rcr of an atom gives that atom's energy and force of the periodic box -- and
+    the call runs on the OpenMP threads it is given (a rank under torch.distributed.run inherits OMP_NUM_THREADS=1) and
+    leaves the oracle's thread count as it found it."""
+    import torch
+
+    from bench import water_box
+    from oracle.sampled_parity import sampled_parity
+    from _util import seeded_state
+
+    sp_np, x_np, cell_np = water_box(7)   # 1029 atoms, 21.7 A edges (>= 2 x 10.2 A)
+    dims, flat, _ = oracle_networks("ani2x", 8, 3)
+    full = oracle64.energy_forces(oracle_params("ani2x"), sp_np, x_np.astype(np.float64), dims, flat, 8, sae=None,
+                                  cell=cell_np, pbc=(True, True, True), cell_list=True)
+    sp, x, cell = torch.from_numpy(sp_np), torch.from_numpy(x_np), torch.from_numpy(cell_np)
+    e = torch.from_numpy(full["atomic_energies"])
+    f = torch.from_numpy(full["forces"])
+    before = oracle64.num_threads()
+    own = np.arange(0, sp_np.size, 3)   # (a rank's owned atoms: here the oxygens)
+    res = sampled_parity(sp, x, cell, e, f, seeded_state("ani2x", 8, 3), "ani2x", 8, n_sample=6, seed=1, candidates=own,
+                         threads=2)
+    assert res["n"] == 6 and res["oracle_threads"] == 2 and oracle64.num_threads() == before
+    assert res["max_dE_atom"] < 1e-11 and res["max_dF"] < 1e-10, res
+    assert 300 < res["cluster_atoms_mean"] < 600
