@@ -126,7 +126,31 @@ def _train_worker(rank, world, port, q):
     scale = float(ref["grad_abs_max"])
     err = max(np.abs(sums - ref["block_sums"]).max(), np.abs(dots - ref["block_dots"]).max(),
               np.abs(heads - ref["block_heads"]).max())
-    q.put((rank, c0, c1, float(err / scale)))
+    # the same gradients as views of ONE flat buffer, tagged the way torchani_amd.optim.Adam tags its parameters (the
+    # optimizer itself needs a ROCm device): the buffer is the bucket, reduced in place
+    import weakref
+
+    from torchani_amd.parallel import _one_flat_group
+
+    class Flat:   # (what _one_flat_group reads of optim._FlatGroup)
+        pass
+
+    fg = Flat()
+    fg.grad = torch.from_numpy(part.copy())
+    fg.params, fg.grad_views = [], []
+    for i in range(len(cuts) - 1):
+        t = torch.nn.Parameter(torch.zeros(int(cuts[i + 1] - cuts[i]), dtype=torch.float64))
+        v = fg.grad[int(cuts[i]):int(cuts[i + 1])]
+        t.grad = v
+        t._anihip_flat = (weakref.ref(fg), i)
+        fg.params.append(t)
+        fg.grad_views.append(v)
+    assert _one_flat_group(fg.params) is fg and _one_flat_group(fg.params[:-1]) is None and _one_flat_group(params) is None
+    ptr = fg.grad.data_ptr()
+    all_reduce_gradients(fg.params, group)
+    assert fg.grad.data_ptr() == ptr and all(t.grad is v for t, v in zip(fg.params, fg.grad_views))
+    err_flat = float(np.abs(fg.grad.numpy() - total).max())
+    q.put((rank, c0, c1, float(err / scale), err_flat / scale))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -147,5 +171,5 @@ def test_two_rank_training_gradients_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == 6   # contiguous cover of the 6 molecules
-    for _, _, _, rel in res:
-        assert rel < 1e-7
+    for _, _, _, rel, rel_flat in res:
+        assert rel < 1e-7 and rel_flat < 1e-15   # (the flat route sums the same two numbers per element)
