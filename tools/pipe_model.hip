@@ -1,0 +1,781 @@
+// Model of the column-split software pipeline proposed for k_mlp_fused (round-5 review, item 1): does the epilogue VALU
+// work of the network kernel hide behind MFMAs when both are interleaved inside ONE wave, with the real LDS plane traffic,
+// the real barriers and the real weight stream?
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/_bin/pipe_model tools/pipe_model.hip && tools/_bin/pipe_model
+//
+// One workgroup per CU walks ITEMS = (64-atom tile, member) like the product kernel: six GEMM phases per item with the shapes
+// of the ANI-2x hydrogen network over four flagged AEV slabs (N x K = 256 x 128, 192 x 256, 160 x 192, 192 x 160, 256 x 192,
+// 128 x 256; 2640 MFMAs of 32x32x16 f16 per item with the three-product split), activations as {hi, lo} fp16 planes in LDS,
+// weights streamed from L2 in fragment order through a register ring, CELU / CELU' / split epilogues, the layer-0 backward's
+// read-add-write of the gradient rows.  Synthetic numbers, real instruction mix.
+//
+// Variants:
+//   SEQ8  : the structure of the shipped kernel -- 8 waves (2 per SIMD), a wave owns one column block x both row blocks,
+//           GEMM phase, then epilogue, then barrier.
+//   PIPE4 : 4 waves (1 per SIMD, 512 registers).  A wave owns column block A = w (both row blocks) and a share B of the column
+//           blocks 4.. of a phase.  Per phase:
+//             S1: G_A over the k steps that read A columns of the previous phase   ||  epilogue of the previous phase's B units
+//             barrier
+//             S2: G_A over the k steps that read B columns
+//             S3: G_B over all k steps                                             ||  epilogue of this phase's A units
+//             barrier
+//           so that every epilogue quad (4 elements: ~30 VALU + 2 LDS writes) sits between the MFMAs of a k step.
+//   PIPE4 with the interleave switched off (epilogues behind their segments): what 4 waves cost without the overlap.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const h8 gh8;
+typedef __attribute__((address_space(1))) const v4f gf4;
+
+constexpr int FRAG = 512;      // halves per fragment plane (64 lanes x 8)
+constexpr int ROWS = 64;
+constexpr int NB1 = 8, NB2 = 6, NB3 = 5, NS = 4;   // column blocks of H1, H2, H3; flagged AEV slabs
+constexpr int H1 = 32 * NB1, H2 = 32 * NB2, H3 = 32 * NB3;
+constexpr int LD0 = H1 + 8, LD1 = H2 + 8, LD2 = H3 + 8;
+constexpr int SLABU = 2 * ROWS * 32;               // halves per kept slab {hi plane, lo plane}
+constexpr int X0_HALVES = 2 * ROWS * LD0, X1_HALVES = 2 * ROWS * LD1, S0_HALVES = NS * SLABU;
+constexpr int FIXED_HALVES = 1024;                 // energy partials etc.
+constexpr size_t LDS_BYTES = 2 * (size_t)(FIXED_HALVES + S0_HALVES + X0_HALVES + X1_HALVES);
+// per member, halves: w0 [NB1][2 NS] | w1 [NB2][2 NB1] | w2 [NB3][2 NB2] | w2t [NB2][2 NB3] | w1t [NB1][2 NB2] | w0t [NS][2 NB1]
+constexpr int64_t W0 = 0, W1 = W0 + (int64_t)NB1 * 2 * NS * 2 * FRAG, W2 = W1 + (int64_t)NB2 * 2 * NB1 * 2 * FRAG,
+                  W2T = W2 + (int64_t)NB3 * 2 * NB2 * 2 * FRAG, W1T = W2T + (int64_t)NB2 * 2 * NB3 * 2 * FRAG,
+                  W0T = W1T + (int64_t)NB1 * 2 * NB2 * 2 * FRAG, WMEM = W0T + (int64_t)NS * 2 * NB1 * 2 * FRAG;
+constexpr int M = 8;
+
+struct Args {
+    const _Float16 *w;     // [M][WMEM]
+    const float *cols;     // [M][4][256] per-column parameters (b0, b1, b2, w3)
+    float *grad;           // [items_total][64][128] d E / d AEV slabs (read-add-write)
+    float *energy;         // [items_total][64]
+    int items_per_wg;
+    int zero_lds;          // the kept layer-0 operand is all zeros (power experiment)
+    long long *cyc;        // [workgroups] cycles of wave 0
+};
+
+template <int D>
+struct Ring {
+    h8 hi[D], lo[D];
+    const _Float16 *base;   // (cb, ks = 0, plane 0) + lane * 8
+    __device__ __forceinline__ void load(int slot, int ks)
+    {
+        const _Float16 *p = base + (int64_t)ks * (2 * FRAG);
+        hi[slot] = *(const gh8 *)p;
+        lo[slot] = *(const gh8 *)(p + FRAG);
+    }
+};
+
+template <int NRB>
+struct AFrag {
+    h8 hi[NRB], lo[NRB];
+    __device__ __forceinline__ void load(const _Float16 *a, int plane, int rbs)
+    {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            hi[rb] = *reinterpret_cast<const h8 *>(a + rb * rbs);
+            lo[rb] = *reinterpret_cast<const h8 *>(a + rb * rbs + plane);
+        }
+    }
+};
+
+#ifndef MODEL_M16
+#define MODEL_M16 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+// one 32x32x16 product -- or (MODEL_M16: power experiment, numbers meaningless) the same flops as two 16x16x32 on quarters of
+// the accumulator
+__device__ __forceinline__ void mm(f32x16 &c, const h8 &a, const h8 &b, int which)
+{
+#if MODEL_M16
+    f4v *q = reinterpret_cast<f4v *>(&c);
+    q[2 * (which & 1)] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q[2 * (which & 1)], 0, 0, 0);
+    q[2 * (which & 1) + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q[2 * (which & 1) + 1], 0, 0, 0);
+#else
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+template <int NRB>
+__device__ __forceinline__ void mfma3(f32x16 (&acc)[NRB], const h8 &whi, const h8 &wlo, const AFrag<NRB> &x)
+{
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) mm(acc[rb], whi, x.lo[rb], 0);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) mm(acc[rb], wlo, x.hi[rb], 1);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) mm(acc[rb], whi, x.hi[rb], 0);
+}
+
+// {hi, lo} fp16 split of four values x * s -> two 8-byte LDS stores
+__device__ __forceinline__ void split_store4(const float (&x)[4], float s, _Float16 *d, int plane)
+{
+    h4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        const h2 h = __builtin_convertvector(v2f{x[e] * s, x[e + 1] * s}, h2);
+        hi[e] = h[0];
+        hi[e + 1] = h[1];
+        h2 l;
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x[e]), "v"(s), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x[e + 1]), "v"(s), "v"(h));
+        lo[e] = l[0];
+        lo[e + 1] = l[1];
+    }
+    *reinterpret_cast<h4 *>(d) = hi;
+    *reinterpret_cast<h4 *>(d + plane) = lo;
+}
+
+// one GEMM segment: NST k steps (global step numbers KS0 .. KS0 + NST - 1 of a ring that covers KSTOT steps) of one column
+// block x NRB row blocks, with NQ epilogue quads spread over the steps (INTER) or run behind them
+template <int NRB, int KS0, int NST, int KSTOT, int D, int NQ, bool INTER, class Addr, class Epi>
+__device__ __forceinline__ void segment(f32x16 (&acc)[NRB], Ring<D> &rg, Addr &&addr, int plane, int rbs, Epi &&epi)
+{
+    AFrag<NRB> xa, xb;
+    xa.load(addr(KS0), plane, rbs);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        const int k = KS0 + st;
+        AFrag<NRB> &xc = (st & 1) ? xb : xa, &xn = (st & 1) ? xa : xb;
+        if (st + 1 < NST) xn.load(addr(k + 1), plane, rbs);
+        mfma3<NRB>(acc, rg.hi[k % D], rg.lo[k % D], xc);
+        if (INTER) {
+#pragma unroll
+            for (int q = (st * NQ) / NST; q < ((st + 1) * NQ) / NST; ++q) epi(q);
+        }
+        if (k + D < KSTOT) rg.load(k % D, k + D);
+        if (INTER) {
+#pragma unroll
+            for (int i = 0; i < 3 * NRB; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);   // up to six VALU
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // an LDS write
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!INTER) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) epi(q);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void ring_start(Ring<D> &rg, const _Float16 *w, int cb, int KS, int lane)
+{
+    rg.base = w + (int64_t)cb * KS * (2 * FRAG) + lane * 8;
+#pragma unroll
+    for (int sl = 0; sl < D; ++sl) rg.load(sl, sl < KS ? sl : KS - 1);
+}
+
+__device__ __forceinline__ void zero(f32x16 &a)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// B share of a wave in a phase that produces NB column blocks (4 waves): kind 2 = a whole column block (both row blocks),
+// 1 = one row block of a column block, 0 = nothing
+struct BShare { int kind, cb, rb; };
+template <int NB>
+__device__ __forceinline__ BShare b_share(int wave)
+{
+    constexpr int nB = NB > 4 ? NB - 4 : 0, FULLS = 2 * nB > 4 ? 2 * nB - 4 : 0;
+    if (wave < FULLS) return BShare{2, 4 + wave, 0};
+    const int idx = wave - FULLS, cb = 4 + FULLS + (idx >> 1);
+    if (cb < NB) return BShare{1, cb, idx & 1};
+    return BShare{0, 0, 0};
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PIPE4.  Three weight rings: r0 = G_A of phases 1..5, r1 = G_B of every phase, r2 = G_A of phase 0 -- each is requested a
+// segment (or more) before the segment that consumes it starts.
+template <bool INTER, int D>
+__global__ __launch_bounds__(256, 1) void k_pipe4(Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    float *s_e = reinterpret_cast<float *>(lds);                 // [4][64]
+    _Float16 *slot0 = lds + FIXED_HALVES;
+    _Float16 *X0 = slot0 + S0_HALVES, *X1 = X0 + X0_HALVES, *X2 = X0;
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // synthetic kept operand
+    for (int i = tid; i < S0_HALVES; i += 256) slot0[i] = (_Float16)(g.zero_lds ? 0.f : ((i * 2654435761u) >> 20 & 1023) * (1.0f / 64.0f));
+    __syncthreads();
+    const float alpha = 0.1f, ia_log2e = 10.0f * 1.44269504f;
+    const long long t0 = __builtin_readcyclecounter();
+
+    // pending epilogue state carried from phase to phase
+    f32x16 pend[2];
+    zero(pend[0]); zero(pend[1]);
+    float dsave0[4][16], dsave1[3][16];   // celu'(act0): A rb0, A rb1, B rb0, B rb1; celu'(act1): A rb0, A rb1, B
+    v4f prevg[2][4];                      // previous members' d E / d AEV of this wave's slab rows (phase 5)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int p4 = 0; p4 < 4; ++p4) prevg[rb][p4] = v4f{0.f, 0.f, 0.f, 0.f};
+    const BShare b0s = b_share<NB1>(wave);   // (NB1 = 8: a whole column block)
+    const BShare b1s = b_share<NB2>(wave);   // (NB2 = 6: one row block of column block 4 or 5)
+    const BShare b2s = b_share<NB3>(wave);   // (NB3 = 5: waves 0, 1 a row block of column block 4; waves 2, 3 nothing)
+    Ring<D> r0, r1, r2;
+    ring_start<D>(r2, g.w + W0, wave, 2 * NS, lane);
+    ring_start<D>(r1, g.w + W0, b0s.cb, 2 * NS, lane);
+    const float s0 = 512.0f, s1 = 512.0f, s2 = 2048.0f, s3 = 2048.0f, s4 = 2048.0f;   // (power-of-two split scales)
+    const float osc = 1.0f / (8192.0f * 512.0f * 8.0f);
+    auto none = [&](int) {};
+
+    for (int it = 0; it < g.items_per_wg; ++it) {
+        const int m = it & 7, mn = (it + 1) & 7;
+        const int64_t item = (int64_t)blockIdx.x * g.items_per_wg + it;
+        const _Float16 *wm = g.w + (int64_t)m * WMEM;
+        const float *cm = g.cols + (int64_t)m * 4 * 256;
+
+        auto cols16 = [&](const float *base, int cb, float (&v)[16]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f t = *(const gf4 *)(base + cb * 32 + 4 * fk + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+            }
+        };
+        // forward epilogue quad: bias, CELU, CELU' (kept), split -> planes of X
+        auto fwd_quad = [&](f32x16 &a, const float (&b)[16], float (&dsv)[16], int q, float o, float s, _Float16 *X, int ld,
+                            int plane, int row, int col) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int r = 4 * q + e;
+                const v2f x = v2f{a[r], a[r + 1]} * o + v2f{b[r], b[r + 1]};
+                const v2f t = x * ia_log2e;
+                const v2f ex = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                const v2f yy = ex * alpha - alpha;
+                dsv[r] = fminf(ex.x, 1.0f);
+                dsv[r + 1] = fminf(ex.y, 1.0f);
+                y[e] = __builtin_amdgcn_fmed3f(x.x, yy.x, 0.f);
+                y[e + 1] = __builtin_amdgcn_fmed3f(x.y, yy.y, 0.f);
+            }
+            split_store4(y, s, X + row * ld + col + 8 * q, plane);
+        };
+        // backward epilogue quad: times CELU', split -> planes of X
+        auto bwd_quad = [&](f32x16 &a, const float (&dsv)[16], int q, float o, float s, _Float16 *X, int ld, int plane, int row,
+                            int col) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = a[4 * q + e] * (o * dsv[4 * q + e]);
+            split_store4(y, s, X + row * ld + col + 8 * q, plane);
+        };
+        // output layer + backward seed of a quad of act2
+        auto head_quad = [&](f32x16 &a, const float (&b)[16], const float (&w3)[16], float &ep, int q, int row, int col) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int r = 4 * q + e;
+                const v2f x = v2f{a[r], a[r + 1]} * osc + v2f{b[r], b[r + 1]};
+                const v2f t = x * ia_log2e;
+                const v2f ex = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                const v2f yy = ex * alpha - alpha;
+                const float y0 = __builtin_amdgcn_fmed3f(x.x, yy.x, 0.f), y1 = __builtin_amdgcn_fmed3f(x.y, yy.y, 0.f);
+                ep = __builtin_fmaf(y0, w3[r], ep);
+                ep = __builtin_fmaf(y1, w3[r + 1], ep);
+                y[e] = 0.125f * w3[r] * fminf(ex.x, 1.0f);
+                y[e + 1] = 0.125f * w3[r + 1] * fminf(ex.y, 1.0f);
+            }
+            split_store4(y, s2, X2 + row * LD2 + col + 8 * q, ROWS * LD2);
+        };
+
+        f32x16 accA[2], accB[2];
+        f32x16(&accB1)[1] = reinterpret_cast<f32x16(&)[1]>(accB[0]);
+        float colA[16], colB[16], colP[16];   // per-column parameters of the A block, the B block, the pending B block
+        float w3A[16], w3B[16];
+        float e_part[2] = {0.f, 0.f}, e_b = 0.f;
+
+        // ======================= phase 0: act0 = celu(aev x W0 + b0), K = 2 NS steps from the kept slabs ==================
+        {
+            auto addr0 = [&](int k) {
+                const int row = fr, sw = (row >> 2) & 3;
+                return slot0 + (k >> 1) * SLABU + row * 32 + (((2 * (k & 1) + fk) ^ sw) << 3);
+            };
+            ring_start<D>(r0, wm + W1, wave, 2 * NB1, lane);   // G_A(1)
+            cols16(cm, wave, colA);
+            cols16(cm, b0s.cb, colB);
+            zero(accA[0]); zero(accA[1]);
+            // G_A over all k steps || the previous item's phase-5 epilogue: the slab tiles leave through wave-private LDS tiles
+            // (whole lines per store), read-add-write on the gradient rows
+            auto epi5 = [&](int q) {
+                if (q < 8) {
+                    const int rb = q >> 2, p4 = q & 3;
+                    float *tile = reinterpret_cast<float *>(X1) + wave * 2048 + rb * 1024;   // wave-private 32 x 32 floats
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = pend[rb][4 * p4 + e] * osc;
+                    *reinterpret_cast<v4f *>(tile + fr * 32 + (((2 * p4 + fk) ^ (fr >> 1)) & 7) * 4) = v;
+                } else {
+                    const int rb = (q - 8) >> 2, p4 = q & 3;
+                    float *tile = reinterpret_cast<float *>(X1) + wave * 2048 + rb * 1024;
+                    const int row = p4 * 8 + (lane >> 3), piece = lane & 7;
+                    const v4f t = *reinterpret_cast<const v4f *>(tile + row * 32 + (((piece ^ (row >> 1)) & 7) << 2));
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = t[e] + prevg[rb][p4][e];
+                    float *dst = g.grad + ((item - 1) * 64 + rb * 32 + row) * 128 + wave * 32 + 4 * piece;
+                    if (it > 0) *reinterpret_cast<v4f *>(dst) = v;
+                }
+            };
+            segment<2, 0, 2 * NS, 2 * NS, D, 16, INTER>(accA, r2, addr0, ROWS * 32, 32 * 32, epi5);
+            // G_B over all k steps || E_A(0)
+            zero(accB[0]); zero(accB[1]);
+            auto epiA = [&](int q) {
+                const int rb = q >> 2;
+                fwd_quad(accA[rb], colA, dsave0[rb], q & 3, osc, s0, X0, LD0, ROWS * LD0, rb * 32 + fr, wave * 32 + 4 * fk);
+            };
+            segment<2, 0, 2 * NS, 2 * NS, D, 8, INTER>(accB, r1, addr0, ROWS * 32, 32 * 32, epiA);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) colP[r] = colB[r];
+            pend[0] = accB[0]; pend[1] = accB[1];
+            __syncthreads();   // beta(0): the A columns of act0 are complete
+        }
+        // ======================= phase 1: act1 = celu(act0 x W1 + b1): N = NB2 blocks, K = 2 NB1 steps =====================
+        {
+            auto addrA = [&](int k) { return X0 + fr * LD0 + k * 16 + fk * 8; };
+            ring_start<D>(r1, wm + W1, b1s.cb, 2 * NB1, lane);   // G_B(1)
+            cols16(cm + 256, wave, colA);
+            cols16(cm + 256, b1s.cb, colB);
+            zero(accA[0]); zero(accA[1]);
+            // S1: G_A over the A range of act0 (k steps 0..7) || E_B(0)
+            auto epiP = [&](int q) {
+                const int rb = q >> 2;
+                fwd_quad(pend[rb], colP, dsave0[2 + rb], q & 3, osc, s0, X0, LD0, ROWS * LD0, rb * 32 + fr, b0s.cb * 32 + 4 * fk);
+            };
+            segment<2, 0, 8, 2 * NB1, D, 8, INTER>(accA, r0, addrA, ROWS * LD0, 32 * LD0, epiP);
+            __syncthreads();   // alpha(1): act0 complete
+            // S2: G_A over the B range (k steps 8..15)
+            segment<2, 8, 2 * NB1 - 8, 2 * NB1, D, 0, false>(accA, r0, addrA, ROWS * LD0, 32 * LD0, none);
+            ring_start<D>(r0, wm + W2, wave, 2 * NB2, lane);   // G_A(2)
+            // S3: G_B (one row block) over all k steps || E_A(1)
+            zero(accB[0]);
+            auto addrB = [&](int k) { return X0 + (b1s.rb * 32 + fr) * LD0 + k * 16 + fk * 8; };
+            auto epiA = [&](int q) {
+                const int rb = q >> 2;
+                fwd_quad(accA[rb], colA, dsave1[rb], q & 3, osc, s1, X1, LD1, ROWS * LD1, rb * 32 + fr, wave * 32 + 4 * fk);
+            };
+            segment<1, 0, 2 * NB1, 2 * NB1, D, 8, INTER>(accB1, r1, addrB, ROWS * LD0, 32 * LD0, epiA);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) colP[r] = colB[r];
+            pend[0] = accB[0];
+            __syncthreads();   // beta(1): A columns of act1 complete, every wave is done reading X0
+        }
+        // ======================= phase 2: act2, output layer, seed: N = NB3 blocks, K = 2 NB2 steps =========================
+        {
+            auto addrA = [&](int k) { return X1 + fr * LD1 + k * 16 + fk * 8; };
+            ring_start<D>(r1, wm + W2, b2s.cb, 2 * NB2, lane);   // G_B(2) (waves without a share request block 0: unused)
+            cols16(cm + 512, wave, colA);
+            cols16(cm + 768, wave, w3A);
+            cols16(cm + 512, b2s.cb, colB);
+            cols16(cm + 768, b2s.cb, w3B);
+            zero(accA[0]); zero(accA[1]);
+            auto epiP = [&](int q) {   // E_B(1): one row block
+                fwd_quad(pend[0], colP, dsave1[2], q & 3, osc, s1, X1, LD1, ROWS * LD1, b1s.rb * 32 + fr, b1s.cb * 32 + 4 * fk);
+            };
+            segment<2, 0, 8, 2 * NB2, D, 4, INTER>(accA, r0, addrA, ROWS * LD1, 32 * LD1, epiP);
+            __syncthreads();   // alpha(2)
+            segment<2, 8, 2 * NB2 - 8, 2 * NB2, D, 0, false>(accA, r0, addrA, ROWS * LD1, 32 * LD1, none);
+            ring_start<D>(r0, wm + W2T, wave, 2 * NB3, lane);   // G_A(3)
+            auto epiA = [&](int q) {
+                const int rb = q >> 2;
+                head_quad(accA[rb], colA, w3A, e_part[rb], q & 3, rb * 32 + fr, wave * 32 + 4 * fk);
+            };
+            if (b2s.kind) {
+                zero(accB[0]);
+                auto addrB = [&](int k) { return X1 + (b2s.rb * 32 + fr) * LD1 + k * 16 + fk * 8; };
+                segment<1, 0, 2 * NB2, 2 * NB2, D, 8, INTER>(accB1, r1, addrB, ROWS * LD1, 32 * LD1, epiA);
+                pend[0] = accB[0];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) epiA(q);
+            }
+            __syncthreads();   // beta(2)
+        }
+        // ======================= phase 3: d act1 = (d act2 x W2) celu'(act1): N = NB2, K = 2 NB3 steps =====================
+        {
+            auto addrA = [&](int k) { return X2 + fr * LD2 + k * 16 + fk * 8; };
+            zero(accA[0]); zero(accA[1]);
+            auto epiP = [&](int q) {   // E_B(2): the head of the B row block (waves 0, 1)
+                head_quad(pend[0], colB, w3B, e_b, q & 3, b2s.rb * 32 + fr, b2s.cb * 32 + 4 * fk);
+            };
+            if (b2s.kind) segment<2, 0, 8, 2 * NB3, D, 4, INTER>(accA, r0, addrA, ROWS * LD2, 32 * LD2, epiP);
+            else segment<2, 0, 8, 2 * NB3, D, 0, false>(accA, r0, addrA, ROWS * LD2, 32 * LD2, none);
+            ring_start<D>(r1, wm + W2T, b1s.cb, 2 * NB3, lane);   // G_B(3)
+            // energy partials of the tile rows: lanes of a row pair up, the waves meet in LDS
+            {
+                float ea = e_part[0] + __shfl_xor(e_part[0], 32), eb = e_part[1] + __shfl_xor(e_part[1], 32);
+                const float ex_ = e_b + __shfl_xor(e_b, 32);
+                if (b2s.kind) { if (b2s.rb == 0) ea += ex_; else eb += ex_; }
+                if (fk == 0) { s_e[wave * 64 + fr] = ea; s_e[wave * 64 + 32 + fr] = eb; }
+            }
+            __syncthreads();   // alpha(3): d act2 complete
+            if (tid < 64) g.energy[item * 64 + tid] = s_e[tid] + s_e[64 + tid] + s_e[128 + tid] + s_e[192 + tid];
+            segment<2, 8, 2 * NB3 - 8, 2 * NB3, D, 0, false>(accA, r0, addrA, ROWS * LD2, 32 * LD2, none);
+            ring_start<D>(r0, wm + W1T, wave, 2 * NB2, lane);   // G_A(4)
+            // S3: G_B (one row block of block 4 / 5) || E_A(3)
+            zero(accB[0]);
+            auto addrB = [&](int k) { return X2 + (b1s.rb * 32 + fr) * LD2 + k * 16 + fk * 8; };
+            auto epiA = [&](int q) {
+                const int rb = q >> 2;
+                bwd_quad(accA[rb], dsave1[rb], q & 3, osc, s3, X1, LD1, ROWS * LD1, rb * 32 + fr, wave * 32 + 4 * fk);
+            };
+            segment<1, 0, 2 * NB3, 2 * NB3, D, 8, INTER>(accB1, r1, addrB, ROWS * LD2, 32 * LD2, epiA);
+            pend[0] = accB[0];
+            __syncthreads();   // beta(3)
+        }
+        // ======================= phase 4: d act0 = (d act1 x W1) celu'(act0): N = NB1, K = 2 NB2 steps =====================
+        {
+            auto addrA = [&](int k) { return X1 + fr * LD1 + k * 16 + fk * 8; };
+            ring_start<D>(r1, wm + W1T, b0s.cb, 2 * NB2, lane);   // G_B(4)
+            zero(accA[0]); zero(accA[1]);
+            auto epiP = [&](int q) {   // E_B(3): one row block
+                bwd_quad(pend[0], dsave1[2], q & 3, osc, s3, X1, LD1, ROWS * LD1, b1s.rb * 32 + fr, b1s.cb * 32 + 4 * fk);
+            };
+            segment<2, 0, 8, 2 * NB2, D, 4, INTER>(accA, r0, addrA, ROWS * LD1, 32 * LD1, epiP);
+            __syncthreads();   // alpha(4)
+            segment<2, 8, 2 * NB2 - 8, 2 * NB2, D, 0, false>(accA, r0, addrA, ROWS * LD1, 32 * LD1, none);
+            ring_start<D>(r0, wm + W0T, wave, 2 * NB1, lane);   // G_A(5)
+            zero(accB[0]); zero(accB[1]);
+            auto epiA = [&](int q) {
+                const int rb = q >> 2;
+                bwd_quad(accA[rb], dsave0[rb], q & 3, osc, s4, X0, LD0, ROWS * LD0, rb * 32 + fr, wave * 32 + 4 * fk);
+            };
+            segment<2, 0, 2 * NB2, 2 * NB2, D, 8, INTER>(accB, r1, addrA, ROWS * LD1, 32 * LD1, epiA);
+            pend[0] = accB[0]; pend[1] = accB[1];
+            __syncthreads();   // beta(4)
+        }
+        // ======================= phase 5: d AEV slabs += d act0 x W0: N = NS blocks (A only), K = 2 NB1 steps ===============
+        {
+            auto addrA = [&](int k) { return X0 + fr * LD0 + k * 16 + fk * 8; };
+            // the next item's layer-0 rings
+            ring_start<D>(r2, g.w + (int64_t)mn * WMEM + W0, wave, 2 * NS, lane);
+            ring_start<D>(r1, g.w + (int64_t)mn * WMEM + W0, b0s.cb, 2 * NS, lane);
+            zero(accA[0]); zero(accA[1]);
+            // what the members before this one left in the rows
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    const int row = p4 * 8 + (lane >> 3), piece = lane & 7;
+                    const float *src = g.grad + (item * 64 + rb * 32 + row) * 128 + wave * 32 + 4 * piece;
+                    prevg[rb][p4] = *(const gf4 *)src;
+                }
+            auto epiP = [&](int q) {   // E_B(4): a whole column block
+                const int rb = q >> 2;
+                bwd_quad(pend[rb], dsave0[2 + rb], q & 3, osc, s4, X0, LD0, ROWS * LD0, rb * 32 + fr, b0s.cb * 32 + 4 * fk);
+            };
+            segment<2, 0, 8, 2 * NB1, D, 8, INTER>(accA, r0, addrA, ROWS * LD0, 32 * LD0, epiP);
+            __syncthreads();   // alpha(5)
+            segment<2, 8, 2 * NB1 - 8, 2 * NB1, D, 0, false>(accA, r0, addrA, ROWS * LD0, 32 * LD0, none);
+            pend[0] = accA[0]; pend[1] = accA[1];   // E(5) runs beside the next item's layer 0
+            __syncthreads();   // every wave is done with X0 / X1 of this item
+        }
+    }
+    float r = pend[0][0] + pend[1][3] + r1.hi[0][0] + r2.lo[1][1];
+    if (r == 12345.678f) g.energy[0] = r;
+    if (lane == 0 && wave == 0) g.cyc[blockIdx.x] = __builtin_readcyclecounter() - t0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SEQ8: the shipped structure.  8 waves; a phase of NB column blocks deals its 2 NB (row block, column block) units like
+// fused_unit() of mlp.hip; GEMM, then epilogue, then barrier.
+struct Unit { int cb, rb0, nrb; };
+template <int NB>
+__device__ __forceinline__ Unit unit8(int wave)
+{
+    constexpr bool deal = NB > 4 && NB < 8;
+    constexpr int whole = deal ? 2 * NB - 8 : NB;
+    if (wave < whole) return Unit{wave, 0, 2};
+    const int idx = wave - whole, cb = whole + (idx >> 1);
+    if (deal && cb < NB) return Unit{cb, idx & 1, 1};
+    return Unit{0, 0, 0};
+}
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void k_seq8(Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    float *s_e = reinterpret_cast<float *>(lds);                 // [8][64]
+    _Float16 *slot0 = lds + FIXED_HALVES;
+    _Float16 *X0 = slot0 + S0_HALVES, *X1 = X0 + X0_HALVES, *X2 = X0;
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < S0_HALVES; i += 512) slot0[i] = (_Float16)(g.zero_lds ? 0.f : ((i * 2654435761u) >> 20 & 1023) * (1.0f / 64.0f));
+    __syncthreads();
+    const float alpha = 0.1f, ia_log2e = 10.0f * 1.44269504f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < g.items_per_wg; ++it) {
+        const int m = it & 7;
+        const int64_t item = (int64_t)blockIdx.x * g.items_per_wg + it;
+        const _Float16 *wm = g.w + (int64_t)m * WMEM;
+        const float *cm = g.cols + (int64_t)m * 4 * 256;
+        const float s0 = 512.0f, s1 = 512.0f, s2 = 2048.0f, s3 = 2048.0f, s4 = 2048.0f;
+        const float osc = 1.0f / (8192.0f * 512.0f * 8.0f);
+        const Unit u1 = unit8<NB1>(wave), u2 = unit8<NB2>(wave), u3 = unit8<NB3>(wave);
+        f32x16 acc[2];
+        Ring<D> rg;
+        float d0f[2][16], d1f[2][16], col[16], w3[16];
+        auto none = [&](int) {};
+        auto cols16 = [&](const float *base, int cb, float (&v)[16]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f t = *(const gf4 *)(base + cb * 32 + 4 * fk + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+            }
+        };
+        auto fwd_quad = [&](f32x16 &a, const float (&b)[16], float (&dsv)[16], int q, float o, float s, _Float16 *X, int ld,
+                            int plane, int row, int cc) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int r = 4 * q + e;
+                const v2f x = v2f{a[r], a[r + 1]} * o + v2f{b[r], b[r + 1]};
+                const v2f t = x * ia_log2e;
+                const v2f ex = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                const v2f yy = ex * alpha - alpha;
+                dsv[r] = fminf(ex.x, 1.0f);
+                dsv[r + 1] = fminf(ex.y, 1.0f);
+                y[e] = __builtin_amdgcn_fmed3f(x.x, yy.x, 0.f);
+                y[e + 1] = __builtin_amdgcn_fmed3f(x.y, yy.y, 0.f);
+            }
+            split_store4(y, s, X + row * ld + cc + 8 * q, plane);
+        };
+        auto bwd_quad = [&](f32x16 &a, const float (&dsv)[16], int q, float o, float s, _Float16 *X, int ld, int plane, int row,
+                            int cc) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = a[4 * q + e] * (o * dsv[4 * q + e]);
+            split_store4(y, s, X + row * ld + cc + 8 * q, plane);
+        };
+        // the GEMM of a unit (nrb row blocks starting at rb0) over KS steps
+#define SEQ_GEMM(U, KS, WOFF, ADDR, PLANE, RBS)                                                                             \
+        zero(acc[0]); zero(acc[1]);                                                                                           \
+        if ((U).nrb == 2) {                                                                                                   \
+            ring_start<D>(rg, wm + (WOFF), (U).cb, (KS), lane);                                                               \
+            segment<2, 0, (KS), (KS), D, 0, false>(acc, rg, ADDR, PLANE, RBS, none);                                          \
+        } else if ((U).nrb == 1) {                                                                                            \
+            ring_start<D>(rg, wm + (WOFF), (U).cb, (KS), lane);                                                               \
+            f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc[0]);                                                          \
+            segment<1, 0, (KS), (KS), D, 0, false>(a1, rg, ADDR, PLANE, RBS, none);                                           \
+        }
+        // phase 0
+        {
+            auto addr0 = [&](int k) {
+                const int row = u1.rb0 * 32 + fr, sw = (row >> 2) & 3;
+                return slot0 + (k >> 1) * SLABU + row * 32 + (((2 * (k & 1) + fk) ^ sw) << 3);
+            };
+            SEQ_GEMM(u1, 2 * NS, W0, addr0, ROWS * 32, 32 * 32)
+            cols16(cm, u1.cb, col);
+            for (int rb = 0; rb < u1.nrb; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    fwd_quad(acc[rb], col, d0f[rb], q, osc, s0, X0, LD0, ROWS * LD0, (u1.rb0 + rb) * 32 + fr, u1.cb * 32 + 4 * fk);
+            __syncthreads();
+        }
+        // phase 1
+        {
+            auto addr = [&](int k) { return X0 + (u2.rb0 * 32 + fr) * LD0 + k * 16 + fk * 8; };
+            SEQ_GEMM(u2, 2 * NB1, W1, addr, ROWS * LD0, 32 * LD0)
+            cols16(cm + 256, u2.cb, col);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                if (rb < u2.nrb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        fwd_quad(acc[rb], col, d1f[rb], q, osc, s1, X1, LD1, ROWS * LD1, (u2.rb0 + rb) * 32 + fr, u2.cb * 32 + 4 * fk);
+            __syncthreads();
+        }
+        // phase 2
+        {
+            auto addr = [&](int k) { return X1 + (u3.rb0 * 32 + fr) * LD1 + k * 16 + fk * 8; };
+            SEQ_GEMM(u3, 2 * NB2, W2, addr, ROWS * LD1, 32 * LD1)
+            cols16(cm + 512, u3.cb, col);
+            cols16(cm + 768, u3.cb, w3);
+            float ep[2] = {0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                if (rb < u3.nrb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            const int r = 4 * q + e;
+                            const v2f x = v2f{acc[rb][r], acc[rb][r + 1]} * osc + v2f{col[r], col[r + 1]};
+                            const v2f t = x * ia_log2e;
+                            const v2f ex = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                            const v2f yy = ex * alpha - alpha;
+                            const float y0 = __builtin_amdgcn_fmed3f(x.x, yy.x, 0.f), y1 = __builtin_amdgcn_fmed3f(x.y, yy.y, 0.f);
+                            ep[rb] = __builtin_fmaf(y0, w3[r], ep[rb]);
+                            ep[rb] = __builtin_fmaf(y1, w3[r + 1], ep[rb]);
+                            y[e] = 0.125f * w3[r] * fminf(ex.x, 1.0f);
+                            y[e + 1] = 0.125f * w3[r + 1] * fminf(ex.y, 1.0f);
+                        }
+                        split_store4(y, s2, X2 + ((u3.rb0 + rb) * 32 + fr) * LD2 + u3.cb * 32 + 4 * fk + 8 * q, ROWS * LD2);
+                    }
+            {
+                float ea = ep[0] + __shfl_xor(ep[0], 32), eb = ep[1] + __shfl_xor(ep[1], 32);
+                float v0 = 0.f, v1 = 0.f;
+                if (u3.nrb == 2) { v0 = ea; v1 = eb; }
+                else if (u3.nrb == 1) { if (u3.rb0 == 0) v0 = ea; else v1 = ea; }
+                if (fk == 0) { s_e[wave * 64 + fr] = v0; s_e[wave * 64 + 32 + fr] = v1; }
+            }
+            __syncthreads();
+            if (tid < 64) {
+                float e = 0.f;
+                for (int w8 = 0; w8 < 8; ++w8) e += s_e[w8 * 64 + tid];
+                g.energy[item * 64 + tid] = e;
+            }
+        }
+        // phase 3
+        {
+            auto addr = [&](int k) { return X2 + (u2.rb0 * 32 + fr) * LD2 + k * 16 + fk * 8; };
+            SEQ_GEMM(u2, 2 * NB3, W2T, addr, ROWS * LD2, 32 * LD2)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                if (rb < u2.nrb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        bwd_quad(acc[rb], d1f[rb], q, osc, s3, X1, LD1, ROWS * LD1, (u2.rb0 + rb) * 32 + fr, u2.cb * 32 + 4 * fk);
+            __syncthreads();
+        }
+        // phase 4
+        {
+            auto addr = [&](int k) { return X1 + (u1.rb0 * 32 + fr) * LD1 + k * 16 + fk * 8; };
+            SEQ_GEMM(u1, 2 * NB2, W1T, addr, ROWS * LD1, 32 * LD1)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+                if (rb < u1.nrb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        bwd_quad(acc[rb], d0f[rb], q, osc, s4, X0, LD0, ROWS * LD0, (u1.rb0 + rb) * 32 + fr, u1.cb * 32 + 4 * fk);
+            __syncthreads();
+        }
+        // phase 5: waves w and w + 4 share slab w & 3 (half of K each, both row blocks), partial tiles meet in LDS
+        {
+            const int half = wave >> 2, slab = wave & 3;
+            v4f prev[4];
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int row = half * 32 + p4 * 8 + (lane >> 3), piece = lane & 7;
+                prev[p4] = *(const gf4 *)(g.grad + (item * 64 + row) * 128 + slab * 32 + 4 * piece);
+            }
+            zero(acc[0]); zero(acc[1]);
+            rg.base = wm + W0T + ((int64_t)slab * 2 * NB1 + half * NB1) * (2 * FRAG) + lane * 8;
+#pragma unroll
+            for (int sl = 0; sl < D; ++sl) rg.load(sl, sl);
+            auto addr = [&](int k) { return X0 + fr * LD0 + (half * NB1 + k) * 16 + fk * 8; };
+            segment<2, 0, NB1, NB1, D, 0, false>(acc, rg, addr, ROWS * LD0, 32 * LD0, none);
+            v4f *xch = reinterpret_cast<v4f *>(X1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v4f t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = half ? acc[0][4 * q + e] : acc[1][4 * q + e];
+                xch[(wave * 4 + q) * 64 + lane] = t;
+            }
+            __syncthreads();
+            float *tile5 = reinterpret_cast<float *>(xch + (wave ^ 4) * 4 * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f t = xch[((wave ^ 4) * 4 + q) * 64 + lane];
+                v4f f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] = (half ? acc[1][4 * q + e] : acc[0][4 * q + e]) + t[e];
+                *reinterpret_cast<v4f *>(tile5 + fr * 32 + ((((2 * q + fk) ^ (fr >> 1)) & 7) << 2)) = f;
+            }
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int row = p4 * 8 + (lane >> 3), piece = lane & 7;
+                const v4f t = *reinterpret_cast<const v4f *>(tile5 + row * 32 + (((piece ^ (row >> 1)) & 7) << 2));
+                v4f v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(t[e], osc, prev[p4][e]);
+                *reinterpret_cast<v4f *>(g.grad + (item * 64 + half * 32 + row) * 128 + slab * 32 + 4 * piece) = v;
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0 && wave == 0) g.cyc[blockIdx.x] = __builtin_readcyclecounter() - t0;
+}
+
+template <class K>
+static void run(const char *name, K kern, int threads, Args a, int nwg)
+{
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    Args warm = a;
+    warm.items_per_wg = 8;
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(threads), LDS_BYTES, 0, warm);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(nwg), dim3(threads), LDS_BYTES, 0, a);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    hipError_t err = hipGetLastError();
+    std::vector<long long> cyc(nwg);
+    hipMemcpy(cyc.data(), a.cyc, nwg * sizeof(long long), hipMemcpyDeviceToHost);
+    double c = 0;
+    for (int i = 0; i < nwg; ++i) c += (double)cyc[i];
+    printf("%-44s %8.3f ms  %7.2f us/item  %8.0f ticks/item  = %5.2f GHz if a tick is a shader clock  (%s)\n", name, best,
+           1e3 * best / a.items_per_wg, c / nwg / a.items_per_wg, c / nwg / (best * 1e6), hipGetErrorString(err));
+}
+
+int main(int argc, char **argv)
+{
+    const int nwg = 256, items = argc > 1 ? atoi(argv[1]) : 128;
+    const int zero_data = argc > 2 ? atoi(argv[2]) : 0;
+    Args a;
+    a.zero_lds = 0;
+    std::vector<_Float16> hw((size_t)M * WMEM);
+    unsigned s = 12345u;
+    for (size_t i = 0; i < hw.size(); ++i) {
+        s = s * 1664525u + 1013904223u;
+        const bool lo = (i / FRAG) & 1;
+        const float u = ((s >> 9) & 0x7fff) * (1.0f / 16384.0f) - 1.0f;
+        hw[i] = (_Float16)(zero_data ? 0.f : lo ? u * 4.0f : u * 8192.0f);
+    }
+    std::vector<float> hc((size_t)M * 4 * 256);
+    for (size_t i = 0; i < hc.size(); ++i) {
+        s = s * 1664525u + 1013904223u;
+        hc[i] = (((s >> 9) & 0x7fff) * (1.0f / 16384.0f) - 1.0f) * 0.1f;
+    }
+    _Float16 *dw; float *dc, *dg, *de; long long *dcy;
+    hipMalloc(&dw, hw.size() * 2);
+    hipMalloc(&dc, hc.size() * 4);
+    const size_t n_items = (size_t)nwg * items;
+    hipMalloc(&dg, n_items * 64 * 128 * 4);
+    hipMalloc(&de, n_items * 64 * 4);
+    hipMalloc(&dcy, nwg * 8);
+    hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dc, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(dg, 0, n_items * 64 * 128 * 4);
+    a.w = dw; a.cols = dc; a.grad = dg; a.energy = de; a.items_per_wg = items; a.cyc = dcy;
+    a.zero_lds = zero_data;
+    printf("data: %s\n", zero_data ? "ZEROS (weights and layer-0 operand)" : "random");
+    printf("LDS %zu bytes per workgroup, %d items per workgroup, %d workgroups\n", LDS_BYTES, items, nwg);
+    run("SEQ8  (shipped structure, ring 6)", k_seq8<6>, 512, a, nwg);
+    run("PIPE4 interleaved, ring 4", k_pipe4<true, 4>, 256, a, nwg);
+    run("PIPE4 interleaved, ring 6", k_pipe4<true, 6>, 256, a, nwg);
+    run("PIPE4 epilogues behind their segments, ring 4", k_pipe4<false, 4>, 256, a, nwg);
+    return 0;
+}

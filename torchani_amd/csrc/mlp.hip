@@ -1501,7 +1501,7 @@ constexpr int64_t FUSED_L0B_MIN_ATOMS = 65536;   // layer-0 backward inside the 
 #endif
 constexpr int FUSED_OWNER_GROUP = ANIHIP_OWNER_GROUP;   // tiles a workgroup takes through the members together (owner order)
 constexpr int FRAG = 512;         // halves per fragment plane: 64 lanes x 8
-constexpr int FR_SLAB_LD = 40;    // halves per staged slab row (32 + 8: conflict-free ds_read_b128)
+constexpr int FR_SLAB_LD = 48;    // halves per staged slab row (32 + 16: conflict-free ds_read_b128 of 16-row fragments)
 constexpr int FR_GROUP = 3;       // slabs per staging slot
 
 template <int RB, int NB>
@@ -1510,17 +1510,17 @@ struct FusedCfg {
     static constexpr int THREADS = 64 * NW;
     static constexpr int ROWS = 32 * RB;            // atoms per workgroup (= THREADS / 8: one staging piece each)
     static constexpr int TPR = THREADS / ROWS;      // = 8
-    static constexpr int DEPTH = 6;                 // k steps of B fragments in flight per wave (even)
+    static constexpr int DEPTH = 2;                 // k2 steps (32 reduction indices) of weight fragments in flight per wave (even)
     // two workgroups per CU hide each other's latencies: per-column parameters are then fetched right where
     // they are used instead of ahead of the GEMM (32 registers less per array during the MFMA loops)
-    static constexpr bool LAZY = NB == 2;
     static constexpr int SLAB = 2 * ROWS * FR_SLAB_LD;            // halves per staged slab {hi plane, lo plane}
     // fixed part of the dynamic LDS: [0] tile max | energy partials [NW][ROWS] | staging slot 0
     // fixed part of the dynamic LDS: [0] tile max | per-species {tile-major base of d0, first sorted position} |
     // energy partials [NW][ROWS] | staging slot 0
     static constexpr int FIXED_BYTES = 16 + 128 + NW * ROWS * 4 + 2 * ROWS * 4;   // ... | atoms of the tile rows [2][ROWS]
     // slot 0 doubles as the home of a tile's KEPT layer-0 operand (owner order, tiles with <= 4 flagged slabs): four slabs,
-    // {hi, lo} planes, unpadded 64-byte rows whose 16-byte pieces are XOR-swizzled with (row >> 2) & 3
+    // {hi, lo} planes, unpadded 64-byte rows whose 16-byte pieces are XOR-swizzled with (-(row >> 2)) & 3 (conflict-free reads
+    // of the 16-row MFMA fragments and of the staging writes)
     static constexpr int KEEP_SLABS = 4, SLABU = 2 * ROWS * 32;
     static constexpr int SLOT0 = FR_GROUP * SLAB > KEEP_SLABS * SLABU ? FR_GROUP * SLAB : KEEP_SLABS * SLABU;
     static constexpr int FIXED_HALVES = FIXED_BYTES / 2 + SLOT0;
@@ -1602,167 +1602,209 @@ __device__ __forceinline__ float pow2_scale_for(float mx)
     return __uint_as_float((unsigned)(127 + 13 - e) << 23);
 }
 
-// Register ring of the B fragments {hi, lo} of NB column blocks, D k steps deep.  Loads are unconditional
-// (callers clamp the k step): a branch around a load makes hipcc drain the whole ring with
-// s_waitcnt vmcnt(0) at every join (CDNA guide, "load everything or hoist the condition").
-template <int NB, int D>
+// ---- GEMM machinery of the fused kernel: v_mfma_f32_16x16x32_f16 ----------------------------------------------------------
+// Round 6: the fused kernel multiplies on 16 x 16 x 32 MFMAs instead of 32 x 32 x 16.  Same flops per instruction-cycle, same
+// operand bytes, but the 32 x 32 x 16 form draws so much more power on real (non-zero mantissa) data that the kernel ran the
+// package at its power limit (rocm-smi: 1.33-1.37 kW) with the shader clock pulled down to ~0.8 of its maximum; a pure stream
+// of either instruction on random fp16 data sustains 1.29 PFLOP/s (32 x 32 x 16) against 1.87 PFLOP/s (16 x 16 x 32)
+// (tools/mfma_power.hip, profiles/r06_mfma_power.txt), and a faithful model of this kernel's item loop runs 23.2 -> 18.3 us
+// per item with nothing but the instruction exchanged (tools/pipe_model.hip, profiles/r06_pipeline_model.txt).
+//
+// Geometry.  A wave's unit is still a 32-column block x 32-row block; it is computed as four 16 x 16 tiles t = 2 ct + rt
+// (ct = column half, rt = row half).  The MFMA computes the TRANSPOSED tile (weights are its first operand): lane
+// (n16 = lane & 15, c4 = lane >> 4) holds tile row n16 and the four consecutive columns 4 c4 .. 4 c4 + 3, so accumulator
+// element r = 4 t + e of a unit is (row 16 rt + n16, column 16 ct + 4 c4 + e) -- runs of four columns, 8-byte LDS stores.
+// A k step covers 32 reduction indices ("k2 step" = two of the pack's 16-wide k steps); lane (x16, c4) of either operand
+// holds the indices 32 s + 8 c4 .. + 7.  The WEIGHT fragments are read from the pack's unchanged 32 x 16 fragment order
+// [N/32][K/16][plane][64 lanes][8 halves] with a different lane -> address map: lane (m, c4) of column half ct takes the
+// 16 bytes of old lane 16 ct + m + 32 (c4 & 1) of old k step 2 s + (c4 >> 1) -- four contiguous 256-byte pieces per load
+// instruction instead of one kilobyte, the same bytes in total.  The ACTIVATION planes are [row][k] with rows padded by 16
+// halves and the 16-byte chunks of every 64-byte group XOR-swizzled with (row >> 2) & 1: conflict-free ds_read_b128 for the
+// 16-row fragments of every hidden width (python brute force over the hardware's lane groups).
+constexpr int FR_XPAD = 16;       // halves of padding per activation-plane row
+
+typedef v4f Acc16[4];             // the four 16 x 16 tiles of a unit
+#define ACC(a, r) (a)[(r) >> 2][(r) & 3]
+
+// Register ring of the weight fragments {hi, lo} x {column half 0, 1} of one column block, D2 k2 steps deep.  Loads are
+// unconditional (callers clamp the step): a branch around a load makes hipcc drain the whole ring with s_waitcnt vmcnt(0)
+// at every join (CDNA guide, "load everything or hoist the condition").
+template <int D2>
 struct WRing {
-    h8 hi[D][NB], lo[D][NB];
-    const _Float16 *base;   // fragment (cb of block 0, ks = 0, plane 0) + lane * 8
-    int64_t nb_stride;      // halves between this wave's consecutive column blocks
-    template <int NBA>
-    __device__ __forceinline__ void load(int slot, int ks)   // (slot: compile-time after unrolling)
+    h8 hi[D2][2], lo[D2][2];
+    const _Float16 *base;   // fragment (cb, k2 step 0, plane 0) + this lane's offset (wring_lane_off)
+    __device__ __forceinline__ void load(int slot, int s2)   // (slot: compile-time after unrolling)
+    {
+        const _Float16 *p = base + (int64_t)s2 * (4 * FRAG);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            hi[slot][ct] = *(const gh8 *)(p + ct * 128);
+            lo[slot][ct] = *(const gh8 *)(p + ct * 128 + FRAG);
+        }
+    }
+};
+// halves from the start of a (column block, even k step) fragment pair to the 16 bytes lane (m, c4) of column half 0 needs
+__device__ __forceinline__ int wring_lane_off(int lane)
+{
+    const int m = lane & 15, c4 = lane >> 4;
+    return (c4 >> 1) * (2 * FRAG) + (m + 32 * (c4 & 1)) * 8;
+}
+
+// activation fragments {hi, lo} x {row half 0, 1} of one 32-row block for one k2 step
+struct AFrag {
+    h8 hi[2], lo[2];
+    // a = this lane's address in the hi plane for row half 0; + a_plane = lo plane; + rt_stride = row half 1
+    __device__ __forceinline__ void load(const _Float16 *a, int a_plane, int rt_stride)
     {
 #pragma unroll
-        for (int nb = 0; nb < NBA; ++nb) {
-            const _Float16 *p = base + nb * nb_stride + (int64_t)ks * (2 * FRAG);
-            hi[slot][nb] = *(const gh8 *)p;
-            lo[slot][nb] = *(const gh8 *)(p + FRAG);
+        for (int rt = 0; rt < 2; ++rt) {
+            hi[rt] = *reinterpret_cast<const h8 *>(a + rt * rt_stride);
+            lo[rt] = *reinterpret_cast<const h8 *>(a + rt * rt_stride + a_plane);
         }
     }
 };
 
-// one k step, three products, RB row blocks x NBA column blocks.  TR: the WEIGHT fragment is the MFMA's first
-// operand and the activation fragment its second, i.e. the wave accumulates the TRANSPOSED tile: lane (fr, fk)
-// ends up with tile row rb*32 + fr and the 16 output columns 8 q + 4 fk + e (q = r >> 2, e = r & 3) of each
-// block -- four runs of four consecutive columns, so the epilogues write 8-byte / 16-byte vectors.
-// a = hi-plane fragment address of this lane for row block 0; + a_plane = lo plane; + rb_stride = next row block
-template <int RB>
-struct AFrag {   // activation fragments {hi, lo} of RB row blocks for one k step
-    h8 hi[RB], lo[RB];
-    __device__ __forceinline__ void load(const _Float16 *a, int a_plane, int rb_stride)
-    {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            hi[rb] = *reinterpret_cast<const h8 *>(a + rb * rb_stride);
-            lo[rb] = *reinterpret_cast<const h8 *>(a + rb * rb_stride + a_plane);
-        }
-    }
-};
-
+// one k2 step of one row block, three products (twelve MFMAs; consecutive MFMAs write different tiles).
 // TWO: the product (weight lo) x (activation hi) is left out -- the weights of this GEMM count as rounded to fp16 (2^-12
 // relative): ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS, backward phases only, off by default
-template <int RB, int NB, int RBA, int NBA, int D, bool TWO = false>
-__device__ __forceinline__ void fr_mfma(f32x16 (&acc)[RB * NB], const WRing<NB, D> &rg, int slot, const AFrag<RBA> &x)
+// (leaving out (weight hi) x (x lo) instead -- the gradients rounded, not the weights -- measures the same: max |dF| 6.9e-6
+// against 5.0e-6 Ha/A on the headline sample)
+template <int D2, bool TWO = false>
+__device__ __forceinline__ void fr_mfma(Acc16 &acc, const WRing<D2> &rg, int slot, const AFrag &x)
 {
 #pragma unroll
-    for (int nb = 0; nb < NBA; ++nb)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int rb = 0; rb < RBA; ++rb)
-            acc[rb * NB + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[slot][nb], x.lo[rb], acc[rb * NB + nb], 0, 0, 0);
-    // (leaving out (weight hi) x (x lo) instead -- the gradients rounded, not the weights -- measures the same: max |dF| 6.9e-6
-    // against 5.0e-6 Ha/A on the headline sample, 25.0 against 25.4 ms)
+        for (int rt = 0; rt < 2; ++rt)
+            acc[2 * ct + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.hi[slot][ct], x.lo[rt], acc[2 * ct + rt], 0, 0, 0);
     if constexpr (!TWO) {
 #pragma unroll
-    for (int nb = 0; nb < NBA; ++nb)
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int rb = 0; rb < RBA; ++rb)
-            acc[rb * NB + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.lo[slot][nb], x.hi[rb], acc[rb * NB + nb], 0, 0, 0);
+            for (int rt = 0; rt < 2; ++rt)
+                acc[2 * ct + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.lo[slot][ct], x.hi[rt], acc[2 * ct + rt], 0, 0, 0);
     }
 #pragma unroll
-    for (int nb = 0; nb < NBA; ++nb)
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int rb = 0; rb < RBA; ++rb)
-            acc[rb * NB + nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(rg.hi[slot][nb], x.hi[rb], acc[rb * NB + nb], 0, 0, 0);
+        for (int rt = 0; rt < 2; ++rt)
+            acc[2 * ct + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.hi[slot][ct], x.hi[rt], acc[2 * ct + rt], 0, 0, 0);
 }
 
-// a = hi-plane fragment address of this lane for the wave's first row block; + a_plane = lo plane; + rb_stride = next
-// row block.  RBA x NBA = the part of the wave's RB x NB accumulators that is active in this phase
-template <int RB, int NB, int RBA, int NBA, int D>
-__device__ __forceinline__ void fr_step(f32x16 (&acc)[RB * NB], const WRing<NB, D> &rg, int slot,
-                                        const _Float16 *a, int a_plane, int rb_stride)
+// ring of column block cb of a [N/32][KS] fragment matrix of member m (KS = 16-wide k steps of the pack, even), the first D2
+// k2 steps in flight.  EVERY ring register is loaded on every path (a wave without a block: block 0) -- inside the item
+// loop of the fused kernel a ring that some path leaves undefined is carried around the loop and holds its registers through
+// the whole item
+template <int D2>
+__device__ __forceinline__ void fr_ring(WRing<D2> &r, const _Float16 *w, int64_t member_halves, int m, int KS, int cb,
+                                        int lane, int nblk)
 {
-    AFrag<RBA> x;
-    x.load(a, a_plane, rb_stride);
-    fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, slot, x);
-}
-
-// ring of this wave's column blocks cb, cb + NW, ... of a [N/32][KS] fragment matrix of member m, first D
-// steps in flight.  nblk = the number of blocks the wave really has: EVERY ring register is loaded on every path
-// (missing blocks: the first block again; none at all: block 0) -- inside the item loop of the fused kernel a
-// ring that some path leaves undefined is carried around the loop and holds its registers through the whole item
-template <int NB, int D>
-__device__ __forceinline__ void fr_ring(WRing<NB, D> &r, const _Float16 *w, int64_t member_halves, int m, int KS,
-                                        int cb, int nw, int lane, int nblk)
-{
-    r.nb_stride = nblk >= NB ? (int64_t)nw * KS * (2 * FRAG) : 0;
-    r.base = w + (int64_t)m * member_halves + (int64_t)(nblk > 0 ? cb : 0) * KS * (2 * FRAG) + lane * 8;
+    const int KS2 = KS >> 1;
+    r.base = w + (int64_t)m * member_halves + (int64_t)(nblk > 0 ? cb : 0) * KS * (2 * FRAG) + wring_lane_off(lane);
 #pragma unroll
-    for (int sl = 0; sl < D; ++sl) r.template load<NB>(sl, min(sl, KS - 1));
-    r.nb_stride = (int64_t)nw * KS * (2 * FRAG);
+    for (int sl = 0; sl < D2; ++sl) r.load(sl, min(sl, KS2 - 1));
 }
 
-// acc += X[rows, K] x B over all KS = K/16 k steps (KS even): whole groups of D steps without a branch, the
-// tail (an even number of steps <= D) issues no loads.  A group requests the D steps behind it, clamped to the last one:
-// the group loop stops as soon as the ring holds everything that is left (k0 + D >= KS), so a reduction length that is
-// a multiple of D (KS = 12, 6: half of the phases of the water networks) issues no repeated request at all -- each
-// repeat moves 2 KB per wave through the CU's 64 B/clk return path and queues ahead of whatever the next phase asks
-// for first.  xa = hi plane of X, ldx = row stride (halves)
-template <int RB, int NB, int RBA, int NBA, int D, bool TWO = false>
-__device__ __forceinline__ void fr_gemm(f32x16 (&acc)[RB * NB], const _Float16 *xa, int ldx, int x_plane,
-                                        WRing<NB, D> &rg, int KS, int lane)
-{    // the activation fragments of step k + 1 are read from LDS before the MFMAs of step k (two register sets)
-    const int fr = lane & 31, fk = lane >> 5;
-    const _Float16 *af = xa + fr * ldx + fk * 8;
-    const int rbs = 32 * ldx;
-    AFrag<RBA> xe, xo;
-    xe.load(af, x_plane, rbs);
+// acc += X[rows, K] x W over all KS2 = K / 32 k2 steps: whole groups of D2 steps without a branch, the tail (<= D2 steps, all
+// of them in the ring) issues no loads.  A group requests the D2 steps behind it, clamped to the last one; the group loop stops
+// as soon as the ring holds everything that is left.  xa = hi plane of X at the wave's first row block, ldx = row stride
+// (halves).  RBA = row blocks of the wave's unit (2, or 1).  The activation fragments of the next row block / k2 step are
+// read from LDS before the MFMAs of the current one (two register sets).
+template <int RBA, int D2, bool TWO = false>
+__device__ __forceinline__ void fr_gemm(Acc16 (&acc)[2], const _Float16 *xa, int ldx, int x_plane, WRing<D2> &rg, int KS2,
+                                        int lane)
+{
+    static_assert(D2 % 2 == 0, "the single-row-block form alternates two fragment sets over the ring's steps");
+    const int n16 = lane & 15, c4 = lane >> 4;
+    const _Float16 *af = xa + n16 * ldx + ((c4 ^ ((n16 >> 2) & 1)) << 3);
+    const int rts = 16 * ldx, rbs = 32 * ldx;
+    AFrag xe, xo;
+    xe.load(af, x_plane, rts);
     int k0 = 0;
-    for (; k0 + D < KS; k0 += D) {
+    if constexpr (RBA == 2) {
+        for (; k0 + D2 < KS2; k0 += D2) {
 #pragma unroll
-        for (int sl = 0; sl < D; sl += 2) {
-            xo.load(af + (k0 + sl + 1) * 16, x_plane, rbs);
-            fr_mfma<RB, NB, RBA, NBA, D, TWO>(acc, rg, sl, xe);
-            rg.template load<NBA>(sl, min(k0 + sl + D, KS - 1));
-            xe.load(af + min(k0 + sl + 2, KS - 1) * 16, x_plane, rbs);
-            fr_mfma<RB, NB, RBA, NBA, D, TWO>(acc, rg, sl + 1, xo);
-            rg.template load<NBA>(sl + 1, min(k0 + sl + 1 + D, KS - 1));
+            for (int sl = 0; sl < D2; ++sl) {
+                xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
+                fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
+                xe.load(af + (k0 + sl + 1) * 32, x_plane, rts);
+                fr_mfma<D2, TWO>(acc[1], rg, sl, xo);
+                rg.load(sl, min(k0 + sl + D2, KS2 - 1));
+            }
         }
-    }
-    const int rem = KS - k0;   // (<= D steps, all of them in the ring)
+        const int rem = KS2 - k0;   // (1 .. D2 steps, all of them in the ring)
 #pragma unroll
-    for (int sl = 0; sl < D; sl += 2) {
-        if (rem > sl) {
-            xo.load(af + (k0 + sl + 1) * 16, x_plane, rbs);
-            fr_mfma<RB, NB, RBA, NBA, D, TWO>(acc, rg, sl, xe);
-            xe.load(af + min(k0 + sl + 2, KS - 1) * 16, x_plane, rbs);
-            fr_mfma<RB, NB, RBA, NBA, D, TWO>(acc, rg, sl + 1, xo);
+        for (int sl = 0; sl < D2; ++sl) {
+            if (rem > sl) {
+                xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
+                fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
+                xe.load(af + min(k0 + sl + 1, KS2 - 1) * 32, x_plane, rts);
+                fr_mfma<D2, TWO>(acc[1], rg, sl, xo);
+            }
+        }
+    } else {
+        for (; k0 + D2 < KS2; k0 += D2) {
+#pragma unroll
+            for (int sl = 0; sl < D2; sl += 2) {
+                xo.load(af + (k0 + sl + 1) * 32, x_plane, rts);
+                fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
+                rg.load(sl, min(k0 + sl + D2, KS2 - 1));
+                xe.load(af + min(k0 + sl + 2, KS2 - 1) * 32, x_plane, rts);
+                fr_mfma<D2, TWO>(acc[0], rg, sl + 1, xo);
+                rg.load(sl + 1, min(k0 + sl + 1 + D2, KS2 - 1));
+            }
+        }
+        const int rem = KS2 - k0;
+#pragma unroll
+        for (int sl = 0; sl < D2; sl += 2) {
+            if (rem > sl) {
+                xo.load(af + min(k0 + sl + 1, KS2 - 1) * 32, x_plane, rts);
+                fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
+                if (rem > sl + 1) {
+                    xe.load(af + min(k0 + sl + 2, KS2 - 1) * 32, x_plane, rts);
+                    fr_mfma<D2, TWO>(acc[0], rg, sl + 1, xo);
+                }
+            }
         }
     }
 }
 
-// layer 0 of the fused kernel: the 12 k steps of one pair of staging slots (2 slots x 3 slabs x 2 steps; 12 % D == 0,
-// ring slot = step % D), A fragments of step k + 1 read from LDS before the MFMAs of step k like fr_gemm.  s0 / s1 =
-// this lane's fragment address in the two slots; the steps of the slabs past the tile's last flagged one (n_live of
-// the pair's 6 are live) have zero operands: no MFMAs, the ring request stays unconditional.
-// STEPS / REQS: the general form walks all 12 steps and requests a fragment behind every one of them (clamped repeats once
-// the tile's steps are used up); a tile with at most FOUR flagged slabs -- every tile of a water box -- has 8 steps, 6 of
-// them in the ring when the loop starts: the short form walks 8 steps and requests 2 (the repeats it leaves out were 20 KB
-// per wave and item through the CU's 64 B/clk return path)
-// KEPT: the operand is the tile's kept copy (FusedCfg::SLABU layout: unpadded rows, swizzled pieces) -- s0 / s1 = this
-// lane's fragment address for the even / odd k step of slab 0
-template <int RB, int NB, int RBA, int NBA, int D, int ROWS, int STEPS, int REQS, bool KEPT = false, class NextKs>
-__device__ __forceinline__ void fr_l0_pair(f32x16 (&acc)[RB * NB], WRing<NB, D> &rg, const _Float16 *s0,
-                                           const _Float16 *s1, int n_live, NextKs &&next_ks)
+// layer 0 of the fused kernel: the k2 steps of one pair of staging slots (2 slots x FR_GROUP slabs: a slab IS one k2 step; ring
+// slot = step % D2).  s0 / s1 = this lane's fragment address (row half 0 of the wave's first row block) in the two slots; the
+// steps of the slabs past the tile's last flagged one (n_live of the pair's 2 FR_GROUP are live) have zero operands: no
+// MFMAs, the ring request stays unconditional.
+// STEPS / REQS: the general form walks all 2 FR_GROUP steps and requests a fragment behind every one of them (clamped repeats
+// once the tile's slabs are used up); a tile with at most FOUR flagged slabs -- every tile of a water box -- has 4 steps, D2 of
+// them in the ring when the loop starts: the short form walks 4 steps and requests 4 - D2.
+// KEPT: the operand is the tile's kept copy (FusedCfg::SLABU layout: unpadded rows, swizzled chunks) -- s0 = this lane's
+// fragment address in slab 0
+template <int RBA, int D2, int ROWS, int STEPS, int REQS, bool KEPT = false, class NextS2>
+__device__ __forceinline__ void fr_l0_pair(Acc16 (&acc)[2], WRing<D2> &rg, const _Float16 *s0, const _Float16 *s1, int n_live,
+                                           NextS2 &&next_s2)
 {
-    static_assert(STEPS % 2 == 0 && STEPS <= 4 * FR_GROUP && REQS % 2 == 0 && REQS <= STEPS && STEPS <= D + REQS, "ring coverage");
+    static_assert(STEPS <= 2 * FR_GROUP && REQS <= STEPS && STEPS <= D2 + REQS, "ring coverage");
     constexpr int SLAB = KEPT ? 2 * ROWS * 32 : 2 * ROWS * FR_SLAB_LD, PL = KEPT ? ROWS * 32 : ROWS * FR_SLAB_LD,
-                  RBS = KEPT ? 32 * 32 : 32 * FR_SLAB_LD;
+                  RTS = KEPT ? 16 * 32 : 16 * FR_SLAB_LD, RBS = 2 * RTS;
     auto addr = [&](int st) {
-        if (KEPT) return ((st & 1) ? s1 : s0) + (st / 2) * SLAB;
-        return (st / (2 * FR_GROUP) ? s1 : s0) + ((st / 2) % FR_GROUP) * SLAB + (st & 1) * 16;
+        if (KEPT) return s0 + st * SLAB;
+        return (st / FR_GROUP ? s1 : s0) + (st % FR_GROUP) * SLAB;
     };
-    AFrag<RBA> xe, xo;
-    xe.load(addr(0), PL, RBS);
+    AFrag xe, xo;
+    xe.load(addr(0), PL, RTS);
 #pragma unroll
-    for (int st = 0; st < STEPS; st += 2) {
-        const bool live = st / 2 < n_live;
-        xo.load(addr(st + 1), PL, RBS);
-        if (live) fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, st % D, xe);
-        if (st < REQS) rg.template load<NBA>(st % D, next_ks());
-        if (st + 2 < STEPS) xe.load(addr(st + 2), PL, RBS);
-        if (live) fr_mfma<RB, NB, RBA, NBA, D>(acc, rg, (st + 1) % D, xo);
-        if (st < REQS) rg.template load<NBA>((st + 1) % D, next_ks());
+    for (int st = 0; st < STEPS; ++st) {
+        const bool live = st < n_live;
+        if constexpr (RBA == 2) {
+            xo.load(addr(st) + RBS, PL, RTS);
+            if (live) fr_mfma<D2>(acc[0], rg, st % D2, xe);
+            if (st + 1 < STEPS) xe.load(addr(st + 1), PL, RTS);
+            if (live) fr_mfma<D2>(acc[1], rg, st % D2, xo);
+        } else {
+            AFrag &xc = (st & 1) ? xo : xe, &xn = (st & 1) ? xe : xo;
+            if (st + 1 < STEPS) xn.load(addr(st + 1), PL, RTS);
+            if (live) fr_mfma<D2>(acc[0], rg, st % D2, xc);
+        }
+        if (st < REQS) rg.load(st % D2, next_s2());
     }
 }
 
@@ -2045,8 +2087,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     static_assert(!L0B || (RB == 2 && NB == 1), "phase 5 is written for 64-row tiles on 8 waves");
     static_assert(!TRAIN || (!L0B && ACT == 0 && NB == 1), "the training instantiation: CELU, d act0 to global memory");
     using C = FusedCfg<RB, NB>;
+    static_assert(NB == 1, "the 16 x 16 x 32 machinery is written for one column block per wave");
     constexpr int NW = C::NW, ROWS = C::ROWS, D = C::DEPTH, SLAB = C::SLAB, NE = RB * NB;
-    typedef WRing<NB, D> Ring;
+    typedef WRing<D> Ring;
     extern __shared__ __attribute__((aligned(16))) _Float16 fsm_all[];
     unsigned *s_tab = reinterpret_cast<unsigned *>(fsm_all);
     unsigned &s_max = s_tab[0];
@@ -2062,7 +2105,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     // (re-derived from an opaque copy of threadIdx.x at the head of every item: hoisted out of the item loop, the
     // per-lane addresses built from these cost more registers than the kernel has)
     int tid = threadIdx.x, lane = tid & 63;
-    int fr = lane & 31, fk = lane >> 5;
+    int n16 = lane & 15, c4 = lane >> 4;   // this lane in an MFMA tile: row n16, k chunk / column run c4
     // staging role of this thread: row srow, 16-B piece spc (4 of a slab's 32 columns)
     int srow = tid >> 3, spc = tid & 7;
     const int KS0 = g.n_slabs * 2;
@@ -2120,7 +2163,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 hi[e] = h;
                 lo[e] = (_Float16)__builtin_fmaf(v[j][e], 4.0f, -(float)h);
             }
-            _Float16 *d = slot0 + (base + j) * C::SLABU + srow * 32 + ((((spc >> 1) ^ (srow >> 2)) & 3) << 3) + (spc & 1) * 4;
+            _Float16 *d = slot0 + (base + j) * C::SLABU + srow * 32 + ((((spc >> 1) ^ (0 - (srow >> 2))) & 3) << 3) + (spc & 1) * 4;
             *reinterpret_cast<h4 *>(d) = hi;
             *reinterpret_cast<h4 *>(d + ROWS * 32) = lo;
         }
@@ -2157,17 +2200,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         mem = 0; tile = item; item = tile * g.M;
         gsz = min(g.owner, (n_tiles - 1 - tile) / (int)gridDim.x + 1);
     }
-    typedef WRing<NB, D> Ring0;
+    typedef Ring Ring0;
     Ring0 rg;                  // layer-0 weight ring of the item being started
-    uint32_t rem_w = 0u;       // k steps of the layer-0 weight ring not yet requested
+    uint32_t rem_w = 0u;       // slabs (= k2 steps) of the layer-0 weight ring not yet requested
     uint32_t tmask = 0u;
-    int w_odd = 0;
-    auto next_ks = [&]() {    // k step (in the slab order of W0) of the next ring request, clamped
+    auto next_s2 = [&]() {    // slab (= k2 step in the slab order of W0) of the next ring request, clamped to the last flagged one
         const int slab = rem_w ? (int)__builtin_ctz(rem_w) : (31 - (int)__builtin_clz(tmask | 1u));
-        const int ks = 2 * slab + (rem_w ? w_odd : 1);
-        if (w_odd) rem_w &= rem_w - 1u;
-        w_odd ^= 1;
-        return ks;
+        rem_w &= rem_w - 1u;
+        return slab;
     };
     v4f va[FR_GROUP], vb[FR_GROUP];
     // slabs 0..5 of an item -> registers (rem_a = the rest)
@@ -2192,16 +2232,13 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const FusedSpecies &fs = g.sp[s];
         tmask = (uint32_t)t.w;
         rem_w = tmask;
-        w_odd = 0;
-        // every ring register is written on every path (blocks this wave does not have: block 0 again), or the
-        // ring of the previous item would stay live through the whole item
+        // every ring register is written on every path (a wave without a block: block 0), or the ring of the previous item
+        // would stay live through the whole item
         const FusedUnit u = fused_unit<RB, NB>(fs.H1, wave);
-        const _Float16 *wm = fs.w0 + (int64_t)m * (fs.H1 >> 5) * KS0 * (2 * FRAG) + lane * 8;
-        rg.nb_stride = u.nba >= NB ? (int64_t)NW * KS0 * (2 * FRAG) : 0;
+        const _Float16 *wm = fs.w0 + (int64_t)m * (fs.H1 >> 5) * KS0 * (2 * FRAG) + wring_lane_off(lane);
         rg.base = wm + (int64_t)u.cb * KS0 * (2 * FRAG);
 #pragma unroll
-        for (int sl = 0; sl < D; ++sl) rg.template load<NB>(sl, next_ks());
-        rg.nb_stride = (int64_t)NW * KS0 * (2 * FRAG);
+        for (int sl = 0; sl < D; ++sl) rg.load(sl, next_s2());
     };
     int4 te = g.tile_tab[tile];
     int staged_tile = -1;   // the tile whose layer-0 operand slot 0 keeps (L0B, <= KEEP_SLABS flagged slabs), or -1
@@ -2214,7 +2251,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     }
     for (;;) {
         asm volatile("" : "+v"(tid));
-        lane = tid & 63; fr = lane & 31; fk = lane >> 5; srow = tid >> 3; spc = tid & 7;
+        lane = tid & 63; n16 = lane & 15; c4 = lane >> 4; srow = tid >> 3; spc = tid & 7;
         float alpha = g.alpha, inv_alpha = g.inv_alpha;   // (same reason: their vector copies and products)
         int Mi = g.M;
         asm volatile("" : "+s"(alpha), "+s"(inv_alpha), "+s"(Mi));
@@ -2255,27 +2292,33 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const int64_t tm_base = s_tmb[s];
         const int rel_tile = p0 - s_off[s];
         const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
-        // LDS carve (halves): X1 planes [2][ROWS][H2+8] | XU = max(X0 planes [2][ROWS][H1+8], X2 planes)
-        const int ld0 = H1 + 8, ld1 = H2 + 8, ld2 = H3 + 8;
+        // LDS carve (halves): X1 planes [2][ROWS][H2+16] | XU = max(X0 planes [2][ROWS][H1+16], X2 planes)
+        const int ld0 = H1 + FR_XPAD, ld1 = H2 + FR_XPAD, ld2 = H3 + FR_XPAD;
         const int x0_plane = ROWS * ld0, x1_plane = ROWS * ld1, x2_plane = ROWS * ld2;
         _Float16 *X1 = fsm;
         _Float16 *XU = fsm + 2 * ROWS * ld1;
         _Float16 *X0 = XU, *X2 = XU;
         // this wave's part of the phases producing H1 / H2 / H3 columns (fused_unit)
         const FusedUnit u1 = fused_unit<RB, NB>(H1, wave), u2 = fused_unit<RB, NB>(H2, wave), u3 = fused_unit<RB, NB>(H3, wave);
-        // accumulator element (rb, nb, r) of this lane <-> tile row (u.rb0 + rb)*32 + fr, column col0(u, nb) + 8 (r >> 2) + (r & 3)
-        auto col0 = [&](const FusedUnit &u, int nb) { return (u.cb + NW * nb) * 32 + 4 * fk; };
+        // accumulator element (rb, r = 4 q + e) of this lane, q = 2 ct + rt  <->  tile row urow(u, rb, q), column ucol(u, q) + e
+        auto urow = [&](const FusedUnit &u, int rb, int q) { return (u.rb0 + rb) * 32 + 16 * (q & 1) + n16; };
+        auto ucol = [&](const FusedUnit &u, int q) { return u.cb * 32 + 16 * (q >> 1) + 4 * c4; };
+        // where the run of four columns ucol(u, q) .. + 3 lies in a row of the activation planes (halves): the 16-byte chunks of
+        // every 64-byte group are XOR-swizzled with (row >> 2) & 1 (the same for both row halves: they are 16 rows apart)
+        auto xcol = [&](const FusedUnit &u, int q) {
+            return u.cb * 32 + (((2 * (q >> 1) + (c4 >> 1)) ^ ((n16 >> 2) & 1)) << 3) + (c4 & 1) * 4;
+        };
 #ifdef ANIHIP_DEV_TRACE
         unsigned long long *trace = g.trace ? g.trace + ((size_t)item * 8 + wave) * 32 : nullptr;
 #endif
         ANIHIP_STAMP(trace, 1);
 
-        f32x16 acc[NE];
+        Acc16 acc[NE];
         auto zero_acc = [&]() {
 #pragma unroll
             for (int i = 0; i < NE; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+                for (int r = 0; r < 16; ++r) ACC(acc[i], r) = 0.f;
         };
         auto tile_max = [&](float vmax) {  // workgroup max of a non-negative value (s_max was reset at the head of the item)
             vmax = wave_max_nonneg(vmax);
@@ -2283,51 +2326,53 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             __syncthreads();
             return __uint_as_float(s_max);
         };
-        // acc * scale -> split planes of X (row stride ldx): this lane's runs of 4 columns of its first nba blocks
+        // acc * scale -> split planes of X (row stride ldx): this lane's runs of 4 columns of its unit
         auto put_acc = [&](_Float16 *X, int plane, int ldx, float scale, const FusedUnit &u) {
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
+            for (int rb = 0; rb < RB; ++rb) {
+                if (rb >= u.nrb || u.nba < 1) continue;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    if (rb >= u.nrb || nb >= u.nba) continue;
+                for (int q = 0; q < 4; ++q) {
+                    h4 hi, lo;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        h4 hi, lo;
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            // hi = fp16(x * scale) for two elements at once (v_pk_mul_f32, v_cvt_pk_f16_f32),
-                            // lo = fp16(x * scale - hi) as one mixed-precision FMA each (the fp16 hi is an operand)
-                            typedef float v2f_ __attribute__((ext_vector_type(2)));
-                            typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
-                            const v2f_ x = v2f_{acc[rb * NB + nb][4 * q + e], acc[rb * NB + nb][4 * q + e + 1]};
-                            const h2_ h = __builtin_convertvector(x * scale, h2_);
-                            hi[e] = h[0];
-                            hi[e + 1] = h[1];
-                            // (written out: left to itself hipcc converts hi back to fp32 and packs again, 2 more
-                            // instructions per pair)
-                            h2_ l;
-                            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]"
-                                : "=v"(l) : "v"(x[0]), "v"(scale), "v"(h));
-                            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
-                                : "+v"(l) : "v"(x[1]), "v"(scale), "v"(h));
-                            lo[e] = l[0];
-                            lo[e + 1] = l[1];
-                        }
-                        _Float16 *d = X + ((u.rb0 + rb) * 32 + fr) * ldx + col0(u, nb) + 8 * q;
-                        *reinterpret_cast<h4 *>(d) = hi;
-                        *reinterpret_cast<h4 *>(d + plane) = lo;
+                    for (int e = 0; e < 4; e += 2) {
+                        // hi = fp16(x * scale) for two elements at once (v_pk_mul_f32, v_cvt_pk_f16_f32),
+                        // lo = fp16(x * scale - hi) as one mixed-precision FMA each (the fp16 hi is an operand)
+                        typedef float v2f_ __attribute__((ext_vector_type(2)));
+                        typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+                        const v2f_ x = v2f_{ACC(acc[rb], 4 * q + e), ACC(acc[rb], 4 * q + e + 1)};
+                        const h2_ h = __builtin_convertvector(x * scale, h2_);
+                        hi[e] = h[0];
+                        hi[e + 1] = h[1];
+                        // (written out: left to itself hipcc converts hi back to fp32 and packs again, 2 more
+                        // instructions per pair)
+                        h2_ l;
+                        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]"
+                            : "=v"(l) : "v"(x[0]), "v"(scale), "v"(h));
+                        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+                            : "+v"(l) : "v"(x[1]), "v"(scale), "v"(h));
+                        lo[e] = l[0];
+                        lo[e + 1] = l[1];
                     }
+                    _Float16 *d = X + urow(u, rb, q) * ldx + xcol(u, q);
+                    *reinterpret_cast<h4 *>(d) = hi;
+                    *reinterpret_cast<h4 *>(d + plane) = lo;
                 }
+            }
         };
         // 16 per-column parameters per block of this lane (bias / output weights), as float4 loads
-        auto load_cols = [&](const float *base, float (&v)[NB][16], const FusedUnit &u) {   // (missing blocks: block 0, unused)
+        // (v[nb][4 q + e] = the parameter of the column of accumulator element 4 q + e: the two row halves of a column half share
+        // their four columns, so these are two float4 loads and eight registers)
+        auto load_cols = [&](const float *base, float (&v)[NB][16], const FusedUnit &u) {   // (a wave without a block: block 0, unused)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const v4f t = *(const gf4 *)(base + (nb < u.nba ? col0(u, nb) : 4 * fk) + 8 * q);
+                for (int ct = 0; ct < 2; ++ct) {
+                    const v4f t = *(const gf4 *)(base + (nb < u.nba ? u.cb * 32 : 0) + 16 * ct + 4 * c4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[nb][4 * q + e] = t[e];
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[nb][4 * (2 * ct + rt) + e] = t[e];
                 }
         };
 
@@ -2338,14 +2383,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     if (rb >= u.nrb || nb >= u.nba) continue;
-                    const int row = (u.rb0 + rb) * 32 + fr;
-                    float *dst = base + (int64_t)(p0 + min(row, n_rows - 1)) * ld + (int64_t)m * H + col0(u, nb);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        v4f v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[rb * NB + nb][4 * q + e];
-                        if (row < n_rows) *reinterpret_cast<v4f *>(dst + 8 * q) = v;
+                        const int row = urow(u, rb, q);
+                        float *dst = base + (int64_t)(p0 + min(row, n_rows - 1)) * ld + (int64_t)m * H + ucol(u, q);
+                        if (row < n_rows) *reinterpret_cast<v4f *>(dst) = acc[rb * NB + nb][q];
                     }
                 }
         };
@@ -2391,17 +2433,17 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 fetch_group(vb);
             }
             if (u1.nrb > 0) {
-                const int lo_ = (u1.rb0 * 32 + fr) * FR_SLAB_LD + fk * 8;   // this lane's fragment inside a staged slab
+                const int lo_ = (u1.rb0 * 32 + n16) * FR_SLAB_LD + c4 * 8;   // this lane's fragment inside a staged slab
                 const _Float16 *s0 = slot(2 * (pr & 1)) + lo_, *s1 = slot(2 * (pr & 1) + 1) + lo_;
                 const int n_live = nact - 2 * FR_GROUP * pr;
-                if (keep) {   // (wave-uniform) the kept copy: this lane's pieces for the even / odd k step of a slab
-                    const int rowk = u1.rb0 * 32 + fr, sw = (rowk >> 2) & 3;
-                    const _Float16 *k0 = slot0 + rowk * 32 + ((fk ^ sw) << 3), *k1 = slot0 + rowk * 32 + (((2 + fk) ^ sw) << 3);
-                    FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS, 8, 2, true>(acc, rg, k0, k1, n_live, next_ks)))
+                if (keep) {   // (wave-uniform) the kept copy: this lane's chunk of a slab's rows
+                    const int rowk = u1.rb0 * 32 + n16, sw = (0 - (rowk >> 2)) & 3;
+                    const _Float16 *k0 = slot0 + rowk * 32 + ((c4 ^ sw) << 3);
+                    FR_UNIT(u1, (fr_l0_pair<RBA, D, ROWS, 4, 4 - D, true>(acc, rg, k0, k0, n_live, next_s2)))
                 } else if (nact <= 4) {   // (wave-uniform)
-                    FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS, 8, 2>(acc, rg, s0, s1, n_live, next_ks)))
+                    FR_UNIT(u1, (fr_l0_pair<RBA, D, ROWS, 4, 4 - D>(acc, rg, s0, s1, n_live, next_s2)))
                 } else {
-                    FR_UNIT(u1, (fr_l0_pair<RB, NB, RBA, NBA, D, ROWS, 4 * FR_GROUP, 4 * FR_GROUP>(acc, rg, s0, s1, n_live, next_ks)))
+                    FR_UNIT(u1, (fr_l0_pair<RBA, D, ROWS, 2 * FR_GROUP, 2 * FR_GROUP>(acc, rg, s0, s1, n_live, next_s2)))
                 }
             }
             if (pr + 1 < npair) {   // (the last pair's successors are zeros nobody reads)
@@ -2413,7 +2455,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         ANIHIP_STAMP(trace, 3);
         // weights of phase 1 start streaming during the layer-0 epilogue
         Ring r1;
-        fr_ring<NB, D>(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, u2.cb, NW, lane, u2.nba);
+        fr_ring<D>(r1, fs.w1, (int64_t)(H2 >> 5) * (H1 >> 4) * 2 * FRAG, m, H1 >> 4, u2.cb, lane, u2.nba);
         // celu and its derivative from one exponential: x > 0: (x, 1), else (alpha (e - 1), e), e = exp(x / alpha)
         const float ia_log2e = inv_alpha * 1.44269504f;
         // two elements at a time: bias + scale, the exponent argument and alpha (e - 1) as packed fp32 operations
@@ -2460,10 +2502,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                         for (int r = 0; r < 16; r += 2) {
                             const int i = rb * NB + nb;
                             float v0, v1;
-                            celu_d2(acc[i][r], acc[i][r + 1], oscale, bias0[nb][r], bias0[nb][r + 1], v0, v1, d0f[i][r],
+                            celu_d2(ACC(acc[i], r), ACC(acc[i], r + 1), oscale, bias0[nb][r], bias0[nb][r + 1], v0, v1, d0f[i][r],
                                     d0f[i][r + 1]);
-                            acc[i][r] = v0;
-                            acc[i][r + 1] = v1;
+                            ACC(acc[i], r) = v0;
+                            ACC(acc[i], r + 1) = v1;
                             if (NB == 1 || nb < u1.nba) vmax = __builtin_fmaxf(vmax, __builtin_fmaxf(v0, v1));
                         }
                 } else {   // (defined on every path, like the rings)
@@ -2491,15 +2533,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 
         // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
         float bias1[NB][16];   // (per-column parameters travel during the GEMM)
-        if (!C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, u2);
+        load_cols(fs.b1 + (int64_t)m * H2, bias1, u2);
         zero_acc();
-        FR_UNIT(u2, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X0 + u2.rb0 * 32 * ld0, ld0, x0_plane, r1, H1 >> 4, lane)))
+        FR_UNIT(u2, (fr_gemm<RBA, D>(acc, X0 + u2.rb0 * 32 * ld0, ld0, x0_plane, r1, H1 >> 5, lane)))
         ANIHIP_STAMP(trace, 5);
         Ring r2;
-        fr_ring<NB, D>(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, u3.cb, NW, lane, u3.nba);
+        fr_ring<D>(r2, fs.w2, (int64_t)(H3 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, u3.cb, lane, u3.nba);
         float d1f[NE][16];   // celu'(act1) of this lane's elements
         {
-            if (C::LAZY) load_cols(fs.b1 + (int64_t)m * H2, bias1, u2);
             const float oscale = fs.is1 / s0;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -2509,11 +2550,11 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                         for (int r = 0; r < 16; r += 2) {
                             const int i = rb * NB + nb;
-                            float dl0, dl1, y0, y1;
-                            celu_d2(acc[i][r], acc[i][r + 1], oscale, bias1[nb][r], bias1[nb][r + 1], y0, y1,
-                                    C::LAZY ? dl0 : d1f[i][r], C::LAZY ? dl1 : d1f[i][r + 1]);
-                            acc[i][r] = y0;
-                            acc[i][r + 1] = y1;
+                            float y0, y1;
+                            celu_d2(ACC(acc[i], r), ACC(acc[i], r + 1), oscale, bias1[nb][r], bias1[nb][r + 1], y0, y1, d1f[i][r],
+                                    d1f[i][r + 1]);
+                            ACC(acc[i], r) = y0;
+                            ACC(acc[i], r + 1) = y1;
                         }
                 } else {   // (defined on every path, like the rings)
 #pragma unroll
@@ -2533,52 +2574,51 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // =============== phase 2: act2 = celu(act1 x W2^T + b2); output layer; backward seed ===============
         float bias2[NB][16], w3[NB][16];
         // (fetching these behind the GEMM as well frees 32 registers and the last two spills, and is 0.4 % SLOWER: measured)
-        if (!C::LAZY) {
-            load_cols(fs.b2 + (int64_t)m * H3, bias2, u3);
-            load_cols(fs.w3 + (int64_t)m * H3, w3, u3);
-        }
+        load_cols(fs.b2 + (int64_t)m * H3, bias2, u3);
+        load_cols(fs.w3 + (int64_t)m * H3, w3, u3);
         zero_acc();
-        FR_UNIT(u3, (fr_gemm<RB, NB, RBA, NBA, D>(acc, X1 + u3.rb0 * 32 * ld1, ld1, x1_plane, r2, H2 >> 4, lane)))
+        FR_UNIT(u3, (fr_gemm<RBA, D>(acc, X1 + u3.rb0 * 32 * ld1, ld1, x1_plane, r2, H2 >> 5, lane)))
         ANIHIP_STAMP(trace, 7);
         Ring r3;   // (also without want_grad: see fr_ring)
-        fr_ring<NB, D>(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, u2.cb, NW, lane, u2.nba);
+        fr_ring<D>(r3, fs.w2t, (int64_t)(H2 >> 5) * (H3 >> 4) * 2 * FRAG, m, H3 >> 4, u2.cb, lane, u2.nba);
         {
-            // e = sum_col act2 * w3 (+ b3): per-lane partial over its columns, the two k halves of a row
-            // combined with a lane swap, the waves through LDS in a fixed order (deterministic sum).
+            // e = sum_col act2 * w3 (+ b3): per-lane partial over its columns of each of its two rows of a row block, the four
+            // lanes of a row (c4 = 0..3) combined with two lane swaps, the waves through LDS in a fixed order (deterministic sum).
             // seed: d act2 = w3 * celu'(act2) / M, kept in the accumulators
-            if (C::LAZY) {
-                load_cols(fs.b2 + (int64_t)m * H3, bias2, u3);
-                load_cols(fs.w3 + (int64_t)m * H3, w3, u3);
-            }
             const float osc2 = fs.is2 / s1;
             const float invM = 1.0f / (float)Mi;
-            float e_loc[RB];
+            float e_loc[RB];   // [row block]: lanes with c4 = rt hold the sum of row half rt
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                float e = 0.f;
+                float e[2] = {0.f, 0.f};
                 if (rb < u3.nrb) {
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                         for (int r = 0; r < 16; r += 2) {
-                            const int i = rb * NB + nb;
+                            const int i = rb * NB + nb, rt = (r >> 2) & 1;
                             float y0, y1, dy0, dy1;
-                            celu_d2(acc[i][r], acc[i][r + 1], osc2, bias2[nb][r], bias2[nb][r + 1], y0, y1, dy0, dy1);
-                            // (NB = 1: a wave inside this loop owns its one column block; the select is for the 2-block tiling)
-                            e = __builtin_fmaf((NB == 1 || nb < u3.nba) ? y0 : 0.f, w3[nb][r], e);
-                            e = __builtin_fmaf((NB == 1 || nb < u3.nba) ? y1 : 0.f, w3[nb][r + 1], e);
-                            acc[i][r] = invM * w3[nb][r] * dy0;
-                            acc[i][r + 1] = invM * w3[nb][r + 1] * dy1;
+                            celu_d2(ACC(acc[i], r), ACC(acc[i], r + 1), osc2, bias2[nb][r], bias2[nb][r + 1], y0, y1, dy0, dy1);
+                            e[rt] = __builtin_fmaf(y0, w3[nb][r], e[rt]);
+                            e[rt] = __builtin_fmaf(y1, w3[nb][r + 1], e[rt]);
+                            ACC(acc[i], r) = invM * w3[nb][r] * dy0;
+                            ACC(acc[i], r + 1) = invM * w3[nb][r + 1] * dy1;
                             if constexpr (TRAIN) {   // act2 leaves from here (the accumulators take the backward seed)
-                                const int row = (u3.rb0 + rb) * 32 + fr;
+                                const int row = urow(u3, rb, r >> 2);
                                 float *dst = g.tr_act[2] + (int64_t)(p0 + min(row, n_rows - 1)) * g.tr_ld[2] + (int64_t)m * H3 +
-                                             col0(u3, nb) + 8 * (r >> 2) + (r & 3);
+                                             ucol(u3, r >> 2) + (r & 3);
                                 if (row < n_rows) *reinterpret_cast<float2 *>(dst) = make_float2(y0, y1);
                             }
                         }
-                    e += __shfl_xor(e, 32);
+                    // the four lanes of a row (c4 = 0..3, sixteen lanes apart) through two permlane swaps on the VALU (no
+                    // LDS round trips): the 16-lane rows of s are [e0.c0 + e0.c1, e1.c0 + e1.c1, e0.c2 + e0.c3, e1.c2 + e1.c3],
+                    // then rows [e0 total, e1 total, e0 total, e1 total]
+                    auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(e[0]), __float_as_uint(e[1]), false, false);
+                    const float s = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+                    auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+                    e[0] = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
                 }
-                e_loc[rb] = e;
+                e_loc[rb] = e[0];
             }
             // every wave writes its partial of every row of the tile (zero for the row blocks it has no unit in)
 #pragma unroll
@@ -2587,7 +2627,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
                     if (t - u3.rb0 == rb && rb < u3.nrb) v = e_loc[rb];
-                if (fk == 0) s_e[wave * ROWS + t * 32 + fr] = v;
+                if (c4 < 2) s_e[wave * ROWS + t * 32 + 16 * c4 + n16] = v;   // (lanes 0..31: row 16 c4 + n16 = lane)
             }
             if constexpr (TRAIN) store_rows(g.tr_dlt[2], g.tr_ld[2], H3, u3);
             ANIHIP_STAMP(trace, 28);
@@ -2607,43 +2647,20 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         if (g.want_grad) {
             // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
             zero_acc();
-            FR_UNIT(u2, (fr_gemm<RB, NB, RBA, NBA, D, B2>(acc, X2 + u2.rb0 * 32 * ld2, ld2, x2_plane, r3, H3 >> 4, lane)))
+            FR_UNIT(u2, (fr_gemm<RBA, D, B2>(acc, X2 + u2.rb0 * 32 * ld2, ld2, x2_plane, r3, H3 >> 5, lane)))
             ANIHIP_STAMP(trace, 10);
         }
-        fr_ring<NB, D>(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, u1.cb, NW, lane, u1.nba);
+        fr_ring<D>(r4, fs.w1t, (int64_t)(H1 >> 5) * (H2 >> 4) * 2 * FRAG, m, H2 >> 4, u1.cb, lane, u1.nba);
         if (g.want_grad) {
             if (u2.nrb > 0) {
                 const float osc3 = fs.is2 / s2;
-                if constexpr (!C::LAZY) {
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) {
-                        if (rb >= u2.nrb) continue;
+                for (int rb = 0; rb < RB; ++rb) {
+                    if (rb >= u2.nrb) continue;
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[rb * NB + nb][r] *= osc3 * d1f[rb * NB + nb][r];
-                    }
-                } else {
-                    // celu'(act1) from act1 itself, which this lane still finds at its own positions of X1
-                    // (celu' = 1 for y > 0, else y / alpha + 1), before d act1 overwrites it
-                    const float inv_s1 = 1.0f / s1;
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            if (rb >= u2.nrb || nb >= u2.nba) continue;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const _Float16 *d = X1 + ((u2.rb0 + rb) * 32 + fr) * ld1 + col0(u2, nb) + 8 * q;
-                                const h4 yh = *reinterpret_cast<const h4 *>(d);
-                                const h4 yl = *reinterpret_cast<const h4 *>(d + x1_plane);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float y = ((float)yh[e] + (float)yl[e]) * inv_s1;
-                                    acc[rb * NB + nb][4 * q + e] *= osc3 * (y > 0.f ? 1.0f : __builtin_fmaf(y, inv_alpha, 1.0f));
-                                }
-                            }
-                        }
+                        for (int r = 0; r < 16; ++r) ACC(acc[rb * NB + nb], r) *= osc3 * d1f[rb * NB + nb][r];
                 }
                 if constexpr (TRAIN) store_rows(g.tr_dlt[1], g.tr_ld[1], H2, u2);
                 ANIHIP_STAMP(trace, 30);
@@ -2662,7 +2679,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global, or -> LDS for phase 5 ===============
         if (g.want_grad && u1.nrb > 0) {
             zero_acc();
-            FR_UNIT(u1, (fr_gemm<RB, NB, RBA, NBA, D, B2>(acc, X1 + u1.rb0 * 32 * ld1, ld1, x1_plane, r4, H2 >> 4, lane)))
+            FR_UNIT(u1, (fr_gemm<RBA, D, B2>(acc, X1 + u1.rb0 * 32 * ld1, ld1, x1_plane, r4, H2 >> 5, lane)))
         }
         ANIHIP_STAMP(trace, 12);
         if constexpr (L0B) {
@@ -2692,11 +2709,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 return mk ? (int)__builtin_ctz(mk) : -1;
             };
             Ring r5;
-            auto ring5 = [&](int sl_) {   // the first D fragments of this wave's k range of slab sl_
-                r5.nb_stride = 0;
-                r5.base = fs.w0t + (int64_t)m * mh5 + ((int64_t)sl_ * KS5 + kbeg) * (2 * FRAG) + lane * 8;
+            auto ring5 = [&](int sl_) {   // the first D k2 steps of this wave's k range of slab sl_
+                r5.base = fs.w0t + (int64_t)m * mh5 + ((int64_t)sl_ * KS5 + kbeg) * (2 * FRAG) + wring_lane_off(lane);
 #pragma unroll
-                for (int sl = 0; sl < D; ++sl) r5.template load<NB>(sl, min(sl, KH - 1));
+                for (int sl = 0; sl < D; ++sl) r5.load(sl, min(sl, (KH >> 1) - 1));
             };
             int slab = nth_slab(wave & 3);
             ring5(max(slab, 0));   // (travels during the epilogue below; requested behind it instead: no faster, measured)
@@ -2706,7 +2722,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
                 for (int i = 0; i < NE; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][r] *= osc4 * d0f[i][r];
+                    for (int r = 0; r < 16; ++r) ACC(acc[i], r) *= osc4 * d0f[i][r];
                 put_acc(X0, x0_plane, ld0, s4, u1);
             }
             ANIHIP_STAMP(trace, 17);
@@ -2756,7 +2772,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     }
                     zero_acc();
                     ANIHIP_STAMP(trace, 19);
-                    if (live) fr_gemm<RB, NB, RB, 1, D, B2>(acc, X0 + kbeg * 16, ld0, x0_plane, r5, KH, lane);
+                    if (live) fr_gemm<RB, D, B2>(acc, X0 + kbeg * 16, ld0, x0_plane, r5, KH >> 1, lane);
                     ANIHIP_STAMP(trace, 20);
                     const int slab_n = nth_slab(c0 + 4 + (wave & 3));
                     if constexpr (LAST) {
@@ -2774,7 +2790,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     for (int q = 0; q < 4; ++q) {
                         v4f t;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = half ? acc[0][4 * q + e] : acc[1][4 * q + e];
+                        for (int e = 0; e < 4; ++e) t[e] = half ? ACC(acc[0], 4 * q + e) : ACC(acc[1], 4 * q + e);
                         xch[(wave * 4 + q) * 64 + lane] = t;
                     }
                     __syncthreads();
@@ -2784,11 +2800,12 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     for (int q = 0; q < 4; ++q) {
                         const v4f t = xch[((wave ^ 4) * 4 + q) * 64 + lane];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) fin[q][e] = (half ? acc[1][4 * q + e] : acc[0][4 * q + e]) + t[e];
+                        for (int e = 0; e < 4; ++e) fin[q][e] = (half ? ACC(acc[1], 4 * q + e) : ACC(acc[0], 4 * q + e)) + t[e];
                     }
                     // (wave-private from here on: the LDS serves a wave's accesses in order)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<v4f *>(t5(fr, 2 * q + fk)) = fin[q];   // (row fr, columns 8 q + 4 fk ..)
+                    for (int q = 0; q < 4; ++q)   // (row 16 rt + n16, columns 16 ct + 4 c4 .. of the slab: q = 2 ct + rt)
+                        *reinterpret_cast<v4f *>(t5(16 * (q & 1) + n16, 4 * (q >> 1) + c4)) = fin[q];
 #pragma unroll
                     for (int p4 = 0; p4 < 4; ++p4) {
                         const v4f t = *reinterpret_cast<const v4f *>(t5(p4 * 8 + (lane >> 3), piece));
@@ -2828,25 +2845,25 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 if (rb >= u1.nrb) continue;
-                const int row = (u1.rb0 + rb) * 32 + fr;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     if (nb >= u1.nba) continue;
-                    float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + col0(u1, nb);
-                    int s1 = 8, s2 = 16;   // run q of this lane's 4 runs of 4 columns lies (q & 1) s1 + (q >> 1) s2 floats on
-                    if (g.d0_tm) {
-                        // fragment order (tm_unit): run q = k step q >> 1, lane slot (q & 1) * 32 + row, floats 4 fk ..
-                        dst = g.d0 + tm_base + (int64_t)(((rel_tile >> 6) * Mi + m) * 64) * H1 +
-                              tm_unit(u1.cb + NW * nb, ((rel_tile >> 5) & 1) + u1.rb0 + rb, 0) + fr * 8 + 4 * fk;
-                        s1 = 256; s2 = 512;   // (q & 1): the other 32 lane slots of the unit; (q >> 1): the next unit
-                    }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 4; ++q) {   // run q = 2 ct + rt: tile row 16 rt + n16 of the row block, columns 16 ct + 4 c4 ..
+                        const int row = urow(u1, rb, q);
+                        float *dst = g.d0 + (int64_t)(p0 + min(row, n_rows - 1)) * g.ld0 + (int64_t)m * H1 + ucol(u1, q);
+                        if (g.d0_tm) {
+                            // fragment order of the 32 x 16 A operand the layer-0 backward GEMMs read (tm_unit): column half ct = its
+                            // k step, lane slot (columns 8 ..: 32 +) row of the block, floats (c4 & 1) * 4 ..
+                            dst = g.d0 + tm_base + (int64_t)(((rel_tile >> 6) * Mi + m) * 64) * H1 +
+                                  tm_unit(u1.cb, ((rel_tile >> 5) & 1) + u1.rb0 + rb, q >> 1) +
+                                  ((c4 >> 1) * 32 + 16 * (q & 1) + n16) * 8 + 4 * (c4 & 1);
+                        }
                         v4f v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            v[e] = acc[rb * NB + nb][4 * q + e] * osc4 * d0f[rb * NB + nb][4 * q + e];
-                        if (row < n_rows) *reinterpret_cast<v4f *>(dst + (q & 1) * s1 + (q >> 1) * s2) = v;
+                            v[e] = ACC(acc[rb * NB + nb], 4 * q + e) * osc4 * d0f[rb * NB + nb][4 * q + e];
+                        if (row < n_rows) *reinterpret_cast<v4f *>(dst) = v;
                     }
                 }
             }
@@ -3745,7 +3762,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             fs.b0 = nn.bias[0]; fs.b1 = nn.bias[1]; fs.b2 = nn.bias[2]; fs.w3 = nn.w[3]; fs.b3 = nn.bias[3];
             fs.bounds = nn.fused_bounds;
             const size_t xu = fs.H1 > fs.H3 ? fs.H1 : fs.H3;
-            size_t halves = 2 * (size_t)rows * (fs.H2 + 8) + 2 * (size_t)rows * (xu + 8);
+            size_t halves = 2 * (size_t)rows * (fs.H2 + FR_XPAD) + 2 * (size_t)rows * (xu + FR_XPAD);
             const size_t slab = 2 * (size_t)rows * FR_SLAB_LD;
             if (halves < 3 * FR_GROUP * slab) halves = 3 * FR_GROUP * slab;   // staging slots 1..3
             halves += FusedCfg<2, 1>::FIXED_HALVES;
@@ -4023,7 +4040,7 @@ static int train_forward_fused(hipStream_t stream, const anihip_mlp_desc *d, int
         fs.b0 = nn.bias[0]; fs.b1 = nn.bias[1]; fs.b2 = nn.bias[2]; fs.w3 = nn.w[3]; fs.b3 = nn.bias[3];
         fs.bounds = nn.fused_bounds;
         const size_t xu = fs.H1 > fs.H3 ? fs.H1 : fs.H3;
-        size_t halves = 2 * (size_t)rows * (fs.H2 + 8) + 2 * (size_t)rows * (xu + 8);
+        size_t halves = 2 * (size_t)rows * (fs.H2 + FR_XPAD) + 2 * (size_t)rows * (xu + FR_XPAD);
         const size_t slab = 2 * (size_t)rows * FR_SLAB_LD;
         if (halves < 3 * FR_GROUP * slab) halves = 3 * FR_GROUP * slab;
         halves += FusedCfg<2, 1>::FIXED_HALVES;
