@@ -1629,6 +1629,14 @@ typedef v4f Acc16[4];             // the four 16 x 16 tiles of a unit
 // Register ring of the weight fragments {hi, lo} x {column half 0, 1} of one column block, D2 k2 steps deep.  Loads are
 // unconditional (callers clamp the step): a branch around a load makes hipcc drain the whole ring with s_waitcnt vmcnt(0)
 // at every join (CDNA guide, "load everything or hoist the condition").
+#ifndef ANIHIP_FR_FENCE
+#define ANIHIP_FR_FENCE 1
+#endif
+#if ANIHIP_FR_FENCE
+#define FR_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FR_FENCE() do { } while (0)
+#endif
 template <int D2>
 struct WRing {
     h8 hi[D2][2], lo[D2][2];
@@ -1725,11 +1733,17 @@ __device__ __forceinline__ void fr_gemm(Acc16 (&acc)[2], const _Float16 *xa, int
         for (; k0 + D2 < KS2; k0 += D2) {
 #pragma unroll
             for (int sl = 0; sl < D2; ++sl) {
+                // (the scheduler sinks the fragment reads to their first use and waits for each of them between the MFMAs:
+                // fences keep the reads of the NEXT half step ahead of the twelve MFMAs of this one)
                 xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
+                FR_FENCE();
                 fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
+                FR_FENCE();
                 xe.load(af + (k0 + sl + 1) * 32, x_plane, rts);
+                FR_FENCE();
                 fr_mfma<D2, TWO>(acc[1], rg, sl, xo);
                 rg.load(sl, min(k0 + sl + D2, KS2 - 1));
+                FR_FENCE();
             }
         }
         const int rem = KS2 - k0;   // (1 .. D2 steps, all of them in the ring)
@@ -1737,9 +1751,13 @@ __device__ __forceinline__ void fr_gemm(Acc16 (&acc)[2], const _Float16 *xa, int
         for (int sl = 0; sl < D2; ++sl) {
             if (rem > sl) {
                 xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
+                FR_FENCE();
                 fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
+                FR_FENCE();
                 xe.load(af + min(k0 + sl + 1, KS2 - 1) * 32, x_plane, rts);
+                FR_FENCE();
                 fr_mfma<D2, TWO>(acc[1], rg, sl, xo);
+                FR_FENCE();
             }
         }
     } else {
@@ -1747,11 +1765,15 @@ __device__ __forceinline__ void fr_gemm(Acc16 (&acc)[2], const _Float16 *xa, int
 #pragma unroll
             for (int sl = 0; sl < D2; sl += 2) {
                 xo.load(af + (k0 + sl + 1) * 32, x_plane, rts);
+                FR_FENCE();
                 fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
                 rg.load(sl, min(k0 + sl + D2, KS2 - 1));
+                FR_FENCE();
                 xe.load(af + min(k0 + sl + 2, KS2 - 1) * 32, x_plane, rts);
+                FR_FENCE();
                 fr_mfma<D2, TWO>(acc[0], rg, sl + 1, xo);
                 rg.load(sl + 1, min(k0 + sl + 1 + D2, KS2 - 1));
+                FR_FENCE();
             }
         }
         const int rem = KS2 - k0;
@@ -1765,6 +1787,72 @@ __device__ __forceinline__ void fr_gemm(Acc16 (&acc)[2], const _Float16 *xa, int
                     fr_mfma<D2, TWO>(acc[0], rg, sl + 1, xo);
                 }
             }
+        }
+    }
+}
+
+// The same for ONE 16-column half of a column block and all 64 rows (phase 5: eight halves of four slabs on eight waves): ring
+// of {hi, lo} of the one column half, four tiles t = 2 rb + rt.  base already points at the column half (+ ct * 128).
+template <int D2>
+struct WRingHalf {
+    h8 hi[D2], lo[D2];
+    const _Float16 *base;
+    __device__ __forceinline__ void load(int slot, int s2)
+    {
+        const _Float16 *p = base + (int64_t)s2 * (4 * FRAG);
+        hi[slot] = *(const gh8 *)p;
+        lo[slot] = *(const gh8 *)(p + FRAG);
+    }
+};
+template <int D2, bool TWO = false>
+__device__ __forceinline__ void fr_gemm_half(v4f (&acc)[4], const _Float16 *xa, int ldx, int x_plane, WRingHalf<D2> &rg, int KS2,
+                                             int lane)
+{
+    const int n16 = lane & 15, c4 = lane >> 4;
+    const _Float16 *af = xa + n16 * ldx + ((c4 ^ ((n16 >> 2) & 1)) << 3);
+    const int rts = 16 * ldx, rbs = 32 * ldx;
+    AFrag xe, xo;
+    auto mm = [&](int rb, int slot, const AFrag &x) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+            acc[2 * rb + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.hi[slot], x.lo[rt], acc[2 * rb + rt], 0, 0, 0);
+        if constexpr (!TWO) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+                acc[2 * rb + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.lo[slot], x.hi[rt], acc[2 * rb + rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+            acc[2 * rb + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.hi[slot], x.hi[rt], acc[2 * rb + rt], 0, 0, 0);
+    };
+    xe.load(af, x_plane, rts);
+    int k0 = 0;
+    for (; k0 + D2 < KS2; k0 += D2) {
+#pragma unroll
+        for (int sl = 0; sl < D2; ++sl) {
+            xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
+            FR_FENCE();
+            mm(0, sl, xe);
+            FR_FENCE();
+            xe.load(af + (k0 + sl + 1) * 32, x_plane, rts);
+            FR_FENCE();
+            mm(1, sl, xo);
+            rg.load(sl, min(k0 + sl + D2, KS2 - 1));
+            FR_FENCE();
+        }
+    }
+    const int rem = KS2 - k0;   // (1 .. D2 steps, all of them in the ring)
+#pragma unroll
+    for (int sl = 0; sl < D2; ++sl) {
+        if (rem > sl) {
+            xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
+            FR_FENCE();
+            mm(0, sl, xe);
+            FR_FENCE();
+            xe.load(af + min(k0 + sl + 1, KS2 - 1) * 32, x_plane, rts);
+            FR_FENCE();
+            mm(1, sl, xo);
+            FR_FENCE();
         }
     }
 }
@@ -2178,6 +2266,10 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     const int n_items = n_tiles * g.M;
     int item = blockIdx.x;
     if (item >= (g.owner ? n_tiles : n_items)) return;
+#ifdef ANIHIP_YOUNG_PRIO
+    // the second-dispatched half of the workgroup loses the issue arbitration of its SIMD on every segment: static priority
+    if ((wave >= 4) == (ANIHIP_YOUNG_PRIO == 1)) __builtin_amdgcn_s_setprio(1);
+#endif
     // per-species constants of the items: looked up from LDS at the head of an item instead of scalar-load chains
     if (threadIdx.x < MAX_S) {
         const int t_ = threadIdx.x;
@@ -2691,30 +2783,29 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             // over the members is a plain read-add-write of the same lane on the same address, member after member in
             // a fixed order: no atomics, no d act0 round trip through HBM, no separate GEMM launch.
             const float s4 = pow2_scale_for(fs.bounds[8 * m + 4] * (ACT == 1 ? 1.13f : 1.0f));   // |d act0| <= [4] max act'
-            // Work of a pass: FOUR flagged slabs x both row blocks x K, dealt so that every SIMD's two waves (w, w + 4) share a
-            // slab: wave w takes the FIRST half of the k steps, wave w + 4 the second, each for both row blocks (every weight
-            // fragment crosses the CU's 64 B/clk L2 port once and feeds six MFMAs).  The two partial tiles meet in LDS (X1's
-            // place, dead since phase 4): a wave hands over the row block it does not own and finishes the other --
-            // w: rows 0..31, w + 4: rows 32..63 -- with the read-add-write on the AEV gradient rows.
-            // (one of the two gets 6 steps when there are 12 or more -- a ring's depth, so that wave issues no repeated request;
-            // it is wave w + 4, which the SIMD's arbiter lets through the phases before this one ~1.5 k clocks behind wave w:
-            // the shorter share evens the two out at the hand-over)
-            const int KS5 = H1 >> 4, KH1 = KS5 >= 12 ? 6 : KS5 - ((KS5 >> 2) << 1);
-            const int half = wave >> 2;
-            const int kbeg = half ? KS5 - KH1 : 0, KH = half ? KH1 : KS5 - KH1;   // (both even)
+            // Work of a pass: FOUR flagged slabs x both row blocks x K = eight 16-column halves, one per wave: wave w takes column
+            // half w & 1 of the pass's slab w >> 1 for all 64 rows and the whole of K -- four 16 x 16 tiles per wave, every weight
+            // fragment {hi, lo} of its column half crosses the CU's 64 B/clk L2 port once and feeds twelve MFMAs.  (Rounds 4-5 split
+            // K between the two waves of a SIMD because a 32 x 32 x 16 unit cannot be narrower than 32 columns; the partial tiles met
+            // in LDS behind a barrier and left through a wave-private LDS tile: a hand-over, a barrier and two LDS round trips per
+            // item that the 16-column units do not need.)  A lane ends up with row 16 t + n16 of the tile and the 16 bytes at
+            // columns 4 c4 .. of its column half, t = 0..3: a store instruction covers 16 rows x 64 contiguous bytes, half a cache
+            // line per row, and the wave of the other column half writes the other half of the same lines.
+            const int KS5 = H1 >> 4;
             const int64_t mh5 = (int64_t)g.n_slabs * KS5 * (2 * FRAG);
             auto nth_slab = [&](int c) {   // c-th flagged slab of the tile (scalar), -1 past the end
                 uint32_t mk = tmask_cur;
                 for (int t = 0; t < c; ++t) mk &= mk - 1u;
                 return mk ? (int)__builtin_ctz(mk) : -1;
             };
-            Ring r5;
-            auto ring5 = [&](int sl_) {   // the first D k2 steps of this wave's k range of slab sl_
-                r5.base = fs.w0t + (int64_t)m * mh5 + ((int64_t)sl_ * KS5 + kbeg) * (2 * FRAG) + wring_lane_off(lane);
+            const int ct5 = wave & 1;
+            WRingHalf<D> r5;
+            auto ring5 = [&](int sl_) {   // the first D k2 steps of slab sl_, this wave's column half
+                r5.base = fs.w0t + (int64_t)m * mh5 + (int64_t)sl_ * KS5 * (2 * FRAG) + wring_lane_off(lane) + ct5 * 128;
 #pragma unroll
-                for (int sl = 0; sl < D; ++sl) r5.load(sl, min(sl, (KH >> 1) - 1));
+                for (int sl = 0; sl < D; ++sl) r5.load(sl, min(sl, (KS5 >> 1) - 1));
             };
-            int slab = nth_slab(wave & 3);
+            int slab = nth_slab(wave >> 1);
             ring5(max(slab, 0));   // (travels during the epilogue below; requested behind it instead: no faster, measured)
             ANIHIP_STAMP(trace, 16);
             if (g.want_grad && u1.nrb > 0) {
@@ -2730,27 +2821,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             ANIHIP_STAMP(trace, 13);
             if (g.want_grad) {
                 const float osc5 = fs.is0 / s4;
-                // The finished 32 x 32 tile of a wave (row block `half` of its slab) leaves through a second, wave-private LDS
-                // tile so that a store instruction covers 8 rows x 128 contiguous bytes -- whole cache lines -- instead of the
-                // MFMA layout's 32 rows x 32 bytes (1.1 ms per step at the headline size went into those partial-line
-                // stores): lane -> row 8 p + (lane >> 3), 16-byte piece lane & 7, p = 0..3.
-                const int piece = lane & 7;
                 float *orow[4];
                 bool rok[4];
 #pragma unroll
-                for (int p4 = 0; p4 < 4; ++p4) {
-                    const int row = half * 32 + p4 * 8 + (lane >> 3);
-                    orow[p4] = g.grad_aev + (int64_t)s_orow[par * ROWS + row] * g.L + 4 * piece;
-                    rok[p4] = row < n_rows;    // (short tiles repeat their last atom: one writer per row only)
+                for (int t = 0; t < 4; ++t) {
+                    const int row = 16 * t + n16;
+                    orow[t] = g.grad_aev + (int64_t)s_orow[par * ROWS + row] * g.L + 16 * ct5 + 4 * c4;
+                    rok[t] = row < n_rows;    // (short tiles repeat their last atom: one writer per row only)
                 }
-                v4f *xch = reinterpret_cast<v4f *>(X1);   // [wave][q][lane]: partial sums handed to the partner wave (X1's place:
-                                                          // 32 KB, dead since phase 4; slot 0 keeps the tile's layer-0 operand)
-                // this wave's finished tile, 32 rows x 32 floats: in the PARTNER's hand-over block, which only this wave reads
-                // (d act0 in XU must stay whole for the further passes of tiles with more than four flagged slabs); the
-                // 16-byte pieces of a row are XOR-swizzled with row >> 1, conflict-free for the MFMA-layout writes and the
-                // row-major reads alike
-                float *tile5 = reinterpret_cast<float *>(xch + (wave ^ 4) * 4 * 64);
-                auto t5 = [&](int row, int pc) { return tile5 + row * 32 + (((pc ^ (row >> 1)) & 7) << 2); };
                 // (the last pass -- the only one of a water tile -- is peeled: what it prefetches for the next item must not be
                 // defined under a condition inside a loop, or it is carried around the loop in registers)
                 auto pass = [&](int c0, auto last_) {
@@ -2759,25 +2837,28 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     const int sl = max(slab, 0);
                     const int col5 = g.kp_rad ? kp_col(g.kp_rad, sl) : 32 * sl;
                     const int nv5 = g.kp_rad ? kp_valid(g.kp_rad, sl) : min(32, (int)g.L - 32 * sl);
+                    const bool cok = live && 16 * ct5 + 4 * c4 < nv5;
                     // what the members before this one left in the rows (this wave wrote it: L2 hits), requested ahead of the
                     // MFMA loop
                     v4f prev[4];
 #pragma unroll
-                    for (int p4 = 0; p4 < 4; ++p4) {
+                    for (int t = 0; t < 4; ++t) {
                         // (lanes with nothing to read -- the first member, waves without a slab -- read a line that is hot in
                         // L2: loads return in order, and a miss to HBM here would hold up the weight ring's requests behind it)
-                        const bool ok = live && rok[p4] && m > 0 && 4 * piece < nv5;
-                        prev[p4] = *(const gf4 *)(ok ? orow[p4] + col5 : fs.bounds);
-                        if (!ok) prev[p4] = v4f{0.f, 0.f, 0.f, 0.f};
+                        const bool ok = cok && rok[t] && m > 0;
+                        prev[t] = *(const gf4 *)(ok ? orow[t] + col5 : fs.bounds);
+                        if (!ok) prev[t] = v4f{0.f, 0.f, 0.f, 0.f};
                     }
-                    zero_acc();
+                    v4f acc5[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc5[t] = v4f{0.f, 0.f, 0.f, 0.f};
                     ANIHIP_STAMP(trace, 19);
-                    if (live) fr_gemm<RB, D, B2>(acc, X0 + kbeg * 16, ld0, x0_plane, r5, KH >> 1, lane);
+                    if (live) fr_gemm_half<D, B2>(acc5, X0, ld0, x0_plane, r5, KS5 >> 1, lane);
                     ANIHIP_STAMP(trace, 20);
-                    const int slab_n = nth_slab(c0 + 4 + (wave & 3));
+                    const int slab_n = nth_slab(c0 + 4 + (wave >> 1));
                     if constexpr (LAST) {
                         // the next item's AEV slabs: behind the last ring request of this item (loads return in order: a
-                        // miss to HBM ahead of a ring request would stall the MFMA loop), ahead of the hand-over and the stores
+                        // miss to HBM ahead of a ring request would stall the MFMA loop), ahead of the stores
                         // (not when the next item is another member of this tile and the tile's operand is kept in LDS)
                         prefetch_w0(te_n, mem_n);   // (the next item's first layer-0 weight fragments: L2 hits)
                         if (!(tile_n == tile && keep)) prefetch_aev(te_n, atom_n);
@@ -2785,36 +2866,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     } else {
                         ring5(max(slab_n, 0));
                     }
-                    // hand the other row block's partial sums to the partner wave, take this one's
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v4f t;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = half ? ACC(acc[0], 4 * q + e) : ACC(acc[1], 4 * q + e);
-                        xch[(wave * 4 + q) * 64 + lane] = t;
-                    }
-                    __syncthreads();
                     ANIHIP_STAMP(trace, 21);
-                    v4f fin[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const v4f t = xch[((wave ^ 4) * 4 + q) * 64 + lane];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) fin[q][e] = (half ? ACC(acc[1], 4 * q + e) : ACC(acc[0], 4 * q + e)) + t[e];
-                    }
-                    // (wave-private from here on: the LDS serves a wave's accesses in order)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)   // (row 16 rt + n16, columns 16 ct + 4 c4 .. of the slab: q = 2 ct + rt)
-                        *reinterpret_cast<v4f *>(t5(16 * (q & 1) + n16, 4 * (q >> 1) + c4)) = fin[q];
-#pragma unroll
-                    for (int p4 = 0; p4 < 4; ++p4) {
-                        const v4f t = *reinterpret_cast<const v4f *>(t5(p4 * 8 + (lane >> 3), piece));
+                    for (int t = 0; t < 4; ++t) {
                         v4f v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(t[e], osc5, prev[p4][e]);
-                        if (live && rok[p4] && 4 * piece < nv5) *reinterpret_cast<v4f *>(orow[p4] + col5) = v;
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc5[t][e], osc5, prev[t][e]);
+                        if (cok && rok[t]) *reinterpret_cast<v4f *>(orow[t] + col5) = v;
                     }
-                    if constexpr (!LAST) __syncthreads();   // (the hand-over buffer and the tiles are written again in the next pass)
                     slab = slab_n;
                 };
                 int c0 = 0;
@@ -2829,8 +2888,8 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             if (spc == 0) s_orow[(par ^ 1) * ROWS + srow] = atom_n;
             // every wave is done with the LDS of this item: the next one may stage its slabs -- unless it stages nothing (another
             // member of this tile, operand kept): its first LDS writes are the act0 planes behind its own layer-0 loop and
-            // tile-maximum barrier, and what this item still reads (the hand-over blocks in X1's place) is not touched before
-            // the next phase-1 epilogue
+            // tile-maximum barrier, which no wave passes before every wave has left this item's phase-5 k loop (the last reader
+            // of the d act0 planes)
             if (!(tile_n == tile && keep)) __syncthreads();
             }
         } else {
