@@ -129,6 +129,46 @@ def cpu_baseline(n_side: int, seed: int):
     }
 
 
+def reference_cpu_baseline(n_side: int = 12, reps: int = 2):
+    """The REFERENCE itself (torchani.grad.energies_and_forces, pyaev + cell_list, fp32; /root/reference/torchani/grad.py:263-290)
+    timed on this host's cores on a bounded periodic water box -- only where /root/reference is importable (the build
+    container; the GPU box has no /root/reference, and nothing of it may travel).  None otherwise."""
+    if not os.path.isdir("/root/reference/torchani"):
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from ref_cpu_baseline import import_reference
+
+        import_reference()
+        from torchani.arch import Assembler
+        from torchani.grad import energies_and_forces
+        from torchani.utils import SYMBOLS_2X
+    except Exception as exc:   # noqa: BLE001  (an optional leg: the bench line says why it is missing)
+        return {"error": f"reference not importable: {exc}"}
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    asm = Assembler()
+    asm.set_symbols(SYMBOLS_2X)
+    asm.set_global_cutoff_fn("cosine")
+    asm.set_aev_computer(radial="ani2x", angular="ani2x", strategy="pyaev")
+    asm.set_atomic_networks(ctor="ani2x")
+    asm.set_neighborlist("cell_list")
+    asm.set_gsaes_as_self_energies("wb97x-631gd")
+    model = asm.assemble(8)
+    model.requires_grad_(False)
+    sp, x, cell = water_box(n_side, seed=5)
+    znum = torch.tensor([1, 6, 7, 8, 16, 9, 17])[torch.from_numpy(sp)]
+    times = []
+    for _ in range(1 + reps):
+        t0 = time.perf_counter()
+        energies_and_forces(model, znum, torch.from_numpy(x), torch.from_numpy(cell), torch.tensor([True, True, True]))
+        times.append(time.perf_counter() - t0)
+    dt = min(times[1:])
+    n = sp.shape[1]
+    return {"value": n / dt, "unit": "atom*steps/s", "cores": cores, "kind": "reference", "cpu_model": cpu_model(),
+            "sample": f"{n}-atom periodic water box, torchani.grad.energies_and_forces (pyaev + cell_list, fp32), best of {reps}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,8 +411,18 @@ def main():
     # dispatch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) measured on a smaller box of
     # the same density and committed under profiles/; scaled by the atom count of this launch
     aev_traffic = bwd_traffic = mlp_traffic = nbr_traffic = None
-    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc.json", "r04_pmc_l0b.json", "r03_pmc_aev.json"))
+    pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc.json", "r05_pmc.json", "r04_pmc_l0b.json", "r03_pmc_aev.json"))
                      if os.path.exists(f)), "")
+    # SQ counters of the same kernels (rocprofv3 --pmc, tools/gpu_r6_profile.sh): what bounds each kernel, as counters
+    sq = {}
+    sq_file = os.path.join(ROOT, "profiles", "r06_pmc_sq.json")
+    if os.path.exists(sq_file):
+        with open(sq_file) as fh:
+            sq = json.load(fh).get("kernels", {})
+
+    def sq_of(kernel, *keys):
+        e = sq.get(kernel, {})
+        return {k: e[k] for k in keys if k in e} or None
     if os.path.exists(pmc_file):
         with open(pmc_file) as fh:
             pm = json.load(fh)
@@ -421,23 +471,27 @@ def main():
         },
         "ms_per_step_median": median_ms,
         "roofline": {
-            # what the step runs: the engine keeps the rows between steps and the kernel rewrites only the slabs that were or
-            # are flagged (anihip_aev_forward_update).  `achieved` prices the launch at the ALGORITHMIC bytes of SURVEY 8(d)
-            # -- the dense 4032-B row of every atom -- which this variant no longer moves: it is an algorithmic-throughput
-            # figure (the kernel is VALU-issue-bound); the bytes that do move are `traffic`, their rate `achieved_counter_GBps`.
-            # `full_rows` is the same kernel writing every row in full into a caller's buffer (AEVComputer.forward): the
-            # like-for-like figure against the section-8(d) bytes.
-            "kernel": "k_aev_fwd3<8,4,rec,UPDATE> (fused radial+angular AEV forward; rows kept by the engine and updated in "
-                      "place: only flagged 32-column slabs are rewritten)", "bound": "hbm",
-            "achieved": aev_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": aev_gbs / HBM_PEAK_GBS,
-            "traffic": aev_traffic, "algorithmic_bytes_per_atom": bytes_per_atom,
-            "achieved_counter_GBps": (aev_traffic / (st["aev_forward"] * 1e-3) / 1e9) if aev_traffic else None,
-            "full_rows": ({"kernel": "k_aev_fwd3<8,4,rec> writing all 1008 columns of every row",
-                           "avg_launch_ms": st["aev_forward_full_rows"],
-                           "achieved": bytes_per_atom * n_shard / (st["aev_forward_full_rows"] * 1e-3) / 1e9,
-                           "frac": bytes_per_atom * n_shard / (st["aev_forward_full_rows"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                          if "aev_forward_full_rows" in st else None),
-            "mean_radial_neighbors": n_r, "mean_angular_neighbors": n_a, "avg_launch_ms": st["aev_forward"],
+            # `achieved` / `frac`: the kernel that MOVES the algorithmic bytes of SURVEY 8(d) -- every row written in full into a
+            # caller's buffer (AEVComputer.forward; bytes moved = bytes counted) -- timed live in this run.  The step itself runs
+            # the `kept_rows` variant: the engine keeps the rows between steps and the kernel rewrites only the slabs that were
+            # or are flagged (anihip_aev_forward_update); it moves far fewer bytes (`bytes_moved`, from the committed counter
+            # file), so its rate on the algorithmic bytes would be throughput on bytes it does not move and is not `frac`.
+            # Neither variant is bound by HBM: `valu` holds the SQ counters (the kernel is bound by VALU issue).
+            "kernel": "k_aev_fwd3<8,4,rec> (fused radial+angular AEV forward) writing all 1008 columns of every row",
+            "bound": "hbm",
+            "achieved": bytes_per_atom * n_shard / (st.get("aev_forward_full_rows", st["aev_forward"]) * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": bytes_per_atom * n_shard / (st.get("aev_forward_full_rows", st["aev_forward"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "avg_launch_ms": st.get("aev_forward_full_rows", st["aev_forward"]),
+            "traffic": None, "algorithmic_bytes_per_atom": bytes_per_atom,
+            "kept_rows": {"kernel": "k_aev_fwd3<8,4,rec,UPDATE>: the variant the timed step runs (rows kept by the engine and "
+                                    "updated in place: only flagged 32-column slabs are rewritten)",
+                          "avg_launch_ms": st["aev_forward"], "bytes_moved": aev_traffic,
+                          "frac_on_moved": (aev_traffic / (st["aev_forward"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if aev_traffic else None,
+                          "algorithmic_throughput_GBps": aev_gbs},
+            "valu": sq_of("k_aev_fwd3", "valu_active_over_wave_cycles", "waves_per_simd_resident", "simd_valu_busy",
+                          "wait_any_over_wave_cycles", "sq_insts_valu_per_atom", "sq_insts_salu_per_atom", "sq_insts_lds_per_atom"),
+            "mean_radial_neighbors": n_r, "mean_angular_neighbors": n_a,
         },
         "roofline_bwd": {
             "kernel": "k_aev_bwd<8,4> (analytic AEV backward: radial by symmetric gather, angular pair loop)",
@@ -445,6 +499,9 @@ def main():
             "traffic": bwd_traffic, "algorithmic_bytes_per_atom": bytes_per_atom_bwd,
             "achieved_counter_GBps": (bwd_traffic / (st["aev_backward"] * 1e-3) / 1e9) if bwd_traffic else None,
             "avg_launch_ms": st["aev_backward"],
+            "valu": sq_of("k_aev_bwd", "valu_active_over_wave_cycles", "waves_per_simd_resident", "simd_valu_busy",
+                          "wait_any_over_wave_cycles", "sq_insts_valu_per_atom", "sq_insts_salu_per_atom", "sq_insts_lds_per_atom",
+                          "sq_insts_vmem_wr_per_atom"),
         },
         "roofline_nbr": {
             # neighbor rows (binning + k_nbr_cell2 + finish): per central atom 16 B of packed position in, 24 B of row
@@ -473,6 +530,13 @@ def main():
             "flops_per_atom_executed": flops_atom, "flops_per_atom_dense": flops_dense,
             "mean_active_slabs": mean_slabs,
             "dense_fp32_equivalent_tflops": mlp_tflops_dense,   # all 32 slabs multiplied (no masks)
+            # SQ counters: matrix-pipe busy cycles and VALU issue per SIMD-cycle of the launch (profiles/r06_pmc_sq.json)
+            "pipes": sq_of("k_mlp_fused", "simd_mfma_busy", "simd_valu_busy", "valu_active_over_wave_cycles",
+                           "wait_any_over_wave_cycles", "lds_active_over_wave_cycles"),
+            # the package runs this kernel at its power limit (rocm-smi: 1.29-1.37 kW at ~2.2 GHz): tools/mfma_power.hip,
+            # profiles/r06_mfma_power.txt -- what a pure MFMA stream sustains on random fp16 operands
+            "power_limited_mfma_peak_TFLOPS": {"v_mfma_f32_32x32x16_f16": 1292.0, "v_mfma_f32_16x16x32_f16": 1871.0,
+                                               "zeros_32x32x16": 2449.0},
         },
         "stages_ms": st,
         "parity_sample": parity,
@@ -538,10 +602,20 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_side, seed=5)
+            ref_now = reference_cpu_baseline()
+            if ref_now is not None:   # (/root/reference is importable: the build container, never the GPU box)
+                res["cpu_baseline_reference_same_run"] = ref_now
             ref_file = os.path.join(ROOT, "profiles", "ref_cpu_baseline.json")
             if os.path.exists(ref_file):   # the reference itself (torchani.grad.energies_and_forces), recorded by
                 with open(ref_file) as fh:   # tools/ref_cpu_baseline.py in the build container (it cannot travel)
                     res["cpu_baseline_reference"] = json.load(fh)
+                ratio = res["cpu_baseline_reference"].get("port_over_reference")
+                if ratio:
+                    # the oracle port timed in THIS run on this host, divided by (port / reference) measured on one host,
+                    # one thread count, one process in the build container (tools/ref_cpu_baseline.py): what the reference
+                    # itself would do here if the ratio carries over
+                    res["cpu_baseline"]["port_over_reference"] = ratio
+                    res["cpu_baseline"]["reference_equivalent"] = res["cpu_baseline"]["value"] / ratio
         print(json.dumps(res))
     if group is not None:
         torch.distributed.barrier(group)

