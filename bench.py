@@ -129,6 +129,27 @@ def cpu_baseline(n_side: int, seed: int):
     }
 
 
+def rccl_transport_detail():
+    """What RCCL's INFO log of THIS process says about its channels: {"P2P/IPC": n, "SHM": n, "NET/...": n, ...} from the
+    "a[x] -> b[y] via <transport>" lines (NCCL_DEBUG_FILE set by main() for N > 1), or None if there is no log."""
+    pat = os.environ.get("NCCL_DEBUG_FILE")
+    if not pat:
+        return None
+    path = pat.replace("%p", str(os.getpid())).replace("%h", socket.gethostname())
+    if not os.path.exists(path):
+        return None
+    counts = {}
+    try:
+        with open(path, errors="replace") as fh:
+            for ln in fh:
+                if " via " in ln and "->" in ln:
+                    t = ln.rsplit(" via ", 1)[1].split()[0].strip()
+                    counts[t] = counts.get(t, 0) + 1
+    except OSError:
+        return None
+    return counts or {"log": "no channel lines"}
+
+
 def reference_cpu_baseline(n_side: int = 12, reps: int = 2):
     """The REFERENCE itself (torchani.grad.energies_and_forces, pyaev + cell_list, fp32; /root/reference/torchani/grad.py:263-290)
     timed on this host's cores on a bounded periodic water box -- only where /root/reference is importable (the build
@@ -189,6 +210,9 @@ def main():
     ap.add_argument("--emulate-shard", default=None, metavar="RANK/WORLD",
                     help="development aid (N=1 only): time what rank RANK of WORLD does in a step, without "
                          "the collective -- prints ms/step and exits")
+    ap.add_argument("--emulate-collective-bytes", action="store_true",
+                    help="with --emulate-shard: also time the pack / unpack of the step's all-to-all with the real byte plan "
+                         "of that rank (no wire: the only term a real N > 1 run adds is bytes / link rate)")
     ap.add_argument("--emulate-option-c", action="store_true",
                     help="with --emulate-shard: cost SURVEY 8(e) option C instead -- a REDUNDANT halo of twice the reach, the "
                          "rank evaluates its owned atoms AND the halo atoms within one reach of them, so every force on an owned "
@@ -215,6 +239,13 @@ def main():
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: RCCL between processes needs it on this driver)
         sys.exit(subprocess.call(cmd, env=env))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and args.dist_backend in (None, "nccl"):
+        # which transport RCCL picks between the ranks (P2P/IPC over xGMI, SHM, NET/Socket) is in its INFO log only: every rank
+        # writes its own file, parsed into collective.ranks_seen[*].rccl_transports after the timed loop (set before RCCL
+        # initialises; a caller's own NCCL_DEBUG settings win)
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,P2P")
+        os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/anihip_rccl_{os.getpid()}_%p.log")
 
     from torchani_amd import _lib
     from torchani_amd.models import ANI2x
@@ -303,6 +334,18 @@ def main():
         gc = torch.zeros((nl, 3), dtype=torch.float32, device=dev)
         st["aev_backward"] = time_stage(lambda: eng.backward(sp_l, nbrs, gaev, gc, shard_rows=True, slab_mask=mask), 3)
         st["scatter results"] = time_stage(lambda: (part.scatter_local(gc), part.scatter_owned(ae)), 3)
+        if args.emulate_collective_bytes:
+            # the step's ONE all-to-all with the real byte plan of this rank, without the wire: pack (gather of the halo rows
+            # by owner + the tail) and unpack (index_add of the received rows, sum of the W tails) are timed; what a real run
+            # adds is bytes / link rate
+            from torchani_amd.parallel import EMULATE_WIRE
+
+            tail = torch.zeros(10, dtype=torch.float64, device=dev)   # energy + nine virial words
+            st["exchange pack+unpack (no wire)"] = time_stage(lambda: part.exchange(gc, tail, EMULATE_WIRE), 5)
+            sent = {int(o): 12 * int(c) for o, c in enumerate(part.send_counts) if c and o != r}
+            recv = {int(h): 12 * int(c) for h, c in enumerate(part.recv_counts) if c and h != r}
+            print(f"  exchange byte plan of rank {r}/{wd}: force rows sent {sent} B, received {recv} B, tail 80 B to each of "
+                  f"{wd - 1} ranks; bytes per step {part.last_bytes}")
         print("  stages ms: " + "  ".join(f"{k} {v:.3f}" for k, v in st.items()))
         per_step = sum(v for k, v in st.items() if not k.startswith("partition"))
         print(f"  sum of the per-step stages: {per_step:.3f} ms")
@@ -550,8 +593,18 @@ def main():
         res["stages_ms_per_rank"] = per_rank
         seen = [None] * world
         props = torch.cuda.get_device_properties(dev)
+        # first contact with a multi-GPU node: can this rank's device reach the devices of its two slab neighbours directly
+        # (hipDeviceCanAccessPeer), and what did RCCL choose per channel
+        peer_access = {}
+        for pr_ in part.peers:
+            pl = pr_ if args.dist_backend != "gloo" else 0   # (one rank per GPU: local rank = rank on one node)
+            try:
+                peer_access[int(pr_)] = bool(pl == dev.index or torch.cuda.can_device_access_peer(dev.index, pl))
+            except Exception as exc:   # noqa: BLE001
+                peer_access[int(pr_)] = f"error: {exc}"
         torch.distributed.all_gather_object(seen, {
             "rank": rank, "local_rank": local, "device": f"cuda:{dev.index}", "name": props.name, "pid": os.getpid(),
+            "peer_access": peer_access, "rccl_transports": rccl_transport_detail(),
             "peers": list(part.peers), "local_atoms": part.n_local, "owned_atoms": part.n_owned,
             "sent_bytes_per_step": lc["bytes"], "ms_per_step_this_rank": elapsed_rank / args.steps * 1e3}, group=group)
         part_ms = time_stage(lambda: type(part)(coords, cell, pbc, world, rank, model._spatial_reach(),

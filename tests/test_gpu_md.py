@@ -56,6 +56,7 @@ def test_verlet_refresh_equals_rebuild(dev, name):
     cd = None if cell is None else torch.from_numpy(cell).to(dev)
     n = spd.numel()
     ver = VerletRows(skin=1.0)
+    ver.rebuild_above = float("inf")   # (the reuse machinery: by default the list is an API shim that rebuilds every step)
     r0 = ver.rows(eng, spd, x0, cd, pbc, 0, n, mode, 256)
     f0 = eng.neighbors(spd, x0, cd, pbc, mode=mode, row_cap=256)
     assert torch.equal(r0.meta[:, 1:], f0.meta[:, 1:])      # same counts per class and species at the build point
@@ -106,6 +107,8 @@ def test_md_verlet_matches_plain_and_conserves_energy(dev):
     runs = {}
     for nl in ("cell_list", "verlet_cell_list"):
         model = make_model(dev, nl)
+        if model.aev_computer.verlet is not None:
+            model.aev_computer.verlet.rebuild_above = float("inf")   # (exercise the reuse path, off by default)
         md = MolecularDynamics(model, spd, xd, cd, pbc, dt=0.25, masses=masses, seed=1)
         md.set_temperature(150.0)
         e0 = md.total_energies().clone()
@@ -227,3 +230,20 @@ def test_ase_calculator_protocol(dev):
     assert frac.min() > -1e-5 and frac.max() < 1 + 1e-5
     with pytest.raises(ValueError, match="periodic_table_index"):
         ANI2x(state_dict=seeded_state("ani2x", 8, g["seed"]), device=dev, periodic_table_index=False).ase()
+
+
+def test_verlet_list_rebuilds_by_default(dev):
+    """neighborlist="verlet_cell_list" is an API-compatibility shim (engine.VerletRows): by default every step takes the plain
+    pair search -- measured faster than or equal to the skin refresh at every size -- and gives the cell list's results."""
+    sp, x, cell, pbc = water(10)
+    spd = torch.from_numpy(sp.astype(np.int64)).to(dev)
+    xd, cd = torch.from_numpy(x).to(dev), torch.from_numpy(cell).to(dev)
+    out = {}
+    for nl in ("cell_list", "verlet_cell_list"):
+        model = make_model(dev, nl)
+        out[nl] = model.energies_and_forces(spd, xd, cd, pbc)
+        if nl == "verlet_cell_list":
+            ver = model.aev_computer.verlet
+            assert ver.rebuild_above == 0 and ver.n_direct >= 1 and ver.n_builds == 0 and ver.n_reuses == 0
+    assert torch.equal(out["cell_list"].energies, out["verlet_cell_list"].energies)
+    assert float((out["cell_list"].forces - out["verlet_cell_list"].forces).abs().max()) < 2e-6

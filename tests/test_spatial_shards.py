@@ -116,7 +116,7 @@ def _worker(rank, world, port, q, transport="collective"):
         from torchani_amd.parallel import SpatialShards
 
         if transport == "p2p":
-            par._EXCHANGE["transport"] = "p2p"
+            par._EXCHANGE["transport"], par._EXCHANGE["probed"] = "p2p", True
         elif transport == "fallback":   # the collective raises on its first call: every rank must switch to p2p and go on
             def broken(*a, **k):
                 raise RuntimeError("all_to_all_single: uneven splits are not supported (simulated)")

@@ -400,19 +400,18 @@ def _pad32(x: int) -> int:
 
 
 class VerletRows:
-    """Neighbor rows with a Verlet skin (the reference's VerletCellList, neighbors.py:759-884): the pair search runs
-    with cutoff Rcr + skin and is repeated only when some atom has moved more than skin / 2 since (or the cell
-    changed); in between, rows come from anihip_nbr_refresh.  Like the reference, the displacement check is a
-    host-synchronising reduction."""
+    """The reference's VerletCellList (neighbors.py:759-884) as an API-COMPATIBILITY SHIM.  The reference reuses a pair list
+    built with cutoff Rcr + skin until an atom has moved skin / 2 because its pair search dominates a step; this engine's
+    O(N) cell-list search is 5 % of a step and a refresh of skin rows (read the longer rows back, update, screen, re-sort)
+    measured SLOWER than or equal to the plain rebuild at every size from 3 000 to 2.3 M atoms (profiles/r06_md_bench.txt,
+    profiles/r05_md_bench.txt: 0.47 / 0.41 ms at 3 k atoms, 0.66 / 0.65 at 12 k, 1.13 / 1.09 at 47 k, 1.83 / 1.74 at 98 k,
+    3.55 / 3.46 at 192 k, 13.59 / 13.11 at 786 k).  So ``neighborlist="verlet_cell_list"`` is accepted, gives the same rows
+    and results, and by default simply rebuilds every step (``rebuild_above = 0``); the reuse machinery (anihip_nbr_refresh,
+    host-synchronising displacement check like the reference's) stays for callers who want the reference's semantics and
+    is switched on with ``rebuild_above = float("inf")`` (tests/test_gpu_md.py, tools/md_bench.py --force-verlet)."""
 
-    # From this many atoms on the list is simply REBUILT every step: the O(N) cell-list search of this engine costs about
-    # what a refresh costs -- a refresh reads the (longer) skin rows back, updates, screens and re-sorts them.  Measured with
-    # tools/md_bench.py --force-verlet (profiles/r05_md_bench.txt, ms per MD step, rebuild vs refresh): 192 k atoms 3.46 / 3.55,
-    # 332 k 5.96 / 6.32, 527 k 9.00 / 9.42, 786 k 13.11 / 13.59, 2.34 M 36.8 / 39.4 (round 4) -- the refresh is 3-7 % SLOWER
-    # at every size measured, so the crossover lies below them; above it the skin buys nothing and now costs nothing (same
-    # rows, same results: 36.97 / 36.90 ms at 2.34 M).  Below it (molecules, small boxes) the reference's semantics are
-    # kept: pair search only when an atom has moved skin / 2.
-    rebuild_above = 100_000
+    # systems of at least this many atoms are rebuilt every step (cell mode); 0 = always (see the class docstring)
+    rebuild_above = 0
 
     def __init__(self, skin: float = 1.0) -> None:
         if skin <= 0.0:

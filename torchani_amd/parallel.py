@@ -501,11 +501,40 @@ def _all_gather(send: torch.Tensor, world: int, group) -> torch.Tensor:
 
 # How the uneven all-to-all of SpatialShards.exchange travels: "collective" = ONE all_to_all_single (RCCL: grouped
 # point-to-point sends, only the non-empty pairs move data), "p2p" = the same pieces as paired isend / irecv in one batch
-# (torch.distributed.batch_isend_irecv: an ncclGroup of sends and receives).  The collective is the default; should its
-# first call raise -- uneven splits over RCCL had never met a peer when this was written -- every rank falls back to "p2p"
-# (the failure is in the call's argument checking, the same on every rank) and stays there.  TORCHANI_AMD_EXCHANGE=p2p
-# forces it from the start.
-_EXCHANGE = {"transport": os.environ.get("TORCHANI_AMD_EXCHANGE", "collective"), "fell_back": None}
+# (torch.distributed.batch_isend_irecv: an ncclGroup of sends and receives).  The transport is chosen ONCE per process, by a
+# probe ahead of the first real exchange (_probe_transport): a tiny uneven all_to_all_single, then an all-reduce (MIN) of
+# "it worked" so that every rank takes the same decision -- a rank-local failure can no longer leave one rank in isend / irecv
+# while its peers wait in the collective (round-5 advice).  After the probe an error of the exchange is raised, not swallowed.
+# TORCHANI_AMD_EXCHANGE=p2p forces the point-to-point form from the start (no probe).
+_EXCHANGE = {"transport": os.environ.get("TORCHANI_AMD_EXCHANGE", "collective"), "fell_back": None,
+             "probed": os.environ.get("TORCHANI_AMD_EXCHANGE") is not None}
+
+# stand-in "group" of development runs on one GPU (bench.py --emulate-shard R/W --emulate-collective-bytes): the exchange packs
+# and unpacks with the real byte plan of rank R and skips the wire (the received words are zeros)
+EMULATE_WIRE = "emulate-wire"
+
+
+def _probe_transport(group, device: torch.device, staged: bool) -> None:
+    """Decide "collective" vs "p2p" for this process group, the same on every rank."""
+    world = torch.distributed.get_world_size(group)
+    rank = torch.distributed.get_rank(group)
+    dev = torch.device("cpu") if staged else device
+    ok, msg = 1, None
+    try:
+        # uneven on purpose: rank r sends 1 + (r + peer) % 2 words to every peer
+        in_split = [1 + (rank + p) % 2 for p in range(world)]
+        out_split = [1 + (p + rank) % 2 for p in range(world)]
+        src = torch.zeros(sum(in_split), dtype=torch.float32, device=dev)
+        got = torch.empty(sum(out_split), dtype=torch.float32, device=dev)
+        torch.distributed.all_to_all_single(got, src, out_split, in_split, group=group)
+    except (RuntimeError, ValueError, NotImplementedError) as err:   # (argument / support errors of the call)
+        ok, msg = 0, f"{type(err).__name__}: {str(err)[:200]}"
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        _EXCHANGE["transport"] = "p2p"
+        _EXCHANGE["fell_back"] = msg or "the probe all_to_all_single raised on another rank"
+    _EXCHANGE["probed"] = True
 
 
 def exchange_transport() -> tp.Dict[str, tp.Optional[str]]:
@@ -539,17 +568,18 @@ def _p2p_exchange(got: torch.Tensor, send: torch.Tensor, in_split: tp.Sequence[i
 
 def _all_to_all(send: torch.Tensor, in_split: tp.Sequence[int], out_split: tp.Sequence[int], group) -> torch.Tensor:
     """all_to_all_single with uneven pieces (RCCL: grouped point-to-point sends, only the non-empty pairs move data), or the
-    same pieces as batched isend / irecv (_EXCHANGE).  The gloo backend (CPU tests, single-GPU development runs with several
-    ranks on one device) is staged through the host."""
+    same pieces as batched isend / irecv (_EXCHANGE, chosen by _probe_transport ahead of the first exchange).  The gloo backend
+    (CPU tests, single-GPU development runs with several ranks on one device) is staged through the host."""
     n_out = int(sum(out_split))
+    if group is EMULATE_WIRE:   # (development: pack / unpack with the real byte plan, no wire)
+        return torch.zeros(n_out, dtype=send.dtype, device=send.device)
     stage = send.is_cuda and torch.distributed.get_backend(group) == "gloo"
+    if not _EXCHANGE["probed"]:
+        _probe_transport(group, send.device, stage)
     src = send.cpu() if stage else send.contiguous()
     got = torch.empty(n_out, dtype=send.dtype, device=src.device)
     if _EXCHANGE["transport"] == "collective":
-        try:
-            torch.distributed.all_to_all_single(got, src, list(out_split), list(in_split), group=group)
-            return got.to(send.device) if stage else got
-        except (RuntimeError, ValueError, NotImplementedError) as err:   # (argument / support errors: raised on every rank alike)
-            _EXCHANGE["transport"], _EXCHANGE["fell_back"] = "p2p", f"{type(err).__name__}: {str(err)[:200]}"
-    _p2p_exchange(got, src, in_split, out_split, group)
+        torch.distributed.all_to_all_single(got, src, list(out_split), list(in_split), group=group)
+    else:
+        _p2p_exchange(got, src, in_split, out_split, group)
     return got.to(send.device) if stage else got
