@@ -99,7 +99,10 @@ for k, d in acc.items():
                         ("lds_active_over_wave_cycles", "SQ_ACTIVE_INST_LDS")):
             if c in g: e[name] = g[c] / wc
     if "GRBM_GUI_ACTIVE" in g:
-        simd_cycles = g["GRBM_GUI_ACTIVE"] * 1024.0   # 256 CUs x 4 SIMDs, every one of them for the whole launch
+        # GRBM_GUI_ACTIVE comes back summed over the eight XCDs (checked on kernels whose occupancy is known: with this
+        # normalisation the resident waves per SIMD come out as 3.9 for the 16-wave-per-CU AEV kernels and 1.93 for the
+        # 8-wave network kernel): cycles of the launch = GRBM_GUI_ACTIVE / 8, SIMD-cycles = that x 256 CUs x 4 SIMDs
+        simd_cycles = g["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
         if "SQ_ACTIVE_INST_VALU" in g: e["simd_valu_busy"] = 4.0 * g["SQ_ACTIVE_INST_VALU"] / simd_cycles   # quad-cycles -> cycles
         if "SQ_VALU_MFMA_BUSY_CYCLES" in g: e["simd_mfma_busy"] = g["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
         if "SQ_WAVE_CYCLES" in g: e["waves_per_simd_resident"] = 4.0 * g["SQ_WAVE_CYCLES"] / simd_cycles

@@ -1495,7 +1495,11 @@ __global__ __launch_bounds__(L0B_THREADS, 2) void k_gemm_l0b(GemmArgs g)
 //   <1, 2>: 32 atoms, 4 waves, 60 KB LDS, TWO workgroups per CU that drift out of phase, so the epilogues
 //           (VALU) of one overlap the GEMM phases (matrix pipe) of the other, at twice the L2 weight traffic.
 constexpr int FR_MAXH = 256;      // largest padded hidden width (8 column blocks)
-constexpr int64_t FUSED_L0B_MIN_ATOMS = 65536;   // layer-0 backward inside the fused kernel from this many atoms on
+// layer-0 backward inside the fused kernel from this many atoms on.  Round 6 (16-column units in phase 5: no hand-over, no mid-phase
+// barrier): measured crossover on water boxes 17 496 atoms 0.387 vs 0.344 ms (loses), 24 000 0.405 vs 0.429, 31 944 0.466 vs
+// 0.535, 59 049 0.812 vs 0.860; solvated 1hz5 (46 357 atoms, five elements) 1.09 vs 1.18 ms per step, 1C17 (16 649) 0.95 vs 0.79
+// (loses).  (65 536 in rounds 4-5.)
+constexpr int64_t FUSED_L0B_MIN_ATOMS = 24000;
 #ifndef ANIHIP_OWNER_GROUP
 #define ANIHIP_OWNER_GROUP 1
 #endif
@@ -3560,7 +3564,7 @@ static FbPlan fb_plan(const anihip_mlp_desc *d, int64_t n, bool want_grad)
     // Layer-0 backward INSIDE the fused kernel (its phase 5): a workgroup owns a tile through all members and adds the
     // members' d E / d AEV in place -- no d act0 round trip through HBM (8 KB per atom written and read back), no layer-0
     // backward launch.  Tiles are then the unit of work (not tile x member items), so it needs enough of them to balance
-    // over the CUs: from 65536 atoms on (1024 tiles).  Smaller inputs keep the member-major sweep + a backward GEMM.
+    // over the CUs: from FUSED_L0B_MIN_ATOMS atoms on.  Smaller inputs keep the member-major sweep + a backward GEMM.
     // (phase 5 hands partial sums between waves through 32 KB of LDS in X1's place: 2 planes x 64 rows x (H2 + 8) halves)
     // (... and its k range is cut in two halves of >= 2 steps each for the two waves of a SIMD: first hidden layers of >= 64
     // columns -- with 32 the first half would be empty and its ring would read in front of the member's planes)

@@ -298,7 +298,9 @@ class ANI(torch.nn.Module):
         (1C17, solvated 1hz5: DESIGN.md section 6), where 256-row tiles are too few to balance over the CUs.  The number of
         elements present costs one host sync per distinct ``species`` tensor: cached by identity and version, with a
         reference to the tensor so that its address cannot be handed to another one meanwhile."""
-        if not 16384 <= n_central < 65536:
+        # (from 24 000 atoms on the layer-0 backward runs inside the fused kernel -- FUSED_L0B_MIN_ATOMS of csrc/mlp.hip, round 6:
+        # 46 357-atom solvated 1hz5 1.18 -> 1.09 ms per step -- and no tiling of a separate backward GEMM is left to choose)
+        if not 16384 <= n_central < 24000:
             return 0
         key = (species.data_ptr(), species._version, tuple(species.shape))
         hit = self.__dict__.get("_n_elem_cache")
