@@ -2337,6 +2337,13 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         for (int sl = 0; sl < D; ++sl) rg.load(sl, next_s2());
     };
     int4 te = g.tile_tab[tile];
+    // phase 5, tiles whose flagged slabs fit ONE pass (every tile of a water box), owner order over single tiles: the members'
+    // d E / d AEV of this wave's 16 columns x 64 rows stay in these sixteen registers from the first member to the last, which
+    // stores them -- one store per tile instead of a read-add-write per member (7 x 512 B read and 7 x 512 B written less per
+    // atom and tile; the same additions in the same order: bit-identical to the read-add-write)
+    v4f gsum[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) gsum[t] = v4f{0.f, 0.f, 0.f, 0.f};
     int staged_tile = -1;   // the tile whose layer-0 operand slot 0 keeps (L0B, <= KEEP_SLABS flagged slabs), or -1
     int par = 0;   // which half of s_orow holds the current item's rows
     {
@@ -2842,14 +2849,17 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     const int col5 = g.kp_rad ? kp_col(g.kp_rad, sl) : 32 * sl;
                     const int nv5 = g.kp_rad ? kp_valid(g.kp_rad, sl) : min(32, (int)g.L - 32 * sl);
                     const bool cok = live && 16 * ct5 + 4 * c4 < nv5;
+                    // (wave-uniform) the members' sum of a single-pass tile stays in registers (gsum)
+                    const bool regsum = LAST && c0 == 0 && g.owner == 1;
                     // what the members before this one left in the rows (this wave wrote it: L2 hits), requested ahead of the
                     // MFMA loop
                     v4f prev[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        // (lanes with nothing to read -- the first member, waves without a slab -- read a line that is hot in
-                        // L2: loads return in order, and a miss to HBM here would hold up the weight ring's requests behind it)
-                        const bool ok = cok && rok[t] && m > 0;
+                        // (lanes with nothing to read -- the first member, waves without a slab, sums kept in registers -- read a
+                        // line that is hot in L2: loads return in order, and a miss to HBM here would hold up the weight ring's
+                        // requests behind it)
+                        const bool ok = cok && rok[t] && m > 0 && !regsum;
                         prev[t] = *(const gf4 *)(ok ? orow[t] + col5 : fs.bounds);
                         if (!ok) prev[t] = v4f{0.f, 0.f, 0.f, 0.f};
                     }
@@ -2875,8 +2885,9 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     for (int t = 0; t < 4; ++t) {
                         v4f v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc5[t][e], osc5, prev[t][e]);
-                        if (cok && rok[t]) *reinterpret_cast<v4f *>(orow[t] + col5) = v;
+                        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc5[t][e], osc5, regsum ? (m > 0 ? gsum[t][e] : 0.f) : prev[t][e]);
+                        gsum[t] = v;
+                        if (cok && rok[t] && (!regsum || m == Mi - 1)) *reinterpret_cast<v4f *>(orow[t] + col5) = v;
                     }
                     slab = slab_n;
                 };
