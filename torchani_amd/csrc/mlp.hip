@@ -2832,13 +2832,21 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             ANIHIP_STAMP(trace, 13);
             if (g.want_grad) {
                 const float osc5 = fs.is0 / s4;
+                // (wave-uniform) a single-pass tile in owner order over single tiles: the members' sum stays in registers (gsum) and
+                // only the last member needs the row pointers (LDS reads + 64-bit address arithmetic: 1.3 k clocks per item)
+                const bool regsum_tile = nact <= 4 && g.owner == 1;
                 float *orow[4];
                 bool rok[4];
+                if (!regsum_tile || m == Mi - 1) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int row = 16 * t + n16;
-                    orow[t] = g.grad_aev + (int64_t)s_orow[par * ROWS + row] * g.L + 16 * ct5 + 4 * c4;
-                    rok[t] = row < n_rows;    // (short tiles repeat their last atom: one writer per row only)
+                    for (int t = 0; t < 4; ++t) {
+                        const int row = 16 * t + n16;
+                        orow[t] = g.grad_aev + (int64_t)s_orow[par * ROWS + row] * g.L + 16 * ct5 + 4 * c4;
+                        rok[t] = row < n_rows;    // (short tiles repeat their last atom: one writer per row only)
+                    }
+                } else {   // (defined on every path)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { orow[t] = g.grad_aev; rok[t] = false; }
                 }
                 // (the last pass -- the only one of a water tile -- is peeled: what it prefetches for the next item must not be
                 // defined under a condition inside a loop, or it is carried around the loop in registers)
@@ -2850,18 +2858,22 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     const int nv5 = g.kp_rad ? kp_valid(g.kp_rad, sl) : min(32, (int)g.L - 32 * sl);
                     const bool cok = live && 16 * ct5 + 4 * c4 < nv5;
                     // (wave-uniform) the members' sum of a single-pass tile stays in registers (gsum)
-                    const bool regsum = LAST && c0 == 0 && g.owner == 1;
+                    const bool regsum = LAST && c0 == 0 && regsum_tile;
                     // what the members before this one left in the rows (this wave wrote it: L2 hits), requested ahead of the
                     // MFMA loop
                     v4f prev[4];
+                    if (!regsum) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        // (lanes with nothing to read -- the first member, waves without a slab, sums kept in registers -- read a
-                        // line that is hot in L2: loads return in order, and a miss to HBM here would hold up the weight ring's
-                        // requests behind it)
-                        const bool ok = cok && rok[t] && m > 0 && !regsum;
-                        prev[t] = *(const gf4 *)(ok ? orow[t] + col5 : fs.bounds);
-                        if (!ok) prev[t] = v4f{0.f, 0.f, 0.f, 0.f};
+                        for (int t = 0; t < 4; ++t) {
+                            // (lanes with nothing to read -- the first member, waves without a slab -- read a line that is hot in
+                            // L2: loads return in order, and a miss to HBM here would hold up the weight ring's requests behind it)
+                            const bool ok = cok && rok[t] && m > 0;
+                            prev[t] = *(const gf4 *)(ok ? orow[t] + col5 : fs.bounds);
+                            if (!ok) prev[t] = v4f{0.f, 0.f, 0.f, 0.f};
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) prev[t] = v4f{0.f, 0.f, 0.f, 0.f};
                     }
                     v4f acc5[4];
 #pragma unroll
