@@ -9,11 +9,32 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+#ifndef OVERLAP_M16
+#define OVERLAP_M16 0   // 1: the G stream issues the same flops as v_mfma_f32_16x16x32_f16 (round 6: not power-limited)
+#endif
 
 __device__ __forceinline__ float gemm_stream(int iters, const _Float16 *lds, int lane)
 {
-    f16v c0 = {}, c1 = {};
     const h8 *a = reinterpret_cast<const h8 *>(lds) + lane;
+#if OVERLAP_M16
+    f4v c[4] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const h8 x = a[(u & 1) * 64], y = a[128 + (u & 1) * 64];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {   // 12 MFMAs of 16x16x32 = the flops of 6 of 32x32x16, four independent accumulators
+                c[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c[0], 0, 0, 0);
+                c[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(y, x, c[1], 0, 0, 0);
+                c[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(y, y, c[2], 0, 0, 0);
+                c[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, x, c[3], 0, 0, 0);
+            }
+        }
+    }
+    return c[0][0] + c[1][1] + c[2][2] + c[3][3];
+#else
+    f16v c0 = {}, c1 = {};
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -27,6 +48,7 @@ __device__ __forceinline__ float gemm_stream(int iters, const _Float16 *lds, int
         }
     }
     return c0[0] + c1[5];
+#endif
 }
 
 __device__ __forceinline__ float epi_stream(int iters, _Float16 *lds, int tid)
@@ -84,7 +106,7 @@ int main()
 {
     float *out; long long *cyc;
     hipMalloc(&out, 4); hipMalloc(&cyc, 256 * 8 * 8);
-    const int iters = 2000;
+    const int iters = 40000;   // (round 6: >= 20 ms per kernel, past the power controller's first milliseconds)
     const int modes[] = {1, 2, 3, 3 | 4, 3 | 8, 16};
     const char *names[] = {"G alone", "E alone", "G + E", "G + E, prio G", "G + E, prio E", "mixed in every wave"};
     for (int i = 0; i < 6; ++i) {

@@ -1681,14 +1681,17 @@ struct AFrag {
 // relative): ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS, backward phases only, off by default
 // (leaving out (weight hi) x (x lo) instead -- the gradients rounded, not the weights -- measures the same: max |dF| 6.9e-6
 // against 5.0e-6 Ha/A on the headline sample)
-template <int D2, bool TWO = false>
+// FIRST: the first k2 step of a GEMM -- the accumulators START from the MFMA's zero operand (no v_mov zero fill: 32-48 VALU
+// instructions per phase and wave, an eighth of the kernel's vector instructions before round 6)
+template <int D2, bool TWO = false, bool FIRST = false>
 __device__ __forceinline__ void fr_mfma(Acc16 &acc, const WRing<D2> &rg, int slot, const AFrag &x)
 {
+    const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
-            acc[2 * ct + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.hi[slot][ct], x.lo[rt], acc[2 * ct + rt], 0, 0, 0);
+            acc[2 * ct + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.hi[slot][ct], x.lo[rt], FIRST ? zero : acc[2 * ct + rt], 0, 0, 0);
     if constexpr (!TWO) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -1726,71 +1729,83 @@ template <int RBA, int D2, bool TWO = false>
 __device__ __forceinline__ void fr_gemm(Acc16 (&acc)[2], const _Float16 *xa, int ldx, int x_plane, WRing<D2> &rg, int KS2,
                                         int lane)
 {
-    static_assert(D2 % 2 == 0, "the single-row-block form alternates two fragment sets over the ring's steps");
+    static_assert(D2 == 2, "the peeled first step and the alternating fragment sets are written for a ring of two k2 steps");
     const int n16 = lane & 15, c4 = lane >> 4;
     const _Float16 *af = xa + n16 * ldx + ((c4 ^ ((n16 >> 2) & 1)) << 3);
     const int rts = 16 * ldx, rbs = 32 * ldx;
     AFrag xe, xo;
     xe.load(af, x_plane, rts);
-    int k0 = 0;
+    // step 0, peeled: it WRITES the accumulators (fr_mfma<FIRST>), the callers do not zero them.  Behind it the ring slot of
+    // step k is (k % D2): the loops below start at k0 = 1 and walk the slots 1, 0.
+    // (the scheduler sinks the fragment reads to their first use and waits for each of them between the MFMAs: fences keep
+    // the reads of the NEXT half step ahead of the twelve MFMAs of this one)
+    int k0 = 1;
     if constexpr (RBA == 2) {
+        xo.load(af + rbs, x_plane, rts);
+        FR_FENCE();
+        fr_mfma<D2, TWO, true>(acc[0], rg, 0, xe);
+        FR_FENCE();
+        xe.load(af + min(1, KS2 - 1) * 32, x_plane, rts);
+        FR_FENCE();
+        fr_mfma<D2, TWO, true>(acc[1], rg, 0, xo);
+        rg.load(0, min(D2, KS2 - 1));
+        FR_FENCE();
         for (; k0 + D2 < KS2; k0 += D2) {
 #pragma unroll
             for (int sl = 0; sl < D2; ++sl) {
-                // (the scheduler sinks the fragment reads to their first use and waits for each of them between the MFMAs:
-                // fences keep the reads of the NEXT half step ahead of the twelve MFMAs of this one)
+                const int slot = (sl + 1) % D2;
                 xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
                 FR_FENCE();
-                fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
+                fr_mfma<D2, TWO>(acc[0], rg, slot, xe);
                 FR_FENCE();
                 xe.load(af + (k0 + sl + 1) * 32, x_plane, rts);
                 FR_FENCE();
-                fr_mfma<D2, TWO>(acc[1], rg, sl, xo);
-                rg.load(sl, min(k0 + sl + D2, KS2 - 1));
+                fr_mfma<D2, TWO>(acc[1], rg, slot, xo);
+                rg.load(slot, min(k0 + sl + D2, KS2 - 1));
                 FR_FENCE();
             }
         }
-        const int rem = KS2 - k0;   // (1 .. D2 steps, all of them in the ring)
+        const int rem = KS2 - k0;   // (0 .. D2 steps, all of them in the ring)
 #pragma unroll
         for (int sl = 0; sl < D2; ++sl) {
             if (rem > sl) {
+                const int slot = (sl + 1) % D2;
                 xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
                 FR_FENCE();
-                fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
+                fr_mfma<D2, TWO>(acc[0], rg, slot, xe);
                 FR_FENCE();
                 xe.load(af + min(k0 + sl + 1, KS2 - 1) * 32, x_plane, rts);
                 FR_FENCE();
-                fr_mfma<D2, TWO>(acc[1], rg, sl, xo);
+                fr_mfma<D2, TWO>(acc[1], rg, slot, xo);
                 FR_FENCE();
             }
         }
     } else {
-        for (; k0 + D2 < KS2; k0 += D2) {
-#pragma unroll
-            for (int sl = 0; sl < D2; sl += 2) {
-                xo.load(af + (k0 + sl + 1) * 32, x_plane, rts);
-                FR_FENCE();
-                fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
-                rg.load(sl, min(k0 + sl + D2, KS2 - 1));
-                FR_FENCE();
-                xe.load(af + min(k0 + sl + 2, KS2 - 1) * 32, x_plane, rts);
-                FR_FENCE();
-                fr_mfma<D2, TWO>(acc[0], rg, sl + 1, xo);
-                rg.load(sl + 1, min(k0 + sl + 1 + D2, KS2 - 1));
-                FR_FENCE();
-            }
+        // one row block: the fragment sets alternate with the steps (xe: even steps, xo: odd steps)
+        xo.load(af + min(1, KS2 - 1) * 32, x_plane, rts);
+        FR_FENCE();
+        fr_mfma<D2, TWO, true>(acc[0], rg, 0, xe);
+        rg.load(0, min(D2, KS2 - 1));
+        FR_FENCE();
+        for (; k0 + D2 < KS2; k0 += D2) {   // (steps k0 (odd: xo, slot 1) and k0 + 1 (even: xe, slot 0))
+            xe.load(af + (k0 + 1) * 32, x_plane, rts);
+            FR_FENCE();
+            fr_mfma<D2, TWO>(acc[0], rg, 1, xo);
+            rg.load(1, min(k0 + D2, KS2 - 1));
+            FR_FENCE();
+            xo.load(af + min(k0 + 2, KS2 - 1) * 32, x_plane, rts);
+            FR_FENCE();
+            fr_mfma<D2, TWO>(acc[0], rg, 0, xe);
+            rg.load(0, min(k0 + 1 + D2, KS2 - 1));
+            FR_FENCE();
         }
         const int rem = KS2 - k0;
-#pragma unroll
-        for (int sl = 0; sl < D2; sl += 2) {
-            if (rem > sl) {
-                xo.load(af + min(k0 + sl + 1, KS2 - 1) * 32, x_plane, rts);
-                fr_mfma<D2, TWO>(acc[0], rg, sl, xe);
-                if (rem > sl + 1) {
-                    xe.load(af + min(k0 + sl + 2, KS2 - 1) * 32, x_plane, rts);
-                    fr_mfma<D2, TWO>(acc[0], rg, sl + 1, xo);
-                }
-            }
+        if (rem > 0) {
+            xe.load(af + min(k0 + 1, KS2 - 1) * 32, x_plane, rts);
+            FR_FENCE();
+            fr_mfma<D2, TWO>(acc[0], rg, 1, xo);
+            FR_FENCE();
+            if (rem > 1) fr_mfma<D2, TWO>(acc[0], rg, 0, xe);
         }
     }
 }
@@ -1816,10 +1831,12 @@ __device__ __forceinline__ void fr_gemm_half(v4f (&acc)[4], const _Float16 *xa, 
     const _Float16 *af = xa + n16 * ldx + ((c4 ^ ((n16 >> 2) & 1)) << 3);
     const int rts = 16 * ldx, rbs = 32 * ldx;
     AFrag xe, xo;
-    auto mm = [&](int rb, int slot, const AFrag &x) {
+    auto mm = [&](int rb, int slot, const AFrag &x, auto first_) {
+        constexpr bool FIRST = decltype(first_)::value;
+        const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
-            acc[2 * rb + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.hi[slot], x.lo[rt], acc[2 * rb + rt], 0, 0, 0);
+            acc[2 * rb + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.hi[slot], x.lo[rt], FIRST ? zero : acc[2 * rb + rt], 0, 0, 0);
         if constexpr (!TWO) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
@@ -1830,32 +1847,44 @@ __device__ __forceinline__ void fr_gemm_half(v4f (&acc)[4], const _Float16 *xa, 
             acc[2 * rb + rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(rg.hi[slot], x.hi[rt], acc[2 * rb + rt], 0, 0, 0);
     };
     xe.load(af, x_plane, rts);
-    int k0 = 0;
+    // step 0, peeled: it writes the accumulators (no zero fill); the loops below start at k0 = 1 with the slots 1, 0, ...
+    xo.load(af + rbs, x_plane, rts);
+    FR_FENCE();
+    mm(0, 0, xe, std::true_type{});
+    FR_FENCE();
+    xe.load(af + min(1, KS2 - 1) * 32, x_plane, rts);
+    FR_FENCE();
+    mm(1, 0, xo, std::true_type{});
+    rg.load(0, min(D2, KS2 - 1));
+    FR_FENCE();
+    int k0 = 1;
     for (; k0 + D2 < KS2; k0 += D2) {
 #pragma unroll
         for (int sl = 0; sl < D2; ++sl) {
+            const int slot = (sl + 1) % D2;
             xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
             FR_FENCE();
-            mm(0, sl, xe);
+            mm(0, slot, xe, std::false_type{});
             FR_FENCE();
             xe.load(af + (k0 + sl + 1) * 32, x_plane, rts);
             FR_FENCE();
-            mm(1, sl, xo);
-            rg.load(sl, min(k0 + sl + D2, KS2 - 1));
+            mm(1, slot, xo, std::false_type{});
+            rg.load(slot, min(k0 + sl + D2, KS2 - 1));
             FR_FENCE();
         }
     }
-    const int rem = KS2 - k0;   // (1 .. D2 steps, all of them in the ring)
+    const int rem = KS2 - k0;   // (0 .. D2 steps, all of them in the ring)
 #pragma unroll
     for (int sl = 0; sl < D2; ++sl) {
         if (rem > sl) {
+            const int slot = (sl + 1) % D2;
             xo.load(af + rbs + (k0 + sl) * 32, x_plane, rts);
             FR_FENCE();
-            mm(0, sl, xe);
+            mm(0, slot, xe, std::false_type{});
             FR_FENCE();
             xe.load(af + min(k0 + sl + 1, KS2 - 1) * 32, x_plane, rts);
             FR_FENCE();
-            mm(1, sl, xo);
+            mm(1, slot, xo, std::false_type{});
             FR_FENCE();
         }
     }
@@ -1870,7 +1899,7 @@ __device__ __forceinline__ void fr_gemm_half(v4f (&acc)[4], const _Float16 *xa, 
 // them in the ring when the loop starts: the short form walks 4 steps and requests 4 - D2.
 // KEPT: the operand is the tile's kept copy (FusedCfg::SLABU layout: unpadded rows, swizzled chunks) -- s0 = this lane's
 // fragment address in slab 0
-template <int RBA, int D2, int ROWS, int STEPS, int REQS, bool KEPT = false, class NextS2>
+template <int RBA, int D2, int ROWS, int STEPS, int REQS, bool KEPT = false, bool FIRST = false, class NextS2>
 __device__ __forceinline__ void fr_l0_pair(Acc16 (&acc)[2], WRing<D2> &rg, const _Float16 *s0, const _Float16 *s1, int n_live,
                                            NextS2 &&next_s2)
 {
@@ -1885,16 +1914,21 @@ __device__ __forceinline__ void fr_l0_pair(Acc16 (&acc)[2], WRing<D2> &rg, const
     xe.load(addr(0), PL, RTS);
 #pragma unroll
     for (int st = 0; st < STEPS; ++st) {
+        // (FIRST: the tile's first flagged slab -- n_live >= 1 -- writes the accumulators, the caller does not zero them)
         const bool live = st < n_live;
+        constexpr bool FST_ = FIRST;
         if constexpr (RBA == 2) {
             xo.load(addr(st) + RBS, PL, RTS);
-            if (live) fr_mfma<D2>(acc[0], rg, st % D2, xe);
+            if (FST_ && st == 0) fr_mfma<D2, false, true>(acc[0], rg, 0, xe);
+            else if (live) fr_mfma<D2>(acc[0], rg, st % D2, xe);
             if (st + 1 < STEPS) xe.load(addr(st + 1), PL, RTS);
-            if (live) fr_mfma<D2>(acc[1], rg, st % D2, xo);
+            if (FST_ && st == 0) fr_mfma<D2, false, true>(acc[1], rg, 0, xo);
+            else if (live) fr_mfma<D2>(acc[1], rg, st % D2, xo);
         } else {
             AFrag &xc = (st & 1) ? xo : xe, &xn = (st & 1) ? xe : xo;
             if (st + 1 < STEPS) xn.load(addr(st + 1), PL, RTS);
-            if (live) fr_mfma<D2>(acc[0], rg, st % D2, xc);
+            if (FST_ && st == 0) fr_mfma<D2, false, true>(acc[0], rg, 0, xc);
+            else if (live) fr_mfma<D2>(acc[0], rg, st % D2, xc);
         }
         if (st < REQS) rg.load(st % D2, next_s2());
     }
@@ -2504,12 +2538,14 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const int nact = __popc(tmask);
         const int npair = (nact + 2 * FR_GROUP - 1) / (2 * FR_GROUP);
         // (AEV slabs 0..5 and the first D weight fragments were requested during the previous item)
-        zero_acc();
         // Owner order (L0B) with at most KEEP_SLABS flagged slabs -- every tile of a water box: the split planes of the tile's
         // AEV slabs are the same for all eight members, so they are staged ONCE, into slot 0 in an unpadded swizzled layout
         // (four slabs in the place of three padded ones), and the items of the other members neither fetch nor convert
         // nor store them again (3.6 KB per atom of fetches and ~1 k clocks per item)
         const bool keep = L0B && nact <= C::KEEP_SLABS;
+        // (the kept path's first slab WRITES the accumulators; every other path -- and a tile of atoms without neighbors, whose
+        // layer 0 multiplies nothing -- starts from zeros)
+        if (!(keep && nact > 0)) zero_acc();
         bool staged = true;
         if (keep) {
             staged = staged_tile != tile;
@@ -2542,7 +2578,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 if (keep) {   // (wave-uniform) the kept copy: this lane's chunk of a slab's rows
                     const int rowk = u1.rb0 * 32 + n16, sw = (0 - (rowk >> 2)) & 3;
                     const _Float16 *k0 = slot0 + rowk * 32 + ((c4 ^ sw) << 3);
-                    FR_UNIT(u1, (fr_l0_pair<RBA, D, ROWS, 4, 4 - D, true>(acc, rg, k0, k0, n_live, next_s2)))
+                    FR_UNIT(u1, (fr_l0_pair<RBA, D, ROWS, 4, 4 - D, true, true>(acc, rg, k0, k0, n_live, next_s2)))
                 } else if (nact <= 4) {   // (wave-uniform)
                     FR_UNIT(u1, (fr_l0_pair<RBA, D, ROWS, 4, 4 - D>(acc, rg, s0, s1, n_live, next_s2)))
                 } else {
@@ -2637,7 +2673,6 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
         float bias1[NB][16];   // (per-column parameters travel during the GEMM)
         load_cols(fs.b1 + (int64_t)m * H2, bias1, u2);
-        zero_acc();
         FR_UNIT(u2, (fr_gemm<RBA, D>(acc, X0 + u2.rb0 * 32 * ld0, ld0, x0_plane, r1, H1 >> 5, lane)))
         ANIHIP_STAMP(trace, 5);
         Ring r2;
@@ -2679,7 +2714,6 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         // (fetching these behind the GEMM as well frees 32 registers and the last two spills, and is 0.4 % SLOWER: measured)
         load_cols(fs.b2 + (int64_t)m * H3, bias2, u3);
         load_cols(fs.w3 + (int64_t)m * H3, w3, u3);
-        zero_acc();
         FR_UNIT(u3, (fr_gemm<RBA, D>(acc, X1 + u3.rb0 * 32 * ld1, ld1, x1_plane, r2, H2 >> 5, lane)))
         ANIHIP_STAMP(trace, 7);
         Ring r3;   // (also without want_grad: see fr_ring)
@@ -2749,7 +2783,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         Ring r4;
         if (g.want_grad) {
             // =============== phase 3: d act1 = (d act2 x W2) * celu'(act1) ===============
-            zero_acc();
+            // (no zero fill: the first k2 step of fr_gemm writes the accumulators)
             FR_UNIT(u2, (fr_gemm<RBA, D, B2>(acc, X2 + u2.rb0 * 32 * ld2, ld2, x2_plane, r3, H3 >> 5, lane)))
             ANIHIP_STAMP(trace, 10);
         }
@@ -2781,7 +2815,6 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         ANIHIP_STAMP(trace, 11);
         // =============== phase 4: d act0 = (d act1 x W1) * celu'(act0)  -> global, or -> LDS for phase 5 ===============
         if (g.want_grad && u1.nrb > 0) {
-            zero_acc();
             FR_UNIT(u1, (fr_gemm<RBA, D, B2>(acc, X1 + u1.rb0 * 32 * ld1, ld1, x1_plane, r4, H2 >> 5, lane)))
         }
         ANIHIP_STAMP(trace, 12);
@@ -2876,10 +2909,12 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                         for (int t = 0; t < 4; ++t) prev[t] = v4f{0.f, 0.f, 0.f, 0.f};
                     }
                     v4f acc5[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) acc5[t] = v4f{0.f, 0.f, 0.f, 0.f};
                     ANIHIP_STAMP(trace, 19);
-                    if (live) fr_gemm_half<D, B2>(acc5, X0, ld0, x0_plane, r5, KS5 >> 1, lane);
+                    if (live) fr_gemm_half<D, B2>(acc5, X0, ld0, x0_plane, r5, KS5 >> 1, lane);   // (writes acc5: no zero fill)
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc5[t] = v4f{0.f, 0.f, 0.f, 0.f};
+                    }
                     ANIHIP_STAMP(trace, 20);
                     const int slab_n = nth_slab(c0 + 4 + (wave >> 1));
                     if constexpr (LAST) {
