@@ -1,7 +1,7 @@
 """Phase timeline of k_mlp_fused from the ANIHIP_FUSED_TRACE stamps (development aid).
 
     (the stamps are compiled out of the shipped library: build a development copy first)
-    VARIANT_TU=mlp tools/build_variants.sh ftrace "-DANIHIP_DEV_TRACE"
+    VARIANT_TU=all tools/build_variants.sh ftrace "-DANIHIP_DEV_TRACE"
     TORCHANI_AMD_LIB=$PWD/build_alt/libanihip_ftrace.so ANIHIP_FUSED_TRACE=/tmp/ft.bin \
           python tools/kbench.py --side 40 --stages mlp --mask on --reps 1
     python tools/fused_trace.py /tmp/ft.bin
