@@ -711,6 +711,245 @@ __global__ __launch_bounds__(512, 2) void k_seq8(Args g)
     if (lane == 0 && wave == 0) g.cyc[blockIdx.x] = __builtin_readcyclecounter() - t0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// SEQ4: the shipped STRUCTURE (GEMM phase -> epilogue -> ONE barrier per phase) on 4 waves x 512 registers: a wave owns column
+// block A = w (both row blocks) AND its share B of the blocks 4.. (b_share), multiplied in the SAME pass over k -- every
+// activation fragment is read from LDS once per wave and phase (half the fragment traffic of 8 waves), one wave per SIMD (no
+// older / younger half), phase 5 = one slab per wave, whole K, no hand-over.
+template <int NRBB, int KS, int D, class AddrA, class AddrB>
+__device__ __forceinline__ void dual_gemm(f32x16 (&accA)[2], f32x16 (&accB)[2], Ring<D> &rA, Ring<D> &rB, AddrA &&addrA, AddrB &&addrB,
+                                          int plane, int rbs)
+{
+    AFrag<2> xa, xb;
+    AFrag<1> ya, yb;   // (the B unit of one row block reads its own row block's fragments: the same bytes as one of xa's)
+    xa.load(addrA(0), plane, rbs);
+    if (NRBB == 1) ya.load(addrB(0), plane, rbs);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        AFrag<2> &xc = (k & 1) ? xb : xa, &xn = (k & 1) ? xa : xb;
+        AFrag<1> &yc = (k & 1) ? yb : ya, &yn = (k & 1) ? ya : yb;
+        if (k + 1 < KS) {
+            xn.load(addrA(k + 1), plane, rbs);
+            if (NRBB == 1) yn.load(addrB(k + 1), plane, rbs);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3<2>(accA, rA.hi[k % D], rA.lo[k % D], xc);
+        if (NRBB == 2) mfma3<2>(accB, rB.hi[k % D], rB.lo[k % D], xc);
+        if (NRBB == 1) {
+            f32x16(&b1)[1] = reinterpret_cast<f32x16(&)[1]>(accB[0]);
+            mfma3<1>(b1, rB.hi[k % D], rB.lo[k % D], yc);
+        }
+        if (k + D < KS) {
+            rA.load(k % D, k + D);
+            if (NRBB > 0) rB.load(k % D, k + D);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 1) void k_seq4(Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    float *s_e = reinterpret_cast<float *>(lds);                 // [4][64]
+    _Float16 *slot0 = lds + FIXED_HALVES;
+    _Float16 *X0 = slot0 + S0_HALVES, *X1 = X0 + X0_HALVES, *X2 = X0;
+    const int tid = threadIdx.x, lane = tid & 63, fr = lane & 31, fk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < S0_HALVES; i += 256) slot0[i] = (_Float16)(g.zero_lds ? 0.f : ((i * 2654435761u) >> 20 & 1023) * (1.0f / 64.0f));
+    __syncthreads();
+    const float alpha = 0.1f, ia_log2e = 10.0f * 1.44269504f;
+    const long long t0 = __builtin_readcyclecounter();
+    const BShare b0s = b_share<NB1>(wave), b1s = b_share<NB2>(wave), b2s = b_share<NB3>(wave);
+    const float s0 = 512.0f, s1 = 512.0f, s2 = 2048.0f, s3 = 2048.0f, s4 = 2048.0f;
+    const float osc = 1.0f / (8192.0f * 512.0f * 8.0f);
+    for (int it = 0; it < g.items_per_wg; ++it) {
+        const int m = it & 7;
+        const int64_t item = (int64_t)blockIdx.x * g.items_per_wg + it;
+        const _Float16 *wm = g.w + (int64_t)m * WMEM;
+        const float *cm = g.cols + (int64_t)m * 4 * 256;
+        f32x16 accA[2], accB[2];
+        Ring<D> rA, rB;
+        float d0A[2][16], d0B[2][16], d1A[2][16], d1B[16], colA[16], colB[16], w3A[16], w3B[16];
+        auto cols16 = [&](const float *base, int cb, float (&v)[16]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f t = *(const gf4 *)(base + cb * 32 + 4 * fk + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+            }
+        };
+        auto fwd_quad = [&](f32x16 &a, const float (&b)[16], float (&dsv)[16], int q, float o, float s, _Float16 *X, int ld,
+                            int plane, int row, int cc) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int r = 4 * q + e;
+                const v2f x = v2f{a[r], a[r + 1]} * o + v2f{b[r], b[r + 1]};
+                const v2f t = x * ia_log2e;
+                const v2f ex = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                const v2f yy = ex * alpha - alpha;
+                dsv[r] = fminf(ex.x, 1.0f);
+                dsv[r + 1] = fminf(ex.y, 1.0f);
+                y[e] = __builtin_amdgcn_fmed3f(x.x, yy.x, 0.f);
+                y[e + 1] = __builtin_amdgcn_fmed3f(x.y, yy.y, 0.f);
+            }
+            split_store4(y, s, X + row * ld + cc + 8 * q, plane);
+        };
+        auto bwd_quad = [&](f32x16 &a, const float (&dsv)[16], int q, float o, float s, _Float16 *X, int ld, int plane, int row,
+                            int cc) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = a[4 * q + e] * (o * dsv[4 * q + e]);
+            split_store4(y, s, X + row * ld + cc + 8 * q, plane);
+        };
+        auto head_quad = [&](f32x16 &a, const float (&b)[16], const float (&w3)[16], float &ep, int q, int row, int cc) {
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const int r = 4 * q + e;
+                const v2f x = v2f{a[r], a[r + 1]} * osc + v2f{b[r], b[r + 1]};
+                const v2f t = x * ia_log2e;
+                const v2f ex = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                const v2f yy = ex * alpha - alpha;
+                const float y0 = __builtin_amdgcn_fmed3f(x.x, yy.x, 0.f), y1 = __builtin_amdgcn_fmed3f(x.y, yy.y, 0.f);
+                ep = __builtin_fmaf(y0, w3[r], ep);
+                ep = __builtin_fmaf(y1, w3[r + 1], ep);
+                y[e] = 0.125f * w3[r] * fminf(ex.x, 1.0f);
+                y[e + 1] = 0.125f * w3[r + 1] * fminf(ex.y, 1.0f);
+            }
+            split_store4(y, s2, X2 + row * LD2 + cc + 8 * q, ROWS * LD2);
+        };
+        // ---- phase 0: N = NB1 (A = cb w, B = cb 4 + w, both row blocks), K = 2 NS from the kept slabs
+        {
+            auto addr0 = [&](int k) {
+                const int row = fr, sw = (row >> 2) & 3;
+                return slot0 + (k >> 1) * SLABU + row * 32 + (((2 * (k & 1) + fk) ^ sw) << 3);
+            };
+            ring_start<D>(rA, wm + W0, wave, 2 * NS, lane);
+            ring_start<D>(rB, wm + W0, b0s.cb, 2 * NS, lane);
+            cols16(cm, wave, colA); cols16(cm, b0s.cb, colB);
+            zero(accA[0]); zero(accA[1]); zero(accB[0]); zero(accB[1]);
+            dual_gemm<2, 2 * NS, D>(accA, accB, rA, rB, addr0, addr0, ROWS * 32, 32 * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                fwd_quad(accA[q >> 2], colA, d0A[q >> 2], q & 3, osc, s0, X0, LD0, ROWS * LD0, (q >> 2) * 32 + fr, wave * 32 + 4 * fk);
+                fwd_quad(accB[q >> 2], colB, d0B[q >> 2], q & 3, osc, s0, X0, LD0, ROWS * LD0, (q >> 2) * 32 + fr, b0s.cb * 32 + 4 * fk);
+            }
+            __syncthreads();
+        }
+        // ---- phase 1: N = NB2 (A = cb w both rb, B = one row block of cb 4 / 5), K = 2 NB1
+        {
+            auto addrA = [&](int k) { return X0 + fr * LD0 + k * 16 + fk * 8; };
+            auto addrB = [&](int k) { return X0 + (b1s.rb * 32 + fr) * LD0 + k * 16 + fk * 8; };
+            ring_start<D>(rA, wm + W1, wave, 2 * NB1, lane);
+            ring_start<D>(rB, wm + W1, b1s.cb, 2 * NB1, lane);
+            cols16(cm + 256, wave, colA); cols16(cm + 256, b1s.cb, colB);
+            zero(accA[0]); zero(accA[1]); zero(accB[0]);
+            dual_gemm<1, 2 * NB1, D>(accA, accB, rA, rB, addrA, addrB, ROWS * LD0, 32 * LD0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                fwd_quad(accA[q >> 2], colA, d1A[q >> 2], q & 3, osc, s1, X1, LD1, ROWS * LD1, (q >> 2) * 32 + fr, wave * 32 + 4 * fk);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                fwd_quad(accB[0], colB, d1B, q, osc, s1, X1, LD1, ROWS * LD1, b1s.rb * 32 + fr, b1s.cb * 32 + 4 * fk);
+            __syncthreads();
+        }
+        // ---- phase 2: N = NB3 (A = cb w; waves 0, 1 also a row block of cb 4), K = 2 NB2; head + seed
+        float eA[2] = {0.f, 0.f}, eB = 0.f;
+        {
+            auto addrA = [&](int k) { return X1 + fr * LD1 + k * 16 + fk * 8; };
+            auto addrB = [&](int k) { return X1 + (b2s.rb * 32 + fr) * LD1 + k * 16 + fk * 8; };
+            ring_start<D>(rA, wm + W2, wave, 2 * NB2, lane);
+            ring_start<D>(rB, wm + W2, b2s.cb, 2 * NB2, lane);
+            cols16(cm + 512, wave, colA); cols16(cm + 768, wave, w3A);
+            cols16(cm + 512, b2s.cb, colB); cols16(cm + 768, b2s.cb, w3B);
+            zero(accA[0]); zero(accA[1]); zero(accB[0]);
+            if (b2s.kind) dual_gemm<1, 2 * NB2, D>(accA, accB, rA, rB, addrA, addrB, ROWS * LD1, 32 * LD1);
+            else dual_gemm<0, 2 * NB2, D>(accA, accB, rA, rB, addrA, addrB, ROWS * LD1, 32 * LD1);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) head_quad(accA[q >> 2], colA, w3A, eA[q >> 2], q & 3, (q >> 2) * 32 + fr, wave * 32 + 4 * fk);
+            if (b2s.kind) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) head_quad(accB[0], colB, w3B, eB, q, b2s.rb * 32 + fr, b2s.cb * 32 + 4 * fk);
+            }
+            float ea = eA[0] + __shfl_xor(eA[0], 32), eb = eA[1] + __shfl_xor(eA[1], 32);
+            const float ex_ = eB + __shfl_xor(eB, 32);
+            if (b2s.kind) { if (b2s.rb == 0) ea += ex_; else eb += ex_; }
+            if (fk == 0) { s_e[wave * 64 + fr] = ea; s_e[wave * 64 + 32 + fr] = eb; }
+            __syncthreads();
+            if (tid < 64) g.energy[item * 64 + tid] = s_e[tid] + s_e[64 + tid] + s_e[128 + tid] + s_e[192 + tid];
+        }
+        // ---- phase 3: N = NB2, K = 2 NB3
+        {
+            auto addrA = [&](int k) { return X2 + fr * LD2 + k * 16 + fk * 8; };
+            auto addrB = [&](int k) { return X2 + (b1s.rb * 32 + fr) * LD2 + k * 16 + fk * 8; };
+            ring_start<D>(rA, wm + W2T, wave, 2 * NB3, lane);
+            ring_start<D>(rB, wm + W2T, b1s.cb, 2 * NB3, lane);
+            zero(accA[0]); zero(accA[1]); zero(accB[0]);
+            dual_gemm<1, 2 * NB3, D>(accA, accB, rA, rB, addrA, addrB, ROWS * LD2, 32 * LD2);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                bwd_quad(accA[q >> 2], d1A[q >> 2], q & 3, osc, s3, X1, LD1, ROWS * LD1, (q >> 2) * 32 + fr, wave * 32 + 4 * fk);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bwd_quad(accB[0], d1B, q, osc, s3, X1, LD1, ROWS * LD1, b1s.rb * 32 + fr, b1s.cb * 32 + 4 * fk);
+            __syncthreads();
+        }
+        // ---- phase 4: N = NB1, K = 2 NB2
+        {
+            auto addrA = [&](int k) { return X1 + fr * LD1 + k * 16 + fk * 8; };
+            ring_start<D>(rA, wm + W1T, wave, 2 * NB2, lane);
+            ring_start<D>(rB, wm + W1T, b0s.cb, 2 * NB2, lane);
+            zero(accA[0]); zero(accA[1]); zero(accB[0]); zero(accB[1]);
+            dual_gemm<2, 2 * NB2, D>(accA, accB, rA, rB, addrA, addrA, ROWS * LD1, 32 * LD1);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                bwd_quad(accA[q >> 2], d0A[q >> 2], q & 3, osc, s4, X0, LD0, ROWS * LD0, (q >> 2) * 32 + fr, wave * 32 + 4 * fk);
+                bwd_quad(accB[q >> 2], d0B[q >> 2], q & 3, osc, s4, X0, LD0, ROWS * LD0, (q >> 2) * 32 + fr, b0s.cb * 32 + 4 * fk);
+            }
+            __syncthreads();
+        }
+        // ---- phase 5: one slab per wave, whole K, the tile leaves through a wave-private LDS tile (whole lines per store)
+        {
+            auto addrA = [&](int k) { return X0 + fr * LD0 + k * 16 + fk * 8; };
+            ring_start<D>(rA, wm + W0T, wave, 2 * NB1, lane);
+            v4f prev[2][4];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    const int row = p4 * 8 + (lane >> 3), piece = lane & 7;
+                    prev[rb][p4] = *(const gf4 *)(g.grad + (item * 64 + rb * 32 + row) * 128 + wave * 32 + 4 * piece);
+                }
+            zero(accA[0]); zero(accA[1]);
+            dual_gemm<0, 2 * NB1, D>(accA, accB, rA, rB, addrA, addrA, ROWS * LD0, 32 * LD0);
+            float *tile = reinterpret_cast<float *>(X1) + wave * 2048;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = accA[rb][4 * q + e] * osc;
+                    *reinterpret_cast<v4f *>(tile + rb * 1024 + fr * 32 + (((2 * q + fk) ^ (fr >> 1)) & 7) * 4) = v;
+                }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    const int row = p4 * 8 + (lane >> 3), piece = lane & 7;
+                    const v4f t = *reinterpret_cast<const v4f *>(tile + rb * 1024 + row * 32 + (((piece ^ (row >> 1)) & 7) << 2));
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = t[e] + prev[rb][p4][e];
+                    *reinterpret_cast<v4f *>(g.grad + (item * 64 + rb * 32 + row) * 128 + wave * 32 + 4 * piece) = v;
+                }
+            __syncthreads();
+        }
+    }
+    if (lane == 0 && wave == 0) g.cyc[blockIdx.x] = __builtin_readcyclecounter() - t0;
+}
+
 template <class K>
 static void run(const char *name, K kern, int threads, Args a, int nwg)
 {
@@ -774,6 +1013,8 @@ int main(int argc, char **argv)
     printf("data: %s\n", zero_data ? "ZEROS (weights and layer-0 operand)" : "random");
     printf("LDS %zu bytes per workgroup, %d items per workgroup, %d workgroups\n", LDS_BYTES, items, nwg);
     run("SEQ8  (shipped structure, ring 6)", k_seq8<6>, 512, a, nwg);
+    run("SEQ4  (shipped structure on 4 waves, ring 4)", k_seq4<4>, 256, a, nwg);
+    run("SEQ4  (shipped structure on 4 waves, ring 6)", k_seq4<6>, 256, a, nwg);
     run("PIPE4 interleaved, ring 4", k_pipe4<true, 4>, 256, a, nwg);
     run("PIPE4 interleaved, ring 6", k_pipe4<true, 6>, 256, a, nwg);
     run("PIPE4 epilogues behind their segments, ring 4", k_pipe4<false, 4>, 256, a, nwg);
