@@ -430,10 +430,13 @@ def main():
         del full
     ae = torch.zeros(n_local, dtype=torch.float32, device=dev)
     gaev = torch.zeros_like(aev)
+    # (the flags the step itself hands to the network stage: models.ANI._tile_hint -- one launch per species with compile-time
+    # network widths where every species present has many rounds of tiles -- + the opt-in two-product backward)
+    stage_hint = model._tile_hint(sp_given, sp32, hi - lo) | (_lib.MLP_FLAG_BWD_TWO_PRODUCTS if args.two_product_backward else 0)
     st["mlp_fwd_bwd"] = time_stage(
         lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev, chunk=model.mlp_chunk,
                                         slab_mask=mask, shard_rows=True,
-                                        tile_hint=_lib.MLP_FLAG_BWD_TWO_PRODUCTS if args.two_product_backward else 0), reps)
+                                        tile_hint=stage_hint), reps)
     if not args.no_dense_stage:
         st["mlp_fwd_bwd_dense"] = time_stage(
             lambda: packed.forward_backward(sp32, aev, lo=lo, hi=hi, atomic_e=ae, grad_aev=gaev,
@@ -559,7 +562,8 @@ def main():
             "avg_launch_ms": st["neighbors"],
         },
         "roofline_mfma": {
-            "kernel": "ensemble fwd + input-gradient bwd: k_mlp_fused<2,1,CELU,L0B> (layer 0 over flagged AEV slabs + hidden "
+            "kernel": "ensemble fwd + input-gradient bwd: k_mlp_fused<2,1,CELU,L0B,H1,H2,H3> on 16x16x32 MFMA tiles, one launch per "
+                      "species with compile-time network widths (layer 0 over flagged AEV slabs + hidden "
                       "stack + backward + layer-0 backward as phase 5: a workgroup owns a tile through all members), "
                       f"precision {packed.precision}",
             "traffic": mlp_traffic,   # HBM bytes of the stage per step from the committed counter file (round 3: 51.8e9)

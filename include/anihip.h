@@ -306,8 +306,13 @@ typedef struct {
 /* (16, 64, 128, 256: development switches of rounds 1-4 -- 32-atom tiles, separate preparation launches, the 4-wave
  * layer-0 backward, tile-owner order without phase 5 -- retired in ABI 11; setting them changes nothing) */
 #define ANIHIP_MLP_FLAG_D0_ROWS 32u       /* d E/d act0 handed to the layer-0 backward row-major, not tile-major */
-#define ANIHIP_MLP_FLAG_FUSED_L0B 512u    /* layer-0 backward inside the fused kernel whatever the size (default: from 65536 atoms) */
+#define ANIHIP_MLP_FLAG_FUSED_L0B 512u    /* layer-0 backward inside the fused kernel whatever the size (default: from 24000 atoms) */
 #define ANIHIP_MLP_FLAG_NO_FUSED_L0B 1024u /* ... never: d E/d act0 through HBM + a layer-0 backward GEMM launch */
+#define ANIHIP_MLP_FLAG_SHAPED 4096u       /* with the layer-0 backward inside the fused kernel: ONE LAUNCH PER SPECIES, restricted to its tiles, with the
+                                             * network widths as compile-time constants where an instantiation exists (every ANI-2x network) -- 6 % faster
+                                             * per tile, but every launch ends with a partly filled last round of the CUs (one tile through all members:
+                                             * ~0.2 ms), so a caller sets it only when every PRESENT species has many rounds of tiles (the Python host:
+                                             * total rounds >= 25 x species present; 2.3 M-atom water box: 143 rounds for 2 species) */
 #define ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS 2048u /* OFF by default.  With the layer-0 backward inside the fused kernel (>= 65536 atoms,
                                                  * CELU): its backward GEMMs leave out (weight lo) x (gradient hi), i.e. use the weights
                                                  * rounded to fp16 -- energies unchanged, d E/d AEV and the forces differ from the default's

@@ -547,7 +547,7 @@ def test_charge_networks_pack_and_normalizer():
 
 
 def test_layer0_tile_hint_from_composition():
-    """ANI._tile_hint: 128-row layer-0 backward tiles between 16 384 and 65 536 atoms when four or more elements are
+    """ANI._tile_hint: 128-row layer-0 backward tiles between 16 384 and 24 000 atoms when four or more elements are
     present, the library's default otherwise; cached per species tensor (held, so its address is not recycled)."""
     import warnings
 
@@ -566,6 +566,12 @@ def test_layer0_tile_hint_from_composition():
     assert m._tile_hint(water, water, 20000) == 0
     assert m._tile_hint(padded, padded, 20000) == _lib.MLP_FLAG_SMALL_TILES
     assert m._tile_hint(organic, organic, 16383) == 0 and m._tile_hint(organic, organic, 65536) == 0
+    # round 6: from 24 000 atoms on the layer-0 backward runs inside the fused kernel; one launch per species with compile-time
+    # network widths only where every species present has many rounds of tiles (>= 25 rounds of the 256 CUs per species)
+    assert m._tile_hint(organic, organic, 24000) == 0
+    assert m._tile_hint(water, water, 2_336_064) == _lib.MLP_FLAG_SHAPED      # 143 rounds, 2 species
+    assert m._tile_hint(organic, organic, 1_000_000) == 0                     # 61 rounds, 5 species
+    assert m._tile_hint(organic, organic, 2_336_064) == _lib.MLP_FLAG_SHAPED  # 143 rounds, 5 species
 
 
 def test_overflow_check_is_skipped_only_where_rows_cannot_overflow():

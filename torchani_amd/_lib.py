@@ -35,6 +35,7 @@ ACT_CELU, ACT_GELU = 0, 1
 # anihip_mlp_desc.flags (ANIHIP_MLP_FLAG_*)
 MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MASK, MLP_FLAG_D0_ROWS = 1, 2, 4, 8, 32
 MLP_FLAG_FUSED_L0B, MLP_FLAG_NO_FUSED_L0B = 512, 1024
+MLP_FLAG_SHAPED = 4096   # one fused launch per species with compile-time network widths (include/anihip.h)
 MLP_FLAG_BWD_TWO_PRODUCTS = 2048   # off by default: two-product backward GEMMs of the large-system path (include/anihip.h)
 ABI_VERSION = 11
 REPACK_FUSED_ONLY = 1

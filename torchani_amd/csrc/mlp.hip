@@ -2627,7 +2627,24 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             ANIHIP_CHECK_HIP(hipMemset(f.trace, 0, sizeof(unsigned long long) * trace_words));
         }
 #endif
-        launch_fused(variant, (unsigned)grid, lds, stream, f);
+        f.only_species = -1;
+        if (variant == FUSED_CELU_L0B && (d->flags & ANIHIP_MLP_FLAG_SHAPED)) {
+            // one launch per species, restricted to its tiles, with the network widths as compile-time constants where an
+            // instantiation exists (every ANI-2x network and ANI-1x hydrogen); a species without atoms exits at once
+            for (int s = 0; s < S; ++s) {
+                const FusedSpecies &fs = f.sp[s];
+                int v = FUSED_CELU_L0B;
+                if (fs.H1 == 256 && fs.H2 == 192 && fs.H3 == 160) v = FUSED_CELU_L0B_256;
+                else if (fs.H1 == 192 && fs.H2 == 160 && fs.H3 == 128) v = FUSED_CELU_L0B_192;
+                else if (fs.H1 == 224 && fs.H2 == 192 && fs.H3 == 160) v = FUSED_CELU_L0B_224;
+                else if (fs.H1 == 160 && fs.H2 == 128 && fs.H3 == 96) v = FUSED_CELU_L0B_160;
+                if (v != FUSED_CELU_L0B) ANIHIP_CHECK_HIP(hipFuncSetAttribute(fused_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                f.only_species = s;
+                launch_fused(v, (unsigned)grid, lds, stream, f);
+            }
+        } else {
+            launch_fused(variant, (unsigned)grid, lds, stream, f);
+        }
 #ifdef ANIHIP_DEV_TRACE
         if (trace_path) {
             ANIHIP_CHECK_HIP(hipStreamSynchronize(stream));

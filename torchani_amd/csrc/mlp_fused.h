@@ -99,6 +99,7 @@ struct FusedArgs {
     int want_grad;
     int l0b;                   // layer-0 backward inside the kernel (needs owner = 1): d E / d AEV -> grad_aev, no d0
     float *grad_aev;           // [n_atoms][L] (l0b): the tile's flagged slabs of its atoms' rows, summed over the members
+    int only_species;          // owner order: the launch takes the tiles of this species only (-1: of every species)
     int owner;                 // item order: 0 = member-major sweep over the tiles; G > 0: a workgroup OWNS its tiles, taken in groups of G
     unsigned long long *trace;   // development builds (-DANIHIP_DEV_TRACE, tools/fused_trace.py): [item][wave][32] stamps
     // TRAIN instantiation (anihip_mlp_train_forward of a split-fp16 pack): everything the weight gradients need leaves the
@@ -111,7 +112,9 @@ struct FusedArgs {
 constexpr int FR_XPAD = 16;       // halves of padding per activation-plane row
 
 // instantiations of k_mlp_fused (csrc/mlp_fused.hip)
-enum FusedVariant { FUSED_CELU = 0, FUSED_CELU_L0B = 1, FUSED_CELU_L0B_B2 = 2, FUSED_GELU = 3, FUSED_TRAIN = 4 };
+enum FusedVariant { FUSED_CELU = 0, FUSED_CELU_L0B = 1, FUSED_CELU_L0B_B2 = 2, FUSED_GELU = 3, FUSED_TRAIN = 4,
+                    // compile-time widths of the ANI-2x networks: H 256 / 192 / 160, N O 192 / 160 / 128, C 224 / 192 / 160, S F Cl 160 / 128 / 96
+                    FUSED_CELU_L0B_256 = 5, FUSED_CELU_L0B_192 = 6, FUSED_CELU_L0B_224 = 7, FUSED_CELU_L0B_160 = 8 };
 const void *fused_kernel(int variant);   // (for hipFuncSetAttribute)
 void launch_fused(int variant, unsigned grid, size_t lds_bytes, hipStream_t stream, const FusedArgs &f);
 

@@ -429,7 +429,11 @@ __device__ __forceinline__ FusedUnit fused_unit(int H, int wave)
 // TRAIN: the forward half of a training step -- the hidden activations and the backward's per-layer gradients are also
 // written to global memory (FusedArgs::tr_*), from the registers of the epilogues that produce them
 // B2: the backward GEMMs (phases 3, 4, 5) with two products instead of three (ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS)
-template <int RB, int NB, int ACT, bool L0B, bool TRAIN = false, bool B2 = false>   // ACT: 0 = CELU(alpha), 1 = GELU (exact, erf)
+// H1C / H2C / H3C > 0: the widths of the networks as compile-time constants (launches restricted to ONE species,
+// FusedArgs::only_species: the k loops unroll, the unit dealing folds) -- instantiated for the ANI-2x hydrogen (256 / 192 / 160) and
+// oxygen / nitrogen (192 / 160 / 128), carbon (224 / 192 / 160) and sulfur / halogen (160 / 128 / 96, also ANI-1x hydrogen) networks;
+// 0: read from the species table
+template <int RB, int NB, int ACT, bool L0B, bool TRAIN = false, bool B2 = false, int H1C = 0, int H2C = 0, int H3C = 0>   // ACT: 0 = CELU(alpha), 1 = GELU (exact, erf)
 __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
 {
     static_assert(!B2 || (L0B && !TRAIN && ACT == 0), "the two-product backward exists for the large-system CELU instantiation");
@@ -523,9 +527,18 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     // head of an item (tile entry -> atom rows -> AEV slabs -> first weight fragments, about 9 k clocks of pure
     // latency when exposed) is issued for item i + 1 while the backward phases of item i run.
     int n_tiles = 0;   // the non-empty tiles come first in the table
-    for (int t = 0; t < g.S; ++t) n_tiles += (g.ctl[CTL_CNT + t] + ROWS - 1) / ROWS;
+    int t_lo = 0;      // owner order restricted to ONE species (only_species >= 0): its tiles t_lo .. n_tiles - 1
+    for (int t = 0; t < g.S; ++t) {
+        const int nt = (g.ctl[CTL_CNT + t] + ROWS - 1) / ROWS;
+        if (g.owner && g.only_species >= 0) {
+            if (t < g.only_species) t_lo += nt;
+            if (t <= g.only_species) n_tiles += nt;
+        } else {
+            n_tiles += nt;
+        }
+    }
     const int n_items = n_tiles * g.M;
-    int item = blockIdx.x;
+    int item = t_lo + blockIdx.x;
     if (item >= (g.owner ? n_tiles : n_items)) return;
 #ifdef ANIHIP_YOUNG_PRIO
     // the second-dispatched half of the workgroup loses the issue arbitration of its SIMD on every segment: static priority
@@ -651,7 +664,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const FusedSpecies &fs = g.sp[s];
         const int64_t tm_base = s_tmb[s];
         const int rel_tile = p0 - s_off[s];
-        const int H1 = fs.H1, H2 = fs.H2, H3 = fs.H3;
+        const int H1 = H1C ? H1C : fs.H1, H2 = H2C ? H2C : fs.H2, H3 = H3C ? H3C : fs.H3;
         // LDS carve (halves): X1 planes [2][ROWS][H2+16] | XU = max(X0 planes [2][ROWS][H1+16], X2 planes)
         const int ld0 = H1 + FR_XPAD, ld1 = H2 + FR_XPAD, ld2 = H3 + FR_XPAD;
         const int x0_plane = ROWS * ld0, x1_plane = ROWS * ld1, x2_plane = ROWS * ld2;
@@ -1232,6 +1245,10 @@ const void *fused_kernel(int variant)
         case FUSED_CELU_L0B_B2: return (const void *)k_mlp_fused<2, 1, 0, true, false, true>;
         case FUSED_GELU: return (const void *)k_mlp_fused<2, 1, 1, false>;
         case FUSED_TRAIN: return (const void *)k_mlp_fused<2, 1, 0, false, true>;
+        case FUSED_CELU_L0B_256: return (const void *)k_mlp_fused<2, 1, 0, true, false, false, 256, 192, 160>;
+        case FUSED_CELU_L0B_192: return (const void *)k_mlp_fused<2, 1, 0, true, false, false, 192, 160, 128>;
+        case FUSED_CELU_L0B_224: return (const void *)k_mlp_fused<2, 1, 0, true, false, false, 224, 192, 160>;
+        case FUSED_CELU_L0B_160: return (const void *)k_mlp_fused<2, 1, 0, true, false, false, 160, 128, 96>;
         default: return (const void *)k_mlp_fused<2, 1, 0, false>;
     }
 }
@@ -1243,6 +1260,10 @@ void launch_fused(int variant, unsigned grid, size_t lds_bytes, hipStream_t stre
         case FUSED_CELU_L0B_B2: hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, true, false, true>), dim3(grid), dim3(512), lds_bytes, stream, f); break;
         case FUSED_GELU: hipLaunchKernelGGL((k_mlp_fused<2, 1, 1, false>), dim3(grid), dim3(512), lds_bytes, stream, f); break;
         case FUSED_TRAIN: hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, false, true>), dim3(grid), dim3(512), lds_bytes, stream, f); break;
+        case FUSED_CELU_L0B_256: hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, true, false, false, 256, 192, 160>), dim3(grid), dim3(512), lds_bytes, stream, f); break;
+        case FUSED_CELU_L0B_192: hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, true, false, false, 192, 160, 128>), dim3(grid), dim3(512), lds_bytes, stream, f); break;
+        case FUSED_CELU_L0B_224: hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, true, false, false, 224, 192, 160>), dim3(grid), dim3(512), lds_bytes, stream, f); break;
+        case FUSED_CELU_L0B_160: hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, true, false, false, 160, 128, 96>), dim3(grid), dim3(512), lds_bytes, stream, f); break;
         default: hipLaunchKernelGGL((k_mlp_fused<2, 1, 0, false>), dim3(grid), dim3(512), lds_bytes, stream, f); break;
     }
 }

@@ -26,7 +26,7 @@ from ._lib import MAX_RAD
 from ._lib import MAX_RAD as _lib_MAX_RAD
 from .constants import GSAES_WB97X_631GD  # noqa: F401
 from . import _lib
-from .engine import FIXED_SCALE, energy_forces_finish, energy_reduce, fixed_to_float
+from .engine import FIXED_SCALE, _n_cus as _n_cus_of, energy_forces_finish, energy_reduce, fixed_to_float
 from .extras.electro import BaseChargeNormalizer, ChargeNormalizer  # noqa: F401
 from .nn import ANINetworks, AtomicNetwork, Ensemble, SelfEnergy, SpeciesConverter
 from .parallel import join_exact, shard_range, split_exact
@@ -298,9 +298,7 @@ class ANI(torch.nn.Module):
         (1C17, solvated 1hz5: DESIGN.md section 6), where 256-row tiles are too few to balance over the CUs.  The number of
         elements present costs one host sync per distinct ``species`` tensor: cached by identity and version, with a
         reference to the tensor so that its address cannot be handed to another one meanwhile."""
-        # (from 24 000 atoms on the layer-0 backward runs inside the fused kernel -- FUSED_L0B_MIN_ATOMS of csrc/mlp.hip, round 6:
-        # 46 357-atom solvated 1hz5 1.18 -> 1.09 ms per step -- and no tiling of a separate backward GEMM is left to choose)
-        if not 16384 <= n_central < 24000:
+        if n_central < 16384:
             return 0
         key = (species.data_ptr(), species._version, tuple(species.shape))
         hit = self.__dict__.get("_n_elem_cache")
@@ -308,7 +306,14 @@ class ANI(torch.nn.Module):
             present = torch.bincount(elem_idxs.reshape(-1).clamp(min=-1) + 1, minlength=len(self.symbols) + 1)[1:]
             hit = (key, int((present > 0).sum()), species)
             self.__dict__["_n_elem_cache"] = hit
-        return _lib.MLP_FLAG_SMALL_TILES if hit[1] >= 4 else 0
+        if n_central < 24000:
+            return _lib.MLP_FLAG_SMALL_TILES if hit[1] >= 4 else 0
+        # Large systems (layer-0 backward inside the fused kernel): one launch per species with compile-time network widths is
+        # 6 % faster per tile (round 6), but every launch ends with a partly filled last round of the 256 CUs -- taken only
+        # when the tiles make at least 25 rounds per species present (2.34 M-atom water box: 143 rounds, 2 species; the 46 k-atom
+        # solvated protein: 3 rounds, 5 species -- there the per-species launches measured 1.9 against 1.1 ms)
+        rounds = n_central / 64.0 / (_n_cus_of(elem_idxs.device) if elem_idxs.is_cuda else 256)
+        return _lib.MLP_FLAG_SHAPED if rounds >= 25.0 * max(1, hit[1]) else 0
 
     # The AEV rows of energies_and_forces are internal: they live in buffers the engine keeps between steps and updates in
     # place (AevEngine.forward_update: zeros are written once, a step rewrites only the slabs that were or are flagged --
