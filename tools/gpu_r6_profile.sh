@@ -85,12 +85,17 @@ for f in glob.glob("gpurun_out/sq_*/**/*counter_collection.csv", recursive=True)
             if name + "<" in k or name + "(" in k:
                 a = acc[name][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
 out = {"n_atoms": 2336064, "workload": "bench.py at the headline size (2336064-atom periodic water box), --steps 1 --warmup 1",
-       "source": "rocprofv3 --pmc, three passes (tools/gpu_r6_profile.sh); mean per dispatch; SQ_WAVE_CYCLES, SQ_WAIT_*, "
+       "source": "rocprofv3 --pmc, three passes (tools/gpu_r6_profile.sh); summed over the launches of a step, mean over the steps; SQ_WAVE_CYCLES, SQ_WAIT_*, "
                  "SQ_ACTIVE_INST_* are quad-cycles summed over the waves, SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE cycles",
        "kernels": {}}
+# (the network kernel runs as one launch per species, some of them empty: counters are summed over a STEP's launches --
+# steps of a pass = dispatches of k_aev_bwd, which runs once per step)
+steps = {c: v[1] for c, v in acc.get("k_aev_bwd", {}).items()}
 for k, d in acc.items():
-    g = {c: v[0] / v[1] for c, v in d.items()}
-    e = {"counters": g, "dispatches": list(d.values())[0][1]}
+    # launches of this kernel per step: 1, or 7 for the per-species launches of the network kernel (a pass also holds a few
+    # extra single launches of the bench's stage timers: mean per dispatch x launches per step)
+    g = {c: v[0] / v[1] * max(1, round(v[1] / max(1, steps.get(c, v[1])))) for c, v in d.items()}
+    e = {"counters_per_step": g, "dispatches": list(d.values())[0][1], "steps": max(steps.values()) if steps else None}
     wc = g.get("SQ_WAVE_CYCLES")
     if wc:
         # share of a resident wave's time in which it issues VALU work / waits / issues anything
@@ -111,5 +116,5 @@ for k, d in acc.items():
     out["kernels"][k] = e
 json.dump(out, open("gpurun_out/r06_pmc_sq.json", "w"), indent=1)
 for k, e in out["kernels"].items():
-    print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in e.items() if a != "counters"})
+    print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in e.items() if a != "counters_per_step"})
 PY
