@@ -68,12 +68,17 @@ typedef struct {
 /* flags: the angular radial shifts ShfA are equally spaced and narrow enough for fp32 exponents -- the forward kernel
  * then evaluates its NA Gaussians per neighbor pair by a three-exponential recurrence instead of NA exponentials. */
 #define ANIHIP_AEV_UNIFORM_SHFA 1
+/* ShfR AND ShfA are equally spaced and every exponent of the chained Gaussians stays inside fp32's range for distances up to
+ * the cutoffs: the backward kernel evaluates its 16 radial Gaussians per neighbor from four of them and its NA angular ones per
+ * neighbor pair from one (products with exp2(+-2 D x) instead of exponentials; constants in free slots of the table). */
+#define ANIHIP_AEV_REC_BWD 2
 
 /* Length in floats of the device constant table consumed by the AEV kernels, and a host-side packer:
  * table = ShfR[32] | ShfA[16] | cos(ShfZ)[16] | sin(ShfZ)[16]  (trig evaluated in double on the
  * fp32-rounded ShfZ) | q_R ShfR[16] | q_A ShfA[16] | cos/2 [16] | sin/2 [16] with
  * q = sqrt(Eta log2 e)  (exp(-Eta x^2) = exp2(-(q x)^2): the kernels keep distances pre-scaled).  The caller uploads
- * it to the device. */
+ * it to the device.  For the 16 / 8 x 4 / 4 x 8 grids the upper halves of the q_A ShfA and cos/2 blocks (slots 104-111,
+ * 120-127) carry the constants of the backward kernel's Gaussian recurrences (ANIHIP_AEV_REC_BWD). */
 #define ANIHIP_AEV_TABLE_FLOATS 144
 int anihip_aev_table_pack(anihip_aev_params *p /* flags are set */, const float *ShfR, const float *ShfA,
                           const float *ShfZ, float *table_out /* host, ANIHIP_AEV_TABLE_FLOATS */);

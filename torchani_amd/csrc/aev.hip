@@ -240,7 +240,11 @@ struct AtomHdr {
 };
 __device__ __forceinline__ uint32_t hdr_load(const uint32_t *meta, const int32_t *species, int64_t i, bool ok)
 {
-    const int lane = lane_id();
+    int lane = lane_id();
+    // (opaque: the per-lane base address below is loop invariant; hoisted out of the atom loop of the backward kernel it is a
+    // 64-bit register pair held -- or spilled: the reload then waits with vmcnt(0) for the prefetch just issued -- through
+    // every phase, for the sake of four vector instructions per atom)
+    asm volatile("" : "+v"(lane));
     // ONE load instruction: lanes 0..5 the meta words, lane 6 the species.  (Two predicated loads into the same register
     // make the second wait for the first -- s_waitcnt vmcnt(0) right behind the issue, i.e. no prefetch at all.)
     const uint32_t *src = lane == META_W ? reinterpret_cast<const uint32_t *>(species + i) : meta + (size_t)i * META_W + lane;
@@ -1103,7 +1107,22 @@ __device__ __forceinline__ void push_grad(float *grad_coords, size_t at, int com
 #ifndef ANIHIP_BWD_WAVES
 #define ANIHIP_BWD_WAVES 4
 #endif
-template <int NA, int NZ, bool VIRIAL, bool FIXED>
+#ifndef ANIHIP_REC_SCOPE
+#define ANIHIP_REC_SCOPE 0
+#endif
+#ifndef ANIHIP_BWD_REC
+#define ANIHIP_BWD_REC 1   // 0: never use the Gaussian recurrences (development A/B)
+#endif
+// REC (ANIHIP_AEV_REC_BWD: equally spaced ShfR and ShfA, constants in the table): Gaussians by recurrence.
+//   radial, 16 shifts s_k = s_0 + k D: four anchors a = 1, 5, 9, 13 evaluated directly, f_a = exp2(-x_a^2), x_a = q r - s_a,
+//   their neighbors as f_(a+m) = f_a gu_a^m K_m, m = -1, 1, 2, with gu_a = exp2(2 D x_a) = gu_9 exp2(-2 D (s_a - s_9)) and
+//   K_m = exp2(-(m D)^2): 6 exponentials and 20 products instead of 16 exponentials; chained in the order (f_a gu) gu, whose
+//   partial products are Gaussians over K_m (never overflow; an anchor that underflows has no significant neighbor).  The
+//   K_m and the shifts ride on the packed FMA: sum_k w_k f_k (1, q r - s_k) = (A, q r A - B), (A, B) = sum (w_k h_k) (K_m, K_m s_k).
+//   angular, NA shifts: ONE anchor c = NA / 2 - 1 and powers of gu = exp2(2 D x), gd = 1 / gu; f_c is common to all NA terms and
+//   multiplies the contracted sums once:  sum_u w_u f_u (1, x - m D) = f_c (X, x X - Y), (X, Y) = sum (w_u gu^m) (K_m, m D K_m):
+//   3 exponentials and 2 NA - 3 products instead of NA exponentials and 3 NA products.
+template <int NA, int NZ, bool VIRIAL, bool FIXED, bool REC>
 __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
     AevArgs a, const float *__restrict__ tab, int64_t lo64, int64_t hi64,
     const int32_t *__restrict__ species, const uint32_t *__restrict__ meta,
@@ -1140,14 +1159,19 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
     const float qR = a.qR, qA = a.qA;
     float shfAq[NA], cZh[NZ], sZh[NZ], shfRq[16];   // wave-uniform (scalar registers)
 #pragma unroll
-    for (int u = 0; u < NA; ++u) shfAq[u] = tab[TAB_SHFAQ + u];
+    for (int u = 0; u < NA; ++u) shfAq[u] = REC ? 0.f : tab[TAB_SHFAQ + u];
 #pragma unroll
     for (int v = 0; v < NZ; ++v) {   // halves: h = 0.5 + 0.5 cos(theta - ShfZ)
         cZh[v] = tab[TAB_COSZH + v];
         sZh[v] = tab[TAB_SINZH + v];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) shfRq[k] = tab[TAB_SHFRQ + k];
+    for (int k = 0; k < 16; ++k) shfRq[k] = REC ? 0.f : tab[TAB_SHFRQ + k];
+    // REC: wave-uniform constants of the recurrences (scalar registers)
+    constexpr int CA = NA / 2 - 1;
+    // (REC: the constants of the recurrences are fetched by scalar loads at the head of the phase that uses them, from an opaque
+    // copy of the table pointer -- hoisted out of the atom loop they overflow the scalar register file together with the other
+    // phase's, and every use of a spilled one is a v_readlane on the vector ALU this kernel is bound by)
     const float pi_rcr = PI_F / a.Rcr, pi_rca = PI_F / a.Rca;
     // factors pulled out of the inner sums (see phase 2): d f2 / d rm = kap (q d) f2, d f1 / d theta = -2 zeta p1 (sz / 2)
     const float kap = -2.0f * a.EtaA / qA, kth0 = 2.0f * 0.95f * a.Zeta, kR2 = -2.0f * a.EtaR / qR;
@@ -1234,6 +1258,16 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
             wave_sync();
             TR_STAMP(1)   // stage own dE/dAEV row
             // ---- phase 1 (lane = neighbor) ----
+            const float *tab1 = tab;
+#if ANIHIP_REC_SCOPE & 1
+            asm volatile("" : "+s"(tab1));
+#endif
+            const float twoDR = tab1[TAB_RECR];
+            const float KR1 = tab1[TAB_RECR + 1], KR1D = tab1[TAB_RECR + 2], KR2 = tab1[TAB_RECR + 3], KR2D = tab1[TAB_RECR + 4];
+            // gu_a / gu_9, gd_a / gd_9 of anchor a = 4 g + 1
+            const float GU[4] = {tab1[TAB_RECR + 6], tab1[TAB_RECR + 5], 1.0f, tab1[TAB_RECR + 7]};
+            const float GD[4] = {tab1[TAB_RECR + 8], tab1[TAB_RECR + 7], 1.0f, tab1[TAB_RECR + 5]};
+            const float sA[4] = {tab1[TAB_SHFRQ + 1], tab1[TAB_SHFRQ + 5], tab1[TAB_SHFRQ + 9], tab1[TAB_SHFRQ + 13]};
             const float *grow0 = grad_aev + (size_t)(spi < 0 ? 0 : spi) * 16;
             const int sbit = spi >> 1;
             for (int c0 = 0; c0 < nR; c0 += WAVE) {
@@ -1278,11 +1312,36 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
                 // cannot take -- one more move per shift, 16 per pass)
                 asm volatile("" : "+v"(rq));
                 v2f AB = (v2f){0.f, 0.f};   // sum w e, sum w e (q d)
+                if constexpr (REC) {
+                    const float eb = twoDR * (rq - sA[2]);
+                    const float gub = __builtin_amdgcn_exp2f(eb), gdb = __builtin_amdgcn_exp2f(-eb);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const float dq = rq - shfRq[k];
-                    const float we = wk[k] * __builtin_amdgcn_exp2f(-dq * dq);
-                    AB += (v2f){we, we} * (v2f){1.0f, dq};
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        // the group's four shifts s_a + m D, m = -1 .. 2:  P = sum_m (w h)_m (K_m, m D K_m), and
+                        // sum_m w f (1, x_a - m D) = (P.x, x_a P.x - P.y)
+                        // (one group after the other: interleaved, the four groups' temporaries push the next atom's prefetched
+                        // rows out of the register file)
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float4 Wg = wo[g4], Gg = g4 == 0 ? G0 : g4 == 1 ? G1 : g4 == 2 ? G2 : G3;
+                        const float xg = rq - sA[g4];
+                        const float gu = g4 == 2 ? gub : gub * GU[g4], gd = g4 == 2 ? gdb : gdb * GD[g4];
+                        const float h1 = __builtin_amdgcn_exp2f(-xg * xg);
+                        const float h0 = h1 * gd, h2 = h1 * gu, h3 = h2 * gu;
+                        const float w0 = (Wg.x + Gg.x) * h0, w1 = (Wg.y + Gg.y) * h1, w2 = (Wg.z + Gg.z) * h2, w3 = (Wg.w + Gg.w) * h3;
+                        v2f P = (v2f){w1, 0.f};
+                        P += (v2f){w0, w0} * (v2f){KR1, -KR1D};
+                        P += (v2f){w2, w2} * (v2f){KR1, KR1D};
+                        P += (v2f){w3, w3} * (v2f){KR2, KR2D};
+                        AB += (v2f){P.x, P.x} * (v2f){1.0f, xg};
+                        AB.y -= P.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float dq = rq - shfRq[k];
+                        const float we = wk[k] * __builtin_amdgcn_exp2f(-dq * dq);
+                        AB += (v2f){we, we} * (v2f){1.0f, dq};
+                    }
                 }
                 float dR = dfcr * AB.x + kR2 * fcr * AB.y;
                 dR = ve ? dR : 0.f;
@@ -1325,6 +1384,18 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
         TR_STAMP(3)   // prefetch issue
 
         // ---- phase 2 (lane = (angular neighbor j, part)) ----
+        const float *tab2 = tab;
+#if ANIHIP_REC_SCOPE & 2
+        asm volatile("" : "+s"(tab2));
+#endif
+        const float twoDA = tab2[TAB_RECA], sC = tab2[TAB_SHFAQ + CA];
+        float KA[5], KAD[5];         // K_m, m D K_m, m = 0 .. 4
+        KA[0] = 1.0f; KAD[0] = 0.f;
+#pragma unroll
+        for (int m = 1; m <= 4; ++m) {
+            KA[m] = tab2[TAB_RECAK + 2 * (m - 1)];
+            KAD[m] = tab2[TAB_RECAK + 2 * (m - 1) + 1];
+        }
         const int n = nA;
         const int dv = (n - 1) >> 1;                 // partners per neighbor in the tournament
         const bool even = (n & 1) == 0;
@@ -1374,18 +1445,48 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
                 v2f XY[NZ];
 #pragma unroll
                 for (int z = 0; z < NZ; ++z) XY[z] = (v2f){0.f, 0.f};
+                float xC = 0.f, fC = 1.0f;   // REC: scaled distance from the anchor shift, the anchor's Gaussian
+                if constexpr (REC) {
+                    xC = srq - sC;
+                    const float e = twoDA * xC;
+                    fC = __builtin_amdgcn_exp2f(-xC * xC);
+                    float pw[NA];   // gu^m of shift u = CA + m
+                    pw[CA] = 1.0f;
+                    pw[CA + 1] = __builtin_amdgcn_exp2f(e);
 #pragma unroll
-                for (int u = 0; u < NA; ++u) {
-                    const float dq = srq - shfAq[u];
-                    const float f2 = __builtin_amdgcn_exp2f(-dq * dq);
-                    const v2f F = (v2f){f2, dq * f2};
+                    for (int u = CA + 2; u < NA; ++u) pw[u] = pw[u - 1] * pw[CA + 1];
+                    if constexpr (CA > 0) {
+                        pw[CA - 1] = __builtin_amdgcn_exp2f(-e);
 #pragma unroll
-                    for (int zq = 0; zq < ZQ; ++zq) {
-                        const float4 w4 = wb[u * ZQ + zq];
-                        XY[4 * zq + 0] += (v2f){w4.x, w4.x} * F;
-                        XY[4 * zq + 1] += (v2f){w4.y, w4.y} * F;
-                        XY[4 * zq + 2] += (v2f){w4.z, w4.z} * F;
-                        XY[4 * zq + 3] += (v2f){w4.w, w4.w} * F;
+                        for (int u = CA - 2; u >= 0; --u) pw[u] = pw[u + 1] * pw[CA - 1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < NA; ++u) {
+                        const int m = u - CA;
+                        const v2f F = (v2f){pw[u], pw[u]} * (v2f){KA[m < 0 ? -m : m], m < 0 ? -KAD[-m] : KAD[m]};
+#pragma unroll
+                        for (int zq = 0; zq < ZQ; ++zq) {
+                            const float4 w4 = wb[u * ZQ + zq];
+                            XY[4 * zq + 0] += (v2f){w4.x, w4.x} * F;
+                            XY[4 * zq + 1] += (v2f){w4.y, w4.y} * F;
+                            XY[4 * zq + 2] += (v2f){w4.z, w4.z} * F;
+                            XY[4 * zq + 3] += (v2f){w4.w, w4.w} * F;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NA; ++u) {
+                        const float dq = srq - shfAq[u];
+                        const float f2 = __builtin_amdgcn_exp2f(-dq * dq);
+                        const v2f F = (v2f){f2, dq * f2};
+#pragma unroll
+                        for (int zq = 0; zq < ZQ; ++zq) {
+                            const float4 w4 = wb[u * ZQ + zq];
+                            XY[4 * zq + 0] += (v2f){w4.x, w4.x} * F;
+                            XY[4 * zq + 1] += (v2f){w4.y, w4.y} * F;
+                            XY[4 * zq + 2] += (v2f){w4.z, w4.z} * F;
+                            XY[4 * zq + 3] += (v2f){w4.w, w4.w} * F;
+                        }
                     }
                 }
                 // C0 = sum w f1 f2 = 2 c0h, Cth = sum w f1' f2 = -2 zeta cth, CR = sum w f1 f2' = 2 kap crh
@@ -1395,6 +1496,10 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
                 for (int z = 0; z < NZ; ++z) {
                     cc += (v2f){XY[z].x, XY[z].x} * fd[z];
                     crh += XY[z].y * fd[z].x;
+                }
+                if constexpr (REC) {   // (X, Y) -> f_c (X, x X - Y)
+                    crh = fC * (xC * cc.x - crh);
+                    cc = cc * fC;
                 }
                 const float m = v ? 1.0f : 0.0f;
                 const float fcc = m * FJ.x * FK.x;
@@ -1532,6 +1637,43 @@ extern "C" int anihip_aev_table_pack(anihip_aev_params *p, const float *ShfR, co
         const float xm = fmaxf(fabsf(qA * p->Rca - t[TAB_SHFAQ + c]), fabsf(t[TAB_SHFAQ + c]));
         if (ok && xm * xm < 100.f && 2.0f * D * xm < 100.f) p->flags |= ANIHIP_AEV_UNIFORM_SHFA;
     }
+    // Gaussian recurrences of the backward kernel (k_aev_bwd<.., REC>): both shift arrays equally spaced.  Everything in double
+    // from the fp32 arrays: a spacing taken as the difference of two fp32 products is 3e-7 off, and it is multiplied by
+    // scaled distances of up to 13.
+    {
+        const int na = p->n_shf_a, ca = na / 2 - 1, nr = p->n_shf_r;
+        const double qa = sqrt((double)p->EtaA * (double)LOG2E), qr = sqrt((double)p->EtaR * (double)LOG2E);
+        const double DA = qa * ((double)ShfA[na - 1] - (double)ShfA[0]) / (na - 1);
+        const double DR = qr * ((double)ShfR[nr - 1] - (double)ShfR[0]) / (nr - 1);
+        bool ok = DA > 0. && DR > 0.;
+        for (int k = 0; k < na; ++k) ok = ok && fabs(qa * ((double)ShfA[k] - (double)ShfA[0]) - k * DA) < 1e-5 * DA;
+        for (int k = 0; k < nr; ++k) ok = ok && fabs(qr * ((double)ShfR[k] - (double)ShfR[0]) - k * DR) < 1e-5 * DR;
+        // angular: powers gu^m, |m| <= NA / 2, of gu = exp2(2 D_A x), x = q_A (r_mean - ShfA[ca]), r_mean in 0 .. Rca
+        const double xa = fmax(fabs(qa * ((double)p->Rca - (double)ShfA[ca])), fabs(qa * (double)ShfA[ca]));
+        ok = ok && (na / 2) * 2. * DA * xa < 110. && (na / 2) * (na / 2) * DA * DA < 110.;
+        // radial: gu = exp2(2 D_R x) exp2(+-16 D_R^2), x = q_R (r - ShfR[9]), r in 0 .. Rcr; chained values <= exp2(4 D_R^2)
+        const double xr = fmax(fabs(qr * ((double)p->Rcr - (double)ShfR[9])), fabs(qr * (double)ShfR[9]));
+        ok = ok && 2. * DR * xr + 16. * DR * DR < 110.;
+        if (ok) {
+            p->flags |= ANIHIP_AEV_REC_BWD;
+            t[TAB_RECA] = (float)(2. * DA);
+            for (int m = 1; m <= 4; ++m) {
+                const double K = exp2(-(m * DA) * (m * DA));
+                t[TAB_RECAK + 2 * (m - 1)] = (float)K;
+                t[TAB_RECAK + 2 * (m - 1) + 1] = (float)(m * DA * K);
+            }
+            const double K1 = exp2(-DR * DR), K2 = exp2(-4. * DR * DR);
+            t[TAB_RECR + 0] = (float)(2. * DR);
+            t[TAB_RECR + 1] = (float)K1;
+            t[TAB_RECR + 2] = (float)(DR * K1);
+            t[TAB_RECR + 3] = (float)K2;
+            t[TAB_RECR + 4] = (float)(2. * DR * K2);
+            t[TAB_RECR + 5] = (float)exp2(8. * DR * DR);
+            t[TAB_RECR + 6] = (float)exp2(16. * DR * DR);
+            t[TAB_RECR + 7] = (float)exp2(-8. * DR * DR);
+            t[TAB_RECR + 8] = (float)exp2(-16. * DR * DR);
+        }
+    }
     return 0;
 }
 
@@ -1663,9 +1805,14 @@ static int aev_backward(void *stream, const anihip_aev_params *p, const float *t
     hipStream_t st = (hipStream_t)stream;
     const bool symmetric = (flags & ANIHIP_BWD_SYMMETRIC) != 0, fixed = (flags & ANIHIP_BWD_FIXED_POINT) != 0;
     const int64_t glo = symmetric ? lo : 0, ghi = symmetric ? hi : 0;   // rows the radial gather may read
-#define ANIHIP_LAUNCH_BWD(NA_, NZ_, VIR_, FIX_)                                                                      \
-    hipLaunchKernelGGL((k_aev_bwd<NA_, NZ_, VIR_, FIX_>), grid, block, 0, st, a, table, lo, hi, species, meta, e4,   \
-                       grad_aev, grad_coords, virial, slab_mask, glo, ghi)
+    const bool rec = (p->flags & ANIHIP_AEV_REC_BWD) != 0 && ANIHIP_BWD_REC;
+#define ANIHIP_LAUNCH_BWD(NA_, NZ_, VIR_, FIX_)                                                                              \
+    if (rec)                                                                                                                 \
+        hipLaunchKernelGGL((k_aev_bwd<NA_, NZ_, VIR_, FIX_, true>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, \
+                           grad_aev, grad_coords, virial, slab_mask, glo, ghi);                                              \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((k_aev_bwd<NA_, NZ_, VIR_, FIX_, false>), grid, block, 0, st, a, table, lo, hi, species, meta, e4, \
+                           grad_aev, grad_coords, virial, slab_mask, glo, ghi)
     const int variant = (p->n_shf_a == 8 ? 0 : 4) + (virial ? 2 : 0) + (fixed ? 1 : 0);
     switch (variant) {
         case 0: ANIHIP_LAUNCH_BWD(8, 4, false, false); break;

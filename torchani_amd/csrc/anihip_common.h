@@ -18,6 +18,13 @@ constexpr uint32_t SP_PAD = 7u;             // species code of a padding atom in
 // offsets into the constant table (anihip_aev_table_pack)
 constexpr int TAB_SHFR = 0, TAB_SHFA = 32, TAB_COSZ = 48, TAB_SINZ = 64;
 constexpr int TAB_SHFRQ = 80, TAB_SHFAQ = 96, TAB_COSZH = 112, TAB_SINZH = 128;   // pre-scaled copies
+// Gaussian recurrences of the backward kernel (ANIHIP_AEV_REC_BWD; 16 / 8 x 4 / 4 x 8 grids only, whose ShfR block uses
+// sixteen of its 32 slots and whose q_A ShfA and sin / 2 blocks use at most eight of their sixteen): D = spacing of
+// the pre-scaled shifts, K_m = exp2(-(m D)^2), all evaluated in double from the fp32 shift arrays (every wave-uniform product
+// is made on the host: gfx950 has no scalar float multiply, uniform products made in the kernel would sit in vector registers)
+constexpr int TAB_RECR = 16;    // 2 D_R | K_1 | D_R K_1 | K_2 | 2 D_R K_2 | exp2(8 D_R^2) | exp2(16 D_R^2) | exp2(-8 D_R^2) | exp2(-16 D_R^2)
+constexpr int TAB_RECA = 104;   // 2 D_A
+constexpr int TAB_RECAK = 136;  // (K_m, m D_A K_m), m = 1 .. 4
 
 void set_error(const char *fmt, ...);
 
