@@ -49,9 +49,9 @@ def test_struct_layouts_match_header(lib):
     n = 1000
     need = lib.anihip_mlp_workspace_bytes(ctypes.byref(d), n)
     acts = 4 * 8 * (256 + 192 + 160) * (n + 1)
-    tiles = (n + 63) // 64 + 8   # tile table of the fused kernel: 16-B entry + 64 atom rows per tile
+    tiles = (n + 63) // 64 + 8   # tile table of the fused kernel: 16-B entry + 64 atom rows per tile, and its cost-sorted copy
     d0_pad = 4 * 8 * 256 * 64 * 8   # layer 0 doubles as the tile-major d E/d act0 buffer: + 64 rows per species slot
-    assert acts <= need <= acts + d0_pad + 4 * (n + 1) * (1 + 8) + (16 + 256) * tiles + 64 * 256
+    assert acts <= need <= acts + d0_pad + 4 * (n + 1) * (1 + 8) + 2 * (16 + 256) * tiles + 66 * 256
     # one forward_backward call of a descriptor the fused kernel cannot serve (no fp16 planes here): the same buffers
     assert lib.anihip_mlp_forward_backward_workspace_bytes(ctypes.byref(d), n, 1) == need
     # training pass: the activations are kept and every hidden layer gets a gradient buffer of the same size
@@ -127,6 +127,39 @@ def test_aev_table_pack_matches_constants(lib):
     z = np.asarray(c.ShfZ, dtype=np.float32).astype(np.float64)
     assert np.allclose(t[48:52], np.cos(z), atol=1e-7) and np.allclose(t[64:68], np.sin(z), atol=1e-7)
     assert c.out_dim == 1008 and c.radial_len == 112 and c.angular_len == 896
+
+
+def test_aev_table_pack_recurrence_constants(lib):
+    """ANIHIP_AEV_REC_BWD: equally spaced ShfR and ShfA give the backward kernel's recurrence constants (double precision on the
+    host, free slots of the table: csrc/anihip_common.h TAB_RECR / TAB_RECA / TAB_RECAK); any unequal spacing clears the flag."""
+    from torchani_amd.constants import aev_constants_1x, aev_constants_2x
+    from torchani_amd.engine import AevEngine
+
+    for c in (aev_constants_2x(), aev_constants_1x()):
+        e = AevEngine(c)
+        t = e.host_table().astype(np.float64)
+        assert e.params.flags & 2 and e.params.flags & 1
+        log2e = 1.4426950408889634
+        shfr, shfa = (np.asarray(v, dtype=np.float32).astype(np.float64) for v in (c.ShfR, c.ShfA))
+        qr, qa = np.sqrt(np.float64(np.float32(c.EtaR)) * np.float64(np.float32(log2e))), np.sqrt(
+            np.float64(np.float32(c.EtaA)) * np.float64(np.float32(log2e)))
+        DR, DA = qr * (shfr[-1] - shfr[0]) / 15, qa * (shfa[-1] - shfa[0]) / (len(shfa) - 1)
+        rel = lambda a, b: abs(a - b) / abs(b)   # noqa: E731
+        assert rel(t[16], 2 * DR) < 2e-7 and rel(t[104], 2 * DA) < 2e-7
+        assert rel(t[17], 2.0 ** -(DR * DR)) < 2e-7 and rel(t[18], DR * 2.0 ** -(DR * DR)) < 2e-7
+        assert rel(t[19], 2.0 ** -(4 * DR * DR)) < 2e-7 and rel(t[20], 2 * DR * 2.0 ** -(4 * DR * DR)) < 2e-7
+        for k, ex in ((21, 8.0), (22, 16.0), (23, -8.0), (24, -16.0)):
+            assert rel(t[k], 2.0 ** (ex * DR * DR)) < 2e-7
+        for m in range(1, 5):
+            K = 2.0 ** -((m * DA) ** 2)
+            assert rel(t[136 + 2 * (m - 1)], K) < 2e-7 and rel(t[137 + 2 * (m - 1)], m * DA * K) < 2e-7
+        # the published entries are where they were
+        assert np.array_equal(e.host_table()[:16], np.asarray(c.ShfR, dtype=np.float32))
+    c = aev_constants_2x()
+    bent = c._replace(ShfR=tuple(v + (0.01 if k == 5 else 0.0) for k, v in enumerate(c.ShfR)))
+    e = AevEngine(bent)
+    e.host_table()
+    assert not e.params.flags & 2 and e.params.flags & 1   # (the forward's flag only looks at ShfA)
 
 
 def test_constants_match_reference_values():

@@ -2172,9 +2172,10 @@ def test_member_model_keeps_pair_potentials(dev):
 
 
 def test_aev_with_unequally_spaced_shifts(dev, oracle64):
-    """AEVComputer constants whose angular radial shifts are NOT equally spaced (from_constants accepts any, aev/_computer.py:
-    602-666): anihip_aev_table_pack leaves ANIHIP_AEV_UNIFORM_SHFA clear and the forward kernel evaluates every Gaussian
-    directly; equally spaced shifts set the flag (three-exponential recurrence).  Both against the oracle."""
+    """AEVComputer constants whose shifts are NOT equally spaced (from_constants accepts any, aev/_computer.py:602-666):
+    anihip_aev_table_pack leaves ANIHIP_AEV_UNIFORM_SHFA (1: the forward's three-exponential recurrence over ShfA) and / or
+    ANIHIP_AEV_REC_BWD (2: the backward's recurrences over ShfR and ShfA) clear and the kernels evaluate every Gaussian
+    directly; equally spaced shifts set both.  AEV and its VJP against the oracle for every combination."""
     from oracle import oracle as orc
     from torchani_amd.aev import AEVComputer
     from torchani_amd.weights import arch_spec
@@ -2182,17 +2183,27 @@ def test_aev_with_unequally_spaced_shifts(dev, oracle64):
     g = load_golden("rand_batch_ani2x")
     base = arch_spec("ani2x")[1]
     sp, x, cell, pbc = to_dev(g, dev)
-    for shfa, want_flag in ((tuple(0.8 + 0.3375 * k + 0.05 * (k % 3) for k in range(8)), 0), (base.ShfA, 1)):
-        consts = base._replace(ShfA=tuple(float(v) for v in shfa))
+    C, A = g["species"].shape
+    w_np = np.random.RandomState(77).uniform(-1.0, 1.0, (C, A, base.out_dim)).astype(np.float32)
+    w = torch.from_numpy(w_np).to(dev)
+    bent_a = tuple(0.8 + 0.3375 * k + 0.05 * (k % 3) for k in range(8))
+    bent_r = tuple(v + (0.02 if k % 5 == 2 else 0.0) for k, v in enumerate(base.ShfR))
+    for shfr, shfa, want_flags in ((base.ShfR, bent_a, 0), (base.ShfR, base.ShfA, 3), (bent_r, base.ShfA, 1)):
+        consts = base._replace(ShfA=tuple(float(v) for v in shfa), ShfR=tuple(float(v) for v in shfr))
         aevc = AEVComputer(consts, neighborlist="batch", row_capacity=256).to(dev)
-        aev = aevc(sp, x, cell, None).cpu().numpy()
-        assert (aevc.engine().params.flags & 1) == want_flag
+        xx = x.clone().requires_grad_(True)
+        aev_t = aevc(sp, xx, cell, None)
+        (vjp,) = torch.autograd.grad((aev_t * w).sum(), xx)
+        aev = aev_t.detach().cpu().numpy()
+        assert (aevc.engine().params.flags & 3) == want_flags
         p = orc.make_params(7, consts.Rcr, consts.Rca, consts.EtaR, consts.EtaA, consts.Zeta, consts.ShfR, consts.ShfA,
                             consts.ShfZ, "cosine")
-        ref = oracle64.aev(p, g["species"], g["coords"].astype(np.float64))
+        ref, ref_vjp = oracle64.aev(p, g["species"], g["coords"].astype(np.float64), grad_aev=w_np.astype(np.float64))
         err = np.abs(aev - ref).max()
-        report(f"aev   custom ShfA (uniform={want_flag})   max|aev err| = {err:.2e}")
+        verr, vmag = np.abs(vjp.cpu().numpy() - ref_vjp).max(), np.abs(ref_vjp).max()
+        report(f"aev   custom shifts (flags={want_flags})   max|aev err| = {err:.2e}   vjp err = {verr:.2e} (|vjp|max {vmag:.1f})")
         assert err < AEV_TOL
+        assert verr <= VJP_REG_REL * max(1.0, vmag)
 
 
 def _stress_state(case, seed=11):

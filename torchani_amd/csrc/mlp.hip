@@ -1509,6 +1509,66 @@ __global__ __launch_bounds__(256) void k_tile_table(const int *ctl, int S, const
     if (lane == 0) tile_tab[tile0] = make_int4(s, p0, n_rows, (int)mk);
 }
 
+// The tile table sorted by falling tile cost, for the fused kernel's tile queue (owner order, mid-size systems): a
+// counting sort over 64 cost classes, entries and row lists copied to their places in a second table (empty entries last, as
+// the kernel expects).  Cost of a tile through one member ~ its species' first hidden width x (1 + 0.17 per pass of four
+// flagged slabs behind the first: the layer-0 k loop and phase 5 grow with the slabs, the phases between them do not).  The order
+// inside a class is whatever the LDS atomics make it: every tile's result is independent of which workgroup computes it and when.
+#ifndef ANIHIP_TILE_QUEUE
+#define ANIHIP_TILE_QUEUE 1   // 0: tiles b, b + grid, ... at every size (development A/B)
+#endif
+struct TileOrderArgs {
+    const int4 *tile_tab;
+    const int *tile_rows;
+    int4 *tile_tab2;
+    int *tile_rows2;
+    int tiles_total;
+    int H1[MAX_S];
+    int *queue;
+    int grid;
+};
+constexpr int TO_CHUNK = 16;   // tiles a workgroup of k_tile_order places (4 waves x 4 tiles)
+__global__ __launch_bounds__(256) void k_tile_order(TileOrderArgs g)
+{
+    // every workgroup counts the whole table (16 bytes per tile, L2 hits) -- the classes' totals and what lies ahead of its
+    // own chunk -- and places its chunk: no second launch, no global histogram
+    __shared__ int s_tot[65], s_pos[65];   // [64]: the empty entries
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * TO_CHUNK;
+    if (tid < 65) { s_tot[tid] = 0; s_pos[tid] = 0; }
+    if (blockIdx.x == 0 && tid == 0) *g.queue = g.grid;
+    __syncthreads();
+    auto cls = [&](const int4 &t) {
+        if (t.x < 0) return 64;
+        const int passes = max(1, (__popc((uint32_t)t.w) + 3) >> 2);
+        const float c = (float)g.H1[t.x] * (1.0f / 256.0f) * (1.0f + 0.17f * (float)(passes - 1));
+        return 63 - min(63, (int)(c * 24.0f));   // class 0 = the most expensive
+    };
+    for (int t = tid; t < g.tiles_total; t += 256) {
+        const int c = cls(g.tile_tab[t]);
+        atomicAdd(&s_tot[c], 1);
+        if (t < c0) atomicAdd(&s_pos[c], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < 65; ++c) { const int n = s_tot[c]; s_pos[c] += run; run += n; }
+    }
+    __syncthreads();
+    // one wave per tile: lane 0 draws the place, every lane copies one row index
+#pragma unroll
+    for (int k = 0; k < TO_CHUNK / 4; ++k) {
+        const int t = c0 + wave * (TO_CHUNK / 4) + k;
+        if (t >= g.tiles_total) break;
+        const int4 e = g.tile_tab[t];
+        int dst = 0;
+        if (lane == 0) dst = atomicAdd(&s_pos[cls(e)], 1);
+        dst = __builtin_amdgcn_readfirstlane(dst);
+        if (lane == 0) g.tile_tab2[dst] = e;
+        g.tile_rows2[(size_t)dst * 64 + lane] = g.tile_rows[(size_t)t * 64 + lane];
+    }
+}
+
 // ---- small inputs: the whole preparation in ONE launch ------------------------------------------------------------
 // Below SMALL_PREP_MAX atoms a step is bound by the number of dependent launches, not by work.  Block 0 (16 waves) does what
 // zero_words + k_sp_count + k_sp_offsets + k_sp_scatter + k_tile_table do in five launches: every wave loads its
@@ -2141,6 +2201,8 @@ struct MlpWorkspace {
     int *perm;
     int4 *tile_tab;
     int *tile_rows;
+    int4 *tile_tab2;    // the table sorted by falling tile cost (k_tile_order; up to FUSED_TILE_QUEUE_MAX 64-row tiles)
+    int *tile_rows2;
     float *act[ANIHIP_MAX_LAYERS];
     int64_t ld[ANIHIP_MAX_LAYERS];
 };
@@ -2165,9 +2227,13 @@ static size_t mlp_carve(const anihip_mlp_desc *d, int64_t n, char *base, MlpWork
     // (row lists: 32 per tile at the finest tiling, 64 per tile at the coarsest, which has up to one partly filled tile
     // per species more rows than atoms)
     int *trows = (int *)take(sizeof(int) * (32 * tiles + 64 * (size_t)ANIHIP_MAX_SPECIES));
+    const size_t tiles64 = (size_t)((n + 63) / 64) + ANIHIP_MAX_SPECIES;
+    const size_t qtiles = tiles64 <= (size_t)FUSED_TILE_QUEUE_MAX ? tiles64 : 0;
+    int4 *ttab2 = (int4 *)take(sizeof(int4) * qtiles);
+    int *trows2 = (int *)take(sizeof(int) * 64 * qtiles);
     if (w) {
         w->ctl = ctl; w->amax = (unsigned *)(ctl + CTL_WORDS); w->perm = perm; w->member_part = mpart;
-        w->tile_tab = ttab; w->tile_rows = trows;
+        w->tile_tab = ttab; w->tile_rows = trows; w->tile_tab2 = qtiles ? ttab2 : nullptr; w->tile_rows2 = qtiles ? trows2 : nullptr;
     }
     const int nh = d->net[0].n_layers - 1;  // hidden layers
     for (int l = 0; l < nh; ++l) {
@@ -2628,6 +2694,16 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
         }
 #endif
         f.only_species = -1;
+        f.queue = nullptr;
+        if (ANIHIP_TILE_QUEUE && f.owner == 1 && variant == FUSED_CELU_L0B && !(d->flags & ANIHIP_MLP_FLAG_SHAPED) && rows == 64 && w.tile_tab2 &&
+            tiles <= FUSED_TILE_QUEUE_MAX && tiles > grid && !small_prep) {
+            TileOrderArgs to{};
+            to.tile_tab = w.tile_tab; to.tile_rows = w.tile_rows; to.tile_tab2 = w.tile_tab2; to.tile_rows2 = w.tile_rows2;
+            to.tiles_total = (int)tiles; to.queue = w.ctl + CTL_QUEUE; to.grid = (int)grid;
+            for (int s = 0; s < S; ++s) to.H1[s] = f.sp[s].H1;
+            hipLaunchKernelGGL(k_tile_order, dim3((unsigned)((tiles + TO_CHUNK - 1) / TO_CHUNK)), dim3(256), 0, stream, to);
+            f.tile_tab = w.tile_tab2; f.tile_rows = w.tile_rows2; f.queue = w.ctl + CTL_QUEUE;
+        }
         if (variant == FUSED_CELU_L0B && (d->flags & ANIHIP_MLP_FLAG_SHAPED)) {
             // one launch per species, restricted to its tiles, with the network widths as compile-time constants where an
             // instantiation exists (every ANI-2x network and ANI-1x hydrogen); a species without atoms exits at once

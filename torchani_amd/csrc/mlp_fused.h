@@ -92,6 +92,9 @@ struct FusedArgs {
     const int *perm;           // sorted position -> atom
     const int4 *tile_tab;      // [tiles_total] {species (-1: empty), first sorted position, rows, slab mask}
     const int *tile_rows;      // [tiles_total][rows per tile] atom of each row (short tiles: last atom repeated)
+    // owner order over single tiles, mid-size systems: the table is sorted by falling tile cost (k_tile_order), workgroup b starts
+    // with tile b and draws its next tile from *queue (starts at the grid size) -- or NULL: tiles b, b + grid, ...
+    int *queue;
     float *member_part;        // [n][M] per-member atomic energies (summed by k_fused_finish)
     int S, M;
     int tiles_total;           // upper bound of the number of tiles (work items = tiles_total * M)
@@ -110,6 +113,10 @@ struct FusedArgs {
     int64_t tr_ld[3];
 };
 constexpr int FR_XPAD = 16;       // halves of padding per activation-plane row
+// Tiles are handed out by falling cost up to this many of them (a solvated protein: 22 % of the tiles flag more than four slabs --
+// up to 17: five passes of phase 5 -- and with tiles b, b + grid, ... the slowest workgroup carries 1.5 x the mean load; beyond
+// a few dozen rounds of tiles the static order evens out by itself and keeps neighbouring tiles on neighbouring CUs)
+constexpr int64_t FUSED_TILE_QUEUE_MAX = 8192;
 
 // instantiations of k_mlp_fused (csrc/mlp_fused.hip)
 enum FusedVariant { FUSED_CELU = 0, FUSED_CELU_L0B = 1, FUSED_CELU_L0B_B2 = 2, FUSED_GELU = 3, FUSED_TRAIN = 4,

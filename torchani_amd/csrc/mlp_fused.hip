@@ -553,6 +553,23 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         s_off[t_] = t_ < g.S ? g.ctl[CTL_OFF + t_] : 0;
     }
     if (threadIdx.x == 0) s_max = 0u;   // (tile maximum: reset again by every item once it has been read)
+    // tile queue (owner order over single tiles): s_tab[1] = position in tile_order of the tile this workgroup takes next
+    // (only the run-time-width instantiation with phase 5 serves mid-size systems.  The draw is inline assembly: a global atomic
+    // the compiler can see counts as a possible write to every table this kernel reads through scalar loads -- tile entries,
+    // bounds, biases -- and turns them all into per-lane vector loads: 116 spilled registers)
+    constexpr bool DYN = L0B && !B2 && H1C == 0;
+#define FR_DYN() (DYN && g.queue != nullptr)
+    auto draw_tile = [&]() {   // one lane: the next position of the queue
+        unsigned q;
+        const int zero = 0, one = 1;
+        // (s_nop: the pointer may come out of a v_readlane right ahead of this block -- the scalar register file is spilled to
+        // vector lanes in this kernel -- and a vector-memory instruction must not read a scalar register a vector instruction
+        // wrote less than five wait states earlier; the compiler pads its own instructions, not the inside of an asm block)
+        asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(q) : "v"(zero), "v"(one), "s"(g.queue));
+        return q;
+    };
+    if (FR_DYN() && threadIdx.x == 0) s_tab[1] = draw_tile();
     __syncthreads();
     // (member, tile) of the item, advanced by gridDim.x tiles per step without divisions
     int mem = item / n_tiles, tile = item - mem * n_tiles;
@@ -641,6 +658,8 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                     mem_n = mem + 1; tile_n = tile - (gsz - 1) * (int)gridDim.x;
                 } else {
                     mem_n = 0;   // (tile_n is the first tile behind the group)
+                    // (the tile drawn while the tile before this one was in its last member)
+                    if (FR_DYN()) tile_n = min(__builtin_amdgcn_readfirstlane((int)s_tab[1]), n_tiles);
                     gsz_n = min(g.owner, (n_tiles - 1 - tile_n) / (int)gridDim.x + 1);
                 }
             }
@@ -904,6 +923,8 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
         const float s3 = pow2_scale_for(bnd[3]);                                  // |d act1| <= [2] ||W2||_1
         __syncthreads();
         if (tid == 0) s_max = 0u;   // (every thread has read the tile maximum; the next item's atomics are many barriers away)
+        // (every thread has also read the queue position at the head of this item: the last member draws the one after it)
+        if (FR_DYN() && tid == 0 && mem == Mi - 1) s_tab[1] = draw_tile();
         ANIHIP_STAMP(trace, 4);
 
         // =============== phase 1: act1 = celu(act0 x W1^T + b1) ===============
@@ -1237,6 +1258,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     }
 }
 #undef FR_UNIT
+#undef FR_DYN
 
 const void *fused_kernel(int variant)
 {

@@ -9,6 +9,7 @@ constexpr int CTL_CNT = 0;      // [8]  atoms per species
 constexpr int CTL_CURSOR = 8;   // [8]  scatter cursors
 constexpr int CTL_OFF = 16;     // [9]  first sorted position of each species
 constexpr int CTL_TILE = 32;    // [9]  first row tile of each species
+constexpr int CTL_QUEUE = 41;    // [1]  tile queue of the fused kernel (owner order, tiles handed out by falling cost)
 constexpr int CTL_WORDS = 48;
 
 // dW = D^T X over the rows (atoms) of one species on v_mfma_f32_32x32x16_bf16 with three-way bf16 splits (train.hip)

@@ -345,7 +345,7 @@ class ANI(torch.nn.Module):
 
         The layer-0 GEMMs skip the 32-column AEV slabs no atom of a tile has a neighbor for.  Radial blocks are 16 columns
         per species, two species to a slab: water under ANI-2x (H = 0, O = 3 of H C N O S F Cl) touches two half-empty
-        radial slabs.  Relabelling the species of a SYSTEM "present ones first" (H -> 0, O -> 1) puts its radial blocks
+        radial slabs.  Relabelling the species of a SYSTEM "present ones first, by falling abundance" (H -> 0, O -> 1) puts its radial blocks
         side by side -- 4 flagged slabs instead of 5 -- and costs nothing but a permutation of the first-layer weights
         (nn.ANINetworks._pack(species_order=...)): the AEV rows are internal to energies_and_forces, nobody sees their
         column order.  Only for systems large enough that the one host read of the species histogram (cached per species
@@ -371,11 +371,17 @@ class ANI(torch.nn.Module):
             S = self.aev_computer.num_species
             present = torch.bincount(species32.reshape(-1).clamp(min=0), minlength=S)[:S]
             present[0] -= (species32 < 0).sum()   # (padding atoms were counted as species 0)
-            have = (present > 0).tolist()
-            order = tuple([s for s in range(S) if have[s]] + [s for s in range(S) if not have[s]])
-            # worth it only if the present species then share fewer radial slabs (two species per slab)
-            n_have = sum(have)
-            if order == tuple(range(S)) or (n_have + 1) // 2 >= len({s >> 1 for s in range(S) if have[s]}):
+            counts = present.tolist()
+            have = [c > 0 for c in counts]
+            # the present species by falling abundance: the two most frequent elements of the system share the first radial
+            # slab (a solvated protein H C N O S: the water's H and O, so that its atoms away from the solute flag four slabs,
+            # the fused kernel's single-pass case, instead of five)
+            order = tuple(sorted((s for s in range(S) if have[s]), key=lambda s: (-counts[s], s))
+                          + [s for s in range(S) if not have[s]])
+            # worth it only if the frequent species then sit closer together: sum over the radial slabs (two species each) of
+            # the count of the slab's most frequent species
+            weight = lambda o: sum(max(counts[s] for s in o[k:k + 2]) for k in range(0, S, 2))   # noqa: E731
+            if order == tuple(range(S)) or weight(order) >= weight(tuple(range(S))):
                 hit = (key, key_tensor, None, None)
             else:
                 lut = torch.full((S + 1,), -1, dtype=torch.int32, device=species32.device)
