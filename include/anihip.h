@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ANIHIP_ABI_VERSION 11
+#define ANIHIP_ABI_VERSION 12
 
 /* status word bits written by the kernels into status[0] */
 #define ANIHIP_ST_ENTRY_OVERFLOW 1u   /* neighbor entries exceeded ent_capacity */
@@ -465,9 +465,11 @@ int anihip_mlp_repack(void *stream, const anihip_mlp_desc *d, const void *const 
  * with t = *step + 1; *step (DEVICE int32: updates done so far) is incremented behind the update, so a captured HIP graph
  * of a training step advances it on every replay.  One launch over n parameters (28 bytes of traffic each) instead of a
  * dozen foreach launches over the model's 448 tensors; buffers 16-byte aligned.  zero_grads != 0: the gradients are zeroed
- * behind the update (the weight-gradient kernels of the next step ADD into them: no memset launch per step). */
+ * behind the update (the weight-gradient kernels of the next step ADD into them: no memset launch per step).
+ * The hyper-parameters are doubles (ABI 12), as torch.optim.Adam holds them: 1 - beta2 taken from the fp32-rounded 0.999 is
+ * 1.3e-5 off, and exp_avg_sq then differs from torch's by that factor. */
 int anihip_adam_step(void *stream, float *params, float *grads, float *exp_avg, float *exp_avg_sq, int64_t n,
-                     float lr, float beta1, float beta2, float eps, float weight_decay, int32_t *step, int32_t zero_grads);
+                     double lr, double beta1, double beta2, double eps, double weight_decay, int32_t *step, int32_t zero_grads);
 
 /* ---------------------------------------------------------------------------------------------
  * Pair potentials on the neighbor rows: the xTB repulsion term of the reference's ANI-2xr / ANI-2dr models

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
-    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.anihip_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_struct_layouts_match_header(lib):
@@ -104,10 +104,10 @@ def test_argument_validation_without_gpu(lib):
     assert rc != 0 and b"null descriptor" in lib.anihip_last_error()
     rc = lib.anihip_mlp_repack(None, None, addr, addr, None, 0)
     assert rc != 0 and b"null descriptor" in lib.anihip_last_error()
-    one = ctypes.c_float(0.5)
+    one = ctypes.c_double(0.5)
     rc = lib.anihip_adam_step(None, addr, addr, addr, None, 16, one, one, one, one, one, addr, 1)
     assert rc != 0 and b"null pointer" in lib.anihip_last_error()
-    rc = lib.anihip_adam_step(None, addr, addr, addr, addr, 16, one, ctypes.c_float(1.5), one, one, one, addr, 1)
+    rc = lib.anihip_adam_step(None, addr, addr, addr, addr, 16, one, ctypes.c_double(1.5), one, one, one, addr, 1)
     assert rc != 0 and b"hyper-parameters" in lib.anihip_last_error()
     d = _lib.MlpDesc()
     d.num_species, d.n_members, d.aev_len, d.celu_alpha, d.precision = 9, 8, 1008, 0.1, _lib.MLP_F16X3

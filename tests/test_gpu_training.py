@@ -163,6 +163,38 @@ def test_fast_training_pass_matches_oracle(dev, oracle64, base):
     assert np.abs(0.5 * fg - ref).max() < WG_REL_TOL * scale
 
 
+def test_stale_layouts_are_refreshed_before_a_layer_by_layer_pass(dev):
+    """A fused-only device refresh leaves the layer-by-layer layouts of a split-fp16 pack at the OLD parameters
+    (PackedNetworks.stale_layouts).  A pass the library serves layer by layer -- here: weight gradients with d Loss / d aev --
+    runs the full repack first, so its results are those of a pack built from the new parameters (round-5 advice)."""
+    from torchani_amd.engine import PackedNetworks
+
+    model = fresh_model("ani2x", 4, dev)
+    nets = model.neural_networks
+    nets.requires_grad_(True)
+    packed = nets._train_pack(dev, fast=True)
+    rs = torch.Generator(device="cpu").manual_seed(6)
+    with torch.no_grad():
+        for q in nets.parameters():
+            q.mul_(1.0 + 0.3 * (torch.rand(q.shape, generator=rs) - 0.5).to(dev))   # (a change no tolerance below hides)
+    assert nets._train_pack(dev, fast=True) is packed and packed.stale_layouts
+    n = 300
+    sp = torch.randint(0, 7, (n,), generator=rs).to(torch.int32).to(dev)
+    aev = torch.rand((n, packed.aev_len), generator=rs).to(dev) * 0.3
+    g = (torch.rand(n, generator=rs) - 0.5).to(dev)
+    gw, gb, e, ga = packed.weight_grads(sp, aev, g, want_grad_aev=True)
+    assert not packed.stale_layouts
+    members = nets._member_networks()
+    lins = [[m.atomics[s].linears() for s in nets.symbols] for m in members]
+    weights = [[[lin.weight for lin in sl] for sl in ml] for ml in lins]
+    biases = [[[lin.bias for lin in sl] for sl in ml] for ml in lins]
+    fresh = PackedNetworks(weights, biases, packed.aev_len, 0.1, dev, "f16x3")
+    gw2, gb2, e2, ga2 = fresh.weight_grads(sp, aev, g, want_grad_aev=True)
+    assert float((e - e2).abs().max()) < 1e-6 * max(1.0, float(e2.abs().max()))
+    assert float((ga - ga2).abs().max()) < 1e-6 * float(ga2.abs().max())
+    assert float((gw[0][0][1] - gw2[0][0][1]).abs().max()) <= 1e-5 * float(gw2[0][0][1].abs().max())
+
+
 def test_device_repack_of_a_split_fp16_pack_equals_the_host_packer(dev):
     """anihip_mlp_repack of an F16X3 descriptor (round 5) rewrites every layout on the device: after the parameters changed,
     the refreshed buffer equals, byte for byte outside the operand bounds, what anihip_mlp_pack builds on the host from the new
@@ -284,13 +316,60 @@ def test_fused_adam_matches_torch_adam(dev, weight_decay):
     assert int(flat.step.item()) == 25
     for a, b in zip(pa, pb):
         assert float((a.detach() - b.detach()).abs().max()) <= 1e-6 * float(b.detach().abs().max())
+    # the state dict has torch.optim.Optimizer's layout: torch.optim.Adam's own loads into ours and the other way round
     sd = ours.state_dict()
+    sd_t = theirs.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == sd_t["param_groups"][0]["params"]
+    for k in sd_t["state"]:
+        assert float(sd["state"][k]["step"]) == float(sd_t["state"][k]["step"]) == 25.0
+        ref = sd_t["state"][k]["exp_avg_sq"]
+        assert float((sd["state"][k]["exp_avg_sq"] - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    ours.load_state_dict(sd_t)
+    assert int(flat.step.item()) == 25
+    back = ours.state_dict()
+    assert all(torch.equal(back["state"][k]["exp_avg"], sd_t["state"][k]["exp_avg"]) for k in sd_t["state"])
+    theirs.load_state_dict(sd)
     ours.load_state_dict(sd)
+    # a parameter without a gradient counts as a zero gradient (documented) -- and is refused where that would decay it
+    pa[3].grad = None
+    if weight_decay > 0.0:
+        with pytest.raises(RuntimeError, match="without a gradient"):
+            ours.step()
+    else:
+        ours.step()
     # a parameter that left the flat buffer is noticed, not silently skipped
     pa[1].data = pa[1].data.clone()
     with pytest.raises(RuntimeError, match="flat buffer"):
-        for _ in range(16):   # (all parameters are looked at every 16th step, the first and the last one every step)
+        for _ in range(4):   # (all parameters are looked at every 4th step, the first and the last one every step)
             ours.step()
+
+
+def test_parameter_hooks_take_the_autograd_route(dev):
+    """With torchani_amd.optim.Adam the weight-gradient kernels add straight into the optimizer's flat buffer and autograd
+    produces nothing for the parameters -- unless a parameter carries a tensor hook: then the gradients go through autograd
+    (the hook fires, p.grad still ends up in the flat buffer's view at step())."""
+    from torchani_amd.optim import Adam
+
+    model = fresh_model("ani2x", 9, dev)
+    nets = model.neural_networks
+    nets.requires_grad_(True)
+    opt = Adam(nets.parameters(), lr=1e-4)
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    sp = torch.randint(0, 4, (4, 16), generator=gen).to(dev)
+    aev = (torch.rand((4, 16, 1008), generator=gen) * 0.2).to(dev)
+    nets(sp, aev).sum().backward()
+    flat = opt._flat[0]
+    g_flat = flat.grad.clone()
+    assert float(g_flat.abs().max()) > 0 and nets.__dict__.get("_flat_target_cache") is not None
+    opt.zero_grad()
+    fired = []
+    p0 = next(iter(nets.parameters()))
+    p0.register_hook(lambda g: fired.append(float(g.abs().max())))
+    nets.__dict__.pop("_flat_target_cache")   # (the hooks are looked at when the gradient table is built)
+    nets(sp, aev).sum().backward()
+    assert fired and fired[0] > 0
+    flat.gather_stray_grads()
+    assert float((flat.grad - g_flat).abs().max()) <= 2e-5 * float(g_flat.abs().max())
 
 
 def test_training_step_with_the_flat_optimizer(dev, oracle64):

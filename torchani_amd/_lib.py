@@ -37,7 +37,7 @@ MLP_FLAG_NO_FUSED, MLP_FLAG_BIG_TILES, MLP_FLAG_SMALL_TILES, MLP_FLAG_NO_SLAB_MA
 MLP_FLAG_FUSED_L0B, MLP_FLAG_NO_FUSED_L0B = 512, 1024
 MLP_FLAG_SHAPED = 4096   # one fused launch per species with compile-time network widths (include/anihip.h)
 MLP_FLAG_BWD_TWO_PRODUCTS = 2048   # off by default: two-product backward GEMMs of the large-system path (include/anihip.h)
-ABI_VERSION = 11
+ABI_VERSION = 12
 REPACK_FUSED_ONLY = 1
 
 
@@ -195,7 +195,7 @@ def lib() -> C.CDLL:
                                                   C.POINTER(SpeciesGrads), vp]
     L.anihip_mlp_train_forward.argtypes = [vp, C.POINTER(MlpDesc), i64, i64, i64, vp, vp, vp, sz, vp]
     L.anihip_mlp_repack.argtypes = [vp, C.POINTER(MlpDesc), vp, vp, vp, i32]
-    L.anihip_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, i32]
+    L.anihip_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, vp, i32]
     L.anihip_adam_step.restype = C.c_int
     L.anihip_energy_reduce.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     L.anihip_energy_forces_finish.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp, vp, i64]

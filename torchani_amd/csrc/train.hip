@@ -263,19 +263,20 @@ void launch_wgrad_b3(hipStream_t stream, const WgradB3Args &a, int64_t rows_tota
 // the gradients are zeroed behind the update (the next backward accumulates into them: no memset launch per step).
 // step: device counter of the updates done so far (the bias corrections need it; on the device so that a captured HIP graph
 // of the training step advances it on replay).
-__global__ __launch_bounds__(256) void k_adam(float *p, float *g, float *m, float *v, int64_t n, float lr, float b1,
-                                              float b2, float eps, float wd, const int32_t *step, int zero_grads)
+__global__ __launch_bounds__(256) void k_adam(float *p, float *g, float *m, float *v, int64_t n, double lr, double b1d,
+                                              double b2d, float eps, float wd, const int32_t *step, int zero_grads)
 {
     __shared__ float s_c[2];
     if (threadIdx.x == 0) {
         const double t = (double)(*step + 1);
-        const double bc1 = 1.0 - pow((double)b1, t), bc2 = 1.0 - pow((double)b2, t);
-        s_c[0] = (float)((double)lr / bc1);   // step size
+        const double bc1 = 1.0 - pow(b1d, t), bc2 = 1.0 - pow(b2d, t);
+        s_c[0] = (float)(lr / bc1);   // step size
         s_c[1] = (float)sqrt(bc2);
     }
     __syncthreads();
     const float step_size = s_c[0], bc2s = s_c[1];
-    const float ob1 = 1.0f - b1, ob2 = 1.0f - b2;
+    // (1 - beta in double, like torch's lerp_ / addcmul_ weights: 1.0f - 0.999f is 1.3e-5 off)
+    const float b2 = (float)b2d, ob1 = (float)(1.0 - b1d), ob2 = (float)(1.0 - b2d);
     const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += stride) {
         v4f pp = reinterpret_cast<v4f *>(p)[i], mm = reinterpret_cast<v4f *>(m)[i], vv = reinterpret_cast<v4f *>(v)[i];
@@ -540,13 +541,13 @@ int repack_f16(hipStream_t stream, const anihip_mlp_desc *d, const void *const *
 using namespace anihip;
 
 extern "C" int anihip_adam_step(void *stream_, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
-                                int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
                                 int32_t *step, int32_t zero_grads)
 {
     hipStream_t stream = (hipStream_t)stream_;
     ANIHIP_REQUIRE(params && grads && exp_avg && exp_avg_sq && step, "null pointer argument");
     ANIHIP_REQUIRE(n >= 0, "negative parameter count");
-    ANIHIP_REQUIRE(lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && weight_decay >= 0.f,
+    ANIHIP_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0. && weight_decay >= 0.,
                    "invalid Adam hyper-parameters");
     ANIHIP_REQUIRE(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
                    "parameter, gradient and moment buffers must be 16-byte aligned");
@@ -555,7 +556,7 @@ extern "C" int anihip_adam_step(void *stream_, float *params, float *grads, floa
         if (blocks > 4096) blocks = 4096;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, n, lr,
-                           beta1, beta2, eps, weight_decay, step, (int)zero_grads);
+                           beta1, beta2, (float)eps, (float)weight_decay, step, (int)zero_grads);
     }
     hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(64), 0, stream, step);
     ANIHIP_CHECK_HIP(hipGetLastError());

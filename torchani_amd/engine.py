@@ -729,10 +729,21 @@ class PackedNetworks:
                 and all(self.desc.net[s].dims[l] <= 256 for s in range(self.S) for l in (1, 2, 3))
                 and self.aev_len <= 1024)
 
+    def _freshen_layouts(self, fused_route: bool) -> None:
+        """A refresh(..., fused_only=True) leaves the layer-by-layer layouts (w / wt / wh / wth) at the parameters of the pack
+        before it.  A call that the library serves layer by layer -- anything but the fused training pass without d Loss /
+        d aev -- must not read them: run the full repack from the parameter table of the last refresh first (round-5
+        advice: the C side decides the route from the descriptor on its own, so the guard sits where both are known)."""
+        if getattr(self, "stale_layouts", False) and not fused_route:
+            _lib.check(_lib.lib().anihip_mlp_repack(_stream(), C.byref(self.desc), _ptr(self._src_tab),
+                                                    self._out_in.ctypes.data, _ptr(getattr(self, "_repack_status", None)), 0))
+            self.stale_layouts = False
+
     def train_forward(self, species: Tensor, aev: Tensor) -> tp.Tuple[Tensor, Tensor]:
         """First half of a training step: exact-fp32 forward that keeps the activations.  Returns (atomic_e [N],
         workspace) -- hand the workspace to weight_grads(..., workspace=ws) for the backward half."""
         _require_cuda(species, aev)
+        self._freshen_layouts(self.fast_training())
         n = species.numel()
         assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == n * self.aev_len
         L = _lib.lib()
@@ -825,6 +836,7 @@ class PackedNetworks:
         plus atomic_e [N] and, optionally, d Loss / d aev [N, L].  Replaces torch autograd through
         nn/_core.py:146-149 / nn/_containers.py:377-421,608-636."""
         _require_cuda(species, aev, grad_atomic_e)
+        self._freshen_layouts(self.fast_training() and not want_grad_aev)
         n = species.numel()
         dev = aev.device
         assert aev.dtype == torch.float32 and aev.is_contiguous() and aev.numel() == n * self.aev_len

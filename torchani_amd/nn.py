@@ -190,6 +190,7 @@ class _MLPFunction(torch.autograd.Function):
 # bumped whenever a parameter or a submodule is registered on any torch.nn.Module (incl. attribute assignment): cached
 # parameter lists of the containers below are valid while it stands still
 _STRUCT_EPOCH = [0]
+_FLAT_ROUTE_NOTE = [False]   # the one-time note of _EngineContainer._flat_target to multi-rank runs
 _VERSION_OF = operator.attrgetter("_version")
 _DATA_PTR_OF = operator.methodcaller("data_ptr")
 
@@ -377,6 +378,21 @@ class _EngineContainer(torch.nn.Module):
         per = 2 * S * nl
         if len(params) != M * per:
             return None
+        # (round-5 advice) on this route autograd never produces a gradient for the parameters: tensor hooks and
+        # post-accumulate hooks registered on them would not fire -- with such hooks present (looked at when the table is built,
+        # not per call) the gradients take the autograd route.  DistributedDataParallel's reducer hooks the gradient
+        # accumulators out of Python's sight: ranks that train with the flat optimizer average their gradients with
+        # torchani_amd.parallel.all_reduce_gradients(optimizer) instead, and are told so once.
+        if any(getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None) for p in params):
+            return None
+        if not _FLAT_ROUTE_NOTE[0]:
+            _FLAT_ROUTE_NOTE[0] = True
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                warnings.warn("torchani_amd: the weight gradients are written straight into torchani_amd.optim.Adam's flat buffer; "
+                              "autograd hooks on the parameters (DistributedDataParallel's reducer) do not see them -- average "
+                              "them across ranks with torchani_amd.parallel.all_reduce_gradients(optimizer)")
         base = [params[i].grad.data_ptr() for i in range(per)]
         stride = sum(params[i].numel() for i in range(per))
         if M > 1:

@@ -73,9 +73,11 @@ class _FlatGroup:
         """The update kernel writes the flat buffer: every parameter must still be its view of it (``model.to(...)``,
         ``p.data = ...`` or a dtype change move a parameter out -- the optimizer would then update memory nobody reads)."""
         base = self.flat.data_ptr()
-        # (every 16th call all of them, in between the first and the last: a model moved as a whole moves those too)
+        # (every 4th call all of them -- 448 pointer reads are 0.1 ms of host time, 4 % of a graphed ANI-2x x 8 step --, in between
+        # the first and the last: a model moved as a whole moves those too.  A single parameter re-homed by hand therefore trains
+        # against stale memory for at most three steps before this raises)
         self._homes_calls = getattr(self, "_homes_calls", -1) + 1
-        idx = range(len(self.params)) if self._homes_calls % 16 == 0 else (0, len(self.params) - 1)
+        idx = range(len(self.params)) if self._homes_calls % 4 == 0 else (0, len(self.params) - 1)
         for i in idx:
             p, off = self.params[i], self.offsets[i]
             if p.data_ptr() != base + 4 * off:
@@ -92,6 +94,7 @@ class _FlatGroup:
                 self.grad_views[i].copy_(g)
             else:
                 self.grad_views[i].zero_()
+                self.saw_none_grad = True
             p.grad = self.grad_views[i]
 
 
@@ -99,7 +102,12 @@ class Adam(torch.optim.Optimizer):
     """``torchani_amd.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0)``: torch.optim.Adam's update
     (amsgrad / maximize / foreach / capturable / differentiable are not options: one fused launch, always capturable).
     The hyper-parameters of a group are read at every ``step()`` (learning-rate schedulers work as usual) and passed by value:
-    a CAPTURED step replays the values it was captured with -- capture again after a scheduler changed them."""
+    a CAPTURED step replays the values it was captured with -- capture again after a scheduler changed them.
+
+    Differences from torch.optim.Adam, all consequences of the one flat update: (1) a parameter whose ``grad`` is None at
+    ``step()`` counts as having a ZERO gradient -- its moments decay and a weight decay still applies -- where torch skips it
+    (``step()`` refuses weight_decay > 0 in that situation instead of decaying silently); (2) ``zero_grad_in_step=True`` (default)
+    clears the gradients inside ``step()``: read gradient norms BEFORE the step, or pass False; (3) one step counter per group."""
 
     def __init__(self, params, lr: float = 1e-3, betas: tp.Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, zero_grad_in_step: bool = True) -> None:
@@ -142,30 +150,76 @@ class Adam(torch.optim.Optimizer):
         L = _lib.lib()
         for group, f in zip(self.param_groups, self._flat):
             f.check_homes()
+            f.saw_none_grad = False
             f.gather_stray_grads()
+            if f.saw_none_grad and group["weight_decay"] > 0.0:
+                raise RuntimeError("torchani_amd.optim.Adam: a parameter without a gradient in a group with weight_decay > 0 -- "
+                                   "torch.optim.Adam would skip it, the flat update would decay it (class docstring)")
             b1, b2 = group["betas"]
             stream = torch.cuda.current_stream(f.flat.device).cuda_stream
             _lib.check(L.anihip_adam_step(stream, f.flat.data_ptr(), f.grad.data_ptr(), f.exp_avg.data_ptr(),
-                                          f.exp_avg_sq.data_ptr(), f.n, C.c_float(group["lr"]), C.c_float(b1), C.c_float(b2),
-                                          C.c_float(group["eps"]), C.c_float(group["weight_decay"]), f.step.data_ptr(),
+                                          f.exp_avg_sq.data_ptr(), f.n, C.c_double(group["lr"]), C.c_double(b1), C.c_double(b2),
+                                          C.c_double(group["eps"]), C.c_double(group["weight_decay"]), f.step.data_ptr(),
                                           1 if self.zero_grad_in_step else 0))
             # the kernel wrote the parameters behind torch's back: bump their versions (packed copies are refreshed by it)
             torch.autograd.graph.increment_version(f.params)
         return loss
 
     def state_dict(self):
-        return {"param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-                "flat": [{"exp_avg": f.exp_avg.clone(), "exp_avg_sq": f.exp_avg_sq.clone(), "step": f.step.clone(),
-                          "sizes": list(f.sizes)} for f in self._flat]}
+        """torch.optim.Optimizer's layout -- ``{"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [{...,
+        "params": [indices]}]}`` with the parameters numbered through the groups in order -- so that generic checkpoint tooling
+        reads it; the per-parameter tensors are copies of the slices of the flat moment buffers, ``step`` a float32 scalar tensor
+        (the device counter of the group)."""
+        state, groups, k = {}, [], 0
+        for g, f in zip(self.param_groups, self._flat):
+            ids = []
+            for i, p in enumerate(f.params):
+                off, n = f.offsets[i], f.sizes[i]
+                state[k] = {"step": f.step.to(torch.float32).reshape(()).clone(),
+                            "exp_avg": f.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": f.exp_avg_sq[off:off + n].view(p.shape).clone()}
+                ids.append(k)
+                k += 1
+            groups.append({**{key: v for key, v in g.items() if key != "params"}, "params": ids})
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, state) -> None:
-        if len(state["flat"]) != len(self._flat):
+        """What ``state_dict()`` returns (the torch layout; also a torch.optim.Adam's own state dict for the same parameters in
+        the same order), or the ``{"param_groups", "flat"}`` form this class wrote before round 6."""
+        if "flat" in state:
+            if len(state["flat"]) != len(self._flat):
+                raise ValueError("state dict of another optimizer layout")
+            for g, sg in zip(self.param_groups, state["param_groups"]):
+                g.update(sg)
+            for f, sf in zip(self._flat, state["flat"]):
+                if list(sf["sizes"]) != list(f.sizes):
+                    raise ValueError("state dict of another parameter layout")
+                f.exp_avg.copy_(sf["exp_avg"])
+                f.exp_avg_sq.copy_(sf["exp_avg_sq"])
+                f.step.copy_(sf["step"])
+            return
+        if len(state["param_groups"]) != len(self._flat):
             raise ValueError("state dict of another optimizer layout")
-        for g, sg in zip(self.param_groups, state["param_groups"]):
-            g.update(sg)
-        for f, sf in zip(self._flat, state["flat"]):
-            if list(sf["sizes"]) != list(f.sizes):
+        for g, sg, f in zip(self.param_groups, state["param_groups"], self._flat):
+            ids = list(sg["params"])
+            if len(ids) != len(f.params):
                 raise ValueError("state dict of another parameter layout")
-            f.exp_avg.copy_(sf["exp_avg"])
-            f.exp_avg_sq.copy_(sf["exp_avg_sq"])
-            f.step.copy_(sf["step"])
+            g.update({key: v for key, v in sg.items() if key != "params"})
+            steps = set()
+            with torch.no_grad():
+                for i, k in enumerate(ids):
+                    st = state["state"].get(k)
+                    off, n = f.offsets[i], f.sizes[i]
+                    if st is None:   # (torch leaves out parameters that never had a gradient: fresh moments)
+                        f.exp_avg[off:off + n].zero_()
+                        f.exp_avg_sq[off:off + n].zero_()
+                        continue
+                    if st["exp_avg"].numel() != n:
+                        raise ValueError("state dict of another parameter layout")
+                    f.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    f.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(float(st["step"])))
+                if len(steps) > 1:
+                    raise ValueError("the parameters of a group carry different step counts: this optimizer keeps ONE counter per "
+                                     "group (torch skips parameters without a gradient, see the class docstring)")
+                f.step.fill_(steps.pop() if steps else 0)
