@@ -162,6 +162,20 @@ def test_aev_table_pack_recurrence_constants(lib):
     assert not e.params.flags & 2 and e.params.flags & 1   # (the forward's flag only looks at ShfA)
 
 
+def test_per_species_launch_rule_follows_the_measurements():
+    """models.ANI._per_species_launches_pay prices "one fused launch per species, compile-time widths" against "one launch, tiles
+    handed out by falling cost" in tiles per workgroup; the choices measured on the MI355X (water boxes 24 k ... 2.3 M atoms, the
+    46 k-atom solvated protein: DESIGN.md section 6) are the ones it makes."""
+    from torchani_amd.models import ANI2x
+
+    m = ANI2x(seed=0)
+    water = lambda n: [2 * n // 3, 0, 0, n // 3, 0, 0, 0]   # noqa: E731
+    measured = {24000: True, 41472: True, 81000: False, 192000: True, 526848: True, 1119744: True, 2336064: True}
+    for n, want in measured.items():
+        assert m._per_species_launches_pay(water(n), 256) is want, n
+    assert m._per_species_launches_pay([30734, 314, 77, 15231, 1, 0, 0], 256) is False   # solvated 1hz5: H C N O S
+
+
 def test_constants_match_reference_values():
     """SURVEY section 0 table (values cross-checked there against the reference's .params files)."""
     from torchani_amd.constants import aev_constants_1x, aev_constants_2x
@@ -600,11 +614,13 @@ def test_layer0_tile_hint_from_composition():
     assert m._tile_hint(padded, padded, 20000) == _lib.MLP_FLAG_SMALL_TILES
     assert m._tile_hint(organic, organic, 16383) == 0 and m._tile_hint(organic, organic, 65536) == 0
     # round 6: from 24 000 atoms on the layer-0 backward runs inside the fused kernel; one launch per species with compile-time
-    # network widths only where every species present has many rounds of tiles (>= 25 rounds of the 256 CUs per species)
-    assert m._tile_hint(organic, organic, 24000) == 0
-    assert m._tile_hint(water, water, 2_336_064) == _lib.MLP_FLAG_SHAPED      # 143 rounds, 2 species
-    assert m._tile_hint(organic, organic, 1_000_000) == 0                     # 61 rounds, 5 species
-    assert m._tile_hint(organic, organic, 2_336_064) == _lib.MLP_FLAG_SHAPED  # 143 rounds, 5 species
+    # network widths where that is cheaper than one launch with a tile queue (test_per_species_launch_rule_follows_the_measurements)
+    big = lambda k, n: torch.from_numpy(rs.randint(0, k, (1, n)))   # noqa: E731
+    o24, w24, w2m, o2m = big(5, 24000), big(2, 24000), big(2, 2_336_064), big(5, 2_336_064)
+    assert m._tile_hint(o24, o24, 24000) == 0                                 # five launches of a third of a round each
+    assert m._tile_hint(w24, w24, 24000) == _lib.MLP_FLAG_SHAPED              # two launches of 0.7 rounds
+    assert m._tile_hint(w2m, w2m, 2_336_064) == _lib.MLP_FLAG_SHAPED          # 71 rounds per species
+    assert m._tile_hint(o2m, o2m, 2_336_064) == _lib.MLP_FLAG_SHAPED          # 28 rounds per species
 
 
 def test_overflow_check_is_skipped_only_where_rows_cannot_overflow():

@@ -8,8 +8,8 @@ SRC=torchani_amd/csrc
 OBJ=/tmp/anihip_obj
 mkdir -p $OBJ build_alt
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC"
-for f in api nbr aev aev_generic mlp mlp_fused pair pack train; do
-  if [ ! -f $OBJ/$f.o ] || [ $SRC/$f.hip -nt $OBJ/$f.o ] || [ $SRC/anihip_common.h -nt $OBJ/$f.o ] || [ $SRC/train.h -nt $OBJ/$f.o ] || [ $SRC/mlp_fused.h -nt $OBJ/$f.o ] || [ include/anihip.h -nt $OBJ/$f.o ]; then
+for f in api nbr aev aev_generic mlp mlp_fused mlp_prep pair pack train; do
+  if [ ! -f $OBJ/$f.o ] || [ $SRC/$f.hip -nt $OBJ/$f.o ] || [ $SRC/anihip_common.h -nt $OBJ/$f.o ] || [ $SRC/train.h -nt $OBJ/$f.o ] || [ $SRC/mlp_fused.h -nt $OBJ/$f.o ] || [ $SRC/mlp_prep.h -nt $OBJ/$f.o ] || [ include/anihip.h -nt $OBJ/$f.o ]; then
     hipcc $FLAGS -c $SRC/$f.hip -o $OBJ/$f.o 2>/dev/null &
   fi
 done
@@ -17,7 +17,7 @@ wait
 while [ $# -ge 2 ]; do
   tag=$1; defs=$2; shift 2
   objs=""
-  for f in api nbr aev aev_generic mlp mlp_fused pair pack train; do
+  for f in api nbr aev aev_generic mlp mlp_fused mlp_prep pair pack train; do
     if grep -q "ANIHIP_" <<< "$defs" && { [ "$f" = "${VARIANT_TU:-aev}" ] || [ "${VARIANT_TU:-aev}" = "all" ]; }; then
       hipcc $FLAGS $defs -c $SRC/$f.hip -o $OBJ/${f}_$tag.o 2>/dev/null
       objs="$objs $OBJ/${f}_$tag.o"

@@ -14,8 +14,8 @@ import typing as tp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TORCHANI_AMD_LIB") or os.path.join(_HERE, "libanihip.so")
-SOURCES = ["api.hip", "nbr.hip", "aev.hip", "aev_generic.hip", "mlp.hip", "mlp_fused.hip", "pair.hip", "pack.hip", "train.hip"]
-HEADERS = ["anihip_common.h", "train.h", "mlp_fused.h", os.path.join("..", "..", "include", "anihip.h")]
+SOURCES = ["api.hip", "nbr.hip", "aev.hip", "aev_generic.hip", "mlp.hip", "mlp_fused.hip", "mlp_prep.hip", "pair.hip", "pack.hip", "train.hip"]
+HEADERS = ["anihip_common.h", "train.h", "mlp_fused.h", "mlp_prep.h", os.path.join("..", "..", "include", "anihip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared"]
 
 MAX_SPECIES = 8

@@ -11,8 +11,6 @@ typedef __attribute__((address_space(1))) const v4f gf4;  // global-memory float
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(1))) const h8 gh8;
 
-constexpr int AMAX_STAGES = 8, AMAX_SLOTS = 32;
-constexpr int AMAX_WORDS = AMAX_STAGES * MAX_S * AMAX_SLOTS;
 
 // d E / d act0 in tile-major MFMA-fragment order: halves / floats from the start of a 64-row x H1 member block to
 // the 2-KB unit (column block cb, row block rb, 16-column half ks)

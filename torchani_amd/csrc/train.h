@@ -11,6 +11,10 @@ constexpr int CTL_OFF = 16;     // [9]  first sorted position of each species
 constexpr int CTL_TILE = 32;    // [9]  first row tile of each species
 constexpr int CTL_QUEUE = 41;    // [1]  tile queue of the fused kernel (owner order, tiles handed out by falling cost)
 constexpr int CTL_WORDS = 48;
+// behind the control block: running |max| of the intermediate tensors of the layer-by-layer split-fp16 kernels, per stage and
+// species, spread over slots to keep the atomics off a single address (float bits)
+constexpr int AMAX_STAGES = 8, AMAX_SLOTS = 32;
+constexpr int AMAX_WORDS = AMAX_STAGES * MAX_S * AMAX_SLOTS;
 
 // dW = D^T X over the rows (atoms) of one species on v_mfma_f32_32x32x16_bf16 with three-way bf16 splits (train.hip)
 struct WgradB3Problem {

@@ -304,16 +304,53 @@ class ANI(torch.nn.Module):
         hit = self.__dict__.get("_n_elem_cache")
         if hit is None or hit[0] != key:
             present = torch.bincount(elem_idxs.reshape(-1).clamp(min=-1) + 1, minlength=len(self.symbols) + 1)[1:]
-            hit = (key, int((present > 0).sum()), species)
+            counts = present.tolist()
+            hit = (key, sum(c > 0 for c in counts), species, counts)
             self.__dict__["_n_elem_cache"] = hit
         if n_central < 24000:
             return _lib.MLP_FLAG_SMALL_TILES if hit[1] >= 4 else 0
         # Large systems (layer-0 backward inside the fused kernel): one launch per species with compile-time network widths is
-        # 6 % faster per tile (round 6), but every launch ends with a partly filled last round of the 256 CUs -- taken only
-        # when the tiles make at least 25 rounds per species present (2.34 M-atom water box: 143 rounds, 2 species; the 46 k-atom
-        # solvated protein: 3 rounds, 5 species -- there the per-species launches measured 1.9 against 1.1 ms)
-        rounds = n_central / 64.0 / (_n_cus_of(elem_idxs.device) if elem_idxs.is_cuda else 256)
-        return _lib.MLP_FLAG_SHAPED if rounds >= 25.0 * max(1, hit[1]) else 0
+        # 5-6 % faster per tile (round 6), but every launch ends with a partly filled last round of the CUs and a species of a
+        # handful of atoms still costs a whole tile through all members; the one-launch kernel hands its tiles out by falling
+        # cost instead (mid-size systems).  Both are priced in units of "one hydrogen tile through the ensemble" and the
+        # cheaper one is taken: 2.34 M-atom water box 143 rounds in 2 launches (per-species); the 46 k-atom solvated protein
+        # 5 launches of 2 + 1 + 1 + 1 + 1 rounds against 3.0 of the queue (one launch); water boxes of 24 k / 41 k / 81 k /
+        # 192 k atoms: per-species / per-species / one launch / per-species -- each as measured.
+        return _lib.MLP_FLAG_SHAPED if self._per_species_launches_pay(hit[3], _n_cus_of(elem_idxs.device) if elem_idxs.is_cuda else 256) else 0
+
+    def _per_species_launches_pay(self, counts: tp.Sequence[int], n_cus: int) -> bool:
+        nets = self.neural_networks
+        members = nets._member_networks() if hasattr(nets, "_member_networks") else []
+        if not members or not hasattr(members[0], "atomics"):
+            return False
+        cost, tiles = [], []
+        for sym, cnt in zip(self.symbols, counts):
+            if cnt <= 0:
+                continue
+            lins = members[0].atomics[sym].linears()
+            if len(lins) != 4:
+                return False
+            h1, h2, h3 = (lin.out_features for lin in lins[:3])
+            # a tile of this species relative to the ANI-2x hydrogen network (256 / 192 / 160 over four flagged slabs): a quarter
+            # of an item does not scale with the widths (measured: oxygen 192 / 160 / 128 at 0.75)
+            cost.append(0.25 + 0.75 * (128 * h1 + h1 * h2 + h2 * h3) / 112640.0)
+            tiles.append((cnt + 63) // 64)
+        if not tiles:
+            return False
+        per_species = sum(-(-t // n_cus) * c for t, c in zip(tiles, cost))
+        if min(t / n_cus for t in tiles) >= 25.0:
+            return True
+        # the queue: longest-processing-time-first over the workgroups, class by class
+        import numpy as np
+
+        load = np.zeros(n_cus)
+        for c, t in sorted(zip(cost, tiles), reverse=True):
+            load += (t // n_cus) * c
+            r = t % n_cus
+            if r:
+                load[np.argpartition(load, r - 1)[:r]] += c
+        one_launch = 1.055 * float(load.max())   # (run-time network widths)
+        return per_species < one_launch
 
     # The AEV rows of energies_and_forces are internal: they live in buffers the engine keeps between steps and updates in
     # place (AevEngine.forward_update: zeros are written once, a step rewrites only the slabs that were or are flagged --
