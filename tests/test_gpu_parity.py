@@ -890,6 +890,31 @@ def test_shards_add_up_to_the_whole(dev, name, world, monkeypatch):
     assert np.abs(e.cpu().numpy() - g["energies"]).max() < E_ATOM_TOL * max(1.0, np.sqrt(n_real))
 
 
+def test_large_shards_pick_their_own_launch_scheme(dev):
+    """Spatial shards of a system whose ranks own >= 24 000 atoms each: a rank prices the two launch schemes of the network stage
+    for the atoms IT owns (models.ANI._per_species_launches_pay: 40 500 water atoms -> one launch per species, compile-time
+    widths) -- central range in the middle of the local system, halo rows around it.  The two ranks' energies and forces add
+    up to those of the whole 81 000-atom box evaluated at once."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from bench import water_box
+
+    sp_np, x_np, cell_np = water_box(30)   # 81 000 atoms
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    pbc = (True, True, True)
+    model = get_model("ani2x", 0, dev, neighborlist="cell", row_capacity=160)
+    whole = model.energies_and_forces(sp, x, cell, pbc)
+    e = torch.zeros(1, dtype=torch.float64, device=dev)
+    f = torch.zeros_like(x)
+    for rank in range(2):
+        part = model.energies_and_forces(sp, x, cell, pbc, shard=(rank, 2))
+        e += part.energies
+        f += part.forces
+        shards = model.__dict__["_spatial_cache"][1]
+        assert shards.n_owned == 40500 and shards._tile_hint_owned == _lib.MLP_FLAG_SHAPED
+    assert float((f - whole.forces).abs().max()) < 2e-6
+    assert abs(float(e - whole.energies)) < 1e-7 * sp.numel()
+
+
 @pytest.mark.parametrize("pair", [(0, 3), (0, 1), (2, 3), (4, 5), (1, 1)])
 def test_skinny_layer0_backward_for_every_slab_count(dev, pair):
     """k_gemm_l0b (layer-0 backward of row tiles with <= 6 flagged AEV slabs) against the row-major hand-over + k_gemm_h2 on

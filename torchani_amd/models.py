@@ -698,6 +698,15 @@ class ANI(torch.nn.Module):
             if plain:
                 slab_mask = torch.zeros(nl, dtype=torch.int32, device=dev)
             aev = eng.forward(sp_l, nbrs, slab_mask=slab_mask, shard_rows=True)
+        if world > 1 and not torch.cuda.is_current_stream_capturing() and part.n_owned >= 24000:
+            # a rank's own launch scheme of the network stage (_tile_hint prices whole systems): from the composition of the atoms
+            # it owns, worked out once per partition (one host read: the partition is cut once per skin of motion)
+            hint_l = getattr(part, "_tile_hint_owned", None)
+            if hint_l is None:
+                counts = torch.bincount(sp_given.view(-1)[lo:hi].clamp(min=-1) + 1, minlength=len(self.symbols) + 1)[1:].tolist()
+                hint_l = _lib.MLP_FLAG_SHAPED if self._per_species_launches_pay(counts, _n_cus_of(dev)) else 0
+                part._tile_hint_owned = hint_l
+            tile_hint |= hint_l
         atomic_e, grad_aev, _ = packed.forward_backward(sp_l, aev, lo=lo, hi=hi, want_grad=True, chunk=self.mlp_chunk,
                                                         slab_mask=slab_mask, shard_rows=True, tile_hint=tile_hint,
                                                         plain_slabs=plain)
