@@ -43,7 +43,7 @@ def measure(dev=None, reps2=50, reps3=20):
     dt = timeit(lambda: model.energies_and_forces(spd, xd, check_overflow=False), reps=reps2)
     f = model.graphed(spd, xd)
     dtg = timeit(lambda: f(xd), reps=reps2)
-    model.auto_graph_atoms = 65536   # the default: energies_and_forces itself replays a graph from the third call on
+    model.auto_graph_atoms = 24000   # the default (models.ANI): energies_and_forces itself replays a graph from the third call on
     dta = timeit(lambda: model.energies_and_forces(spd, xd), reps=reps2)
     out["config2"] = {"workload": f"256 molecules (13.xyz / 28.xyz frames 0-127, A = 28, {n_real} real atoms), batch mode",
                       "ms_eager": dt * 1e3, "ms_graph_replay": dtg * 1e3, "ms_default_api": dta * 1e3,

@@ -67,8 +67,10 @@ class ANI(torch.nn.Module):
         # accumulator traffic (the reference's cuAEV backward is not reproducible: float atomics, csrc/aev.cu:700-704)
         self.deterministic_forces = False
         # energies_and_forces replays systems of at most this many atoms as a HIP graph once the same species tensor
-        # has been seen three times (launch-bound sizes; 0 disables)
-        self.auto_graph_atoms = 65536
+        # has been seen three times (launch-bound sizes; 0 disables).  From 24 000 atoms on the eager step is the faster one
+        # on an MI355X host: it keeps the AEV rows between steps and rewrites only the flagged slabs, which a captured step
+        # cannot (46 357-atom solvated protein: 0.94 ms eager, 0.98 replayed; 16 649 atoms: 0.80 either way; round 6)
+        self.auto_graph_atoms = 24000
         self._graphs: tp.Dict[tuple, list] = {}
 
     # arch.py:263-275 convenience accessors
