@@ -456,7 +456,7 @@ def main():
     # HBM traffic of the AEV forward kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB per
     # dispatch; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md) measured on a smaller box of
     # the same density and committed under profiles/; scaled by the atom count of this launch
-    aev_traffic = bwd_traffic = mlp_traffic = nbr_traffic = None
+    aev_traffic = aev_full_traffic = bwd_traffic = mlp_traffic = nbr_traffic = None
     pmc_file = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc.json", "r05_pmc.json", "r04_pmc_l0b.json", "r03_pmc_aev.json"))
                      if os.path.exists(f)), "")
     # SQ counters of the same kernels (rocprofv3 --pmc, tools/gpu_r6_profile.sh): what bounds each kernel, as counters
@@ -475,6 +475,14 @@ def main():
         per_atom = {k: (v["fetch_size_kb"] * pm["fetch_correction"] + v["write_size_kb"]) * 1024.0 / pm["n_atoms"]
                     for k, v in pm["kernels"].items()}
         aev_traffic, bwd_traffic = per_atom["k_aev_fwd3"] * n_shard, per_atom["k_aev_bwd"] * n_shard
+        # (the forward kernel's two roles, told apart in the counter file: the launch that writes every row -- what `roofline`
+        # prices -- and the kept-rows update the timed step runs)
+        fw = pm["kernels"]["k_aev_fwd3"]
+        role = lambda r: ((fw[r]["fetch_size_kb"] * pm["fetch_correction"] + fw[r]["write_size_kb"]) * 1024.0 / pm["n_atoms"]   # noqa: E731
+                          * n_shard) if r in fw else None
+        aev_full_traffic = role("full_rows")
+        if role("kept_rows") is not None:
+            aev_traffic = role("kept_rows")
         nbr_traffic = per_atom["k_nbr_cell2"] * n_shard if "k_nbr_cell2" in per_atom else None
         # (the network stage: every kernel of it that the counter file knows, per atom of a launch)
         # (the counter file holds means per DISPATCH; the network kernels run once per launch group: dispatches per step =
@@ -529,7 +537,7 @@ def main():
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": bytes_per_atom * n_shard / (st.get("aev_forward_full_rows", st["aev_forward"]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "avg_launch_ms": st.get("aev_forward_full_rows", st["aev_forward"]),
-            "traffic": None, "algorithmic_bytes_per_atom": bytes_per_atom,
+            "traffic": aev_full_traffic, "algorithmic_bytes_per_atom": bytes_per_atom,
             "kept_rows": {"kernel": "k_aev_fwd3<8,4,rec,UPDATE>: the variant the timed step runs (rows kept by the engine and "
                                     "updated in place: only flagged 32-column slabs are rewritten)",
                           "avg_launch_ms": st["aev_forward"], "bytes_moved": aev_traffic,
