@@ -1783,6 +1783,10 @@ static size_t mlp_tangent_carve(const anihip_mlp_desc *d, int64_t n, char *base,
 
 using namespace anihip;
 
+#ifndef ANIHIP_WGRAD_F16
+#define ANIHIP_WGRAD_F16 1   // 0: the weight gradients of the fast training path on six bf16 products (development A/B)
+#endif
+
 extern "C" size_t anihip_mlp_workspace_bytes(const anihip_mlp_desc *d, int64_t n_central)
 {
     if (!d || n_central < 0) return 0;
@@ -2537,6 +2541,8 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
         if (!forward_done)
             if (int rc = train_forward_fused(stream, d, n_atoms, lo, hi, species, aev, w, dlt, atomic_e)) return rc;
         const int cr_chunks = (int)((n + CR_ROWS - 1) / CR_ROWS) + S;
+        // (max |d Loss / d atomic_e| over the atoms of this call: the fp16 scale of the weight-gradient kernels' D operand)
+        if (ANIHIP_WGRAD_F16) launch_absmax(stream, grad_atomic_e + lo, n, w.amax, AMAX_STAGE_GATOM);
         for (int l = nl - 1; l >= 0; --l) {
             const bool output_layer = l == nl - 1;
             ColReduceArgs c{};
@@ -2584,6 +2590,14 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
             }
             a.ki_max = (kmax + 127) / 128;
             a.nj_max = (nmax + 127) / 128;
+            // three fp16 products with scales from bounds (train.hip) where every species has its operand bounds; the six
+            // bf16 products (no scales) otherwise or on request
+            a.layer = l; a.M = M; a.amax = nullptr;
+            if (ANIHIP_WGRAD_F16) {
+                bool have = true;
+                for (int s = 0; s < S; ++s) { a.bounds[s] = d->net[s].fused_bounds; have = have && a.bounds[s]; }
+                if (have) a.amax = w.amax;
+            }
             // layer 0 of a whole system: only the AEV slabs of species (pairs) that occur in it (train.h)
             a.ani_species = S;
             a.x_slab_rad = (l == 0 && lo == 0 && hi == n_atoms && d->aev_radial_len == 16 * S && S * (S + 1) / 2 + (16 * S + 31) / 32 <= 32)

@@ -912,6 +912,16 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
             if constexpr (TRAIN) store_rows(g.tr_act[0], g.tr_ld[0], H1, u1);
             ANIHIP_STAMP(trace, 23);
             a0max = tile_max(vmax);   // (barriers: every wave is past the staging slots)
+            if constexpr (TRAIN) {
+                // the weight-gradient kernels take the fp16 scale of their act0 / act1 operands from the largest |act0| of the
+                // launch (train.h AMAX_STAGE_ACT0): one atomic per item.  Inline assembly for the reason given at draw_tile
+                // (a visible global atomic turns the kernel's scalar loads into vector loads), s_nop for the same hazard.
+                if (tid == 0) {
+                    const int off = ((AMAX_STAGE_ACT0 * MAX_S + s) * AMAX_SLOTS + (int)(blockIdx.x & (AMAX_SLOTS - 1))) * 4;
+                    const unsigned bits = __float_as_uint(a0max);
+                    asm volatile("s_nop 4\n\tglobal_atomic_umax %0, %1, %2" : : "v"(off), "v"(bits), "s"(g.amax));
+                }
+            }
             ANIHIP_STAMP(trace, 24);
         }
         const float s0 = pow2_scale_for(a0max);

@@ -15,6 +15,9 @@ constexpr int CTL_WORDS = 48;
 // species, spread over slots to keep the atomics off a single address (float bits)
 constexpr int AMAX_STAGES = 8, AMAX_SLOTS = 32;
 constexpr int AMAX_WORDS = AMAX_STAGES * MAX_S * AMAX_SLOTS;
+// stages 0..5: the layer-by-layer kernels and the fused kernel's d0 scale; of the training step's weight gradients:
+constexpr int AMAX_STAGE_ACT0 = 6;    // [species] max |act0| over the tiles and members of the fused training kernel
+constexpr int AMAX_STAGE_GATOM = 7;   // [0] max |d Loss / d atomic_e| over the atoms of the call
 
 // dW = D^T X over the rows (atoms) of one species on v_mfma_f32_32x32x16_bf16 with three-way bf16 splits (train.hip)
 struct WgradB3Problem {
@@ -43,12 +46,19 @@ struct WgradB3Args {
     // atom, so their gradient columns are zero -- the X tiles run over the COMPACTED list of the slabs that can be non-zero
     // (H C N O under ANI-2x: 12 of 32 slabs, 3 column tiles instead of 8).  0: plain columns
     int x_slab_rad, ani_species;
+    // fp16 x 3 arithmetic (round 6; amax and bounds[0] non-NULL): scales from bounds instead of a pass over the data --
+    // bounds[s] = anihip_species_net.fused_bounds ([M][8]), amax = the workspace's running-max table holding max |g_atom|
+    // (AMAX_STAGE_GATOM) and max |act0| per species (AMAX_STAGE_ACT0, written by the fused training kernel); layer = 0, 1, 2
+    const float *bounds[MAX_S];
+    const unsigned *amax;
+    int layer, M;
     // bias gradients on the way (workgroups of the first X tile only): gbias[s][member][j] += sum_a g_a D[a][j]
     float *gbias[MAX_S];
     int64_t b_mstride[MAX_S];   // floats between the members' bias gradients
 };
 // rows_total: atoms of all species together (bounds the number of row chunks)
 void launch_wgrad_b3(hipStream_t stream, const WgradB3Args &a, int64_t rows_total);
+void launch_absmax(hipStream_t stream, const float *x, int64_t n, unsigned *amax, int stage);
 
 // anihip_mlp_repack of an ANIHIP_MLP_F16X3 descriptor (train.hip)
 int repack_f16(hipStream_t stream, const anihip_mlp_desc *d, const void *const *src, const int32_t *out_in, int32_t *status,

@@ -1,7 +1,8 @@
 // Training passes of the ensemble that have no counterpart in the reference's native code (csrc/mnp.cpp has no weight
 // gradients: the reference trains through eager autograd, nn/_core.py:146-149, with torch.optim.Adam,
 // tools/training-aev-benchmark.py:88,120-150):
-//   k_wgrad_b3        dW = D^T X on v_mfma_f32_32x32x16_bf16, both operands split three ways into bf16 on the fly
+//   k_wgrad_x3        dW = D^T X on v_mfma_f32_32x32x16_{f16, bf16}: both operands split on the fly -- two fp16 planes with power-of-two
+//                     scales from bounds (three products), or three bf16 planes without scales (six products)
 //   k_adam            one launch over the flat parameter / gradient / moment buffers (torch.optim.Adam's update)
 //   k_repack_f16      refresh EVERY layout of an ANIHIP_MLP_F16X3 pack from the nn.Linear tensors after an optimizer step
 //   k_fused_bounds    ... and the operand bounds of the fused network kernel
@@ -39,6 +40,50 @@ constexpr int WB_THREADS = 256;
 
 __device__ __forceinline__ unsigned bf2_bits(v2f v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2)); }
 
+// ---- the same on three fp16 products (round 6) --------------------------------------------------------------------------
+// x s = hi + lo in fp16 with ONE power-of-two scale s per launch-side operand and workgroup: the split keeps 2^-25 of the scaled
+// maximum (2^13 .. 2^14) in absolute terms, i.e. 2^-39 of the bound the scale was taken from -- a bound that is loose by a factor
+// of a thousand still leaves 2^-29 of the true maximum, far below the fp32 accumulation of the products.  The bounds need no
+// pass over the data: |D| <= fused_bounds[2 | 3 | 4] (weight norms: include/anihip.h) x max |g_atom| (k_absmax, one tiny
+// launch), |X| <= 16376 for the AEV rows (static scale 4, as in the inference kernels), max |act0| as measured by the fused
+// training kernel (one atomic per tile), |act1| <= max |act0| [0] + [1].  Three products hi hi + hi lo + lo hi (2^-22 relative),
+// two planes per operand instead of three.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(float x0, float x1, float scale, unsigned &hi, unsigned &lo)
+{
+    const v2f x = v2f{x0, x1} * scale;
+    const h2 h = __builtin_convertvector(x, h2);
+    const v2f r = x - __builtin_convertvector(h, v2f);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2));
+}
+__device__ __forceinline__ float pow2_scale_of(float mx)   // mx * scale in [2^13, 2^14); 1 for mx = 0 (or not finite: nothing to save)
+{
+    if (!(mx > 0.f) || !(mx < 3.0e38f)) return 1.0f;
+    const int e = (int)(__float_as_uint(mx) >> 23) - 127;
+    return __uint_as_float((unsigned)(127 + 13 - e) << 23);
+}
+// max |x| over n floats into the running-max table (slot of the stage, species 0)
+__global__ __launch_bounds__(256) void k_absmax(const float *x, int64_t n, unsigned *amax, int stage)
+{
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f)
+        atomicMax(amax + (stage * MAX_S) * AMAX_SLOTS + (blockIdx.x & (AMAX_SLOTS - 1)), __float_as_uint(m));
+}
+// the running maximum of (stage, s): every lane reads a slot, wave max
+__device__ __forceinline__ float amax_value(const unsigned *amax, int stage, int s)
+{
+    unsigned v = amax[(stage * MAX_S + s) * AMAX_SLOTS + (threadIdx.x & (AMAX_SLOTS - 1))];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    return __uint_as_float(v);
+}
+
 // (x0, x1) -> packed {hi, mid, lo} pairs: low half = x0, high half = x1
 __device__ __forceinline__ void split3(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo)
 {
@@ -49,10 +94,15 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned &hi, unsigne
     lo = bf2_bits(v2f{t0, t1});
 }
 
-__global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
+#ifndef ANIHIP_WGRAD_WGS
+#define ANIHIP_WGRAD_WGS 2   // workgroups per CU the fp16 instantiation is compiled for
+#endif
+template <bool F16>
+__global__ __launch_bounds__(WB_THREADS, F16 ? ANIHIP_WGRAD_WGS : 2) void k_wgrad_x3(WgradB3Args g)
 {
-    __shared__ __attribute__((aligned(16))) unsigned s_all[6 * WB_PLANE / 2];   // D planes {hi, mid, lo} | X planes
-    unsigned *sD = s_all, *sX = s_all + 3 * (WB_PLANE / 2);
+    constexpr int NPL = F16 ? 2 : 3;   // planes per operand
+    __shared__ __attribute__((aligned(16))) unsigned s_all[2 * NPL * WB_PLANE / 2];   // D planes {hi, (mid,) lo} | X planes
+    unsigned *sD = s_all, *sX = s_all + NPL * (WB_PLANE / 2);
     int id = blockIdx.x;
     const int nj = id % g.nj_max; id /= g.nj_max;
     const int ki = id % g.ki_max; id /= g.ki_max;
@@ -102,6 +152,20 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int wn = wave & 1, wk = wave >> 1;
 
+    // F16: the workgroup's two scales (wave-uniform; layer 0 holds all members side by side: the largest bound)
+    float scale_d = 1.0f, scale_x = 1.0f;
+    if constexpr (F16) {
+        const float gam = amax_value(g.amax, AMAX_STAGE_GATOM, 0), a0m = amax_value(g.amax, AMAX_STAGE_ACT0, s);
+        const float *bnd = g.bounds[s];
+        float bd = 0.f, bx = 0.f;
+        const int m_lo = g.layer == 0 ? 0 : bb, m_hi = g.layer == 0 ? g.M : bb + 1;
+        for (int m = m_lo; m < m_hi; ++m) {
+            bd = fmaxf(bd, bnd[8 * m + (g.layer == 0 ? 4 : (g.layer == 1 ? 3 : 2))]);
+            bx = fmaxf(bx, g.layer == 1 ? a0m : __builtin_fmaf(a0m, bnd[8 * m + 0], bnd[8 * m + 1]));
+        }
+        scale_d = pow2_scale_of(bd * gam);
+        scale_x = g.layer == 0 ? 4.0f : pow2_scale_of(bx);
+    }
     // staging role: atom pair `pair` of the stage, column groups cg0 and cg0 + 16 (four columns each) of D and of X
     const int pair = tid & 15, cg0 = tid >> 4;
     const float *Db = pr.D + (int64_t)bb * pr.d_boff, *Xb = pr.X + (int64_t)bb * pr.x_boff;
@@ -116,18 +180,37 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
         xok[u] = x_column(i0 + c, col);   // (four consecutive columns lie inside one slab: the first decides)
         xcol[u] = xok[u] ? col : 0;
     }
-    v4f rd[2][2], rx[2][2];   // [column group][row of the pair]
-    float ga[2];
-    auto load = [&](int r0) {
+    struct Rows { v4f rd[2][2], rx[2][2]; float ga[2]; };   // a stage's rows of this thread: [column group][row of the pair]
+    Rows ra;
+    // The row indices of a stage (atom of the row for g_atom, source row of X for layer 0) are loads of their own that the data
+    // loads depend on: fetched ONE STAGE AHEAD of the data (load_idx), or the data "prefetch" waits for them right where it is
+    // issued -- a microsecond per 32-atom stage in front of its MFMAs (round 6: the stage took 9 k cycles for 3.6 k of work)
+    int i_atom[2];
+    int64_t i_xrow[2];
+    auto load_idx = [&](int r0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = r0 + 2 * pair + h;
+            const int p = p0 + (r < n_rows ? r : 0);   // (clamped: always valid memory)
+            i_xrow[h] = g.x_gather ? (int64_t)g.x_gather[p] : (int64_t)p;
+            i_atom[h] = g.g_atom ? g.perm[p] : 0;
+        }
+    };
+    auto load = [&](Rows &R, int r0) {   // (with the indices load_idx(r0) fetched)
+        v4f (&rd)[2][2] = R.rd, (&rx)[2][2] = R.rx;
+        float (&ga)[2] = R.ga;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = r0 + 2 * pair + h;
             const bool v = r < n_rows;
-            const int p = p0 + (v ? r : 0);   // (clamped: always valid memory)
-            const int64_t xrow = g.x_gather ? (int64_t)g.x_gather[p] : (int64_t)p;
-            ga[h] = v ? (g.g_atom ? g.g_atom[g.perm[p]] : 1.0f) : 0.f;
+            const int p = p0 + (v ? r : 0);
+            const int64_t xrow = i_xrow[h];
+            ga[h] = v ? (g.g_atom ? g.g_atom[i_atom[h]] : 1.0f) : 0.f;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                // (unconditional, clamped columns: a load under a condition -- even a wave-uniform one, tried for the empty
+                // 64-column halves of the hidden layers' edge tiles -- is waited for right behind its issue; measured: the whole
+                // gain of the early indices gone)
                 v4f d = *(const gf4 *)(Db + (int64_t)p * pr.ldd + dcol[u]);
                 v4f x = *(const gf4 *)(Xb + xrow * pr.ldx + xcol[u]);
                 if (!dok[u]) d = v4f{0.f, 0.f, 0.f, 0.f};
@@ -142,7 +225,9 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int e = 0; e < 4; ++e) bsum[u][e] = 0.f;
-    auto store = [&]() {
+    auto store = [&](const Rows &R) {
+        const v4f (&rd)[2][2] = R.rd, (&rx)[2][2] = R.rx;
+        const float (&ga)[2] = R.ga;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -151,10 +236,17 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
                 unsigned hi, mid, lo;
                 const float d0 = rd[u][0][e] * ga[0], d1 = rd[u][1][e] * ga[1];
                 bsum[u][e] += d0 + d1;
-                split3(d0, d1, hi, mid, lo);
-                sD[at] = hi; sD[at + WB_PLANE / 2] = mid; sD[at + 2 * (WB_PLANE / 2)] = lo;
-                split3(rx[u][0][e], rx[u][1][e], hi, mid, lo);
-                sX[at] = hi; sX[at + WB_PLANE / 2] = mid; sX[at + 2 * (WB_PLANE / 2)] = lo;
+                if constexpr (F16) {
+                    split2h(d0, d1, scale_d, hi, lo);
+                    sD[at] = hi; sD[at + WB_PLANE / 2] = lo;
+                    split2h(rx[u][0][e], rx[u][1][e], scale_x, hi, lo);
+                    sX[at] = hi; sX[at + WB_PLANE / 2] = lo;
+                } else {
+                    split3(d0, d1, hi, mid, lo);
+                    sD[at] = hi; sD[at + WB_PLANE / 2] = mid; sD[at + 2 * (WB_PLANE / 2)] = lo;
+                    split3(rx[u][0][e], rx[u][1][e], hi, mid, lo);
+                    sX[at] = hi; sX[at + WB_PLANE / 2] = mid; sX[at + 2 * (WB_PLANE / 2)] = lo;
+                }
             }
     };
 
@@ -173,15 +265,34 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
     const int fcol = lane & 31, fk = lane >> 5;
     const unsigned short *hD = reinterpret_cast<const unsigned short *>(sD), *hX = reinterpret_cast<const unsigned short *>(sX);
 
-    load(0);
-    for (int r0 = 0; r0 < n_rows; r0 += WB_KS) {
-        __syncthreads();   // (every wave is done reading the previous stage)
-        store();
-        __syncthreads();
-        load(r0 + WB_KS);   // (unconditional: rows behind the chunk read clamped addresses and count as zeros)
+    auto mfma_stage = [&]() {
         if (active) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (F16) {
+                    h8 a[2][2], b[2][2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) {
+                            a[q][pl] = *reinterpret_cast<const h8 *>(hD + pl * WB_PLANE + (wn * 64 + q * 32 + fcol) * WB_STR + ks * 16 + fk * 8);
+                            b[q][pl] = *reinterpret_cast<const h8 *>(hX + pl * WB_PLANE + (wk * 64 + q * 32 + fcol) * WB_STR + ks * 16 + fk * 8);
+                        }
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        if (nb >= nbv) continue;
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb) {
+                            if (kb >= kbv) continue;
+                            f32x16 c = acc[nb][kb];
+                            // (the small terms first)
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb][1], b[kb][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb][0], b[kb][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb][0], b[kb][0], c, 0, 0, 0);
+                            acc[nb][kb] = c;
+                        }
+                    }
+                } else {
                 bf8 a[2][3], b[2][3];
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
@@ -207,8 +318,22 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
                         acc[nb][kb] = c;
                     }
                 }
+                }
             }
         }
+    };
+    // stage pipeline: the indices two stages, the data one stage ahead of the MFMAs.  (Two register sets -- data two stages
+    // ahead -- do not fit: 256 registers with 70 spilled.)
+    load_idx(0);
+    load(ra, 0);
+    load_idx(WB_KS);
+    for (int r0 = 0; r0 < n_rows; r0 += WB_KS) {
+        __syncthreads();   // (every wave is done reading the previous stage)
+        store(ra);
+        __syncthreads();
+        load(ra, r0 + WB_KS);   // (unconditional: rows behind the chunk read clamped addresses and count as zeros)
+        load_idx(r0 + 2 * WB_KS);
+        mfma_stage();
     }
     if (ki == 0 && g.gbias[s]) {
         // bias gradients: the sixteen atom pairs of a column lie in the sixteen lanes of a DPP row
@@ -229,6 +354,7 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
             }
     }
     if (!active) return;
+    const float unscale = F16 ? 1.0f / (scale_d * scale_x) : 1.0f;   // (powers of two: exact)
     // accumulator element r of lane l: row (output unit) (r & 3) + 8 (r >> 2) + 4 (l >> 5), column (input unit) l & 31
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -243,7 +369,7 @@ __global__ __launch_bounds__(WB_THREADS, 2) void k_wgrad_b3(WgradB3Args g)
                 const int j = j0 + wn * 64 + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (j >= pr.N) continue;
                 const int mem = j / pr.n_per, row = j - mem * pr.n_per;
-                atomicAdd(pr.dW + (int64_t)(bb + mem) * pr.w_mstride + (int64_t)row * pr.ldw + i, acc[nb][kb][r]);
+                atomicAdd(pr.dW + (int64_t)(bb + mem) * pr.w_mstride + (int64_t)row * pr.ldw + i, acc[nb][kb][r] * unscale);
             }
         }
     }
@@ -254,7 +380,20 @@ void launch_wgrad_b3(hipStream_t stream, const WgradB3Args &a, int64_t rows_tota
     const int64_t chunks = (rows_total + a.rows_per_chunk - 1) / a.rows_per_chunk + a.S;
     const int64_t total = chunks * a.batch * a.ki_max * a.nj_max;
     if (total <= 0) return;
-    hipLaunchKernelGGL(k_wgrad_b3, dim3((unsigned)total), dim3(WB_THREADS), 0, stream, a);
+    if (a.amax && a.bounds[0]) {
+        // (max |g_atom| of the rows of this call: the scale of the D operand needs it -- one small launch per weight-gradient launch)
+        hipLaunchKernelGGL(k_wgrad_x3<true>, dim3((unsigned)total), dim3(WB_THREADS), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(k_wgrad_x3<false>, dim3((unsigned)total), dim3(WB_THREADS), 0, stream, a);
+    }
+}
+
+void launch_absmax(hipStream_t stream, const float *x, int64_t n, unsigned *amax, int stage)
+{
+    if (n <= 0) return;
+    int64_t blocks = (n + 1023) / 1024;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, amax, stage);
 }
 
 // ---- Adam ---------------------------------------------------------------------------------------------------------------
