@@ -401,9 +401,11 @@ int anihip_mlp_forward_backward(void *stream, const anihip_mlp_desc *d, int64_t 
  *     and the backward down to d e / d z0 run as ONE launch of the fused network kernel (split-fp16 MFMA, the arithmetic of
  *     inference: per-atom energies within 1e-7 Ha of fp64) for a unit upstream gradient, leaving activations and d e / d z in
  *     the workspace; the weight gradients dW_l = sum_atoms g_a (d e / d z_l)^T x_{l-1} are one launch per layer on
- *     v_mfma_f32_32x32x16_bf16 with both operands split three ways into bf16 on the fly (six products: 2^-24 relative, no
- *     operand scales), the bias gradients one column reduction per layer.  A call that asks for grad_aev takes the exact-fp32
- *     backward instead (on the activations of whichever forward ran).
+ *     v_mfma_f32_32x32x16_f16 with both operands split into two fp16 planes on the fly (three products: 2^-22 relative; the
+ *     power-of-two operand scales come from fused_bounds, max |g_a| and the largest |act0| the forward recorded -- round 6), or,
+ *     for a pack without fused_bounds, on v_mfma_f32_32x32x16_bf16 with three-way bf16 splits (six products, no scales); the
+ *     bias gradients one column reduction per layer.  A call that asks for grad_aev takes the exact-fp32 backward instead (on
+ *     the activations of whichever forward ran).
  * member_stride (fast path only; 0 = the packed [M][...] arrays above): gw[l] / gbias[l] point at MEMBER 0's arrays and
  * member m's lie member_stride floats further on each -- the layout of a flat parameter buffer in torch's parameter order
  * (member -> species -> layer -> weight, bias), so an optimizer that owns ONE flat gradient buffer receives the gradients

@@ -2614,7 +2614,11 @@ extern "C" int anihip_mlp_weight_grads(void *stream_, const anihip_mlp_desc *d, 
                 // 6144 3.30, 12288 3.40 -- more chunks cost more atomics than their finer tail saves; 1536 for the wide layer-0
                 // launch with 640 for the small hidden layers 3.37: those are chains of dependent stages and want MANY short
                 // workgroups)
-                const int64_t target_wgs = tiles >= 64 ? 1536 : 3072;
+#ifndef ANIHIP_WG_T1
+#define ANIHIP_WG_T1 1536
+#define ANIHIP_WG_T2 3072
+#endif
+                const int64_t target_wgs = tiles >= 64 ? ANIHIP_WG_T1 : ANIHIP_WG_T2;
                 int64_t rows = (n * tiles / target_wgs + 255) / 256 * 256;
                 a.rows_per_chunk = (int)(rows < 512 ? 512 : (rows > 4096 ? 4096 : rows));
             }
