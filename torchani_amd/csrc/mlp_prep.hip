@@ -111,15 +111,18 @@ __global__ void k_sp_scatter(int64_t lo, int64_t hi, const int32_t *species, int
                 if (sp == t) perm[base[t] + mbcnt(m)] = (int)i;
                 base[t] += __popcll(m);
             }
-        for (uint64_t pad = __ballot(i < hi && sp < 0); pad; pad &= pad - 1) {
-            const int64_t ip = c0 + it * WAVE + (int)__builtin_ctzll(pad);
-            if (lane_id() == 0 && atomic_e) atomic_e[ip] = 0.f;
-            if (member_e && lane_id() < M) member_e[(int64_t)lane_id() * n_atoms + ip] = 0.f;
-            if (grad_aev) {
+        // (the per-atom scalars by the padding atom's own lane; only the gradient rows take the whole wave, one row at a time --
+        // a training batch is half padding, 512 serial trips per wave here when every output went that way: 55 -> 15 us)
+        const bool is_pad = i < hi && sp < 0;
+        if (is_pad && atomic_e) atomic_e[i] = 0.f;
+        if (is_pad && member_e)
+            for (int m = 0; m < M; ++m) member_e[(int64_t)m * n_atoms + i] = 0.f;
+        if (grad_aev)
+            for (uint64_t pad = __ballot(is_pad); pad; pad &= pad - 1) {
+                const int64_t ip = c0 + it * WAVE + (int)__builtin_ctzll(pad);
                 float4 *row = reinterpret_cast<float4 *>(grad_aev + (size_t)ip * L);
                 for (int f = lane_id(); f < (L >> 2); f += WAVE) row[f] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
     }
 }
 
