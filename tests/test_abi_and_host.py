@@ -872,6 +872,12 @@ def test_no_inline_asm_valu_to_mfma_hazard():
             seq = [("k", prod)] + ([("k", f"s_nop {pad - 1}")] if pad else []) + [("k", cons)]
             n_, bad_ = mod.check_instructions(seq)
             assert n_ == 1 and (len(bad_) == 1) == (pad < need), (prod, cons, pad, bad_)
+    # (f) a scalar register written by the vector ALU as the base of a vector-memory instruction: five wait states
+    for pad in range(6):
+        seq = [("k", "v_readlane_b32 s59, v254, 6")] + ([("k", f"s_nop {pad - 1}")] if pad else []) + \
+              [("k", "global_atomic_add v75, v2, v74, s[58:59] sc0")]
+        n_, bad_ = mod.check_instructions(seq)
+        assert n_ == 1 and (len(bad_) == 1) == (pad < 5), (pad, bad_)
     # an unrelated register, or an instruction in between, is no hazard
     assert mod.check_instructions([("k", "v_exp_f32_e32 v5, v4"), ("k", "v_mul_f32_e32 v6, v7, v7")]) == (0, [])
     assert mod.check_instructions([("k", "v_exp_f32_e32 v5, v4"), ("k", "v_mov_b32_e32 v8, v1"), ("k", "v_mul_f32_e32 v6, v5, v5")])[1] == []

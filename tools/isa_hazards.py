@@ -90,6 +90,8 @@ def check(lib_path):
       (c) VALU write of a VGPR -> DPP instruction reading it: 2
       (d) VALU write of a VGPR -> v_readlane / v_readfirstlane of it: 1
       (e) VALU write of a VGPR -> v_permlane{16,32}_swap using it: 2
+      (f) v_readlane / v_readfirstlane write of an SGPR -> vector-memory instruction using it as (part of) its scalar base: 5
+          [round 6: the fused kernel's inline-assembly queue draw faulted behind the v_readlane that restores a spilled pointer]
     hipcc pads these for the code it schedules itself; behind asm() it cannot see the producer."""
     checked, bad = 0, []
     for code in code_objects(lib_path):
@@ -145,6 +147,31 @@ def check_instructions(ins):
                 if nops and (_regs(nops[0]) & dst) and not nxt.startswith(("v_mfma",)):
                     break
                 wait += 1
+    # (f) VALU write of an SGPR -> VMEM reading it as scalar base
+    for k, (kern, line) in enumerate(ins):
+        m = re.match(r"v_(?:readlane|readfirstlane)_b32 s(\d+),", line)
+        if not m:
+            continue
+        sreg, wait = int(m.group(1)), 0
+        for kern2, nxt in ins[k + 1:k + 7]:
+            if kern2 != kern or nxt.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                break
+            if nxt.startswith("s_nop"):
+                wait += _states(nxt)
+                continue
+            if nxt.startswith(("global_", "buffer_", "scratch_", "flat_")):
+                used = set()
+                for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", nxt):
+                    used |= set(range(int(a), int(b) + 1))
+                used |= {int(a) for a in re.findall(r"\bs(\d+)\b", nxt)}
+                if sreg in used:
+                    checked += 1
+                    if wait < 5:
+                        bad.append((kern, wait, "readlane SGPR -> VMEM base: " + line, nxt))
+                    break
+            if re.match(r"(?:s_\w+|v_(?:readlane|readfirstlane)_b32) s(?:\[%d:\d+\]|%d)\b" % (sreg, sreg), nxt):
+                break   # (the register is written again)
+            wait += 1
     return checked, bad
 
 
