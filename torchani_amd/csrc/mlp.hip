@@ -1884,6 +1884,32 @@ extern "C" size_t anihip_mlp_forward_backward_workspace_bytes(const anihip_mlp_d
     return mlp_carve(d, n_central, nullptr, nullptr, fb_plan(d, n_central, want_grad != 0).n_act);
 }
 
+#ifndef ANIHIP_SHAPED_OVERLAP
+#define ANIHIP_SHAPED_OVERLAP 1   // 0: the per-species launches of the fused kernel one after the other, static tile order (development A/B)
+#endif
+// second stream + fork / join events of the per-species launches, one set per device, created on first use (never destroyed:
+// they live as long as the process; NULL on failure -- the launches then stay on the caller's stream)
+static void overlap_resources(hipStream_t *aux, hipEvent_t *ev_fork, hipEvent_t *ev_join)
+{
+    struct Res { hipStream_t st; hipEvent_t a, b; int state; };
+    static Res res[64] = {};
+    int dev = 0;
+    *aux = nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    Res &r = res[dev];
+    if (r.state == 0) {
+        r.state = -1;
+        if (hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&r.a, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&r.b, hipEventDisableTiming) == hipSuccess)
+            r.state = 1;
+        else
+            (void)hipGetLastError();
+    }
+    if (r.state != 1) return;
+    *aux = r.st; *ev_fork = r.a; *ev_join = r.b;
+}
+
 template <int EPI>
 static int launch_gemm_big(hipStream_t stream, GemmArgs &g, int64_t n_rows_total)
 {
@@ -2158,14 +2184,32 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             tiles <= FUSED_TILE_QUEUE_MAX && tiles > grid && !small_prep) {
             TileOrderArgs to{};
             to.tile_tab = w.tile_tab; to.tile_rows = w.tile_rows; to.tile_tab2 = w.tile_tab2; to.tile_rows2 = w.tile_rows2;
-            to.tiles_total = (int)tiles; to.queue = w.ctl + CTL_QUEUE; to.grid = (int)grid;
+            to.tiles_total = (int)tiles;
             for (int s = 0; s < S; ++s) to.H1[s] = f.sp[s].H1;
             launch_tile_order(stream, to);
             f.tile_tab = w.tile_tab2; f.tile_rows = w.tile_rows2; f.queue = w.ctl + CTL_QUEUE;
         }
         if (variant == FUSED_CELU_L0B && (d->flags & ANIHIP_MLP_FLAG_SHAPED)) {
             // one launch per species, restricted to its tiles, with the network widths as compile-time constants where an
-            // instantiation exists (every ANI-2x network and ANI-1x hydrogen); a species without atoms exits at once
+            // instantiation exists (every ANI-2x network and ANI-1x hydrogen); a species without atoms exits at once.
+            // Every launch ends with a partly filled last round of the CUs (the hydrogen tiles of the 2.34 M-atom water box: 16
+            // of 256 workgroups, eight items long).  The launches alternate between the caller's stream and a second one
+            // (forked and joined with events; they touch disjoint atoms) and draw their tiles from a queue per species: the next
+            // species' workgroups start on the CUs as they come free and take fewer tiles the later they start.  (Without the
+            // queue the overlap buys nothing: a late workgroup then carries its static share to the end.)  Not inside a stream
+            // capture (the step then stays a chain of kernel nodes).
+            hipStream_t aux = nullptr;
+            hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            // (from four rounds of tiles on: below, the fork / join and the draws cost more than they balance -- water boxes of
+            // 24 000 / 41 472 atoms 0.399 / 0.606 ms against 0.385 / 0.581 with plain launches; 81 000: 1.01 against 1.10)
+            if (ANIHIP_SHAPED_OVERLAP && tiles >= 4 * grid && S <= CTL_WORDS - CTL_QUEUE &&
+                hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)
+                overlap_resources(&aux, &ev_fork, &ev_join);
+            if (aux) {
+                ANIHIP_CHECK_HIP(hipEventRecord(ev_fork, stream));
+                ANIHIP_CHECK_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+            }
             for (int s = 0; s < S; ++s) {
                 const FusedSpecies &fs = f.sp[s];
                 int v = FUSED_CELU_L0B;
@@ -2175,7 +2219,12 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                 else if (fs.H1 == 160 && fs.H2 == 128 && fs.H3 == 96) v = FUSED_CELU_L0B_160;
                 if (v != FUSED_CELU_L0B) ANIHIP_CHECK_HIP(hipFuncSetAttribute(fused_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 f.only_species = s;
-                launch_fused(v, (unsigned)grid, lds, stream, f);
+                f.queue = aux ? w.ctl + CTL_QUEUE + s : nullptr;   // (zeroed with the control block by the bucketing)
+                launch_fused(v, (unsigned)grid, lds, (aux && (s & 1)) ? aux : stream, f);
+            }
+            if (aux) {
+                ANIHIP_CHECK_HIP(hipEventRecord(ev_join, aux));
+                ANIHIP_CHECK_HIP(hipStreamWaitEvent(stream, ev_join, 0));
             }
         } else {
             launch_fused(variant, (unsigned)grid, lds, stream, f);

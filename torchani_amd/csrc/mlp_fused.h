@@ -90,8 +90,10 @@ struct FusedArgs {
     const int *perm;           // sorted position -> atom
     const int4 *tile_tab;      // [tiles_total] {species (-1: empty), first sorted position, rows, slab mask}
     const int *tile_rows;      // [tiles_total][rows per tile] atom of each row (short tiles: last atom repeated)
-    // owner order over single tiles, mid-size systems: the table is sorted by falling tile cost (k_tile_order), workgroup b starts
-    // with tile b and draws its next tile from *queue (starts at the grid size) -- or NULL: tiles b, b + grid, ...
+    // owner order over single tiles: workgroup b starts with tile t_lo + b of its launch's range and draws its next tile from
+    // *queue (a counter that starts at ZERO: position q = tile t_lo + grid + q) -- or NULL: tiles b, b + grid, ...  Mid-size
+    // systems: the table is sorted by falling tile cost first (k_tile_order); per-species launches: one counter per species, the
+    // launches of two species overlap on two streams and a workgroup that starts late draws fewer tiles
     int *queue;
     float *member_part;        // [n][M] per-member atomic energies (summed by k_fused_finish)
     int S, M;

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
     // (only the run-time-width instantiation with phase 5 serves mid-size systems.  The draw is inline assembly: a global atomic
     // the compiler can see counts as a possible write to every table this kernel reads through scalar loads -- tile entries,
     // bounds, biases -- and turns them all into per-lane vector loads: 116 spilled registers)
-    constexpr bool DYN = L0B && !B2 && H1C == 0;
+    constexpr bool DYN = L0B && !B2;
 #define FR_DYN() (DYN && g.queue != nullptr)
     auto draw_tile = [&]() {   // one lane: the next position of the queue
         unsigned q;
@@ -659,7 +659,8 @@ __global__ __launch_bounds__(64 * (8 / NB), 2) void k_mlp_fused(FusedArgs g)
                 } else {
                     mem_n = 0;   // (tile_n is the first tile behind the group)
                     // (the tile drawn while the tile before this one was in its last member)
-                    if (FR_DYN()) tile_n = min(__builtin_amdgcn_readfirstlane((int)s_tab[1]), n_tiles);
+                    // (the counter starts at zero: position q of the queue is tile t_lo + grid + q of the launch's range)
+                    if (FR_DYN()) tile_n = min(t_lo + (int)gridDim.x + __builtin_amdgcn_readfirstlane((int)s_tab[1]), n_tiles);
                     gsz_n = min(g.owner, (n_tiles - 1 - tile_n) / (int)gridDim.x + 1);
                 }
             }

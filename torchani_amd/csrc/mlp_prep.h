@@ -49,8 +49,6 @@ struct TileOrderArgs {
     int *tile_rows2;
     int tiles_total;
     int H1[MAX_S];
-    int *queue;
-    int grid;
 };
 
 // ---- launchers (stream-ordered, no host synchronisation) ------------------------------------------------------------------

@@ -189,7 +189,6 @@ __global__ __launch_bounds__(256) void k_tile_order(TileOrderArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * TO_CHUNK;
     if (tid < 65) { s_tot[tid] = 0; s_pos[tid] = 0; }
-    if (blockIdx.x == 0 && tid == 0) *g.queue = g.grid;
     __syncthreads();
     auto cls = [&](const int4 &t) {
         if (t.x < 0) return 64;

@@ -340,8 +340,10 @@ class ANI(torch.nn.Module):
         if not tiles:
             return False
         per_species = sum(-(-t // n_cus) * c for t, c in zip(tiles, cost))
-        if min(t / n_cus for t in tiles) >= 25.0:
-            return True
+        if (sum(counts) + 63) // 64 + len(self.symbols) >= 4 * n_cus:
+            # (from four rounds of tiles on the library draws the tiles of a per-species launch from a queue and lets the next
+            # species' launch fill the CUs as they come free: no partly filled rounds, one tile of tail)
+            per_species = sum(t * c for t, c in zip(tiles, cost)) / n_cus + 0.6
         # the queue: longest-processing-time-first over the workgroups, class by class
         import numpy as np
 
