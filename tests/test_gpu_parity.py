@@ -915,6 +915,35 @@ def test_large_shards_pick_their_own_launch_scheme(dev):
     assert abs(float(e - whole.energies)) < 1e-7 * sp.numel()
 
 
+def test_queued_per_species_launches_on_two_streams(dev):
+    """From four rounds of tiles on, the per-species launches of the fused kernel draw their tiles from a queue and alternate
+    between the caller's stream and a second one (csrc/mlp.hip).  139 968 water atoms: the eager step (queue + two streams), the same
+    step on a side stream of the caller's, and the step captured into a HIP graph (plain launches: a capture stays a chain of kernel
+    nodes) give the same energies and forces; per-atom energies are bit-identical (a tile's result does not depend on who computes
+    it or when), forces within the float-atomic noise of the AEV backward."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from bench import water_box
+
+    sp_np, x_np, cell_np = water_box(36)   # 139 968 atoms: 2187 tiles of 64
+    sp, x, cell = torch.from_numpy(sp_np).to(dev), torch.from_numpy(x_np).to(dev), torch.from_numpy(cell_np).to(dev)
+    pbc = (True, True, True)
+    model = get_model("ani2x", 0, dev, neighborlist="cell", row_capacity=160)
+    assert model._tile_hint(sp, model._elem_idxs(sp).to(torch.int32), sp.numel()) == _lib.MLP_FLAG_SHAPED
+    a = model.energies_and_forces(sp, x, cell, pbc)
+    b = model.energies_and_forces(sp, x, cell, pbc)
+    assert torch.equal(a.atomic_energies, b.atomic_energies) and float((a.forces - b.forces).abs().max()) < 1e-6
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        c = model.energies_and_forces(sp, x, cell, pbc)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    assert torch.equal(a.atomic_energies, c.atomic_energies) and float((a.forces - c.forces).abs().max()) < 1e-6
+    graph = model.graphed(sp, x, cell, pbc)
+    g = graph(x)
+    assert torch.equal(a.atomic_energies, g.atomic_energies) and float((a.forces - g.forces).abs().max()) < 1e-6
+    assert abs(float(a.energies - g.energies)) < 1e-9 * sp.numel()
+
+
 @pytest.mark.parametrize("pair", [(0, 3), (0, 1), (2, 3), (4, 5), (1, 1)])
 def test_skinny_layer0_backward_for_every_slab_count(dev, pair):
     """k_gemm_l0b (layer-0 backward of row tiles with <= 6 flagged AEV slabs) against the row-major hand-over + k_gemm_h2 on

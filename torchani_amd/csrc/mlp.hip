@@ -2203,9 +2203,12 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             // (from four rounds of tiles on: below, the fork / join and the draws cost more than they balance -- water boxes of
             // 24 000 / 41 472 atoms 0.399 / 0.606 ms against 0.385 / 0.581 with plain launches; 81 000: 1.01 against 1.10)
-            if (ANIHIP_SHAPED_OVERLAP && tiles >= 4 * grid && S <= CTL_WORDS - CTL_QUEUE &&
-                hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)
-                overlap_resources(&aux, &ev_fork, &ev_join);
+            if (ANIHIP_SHAPED_OVERLAP && tiles >= 4 * grid && S <= CTL_WORDS - CTL_QUEUE) {
+                if (hipStreamIsCapturing(stream, &cap) != hipSuccess)
+                    (void)hipGetLastError();   // (not a reason to fail the call: plain launches)
+                else if (cap == hipStreamCaptureStatusNone)
+                    overlap_resources(&aux, &ev_fork, &ev_join);
+            }
             if (aux) {
                 ANIHIP_CHECK_HIP(hipEventRecord(ev_fork, stream));
                 ANIHIP_CHECK_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
