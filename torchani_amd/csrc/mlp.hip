@@ -6,7 +6,9 @@
 //
 //   A. split-fp16 ("f16x3", default), three hidden layers of width <= 256 (ANI-1x / ANI-2x):
 //        >= 16384 atoms: k_tile_table -> k_mlp_fused<RB,NB> -> k_fused_finish -> k_gemm_l0b + k_gemm_h2<EPI_SCATTER>
-//        >= 65536 atoms: k_tile_table -> k_mlp_fused<2,1,ACT,L0B = true> (layer-0 backward inside: phase 5) -> k_fused_finish
+//        >= 24000 atoms: k_tile_table (-> k_tile_order: tiles by falling cost, drawn from a queue) -> k_mlp_fused<2,1,ACT,L0B = true>
+//                        (layer-0 backward inside: phase 5; ANIHIP_MLP_FLAG_SHAPED: one launch per species with compile-time widths,
+//                        queued on two streams from four rounds of tiles on) -> k_fused_finish
 //        fewer:          k_small_prep (bucketing + tile table + padding rows) -> k_mlp_fused -> k_gemm_l0s (+ finish)
 //      one fused kernel from the AEV rows to d E / d act0 (layer 0 only over the AEV slabs flagged non-zero,
 //      activations in LDS, weights streamed from L2 in MFMA fragment order), then the layer-0 backward
