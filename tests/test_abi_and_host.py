@@ -150,6 +150,7 @@ def test_aev_table_pack_recurrence_constants(lib):
         assert rel(t[19], 2.0 ** -(4 * DR * DR)) < 2e-7 and rel(t[20], 2 * DR * 2.0 ** -(4 * DR * DR)) < 2e-7
         for k, ex in ((21, 8.0), (22, 16.0), (23, -8.0), (24, -16.0)):
             assert rel(t[k], 2.0 ** (ex * DR * DR)) < 2e-7
+        assert rel(t[25], 120.0 - 16.0 * DR * DR) < 2e-7 and 2 * DR * max(abs(qr * c.Rcr - qr * shfr[9]), qr * shfr[9]) < t[25]
         for m in range(1, 5):
             K = 2.0 ** -((m * DA) ** 2)
             assert rel(t[136 + 2 * (m - 1)], K) < 2e-7 and rel(t[137 + 2 * (m - 1)], m * DA * K) < 2e-7

@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
 #if ANIHIP_REC_SCOPE & 1
             asm volatile("" : "+s"(tab1));
 #endif
-            const float twoDR = tab1[TAB_RECR];
+            const float twoDR = tab1[TAB_RECR], ebmax = tab1[TAB_RECR + 9];
             const float KR1 = tab1[TAB_RECR + 1], KR1D = tab1[TAB_RECR + 2], KR2 = tab1[TAB_RECR + 3], KR2D = tab1[TAB_RECR + 4];
             // gu_a / gu_9, gd_a / gd_9 of anchor a = 4 g + 1
             const float GU[4] = {tab1[TAB_RECR + 6], tab1[TAB_RECR + 5], 1.0f, tab1[TAB_RECR + 7]};
@@ -1313,7 +1313,9 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
                 asm volatile("" : "+v"(rq));
                 v2f AB = (v2f){0.f, 0.f};   // sum w e, sum w e (q d)
                 if constexpr (REC) {
-                    const float eb = twoDR * (rq - sA[2]);
+                    // (clamped: distances inside the cutoff stay far from the bound -- anihip_aev_table_pack checked that --, an entry
+                    // beyond it, which no row builder of this library produces, gets finite nonsense instead of inf x 0 = NaN)
+                    const float eb = __builtin_amdgcn_fmed3f(twoDR * (rq - sA[2]), -ebmax, ebmax);
                     const float gub = __builtin_amdgcn_exp2f(eb), gdb = __builtin_amdgcn_exp2f(-eb);
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
@@ -1448,7 +1450,8 @@ __global__ __launch_bounds__(BWD_WPB * WAVE, ANIHIP_BWD_WAVES) void k_aev_bwd(
                 float xC = 0.f, fC = 1.0f;   // REC: scaled distance from the anchor shift, the anchor's Gaussian
                 if constexpr (REC) {
                     xC = srq - sC;
-                    const float e = twoDA * xC;
+                    // (see the radial clamp: gu^(NA / 2) stays finite; the table packer admits |e| NA / 2 < 110)
+                    const float e = __builtin_amdgcn_fmed3f(twoDA * xC, -240.0f / NA, 240.0f / NA);
                     fC = __builtin_amdgcn_exp2f(-xC * xC);
                     float pw[NA];   // gu^m of shift u = CA + m
                     pw[CA] = 1.0f;
@@ -1672,6 +1675,7 @@ extern "C" int anihip_aev_table_pack(anihip_aev_params *p, const float *ShfR, co
             t[TAB_RECR + 6] = (float)exp2(16. * DR * DR);
             t[TAB_RECR + 7] = (float)exp2(-8. * DR * DR);
             t[TAB_RECR + 8] = (float)exp2(-16. * DR * DR);
+            t[TAB_RECR + 9] = (float)(120. - 16. * DR * DR);   // clamp of |2 D_R x|: gu_9 exp2(16 D_R^2) stays finite
         }
     }
     return 0;

@@ -22,7 +22,7 @@ constexpr int TAB_SHFRQ = 80, TAB_SHFAQ = 96, TAB_COSZH = 112, TAB_SINZH = 128; 
 // sixteen of its 32 slots and whose q_A ShfA and sin / 2 blocks use at most eight of their sixteen): D = spacing of
 // the pre-scaled shifts, K_m = exp2(-(m D)^2), all evaluated in double from the fp32 shift arrays (every wave-uniform product
 // is made on the host: gfx950 has no scalar float multiply, uniform products made in the kernel would sit in vector registers)
-constexpr int TAB_RECR = 16;    // 2 D_R | K_1 | D_R K_1 | K_2 | 2 D_R K_2 | exp2(8 D_R^2) | exp2(16 D_R^2) | exp2(-8 D_R^2) | exp2(-16 D_R^2)
+constexpr int TAB_RECR = 16;    // 2 D_R | K_1 | D_R K_1 | K_2 | 2 D_R K_2 | exp2(8 D_R^2) | exp2(16 D_R^2) | exp2(-8 D_R^2) | exp2(-16 D_R^2) | 120 - 16 D_R^2
 constexpr int TAB_RECA = 104;   // 2 D_A
 constexpr int TAB_RECAK = 136;  // (K_m, m D_A K_m), m = 1 .. 4
 
