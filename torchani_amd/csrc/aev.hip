@@ -932,7 +932,8 @@ __global__ __launch_bounds__(FWD3_WPB * WAVE, ANIHIP_FWD3_WAVES) void k_aev_fwd3
                         // rounded factors: 3e-7 relative)
                         constexpr int C = NA / 2 - 1;
                         const float x = sr - shfAq[C];
-                        const float e = (2.0f * gD) * x - gD * gD;
+                        // (clamped like the backward's: inside the cutoff |e| < 100 by anihip_aev_table_pack's check)
+                        const float e = __builtin_amdgcn_fmed3f((2.0f * gD) * x - gD * gD, -100.0f, 100.0f);
                         f2[C] = __builtin_amdgcn_exp2f(-x * x);
                         float ru = __builtin_amdgcn_exp2f(e), rd = __builtin_amdgcn_exp2f(-e);
 #pragma unroll
