@@ -40,6 +40,7 @@
 #include <type_traits>
 #include <vector>
 #include <cstdio>
+#include <mutex>
 
 namespace anihip {
 
@@ -1890,26 +1891,33 @@ extern "C" size_t anihip_mlp_forward_backward_workspace_bytes(const anihip_mlp_d
 #define ANIHIP_SHAPED_OVERLAP 1   // 0: the per-species launches of the fused kernel one after the other, static tile order (development A/B)
 #endif
 // second stream + fork / join events of the per-species launches, one set per device, created on first use (never destroyed:
-// they live as long as the process; NULL on failure -- the launches then stay on the caller's stream)
-static void overlap_resources(hipStream_t *aux, hipEvent_t *ev_fork, hipEvent_t *ev_join)
+// they live as long as the process; NULL on failure -- the launches then stay on the caller's stream).  A caller holds the
+// set's mutex from its fork to its join: two host threads of one process share the stream and the events, and an event
+// re-recorded by the other thread between a record and its wait would order the second stream behind the wrong work.
+struct OverlapSet {
+    hipStream_t st;
+    hipEvent_t fork, join;
+    int state;
+    std::mutex mu;
+};
+static OverlapSet *overlap_resources()
 {
-    struct Res { hipStream_t st; hipEvent_t a, b; int state; };
-    static Res res[64] = {};
+    static OverlapSet res[64];
+    static std::mutex create;
     int dev = 0;
-    *aux = nullptr;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-    Res &r = res[dev];
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(create);
+    OverlapSet &r = res[dev];
     if (r.state == 0) {
         r.state = -1;
         if (hipStreamCreateWithFlags(&r.st, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&r.a, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&r.b, hipEventDisableTiming) == hipSuccess)
+            hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&r.join, hipEventDisableTiming) == hipSuccess)
             r.state = 1;
         else
             (void)hipGetLastError();
     }
-    if (r.state != 1) return;
-    *aux = r.st; *ev_fork = r.a; *ev_join = r.b;
+    return r.state == 1 ? &r : nullptr;
 }
 
 template <int EPI>
@@ -2200,8 +2208,7 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
             // species' workgroups start on the CUs as they come free and take fewer tiles the later they start.  (Without the
             // queue the overlap buys nothing: a late workgroup then carries its static share to the end.)  Not inside a stream
             // capture (the step then stays a chain of kernel nodes).
-            hipStream_t aux = nullptr;
-            hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+            OverlapSet *ov = nullptr;
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             // (from four rounds of tiles on: below, the fork / join and the draws cost more than they balance -- water boxes of
             // 24 000 / 41 472 atoms 0.399 / 0.606 ms against 0.385 / 0.581 with plain launches; 81 000: 1.01 against 1.10)
@@ -2209,11 +2216,15 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                 if (hipStreamIsCapturing(stream, &cap) != hipSuccess)
                     (void)hipGetLastError();   // (not a reason to fail the call: plain launches)
                 else if (cap == hipStreamCaptureStatusNone)
-                    overlap_resources(&aux, &ev_fork, &ev_join);
+                    ov = overlap_resources();
             }
-            if (aux) {
-                ANIHIP_CHECK_HIP(hipEventRecord(ev_fork, stream));
-                ANIHIP_CHECK_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+            std::unique_lock<std::mutex> ov_lock;
+            hipStream_t aux = nullptr;
+            if (ov) {
+                ov_lock = std::unique_lock<std::mutex>(ov->mu);
+                aux = ov->st;
+                ANIHIP_CHECK_HIP(hipEventRecord(ov->fork, stream));
+                ANIHIP_CHECK_HIP(hipStreamWaitEvent(aux, ov->fork, 0));
             }
             for (int s = 0; s < S; ++s) {
                 const FusedSpecies &fs = f.sp[s];
@@ -2227,9 +2238,9 @@ extern "C" int anihip_mlp_forward_backward(void *stream_, const anihip_mlp_desc 
                 f.queue = aux ? w.ctl + CTL_QUEUE + s : nullptr;   // (zeroed with the control block by the bucketing)
                 launch_fused(v, (unsigned)grid, lds, (aux && (s & 1)) ? aux : stream, f);
             }
-            if (aux) {
-                ANIHIP_CHECK_HIP(hipEventRecord(ev_join, aux));
-                ANIHIP_CHECK_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+            if (ov) {
+                ANIHIP_CHECK_HIP(hipEventRecord(ov->join, aux));
+                ANIHIP_CHECK_HIP(hipStreamWaitEvent(stream, ov->join, 0));
             }
         } else {
             launch_fused(variant, (unsigned)grid, lds, stream, f);
