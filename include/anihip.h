@@ -314,11 +314,15 @@ typedef struct {
 #define ANIHIP_MLP_FLAG_FUSED_L0B 512u    /* layer-0 backward inside the fused kernel whatever the size (default: from 24000 atoms) */
 #define ANIHIP_MLP_FLAG_NO_FUSED_L0B 1024u /* ... never: d E/d act0 through HBM + a layer-0 backward GEMM launch */
 #define ANIHIP_MLP_FLAG_SHAPED 4096u       /* with the layer-0 backward inside the fused kernel: ONE LAUNCH PER SPECIES, restricted to its tiles, with the
-                                             * network widths as compile-time constants where an instantiation exists (every ANI-2x network) -- 6 % faster
-                                             * per tile, but every launch ends with a partly filled last round of the CUs (one tile through all members:
-                                             * ~0.2 ms), so a caller sets it only when every PRESENT species has many rounds of tiles (the Python host:
-                                             * total rounds >= 25 x species present; 2.3 M-atom water box: 143 rounds for 2 species) */
-#define ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS 2048u /* OFF by default.  With the layer-0 backward inside the fused kernel (>= 65536 atoms,
+                                             * network widths as compile-time constants where an instantiation exists (every ANI-2x network) -- 5-6 % faster
+                                             * per tile.  Below four rounds of tiles these are plain launches on the caller's stream, each ending with a
+                                             * partly filled last round of the CUs (a species of a handful of atoms still costs a tile through all members);
+                                             * from four rounds on the launches draw their tiles from a queue per species and alternate between the
+                                             * caller's stream and a SECOND STREAM OF THE LIBRARY'S OWN (one per device, created on first use; forked from and
+                                             * joined to the caller's stream with events, so the call stays stream-ordered for the caller; not inside a
+                                             * stream capture).  Whether it pays depends on the composition: the Python host prices both schemes
+                                             * (models.ANI._per_species_launches_pay) -- 2.3 M-atom water box: yes; 46 k-atom solvated protein: no */
+#define ANIHIP_MLP_FLAG_BWD_TWO_PRODUCTS 2048u /* OFF by default.  With the layer-0 backward inside the fused kernel (>= 24000 atoms,
                                                  * CELU): its backward GEMMs leave out (weight lo) x (gradient hi), i.e. use the weights
                                                  * rounded to fp16 -- energies unchanged, d E/d AEV and the forces differ from the default's
                                                  * by ~1e-6 Ha/A (inside the 1e-4 Ha/A gate of the parity tests, OUTSIDE their 5e-6 regression
