@@ -213,37 +213,58 @@ __global__ void k_prep_batch(GridDesc *g, int64_t n, const int32_t *species, con
 
 // ---- cell mode: binning ----------------------------------------------------------------------------
 
+// Runs of equal keys among the consecutive lanes of a wave (atoms that follow each other in memory mostly share their bin:
+// lattice order, cell-sorted order): the first lane of a run does ONE atomic for the whole run -- the 2.3 M same-address
+// conflicts of a lane-per-atom atomic went through the L2 one by one (k_bin_fill: 101 us).  key < 0: the lane takes no part.
+// Returns the run's length in its first lane (0 elsewhere); rank = this lane's place in its run, head = the run's first lane.
+__device__ __forceinline__ int wave_runs(int key, int &rank, int &head)
+{
+    const int lane = lane_id();
+    const int k = key < 0 ? -1 - lane : key;   // (unique: a run of its own)
+    const int prev = __shfl_up(k, 1);
+    const bool is_head = lane == 0 || k != prev;
+    const uint64_t heads = __ballot(is_head);
+    const uint64_t below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    head = 63 - (int)__builtin_clzll(below);
+    rank = lane - head;
+    const uint64_t above = lane == 63 ? 0ull : (heads >> (lane + 1));
+    const int next = above ? lane + 1 + (int)__builtin_ctzll(above) : 64;
+    return (is_head && key >= 0) ? next - lane : 0;
+}
+
 __global__ void k_bin_count(const GridDesc *g, int64_t n, const int32_t *species, const float *coords,
                             float4 *pos4, int *cellid, int *cell_cnt)
 {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int sp = species[i];
-    if (sp < 0) {
-        cellid[i] = -1;
-        return;
+    int c = -1;
+    if (i < n) {
+        int sp = species[i];
+        if (sp >= 0) {
+            double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
+            int b[3];
+            double loc[3];
+            for (int k = 0; k < 3; ++k) {
+                double f = x * g->inv[0 + k] + y * g->inv[3 + k] + z * g->inv[6 + k];
+                if (g->pbc[k]) f -= floor(f);
+                double q = (f - g->f0[k]) * g->sc[k];
+                int bk = (int)floor(q);
+                bk = bk < 0 ? 0 : (bk >= g->nb[k] ? g->nb[k] - 1 : bk);
+                b[k] = bk;
+                loc[k] = (q - bk) / g->sc[k];  // fractional offset from the bin corner
+            }
+            // bin-local cartesian offset: small magnitude => fp32 keeps ~1e-7 A resolution in any box size
+            float ox = (float)(loc[0] * g->cell[0] + loc[1] * g->cell[3] + loc[2] * g->cell[6]);
+            float oy = (float)(loc[0] * g->cell[1] + loc[1] * g->cell[4] + loc[2] * g->cell[7]);
+            float oz = (float)(loc[0] * g->cell[2] + loc[1] * g->cell[5] + loc[2] * g->cell[8]);
+            uint32_t w = ((uint32_t)i & IDX_MASK) | ((uint32_t)sp << 28);
+            pos4[i] = make_float4(ox, oy, oz, __uint_as_float(w));
+            c = (b[0] * g->nb[1] + b[1]) * g->nb[2] + b[2];
+        }
+        cellid[i] = c;
     }
-    double x = coords[3 * i], y = coords[3 * i + 1], z = coords[3 * i + 2];
-    int b[3];
-    double loc[3];
-    for (int k = 0; k < 3; ++k) {
-        double f = x * g->inv[0 + k] + y * g->inv[3 + k] + z * g->inv[6 + k];
-        if (g->pbc[k]) f -= floor(f);
-        double q = (f - g->f0[k]) * g->sc[k];
-        int bk = (int)floor(q);
-        bk = bk < 0 ? 0 : (bk >= g->nb[k] ? g->nb[k] - 1 : bk);
-        b[k] = bk;
-        loc[k] = (q - bk) / g->sc[k];  // fractional offset from the bin corner
-    }
-    // bin-local cartesian offset: small magnitude => fp32 keeps ~1e-7 A resolution in any box size
-    float ox = (float)(loc[0] * g->cell[0] + loc[1] * g->cell[3] + loc[2] * g->cell[6]);
-    float oy = (float)(loc[0] * g->cell[1] + loc[1] * g->cell[4] + loc[2] * g->cell[7]);
-    float oz = (float)(loc[0] * g->cell[2] + loc[1] * g->cell[5] + loc[2] * g->cell[8]);
-    uint32_t w = ((uint32_t)i & IDX_MASK) | ((uint32_t)sp << 28);
-    pos4[i] = make_float4(ox, oy, oz, __uint_as_float(w));
-    int c = (b[0] * g->nb[1] + b[1]) * g->nb[2] + b[2];
-    cellid[i] = c;
-    atomicAdd(&cell_cnt[c], 1);
+    int rank, head;
+    const int run = wave_runs(c, rank, head);
+    if (run > 0) atomicAdd(&cell_cnt[c], run);
 }
 
 // exclusive scan of `in[0..n)` (n read from device) into out[0..n], three small kernels
@@ -304,11 +325,13 @@ __global__ void k_bin_fill(int64_t n, const int *cellid, const int *cell_start, 
                            int *sorted_idx)
 {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int c = cellid[i];
-    if (c < 0) return;
-    int slot = atomicAdd(&cell_fill[c], 1);
-    sorted_idx[cell_start[c] + slot] = (int)i;
+    const int c = i < n ? cellid[i] : -1;
+    int rank, head;
+    const int run = wave_runs(c, rank, head);
+    int base = 0;
+    if (run > 0) base = atomicAdd(&cell_fill[c], run);   // (one returning atomic per run of atoms of one bin)
+    base = __shfl(base, head);
+    if (c >= 0) sorted_idx[cell_start[c] + base + rank] = (int)i;
 }
 
 // make the order inside every bin deterministic (ascending atom index) and gather the positions: one thread per ATOM
